@@ -1,0 +1,55 @@
+/*
+ * oracle/oracle_dsp.c -- TEST INFRASTRUCTURE ONLY.
+ * Instantiates the stage restatements for float (POES) and double (ARGOS) and
+ * implements the chunk loop + byte synchronisers on top of them.
+ */
+#define _GNU_SOURCE
+#include <math.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#include "oracle.h"
+
+/* ---- float instantiation */
+#define DT float
+#define SFX _f32
+#define SINCOS(p, s, c) orc_sincosf((p), (s), (c))
+#define ARCTAN2(y, x) orc_arctan2_f32((y), (x))
+#define FABS(x) fabsf(x)
+#define FABSNARROW(x) fabsf((float)(x))
+#define SIN(x) sinf(x)
+#define HYPOT(x, y) orc_hypotf((x), (y))
+#define RINT(x) rintf(x)
+#include "oracle_dsp_tmpl.inc"
+#undef DT
+#undef SFX
+#undef SINCOS
+#undef ARCTAN2
+#undef FABS
+#undef FABSNARROW
+#undef SIN
+#undef HYPOT
+#undef RINT
+
+/* ---- double instantiation */
+#define DT double
+#define SFX _f64
+#define SINCOS(p, s, c) orc_sincos((p), (s), (c))
+#define ARCTAN2(y, x) orc_arctan2_f64((y), (x))
+#define FABS(x) fabs(x)
+#define FABSNARROW(x) fabs(x)
+#define SIN(x) sin(x)
+#define HYPOT(x, y) orc_hypot((x), (y))
+#define RINT(x) rint(x)
+#include "oracle_dsp_tmpl.inc"
+#undef DT
+#undef SFX
+#undef SINCOS
+#undef ARCTAN2
+#undef FABS
+#undef FABSNARROW
+#undef SIN
+#undef HYPOT
+#undef RINT
+
+#include "oracle_pipeline.inc"
