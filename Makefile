@@ -1,0 +1,41 @@
+# Top-level build: the HIP library (gfx950 only), the C host programs, the synthetic
+# generator and the oracle (test infrastructure).  `python __graft_entry__.py` calls this.
+PKG      := project-desert-tortoise_amd
+HIPCC    ?= /opt/rocm/bin/hipcc
+ARCH     ?= gfx950
+HIPFLAGS := --offload-arch=$(ARCH) -O3 -std=c++17 -ffp-contract=off -fPIC -Wall -Wno-unused-function
+CC       := gcc
+CFLAGS   := -O2 -Wall -ffp-contract=off
+
+CSRC     := $(PKG)/csrc
+LIBPDT   := $(CSRC)/libpdt.so
+LIBSYNTH := $(PKG)/synth/libpdtsynth.so
+
+all: $(LIBPDT) $(LIBSYNTH) bin/synth_wav bin/demodPOES bin/demodARGOS oracle
+
+$(LIBPDT): $(CSRC)/pdt_api.hip $(CSRC)/pdt_kernels_front.h $(CSRC)/pdt_kernels_back.h $(CSRC)/pdt_device_math.h $(CSRC)/pdt_timeaxis.h include/pdt.h
+	$(HIPCC) $(HIPFLAGS) -shared -o $@ $(CSRC)/pdt_api.hip
+
+$(LIBSYNTH): $(PKG)/synth/pdt_synth.c $(PKG)/synth/pdt_synth.h
+	$(CC) $(CFLAGS) -fPIC -shared -o $@ $(PKG)/synth/pdt_synth.c -lm
+
+bin/synth_wav: $(PKG)/synth/pdt_synth.c $(PKG)/synth/pdt_synth.h
+	mkdir -p bin
+	$(CC) $(CFLAGS) -DPDT_SYNTH_MAIN -o $@ $(PKG)/synth/pdt_synth.c -lm
+
+bin/demodPOES: $(PKG)/host/demod_main.c include/pdt.h $(LIBPDT)
+	mkdir -p bin
+	$(CC) $(CFLAGS) -Iinclude -o $@ $(PKG)/host/demod_main.c -L$(CSRC) -lpdt -Wl,-rpath,'$$ORIGIN/../$(CSRC)'
+
+bin/demodARGOS: $(PKG)/host/demod_main.c include/pdt.h $(LIBPDT)
+	mkdir -p bin
+	$(CC) $(CFLAGS) -DPDT_ARGOS -Iinclude -o $@ $(PKG)/host/demod_main.c -L$(CSRC) -lpdt -Wl,-rpath,'$$ORIGIN/../$(CSRC)'
+
+oracle:
+	$(MAKE) -C oracle
+
+clean:
+	rm -f $(LIBPDT) $(LIBSYNTH) bin/*
+	$(MAKE) -C oracle clean
+
+.PHONY: all oracle clean

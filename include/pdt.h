@@ -1,0 +1,165 @@
+/*
+ * include/pdt.h -- C ABI of libpdt.so, the MI355X (gfx950) implementation of the
+ * POES-TIP / ARGOS IQ demodulation chain of nebarnix/Project-Desert-Tortoise.
+ *
+ * The reference has no FFI layer: its boundary is (i) the demodPOES/demodARGOS
+ * command lines with their minorFrames_*.txt / packets_*.txt files and (ii) the
+ * C functions of common/ that POESTIPdemod/main.c and ARGOSdemod/main.c call
+ * once per 10 000-sample chunk.  A GPU cannot usefully be entered once per
+ * chunk per stage, so this ABI sits one level up: a re-entrant context receives
+ * a whole capture (or a large span of it), emulates the reference's chunked
+ * semantics internally (chunk size is observable in the output)
+ * and hands back decoded frame records; the host program formats the text
+ * exactly like POESTIPdemod/ByteSync.c:62-69,96-101 / ARGOSdemod/ByteSync.c:62-70,99-103.
+ * Per-stage read-back (pdt_read_stage) exposes every intermediate stream that
+ * the reference passes between its stage functions so each stage can be
+ * compared with the reference's own output.
+ *
+ * Plain C types only; caller-owned memory; integer error codes; no globals:
+ * one context per capture, contexts are independent (one per GPU / stream).
+ *
+ * Reference interface replaced by each entry point:
+ *   pdt_open            the lazy first-call initialisation of every stage
+ *                       (CarrierTrackingPLL.c:88-100, LowPassFilter.c:30-40, AGC.c:92-96,
+ *                       GardenerClockRecovery.c:17-21, ByteSync.c:28-39) plus the
+ *                       constants at the call sites POESTIPdemod/main.c:346-369,413-454,
+ *                       ARGOSdemod/main.c:248-284
+ *   pdt_demod_pcm16     the while(!feof) chunk loop POESTIPdemod/main.c:373-492 /
+ *                       ARGOSdemod/main.c:250-306 over GetComplexWaveChunk (wave.c:59-175),
+ *                       StaticGain (AGC.c:48-75), CarrierTrackPLL (CarrierTrackingPLL.c:54-278),
+ *                       LowPassFilterInterp / LowPassFilter (LowPassFilter.c:13-71,76-125),
+ *                       NormalizingAGC (AGC.c:78-132), Squelch (AGC.c:24-46),
+ *                       GardenerClockRecovery (GardenerClockRecovery.c:5-114),
+ *                       ManchesterDecode (ManchesterDecode.c:10-100),
+ *                       ByteSyncOnSyncword (POESTIPdemod/ByteSync.c:16-150) /
+ *                       FindSyncWords (ARGOSdemod/ByteSync.c:17-150)
+ *   pdt_demod_device    same, input already resident in HBM (bench / multi-capture)
+ *   pdt_frames          the fprintf stream of ByteSync.c, as records
+ *   pdt_format_frames   the text ByteSync.c writes to the output file
+ *   pdt_make_lpf        MakeLPFIR (LowPassFilter.c:127-175)
+ *   pdt_wav_parse_header ReadWavHeader (wave.c:303-378)
+ */
+#ifndef PDT_H
+#define PDT_H
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define PDT_ABI_VERSION 1
+
+enum { PDT_MODE_POES = 0, PDT_MODE_ARGOS = 1 };
+
+enum {
+    PDT_OK = 0,
+    PDT_ERR_ARG = -1,       /* bad argument                                  */
+    PDT_ERR_NOGPU = -2,     /* no HIP device / HIP runtime failure           */
+    PDT_ERR_NOMEM = -3,
+    PDT_ERR_FORMAT = -4,    /* unsupported WAV format                        */
+    PDT_ERR_RATE = -5,      /* sample rate gives interpolation factor 0 (Fs > 300 kHz, POESTIPdemod/main.c:347) */
+    PDT_ERR_STATE = -6      /* call sequence error                           */
+};
+
+/* intermediate streams, in the order the reference produces them */
+enum {
+    PDT_ST_PLL = 0,     /* realDataOut of CarrierTrackPLL            DT per input sample        */
+    PDT_ST_LOCK,        /* lockSignalStreamOut (ARGOS only)          DT per input sample        */
+    PDT_ST_FIR,         /* low-pass output                           DT per interpolated sample */
+    PDT_ST_AGC,         /* NormalizingAGC (+Squelch, ARGOS) output   DT per interpolated sample */
+    PDT_ST_SYM,         /* Gardner symbols                           DT per symbol              */
+    PDT_ST_SYMIDX,      /* global interpolated-sample index each symbol was taken at, int64    */
+    PDT_ST_BITS,        /* Manchester bits, '0'/'1'                  uint8 per bit              */
+    PDT_ST_BITSYM,      /* global symbol index each bit's time stamp comes from, uint32         */
+    PDT_ST_COUNT
+};
+
+typedef struct pdt_config {
+    int32_t  mode;            /* PDT_MODE_POES / PDT_MODE_ARGOS                                   */
+    uint32_t sample_rate;     /* Hz, the WAV header value (after the -s override, Q6)             */
+    uint64_t chunk;           /* reference chunk size in input samples; 0 = 10000 / 2400          */
+    double   norm_override;   /* -n option; 0 = StaticGain of the first chunk                     */
+    int32_t  device;          /* HIP device ordinal                                               */
+    int32_t  profile;         /* 1 = bracket every kernel with HIP events (pdt_kernel_times)      */
+    /* Block-parallel evaluation of the PLL / AGC recurrences: each block replays
+     * `warm` samples before its own `block` samples; seams are validated bitwise
+     * and re-run sequentially on mismatch, so results never depend on these.
+     * 0 = defaults derived from the sample rate.                                                  */
+    uint32_t pll_block, pll_warm, agc_block, agc_warm;
+} pdt_config;
+
+typedef struct pdt_frame {
+    double   time;        /* time stamp the reference prints with "%.5f"                          */
+    int64_t  bit_index;   /* global index of the bit that completed the sync word                 */
+    int64_t  time_src;    /* global interpolated-sample index the time stamp derives from         */
+    uint8_t  inverted;    /* found through the inverse sync word ("i" suffix, POES only)          */
+    uint8_t  nbytes;      /* bytes present: 104 (POES) / 7 (ARGOS) when complete                  */
+    uint8_t  complete;    /* all bytes seen (newline emitted)                                     */
+    uint8_t  pad;
+    uint8_t  bytes[104];
+} pdt_frame;
+
+typedef struct pdt_stats {
+    uint64_t samples, out_samples, symbols, bits, frames;
+    int64_t  lock_sample;         /* global sample index of the one-time PLL lock, -1 = never     */
+    double   lock_freq_hz;        /* " : PLL locked at %0.2fHz"                                   */
+    double   norm_factor;         /* "Normalization Factor: %f"                                   */
+    double   avg_phase;           /* CarrierTrackPLL return value at the lock sample (quality)    */
+    uint32_t interp, ntaps;
+    uint32_t pll_blocks, pll_seam_fixes, agc_blocks, agc_seam_fixes;
+    double   gpu_ms;              /* device time of the last pdt_demod_* call (HIP events)        */
+} pdt_stats;
+
+typedef struct pdt_kernel_time {
+    char     name[32];
+    uint32_t launches;
+    double   total_ms;
+} pdt_kernel_time;
+
+typedef struct pdt_ctx pdt_ctx;
+
+int  pdt_abi_version(void);
+const char *pdt_strerror(int code);
+int  pdt_device_count(void);
+
+int  pdt_open(const pdt_config *cfg, pdt_ctx **out);
+void pdt_close(pdt_ctx *ctx);
+
+/* Use an existing HIP stream (hipStream_t passed as void*) for all work; NULL = own stream. */
+int  pdt_set_stream(pdt_ctx *ctx, void *hip_stream);
+
+/* Demodulate one whole capture: nframes interleaved little-endian int16 I,Q pairs
+ * in host memory (copied to the GPU) ...                                                        */
+int  pdt_demod_pcm16(pdt_ctx *ctx, const int16_t *iq_host, uint64_t nframes);
+/* ... or already resident in device memory (no copy; buffer is only read).                      */
+int  pdt_demod_device(pdt_ctx *ctx, const void *iq_device, uint64_t nframes);
+
+/* Results of the last pdt_demod_* call. */
+uint64_t pdt_num_frames(const pdt_ctx *ctx);
+uint64_t pdt_frames(const pdt_ctx *ctx, pdt_frame *out, uint64_t max_frames);
+int      pdt_get_stats(const pdt_ctx *ctx, pdt_stats *out);
+/* Text exactly as the reference writes it to minorFrames_*.txt / packets_*.txt.
+ * Returns the number of bytes needed; writes at most `cap` bytes.                               */
+uint64_t pdt_format_frames(const pdt_ctx *ctx, char *buf, uint64_t cap);
+
+/* Copy an intermediate stream back to the host (elements [first, first+count)); returns the
+ * number of elements copied, or a negative error.  Element type per the PDT_ST_* table;
+ * DT = float (POES) / double (ARGOS).                                                           */
+int64_t  pdt_read_stage(const pdt_ctx *ctx, int stage, uint64_t first, uint64_t count, void *out);
+uint64_t pdt_stage_len(const pdt_ctx *ctx, int stage);
+
+/* Per-kernel device times of the last call (cfg.profile = 1). Returns the entry count. */
+int      pdt_kernel_times(const pdt_ctx *ctx, pdt_kernel_time *out, int max_entries);
+
+/* Host-side helpers */
+int  pdt_make_lpf(int mode, uint32_t sample_rate, void *taps_out, int *ntaps, int *interp);
+int  pdt_wav_parse_header(const uint8_t hdr[44], uint32_t *sample_rate, uint32_t *channels,
+                          uint32_t *bits_per_sample, uint32_t *format, uint32_t *data_bytes);
+/* The reference's running-sum time axis (wave.c:91,96-97,167-168): value after m additions of Ts. */
+double pdt_time_axis(int mode, uint32_t sample_rate, uint64_t m);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

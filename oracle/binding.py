@@ -1,0 +1,130 @@
+"""ctypes binding of oracle/liboracle.so -- TEST INFRASTRUCTURE ONLY.
+
+Importable only from tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB = os.path.join(HERE, "liboracle.so")
+
+POES, ARGOS = 0, 1
+(ST_IQ, ST_TIME, ST_PLL, ST_LOCK, ST_FIR, ST_AGC, ST_SYM, ST_SYMT, ST_BITS, ST_BITT, ST_COUNTS, ST_TAPS,
+ ST_SYMIDX) = range(13)
+
+
+class OrcFrame(C.Structure):
+    _fields_ = [("time", C.c_double), ("bit_index", C.c_int64), ("inverted", C.c_uint8), ("nbytes", C.c_uint8),
+                ("complete", C.c_uint8), ("pad", C.c_uint8), ("bytes", C.c_uint8 * 104)]
+
+
+_lib = None
+
+
+def build():
+    subprocess.run(["make", "-C", HERE, "liboracle.so", "oracle_demod"], check=True, capture_output=True)
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB):
+            build()
+        L = C.CDLL(LIB)
+        L.orc_open.restype = C.c_void_p
+        L.orc_open.argtypes = [C.c_int, C.c_uint, C.c_ulong, C.c_double, C.c_int]
+        L.orc_close.argtypes = [C.c_void_p]
+        L.orc_run_pcm16.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t]
+        L.orc_text.restype = C.c_void_p
+        L.orc_text.argtypes = [C.c_void_p, C.POINTER(C.c_size_t)]
+        L.orc_num_frames.restype = C.c_size_t
+        L.orc_num_frames.argtypes = [C.c_void_p]
+        L.orc_frames.restype = C.POINTER(OrcFrame)
+        L.orc_frames.argtypes = [C.c_void_p]
+        L.orc_stage.restype = C.c_size_t
+        L.orc_stage.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_size_t]
+        L.orc_norm_factor.restype = C.c_double
+        L.orc_norm_factor.argtypes = [C.c_void_p]
+        L.orc_lock_sample.restype = C.c_long
+        L.orc_lock_sample.argtypes = [C.c_void_p]
+        L.orc_lock_freq_hz.restype = C.c_double
+        L.orc_lock_freq_hz.argtypes = [C.c_void_p]
+        L.orc_interp.argtypes = [C.c_void_p]
+        L.orc_ntaps.argtypes = [C.c_void_p]
+        L.orc_totals.restype = C.c_size_t
+        L.orc_totals.argtypes = [C.c_void_p] + [C.POINTER(C.c_uint64)] * 3
+        L.orc_sincosf.argtypes = [C.c_float, C.POINTER(C.c_float), C.POINTER(C.c_float)]
+        L.orc_sincosf.restype = None
+        L.orc_hypotf.argtypes = [C.c_float, C.c_float]
+        L.orc_hypotf.restype = C.c_float
+        L.orc_q_rsqrt.argtypes = [C.c_float]
+        L.orc_q_rsqrt.restype = C.c_float
+        L.orc_arctan2_f32.argtypes = [C.c_float, C.c_float]
+        L.orc_arctan2_f32.restype = C.c_float
+        L.orc_make_lpf_f32.argtypes = [C.c_void_p, C.c_int, C.c_float, C.c_float, C.c_int]
+        L.orc_make_lpf_f64.argtypes = [C.c_void_p, C.c_int, C.c_double, C.c_double, C.c_int]
+        _lib = L
+    return _lib
+
+
+class Oracle:
+    """Run the CPU restatement over a whole capture (int16[n,2])."""
+
+    def __init__(self, mode: int, sample_rate: int, iq: np.ndarray, chunk: int = 0, norm_override: float = 0.0,
+                 keep_stages: bool = True):
+        L = lib()
+        self._L = L
+        self.mode = mode
+        self.dtype = np.float64 if mode == ARGOS else np.float32
+        self._h = L.orc_open(mode, sample_rate, chunk, norm_override, int(keep_stages))
+        a = np.ascontiguousarray(iq, dtype="<i2").reshape(-1)
+        L.orc_run_pcm16(self._h, a.ctypes.data, a.size // 2)
+
+    def __del__(self):
+        if getattr(self, "_h", None):
+            self._L.orc_close(self._h)
+            self._h = None
+
+    def text(self) -> bytes:
+        n = C.c_size_t()
+        p = self._L.orc_text(self._h, C.byref(n))
+        return C.string_at(p, n.value)
+
+    def frames(self):
+        n = self._L.orc_num_frames(self._h)
+        p = self._L.orc_frames(self._h)
+        return [p[i] for i in range(n)]
+
+    def stage(self, st: int) -> np.ndarray:
+        n = self._L.orc_stage(self._h, st, None, 0)
+        dt = {ST_BITS: np.uint8, ST_COUNTS: np.uint64, ST_SYMIDX: np.int64}.get(st, self.dtype)
+        out = np.zeros(n // np.dtype(dt).itemsize, dtype=dt)
+        if n:
+            self._L.orc_stage(self._h, st, out.ctypes.data, n)
+        return out
+
+    @property
+    def norm_factor(self):
+        return self._L.orc_norm_factor(self._h)
+
+    @property
+    def lock_sample(self):
+        return self._L.orc_lock_sample(self._h)
+
+    @property
+    def lock_freq_hz(self):
+        return self._L.orc_lock_freq_hz(self._h)
+
+    @property
+    def interp(self):
+        return self._L.orc_interp(self._h)
+
+    def totals(self):
+        a, b, c = C.c_uint64(), C.c_uint64(), C.c_uint64()
+        f = self._L.orc_totals(self._h, C.byref(a), C.byref(b), C.byref(c))
+        return a.value, b.value, c.value, f

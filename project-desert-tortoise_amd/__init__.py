@@ -1,0 +1,354 @@
+"""project-desert-tortoise_amd -- MI355X (gfx950) POES-TIP / ARGOS IQ demodulation chain.
+
+Python is only a thin ctypes veneer over ``csrc/libpdt.so`` (hand-written HIP kernels behind the
+C ABI of ``include/pdt.h``) and ``synth/libpdtsynth.so`` (integer-only synthetic captures).
+There is **no CPU fallback**: if the HIP library is missing, or no GPU is visible when a
+context is opened, the call fails loudly.
+
+The directory name contains hyphens, so import it with::
+
+    import importlib; pdt = importlib.import_module("project-desert-tortoise_amd")
+
+Reference behaviour mirrored here (file:line in nebarnix/Project-Desert-Tortoise):
+  * ``Demodulator`` == one run of the chunk loop POESTIPdemod/main.c:373-492 or
+    ARGOSdemod/main.c:250-306 over a whole capture.
+  * ``Demodulator.text()`` == the bytes POESTIPdemod/ByteSync.c:62-69,96-101 /
+    ARGOSdemod/ByteSync.c:62-70,99-103 write to minorFrames_*.txt / packets_*.txt.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import struct
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIBPDT_PATH = os.path.join(_HERE, "csrc", "libpdt.so")
+LIBSYNTH_PATH = os.path.join(_HERE, "synth", "libpdtsynth.so")
+
+MODE_POES, MODE_ARGOS = 0, 1
+ST_PLL, ST_LOCK, ST_FIR, ST_AGC, ST_SYM, ST_SYMIDX, ST_BITS, ST_BITSYM = range(8)
+
+
+class PdtError(RuntimeError):
+    pass
+
+
+class Config(C.Structure):
+    _fields_ = [
+        ("mode", C.c_int32),
+        ("sample_rate", C.c_uint32),
+        ("chunk", C.c_uint64),
+        ("norm_override", C.c_double),
+        ("device", C.c_int32),
+        ("profile", C.c_int32),
+        ("pll_block", C.c_uint32),
+        ("pll_warm", C.c_uint32),
+        ("agc_block", C.c_uint32),
+        ("agc_warm", C.c_uint32),
+    ]
+
+
+class Frame(C.Structure):
+    _fields_ = [
+        ("time", C.c_double),
+        ("bit_index", C.c_int64),
+        ("time_src", C.c_int64),
+        ("inverted", C.c_uint8),
+        ("nbytes", C.c_uint8),
+        ("complete", C.c_uint8),
+        ("pad", C.c_uint8),
+        ("bytes", C.c_uint8 * 104),
+    ]
+
+
+class Stats(C.Structure):
+    _fields_ = [
+        ("samples", C.c_uint64),
+        ("out_samples", C.c_uint64),
+        ("symbols", C.c_uint64),
+        ("bits", C.c_uint64),
+        ("frames", C.c_uint64),
+        ("lock_sample", C.c_int64),
+        ("lock_freq_hz", C.c_double),
+        ("norm_factor", C.c_double),
+        ("avg_phase", C.c_double),
+        ("interp", C.c_uint32),
+        ("ntaps", C.c_uint32),
+        ("pll_blocks", C.c_uint32),
+        ("pll_seam_fixes", C.c_uint32),
+        ("agc_blocks", C.c_uint32),
+        ("agc_seam_fixes", C.c_uint32),
+        ("gpu_ms", C.c_double),
+    ]
+
+
+class KernelTime(C.Structure):
+    _fields_ = [("name", C.c_char * 32), ("launches", C.c_uint32), ("total_ms", C.c_double)]
+
+
+# every symbol include/pdt.h declares (tests check the library exports all of them)
+ABI_SYMBOLS = [
+    "pdt_abi_version", "pdt_strerror", "pdt_device_count", "pdt_open", "pdt_close", "pdt_set_stream",
+    "pdt_demod_pcm16", "pdt_demod_device", "pdt_num_frames", "pdt_frames", "pdt_get_stats",
+    "pdt_format_frames", "pdt_read_stage", "pdt_stage_len", "pdt_kernel_times", "pdt_make_lpf",
+    "pdt_wav_parse_header", "pdt_time_axis",
+]
+
+_lib = None
+
+
+def lib():
+    """Load libpdt.so (built in-tree by ``make`` / ``__graft_entry__.build()``); fail loudly if absent."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIBPDT_PATH):
+        raise PdtError(
+            f"{LIBPDT_PATH} is missing: build it with `make` (hipcc --offload-arch=gfx950). "
+            "There is no CPU implementation to fall back to."
+        )
+    L = C.CDLL(LIBPDT_PATH)
+    L.pdt_abi_version.restype = C.c_int
+    L.pdt_strerror.restype = C.c_char_p
+    L.pdt_strerror.argtypes = [C.c_int]
+    L.pdt_device_count.restype = C.c_int
+    L.pdt_open.argtypes = [C.POINTER(Config), C.POINTER(C.c_void_p)]
+    L.pdt_close.argtypes = [C.c_void_p]
+    L.pdt_close.restype = None
+    L.pdt_set_stream.argtypes = [C.c_void_p, C.c_void_p]
+    L.pdt_demod_pcm16.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64]
+    L.pdt_demod_device.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64]
+    L.pdt_num_frames.argtypes = [C.c_void_p]
+    L.pdt_num_frames.restype = C.c_uint64
+    L.pdt_frames.argtypes = [C.c_void_p, C.POINTER(Frame), C.c_uint64]
+    L.pdt_frames.restype = C.c_uint64
+    L.pdt_get_stats.argtypes = [C.c_void_p, C.POINTER(Stats)]
+    L.pdt_format_frames.argtypes = [C.c_void_p, C.c_char_p, C.c_uint64]
+    L.pdt_format_frames.restype = C.c_uint64
+    L.pdt_read_stage.argtypes = [C.c_void_p, C.c_int, C.c_uint64, C.c_uint64, C.c_void_p]
+    L.pdt_read_stage.restype = C.c_int64
+    L.pdt_stage_len.argtypes = [C.c_void_p, C.c_int]
+    L.pdt_stage_len.restype = C.c_uint64
+    L.pdt_kernel_times.argtypes = [C.c_void_p, C.POINTER(KernelTime), C.c_int]
+    L.pdt_make_lpf.argtypes = [C.c_int, C.c_uint32, C.c_void_p, C.POINTER(C.c_int), C.POINTER(C.c_int)]
+    L.pdt_wav_parse_header.argtypes = [C.c_char_p] + [C.POINTER(C.c_uint32)] * 5
+    L.pdt_time_axis.argtypes = [C.c_int, C.c_uint32, C.c_uint64]
+    L.pdt_time_axis.restype = C.c_double
+    if L.pdt_abi_version() != 1:
+        raise PdtError("libpdt.so ABI version mismatch")
+    _lib = L
+    return L
+
+
+def _check(rc: int, what: str):
+    if rc != 0:
+        raise PdtError(f"{what}: {lib().pdt_strerror(rc).decode()} ({rc})")
+
+
+def make_lpf(mode: int, sample_rate: int) -> tuple[np.ndarray, int]:
+    """MakeLPFIR as the reference's mains call it (LowPassFilter.c:127-175). Returns (taps, interp)."""
+    L = lib()
+    nt, ip = C.c_int(), C.c_int()
+    _check(L.pdt_make_lpf(mode, sample_rate, None, C.byref(nt), C.byref(ip)), "pdt_make_lpf")
+    taps = np.zeros(nt.value, dtype=np.float64 if mode == MODE_ARGOS else np.float32)
+    _check(L.pdt_make_lpf(mode, sample_rate, taps.ctypes.data, None, None), "pdt_make_lpf")
+    return taps, ip.value
+
+
+def time_axis(mode: int, sample_rate: int, m: int) -> float:
+    return lib().pdt_time_axis(mode, sample_rate, m)
+
+
+def read_wav(path: str) -> tuple[int, np.ndarray]:
+    """44-byte canonical header only, like ReadWavHeader (wave.c:303-378); every byte after it is
+    sample data (the reference reads to EOF, POESTIPdemod/main.c:373).  Returns (rate, int16[n,2])."""
+    with open(path, "rb") as f:
+        hdr = f.read(44)
+        data = f.read()
+    if len(hdr) < 44:
+        raise PdtError("short WAV header")
+    fmt, ch, rate = struct.unpack_from("<HHI", hdr, 20)
+    bits = struct.unpack_from("<H", hdr, 34)[0]
+    if fmt != 1 or ch != 2 or bits != 16:
+        raise PdtError("need 16-bit PCM with 2 channels (I,Q)")
+    n = len(data) // 4
+    return rate, np.frombuffer(data, dtype="<i2", count=2 * n).reshape(n, 2)
+
+
+class Demodulator:
+    """One capture -> minor frames / packets on one GPU (context of include/pdt.h)."""
+
+    def __init__(self, mode: int, sample_rate: int, chunk: int = 0, norm_override: float = 0.0, device: int = 0,
+                 profile: bool = False, pll_block: int = 0, pll_warm: int = 0, agc_block: int = 0, agc_warm: int = 0):
+        self._L = lib()
+        self.mode = mode
+        cfg = Config(mode, sample_rate, chunk, norm_override, device, int(profile), pll_block, pll_warm, agc_block,
+                     agc_warm)
+        self._h = C.c_void_p()
+        _check(self._L.pdt_open(C.byref(cfg), C.byref(self._h)), "pdt_open")
+        self.dtype = np.float64 if mode == MODE_ARGOS else np.float32
+
+    def close(self):
+        if self._h:
+            self._L.pdt_close(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        self.close()
+
+    def set_stream(self, stream_handle: int):
+        _check(self._L.pdt_set_stream(self._h, C.c_void_p(stream_handle)), "pdt_set_stream")
+
+    def demod(self, iq: np.ndarray):
+        """iq: int16 array of shape (n, 2) or flat interleaved I,Q in host memory."""
+        a = np.ascontiguousarray(iq, dtype="<i2").reshape(-1)
+        _check(self._L.pdt_demod_pcm16(self._h, a.ctypes.data, a.size // 2), "pdt_demod_pcm16")
+        return self
+
+    def demod_device(self, dev_ptr: int, nframes: int):
+        """Input already resident in HBM (e.g. ``tensor.data_ptr()`` of an int16 torch tensor)."""
+        _check(self._L.pdt_demod_device(self._h, C.c_void_p(dev_ptr), nframes), "pdt_demod_device")
+        return self
+
+    def frames(self) -> list[Frame]:
+        n = self._L.pdt_num_frames(self._h)
+        arr = (Frame * max(n, 1))()
+        got = self._L.pdt_frames(self._h, arr, n)
+        return [arr[i] for i in range(got)]
+
+    def frames_array(self) -> np.ndarray:
+        """Frames as a structured numpy array (same layout as ``pdt_frame``)."""
+        n = self._L.pdt_num_frames(self._h)
+        buf = np.zeros(n, dtype=FRAME_DTYPE)
+        if n:
+            self._L.pdt_frames(self._h, C.cast(buf.ctypes.data, C.POINTER(Frame)), n)
+        return buf
+
+    def stats(self) -> Stats:
+        s = Stats()
+        _check(self._L.pdt_get_stats(self._h, C.byref(s)), "pdt_get_stats")
+        return s
+
+    def text(self) -> bytes:
+        n = self._L.pdt_format_frames(self._h, None, 0)
+        buf = C.create_string_buffer(n + 1)
+        self._L.pdt_format_frames(self._h, buf, n)
+        return buf.raw[:n]
+
+    def stage(self, st: int, first: int = 0, count: int | None = None) -> np.ndarray:
+        total = self._L.pdt_stage_len(self._h, st)
+        if count is None:
+            count = max(total - first, 0)
+        dt = {ST_SYMIDX: np.int64, ST_BITS: np.uint8, ST_BITSYM: np.uint32}.get(st, self.dtype)
+        out = np.zeros(count, dtype=dt)
+        if count:
+            got = self._L.pdt_read_stage(self._h, st, first, count, out.ctypes.data)
+            if got < 0:
+                _check(int(got), "pdt_read_stage")
+            out = out[:got]
+        return out
+
+    def kernel_times(self) -> dict[str, tuple[int, float]]:
+        n = self._L.pdt_kernel_times(self._h, None, 0)
+        arr = (KernelTime * max(n, 1))()
+        self._L.pdt_kernel_times(self._h, arr, n)
+        return {arr[i].name.decode(): (arr[i].launches, arr[i].total_ms) for i in range(n)}
+
+
+FRAME_DTYPE = np.dtype([
+    ("time", "<f8"), ("bit_index", "<i8"), ("time_src", "<i8"), ("inverted", "u1"), ("nbytes", "u1"),
+    ("complete", "u1"), ("pad", "u1"), ("bytes", "u1", (104,)), ("_tail", "u1", (4,)),   # C struct is padded to 136
+])
+assert FRAME_DTYPE.itemsize == C.sizeof(Frame)
+
+
+def format_frames(frames: np.ndarray) -> bytes:
+    """Text of a (possibly gathered) frame array, same rules as ``pdt_format_frames``."""
+    out = []
+    for f in frames:
+        out.append((b"%.5fi " if f["inverted"] else b"%.5f ") % f["time"])
+        out.append(b"".join(b"%.2X " % b for b in f["bytes"][: f["nbytes"]]))
+        if f["complete"]:
+            out.append(b"\n")
+    return b"".join(out)
+
+
+# ------------------------------------------------------------------ synthetic captures
+class SynthParams(C.Structure):
+    _fields_ = [
+        ("kind", C.c_uint32), ("sample_rate", C.c_uint32), ("carrier_step", C.c_uint32), ("phase0", C.c_uint32),
+        ("mod_index", C.c_uint32), ("amplitude", C.c_int32), ("noise_gain", C.c_int32), ("seed", C.c_uint64),
+    ]
+
+
+_synth = None
+
+
+def synth_lib():
+    global _synth
+    if _synth is None:
+        if not os.path.exists(LIBSYNTH_PATH):
+            raise PdtError(f"{LIBSYNTH_PATH} is missing: run `make`")
+        S = C.CDLL(LIBSYNTH_PATH)
+        S.pdt_synth_default_params.argtypes = [C.POINTER(SynthParams), C.c_int, C.c_uint32, C.c_double, C.c_uint64]
+        S.pdt_synth_default_params.restype = None
+        S.pdt_synth_fill.argtypes = [C.POINTER(SynthParams), C.c_uint64, C.c_uint64, C.c_void_p]
+        S.pdt_synth_fill.restype = None
+        S.pdt_synth_poes_frame.argtypes = [C.POINTER(SynthParams), C.c_uint64, C.c_void_p]
+        S.pdt_synth_poes_frame.restype = None
+        S.pdt_synth_argos_payload.argtypes = [C.POINTER(SynthParams), C.c_uint64, C.c_void_p]
+        S.pdt_synth_argos_payload.restype = None
+        S.pdt_synth_sine_table.restype = C.POINTER(C.c_int16)
+        S.pdt_synth_wav_header.argtypes = [C.c_void_p, C.c_uint32, C.c_uint64]
+        S.pdt_synth_wav_header.restype = None
+        _synth = S
+    return _synth
+
+
+def synth_params(kind: int, sample_rate: int, f0_hz: float = 1000.0, seed: int = 1234) -> SynthParams:
+    p = SynthParams()
+    synth_lib().pdt_synth_default_params(C.byref(p), kind, sample_rate, f0_hz, seed)
+    return p
+
+
+def synth_capture(kind: int, sample_rate: int, seconds: float, f0_hz: float | None = None, seed: int = 1234,
+                  start: int = 0) -> np.ndarray:
+    """int16[n,2] synthetic POES (kind 0) / ARGOS (kind 1) capture; bit-reproducible everywhere."""
+    if f0_hz is None:
+        f0_hz = 1000.0 if kind == 0 else 120.0
+    p = synth_params(kind, sample_rate, f0_hz, seed)
+    n = int(round(seconds * sample_rate))
+    out = np.zeros((n, 2), dtype="<i2")
+    synth_lib().pdt_synth_fill(C.byref(p), start, n, out.ctypes.data)
+    return out
+
+
+def synth_poes_frame(p: SynthParams, fr: int) -> np.ndarray:
+    out = np.zeros(104, dtype=np.uint8)
+    synth_lib().pdt_synth_poes_frame(C.byref(p), fr, out.ctypes.data)
+    return out
+
+
+def synth_argos_payload(p: SynthParams, burst: int) -> np.ndarray:
+    out = np.zeros(7, dtype=np.uint8)
+    synth_lib().pdt_synth_argos_payload(C.byref(p), burst, out.ctypes.data)
+    return out
+
+
+def write_wav(path: str, sample_rate: int, iq: np.ndarray):
+    hdr = C.create_string_buffer(44)
+    synth_lib().pdt_synth_wav_header(hdr, sample_rate, iq.shape[0])
+    with open(path, "wb") as f:
+        f.write(hdr.raw)
+        f.write(np.ascontiguousarray(iq, dtype="<i2").tobytes())

@@ -1,0 +1,738 @@
+// pdt_api.hip -- libpdt.so: context management, kernel orchestration and the C ABI of
+// include/pdt.h.  Compiled for gfx950 only, with -ffp-contract=off (see pdt_device_math.h).
+#include <hip/hip_runtime.h>
+#include <math.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include <algorithm>
+#include <string>
+#include <vector>
+
+#include "../../include/pdt.h"
+#include "pdt_kernels_back.h"
+#include "pdt_kernels_front.h"
+#include "pdt_timeaxis.h"
+
+using namespace pdt;
+
+#define HIP_TRY(expr)                                                                                  \
+    do {                                                                                               \
+        hipError_t e_ = (expr);                                                                        \
+        if (e_ != hipSuccess) {                                                                        \
+            fprintf(stderr, "libpdt: %s failed: %s (%s:%d)\n", #expr, hipGetErrorString(e_), __FILE__, \
+                    __LINE__);                                                                         \
+            return PDT_ERR_NOGPU;                                                                      \
+        }                                                                                              \
+    } while (0)
+
+namespace {
+
+struct DevBuf {
+    void *p = nullptr;
+    size_t cap = 0;
+    int ensure(size_t bytes)
+    {
+        if (bytes <= cap) return PDT_OK;
+        if (p) (void)hipFree(p);
+        p = nullptr;
+        cap = 0;
+        size_t want = bytes + bytes / 16 + 4096;
+        if (hipMalloc(&p, want) != hipSuccess) {
+            (void)hipGetLastError();
+            return PDT_ERR_NOMEM;
+        }
+        cap = want;
+        return PDT_OK;
+    }
+    void release()
+    {
+        if (p) (void)hipFree(p);
+        p = nullptr;
+        cap = 0;
+    }
+};
+
+struct KTimer {
+    std::string name;
+    hipEvent_t a, b;
+};
+
+// device-side scalar block shared by all stages of one run
+struct DevScalars {
+    unsigned long long nsym;
+    unsigned long long nbits;
+    unsigned nhits;
+    unsigned nframes;
+    unsigned counters[4];   // pll blocks, pll fixes, agc blocks, agc fixes
+    double norm;            // storage for the normalisation factor (float or double)
+};
+
+}  // namespace
+
+struct pdt_ctx {
+    pdt_config cfg;
+    int elem;                 // sizeof(DT)
+    uint32_t interp, ntaps;
+    hipStream_t stream = nullptr;
+    bool own_stream = false;
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+
+    DevBuf pcm, pll, lock, fir, agc, sym, symidx, bits, bitsym, hits, frames, taps, mag, seams_pll, seams_agc, scal, lockinfo;
+    const void *pcm_dev = nullptr;     // input actually used (own copy or caller's buffer)
+
+    std::vector<unsigned char> taps_host;
+    // results
+    uint64_t n_samples = 0, n_out = 0;
+    std::vector<pdt_frame> frames_host;
+    pdt_stats stats;
+    std::vector<pdt_kernel_time> ktimes;
+    std::vector<KTimer> timers;
+    uint64_t stage_len[PDT_ST_COUNT];
+    TimeAxis<float> axis_f;
+    TimeAxis<double> axis_d;
+};
+
+namespace {
+
+// ---------------------------------------------------------------- FIR taps (LowPassFilter.c:127-175)
+// Evaluated on the host exactly like the reference does (libm sinf/sin + cos), once per context.
+template <typename T> void make_lpf(T *h, int N, T Fc, T Fs, int interp)
+{
+    const T Tt = (T)(1.0 / (double)Fs);
+    const T wc = (T)(2.0 * M_PI * (double)Fc * (double)Tt);
+    const T tou = (T)((N - 1.0) / 2.0);
+    for (int n = 0; n < N; n++) {
+        const T arg = wc * ((T)n - tou);
+        const T sv = (sizeof(T) == 4) ? (T)sinf((float)arg) : (T)sin((double)arg);
+        T hd = (T)((double)sv / (M_PI * (double)((T)n - tou)));
+        if (((T)n == tou) && ((N / 2) * 2 != N)) hd = (T)((double)wc / M_PI);
+        const T wn = (T)(0.42 - 0.5 * cos((2 * M_PI * n) / (N - 1)) + 0.08 * cos((4 * M_PI * n) / (N - 1)));
+        h[n] = hd * wn * (T)interp;
+    }
+}
+
+int poes_interp(uint32_t rate) { return (int)rint(150000.0 / (double)(float)rate); }   // POESTIPdemod/main.c:347
+
+class Launcher {
+  public:
+    Launcher(pdt_ctx *c) : ctx(c) {}
+    void begin(const char *name)
+    {
+        if (!ctx->cfg.profile) return;
+        KTimer t;
+        t.name = name;
+        (void)hipEventCreate(&t.a);
+        (void)hipEventCreate(&t.b);
+        (void)hipEventRecord(t.a, ctx->stream);
+        ctx->timers.push_back(t);
+    }
+    void end()
+    {
+        if (!ctx->cfg.profile) return;
+        (void)hipEventRecord(ctx->timers.back().b, ctx->stream);
+    }
+
+  private:
+    pdt_ctx *ctx;
+};
+
+template <typename T> PllParams<T> make_pll_params(const pdt_ctx *ctx)
+{
+    // call-site constants: POESTIPdemod/main.c:32-46,413 / ARGOSdemod/main.c:33-44,265
+    PllParams<T> P;
+    const T Fs = (T)ctx->cfg.sample_rate;
+    const bool argos = ctx->cfg.mode == PDT_MODE_ARGOS;
+    const T freqRange = argos ? (T)550.0 : (T)4500.0;
+    const double w = 2.0 * M_PI / (double)Fs;
+    const T bw_acq = (T)((argos ? 16.0 : 127.3240) * w);
+    const T bw_trk = (T)((argos ? 16.0 : 10.3451) * w);
+    P.Fs = Fs;
+    P.lock_thr = argos ? (T)0.1 : (T)0.08;
+    P.lock_alpha = (T)((argos ? 3.1831 : 0.3979) * w);
+    const T damp = (T)0.999;
+    const T four = 4, one = 1, two = 2;
+    P.alpha_acq = (four * damp * bw_acq) / (one + two * damp * bw_acq + bw_acq * bw_acq);     // :90-91, all DT
+    P.beta_acq = (four * bw_acq * bw_acq) / (one + two * damp * bw_acq + bw_acq * bw_acq);
+    const double dd = (double)damp, db = (double)bw_trk;
+    P.alpha_trk = (T)((4.0 * dd * db) / (1.0 + 2.0 * dd * db + (double)(bw_trk * bw_trk)));   // :272-273, double
+    P.beta_trk = (T)((4.0 * db * db) / (1.0 + 2.0 * dd * db + (double)(bw_trk * bw_trk)));
+    P.max_freq = (T)(2.0 * M_PI * (double)freqRange / (double)Fs);
+    P.min_freq = (T)(-2.0 * M_PI * (double)freqRange / (double)Fs);
+    P.sweep0 = (T)(0.2 * (2.0 * M_PI / (double)Fs));
+    P.avg0 = (T)(M_PI / 2.0);
+    P.phase0 = (T)0.1;
+    P.want_lock = argos ? 1 : 0;
+    return P;
+}
+
+uint32_t next_pow2(uint32_t v)
+{
+    uint32_t p = 1;
+    while (p < v) p <<= 1;
+    return p;
+}
+
+template <typename T> int run_capture(pdt_ctx *ctx, uint64_t n)
+{
+    const bool argos = ctx->cfg.mode == PDT_MODE_ARGOS;
+    const long long N = (long long)n;
+    const int interp = (int)ctx->interp;
+    const int ntaps = (int)ctx->ntaps;
+    const long long n_out = N * interp;
+    const long long chunk = (long long)ctx->cfg.chunk;
+    const long long chunk_out = chunk * interp;
+    hipStream_t st = ctx->stream;
+    Launcher L(ctx);
+
+    // ---- parameters
+    const T Fs = (T)ctx->cfg.sample_rate;
+    PllParams<T> PP = make_pll_params<T>(ctx);
+    AgcParams<T> AP;
+    const T fsi = Fs * (T)interp;                                              // POESTIPdemod/main.c:429
+    AP.attack = (T)(79.5775 * (2.0 * M_PI / (double)fsi));
+    AP.decay = (T)(159.1549 * (2.0 * M_PI / (double)fsi));
+    AP.squelch = argos ? 1 : 0;
+    AP.squelch_thr = (T)0.15;                                                  // ARGOSdemod/main.c:46,276
+    GardnerParams<T> GP;
+    const T baud = argos ? (T)(400 * 2.0) : (T)(8320 * 2 + 0.3);              // main.c:90 / ARGOS main.c:64
+    GP.step = (T)(int)fsi / baud;                                              // GardenerClockRecovery.c:19
+    GP.kp = (T)3.0;
+    GP.lim = (T)0.1;
+    GP.n_total = n_out;
+    GP.chunk_out = chunk_out;
+    GP.argos_heap = 0;
+    GP.argos_field_bits = 0;
+    GP.argos_even = 0;
+    if (argos && (size_t)chunk * 8 < 128 * 1024) {                            // Q16, below M_MMAP_THRESHOLD
+        const unsigned long long req = 8ull * (unsigned long long)chunk;
+        GP.argos_heap = 1;
+        GP.argos_field_bits = ((req + 8 + 15) & ~15ull) | 1ull;
+        GP.argos_even = ((req + 8) % 16) != 0;
+    }
+    const T manch_thr = argos ? (T)0.5 : (T)1.0;                               // main.c:445 / ARGOS main.c:282
+    SyncParams SP;
+    if (argos) {
+        SP.pattern = 0x02F0ull;   // "0001011110000"
+        SP.len = 13; SP.allow_inverse = 0; SP.span = 56; SP.first_bits = 8; SP.nbytes = 7; SP.prefix = 0;
+    } else {
+        SP.pattern = 0x76F10ull;  // "1110110111100010000"
+        SP.len = 19; SP.allow_inverse = 1; SP.span = 813; SP.first_bits = 5; SP.nbytes = 102; SP.prefix = 2;
+    }
+
+    // ---- block-parallel geometry
+    long long Bp = ctx->cfg.pll_block ? ctx->cfg.pll_block : (long long)(0.4 * ctx->cfg.sample_rate);
+    long long Wp = ctx->cfg.pll_warm ? ctx->cfg.pll_warm : (long long)(0.4 * ctx->cfg.sample_rate);
+    if (argos) {   // the lock-detector EMA (alpha 6e-4 at 32 ksps, 53-bit state) needs seconds to re-converge
+        if (!ctx->cfg.pll_block) Bp = (long long)(4.0 * ctx->cfg.sample_rate);
+        if (!ctx->cfg.pll_warm) Wp = (long long)(8.0 * ctx->cfg.sample_rate);
+    }
+    long long Ba = ctx->cfg.agc_block ? ctx->cfg.agc_block : (long long)(0.5 * ctx->cfg.sample_rate * interp);
+    long long Wa = ctx->cfg.agc_warm ? ctx->cfg.agc_warm : (long long)(1.0 * ctx->cfg.sample_rate * interp);
+    if (argos) {
+        if (!ctx->cfg.agc_block) Ba = (long long)(4.0 * ctx->cfg.sample_rate);
+        if (!ctx->cfg.agc_warm) Wa = (long long)(8.0 * ctx->cfg.sample_rate);
+    }
+    if (Bp < 64) Bp = 64;
+    if (Ba < 64) Ba = 64;
+    const long long nb_pll = (N + Bp - 1) / Bp + 1;
+    const long long nb_agc = (n_out + Ba - 1) / Ba + 1;
+
+    // ---- capacities
+    const double min_step = (double)GP.step - 0.25;
+    const long long n_chunks = chunk_out > 0 ? (n_out + chunk_out - 1) / chunk_out : 0;
+    const long long sym_cap = (long long)((double)n_out / min_step) + n_chunks + 64;
+    const long long bit_cap = sym_cap;
+    const uint32_t hit_cap = next_pow2((uint32_t)(bit_cap / 64 + 4096));
+    const uint32_t frame_cap = (uint32_t)(bit_cap / SP.span + 16);
+    const long long n_tiles = (sym_cap + PDT_TILE - 1) / PDT_TILE;
+    const long long n0 = std::min<long long>(chunk, N);
+
+    int rc;
+    if ((rc = ctx->pll.ensure((size_t)(N + 1) * sizeof(T)))) return rc;
+    if (argos && (rc = ctx->lock.ensure((size_t)(N + 1) * sizeof(T)))) return rc;
+    if ((rc = ctx->fir.ensure((size_t)(n_out + 1) * sizeof(T)))) return rc;
+    if ((rc = ctx->agc.ensure((size_t)(n_out + 1) * sizeof(T)))) return rc;
+    if ((rc = ctx->sym.ensure((size_t)sym_cap * sizeof(T)))) return rc;
+    if ((rc = ctx->symidx.ensure((size_t)sym_cap * sizeof(long long)))) return rc;
+    if ((rc = ctx->bits.ensure((size_t)bit_cap))) return rc;
+    if ((rc = ctx->bitsym.ensure((size_t)bit_cap * sizeof(unsigned)))) return rc;
+    if ((rc = ctx->hits.ensure((size_t)hit_cap * sizeof(unsigned) + (size_t)n_tiles * sizeof(ManchTile)))) return rc;
+    if ((rc = ctx->frames.ensure((size_t)frame_cap * sizeof(FrameRec)))) return rc;
+    if ((rc = ctx->mag.ensure((size_t)(n0 + 1) * sizeof(T)))) return rc;
+    if ((rc = ctx->seams_pll.ensure((size_t)nb_pll * sizeof(PllSeam<T>)))) return rc;
+    if ((rc = ctx->seams_agc.ensure((size_t)nb_agc * sizeof(AgcSeam<T>)))) return rc;
+    if ((rc = ctx->scal.ensure(sizeof(DevScalars)))) return rc;
+    if ((rc = ctx->lockinfo.ensure(sizeof(PllLockInfo<T>)))) return rc;
+
+    const int *d_pcm = (const int *)ctx->pcm_dev;
+    T *d_pll = (T *)ctx->pll.p;
+    T *d_lock = argos ? (T *)ctx->lock.p : nullptr;
+    T *d_fir = (T *)ctx->fir.p;
+    T *d_agc = (T *)ctx->agc.p;
+    T *d_sym = (T *)ctx->sym.p;
+    long long *d_symidx = (long long *)ctx->symidx.p;
+    unsigned char *d_bits = (unsigned char *)ctx->bits.p;
+    unsigned *d_bitsym = (unsigned *)ctx->bitsym.p;
+    unsigned *d_hits = (unsigned *)ctx->hits.p;
+    ManchTile *d_tiles = (ManchTile *)((unsigned char *)ctx->hits.p + (size_t)hit_cap * sizeof(unsigned));
+    FrameRec *d_frames = (FrameRec *)ctx->frames.p;
+    DevScalars *d_sc = (DevScalars *)ctx->scal.p;
+    PllLockInfo<T> *d_info = (PllLockInfo<T> *)ctx->lockinfo.p;
+    T *d_norm = (T *)&d_sc->norm;
+    T *d_taps = (T *)ctx->taps.p;
+
+    HIP_TRY(hipEventRecord(ctx->ev0, st));
+    HIP_TRY(hipMemsetAsync(d_sc, 0, sizeof(DevScalars), st));
+    HIP_TRY(hipMemsetAsync(d_frames, 0, (size_t)frame_cap * sizeof(FrameRec), st));
+
+    // ---- StaticGain over the first chunk (main.c:384-389)
+    L.begin("static_gain");
+    hipLaunchKernelGGL(k_static_gain<T>, dim3(1), dim3(256), 0, st, d_pcm, n0, (T *)ctx->mag.p, (T)1.0,
+                       ctx->cfg.norm_override, d_norm);
+    L.end();
+
+    // ---- PLL: sequential acquisition, block-parallel tracking, seam repair
+    L.begin("pll_acquire");
+    hipLaunchKernelGGL(k_pll_acquire<T>, dim3(1), dim3(64), 0, st, d_pcm, N, PP, d_pll, d_lock, d_info);
+    L.end();
+    {
+        const long long grid = (nb_pll + 63) / 64;
+        L.begin("pll_track");
+        if (argos)
+            hipLaunchKernelGGL((k_pll_track<T, true>), dim3((unsigned)grid), dim3(64), 0, st, d_pcm, N, PP, d_info, Bp, Wp,
+                               d_pll, d_lock, (PllSeam<T> *)ctx->seams_pll.p, nb_pll);
+        else
+            hipLaunchKernelGGL((k_pll_track<T, false>), dim3((unsigned)grid), dim3(64), 0, st, d_pcm, N, PP, d_info, Bp, Wp,
+                               d_pll, d_lock, (PllSeam<T> *)ctx->seams_pll.p, nb_pll);
+        L.end();
+        L.begin("pll_fix");
+        if (argos)
+            hipLaunchKernelGGL((k_pll_fix<T, true>), dim3(1), dim3(64), 0, st, d_pcm, N, PP, d_info, Bp, d_pll, d_lock,
+                               (PllSeam<T> *)ctx->seams_pll.p, nb_pll, d_sc->counters);
+        else
+            hipLaunchKernelGGL((k_pll_fix<T, false>), dim3(1), dim3(64), 0, st, d_pcm, N, PP, d_info, Bp, d_pll, d_lock,
+                               (PllSeam<T> *)ctx->seams_pll.p, nb_pll, d_sc->counters);
+        L.end();
+    }
+
+    // ---- FIR
+    if (n_out > 0) {
+        const int opt = 8;
+        const long long tile = (long long)PDT_FIR_THREADS * opt;
+        const long long grid = (n_out + tile - 1) / tile;
+        L.begin("fir");
+        if (argos) {
+            const size_t sh = (size_t)(ntaps + tile + ntaps + 8) * sizeof(T);
+            hipLaunchKernelGGL(k_fir_plain<T>, dim3((unsigned)grid), dim3(PDT_FIR_THREADS), sh, st, d_pll, N, ntaps, d_taps,
+                               d_fir, opt);
+        } else {
+            const int K = ntaps / interp;
+            const size_t sh = (size_t)(ntaps + tile / interp + K + 8) * sizeof(T);
+            hipLaunchKernelGGL(k_fir_interp<T>, dim3((unsigned)grid), dim3(PDT_FIR_THREADS), sh, st, d_pll, N, interp, K,
+                               d_taps, d_fir, opt);
+        }
+        L.end();
+    }
+
+    // ---- AGC (+Squelch)
+    if (n_out > 0) {
+        const long long nb = (n_out + Ba - 1) / Ba;
+        const long long grid = (nb + 63) / 64;
+        L.begin("agc_block");
+        hipLaunchKernelGGL(k_agc_block<T>, dim3((unsigned)grid), dim3(64), 0, st, d_fir, n_out, AP, d_norm, Ba, Wa, d_lock,
+                           d_agc, (AgcSeam<T> *)ctx->seams_agc.p);
+        L.end();
+        L.begin("agc_fix");
+        hipLaunchKernelGGL(k_agc_fix<T>, dim3(1), dim3(64), 0, st, d_fir, n_out, AP, Ba, d_lock, d_agc,
+                           (AgcSeam<T> *)ctx->seams_agc.p, d_sc->counters);
+        L.end();
+    }
+
+    // ---- Gardner (sequential chain)
+    L.begin("gardner");
+    hipLaunchKernelGGL(k_gardner<T>, dim3(1), dim3(PDT_GARDNER_THREADS), 0, st, d_agc, d_lock, GP, d_sym, d_symidx,
+                       &d_sc->nsym, sym_cap);
+    L.end();
+
+    // ---- Manchester
+    L.begin("manchester");
+    hipLaunchKernelGGL(k_manch_tile<T>, dim3((unsigned)n_tiles), dim3(PDT_TILE_THREADS), 0, st, d_sym, &d_sc->nsym, manch_thr,
+                       d_tiles);
+    hipLaunchKernelGGL(k_manch_scan, dim3(1), dim3(64), 0, st, d_tiles, &d_sc->nsym, &d_sc->nbits);
+    hipLaunchKernelGGL(k_manch_emit<T>, dim3((unsigned)n_tiles), dim3(PDT_TILE_THREADS), 0, st, d_sym, &d_sc->nsym, manch_thr,
+                       d_tiles, d_bits, d_bitsym, bit_cap);
+    L.end();
+
+    // ---- byte sync
+    L.begin("bytesync");
+    {
+        const long long grid = (bit_cap + 255) / 256;
+        hipLaunchKernelGGL(k_sync_hits, dim3((unsigned)grid), dim3(256), 0, st, d_bits, &d_sc->nbits, SP, d_hits, &d_sc->nhits,
+                           hit_cap);
+        hipLaunchKernelGGL(k_sync_frames, dim3(1), dim3(256), 0, st, d_hits, &d_sc->nhits, hit_cap, SP, d_frames,
+                           &d_sc->nframes, frame_cap);
+        hipLaunchKernelGGL(k_frame_pack, dim3(frame_cap), dim3(128), 0, st, d_bits, &d_sc->nbits, d_bitsym, d_symidx, SP,
+                           d_frames, &d_sc->nframes, frame_cap);
+    }
+    L.end();
+    HIP_TRY(hipEventRecord(ctx->ev1, st));
+    HIP_TRY(hipGetLastError());
+
+    // ---- results back to the host
+    DevScalars sc;
+    PllLockInfo<T> info;
+    HIP_TRY(hipMemcpyAsync(&sc, d_sc, sizeof sc, hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipMemcpyAsync(&info, d_info, sizeof info, hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipStreamSynchronize(st));
+    if (sc.nframes > frame_cap || sc.nhits > hit_cap || (long long)sc.nsym > sym_cap) {
+        fprintf(stderr, "libpdt: internal capacity exceeded (frames %u/%u hits %u/%u symbols %llu/%lld)\n", sc.nframes,
+                frame_cap, sc.nhits, hit_cap, sc.nsym, sym_cap);
+        return PDT_ERR_STATE;
+    }
+    std::vector<FrameRec> recs(sc.nframes);
+    if (sc.nframes) HIP_TRY(hipMemcpy(recs.data(), d_frames, (size_t)sc.nframes * sizeof(FrameRec), hipMemcpyDeviceToHost));
+
+    float ms = 0;
+    (void)hipEventElapsedTime(&ms, ctx->ev0, ctx->ev1);
+
+    T norm_val;
+    memcpy(&norm_val, &sc.norm, sizeof(T));
+    pdt_stats &S = ctx->stats;
+    memset(&S, 0, sizeof S);
+    S.samples = n;
+    S.out_samples = (uint64_t)n_out;
+    S.symbols = sc.nsym;
+    S.bits = sc.nbits;
+    S.frames = sc.nframes;
+    S.lock_sample = info.lock_sample;
+    S.lock_freq_hz = (double)(info.freq_at_lock * Fs) / (2.0 * M_PI);         // CarrierTrackingPLL.c:269
+    S.avg_phase = (double)info.avg_at_lock;
+    S.norm_factor = (double)norm_val;
+    S.interp = (uint32_t)interp;
+    S.ntaps = (uint32_t)ntaps;
+    S.pll_blocks = sc.counters[0];
+    S.pll_seam_fixes = sc.counters[1];
+    S.agc_blocks = sc.counters[2];
+    S.agc_seam_fixes = sc.counters[3];
+    S.gpu_ms = ms;
+
+    ctx->stage_len[PDT_ST_PLL] = n;
+    ctx->stage_len[PDT_ST_LOCK] = argos ? n : 0;
+    ctx->stage_len[PDT_ST_FIR] = (uint64_t)n_out;
+    ctx->stage_len[PDT_ST_AGC] = (uint64_t)n_out;
+    ctx->stage_len[PDT_ST_SYM] = sc.nsym;
+    ctx->stage_len[PDT_ST_SYMIDX] = sc.nsym;
+    ctx->stage_len[PDT_ST_BITS] = sc.nbits;
+    ctx->stage_len[PDT_ST_BITSYM] = sc.nbits;
+
+    // ---- time stamps (host): SURVEY Appendix B Q1/Q2/Q4
+    ctx->frames_host.resize(sc.nframes);
+    for (unsigned f = 0; f < sc.nframes; f++) {
+        pdt_frame &o = ctx->frames_host[f];
+        const FrameRec &r = recs[f];
+        memset(&o, 0, sizeof o);
+        o.bit_index = r.bit_index;
+        o.time_src = r.time_src;
+        o.inverted = r.inverted;
+        o.nbytes = r.nbytes;
+        o.complete = r.complete;
+        memcpy(o.bytes, r.bytes, 104);
+        const long long g = r.time_src;
+        if (argos) {
+            o.time = ctx->axis_d.at((uint64_t)g + 1);                         // waveDataTime[i] = (i+1)-th partial sum
+        } else {
+            const long long c = g / chunk_out, rr = g % chunk_out;
+            const long long j = rr / interp + 1;                              // Q2: time of the *next* input sample
+            const long long ns_c = std::min<long long>(chunk, N - c * chunk);
+            if (j < ns_c)
+                o.time = (double)ctx->axis_f.at((uint64_t)(c * chunk + j + 1));
+            else if (ns_c == chunk || c == 0)
+                o.time = 0.0;                                                 // one past the array: never-written zero
+            else
+                o.time = (double)ctx->axis_f.at((uint64_t)((c - 1) * chunk + j + 1));   // stale value of the previous chunk
+        }
+    }
+
+    // ---- per-kernel timings
+    ctx->ktimes.clear();
+    for (auto &t : ctx->timers) {
+        float tms = 0;
+        (void)hipEventElapsedTime(&tms, t.a, t.b);
+        bool found = false;
+        for (auto &k : ctx->ktimes)
+            if (t.name == k.name) {
+                k.launches++;
+                k.total_ms += tms;
+                found = true;
+            }
+        if (!found) {
+            pdt_kernel_time k;
+            memset(&k, 0, sizeof k);
+            snprintf(k.name, sizeof k.name, "%s", t.name.c_str());
+            k.launches = 1;
+            k.total_ms = tms;
+            ctx->ktimes.push_back(k);
+        }
+        (void)hipEventDestroy(t.a);
+        (void)hipEventDestroy(t.b);
+    }
+    ctx->timers.clear();
+    return PDT_OK;
+}
+
+}  // namespace
+
+// ================================================================================= C ABI
+extern "C" {
+
+int pdt_abi_version(void) { return PDT_ABI_VERSION; }
+
+const char *pdt_strerror(int code)
+{
+    switch (code) {
+    case PDT_OK: return "ok";
+    case PDT_ERR_ARG: return "bad argument";
+    case PDT_ERR_NOGPU: return "no usable HIP device / HIP runtime error";
+    case PDT_ERR_NOMEM: return "out of device memory";
+    case PDT_ERR_FORMAT: return "unsupported WAV format (need 16-bit PCM, 2 channels)";
+    case PDT_ERR_RATE: return "sample rate too high: interpolation factor would be 0";
+    case PDT_ERR_STATE: return "call sequence / internal capacity error";
+    default: return "unknown error";
+    }
+}
+
+int pdt_device_count(void)
+{
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) {
+        (void)hipGetLastError();
+        return 0;
+    }
+    return n;
+}
+
+int pdt_make_lpf(int mode, uint32_t sample_rate, void *taps_out, int *ntaps, int *interp)
+{
+    if (!sample_rate) return PDT_ERR_ARG;
+    if (mode == PDT_MODE_ARGOS) {
+        if (ntaps) *ntaps = 50;
+        if (interp) *interp = 1;
+        if (taps_out) make_lpf<double>((double *)taps_out, 50, 700.0, (double)sample_rate, 1);   // ARGOSdemod/main.c:248
+        return PDT_OK;
+    }
+    const int ip = poes_interp(sample_rate);
+    if (ip < 1) return PDT_ERR_RATE;
+    const int N = 26 * ip;
+    if (ntaps) *ntaps = N;
+    if (interp) *interp = ip;
+    if (taps_out) {
+        const float Fs = (float)sample_rate;
+        make_lpf<float>((float *)taps_out, N, (float)11000.0, Fs * (float)ip, ip);              // POESTIPdemod/main.c:369
+    }
+    return PDT_OK;
+}
+
+int pdt_wav_parse_header(const uint8_t h[44], uint32_t *sample_rate, uint32_t *channels, uint32_t *bits_per_sample,
+                         uint32_t *format, uint32_t *data_bytes)
+{
+    if (!h) return PDT_ERR_ARG;
+    auto r32 = [&](int o) { return (uint32_t)h[o] | ((uint32_t)h[o + 1] << 8) | ((uint32_t)h[o + 2] << 16) | ((uint32_t)h[o + 3] << 24); };
+    auto r16 = [&](int o) { return (uint32_t)h[o] | ((uint32_t)h[o + 1] << 8); };
+    if (format) *format = r16(20);
+    if (channels) *channels = r16(22);
+    if (sample_rate) *sample_rate = r32(24);
+    if (bits_per_sample) *bits_per_sample = r16(34);
+    if (data_bytes) *data_bytes = r32(40);
+    return PDT_OK;
+}
+
+double pdt_time_axis(int mode, uint32_t sample_rate, uint64_t m)
+{
+    if (mode == PDT_MODE_ARGOS) {
+        TimeAxis<double> ax;
+        ax.init(1.0 / (double)sample_rate);
+        return ax.at(m);
+    }
+    TimeAxis<float> ax;
+    ax.init((float)(1.0 / (double)(float)sample_rate));
+    return (double)ax.at(m);
+}
+
+int pdt_open(const pdt_config *cfg, pdt_ctx **out)
+{
+    if (!cfg || !out) return PDT_ERR_ARG;
+    if (cfg->mode != PDT_MODE_POES && cfg->mode != PDT_MODE_ARGOS) return PDT_ERR_ARG;
+    if (!cfg->sample_rate) return PDT_ERR_ARG;
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) {
+        (void)hipGetLastError();
+        fprintf(stderr, "libpdt: no HIP device available -- this library has no CPU path\n");
+        return PDT_ERR_NOGPU;
+    }
+    if (cfg->device < 0 || cfg->device >= ndev) return PDT_ERR_ARG;
+    HIP_TRY(hipSetDevice(cfg->device));
+    pdt_ctx *ctx = new pdt_ctx();
+    ctx->cfg = *cfg;
+    if (!ctx->cfg.chunk) ctx->cfg.chunk = cfg->mode == PDT_MODE_ARGOS ? 2400 : 10000;
+    ctx->elem = cfg->mode == PDT_MODE_ARGOS ? 8 : 4;
+    int nt = 0, ip = 0;
+    int rc = pdt_make_lpf(cfg->mode, cfg->sample_rate, nullptr, &nt, &ip);
+    if (rc) { delete ctx; return rc; }
+    ctx->interp = (uint32_t)ip;
+    ctx->ntaps = (uint32_t)nt;
+    ctx->taps_host.resize((size_t)nt * ctx->elem);
+    pdt_make_lpf(cfg->mode, cfg->sample_rate, ctx->taps_host.data(), nullptr, nullptr);
+    if ((rc = ctx->taps.ensure(ctx->taps_host.size()))) { delete ctx; return rc; }
+    if (hipMemcpy(ctx->taps.p, ctx->taps_host.data(), ctx->taps_host.size(), hipMemcpyHostToDevice) != hipSuccess) {
+        delete ctx;
+        return PDT_ERR_NOGPU;
+    }
+    if (hipStreamCreate(&ctx->stream) != hipSuccess) { delete ctx; return PDT_ERR_NOGPU; }
+    ctx->own_stream = true;
+    (void)hipEventCreate(&ctx->ev0);
+    (void)hipEventCreate(&ctx->ev1);
+    memset(&ctx->stats, 0, sizeof ctx->stats);
+    memset(ctx->stage_len, 0, sizeof ctx->stage_len);
+    ctx->axis_f.init((float)(1.0 / (double)(float)cfg->sample_rate));        // wave.c:96-97
+    ctx->axis_d.init(1.0 / (double)cfg->sample_rate);
+    *out = ctx;
+    return PDT_OK;
+}
+
+void pdt_close(pdt_ctx *ctx)
+{
+    if (!ctx) return;
+    (void)hipSetDevice(ctx->cfg.device);
+    DevBuf *bufs[] = { &ctx->pcm, &ctx->pll, &ctx->lock, &ctx->fir, &ctx->agc, &ctx->sym, &ctx->symidx, &ctx->bits, &ctx->bitsym,
+                       &ctx->hits, &ctx->frames, &ctx->taps, &ctx->mag, &ctx->seams_pll, &ctx->seams_agc, &ctx->scal, &ctx->lockinfo };
+    for (DevBuf *b : bufs) b->release();
+    if (ctx->ev0) (void)hipEventDestroy(ctx->ev0);
+    if (ctx->ev1) (void)hipEventDestroy(ctx->ev1);
+    if (ctx->own_stream && ctx->stream) (void)hipStreamDestroy(ctx->stream);
+    delete ctx;
+}
+
+int pdt_set_stream(pdt_ctx *ctx, void *hip_stream)
+{
+    if (!ctx) return PDT_ERR_ARG;
+    if (ctx->own_stream && ctx->stream) (void)hipStreamDestroy(ctx->stream);
+    ctx->own_stream = false;
+    ctx->stream = (hipStream_t)hip_stream;
+    if (!hip_stream) {
+        if (hipStreamCreate(&ctx->stream) != hipSuccess) return PDT_ERR_NOGPU;
+        ctx->own_stream = true;
+    }
+    return PDT_OK;
+}
+
+static int demod_common(pdt_ctx *ctx, uint64_t nframes)
+{
+    HIP_TRY(hipSetDevice(ctx->cfg.device));
+    ctx->n_samples = nframes;
+    ctx->n_out = nframes * ctx->interp;
+    if (ctx->cfg.mode == PDT_MODE_ARGOS) {
+        fprintf(stderr, "libpdt: ARGOS (double) device path not built yet\n");
+        return PDT_ERR_ARG;
+    }
+    return run_capture<float>(ctx, nframes);
+}
+
+int pdt_demod_pcm16(pdt_ctx *ctx, const int16_t *iq_host, uint64_t nframes)
+{
+    if (!ctx || (!iq_host && nframes)) return PDT_ERR_ARG;
+    HIP_TRY(hipSetDevice(ctx->cfg.device));
+    int rc = ctx->pcm.ensure((size_t)nframes * 4 + 16);
+    if (rc) return rc;
+    if (nframes) HIP_TRY(hipMemcpyAsync(ctx->pcm.p, iq_host, (size_t)nframes * 4, hipMemcpyHostToDevice, ctx->stream));
+    ctx->pcm_dev = ctx->pcm.p;
+    return demod_common(ctx, nframes);
+}
+
+int pdt_demod_device(pdt_ctx *ctx, const void *iq_device, uint64_t nframes)
+{
+    if (!ctx || (!iq_device && nframes)) return PDT_ERR_ARG;
+    ctx->pcm_dev = iq_device;
+    return demod_common(ctx, nframes);
+}
+
+uint64_t pdt_num_frames(const pdt_ctx *ctx) { return ctx ? ctx->frames_host.size() : 0; }
+
+uint64_t pdt_frames(const pdt_ctx *ctx, pdt_frame *out, uint64_t max_frames)
+{
+    if (!ctx) return 0;
+    const uint64_t n = std::min<uint64_t>(max_frames, ctx->frames_host.size());
+    if (out && n) memcpy(out, ctx->frames_host.data(), (size_t)n * sizeof(pdt_frame));
+    return n;
+}
+
+int pdt_get_stats(const pdt_ctx *ctx, pdt_stats *out)
+{
+    if (!ctx || !out) return PDT_ERR_ARG;
+    *out = ctx->stats;
+    return PDT_OK;
+}
+
+uint64_t pdt_format_frames(const pdt_ctx *ctx, char *buf, uint64_t cap)
+{
+    if (!ctx) return 0;
+    const bool argos = ctx->cfg.mode == PDT_MODE_ARGOS;
+    std::string s;
+    s.reserve(ctx->frames_host.size() * 330);
+    char tmp[64];
+    for (const pdt_frame &f : ctx->frames_host) {
+        snprintf(tmp, sizeof tmp, f.inverted ? "%.5fi " : "%.5f ", f.time);   // ByteSync.c:96-99,126-129
+        s += tmp;
+        for (unsigned b = 0; b < f.nbytes; b++) {
+            snprintf(tmp, sizeof tmp, "%.2X ", f.bytes[b]);                   // ByteSync.c:62,100-101
+            s += tmp;
+        }
+        if (f.complete) s += "\n";                                            // ByteSync.c:66-70
+    }
+    (void)argos;
+    if (buf && cap) memcpy(buf, s.data(), (size_t)std::min<uint64_t>(cap, s.size()));
+    return s.size();
+}
+
+uint64_t pdt_stage_len(const pdt_ctx *ctx, int stage)
+{
+    if (!ctx || stage < 0 || stage >= PDT_ST_COUNT) return 0;
+    return ctx->stage_len[stage];
+}
+
+int64_t pdt_read_stage(const pdt_ctx *ctx, int stage, uint64_t first, uint64_t count, void *out)
+{
+    if (!ctx || !out || stage < 0 || stage >= PDT_ST_COUNT) return PDT_ERR_ARG;
+    const uint64_t len = ctx->stage_len[stage];
+    if (first >= len) return 0;
+    count = std::min<uint64_t>(count, len - first);
+    const void *src = nullptr;
+    size_t es = ctx->elem;
+    switch (stage) {
+    case PDT_ST_PLL: src = ctx->pll.p; break;
+    case PDT_ST_LOCK: src = ctx->lock.p; break;
+    case PDT_ST_FIR: src = ctx->fir.p; break;
+    case PDT_ST_AGC: src = ctx->agc.p; break;
+    case PDT_ST_SYM: src = ctx->sym.p; break;
+    case PDT_ST_SYMIDX: src = ctx->symidx.p; es = 8; break;
+    case PDT_ST_BITS: src = ctx->bits.p; es = 1; break;
+    case PDT_ST_BITSYM: src = ctx->bitsym.p; es = 4; break;
+    }
+    if (!src) return PDT_ERR_STATE;
+    if (hipSetDevice(ctx->cfg.device) != hipSuccess) return PDT_ERR_NOGPU;
+    if (hipMemcpy(out, (const unsigned char *)src + first * es, (size_t)count * es, hipMemcpyDeviceToHost) != hipSuccess)
+        return PDT_ERR_NOGPU;
+    return (int64_t)count;
+}
+
+int pdt_kernel_times(const pdt_ctx *ctx, pdt_kernel_time *out, int max_entries)
+{
+    if (!ctx) return 0;
+    const int n = std::min<int>(max_entries, (int)ctx->ktimes.size());
+    if (out)
+        for (int i = 0; i < n; i++) out[i] = ctx->ktimes[i];
+    return (int)ctx->ktimes.size();
+}
+
+}  // extern "C"

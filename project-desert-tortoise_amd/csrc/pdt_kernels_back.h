@@ -1,0 +1,481 @@
+// pdt_kernels_back.h -- back half of the chain on gfx950: Gardner symbol sampler,
+// Manchester decision, sync-word search and frame extraction.
+#pragma once
+#include "pdt_device_math.h"
+
+namespace pdt {
+
+// ------------------------------------------------------------------------------------------
+// Gardner clock recovery (reference: common/GardenerClockRecovery.c:5-114)
+//
+// The sampler is a leak-free integrator of a data-dependent, clipped error with
+// nearest-sample picks: perturbed trajectories do not re-merge, so
+// this stage is a true sequential chain over the symbols of one capture.  One lane
+// walks it; the other lanes of the workgroup only stage the current reference chunk
+// (chunk-relative coordinates are part of the arithmetic: float spacing depends on
+// the position inside the chunk) into LDS with coalesced loads.
+// ------------------------------------------------------------------------------------------
+template <typename T> struct GardnerParams {
+    T step, kp, lim;
+    long long n_total;       // interpolated samples in the capture
+    long long chunk_out;     // reference chunk size in interpolated samples (chunk * interp)
+    int argos_heap;          // 1 = reproduce the ARGOS heap adjacency (Q16) for reads past the chunk
+    unsigned long long argos_field_bits;   // malloc size field seen as a double
+    int argos_even;          // chunk even -> one 8-byte slack double before the size field
+};
+
+// value the reference would read at chunk-relative index idx >= n_cur of chunk c (Q3/Q16)
+template <typename T>
+__device__ __forceinline__ T gardner_beyond(const T *__restrict__ in, const T *__restrict__ lock, const GardnerParams<T> &P,
+                                            long long c, long long n_cur, long long idx)
+{
+    const long long C = P.chunk_out;
+    if (idx < C)                                   // stale data of the previous chunk (only in a short last chunk)
+        return (c >= 1) ? in[(c - 1) * C + idx] : (T)0;
+    if (!P.argos_heap) return (T)0;                // POES: over-allocated, never written -> zero pages
+    long long k = idx - C;
+    if (P.argos_even) {
+        if (k == 0) return (T)0;
+        k -= 1;
+    }
+    if (k == 0) {
+        if (sizeof(T) == 8) return (T)__longlong_as_double((long long)P.argos_field_bits);
+        return (T)0;
+    }
+    k -= 1;                                        // index into the lock-signal array of the current chunk
+    if (k < n_cur) return lock[c * C + k];
+    if (k < C) return (c >= 1) ? lock[(c - 1) * C + k] : (T)0;
+    return (T)0;
+}
+
+template <typename T> struct GardnerLds;
+template <> struct GardnerLds<float> { static constexpr int LEN = 38912; };    // 152 KiB of the 160 KiB LDS
+template <> struct GardnerLds<double> { static constexpr int LEN = 19456; };
+
+#define PDT_GARDNER_THREADS 256
+
+template <typename T>
+__global__ void __launch_bounds__(PDT_GARDNER_THREADS) k_gardner(const T *__restrict__ in, const T *__restrict__ lock,
+                                                                  GardnerParams<T> P, T *__restrict__ sym,
+                                                                  long long *__restrict__ symidx,
+                                                                  unsigned long long *__restrict__ nsym_out,
+                                                                  long long sym_cap)
+{
+    constexpr int LEN = GardnerLds<T>::LEN;
+    __shared__ T win[LEN];
+    __shared__ long long s_chunk, s_wbase;
+    __shared__ int s_done;
+    // persistent sampler state (thread 0 only)
+    T ns = 0, prev = 0, half = 0;
+    long long count = 0;
+    const long long C = P.chunk_out;
+    const long long n_chunks = (P.n_total + C - 1) / C;
+    if (threadIdx.x == 0) {
+        s_chunk = 0;
+        s_wbase = 0;
+        s_done = (n_chunks == 0);
+    }
+    __syncthreads();
+    while (!s_done) {
+        const long long c = s_chunk, wbase = s_wbase;
+        const long long base = c * C;
+        const long long n_cur = (P.n_total - base < C) ? (P.n_total - base) : C;
+        // stage [wbase, wbase+LEN) of the chunk, applying the past-the-end rule
+        for (int t = threadIdx.x; t < LEN; t += PDT_GARDNER_THREADS) {
+            const long long idx = wbase + t;
+            win[t] = (idx < n_cur) ? in[base + idx] : gardner_beyond(in, lock, P, c, n_cur, idx);
+        }
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            const long long wend = wbase + LEN;
+            const T nT = (T)n_cur;
+            bool chunk_finished = false;
+            while (true) {
+                const T rn = Real<T>::rint(ns);
+                if (!(rn < nT)) { chunk_finished = true; break; }
+                const long long i_cur = (long long)(unsigned)rn;
+                if (i_cur >= wend) break;                      // need the next window
+                const T cur = win[i_cur - wbase];
+                const long long i_half = (long long)(unsigned)Real<T>::rint(half);
+                T mid;
+                if (i_half >= wbase && i_half < wend)
+                    mid = win[i_half - wbase];
+                else
+                    mid = (i_half < n_cur) ? in[base + i_half] : gardner_beyond(in, lock, P, c, n_cur, i_half);
+                if (count < sym_cap) {
+                    sym[count] = cur;
+                    symidx[count] = base + i_cur;
+                }
+                T err = P.kp * (cur - prev) * mid;
+                if (err > P.lim)
+                    err = P.lim;
+                else if (err < -P.lim)
+                    err = -P.lim;
+                ns = ns - err;
+                half = (T)((double)ns + (double)P.step / 2.0);
+                ns = ns + P.step;
+                prev = cur;
+                count++;
+            }
+            if (chunk_finished) {
+                ns = ns - nT;                                  // roll over; `half` is deliberately not (Q3)
+                s_chunk = c + 1;
+                s_wbase = 0;
+                if (c + 1 >= n_chunks) s_done = 1;
+            } else {
+                long long nb = (long long)(unsigned)Real<T>::rint(ns) - 64;   // keep the mid-point sample in view
+                if (nb < 0) nb = 0;
+                s_wbase = nb;
+            }
+        }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) *nsym_out = (unsigned long long)count;
+}
+
+// ------------------------------------------------------------------------------------------
+// Manchester decision (reference: common/ManchesterDecode.c:10-100)
+//
+// With q_i = parity of the global symbol index i, pp = sym[i-2], p = sym[i-1], cur = sym[i]
+// (0 before the stream start) and R_i = sign(pp)==sign(p) && |pp|>thr && |p|>thr, the
+// reference's clockmod after symbol i is q_j for the last j <= i with R_j (initially 0),
+// and a bit is emitted at i iff q_i == clockmod_i.  That is a "last flagged position" scan
+// plus an ordered compaction: three passes over 4096-symbol tiles.
+// ------------------------------------------------------------------------------------------
+#define PDT_TILE 4096
+#define PDT_TILE_THREADS 256
+
+template <typename T> __device__ __forceinline__ int sgn(T x) { return (x > 0) - (x < 0); }
+
+template <typename T> __device__ __forceinline__ bool manch_resync(const T *sym, long long i, T thr)
+{
+    const T pp = (i >= 2) ? sym[i - 2] : (T)0;
+    const T p = (i >= 1) ? sym[i - 1] : (T)0;
+    return sgn(pp) == sgn(p) && Real<T>::abs(pp) > thr && Real<T>::abs(p) > thr;
+}
+
+struct ManchTile {
+    int last_r_parity;      // parity of the last resync position in the tile, -1 = none
+    unsigned first_r;       // tile-relative index of the first resync position, PDT_TILE = none
+    unsigned cnt_before[2]; // bits emitted before first_r when the incoming clockmod is 0 / 1
+    unsigned cnt_after;     // bits emitted from first_r on
+    unsigned clock_in;      // filled by the scan pass
+    unsigned long long out_base;
+};
+
+// block-wide inclusive max-scan of (position of last flagged symbol) in LDS
+template <typename T>
+__global__ void __launch_bounds__(PDT_TILE_THREADS) k_manch_tile(const T *__restrict__ sym,
+                                                                  const unsigned long long *__restrict__ nsym_p, T thr,
+                                                                  ManchTile *__restrict__ tiles)
+{
+    const long long nsym = (long long)*nsym_p;
+    const long long t0 = (long long)blockIdx.x * PDT_TILE;
+    if (t0 >= nsym) return;
+    __shared__ int s_last[PDT_TILE];     // tile-relative index of last R at or before i, -1 none
+    __shared__ unsigned s_first;
+    __shared__ unsigned s_cnt[3];
+    if (threadIdx.x == 0) { s_first = PDT_TILE; s_cnt[0] = s_cnt[1] = s_cnt[2] = 0; }
+    __syncthreads();
+    const int per = PDT_TILE / PDT_TILE_THREADS;            // 16 consecutive symbols per thread
+    const int lo = threadIdx.x * per;
+    int last = -1;
+    for (int u = 0; u < per; u++) {
+        const long long i = t0 + lo + u;
+        if (i < nsym && manch_resync(sym, i, thr)) last = lo + u;
+        s_last[lo + u] = last;
+    }
+    __syncthreads();
+    // propagate across threads: thread t needs the last R of all previous threads
+    __shared__ int s_tlast[PDT_TILE_THREADS];
+    s_tlast[threadIdx.x] = last;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        int run = -1;
+        for (int t = 0; t < PDT_TILE_THREADS; t++) {
+            const int v = s_tlast[t];
+            s_tlast[t] = run;            // exclusive prefix
+            if (v >= 0) run = v;
+        }
+    }
+    __syncthreads();
+    const int carry = s_tlast[threadIdx.x];
+    unsigned c_b0 = 0, c_b1 = 0, c_a = 0;
+    unsigned my_first = PDT_TILE;
+    for (int u = 0; u < per; u++) {
+        const long long i = t0 + lo + u;
+        if (i >= nsym) break;
+        int l = s_last[lo + u];
+        if (l < 0) l = carry;
+        const unsigned q = (unsigned)(i & 1);
+        if (l < 0) {                       // clockmod still the incoming one
+            c_b0 += (q == 0);
+            c_b1 += (q == 1);
+        } else {
+            if (my_first == PDT_TILE) my_first = (unsigned)l;
+            const unsigned cm = (unsigned)((t0 + l) & 1);
+            c_a += (q == cm);
+        }
+    }
+    atomicAdd(&s_cnt[0], c_b0);
+    atomicAdd(&s_cnt[1], c_b1);
+    atomicAdd(&s_cnt[2], c_a);
+    atomicMin(&s_first, my_first);
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        ManchTile mt;
+        const long long t1 = (t0 + PDT_TILE < nsym) ? t0 + PDT_TILE : nsym;
+        const int l_end = s_last[(int)(t1 - t0 - 1)] >= 0 ? s_last[(int)(t1 - t0 - 1)] : s_tlast[(int)((t1 - t0 - 1) / per)];
+        mt.last_r_parity = (l_end >= 0) ? (int)((t0 + l_end) & 1) : -1;
+        mt.first_r = s_first;
+        mt.cnt_before[0] = s_cnt[0];
+        mt.cnt_before[1] = s_cnt[1];
+        mt.cnt_after = s_cnt[2];
+        mt.clock_in = 0;
+        mt.out_base = 0;
+        tiles[blockIdx.x] = mt;
+    }
+}
+
+// sequential pass over the tile summaries (a few thousand entries)
+__global__ void k_manch_scan(ManchTile *__restrict__ tiles, const unsigned long long *__restrict__ nsym_p,
+                             unsigned long long *__restrict__ nbits_out)
+{
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    const long long nsym = (long long)*nsym_p;
+    const long long nt = (nsym + PDT_TILE - 1) / PDT_TILE;
+    unsigned clock = 0;
+    unsigned long long base = 0;
+    for (long long t = 0; t < nt; t++) {
+        ManchTile mt = tiles[t];
+        tiles[t].clock_in = clock;
+        tiles[t].out_base = base;
+        base += mt.cnt_before[clock] + mt.cnt_after;
+        if (mt.last_r_parity >= 0) clock = (unsigned)mt.last_r_parity;
+    }
+    *nbits_out = base;
+}
+
+template <typename T>
+__global__ void __launch_bounds__(PDT_TILE_THREADS) k_manch_emit(const T *__restrict__ sym,
+                                                                  const unsigned long long *__restrict__ nsym_p, T thr,
+                                                                  const ManchTile *__restrict__ tiles,
+                                                                  unsigned char *__restrict__ bits,
+                                                                  unsigned *__restrict__ bitsym, long long bit_cap)
+{
+    const long long nsym = (long long)*nsym_p;
+    const long long t0 = (long long)blockIdx.x * PDT_TILE;
+    if (t0 >= nsym) return;
+    const ManchTile mt = tiles[blockIdx.x];
+    __shared__ int s_tlast[PDT_TILE_THREADS];
+    __shared__ unsigned s_tcnt[PDT_TILE_THREADS];
+    const int per = PDT_TILE / PDT_TILE_THREADS;
+    const int lo = threadIdx.x * per;
+    // pass 1: per-thread last-R and (given the carry) emitted count -- two sweeps over 16 symbols
+    int last = -1;
+    for (int u = 0; u < per; u++) {
+        const long long i = t0 + lo + u;
+        if (i < nsym && manch_resync(sym, i, thr)) last = lo + u;
+    }
+    s_tlast[threadIdx.x] = last;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        int run = -1;
+        for (int t = 0; t < PDT_TILE_THREADS; t++) {
+            const int v = s_tlast[t];
+            s_tlast[t] = run;
+            if (v >= 0) run = v;
+        }
+    }
+    __syncthreads();
+    const int carry = s_tlast[threadIdx.x];
+    unsigned clock = (carry >= 0) ? (unsigned)((t0 + carry) & 1) : mt.clock_in;
+    unsigned emit_mask = 0;
+    unsigned my_cnt = 0;
+    for (int u = 0; u < per; u++) {
+        const long long i = t0 + lo + u;
+        if (i >= nsym) break;
+        const unsigned q = (unsigned)(i & 1);
+        if (manch_resync(sym, i, thr)) clock = q;
+        if (q == clock) { emit_mask |= 1u << u; my_cnt++; }
+    }
+    s_tcnt[threadIdx.x] = my_cnt;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        unsigned run = 0;
+        for (int t = 0; t < PDT_TILE_THREADS; t++) {
+            const unsigned v = s_tcnt[t];
+            s_tcnt[t] = run;
+            run += v;
+        }
+    }
+    __syncthreads();
+    unsigned long long o = mt.out_base + s_tcnt[threadIdx.x];
+    for (int u = 0; u < per; u++) {
+        if (!(emit_mask & (1u << u))) continue;
+        const long long i = t0 + lo + u;
+        const T p = (i >= 1) ? sym[i - 1] : (T)0;
+        const T cur = sym[i];
+        unsigned char bit;
+        if (Real<T>::abs(p) > Real<T>::abs(cur))
+            bit = (p > 0) ? '1' : '0';
+        else
+            bit = (cur > 0) ? '0' : '1';
+        if ((long long)o < bit_cap) {
+            bits[o] = bit;
+            bitsym[o] = (unsigned)i;
+        }
+        o++;
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// Sync-word search + frame extraction
+// (reference: POESTIPdemod/ByteSync.c:16-150, ARGOSdemod/ByteSync.c:17-150)
+//
+// Pass 1 marks every bit position whose trailing `len` bits equal the sync word or
+// (POES) its complement; history before the first bit is '0' (ByteSync.c:39).
+// Pass 2 (one lane, hits are ~1 per 832 bits) applies the "not already inside a frame"
+// rule: a frame opened at bit p absorbs `span` following bits, and a new frame may open
+// at p + span at the earliest (the in-frame flag is cleared before the sync test of that
+// same bit, ByteSync.c:63-67,93).  Pass 3 packs each frame's bytes in parallel.
+// ------------------------------------------------------------------------------------------
+struct SyncParams {
+    unsigned long long pattern;    // sync word, first bit = MSB of the low `len` bits
+    unsigned len;
+    unsigned allow_inverse;
+    unsigned span;                 // bits after the sync bit until the frame closes: 813 POES, 56 ARGOS
+    unsigned first_bits;           // bits of the first (partial) byte: 5 POES (bitIdx starts at 3), 8 ARGOS
+    unsigned nbytes;               // payload bytes shifted in: 102 POES, 7 ARGOS
+    unsigned prefix;               // literal bytes printed first: 2 POES (ED E2), 0 ARGOS
+};
+
+__global__ void __launch_bounds__(256) k_sync_hits(const unsigned char *__restrict__ bits,
+                                                    const unsigned long long *__restrict__ nbits_p, SyncParams P,
+                                                    unsigned *__restrict__ hits, unsigned *__restrict__ nhits,
+                                                    unsigned hit_cap)
+{
+    const long long nbits = (long long)*nbits_p;
+    const long long b = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= nbits) return;
+    unsigned long long w = 0;
+    for (unsigned k = 0; k < P.len; k++) {
+        const long long idx = b - (long long)(P.len - 1) + k;
+        const unsigned v = (idx >= 0) ? (unsigned)(bits[idx] != '0') : 0u;
+        w = (w << 1) | v;
+    }
+    const unsigned long long mask = (P.len >= 64) ? ~0ull : ((1ull << P.len) - 1ull);
+    unsigned kind = 0;
+    if (w == P.pattern)
+        kind = 1;
+    else if (P.allow_inverse && w == (~P.pattern & mask))
+        kind = 2;
+    if (kind) {
+        const unsigned slot = atomicAdd(nhits, 1u);
+        if (slot < hit_cap) hits[slot] = ((unsigned)b << 1) | (kind - 1);   // bit index < 2^31
+    }
+}
+
+struct FrameRec {
+    long long bit_index;
+    long long time_src;
+    unsigned char inverted, nbytes, complete, pad;
+    unsigned char bytes[104];
+};
+
+// single workgroup: sort the (sparse, unordered) hit list, then walk it sequentially
+__global__ void __launch_bounds__(256) k_sync_frames(unsigned *__restrict__ hits, const unsigned *__restrict__ nhits_p,
+                                                      unsigned hit_cap, SyncParams P, FrameRec *__restrict__ frames,
+                                                      unsigned *__restrict__ nframes, unsigned frame_cap)
+{
+    unsigned nh = *nhits_p;
+    if (nh > hit_cap) nh = hit_cap;
+    // odd-even transposition would be O(n^2); hits arrive nearly sorted (atomic order follows
+    // block order closely), so use a parallel rank sort in chunks: each thread ranks its
+    // elements by counting smaller ones in a window, falling back to a full count.
+    // For simplicity and determinism: bitonic sort in global memory over the next power of two.
+    unsigned np2 = 1;
+    while (np2 < nh) np2 <<= 1;
+    for (unsigned i = nh + threadIdx.x; i < np2 && i < hit_cap; i += blockDim.x) hits[i] = 0xffffffffu;
+    __syncthreads();
+    if (np2 <= hit_cap) {
+        for (unsigned k = 2; k <= np2; k <<= 1) {
+            for (unsigned j = k >> 1; j > 0; j >>= 1) {
+                for (unsigned i = threadIdx.x; i < np2; i += blockDim.x) {
+                    const unsigned ixj = i ^ j;
+                    if (ixj > i) {
+                        const unsigned a = hits[i], b = hits[ixj];
+                        const bool up = ((i & k) == 0);
+                        if ((a > b) == up) { hits[i] = b; hits[ixj] = a; }
+                    }
+                }
+                __threadfence_block();
+                __syncthreads();
+            }
+        }
+    }
+    if (threadIdx.x == 0) {
+        unsigned nf = 0;
+        long long next_free = 0;
+        for (unsigned h = 0; h < nh; h++) {
+            const unsigned v = hits[h];
+            const long long pos = (long long)(v >> 1);
+            if (pos < next_free) continue;
+            if (nf < frame_cap) {
+                frames[nf].bit_index = pos;
+                frames[nf].inverted = (unsigned char)(v & 1u);
+            }
+            nf++;
+            next_free = pos + P.span;
+        }
+        *nframes = nf;
+    }
+}
+
+__global__ void __launch_bounds__(128) k_frame_pack(const unsigned char *__restrict__ bits,
+                                                     const unsigned long long *__restrict__ nbits_p,
+                                                     const unsigned *__restrict__ bitsym,
+                                                     const long long *__restrict__ symidx, SyncParams P,
+                                                     FrameRec *__restrict__ frames, const unsigned *__restrict__ nframes_p,
+                                                     unsigned frame_cap)
+{
+    unsigned nf = *nframes_p;
+    if (nf > frame_cap) nf = frame_cap;
+    const unsigned f = blockIdx.x;
+    if (f >= nf) return;
+    const long long nbits = (long long)*nbits_p;
+    const long long pos = frames[f].bit_index;
+    const unsigned inv = frames[f].inverted;
+    const unsigned t = threadIdx.x;
+    if (t < P.nbytes) {
+        // payload byte t: its bits start at pos + 1 + (t ? first_bits + 8*(t-1) : 0)
+        const unsigned width = t ? 8u : P.first_bits;
+        const long long b0 = pos + 1 + (t ? (long long)P.first_bits + 8ll * (t - 1) : 0ll);
+        if (b0 + width <= nbits) {
+            unsigned v = 0;
+            for (unsigned k = 0; k < width; k++) {
+                unsigned bit = (unsigned)(bits[b0 + k] != '0');
+                if (inv) bit ^= 1u;
+                v = (v << 1) | bit;
+            }
+            frames[f].bytes[P.prefix + t] = (unsigned char)v;
+        }
+    }
+    if (t == 0) {
+        if (P.prefix == 2) {
+            frames[f].bytes[0] = 0xED;
+            frames[f].bytes[1] = 0xE2;
+        }
+        // bytes completed before the stream ended
+        const long long avail = nbits - (pos + 1);
+        unsigned done = 0;
+        if (avail >= (long long)P.first_bits) done = 1 + (unsigned)((avail - P.first_bits) / 8);
+        if (done > P.nbytes) done = P.nbytes;
+        frames[f].nbytes = (unsigned char)(P.prefix + done);
+        frames[f].complete = (unsigned char)(done == P.nbytes);
+        frames[f].pad = 0;
+        frames[f].time_src = symidx[bitsym[pos]];
+    }
+}
+
+}  // namespace pdt
