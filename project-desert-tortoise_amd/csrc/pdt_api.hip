@@ -79,7 +79,7 @@ struct pdt_ctx {
     bool own_stream = false;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
 
-    DevBuf pcm, pll, lock, fir, agc, sym, symidx, bits, bitsym, hits, frames, taps, mag, seams_pll, seams_agc, scal, lockinfo;
+    DevBuf pcm, pll, lock, fir, agc, sym, symidx, bits, bitsym, hits, frames, taps, mag, seams_pll, seams_agc, scal, lockinfo, term, seams_ema;
     const void *pcm_dev = nullptr;     // input actually used (own copy or caller's buffer)
 
     std::vector<unsigned char> taps_host;
@@ -221,22 +221,23 @@ template <typename T> int run_capture(pdt_ctx *ctx, uint64_t n)
         SP.len = 19; SP.allow_inverse = 1; SP.span = 813; SP.first_bits = 5; SP.nbytes = 102; SP.prefix = 2;
     }
 
-    // ---- block-parallel geometry
-    long long Bp = ctx->cfg.pll_block ? ctx->cfg.pll_block : (long long)(0.4 * ctx->cfg.sample_rate);
-    long long Wp = ctx->cfg.pll_warm ? ctx->cfg.pll_warm : (long long)(0.4 * ctx->cfg.sample_rate);
-    if (argos) {   // the lock-detector EMA (alpha 6e-4 at 32 ksps, 53-bit state) needs seconds to re-converge
-        if (!ctx->cfg.pll_block) Bp = (long long)(4.0 * ctx->cfg.sample_rate);
-        if (!ctx->cfg.pll_warm) Wp = (long long)(8.0 * ctx->cfg.sample_rate);
-    }
-    long long Ba = ctx->cfg.agc_block ? ctx->cfg.agc_block : (long long)(0.5 * ctx->cfg.sample_rate * interp);
-    long long Wa = ctx->cfg.agc_warm ? ctx->cfg.agc_warm : (long long)(1.0 * ctx->cfg.sample_rate * interp);
-    if (argos) {
-        if (!ctx->cfg.agc_block) Ba = (long long)(4.0 * ctx->cfg.sample_rate);
-        if (!ctx->cfg.agc_warm) Wa = (long long)(8.0 * ctx->cfg.sample_rate);
-    }
-    if (Bp < 64) Bp = 64;
-    if (Ba < 64) Ba = 64;
-    const long long nb_pll = (N + Bp - 1) / Bp + 1;
+    // ---- block-parallel geometry (any values give the same output; they only move time around)
+    const double fs_d = (double)ctx->cfg.sample_rate;
+    auto round4 = [](long long v) { return (v + 3) / 4 * 4; };
+    long long Bp = ctx->cfg.pll_block ? ctx->cfg.pll_block : (long long)((argos ? 4.0 : 0.2) * fs_d);
+    long long Wp = ctx->cfg.pll_warm ? ctx->cfg.pll_warm : (long long)((argos ? 8.0 : 0.3) * fs_d);
+    long long Wacq = (long long)(0.02 * fs_d);             // acquisition-gain stage of the warm-up
+    long long Ba = ctx->cfg.agc_block ? ctx->cfg.agc_block : (long long)((argos ? 4.0 : 0.5) * fs_d * interp);
+    long long Wa = ctx->cfg.agc_warm ? ctx->cfg.agc_warm : (long long)((argos ? 8.0 : 1.0) * fs_d * interp);
+    Bp = std::max<long long>(64, round4(Bp));
+    Ba = std::max<long long>(64, round4(Ba));
+    Wp = round4(Wp);
+    Wa = round4(Wa);
+    Wacq = round4(Wacq);
+    int lag = (int)(fs_d / 10000.0);                        // pi/lag must exceed the PLL's frequency limit
+    lag = std::max(1, std::min(32, lag));
+    if (argos) lag = std::max(1, std::min(32, (int)(fs_d / 1200.0)));
+    const long long nb_pll = N / Bp + 2;
     const long long nb_agc = (n_out + Ba - 1) / Ba + 1;
 
     // ---- capacities
@@ -263,6 +264,8 @@ template <typename T> int run_capture(pdt_ctx *ctx, uint64_t n)
     if ((rc = ctx->mag.ensure((size_t)(n0 + 1) * sizeof(T)))) return rc;
     if ((rc = ctx->seams_pll.ensure((size_t)nb_pll * sizeof(PllSeam<T>)))) return rc;
     if ((rc = ctx->seams_agc.ensure((size_t)nb_agc * sizeof(AgcSeam<T>)))) return rc;
+    if (argos && (rc = ctx->term.ensure((size_t)(N + 1) * sizeof(T)))) return rc;
+    if (argos && (rc = ctx->seams_ema.ensure((size_t)nb_pll * sizeof(EmaSeam<T>)))) return rc;
     if ((rc = ctx->scal.ensure(sizeof(DevScalars)))) return rc;
     if ((rc = ctx->lockinfo.ensure(sizeof(PllLockInfo<T>)))) return rc;
 
@@ -293,28 +296,44 @@ template <typename T> int run_capture(pdt_ctx *ctx, uint64_t n)
                        ctx->cfg.norm_override, d_norm);
     L.end();
 
-    // ---- PLL: sequential acquisition, block-parallel tracking, seam repair
+    // ---- PLL: sequential acquisition, then theta / block-parallel phase recurrence / seam repair / mix.
+    // theta and phase live in the (not yet used) FIR and AGC buffers.
+    T *d_theta = d_fir;
+    T *d_phi = d_agc;
+    if (N > 0) {
+        L.begin("pll_theta");
+        hipLaunchKernelGGL(k_pll_theta<T>, dim3((unsigned)((N + 255) / 256)), dim3(256), 0, st, d_pcm, N, d_theta);
+        L.end();
+    }
     L.begin("pll_acquire");
     hipLaunchKernelGGL(k_pll_acquire<T>, dim3(1), dim3(64), 0, st, d_pcm, N, PP, d_pll, d_lock, d_info);
     L.end();
-    {
+    if (N > 0) {
         const long long grid = (nb_pll + 63) / 64;
-        L.begin("pll_track");
-        if (argos)
-            hipLaunchKernelGGL((k_pll_track<T, true>), dim3((unsigned)grid), dim3(64), 0, st, d_pcm, N, PP, d_info, Bp, Wp,
-                               d_pll, d_lock, (PllSeam<T> *)ctx->seams_pll.p, nb_pll);
-        else
-            hipLaunchKernelGGL((k_pll_track<T, false>), dim3((unsigned)grid), dim3(64), 0, st, d_pcm, N, PP, d_info, Bp, Wp,
-                               d_pll, d_lock, (PllSeam<T> *)ctx->seams_pll.p, nb_pll);
+        L.begin("pll_phase");
+        hipLaunchKernelGGL(k_pll_phase<T>, dim3((unsigned)grid), dim3(64), 0, st, d_pcm, d_theta, N, PP, d_info, Bp, Wacq, Wp,
+                           lag, d_phi, (PllSeam<T> *)ctx->seams_pll.p);
         L.end();
         L.begin("pll_fix");
-        if (argos)
-            hipLaunchKernelGGL((k_pll_fix<T, true>), dim3(1), dim3(64), 0, st, d_pcm, N, PP, d_info, Bp, d_pll, d_lock,
-                               (PllSeam<T> *)ctx->seams_pll.p, nb_pll, d_sc->counters);
-        else
-            hipLaunchKernelGGL((k_pll_fix<T, false>), dim3(1), dim3(64), 0, st, d_pcm, N, PP, d_info, Bp, d_pll, d_lock,
-                               (PllSeam<T> *)ctx->seams_pll.p, nb_pll, d_sc->counters);
+        hipLaunchKernelGGL(k_pll_fix<T>, dim3(1), dim3(64), 0, st, d_theta, N, PP, d_info, Bp, d_phi,
+                           (PllSeam<T> *)ctx->seams_pll.p, d_sc->counters);
         L.end();
+        L.begin("pll_mix");
+        if (argos)
+            hipLaunchKernelGGL((k_pll_mix<T, true>), dim3((unsigned)((N + 255) / 256)), dim3(256), 0, st, d_pcm, d_phi, N, PP,
+                               d_info, d_pll, (T *)ctx->term.p);
+        else
+            hipLaunchKernelGGL((k_pll_mix<T, false>), dim3((unsigned)((N + 255) / 256)), dim3(256), 0, st, d_pcm, d_phi, N, PP,
+                               d_info, d_pll, (T *)nullptr);
+        L.end();
+        if (argos) {
+            L.begin("lock_ema");
+            hipLaunchKernelGGL(k_lock_ema<T>, dim3((unsigned)grid), dim3(64), 0, st, (const T *)ctx->term.p, N, PP.lock_alpha,
+                               d_info, Bp, Wp, d_lock, (EmaSeam<T> *)ctx->seams_ema.p);
+            hipLaunchKernelGGL(k_lock_ema_fix<T>, dim3(1), dim3(64), 0, st, (const T *)ctx->term.p, N, PP.lock_alpha, d_info,
+                               Bp, d_lock, (EmaSeam<T> *)ctx->seams_ema.p, &d_sc->counters[1]);
+            L.end();
+        }
     }
 
     // ---- FIR
@@ -606,7 +625,8 @@ void pdt_close(pdt_ctx *ctx)
     if (!ctx) return;
     (void)hipSetDevice(ctx->cfg.device);
     DevBuf *bufs[] = { &ctx->pcm, &ctx->pll, &ctx->lock, &ctx->fir, &ctx->agc, &ctx->sym, &ctx->symidx, &ctx->bits, &ctx->bitsym,
-                       &ctx->hits, &ctx->frames, &ctx->taps, &ctx->mag, &ctx->seams_pll, &ctx->seams_agc, &ctx->scal, &ctx->lockinfo };
+                       &ctx->hits, &ctx->frames, &ctx->taps, &ctx->mag, &ctx->seams_pll, &ctx->seams_agc, &ctx->scal, &ctx->lockinfo,
+                       &ctx->term, &ctx->seams_ema };
     for (DevBuf *b : bufs) b->release();
     if (ctx->ev0) (void)hipEventDestroy(ctx->ev0);
     if (ctx->ev1) (void)hipEventDestroy(ctx->ev1);

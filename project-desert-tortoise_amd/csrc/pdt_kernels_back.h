@@ -48,12 +48,28 @@ __device__ __forceinline__ T gardner_beyond(const T *__restrict__ in, const T *_
     return (T)0;
 }
 
+// LDS budget (160 KiB per CU): input window + symbol staging buffers.
 template <typename T> struct GardnerLds;
-template <> struct GardnerLds<float> { static constexpr int LEN = 38912; };    // 152 KiB of the 160 KiB LDS
-template <> struct GardnerLds<double> { static constexpr int LEN = 19456; };
+template <> struct GardnerLds<float> { static constexpr int LEN = 31232; static constexpr int OUT = 4096; };   // 122 + 32 KiB
+template <> struct GardnerLds<double> { static constexpr int LEN = 14336; static constexpr int OUT = 3072; };  // 112 + 36 KiB
 
-#define PDT_GARDNER_THREADS 256
+#define PDT_GARDNER_THREADS 64
 
+template <typename T> __device__ __forceinline__ T uniform(T v);
+template <> __device__ __forceinline__ int uniform<int>(int v) { return __builtin_amdgcn_readfirstlane(v); }
+template <> __device__ __forceinline__ unsigned uniform<unsigned>(unsigned v)
+{
+    return (unsigned)__builtin_amdgcn_readfirstlane((int)v);
+}
+
+// One workgroup of ONE wavefront.  All 64 lanes carry the same sampler state and execute
+// the same instructions (LDS reads of one address broadcast), so every branch is
+// wave-uniform and is made scalar with readfirstlane: no exec-mask bookkeeping in the
+// symbol loop.  The lanes differ only when they stage a window or flush symbols.
+//
+// Symbol loop = [one fully checked step] + [a counted batch of check-free steps].  The
+// batch length is the number of steps that provably stay inside the chunk, the LDS window
+// and the staging buffer: a step advances the sampling instant by at most step + 0.1.
 template <typename T>
 __global__ void __launch_bounds__(PDT_GARDNER_THREADS) k_gardner(const T *__restrict__ in, const T *__restrict__ lock,
                                                                   GardnerParams<T> P, T *__restrict__ sym,
@@ -62,75 +78,120 @@ __global__ void __launch_bounds__(PDT_GARDNER_THREADS) k_gardner(const T *__rest
                                                                   long long sym_cap)
 {
     constexpr int LEN = GardnerLds<T>::LEN;
+    constexpr int OUT = GardnerLds<T>::OUT;
     __shared__ T win[LEN];
-    __shared__ long long s_chunk, s_wbase;
-    __shared__ int s_done;
-    // persistent sampler state (thread 0 only)
-    T ns = 0, prev = 0, half = 0;
-    long long count = 0;
+    __shared__ T o_val[OUT];
+    __shared__ unsigned o_idx[OUT];
+    const int lane = threadIdx.x;
+    T ns = 0, prev = 0, half = 0;                 // identical in every lane
+    const T hs = (T)((double)P.step / 2.0);       // exact: step/2 is representable
+    const T kp = P.kp, lim = P.lim, step = P.step;
+    const T adv = step + (T)0.101;                // upper bound of one step's advance
     const long long C = P.chunk_out;
     const long long n_chunks = (P.n_total + C - 1) / C;
-    if (threadIdx.x == 0) {
-        s_chunk = 0;
-        s_wbase = 0;
-        s_done = (n_chunks == 0);
-    }
-    __syncthreads();
-    while (!s_done) {
-        const long long c = s_chunk, wbase = s_wbase;
+    long long count = 0;
+    for (long long c = 0; c < n_chunks; c++) {
         const long long base = c * C;
-        const long long n_cur = (P.n_total - base < C) ? (P.n_total - base) : C;
-        // stage [wbase, wbase+LEN) of the chunk, applying the past-the-end rule
-        for (int t = threadIdx.x; t < LEN; t += PDT_GARDNER_THREADS) {
-            const long long idx = wbase + t;
-            win[t] = (idx < n_cur) ? in[base + idx] : gardner_beyond(in, lock, P, c, n_cur, idx);
-        }
-        __syncthreads();
-        if (threadIdx.x == 0) {
-            const long long wend = wbase + LEN;
-            const T nT = (T)n_cur;
-            bool chunk_finished = false;
-            while (true) {
-                const T rn = Real<T>::rint(ns);
-                if (!(rn < nT)) { chunk_finished = true; break; }
-                const long long i_cur = (long long)(unsigned)rn;
-                if (i_cur >= wend) break;                      // need the next window
-                const T cur = win[i_cur - wbase];
-                const long long i_half = (long long)(unsigned)Real<T>::rint(half);
-                T mid;
-                if (i_half >= wbase && i_half < wend)
-                    mid = win[i_half - wbase];
-                else
-                    mid = (i_half < n_cur) ? in[base + i_half] : gardner_beyond(in, lock, P, c, n_cur, i_half);
-                if (count < sym_cap) {
-                    sym[count] = cur;
-                    symidx[count] = base + i_cur;
+        const unsigned n_cur = (unsigned)((P.n_total - base < C) ? (P.n_total - base) : C);
+        const T nT = (T)n_cur;
+        unsigned wbase = 0;
+        bool chunk_done = false;
+        while (!chunk_done) {
+            // ---- stage the part of [wbase, wbase+LEN) the sampler can touch: chunk data with 8
+            // independent loads in flight per lane, then the few past-the-end values (Q3/Q16)
+            __syncthreads();
+            int n_staged;
+            {
+                const unsigned avail = (n_cur > wbase) ? n_cur - wbase : 0u;
+                const int n_data = (int)((avail < (unsigned)LEN) ? avail : (unsigned)LEN);
+                const T *src = in + base + wbase;
+                int t = lane;
+                for (; t + 7 * PDT_GARDNER_THREADS < n_data; t += 8 * PDT_GARDNER_THREADS) {
+                    T r[8];
+#pragma unroll
+                    for (int u = 0; u < 8; u++) r[u] = src[t + u * PDT_GARDNER_THREADS];
+#pragma unroll
+                    for (int u = 0; u < 8; u++) win[t + u * PDT_GARDNER_THREADS] = r[u];
                 }
-                T err = P.kp * (cur - prev) * mid;
-                if (err > P.lim)
-                    err = P.lim;
-                else if (err < -P.lim)
-                    err = -P.lim;
-                ns = ns - err;
-                half = (T)((double)ns + (double)P.step / 2.0);
-                ns = ns + P.step;
-                prev = cur;
-                count++;
+                for (; t < n_data; t += PDT_GARDNER_THREADS) win[t] = src[t];
+                int n_tail = n_data + 2 * (int)step + 24;          // furthest look-ahead of the mid-point / prefetch
+                if (n_tail > LEN) n_tail = LEN;
+                for (int q = n_data + lane; q < n_tail; q += PDT_GARDNER_THREADS)
+                    win[q] = gardner_beyond(in, lock, P, c, (long long)n_cur, (long long)(wbase + (unsigned)q));
+                n_staged = n_tail;
             }
-            if (chunk_finished) {
-                ns = ns - nT;                                  // roll over; `half` is deliberately not (Q3)
-                s_chunk = c + 1;
-                s_wbase = 0;
-                if (c + 1 >= n_chunks) s_done = 1;
-            } else {
-                long long nb = (long long)(unsigned)Real<T>::rint(ns) - 64;   // keep the mid-point sample in view
-                if (nb < 0) nb = 0;
-                s_wbase = nb;
+            __syncthreads();
+            const unsigned wend = wbase + (unsigned)LEN;
+            const unsigned lim_idx = (n_cur < wend) ? n_cur : wend;   // first index the batch must not reach
+            int nout = 0;
+            bool window_done = false;
+            while (!window_done) {
+                // ---- checked step
+                const T rn = Real<T>::rint(ns);
+                const int in_chunk = uniform<int>((int)(rn < nT));
+                if (!in_chunk) { chunk_done = true; break; }
+                const unsigned i_abs = uniform<unsigned>((unsigned)rn);
+                if (i_abs - wbase >= (unsigned)LEN || nout >= OUT) break;          // new window / flush
+                const unsigned h_abs = uniform<unsigned>((unsigned)Real<T>::rint(half));
+                const T cur = win[i_abs - wbase];
+                T mid;
+                if (h_abs - wbase < (unsigned)n_staged)
+                    mid = win[h_abs - wbase];
+                else
+                    mid = (h_abs < n_cur) ? in[base + h_abs] : gardner_beyond(in, lock, P, c, (long long)n_cur, (long long)h_abs);
+                o_val[nout] = cur;
+                o_idx[nout] = i_abs;
+                nout++;
+                {
+                    T err = kp * (cur - prev) * mid;
+                    err = (err > lim) ? lim : ((err < -lim) ? -lim : err);
+                    ns = ns - err;
+                    half = ns + hs;   // == (T)((double)ns + (double)step/2.0): that double sum is exact
+                    ns = ns + step;
+                    prev = cur;
+                }
+                // ---- check-free batch
+                const T room = (T)lim_idx - (T)2 - ns;
+                int K = (room > (T)0) ? (int)(room / adv) : 0;
+                K = uniform<int>(K);
+                if (K > OUT - nout) K = OUT - nout;
+                const T wb = (T)wbase;
+                T *ov = o_val + nout;
+                unsigned *oi = o_idx + nout;
+                for (int k = 0; k < K; k++) {
+                    const T rnk = Real<T>::rint(ns);
+                    const T rhk = Real<T>::rint(half);
+                    const T c_k = win[(int)(rnk - wb)];
+                    const T m_k = win[(int)(rhk - wb)];
+                    ov[k] = c_k;
+                    oi[k] = (unsigned)rnk;
+                    T err = kp * (c_k - prev) * m_k;
+                    err = (err > lim) ? lim : ((err < -lim) ? -lim : err);
+                    ns = ns - err;
+                    half = ns + hs;
+                    ns = ns + step;
+                    prev = c_k;
+                }
+                nout += K;
+            }
+            // ---- flush staged symbols with coalesced stores
+            __syncthreads();
+            for (int t = lane; t < nout; t += PDT_GARDNER_THREADS) {
+                const long long k = count + t;
+                if (k < sym_cap) {
+                    sym[k] = o_val[t];
+                    symidx[k] = base + (long long)o_idx[t];
+                }
+            }
+            count += nout;
+            if (!chunk_done) {
+                const unsigned cur_i = uniform<unsigned>((unsigned)Real<T>::rint(ns));
+                if (cur_i - wbase >= (unsigned)LEN) wbase = (cur_i > 64u) ? cur_i - 64u : 0u;   // keep the mid-point in view
             }
         }
-        __syncthreads();
+        ns = ns - nT;                              // roll over; `half` is deliberately not (Q3)
     }
-    if (threadIdx.x == 0) *nsym_out = (unsigned long long)count;
+    if (lane == 0) *nsym_out = (unsigned long long)count;
 }
 
 // ------------------------------------------------------------------------------------------

@@ -1,0 +1,84 @@
+"""The C-ABI library: builds, loads, exports every symbol include/pdt.h declares, and fails
+loudly when no GPU is present (no compute calls here)."""
+import ctypes as C
+import os
+import re
+import subprocess
+
+import numpy as np
+import pytest
+
+from conftest import GOLDEN, ROOT
+
+
+def header_functions():
+    src = open(os.path.join(ROOT, "include", "pdt.h")).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    return sorted(set(re.findall(r"\b(pdt_[a-z0-9_]+)\s*\(", src)))
+
+
+def test_library_is_built(pdt):
+    assert os.path.exists(pdt.LIBPDT_PATH), "run `make` (hipcc cross-compiles gfx950 without a GPU)"
+
+
+def test_exports_every_declared_symbol(pdt):
+    names = header_functions()
+    assert len(names) >= 15
+    L = C.CDLL(pdt.LIBPDT_PATH)
+    for n in names:
+        assert hasattr(L, n), f"{n} declared in include/pdt.h but not exported by libpdt.so"
+    assert set(pdt.ABI_SYMBOLS) == set(names)
+
+
+def test_library_contains_gfx950_code_object(pdt):
+    out = subprocess.run(["strings", "-a", pdt.LIBPDT_PATH], capture_output=True, text=True).stdout
+    assert "gfx950" in out
+    assert "k_gardner" in out and "k_pll_phase" in out and "k_fir_interp" in out
+
+
+def test_struct_layouts_match_header(pdt):
+    assert C.sizeof(pdt.Frame) == 136
+    assert C.sizeof(pdt.Config) == 48
+    assert pdt.FRAME_DTYPE.itemsize == 136
+
+
+def test_no_gpu_fails_loudly(pdt, gpu_available):
+    if gpu_available:
+        pytest.skip("a GPU is present")
+    with pytest.raises(pdt.PdtError, match="no usable HIP device"):
+        pdt.Demodulator(pdt.MODE_POES, 50000)
+
+
+def test_host_helpers_need_no_gpu(pdt, golden):
+    for fs in golden["params"]["poes_rates"]:
+        taps, interp = pdt.make_lpf(pdt.MODE_POES, fs)
+        ref = np.fromfile(os.path.join(GOLDEN, f"taps_poes_{fs}.f32"), dtype=np.float32)
+        assert interp == round(150000 / fs) and len(taps) == 26 * interp
+        assert taps.tobytes() == ref.tobytes(), f"MakeLPFIR taps differ from the reference's at {fs} Hz"
+    taps, interp = pdt.make_lpf(pdt.MODE_ARGOS, 32000)
+    assert interp == 1
+    assert taps.tobytes() == np.fromfile(os.path.join(GOLDEN, "taps_argos_32000.f64"), dtype=np.float64).tobytes()
+    with pytest.raises(pdt.PdtError, match="interpolation factor"):
+        pdt.make_lpf(pdt.MODE_POES, 400000)          # rint(150000/Fs) == 0 (reference divides by zero)
+
+
+def test_wav_header_parse(pdt):
+    L = pdt.lib()
+    hdr = open(os.path.join(GOLDEN, "5sec_clip.wav"), "rb").read(44)
+    vals = [C.c_uint32() for _ in range(5)]
+    assert L.pdt_wav_parse_header(hdr, *[C.byref(v) for v in vals]) == 0
+    rate, ch, bits, fmt, data = [v.value for v in vals]
+    assert (rate, ch, bits, fmt, data) == (50000, 2, 16, 1, 250195 * 4)
+
+
+def test_cli_binaries_fail_without_gpu(gpu_available):
+    exe = os.path.join(ROOT, "bin", "demodPOES")
+    if not os.path.exists(exe):
+        pytest.skip("bin/demodPOES not built")
+    r = subprocess.run([exe], capture_output=True, text=True)
+    assert r.returncode == 1 and "No wave file specified" in r.stdout
+    if not gpu_available:
+        r = subprocess.run([exe, "-o", "/tmp/pdt_cli_test.txt", os.path.join(GOLDEN, "5sec_clip.wav")], capture_output=True,
+                           text=True)
+        assert r.returncode == 1 and "GPU demodulator unavailable" in r.stdout
+        assert not os.path.exists("/tmp/pdt_cli_test.txt")

@@ -1,0 +1,195 @@
+"""Parity of the HIP path (through the C ABI) with the oracle -- the tests proper.
+
+Bit-exact at every stage: PLL output, FIR output, AGC output (float32 bit patterns), Gardner
+symbols and their sample indices, Manchester bits, frame bytes, and the output-file text
+including the %.5f time stamps.
+"""
+import hashlib
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+from conftest import GOLDEN, ROOT, golden_text
+
+pytestmark = pytest.mark.gpu
+
+
+def assert_stage_equal(name, g, o):
+    assert len(g) == len(o), f"{name}: length {len(g)} vs {len(o)}"
+    if g.tobytes() != o.tobytes():
+        gv = g.view(np.uint8).reshape(len(g), -1)
+        ov = o.view(np.uint8).reshape(len(o), -1)
+        first = int(np.flatnonzero((gv != ov).any(axis=1))[0])
+        raise AssertionError(f"{name}: first difference at {first}: gpu {g[first:first+3]} oracle {o[first:first+3]}")
+
+
+def check_all_stages(pdt, orc, d, o):
+    assert_stage_equal("pll", d.stage(pdt.ST_PLL), o.stage(orc.ST_PLL))
+    assert_stage_equal("fir", d.stage(pdt.ST_FIR), o.stage(orc.ST_FIR))
+    assert_stage_equal("agc", d.stage(pdt.ST_AGC), o.stage(orc.ST_AGC))
+    assert_stage_equal("sym", d.stage(pdt.ST_SYM), o.stage(orc.ST_SYM))
+    assert_stage_equal("symidx", d.stage(pdt.ST_SYMIDX), o.stage(orc.ST_SYMIDX))
+    assert_stage_equal("bits", d.stage(pdt.ST_BITS), o.stage(orc.ST_BITS))
+    assert d.text() == o.text()
+    s = d.stats()
+    ns, nsym, nbits, nfr = o.totals()
+    assert (s.samples, s.symbols, s.bits, s.frames) == (ns, nsym, nbits, nfr)
+    assert s.lock_sample == o.lock_sample
+    if o.lock_sample >= 0:
+        assert f"{s.lock_freq_hz:0.2f}" == f"{o.lock_freq_hz:0.2f}"
+    assert np.float32(s.norm_factor) == np.float32(o.norm_factor)
+
+
+@pytest.mark.parametrize("chunk", [0, 1000, 3333, 260000])
+def test_clip_all_stages(pdt, orc, clip, chunk):
+    rate, iq = clip
+    o = orc.Oracle(orc.POES, rate, iq, chunk=chunk)
+    with pdt.Demodulator(pdt.MODE_POES, rate, chunk=chunk) as d:
+        d.demod(iq)
+        check_all_stages(pdt, orc, d, o)
+        if chunk in (0, 1000):
+            assert d.text() == golden_text("clip.c10000.txt")
+            assert hashlib.md5(d.text()).hexdigest() == "d3c496d003a29eeee061c01b00ce025c"      # SURVEY 8c golden
+        if chunk == 260000:
+            assert d.text() == golden_text("clip.c260000.txt")
+
+
+def test_clip_norm_override(pdt, orc, clip):
+    rate, iq = clip
+    with pdt.Demodulator(pdt.MODE_POES, rate, norm_override=12.5) as d:
+        d.demod(iq)
+        assert d.text() == golden_text("clip.n12.txt")
+
+
+@pytest.mark.parametrize("fs", [18750, 32000, 50000, 100000, 250000])
+def test_synthetic_rates_golden(pdt, orc, golden, fs):
+    p = golden["params"]
+    iq = pdt.synth_capture(0, fs, p["poes_seconds"], seed=p["poes_seed"])
+    assert hashlib.sha256(iq.tobytes()).hexdigest() == golden["synth"][f"poes_{fs}"]
+    o = orc.Oracle(orc.POES, fs, iq)
+    with pdt.Demodulator(pdt.MODE_POES, fs) as d:
+        d.demod(iq)
+        check_all_stages(pdt, orc, d, o)
+        assert d.text() == golden_text(f"poes_{fs}.txt")
+
+
+@pytest.mark.parametrize("kw", [
+    dict(pll_block=4000, pll_warm=8000, agc_block=12000, agc_warm=90000),     # many seams
+    dict(pll_block=64, pll_warm=64, agc_block=64, agc_warm=64),               # warm-up far too short: every seam repaired
+    dict(pll_block=1 << 30, pll_warm=0, agc_block=1 << 30, agc_warm=0),       # one block: purely sequential
+])
+def test_block_geometry_never_changes_the_result(pdt, orc, clip, kw):
+    rate, iq = clip
+    iq = iq[:120000]
+    o = orc.Oracle(orc.POES, rate, iq)
+    with pdt.Demodulator(pdt.MODE_POES, rate, **kw) as d:
+        d.demod(iq)
+        check_all_stages(pdt, orc, d, o)
+        if kw["pll_block"] == 64:
+            assert d.stats().pll_seam_fixes > 0 and d.stats().agc_seam_fixes > 0
+
+
+@pytest.mark.parametrize("n", [0, 1, 5, 77, 9999, 10000, 10001, 20000, 25000])
+def test_short_and_ragged_captures(pdt, orc, clip, n):
+    """empty input, less than one chunk, exact multiples of the chunk (Q7), ragged tail"""
+    rate, iq = clip
+    part = iq[30000:30000 + n]
+    o = orc.Oracle(orc.POES, rate, part)
+    with pdt.Demodulator(pdt.MODE_POES, rate) as d:
+        d.demod(part)
+        check_all_stages(pdt, orc, d, o)
+
+
+def test_noise_only_never_locks(pdt, orc):
+    rng = np.random.default_rng(5)
+    iq = rng.integers(-400, 400, size=(150000, 2)).astype(np.int16)
+    o = orc.Oracle(orc.POES, 50000, iq)
+    with pdt.Demodulator(pdt.MODE_POES, 50000) as d:
+        d.demod(iq)
+        check_all_stages(pdt, orc, d, o)
+
+
+def test_negative_and_large_carrier_offsets(pdt, orc):
+    for f0, seed in ((-3100.0, 21), (4200.0, 22), (12.0, 23)):
+        iq = pdt.synth_capture(0, 50000, 4.0, f0_hz=f0, seed=seed)
+        o = orc.Oracle(orc.POES, 50000, iq)
+        with pdt.Demodulator(pdt.MODE_POES, 50000) as d:
+            d.demod(iq)
+            check_all_stages(pdt, orc, d, o)
+
+
+def test_inverted_frames(pdt, orc):
+    """I/Q swapped -> the PLL locks on the mirrored spectrum and frames arrive through the inverse sync word."""
+    iq = pdt.synth_capture(0, 50000, 5.0, seed=31)[:, ::-1].copy()
+    o = orc.Oracle(orc.POES, 50000, iq)
+    with pdt.Demodulator(pdt.MODE_POES, 50000) as d:
+        d.demod(iq)
+        check_all_stages(pdt, orc, d, o)
+
+
+def test_context_reuse_and_device_input(pdt, orc, clip):
+    import torch
+    rate, iq = clip
+    o_full = orc.Oracle(orc.POES, rate, iq, keep_stages=False)
+    o_half = orc.Oracle(orc.POES, rate, iq[:100000], keep_stages=False)
+    t = torch.from_numpy(iq.copy()).cuda()
+    with pdt.Demodulator(pdt.MODE_POES, rate) as d:
+        d.demod(iq)
+        assert d.text() == o_full.text()
+        d.demod(iq[:100000])                      # smaller capture on the same context
+        assert d.text() == o_half.text()
+        d.set_stream(torch.cuda.current_stream().cuda_stream)
+        d.demod_device(t.data_ptr(), len(iq))     # input already resident in HBM
+        assert d.text() == o_full.text()
+
+
+def test_round_trip_two_minutes(pdt):
+    """Size-independent property at a larger size: every complete decoded frame is one of the
+    transmitted frames, consecutive, and nearly all of them arrive."""
+    fs, secs, seed = 50000, 120.0, 4242
+    iq = pdt.synth_capture(0, fs, secs, seed=seed)
+    par = pdt.synth_params(0, fs, 1000.0, seed)
+    with pdt.Demodulator(pdt.MODE_POES, fs) as d:
+        d.demod(iq)
+        fr = d.frames_array()
+        st = d.stats()
+    complete = fr[fr["complete"] == 1]
+    assert len(complete) >= 1190
+    sent = {bytes(pdt.synth_poes_frame(par, k)): k for k in range(0, 1210)}
+    idx = [sent.get(bytes(f["bytes"])) for f in complete]
+    assert all(i is not None for i in idx)
+    assert idx == list(range(idx[0], idx[0] + len(idx)))
+    assert st.pll_seam_fixes == 0 and st.agc_seam_fixes == 0      # the warm-up re-converged at every seam
+    # time stamps: monotone apart from the documented zeros (Q2/Q4), 0.1 s frame period
+    t = fr["time"][fr["time"] > 0]
+    assert np.all(np.diff(t) > 0.09)
+
+
+def test_ten_minute_capture_matches_oracle(pdt, orc):
+    """BASELINE configs[1] at full size: 30 000 000 samples, bit-exact output file vs the CPU oracle."""
+    fs = 50000
+    iq = pdt.synth_capture(0, fs, 600.0, seed=1234)
+    o = orc.Oracle(orc.POES, fs, iq, keep_stages=False)
+    with pdt.Demodulator(pdt.MODE_POES, fs) as d:
+        d.demod(iq)
+        assert d.text() == o.text()
+        assert d.stats().frames == len(o.frames()) >= 5990
+
+
+def test_cli_demodpoes(pdt, tmp_path):
+    exe = os.path.join(ROOT, "bin", "demodPOES")
+    out = tmp_path / "mf.txt"
+    r = subprocess.run([exe, "-o", str(out), os.path.join(GOLDEN, "5sec_clip.wav")], capture_output=True, text=True)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert out.read_bytes() == golden_text("clip.c10000.txt")
+    assert "Normalization Factor: 17.583342" in r.stdout
+    assert " : PLL locked at -3466.19Hz" in r.stdout
+    # no frames -> output file removed (POESTIPdemod/main.c:508-512)
+    silent = tmp_path / "silence.wav"
+    pdt.write_wav(str(silent), 50000, np.zeros((30000, 2), dtype=np.int16))
+    out2 = tmp_path / "none.txt"
+    r = subprocess.run([exe, "-o", str(out2), str(silent)], capture_output=True, text=True)
+    assert r.returncode == 0 and not out2.exists()
+    assert "None bits found" in r.stdout

@@ -1,0 +1,55 @@
+"""The oracle's own transcendental restatements against the container's glibc (bit equality)."""
+import ctypes as C
+import ctypes.util
+
+import numpy as np
+
+libm = C.CDLL(ctypes.util.find_library("m"))
+libm.sincosf.argtypes = [C.c_float, C.POINTER(C.c_float), C.POINTER(C.c_float)]
+libm.sincosf.restype = None
+libm.hypotf.argtypes = [C.c_float, C.c_float]
+libm.hypotf.restype = C.c_float
+
+
+def bits(x):
+    return np.float32(x).view(np.uint32)
+
+
+def test_sincosf_matches_glibc_bitwise(orc):
+    L = orc.lib()
+    rng = np.random.default_rng(0)
+    xs = np.concatenate([
+        rng.uniform(-2 * np.pi, 2 * np.pi, 200000),
+        rng.uniform(-1e-3, 1e-3, 20000),
+        np.linspace(-6.2832, 6.2832, 100001),
+        np.array([0.0, 0.1, -0.1, 0.785398, 0.7853982, 2.4e-4, 2.5e-4, 6.2831855, -6.2831855, 3.1415927]),
+    ]).astype(np.float32)
+    s1, c1, s2, c2 = C.c_float(), C.c_float(), C.c_float(), C.c_float()
+    bad = 0
+    for x in xs:
+        L.orc_sincosf(float(x), C.byref(s1), C.byref(c1))
+        libm.sincosf(float(x), C.byref(s2), C.byref(c2))
+        if bits(s1.value) != bits(s2.value) or bits(c1.value) != bits(c2.value):
+            bad += 1
+    assert bad == 0, f"{bad} of {len(xs)} arguments differ from this machine's glibc sincosf (FMA ifunc variant expected)"
+
+
+def test_hypotf_matches_glibc_bitwise(orc):
+    L = orc.lib()
+    rng = np.random.default_rng(1)
+    a = (rng.integers(-32768, 32768, 100000) / 32768.0).astype(np.float32)
+    b = (rng.integers(-32768, 32768, 100000) / 32768.0).astype(np.float32)
+    for x, y in zip(a, b):
+        assert bits(L.orc_hypotf(float(x), float(y))) == bits(libm.hypotf(float(x), float(y)))
+
+
+def test_q_rsqrt_and_arctan2_known_values(orc):
+    L = orc.lib()
+    # two Newton steps of the 0x5f3759df seed
+    assert abs(L.orc_q_rsqrt(4.0) - 0.5) < 1e-5
+    assert abs(L.orc_q_rsqrt(0.25) - 2.0) < 1e-4
+    # rational approximation: exact at the octant centres
+    assert abs(L.orc_arctan2_f32(1.0, 1.0) - np.pi / 4) < 1e-6
+    assert abs(L.orc_arctan2_f32(1.0, -1.0) - 3 * np.pi / 4) < 1e-6
+    assert L.orc_arctan2_f32(-1.0, 1.0) == -L.orc_arctan2_f32(1.0, 1.0)
+    assert abs(L.orc_arctan2_f32(0.0, 1.0)) < 1e-6

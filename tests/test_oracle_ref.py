@@ -1,0 +1,90 @@
+"""Oracle restatement vs the reference's own compiled DSP objects (oracle/_ref), stage by stage.
+Skipped where oracle/_ref was not built (no /root/reference and no prebuilt files)."""
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+from conftest import GOLDEN, ROOT
+
+REF_POES = os.path.join(ROOT, "oracle/_ref/ref_demodPOES")
+REF_ARGOS = os.path.join(ROOT, "oracle/_ref/ref_demodARGOS")
+pytestmark = pytest.mark.skipif(not (os.path.exists(REF_POES) and os.path.exists(REF_ARGOS)),
+                                reason="oracle/_ref not built (make -C oracle ref)")
+
+STAGES = {"pll": 2, "lock": 3, "fir": 4, "agc": 5, "sym": 6, "symt": 7, "bits": 8, "bitt": 9, "taps": 11, "iq": 0,
+          "time": 1}
+
+
+def run_ref(binary, wav, tmp_path, extra=()):
+    out = tmp_path / "ref.txt"
+    dump = tmp_path / "refdump"
+    subprocess.run([binary, *extra, "-d", str(dump), str(wav), str(out)], check=True, capture_output=True)
+    text = out.read_bytes() if out.exists() else b""
+    return text, dump
+
+
+def compare_all(o, dump):
+    for name, sid in STAGES.items():
+        path = f"{dump}.{name}"
+        if not os.path.exists(path):
+            continue
+        ref = open(path, "rb").read()
+        if name == "lock" and o.mode == 0:
+            continue
+        assert o.stage(sid).tobytes() == ref, f"stage {name}: restatement differs from the reference objects"
+
+
+@pytest.mark.parametrize("chunk", [10000, 3333, 777])
+def test_clip_all_stages(orc, clip, tmp_path, chunk):
+    rate, iq = clip
+    text, dump = run_ref(REF_POES, os.path.join(GOLDEN, "5sec_clip.wav"), tmp_path, ["-c", str(chunk)])
+    o = orc.Oracle(orc.POES, rate, iq, chunk=chunk)
+    compare_all(o, dump)
+    assert o.text() == text
+
+
+@pytest.mark.parametrize("fs,seed,f0", [(50000, 5, -2300.0), (250000, 6, 3100.0), (32000, 7, 400.0)])
+def test_synthetic_poes_all_stages(orc, pdt, tmp_path, fs, seed, f0):
+    iq = pdt.synth_capture(0, fs, 4.0, f0_hz=f0, seed=seed)
+    wav = tmp_path / "s.wav"
+    pdt.write_wav(str(wav), fs, iq)
+    text, dump = run_ref(REF_POES, wav, tmp_path)
+    o = orc.Oracle(orc.POES, fs, iq)
+    compare_all(o, dump)
+    assert o.text() == text and len(text) > 0
+
+
+def test_exact_multiple_of_chunk(orc, pdt, tmp_path):
+    """Q7: data length an exact multiple of the chunk -> one extra empty iteration in the reference."""
+    fs = 50000
+    iq = pdt.synth_capture(0, fs, 2.0, seed=3)          # 100000 = 10 chunks exactly
+    wav = tmp_path / "s.wav"
+    pdt.write_wav(str(wav), fs, iq)
+    text, dump = run_ref(REF_POES, wav, tmp_path)
+    o = orc.Oracle(orc.POES, fs, iq)
+    compare_all(o, dump)
+    assert o.text() == text
+
+
+@pytest.mark.parametrize("chunk", [2400, 1000, 2401])
+def test_synthetic_argos_all_stages(orc, pdt, tmp_path, chunk):
+    iq = pdt.synth_capture(1, 32000, 7.0, f0_hz=160.0, seed=11)
+    wav = tmp_path / "a.wav"
+    pdt.write_wav(str(wav), 32000, iq)
+    text, dump = run_ref(REF_ARGOS, wav, tmp_path, ["-c", str(chunk)])
+    o = orc.Oracle(orc.ARGOS, 32000, iq, chunk=chunk)
+    compare_all(o, dump)
+    assert o.text() == text and len(text) > 0
+
+
+def test_noise_only_no_frames(orc, tmp_path, pdt):
+    rng = np.random.default_rng(1)
+    iq = rng.integers(-300, 300, size=(60000, 2)).astype(np.int16)
+    wav = tmp_path / "n.wav"
+    pdt.write_wav(str(wav), 50000, iq)
+    text, dump = run_ref(REF_POES, wav, tmp_path)
+    o = orc.Oracle(orc.POES, 50000, iq)
+    compare_all(o, dump)
+    assert o.text() == text

@@ -64,8 +64,8 @@ if __name__ == "__main__":
     allok &= run("5sec_clip", pdt.MODE_POES, rate, iq)
     allok &= run("5sec_clip c=3333", pdt.MODE_POES, rate, iq, chunk=3333)
     allok &= run("5sec_clip small blocks", pdt.MODE_POES, rate, iq, pll_block=5000, pll_warm=12000, agc_block=20000, agc_warm=100000)
-    for fs in (50000, 250000, 18750):
-        iq = pdt.synth_capture(0, fs, 6.0)
-        allok &= run(f"synth {fs}", pdt.MODE_POES, fs, iq)
+    for fs, secs in ((50000, 6.0), (250000, 6.0), (18750, 6.0), (50000, 60.0)):
+        iq = pdt.synth_capture(0, fs, secs)
+        allok &= run(f"synth {fs} {secs}s", pdt.MODE_POES, fs, iq)
     print("ALL OK" if allok else "FAILURES")
     sys.exit(0 if allok else 1)
