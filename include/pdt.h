@@ -109,6 +109,9 @@ typedef struct pdt_stats {
     uint32_t interp, ntaps;
     uint32_t pll_blocks, pll_seam_fixes, agc_blocks, agc_seam_fixes;
     double   gpu_ms;              /* device time of the last pdt_demod_* call (HIP events)        */
+    uint32_t gardner_parallel;    /* 1 = symbol sampler ran through the parallel boundary-state tables,
+                                     0 = single-wavefront sequential chain                         */
+    uint32_t reserved;
 } pdt_stats;
 
 typedef struct pdt_kernel_time {

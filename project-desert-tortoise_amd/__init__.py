@@ -81,6 +81,8 @@ class Stats(C.Structure):
         ("agc_blocks", C.c_uint32),
         ("agc_seam_fixes", C.c_uint32),
         ("gpu_ms", C.c_double),
+        ("gardner_parallel", C.c_uint32),
+        ("reserved", C.c_uint32),
     ]
 
 

@@ -8,6 +8,7 @@
 
 #include <algorithm>
 #include <string>
+#include <type_traits>
 #include <vector>
 
 #include "../../include/pdt.h"
@@ -66,6 +67,8 @@ struct DevScalars {
     unsigned nhits;
     unsigned nframes;
     unsigned counters[4];   // pll blocks, pll fixes, agc blocks, agc fixes
+    unsigned gardner_bad;   // state-table method: candidates whose exit fell outside the enumerated domain
+    unsigned pad_;
     double norm;            // storage for the normalisation factor (float or double)
 };
 
@@ -79,7 +82,9 @@ struct pdt_ctx {
     bool own_stream = false;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
 
-    DevBuf pcm, pll, lock, fir, agc, sym, symidx, bits, bitsym, hits, frames, taps, mag, seams_pll, seams_agc, scal, lockinfo, term, seams_ema;
+    DevBuf pcm, pll, lock, fir, agc, sym, symidx, bits, bitsym, hits, frames, taps, mag, seams_pll, seams_agc, scal, lockinfo, term, seams_ema, gtable, gentries;
+    bool force_sequential_gardner = false;
+    int gardner_mode = 0;              // 0 sequential, 1 state table (last run)
     const void *pcm_dev = nullptr;     // input actually used (own copy or caller's buffer)
 
     std::vector<unsigned char> taps_host;
@@ -369,11 +374,58 @@ template <typename T> int run_capture(pdt_ctx *ctx, uint64_t n)
         L.end();
     }
 
-    // ---- Gardner (sequential chain)
-    L.begin("gardner");
-    hipLaunchKernelGGL(k_gardner<T>, dim3(1), dim3(PDT_GARDNER_THREADS), 0, st, d_agc, d_lock, GP, d_sym, d_symidx,
-                       &d_sc->nsym, sym_cap);
-    L.end();
+    // ---- Gardner: exact parallel evaluation through boundary-state tables when the chunk geometry
+    // allows it (float build, chunk fits the LDS window, boundary states in one binade), otherwise the
+    // single-wavefront sequential chain.
+    bool use_table = false;
+    GardnerDomain GD;
+    GD.q_min = 0; GD.u = 0; GD.n_q = 0;
+    if constexpr (std::is_same<T, float>::value) {
+        const int table_len = GardnerLds<float>::LEN + 2 * GardnerLds<float>::OUT;
+        const float nT = (float)chunk_out, stepf = (float)GP.step;
+        if (!argos && !ctx->force_sequential_gardner && n_chunks >= 4 && chunk_out >= 64 &&
+            chunk_out + 2 * (long long)stepf + 24 <= table_len && chunk_out < (1 << 23)) {
+            int e;
+            (void)frexpf(nT - stepf - 1.0f, &e);                              // value in [2^(e-1), 2^e)
+            const float u = ldexpf(1.0f, e - 24);
+            const float q_min = u * floorf((nT - stepf - 1.0f) / u);
+            const int n_q = (int)ceilf((stepf + 1.8f) / u);
+            const float q_max = q_min + (float)n_q * u;
+            const double max_count = (double)chunk_out / ((double)stepf - 0.11) + 2.0;
+            if (q_min >= ldexpf(1.0f, e - 1) && q_max < ldexpf(1.0f, e) && 2 * (long long)n_q < (1 << 20) && max_count < 4095.0) {
+                use_table = true;
+                GD.q_min = q_min;
+                GD.u = u;
+                GD.n_q = n_q;
+            }
+        }
+    }
+    ctx->gardner_mode = use_table ? 1 : 0;
+    if (use_table) {
+        if constexpr (std::is_same<T, float>::value) {
+            const long long n_tab = n_chunks - 1;
+            if ((rc = ctx->gtable.ensure((size_t)n_tab * (size_t)(2 * GD.n_q) * sizeof(unsigned)))) return rc;
+            if ((rc = ctx->gentries.ensure((size_t)n_chunks * sizeof(GardnerEntry<float>)))) return rc;
+            L.begin("gardner_table");
+            hipLaunchKernelGGL(k_gardner_table, dim3((unsigned)n_tab), dim3(PDT_GTAB_THREADS), 0, st, (const float *)d_agc, GP, GD,
+                               n_tab, (unsigned *)ctx->gtable.p, &d_sc->gardner_bad);
+            L.end();
+            L.begin("gardner_chain");
+            hipLaunchKernelGGL(k_gardner_chain, dim3(1), dim3(64), 0, st, (const float *)d_agc, GP, GD, n_chunks,
+                               (const unsigned *)ctx->gtable.p, (GardnerEntry<float> *)ctx->gentries.p, &d_sc->gardner_bad);
+            L.end();
+            L.begin("gardner");
+            hipLaunchKernelGGL(k_gardner<float>, dim3((unsigned)n_chunks), dim3(PDT_GARDNER_THREADS), 0, st, (const float *)d_agc,
+                               (const float *)d_lock, GP, (float *)d_sym, d_symidx, &d_sc->nsym, sym_cap,
+                               (const GardnerEntry<float> *)ctx->gentries.p);
+            L.end();
+        }
+    } else {
+        L.begin("gardner");
+        hipLaunchKernelGGL(k_gardner<T>, dim3(1), dim3(PDT_GARDNER_THREADS), 0, st, d_agc, d_lock, GP, d_sym, d_symidx,
+                           &d_sc->nsym, sym_cap, (const GardnerEntry<T> *)nullptr);
+        L.end();
+    }
 
     // ---- Manchester
     L.begin("manchester");
@@ -405,6 +457,16 @@ template <typename T> int run_capture(pdt_ctx *ctx, uint64_t n)
     HIP_TRY(hipMemcpyAsync(&sc, d_sc, sizeof sc, hipMemcpyDeviceToHost, st));
     HIP_TRY(hipMemcpyAsync(&info, d_info, sizeof info, hipMemcpyDeviceToHost, st));
     HIP_TRY(hipStreamSynchronize(st));
+    if (use_table && sc.gardner_bad) {
+        // a boundary state fell outside the enumerated domain: redo the capture with the sequential sampler
+        fprintf(stderr, "libpdt: Gardner state table miss (%u), falling back to the sequential sampler\n", sc.gardner_bad);
+        ctx->force_sequential_gardner = true;
+        for (auto &t : ctx->timers) { (void)hipEventDestroy(t.a); (void)hipEventDestroy(t.b); }
+        ctx->timers.clear();
+        const int rc2 = run_capture<T>(ctx, n);
+        ctx->force_sequential_gardner = false;
+        return rc2;
+    }
     if (sc.nframes > frame_cap || sc.nhits > hit_cap || (long long)sc.nsym > sym_cap) {
         fprintf(stderr, "libpdt: internal capacity exceeded (frames %u/%u hits %u/%u symbols %llu/%lld)\n", sc.nframes,
                 frame_cap, sc.nhits, hit_cap, sc.nsym, sym_cap);
@@ -436,6 +498,7 @@ template <typename T> int run_capture(pdt_ctx *ctx, uint64_t n)
     S.agc_blocks = sc.counters[2];
     S.agc_seam_fixes = sc.counters[3];
     S.gpu_ms = ms;
+    S.gardner_parallel = (uint32_t)ctx->gardner_mode;
 
     ctx->stage_len[PDT_ST_PLL] = n;
     ctx->stage_len[PDT_ST_LOCK] = argos ? n : 0;
@@ -626,7 +689,7 @@ void pdt_close(pdt_ctx *ctx)
     (void)hipSetDevice(ctx->cfg.device);
     DevBuf *bufs[] = { &ctx->pcm, &ctx->pll, &ctx->lock, &ctx->fir, &ctx->agc, &ctx->sym, &ctx->symidx, &ctx->bits, &ctx->bitsym,
                        &ctx->hits, &ctx->frames, &ctx->taps, &ctx->mag, &ctx->seams_pll, &ctx->seams_agc, &ctx->scal, &ctx->lockinfo,
-                       &ctx->term, &ctx->seams_ema };
+                       &ctx->term, &ctx->seams_ema, &ctx->gtable, &ctx->gentries };
     for (DevBuf *b : bufs) b->release();
     if (ctx->ev0) (void)hipEventDestroy(ctx->ev0);
     if (ctx->ev1) (void)hipEventDestroy(ctx->ev1);

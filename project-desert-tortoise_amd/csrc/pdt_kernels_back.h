@@ -70,12 +70,19 @@ template <> __device__ __forceinline__ unsigned uniform<unsigned>(unsigned v)
 // Symbol loop = [one fully checked step] + [a counted batch of check-free steps].  The
 // batch length is the number of steps that provably stay inside the chunk, the LDS window
 // and the staging buffer: a step advances the sampling instant by at most step + 0.1.
+// entry state of one reference chunk, produced by k_gardner_chain for the parallel path
+template <typename T> struct GardnerEntry {
+    T ns, prev, half;
+    long long offset;        // symbols emitted before this chunk
+};
+
 template <typename T>
 __global__ void __launch_bounds__(PDT_GARDNER_THREADS) k_gardner(const T *__restrict__ in, const T *__restrict__ lock,
                                                                   GardnerParams<T> P, T *__restrict__ sym,
                                                                   long long *__restrict__ symidx,
                                                                   unsigned long long *__restrict__ nsym_out,
-                                                                  long long sym_cap)
+                                                                  long long sym_cap,
+                                                                  const GardnerEntry<T> *__restrict__ entries)
 {
     constexpr int LEN = GardnerLds<T>::LEN;
     constexpr int OUT = GardnerLds<T>::OUT;
@@ -90,7 +97,20 @@ __global__ void __launch_bounds__(PDT_GARDNER_THREADS) k_gardner(const T *__rest
     const long long C = P.chunk_out;
     const long long n_chunks = (P.n_total + C - 1) / C;
     long long count = 0;
-    for (long long c = 0; c < n_chunks; c++) {
+    // sequential mode (entries == nullptr): this one wavefront walks every chunk in order.
+    // parallel mode: block b owns chunk b and starts from the tabulated entry state.
+    long long c_begin = 0, c_end = n_chunks;
+    if (entries) {
+        c_begin = blockIdx.x;
+        c_end = c_begin + 1;
+        if (c_begin >= n_chunks) return;
+        const GardnerEntry<T> e = entries[c_begin];
+        ns = e.ns;
+        prev = e.prev;
+        half = e.half;
+        count = e.offset;
+    }
+    for (long long c = c_begin; c < c_end; c++) {
         const long long base = c * C;
         const unsigned n_cur = (unsigned)((P.n_total - base < C) ? (P.n_total - base) : C);
         const T nT = (T)n_cur;
@@ -191,7 +211,125 @@ __global__ void __launch_bounds__(PDT_GARDNER_THREADS) k_gardner(const T *__rest
         }
         ns = ns - nT;                              // roll over; `half` is deliberately not (Q3)
     }
-    if (lane == 0) *nsym_out = (unsigned long long)count;
+    if (lane == 0 && (!entries || c_end == n_chunks)) *nsym_out = (unsigned long long)count;
+}
+
+// ------------------------------------------------------------------------------------------
+// Exact parallel Gardner ("state table" method, float only)
+//
+// The sampler state that crosses a chunk boundary is (ns, prev, half).  All three are functions
+// of q = the sampling instant of the chunk's last symbol after the error correction and before
+// the step is added (ns_end = q + step, half = q + step/2, prev = in[rint(ns_last)] with
+// rint(ns_last) in {floor q, floor q + 1}).  At the end of a chunk q lies in
+// [n - step - 0.6, n - 0.4), a single float binade for the usual chunk sizes, so q takes only
+// (step + ~1.5)/ulp distinct values (4.7 k for n = 30000): the set of *possible* boundary states
+// is small and known in advance, although which one occurs depends on the whole past.
+//   level 1  (parallel over chunks x candidate states): run every full chunk from every
+//            candidate entry state; record the exit state's index and the symbol count;
+//   level 2  (one lane): follow the true chain  k_{c+1} = table_c[k_c]  from the known start;
+//   level 3  (parallel over chunks): re-run each chunk from its now known entry state and
+//            emit its symbols at the prefix-summed offset (k_gardner in parallel mode).
+// Every float operation of the true trajectory is executed exactly as in the sequential loop,
+// so the result is bit-identical by construction; a table index outside the candidate range
+// raises a flag and the host falls back to the sequential kernel.
+// ------------------------------------------------------------------------------------------
+struct GardnerDomain {
+    float q_min;       // smallest candidate q (multiple of u)
+    float u;           // grid spacing (ulp of the binade that contains the chunk end)
+    int n_q;           // number of q values; candidates = 2 * n_q (two choices of the last pick)
+};
+
+#define PDT_GTAB_THREADS 1024
+
+__device__ __forceinline__ void gardner_entry_from_candidate(const float *__restrict__ in, const GardnerParams<float> &P,
+                                                             const GardnerDomain &D, long long c, int k, float &ns,
+                                                             float &prev, float &half)
+{
+    // candidate k of the boundary between chunk c-1 (full) and chunk c
+    const float q = D.q_min + (float)(k >> 1) * D.u;          // exact: both are multiples of u in one binade
+    const float hs = (float)((double)P.step / 2.0);
+    const float ns_end = q + P.step;
+    ns = ns_end - (float)P.chunk_out;
+    half = q + hs;
+    const long long i_last = (long long)floorf(q) + (k & 1);
+    prev = in[(c - 1) * P.chunk_out + i_last];
+}
+
+__global__ void __launch_bounds__(PDT_GTAB_THREADS) k_gardner_table(const float *__restrict__ in, GardnerParams<float> P,
+                                                                     GardnerDomain D, long long n_tab_chunks,
+                                                                     unsigned *__restrict__ table,
+                                                                     unsigned *__restrict__ bad)
+{
+    constexpr int LEN = GardnerLds<float>::LEN + GardnerLds<float>::OUT * 2;      // the whole 160 KiB budget as window
+    __shared__ float win[LEN];
+    const long long c = blockIdx.x;                 // chunk (always a full one)
+    if (c >= n_tab_chunks) return;
+    const long long C = P.chunk_out;
+    const long long base = c * C;
+    const int n_cur = (int)C;
+    int n_stage = n_cur + 2 * (int)P.step + 24;
+    if (n_stage > LEN) n_stage = LEN;               // host guarantees n_cur + margin <= LEN
+    for (int t = threadIdx.x; t < n_stage; t += PDT_GTAB_THREADS)
+        win[t] = (t < n_cur) ? in[base + t] : gardner_beyond(in, (const float *)nullptr, P, c, (long long)n_cur, (long long)t);
+    __syncthreads();
+    const float hs = (float)((double)P.step / 2.0);
+    const float kp = P.kp, lim = P.lim, step = P.step, nT = (float)n_cur;
+    const int ncand = (c == 0) ? 1 : 2 * D.n_q;
+    unsigned *row = table + (size_t)c * (size_t)(2 * D.n_q);
+    for (int k = threadIdx.x; k < ncand; k += PDT_GTAB_THREADS) {
+        float ns, prev, half;
+        if (c == 0) { ns = 0; prev = 0; half = 0; }
+        else gardner_entry_from_candidate(in, P, D, c, k, ns, prev, half);
+        float q_last = 0;
+        unsigned i_last = 0, count = 0;
+        for (;;) {
+            const float rn = __builtin_rintf(ns);
+            if (!(rn < nT)) break;
+            const unsigned i_cur = (unsigned)rn;
+            const unsigned i_half = (unsigned)__builtin_rintf(half);
+            const float cur = win[i_cur];
+            const float mid = (i_half < (unsigned)n_stage) ? win[i_half] : 0.0f;
+            float err = kp * (cur - prev) * mid;
+            err = (err > lim) ? lim : ((err < -lim) ? -lim : err);
+            ns = ns - err;
+            q_last = ns;
+            half = ns + hs;
+            ns = ns + step;
+            prev = cur;
+            i_last = i_cur;
+            count++;
+        }
+        // encode the exit state
+        const float mf = (q_last - D.q_min) / D.u;           // exact small integer for in-domain states
+        const int m = (int)mf;
+        const int v = (int)i_last - (int)floorf(q_last);
+        unsigned ok = (count > 0) && (mf == (float)m) && (m >= 0) && (m < D.n_q) && (v == 0 || v == 1) && (count < 4096u);
+        // the stale mid-point of the first symbol must have been inside the staged window
+        if (!ok) atomicAdd(bad, 1u);
+        row[k] = ok ? (((unsigned)(2 * m + v)) | (count << 20)) : 0xffffffffu;    // 20-bit index, 12-bit count
+    }
+}
+
+// level 2: follow the chain of tables; one lane.  entries[c] for every chunk, incl. the last.
+__global__ void k_gardner_chain(const float *__restrict__ in, GardnerParams<float> P, GardnerDomain D, long long n_chunks,
+                                const unsigned *__restrict__ table, GardnerEntry<float> *__restrict__ entries,
+                                unsigned *__restrict__ bad)
+{
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    GardnerEntry<float> e;
+    e.ns = 0; e.prev = 0; e.half = 0; e.offset = 0;
+    entries[0] = e;
+    long long off = 0;
+    unsigned cell = (n_chunks > 1) ? table[0] : 0u;            // chunk 0 has a single candidate
+    for (long long c = 1; c < n_chunks; c++) {
+        if (cell == 0xffffffffu) { atomicAdd(bad, 1u); return; }
+        const int k = (int)(cell & 0xfffffu);
+        off += (long long)(cell >> 20);
+        gardner_entry_from_candidate(in, P, D, c, k, e.ns, e.prev, e.half);
+        e.offset = off;
+        entries[c] = e;
+        if (c + 1 < n_chunks) cell = table[(size_t)c * (size_t)(2 * D.n_q) + (size_t)k];
+    }
 }
 
 // ------------------------------------------------------------------------------------------
