@@ -111,7 +111,7 @@ typedef struct pdt_stats {
     double   gpu_ms;              /* device time of the last pdt_demod_* call (HIP events)        */
     uint32_t gardner_parallel;    /* 1 = symbol sampler ran through the parallel boundary-state tables,
                                      0 = single-wavefront sequential chain                         */
-    uint32_t reserved;
+    uint32_t reserved;            /* diagnostics: chunks walked by the chain | full-domain chunks << 16 */
 } pdt_stats;
 
 typedef struct pdt_kernel_time {

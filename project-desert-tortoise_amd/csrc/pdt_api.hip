@@ -67,8 +67,8 @@ struct DevScalars {
     unsigned nhits;
     unsigned nframes;
     unsigned counters[4];   // pll blocks, pll fixes, agc blocks, agc fixes
-    unsigned gardner_bad;   // state-table method: candidates whose exit fell outside the enumerated domain
-    unsigned pad_;
+    unsigned gstats[4];     // boundary-state tables: [0] exits outside the domain, [1] full-domain chunks,
+                            //                        [2] chunks the chain had to walk, [3] unused
     double norm;            // storage for the normalisation factor (float or double)
 };
 
@@ -82,7 +82,8 @@ struct pdt_ctx {
     bool own_stream = false;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
 
-    DevBuf pcm, pll, lock, fir, agc, sym, symidx, bits, bitsym, hits, frames, taps, mag, seams_pll, seams_agc, scal, lockinfo, term, seams_ema, gtable, gentries;
+    DevBuf pcm, pll, lock, fir, agc, sym, symidx, bits, bitsym, hits, frames, taps, mag, seams_pll, seams_agc, scal, lockinfo, term, seams_ema, gtable, gentries, gcand, gmfirst;
+    long long gcand_key = -1;          // (chunk_out, step) the candidate list on the device was built for
     bool force_sequential_gardner = false;
     int gardner_mode = 0;              // 0 sequential, 1 state table (last run)
     const void *pcm_dev = nullptr;     // input actually used (own copy or caller's buffer)
@@ -379,11 +380,11 @@ template <typename T> int run_capture(pdt_ctx *ctx, uint64_t n)
     // single-wavefront sequential chain.
     bool use_table = false;
     GardnerDomain GD;
-    GD.q_min = 0; GD.u = 0; GD.n_q = 0;
+    GD.q_min = 0; GD.u = 0; GD.n_q = 0; GD.n_cand = 0;
     if constexpr (std::is_same<T, float>::value) {
-        const int table_len = GardnerLds<float>::LEN + 2 * GardnerLds<float>::OUT;
+        const int table_len = GardnerLds<float>::LEN + 2 * GardnerLds<float>::OUT - PDT_GTAB_TAIL - 64;
         const float nT = (float)chunk_out, stepf = (float)GP.step;
-        if (!argos && !ctx->force_sequential_gardner && n_chunks >= 4 && chunk_out >= 64 &&
+        if (!argos && !ctx->force_sequential_gardner && n_chunks >= 4 && chunk_out >= 256 &&
             chunk_out + 2 * (long long)stepf + 24 <= table_len && chunk_out < (1 << 23)) {
             int e;
             (void)frexpf(nT - stepf - 1.0f, &e);                              // value in [2^(e-1), 2^e)
@@ -403,16 +404,39 @@ template <typename T> int run_capture(pdt_ctx *ctx, uint64_t n)
     ctx->gardner_mode = use_table ? 1 : 0;
     if (use_table) {
         if constexpr (std::is_same<T, float>::value) {
+            // consistent (q, last pick) combinations: the last pick is rint(q + err), |err| <= 0.1
+            std::vector<unsigned> cand;
+            std::vector<int> mfirst((size_t)GD.n_q + 1);
+            cand.reserve((size_t)GD.n_q * 2);
+            for (int m = 0; m < GD.n_q; m++) {
+                mfirst[(size_t)m] = (int)cand.size();
+                const float q = GD.q_min + (float)m * GD.u;
+                const float fr = q - floorf(q);
+                if (fr <= 0.61f) cand.push_back((unsigned)(2 * m));
+                if (fr >= 0.39f) cand.push_back((unsigned)(2 * m + 1));
+            }
+            mfirst[(size_t)GD.n_q] = (int)cand.size();
+            GD.n_cand = (int)cand.size();
+            const long long key = chunk_out * 1000003ll + (long long)llround((double)GP.step * 4096.0);
+            if ((rc = ctx->gcand.ensure(cand.size() * sizeof(unsigned)))) return rc;
+            if ((rc = ctx->gmfirst.ensure(mfirst.size() * sizeof(int)))) return rc;
+            if (ctx->gcand_key != key) {
+                HIP_TRY(hipMemcpyAsync(ctx->gcand.p, cand.data(), cand.size() * sizeof(unsigned), hipMemcpyHostToDevice, st));
+                HIP_TRY(hipMemcpyAsync(ctx->gmfirst.p, mfirst.data(), mfirst.size() * sizeof(int), hipMemcpyHostToDevice, st));
+                HIP_TRY(hipStreamSynchronize(st));              // the host vectors die at the end of this scope
+                ctx->gcand_key = key;
+            }
             const long long n_tab = n_chunks - 1;
             if ((rc = ctx->gtable.ensure((size_t)n_tab * (size_t)(2 * GD.n_q) * sizeof(unsigned)))) return rc;
             if ((rc = ctx->gentries.ensure((size_t)n_chunks * sizeof(GardnerEntry<float>)))) return rc;
             L.begin("gardner_table");
             hipLaunchKernelGGL(k_gardner_table, dim3((unsigned)n_tab), dim3(PDT_GTAB_THREADS), 0, st, (const float *)d_agc, GP, GD,
-                               n_tab, (unsigned *)ctx->gtable.p, &d_sc->gardner_bad);
+                               n_tab, (const unsigned *)ctx->gcand.p, (const int *)ctx->gmfirst.p, (unsigned *)ctx->gtable.p,
+                               d_sc->gstats);
             L.end();
             L.begin("gardner_chain");
-            hipLaunchKernelGGL(k_gardner_chain, dim3(1), dim3(64), 0, st, (const float *)d_agc, GP, GD, n_chunks,
-                               (const unsigned *)ctx->gtable.p, (GardnerEntry<float> *)ctx->gentries.p, &d_sc->gardner_bad);
+            hipLaunchKernelGGL(k_gardner_chain, dim3(1), dim3(PDT_GARDNER_THREADS), 0, st, (const float *)d_agc, GP, GD, n_chunks,
+                               (const unsigned *)ctx->gtable.p, (GardnerEntry<float> *)ctx->gentries.p, d_sc->gstats);
             L.end();
             L.begin("gardner");
             hipLaunchKernelGGL(k_gardner<float>, dim3((unsigned)n_chunks), dim3(PDT_GARDNER_THREADS), 0, st, (const float *)d_agc,
@@ -457,16 +481,6 @@ template <typename T> int run_capture(pdt_ctx *ctx, uint64_t n)
     HIP_TRY(hipMemcpyAsync(&sc, d_sc, sizeof sc, hipMemcpyDeviceToHost, st));
     HIP_TRY(hipMemcpyAsync(&info, d_info, sizeof info, hipMemcpyDeviceToHost, st));
     HIP_TRY(hipStreamSynchronize(st));
-    if (use_table && sc.gardner_bad) {
-        // a boundary state fell outside the enumerated domain: redo the capture with the sequential sampler
-        fprintf(stderr, "libpdt: Gardner state table miss (%u), falling back to the sequential sampler\n", sc.gardner_bad);
-        ctx->force_sequential_gardner = true;
-        for (auto &t : ctx->timers) { (void)hipEventDestroy(t.a); (void)hipEventDestroy(t.b); }
-        ctx->timers.clear();
-        const int rc2 = run_capture<T>(ctx, n);
-        ctx->force_sequential_gardner = false;
-        return rc2;
-    }
     if (sc.nframes > frame_cap || sc.nhits > hit_cap || (long long)sc.nsym > sym_cap) {
         fprintf(stderr, "libpdt: internal capacity exceeded (frames %u/%u hits %u/%u symbols %llu/%lld)\n", sc.nframes,
                 frame_cap, sc.nhits, hit_cap, sc.nsym, sym_cap);
@@ -499,6 +513,7 @@ template <typename T> int run_capture(pdt_ctx *ctx, uint64_t n)
     S.agc_seam_fixes = sc.counters[3];
     S.gpu_ms = ms;
     S.gardner_parallel = (uint32_t)ctx->gardner_mode;
+    S.reserved = use_table ? ((sc.gstats[2] & 0xffffu) | ((sc.gstats[1] & 0xffffu) << 16)) : 0u;   // walked | full-domain chunks
 
     ctx->stage_len[PDT_ST_PLL] = n;
     ctx->stage_len[PDT_ST_LOCK] = argos ? n : 0;
@@ -689,7 +704,8 @@ void pdt_close(pdt_ctx *ctx)
     (void)hipSetDevice(ctx->cfg.device);
     DevBuf *bufs[] = { &ctx->pcm, &ctx->pll, &ctx->lock, &ctx->fir, &ctx->agc, &ctx->sym, &ctx->symidx, &ctx->bits, &ctx->bitsym,
                        &ctx->hits, &ctx->frames, &ctx->taps, &ctx->mag, &ctx->seams_pll, &ctx->seams_agc, &ctx->scal, &ctx->lockinfo,
-                       &ctx->term, &ctx->seams_ema, &ctx->gtable, &ctx->gentries };
+                       &ctx->term, &ctx->seams_ema, &ctx->gtable, &ctx->gentries, &ctx->gcand,
+                       &ctx->gmfirst };
     for (DevBuf *b : bufs) b->release();
     if (ctx->ev0) (void)hipEventDestroy(ctx->ev0);
     if (ctx->ev1) (void)hipEventDestroy(ctx->ev1);

@@ -62,139 +62,129 @@ template <> __device__ __forceinline__ unsigned uniform<unsigned>(unsigned v)
     return (unsigned)__builtin_amdgcn_readfirstlane((int)v);
 }
 
-// One workgroup of ONE wavefront.  All 64 lanes carry the same sampler state and execute
-// the same instructions (LDS reads of one address broadcast), so every branch is
-// wave-uniform and is made scalar with readfirstlane: no exec-mask bookkeeping in the
-// symbol loop.  The lanes differ only when they stage a window or flush symbols.
-//
-// Symbol loop = [one fully checked step] + [a counted batch of check-free steps].  The
-// batch length is the number of steps that provably stay inside the chunk, the LDS window
-// and the staging buffer: a step advances the sampling instant by at most step + 0.1.
-// entry state of one reference chunk, produced by k_gardner_chain for the parallel path
-template <typename T> struct GardnerEntry {
-    T ns, prev, half;
-    long long offset;        // symbols emitted before this chunk
+template <typename T> struct GardnerState {
+    T ns, prev, half;      // sampler state (identical in every lane of the wavefront)
+    T q_last;              // sampling instant of the last symbol after the error correction
+    unsigned i_last;       // index the last symbol was taken at
 };
 
-template <typename T>
-__global__ void __launch_bounds__(PDT_GARDNER_THREADS) k_gardner(const T *__restrict__ in, const T *__restrict__ lock,
-                                                                  GardnerParams<T> P, T *__restrict__ sym,
-                                                                  long long *__restrict__ symidx,
-                                                                  unsigned long long *__restrict__ nsym_out,
-                                                                  long long sym_cap,
-                                                                  const GardnerEntry<T> *__restrict__ entries)
+// Walk ONE reference chunk with ONE wavefront.  All 64 lanes carry the same sampler state and
+// execute the same instructions (LDS reads of one address broadcast), so every branch is
+// wave-uniform and made scalar with readfirstlane: no exec-mask bookkeeping in the symbol
+// loop.  The lanes differ only when they stage a window or flush symbols.
+//
+// Symbol loop = [one fully checked step] + [a counted batch of check-free steps].  The batch
+// length is the number of steps that provably stay inside the chunk, the LDS window and the
+// staging buffer: a step advances the sampling instant by at most step + 0.1.
+// Returns the number of symbols of the chunk; EMIT stores them at sym[count0...].
+template <typename T, bool EMIT>
+__device__ __forceinline__ long long gardner_walk_chunk(const T *__restrict__ in, const T *__restrict__ lock,
+                                                        const GardnerParams<T> &P, long long c, GardnerState<T> &S, T *win,
+                                                        T *o_val, unsigned *o_idx, T *__restrict__ sym,
+                                                        long long *__restrict__ symidx, long long count0, long long sym_cap)
 {
     constexpr int LEN = GardnerLds<T>::LEN;
     constexpr int OUT = GardnerLds<T>::OUT;
-    __shared__ T win[LEN];
-    __shared__ T o_val[OUT];
-    __shared__ unsigned o_idx[OUT];
     const int lane = threadIdx.x;
-    T ns = 0, prev = 0, half = 0;                 // identical in every lane
+    T ns = S.ns, prev = S.prev, half = S.half, q_last = S.q_last;
+    unsigned i_last = S.i_last;
     const T hs = (T)((double)P.step / 2.0);       // exact: step/2 is representable
     const T kp = P.kp, lim = P.lim, step = P.step;
     const T adv = step + (T)0.101;                // upper bound of one step's advance
     const long long C = P.chunk_out;
-    const long long n_chunks = (P.n_total + C - 1) / C;
-    long long count = 0;
-    // sequential mode (entries == nullptr): this one wavefront walks every chunk in order.
-    // parallel mode: block b owns chunk b and starts from the tabulated entry state.
-    long long c_begin = 0, c_end = n_chunks;
-    if (entries) {
-        c_begin = blockIdx.x;
-        c_end = c_begin + 1;
-        if (c_begin >= n_chunks) return;
-        const GardnerEntry<T> e = entries[c_begin];
-        ns = e.ns;
-        prev = e.prev;
-        half = e.half;
-        count = e.offset;
-    }
-    for (long long c = c_begin; c < c_end; c++) {
-        const long long base = c * C;
-        const unsigned n_cur = (unsigned)((P.n_total - base < C) ? (P.n_total - base) : C);
-        const T nT = (T)n_cur;
-        unsigned wbase = 0;
-        bool chunk_done = false;
-        while (!chunk_done) {
-            // ---- stage the part of [wbase, wbase+LEN) the sampler can touch: chunk data with 8
-            // independent loads in flight per lane, then the few past-the-end values (Q3/Q16)
-            __syncthreads();
-            int n_staged;
-            {
-                const unsigned avail = (n_cur > wbase) ? n_cur - wbase : 0u;
-                const int n_data = (int)((avail < (unsigned)LEN) ? avail : (unsigned)LEN);
-                const T *src = in + base + wbase;
-                int t = lane;
-                for (; t + 7 * PDT_GARDNER_THREADS < n_data; t += 8 * PDT_GARDNER_THREADS) {
-                    T r[8];
+    const long long base = c * C;
+    const unsigned n_cur = (unsigned)((P.n_total - base < C) ? (P.n_total - base) : C);
+    const T nT = (T)n_cur;
+    long long count = count0;
+    unsigned wbase = 0;
+    bool chunk_done = false;
+    while (!chunk_done) {
+        // ---- stage the part of [wbase, wbase+LEN) the sampler can touch: chunk data with 8
+        // independent loads in flight per lane, then the few past-the-end values (Q3/Q16)
+        __syncthreads();
+        int n_staged;
+        {
+            const unsigned avail = (n_cur > wbase) ? n_cur - wbase : 0u;
+            const int n_data = (int)((avail < (unsigned)LEN) ? avail : (unsigned)LEN);
+            const T *src = in + base + wbase;
+            int t = lane;
+            for (; t + 7 * PDT_GARDNER_THREADS < n_data; t += 8 * PDT_GARDNER_THREADS) {
+                T r[8];
 #pragma unroll
-                    for (int u = 0; u < 8; u++) r[u] = src[t + u * PDT_GARDNER_THREADS];
+                for (int u = 0; u < 8; u++) r[u] = src[t + u * PDT_GARDNER_THREADS];
 #pragma unroll
-                    for (int u = 0; u < 8; u++) win[t + u * PDT_GARDNER_THREADS] = r[u];
-                }
-                for (; t < n_data; t += PDT_GARDNER_THREADS) win[t] = src[t];
-                int n_tail = n_data + 2 * (int)step + 24;          // furthest look-ahead of the mid-point / prefetch
-                if (n_tail > LEN) n_tail = LEN;
-                for (int q = n_data + lane; q < n_tail; q += PDT_GARDNER_THREADS)
-                    win[q] = gardner_beyond(in, lock, P, c, (long long)n_cur, (long long)(wbase + (unsigned)q));
-                n_staged = n_tail;
+                for (int u = 0; u < 8; u++) win[t + u * PDT_GARDNER_THREADS] = r[u];
             }
-            __syncthreads();
-            const unsigned wend = wbase + (unsigned)LEN;
-            const unsigned lim_idx = (n_cur < wend) ? n_cur : wend;   // first index the batch must not reach
-            int nout = 0;
-            bool window_done = false;
-            while (!window_done) {
-                // ---- checked step
-                const T rn = Real<T>::rint(ns);
-                const int in_chunk = uniform<int>((int)(rn < nT));
-                if (!in_chunk) { chunk_done = true; break; }
-                const unsigned i_abs = uniform<unsigned>((unsigned)rn);
-                if (i_abs - wbase >= (unsigned)LEN || nout >= OUT) break;          // new window / flush
-                const unsigned h_abs = uniform<unsigned>((unsigned)Real<T>::rint(half));
-                const T cur = win[i_abs - wbase];
-                T mid;
-                if (h_abs - wbase < (unsigned)n_staged)
-                    mid = win[h_abs - wbase];
-                else
-                    mid = (h_abs < n_cur) ? in[base + h_abs] : gardner_beyond(in, lock, P, c, (long long)n_cur, (long long)h_abs);
+            for (; t < n_data; t += PDT_GARDNER_THREADS) win[t] = src[t];
+            int n_tail = n_data + 2 * (int)step + 24;          // furthest look-ahead of the mid-point
+            if (n_tail > LEN) n_tail = LEN;
+            for (int q = n_data + lane; q < n_tail; q += PDT_GARDNER_THREADS)
+                win[q] = gardner_beyond(in, lock, P, c, (long long)n_cur, (long long)(wbase + (unsigned)q));
+            n_staged = n_tail;
+        }
+        __syncthreads();
+        const unsigned wend = wbase + (unsigned)LEN;
+        const unsigned lim_idx = (n_cur < wend) ? n_cur : wend;   // first index the batch must not reach
+        int nout = 0;
+        for (;;) {
+            // ---- checked step
+            const T rn = Real<T>::rint(ns);
+            const int in_chunk = uniform<int>((int)(rn < nT));
+            if (!in_chunk) { chunk_done = true; break; }
+            const unsigned i_abs = uniform<unsigned>((unsigned)rn);
+            if (i_abs - wbase >= (unsigned)LEN || nout >= OUT) break;          // new window / flush
+            const unsigned h_abs = uniform<unsigned>((unsigned)Real<T>::rint(half));
+            const T cur = win[i_abs - wbase];
+            T mid;
+            if (h_abs - wbase < (unsigned)n_staged)
+                mid = win[h_abs - wbase];
+            else
+                mid = (h_abs < n_cur) ? in[base + h_abs] : gardner_beyond(in, lock, P, c, (long long)n_cur, (long long)h_abs);
+            if (EMIT) {
                 o_val[nout] = cur;
                 o_idx[nout] = i_abs;
-                nout++;
-                {
-                    T err = kp * (cur - prev) * mid;
-                    err = (err > lim) ? lim : ((err < -lim) ? -lim : err);
-                    ns = ns - err;
-                    half = ns + hs;   // == (T)((double)ns + (double)step/2.0): that double sum is exact
-                    ns = ns + step;
-                    prev = cur;
-                }
-                // ---- check-free batch
-                const T room = (T)lim_idx - (T)2 - ns;
-                int K = (room > (T)0) ? (int)(room / adv) : 0;
-                K = uniform<int>(K);
-                if (K > OUT - nout) K = OUT - nout;
-                const T wb = (T)wbase;
-                T *ov = o_val + nout;
-                unsigned *oi = o_idx + nout;
-                for (int k = 0; k < K; k++) {
-                    const T rnk = Real<T>::rint(ns);
-                    const T rhk = Real<T>::rint(half);
-                    const T c_k = win[(int)(rnk - wb)];
-                    const T m_k = win[(int)(rhk - wb)];
-                    ov[k] = c_k;
-                    oi[k] = (unsigned)rnk;
-                    T err = kp * (c_k - prev) * m_k;
-                    err = (err > lim) ? lim : ((err < -lim) ? -lim : err);
-                    ns = ns - err;
-                    half = ns + hs;
-                    ns = ns + step;
-                    prev = c_k;
-                }
-                nout += K;
             }
-            // ---- flush staged symbols with coalesced stores
+            nout++;
+            {
+                T err = kp * (cur - prev) * mid;
+                err = (err > lim) ? lim : ((err < -lim) ? -lim : err);
+                ns = ns - err;
+                q_last = ns;
+                half = ns + hs;   // == (T)((double)ns + (double)step/2.0): that double sum is exact
+                ns = ns + step;
+                prev = cur;
+                i_last = i_abs;
+            }
+            // ---- check-free batch
+            const T room = (T)lim_idx - (T)2 - ns;
+            int K = (room > (T)0) ? (int)(room / adv) : 0;
+            K = uniform<int>(K);
+            if (K > OUT - nout) K = OUT - nout;
+            const T wb = (T)wbase;
+            T *ov = o_val + nout;
+            unsigned *oi = o_idx + nout;
+            for (int k = 0; k < K; k++) {
+                const T rnk = Real<T>::rint(ns);
+                const T rhk = Real<T>::rint(half);
+                const T c_k = win[(int)(rnk - wb)];
+                const T m_k = win[(int)(rhk - wb)];
+                i_last = (unsigned)rnk;
+                if (EMIT) {
+                    ov[k] = c_k;
+                    oi[k] = i_last;
+                }
+                T err = kp * (c_k - prev) * m_k;
+                err = (err > lim) ? lim : ((err < -lim) ? -lim : err);
+                ns = ns - err;
+                q_last = ns;
+                half = ns + hs;
+                ns = ns + step;
+                prev = c_k;
+            }
+            nout += K;
+        }
+        // ---- flush staged symbols with coalesced stores
+        if (EMIT) {
             __syncthreads();
             for (int t = lane; t < nout; t += PDT_GARDNER_THREADS) {
                 const long long k = count + t;
@@ -203,19 +193,63 @@ __global__ void __launch_bounds__(PDT_GARDNER_THREADS) k_gardner(const T *__rest
                     symidx[k] = base + (long long)o_idx[t];
                 }
             }
-            count += nout;
-            if (!chunk_done) {
-                const unsigned cur_i = uniform<unsigned>((unsigned)Real<T>::rint(ns));
-                if (cur_i - wbase >= (unsigned)LEN) wbase = (cur_i > 64u) ? cur_i - 64u : 0u;   // keep the mid-point in view
-            }
         }
-        ns = ns - nT;                              // roll over; `half` is deliberately not (Q3)
+        count += nout;
+        if (!chunk_done) {
+            const unsigned cur_i = uniform<unsigned>((unsigned)Real<T>::rint(ns));
+            if (cur_i - wbase >= (unsigned)LEN) wbase = (cur_i > 64u) ? cur_i - 64u : 0u;   // keep the mid-point in view
+        }
     }
-    if (lane == 0 && (!entries || c_end == n_chunks)) *nsym_out = (unsigned long long)count;
+    S.ns = ns - nT;                                // roll over; `half` is deliberately not (Q3)
+    S.prev = prev;
+    S.half = half;
+    S.q_last = q_last;
+    S.i_last = i_last;
+    return count - count0;
+}
+
+// entry state of one reference chunk, produced by k_gardner_chain for the parallel path
+template <typename T> struct GardnerEntry {
+    T ns, prev, half;
+    long long offset;        // symbols emitted before this chunk
+};
+
+// sequential mode (entries == nullptr): one wavefront walks every chunk in order.
+// parallel mode: block b owns chunk b and starts from the tabulated entry state.
+template <typename T>
+__global__ void __launch_bounds__(PDT_GARDNER_THREADS) k_gardner(const T *__restrict__ in, const T *__restrict__ lock,
+                                                                  GardnerParams<T> P, T *__restrict__ sym,
+                                                                  long long *__restrict__ symidx,
+                                                                  unsigned long long *__restrict__ nsym_out,
+                                                                  long long sym_cap,
+                                                                  const GardnerEntry<T> *__restrict__ entries)
+{
+    __shared__ T win[GardnerLds<T>::LEN];
+    __shared__ T o_val[GardnerLds<T>::OUT];
+    __shared__ unsigned o_idx[GardnerLds<T>::OUT];
+    const long long C = P.chunk_out;
+    const long long n_chunks = (P.n_total + C - 1) / C;
+    GardnerState<T> S;
+    S.ns = 0; S.prev = 0; S.half = 0; S.q_last = 0; S.i_last = 0;
+    long long count = 0;
+    long long c_begin = 0, c_end = n_chunks;
+    if (entries) {
+        c_begin = blockIdx.x;
+        c_end = c_begin + 1;
+        if (c_begin >= n_chunks) return;
+        const GardnerEntry<T> e = entries[c_begin];
+        S.ns = e.ns;
+        S.prev = e.prev;
+        S.half = e.half;
+        count = e.offset;
+    }
+    for (long long c = c_begin; c < c_end; c++)
+        count += gardner_walk_chunk<T, true>(in, lock, P, c, S, win, o_val, o_idx, sym, symidx, count, sym_cap);
+    if (threadIdx.x == 0 && (!entries || c_end == n_chunks)) *nsym_out = (unsigned long long)count;
 }
 
 // ------------------------------------------------------------------------------------------
-// Exact parallel Gardner ("state table" method, float only)
+// Exact parallel Gardner ("boundary-state table" method, float only)
 //
 // The sampler state that crosses a chunk boundary is (ns, prev, half).  All three are functions
 // of q = the sampling instant of the chunk's last symbol after the error correction and before
@@ -224,22 +258,29 @@ __global__ void __launch_bounds__(PDT_GARDNER_THREADS) k_gardner(const T *__rest
 // [n - step - 0.6, n - 0.4), a single float binade for the usual chunk sizes, so q takes only
 // (step + ~1.5)/ulp distinct values (4.7 k for n = 30000): the set of *possible* boundary states
 // is small and known in advance, although which one occurs depends on the whole past.
-//   level 1  (parallel over chunks x candidate states): run every full chunk from every
-//            candidate entry state; record the exit state's index and the symbol count;
-//   level 2  (one lane): follow the true chain  k_{c+1} = table_c[k_c]  from the known start;
-//   level 3  (parallel over chunks): re-run each chunk from its now known entry state and
-//            emit its symbols at the prefix-summed offset (k_gardner in parallel mode).
+//   level 1  (parallel over chunks x candidate states): run every full chunk from candidate
+//            entry states; record the exit state's index and the symbol count.  Only the
+//            consistent (q, last-pick) combinations are enumerated, and when 64 scout
+//            trajectories started at spread-out phases over the tail of the previous chunk all
+//            end within one sample of each other (the timing loop is locked) only the
+//            candidates around that instant are run;
+//   level 2  (one wavefront): follow the true chain  k_{c+1} = table_c[k_c]  from the known
+//            start; a state that was not tabulated (outside the scouts' band) is simply walked;
+//   level 3  (parallel over chunks): re-run each chunk from its now known entry state and emit
+//            its symbols at the prefix-summed offset (k_gardner in parallel mode).
 // Every float operation of the true trajectory is executed exactly as in the sequential loop,
-// so the result is bit-identical by construction; a table index outside the candidate range
-// raises a flag and the host falls back to the sequential kernel.
+// so the result is bit-identical by construction.
 // ------------------------------------------------------------------------------------------
 struct GardnerDomain {
     float q_min;       // smallest candidate q (multiple of u)
     float u;           // grid spacing (ulp of the binade that contains the chunk end)
-    int n_q;           // number of q values; candidates = 2 * n_q (two choices of the last pick)
+    int n_q;           // number of q values; table row = 2 * n_q cells (two choices of the last pick)
+    int n_cand;        // consistent (q, pick) combinations, listed in cand_k in increasing q
 };
 
 #define PDT_GTAB_THREADS 1024
+#define PDT_GTAB_TAIL 8192           // samples of the previous chunk the scouts run over
+#define PDT_GTAB_MISS 0xffffffffu    // cell not tabulated
 
 __device__ __forceinline__ void gardner_entry_from_candidate(const float *__restrict__ in, const GardnerParams<float> &P,
                                                              const GardnerDomain &D, long long c, int k, float &ns,
@@ -255,13 +296,27 @@ __device__ __forceinline__ void gardner_entry_from_candidate(const float *__rest
     prev = in[(c - 1) * P.chunk_out + i_last];
 }
 
+// exit state -> table cell (20-bit candidate index | 12-bit symbol count); MISS if outside the domain
+__device__ __forceinline__ unsigned gardner_encode_exit(const GardnerDomain &D, float q_last, unsigned i_last, unsigned count)
+{
+    const float mf = (q_last - D.q_min) / D.u;               // exact small integer for in-domain states
+    const int m = (int)mf;
+    const int v = (int)i_last - (int)floorf(q_last);
+    const bool ok = (count > 0) && (mf == (float)m) && (m >= 0) && (m < D.n_q) && (v == 0 || v == 1) && (count < 4096u);
+    return ok ? (((unsigned)(2 * m + v)) | (count << 20)) : PDT_GTAB_MISS;
+}
+
 __global__ void __launch_bounds__(PDT_GTAB_THREADS) k_gardner_table(const float *__restrict__ in, GardnerParams<float> P,
                                                                      GardnerDomain D, long long n_tab_chunks,
+                                                                     const unsigned *__restrict__ cand_k,
+                                                                     const int *__restrict__ m_first,
                                                                      unsigned *__restrict__ table,
-                                                                     unsigned *__restrict__ bad)
+                                                                     unsigned *__restrict__ stats /* [0] bad [1] full-domain chunks */)
 {
-    constexpr int LEN = GardnerLds<float>::LEN + GardnerLds<float>::OUT * 2;      // the whole 160 KiB budget as window
+    constexpr int LEN = GardnerLds<float>::LEN + GardnerLds<float>::OUT * 2 - PDT_GTAB_TAIL - 64;
     __shared__ float win[LEN];
+    __shared__ float tail[PDT_GTAB_TAIL];
+    __shared__ int s_mmin, s_mmax;
     const long long c = blockIdx.x;                 // chunk (always a full one)
     if (c >= n_tab_chunks) return;
     const long long C = P.chunk_out;
@@ -271,65 +326,165 @@ __global__ void __launch_bounds__(PDT_GTAB_THREADS) k_gardner_table(const float 
     if (n_stage > LEN) n_stage = LEN;               // host guarantees n_cur + margin <= LEN
     for (int t = threadIdx.x; t < n_stage; t += PDT_GTAB_THREADS)
         win[t] = (t < n_cur) ? in[base + t] : gardner_beyond(in, (const float *)nullptr, P, c, (long long)n_cur, (long long)t);
+    const int tail_n = (C < PDT_GTAB_TAIL) ? (int)C : PDT_GTAB_TAIL;
+    if (c >= 1)
+        for (int t = threadIdx.x; t < tail_n; t += PDT_GTAB_THREADS) tail[t] = in[base - tail_n + t];
+    if (threadIdx.x == 0) { s_mmin = 0x7fffffff; s_mmax = -0x7fffffff; }
+    unsigned *row = table + (size_t)c * (size_t)(2 * D.n_q);
+    for (int t = threadIdx.x; t < 2 * D.n_q; t += PDT_GTAB_THREADS) row[t] = PDT_GTAB_MISS;
     __syncthreads();
     const float hs = (float)((double)P.step / 2.0);
     const float kp = P.kp, lim = P.lim, step = P.step, nT = (float)n_cur;
-    const int ncand = (c == 0) ? 1 : 2 * D.n_q;
-    unsigned *row = table + (size_t)c * (size_t)(2 * D.n_q);
-    for (int k = threadIdx.x; k < ncand; k += PDT_GTAB_THREADS) {
+
+    // ---- scouts: 64 trajectories over the tail of chunk c-1, started one 64th of a symbol apart
+    int j_lo = 0, j_hi = (c == 0) ? 1 : D.n_cand;
+    if (c >= 1) {
+        if (threadIdx.x < 64) {
+            const float t0 = (float)(n_cur - tail_n);
+            float ns = t0 + 8.0f + step * (float)threadIdx.x * (1.0f / 64.0f);
+            float prev = 0, half = ns - hs, q_last = ns;
+            for (;;) {
+                const float rn = __builtin_rintf(ns);
+                if (!(rn < nT)) break;
+                const int i_cur = (int)(rn - t0);
+                int i_half = (int)(__builtin_rintf(half) - t0);
+                i_half = (i_half < 0) ? 0 : i_half;
+                const float cur = tail[i_cur];
+                const float mid = tail[(i_half < tail_n) ? i_half : tail_n - 1];
+                float err = kp * (cur - prev) * mid;
+                err = (err > lim) ? lim : ((err < -lim) ? -lim : err);
+                ns = ns - err;
+                q_last = ns;
+                half = ns + hs;
+                ns = ns + step;
+                prev = cur;
+            }
+            const int m = (int)floorf((q_last - D.q_min) / D.u);
+            atomicMin(&s_mmin, m);
+            atomicMax(&s_mmax, m);
+        }
+        __syncthreads();
+        const int one = (int)(1.0f / D.u);                        // grid points per sample
+        const int spread = s_mmax - s_mmin;
+        if (spread <= one && s_mmin >= 0 && s_mmax < D.n_q) {     // locked: candidates within +-1 sample of the scouts
+            int m_lo = s_mmin - one / 2, m_hi = s_mmax + one / 2;
+            m_lo = (m_lo < 0) ? 0 : m_lo;
+            m_hi = (m_hi > D.n_q - 1) ? D.n_q - 1 : m_hi;
+            j_lo = m_first[m_lo];
+            j_hi = m_first[m_hi + 1];
+        } else if (threadIdx.x == 0) {
+            atomicAdd(&stats[1], 1u);
+        }
+    }
+
+    // ---- candidates.  Every trajectory takes at least k_min steps before it can reach the end
+    // of the chunk (a step advances by at most step + 0.1 and entry instants are < step + 1), so
+    // the bulk of the walk is a counted, wave-uniform loop without any per-lane test; only the
+    // first symbol (stale mid-point index, Q3) and the last few are handled with checks.
+    int k_min = (int)((nT - 4.0f - (step + 1.2f)) / (step + 0.101f)) - 1;
+    if (k_min < 0) k_min = 0;
+    for (int j = j_lo + (int)threadIdx.x; j < j_hi; j += PDT_GTAB_THREADS) {
         float ns, prev, half;
+        int k = 0;
         if (c == 0) { ns = 0; prev = 0; half = 0; }
-        else gardner_entry_from_candidate(in, P, D, c, k, ns, prev, half);
+        else {
+            k = (int)cand_k[j];
+            gardner_entry_from_candidate(in, P, D, c, k, ns, prev, half);
+        }
         float q_last = 0;
         unsigned i_last = 0, count = 0;
-        for (;;) {
+        // first symbol: the mid-point index is the stale one of the previous chunk
+        {
             const float rn = __builtin_rintf(ns);
-            if (!(rn < nT)) break;
-            const unsigned i_cur = (unsigned)rn;
-            const unsigned i_half = (unsigned)__builtin_rintf(half);
-            const float cur = win[i_cur];
-            const float mid = (i_half < (unsigned)n_stage) ? win[i_half] : 0.0f;
-            float err = kp * (cur - prev) * mid;
-            err = (err > lim) ? lim : ((err < -lim) ? -lim : err);
-            ns = ns - err;
-            q_last = ns;
-            half = ns + hs;
-            ns = ns + step;
-            prev = cur;
-            i_last = i_cur;
-            count++;
+            if (rn < nT) {
+                const unsigned i_cur = (unsigned)rn;
+                const unsigned i_half = (unsigned)__builtin_rintf(half);
+                const float cur = win[i_cur];
+                const float mid = (i_half < (unsigned)n_stage) ? win[i_half] : 0.0f;
+                const float err = __builtin_amdgcn_fmed3f(kp * (cur - prev) * mid, -lim, lim);
+                ns = ns - err;
+                q_last = ns;
+                half = ns + hs;
+                ns = ns + step;
+                prev = cur;
+                i_last = i_cur;
+                count = 1;
+            }
         }
-        // encode the exit state
-        const float mf = (q_last - D.q_min) / D.u;           // exact small integer for in-domain states
-        const int m = (int)mf;
-        const int v = (int)i_last - (int)floorf(q_last);
-        unsigned ok = (count > 0) && (mf == (float)m) && (m >= 0) && (m < D.n_q) && (v == 0 || v == 1) && (count < 4096u);
-        // the stale mid-point of the first symbol must have been inside the staged window
-        if (!ok) atomicAdd(bad, 1u);
-        row[k] = ok ? (((unsigned)(2 * m + v)) | (count << 20)) : 0xffffffffu;    // 20-bit index, 12-bit count
+        if (count == 1) {
+            for (int it = 1; it < k_min; it++) {
+                const float cur = win[(unsigned)__builtin_rintf(ns)];
+                const float mid = win[(unsigned)__builtin_rintf(half)];
+                const float err = __builtin_amdgcn_fmed3f(kp * (cur - prev) * mid, -lim, lim);
+                ns = ns - err;
+                half = ns + hs;
+                ns = ns + step;
+                prev = cur;
+            }
+            if (k_min > 1) count = (unsigned)k_min;
+            for (;;) {
+                const float rn = __builtin_rintf(ns);
+                if (!(rn < nT)) break;
+                const unsigned i_cur = (unsigned)rn;
+                const float cur = win[i_cur];
+                const float mid = win[(unsigned)__builtin_rintf(half)];
+                const float err = __builtin_amdgcn_fmed3f(kp * (cur - prev) * mid, -lim, lim);
+                ns = ns - err;
+                q_last = ns;
+                half = ns + hs;
+                ns = ns + step;
+                prev = cur;
+                i_last = i_cur;
+                count++;
+            }
+        }
+        const unsigned cell = gardner_encode_exit(D, q_last, i_last, count);
+        if (cell == PDT_GTAB_MISS) atomicAdd(&stats[0], 1u);      // exit outside the enumerated domain (never expected)
+        row[k] = cell;
     }
 }
 
-// level 2: follow the chain of tables; one lane.  entries[c] for every chunk, incl. the last.
-__global__ void k_gardner_chain(const float *__restrict__ in, GardnerParams<float> P, GardnerDomain D, long long n_chunks,
-                                const unsigned *__restrict__ table, GardnerEntry<float> *__restrict__ entries,
-                                unsigned *__restrict__ bad)
+// level 2: follow the chain of tables with one wavefront; walk the chunk when its entry state
+// was not tabulated.  Writes entries[c] for every chunk, including the last.
+__global__ void __launch_bounds__(PDT_GARDNER_THREADS) k_gardner_chain(const float *__restrict__ in, GardnerParams<float> P,
+                                                                        GardnerDomain D, long long n_chunks,
+                                                                        const unsigned *__restrict__ table,
+                                                                        GardnerEntry<float> *__restrict__ entries,
+                                                                        unsigned *__restrict__ stats /* [2] walked chunks */)
 {
-    if (threadIdx.x != 0 || blockIdx.x != 0) return;
-    GardnerEntry<float> e;
-    e.ns = 0; e.prev = 0; e.half = 0; e.offset = 0;
-    entries[0] = e;
+    __shared__ float win[GardnerLds<float>::LEN];
+    GardnerState<float> S;
+    S.ns = 0; S.prev = 0; S.half = 0; S.q_last = 0; S.i_last = 0;
     long long off = 0;
+    unsigned walked = 0;
     unsigned cell = (n_chunks > 1) ? table[0] : 0u;            // chunk 0 has a single candidate
-    for (long long c = 1; c < n_chunks; c++) {
-        if (cell == 0xffffffffu) { atomicAdd(bad, 1u); return; }
+    for (long long c = 0; c < n_chunks; c++) {
+        if (threadIdx.x == 0) {
+            GardnerEntry<float> e;
+            e.ns = S.ns; e.prev = S.prev; e.half = S.half; e.offset = off;
+            entries[c] = e;
+        }
+        if (c + 1 >= n_chunks) break;
+        // cell = table_c[entry state of chunk c]  (or MISS)
+        cell = uniform<unsigned>(cell);
+        if (cell == PDT_GTAB_MISS) {
+            const long long cnt = gardner_walk_chunk<float, false>(in, (const float *)nullptr, P, c, S, win, (float *)nullptr,
+                                                                    (unsigned *)nullptr, (float *)nullptr, (long long *)nullptr,
+                                                                    0, 0);
+            cell = gardner_encode_exit(D, S.q_last, S.i_last, (unsigned)cnt);
+            walked++;
+            if (cell == PDT_GTAB_MISS) {
+                // the exit is not a tabulated boundary state (irregular geometry): keep walking
+                off += cnt;
+                continue;
+            }
+        }
         const int k = (int)(cell & 0xfffffu);
         off += (long long)(cell >> 20);
-        gardner_entry_from_candidate(in, P, D, c, k, e.ns, e.prev, e.half);
-        e.offset = off;
-        entries[c] = e;
-        if (c + 1 < n_chunks) cell = table[(size_t)c * (size_t)(2 * D.n_q) + (size_t)k];
+        gardner_entry_from_candidate(in, P, D, c + 1, k, S.ns, S.prev, S.half);
+        if (c + 2 < n_chunks) cell = table[(size_t)(c + 1) * (size_t)(2 * D.n_q) + (size_t)k];
     }
+    if (threadIdx.x == 0) stats[2] = walked;
 }
 
 // ------------------------------------------------------------------------------------------
