@@ -68,22 +68,34 @@ def lib():
         L.orc_arctan2_f32.restype = C.c_float
         L.orc_make_lpf_f32.argtypes = [C.c_void_p, C.c_int, C.c_float, C.c_float, C.c_int]
         L.orc_make_lpf_f64.argtypes = [C.c_void_p, C.c_int, C.c_double, C.c_double, C.c_int]
+        L.orc_set_math_mode.argtypes = [C.c_int]
+        L.orc_set_math_mode.restype = None
+        L.orc_sincos_portable.argtypes = [C.c_double, C.POINTER(C.c_double), C.POINTER(C.c_double)]
+        L.orc_sincos_portable.restype = None
         _lib = L
     return _lib
 
 
+MATH_LIBM, MATH_PORTABLE = 0, 1
+
+
 class Oracle:
-    """Run the CPU restatement over a whole capture (int16[n,2])."""
+    """Run the CPU restatement over a whole capture (int16[n,2]).
+
+    math_mode (ARGOS/double only): MATH_LIBM = glibc sincos/hypot (bit-identical to the reference
+    objects), MATH_PORTABLE = the plain-double evaluation the HIP kernels use."""
 
     def __init__(self, mode: int, sample_rate: int, iq: np.ndarray, chunk: int = 0, norm_override: float = 0.0,
-                 keep_stages: bool = True):
+                 keep_stages: bool = True, math_mode: int = MATH_LIBM):
         L = lib()
+        L.orc_set_math_mode(math_mode)
         self._L = L
         self.mode = mode
         self.dtype = np.float64 if mode == ARGOS else np.float32
         self._h = L.orc_open(mode, sample_rate, chunk, norm_override, int(keep_stages))
         a = np.ascontiguousarray(iq, dtype="<i2").reshape(-1)
         L.orc_run_pcm16(self._h, a.ctypes.data, a.size // 2)
+        L.orc_set_math_mode(MATH_LIBM)
 
     def __del__(self):
         if getattr(self, "_h", None):

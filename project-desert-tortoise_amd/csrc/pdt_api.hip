@@ -731,10 +731,7 @@ static int demod_common(pdt_ctx *ctx, uint64_t nframes)
     HIP_TRY(hipSetDevice(ctx->cfg.device));
     ctx->n_samples = nframes;
     ctx->n_out = nframes * ctx->interp;
-    if (ctx->cfg.mode == PDT_MODE_ARGOS) {
-        fprintf(stderr, "libpdt: ARGOS (double) device path not built yet\n");
-        return PDT_ERR_ARG;
-    }
+    if (ctx->cfg.mode == PDT_MODE_ARGOS) return run_capture<double>(ctx, nframes);
     return run_capture<float>(ctx, nframes);
 }
 

@@ -114,7 +114,53 @@ __device__ __forceinline__ float hypotf_glibc(float x, float y)
     return (float)__builtin_sqrt((double)x * (double)x + (double)y * (double)y);
 }
 
+// ---- double-precision sine/cosine for the ARGOS chain: plain IEEE double operations only
+// (Cody-Waite reduction by pi/2 in two steps, fdlibm/musl minimax kernels).  The reference calls
+// glibc's table-driven sincos() here (CarrierTrackingPLL.c:134-135); this evaluation differs from
+// it in the last bit of ~3% of arguments, which the contracting stages absorb -- the oracle has a
+// matching "portable" mode that is checked against the reference's bit/packet output.
+__device__ __forceinline__ double ksin_d(double x, double y)
+{
+    const double S1 = -1.66666666666666324348e-01, S2 = 8.33333333332248946124e-03, S3 = -1.98412698298579493134e-04,
+                 S4 = 2.75573137070700676789e-06, S5 = -2.50507602534068634195e-08, S6 = 1.58969099521155010221e-10;
+    const double z = x * x, w = z * z;
+    const double r = S2 + z * (S3 + z * S4) + z * w * (S5 + z * S6);
+    const double v = z * x;
+    return x - ((z * (0.5 * y - v * r) - y) - v * S1);
+}
+__device__ __forceinline__ double kcos_d(double x, double y)
+{
+    const double C1 = 4.16666666666666019037e-02, C2 = -1.38888888888741095749e-03, C3 = 2.48015872894767294178e-05,
+                 C4 = -2.75573143513906633035e-07, C5 = 2.08757232129817482790e-09, C6 = -1.13596475577881948265e-11;
+    const double z = x * x, w0 = z * z;
+    const double r = z * (C1 + z * (C2 + z * C3)) + (w0 * w0) * (C4 + z * (C5 + z * C6));
+    const double hz = 0.5 * z;
+    const double w = 1.0 - hz;
+    return w + (((1.0 - w) - hz) + (z * r - x * y));
+}
+__device__ __forceinline__ void sincos_portable(double x, double &sv, double &cv)
+{
+    const double fn = __builtin_rint(x * 6.36619772367581382433e-01);
+    const int n = (int)fn;
+    const double t2 = x - fn * 1.57079632673412561417e+00;
+    double w = fn * 6.07710050630396597660e-11;
+    const double t = t2 - w;
+    w = fn * 2.02226624879595063154e-21 - ((t2 - t) - w);
+    const double y0 = t - w;
+    const double y1 = (t - y0) - w;
+    const double s = ksin_d(y0, y1), c = kcos_d(y0, y1);
+    const int q = n & 3;
+    sv = (q == 0) ? s : ((q == 1) ? c : ((q == 2) ? -s : -c));
+    cv = (q == 0) ? c : ((q == 1) ? -s : ((q == 2) ? -c : s));
+}
+
 template <typename T> struct Real;
+template <> struct Real<double> {
+    static __device__ __forceinline__ double abs(double v) { return __builtin_fabs(v); }
+    static __device__ __forceinline__ double rint(double v) { return __builtin_rint(v); }
+    static __device__ __forceinline__ void sincos(double p, double &s, double &c) { sincos_portable(p, s, c); }
+    static __device__ __forceinline__ double hypot(double x, double y) { return __builtin_sqrt(x * x + y * y); }
+};
 template <> struct Real<float> {
     static __device__ __forceinline__ float abs(float v) { return __builtin_fabsf(v); }
     static __device__ __forceinline__ float rint(float v) { return __builtin_rintf(v); }

@@ -51,6 +51,15 @@ template <> struct IqSample<float> {
     }
 };
 
+template <> struct IqSample<double> {
+    static __device__ __forceinline__ void get(const int *pcm, long long i, double &a, double &b)
+    {
+        const int v = pcm[i];
+        a = (double)(short)(v & 0xffff) / 32768.0;
+        b = (double)(short)(v >> 16) / 32768.0;
+    }
+};
+
 // shared part of one PLL iteration: mix, error, loop update, wrap, clamp (:106-188)
 template <typename T>
 __device__ __forceinline__ void pll_core(T a, T b, T &phase, T &freq, T alpha, T beta, T maxf, T minf, T &o_re, T &o_im,

@@ -88,3 +88,30 @@ def test_noise_only_no_frames(orc, tmp_path, pdt):
     o = orc.Oracle(orc.POES, 50000, iq)
     compare_all(o, dump)
     assert o.text() == text
+
+
+@pytest.mark.parametrize("seed,f0,secs,chunk", [(99, 120.0, 13.0, 2400), (12, -90.0, 20.0, 1000), (13, 60.0, 24.0, 2401),
+                                                (14, 199.0, 16.0, 4800)])
+def test_argos_portable_math_keeps_the_reference_output(orc, pdt, tmp_path, seed, f0, secs, chunk):
+    """The GPU evaluates the double sine/cosine with plain IEEE operations instead of glibc's
+    table-driven routine.  The oracle's matching "portable" mode must still reproduce the
+    reference's symbol picks, bits and packet file exactly (the float streams differ in last bits)."""
+    iq = pdt.synth_capture(1, 32000, secs, f0_hz=f0, seed=seed)
+    wav = tmp_path / "a.wav"
+    pdt.write_wav(str(wav), 32000, iq)
+    text, dump = run_ref(REF_ARGOS, wav, tmp_path, ["-c", str(chunk)])
+    o = orc.Oracle(orc.ARGOS, 32000, iq, chunk=chunk, math_mode=orc.MATH_PORTABLE)
+    assert o.text() == text and len(text) > 0
+    assert o.stage(orc.ST_BITS).tobytes() == open(f"{dump}.bits", "rb").read()
+    ref_sym = np.fromfile(f"{dump}.sym", dtype=np.float64)
+    sym = o.stage(orc.ST_SYM)
+    assert len(sym) == len(ref_sym)
+    assert np.allclose(sym, ref_sym, rtol=1e-9, atol=1e-12)          # same picks, last-bit differences only
+    # and the portable sine/cosine itself is a <1 ulp evaluation
+    import ctypes as C, math
+    s, c = C.c_double(), C.c_double()
+    rng = np.random.default_rng(0)
+    for x in rng.uniform(-2 * np.pi, 2 * np.pi, 20000):
+        orc.lib().orc_sincos_portable(float(x), C.byref(s), C.byref(c))
+        assert abs(s.value - math.sin(x)) <= 1.2e-16 * max(abs(math.sin(x)), 1e-300) * 2 or abs(s.value - math.sin(x)) < 2.3e-16
+        assert abs(c.value - math.cos(x)) < 2.3e-16

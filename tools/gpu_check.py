@@ -30,7 +30,7 @@ def compare(name, a, b):
 def run(label, mode, rate, iq, chunk=0, **kw):
     print(f"== {label}: {len(iq)} samples @ {rate} Hz chunk {chunk or 'default'}")
     t0 = time.time()
-    o = orc.Oracle(mode, rate, iq, chunk=chunk)
+    o = orc.Oracle(mode, rate, iq, chunk=chunk, math_mode=orc.MATH_PORTABLE)
     t1 = time.time()
     d = pdt.Demodulator(mode, rate, chunk=chunk, profile=True, **kw)
     d.demod(iq)
@@ -43,6 +43,8 @@ def run(label, mode, rate, iq, chunk=0, **kw):
     print(f"  pll blocks {s.pll_blocks} fixes {s.pll_seam_fixes}; agc blocks {s.agc_blocks} fixes {s.agc_seam_fixes}; sym {s.symbols} bits {s.bits} frames {s.frames} gardner_parallel {s.gardner_parallel} walked {s.reserved & 0xffff} fulldomain {s.reserved >> 16}")
     ok = True
     ok &= compare("pll", d.stage(pdt.ST_PLL), o.stage(orc.ST_PLL))
+    if mode == pdt.MODE_ARGOS:
+        ok &= compare("lock", d.stage(pdt.ST_LOCK), o.stage(orc.ST_LOCK))
     ok &= compare("fir", d.stage(pdt.ST_FIR), o.stage(orc.ST_FIR))
     ok &= compare("agc", d.stage(pdt.ST_AGC), o.stage(orc.ST_AGC))
     ok &= compare("sym", d.stage(pdt.ST_SYM), o.stage(orc.ST_SYM))
@@ -67,5 +69,8 @@ if __name__ == "__main__":
     for fs, secs in ((50000, 6.0), (250000, 6.0), (18750, 6.0), (50000, 60.0)):
         iq = pdt.synth_capture(0, fs, secs)
         allok &= run(f"synth {fs} {secs}s", pdt.MODE_POES, fs, iq)
+    for seed, f0, secs, chunk in ((99, 120.0, 13.0, 0), (12, -90.0, 20.0, 1000), (13, 60.0, 30.0, 2401)):
+        iq = pdt.synth_capture(1, 32000, secs, f0_hz=f0, seed=seed)
+        allok &= run(f"argos seed {seed} chunk {chunk}", pdt.MODE_ARGOS, 32000, iq, chunk=chunk)
     print("ALL OK" if allok else "FAILURES")
     sys.exit(0 if allok else 1)
