@@ -230,10 +230,10 @@ template <typename T> int run_capture(pdt_ctx *ctx, uint64_t n)
     // ---- block-parallel geometry (any values give the same output; they only move time around)
     const double fs_d = (double)ctx->cfg.sample_rate;
     auto round4 = [](long long v) { return (v + 3) / 4 * 4; };
-    long long Bp = ctx->cfg.pll_block ? ctx->cfg.pll_block : (long long)((argos ? 4.0 : 0.2) * fs_d);
+    long long Bp = ctx->cfg.pll_block ? ctx->cfg.pll_block : (long long)((argos ? 4.0 : 0.1) * fs_d);
     long long Wp = ctx->cfg.pll_warm ? ctx->cfg.pll_warm : (long long)((argos ? 8.0 : 0.3) * fs_d);
     long long Wacq = (long long)(0.02 * fs_d);             // acquisition-gain stage of the warm-up
-    long long Ba = ctx->cfg.agc_block ? ctx->cfg.agc_block : (long long)((argos ? 4.0 : 0.5) * fs_d * interp);
+    long long Ba = ctx->cfg.agc_block ? ctx->cfg.agc_block : (long long)((argos ? 4.0 : 0.125) * fs_d * interp);
     long long Wa = ctx->cfg.agc_warm ? ctx->cfg.agc_warm : (long long)((argos ? 8.0 : 1.0) * fs_d * interp);
     Bp = std::max<long long>(64, round4(Bp));
     Ba = std::max<long long>(64, round4(Ba));
@@ -316,13 +316,25 @@ template <typename T> int run_capture(pdt_ctx *ctx, uint64_t n)
     L.end();
     if (N > 0) {
         const long long grid = (nb_pll + 63) / 64;
+        // a single +-2pi correction per step is exact as long as one step cannot move the phase by 2pi
+        const double worst = (double)PP.max_freq + M_PI * std::max((double)PP.alpha_acq + (double)PP.beta_acq,
+                                                                   (double)PP.alpha_trk + (double)PP.beta_trk);
+        const bool slow_wrap = worst >= 2.0 * M_PI - 0.05;
         L.begin("pll_phase");
-        hipLaunchKernelGGL(k_pll_phase<T>, dim3((unsigned)grid), dim3(64), 0, st, d_pcm, d_theta, N, PP, d_info, Bp, Wacq, Wp,
-                           lag, d_phi, (PllSeam<T> *)ctx->seams_pll.p);
+        if (slow_wrap)
+            hipLaunchKernelGGL((k_pll_phase<T, true>), dim3((unsigned)grid), dim3(64), 0, st, d_pcm, d_theta, N, PP, d_info, Bp,
+                               Wacq, Wp, lag, d_phi, (PllSeam<T> *)ctx->seams_pll.p);
+        else
+            hipLaunchKernelGGL((k_pll_phase<T, false>), dim3((unsigned)grid), dim3(64), 0, st, d_pcm, d_theta, N, PP, d_info, Bp,
+                               Wacq, Wp, lag, d_phi, (PllSeam<T> *)ctx->seams_pll.p);
         L.end();
         L.begin("pll_fix");
-        hipLaunchKernelGGL(k_pll_fix<T>, dim3(1), dim3(64), 0, st, d_theta, N, PP, d_info, Bp, d_phi,
-                           (PllSeam<T> *)ctx->seams_pll.p, d_sc->counters);
+        if (slow_wrap)
+            hipLaunchKernelGGL((k_pll_fix<T, true>), dim3(1), dim3(64), 0, st, d_theta, N, PP, d_info, Bp, d_phi,
+                               (PllSeam<T> *)ctx->seams_pll.p, d_sc->counters);
+        else
+            hipLaunchKernelGGL((k_pll_fix<T, false>), dim3(1), dim3(64), 0, st, d_theta, N, PP, d_info, Bp, d_phi,
+                               (PllSeam<T> *)ctx->seams_pll.p, d_sc->counters);
         L.end();
         L.begin("pll_mix");
         if (argos)
@@ -439,14 +451,15 @@ template <typename T> int run_capture(pdt_ctx *ctx, uint64_t n)
                                (const unsigned *)ctx->gtable.p, (GardnerEntry<float> *)ctx->gentries.p, d_sc->gstats);
             L.end();
             L.begin("gardner");
-            hipLaunchKernelGGL(k_gardner<float>, dim3((unsigned)n_chunks), dim3(PDT_GARDNER_THREADS), 0, st, (const float *)d_agc,
+            // per-chunk emission: small LDS windows so that four chunks share a CU
+            hipLaunchKernelGGL((k_gardner<float, 8192, 1024>), dim3((unsigned)n_chunks), dim3(PDT_GARDNER_THREADS), 0, st, (const float *)d_agc,
                                (const float *)d_lock, GP, (float *)d_sym, d_symidx, &d_sc->nsym, sym_cap,
                                (const GardnerEntry<float> *)ctx->gentries.p);
             L.end();
         }
     } else {
         L.begin("gardner");
-        hipLaunchKernelGGL(k_gardner<T>, dim3(1), dim3(PDT_GARDNER_THREADS), 0, st, d_agc, d_lock, GP, d_sym, d_symidx,
+        hipLaunchKernelGGL((k_gardner<T, GardnerLds<T>::LEN, GardnerLds<T>::OUT>), dim3(1), dim3(PDT_GARDNER_THREADS), 0, st, d_agc, d_lock, GP, d_sym, d_symidx,
                            &d_sc->nsym, sym_cap, (const GardnerEntry<T> *)nullptr);
         L.end();
     }

@@ -77,14 +77,12 @@ template <typename T> struct GardnerState {
 // length is the number of steps that provably stay inside the chunk, the LDS window and the
 // staging buffer: a step advances the sampling instant by at most step + 0.1.
 // Returns the number of symbols of the chunk; EMIT stores them at sym[count0...].
-template <typename T, bool EMIT>
+template <typename T, bool EMIT, int LEN, int OUT>
 __device__ __forceinline__ long long gardner_walk_chunk(const T *__restrict__ in, const T *__restrict__ lock,
                                                         const GardnerParams<T> &P, long long c, GardnerState<T> &S, T *win,
                                                         T *o_val, unsigned *o_idx, T *__restrict__ sym,
                                                         long long *__restrict__ symidx, long long count0, long long sym_cap)
 {
-    constexpr int LEN = GardnerLds<T>::LEN;
-    constexpr int OUT = GardnerLds<T>::OUT;
     const int lane = threadIdx.x;
     T ns = S.ns, prev = S.prev, half = S.half, q_last = S.q_last;
     unsigned i_last = S.i_last;
@@ -216,7 +214,7 @@ template <typename T> struct GardnerEntry {
 
 // sequential mode (entries == nullptr): one wavefront walks every chunk in order.
 // parallel mode: block b owns chunk b and starts from the tabulated entry state.
-template <typename T>
+template <typename T, int LEN, int OUT>
 __global__ void __launch_bounds__(PDT_GARDNER_THREADS) k_gardner(const T *__restrict__ in, const T *__restrict__ lock,
                                                                   GardnerParams<T> P, T *__restrict__ sym,
                                                                   long long *__restrict__ symidx,
@@ -224,9 +222,9 @@ __global__ void __launch_bounds__(PDT_GARDNER_THREADS) k_gardner(const T *__rest
                                                                   long long sym_cap,
                                                                   const GardnerEntry<T> *__restrict__ entries)
 {
-    __shared__ T win[GardnerLds<T>::LEN];
-    __shared__ T o_val[GardnerLds<T>::OUT];
-    __shared__ unsigned o_idx[GardnerLds<T>::OUT];
+    __shared__ T win[LEN];
+    __shared__ T o_val[OUT];
+    __shared__ unsigned o_idx[OUT];
     const long long C = P.chunk_out;
     const long long n_chunks = (P.n_total + C - 1) / C;
     GardnerState<T> S;
@@ -244,7 +242,7 @@ __global__ void __launch_bounds__(PDT_GARDNER_THREADS) k_gardner(const T *__rest
         count = e.offset;
     }
     for (long long c = c_begin; c < c_end; c++)
-        count += gardner_walk_chunk<T, true>(in, lock, P, c, S, win, o_val, o_idx, sym, symidx, count, sym_cap);
+        count += gardner_walk_chunk<T, true, LEN, OUT>(in, lock, P, c, S, win, o_val, o_idx, sym, symidx, count, sym_cap);
     if (threadIdx.x == 0 && (!entries || c_end == n_chunks)) *nsym_out = (unsigned long long)count;
 }
 
@@ -468,7 +466,7 @@ __global__ void __launch_bounds__(PDT_GARDNER_THREADS) k_gardner_chain(const flo
         // cell = table_c[entry state of chunk c]  (or MISS)
         cell = uniform<unsigned>(cell);
         if (cell == PDT_GTAB_MISS) {
-            const long long cnt = gardner_walk_chunk<float, false>(in, (const float *)nullptr, P, c, S, win, (float *)nullptr,
+            const long long cnt = gardner_walk_chunk<float, false, GardnerLds<float>::LEN, GardnerLds<float>::OUT>(in, (const float *)nullptr, P, c, S, win, (float *)nullptr,
                                                                     (unsigned *)nullptr, (float *)nullptr, (long long *)nullptr,
                                                                     0, 0);
             cell = gardner_encode_exit(D, S.q_last, S.i_last, (unsigned)cnt);

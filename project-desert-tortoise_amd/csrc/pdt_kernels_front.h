@@ -185,30 +185,49 @@ template <> struct PiCmp<double> {
     static __device__ __forceinline__ bool lt_m2pi(double x) { return x < -2 * PDT_PI; }
 };
 
-// one step of the loop filter given theta (:165-188), branch-free on the hot path
-template <typename T> __device__ __forceinline__ void pll_phase_step(T th, T &phase, T &freq, T alpha, T beta, T maxf, T minf)
+// |x| against pi / 2pi with the reference's promoted comparison semantics (see PiCmp)
+template <typename T> struct PiAbs;
+template <> struct PiAbs<float> {
+    static __device__ __forceinline__ bool ge_pi(float x) { return __builtin_fabsf(x) >= 3.14159274101257324f; }
+    static __device__ __forceinline__ bool ge_2pi(float x) { return __builtin_fabsf(x) >= 6.28318548202514648f; }
+    static __device__ __forceinline__ float clamp(float v, float lo, float hi) { return __builtin_amdgcn_fmed3f(v, lo, hi); }
+};
+template <> struct PiAbs<double> {
+    static __device__ __forceinline__ bool ge_pi(double x) { return __builtin_fabs(x) > PDT_PI; }
+    static __device__ __forceinline__ bool ge_2pi(double x) { return __builtin_fabs(x) > 2 * PDT_PI; }
+    static __device__ __forceinline__ double clamp(double v, double lo, double hi) { return (v > hi) ? hi : ((v < lo) ? lo : v); }
+};
+
+// x -/+ 2pi evaluated in double and narrowed, exactly as the reference writes it
+// ("error = (..) - 2*M_PI" / "+ 2*M_PI", "d_phase - 2.0*M_PI" / "+ 2.0*M_PI"): the sign of the
+// correction is the opposite of the sign of x, so one f64 add serves both branches.
+template <typename T> __device__ __forceinline__ T unwrap_2pi(T x)
+{
+    const double off = __builtin_copysign(2.0 * PDT_PI, -(double)x);
+    T r = (T)((double)x + off);
+    asm volatile("" : "+v"(r));          // keep it a value (select below), not a re-branched computation
+    return r;
+}
+
+// one step of the loop filter given theta (:165-188), branch-free.
+// SLOW_WRAP keeps the reference's "while" wrap loops for loop gains so large that a single
+// +-2pi correction might not suffice (|freq| + alpha*pi + beta*pi >= 2pi); the host selects it.
+template <typename T, bool SLOW_WRAP = false>
+__device__ __forceinline__ void pll_phase_step(T th, T &phase, T &freq, T alpha, T beta, T maxf, T minf)
 {
     const T diff = th - phase;
-    const double dd = (double)diff;
-    const T e_dn = (T)(dd - 2 * PDT_PI);
-    const T e_up = (T)(dd + 2 * PDT_PI);
-    const T err = PiCmp<T>::gt_pi(diff) ? e_dn : (PiCmp<T>::lt_mpi(diff) ? e_up : diff);
+    const T wrapped = unwrap_2pi(diff);
+    const T err = PiAbs<T>::ge_pi(diff) ? wrapped : diff;
     const T f1 = freq + beta * err;
     T ph = phase + f1 + alpha * err;
-    {
-        const double dp = (double)ph;
-        const T w_dn = (T)(dp - 2.0 * PDT_PI);
-        const T w_up = (T)(dp + 2.0 * PDT_PI);
-        const bool hi = PiCmp<T>::gt_2pi(ph);
-        // the reference runs "while > 2pi" to completion before "while < -2pi"; one pass of each
-        // is all that can ever trigger (|increment| < 2pi), the loops below keep it exact anyway
-        ph = hi ? w_dn : ph;
+    const T phw = unwrap_2pi(ph);
+    ph = PiAbs<T>::ge_2pi(ph) ? phw : ph;
+    if (SLOW_WRAP) {
         while (PiCmp<T>::gt_2pi(ph)) ph = (T)((double)ph - 2.0 * PDT_PI);
-        ph = (!hi && PiCmp<T>::lt_m2pi(ph)) ? w_up : ph;
         while (PiCmp<T>::lt_m2pi(ph)) ph = (T)((double)ph + 2.0 * PDT_PI);
     }
     phase = ph;
-    freq = (f1 > maxf) ? maxf : ((f1 < minf) ? minf : f1);
+    freq = PiAbs<T>::clamp(f1, minf, maxf);
 }
 
 template <typename T> struct PllSeam {
@@ -225,7 +244,7 @@ template <typename T> struct alignas(16) Vec16 {
 
 // run the recurrence over [i0, i1), optionally storing the pre-update phase of every sample;
 // 16-byte vector loads/stores on the aligned body (each lane streams its own block)
-template <typename T, bool STORE>
+template <typename T, bool STORE, bool SLOW>
 __device__ __forceinline__ void pll_phase_range(const T *__restrict__ theta, T *__restrict__ phi, long long i0, long long i1,
                                                 T &phase, T &freq, T alpha, T beta, T maxf, T minf)
 {
@@ -233,7 +252,7 @@ __device__ __forceinline__ void pll_phase_range(const T *__restrict__ theta, T *
     long long i = i0;
     for (; i < i1 && (i % VN) != 0; i++) {
         if (STORE) phi[i] = phase;
-        pll_phase_step(theta[i], phase, freq, alpha, beta, maxf, minf);
+        pll_phase_step<T, SLOW>(theta[i], phase, freq, alpha, beta, maxf, minf);
     }
     // Software pipeline: PDT_PF vectors per lane are always in flight; each register set is
     // re-loaded right after it has been consumed and is next needed PDT_PF-1 vectors later, so the
@@ -255,7 +274,7 @@ __device__ __forceinline__ void pll_phase_range(const T *__restrict__ theta, T *
 #pragma unroll
                 for (int w = 0; w < VN; w++) {
                     pv.v[w] = phase;
-                    pll_phase_step(tv.v[w], phase, freq, alpha, beta, maxf, minf);
+                    pll_phase_step<T, SLOW>(tv.v[w], phase, freq, alpha, beta, maxf, minf);
                 }
                 if (STORE) *reinterpret_cast<Vec16<T> *>(phi + i + u * VN) = pv;
             }
@@ -267,13 +286,13 @@ __device__ __forceinline__ void pll_phase_range(const T *__restrict__ theta, T *
 #pragma unroll
         for (int w = 0; w < VN; w++) {
             pv.v[w] = phase;
-            pll_phase_step(tv.v[w], phase, freq, alpha, beta, maxf, minf);
+            pll_phase_step<T, SLOW>(tv.v[w], phase, freq, alpha, beta, maxf, minf);
         }
         if (STORE) *reinterpret_cast<Vec16<T> *>(phi + i) = pv;
     }
     for (; i < i1; i++) {
         if (STORE) phi[i] = phase;
-        pll_phase_step(theta[i], phase, freq, alpha, beta, maxf, minf);
+        pll_phase_step<T, SLOW>(theta[i], phase, freq, alpha, beta, maxf, minf);
     }
 }
 
@@ -333,7 +352,7 @@ __device__ __forceinline__ void pll_guess(const int *__restrict__ pcm, long long
 
 // Blocks are aligned to absolute multiples of B; block j covers [max(S, j*B), min(n, (j+1)*B)).
 // Warm-up = [acquisition-gain stage of Wacq samples] + [tracking-gain stage of Wtrk samples].
-template <typename T>
+template <typename T, bool SLOW>
 __global__ void __launch_bounds__(64) k_pll_phase(const int *__restrict__ pcm, const T *__restrict__ theta, long long n,
                                                    PllParams<T> P, const PllLockInfo<T> *__restrict__ info, long long B,
                                                    long long Wacq, long long Wtrk, int lag, T *__restrict__ phi,
@@ -352,7 +371,7 @@ __global__ void __launch_bounds__(64) k_pll_phase(const int *__restrict__ pcm, c
         // replay from the true post-lock state: exact by construction
         phase = info->st.phase;
         freq = info->st.freq;
-        pll_phase_range<T, false>(theta, phi, S, start, phase, freq, P.alpha_trk, P.beta_trk, P.max_freq, P.min_freq);
+        pll_phase_range<T, false, SLOW>(theta, phi, S, start, phase, freq, P.alpha_trk, P.beta_trk, P.max_freq, P.min_freq);
     } else {
         const long long ws = start - (Wacq + Wtrk);
         pll_guess(pcm, ws, n, lag, info->st.freq, phase, freq);
@@ -362,7 +381,7 @@ __global__ void __launch_bounds__(64) k_pll_phase(const int *__restrict__ pcm, c
         // points we fell into: at the carrier the detector error sits at +-m (|err| < pi/2), at
         // the false point pi away it sits at +-(pi - m) (|err| > pi/2)
         const long long vote0 = (Wacq > 160) ? ws + Wacq - 128 : ws + Wacq;
-        pll_phase_range<T, false>(theta, phi, ws, vote0, phase, freq, P.alpha_acq, P.beta_acq, P.max_freq, P.min_freq);
+        pll_phase_range<T, false, SLOW>(theta, phi, ws, vote0, phase, freq, P.alpha_acq, P.beta_acq, P.max_freq, P.min_freq);
         int far = 0, seen = 0;
         for (long long i = vote0; i < ws + Wacq; i++) {
             const T th = theta[i];
@@ -371,19 +390,19 @@ __global__ void __launch_bounds__(64) k_pll_phase(const int *__restrict__ pcm, c
             if (d < (T)-PDT_PI) d += (T)(2 * PDT_PI);
             far += (Real<T>::abs(d) > (T)(PDT_PI / 2)) ? 1 : 0;
             seen++;
-            pll_phase_step(th, phase, freq, P.alpha_acq, P.beta_acq, P.max_freq, P.min_freq);
+            pll_phase_step<T, SLOW>(th, phase, freq, P.alpha_acq, P.beta_acq, P.max_freq, P.min_freq);
         }
         if (2 * far > seen) {
             phase = (phase > 0) ? phase - (T)PDT_PI : phase + (T)PDT_PI;     // stays inside (-2pi, 2pi)
             if (freq >= 0 && phase < 0) phase += (T)(2 * PDT_PI);
             if (freq < 0 && phase > 0) phase -= (T)(2 * PDT_PI);
         }
-        pll_phase_range<T, false>(theta, phi, ws + Wacq, start, phase, freq, P.alpha_trk, P.beta_trk, P.max_freq, P.min_freq);
+        pll_phase_range<T, false, SLOW>(theta, phi, ws + Wacq, start, phase, freq, P.alpha_trk, P.beta_trk, P.max_freq, P.min_freq);
     }
     PllSeam<T> sm;
     sm.phase0 = phase;
     sm.freq0 = freq;
-    pll_phase_range<T, true>(theta, phi, start, end, phase, freq, P.alpha_trk, P.beta_trk, P.max_freq, P.min_freq);
+    pll_phase_range<T, true, SLOW>(theta, phi, start, end, phase, freq, P.alpha_trk, P.beta_trk, P.max_freq, P.min_freq);
     sm.phase1 = phase;
     sm.freq1 = freq;
     seams[j - S / B] = sm;
@@ -400,7 +419,7 @@ template <> __device__ __forceinline__ bool bits_equal<double>(double x, double 
 }
 
 // Seam validation + sequential repair.  One lane walks the seams in order.
-template <typename T>
+template <typename T, bool SLOW>
 __global__ void __launch_bounds__(64) k_pll_fix(const T *__restrict__ theta, long long n, PllParams<T> P,
                                                  const PllLockInfo<T> *__restrict__ info, long long B, T *__restrict__ phi,
                                                  PllSeam<T> *__restrict__ seams,
@@ -421,7 +440,7 @@ __global__ void __launch_bounds__(64) k_pll_fix(const T *__restrict__ theta, lon
         T phase = prev.phase1, freq = prev.freq1;
         const long long start = (j0 + r) * B;
         const long long end = ((j0 + r + 1) * B < n) ? (j0 + r + 1) * B : n;
-        pll_phase_range<T, true>(theta, phi, start, end, phase, freq, P.alpha_trk, P.beta_trk, P.max_freq, P.min_freq);
+        pll_phase_range<T, true, SLOW>(theta, phi, start, end, phase, freq, P.alpha_trk, P.beta_trk, P.max_freq, P.min_freq);
         PllSeam<T> upd;
         upd.phase0 = prev.phase1;
         upd.freq0 = prev.freq1;
@@ -611,25 +630,43 @@ __global__ void __launch_bounds__(256) k_static_gain(const int *__restrict__ pcm
         if (threadIdx.x == 0) *norm_out = (T)override_norm;
         return;
     }
-    for (long long i = threadIdx.x; i < n0; i += blockDim.x) {
-        T a, b;
-        IqSample<T>::get(pcm, i, a, b);
-        mag_scratch[i] = Real<T>::hypot(a, b);
-    }
-    __threadfence_block();
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        T avg = (n0 > 0) ? mag_scratch[0] : (T)0;   // n0 == 0: the reference reads a zeroed buffer
-        // the half-weight EMA forgets: start far enough back that the tail is bit-identical
-        // (each step halves the influence of the start value; 4096 steps >> mantissa width),
-        // but only when that is provably the same: we simply run the whole chunk -- the loads
-        // are independent of the chain and stream from L2.
-        for (long long i = 0; i < n0; i++) {
-            avg = avg + mag_scratch[i];
-            avg = avg * (T)0.5;                     // == (T)((double)avg / 2.0), exact
+    // magnitudes of the first chunk, in parallel; the chain then streams them from LDS in
+    // batches of 8 (one wide LDS read per 16 dependent operations)
+    constexpr int CAP = 16384;
+    __shared__ T s_mag[CAP];
+    T avg = 0;
+    for (long long base = 0; base < n0 || base == 0; base += CAP) {
+        const long long cnt = (n0 - base < CAP) ? (n0 - base) : CAP;
+        __syncthreads();
+        for (long long i = threadIdx.x; i < cnt; i += blockDim.x) {
+            T a, b;
+            IqSample<T>::get(pcm, base + i, a, b);
+            s_mag[i] = Real<T>::hypot(a, b);
         }
-        *norm_out = desired / avg;
+        for (long long i = cnt + threadIdx.x; i < ((cnt + 7) & ~7ll); i += blockDim.x) s_mag[i] = 0;
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            if (base == 0) avg = (n0 > 0) ? s_mag[0] : (T)0;      // n0 == 0: the reference reads a zeroed buffer
+            long long i = 0;
+            for (; i + 8 <= cnt; i += 8) {
+                T m[8];
+#pragma unroll
+                for (int u = 0; u < 8; u++) m[u] = s_mag[i + u];
+#pragma unroll
+                for (int u = 0; u < 8; u++) {
+                    avg = avg + m[u];
+                    avg = avg * (T)0.5;                           // == (T)((double)avg / 2.0), exact
+                }
+            }
+            for (; i < cnt; i++) {
+                avg = avg + s_mag[i];
+                avg = avg * (T)0.5;
+            }
+        }
+        if (n0 == 0) break;
     }
+    if (threadIdx.x == 0) *norm_out = desired / avg;
+    (void)mag_scratch;
 }
 
 // ------------------------------------------------------------------------------------------
@@ -727,9 +764,36 @@ __global__ void __launch_bounds__(64) k_agc_block(const T *__restrict__ in, long
     const long long start = j * B;
     if (start >= n) return;
     const long long end = (start + B < n) ? start + B : n;
-    long long ws = start - W;
-    T gain = *norm;                    // true initial state for block 0, guess for the others
-    if (ws < 0) ws = 0;
+    // The gain contracts with time constant ~ gain/decay samples, so the warm-up a block needs
+    // scales with the local signal level: estimate it from 64 samples spread over the longest
+    // admissible warm-up [start-W, start), start from the gain that level implies and replay K
+    // time constants (K = 45 for float: measured 0.15 s for the strong synthetic carrier, 0.7 s
+    // for 5sec_clip.wav at 150 ksps; more bits to agree on in double).  Any choice is exact:
+    // seams are verified bitwise.  Blocks whose warm-up would reach back to sample 0 replay from
+    // the true initial gain instead.
+    T gain = *norm;
+    const long long lo = (start - W > 0) ? start - W : 0;
+    long long ws = lo;                 // lo == 0: the true initial gain; else a guess refined below
+    if (start - lo >= 4096) {
+        T acc = 0;
+        const long long stride = (start - lo) / 64;
+#pragma unroll 16
+        for (int q = 0; q < 64; q++) acc += Real<T>::abs(in[lo + q * stride]);
+        long long need = W;
+        T g_est = gain;
+        if (acc > (T)0) {
+            g_est = (T)64 / acc;
+            const T K = (sizeof(T) == 4) ? (T)45 : (T)110;
+            const T nd = K * g_est / P.decay;
+            need = (nd < (T)W) ? (long long)nd : W;
+            need = (need + 3) & ~3ll;
+            if (need < 4096) need = 4096;
+        }
+        if (start - need > 0) {        // otherwise keep replaying from the true initial gain at sample 0
+            ws = start - need;
+            gain = (g_est < (T)5000) ? g_est : (T)5000;
+        }
+    }
     agc_range<T, false>(in, lock, out, ws, start, gain, P);
     AgcSeam<T> sm;
     sm.g0 = gain;
