@@ -152,6 +152,13 @@ uint64_t pdt_format_frames(const pdt_ctx *ctx, char *buf, uint64_t cap);
 int64_t  pdt_read_stage(const pdt_ctx *ctx, int stage, uint64_t first, uint64_t count, void *out);
 uint64_t pdt_stage_len(const pdt_ctx *ctx, int stage);
 
+/* Stage-level entry: run only the sync-word search + frame extraction kernels
+ * (ByteSyncOnSyncword, POESTIPdemod/ByteSync.c:16-150 / FindSyncWords, ARGOSdemod/ByteSync.c:17-150)
+ * on a string of '0'/'1' characters; the time stamp of bit k is k.  Results through pdt_frames /
+ * pdt_format_frames.  (The reference ships exactly such a bit-string harness, commented out, at
+ * POESTIPdemod/ByteSync.c:6-14.)                                                                  */
+int      pdt_stage_bytesync(pdt_ctx *ctx, const uint8_t *bits_host, uint64_t nbits);
+
 /* Per-kernel device times of the last call (cfg.profile = 1). Returns the entry count. */
 int      pdt_kernel_times(const pdt_ctx *ctx, pdt_kernel_time *out, int max_entries);
 

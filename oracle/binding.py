@@ -40,6 +40,7 @@ def lib():
         L.orc_open.argtypes = [C.c_int, C.c_uint, C.c_ulong, C.c_double, C.c_int]
         L.orc_close.argtypes = [C.c_void_p]
         L.orc_run_pcm16.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t]
+        L.orc_run_bits.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_size_t]
         L.orc_text.restype = C.c_void_p
         L.orc_text.argtypes = [C.c_void_p, C.POINTER(C.c_size_t)]
         L.orc_num_frames.restype = C.c_size_t
@@ -77,6 +78,23 @@ def lib():
 
 
 MATH_LIBM, MATH_PORTABLE = 0, 1
+
+
+def bytesync(mode: int, bits: np.ndarray, piece: int = 4160):
+    """Run only the byte synchroniser of the restatement on a uint8 array of '0'/'1' characters.
+    Returns (text, frames); the time stamp of bit k is k."""
+    L = lib()
+    h = L.orc_open(mode, 50000, 0, 0.0, 0)
+    b = np.ascontiguousarray(bits, dtype=np.uint8)
+    L.orc_run_bits(h, b.ctypes.data, b.size, piece)
+    n = C.c_size_t()
+    p = L.orc_text(h, C.byref(n))
+    text = C.string_at(p, n.value)
+    nf = L.orc_num_frames(h)
+    fp = L.orc_frames(h)
+    frames = [(fp[i].time, fp[i].bit_index, fp[i].inverted, fp[i].nbytes, fp[i].complete, bytes(fp[i].bytes)) for i in range(nf)]
+    L.orc_close(h)
+    return text, frames
 
 
 class Oracle:

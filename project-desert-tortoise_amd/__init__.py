@@ -95,7 +95,7 @@ ABI_SYMBOLS = [
     "pdt_abi_version", "pdt_strerror", "pdt_device_count", "pdt_open", "pdt_close", "pdt_set_stream",
     "pdt_demod_pcm16", "pdt_demod_device", "pdt_num_frames", "pdt_frames", "pdt_get_stats",
     "pdt_format_frames", "pdt_read_stage", "pdt_stage_len", "pdt_kernel_times", "pdt_make_lpf",
-    "pdt_wav_parse_header", "pdt_time_axis",
+    "pdt_wav_parse_header", "pdt_time_axis", "pdt_stage_bytesync",
 ]
 
 _lib = None
@@ -138,6 +138,7 @@ def lib():
     L.pdt_wav_parse_header.argtypes = [C.c_char_p] + [C.POINTER(C.c_uint32)] * 5
     L.pdt_time_axis.argtypes = [C.c_int, C.c_uint32, C.c_uint64]
     L.pdt_time_axis.restype = C.c_double
+    L.pdt_stage_bytesync.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64]
     if L.pdt_abi_version() != 1:
         raise PdtError("libpdt.so ABI version mismatch")
     _lib = L
@@ -221,6 +222,12 @@ class Demodulator:
     def demod_device(self, dev_ptr: int, nframes: int):
         """Input already resident in HBM (e.g. ``tensor.data_ptr()`` of an int16 torch tensor)."""
         _check(self._L.pdt_demod_device(self._h, C.c_void_p(dev_ptr), nframes), "pdt_demod_device")
+        return self
+
+    def bytesync(self, bits: np.ndarray):
+        """Stage-level entry: only the sync-word search / frame extraction on a uint8 '0'/'1' array."""
+        b = np.ascontiguousarray(bits, dtype=np.uint8)
+        _check(self._L.pdt_stage_bytesync(self._h, b.ctypes.data, b.size), "pdt_stage_bytesync")
         return self
 
     def frames(self) -> list[Frame]:

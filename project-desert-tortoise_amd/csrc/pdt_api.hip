@@ -67,6 +67,8 @@ struct DevScalars {
     unsigned nhits;
     unsigned nframes;
     unsigned counters[4];   // pll blocks, pll fixes, agc blocks, agc fixes
+    unsigned sync_overflow; // a 4096-bit tile held more than 31 sync hits: generic path used
+    unsigned pad0_;
     unsigned gstats[4];     // boundary-state tables: [0] exits outside the domain, [1] full-domain chunks,
                             //                        [2] chunks the chain had to walk, [3] unused
     double norm;            // storage for the normalisation factor (float or double)
@@ -82,7 +84,7 @@ struct pdt_ctx {
     bool own_stream = false;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
 
-    DevBuf pcm, pll, lock, fir, agc, sym, symidx, bits, bitsym, hits, frames, taps, mag, seams_pll, seams_agc, scal, lockinfo, term, seams_ema, gtable, gentries, gcand, gmfirst;
+    DevBuf pcm, pll, lock, fir, agc, sym, symidx, bits, bitsym, hits, frames, taps, mag, seams_pll, seams_agc, scal, lockinfo, term, seams_ema, gtable, gentries, gcand, gmfirst, stiles;
     long long gcand_key = -1;          // (chunk_out, step) the candidate list on the device was built for
     bool force_sequential_gardner = false;
     int gardner_mode = 0;              // 0 sequential, 1 state table (last run)
@@ -180,6 +182,43 @@ uint32_t next_pow2(uint32_t v)
     return p;
 }
 
+SyncParams make_sync_params(bool argos)
+{
+    SyncParams SP;
+    if (argos) {
+        SP.pattern = 0x02F0ull;   // "0001011110000"
+        SP.len = 13; SP.allow_inverse = 0; SP.span = 56; SP.first_bits = 8; SP.nbytes = 7; SP.prefix = 0;
+    } else {
+        SP.pattern = 0x76F10ull;  // "1110110111100010000"
+        SP.len = 19; SP.allow_inverse = 1; SP.span = 813; SP.first_bits = 5; SP.nbytes = 102; SP.prefix = 2;
+    }
+    return SP;
+}
+
+void launch_bytesync(pdt_ctx *ctx, hipStream_t st, const SyncParams &SP, DevScalars *d_sc, long long bit_cap, uint32_t hit_cap,
+                     uint32_t frame_cap)
+{
+    unsigned char *d_bits = (unsigned char *)ctx->bits.p;
+    unsigned *d_bitsym = (unsigned *)ctx->bitsym.p;
+    long long *d_symidx = (long long *)ctx->symidx.p;
+    unsigned *d_hits = (unsigned *)ctx->hits.p;
+    FrameRec *d_frames = (FrameRec *)ctx->frames.p;
+    const long long n_stiles = (bit_cap + 4095) / 4096;
+    SyncTile *d_stiles = (SyncTile *)ctx->stiles.p;
+    hipLaunchKernelGGL(k_sync_hits_tile, dim3((unsigned)n_stiles), dim3(256), 0, st, d_bits, &d_sc->nbits, SP, d_stiles,
+                       &d_sc->sync_overflow);
+    hipLaunchKernelGGL(k_sync_frames_tiles, dim3(1), dim3(64), 0, st, (const SyncTile *)d_stiles, &d_sc->nbits, SP, d_frames,
+                       &d_sc->nframes, frame_cap, &d_sc->sync_overflow);
+    // generic path (atomic append + sort), only when a tile overflowed
+    const long long grid = (bit_cap + 255) / 256;
+    hipLaunchKernelGGL(k_sync_hits, dim3((unsigned)grid), dim3(256), 0, st, d_bits, &d_sc->nbits, SP, d_hits, &d_sc->nhits, hit_cap,
+                       &d_sc->sync_overflow);
+    hipLaunchKernelGGL(k_sync_frames, dim3(1), dim3(256), 0, st, d_hits, &d_sc->nhits, hit_cap, SP, d_frames, &d_sc->nframes,
+                       frame_cap, &d_sc->sync_overflow);
+    hipLaunchKernelGGL(k_frame_pack, dim3(frame_cap), dim3(128), 0, st, d_bits, &d_sc->nbits, d_bitsym, d_symidx, SP, d_frames,
+                       &d_sc->nframes, frame_cap);
+}
+
 template <typename T> int run_capture(pdt_ctx *ctx, uint64_t n)
 {
     const bool argos = ctx->cfg.mode == PDT_MODE_ARGOS;
@@ -218,14 +257,7 @@ template <typename T> int run_capture(pdt_ctx *ctx, uint64_t n)
         GP.argos_even = ((req + 8) % 16) != 0;
     }
     const T manch_thr = argos ? (T)0.5 : (T)1.0;                               // main.c:445 / ARGOS main.c:282
-    SyncParams SP;
-    if (argos) {
-        SP.pattern = 0x02F0ull;   // "0001011110000"
-        SP.len = 13; SP.allow_inverse = 0; SP.span = 56; SP.first_bits = 8; SP.nbytes = 7; SP.prefix = 0;
-    } else {
-        SP.pattern = 0x76F10ull;  // "1110110111100010000"
-        SP.len = 19; SP.allow_inverse = 1; SP.span = 813; SP.first_bits = 5; SP.nbytes = 102; SP.prefix = 2;
-    }
+    const SyncParams SP = make_sync_params(argos);
 
     // ---- block-parallel geometry (any values give the same output; they only move time around)
     const double fs_d = (double)ctx->cfg.sample_rate;
@@ -267,6 +299,7 @@ template <typename T> int run_capture(pdt_ctx *ctx, uint64_t n)
     if ((rc = ctx->bitsym.ensure((size_t)bit_cap * sizeof(unsigned)))) return rc;
     if ((rc = ctx->hits.ensure((size_t)hit_cap * sizeof(unsigned) + (size_t)n_tiles * sizeof(ManchTile)))) return rc;
     if ((rc = ctx->frames.ensure((size_t)frame_cap * sizeof(FrameRec)))) return rc;
+    if ((rc = ctx->stiles.ensure((size_t)((bit_cap + 4095) / 4096 + 1) * sizeof(SyncTile)))) return rc;
     if ((rc = ctx->mag.ensure((size_t)(n0 + 1) * sizeof(T)))) return rc;
     if ((rc = ctx->seams_pll.ensure((size_t)nb_pll * sizeof(PllSeam<T>)))) return rc;
     if ((rc = ctx->seams_agc.ensure((size_t)nb_agc * sizeof(AgcSeam<T>)))) return rc;
@@ -284,7 +317,6 @@ template <typename T> int run_capture(pdt_ctx *ctx, uint64_t n)
     long long *d_symidx = (long long *)ctx->symidx.p;
     unsigned char *d_bits = (unsigned char *)ctx->bits.p;
     unsigned *d_bitsym = (unsigned *)ctx->bitsym.p;
-    unsigned *d_hits = (unsigned *)ctx->hits.p;
     ManchTile *d_tiles = (ManchTile *)((unsigned char *)ctx->hits.p + (size_t)hit_cap * sizeof(unsigned));
     FrameRec *d_frames = (FrameRec *)ctx->frames.p;
     DevScalars *d_sc = (DevScalars *)ctx->scal.p;
@@ -475,15 +507,7 @@ template <typename T> int run_capture(pdt_ctx *ctx, uint64_t n)
 
     // ---- byte sync
     L.begin("bytesync");
-    {
-        const long long grid = (bit_cap + 255) / 256;
-        hipLaunchKernelGGL(k_sync_hits, dim3((unsigned)grid), dim3(256), 0, st, d_bits, &d_sc->nbits, SP, d_hits, &d_sc->nhits,
-                           hit_cap);
-        hipLaunchKernelGGL(k_sync_frames, dim3(1), dim3(256), 0, st, d_hits, &d_sc->nhits, hit_cap, SP, d_frames,
-                           &d_sc->nframes, frame_cap);
-        hipLaunchKernelGGL(k_frame_pack, dim3(frame_cap), dim3(128), 0, st, d_bits, &d_sc->nbits, d_bitsym, d_symidx, SP,
-                           d_frames, &d_sc->nframes, frame_cap);
-    }
+    launch_bytesync(ctx, st, SP, d_sc, bit_cap, hit_cap, frame_cap);
     L.end();
     HIP_TRY(hipEventRecord(ctx->ev1, st));
     HIP_TRY(hipGetLastError());
@@ -718,7 +742,7 @@ void pdt_close(pdt_ctx *ctx)
     DevBuf *bufs[] = { &ctx->pcm, &ctx->pll, &ctx->lock, &ctx->fir, &ctx->agc, &ctx->sym, &ctx->symidx, &ctx->bits, &ctx->bitsym,
                        &ctx->hits, &ctx->frames, &ctx->taps, &ctx->mag, &ctx->seams_pll, &ctx->seams_agc, &ctx->scal, &ctx->lockinfo,
                        &ctx->term, &ctx->seams_ema, &ctx->gtable, &ctx->gentries, &ctx->gcand,
-                       &ctx->gmfirst };
+                       &ctx->gmfirst, &ctx->stiles };
     for (DevBuf *b : bufs) b->release();
     if (ctx->ev0) (void)hipEventDestroy(ctx->ev0);
     if (ctx->ev1) (void)hipEventDestroy(ctx->ev1);
@@ -764,6 +788,60 @@ int pdt_demod_device(pdt_ctx *ctx, const void *iq_device, uint64_t nframes)
     if (!ctx || (!iq_device && nframes)) return PDT_ERR_ARG;
     ctx->pcm_dev = iq_device;
     return demod_common(ctx, nframes);
+}
+
+int pdt_stage_bytesync(pdt_ctx *ctx, const uint8_t *bits_host, uint64_t nbits)
+{
+    if (!ctx || (!bits_host && nbits)) return PDT_ERR_ARG;
+    if (nbits >= (1ull << 31)) return PDT_ERR_ARG;
+    HIP_TRY(hipSetDevice(ctx->cfg.device));
+    const bool argos = ctx->cfg.mode == PDT_MODE_ARGOS;
+    const SyncParams SP = make_sync_params(argos);
+    const long long bit_cap = (long long)nbits + 64;
+    const uint32_t hit_cap = next_pow2((uint32_t)(bit_cap / 4 + 4096));
+    const uint32_t frame_cap = (uint32_t)(bit_cap / SP.span + 16);
+    int rc;
+    if ((rc = ctx->bits.ensure((size_t)bit_cap))) return rc;
+    if ((rc = ctx->bitsym.ensure((size_t)bit_cap * sizeof(unsigned)))) return rc;
+    if ((rc = ctx->symidx.ensure((size_t)bit_cap * sizeof(long long)))) return rc;
+    if ((rc = ctx->hits.ensure((size_t)hit_cap * sizeof(unsigned)))) return rc;
+    if ((rc = ctx->frames.ensure((size_t)frame_cap * sizeof(FrameRec)))) return rc;
+    if ((rc = ctx->stiles.ensure((size_t)((bit_cap + 4095) / 4096 + 1) * sizeof(SyncTile)))) return rc;
+    if ((rc = ctx->scal.ensure(sizeof(DevScalars)))) return rc;
+    hipStream_t st = ctx->stream;
+    DevScalars *d_sc = (DevScalars *)ctx->scal.p;
+    DevScalars sc;
+    memset(&sc, 0, sizeof sc);
+    sc.nbits = nbits;
+    HIP_TRY(hipMemcpyAsync(d_sc, &sc, sizeof sc, hipMemcpyHostToDevice, st));
+    if (nbits) HIP_TRY(hipMemcpyAsync(ctx->bits.p, bits_host, (size_t)nbits, hipMemcpyHostToDevice, st));
+    HIP_TRY(hipMemsetAsync(ctx->frames.p, 0, (size_t)frame_cap * sizeof(FrameRec), st));
+    hipLaunchKernelGGL(k_iota, dim3((unsigned)((bit_cap + 255) / 256)), dim3(256), 0, st, (unsigned *)ctx->bitsym.p,
+                       (long long *)ctx->symidx.p, bit_cap);
+    launch_bytesync(ctx, st, SP, d_sc, bit_cap, hit_cap, frame_cap);
+    HIP_TRY(hipMemcpyAsync(&sc, d_sc, sizeof sc, hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipStreamSynchronize(st));
+    if (sc.nframes > frame_cap || (sc.sync_overflow && sc.nhits > hit_cap)) return PDT_ERR_STATE;
+    std::vector<FrameRec> recs(sc.nframes);
+    if (sc.nframes) HIP_TRY(hipMemcpy(recs.data(), ctx->frames.p, (size_t)sc.nframes * sizeof(FrameRec), hipMemcpyDeviceToHost));
+    ctx->frames_host.resize(sc.nframes);
+    for (unsigned f = 0; f < sc.nframes; f++) {
+        pdt_frame &o = ctx->frames_host[f];
+        memset(&o, 0, sizeof o);
+        o.bit_index = recs[f].bit_index;
+        o.time_src = recs[f].time_src;
+        o.time = (double)recs[f].time_src;
+        o.inverted = recs[f].inverted;
+        o.nbytes = recs[f].nbytes;
+        o.complete = recs[f].complete;
+        memcpy(o.bytes, recs[f].bytes, 104);
+    }
+    memset(&ctx->stats, 0, sizeof ctx->stats);
+    ctx->stats.bits = nbits;
+    ctx->stats.frames = sc.nframes;
+    ctx->stats.reserved = sc.sync_overflow;
+    memset(ctx->stage_len, 0, sizeof ctx->stage_len);
+    return PDT_OK;
 }
 
 uint64_t pdt_num_frames(const pdt_ctx *ctx) { return ctx ? ctx->frames_host.size() : 0; }

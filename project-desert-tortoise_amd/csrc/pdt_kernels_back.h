@@ -589,23 +589,39 @@ __global__ void __launch_bounds__(PDT_TILE_THREADS) k_manch_tile(const T *__rest
     }
 }
 
-// sequential pass over the tile summaries (a few thousand entries)
-__global__ void k_manch_scan(ManchTile *__restrict__ tiles, const unsigned long long *__restrict__ nsym_p,
-                             unsigned long long *__restrict__ nbits_out)
+// pass over the tile summaries: one wavefront, 64 tiles per round trip; the (clockmod, output
+// offset) chain itself is evaluated redundantly by all lanes from shuffled values
+__global__ void __launch_bounds__(64) k_manch_scan(ManchTile *__restrict__ tiles, const unsigned long long *__restrict__ nsym_p,
+                                                    unsigned long long *__restrict__ nbits_out)
 {
-    if (threadIdx.x != 0 || blockIdx.x != 0) return;
     const long long nsym = (long long)*nsym_p;
     const long long nt = (nsym + PDT_TILE - 1) / PDT_TILE;
     unsigned clock = 0;
     unsigned long long base = 0;
-    for (long long t = 0; t < nt; t++) {
-        ManchTile mt = tiles[t];
-        tiles[t].clock_in = clock;
-        tiles[t].out_base = base;
-        base += mt.cnt_before[clock] + mt.cnt_after;
-        if (mt.last_r_parity >= 0) clock = (unsigned)mt.last_r_parity;
+    for (long long t0 = 0; t0 < nt; t0 += 64) {
+        const long long mine = t0 + threadIdx.x;
+        ManchTile mt;
+        mt.last_r_parity = -1; mt.first_r = PDT_TILE; mt.cnt_before[0] = mt.cnt_before[1] = 0; mt.cnt_after = 0;
+        mt.clock_in = 0; mt.out_base = 0;
+        if (mine < nt) mt = tiles[mine];
+        unsigned my_clock = 0;
+        unsigned long long my_base = 0;
+        const int lim = (nt - t0 < 64) ? (int)(nt - t0) : 64;
+        for (int t = 0; t < lim; t++) {
+            const unsigned cb0 = (unsigned)__shfl((int)mt.cnt_before[0], t);
+            const unsigned cb1 = (unsigned)__shfl((int)mt.cnt_before[1], t);
+            const unsigned ca = (unsigned)__shfl((int)mt.cnt_after, t);
+            const int lp = __shfl(mt.last_r_parity, t);
+            if ((int)threadIdx.x == t) { my_clock = clock; my_base = base; }
+            base += (clock ? cb1 : cb0) + ca;
+            if (lp >= 0) clock = (unsigned)lp;
+        }
+        if (mine < nt) {
+            tiles[mine].clock_in = my_clock;
+            tiles[mine].out_base = my_base;
+        }
     }
-    *nbits_out = base;
+    if (threadIdx.x == 0) *nbits_out = base;
 }
 
 template <typename T>
@@ -705,8 +721,9 @@ struct SyncParams {
 __global__ void __launch_bounds__(256) k_sync_hits(const unsigned char *__restrict__ bits,
                                                     const unsigned long long *__restrict__ nbits_p, SyncParams P,
                                                     unsigned *__restrict__ hits, unsigned *__restrict__ nhits,
-                                                    unsigned hit_cap)
+                                                    unsigned hit_cap, const unsigned *__restrict__ only_if)
 {
+    if (only_if && *only_if == 0) return;            // generic path: only when the tile path overflowed
     const long long nbits = (long long)*nbits_p;
     const long long b = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (b >= nbits) return;
@@ -728,6 +745,65 @@ __global__ void __launch_bounds__(256) k_sync_hits(const unsigned char *__restri
     }
 }
 
+// Ordered hit collection: one 128-byte record per 4096-bit tile (hits are ~5 per tile: one per
+// 832-bit frame plus the odd chance match), sorted inside the tile, so that the frame filter can
+// walk tiles in order without a global sort.  More than 31 hits in a tile raises `overflow` and
+// the generic path (atomic append + bitonic sort) takes over.
+struct SyncTile {
+    unsigned count;
+    unsigned hits[31];     // (bit index << 1) | inverse
+};
+
+__global__ void __launch_bounds__(256) k_sync_hits_tile(const unsigned char *__restrict__ bits,
+                                                         const unsigned long long *__restrict__ nbits_p, SyncParams P,
+                                                         SyncTile *__restrict__ tiles, unsigned *__restrict__ overflow)
+{
+    const long long nbits = (long long)*nbits_p;
+    const long long t0 = (long long)blockIdx.x * 4096;
+    if (t0 >= nbits) return;
+    __shared__ unsigned s_hits[64];
+    __shared__ unsigned s_n;
+    if (threadIdx.x == 0) s_n = 0;
+    __syncthreads();
+    const unsigned long long mask = (P.len >= 64) ? ~0ull : ((1ull << P.len) - 1ull);
+    const long long b0 = t0 + (long long)threadIdx.x * 16;
+    // window ending at b0-1
+    unsigned long long w = 0;
+    for (unsigned k = 0; k + 1 < P.len; k++) {
+        const long long idx = b0 - (long long)(P.len - 1) + k;
+        const unsigned v = (idx >= 0 && idx < nbits) ? (unsigned)(bits[idx] != '0') : 0u;
+        w = (w << 1) | v;
+    }
+    for (int u = 0; u < 16; u++) {
+        const long long b = b0 + u;
+        if (b >= nbits) break;
+        w = ((w << 1) | (unsigned long long)(bits[b] != '0')) & mask;
+        unsigned kind = 0;
+        if (w == P.pattern) kind = 1;
+        else if (P.allow_inverse && w == (~P.pattern & mask)) kind = 2;
+        if (kind) {
+            const unsigned slot = atomicAdd(&s_n, 1u);
+            if (slot < 64) s_hits[slot] = ((unsigned)b << 1) | (kind - 1);
+        }
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        unsigned nh = s_n;
+        if (nh > 31) { atomicAdd(overflow, 1u); nh = (nh > 64) ? 64 : nh; }
+        // insertion sort (a handful of entries)
+        for (unsigned i = 1; i < nh; i++) {
+            const unsigned v = s_hits[i];
+            int j = (int)i - 1;
+            while (j >= 0 && s_hits[j] > v) { s_hits[j + 1] = s_hits[j]; j--; }
+            s_hits[j + 1] = v;
+        }
+        SyncTile tl;
+        tl.count = (nh > 31) ? 31 : nh;
+        for (unsigned i = 0; i < 31; i++) tl.hits[i] = (i < nh) ? s_hits[i] : 0u;
+        tiles[blockIdx.x] = tl;
+    }
+}
+
 struct FrameRec {
     long long bit_index;
     long long time_src;
@@ -738,8 +814,10 @@ struct FrameRec {
 // single workgroup: sort the (sparse, unordered) hit list, then walk it sequentially
 __global__ void __launch_bounds__(256) k_sync_frames(unsigned *__restrict__ hits, const unsigned *__restrict__ nhits_p,
                                                       unsigned hit_cap, SyncParams P, FrameRec *__restrict__ frames,
-                                                      unsigned *__restrict__ nframes, unsigned frame_cap)
+                                                      unsigned *__restrict__ nframes, unsigned frame_cap,
+                                                      const unsigned *__restrict__ only_if)
 {
+    if (only_if && *only_if == 0) return;
     unsigned nh = *nhits_p;
     if (nh > hit_cap) nh = hit_cap;
     // odd-even transposition would be O(n^2); hits arrive nearly sorted (atomic order follows
@@ -782,6 +860,58 @@ __global__ void __launch_bounds__(256) k_sync_frames(unsigned *__restrict__ hits
         }
         *nframes = nf;
     }
+}
+
+// frame filter over the ordered tiles: one wavefront, 64 tiles per round trip
+__global__ void __launch_bounds__(64) k_sync_frames_tiles(const SyncTile *__restrict__ tiles,
+                                                           const unsigned long long *__restrict__ nbits_p, SyncParams P,
+                                                           FrameRec *__restrict__ frames, unsigned *__restrict__ nframes,
+                                                           unsigned frame_cap, const unsigned *__restrict__ overflow)
+{
+    if (*overflow) return;                       // the generic path handles this capture
+    const long long nbits = (long long)*nbits_p;
+    const long long nt = (nbits + 4095) / 4096;
+    unsigned nf = 0;
+    long long next_free = 0;
+    for (long long t0 = 0; t0 < nt; t0 += 64) {
+        const long long mine = t0 + threadIdx.x;
+        unsigned cnt = 0, h[7];
+#pragma unroll
+        for (int q = 0; q < 7; q++) h[q] = 0;
+        if (mine < nt) {
+            const uint4 a = *reinterpret_cast<const uint4 *>(&tiles[mine]);
+            const uint4 b = *(reinterpret_cast<const uint4 *>(&tiles[mine]) + 1);
+            cnt = a.x; h[0] = a.y; h[1] = a.z; h[2] = a.w; h[3] = b.x; h[4] = b.y; h[5] = b.z; h[6] = b.w;
+        }
+        if (__ballot(cnt != 0) == 0) continue;
+        const int lim = (nt - t0 < 64) ? (int)(nt - t0) : 64;
+        for (int t = 0; t < lim; t++) {
+            const unsigned c = (unsigned)__shfl((int)cnt, t);
+            for (unsigned q = 0; q < c; q++) {
+                unsigned v;
+                if (q < 7) {
+                    v = (unsigned)__shfl((int)h[0], t);
+                    if (q == 1) v = (unsigned)__shfl((int)h[1], t);
+                    if (q == 2) v = (unsigned)__shfl((int)h[2], t);
+                    if (q == 3) v = (unsigned)__shfl((int)h[3], t);
+                    if (q == 4) v = (unsigned)__shfl((int)h[4], t);
+                    if (q == 5) v = (unsigned)__shfl((int)h[5], t);
+                    if (q == 6) v = (unsigned)__shfl((int)h[6], t);
+                } else {
+                    v = tiles[t0 + t].hits[q];
+                }
+                const long long pos = (long long)(v >> 1);
+                if (pos < next_free) continue;
+                if (threadIdx.x == 0 && nf < frame_cap) {
+                    frames[nf].bit_index = pos;
+                    frames[nf].inverted = (unsigned char)(v & 1u);
+                }
+                nf++;
+                next_free = pos + P.span;
+            }
+        }
+    }
+    if (threadIdx.x == 0) *nframes = nf;
 }
 
 __global__ void __launch_bounds__(128) k_frame_pack(const unsigned char *__restrict__ bits,
@@ -828,6 +958,13 @@ __global__ void __launch_bounds__(128) k_frame_pack(const unsigned char *__restr
         frames[f].pad = 0;
         frames[f].time_src = symidx[bitsym[pos]];
     }
+}
+
+// identity index maps for the stage-level byte-sync entry (time stamp of bit k = k)
+__global__ void k_iota(unsigned *__restrict__ bitsym, long long *__restrict__ symidx, long long n)
+{
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) { bitsym[i] = (unsigned)i; symidx[i] = i; }
 }
 
 }  // namespace pdt

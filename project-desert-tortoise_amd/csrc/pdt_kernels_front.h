@@ -418,38 +418,60 @@ template <> __device__ __forceinline__ bool bits_equal<double>(double x, double 
     return __double_as_longlong(x) == __double_as_longlong(y);
 }
 
-// Seam validation + sequential repair.  One lane walks the seams in order.
+// Seam validation + repair.  One wavefront scans 64 seams per round trip (a seam is healthy when
+// the previous block's end state equals, bit for bit, the state this block reached at its
+// official start after its warm-up); a mismatching block is re-run from the true state by the
+// whole wave in lock step (uniform work, lane 0's stores count), after which the scan resumes at
+// the following seam so that a changed end state is compared again.
 template <typename T, bool SLOW>
 __global__ void __launch_bounds__(64) k_pll_fix(const T *__restrict__ theta, long long n, PllParams<T> P,
                                                  const PllLockInfo<T> *__restrict__ info, long long B, T *__restrict__ phi,
                                                  PllSeam<T> *__restrict__ seams,
                                                  unsigned *__restrict__ counters /* [0]=blocks [1]=fixes */)
 {
-    if (threadIdx.x != 0 || blockIdx.x != 0) return;
     const long long lock_at = info->lock_sample;
-    if (lock_at < 0) { counters[0] = 0; counters[1] = 0; return; }
+    if (lock_at < 0) {
+        if (threadIdx.x == 0) { counters[0] = 0; counters[1] = 0; }
+        return;
+    }
     const long long S = lock_at + 1;
     const long long j0 = S / B;
     const long long nb = (S < n) ? ((n - 1) / B - j0 + 1) : 0;
     unsigned fixes = 0;
-    for (long long r = 1; r < nb; r++) {
-        const PllSeam<T> prev = seams[r - 1];
-        const PllSeam<T> cur = seams[r];
-        if (bits_equal(prev.phase1, cur.phase0) && bits_equal(prev.freq1, cur.freq0)) continue;
+    long long r = 1;
+    while (r < nb) {
+        const long long mine = r + threadIdx.x;
+        bool bad = false;
+        if (mine < nb) {
+            const PllSeam<T> prev = seams[mine - 1];
+            const PllSeam<T> cur = seams[mine];
+            bad = !(bits_equal(prev.phase1, cur.phase0) && bits_equal(prev.freq1, cur.freq0));
+        }
+        const unsigned long long mask = __ballot(bad);
+        if (mask == 0) { r += 64; continue; }
+        const long long rb = r + (long long)__builtin_ctzll(mask);       // first unhealthy seam
         fixes++;
+        const PllSeam<T> prev = seams[rb - 1];
         T phase = prev.phase1, freq = prev.freq1;
-        const long long start = (j0 + r) * B;
-        const long long end = ((j0 + r + 1) * B < n) ? (j0 + r + 1) * B : n;
-        pll_phase_range<T, true, SLOW>(theta, phi, start, end, phase, freq, P.alpha_trk, P.beta_trk, P.max_freq, P.min_freq);
-        PllSeam<T> upd;
-        upd.phase0 = prev.phase1;
-        upd.freq0 = prev.freq1;
-        upd.phase1 = phase;
-        upd.freq1 = freq;
-        seams[r] = upd;
+        const long long start = (j0 + rb) * B;
+        const long long end = ((j0 + rb + 1) * B < n) ? (j0 + rb + 1) * B : n;
+        if (threadIdx.x == 0) {
+            pll_phase_range<T, true, SLOW>(theta, phi, start, end, phase, freq, P.alpha_trk, P.beta_trk, P.max_freq, P.min_freq);
+            PllSeam<T> upd;
+            upd.phase0 = prev.phase1;
+            upd.freq0 = prev.freq1;
+            upd.phase1 = phase;
+            upd.freq1 = freq;
+            seams[rb] = upd;
+        }
+        __threadfence_block();
+        __syncthreads();
+        r = rb + 1;
     }
-    counters[0] = (unsigned)nb;
-    counters[1] = fixes;
+    if (threadIdx.x == 0) {
+        counters[0] = (unsigned)nb;
+        counters[1] = fixes;
+    }
 }
 
 // elementwise mix for the samples after the lock (:106-113), and the lock-detector input
@@ -514,7 +536,6 @@ __global__ void __launch_bounds__(64) k_lock_ema_fix(const T *__restrict__ term,
                                                       T *__restrict__ lock_out, EmaSeam<T> *__restrict__ seams,
                                                       unsigned *__restrict__ fixes_out)
 {
-    if (threadIdx.x != 0 || blockIdx.x != 0) return;
     const long long lock_at = info->lock_sample;
     if (lock_at < 0) return;
     const long long S = lock_at + 1;
@@ -522,21 +543,32 @@ __global__ void __launch_bounds__(64) k_lock_ema_fix(const T *__restrict__ term,
     const long long nb = (S < n) ? ((n - 1) / B - j0 + 1) : 0;
     const double k = 1.0 - (double)lock_alpha;
     unsigned fixes = 0;
-    for (long long r = 1; r < nb; r++) {
-        const T truth = seams[r - 1].v1;
-        if (bits_equal(truth, seams[r].v0)) continue;
+    long long r = 1;
+    while (r < nb) {
+        const long long mine = r + threadIdx.x;
+        bool bad = false;
+        if (mine < nb) bad = !bits_equal(seams[mine - 1].v1, seams[mine].v0);
+        const unsigned long long mask = __ballot(bad);
+        if (mask == 0) { r += 64; continue; }
+        const long long rb = r + (long long)__builtin_ctzll(mask);
         fixes++;
-        T L = truth;
-        const long long start = (j0 + r) * B;
-        const long long end = ((j0 + r + 1) * B < n) ? (j0 + r + 1) * B : n;
-        for (long long i = start; i < end; i++) {
-            L = (T)((double)L * k + (double)term[i]);
-            lock_out[i] = L;
+        const T truth = seams[rb - 1].v1;
+        if (threadIdx.x == 0) {
+            T L = truth;
+            const long long start = (j0 + rb) * B;
+            const long long end = ((j0 + rb + 1) * B < n) ? (j0 + rb + 1) * B : n;
+            for (long long i = start; i < end; i++) {
+                L = (T)((double)L * k + (double)term[i]);
+                lock_out[i] = L;
+            }
+            seams[rb].v0 = truth;
+            seams[rb].v1 = L;
         }
-        seams[r].v0 = truth;
-        seams[r].v1 = L;
+        __threadfence_block();
+        __syncthreads();
+        r = rb + 1;
     }
-    *fixes_out += fixes;
+    if (threadIdx.x == 0) *fixes_out += fixes;
 }
 
 // ------------------------------------------------------------------------------------------
@@ -807,22 +839,35 @@ __global__ void __launch_bounds__(64) k_agc_fix(const T *__restrict__ in, long l
                                                  const T *__restrict__ lock, T *__restrict__ out,
                                                  AgcSeam<T> *__restrict__ seams, unsigned *__restrict__ counters)
 {
-    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    // same wave-parallel seam scan as k_pll_fix
     const long long nb = (n + B - 1) / B;
     unsigned fixes = 0;
-    for (long long j = 1; j < nb; j++) {
-        const T g_true = seams[j - 1].g1;
-        if (bits_equal(g_true, seams[j].g0)) continue;
+    long long r = 1;
+    while (r < nb) {
+        const long long mine = r + threadIdx.x;
+        bool bad = false;
+        if (mine < nb) bad = !bits_equal(seams[mine - 1].g1, seams[mine].g0);
+        const unsigned long long mask = __ballot(bad);
+        if (mask == 0) { r += 64; continue; }
+        const long long rb = r + (long long)__builtin_ctzll(mask);
         fixes++;
-        T gain = g_true;
-        const long long start = j * B;
-        const long long end = (start + B < n) ? start + B : n;
-        agc_range<T, true>(in, lock, out, start, end, gain, P);
-        seams[j].g0 = g_true;
-        seams[j].g1 = gain;
+        const T g_true = seams[rb - 1].g1;
+        if (threadIdx.x == 0) {
+            T gain = g_true;
+            const long long start = rb * B;
+            const long long end = (start + B < n) ? start + B : n;
+            agc_range<T, true>(in, lock, out, start, end, gain, P);
+            seams[rb].g0 = g_true;
+            seams[rb].g1 = gain;
+        }
+        __threadfence_block();
+        __syncthreads();
+        r = rb + 1;
     }
-    counters[2] = (unsigned)nb;
-    counters[3] = fixes;
+    if (threadIdx.x == 0) {
+        counters[2] = (unsigned)nb;
+        counters[3] = fixes;
+    }
 }
 
 }  // namespace pdt
