@@ -111,7 +111,10 @@ typedef struct pdt_stats {
     double   gpu_ms;              /* device time of the last pdt_demod_* call (HIP events)        */
     uint32_t gardner_parallel;    /* 1 = symbol sampler ran through the parallel boundary-state tables,
                                      0 = single-wavefront sequential chain                         */
-    uint32_t reserved;            /* diagnostics: chunks walked by the chain | full-domain chunks << 16 */
+    uint32_t gardner_walked;      /* chunks whose entry state was outside the tabulated band (walked by the chain) */
+    uint32_t gardner_full_domain; /* chunks tabulated over the full boundary-state domain (scouts not locked)       */
+    uint32_t sync_overflow;       /* 4096-bit tiles with more than 31 sync hits (generic path used)                */
+    uint64_t gardner_candidates;  /* boundary states evaluated by the table kernel                                  */
 } pdt_stats;
 
 typedef struct pdt_kernel_time {

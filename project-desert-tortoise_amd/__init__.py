@@ -82,7 +82,10 @@ class Stats(C.Structure):
         ("agc_seam_fixes", C.c_uint32),
         ("gpu_ms", C.c_double),
         ("gardner_parallel", C.c_uint32),
-        ("reserved", C.c_uint32),
+        ("gardner_walked", C.c_uint32),
+        ("gardner_full_domain", C.c_uint32),
+        ("sync_overflow", C.c_uint32),
+        ("gardner_candidates", C.c_uint64),
     ]
 
 

@@ -166,6 +166,11 @@ template <typename T> PllParams<T> make_pll_params(const pdt_ctx *ctx)
     const double dd = (double)damp, db = (double)bw_trk;
     P.alpha_trk = (T)((4.0 * dd * db) / (1.0 + 2.0 * dd * db + (double)(bw_trk * bw_trk)));   // :272-273, double
     P.beta_trk = (T)((4.0 * db * db) / (1.0 + 2.0 * dd * db + (double)(bw_trk * bw_trk)));
+    {
+        const T bw_w = bw_acq * (T)8;
+        P.alpha_wide = (four * damp * bw_w) / (one + two * damp * bw_w + bw_w * bw_w);
+        P.beta_wide = (four * bw_w * bw_w) / (one + two * damp * bw_w + bw_w * bw_w);
+    }
     P.max_freq = (T)(2.0 * M_PI * (double)freqRange / (double)Fs);
     P.min_freq = (T)(-2.0 * M_PI * (double)freqRange / (double)Fs);
     P.sweep0 = (T)(0.2 * (2.0 * M_PI / (double)Fs));
@@ -272,9 +277,13 @@ template <typename T> int run_capture(pdt_ctx *ctx, uint64_t n)
     Wp = round4(Wp);
     Wa = round4(Wa);
     Wacq = round4(Wacq);
-    int lag = (int)(fs_d / 10000.0);                        // pi/lag must exceed the PLL's frequency limit
-    lag = std::max(1, std::min(32, lag));
-    if (argos) lag = std::max(1, std::min(32, (int)(fs_d / 1200.0)));
+    // lag of the autocorrelation frequency guess: at least one Manchester symbol (so that the
+    // modulation of the two samples is independent and the carrier term dominates the mean), while
+    // pi/lag stays above the PLL's frequency limit
+    const double sym_rate = argos ? 800.0 : 16640.0, f_lim = argos ? 550.0 : 4500.0;
+    int lag = (int)ceil(fs_d / sym_rate);
+    lag = std::max(1, std::min(lag, (int)(fs_d / (2.2 * f_lim))));
+    lag = std::min(lag, 64);
     const long long nb_pll = N / Bp + 2;
     const long long nb_agc = (n_out + Ba - 1) / Ba + 1;
 
@@ -349,8 +358,9 @@ template <typename T> int run_capture(pdt_ctx *ctx, uint64_t n)
     if (N > 0) {
         const long long grid = (nb_pll + 63) / 64;
         // a single +-2pi correction per step is exact as long as one step cannot move the phase by 2pi
-        const double worst = (double)PP.max_freq + M_PI * std::max((double)PP.alpha_acq + (double)PP.beta_acq,
-                                                                   (double)PP.alpha_trk + (double)PP.beta_trk);
+        const double worst = (double)PP.max_freq + M_PI * std::max({(double)PP.alpha_acq + (double)PP.beta_acq,
+                                                                    (double)PP.alpha_trk + (double)PP.beta_trk,
+                                                                    (double)PP.alpha_wide + (double)PP.beta_wide});
         const bool slow_wrap = worst >= 2.0 * M_PI - 0.05;
         L.begin("pll_phase");
         if (slow_wrap)
@@ -550,7 +560,10 @@ template <typename T> int run_capture(pdt_ctx *ctx, uint64_t n)
     S.agc_seam_fixes = sc.counters[3];
     S.gpu_ms = ms;
     S.gardner_parallel = (uint32_t)ctx->gardner_mode;
-    S.reserved = use_table ? ((sc.gstats[2] & 0xffffu) | ((sc.gstats[1] & 0xffffu) << 16)) : 0u;   // walked | full-domain chunks
+    S.gardner_walked = use_table ? sc.gstats[2] : 0u;
+    S.gardner_full_domain = use_table ? sc.gstats[1] : 0u;
+    S.gardner_candidates = use_table ? sc.gstats[3] : 0u;
+    S.sync_overflow = sc.sync_overflow;
 
     ctx->stage_len[PDT_ST_PLL] = n;
     ctx->stage_len[PDT_ST_LOCK] = argos ? n : 0;
@@ -839,7 +852,7 @@ int pdt_stage_bytesync(pdt_ctx *ctx, const uint8_t *bits_host, uint64_t nbits)
     memset(&ctx->stats, 0, sizeof ctx->stats);
     ctx->stats.bits = nbits;
     ctx->stats.frames = sc.nframes;
-    ctx->stats.reserved = sc.sync_overflow;
+    ctx->stats.sync_overflow = sc.sync_overflow;
     memset(ctx->stage_len, 0, sizeof ctx->stage_len);
     return PDT_OK;
 }

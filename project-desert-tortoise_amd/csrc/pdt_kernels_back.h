@@ -277,7 +277,7 @@ struct GardnerDomain {
 };
 
 #define PDT_GTAB_THREADS 1024
-#define PDT_GTAB_TAIL 8192           // samples of the previous chunk the scouts run over
+#define PDT_GTAB_TAIL 4096           // samples of the previous chunk the scouts run over
 #define PDT_GTAB_MISS 0xffffffffu    // cell not tabulated
 
 __device__ __forceinline__ void gardner_entry_from_candidate(const float *__restrict__ in, const GardnerParams<float> &P,
@@ -322,49 +322,60 @@ __global__ void __launch_bounds__(PDT_GTAB_THREADS) k_gardner_table(const float 
     const int n_cur = (int)C;
     int n_stage = n_cur + 2 * (int)P.step + 24;
     if (n_stage > LEN) n_stage = LEN;               // host guarantees n_cur + margin <= LEN
-    for (int t = threadIdx.x; t < n_stage; t += PDT_GTAB_THREADS)
-        win[t] = (t < n_cur) ? in[base + t] : gardner_beyond(in, (const float *)nullptr, P, c, (long long)n_cur, (long long)t);
     const int tail_n = (C < PDT_GTAB_TAIL) ? (int)C : PDT_GTAB_TAIL;
-    if (c >= 1)
-        for (int t = threadIdx.x; t < tail_n; t += PDT_GTAB_THREADS) tail[t] = in[base - tail_n + t];
     if (threadIdx.x == 0) { s_mmin = 0x7fffffff; s_mmax = -0x7fffffff; }
     unsigned *row = table + (size_t)c * (size_t)(2 * D.n_q);
-    for (int t = threadIdx.x; t < 2 * D.n_q; t += PDT_GTAB_THREADS) row[t] = PDT_GTAB_MISS;
-    __syncthreads();
     const float hs = (float)((double)P.step / 2.0);
     const float kp = P.kp, lim = P.lim, step = P.step, nT = (float)n_cur;
+    __syncthreads();
+    if (threadIdx.x < 64 && c >= 1) {
+        // ---- wavefront 0: stage the tail of chunk c-1 and run the scouts while the other 15
+        // wavefronts stage chunk c.  64 trajectories started one 64th of a symbol apart.
+        for (int t = threadIdx.x; t < tail_n; t += 64 * 8) {
+            float r[8];
+#pragma unroll
+            for (int u = 0; u < 8; u++) r[u] = (t + u * 64 < tail_n) ? in[base - tail_n + t + u * 64] : 0.0f;
+#pragma unroll
+            for (int u = 0; u < 8; u++)
+                if (t + u * 64 < tail_n) tail[t + u * 64] = r[u];
+        }
+        __builtin_amdgcn_s_waitcnt(0);       // single wavefront: its own LDS writes are visible to it in order
+        __builtin_amdgcn_wave_barrier();
+        const float t0 = (float)(n_cur - tail_n);
+        float ns = t0 + 8.0f + step * (float)threadIdx.x * (1.0f / 64.0f);
+        float prev = 0, half = ns - hs, q_last = ns;
+        for (;;) {
+            const float rn = __builtin_rintf(ns);
+            if (!(rn < nT)) break;
+            const int i_cur = (int)(rn - t0);
+            int i_half = (int)(__builtin_rintf(half) - t0);
+            i_half = (i_half < 0) ? 0 : i_half;
+            const float cur = tail[i_cur];
+            const float mid = tail[(i_half < tail_n) ? i_half : tail_n - 1];
+            const float err = __builtin_amdgcn_fmed3f(kp * (cur - prev) * mid, -lim, lim);
+            ns = ns - err;
+            q_last = ns;
+            half = ns + hs;
+            ns = ns + step;
+            prev = cur;
+        }
+        const int m = (int)floorf((q_last - D.q_min) / D.u);
+        atomicMin(&s_mmin, m);
+        atomicMax(&s_mmax, m);
+    } else {
+        const int nthr = (c >= 1) ? PDT_GTAB_THREADS - 64 : PDT_GTAB_THREADS;
+        const int tid = (c >= 1) ? (int)threadIdx.x - 64 : (int)threadIdx.x;
+        for (int t = tid; t < n_stage; t += nthr)
+            win[t] = (t < n_cur) ? in[base + t] : gardner_beyond(in, (const float *)nullptr, P, c, (long long)n_cur, (long long)t);
+        for (int t = tid; t < 2 * D.n_q; t += nthr) row[t] = PDT_GTAB_MISS;
+    }
+    __syncthreads();
 
-    // ---- scouts: 64 trajectories over the tail of chunk c-1, started one 64th of a symbol apart
     int j_lo = 0, j_hi = (c == 0) ? 1 : D.n_cand;
     if (c >= 1) {
-        if (threadIdx.x < 64) {
-            const float t0 = (float)(n_cur - tail_n);
-            float ns = t0 + 8.0f + step * (float)threadIdx.x * (1.0f / 64.0f);
-            float prev = 0, half = ns - hs, q_last = ns;
-            for (;;) {
-                const float rn = __builtin_rintf(ns);
-                if (!(rn < nT)) break;
-                const int i_cur = (int)(rn - t0);
-                int i_half = (int)(__builtin_rintf(half) - t0);
-                i_half = (i_half < 0) ? 0 : i_half;
-                const float cur = tail[i_cur];
-                const float mid = tail[(i_half < tail_n) ? i_half : tail_n - 1];
-                float err = kp * (cur - prev) * mid;
-                err = (err > lim) ? lim : ((err < -lim) ? -lim : err);
-                ns = ns - err;
-                q_last = ns;
-                half = ns + hs;
-                ns = ns + step;
-                prev = cur;
-            }
-            const int m = (int)floorf((q_last - D.q_min) / D.u);
-            atomicMin(&s_mmin, m);
-            atomicMax(&s_mmax, m);
-        }
-        __syncthreads();
         const int one = (int)(1.0f / D.u);                        // grid points per sample
         const int spread = s_mmax - s_mmin;
-        if (spread <= one && s_mmin >= 0 && s_mmax < D.n_q) {     // locked: candidates within +-1 sample of the scouts
+        if (spread <= one && s_mmin >= 0 && s_mmax < D.n_q) {     // locked: candidates within +-1/2 sample of the scouts
             int m_lo = s_mmin - one / 2, m_hi = s_mmax + one / 2;
             m_lo = (m_lo < 0) ? 0 : m_lo;
             m_hi = (m_hi > D.n_q - 1) ? D.n_q - 1 : m_hi;
@@ -374,6 +385,7 @@ __global__ void __launch_bounds__(PDT_GTAB_THREADS) k_gardner_table(const float 
             atomicAdd(&stats[1], 1u);
         }
     }
+    if (threadIdx.x == 0) atomicAdd(&stats[3], (unsigned)(j_hi - j_lo));
 
     // ---- candidates.  Every trajectory takes at least k_min steps before it can reach the end
     // of the chunk (a step advances by at most step + 0.1 and entry instants are < step + 1), so

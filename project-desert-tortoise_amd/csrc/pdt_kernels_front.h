@@ -24,6 +24,7 @@ template <typename T> struct PllParams {
     T lock_thr;      // d_lock_threshold
     T lock_alpha;    // lockSigAlpha
     T alpha_acq, beta_acq, alpha_trk, beta_trk;
+    T alpha_wide, beta_wide;   // warm-up only: 8x the acquisition bandwidth (pulls in a kHz-off frequency guess)
     T max_freq, min_freq;
     T sweep0, avg0, phase0;
     int want_lock;   // 1 = lockSignalStreamOut != NULL (ARGOS)
@@ -351,7 +352,10 @@ __device__ __forceinline__ void pll_guess(const int *__restrict__ pcm, long long
 }
 
 // Blocks are aligned to absolute multiples of B; block j covers [max(S, j*B), min(n, (j+1)*B)).
-// Warm-up = [acquisition-gain stage of Wacq samples] + [tracking-gain stage of Wtrk samples].
+// Warm-up = [wide-band stage, Wacq/4 samples] + [acquisition-gain stage, Wacq] + [tracking-gain
+// stage, Wtrk].  The loop gains of the first two stages are free choices (they only steer the
+// guess); the tracking stage runs the reference's own gains so that the state merges with the
+// true trajectory.
 template <typename T, bool SLOW>
 __global__ void __launch_bounds__(64) k_pll_phase(const int *__restrict__ pcm, const T *__restrict__ theta, long long n,
                                                    PllParams<T> P, const PllLockInfo<T> *__restrict__ info, long long B,
@@ -373,10 +377,19 @@ __global__ void __launch_bounds__(64) k_pll_phase(const int *__restrict__ pcm, c
         freq = info->st.freq;
         pll_phase_range<T, false, SLOW>(theta, phi, S, start, phase, freq, P.alpha_trk, P.beta_trk, P.max_freq, P.min_freq);
     } else {
-        const long long ws = start - (Wacq + Wtrk);
-        pll_guess(pcm, ws, n, lag, info->st.freq, phase, freq);
-        if (freq > P.max_freq) freq = P.max_freq;
-        if (freq < P.min_freq) freq = P.min_freq;
+        const long long Wwide = (Wacq / 4 + 3) & ~3ll;
+        long long ws = start - (Wacq + Wtrk);
+        if (ws - Wwide > S) {
+            pll_guess(pcm, ws - Wwide, n, lag, info->st.freq, phase, freq);
+            if (freq > P.max_freq) freq = P.max_freq;
+            if (freq < P.min_freq) freq = P.min_freq;
+            pll_phase_range<T, false, SLOW>(theta, phi, ws - Wwide, ws, phase, freq, P.alpha_wide, P.beta_wide, P.max_freq,
+                                            P.min_freq);
+        } else {
+            pll_guess(pcm, ws, n, lag, info->st.freq, phase, freq);
+            if (freq > P.max_freq) freq = P.max_freq;
+            if (freq < P.min_freq) freq = P.min_freq;
+        }
         // acquisition-gain stage; its last 128 samples vote on which of the two stable lock
         // points we fell into: at the carrier the detector error sits at +-m (|err| < pi/2), at
         // the false point pi away it sits at +-(pi - m) (|err| > pi/2)

@@ -29,7 +29,7 @@ def check(pdt, orc, mode, bitstr, piece=4160):
         for g, f in zip(got, frames):
             assert (g["time"], g["bit_index"], g["inverted"], g["nbytes"], g["complete"]) == f[:5]
             assert bytes(g["bytes"]) == f[5]
-        return d.stats().reserved, len(frames)
+        return d.stats().sync_overflow, len(frames)
 
 
 def inv(s):

@@ -40,7 +40,7 @@ def run(label, mode, rate, iq, chunk=0, **kw):
     s = d.stats()
     print(f"  oracle {t1 - t0:.3f}s  gpu first {t2 - t1:.3f}s second {t3 - t2:.3f}s gpu_ms {s.gpu_ms:.3f}")
     print(f"  lock gpu {s.lock_sample} {s.lock_freq_hz:.2f}Hz norm {s.norm_factor:.7f} | orc {o.lock_sample} {o.lock_freq_hz:.2f}Hz norm {o.norm_factor:.7f}")
-    print(f"  pll blocks {s.pll_blocks} fixes {s.pll_seam_fixes}; agc blocks {s.agc_blocks} fixes {s.agc_seam_fixes}; sym {s.symbols} bits {s.bits} frames {s.frames} gardner_parallel {s.gardner_parallel} walked {s.reserved & 0xffff} fulldomain {s.reserved >> 16}")
+    print(f"  pll blocks {s.pll_blocks} fixes {s.pll_seam_fixes}; agc blocks {s.agc_blocks} fixes {s.agc_seam_fixes}; sym {s.symbols} bits {s.bits} frames {s.frames} gardner_parallel {s.gardner_parallel} walked {s.gardner_walked} fulldomain {s.gardner_full_domain} cand {s.gardner_candidates}")
     ok = True
     ok &= compare("pll", d.stage(pdt.ST_PLL), o.stage(orc.ST_PLL))
     if mode == pdt.MODE_ARGOS:
