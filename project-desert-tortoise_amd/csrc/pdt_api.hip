@@ -436,10 +436,10 @@ template <typename T> int run_capture(pdt_ctx *ctx, uint64_t n)
     GardnerDomain GD;
     GD.q_min = 0; GD.u = 0; GD.n_q = 0; GD.n_cand = 0;
     if constexpr (std::is_same<T, float>::value) {
-        const int table_len = GardnerLds<float>::LEN + 2 * GardnerLds<float>::OUT - PDT_GTAB_TAIL - 64;
+        const int table_len = 1 << 22;     // the table kernel walks the chunk in LDS windows: no size limit of its own
         const float nT = (float)chunk_out, stepf = (float)GP.step;
         if (!argos && !ctx->force_sequential_gardner && n_chunks >= 4 && chunk_out >= 256 &&
-            chunk_out + 2 * (long long)stepf + 24 <= table_len && chunk_out < (1 << 23)) {
+            chunk_out + 2 * (long long)stepf + 24 <= table_len && 8 * (long long)stepf + 256 < PDT_GTAB_WIN && chunk_out < (1 << 23)) {
             int e;
             (void)frexpf(nT - stepf - 1.0f, &e);                              // value in [2^(e-1), 2^e)
             const float u = ldexpf(1.0f, e - 24);

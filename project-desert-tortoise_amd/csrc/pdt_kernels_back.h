@@ -304,15 +304,16 @@ __device__ __forceinline__ unsigned gardner_encode_exit(const GardnerDomain &D, 
     return ok ? (((unsigned)(2 * m + v)) | (count << 20)) : PDT_GTAB_MISS;
 }
 
-__global__ void __launch_bounds__(PDT_GTAB_THREADS) k_gardner_table(const float *__restrict__ in, GardnerParams<float> P,
-                                                                     GardnerDomain D, long long n_tab_chunks,
-                                                                     const unsigned *__restrict__ cand_k,
-                                                                     const int *__restrict__ m_first,
-                                                                     unsigned *__restrict__ table,
-                                                                     unsigned *__restrict__ stats /* [0] bad [1] full-domain chunks */)
+#define PDT_GTAB_WIN 15872          // LDS window (floats): 62 KiB + 16 KiB tail -> two blocks per CU
+
+__global__ void __launch_bounds__(PDT_GTAB_THREADS, 8) k_gardner_table(const float *__restrict__ in, GardnerParams<float> P,
+                                                                        GardnerDomain D, long long n_tab_chunks,
+                                                                        const unsigned *__restrict__ cand_k,
+                                                                        const int *__restrict__ m_first,
+                                                                        unsigned *__restrict__ table,
+                                                                        unsigned *__restrict__ stats /* [0] bad [1] full-domain chunks [3] candidates */)
 {
-    constexpr int LEN = GardnerLds<float>::LEN + GardnerLds<float>::OUT * 2 - PDT_GTAB_TAIL - 64;
-    __shared__ float win[LEN];
+    __shared__ float win[PDT_GTAB_WIN];
     __shared__ float tail[PDT_GTAB_TAIL];
     __shared__ int s_mmin, s_mmax;
     const long long c = blockIdx.x;                 // chunk (always a full one)
@@ -320,17 +321,17 @@ __global__ void __launch_bounds__(PDT_GTAB_THREADS) k_gardner_table(const float 
     const long long C = P.chunk_out;
     const long long base = c * C;
     const int n_cur = (int)C;
-    int n_stage = n_cur + 2 * (int)P.step + 24;
-    if (n_stage > LEN) n_stage = LEN;               // host guarantees n_cur + margin <= LEN
     const int tail_n = (C < PDT_GTAB_TAIL) ? (int)C : PDT_GTAB_TAIL;
     if (threadIdx.x == 0) { s_mmin = 0x7fffffff; s_mmax = -0x7fffffff; }
     unsigned *row = table + (size_t)c * (size_t)(2 * D.n_q);
     const float hs = (float)((double)P.step / 2.0);
     const float kp = P.kp, lim = P.lim, step = P.step, nT = (float)n_cur;
+    const int margin = 2 * (int)step + 24;          // look-ahead the staged data must cover past a stop point
+    const int back = (int)step + 8;                 // a mid-point lies at most this far behind a stop point
     __syncthreads();
+
+    // ---- scouts (wavefront 0) while the others initialise the table row
     if (threadIdx.x < 64 && c >= 1) {
-        // ---- wavefront 0: stage the tail of chunk c-1 and run the scouts while the other 15
-        // wavefronts stage chunk c.  64 trajectories started one 64th of a symbol apart.
         for (int t = threadIdx.x; t < tail_n; t += 64 * 8) {
             float r[8];
 #pragma unroll
@@ -339,7 +340,7 @@ __global__ void __launch_bounds__(PDT_GTAB_THREADS) k_gardner_table(const float 
             for (int u = 0; u < 8; u++)
                 if (t + u * 64 < tail_n) tail[t + u * 64] = r[u];
         }
-        __builtin_amdgcn_s_waitcnt(0);       // single wavefront: its own LDS writes are visible to it in order
+        __builtin_amdgcn_s_waitcnt(0);
         __builtin_amdgcn_wave_barrier();
         const float t0 = (float)(n_cur - tail_n);
         float ns = t0 + 8.0f + step * (float)threadIdx.x * (1.0f / 64.0f);
@@ -365,8 +366,6 @@ __global__ void __launch_bounds__(PDT_GTAB_THREADS) k_gardner_table(const float 
     } else {
         const int nthr = (c >= 1) ? PDT_GTAB_THREADS - 64 : PDT_GTAB_THREADS;
         const int tid = (c >= 1) ? (int)threadIdx.x - 64 : (int)threadIdx.x;
-        for (int t = tid; t < n_stage; t += nthr)
-            win[t] = (t < n_cur) ? in[base + t] : gardner_beyond(in, (const float *)nullptr, P, c, (long long)n_cur, (long long)t);
         for (int t = tid; t < 2 * D.n_q; t += nthr) row[t] = PDT_GTAB_MISS;
     }
     __syncthreads();
@@ -387,70 +386,96 @@ __global__ void __launch_bounds__(PDT_GTAB_THREADS) k_gardner_table(const float 
     }
     if (threadIdx.x == 0) atomicAdd(&stats[3], (unsigned)(j_hi - j_lo));
 
-    // ---- candidates.  Every trajectory takes at least k_min steps before it can reach the end
-    // of the chunk (a step advances by at most step + 0.1 and entry instants are < step + 1), so
-    // the bulk of the walk is a counted, wave-uniform loop without any per-lane test; only the
-    // first symbol (stale mid-point index, Q3) and the last few are handled with checks.
-    int k_min = (int)((nT - 4.0f - (step + 1.2f)) / (step + 0.101f)) - 1;
-    if (k_min < 0) k_min = 0;
-    for (int j = j_lo + (int)threadIdx.x; j < j_hi; j += PDT_GTAB_THREADS) {
-        float ns, prev, half;
+    // ---- candidates, 1024 at a time; each pass walks the chunk window by window.  All lanes of a
+    // pass are within a symbol of each other, so they cross the window seams together.  Inside a
+    // window every trajectory takes at least k_min steps before it can reach the stop point (a
+    // step advances by at most step + 0.1), so the bulk of the walk is a counted, wave-uniform
+    // loop without any per-lane test.
+    for (int j0 = j_lo; j0 < j_hi; j0 += PDT_GTAB_THREADS) {
+        const int j = j0 + (int)threadIdx.x;
+        const bool active = j < j_hi;
+        float ns = 0, prev = 0, half = 0, q_last = 0;
+        unsigned i_last = 0, count = 0;
         int k = 0;
-        if (c == 0) { ns = 0; prev = 0; half = 0; }
-        else {
+        if (active && c >= 1) {
             k = (int)cand_k[j];
             gardner_entry_from_candidate(in, P, D, c, k, ns, prev, half);
         }
-        float q_last = 0;
-        unsigned i_last = 0, count = 0;
-        // first symbol: the mid-point index is the stale one of the previous chunk
-        {
-            const float rn = __builtin_rintf(ns);
-            if (rn < nT) {
-                const unsigned i_cur = (unsigned)rn;
-                const unsigned i_half = (unsigned)__builtin_rintf(half);
-                const float cur = win[i_cur];
-                const float mid = (i_half < (unsigned)n_stage) ? win[i_half] : 0.0f;
-                const float err = __builtin_amdgcn_fmed3f(kp * (cur - prev) * mid, -lim, lim);
-                ns = ns - err;
-                q_last = ns;
-                half = ns + hs;
-                ns = ns + step;
-                prev = cur;
-                i_last = i_cur;
-                count = 1;
+        int wbase = 0;
+        float enter_hi = step + 1.2f;                 // upper bound of ns when entering the window
+        for (;;) {
+            // stage [wbase, wbase + PDT_GTAB_WIN)
+            __syncthreads();
+            for (int t = threadIdx.x; t < PDT_GTAB_WIN; t += PDT_GTAB_THREADS) {
+                const int idx = wbase + t;
+                win[t] = (idx < n_cur) ? in[base + idx]
+                                       : ((idx < n_cur + margin) ? gardner_beyond(in, (const float *)nullptr, P, c, (long long)n_cur, (long long)idx) : 0.0f);
             }
+            __syncthreads();
+            const int wend = wbase + PDT_GTAB_WIN;
+            const bool last_window = (wend - margin >= n_cur);
+            const float stop = last_window ? nT : (float)(wend - margin);    // lanes leave the window at rint(ns) >= stop
+            const float wb = (float)wbase;
+            if (active) {
+                if (wbase == 0) {
+                    // first symbol: the mid-point index is the stale one of the previous chunk (Q3)
+                    const float rn = __builtin_rintf(ns);
+                    if (rn < nT) {
+                        const unsigned i_cur = (unsigned)rn;
+                        const unsigned i_half = (unsigned)__builtin_rintf(half);
+                        const float cur = win[i_cur];
+                        float mid;
+                        if (i_half < (unsigned)PDT_GTAB_WIN) mid = win[i_half];
+                        else mid = (i_half < (unsigned)n_cur) ? in[base + i_half]
+                                                              : gardner_beyond(in, (const float *)nullptr, P, c, (long long)n_cur, (long long)i_half);
+                        const float err = __builtin_amdgcn_fmed3f(kp * (cur - prev) * mid, -lim, lim);
+                        ns = ns - err;
+                        q_last = ns;
+                        half = ns + hs;
+                        ns = ns + step;
+                        prev = cur;
+                        i_last = i_cur;
+                        count = 1;
+                    }
+                }
+                if (count >= 1) {
+                    int k_min = (int)((stop - 4.0f - enter_hi) / (step + 0.101f)) - 1;
+                    if (k_min < 0) k_min = 0;
+                    for (int it = 0; it < k_min; it++) {
+                        const float cur = win[(int)(__builtin_rintf(ns) - wb)];
+                        const float mid = win[(int)(__builtin_rintf(half) - wb)];
+                        const float err = __builtin_amdgcn_fmed3f(kp * (cur - prev) * mid, -lim, lim);
+                        ns = ns - err;
+                        half = ns + hs;
+                        ns = ns + step;
+                        prev = cur;
+                    }
+                    count += (unsigned)k_min;
+                    for (;;) {
+                        const float rn = __builtin_rintf(ns);
+                        if (!(rn < stop)) break;
+                        const float cur = win[(int)(rn - wb)];
+                        const float mid = win[(int)(__builtin_rintf(half) - wb)];
+                        const float err = __builtin_amdgcn_fmed3f(kp * (cur - prev) * mid, -lim, lim);
+                        ns = ns - err;
+                        q_last = ns;
+                        half = ns + hs;
+                        ns = ns + step;
+                        prev = cur;
+                        i_last = (unsigned)rn;
+                        count++;
+                    }
+                }
+            }
+            if (last_window) break;
+            enter_hi = stop + step + 1.2f;
+            wbase = wend - margin - back;
         }
-        if (count == 1) {
-            for (int it = 1; it < k_min; it++) {
-                const float cur = win[(unsigned)__builtin_rintf(ns)];
-                const float mid = win[(unsigned)__builtin_rintf(half)];
-                const float err = __builtin_amdgcn_fmed3f(kp * (cur - prev) * mid, -lim, lim);
-                ns = ns - err;
-                half = ns + hs;
-                ns = ns + step;
-                prev = cur;
-            }
-            if (k_min > 1) count = (unsigned)k_min;
-            for (;;) {
-                const float rn = __builtin_rintf(ns);
-                if (!(rn < nT)) break;
-                const unsigned i_cur = (unsigned)rn;
-                const float cur = win[i_cur];
-                const float mid = win[(unsigned)__builtin_rintf(half)];
-                const float err = __builtin_amdgcn_fmed3f(kp * (cur - prev) * mid, -lim, lim);
-                ns = ns - err;
-                q_last = ns;
-                half = ns + hs;
-                ns = ns + step;
-                prev = cur;
-                i_last = i_cur;
-                count++;
-            }
+        if (active) {
+            const unsigned cell = gardner_encode_exit(D, q_last, i_last, count);
+            if (cell == PDT_GTAB_MISS) atomicAdd(&stats[0], 1u);  // exit outside the enumerated domain (never expected)
+            row[k] = cell;
         }
-        const unsigned cell = gardner_encode_exit(D, q_last, i_last, count);
-        if (cell == PDT_GTAB_MISS) atomicAdd(&stats[0], 1u);      // exit outside the enumerated domain (never expected)
-        row[k] = cell;
     }
 }
 
