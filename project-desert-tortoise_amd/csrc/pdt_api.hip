@@ -82,7 +82,8 @@ struct pdt_ctx {
     uint32_t interp, ntaps;
     hipStream_t stream = nullptr;
     bool own_stream = false;
-    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    hipEvent_t ev0 = nullptr, ev1 = nullptr, ev_fork = nullptr, ev_join = nullptr;
+    hipStream_t stream2 = nullptr;     // side stream: block-parallel PLL phase runs beside the sequential acquisition
 
     DevBuf pcm, pll, lock, fir, agc, sym, symidx, bits, bitsym, hits, frames, taps, mag, seams_pll, seams_agc, scal, lockinfo, term, seams_ema, gtable, gentries, gcand, gmfirst, stiles;
     long long gcand_key = -1;          // (chunk_out, step) the candidate list on the device was built for
@@ -126,24 +127,28 @@ int poes_interp(uint32_t rate) { return (int)rint(150000.0 / (double)(float)rate
 class Launcher {
   public:
     Launcher(pdt_ctx *c) : ctx(c) {}
-    void begin(const char *name)
+    void begin(const char *name, hipStream_t s = nullptr)
     {
         if (!ctx->cfg.profile) return;
         KTimer t;
         t.name = name;
         (void)hipEventCreate(&t.a);
         (void)hipEventCreate(&t.b);
-        (void)hipEventRecord(t.a, ctx->stream);
+        cur = s ? s : ctx->stream;
+        (void)hipEventRecord(t.a, cur);
         ctx->timers.push_back(t);
+        open_idx = ctx->timers.size() - 1;
     }
     void end()
     {
         if (!ctx->cfg.profile) return;
-        (void)hipEventRecord(ctx->timers.back().b, ctx->stream);
+        (void)hipEventRecord(ctx->timers[open_idx].b, cur);
     }
 
   private:
     pdt_ctx *ctx;
+    hipStream_t cur = nullptr;
+    size_t open_idx = 0;
 };
 
 template <typename T> PllParams<T> make_pll_params(const pdt_ctx *ctx)
@@ -352,32 +357,46 @@ template <typename T> int run_capture(pdt_ctx *ctx, uint64_t n)
         hipLaunchKernelGGL(k_pll_theta<T>, dim3((unsigned)((N + 255) / 256)), dim3(256), 0, st, d_pcm, N, d_theta);
         L.end();
     }
+    // fork: the block-parallel phase recurrence (side stream) runs beside the sequential acquisition
+    const long long grid_pll = (nb_pll + 63) / 64;
+    // a single +-2pi correction per step is exact as long as one step cannot move the phase by 2pi
+    const double worst = (double)PP.max_freq + M_PI * std::max({(double)PP.alpha_acq + (double)PP.beta_acq,
+                                                                (double)PP.alpha_trk + (double)PP.beta_trk,
+                                                                (double)PP.alpha_wide + (double)PP.beta_wide});
+    const bool slow_wrap = worst >= 2.0 * M_PI - 0.05;
+    if (N > 0) {
+        HIP_TRY(hipEventRecord(ctx->ev_fork, st));
+        HIP_TRY(hipStreamWaitEvent(ctx->stream2, ctx->ev_fork, 0));
+        L.begin("pll_phase", ctx->stream2);
+        if (slow_wrap)
+            hipLaunchKernelGGL((k_pll_phase<T, true>), dim3((unsigned)grid_pll), dim3(64), 0, ctx->stream2, d_pcm, d_theta, N, PP, Bp,
+                               Wacq, Wp, lag, d_phi, (PllSeam<T> *)ctx->seams_pll.p);
+        else
+            hipLaunchKernelGGL((k_pll_phase<T, false>), dim3((unsigned)grid_pll), dim3(64), 0, ctx->stream2, d_pcm, d_theta, N, PP, Bp,
+                               Wacq, Wp, lag, d_phi, (PllSeam<T> *)ctx->seams_pll.p);
+        L.end();
+        HIP_TRY(hipEventRecord(ctx->ev_join, ctx->stream2));
+    }
     L.begin("pll_acquire");
     hipLaunchKernelGGL(k_pll_acquire<T>, dim3(1), dim3(64), 0, st, d_pcm, N, PP, d_pll, d_lock, d_info);
     L.end();
     if (N > 0) {
-        const long long grid = (nb_pll + 63) / 64;
-        // a single +-2pi correction per step is exact as long as one step cannot move the phase by 2pi
-        const double worst = (double)PP.max_freq + M_PI * std::max({(double)PP.alpha_acq + (double)PP.beta_acq,
-                                                                    (double)PP.alpha_trk + (double)PP.beta_trk,
-                                                                    (double)PP.alpha_wide + (double)PP.beta_wide});
-        const bool slow_wrap = worst >= 2.0 * M_PI - 0.05;
-        L.begin("pll_phase");
-        if (slow_wrap)
-            hipLaunchKernelGGL((k_pll_phase<T, true>), dim3((unsigned)grid), dim3(64), 0, st, d_pcm, d_theta, N, PP, d_info, Bp,
-                               Wacq, Wp, lag, d_phi, (PllSeam<T> *)ctx->seams_pll.p);
-        else
-            hipLaunchKernelGGL((k_pll_phase<T, false>), dim3((unsigned)grid), dim3(64), 0, st, d_pcm, d_theta, N, PP, d_info, Bp,
-                               Wacq, Wp, lag, d_phi, (PllSeam<T> *)ctx->seams_pll.p);
-        L.end();
+        const long long grid = grid_pll;
+        HIP_TRY(hipStreamWaitEvent(st, ctx->ev_join, 0));                  // join
         L.begin("pll_fix");
-        if (slow_wrap)
+        if (slow_wrap) {
+            hipLaunchKernelGGL((k_pll_head<T, true>), dim3(1), dim3(64), 0, st, d_theta, N, PP, d_info, Bp, d_phi,
+                               (PllSeam<T> *)ctx->seams_pll.p);
             hipLaunchKernelGGL((k_pll_fix<T, true>), dim3(1), dim3(64), 0, st, d_theta, N, PP, d_info, Bp, d_phi,
                                (PllSeam<T> *)ctx->seams_pll.p, d_sc->counters);
-        else
+        } else {
+            hipLaunchKernelGGL((k_pll_head<T, false>), dim3(1), dim3(64), 0, st, d_theta, N, PP, d_info, Bp, d_phi,
+                               (PllSeam<T> *)ctx->seams_pll.p);
             hipLaunchKernelGGL((k_pll_fix<T, false>), dim3(1), dim3(64), 0, st, d_theta, N, PP, d_info, Bp, d_phi,
                                (PllSeam<T> *)ctx->seams_pll.p, d_sc->counters);
+        }
         L.end();
+        (void)grid;
         L.begin("pll_mix");
         if (argos)
             hipLaunchKernelGGL((k_pll_mix<T, true>), dim3((unsigned)((N + 255) / 256)), dim3(256), 0, st, d_pcm, d_phi, N, PP,
@@ -740,6 +759,9 @@ int pdt_open(const pdt_config *cfg, pdt_ctx **out)
     ctx->own_stream = true;
     (void)hipEventCreate(&ctx->ev0);
     (void)hipEventCreate(&ctx->ev1);
+    (void)hipEventCreateWithFlags(&ctx->ev_fork, hipEventDisableTiming);
+    (void)hipEventCreateWithFlags(&ctx->ev_join, hipEventDisableTiming);
+    if (hipStreamCreateWithFlags(&ctx->stream2, hipStreamNonBlocking) != hipSuccess) { delete ctx; return PDT_ERR_NOGPU; }
     memset(&ctx->stats, 0, sizeof ctx->stats);
     memset(ctx->stage_len, 0, sizeof ctx->stage_len);
     ctx->axis_f.init((float)(1.0 / (double)(float)cfg->sample_rate));        // wave.c:96-97
@@ -759,6 +781,9 @@ void pdt_close(pdt_ctx *ctx)
     for (DevBuf *b : bufs) b->release();
     if (ctx->ev0) (void)hipEventDestroy(ctx->ev0);
     if (ctx->ev1) (void)hipEventDestroy(ctx->ev1);
+    if (ctx->ev_fork) (void)hipEventDestroy(ctx->ev_fork);
+    if (ctx->ev_join) (void)hipEventDestroy(ctx->ev_join);
+    if (ctx->stream2) (void)hipStreamDestroy(ctx->stream2);
     if (ctx->own_stream && ctx->stream) (void)hipStreamDestroy(ctx->stream);
     delete ctx;
 }

@@ -351,74 +351,94 @@ __device__ __forceinline__ void pll_guess(const int *__restrict__ pcm, long long
     freq = (T)f;
 }
 
-// Blocks are aligned to absolute multiples of B; block j covers [max(S, j*B), min(n, (j+1)*B)).
+// Blocks are aligned to absolute multiples of B: block j covers [j*B, min(n, (j+1)*B)).
 // Warm-up = [wide-band stage, Wacq/4 samples] + [acquisition-gain stage, Wacq] + [tracking-gain
 // stage, Wtrk].  The loop gains of the first two stages are free choices (they only steer the
 // guess); the tracking stage runs the reference's own gains so that the state merges with the
 // true trajectory.
+//
+// The kernel does not need to know where the one-time lock happened: every block starts from a
+// data-derived guess, so it runs CONCURRENTLY with the sequential acquisition kernel (second
+// stream).  k_pll_head then walks from the lock sample to the end of its block with the true
+// state, and k_pll_fix validates every later seam against that chain; phases computed for
+// samples before the lock are simply never used.
 template <typename T, bool SLOW>
 __global__ void __launch_bounds__(64) k_pll_phase(const int *__restrict__ pcm, const T *__restrict__ theta, long long n,
-                                                   PllParams<T> P, const PllLockInfo<T> *__restrict__ info, long long B,
-                                                   long long Wacq, long long Wtrk, int lag, T *__restrict__ phi,
-                                                   PllSeam<T> *__restrict__ seams)
+                                                   PllParams<T> P, long long B, long long Wacq, long long Wtrk, int lag,
+                                                   T *__restrict__ phi, PllSeam<T> *__restrict__ seams)
 {
-    const long long lock_at = info->lock_sample;
-    if (lock_at < 0) return;
-    const long long S = lock_at + 1;
-    const long long j = S / B + (long long)blockIdx.x * blockDim.x + threadIdx.x;
-    long long start = j * B;
+    const long long j = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    const long long start = j * B;
     if (start >= n) return;
-    if (start < S) start = S;
-    const long long end = ((j + 1) * B < n) ? (j + 1) * B : n;
-    T phase, freq;
-    if (start - (Wacq + Wtrk) <= S) {
-        // replay from the true post-lock state: exact by construction
-        phase = info->st.phase;
-        freq = info->st.freq;
-        pll_phase_range<T, false, SLOW>(theta, phi, S, start, phase, freq, P.alpha_trk, P.beta_trk, P.max_freq, P.min_freq);
-    } else {
-        const long long Wwide = (Wacq / 4 + 3) & ~3ll;
-        long long ws = start - (Wacq + Wtrk);
-        if (ws - Wwide > S) {
-            pll_guess(pcm, ws - Wwide, n, lag, info->st.freq, phase, freq);
-            if (freq > P.max_freq) freq = P.max_freq;
-            if (freq < P.min_freq) freq = P.min_freq;
-            pll_phase_range<T, false, SLOW>(theta, phi, ws - Wwide, ws, phase, freq, P.alpha_wide, P.beta_wide, P.max_freq,
-                                            P.min_freq);
-        } else {
-            pll_guess(pcm, ws, n, lag, info->st.freq, phase, freq);
-            if (freq > P.max_freq) freq = P.max_freq;
-            if (freq < P.min_freq) freq = P.min_freq;
-        }
-        // acquisition-gain stage; its last 128 samples vote on which of the two stable lock
-        // points we fell into: at the carrier the detector error sits at +-m (|err| < pi/2), at
-        // the false point pi away it sits at +-(pi - m) (|err| > pi/2)
-        const long long vote0 = (Wacq > 160) ? ws + Wacq - 128 : ws + Wacq;
-        pll_phase_range<T, false, SLOW>(theta, phi, ws, vote0, phase, freq, P.alpha_acq, P.beta_acq, P.max_freq, P.min_freq);
-        int far = 0, seen = 0;
-        for (long long i = vote0; i < ws + Wacq; i++) {
-            const T th = theta[i];
-            T d = th - phase;
-            if (d > (T)PDT_PI) d -= (T)(2 * PDT_PI);
-            if (d < (T)-PDT_PI) d += (T)(2 * PDT_PI);
-            far += (Real<T>::abs(d) > (T)(PDT_PI / 2)) ? 1 : 0;
-            seen++;
-            pll_phase_step<T, SLOW>(th, phase, freq, P.alpha_acq, P.beta_acq, P.max_freq, P.min_freq);
-        }
-        if (2 * far > seen) {
-            phase = (phase > 0) ? phase - (T)PDT_PI : phase + (T)PDT_PI;     // stays inside (-2pi, 2pi)
-            if (freq >= 0 && phase < 0) phase += (T)(2 * PDT_PI);
-            if (freq < 0 && phase > 0) phase -= (T)(2 * PDT_PI);
-        }
-        pll_phase_range<T, false, SLOW>(theta, phi, ws + Wacq, start, phase, freq, P.alpha_trk, P.beta_trk, P.max_freq, P.min_freq);
+    const long long end = (start + B < n) ? start + B : n;
+    const long long Wwide = (Wacq / 4 + 3) & ~3ll;
+    long long w_wide = Wwide, w_acq = Wacq, w_trk = Wtrk;
+    if (start < w_wide + w_acq + w_trk) {           // near the beginning of the capture: shrink the stages
+        w_trk = (start < w_trk) ? start : w_trk;
+        w_acq = (start - w_trk < w_acq) ? start - w_trk : w_acq;
+        w_wide = (start - w_trk - w_acq < w_wide) ? start - w_trk - w_acq : w_wide;
+        w_acq &= ~3ll;
+        w_wide &= ~3ll;
     }
+    const long long ws = start - w_trk - w_acq - w_wide;
+    T phase, freq;
+    pll_guess(pcm, ws, n, lag, (T)0, phase, freq);
+    if (freq > P.max_freq) freq = P.max_freq;
+    if (freq < P.min_freq) freq = P.min_freq;
+    pll_phase_range<T, false, SLOW>(theta, phi, ws, ws + w_wide, phase, freq, P.alpha_wide, P.beta_wide, P.max_freq, P.min_freq);
+    // acquisition-gain stage; its last 128 samples vote on which of the two stable lock points we
+    // fell into: at the carrier the detector error sits at +-m (|err| < pi/2), at the false point
+    // pi away it sits at +-(pi - m) (|err| > pi/2)
+    const long long a0 = ws + w_wide, a1 = a0 + w_acq;
+    const long long vote0 = (w_acq > 160) ? a1 - 128 : a1;
+    pll_phase_range<T, false, SLOW>(theta, phi, a0, vote0, phase, freq, P.alpha_acq, P.beta_acq, P.max_freq, P.min_freq);
+    int far = 0, seen = 0;
+    for (long long i = vote0; i < a1; i++) {
+        const T th = theta[i];
+        T d = th - phase;
+        if (d > (T)PDT_PI) d -= (T)(2 * PDT_PI);
+        if (d < (T)-PDT_PI) d += (T)(2 * PDT_PI);
+        far += (Real<T>::abs(d) > (T)(PDT_PI / 2)) ? 1 : 0;
+        seen++;
+        pll_phase_step<T, SLOW>(th, phase, freq, P.alpha_acq, P.beta_acq, P.max_freq, P.min_freq);
+    }
+    if (2 * far > seen) {
+        phase = (phase > 0) ? phase - (T)PDT_PI : phase + (T)PDT_PI;     // stays inside (-2pi, 2pi)
+        if (freq >= 0 && phase < 0) phase += (T)(2 * PDT_PI);
+        if (freq < 0 && phase > 0) phase -= (T)(2 * PDT_PI);
+    }
+    pll_phase_range<T, false, SLOW>(theta, phi, a1, start, phase, freq, P.alpha_trk, P.beta_trk, P.max_freq, P.min_freq);
     PllSeam<T> sm;
     sm.phase0 = phase;
     sm.freq0 = freq;
     pll_phase_range<T, true, SLOW>(theta, phi, start, end, phase, freq, P.alpha_trk, P.beta_trk, P.max_freq, P.min_freq);
     sm.phase1 = phase;
     sm.freq1 = freq;
-    seams[j - S / B] = sm;
+    seams[j] = sm;
+}
+
+// From the sample after the lock to the end of its block with the TRUE state (one lane); the
+// block's seam record then carries the true end state, the anchor of the validation chain.
+template <typename T, bool SLOW>
+__global__ void __launch_bounds__(64) k_pll_head(const T *__restrict__ theta, long long n, PllParams<T> P,
+                                                  const PllLockInfo<T> *__restrict__ info, long long B, T *__restrict__ phi,
+                                                  PllSeam<T> *__restrict__ seams)
+{
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    const long long lock_at = info->lock_sample;
+    if (lock_at < 0) return;
+    const long long S = lock_at + 1;
+    if (S >= n) return;
+    const long long j0 = S / B;
+    const long long end = ((j0 + 1) * B < n) ? (j0 + 1) * B : n;
+    T phase = info->st.phase, freq = info->st.freq;
+    pll_phase_range<T, true, SLOW>(theta, phi, S, end, phase, freq, P.alpha_trk, P.beta_trk, P.max_freq, P.min_freq);
+    PllSeam<T> sm;
+    sm.phase0 = info->st.phase;
+    sm.freq0 = info->st.freq;
+    sm.phase1 = phase;
+    sm.freq1 = freq;
+    seams[j0] = sm;
 }
 
 template <typename T> __device__ __forceinline__ bool bits_equal(T x, T y);
@@ -448,14 +468,14 @@ __global__ void __launch_bounds__(64) k_pll_fix(const T *__restrict__ theta, lon
         return;
     }
     const long long S = lock_at + 1;
-    const long long j0 = S / B;
-    const long long nb = (S < n) ? ((n - 1) / B - j0 + 1) : 0;
+    const long long j0 = S / B;                                     // block that contains the lock (anchored by k_pll_head)
+    const long long nb_abs = (n + B - 1) / B;                       // absolute block count
     unsigned fixes = 0;
-    long long r = 1;
-    while (r < nb) {
+    long long r = j0 + 1;
+    while (r < nb_abs) {
         const long long mine = r + threadIdx.x;
         bool bad = false;
-        if (mine < nb) {
+        if (mine < nb_abs) {
             const PllSeam<T> prev = seams[mine - 1];
             const PllSeam<T> cur = seams[mine];
             bad = !(bits_equal(prev.phase1, cur.phase0) && bits_equal(prev.freq1, cur.freq0));
@@ -466,8 +486,8 @@ __global__ void __launch_bounds__(64) k_pll_fix(const T *__restrict__ theta, lon
         fixes++;
         const PllSeam<T> prev = seams[rb - 1];
         T phase = prev.phase1, freq = prev.freq1;
-        const long long start = (j0 + rb) * B;
-        const long long end = ((j0 + rb + 1) * B < n) ? (j0 + rb + 1) * B : n;
+        const long long start = rb * B;
+        const long long end = ((rb + 1) * B < n) ? (rb + 1) * B : n;
         if (threadIdx.x == 0) {
             pll_phase_range<T, true, SLOW>(theta, phi, start, end, phase, freq, P.alpha_trk, P.beta_trk, P.max_freq, P.min_freq);
             PllSeam<T> upd;
@@ -482,7 +502,7 @@ __global__ void __launch_bounds__(64) k_pll_fix(const T *__restrict__ theta, lon
         r = rb + 1;
     }
     if (threadIdx.x == 0) {
-        counters[0] = (unsigned)nb;
+        counters[0] = (unsigned)((S < n) ? nb_abs - j0 : 0);
         counters[1] = fixes;
     }
 }
