@@ -85,7 +85,7 @@ struct pdt_ctx {
     hipEvent_t ev0 = nullptr, ev1 = nullptr, ev_fork = nullptr, ev_join = nullptr;
     hipStream_t stream2 = nullptr;     // side stream: block-parallel PLL phase runs beside the sequential acquisition
 
-    DevBuf pcm, pll, lock, fir, agc, sym, symidx, bits, bitsym, hits, frames, taps, mag, seams_pll, seams_agc, scal, lockinfo, term, seams_ema, gtable, gentries, gcand, gmfirst, stiles;
+    DevBuf pcm, pll, lock, fir, agc, sym, symidx, bits, bitsym, hits, frames, taps, mag, seams_pll, seams_agc, scal, lockinfo, term, seams_ema, gtable, gentries, gcand, gmfirst, stiles, gsegmap, gsegstart;
     long long gcand_key = -1;          // (chunk_out, step) the candidate list on the device was built for
     bool force_sequential_gardner = false;
     int gardner_mode = 0;              // 0 sequential, 1 state table (last run)
@@ -217,8 +217,8 @@ void launch_bytesync(pdt_ctx *ctx, hipStream_t st, const SyncParams &SP, DevScal
     SyncTile *d_stiles = (SyncTile *)ctx->stiles.p;
     hipLaunchKernelGGL(k_sync_hits_tile, dim3((unsigned)n_stiles), dim3(256), 0, st, d_bits, &d_sc->nbits, SP, d_stiles,
                        &d_sc->sync_overflow);
-    hipLaunchKernelGGL(k_sync_frames_tiles, dim3(1), dim3(64), 0, st, (const SyncTile *)d_stiles, &d_sc->nbits, SP, d_frames,
-                       &d_sc->nframes, frame_cap, &d_sc->sync_overflow);
+    hipLaunchKernelGGL(k_sync_frames_tiles, dim3(1), dim3(256), 0, st, (const SyncTile *)d_stiles, &d_sc->nbits, SP, d_hits, hit_cap,
+                       d_frames, &d_sc->nframes, frame_cap, &d_sc->sync_overflow);
     // generic path (atomic append + sort), only when a tile overflowed
     const long long grid = (bit_cap + 255) / 256;
     hipLaunchKernelGGL(k_sync_hits, dim3((unsigned)grid), dim3(256), 0, st, d_bits, &d_sc->nbits, SP, d_hits, &d_sc->nhits, hit_cap,
@@ -507,9 +507,20 @@ template <typename T> int run_capture(pdt_ctx *ctx, uint64_t n)
                                n_tab, (const unsigned *)ctx->gcand.p, (const int *)ctx->gmfirst.p, (unsigned *)ctx->gtable.p,
                                d_sc->gstats);
             L.end();
+            const int G = 32;                                                  // chunks per chain segment
+            const long long n_seg = (n_chunks + G - 1) / G;
+            if ((rc = ctx->gsegmap.ensure((size_t)n_seg * (size_t)(2 * GD.n_q) * sizeof(GardnerSegCell)))) return rc;
+            if ((rc = ctx->gsegstart.ensure((size_t)n_seg * sizeof(GardnerSegStart)))) return rc;
             L.begin("gardner_chain");
+            HIP_TRY(hipMemsetAsync(ctx->gsegstart.p, 0, (size_t)n_seg * sizeof(GardnerSegStart), st));
+            hipLaunchKernelGGL(k_gardner_segmap, dim3((unsigned)n_seg), dim3(1024), 0, st, (const unsigned *)ctx->gtable.p, GD, n_chunks,
+                               G, (GardnerSegCell *)ctx->gsegmap.p);
             hipLaunchKernelGGL(k_gardner_chain, dim3(1), dim3(PDT_GARDNER_THREADS), 0, st, (const float *)d_agc, GP, GD, n_chunks,
-                               (const unsigned *)ctx->gtable.p, (GardnerEntry<float> *)ctx->gentries.p, d_sc->gstats);
+                               (const unsigned *)ctx->gtable.p, (const GardnerSegCell *)ctx->gsegmap.p, G,
+                               (GardnerSegStart *)ctx->gsegstart.p, (GardnerEntry<float> *)ctx->gentries.p, d_sc->gstats);
+            hipLaunchKernelGGL(k_gardner_segfill, dim3((unsigned)n_seg), dim3(64), 0, st, (const float *)d_agc, GP, GD, n_chunks,
+                               (const unsigned *)ctx->gtable.p, G, (const GardnerSegStart *)ctx->gsegstart.p,
+                               (GardnerEntry<float> *)ctx->gentries.p);
             L.end();
             L.begin("gardner");
             // per-chunk emission: small LDS windows so that four chunks share a CU
@@ -777,7 +788,7 @@ void pdt_close(pdt_ctx *ctx)
     DevBuf *bufs[] = { &ctx->pcm, &ctx->pll, &ctx->lock, &ctx->fir, &ctx->agc, &ctx->sym, &ctx->symidx, &ctx->bits, &ctx->bitsym,
                        &ctx->hits, &ctx->frames, &ctx->taps, &ctx->mag, &ctx->seams_pll, &ctx->seams_agc, &ctx->scal, &ctx->lockinfo,
                        &ctx->term, &ctx->seams_ema, &ctx->gtable, &ctx->gentries, &ctx->gcand,
-                       &ctx->gmfirst, &ctx->stiles };
+                       &ctx->gmfirst, &ctx->stiles, &ctx->gsegmap, &ctx->gsegstart };
     for (DevBuf *b : bufs) b->release();
     if (ctx->ev0) (void)hipEventDestroy(ctx->ev0);
     if (ctx->ev1) (void)hipEventDestroy(ctx->ev1);

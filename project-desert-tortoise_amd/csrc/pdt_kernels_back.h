@@ -479,47 +479,142 @@ __global__ void __launch_bounds__(PDT_GTAB_THREADS, 8) k_gardner_table(const flo
     }
 }
 
-// level 2: follow the chain of tables with one wavefront; walk the chunk when its entry state
-// was not tabulated.  Writes entries[c] for every chunk, including the last.
+// level 2: follow the chain  k_{c+1} = table_c[k_c]  (k_0 = 0).  A chain of n dependent HBM lookups
+// would cost ~0.5 us each, so it is cut into segments of G chunks:
+//   k_gardner_segmap   composes, for every tabulated entry state of a segment's first chunk, the G
+//                      table steps of the segment (parallel over segments x states);
+//   k_gardner_chain    one wavefront hops from segment to segment through those composite maps;
+//                      where a hop is impossible (state not tabulated, end of the capture) it
+//                      falls back to chunk-by-chunk stepping and simply WALKS a chunk whose entry
+//                      state was outside the scouts' band;
+//   k_gardner_segfill  re-traces every hopped segment from its now known start, in parallel,
+//                      to produce the per-chunk entry states and symbol offsets.
+struct GardnerSegCell { unsigned next, count; };
+struct GardnerSegStart { unsigned key; unsigned hopped; long long offset; };
+
+__global__ void __launch_bounds__(1024) k_gardner_segmap(const unsigned *__restrict__ table, GardnerDomain D, long long n_chunks,
+                                                          int G, GardnerSegCell *__restrict__ segmap)
+{
+    const long long s = blockIdx.x;
+    const long long c0 = s * G;
+    if (c0 + G > n_chunks - 1) return;                  // only whole segments whose chunks all have a table row
+    const size_t stride = (size_t)(2 * D.n_q);
+    for (int k0 = threadIdx.x; k0 < 2 * D.n_q; k0 += 1024) {
+        unsigned k = (unsigned)k0, total = 0;
+        bool ok = true;
+        for (int g = 0; g < G; g++) {
+            const unsigned cell = table[(size_t)(c0 + g) * stride + k];
+            if (cell == PDT_GTAB_MISS) { ok = false; break; }
+            k = cell & 0xfffffu;
+            total += cell >> 20;
+        }
+        GardnerSegCell sc;
+        sc.next = ok ? k : PDT_GTAB_MISS;
+        sc.count = total;
+        segmap[(size_t)s * stride + (size_t)k0] = sc;
+    }
+}
+
 __global__ void __launch_bounds__(PDT_GARDNER_THREADS) k_gardner_chain(const float *__restrict__ in, GardnerParams<float> P,
                                                                         GardnerDomain D, long long n_chunks,
                                                                         const unsigned *__restrict__ table,
+                                                                        const GardnerSegCell *__restrict__ segmap, int G,
+                                                                        GardnerSegStart *__restrict__ segstart,
                                                                         GardnerEntry<float> *__restrict__ entries,
                                                                         unsigned *__restrict__ stats /* [2] walked chunks */)
 {
     __shared__ float win[GardnerLds<float>::LEN];
+    const size_t stride = (size_t)(2 * D.n_q);
     GardnerState<float> S;
     S.ns = 0; S.prev = 0; S.half = 0; S.q_last = 0; S.i_last = 0;
     long long off = 0;
-    unsigned walked = 0;
-    unsigned cell = (n_chunks > 1) ? table[0] : 0u;            // chunk 0 has a single candidate
-    for (long long c = 0; c < n_chunks; c++) {
+    unsigned walked = 0, key = 0;
+    bool have_key = true;                                // chunk 0: the single start state is cell 0 of row 0
+    long long c = 0;
+    while (c < n_chunks) {
+        // ---- hop over a whole segment
+        if (have_key && (c % G) == 0 && c + G <= n_chunks - 1) {
+            const long long s = c / G;
+            const GardnerSegCell sc = segmap[(size_t)s * stride + key];
+            const unsigned nxt = uniform<unsigned>(sc.next);
+            if (nxt != PDT_GTAB_MISS) {
+                if (threadIdx.x == 0) {
+                    GardnerSegStart ss;
+                    ss.key = key; ss.hopped = 1; ss.offset = off;
+                    segstart[s] = ss;
+                }
+                key = nxt;
+                off += (long long)uniform<unsigned>(sc.count);
+                c += G;
+                continue;
+            }
+        }
+        // ---- one chunk
+        if (have_key && c >= 1) gardner_entry_from_candidate(in, P, D, c, (int)key, S.ns, S.prev, S.half);
         if (threadIdx.x == 0) {
             GardnerEntry<float> e;
             e.ns = S.ns; e.prev = S.prev; e.half = S.half; e.offset = off;
             entries[c] = e;
         }
         if (c + 1 >= n_chunks) break;
-        // cell = table_c[entry state of chunk c]  (or MISS)
+        unsigned cell = have_key ? table[(size_t)c * stride + key] : PDT_GTAB_MISS;
         cell = uniform<unsigned>(cell);
         if (cell == PDT_GTAB_MISS) {
-            const long long cnt = gardner_walk_chunk<float, false, GardnerLds<float>::LEN, GardnerLds<float>::OUT>(in, (const float *)nullptr, P, c, S, win, (float *)nullptr,
-                                                                    (unsigned *)nullptr, (float *)nullptr, (long long *)nullptr,
-                                                                    0, 0);
-            cell = gardner_encode_exit(D, S.q_last, S.i_last, (unsigned)cnt);
+            const long long cnt = gardner_walk_chunk<float, false, GardnerLds<float>::LEN, GardnerLds<float>::OUT>(
+                in, (const float *)nullptr, P, c, S, win, (float *)nullptr, (unsigned *)nullptr, (float *)nullptr, (long long *)nullptr, 0, 0);
             walked++;
+            cell = gardner_encode_exit(D, S.q_last, S.i_last, (unsigned)cnt);
             if (cell == PDT_GTAB_MISS) {
                 // the exit is not a tabulated boundary state (irregular geometry): keep walking
                 off += cnt;
+                have_key = false;
+                c++;
                 continue;
             }
         }
-        const int k = (int)(cell & 0xfffffu);
+        key = cell & 0xfffffu;
         off += (long long)(cell >> 20);
-        gardner_entry_from_candidate(in, P, D, c + 1, k, S.ns, S.prev, S.half);
-        if (c + 2 < n_chunks) cell = table[(size_t)(c + 1) * (size_t)(2 * D.n_q) + (size_t)k];
+        have_key = true;
+        c++;
     }
     if (threadIdx.x == 0) stats[2] = walked;
+}
+
+__global__ void __launch_bounds__(64) k_gardner_segfill(const float *__restrict__ in, GardnerParams<float> P, GardnerDomain D,
+                                                         long long n_chunks, const unsigned *__restrict__ table, int G,
+                                                         const GardnerSegStart *__restrict__ segstart,
+                                                         GardnerEntry<float> *__restrict__ entries)
+{
+    const long long s = blockIdx.x;
+    const long long c0 = s * G;
+    if (c0 + G > n_chunks - 1) return;
+    const GardnerSegStart ss = segstart[s];
+    if (!ss.hopped) return;
+    // 64 lanes, G <= 64 chunks: the key chain is serial (G dependent lookups), the entry states are not
+    const size_t stride = (size_t)(2 * D.n_q);
+    __shared__ unsigned s_key[64];
+    __shared__ long long s_off[64];
+    if (threadIdx.x == 0) {
+        unsigned k = ss.key;
+        long long off = ss.offset;
+        for (int g = 0; g < G; g++) {
+            s_key[g] = k;
+            s_off[g] = off;
+            const unsigned cell = table[(size_t)(c0 + g) * stride + k];
+            k = cell & 0xfffffu;
+            off += (long long)(cell >> 20);
+        }
+    }
+    __syncthreads();
+    const int g = threadIdx.x;
+    if (g < G) {
+        const long long c = c0 + g;
+        GardnerEntry<float> e;
+        e.ns = 0; e.prev = 0; e.half = 0;
+        if (c >= 1) gardner_entry_from_candidate(in, P, D, c, (int)s_key[g], e.ns, e.prev, e.half);
+        e.offset = s_off[g];
+        entries[c] = e;
+    }
 }
 
 // ------------------------------------------------------------------------------------------
@@ -899,52 +994,74 @@ __global__ void __launch_bounds__(256) k_sync_frames(unsigned *__restrict__ hits
     }
 }
 
-// frame filter over the ordered tiles: one wavefront, 64 tiles per round trip
-__global__ void __launch_bounds__(64) k_sync_frames_tiles(const SyncTile *__restrict__ tiles,
-                                                           const unsigned long long *__restrict__ nbits_p, SyncParams P,
-                                                           FrameRec *__restrict__ frames, unsigned *__restrict__ nframes,
-                                                           unsigned frame_cap, const unsigned *__restrict__ overflow)
+// frame filter over the ordered tiles.  One workgroup: (A) the tile hit lists are compacted, in
+// order, into one dense list (block-wide scan of the tile counts); (B) the dense list is staged
+// through LDS in batches and one lane applies the "not inside a frame" rule with the loads off
+// its dependent chain (8 hits per wide LDS read).
+#define PDT_SYNC_BATCH 8192
+__global__ void __launch_bounds__(256) k_sync_frames_tiles(const SyncTile *__restrict__ tiles,
+                                                            const unsigned long long *__restrict__ nbits_p, SyncParams P,
+                                                            unsigned *__restrict__ dense, unsigned dense_cap,
+                                                            FrameRec *__restrict__ frames, unsigned *__restrict__ nframes,
+                                                            unsigned frame_cap, const unsigned *__restrict__ overflow)
 {
     if (*overflow) return;                       // the generic path handles this capture
     const long long nbits = (long long)*nbits_p;
     const long long nt = (nbits + 4095) / 4096;
+    __shared__ unsigned s_scan[256];
+    __shared__ unsigned s_base;
+    __shared__ unsigned s_hits[PDT_SYNC_BATCH];
+    if (threadIdx.x == 0) s_base = 0;
+    __syncthreads();
+    // ---- (A) ordered compaction
+    for (long long t0 = 0; t0 < nt; t0 += 256) {
+        const long long mine = t0 + threadIdx.x;
+        const unsigned cnt = (mine < nt) ? tiles[mine].count : 0u;
+        s_scan[threadIdx.x] = cnt;
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            unsigned run = s_base;
+            for (int t = 0; t < 256; t++) {
+                const unsigned v = s_scan[t];
+                s_scan[t] = run;
+                run += v;
+            }
+            s_base = run;
+        }
+        __syncthreads();
+        const unsigned off = s_scan[threadIdx.x];
+        for (unsigned q = 0; q < cnt; q++)
+            if (off + q < dense_cap) dense[off + q] = tiles[mine].hits[q];
+        __syncthreads();
+    }
+    __threadfence_block();
+    __syncthreads();
+    const unsigned nh = (s_base < dense_cap) ? s_base : dense_cap;
+    // ---- (B) sequential filter over the dense, sorted list
     unsigned nf = 0;
     long long next_free = 0;
-    for (long long t0 = 0; t0 < nt; t0 += 64) {
-        const long long mine = t0 + threadIdx.x;
-        unsigned cnt = 0, h[7];
+    for (unsigned b0 = 0; b0 < nh; b0 += PDT_SYNC_BATCH) {
+        const unsigned cnt = (nh - b0 < PDT_SYNC_BATCH) ? nh - b0 : PDT_SYNC_BATCH;
+        __syncthreads();
+        for (unsigned t = threadIdx.x; t < ((cnt + 7u) & ~7u); t += 256) s_hits[t] = (t < cnt) ? dense[b0 + t] : 0xffffffffu;
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            for (unsigned i = 0; i < cnt; i += 8) {
+                unsigned v[8];
 #pragma unroll
-        for (int q = 0; q < 7; q++) h[q] = 0;
-        if (mine < nt) {
-            const uint4 a = *reinterpret_cast<const uint4 *>(&tiles[mine]);
-            const uint4 b = *(reinterpret_cast<const uint4 *>(&tiles[mine]) + 1);
-            cnt = a.x; h[0] = a.y; h[1] = a.z; h[2] = a.w; h[3] = b.x; h[4] = b.y; h[5] = b.z; h[6] = b.w;
-        }
-        if (__ballot(cnt != 0) == 0) continue;
-        const int lim = (nt - t0 < 64) ? (int)(nt - t0) : 64;
-        for (int t = 0; t < lim; t++) {
-            const unsigned c = (unsigned)__shfl((int)cnt, t);
-            for (unsigned q = 0; q < c; q++) {
-                unsigned v;
-                if (q < 7) {
-                    v = (unsigned)__shfl((int)h[0], t);
-                    if (q == 1) v = (unsigned)__shfl((int)h[1], t);
-                    if (q == 2) v = (unsigned)__shfl((int)h[2], t);
-                    if (q == 3) v = (unsigned)__shfl((int)h[3], t);
-                    if (q == 4) v = (unsigned)__shfl((int)h[4], t);
-                    if (q == 5) v = (unsigned)__shfl((int)h[5], t);
-                    if (q == 6) v = (unsigned)__shfl((int)h[6], t);
-                } else {
-                    v = tiles[t0 + t].hits[q];
+                for (int u = 0; u < 8; u++) v[u] = s_hits[i + u];
+#pragma unroll
+                for (int u = 0; u < 8; u++) {
+                    const long long pos = (long long)(v[u] >> 1);
+                    if (v[u] != 0xffffffffu && pos >= next_free) {
+                        if (nf < frame_cap) {
+                            frames[nf].bit_index = pos;
+                            frames[nf].inverted = (unsigned char)(v[u] & 1u);
+                        }
+                        nf++;
+                        next_free = pos + P.span;
+                    }
                 }
-                const long long pos = (long long)(v >> 1);
-                if (pos < next_free) continue;
-                if (threadIdx.x == 0 && nf < frame_cap) {
-                    frames[nf].bit_index = pos;
-                    frames[nf].inverted = (unsigned char)(v & 1u);
-                }
-                nf++;
-                next_free = pos + P.span;
             }
         }
     }
