@@ -47,6 +47,7 @@ class Config(C.Structure):
         ("pll_warm", C.c_uint32),
         ("agc_block", C.c_uint32),
         ("agc_warm", C.c_uint32),
+        ("gardner_band_pad", C.c_double),
     ]
 
 
@@ -187,11 +188,12 @@ class Demodulator:
     """One capture -> minor frames / packets on one GPU (context of include/pdt.h)."""
 
     def __init__(self, mode: int, sample_rate: int, chunk: int = 0, norm_override: float = 0.0, device: int = 0,
-                 profile: bool = False, pll_block: int = 0, pll_warm: int = 0, agc_block: int = 0, agc_warm: int = 0):
+                 profile: bool = False, pll_block: int = 0, pll_warm: int = 0, agc_block: int = 0, agc_warm: int = 0,
+                 gardner_band_pad: float = 0.0):
         self._L = lib()
         self.mode = mode
         cfg = Config(mode, sample_rate, chunk, norm_override, device, int(profile), pll_block, pll_warm, agc_block,
-                     agc_warm)
+                     agc_warm, gardner_band_pad)
         self._h = C.c_void_p()
         _check(self._L.pdt_open(C.byref(cfg), C.byref(self._h)), "pdt_open")
         self.dtype = np.float64 if mode == MODE_ARGOS else np.float32

@@ -85,7 +85,7 @@ struct pdt_ctx {
     hipEvent_t ev0 = nullptr, ev1 = nullptr, ev_fork = nullptr, ev_join = nullptr;
     hipStream_t stream2 = nullptr;     // side stream: block-parallel PLL phase runs beside the sequential acquisition
 
-    DevBuf pcm, pll, lock, fir, agc, sym, symidx, bits, bitsym, hits, frames, taps, mag, seams_pll, seams_agc, scal, lockinfo, term, seams_ema, gtable, gentries, gcand, gmfirst, stiles, gsegmap, gsegstart;
+    DevBuf pcm, pll, lock, fir, agc, sym, symidx, bits, bitsym, hits, frames, taps, mag, seams_pll, seams_agc, scal, lockinfo, term, seams_ema, gtable, gentries, gcand, gmfirst, stiles, gsegmap, gsegstart, gbands;
     long long gcand_key = -1;          // (chunk_out, step) the candidate list on the device was built for
     bool force_sequential_gardner = false;
     int gardner_mode = 0;              // 0 sequential, 1 state table (last run)
@@ -453,12 +453,12 @@ template <typename T> int run_capture(pdt_ctx *ctx, uint64_t n)
     // single-wavefront sequential chain.
     bool use_table = false;
     GardnerDomain GD;
-    GD.q_min = 0; GD.u = 0; GD.n_q = 0; GD.n_cand = 0;
+    GD.q_min = 0; GD.u = 0; GD.n_q = 0; GD.n_cand = 0; GD.pad_q = 0;
     if constexpr (std::is_same<T, float>::value) {
         const int table_len = 1 << 22;     // the table kernel walks the chunk in LDS windows: no size limit of its own
         const float nT = (float)chunk_out, stepf = (float)GP.step;
         if (!argos && !ctx->force_sequential_gardner && n_chunks >= 4 && chunk_out >= 256 &&
-            chunk_out + 2 * (long long)stepf + 24 <= table_len && 8 * (long long)stepf + 256 < PDT_GTAB_WIN && chunk_out < (1 << 23)) {
+            chunk_out + 2 * (long long)stepf + 24 <= table_len && 8 * (long long)stepf + 256 < PDT_GTAB_WIN && chunk_out < (1 << 22)) {
             int e;
             (void)frexpf(nT - stepf - 1.0f, &e);                              // value in [2^(e-1), 2^e)
             const float u = ldexpf(1.0f, e - 24);
@@ -471,6 +471,8 @@ template <typename T> int run_capture(pdt_ctx *ctx, uint64_t n)
                 GD.q_min = q_min;
                 GD.u = u;
                 GD.n_q = n_q;
+                const double pad = ctx->cfg.gardner_band_pad > 0 ? ctx->cfg.gardner_band_pad : 0.25;
+                GD.pad_q = (int)(pad / (double)u);
             }
         }
     }
@@ -502,10 +504,16 @@ template <typename T> int run_capture(pdt_ctx *ctx, uint64_t n)
             const long long n_tab = n_chunks - 1;
             if ((rc = ctx->gtable.ensure((size_t)n_tab * (size_t)(2 * GD.n_q) * sizeof(unsigned)))) return rc;
             if ((rc = ctx->gentries.ensure((size_t)n_chunks * sizeof(GardnerEntry<float>)))) return rc;
+            if ((rc = ctx->gbands.ensure((size_t)n_tab * sizeof(GardnerBand)))) return rc;
             L.begin("gardner_table");
-            hipLaunchKernelGGL(k_gardner_table, dim3((unsigned)n_tab), dim3(PDT_GTAB_THREADS), 0, st, (const float *)d_agc, GP, GD,
-                               n_tab, (const unsigned *)ctx->gcand.p, (const int *)ctx->gmfirst.p, (unsigned *)ctx->gtable.p,
-                               d_sc->gstats);
+            hipLaunchKernelGGL(k_gardner_scout, dim3((unsigned)n_tab), dim3(64), 0, st, (const float *)d_agc, GP, GD, n_tab,
+                               (const int *)ctx->gmfirst.p, (unsigned *)ctx->gtable.p, (GardnerBand *)ctx->gbands.p, d_sc->gstats);
+            {
+                const unsigned parts = (unsigned)((GD.n_cand + 2 * PDT_GTAB_THREADS - 1) / (2 * PDT_GTAB_THREADS));
+                hipLaunchKernelGGL(k_gardner_table, dim3((unsigned)n_tab, parts), dim3(PDT_GTAB_THREADS), 0, st, (const float *)d_agc, GP,
+                                   GD, n_tab, (const unsigned *)ctx->gcand.p, (const GardnerBand *)ctx->gbands.p,
+                                   (unsigned *)ctx->gtable.p, d_sc->gstats);
+            }
             L.end();
             const int G = 32;                                                  // chunks per chain segment
             const long long n_seg = (n_chunks + G - 1) / G;
@@ -788,7 +796,7 @@ void pdt_close(pdt_ctx *ctx)
     DevBuf *bufs[] = { &ctx->pcm, &ctx->pll, &ctx->lock, &ctx->fir, &ctx->agc, &ctx->sym, &ctx->symidx, &ctx->bits, &ctx->bitsym,
                        &ctx->hits, &ctx->frames, &ctx->taps, &ctx->mag, &ctx->seams_pll, &ctx->seams_agc, &ctx->scal, &ctx->lockinfo,
                        &ctx->term, &ctx->seams_ema, &ctx->gtable, &ctx->gentries, &ctx->gcand,
-                       &ctx->gmfirst, &ctx->stiles, &ctx->gsegmap, &ctx->gsegstart };
+                       &ctx->gmfirst, &ctx->stiles, &ctx->gsegmap, &ctx->gsegstart, &ctx->gbands };
     for (DevBuf *b : bufs) b->release();
     if (ctx->ev0) (void)hipEventDestroy(ctx->ev0);
     if (ctx->ev1) (void)hipEventDestroy(ctx->ev1);

@@ -274,9 +274,10 @@ struct GardnerDomain {
     float u;           // grid spacing (ulp of the binade that contains the chunk end)
     int n_q;           // number of q values; table row = 2 * n_q cells (two choices of the last pick)
     int n_cand;        // consistent (q, pick) combinations, listed in cand_k in increasing q
+    int pad_q;         // candidates are tabulated this many grid points beyond the scouts' hull (default 1/2 sample)
 };
 
-#define PDT_GTAB_THREADS 1024
+#define PDT_GTAB_THREADS 512
 #define PDT_GTAB_TAIL 4096           // samples of the previous chunk the scouts run over
 #define PDT_GTAB_MISS 0xffffffffu    // cell not tabulated
 
@@ -304,34 +305,80 @@ __device__ __forceinline__ unsigned gardner_encode_exit(const GardnerDomain &D, 
     return ok ? (((unsigned)(2 * m + v)) | (count << 20)) : PDT_GTAB_MISS;
 }
 
-#define PDT_GTAB_WIN 15872          // LDS window (floats): 62 KiB + 16 KiB tail -> two blocks per CU
+#define PDT_GTAB_WIN 6128           // LDS window (floats): 24 KiB + 16 KiB tail -> four 512-thread blocks per CU
 
-__global__ void __launch_bounds__(PDT_GTAB_THREADS, 8) k_gardner_table(const float *__restrict__ in, GardnerParams<float> P,
-                                                                        GardnerDomain D, long long n_tab_chunks,
-                                                                        const unsigned *__restrict__ cand_k,
-                                                                        const int *__restrict__ m_first,
-                                                                        unsigned *__restrict__ table,
-                                                                        unsigned *__restrict__ stats /* [0] bad [1] full-domain chunks [3] candidates */)
+// rint(x) as an integer for 0 <= x < 2^22: adding 1.5*2^23 makes the FPU round x to an integer
+// (nearest-even, exactly like rintf) and leaves it in the low mantissa bits
+__device__ __forceinline__ int rint_index(float x)
 {
-    __shared__ float win[PDT_GTAB_WIN];
+    return __float_as_int(x + 12582912.0f) - 0x4B400000;
+}
+
+// one candidate trajectory carried by a lane
+struct GardnerLane {
+    float ns, prev, half, q_last;
+    unsigned i_last, count;
+    int k;
+    bool active;
+};
+
+__device__ __forceinline__ void gardner_lane_step(GardnerLane &L, const float *wrel, float kp, float lim, float hs, float step)
+{
+    const float cur = wrel[rint_index(L.ns)];
+    const float mid = wrel[rint_index(L.half)];
+    const float err = __builtin_amdgcn_fmed3f(kp * (cur - L.prev) * mid, -lim, lim);
+    L.ns = L.ns - err;
+    L.half = L.ns + hs;
+    L.ns = L.ns + step;
+    L.prev = cur;
+}
+
+__device__ __forceinline__ void gardner_lane_tail(GardnerLane &L, const float *wrel, float stop, float kp, float lim, float hs,
+                                                  float step)
+{
+    for (;;) {
+        const float rn = __builtin_rintf(L.ns);
+        if (!(rn < stop)) break;
+        const float cur = wrel[(int)rn];
+        const float mid = wrel[rint_index(L.half)];
+        const float err = __builtin_amdgcn_fmed3f(kp * (cur - L.prev) * mid, -lim, lim);
+        L.ns = L.ns - err;
+        L.q_last = L.ns;
+        L.half = L.ns + hs;
+        L.ns = L.ns + step;
+        L.prev = cur;
+        L.i_last = (unsigned)rn;
+        L.count++;
+    }
+}
+
+// scouts: one wavefront per chunk.  64 trajectories over the tail of chunk c-1, started one 64th
+// of a symbol apart; when they all end within one sample of each other the timing loop is locked
+// and only candidates around their hull need tabulating.  Also clears the chunk's table row.
+struct GardnerBand { int j_lo, j_hi; };
+
+__global__ void __launch_bounds__(64) k_gardner_scout(const float *__restrict__ in, GardnerParams<float> P, GardnerDomain D,
+                                                       long long n_tab_chunks, const int *__restrict__ m_first,
+                                                       unsigned *__restrict__ table, GardnerBand *__restrict__ bands,
+                                                       unsigned *__restrict__ stats /* [1] full-domain chunks [3] candidates */)
+{
     __shared__ float tail[PDT_GTAB_TAIL];
     __shared__ int s_mmin, s_mmax;
-    const long long c = blockIdx.x;                 // chunk (always a full one)
+    const long long c = blockIdx.x;
     if (c >= n_tab_chunks) return;
     const long long C = P.chunk_out;
     const long long base = c * C;
     const int n_cur = (int)C;
     const int tail_n = (C < PDT_GTAB_TAIL) ? (int)C : PDT_GTAB_TAIL;
-    if (threadIdx.x == 0) { s_mmin = 0x7fffffff; s_mmax = -0x7fffffff; }
     unsigned *row = table + (size_t)c * (size_t)(2 * D.n_q);
-    const float hs = (float)((double)P.step / 2.0);
-    const float kp = P.kp, lim = P.lim, step = P.step, nT = (float)n_cur;
-    const int margin = 2 * (int)step + 24;          // look-ahead the staged data must cover past a stop point
-    const int back = (int)step + 8;                 // a mid-point lies at most this far behind a stop point
-    __syncthreads();
-
-    // ---- scouts (wavefront 0) while the others initialise the table row
-    if (threadIdx.x < 64 && c >= 1) {
+    for (int t = threadIdx.x; t < 2 * D.n_q; t += 64) row[t] = PDT_GTAB_MISS;
+    GardnerBand bd;
+    bd.j_lo = 0;
+    bd.j_hi = (c == 0) ? 1 : D.n_cand;
+    if (c >= 1) {
+        if (threadIdx.x == 0) { s_mmin = 0x7fffffff; s_mmax = -0x7fffffff; }
+        const float hs = (float)((double)P.step / 2.0);
+        const float kp = P.kp, lim = P.lim, step = P.step, nT = (float)n_cur;
         for (int t = threadIdx.x; t < tail_n; t += 64 * 8) {
             float r[8];
 #pragma unroll
@@ -340,8 +387,7 @@ __global__ void __launch_bounds__(PDT_GTAB_THREADS, 8) k_gardner_table(const flo
             for (int u = 0; u < 8; u++)
                 if (t + u * 64 < tail_n) tail[t + u * 64] = r[u];
         }
-        __builtin_amdgcn_s_waitcnt(0);
-        __builtin_amdgcn_wave_barrier();
+        __syncthreads();
         const float t0 = (float)(n_cur - tail_n);
         float ns = t0 + 8.0f + step * (float)threadIdx.x * (1.0f / 64.0f);
         float prev = 0, half = ns - hs, q_last = ns;
@@ -363,119 +409,134 @@ __global__ void __launch_bounds__(PDT_GTAB_THREADS, 8) k_gardner_table(const flo
         const int m = (int)floorf((q_last - D.q_min) / D.u);
         atomicMin(&s_mmin, m);
         atomicMax(&s_mmax, m);
-    } else {
-        const int nthr = (c >= 1) ? PDT_GTAB_THREADS - 64 : PDT_GTAB_THREADS;
-        const int tid = (c >= 1) ? (int)threadIdx.x - 64 : (int)threadIdx.x;
-        for (int t = tid; t < 2 * D.n_q; t += nthr) row[t] = PDT_GTAB_MISS;
-    }
-    __syncthreads();
-
-    int j_lo = 0, j_hi = (c == 0) ? 1 : D.n_cand;
-    if (c >= 1) {
+        __syncthreads();
         const int one = (int)(1.0f / D.u);                        // grid points per sample
         const int spread = s_mmax - s_mmin;
-        if (spread <= one && s_mmin >= 0 && s_mmax < D.n_q) {     // locked: candidates within +-1/2 sample of the scouts
-            int m_lo = s_mmin - one / 2, m_hi = s_mmax + one / 2;
+        if (spread <= one && s_mmin >= 0 && s_mmax < D.n_q) {     // locked: candidates around the scouts' hull
+            int m_lo = s_mmin - D.pad_q, m_hi = s_mmax + D.pad_q;
             m_lo = (m_lo < 0) ? 0 : m_lo;
             m_hi = (m_hi > D.n_q - 1) ? D.n_q - 1 : m_hi;
-            j_lo = m_first[m_lo];
-            j_hi = m_first[m_hi + 1];
+            bd.j_lo = m_first[m_lo];
+            bd.j_hi = m_first[m_hi + 1];
         } else if (threadIdx.x == 0) {
             atomicAdd(&stats[1], 1u);
         }
     }
-    if (threadIdx.x == 0) atomicAdd(&stats[3], (unsigned)(j_hi - j_lo));
+    if (threadIdx.x == 0) {
+        bands[c] = bd;
+        atomicAdd(&stats[3], (unsigned)(bd.j_hi - bd.j_lo));
+    }
+}
 
-    // ---- candidates, 1024 at a time; each pass walks the chunk window by window.  All lanes of a
-    // pass are within a symbol of each other, so they cross the window seams together.  Inside a
-    // window every trajectory takes at least k_min steps before it can reach the stop point (a
-    // step advances by at most step + 0.1), so the bulk of the walk is a counted, wave-uniform
-    // loop without any per-lane test.
-    for (int j0 = j_lo; j0 < j_hi; j0 += PDT_GTAB_THREADS) {
-        const int j = j0 + (int)threadIdx.x;
-        const bool active = j < j_hi;
-        float ns = 0, prev = 0, half = 0, q_last = 0;
-        unsigned i_last = 0, count = 0;
-        int k = 0;
-        if (active && c >= 1) {
-            k = (int)cand_k[j];
-            gardner_entry_from_candidate(in, P, D, c, k, ns, prev, half);
+// level 1: block (c, p) runs slice p (2 x 512 candidates) of chunk c's band, window by window.
+// Every lane carries two interleaved trajectories.  All lanes are within a symbol of each other,
+// so they cross the window seams together; inside a window every trajectory takes at least
+// k_min steps before it can reach the stop point (a step advances by at most step + 0.1), so the
+// bulk of the walk is a counted, wave-uniform loop without any per-lane test.
+__global__ void __launch_bounds__(PDT_GTAB_THREADS, 8) k_gardner_table(const float *__restrict__ in, GardnerParams<float> P,
+                                                                        GardnerDomain D, long long n_tab_chunks,
+                                                                        const unsigned *__restrict__ cand_k,
+                                                                        const GardnerBand *__restrict__ bands,
+                                                                        unsigned *__restrict__ table,
+                                                                        unsigned *__restrict__ stats /* [0] bad */)
+{
+    __shared__ float win[PDT_GTAB_WIN];
+    const long long c = blockIdx.x;                 // chunk (always a full one)
+    if (c >= n_tab_chunks) return;
+    const GardnerBand bd = bands[c];
+    const int j0 = bd.j_lo + (int)blockIdx.y * 2 * PDT_GTAB_THREADS;
+    const int j_hi = bd.j_hi;
+    if (j0 >= j_hi) return;
+    const long long C = P.chunk_out;
+    const long long base = c * C;
+    const int n_cur = (int)C;
+    unsigned *row = table + (size_t)c * (size_t)(2 * D.n_q);
+    const float hs = (float)((double)P.step / 2.0);
+    const float kp = P.kp, lim = P.lim, step = P.step, nT = (float)n_cur;
+    const int margin = 2 * (int)step + 24;          // look-ahead the staged data must cover past a stop point
+    const int back = (int)step + 8;                 // a mid-point lies at most this far behind a stop point
+
+    GardnerLane La, Lb;
+    La.ns = La.prev = La.half = La.q_last = 0; La.i_last = La.count = 0; La.k = 0;
+    Lb = La;
+    La.active = (j0 + (int)threadIdx.x) < j_hi;
+    Lb.active = (j0 + PDT_GTAB_THREADS + (int)threadIdx.x) < j_hi;
+    if (La.active && c >= 1) {
+        La.k = (int)cand_k[j0 + threadIdx.x];
+        gardner_entry_from_candidate(in, P, D, c, La.k, La.ns, La.prev, La.half);
+    }
+    if (Lb.active && c >= 1) {
+        Lb.k = (int)cand_k[j0 + PDT_GTAB_THREADS + threadIdx.x];
+        gardner_entry_from_candidate(in, P, D, c, Lb.k, Lb.ns, Lb.prev, Lb.half);
+    }
+    if (!Lb.active) Lb = La;                      // idle second slot: shadow the first (its result is discarded)
+    int wbase = 0;
+    float enter_hi = step + 1.2f;                 // upper bound of ns when entering the window
+    for (;;) {
+        // stage [wbase, wbase + PDT_GTAB_WIN)
+        __syncthreads();
+        for (int t = threadIdx.x; t < PDT_GTAB_WIN; t += PDT_GTAB_THREADS) {
+            const int idx = wbase + t;
+            win[t] = (idx < n_cur) ? in[base + idx]
+                                   : ((idx < n_cur + margin) ? gardner_beyond(in, (const float *)nullptr, P, c, (long long)n_cur, (long long)idx) : 0.0f);
         }
-        int wbase = 0;
-        float enter_hi = step + 1.2f;                 // upper bound of ns when entering the window
-        for (;;) {
-            // stage [wbase, wbase + PDT_GTAB_WIN)
-            __syncthreads();
-            for (int t = threadIdx.x; t < PDT_GTAB_WIN; t += PDT_GTAB_THREADS) {
-                const int idx = wbase + t;
-                win[t] = (idx < n_cur) ? in[base + idx]
-                                       : ((idx < n_cur + margin) ? gardner_beyond(in, (const float *)nullptr, P, c, (long long)n_cur, (long long)idx) : 0.0f);
-            }
-            __syncthreads();
-            const int wend = wbase + PDT_GTAB_WIN;
-            const bool last_window = (wend - margin >= n_cur);
-            const float stop = last_window ? nT : (float)(wend - margin);    // lanes leave the window at rint(ns) >= stop
-            const float wb = (float)wbase;
-            if (active) {
-                if (wbase == 0) {
-                    // first symbol: the mid-point index is the stale one of the previous chunk (Q3)
-                    const float rn = __builtin_rintf(ns);
+        __syncthreads();
+        const int wend = wbase + PDT_GTAB_WIN;
+        const bool last_window = (wend - margin >= n_cur);
+        const float stop = last_window ? nT : (float)(wend - margin);    // lanes leave the window at rint(ns) >= stop
+        const float *wrel = win - wbase;          // indexed with chunk-relative indices
+        if (La.active) {
+            if (wbase == 0) {
+                // first symbol: the mid-point index is the stale one of the previous chunk (Q3)
+#pragma unroll
+                for (int which = 0; which < 2; which++) {
+                    GardnerLane &L = which ? Lb : La;
+                    const float rn = __builtin_rintf(L.ns);
                     if (rn < nT) {
                         const unsigned i_cur = (unsigned)rn;
-                        const unsigned i_half = (unsigned)__builtin_rintf(half);
+                        const unsigned i_half = (unsigned)__builtin_rintf(L.half);
                         const float cur = win[i_cur];
                         float mid;
                         if (i_half < (unsigned)PDT_GTAB_WIN) mid = win[i_half];
                         else mid = (i_half < (unsigned)n_cur) ? in[base + i_half]
                                                               : gardner_beyond(in, (const float *)nullptr, P, c, (long long)n_cur, (long long)i_half);
-                        const float err = __builtin_amdgcn_fmed3f(kp * (cur - prev) * mid, -lim, lim);
-                        ns = ns - err;
-                        q_last = ns;
-                        half = ns + hs;
-                        ns = ns + step;
-                        prev = cur;
-                        i_last = i_cur;
-                        count = 1;
-                    }
-                }
-                if (count >= 1) {
-                    int k_min = (int)((stop - 4.0f - enter_hi) / (step + 0.101f)) - 1;
-                    if (k_min < 0) k_min = 0;
-                    for (int it = 0; it < k_min; it++) {
-                        const float cur = win[(int)(__builtin_rintf(ns) - wb)];
-                        const float mid = win[(int)(__builtin_rintf(half) - wb)];
-                        const float err = __builtin_amdgcn_fmed3f(kp * (cur - prev) * mid, -lim, lim);
-                        ns = ns - err;
-                        half = ns + hs;
-                        ns = ns + step;
-                        prev = cur;
-                    }
-                    count += (unsigned)k_min;
-                    for (;;) {
-                        const float rn = __builtin_rintf(ns);
-                        if (!(rn < stop)) break;
-                        const float cur = win[(int)(rn - wb)];
-                        const float mid = win[(int)(__builtin_rintf(half) - wb)];
-                        const float err = __builtin_amdgcn_fmed3f(kp * (cur - prev) * mid, -lim, lim);
-                        ns = ns - err;
-                        q_last = ns;
-                        half = ns + hs;
-                        ns = ns + step;
-                        prev = cur;
-                        i_last = (unsigned)rn;
-                        count++;
+                        const float err = __builtin_amdgcn_fmed3f(kp * (cur - L.prev) * mid, -lim, lim);
+                        L.ns = L.ns - err;
+                        L.q_last = L.ns;
+                        L.half = L.ns + hs;
+                        L.ns = L.ns + step;
+                        L.prev = cur;
+                        L.i_last = i_cur;
+                        L.count = 1;
                     }
                 }
             }
-            if (last_window) break;
-            enter_hi = stop + step + 1.2f;
-            wbase = wend - margin - back;
+            if (La.count >= 1 && Lb.count >= 1) {
+                int k_min = (int)((stop - 4.0f - enter_hi) / (step + 0.101f)) - 1;
+                if (k_min < 0) k_min = 0;
+                for (int it = 0; it < k_min; it++) {
+                    gardner_lane_step(La, wrel, kp, lim, hs, step);
+                    gardner_lane_step(Lb, wrel, kp, lim, hs, step);
+                }
+                La.count += (unsigned)k_min;
+                Lb.count += (unsigned)k_min;
+                gardner_lane_tail(La, wrel, stop, kp, lim, hs, step);
+                gardner_lane_tail(Lb, wrel, stop, kp, lim, hs, step);
+            }
         }
-        if (active) {
-            const unsigned cell = gardner_encode_exit(D, q_last, i_last, count);
-            if (cell == PDT_GTAB_MISS) atomicAdd(&stats[0], 1u);  // exit outside the enumerated domain (never expected)
-            row[k] = cell;
-        }
+        if (last_window) break;
+        enter_hi = stop + step + 1.2f;
+        wbase = wend - margin - back;
+    }
+    if (La.active) {
+        const unsigned cell = gardner_encode_exit(D, La.q_last, La.i_last, La.count);
+        if (cell == PDT_GTAB_MISS) atomicAdd(&stats[0], 1u);  // exit outside the enumerated domain (never expected)
+        row[La.k] = cell;
+    }
+    if (Lb.active) {
+        const unsigned cell = gardner_encode_exit(D, Lb.q_last, Lb.i_last, Lb.count);
+        if (cell == PDT_GTAB_MISS) atomicAdd(&stats[0], 1u);
+        row[Lb.k] = cell;
     }
 }
 
