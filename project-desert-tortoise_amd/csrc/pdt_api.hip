@@ -85,7 +85,7 @@ struct pdt_ctx {
     hipEvent_t ev0 = nullptr, ev1 = nullptr, ev_fork = nullptr, ev_join = nullptr;
     hipStream_t stream2 = nullptr;     // side stream: block-parallel PLL phase runs beside the sequential acquisition
 
-    DevBuf pcm, pll, lock, fir, agc, sym, symidx, bits, bitsym, hits, frames, taps, mag, seams_pll, seams_agc, scal, lockinfo, term, seams_ema, gtable, gentries, gcand, gmfirst, stiles, gsegmap, gsegstart, gbands;
+    DevBuf pcm, pll, lock, fir, agc, sym, symidx, bits, bitsym, hits, frames, taps, mag, seams_pll, seams_agc, scal, lockinfo, term, seams_ema, gtable, gentries, gcand, gmfirst, stiles, gsegmap, gsegstart, gbands, agc_maps;
     long long gcand_key = -1;          // (chunk_out, step) the candidate list on the device was built for
     bool force_sequential_gardner = false;
     int gardner_mode = 0;              // 0 sequential, 1 state table (last run)
@@ -275,7 +275,7 @@ template <typename T> int run_capture(pdt_ctx *ctx, uint64_t n)
     long long Bp = ctx->cfg.pll_block ? ctx->cfg.pll_block : (long long)((argos ? 4.0 : 0.1) * fs_d);
     long long Wp = ctx->cfg.pll_warm ? ctx->cfg.pll_warm : (long long)((argos ? 8.0 : 0.3) * fs_d);
     long long Wacq = (long long)(0.02 * fs_d);             // acquisition-gain stage of the warm-up
-    long long Ba = ctx->cfg.agc_block ? ctx->cfg.agc_block : (long long)((argos ? 4.0 : 0.125) * fs_d * interp);
+    long long Ba = ctx->cfg.agc_block ? ctx->cfg.agc_block : (long long)((argos ? 1.0 : 0.0625) * fs_d * interp);
     long long Wa = ctx->cfg.agc_warm ? ctx->cfg.agc_warm : (long long)((argos ? 8.0 : 1.0) * fs_d * interp);
     Bp = std::max<long long>(64, round4(Bp));
     Ba = std::max<long long>(64, round4(Ba));
@@ -438,9 +438,14 @@ template <typename T> int run_capture(pdt_ctx *ctx, uint64_t n)
     if (n_out > 0) {
         const long long nb = (n_out + Ba - 1) / Ba;
         const long long grid = (nb + 63) / 64;
+        if ((rc = ctx->agc_maps.ensure((size_t)(nb + 1) * (sizeof(AgcMap) + sizeof(double))))) return rc;
+        AgcMap *d_maps = (AgcMap *)ctx->agc_maps.p;
+        double *d_guess = (double *)(d_maps + nb + 1);
         L.begin("agc_block");
-        hipLaunchKernelGGL(k_agc_block<T>, dim3((unsigned)grid), dim3(64), 0, st, d_fir, n_out, AP, d_norm, Ba, Wa, d_lock,
-                           d_agc, (AgcSeam<T> *)ctx->seams_agc.p);
+        hipLaunchKernelGGL(k_agc_affine<T>, dim3((unsigned)nb), dim3(256), 0, st, d_fir, n_out, AP.decay, Ba, d_maps);
+        hipLaunchKernelGGL(k_agc_guess<T>, dim3(1), dim3(1024), 0, st, (const AgcMap *)d_maps, nb, (const T *)d_norm, d_guess);
+        hipLaunchKernelGGL(k_agc_block<T>, dim3((unsigned)grid), dim3(64), 0, st, d_fir, n_out, AP, d_norm, Ba, Wa,
+                           (const double *)d_guess, d_lock, d_agc, (AgcSeam<T> *)ctx->seams_agc.p);
         L.end();
         L.begin("agc_fix");
         hipLaunchKernelGGL(k_agc_fix<T>, dim3(1), dim3(64), 0, st, d_fir, n_out, AP, Ba, d_lock, d_agc,
@@ -531,8 +536,8 @@ template <typename T> int run_capture(pdt_ctx *ctx, uint64_t n)
                                (GardnerEntry<float> *)ctx->gentries.p);
             L.end();
             L.begin("gardner");
-            // per-chunk emission: small LDS windows so that four chunks share a CU
-            hipLaunchKernelGGL((k_gardner<float, 8192, 1024>), dim3((unsigned)n_chunks), dim3(PDT_GARDNER_THREADS), 0, st, (const float *)d_agc,
+            // per-chunk emission: small LDS windows (16 + 4 KiB) so that several chunks share a CU
+            hipLaunchKernelGGL((k_gardner<float, 4096, 512>), dim3((unsigned)n_chunks), dim3(PDT_GARDNER_THREADS), 0, st, (const float *)d_agc,
                                (const float *)d_lock, GP, (float *)d_sym, d_symidx, &d_sc->nsym, sym_cap,
                                (const GardnerEntry<float> *)ctx->gentries.p);
             L.end();
@@ -796,7 +801,7 @@ void pdt_close(pdt_ctx *ctx)
     DevBuf *bufs[] = { &ctx->pcm, &ctx->pll, &ctx->lock, &ctx->fir, &ctx->agc, &ctx->sym, &ctx->symidx, &ctx->bits, &ctx->bitsym,
                        &ctx->hits, &ctx->frames, &ctx->taps, &ctx->mag, &ctx->seams_pll, &ctx->seams_agc, &ctx->scal, &ctx->lockinfo,
                        &ctx->term, &ctx->seams_ema, &ctx->gtable, &ctx->gentries, &ctx->gcand,
-                       &ctx->gmfirst, &ctx->stiles, &ctx->gsegmap, &ctx->gsegstart, &ctx->gbands };
+                       &ctx->gmfirst, &ctx->stiles, &ctx->gsegmap, &ctx->gsegstart, &ctx->gbands, &ctx->agc_maps };
     for (DevBuf *b : bufs) b->release();
     if (ctx->ev0) (void)hipEventDestroy(ctx->ev0);
     if (ctx->ev1) (void)hipEventDestroy(ctx->ev1);

@@ -1100,31 +1100,40 @@ __global__ void __launch_bounds__(256) k_sync_frames_tiles(const SyncTile *__res
     const unsigned nh = (s_base < dense_cap) ? s_base : dense_cap;
     // ---- (B) sequential filter over the dense, sorted list
     unsigned nf = 0;
-    long long next_free = 0;
+    unsigned next_free = 0;                            // bit indices are < 2^31
     for (unsigned b0 = 0; b0 < nh; b0 += PDT_SYNC_BATCH) {
         const unsigned cnt = (nh - b0 < PDT_SYNC_BATCH) ? nh - b0 : PDT_SYNC_BATCH;
         __syncthreads();
         for (unsigned t = threadIdx.x; t < ((cnt + 7u) & ~7u); t += 256) s_hits[t] = (t < cnt) ? dense[b0 + t] : 0xffffffffu;
         __syncthreads();
         if (threadIdx.x == 0) {
+            // accepted hits are written back in place (LDS), the records go out afterwards in parallel
+            unsigned na = 0;
             for (unsigned i = 0; i < cnt; i += 8) {
                 unsigned v[8];
 #pragma unroll
                 for (int u = 0; u < 8; u++) v[u] = s_hits[i + u];
 #pragma unroll
                 for (int u = 0; u < 8; u++) {
-                    const long long pos = (long long)(v[u] >> 1);
-                    if (v[u] != 0xffffffffu && pos >= next_free) {
-                        if (nf < frame_cap) {
-                            frames[nf].bit_index = pos;
-                            frames[nf].inverted = (unsigned char)(v[u] & 1u);
-                        }
-                        nf++;
+                    const unsigned pos = v[u] >> 1;
+                    const bool take = (v[u] != 0xffffffffu) && (pos >= next_free);
+                    if (take) {
+                        s_hits[na++] = v[u];
                         next_free = pos + P.span;
                     }
                 }
             }
+            s_scan[0] = na;
         }
+        __syncthreads();
+        const unsigned na = s_scan[0];
+        for (unsigned t = threadIdx.x; t < na; t += 256) {
+            if (nf + t < frame_cap) {
+                frames[nf + t].bit_index = (long long)(s_hits[t] >> 1);
+                frames[nf + t].inverted = (unsigned char)(s_hits[t] & 1u);
+            }
+        }
+        nf += na;
     }
     if (threadIdx.x == 0) *nframes = nf;
 }

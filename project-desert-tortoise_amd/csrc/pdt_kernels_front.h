@@ -819,44 +819,151 @@ __device__ __forceinline__ void agc_range(const T *__restrict__ in, const T *__r
     }
 }
 
+// Starting guesses for the block-parallel AGC.  In its steady regime (decay branch, no clamp) one
+// AGC step is the affine map g -> g (1 - decay |x|) + decay; affine maps compose associatively,
+// so the gain at every block boundary is available from a parallel composition in double
+// precision -- up to the float rounding noise the real recurrence accumulates (~1e-6 relative).
+// That is only a GUESS: each block still replays a warm-up with the exact float recurrence and
+// its seam is verified bitwise; but a guess this close cuts the warm-up from ~45 to ~14 time
+// constants.
+struct AgcMap { double A, B; };
+
+#define PDT_AFF_TILE 8192
+template <typename T>
+__global__ void __launch_bounds__(256) k_agc_affine(const T *__restrict__ in, long long n, T decay, long long Bk,
+                                                     AgcMap *__restrict__ maps)
+{
+    // one workgroup per AGC block: tiles of 8192 samples are staged in LDS with coalesced loads,
+    // every thread composes 32 consecutive samples, the 256 partial maps are scanned in LDS
+    // (ordered: thread t's samples precede thread t+1's) and folded into the running block map
+    __shared__ T s_x[PDT_AFF_TILE];
+    __shared__ double sA[256], sB[256];
+    const long long j = blockIdx.x;
+    const long long start = j * Bk;
+    if (start >= n) return;
+    const long long end = (start + Bk < n) ? start + Bk : n;
+    const double r = (double)decay;
+    double runA = 1.0, runB = 0.0;                     // block map so far (meaningful in thread 0)
+    for (long long t0 = start; t0 < end; t0 += PDT_AFF_TILE) {
+        const int cnt = (int)((end - t0 < PDT_AFF_TILE) ? (end - t0) : PDT_AFF_TILE);
+        __syncthreads();
+        for (int t = threadIdx.x; t < cnt; t += 256) s_x[t] = in[t0 + t];
+        __syncthreads();
+        const int per = PDT_AFF_TILE / 256;
+        const int i0 = threadIdx.x * per;
+        double A = 1.0, Bc = 0.0;
+        for (int u = 0; u < per; u++) {
+            const int i = i0 + u;
+            if (i < cnt) {
+                const double a = 1.0 - r * (double)Real<T>::abs(s_x[i]);
+                A = a * A;
+                Bc = a * Bc + r;
+            }
+        }
+        sA[threadIdx.x] = A;
+        sB[threadIdx.x] = Bc;
+        __syncthreads();
+        for (int d = 1; d < 256; d <<= 1) {
+            double Ap = 1.0, Bp = 0.0;
+            if ((int)threadIdx.x >= d) { Ap = sA[threadIdx.x - d]; Bp = sB[threadIdx.x - d]; }
+            __syncthreads();
+            if ((int)threadIdx.x >= d) {
+                Bc = A * Bp + Bc;
+                A = A * Ap;
+                sA[threadIdx.x] = A;
+                sB[threadIdx.x] = Bc;
+            }
+            __syncthreads();
+        }
+        if (threadIdx.x == 0) {
+            const double tA = sA[255], tB = sB[255];   // map of the whole tile
+            runB = tA * runB + tB;
+            runA = tA * runA;
+        }
+    }
+    if (threadIdx.x == 0) {
+        AgcMap m;
+        m.A = runA;
+        m.B = runB;
+        maps[j] = m;
+    }
+}
+
+// gain at every block boundary = exclusive prefix composition of the block maps applied to the
+// initial gain: one workgroup, each thread composes a contiguous slice, the slices are scanned in
+// LDS (affine maps form a monoid), then every thread replays its slice from its prefix.
+template <typename T>
+__global__ void __launch_bounds__(1024) k_agc_guess(const AgcMap *__restrict__ maps, long long nb, const T *__restrict__ norm,
+                                                     double *__restrict__ guesses)
+{
+    __shared__ double sA[1024], sB[1024];
+    const long long per = (nb + 1023) / 1024;
+    long long j0 = (long long)threadIdx.x * per, j1 = j0 + per;
+    if (j0 > nb) j0 = nb;
+    if (j1 > nb) j1 = nb;
+    double A = 1.0, Bc = 0.0;
+    for (long long j = j0; j < j1; j++) {
+        const AgcMap m = maps[j];
+        Bc = m.A * Bc + m.B;
+        A = m.A * A;
+    }
+    sA[threadIdx.x] = A;
+    sB[threadIdx.x] = Bc;
+    __syncthreads();
+    for (int d = 1; d < 1024; d <<= 1) {            // inclusive Hillis-Steele scan of the slice maps
+        double Ap = 1.0, Bp = 0.0;
+        if ((int)threadIdx.x >= d) { Ap = sA[threadIdx.x - d]; Bp = sB[threadIdx.x - d]; }
+        __syncthreads();
+        if ((int)threadIdx.x >= d) {
+            Bc = A * Bp + Bc;
+            A = A * Ap;
+            sA[threadIdx.x] = A;
+            sB[threadIdx.x] = Bc;
+        }
+        __syncthreads();
+    }
+    // exclusive prefix of this thread's slice
+    double Ae = 1.0, Be = 0.0;
+    if (threadIdx.x > 0) { Ae = sA[threadIdx.x - 1]; Be = sB[threadIdx.x - 1]; }
+    double g = Ae * (double)*norm + Be;
+    for (long long j = j0; j < j1; j++) {
+        double gg = g;
+        if (!(gg > 1e-4)) gg = 1e-4;                // keep the model sane where the real AGC would clamp
+        if (gg > 5000.0) gg = 5000.0;
+        guesses[j] = gg;
+        const AgcMap m = maps[j];
+        g = m.A * g + m.B;
+    }
+}
+
 template <typename T>
 __global__ void __launch_bounds__(64) k_agc_block(const T *__restrict__ in, long long n, AgcParams<T> P,
                                                    const T *__restrict__ norm, long long B, long long W,
-                                                   const T *__restrict__ lock, T *__restrict__ out,
-                                                   AgcSeam<T> *__restrict__ seams)
+                                                   const double *__restrict__ guesses, const T *__restrict__ lock,
+                                                   T *__restrict__ out, AgcSeam<T> *__restrict__ seams)
 {
     const long long j = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     const long long start = j * B;
     if (start >= n) return;
     const long long end = (start + B < n) ? start + B : n;
-    // The gain contracts with time constant ~ gain/decay samples, so the warm-up a block needs
-    // scales with the local signal level: estimate it from 64 samples spread over the longest
-    // admissible warm-up [start-W, start), start from the gain that level implies and replay K
-    // time constants (K = 45 for float: measured 0.15 s for the strong synthetic carrier, 0.7 s
-    // for 5sec_clip.wav at 150 ksps; more bits to agree on in double).  Any choice is exact:
-    // seams are verified bitwise.  Blocks whose warm-up would reach back to sample 0 replay from
-    // the true initial gain instead.
+    // The gain contracts with time constant tau ~ gain/decay samples.  Start from the affine-model
+    // guess at a block boundary K time constants back (K = 14 for float, more bits to agree on in
+    // double), never more than W samples; blocks whose warm-up would reach sample 0 replay from
+    // the true initial gain.  Any choice is exact: seams are verified bitwise.
+    long long ws = 0;
     T gain = *norm;
-    const long long lo = (start - W > 0) ? start - W : 0;
-    long long ws = lo;                 // lo == 0: the true initial gain; else a guess refined below
-    if (start - lo >= 4096) {
-        T acc = 0;
-        const long long stride = (start - lo) / 64;
-#pragma unroll 16
-        for (int q = 0; q < 64; q++) acc += Real<T>::abs(in[lo + q * stride]);
-        long long need = W;
-        T g_est = gain;
-        if (acc > (T)0) {
-            g_est = (T)64 / acc;
-            const T K = (sizeof(T) == 4) ? (T)45 : (T)110;
-            const T nd = K * g_est / P.decay;
-            need = (nd < (T)W) ? (long long)nd : W;
-            need = (need + 3) & ~3ll;
-            if (need < 4096) need = 4096;
-        }
-        if (start - need > 0) {        // otherwise keep replaying from the true initial gain at sample 0
-            ws = start - need;
-            gain = (g_est < (T)5000) ? g_est : (T)5000;
+    if (j >= 1) {
+        const double g_here = guesses[j];
+        const double K = (sizeof(T) == 4) ? 14.0 : 34.0;
+        double need = K * g_here / (double)P.decay;
+        if (need < 4096.0) need = 4096.0;
+        if (need > (double)W) need = (double)W;
+        long long m = (long long)((need + (double)B - 1.0) / (double)B);
+        if (m < 1) m = 1;
+        if (j - m >= 1) {
+            ws = (j - m) * B;
+            const double g0 = guesses[j - m];
+            gain = (T)g0;
         }
     }
     agc_range<T, false>(in, lock, out, ws, start, gain, P);
