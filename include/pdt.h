@@ -34,6 +34,7 @@
  *                       ByteSyncOnSyncword (POESTIPdemod/ByteSync.c:16-150) /
  *                       FindSyncWords (ARGOSdemod/ByteSync.c:17-150)
  *   pdt_demod_device    same, input already resident in HBM (bench / multi-capture)
+ *   pdt_demod_f32       the same loop over GetComplexRawChunk (wave.c:413-540): RAW float32 captures
  *   pdt_frames          the fprintf stream of ByteSync.c, as records
  *   pdt_format_frames   the text ByteSync.c writes to the output file
  *   pdt_make_lpf        MakeLPFIR (LowPassFilter.c:127-175)
@@ -144,6 +145,12 @@ int  pdt_set_stream(pdt_ctx *ctx, void *hip_stream);
 int  pdt_demod_pcm16(pdt_ctx *ctx, const int16_t *iq_host, uint64_t nframes);
 /* ... or already resident in device memory (no copy; buffer is only read).                      */
 int  pdt_demod_device(pdt_ctx *ctx, const void *iq_device, uint64_t nframes);
+
+/* RAW input of demodPOES (".raw": interleaved IEEE float32 I,Q used as they are, no normalisation;
+ * GetComplexRawChunk, wave.c:413-540, POESTIPdemod/main.c:313-339; the sample rate comes from -s).
+ * POES only -- ARGOSdemod/main.c:238-241 refuses RAW files.                                       */
+int  pdt_demod_f32(pdt_ctx *ctx, const float *iq_host, uint64_t nframes);
+int  pdt_demod_device_f32(pdt_ctx *ctx, const void *iq_device, uint64_t nframes);
 
 /* Results of the last pdt_demod_* call. */
 uint64_t pdt_num_frames(const pdt_ctx *ctx);

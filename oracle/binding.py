@@ -40,6 +40,7 @@ def lib():
         L.orc_open.argtypes = [C.c_int, C.c_uint, C.c_ulong, C.c_double, C.c_int]
         L.orc_close.argtypes = [C.c_void_p]
         L.orc_run_pcm16.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t]
+        L.orc_run_f32.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t]
         L.orc_run_bits.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_size_t]
         L.orc_text.restype = C.c_void_p
         L.orc_text.argtypes = [C.c_void_p, C.POINTER(C.c_size_t)]
@@ -111,8 +112,12 @@ class Oracle:
         self.mode = mode
         self.dtype = np.float64 if mode == ARGOS else np.float32
         self._h = L.orc_open(mode, sample_rate, chunk, norm_override, int(keep_stages))
-        a = np.ascontiguousarray(iq, dtype="<i2").reshape(-1)
-        L.orc_run_pcm16(self._h, a.ctypes.data, a.size // 2)
+        if np.asarray(iq).dtype.kind == "f":                     # RAW float32 capture
+            a = np.ascontiguousarray(iq, dtype="<f4").reshape(-1)
+            L.orc_run_f32(self._h, a.ctypes.data, a.size // 2)
+        else:
+            a = np.ascontiguousarray(iq, dtype="<i2").reshape(-1)
+            L.orc_run_pcm16(self._h, a.ctypes.data, a.size // 2)
         L.orc_set_math_mode(MATH_LIBM)
 
     def __del__(self):

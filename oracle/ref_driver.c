@@ -32,6 +32,7 @@
 #include <complex.h>
 #include <math.h>
 #include <unistd.h>
+#include <strings.h>
 
 #ifdef ARGOS
 #define DECIMAL_TYPE double
@@ -103,10 +104,28 @@ int main(int argc, char **argv)
     FILE *out = fopen(argv[optind + 1], "w");
     if (!in || !out) { fprintf(stderr, "cannot open files\n"); return 1; }
 
-    HEADER header = ReadWavHeader(in);
+    HEADER header;
+    memset(&header, 0, sizeof header);
+    int is_raw = 0;
 #ifndef ARGOS
-    if (sampleRate > 1) header.sample_rate = sampleRate;       /* main.c:343-344 (Q6) */
+    {
+        const char *dot = strrchr(inFileName, '.');
+        is_raw = dot && strcasecmp(dot + 1, "raw") == 0;
+    }
+    if (is_raw) {                                               /* POESTIPdemod/main.c:313-339 */
+        if (sampleRate < 1) { fprintf(stderr, "Sample Rate (in Khz) must be specified when using RAW files\n"); return 1; }
+        header.type = 1;
+        header.sample_rate = sampleRate * 1000.0;
+        header.channels = 2;
+        header.bits_per_sample = 32;
+    } else
 #endif
+    {
+        header = ReadWavHeader(in);
+#ifndef ARGOS
+        if (sampleRate > 1) header.sample_rate = sampleRate;   /* main.c:343-344 (Q6) */
+#endif
+    }
     DT Fs = (DT)header.sample_rate;
 
 #ifdef ARGOS
@@ -129,7 +148,8 @@ int main(int argc, char **argv)
 
     unsigned long i = 0, nSamples, nSymbols, nBits, totalFrames = 0;
     while (!feof(in)) {
-        nSamples = GetComplexWaveChunk(in, header, waveData, waveDataTime, chunk);
+        nSamples = is_raw ? GetComplexRawChunk(in, header, waveData, waveDataTime, chunk)
+                          : GetComplexWaveChunk(in, header, waveData, waveDataTime, chunk);
         if (i == 0 && normFactor == 0) {
             normFactor = StaticGain(waveData, nSamples, 1.0);
             printf("Normalization Factor: %f\n", normFactor);

@@ -97,7 +97,7 @@ class KernelTime(C.Structure):
 # every symbol include/pdt.h declares (tests check the library exports all of them)
 ABI_SYMBOLS = [
     "pdt_abi_version", "pdt_strerror", "pdt_device_count", "pdt_open", "pdt_close", "pdt_set_stream",
-    "pdt_demod_pcm16", "pdt_demod_device", "pdt_num_frames", "pdt_frames", "pdt_get_stats",
+    "pdt_demod_pcm16", "pdt_demod_device", "pdt_demod_f32", "pdt_demod_device_f32", "pdt_num_frames", "pdt_frames", "pdt_get_stats",
     "pdt_format_frames", "pdt_read_stage", "pdt_stage_len", "pdt_kernel_times", "pdt_make_lpf",
     "pdt_wav_parse_header", "pdt_time_axis", "pdt_stage_bytesync",
 ]
@@ -126,6 +126,8 @@ def lib():
     L.pdt_set_stream.argtypes = [C.c_void_p, C.c_void_p]
     L.pdt_demod_pcm16.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64]
     L.pdt_demod_device.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64]
+    L.pdt_demod_f32.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64]
+    L.pdt_demod_device_f32.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64]
     L.pdt_num_frames.argtypes = [C.c_void_p]
     L.pdt_num_frames.restype = C.c_uint64
     L.pdt_frames.argtypes = [C.c_void_p, C.POINTER(Frame), C.c_uint64]
@@ -222,6 +224,12 @@ class Demodulator:
         """iq: int16 array of shape (n, 2) or flat interleaved I,Q in host memory."""
         a = np.ascontiguousarray(iq, dtype="<i2").reshape(-1)
         _check(self._L.pdt_demod_pcm16(self._h, a.ctypes.data, a.size // 2), "pdt_demod_pcm16")
+        return self
+
+    def demod_raw(self, iq: np.ndarray):
+        """RAW capture: float32 array of shape (n, 2) or flat interleaved I,Q, used without normalisation."""
+        a = np.ascontiguousarray(iq, dtype="<f4").reshape(-1)
+        _check(self._L.pdt_demod_f32(self._h, a.ctypes.data, a.size // 2), "pdt_demod_f32")
         return self
 
     def demod_device(self, dev_ptr: int, nframes: int):

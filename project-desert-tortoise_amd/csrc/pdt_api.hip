@@ -90,6 +90,7 @@ struct pdt_ctx {
     bool force_sequential_gardner = false;
     int gardner_mode = 0;              // 0 sequential, 1 state table (last run)
     const void *pcm_dev = nullptr;     // input actually used (own copy or caller's buffer)
+    int pcm_fmt = 0;                   // 0 = int16 pairs, 1 = float32 pairs
 
     std::vector<unsigned char> taps_host;
     // results
@@ -322,7 +323,9 @@ template <typename T> int run_capture(pdt_ctx *ctx, uint64_t n)
     if ((rc = ctx->scal.ensure(sizeof(DevScalars)))) return rc;
     if ((rc = ctx->lockinfo.ensure(sizeof(PllLockInfo<T>)))) return rc;
 
-    const int *d_pcm = (const int *)ctx->pcm_dev;
+    IqSrc d_pcm;
+    d_pcm.p = ctx->pcm_dev;
+    d_pcm.fmt = ctx->pcm_fmt;
     T *d_pll = (T *)ctx->pll.p;
     T *d_lock = argos ? (T *)ctx->lock.p : nullptr;
     T *d_fir = (T *)ctx->fir.p;
@@ -842,6 +845,7 @@ int pdt_demod_pcm16(pdt_ctx *ctx, const int16_t *iq_host, uint64_t nframes)
     if (rc) return rc;
     if (nframes) HIP_TRY(hipMemcpyAsync(ctx->pcm.p, iq_host, (size_t)nframes * 4, hipMemcpyHostToDevice, ctx->stream));
     ctx->pcm_dev = ctx->pcm.p;
+    ctx->pcm_fmt = 0;
     return demod_common(ctx, nframes);
 }
 
@@ -849,6 +853,29 @@ int pdt_demod_device(pdt_ctx *ctx, const void *iq_device, uint64_t nframes)
 {
     if (!ctx || (!iq_device && nframes)) return PDT_ERR_ARG;
     ctx->pcm_dev = iq_device;
+    ctx->pcm_fmt = 0;
+    return demod_common(ctx, nframes);
+}
+
+int pdt_demod_f32(pdt_ctx *ctx, const float *iq_host, uint64_t nframes)
+{
+    if (!ctx || (!iq_host && nframes)) return PDT_ERR_ARG;
+    if (ctx->cfg.mode != PDT_MODE_POES) return PDT_ERR_FORMAT;       // ARGOSdemod/main.c:238-241: "RAW files not yet supported"
+    HIP_TRY(hipSetDevice(ctx->cfg.device));
+    int rc = ctx->pcm.ensure((size_t)nframes * 8 + 16);
+    if (rc) return rc;
+    if (nframes) HIP_TRY(hipMemcpyAsync(ctx->pcm.p, iq_host, (size_t)nframes * 8, hipMemcpyHostToDevice, ctx->stream));
+    ctx->pcm_dev = ctx->pcm.p;
+    ctx->pcm_fmt = 1;
+    return demod_common(ctx, nframes);
+}
+
+int pdt_demod_device_f32(pdt_ctx *ctx, const void *iq_device, uint64_t nframes)
+{
+    if (!ctx || (!iq_device && nframes)) return PDT_ERR_ARG;
+    if (ctx->cfg.mode != PDT_MODE_POES) return PDT_ERR_FORMAT;
+    ctx->pcm_dev = iq_device;
+    ctx->pcm_fmt = 1;
     return demod_common(ctx, nframes);
 }
 

@@ -42,22 +42,25 @@ template <typename T> struct PllLockInfo {
     T avg_at_lock;
 };
 
-template <typename T> struct IqSample;
-template <> struct IqSample<float> {
-    static __device__ __forceinline__ void get(const int *pcm, long long i, float &a, float &b)
-    {
-        const int v = pcm[i];                                   // I | Q<<16, little endian
-        a = (float)(short)(v & 0xffff) / 32768.0f;              // wave.c:150-165
-        b = (float)(short)(v >> 16) / 32768.0f;
-    }
+// Sample source: the WAV payload as it is (interleaved int16 I,Q -> value/32768, wave.c:127-172) or
+// RAW interleaved float32 I,Q taken as they are (wave.c:413-540).  The format is uniform per launch.
+struct IqSrc {
+    const void *p;
+    int fmt;          // 0 = PCM16 pairs, 1 = float32 pairs
 };
 
-template <> struct IqSample<double> {
-    static __device__ __forceinline__ void get(const int *pcm, long long i, double &a, double &b)
+template <typename T> struct IqSample {
+    static __device__ __forceinline__ void get(IqSrc s, long long i, T &a, T &b)
     {
-        const int v = pcm[i];
-        a = (double)(short)(v & 0xffff) / 32768.0;
-        b = (double)(short)(v >> 16) / 32768.0;
+        if (s.fmt == 0) {
+            const int v = reinterpret_cast<const int *>(s.p)[i];     // I | Q<<16, little endian
+            a = (T)(short)(v & 0xffff) / (T)32768;
+            b = (T)(short)(v >> 16) / (T)32768;
+        } else {
+            const float2 v = reinterpret_cast<const float2 *>(s.p)[i];
+            a = (T)v.x;
+            b = (T)v.y;
+        }
     }
 };
 
@@ -100,7 +103,7 @@ template <typename T> __device__ __forceinline__ T pll_locksig(T a, T b, T t_rea
 
 // Acquisition: strictly sequential until the one-time lock event (Q9).  One lane.
 template <typename T>
-__global__ void __launch_bounds__(64) k_pll_acquire(const int *__restrict__ pcm, long long n, PllParams<T> P,
+__global__ void __launch_bounds__(64) k_pll_acquire(IqSrc pcm, long long n, PllParams<T> P,
                                                      T *__restrict__ out, T *__restrict__ lock_out,
                                                      PllLockInfo<T> *__restrict__ info)
 {
@@ -158,7 +161,7 @@ __global__ void __launch_bounds__(64) k_pll_acquire(const int *__restrict__ pcm,
 // reference; only the order in which *independent* iterations' pieces run is changed.
 
 template <typename T>
-__global__ void __launch_bounds__(256) k_pll_theta(const int *__restrict__ pcm, long long n, T *__restrict__ theta)
+__global__ void __launch_bounds__(256) k_pll_theta(IqSrc pcm, long long n, T *__restrict__ theta)
 {
     const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
@@ -304,7 +307,7 @@ __device__ __forceinline__ void pll_phase_range(const T *__restrict__ theta, T *
 // phase from the coherent sum of the de-rotated samples (the +-m modulation averages to
 // cos m > 0 along the carrier).
 template <typename T>
-__device__ __forceinline__ void pll_guess(const int *__restrict__ pcm, long long ws, long long n, int lag, T fallback_freq,
+__device__ __forceinline__ void pll_guess(IqSrc pcm, long long ws, long long n, int lag, T fallback_freq,
                                           T &phase, T &freq)
 {
     const int K = 1024, KP = 96;
@@ -312,15 +315,16 @@ __device__ __forceinline__ void pll_guess(const int *__restrict__ pcm, long long
     long long cnt = 0;
     if (ws + K + lag <= n) {
         for (int k0 = 0; k0 < K; k0 += 8) {              // 16 independent loads in flight
-            int v0[8], v1[8];
-#pragma unroll
-            for (int u = 0; u < 8; u++) { v0[u] = pcm[ws + k0 + u]; v1[u] = pcm[ws + k0 + u + lag]; }
+            float a0[8], b0[8], a1[8], b1[8];
 #pragma unroll
             for (int u = 0; u < 8; u++) {
-                const float a0 = (float)(short)(v0[u] & 0xffff), b0 = (float)(short)(v0[u] >> 16);
-                const float a1 = (float)(short)(v1[u] & 0xffff), b1 = (float)(short)(v1[u] >> 16);
-                rr += a1 * a0 + b1 * b0;                  // x1 * conj(x0)
-                ri += b1 * a0 - a1 * b0;
+                IqSample<float>::get(pcm, ws + k0 + u, a0[u], b0[u]);
+                IqSample<float>::get(pcm, ws + k0 + u + lag, a1[u], b1[u]);
+            }
+#pragma unroll
+            for (int u = 0; u < 8; u++) {
+                rr += a1[u] * a0[u] + b1[u] * b0[u];      // x1 * conj(x0)
+                ri += b1[u] * a0[u] - a1[u] * b0[u];
             }
         }
         cnt = K;
@@ -330,16 +334,15 @@ __device__ __forceinline__ void pll_guess(const int *__restrict__ pcm, long long
     float sr = 0, si = 0;
     if (ws + KP <= n) {
         for (int k0 = 0; k0 < KP; k0 += 8) {
-            int v0[8];
+            float a0[8], b0[8];
 #pragma unroll
-            for (int u = 0; u < 8; u++) v0[u] = pcm[ws + k0 + u];
+            for (int u = 0; u < 8; u++) IqSample<float>::get(pcm, ws + k0 + u, a0[u], b0[u]);
 #pragma unroll
             for (int u = 0; u < 8; u++) {
-                const float a0 = (float)(short)(v0[u] & 0xffff), b0 = (float)(short)(v0[u] >> 16);
                 float sn, cs;
                 __sincosf(f * (float)(k0 + u), &sn, &cs);
-                sr += a0 * cs + b0 * sn;                  // x * e^{-j f k}
-                si += b0 * cs - a0 * sn;
+                sr += a0[u] * cs + b0[u] * sn;            // x * e^{-j f k}
+                si += b0[u] * cs - a0[u] * sn;
             }
         }
     }
@@ -363,7 +366,7 @@ __device__ __forceinline__ void pll_guess(const int *__restrict__ pcm, long long
 // state, and k_pll_fix validates every later seam against that chain; phases computed for
 // samples before the lock are simply never used.
 template <typename T, bool SLOW>
-__global__ void __launch_bounds__(64) k_pll_phase(const int *__restrict__ pcm, const T *__restrict__ theta, long long n,
+__global__ void __launch_bounds__(64) k_pll_phase(IqSrc pcm, const T *__restrict__ theta, long long n,
                                                    PllParams<T> P, long long B, long long Wacq, long long Wtrk, int lag,
                                                    T *__restrict__ phi, PllSeam<T> *__restrict__ seams)
 {
@@ -510,7 +513,7 @@ __global__ void __launch_bounds__(64) k_pll_fix(const T *__restrict__ theta, lon
 // elementwise mix for the samples after the lock (:106-113), and the lock-detector input
 // term lockSigAlpha*(re*t_real + im*t_imag) (:194-220) when the lock stream is wanted
 template <typename T, bool LOCKSIG>
-__global__ void __launch_bounds__(256) k_pll_mix(const int *__restrict__ pcm, const T *__restrict__ phi, long long n,
+__global__ void __launch_bounds__(256) k_pll_mix(IqSrc pcm, const T *__restrict__ phi, long long n,
                                                   PllParams<T> P, const PllLockInfo<T> *__restrict__ info,
                                                   T *__restrict__ out, T *__restrict__ lock_term)
 {
@@ -688,7 +691,7 @@ __global__ void __launch_bounds__(PDT_FIR_THREADS) k_fir_plain(const T *__restri
 // Magnitudes in parallel, the 2-op recurrence on one lane.
 // ------------------------------------------------------------------------------------------
 template <typename T>
-__global__ void __launch_bounds__(256) k_static_gain(const int *__restrict__ pcm, long long n0, T *__restrict__ mag_scratch,
+__global__ void __launch_bounds__(256) k_static_gain(IqSrc pcm, long long n0, T *__restrict__ mag_scratch,
                                                       T desired, double override_norm, T *__restrict__ norm_out)
 {
     if (override_norm != 0.0) {

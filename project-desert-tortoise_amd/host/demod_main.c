@@ -18,7 +18,8 @@
  *   output removed when no frame was found             main.c:508-512
  * Additions: -o <file> chooses the output name (tests), -d <n> picks the GPU.
  * Not reproduced: the per-chunk "\r" progress line (there are no chunks on the GPU; one
- * summary line is printed instead) and the RAW float32 input path ("next").
+ * summary line is printed instead).  RAW float32 input (".raw", -s mandatory) is supported for POES
+ * exactly as in POESTIPdemod/main.c:313-339.
  */
 #include <ctype.h>
 #include <stdio.h>
@@ -129,54 +130,69 @@ int main(int argc, char **argv)
         fclose(raw);
     }
 
+    int is_raw = 0;
     if (strcasecmp(get_filename_ext(inFileName), "wav") != 0) {
 #ifdef PDT_ARGOS
         printf("RAW files not yet supported :(\n");
-#else
-        if (strcasecmp(get_filename_ext(inFileName), "raw") == 0)
-            printf("RAW float32 input is not supported by the MI355X build yet\n");
-        else
-            printf("Unrecognized file format %s\n", get_filename_ext(inFileName));
-#endif
         exit(1);
+#else
+        if (strcasecmp(get_filename_ext(inFileName), "raw") == 0) {
+            if (sampleRate < 1) {                                     /* main.c:317-321 */
+                printf("Sample Rate (in Khz) must be specified when using RAW files\n");
+                exit(1);
+            }
+            printf("Assuming 32-bit IEEE Floating Point RAW input\n");
+            is_raw = 1;
+        } else {
+            printf("Unrecognized file format %s\n", get_filename_ext(inFileName));
+            exit(1);
+        }
+#endif
     }
 
-    uint8_t hdr[44];
-    if (fread(hdr, 1, 44, in) != 44) {
-        printf("Error reading WAV header\n");
-        exit(1);
-    }
-    uint32_t rate, channels, bits, format, data_bytes;
-    pdt_wav_parse_header(hdr, &rate, &channels, &bits, &format, &data_bytes);
-    if (channels != 2) {
-        printf("Complex read requires 2 channels (I and Q)\n");
-        exit(1);
-    }
-    if (format != 1) {
-        printf("Only PCM is currently supported :(\n");
-        exit(1);
-    }
-    if (bits != 16) {
-        printf("Only 16-bit PCM is supported by the MI355X build (the reference truncates other widths, Q5)\n");
-        exit(1);
-    }
+    uint32_t rate = 0, channels = 2, bits = 32, format = 1, data_bytes = 0;
+    long data_offset = 0;
+    if (!is_raw) {
+        uint8_t hdr[44];
+        if (fread(hdr, 1, 44, in) != 44) {
+            printf("Error reading WAV header\n");
+            exit(1);
+        }
+        pdt_wav_parse_header(hdr, &rate, &channels, &bits, &format, &data_bytes);
+        data_offset = 44;
+        if (channels != 2) {
+            printf("Complex read requires 2 channels (I and Q)\n");
+            exit(1);
+        }
+        if (format != 1) {
+            printf("Only PCM is currently supported :(\n");
+            exit(1);
+        }
+        if (bits != 16) {
+            printf("Only 16-bit PCM is supported by the MI355X build (the reference truncates other widths, Q5)\n");
+            exit(1);
+        }
 #ifndef PDT_ARGOS
-    if (sampleRate > 1) rate = (uint32_t)sampleRate;                 /* main.c:343-344 (Q6) */
+        if (sampleRate > 1) rate = (uint32_t)sampleRate;             /* main.c:343-344 (Q6) */
 #endif
-    long num_samples = (long)((8.0 * data_bytes) / (channels * bits));
-    printf("Sample Rate %.2fKHz and %d bits per sample. Total samples %ld\n", (float)rate / 1000.0, bits, num_samples);
+        long num_samples = (long)((8.0 * data_bytes) / (channels * bits));
+        printf("Sample Rate %.2fKHz and %d bits per sample. Total samples %ld\n", (float)rate / 1000.0, bits, num_samples);
+    } else {
+        rate = (uint32_t)(sampleRate * 1000.0);                      /* main.c:329: entered in kHz */
+    }
 
     /* the reference reads until EOF, not header.data_size */
     fseek(in, 0, SEEK_END);
     long fsz = ftell(in);
-    fseek(in, 44, SEEK_SET);
-    uint64_t nframes = fsz > 44 ? (uint64_t)(fsz - 44) / 4 : 0;
-    int16_t *pcm = (int16_t *)malloc(nframes * 4 + 16);
-    if (!pcm) {
+    fseek(in, data_offset, SEEK_SET);
+    const size_t frame_bytes = is_raw ? 8 : 4;
+    uint64_t nframes = fsz > data_offset ? (uint64_t)(fsz - data_offset) / frame_bytes : 0;
+    void *samples = malloc(nframes * frame_bytes + 16);
+    if (!samples) {
         printf("Error in malloc\n");
         exit(1);
     }
-    if (fread(pcm, 4, nframes, in) != nframes) {
+    if (fread(samples, frame_bytes, nframes, in) != nframes) {
         printf("Error reading samples\n");
         exit(1);
     }
@@ -197,7 +213,7 @@ int main(int argc, char **argv)
         remove(outFileName);
         exit(1);
     }
-    rc = pdt_demod_pcm16(ctx, pcm, nframes);
+    rc = is_raw ? pdt_demod_f32(ctx, (const float *)samples, nframes) : pdt_demod_pcm16(ctx, (const int16_t *)samples, nframes);
     if (rc != PDT_OK) {
         printf("Demodulation failed: %s\n", pdt_strerror(rc));
         fclose(out);
@@ -233,7 +249,7 @@ int main(int argc, char **argv)
         printf("\nAll done! Closing files and exiting.\nENJOY YOUR BITS AND HAVE A NICE DAY\n");
     }
     free(text);
-    free(pcm);
+    free(samples);
     pdt_close(ctx);
     return 0;
 }

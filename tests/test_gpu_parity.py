@@ -182,6 +182,29 @@ def test_cli_demodargos(pdt, tmp_path, golden):
     assert golden_text("argos_32000.txt").decode() in r.stdout          # packets are mirrored to stdout (ARGOSdemod/ByteSync.c)
 
 
+@pytest.mark.parametrize("scale", [1.0, 37.5, 0.004])
+def test_raw_float32_input(pdt, orc, tmp_path, scale):
+    """RAW float32 captures (pdt_demod_f32): bit-exact vs the oracle's RAW path, through the CLI too."""
+    iq = pdt.synth_capture(0, 50000, 4.0, seed=5)
+    raw = (iq.astype(np.float32) / np.float32(32768.0)) * np.float32(scale)
+    o = orc.Oracle(orc.POES, 50000, raw)
+    with pdt.Demodulator(pdt.MODE_POES, 50000) as d:
+        d.demod_raw(raw)
+        check_all_stages(pdt, orc, d, o)
+        assert d.stats().frames >= 38
+    path = tmp_path / "cap.raw"
+    raw.tofile(path)
+    out = tmp_path / "mf.txt"
+    r = subprocess.run([os.path.join(ROOT, "bin", "demodPOES"), "-s", "50", "-o", str(out), str(path)], capture_output=True,
+                       text=True)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert out.read_bytes() == o.text()
+    r = subprocess.run([os.path.join(ROOT, "bin", "demodPOES"), "-o", str(out), str(path)], capture_output=True, text=True)
+    assert r.returncode == 1 and "Sample Rate (in Khz) must be specified" in r.stdout
+    with pytest.raises(pdt.PdtError):
+        pdt.Demodulator(pdt.MODE_ARGOS, 32000).demod_raw(raw)        # the ARGOS program refuses RAW files
+
+
 def test_context_reuse_and_device_input(pdt, orc, clip):
     import torch
     rate, iq = clip

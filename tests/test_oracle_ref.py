@@ -115,3 +115,20 @@ def test_argos_portable_math_keeps_the_reference_output(orc, pdt, tmp_path, seed
         orc.lib().orc_sincos_portable(float(x), C.byref(s), C.byref(c))
         assert abs(s.value - math.sin(x)) <= 1.2e-16 * max(abs(math.sin(x)), 1e-300) * 2 or abs(s.value - math.sin(x)) < 2.3e-16
         assert abs(c.value - math.cos(x)) < 2.3e-16
+
+
+@pytest.mark.parametrize("scale", [1.0, 37.5, 0.004])
+def test_raw_float32_input(orc, pdt, tmp_path, scale):
+    """RAW path (GetComplexRawChunk, wave.c:413-540; POESTIPdemod/main.c:313-339): interleaved float32
+    I,Q used without normalisation, rate from -s in kHz."""
+    iq = pdt.synth_capture(0, 50000, 4.0, seed=5)
+    raw = (iq.astype(np.float32) / np.float32(32768.0)) * np.float32(scale)
+    path = tmp_path / "cap.raw"
+    raw.tofile(path)
+    text, dump = run_ref(REF_POES, path, tmp_path, ["-s", "50"])
+    o = orc.Oracle(orc.POES, 50000, raw)
+    compare_all(o, dump)
+    assert o.text() == text and len(text) > 0
+    if scale == 1.0:
+        # the same samples as a WAV give the same file
+        assert text == orc.Oracle(orc.POES, 50000, iq, keep_stages=False).text()
