@@ -381,7 +381,14 @@ template <typename T> int run_capture(pdt_ctx *ctx, uint64_t n)
         HIP_TRY(hipEventRecord(ctx->ev_join, ctx->stream2));
     }
     L.begin("pll_acquire");
-    hipLaunchKernelGGL(k_pll_acquire<T>, dim3(1), dim3(64), 0, st, d_pcm, N, PP, d_pll, d_lock, d_info);
+    if (getenv("PDT_ACQUIRE_SIMPLE"))       // plain one-lane form, kept for A/B checks
+        hipLaunchKernelGGL(k_pll_acquire<T>, dim3(1), dim3(64), 0, st, d_pcm, N, PP, d_pll, d_lock, d_info);
+    else if (slow_wrap)
+        hipLaunchKernelGGL((k_pll_acquire_fast<T, true>), dim3(1), dim3(64), 0, st, d_pcm, (const T *)d_theta, N, PP, d_pll, d_lock,
+                           d_info);
+    else
+        hipLaunchKernelGGL((k_pll_acquire_fast<T, false>), dim3(1), dim3(64), 0, st, d_pcm, (const T *)d_theta, N, PP, d_pll, d_lock,
+                           d_info);
     L.end();
     if (N > 0) {
         const long long grid = grid_pll;

@@ -234,6 +234,165 @@ __device__ __forceinline__ void pll_phase_step(T th, T &phase, T &freq, T alpha,
     freq = PiAbs<T>::clamp(f1, minf, maxf);
 }
 
+// Acquisition, fast form.  One wavefront; the stream is taken in batches of 32 samples, sample k
+// of the batch living in lane k:
+//   pass 1 (serial, every lane computes the same values): the (phase, freq) loop filter over the
+//           precomputed theta, under the hypothesis that the sweep condition
+//           |pi/2 - averagePhase| < 0.05 keeps the value it had at the previous sample (it changes a
+//           handful of times per capture); lane k keeps the states around sample k;
+//   pass 2 (lane-parallel): everything that depends only on phase_k -- sincos, the mix, arctan2 of
+//           the output, the two EMA input terms;
+//   pass 3 (serial): the averagePhase and lock-detector EMAs (two interleaved f64 chains), the
+//           sweep condition and the lock test of every sample; the first sample whose sweep
+//           condition contradicts the hypothesis rolls the batch back to that sample.
+// The operations per sample and their order are those of the reference iteration
+// (CarrierTrackingPLL.c:102-275); only independent pieces of different samples are interleaved.
+// Lane <-> uniform traffic is v_readlane / v_cndmask only: no LDS, no barriers, and the only
+// memory operations are one coalesced load of theta and IQ per batch (issued one batch ahead).
+#define PDT_ACQ_NB 32
+__device__ __forceinline__ float lane_get(float v, int k) { return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), k)); }
+__device__ __forceinline__ double lane_get(double v, int k)
+{
+    const long long b = __double_as_longlong(v);
+    const unsigned lo = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)b, k);
+    const unsigned hi = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)(b >> 32), k);
+    return __longlong_as_double((long long)(((unsigned long long)hi << 32) | lo));
+}
+
+template <typename T> __device__ __forceinline__ void pll_sweep_step(T &fr, T &sw, T maxf, T minf)
+{
+    fr = fr + sw;                                    // :239-252
+    if (fr >= maxf) sw = -sw;
+    else if (fr <= minf) sw = -sw;
+    else if (fr >= 0) sw = Real<T>::abs(sw);
+    else sw = -Real<T>::abs(sw);
+}
+
+template <typename T, bool SLOW>
+__global__ void __launch_bounds__(64) k_pll_acquire_fast(IqSrc pcm, const T *__restrict__ theta, long long n, PllParams<T> P,
+                                                          T *__restrict__ out, T *__restrict__ lock_out,
+                                                          PllLockInfo<T> *__restrict__ info)
+{
+    const int lane = threadIdx.x;
+    const T avg_alpha = (T)0.00005;
+    const double k_avg = 1.0 - (double)avg_alpha, k_lock = 1.0 - (double)P.lock_alpha;
+    T phase = P.phase0, freq = 0, avg = P.avg0, locksig = 0, sweep = P.sweep0;
+    bool hyp = (double)Real<T>::abs((T)(PDT_PI / 2.0 - (double)avg)) < 0.05;   // sweep condition assumed for the next sample
+    long long lock_at = -1;
+    T freq_at_lock = 0, avg_at_lock = P.avg0;
+    long long i0 = 0;
+    // per-lane inputs of the current batch and of the one after it
+    T th_l = 0, a_l = 0, b_l = 0, th_n = 0, a_n = 0, b_n = 0;
+    long long i_next = -1;     // batch start th_n/a_n/b_n were loaded for
+    if (lane < PDT_ACQ_NB && lane < n) {
+        th_l = theta[lane];
+        IqSample<T>::get(pcm, lane, a_l, b_l);
+    }
+    while (i0 < n && lock_at < 0) {
+        const int nb = (int)((n - i0 < PDT_ACQ_NB) ? (n - i0) : PDT_ACQ_NB);
+        i_next = i0 + PDT_ACQ_NB;
+        if (lane < PDT_ACQ_NB && i_next + lane < n) {
+            th_n = theta[i_next + lane];
+            IqSample<T>::get(pcm, i_next + lane, a_n, b_n);
+        }
+        // ---- pass 1: loop filter; lane k keeps phase before / after sample k, freq before the sweep
+        // step, and the sweep increment before it
+        T phi_l = 0, phn_l = 0, fpre_l = 0, swb_l = 0;
+        {
+            T ph = phase, fr = freq, sw = sweep;
+            for (int k = 0; k < nb; k++) {
+                const T th = lane_get(th_l, k);
+                const bool mine = lane == k;
+                phi_l = mine ? ph : phi_l;
+                pll_phase_step<T, SLOW>(th, ph, fr, P.alpha_acq, P.beta_acq, P.max_freq, P.min_freq);
+                phn_l = mine ? ph : phn_l;
+                fpre_l = mine ? fr : fpre_l;
+                swb_l = mine ? sw : swb_l;
+                if (hyp) pll_sweep_step(fr, sw, P.max_freq, P.min_freq);
+            }
+        }
+        // ---- pass 2: per-sample work (lane k <-> sample k)
+        T t_l = 0, u_l = 0, o_l = 0;
+        {
+            T t_real, t_imag;
+            Real<T>::sincos(phi_l, t_imag, t_real);
+            const T c = t_real, d = -t_imag;
+            const T o_re = a_l * c - b_l * d;
+            const T o_im = a_l * d + b_l * c;
+            o_l = o_im;
+            const T ph = arctan2_ref(o_im, o_re);
+            t_l = avg_alpha * Real<T>::abs(ph);
+            const T mag2 = a_l * a_l + b_l * b_l;
+            const T inv = (T)q_rsqrt((float)mag2);
+            const T re = a_l * inv, im = b_l * inv;
+            u_l = P.lock_alpha * (re * t_real + im * t_imag);
+        }
+        // ---- pass 3: EMAs, sweep condition, lock test
+        int done = nb;            // samples of this batch that stand
+        bool flip = false;
+        T ls_l = 0;
+        {
+            T av = avg, ls = locksig;
+            int k = 0;
+            for (; k < nb; k++) {
+                av = (T)((double)av * k_avg + (double)lane_get(t_l, k));
+                ls = (T)((double)ls * k_lock + (double)lane_get(u_l, k));
+                ls_l = (lane == k) ? ls : ls_l;
+                const bool cond = (double)Real<T>::abs((T)(PDT_PI / 2.0 - (double)av)) < 0.05;
+                if (cond != hyp || ls > P.lock_thr) {
+                    flip = cond != hyp;
+                    break;
+                }
+            }
+            avg = av;
+            locksig = ls;
+            if (k < nb) {
+                // sample k ends the batch: its sweep step is taken with its own (true) condition
+                const bool cond = flip ? !hyp : hyp;
+                T fr = lane_get(fpre_l, k), sw = lane_get(swb_l, k);
+                if (cond) pll_sweep_step(fr, sw, P.max_freq, P.min_freq);
+                phase = lane_get(phn_l, k);
+                freq = fr;
+                sweep = sw;
+                hyp = cond;
+                done = k + 1;
+                if (ls > P.lock_thr) {
+                    lock_at = i0 + k;
+                    freq_at_lock = freq;
+                    avg_at_lock = av;
+                }
+            } else {
+                // the whole batch stands: adopt the state after its last sample
+                const int kl = nb - 1;
+                T fr = lane_get(fpre_l, kl), sw = lane_get(swb_l, kl);
+                if (hyp) pll_sweep_step(fr, sw, P.max_freq, P.min_freq);
+                phase = lane_get(phn_l, kl);
+                freq = fr;
+                sweep = sw;
+            }
+        }
+        if (lane < done) {
+            out[i0 + lane] = o_l;
+            if (lock_out) lock_out[i0 + lane] = ls_l;
+        }
+        i0 += done;
+        if (i0 == i_next) {
+            th_l = th_n; a_l = a_n; b_l = b_n;
+        } else if (lane < PDT_ACQ_NB && i0 + lane < n) {
+            th_l = theta[i0 + lane];
+            IqSample<T>::get(pcm, i0 + lane, a_l, b_l);
+        }
+    }
+    if (lane == 0) {
+        PllState<T> st;
+        st.phase = phase; st.freq = freq; st.avg_phase = avg; st.locksig = locksig; st.sweep = sweep;
+        info->lock_sample = lock_at;
+        info->st = st;
+        info->freq_at_lock = freq_at_lock;
+        info->avg_at_lock = avg_at_lock;
+    }
+}
+
 template <typename T> struct PllSeam {
     T phase0, freq0;   // state at the block's official start (after warm-up)
     T phase1, freq1;   // state after the block's last sample
