@@ -88,9 +88,10 @@ typedef struct pdt_config {
      * and re-run sequentially on mismatch, so results never depend on these.
      * 0 = defaults derived from the sample rate.                                                  */
     uint32_t pll_block, pll_warm, agc_block, agc_warm;
-    /* Gardner boundary-state tables: candidates are tabulated this many samples beyond the hull of
-     * the scout trajectories (0 = default 0.25; no chunk needed more than 1/16 in any test capture).  Smaller = less work, more chunks walked serially;
-     * the result never depends on it.                                                             */
+    /* Gardner boundary-state tables: candidate entry states are tabulated within this many samples of
+     * the end point of each of 64 scout trajectories (0 = default 1/16; the true state was further
+     * from every scout in ~1 chunk per 1500 of the test captures).  Smaller = less work, more chunks
+     * walked serially; the result never depends on it.                                            */
     double   gardner_band_pad;
 } pdt_config;
 

@@ -24,7 +24,7 @@ import struct
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIBPDT_PATH = os.path.join(_HERE, "csrc", "libpdt.so")
+LIBPDT_PATH = os.environ.get("PDT_LIBPDT_PATH") or os.path.join(_HERE, "csrc", "libpdt.so")   # override: tuning experiments only
 LIBSYNTH_PATH = os.path.join(_HERE, "synth", "libpdtsynth.so")
 
 MODE_POES, MODE_ARGOS = 0, 1

@@ -85,7 +85,7 @@ struct pdt_ctx {
     hipEvent_t ev0 = nullptr, ev1 = nullptr, ev_fork = nullptr, ev_join = nullptr;
     hipStream_t stream2 = nullptr;     // side stream: block-parallel PLL phase runs beside the sequential acquisition
 
-    DevBuf pcm, pll, lock, fir, agc, sym, symidx, bits, bitsym, hits, frames, taps, mag, seams_pll, seams_agc, scal, lockinfo, term, seams_ema, gtable, gentries, gcand, gmfirst, stiles, gsegmap, gsegstart, gbands, agc_maps;
+    DevBuf pcm, pll, lock, fir, agc, sym, symidx, bits, bitsym, hits, frames, taps, mag, seams_pll, seams_agc, scal, lockinfo, term, seams_ema, gtable, gentries, gcand, gmfirst, stiles, gsegmap, gsegstart, gbands, gclist, agc_maps;
     long long gcand_key = -1;          // (chunk_out, step) the candidate list on the device was built for
     bool force_sequential_gardner = false;
     int gardner_mode = 0;              // 0 sequential, 1 state table (last run)
@@ -451,11 +451,15 @@ template <typename T> int run_capture(pdt_ctx *ctx, uint64_t n)
         if ((rc = ctx->agc_maps.ensure((size_t)(nb + 1) * (sizeof(AgcMap) + sizeof(double))))) return rc;
         AgcMap *d_maps = (AgcMap *)ctx->agc_maps.p;
         double *d_guess = (double *)(d_maps + nb + 1);
+        // warm-up length in gain time constants: the affine guess is off by the accumulated float rounding of
+        // the true recurrence only, so a few time constants make the trajectories agree to the last bit
+        double agc_K = (sizeof(T) == 4) ? 11.0 : 34.0;
+        if (const char *e = getenv("PDT_AGC_K")) agc_K = atof(e);
         L.begin("agc_block");
         hipLaunchKernelGGL(k_agc_affine<T>, dim3((unsigned)nb), dim3(256), 0, st, d_fir, n_out, AP.decay, Ba, d_maps);
         hipLaunchKernelGGL(k_agc_guess<T>, dim3(1), dim3(1024), 0, st, (const AgcMap *)d_maps, nb, (const T *)d_norm, d_guess);
         hipLaunchKernelGGL(k_agc_block<T>, dim3((unsigned)grid), dim3(64), 0, st, d_fir, n_out, AP, d_norm, Ba, Wa,
-                           (const double *)d_guess, d_lock, d_agc, (AgcSeam<T> *)ctx->seams_agc.p);
+                           (const double *)d_guess, d_lock, d_agc, (AgcSeam<T> *)ctx->seams_agc.p, agc_K);
         L.end();
         L.begin("agc_fix");
         hipLaunchKernelGGL(k_agc_fix<T>, dim3(1), dim3(64), 0, st, d_fir, n_out, AP, Ba, d_lock, d_agc,
@@ -486,8 +490,8 @@ template <typename T> int run_capture(pdt_ctx *ctx, uint64_t n)
                 GD.q_min = q_min;
                 GD.u = u;
                 GD.n_q = n_q;
-                const double pad = ctx->cfg.gardner_band_pad > 0 ? ctx->cfg.gardner_band_pad : 0.25;
-                GD.pad_q = (int)(pad / (double)u);
+                const double pad = ctx->cfg.gardner_band_pad > 0 ? ctx->cfg.gardner_band_pad : 1.0 / 16.0;
+                GD.pad_q = std::max(2, (int)(pad / (double)u));
             }
         }
     }
@@ -521,13 +525,17 @@ template <typename T> int run_capture(pdt_ctx *ctx, uint64_t n)
             if ((rc = ctx->gentries.ensure((size_t)n_chunks * sizeof(GardnerEntry<float>)))) return rc;
             if ((rc = ctx->gbands.ensure((size_t)n_tab * sizeof(GardnerBand)))) return rc;
             L.begin("gardner_table");
+            if ((rc = ctx->gclist.ensure((size_t)n_tab * PDT_GTAB_LIST * sizeof(unsigned)))) return rc;
             hipLaunchKernelGGL(k_gardner_scout, dim3((unsigned)n_tab), dim3(64), 0, st, (const float *)d_agc, GP, GD, n_tab,
-                               (const int *)ctx->gmfirst.p, (unsigned *)ctx->gtable.p, (GardnerBand *)ctx->gbands.p, d_sc->gstats);
+                               (const int *)ctx->gmfirst.p, (const unsigned *)ctx->gcand.p, (unsigned *)ctx->gtable.p,
+                               (GardnerBand *)ctx->gbands.p, (unsigned *)ctx->gclist.p, d_sc->gstats);
             {
-                const unsigned parts = (unsigned)((GD.n_cand + 2 * PDT_GTAB_THREADS - 1) / (2 * PDT_GTAB_THREADS));
-                hipLaunchKernelGGL(k_gardner_table, dim3((unsigned)n_tab, parts), dim3(PDT_GTAB_THREADS), 0, st, (const float *)d_agc, GP,
+                // locked chunks carry 100-300 candidates: small blocks (2 candidates per lane), many per CU
+                constexpr int TT = PDT_GTAB_THREADS, TW = PDT_GTAB_WIN;
+                const unsigned parts = (unsigned)((GD.n_cand + 2 * TT - 1) / (2 * TT));
+                hipLaunchKernelGGL((k_gardner_table<TT, TW>), dim3((unsigned)n_tab, parts), dim3(TT), 0, st, (const float *)d_agc, GP,
                                    GD, n_tab, (const unsigned *)ctx->gcand.p, (const GardnerBand *)ctx->gbands.p,
-                                   (unsigned *)ctx->gtable.p, d_sc->gstats);
+                                   (const unsigned *)ctx->gclist.p, (unsigned *)ctx->gtable.p, d_sc->gstats);
             }
             L.end();
             const int G = 32;                                                  // chunks per chain segment
@@ -546,8 +554,8 @@ template <typename T> int run_capture(pdt_ctx *ctx, uint64_t n)
                                (GardnerEntry<float> *)ctx->gentries.p);
             L.end();
             L.begin("gardner");
-            // per-chunk emission: small LDS windows (16 + 4 KiB) so that several chunks share a CU
-            hipLaunchKernelGGL((k_gardner<float, 4096, 512>), dim3((unsigned)n_chunks), dim3(PDT_GARDNER_THREADS), 0, st, (const float *)d_agc,
+            // per-chunk emission: small LDS windows so that every chunk of a 10-minute capture is resident at once
+            hipLaunchKernelGGL((k_gardner<float, PDT_GEMIT_LEN, PDT_GEMIT_OUT>), dim3((unsigned)n_chunks), dim3(PDT_GARDNER_THREADS), 0, st, (const float *)d_agc,
                                (const float *)d_lock, GP, (float *)d_sym, d_symidx, &d_sc->nsym, sym_cap,
                                (const GardnerEntry<float> *)ctx->gentries.p);
             L.end();
@@ -811,7 +819,7 @@ void pdt_close(pdt_ctx *ctx)
     DevBuf *bufs[] = { &ctx->pcm, &ctx->pll, &ctx->lock, &ctx->fir, &ctx->agc, &ctx->sym, &ctx->symidx, &ctx->bits, &ctx->bitsym,
                        &ctx->hits, &ctx->frames, &ctx->taps, &ctx->mag, &ctx->seams_pll, &ctx->seams_agc, &ctx->scal, &ctx->lockinfo,
                        &ctx->term, &ctx->seams_ema, &ctx->gtable, &ctx->gentries, &ctx->gcand,
-                       &ctx->gmfirst, &ctx->stiles, &ctx->gsegmap, &ctx->gsegstart, &ctx->gbands, &ctx->agc_maps };
+                       &ctx->gmfirst, &ctx->stiles, &ctx->gsegmap, &ctx->gsegstart, &ctx->gbands, &ctx->gclist, &ctx->agc_maps };
     for (DevBuf *b : bufs) b->release();
     if (ctx->ev0) (void)hipEventDestroy(ctx->ev0);
     if (ctx->ev1) (void)hipEventDestroy(ctx->ev1);

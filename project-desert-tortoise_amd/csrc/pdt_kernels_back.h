@@ -54,6 +54,12 @@ template <> struct GardnerLds<float> { static constexpr int LEN = 31232; static 
 template <> struct GardnerLds<double> { static constexpr int LEN = 14336; static constexpr int OUT = 3072; };  // 112 + 36 KiB
 
 #define PDT_GARDNER_THREADS 64
+#ifndef PDT_GEMIT_LEN
+#define PDT_GEMIT_LEN 2048            // parallel emission: LDS window (samples) and symbol staging buffer per chunk
+#endif
+#ifndef PDT_GEMIT_OUT
+#define PDT_GEMIT_OUT 256
+#endif
 
 template <typename T> __device__ __forceinline__ T uniform(T v);
 template <> __device__ __forceinline__ int uniform<int>(int v) { return __builtin_amdgcn_readfirstlane(v); }
@@ -277,8 +283,13 @@ struct GardnerDomain {
     int pad_q;         // candidates are tabulated this many grid points beyond the scouts' hull (default 1/2 sample)
 };
 
-#define PDT_GTAB_THREADS 512
 #define PDT_GTAB_TAIL 4096           // samples of the previous chunk the scouts run over
+#ifndef PDT_GTAB_THREADS
+#define PDT_GTAB_THREADS 64           // table kernel: threads per block (one or two candidates per lane)
+#endif
+#ifndef PDT_GTAB_WIN
+#define PDT_GTAB_WIN 2048             // table kernel: LDS window in floats (8 KiB: every chunk of a 10-minute capture resident)
+#endif
 #define PDT_GTAB_MISS 0xffffffffu    // cell not tabulated
 
 __device__ __forceinline__ void gardner_entry_from_candidate(const float *__restrict__ in, const GardnerParams<float> &P,
@@ -305,7 +316,6 @@ __device__ __forceinline__ unsigned gardner_encode_exit(const GardnerDomain &D, 
     return ok ? (((unsigned)(2 * m + v)) | (count << 20)) : PDT_GTAB_MISS;
 }
 
-#define PDT_GTAB_WIN 6128           // LDS window (floats): 24 KiB + 16 KiB tail -> four 512-thread blocks per CU
 
 // rint(x) as an integer for 0 <= x < 2^22: adding 1.5*2^23 makes the FPU round x to an integer
 // (nearest-even, exactly like rintf) and leaves it in the low mantissa bits
@@ -353,33 +363,40 @@ __device__ __forceinline__ void gardner_lane_tail(GardnerLane &L, const float *w
 }
 
 // scouts: one wavefront per chunk.  64 trajectories over the tail of chunk c-1, started one 64th
-// of a symbol apart; when they all end within one sample of each other the timing loop is locked
-// and only candidates around their hull need tabulating.  Also clears the chunk's table row.
-struct GardnerBand { int j_lo, j_hi; };
+// of a symbol apart.  In lock they collapse onto a few tight clusters (trajectories that pick the
+// same samples receive the same corrections and merge exactly), and the true trajectory -- which has
+// been running far longer -- ends on or within a few grid points of one of them.  The chunk's
+// candidate list is the union of the neighbourhoods [m - pad, m + pad] of the scouts' end points m;
+// when the scouts end more than 1.5 samples apart (no timing lock) the full domain is tabulated.
+// Also clears the chunk's table row.
+struct GardnerBand { int j_lo, j_hi, listed; };   // candidates [j_lo, j_hi) of cand_k, or of the chunk's own list
+#define PDT_GTAB_LIST 2048                        // capacity of a chunk's candidate list
 
 __global__ void __launch_bounds__(64) k_gardner_scout(const float *__restrict__ in, GardnerParams<float> P, GardnerDomain D,
                                                        long long n_tab_chunks, const int *__restrict__ m_first,
-                                                       unsigned *__restrict__ table, GardnerBand *__restrict__ bands,
+                                                       const unsigned *__restrict__ cand_k, unsigned *__restrict__ table,
+                                                       GardnerBand *__restrict__ bands, unsigned *__restrict__ clist,
                                                        unsigned *__restrict__ stats /* [1] full-domain chunks [3] candidates */)
 {
     __shared__ float tail[PDT_GTAB_TAIL];
-    __shared__ int s_mmin, s_mmax;
+    __shared__ int s_sorted[64], s_lo[64], s_hi[64], s_off[65];
     const long long c = blockIdx.x;
     if (c >= n_tab_chunks) return;
     const long long C = P.chunk_out;
     const long long base = c * C;
     const int n_cur = (int)C;
     const int tail_n = (C < PDT_GTAB_TAIL) ? (int)C : PDT_GTAB_TAIL;
+    const int lane = threadIdx.x;
     unsigned *row = table + (size_t)c * (size_t)(2 * D.n_q);
-    for (int t = threadIdx.x; t < 2 * D.n_q; t += 64) row[t] = PDT_GTAB_MISS;
+    for (int t = lane; t < 2 * D.n_q; t += 64) row[t] = PDT_GTAB_MISS;
     GardnerBand bd;
     bd.j_lo = 0;
     bd.j_hi = (c == 0) ? 1 : D.n_cand;
+    bd.listed = 0;
     if (c >= 1) {
-        if (threadIdx.x == 0) { s_mmin = 0x7fffffff; s_mmax = -0x7fffffff; }
         const float hs = (float)((double)P.step / 2.0);
         const float kp = P.kp, lim = P.lim, step = P.step, nT = (float)n_cur;
-        for (int t = threadIdx.x; t < tail_n; t += 64 * 8) {
+        for (int t = lane; t < tail_n; t += 64 * 8) {
             float r[8];
 #pragma unroll
             for (int u = 0; u < 8; u++) r[u] = (t + u * 64 < tail_n) ? in[base - tail_n + t + u * 64] : 0.0f;
@@ -389,7 +406,7 @@ __global__ void __launch_bounds__(64) k_gardner_scout(const float *__restrict__ 
         }
         __syncthreads();
         const float t0 = (float)(n_cur - tail_n);
-        float ns = t0 + 8.0f + step * (float)threadIdx.x * (1.0f / 64.0f);
+        float ns = t0 + 8.0f + step * (float)lane * (1.0f / 64.0f);
         float prev = 0, half = ns - hs, q_last = ns;
         for (;;) {
             const float rn = __builtin_rintf(ns);
@@ -407,137 +424,208 @@ __global__ void __launch_bounds__(64) k_gardner_scout(const float *__restrict__ 
             prev = cur;
         }
         const int m = (int)floorf((q_last - D.q_min) / D.u);
-        atomicMin(&s_mmin, m);
-        atomicMax(&s_mmax, m);
+        // rank sort of the 64 end points
+        int rank = 0;
+        for (int j = 0; j < 64; j++) {
+            const int mj = __builtin_amdgcn_readlane(m, j);
+            rank += (mj < m || (mj == m && j < lane)) ? 1 : 0;
+        }
+        s_sorted[rank] = m;
         __syncthreads();
+        const int mine = s_sorted[lane];
+        const int before = (lane > 0) ? s_sorted[lane - 1] : mine;
+        const int m_min = s_sorted[0], m_max = s_sorted[63];
         const int one = (int)(1.0f / D.u);                        // grid points per sample
-        const int spread = s_mmax - s_mmin;
-        if (spread <= one && s_mmin >= 0 && s_mmax < D.n_q) {     // locked: candidates around the scouts' hull
-            int m_lo = s_mmin - D.pad_q, m_hi = s_mmax + D.pad_q;
+        const bool locked = (m_max - m_min) <= one + one / 2 && m_min >= 0 && m_max < D.n_q;
+        // a lane opens an interval when its neighbourhood does not touch the previous scout's
+        const bool opens = lane == 0 || (mine - before) > 2 * D.pad_q + 1;
+        const unsigned long long open_mask = __ballot(opens);
+        int cnt = 0;
+        if (opens) {
+            const unsigned long long above = (lane < 63) ? (open_mask >> (lane + 1)) : 0ull;
+            const int last = above ? (lane + __builtin_ctzll(above)) : 63;       // last scout of this interval
+            int m_lo = mine - D.pad_q, m_hi = s_sorted[last] + D.pad_q;
             m_lo = (m_lo < 0) ? 0 : m_lo;
             m_hi = (m_hi > D.n_q - 1) ? D.n_q - 1 : m_hi;
-            bd.j_lo = m_first[m_lo];
-            bd.j_hi = m_first[m_hi + 1];
-        } else if (threadIdx.x == 0) {
+            m_lo = (m_lo > D.n_q - 1) ? D.n_q - 1 : m_lo;
+            m_hi = (m_hi < m_lo) ? m_lo : m_hi;
+            s_lo[lane] = m_first[m_lo];
+            cnt = m_first[m_hi + 1] - s_lo[lane];
+        }
+        s_hi[lane] = cnt;
+        __syncthreads();
+        if (lane == 0) {
+            int acc = 0;
+            for (int j = 0; j < 64; j++) { s_off[j] = acc; acc += s_hi[j]; }
+            s_off[64] = acc;
+        }
+        __syncthreads();
+        const int total = s_off[64];
+        if (locked && total <= PDT_GTAB_LIST) {
+            unsigned *mylist = clist + (size_t)c * PDT_GTAB_LIST;
+            for (int j = 0; j < 64; j++) {
+                const int nj = s_hi[j];
+                if (nj == 0) continue;
+                const int jl = s_lo[j], off = s_off[j];
+                for (int t = lane; t < nj; t += 64) mylist[off + t] = cand_k[jl + t];
+            }
+            bd.j_lo = 0;
+            bd.j_hi = total;
+            bd.listed = 1;
+        } else if (lane == 0) {
             atomicAdd(&stats[1], 1u);
         }
     }
-    if (threadIdx.x == 0) {
+    if (lane == 0) {
         bands[c] = bd;
         atomicAdd(&stats[3], (unsigned)(bd.j_hi - bd.j_lo));
     }
 }
 
-// level 1: block (c, p) runs slice p (2 x 512 candidates) of chunk c's band, window by window.
-// Every lane carries two interleaved trajectories.  All lanes are within a symbol of each other,
-// so they cross the window seams together; inside a window every trajectory takes at least
-// k_min steps before it can reach the stop point (a step advances by at most step + 0.1), so the
-// bulk of the walk is a counted, wave-uniform loop without any per-lane test.
-__global__ void __launch_bounds__(PDT_GTAB_THREADS, 8) k_gardner_table(const float *__restrict__ in, GardnerParams<float> P,
-                                                                        GardnerDomain D, long long n_tab_chunks,
-                                                                        const unsigned *__restrict__ cand_k,
-                                                                        const GardnerBand *__restrict__ bands,
-                                                                        unsigned *__restrict__ table,
-                                                                        unsigned *__restrict__ stats /* [0] bad */)
+// level 1: block (c, p) runs slice p (2 x THREADS candidates) of chunk c's candidate list, window by
+// window (WIN floats of LDS at a time).  A lane carries NL = 1 or 2 interleaved trajectories (one when
+// the slice holds no more candidates than threads: half the instructions).  All lanes are within a
+// symbol of each other, so they cross the window seams together; inside a window every trajectory
+// takes at least k_min steps before it can reach the stop point (a step advances by at most
+// step + 0.1), so the bulk of the walk is a counted, wave-uniform loop without any per-lane test.
+template <int THREADS, int WIN, int NL>
+__device__ __forceinline__ void gardner_table_block(float *win, const float *__restrict__ in, const GardnerParams<float> &P,
+                                                    const GardnerDomain &D, long long c, const unsigned *__restrict__ cand,
+                                                    int j0, int j_hi, unsigned *__restrict__ row, unsigned *__restrict__ stats)
 {
-    __shared__ float win[PDT_GTAB_WIN];
-    const long long c = blockIdx.x;                 // chunk (always a full one)
-    if (c >= n_tab_chunks) return;
-    const GardnerBand bd = bands[c];
-    const int j0 = bd.j_lo + (int)blockIdx.y * 2 * PDT_GTAB_THREADS;
-    const int j_hi = bd.j_hi;
-    if (j0 >= j_hi) return;
     const long long C = P.chunk_out;
     const long long base = c * C;
     const int n_cur = (int)C;
-    unsigned *row = table + (size_t)c * (size_t)(2 * D.n_q);
     const float hs = (float)((double)P.step / 2.0);
     const float kp = P.kp, lim = P.lim, step = P.step, nT = (float)n_cur;
     const int margin = 2 * (int)step + 24;          // look-ahead the staged data must cover past a stop point
     const int back = (int)step + 8;                 // a mid-point lies at most this far behind a stop point
 
-    GardnerLane La, Lb;
-    La.ns = La.prev = La.half = La.q_last = 0; La.i_last = La.count = 0; La.k = 0;
-    Lb = La;
-    La.active = (j0 + (int)threadIdx.x) < j_hi;
-    Lb.active = (j0 + PDT_GTAB_THREADS + (int)threadIdx.x) < j_hi;
-    if (La.active && c >= 1) {
-        La.k = (int)cand_k[j0 + threadIdx.x];
-        gardner_entry_from_candidate(in, P, D, c, La.k, La.ns, La.prev, La.half);
+    GardnerLane L[NL];
+#pragma unroll
+    for (int l = 0; l < NL; l++) {
+        L[l].ns = L[l].prev = L[l].half = L[l].q_last = 0;
+        L[l].i_last = L[l].count = 0;
+        L[l].k = 0;
+        L[l].active = (j0 + l * THREADS + (int)threadIdx.x) < j_hi;
+        if (L[l].active && c >= 1) {
+            L[l].k = (int)cand[j0 + l * THREADS + threadIdx.x];
+            gardner_entry_from_candidate(in, P, D, c, L[l].k, L[l].ns, L[l].prev, L[l].half);
+        }
     }
-    if (Lb.active && c >= 1) {
-        Lb.k = (int)cand_k[j0 + PDT_GTAB_THREADS + threadIdx.x];
-        gardner_entry_from_candidate(in, P, D, c, Lb.k, Lb.ns, Lb.prev, Lb.half);
+    // idle slots shadow an active one of the block (their results are discarded) so that every lane
+    // stays inside the staged windows
+    {
+        __shared__ float s_ref[3];
+        if (threadIdx.x == 0) { s_ref[0] = L[0].ns; s_ref[1] = L[0].prev; s_ref[2] = L[0].half; }
+        __syncthreads();
+#pragma unroll
+        for (int l = 0; l < NL; l++)
+            if (!L[l].active) { L[l].ns = s_ref[0]; L[l].prev = s_ref[1]; L[l].half = s_ref[2]; }
     }
-    if (!Lb.active) Lb = La;                      // idle second slot: shadow the first (its result is discarded)
     int wbase = 0;
     float enter_hi = step + 1.2f;                 // upper bound of ns when entering the window
     for (;;) {
-        // stage [wbase, wbase + PDT_GTAB_WIN)
+        // stage [wbase, wbase + WIN)
         __syncthreads();
-        for (int t = threadIdx.x; t < PDT_GTAB_WIN; t += PDT_GTAB_THREADS) {
-            const int idx = wbase + t;
-            win[t] = (idx < n_cur) ? in[base + idx]
-                                   : ((idx < n_cur + margin) ? gardner_beyond(in, (const float *)nullptr, P, c, (long long)n_cur, (long long)idx) : 0.0f);
+        for (int t0 = 0; t0 < WIN; t0 += THREADS * 8) {
+            float r[8];
+#pragma unroll
+            for (int u = 0; u < 8; u++) {
+                const int t = t0 + u * THREADS + (int)threadIdx.x;
+                const int idx = wbase + t;
+                r[u] = (t < WIN && idx < n_cur) ? in[base + idx] : 0.0f;
+            }
+#pragma unroll
+            for (int u = 0; u < 8; u++) {
+                const int t = t0 + u * THREADS + (int)threadIdx.x;
+                const int idx = wbase + t;
+                if (t < WIN) {
+                    if (idx >= n_cur && idx < n_cur + margin)
+                        r[u] = gardner_beyond(in, (const float *)nullptr, P, c, (long long)n_cur, (long long)idx);
+                    win[t] = r[u];
+                }
+            }
         }
         __syncthreads();
-        const int wend = wbase + PDT_GTAB_WIN;
+        const int wend = wbase + WIN;
         const bool last_window = (wend - margin >= n_cur);
         const float stop = last_window ? nT : (float)(wend - margin);    // lanes leave the window at rint(ns) >= stop
         const float *wrel = win - wbase;          // indexed with chunk-relative indices
-        if (La.active) {
-            if (wbase == 0) {
-                // first symbol: the mid-point index is the stale one of the previous chunk (Q3)
+        if (wbase == 0) {
+            // first symbol: the mid-point index is the stale one of the previous chunk (Q3)
 #pragma unroll
-                for (int which = 0; which < 2; which++) {
-                    GardnerLane &L = which ? Lb : La;
-                    const float rn = __builtin_rintf(L.ns);
-                    if (rn < nT) {
-                        const unsigned i_cur = (unsigned)rn;
-                        const unsigned i_half = (unsigned)__builtin_rintf(L.half);
-                        const float cur = win[i_cur];
-                        float mid;
-                        if (i_half < (unsigned)PDT_GTAB_WIN) mid = win[i_half];
-                        else mid = (i_half < (unsigned)n_cur) ? in[base + i_half]
-                                                              : gardner_beyond(in, (const float *)nullptr, P, c, (long long)n_cur, (long long)i_half);
-                        const float err = __builtin_amdgcn_fmed3f(kp * (cur - L.prev) * mid, -lim, lim);
-                        L.ns = L.ns - err;
-                        L.q_last = L.ns;
-                        L.half = L.ns + hs;
-                        L.ns = L.ns + step;
-                        L.prev = cur;
-                        L.i_last = i_cur;
-                        L.count = 1;
-                    }
+            for (int l = 0; l < NL; l++) {
+                const float rn = __builtin_rintf(L[l].ns);
+                if (rn < nT) {
+                    const unsigned i_cur = (unsigned)rn;
+                    const unsigned i_half = (unsigned)__builtin_rintf(L[l].half);
+                    const float cur = win[i_cur];
+                    float mid;
+                    if (i_half < (unsigned)WIN) mid = win[i_half];
+                    else mid = (i_half < (unsigned)n_cur) ? in[base + i_half]
+                                                          : gardner_beyond(in, (const float *)nullptr, P, c, (long long)n_cur, (long long)i_half);
+                    const float err = __builtin_amdgcn_fmed3f(kp * (cur - L[l].prev) * mid, -lim, lim);
+                    L[l].ns = L[l].ns - err;
+                    L[l].q_last = L[l].ns;
+                    L[l].half = L[l].ns + hs;
+                    L[l].ns = L[l].ns + step;
+                    L[l].prev = cur;
+                    L[l].i_last = i_cur;
+                    L[l].count = 1;
                 }
             }
-            if (La.count >= 1 && Lb.count >= 1) {
-                int k_min = (int)((stop - 4.0f - enter_hi) / (step + 0.101f)) - 1;
-                if (k_min < 0) k_min = 0;
-                for (int it = 0; it < k_min; it++) {
-                    gardner_lane_step(La, wrel, kp, lim, hs, step);
-                    gardner_lane_step(Lb, wrel, kp, lim, hs, step);
-                }
-                La.count += (unsigned)k_min;
-                Lb.count += (unsigned)k_min;
-                gardner_lane_tail(La, wrel, stop, kp, lim, hs, step);
-                gardner_lane_tail(Lb, wrel, stop, kp, lim, hs, step);
+        }
+        bool all_started = true;
+#pragma unroll
+        for (int l = 0; l < NL; l++) all_started = all_started && (L[l].count >= 1);
+        if (all_started) {
+            int k_min = (int)((stop - 4.0f - enter_hi) / (step + 0.101f)) - 1;
+            if (k_min < 0) k_min = 0;
+            for (int it = 0; it < k_min; it++) {
+#pragma unroll
+                for (int l = 0; l < NL; l++) gardner_lane_step(L[l], wrel, kp, lim, hs, step);
+            }
+#pragma unroll
+            for (int l = 0; l < NL; l++) {
+                L[l].count += (unsigned)k_min;
+                gardner_lane_tail(L[l], wrel, stop, kp, lim, hs, step);
             }
         }
         if (last_window) break;
         enter_hi = stop + step + 1.2f;
         wbase = wend - margin - back;
     }
-    if (La.active) {
-        const unsigned cell = gardner_encode_exit(D, La.q_last, La.i_last, La.count);
-        if (cell == PDT_GTAB_MISS) atomicAdd(&stats[0], 1u);  // exit outside the enumerated domain (never expected)
-        row[La.k] = cell;
+#pragma unroll
+    for (int l = 0; l < NL; l++) {
+        if (L[l].active) {
+            const unsigned cell = gardner_encode_exit(D, L[l].q_last, L[l].i_last, L[l].count);
+            if (cell == PDT_GTAB_MISS) atomicAdd(&stats[0], 1u);  // exit outside the enumerated domain (never expected)
+            row[L[l].k] = cell;
+        }
     }
-    if (Lb.active) {
-        const unsigned cell = gardner_encode_exit(D, Lb.q_last, Lb.i_last, Lb.count);
-        if (cell == PDT_GTAB_MISS) atomicAdd(&stats[0], 1u);
-        row[Lb.k] = cell;
-    }
+}
+
+template <int THREADS, int WIN>
+__global__ void __launch_bounds__(THREADS) k_gardner_table(const float *__restrict__ in, GardnerParams<float> P,
+                                                            GardnerDomain D, long long n_tab_chunks,
+                                                            const unsigned *__restrict__ cand_k,
+                                                            const GardnerBand *__restrict__ bands,
+                                                            const unsigned *__restrict__ clist,
+                                                            unsigned *__restrict__ table,
+                                                            unsigned *__restrict__ stats /* [0] bad */)
+{
+    __shared__ float win[WIN];
+    const long long c = blockIdx.x;                 // chunk (always a full one)
+    if (c >= n_tab_chunks) return;
+    const GardnerBand bd = bands[c];
+    const int j0 = bd.j_lo + (int)blockIdx.y * 2 * THREADS;
+    const int j_hi = bd.j_hi;
+    if (j0 >= j_hi) return;
+    const unsigned *cand = bd.listed ? (clist + (size_t)blockIdx.x * PDT_GTAB_LIST) : cand_k;
+    unsigned *row = table + (size_t)c * (size_t)(2 * D.n_q);
+    if (j_hi - j0 <= THREADS) gardner_table_block<THREADS, WIN, 1>(win, in, P, D, c, cand, j0, j_hi, row, stats);
+    else gardner_table_block<THREADS, WIN, 2>(win, in, P, D, c, cand, j0, j_hi, row, stats);
 }
 
 // level 2: follow the chain  k_{c+1} = table_c[k_c]  (k_0 = 0).  A chain of n dependent HBM lookups

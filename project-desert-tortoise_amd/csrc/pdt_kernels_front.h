@@ -1102,7 +1102,7 @@ template <typename T>
 __global__ void __launch_bounds__(64) k_agc_block(const T *__restrict__ in, long long n, AgcParams<T> P,
                                                    const T *__restrict__ norm, long long B, long long W,
                                                    const double *__restrict__ guesses, const T *__restrict__ lock,
-                                                   T *__restrict__ out, AgcSeam<T> *__restrict__ seams)
+                                                   T *__restrict__ out, AgcSeam<T> *__restrict__ seams, double K)
 {
     const long long j = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     const long long start = j * B;
@@ -1116,7 +1116,6 @@ __global__ void __launch_bounds__(64) k_agc_block(const T *__restrict__ in, long
     T gain = *norm;
     if (j >= 1) {
         const double g_here = guesses[j];
-        const double K = (sizeof(T) == 4) ? 14.0 : 34.0;
         double need = K * g_here / (double)P.decay;
         if (need < 4096.0) need = 4096.0;
         if (need > (double)W) need = (double)W;
