@@ -85,7 +85,7 @@ struct pdt_ctx {
     hipEvent_t ev0 = nullptr, ev1 = nullptr, ev_fork = nullptr, ev_join = nullptr;
     hipStream_t stream2 = nullptr;     // side stream: block-parallel PLL phase runs beside the sequential acquisition
 
-    DevBuf pcm, pll, lock, fir, agc, sym, symidx, bits, bitsym, hits, frames, taps, mag, seams_pll, seams_agc, scal, lockinfo, term, seams_ema, gtable, gentries, gcand, gmfirst, stiles, gsegmap, gsegstart, gbands, gclist, agc_maps;
+    DevBuf pcm, pll, lock, fir, agc, sym, symidx, bits, bitsym, hits, frames, taps, mag, seams_pll, seams_agc, scal, lockinfo, term, seams_ema, gtable, gentries, gcand, gmfirst, stiles, gsegmap, gsegstart, gbands, gclist, agc_maps, pll_head;
     long long gcand_key = -1;          // (chunk_out, step) the candidate list on the device was built for
     bool force_sequential_gardner = false;
     int gardner_mode = 0;              // 0 sequential, 1 state table (last run)
@@ -392,19 +392,36 @@ template <typename T> int run_capture(pdt_ctx *ctx, uint64_t n)
     L.end();
     if (N > 0) {
         const long long grid = grid_pll;
+        // the sequential head (true state from the lock onwards, ~W samples) also runs beside k_pll_phase
+        // its length: until the true state has forgotten the acquisition (time constant of the critically
+        // damped tracking loop = 2 / alpha samples; 40 of them to agree in 24 bits, 90 in 53), at most the warm-up
+        const double tau_trk = 2.0 / (double)PP.alpha_trk;
+        const long long Hd = std::min<long long>(Wp, (long long)((sizeof(T) == 4 ? 40.0 : 90.0) * tau_trk));
+        const long long head_blocks = Hd / Bp + 3;
+        if ((rc = ctx->pll_head.ensure((size_t)(head_blocks * Bp + 64) * sizeof(T) + (size_t)head_blocks * sizeof(PllSeam<T>) +
+                                       sizeof(PllHeadInfo<T>) + 64)))
+            return rc;
+        PllHeadInfo<T> *d_hinfo = (PllHeadInfo<T> *)ctx->pll_head.p;
+        PllSeam<T> *d_hseams = (PllSeam<T> *)((unsigned char *)ctx->pll_head.p + 64);
+        T *d_hphi = (T *)((unsigned char *)d_hseams + (((size_t)head_blocks * sizeof(PllSeam<T>) + 63) & ~(size_t)63));
+        L.begin("pll_head");
+        if (slow_wrap)
+            hipLaunchKernelGGL((k_pll_head<T, true>), dim3(1), dim3(64), 0, st, d_theta, N, PP, d_info, Bp, Hd, d_hphi, d_hseams,
+                               d_hinfo, head_blocks);
+        else
+            hipLaunchKernelGGL((k_pll_head<T, false>), dim3(1), dim3(64), 0, st, d_theta, N, PP, d_info, Bp, Hd, d_hphi, d_hseams,
+                               d_hinfo, head_blocks);
+        L.end();
         HIP_TRY(hipStreamWaitEvent(st, ctx->ev_join, 0));                  // join
         L.begin("pll_fix");
-        if (slow_wrap) {
-            hipLaunchKernelGGL((k_pll_head<T, true>), dim3(1), dim3(64), 0, st, d_theta, N, PP, d_info, Bp, d_phi,
-                               (PllSeam<T> *)ctx->seams_pll.p);
+        if (slow_wrap)
             hipLaunchKernelGGL((k_pll_fix<T, true>), dim3(1), dim3(64), 0, st, d_theta, N, PP, d_info, Bp, d_phi,
-                               (PllSeam<T> *)ctx->seams_pll.p, d_sc->counters);
-        } else {
-            hipLaunchKernelGGL((k_pll_head<T, false>), dim3(1), dim3(64), 0, st, d_theta, N, PP, d_info, Bp, d_phi,
-                               (PllSeam<T> *)ctx->seams_pll.p);
+                               (PllSeam<T> *)ctx->seams_pll.p, (const T *)d_hphi, (const PllSeam<T> *)d_hseams,
+                               (const PllHeadInfo<T> *)d_hinfo, d_sc->counters);
+        else
             hipLaunchKernelGGL((k_pll_fix<T, false>), dim3(1), dim3(64), 0, st, d_theta, N, PP, d_info, Bp, d_phi,
-                               (PllSeam<T> *)ctx->seams_pll.p, d_sc->counters);
-        }
+                               (PllSeam<T> *)ctx->seams_pll.p, (const T *)d_hphi, (const PllSeam<T> *)d_hseams,
+                               (const PllHeadInfo<T> *)d_hinfo, d_sc->counters);
         L.end();
         (void)grid;
         L.begin("pll_mix");
@@ -819,7 +836,7 @@ void pdt_close(pdt_ctx *ctx)
     DevBuf *bufs[] = { &ctx->pcm, &ctx->pll, &ctx->lock, &ctx->fir, &ctx->agc, &ctx->sym, &ctx->symidx, &ctx->bits, &ctx->bitsym,
                        &ctx->hits, &ctx->frames, &ctx->taps, &ctx->mag, &ctx->seams_pll, &ctx->seams_agc, &ctx->scal, &ctx->lockinfo,
                        &ctx->term, &ctx->seams_ema, &ctx->gtable, &ctx->gentries, &ctx->gcand,
-                       &ctx->gmfirst, &ctx->stiles, &ctx->gsegmap, &ctx->gsegstart, &ctx->gbands, &ctx->gclist, &ctx->agc_maps };
+                       &ctx->gmfirst, &ctx->stiles, &ctx->gsegmap, &ctx->gsegstart, &ctx->gbands, &ctx->gclist, &ctx->agc_maps, &ctx->pll_head };
     for (DevBuf *b : bufs) b->release();
     if (ctx->ev0) (void)hipEventDestroy(ctx->ev0);
     if (ctx->ev1) (void)hipEventDestroy(ctx->ev1);

@@ -212,6 +212,19 @@ template <typename T> __device__ __forceinline__ T unwrap_2pi(T x)
     asm volatile("" : "+v"(r));          // keep it a value (select below), not a re-branched computation
     return r;
 }
+// float: (float)((double)x -+ 2pi) without leaving f32.  With hi = (float)(2pi) and
+// d = (float)(hi - 2pi) [hi lies above 2pi], x - hi is exact for pi <= |x| <= 4pi (Sterbenz) and
+// (x - hi) + d rounds to the same float as the double expression for EVERY float in that range
+// (all 17.2 M of them compared in tests/test_oracle_math.py::test_unwrap_f32_exhaustive); the
+// result is only used when |x| >= pi, and |x| < 13 always holds (|theta| <= pi, |phase| < 2pi + 2).
+template <> __device__ __forceinline__ float unwrap_2pi<float>(float x)
+{
+    const float hi = __builtin_copysignf(6.2831854820251465f, x);
+    const float d = __builtin_copysignf(1.7484555314695172e-07f, x);
+    float r = (x - hi) + d;
+    asm volatile("" : "+v"(r));
+    return r;
+}
 
 // one step of the loop filter given theta (:165-188), branch-free.
 // SLOW_WRAP keeps the reference's "while" wrap loops for loop gains so large that a single
@@ -398,7 +411,9 @@ template <typename T> struct PllSeam {
     T phase1, freq1;   // state after the block's last sample
 };
 
+#ifndef PDT_PF
 #define PDT_PF 8   // look-ahead depth (vectors per lane) of the lane-per-block stream walkers
+#endif
 
 template <typename T> struct alignas(16) Vec16 {
     static constexpr int N = 16 / sizeof(T);
@@ -407,7 +422,7 @@ template <typename T> struct alignas(16) Vec16 {
 
 // run the recurrence over [i0, i1), optionally storing the pre-update phase of every sample;
 // 16-byte vector loads/stores on the aligned body (each lane streams its own block)
-template <typename T, bool STORE, bool SLOW>
+template <typename T, bool STORE, bool SLOW, int PF = PDT_PF>
 __device__ __forceinline__ void pll_phase_range(const T *__restrict__ theta, T *__restrict__ phi, long long i0, long long i1,
                                                 T &phase, T &freq, T alpha, T beta, T maxf, T minf)
 {
@@ -417,29 +432,33 @@ __device__ __forceinline__ void pll_phase_range(const T *__restrict__ theta, T *
         if (STORE) phi[i] = phase;
         pll_phase_step<T, SLOW>(theta[i], phase, freq, alpha, beta, maxf, minf);
     }
-    // Software pipeline: PDT_PF vectors per lane are always in flight; each register set is
-    // re-loaded right after it has been consumed and is next needed PDT_PF-1 vectors later, so the
+    // (On gfx9 stores share the vmcnt counter with loads, so waiting for a look-ahead load also waits
+    // for every older store: the single-lane walkers of the head and the seam repairs use PF = 32 to
+    // give their stores ~2 us to retire.)
+    // Software pipeline: PF vectors per lane are always in flight; each register set is
+    // re-loaded right after it has been consumed and is next needed PF-1 vectors later, so the
     // recurrence never waits on memory.  (Look-ahead loads run past i1 by < 4 KiB: every stream
     // buffer is allocated with that much slack.  The opaque offset stops the compiler from
     // sinking the look-ahead load back to its use.)
-    if (i + PDT_PF * VN <= i1) {
-        Vec16<T> buf[PDT_PF];
+    if (i + PF * VN <= i1) {
+        Vec16<T> buf[PF];
 #pragma unroll
-        for (int u = 0; u < PDT_PF; u++) buf[u] = *reinterpret_cast<const Vec16<T> *>(theta + i + u * VN);
-        for (; i + PDT_PF * VN <= i1; i += PDT_PF * VN) {
+        for (int u = 0; u < PF; u++) buf[u] = *reinterpret_cast<const Vec16<T> *>(theta + i + u * VN);
+        for (; i + PF * VN <= i1; i += PF * VN) {
 #pragma unroll
-            for (int u = 0; u < PDT_PF; u++) {
-                const Vec16<T> tv = buf[u];
-                long long q = i + (PDT_PF + u) * VN;
-                asm volatile("" : "+v"(q));
-                buf[u] = *reinterpret_cast<const Vec16<T> *>(theta + q);
+            for (int u = 0; u < PF; u++) {
                 Vec16<T> pv;
 #pragma unroll
                 for (int w = 0; w < VN; w++) {
                     pv.v[w] = phase;
-                    pll_phase_step<T, SLOW>(tv.v[w], phase, freq, alpha, beta, maxf, minf);
+                    pll_phase_step<T, SLOW>(buf[u].v[w], phase, freq, alpha, beta, maxf, minf);
                 }
                 if (STORE) *reinterpret_cast<Vec16<T> *>(phi + i + u * VN) = pv;
+                // reload the slot only after its last use: the new value can then live in the same
+                // registers (a reload issued earlier is copied at the loop end, behind a full wait)
+                long long q = i + (PF + u) * VN;
+                asm volatile("" : "+v"(q));
+                buf[u] = *reinterpret_cast<const Vec16<T> *>(theta + q);
             }
         }
     }
@@ -579,28 +598,48 @@ __global__ void __launch_bounds__(64) k_pll_phase(IqSrc pcm, const T *__restrict
     seams[j] = sm;
 }
 
-// From the sample after the lock to the end of its block with the TRUE state (one lane); the
-// block's seam record then carries the true end state, the anchor of the validation chain.
+// The first samples after the lock cannot be block-parallel: the true state starts from the
+// acquisition's state and needs ~W samples to merge with anything a warm-up can reach.  One wavefront
+// walks them -- from the sample after the lock to the end of the first block that begins W samples
+// later -- with the TRUE state (one lane; a speculative straight-line variant that skipped the wrap
+// logic was measured slower than the plain select-based step).  It runs beside k_pll_phase (it depends only on the acquisition),
+// so it writes the phases and the per-block seam records to side buffers; k_pll_fix grafts them over
+// the block-parallel results before it validates the later seams.
+template <typename T> struct PllHeadInfo { long long s0, s1, j0, nblk; };
+
 template <typename T, bool SLOW>
 __global__ void __launch_bounds__(64) k_pll_head(const T *__restrict__ theta, long long n, PllParams<T> P,
-                                                  const PllLockInfo<T> *__restrict__ info, long long B, T *__restrict__ phi,
-                                                  PllSeam<T> *__restrict__ seams)
+                                                  const PllLockInfo<T> *__restrict__ info, long long B, long long W,
+                                                  T *__restrict__ phi_head, PllSeam<T> *__restrict__ seams_head,
+                                                  PllHeadInfo<T> *__restrict__ hinfo, long long max_blocks)
 {
-    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    if (blockIdx.x != 0 || threadIdx.x != 0) return;
     const long long lock_at = info->lock_sample;
-    if (lock_at < 0) return;
+    PllHeadInfo<T> hi;
+    hi.s0 = hi.s1 = 0; hi.j0 = 0; hi.nblk = 0;
     const long long S = lock_at + 1;
-    if (S >= n) return;
-    const long long j0 = S / B;
-    const long long end = ((j0 + 1) * B < n) ? (j0 + 1) * B : n;
-    T phase = info->st.phase, freq = info->st.freq;
-    pll_phase_range<T, true, SLOW>(theta, phi, S, end, phase, freq, P.alpha_trk, P.beta_trk, P.max_freq, P.min_freq);
-    PllSeam<T> sm;
-    sm.phase0 = info->st.phase;
-    sm.freq0 = info->st.freq;
-    sm.phase1 = phase;
-    sm.freq1 = freq;
-    seams[j0] = sm;
+    if (lock_at >= 0 && S < n) {
+        const long long j0 = S / B;
+        long long j1 = (S + W + B - 1) / B;                 // first block that starts >= W after the lock
+        if (j1 - j0 + 1 > max_blocks) j1 = j0 + max_blocks - 1;
+        T phase = info->st.phase, freq = info->st.freq;
+        long long pos = S, k = 0;
+        for (long long j = j0; j <= j1 && pos < n; j++, k++) {
+            const long long end = ((j + 1) * B < n) ? (j + 1) * B : n;
+            PllSeam<T> sm;
+            sm.phase0 = phase;
+            sm.freq0 = freq;
+            // phi_head is indexed from the 16-byte aligned sample at or below S (vector stores stay aligned)
+            pll_phase_range<T, true, SLOW, 32>(theta, phi_head - (S & ~3ll), pos, end, phase, freq, P.alpha_trk, P.beta_trk,
+                                               P.max_freq, P.min_freq);
+            sm.phase1 = phase;
+            sm.freq1 = freq;
+            seams_head[k] = sm;
+            pos = end;
+        }
+        hi.s0 = S; hi.s1 = pos; hi.j0 = j0; hi.nblk = k;
+    }
+    *hinfo = hi;
 }
 
 template <typename T> __device__ __forceinline__ bool bits_equal(T x, T y);
@@ -621,7 +660,9 @@ template <> __device__ __forceinline__ bool bits_equal<double>(double x, double 
 template <typename T, bool SLOW>
 __global__ void __launch_bounds__(64) k_pll_fix(const T *__restrict__ theta, long long n, PllParams<T> P,
                                                  const PllLockInfo<T> *__restrict__ info, long long B, T *__restrict__ phi,
-                                                 PllSeam<T> *__restrict__ seams,
+                                                 PllSeam<T> *__restrict__ seams, const T *__restrict__ phi_head,
+                                                 const PllSeam<T> *__restrict__ seams_head,
+                                                 const PllHeadInfo<T> *__restrict__ hinfo,
                                                  unsigned *__restrict__ counters /* [0]=blocks [1]=fixes */)
 {
     const long long lock_at = info->lock_sample;
@@ -630,10 +671,17 @@ __global__ void __launch_bounds__(64) k_pll_fix(const T *__restrict__ theta, lon
         return;
     }
     const long long S = lock_at + 1;
-    const long long j0 = S / B;                                     // block that contains the lock (anchored by k_pll_head)
+    const PllHeadInfo<T> hi = *hinfo;
+    const long long j0 = hi.j0;                                     // block that contains the lock
     const long long nb_abs = (n + B - 1) / B;                       // absolute block count
+    // graft the head's true phases and seam records over the block-parallel ones
+    for (long long i = hi.s0 + threadIdx.x; i < hi.s1; i += 64) phi[i] = phi_head[i - (hi.s0 & ~3ll)];
+    for (long long k = threadIdx.x; k < hi.nblk; k += 64) seams[j0 + k] = seams_head[k];
+    __threadfence_block();
+    __syncthreads();
     unsigned fixes = 0;
-    long long r = j0 + 1;
+    long long r = j0 + hi.nblk;                                     // first seam that needs checking
+    if (hi.nblk == 0) r = nb_abs;
     while (r < nb_abs) {
         const long long mine = r + threadIdx.x;
         bool bad = false;
@@ -651,7 +699,7 @@ __global__ void __launch_bounds__(64) k_pll_fix(const T *__restrict__ theta, lon
         const long long start = rb * B;
         const long long end = ((rb + 1) * B < n) ? (rb + 1) * B : n;
         if (threadIdx.x == 0) {
-            pll_phase_range<T, true, SLOW>(theta, phi, start, end, phase, freq, P.alpha_trk, P.beta_trk, P.max_freq, P.min_freq);
+            pll_phase_range<T, true, SLOW, 32>(theta, phi, start, end, phase, freq, P.alpha_trk, P.beta_trk, P.max_freq, P.min_freq);
             PllSeam<T> upd;
             upd.phase0 = prev.phase1;
             upd.freq0 = prev.freq1;
@@ -938,13 +986,9 @@ __device__ __forceinline__ void agc_range(const T *__restrict__ in, const T *__r
         for (; i + PDT_PF * VN <= i1; i += PDT_PF * VN) {
 #pragma unroll
             for (int u = 0; u < PDT_PF; u++) {
-                const Vec16<T> xv = buf[u];
-                long long q = i + (PDT_PF + u) * VN;
-                asm volatile("" : "+v"(q));
-                buf[u] = *reinterpret_cast<const Vec16<T> *>(in + q);
                 Vec16<T> yv;
 #pragma unroll
-                for (int w = 0; w < VN; w++) yv.v[w] = agc_step(xv.v[w], gain, P);
+                for (int w = 0; w < VN; w++) yv.v[w] = agc_step(buf[u].v[w], gain, P);
                 if (STORE) {
                     if (P.squelch) {
                         const Vec16<T> lv = *reinterpret_cast<const Vec16<T> *>(lock + i + u * VN);
@@ -954,6 +998,9 @@ __device__ __forceinline__ void agc_range(const T *__restrict__ in, const T *__r
                     }
                     *reinterpret_cast<Vec16<T> *>(out + i + u * VN) = yv;
                 }
+                long long q = i + (PDT_PF + u) * VN;      // reload after the last use (see pll_phase_range)
+                asm volatile("" : "+v"(q));
+                buf[u] = *reinterpret_cast<const Vec16<T> *>(in + q);
             }
         }
     }

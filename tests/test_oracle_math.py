@@ -53,3 +53,26 @@ def test_q_rsqrt_and_arctan2_known_values(orc):
     assert abs(L.orc_arctan2_f32(1.0, -1.0) - 3 * np.pi / 4) < 1e-6
     assert L.orc_arctan2_f32(-1.0, 1.0) == -L.orc_arctan2_f32(1.0, 1.0)
     assert abs(L.orc_arctan2_f32(0.0, 1.0)) < 1e-6
+
+
+def test_unwrap_f32_exhaustive():
+    """The HIP PLL kernels evaluate the reference's (float)((double)x -+ 2*M_PI) wrap
+    (CarrierTrackingPLL.c:169-172,183-186) in f32 as (x - hi) + d, hi = (float)(2pi), d = (float)(hi - 2pi).
+    Compare the two forms for every float with pi <= |x| <= 13 (the PLL never wraps a larger value)."""
+    two_pi = 2.0 * np.pi
+    hi = np.float32(two_pi)
+    d = np.float32(np.float64(hi) - two_pi)
+    assert float(hi) == 6.2831854820251465 and float(d) == 1.7484555314695172e-07
+    lo_u = int(np.float32(np.pi).view(np.uint32))
+    hi_u = int(np.float32(13.0).view(np.uint32))
+    step = 1 << 22
+    for u0 in range(lo_u, hi_u + 1, step):
+        x = np.arange(u0, min(u0 + step, hi_u + 1), dtype=np.uint32).view(np.float32)
+        ref = (x.astype(np.float64) - two_pi).astype(np.float32)
+        emu = (x - hi) + d
+        assert emu.dtype == np.float32
+        assert np.array_equal(ref.view(np.uint32), emu.view(np.uint32))
+        xn = -x
+        refn = (xn.astype(np.float64) + two_pi).astype(np.float32)
+        emun = (xn + hi) - d
+        assert np.array_equal(refn.view(np.uint32), emun.view(np.uint32))
