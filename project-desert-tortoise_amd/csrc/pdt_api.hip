@@ -85,7 +85,7 @@ struct pdt_ctx {
     hipEvent_t ev0 = nullptr, ev1 = nullptr, ev_fork = nullptr, ev_join = nullptr;
     hipStream_t stream2 = nullptr;     // side stream: block-parallel PLL phase runs beside the sequential acquisition
 
-    DevBuf pcm, pll, lock, fir, agc, sym, symidx, bits, bitsym, hits, frames, taps, mag, seams_pll, seams_agc, scal, lockinfo, term, seams_ema, gtable, gentries, gcand, gmfirst, stiles, gsegmap, gsegstart, gbands, gclist, agc_maps, pll_head;
+    DevBuf pcm, pll, lock, fir, agc, sym, symidx, bits, bitsym, hits, frames, taps, mag, seams_pll, seams_agc, scal, lockinfo, term, seams_ema, gtable, gentries, gcand, gmfirst, stiles, gsegmap, gsegstart, gbands, gclist, agc_maps, pll_head, taps_rot;
     long long gcand_key = -1;          // (chunk_out, step) the candidate list on the device was built for
     bool force_sequential_gardner = false;
     int gardner_mode = 0;              // 0 sequential, 1 state table (last run)
@@ -454,9 +454,27 @@ template <typename T> int run_capture(pdt_ctx *ctx, uint64_t n)
                                d_fir, opt);
         } else {
             const int K = ntaps / interp;
-            const size_t sh = (size_t)(ntaps + tile / interp + K + 8) * sizeof(T);
-            hipLaunchKernelGGL(k_fir_interp<T>, dim3((unsigned)grid), dim3(PDT_FIR_THREADS), sh, st, d_pll, N, interp, K,
-                               d_taps, d_fir, opt);
+            const int rs = (interp == 3) ? 4 : interp;
+            const size_t sh_rt = (size_t)(65 * (K + 1) + 3 + K * K * rs + 64 * K * interp) * sizeof(T);
+            const unsigned grid_rt = (unsigned)((N + 64ll * K - 1) / (64ll * K));
+            bool done = false;
+            if (K == 26 && sh_rt <= 64000 && ctx->taps_rot.p && !getenv("PDT_FIR_GENERIC")) {
+                done = true;
+                switch (interp) {
+#define PDT_FIR_CASE(I)                                                                                                       \
+    case I:                                                                                                                   \
+        hipLaunchKernelGGL((k_fir_interp_rt<T, I, 26>), dim3(grid_rt), dim3(PDT_FIR_THREADS), sh_rt, st, d_pll, N, (const T *)ctx->taps_rot.p, d_fir); \
+        break;
+                    PDT_FIR_CASE(1) PDT_FIR_CASE(2) PDT_FIR_CASE(3) PDT_FIR_CASE(4) PDT_FIR_CASE(5) PDT_FIR_CASE(6)
+#undef PDT_FIR_CASE
+                default: done = false;
+                }
+            }
+            if (!done) {                                       // any other interpolation factor: generic form
+                const size_t sh = (size_t)(ntaps + tile / interp + K + 8) * sizeof(T);
+                hipLaunchKernelGGL(k_fir_interp<T>, dim3((unsigned)grid), dim3(PDT_FIR_THREADS), sh, st, d_pll, N, interp, K,
+                                   d_taps, d_fir, opt);
+            }
         }
         L.end();
     }
@@ -814,6 +832,20 @@ int pdt_open(const pdt_config *cfg, pdt_ctx **out)
         delete ctx;
         return PDT_ERR_NOGPU;
     }
+    if (cfg->mode == PDT_MODE_POES && nt == 26 * ip) {
+        // tap table of the register-tiled FIR, rotated per ring residue: rot[c][t][r] = h[N-1-r-((c-t) mod K)*interp]
+        const int K = 26, rs = (ip == 3) ? 4 : ip;
+        std::vector<float> rot((size_t)K * K * rs, 0.0f);
+        const float *h = (const float *)ctx->taps_host.data();
+        for (int c = 0; c < K; c++)
+            for (int t = 0; t < K; t++)
+                for (int r = 0; r < ip; r++) rot[((size_t)c * K + t) * rs + r] = h[nt - 1 - r - ((c - t + K) % K) * ip];
+        if ((rc = ctx->taps_rot.ensure(rot.size() * sizeof(float)))) { delete ctx; return rc; }
+        if (hipMemcpy(ctx->taps_rot.p, rot.data(), rot.size() * sizeof(float), hipMemcpyHostToDevice) != hipSuccess) {
+            delete ctx;
+            return PDT_ERR_NOGPU;
+        }
+    }
     if (hipStreamCreate(&ctx->stream) != hipSuccess) { delete ctx; return PDT_ERR_NOGPU; }
     ctx->own_stream = true;
     (void)hipEventCreate(&ctx->ev0);
@@ -836,7 +868,7 @@ void pdt_close(pdt_ctx *ctx)
     DevBuf *bufs[] = { &ctx->pcm, &ctx->pll, &ctx->lock, &ctx->fir, &ctx->agc, &ctx->sym, &ctx->symidx, &ctx->bits, &ctx->bitsym,
                        &ctx->hits, &ctx->frames, &ctx->taps, &ctx->mag, &ctx->seams_pll, &ctx->seams_agc, &ctx->scal, &ctx->lockinfo,
                        &ctx->term, &ctx->seams_ema, &ctx->gtable, &ctx->gentries, &ctx->gcand,
-                       &ctx->gmfirst, &ctx->stiles, &ctx->gsegmap, &ctx->gsegstart, &ctx->gbands, &ctx->gclist, &ctx->agc_maps, &ctx->pll_head };
+                       &ctx->gmfirst, &ctx->stiles, &ctx->gsegmap, &ctx->gsegstart, &ctx->gbands, &ctx->gclist, &ctx->agc_maps, &ctx->pll_head, &ctx->taps_rot };
     for (DevBuf *b : bufs) b->release();
     if (ctx->ev0) (void)hipEventDestroy(ctx->ev0);
     if (ctx->ev1) (void)hipEventDestroy(ctx->ev1);
