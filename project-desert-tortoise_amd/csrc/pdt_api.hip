@@ -218,7 +218,7 @@ void launch_bytesync(pdt_ctx *ctx, hipStream_t st, const SyncParams &SP, DevScal
     SyncTile *d_stiles = (SyncTile *)ctx->stiles.p;
     hipLaunchKernelGGL(k_sync_hits_tile, dim3((unsigned)n_stiles), dim3(256), 0, st, d_bits, &d_sc->nbits, SP, d_stiles,
                        &d_sc->sync_overflow);
-    hipLaunchKernelGGL(k_sync_frames_tiles, dim3(1), dim3(256), 0, st, (const SyncTile *)d_stiles, &d_sc->nbits, SP, d_hits, hit_cap,
+    hipLaunchKernelGGL(k_sync_frames_tiles, dim3(1), dim3(PDT_SYNC_THREADS), 0, st, (const SyncTile *)d_stiles, &d_sc->nbits, SP, d_hits, hit_cap,
                        d_frames, &d_sc->nframes, frame_cap, &d_sc->sync_overflow);
     // generic path (atomic append + sort), only when a tile overflowed
     const long long grid = (bit_cap + 255) / 256;
@@ -606,7 +606,7 @@ template <typename T> int run_capture(pdt_ctx *ctx, uint64_t n)
     L.begin("manchester");
     hipLaunchKernelGGL(k_manch_tile<T>, dim3((unsigned)n_tiles), dim3(PDT_TILE_THREADS), 0, st, d_sym, &d_sc->nsym, manch_thr,
                        d_tiles);
-    hipLaunchKernelGGL(k_manch_scan, dim3(1), dim3(64), 0, st, d_tiles, &d_sc->nsym, &d_sc->nbits);
+    hipLaunchKernelGGL(k_manch_scan, dim3(1), dim3(1024), 0, st, d_tiles, &d_sc->nsym, &d_sc->nbits);
     hipLaunchKernelGGL(k_manch_emit<T>, dim3((unsigned)n_tiles), dim3(PDT_TILE_THREADS), 0, st, d_sym, &d_sc->nsym, manch_thr,
                        d_tiles, d_bits, d_bitsym, bit_cap);
     L.end();

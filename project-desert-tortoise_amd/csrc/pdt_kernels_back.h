@@ -872,37 +872,73 @@ __global__ void __launch_bounds__(PDT_TILE_THREADS) k_manch_tile(const T *__rest
 
 // pass over the tile summaries: one wavefront, 64 tiles per round trip; the (clockmod, output
 // offset) chain itself is evaluated redundantly by all lanes from shuffled values
-__global__ void __launch_bounds__(64) k_manch_scan(ManchTile *__restrict__ tiles, const unsigned long long *__restrict__ nsym_p,
-                                                    unsigned long long *__restrict__ nbits_out)
+// A tile acts on the running (clockmod, bit count) as a function of the incoming clockmod c in {0,1}:
+// clockmod' = o[c], count += a[c].  Such maps compose associatively, so the tile chain is a block-wide
+// scan (1024 tiles per round, Hillis-Steele in LDS) instead of a walk.
+struct ManchMap { unsigned o0, o1; unsigned long long a0, a1; };
+__device__ __forceinline__ ManchMap manch_compose(const ManchMap &f, const ManchMap &g)   // f first, then g
 {
+    ManchMap r;
+    r.o0 = f.o0 ? g.o1 : g.o0;
+    r.o1 = f.o1 ? g.o1 : g.o0;
+    r.a0 = f.a0 + (f.o0 ? g.a1 : g.a0);
+    r.a1 = f.a1 + (f.o1 ? g.a1 : g.a0);
+    return r;
+}
+
+__global__ void __launch_bounds__(1024) k_manch_scan(ManchTile *__restrict__ tiles, const unsigned long long *__restrict__ nsym_p,
+                                                      unsigned long long *__restrict__ nbits_out)
+{
+    __shared__ ManchMap s_map[1024];
+    __shared__ unsigned s_clock;
+    __shared__ unsigned long long s_base;
     const long long nsym = (long long)*nsym_p;
     const long long nt = (nsym + PDT_TILE - 1) / PDT_TILE;
-    unsigned clock = 0;
-    unsigned long long base = 0;
-    for (long long t0 = 0; t0 < nt; t0 += 64) {
+    if (threadIdx.x == 0) { s_clock = 0; s_base = 0; }
+    __syncthreads();
+    for (long long t0 = 0; t0 < nt; t0 += 1024) {
         const long long mine = t0 + threadIdx.x;
-        ManchTile mt;
-        mt.last_r_parity = -1; mt.first_r = PDT_TILE; mt.cnt_before[0] = mt.cnt_before[1] = 0; mt.cnt_after = 0;
-        mt.clock_in = 0; mt.out_base = 0;
-        if (mine < nt) mt = tiles[mine];
-        unsigned my_clock = 0;
-        unsigned long long my_base = 0;
-        const int lim = (nt - t0 < 64) ? (int)(nt - t0) : 64;
-        for (int t = 0; t < lim; t++) {
-            const unsigned cb0 = (unsigned)__shfl((int)mt.cnt_before[0], t);
-            const unsigned cb1 = (unsigned)__shfl((int)mt.cnt_before[1], t);
-            const unsigned ca = (unsigned)__shfl((int)mt.cnt_after, t);
-            const int lp = __shfl(mt.last_r_parity, t);
-            if ((int)threadIdx.x == t) { my_clock = clock; my_base = base; }
-            base += (clock ? cb1 : cb0) + ca;
-            if (lp >= 0) clock = (unsigned)lp;
+        ManchMap m;
+        m.o0 = 0; m.o1 = 1; m.a0 = 0; m.a1 = 0;                       // identity for the padding lanes
+        if (mine < nt) {
+            const ManchTile mt = tiles[mine];
+            m.a0 = (unsigned long long)mt.cnt_before[0] + mt.cnt_after;
+            m.a1 = (unsigned long long)mt.cnt_before[1] + mt.cnt_after;
+            if (mt.last_r_parity >= 0) m.o0 = m.o1 = (unsigned)mt.last_r_parity;
+        }
+        s_map[threadIdx.x] = m;
+        __syncthreads();
+        for (int d = 1; d < 1024; d <<= 1) {                          // inclusive scan
+            ManchMap left;
+            const bool has = (int)threadIdx.x >= d;
+            if (has) left = s_map[threadIdx.x - d];
+            __syncthreads();
+            if (has) s_map[threadIdx.x] = manch_compose(left, s_map[threadIdx.x]);
+            __syncthreads();
+        }
+        const unsigned clock0 = s_clock;
+        const unsigned long long base0 = s_base;
+        // state entering my tile = carry applied through the maps of the tiles before it
+        unsigned my_clock = clock0;
+        unsigned long long my_base = base0;
+        if (threadIdx.x > 0) {
+            const ManchMap p = s_map[threadIdx.x - 1];
+            my_clock = clock0 ? p.o1 : p.o0;
+            my_base = base0 + (clock0 ? p.a1 : p.a0);
         }
         if (mine < nt) {
             tiles[mine].clock_in = my_clock;
             tiles[mine].out_base = my_base;
         }
+        const ManchMap all = s_map[1023];
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            s_clock = clock0 ? all.o1 : all.o0;
+            s_base = base0 + (clock0 ? all.a1 : all.a0);
+        }
+        __syncthreads();
     }
-    if (threadIdx.x == 0) *nbits_out = base;
+    if (threadIdx.x == 0) *nbits_out = s_base;
 }
 
 template <typename T>
@@ -1143,12 +1179,30 @@ __global__ void __launch_bounds__(256) k_sync_frames(unsigned *__restrict__ hits
     }
 }
 
-// frame filter over the ordered tiles.  One workgroup: (A) the tile hit lists are compacted, in
-// order, into one dense list (block-wide scan of the tile counts); (B) the dense list is staged
-// through LDS in batches and one lane applies the "not inside a frame" rule with the loads off
-// its dependent chain (8 hits per wide LDS read).
+// frame filter over the ordered tiles.  One workgroup of 1024:
+//  (A) the tile hit lists are compacted, in order, into one dense list (block-wide scan of the counts);
+//  (B) the "a hit inside an open frame is ignored" rule is a walk along successor links --
+//      succ(a) = first hit at least `span` bits after hit a -- starting at hit 0.  With up to 8192
+//      hits the links are found by binary search in LDS and the set reachable from hit 0 by pointer
+//      doubling (marks spread through J = succ^(2^k) while J is squared), ~13 rounds instead of a
+//      serial pass over every hit; longer lists go through the serial pass in LDS batches.
+//  (C) the surviving hits are compacted, in order, into the frame records.
 #define PDT_SYNC_BATCH 8192
-__global__ void __launch_bounds__(256) k_sync_frames_tiles(const SyncTile *__restrict__ tiles,
+#define PDT_SYNC_THREADS 1024
+__device__ __forceinline__ unsigned sync_block_scan(unsigned v, unsigned *s_scan)   // inclusive, 1024 threads
+{
+    s_scan[threadIdx.x] = v;
+    __syncthreads();
+    for (int d = 1; d < PDT_SYNC_THREADS; d <<= 1) {
+        const unsigned add = ((int)threadIdx.x >= d) ? s_scan[threadIdx.x - d] : 0u;
+        __syncthreads();
+        s_scan[threadIdx.x] += add;
+        __syncthreads();
+    }
+    return s_scan[threadIdx.x];
+}
+
+__global__ void __launch_bounds__(PDT_SYNC_THREADS) k_sync_frames_tiles(const SyncTile *__restrict__ tiles,
                                                             const unsigned long long *__restrict__ nbits_p, SyncParams P,
                                                             unsigned *__restrict__ dense, unsigned dense_cap,
                                                             FrameRec *__restrict__ frames, unsigned *__restrict__ nframes,
@@ -1157,42 +1211,105 @@ __global__ void __launch_bounds__(256) k_sync_frames_tiles(const SyncTile *__res
     if (*overflow) return;                       // the generic path handles this capture
     const long long nbits = (long long)*nbits_p;
     const long long nt = (nbits + 4095) / 4096;
-    __shared__ unsigned s_scan[256];
+    __shared__ unsigned s_scan[PDT_SYNC_THREADS];
     __shared__ unsigned s_base;
-    __shared__ unsigned s_hits[PDT_SYNC_BATCH];
+    __shared__ unsigned s_hits[PDT_SYNC_BATCH];            // positions, later the two link tables (2 x u16)
+    __shared__ unsigned s_mark[PDT_SYNC_BATCH / 32];
     if (threadIdx.x == 0) s_base = 0;
     __syncthreads();
     // ---- (A) ordered compaction
-    for (long long t0 = 0; t0 < nt; t0 += 256) {
+    for (long long t0 = 0; t0 < nt; t0 += PDT_SYNC_THREADS) {
         const long long mine = t0 + threadIdx.x;
         const unsigned cnt = (mine < nt) ? tiles[mine].count : 0u;
-        s_scan[threadIdx.x] = cnt;
-        __syncthreads();
-        if (threadIdx.x == 0) {
-            unsigned run = s_base;
-            for (int t = 0; t < 256; t++) {
-                const unsigned v = s_scan[t];
-                s_scan[t] = run;
-                run += v;
-            }
-            s_base = run;
-        }
-        __syncthreads();
-        const unsigned off = s_scan[threadIdx.x];
+        const unsigned incl = sync_block_scan(cnt, s_scan);
+        const unsigned base = s_base;
+        const unsigned off = base + incl - cnt;
+        const unsigned total = s_scan[PDT_SYNC_THREADS - 1];
         for (unsigned q = 0; q < cnt; q++)
             if (off + q < dense_cap) dense[off + q] = tiles[mine].hits[q];
+        __syncthreads();
+        if (threadIdx.x == 0) s_base = base + total;
         __syncthreads();
     }
     __threadfence_block();
     __syncthreads();
     const unsigned nh = (s_base < dense_cap) ? s_base : dense_cap;
-    // ---- (B) sequential filter over the dense, sorted list
+    if (nh <= PDT_SYNC_BATCH - 2) {                    // both link tables (nh + 1 u16 entries each) fit the staging array
+        // ---- (B) parallel: successor links, then pointer doubling from hit 0
+        constexpr int PER = PDT_SYNC_BATCH / PDT_SYNC_THREADS;       // 8 hits per thread
+        for (unsigned i = threadIdx.x; i < nh; i += PDT_SYNC_THREADS) s_hits[i] = dense[i] >> 1;
+        for (unsigned i = threadIdx.x; i < PDT_SYNC_BATCH / 32; i += PDT_SYNC_THREADS) s_mark[i] = (i == 0 && nh > 0) ? 1u : 0u;
+        __syncthreads();
+        unsigned succ[PER];
+#pragma unroll
+        for (int k = 0; k < PER; k++) {
+            const unsigned i = threadIdx.x + (unsigned)k * PDT_SYNC_THREADS;
+            succ[k] = nh;
+            if (i < nh) {
+                const unsigned want = s_hits[i] + P.span;
+                unsigned lo = i + 1, hi = nh;                          // first index in (i, nh) with pos >= want
+                while (lo < hi) {
+                    const unsigned mid = (lo + hi) >> 1;
+                    if (s_hits[mid] >= want) hi = mid; else lo = mid + 1;
+                }
+                succ[k] = lo;
+            }
+        }
+        __syncthreads();
+        unsigned short *J0 = reinterpret_cast<unsigned short *>(s_hits);
+        unsigned short *J1 = J0 + PDT_SYNC_BATCH;
+#pragma unroll
+        for (int k = 0; k < PER; k++) {
+            const unsigned i = threadIdx.x + (unsigned)k * PDT_SYNC_THREADS;
+            if (i < nh) J0[i] = (unsigned short)succ[k];
+        }
+        if (threadIdx.x == 0) J0[nh] = (unsigned short)nh;              // the end is its own successor
+        __syncthreads();
+        unsigned short *Jc = J0, *Jn = J1;
+        for (unsigned reach = 1; reach < nh; reach <<= 1) {
+#pragma unroll
+            for (int k = 0; k < PER; k++) {
+                const unsigned i = threadIdx.x + (unsigned)k * PDT_SYNC_THREADS;
+                if (i <= nh) {
+                    const unsigned jm = Jc[i];
+                    if (i < nh && jm < nh && ((s_mark[i >> 5] >> (i & 31)) & 1u)) atomicOr(&s_mark[jm >> 5], 1u << (jm & 31));
+                    Jn[i] = Jc[jm];
+                }
+            }
+            __syncthreads();
+            unsigned short *tmp = Jc; Jc = Jn; Jn = tmp;
+        }
+        // ---- (C) ordered compaction of the marked hits (thread t owns hits [8t, 8t+8))
+        const unsigned i0 = threadIdx.x * PER;
+        unsigned mine = 0;
+#pragma unroll
+        for (int k = 0; k < PER; k++) {
+            const unsigned i = i0 + k;
+            mine += (i < nh && ((s_mark[i >> 5] >> (i & 31)) & 1u)) ? 1u : 0u;
+        }
+        const unsigned incl = sync_block_scan(mine, s_scan);
+        unsigned at = incl - mine;
+        for (int k = 0; k < PER; k++) {
+            const unsigned i = i0 + k;
+            if (i < nh && ((s_mark[i >> 5] >> (i & 31)) & 1u)) {
+                if (at < frame_cap) {
+                    const unsigned v = dense[i];
+                    frames[at].bit_index = (long long)(v >> 1);
+                    frames[at].inverted = (unsigned char)(v & 1u);
+                }
+                at++;
+            }
+        }
+        if (threadIdx.x == PDT_SYNC_THREADS - 1) *nframes = incl;
+        return;
+    }
+    // ---- (B') serial filter over the dense, sorted list, staged through LDS
     unsigned nf = 0;
     unsigned next_free = 0;                            // bit indices are < 2^31
     for (unsigned b0 = 0; b0 < nh; b0 += PDT_SYNC_BATCH) {
         const unsigned cnt = (nh - b0 < PDT_SYNC_BATCH) ? nh - b0 : PDT_SYNC_BATCH;
         __syncthreads();
-        for (unsigned t = threadIdx.x; t < ((cnt + 7u) & ~7u); t += 256) s_hits[t] = (t < cnt) ? dense[b0 + t] : 0xffffffffu;
+        for (unsigned t = threadIdx.x; t < ((cnt + 7u) & ~7u); t += PDT_SYNC_THREADS) s_hits[t] = (t < cnt) ? dense[b0 + t] : 0xffffffffu;
         __syncthreads();
         if (threadIdx.x == 0) {
             // accepted hits are written back in place (LDS), the records go out afterwards in parallel
@@ -1215,7 +1332,7 @@ __global__ void __launch_bounds__(256) k_sync_frames_tiles(const SyncTile *__res
         }
         __syncthreads();
         const unsigned na = s_scan[0];
-        for (unsigned t = threadIdx.x; t < na; t += 256) {
+        for (unsigned t = threadIdx.x; t < na; t += PDT_SYNC_THREADS) {
             if (nf + t < frame_cap) {
                 frames[nf + t].bit_index = (long long)(s_hits[t] >> 1);
                 frames[nf + t].inverted = (unsigned char)(s_hits[t] & 1u);

@@ -978,10 +978,47 @@ __global__ void __launch_bounds__(256) k_static_gain(IqSrc pcm, long long n0, T 
         if (threadIdx.x == 0) *norm_out = (T)override_norm;
         return;
     }
-    // magnitudes of the first chunk, in parallel; the chain then streams them from LDS in
-    // batches of 8 (one wide LDS read per 16 dependent operations)
+    // Fast path.  avg <- (avg + m)/2 forgets its past within a few dozen steps, and the step is a
+    // monotone map of avg (rounding is monotone), while avg always lies in [0, max m].  So two chains
+    // over the last TAIL magnitudes, started from 0 and from the chunk's largest magnitude, bracket
+    // the true chain; when they end on the same float -- they always do -- that float IS the
+    // reference's result, whatever came before.  Otherwise the full chain below runs.
+    constexpr int TAIL = 192;
     constexpr int CAP = 16384;
     __shared__ T s_mag[CAP];
+    __shared__ T s_red[256];
+    if (n0 > TAIL) {
+        T mx = 0;
+        for (long long i = threadIdx.x; i < n0; i += blockDim.x) {
+            T a, b;
+            IqSample<T>::get(pcm, i, a, b);
+            const T m = Real<T>::hypot(a, b);
+            mx = (m > mx) ? m : mx;
+            if (i >= n0 - TAIL) s_mag[i - (n0 - TAIL)] = m;
+        }
+        s_red[threadIdx.x] = mx;
+        __syncthreads();
+        for (int w = 128; w >= 1; w >>= 1) {
+            if ((int)threadIdx.x < w) s_red[threadIdx.x] = (s_red[threadIdx.x + w] > s_red[threadIdx.x]) ? s_red[threadIdx.x + w] : s_red[threadIdx.x];
+            __syncthreads();
+        }
+        T a = (threadIdx.x == 0) ? (T)0 : s_red[0];
+        if (threadIdx.x < 2) {
+            for (int k = 0; k < TAIL; k++) {
+                a = a + s_mag[k];
+                a = a * (T)0.5;
+            }
+        }
+        __syncthreads();
+        if (threadIdx.x < 2) s_red[threadIdx.x] = a;
+        __syncthreads();
+        const bool same = bits_equal(s_red[0], s_red[1]);
+        if (same) {
+            if (threadIdx.x == 0) *norm_out = desired / s_red[0];
+            return;
+        }
+        __syncthreads();
+    }
     T avg = 0;
     for (long long base = 0; base < n0 || base == 0; base += CAP) {
         const long long cnt = (n0 - base < CAP) ? (n0 - base) : CAP;
