@@ -89,8 +89,9 @@ typedef struct pdt_config {
      * 0 = defaults derived from the sample rate.                                                  */
     uint32_t pll_block, pll_warm, agc_block, agc_warm;
     /* Gardner boundary-state tables: candidate entry states are tabulated within this many samples of
-     * the end point of each of 64 scout trajectories (0 = default 1/16; the true state was further
-     * from every scout in ~1 chunk per 1500 of the test captures).  Smaller = less work, more chunks
+     * the end point of each of 64 scout trajectories (0 = default 1/8; the true state was further
+     * from every scout in ~1 chunk per 9000 of the test captures; candidates merge within a few hundred
+     * symbols, so a wider pad costs little).  Smaller = less work, more chunks
      * walked serially; the result never depends on it.                                            */
     double   gardner_band_pad;
 } pdt_config;

@@ -525,7 +525,7 @@ template <typename T> int run_capture(pdt_ctx *ctx, uint64_t n)
                 GD.q_min = q_min;
                 GD.u = u;
                 GD.n_q = n_q;
-                const double pad = ctx->cfg.gardner_band_pad > 0 ? ctx->cfg.gardner_band_pad : 1.0 / 16.0;
+                const double pad = ctx->cfg.gardner_band_pad > 0 ? ctx->cfg.gardner_band_pad : 1.0 / 8.0;
                 GD.pad_q = std::max(2, (int)(pad / (double)u));
             }
         }
@@ -565,12 +565,20 @@ template <typename T> int run_capture(pdt_ctx *ctx, uint64_t n)
                                (const int *)ctx->gmfirst.p, (const unsigned *)ctx->gcand.p, (unsigned *)ctx->gtable.p,
                                (GardnerBand *)ctx->gbands.p, (unsigned *)ctx->gclist.p, d_sc->gstats);
             {
-                // locked chunks carry 100-300 candidates: small blocks (2 candidates per lane), many per CU
-                constexpr int TT = PDT_GTAB_THREADS, TW = PDT_GTAB_WIN;
-                const unsigned parts = (unsigned)((GD.n_cand + 2 * TT - 1) / (2 * TT));
-                hipLaunchKernelGGL((k_gardner_table<TT, TW>), dim3((unsigned)n_tab, parts), dim3(TT), 0, st, (const float *)d_agc, GP,
-                                   GD, n_tab, (const unsigned *)ctx->gcand.p, (const GardnerBand *)ctx->gbands.p,
-                                   (const unsigned *)ctx->gclist.p, (unsigned *)ctx->gtable.p, d_sc->gstats);
+                // locked chunks carry 100-300 candidates that merge quickly: see k_gardner_table_merge
+                if (getenv("PDT_GTAB_NOMERGE")) {
+                    constexpr int TT = PDT_GTAB_THREADS, TW = PDT_GTAB_WIN;
+                    const unsigned parts = (unsigned)((GD.n_cand + 2 * TT - 1) / (2 * TT));
+                    hipLaunchKernelGGL((k_gardner_table<TT, TW>), dim3((unsigned)n_tab, parts), dim3(TT), 0, st, (const float *)d_agc, GP,
+                                       GD, n_tab, (const unsigned *)ctx->gcand.p, (const GardnerBand *)ctx->gbands.p,
+                                       (const unsigned *)ctx->gclist.p, (unsigned *)ctx->gtable.p, d_sc->gstats);
+                } else {
+                    const unsigned parts = (unsigned)((GD.n_cand + PDT_GTM_SLOTS - 1) / PDT_GTM_SLOTS);
+                    hipLaunchKernelGGL((k_gardner_table_merge<PDT_GTAB_WIN>), dim3((unsigned)n_tab, parts), dim3(PDT_GTM_THREADS), 0, st,
+                                       (const float *)d_agc, GP, GD, n_tab, (const unsigned *)ctx->gcand.p,
+                                       (const GardnerBand *)ctx->gbands.p, (const unsigned *)ctx->gclist.p,
+                                       (unsigned *)ctx->gtable.p, d_sc->gstats);
+                }
             }
             L.end();
             const int G = 32;                                                  // chunks per chain segment

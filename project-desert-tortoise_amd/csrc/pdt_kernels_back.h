@@ -628,6 +628,274 @@ __global__ void __launch_bounds__(THREADS) k_gardner_table(const float *__restri
     else gardner_table_block<THREADS, WIN, 2>(win, in, P, D, c, cand, j0, j_hi, row, stats);
 }
 
+// level 1 with merging.  Candidate trajectories of one chunk collapse onto each other as they go
+// (same picks -> same corrections -> identical state from then on): of ~150 entry states only a
+// handful of distinct trajectories are left after a few hundred symbols.  A workgroup of two
+// wavefronts therefore starts with up to 256 candidates (two per lane), and at every window seam,
+// while more than 64 trajectories are alive, identical states (ns, prev, half) are found through a
+// hash table in LDS, the duplicates are dropped -- each original candidate remembers which survivor
+// carries it and by how many symbols its own count differs -- and the survivors are packed into the
+// low lanes.  From 128 survivors on one trajectory per lane is walked, from 64 on one wavefront.
+// Every walked trajectory executes exactly the arithmetic of the sequential loop; merging only
+// avoids repeating identical work, so the table is the same as without it.
+#define PDT_GTM_THREADS 128
+#define PDT_GTM_SLOTS 256
+#define PDT_GTM_HASH 512
+template <int WIN>
+__global__ void __launch_bounds__(PDT_GTM_THREADS) k_gardner_table_merge(const float *__restrict__ in, GardnerParams<float> P,
+                                                                          GardnerDomain D, long long n_tab_chunks,
+                                                                          const unsigned *__restrict__ cand_k,
+                                                                          const GardnerBand *__restrict__ bands,
+                                                                          const unsigned *__restrict__ clist,
+                                                                          unsigned *__restrict__ table,
+                                                                          unsigned *__restrict__ stats /* [0] bad */)
+{
+    static_assert(WIN * 4 >= PDT_GTM_SLOTS * 4 * 6 + PDT_GTM_HASH * 4, "exchange arrays alias the sample window");
+    __shared__ __attribute__((aligned(16))) float win[WIN];
+    __shared__ unsigned short own[PDT_GTM_SLOTS], dupof[PDT_GTM_SLOTS], newidx[PDT_GTM_SLOTS];
+    __shared__ int extra[PDT_GTM_SLOTS];
+    __shared__ unsigned s_wcnt[2 * (PDT_GTM_THREADS / 64)];
+    // exchange arrays, valid only between two windows (they overlay the sample window)
+    float *x_ns = win, *x_prev = win + PDT_GTM_SLOTS, *x_half = win + 2 * PDT_GTM_SLOTS, *x_q = win + 3 * PDT_GTM_SLOTS;
+    unsigned *x_cnt = reinterpret_cast<unsigned *>(win + 4 * PDT_GTM_SLOTS);
+    unsigned *x_il = reinterpret_cast<unsigned *>(win + 5 * PDT_GTM_SLOTS);
+    unsigned *htab = reinterpret_cast<unsigned *>(win + 6 * PDT_GTM_SLOTS);
+
+    const long long c = blockIdx.x;                 // chunk (always a full one)
+    if (c >= n_tab_chunks) return;
+    const GardnerBand bd = bands[c];
+    const int j0 = bd.j_lo + (int)blockIdx.y * PDT_GTM_SLOTS;
+    const int j_hi = bd.j_hi;
+    if (j0 >= j_hi) return;
+    const unsigned *cand = bd.listed ? (clist + (size_t)blockIdx.x * PDT_GTAB_LIST) : cand_k;
+    unsigned *row = table + (size_t)c * (size_t)(2 * D.n_q);
+    const int tid = threadIdx.x;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const long long C = P.chunk_out;
+    const long long base = c * C;
+    const int n_cur = (int)C;
+    const float hs = (float)((double)P.step / 2.0);
+    const float kp = P.kp, lim = P.lim, step = P.step, nT = (float)n_cur;
+    const int margin = 2 * (int)step + 24;          // look-ahead the staged data must cover past a stop point
+    const int back = (int)step + 8;                 // a mid-point lies at most this far behind a stop point
+
+    int n_alive = (j_hi - j0 < PDT_GTM_SLOTS) ? (j_hi - j0) : PDT_GTM_SLOTS;     // trajectories at positions [0, n_alive)
+    const int n_slots = n_alive;                                                  // original candidates of this block
+    // position p lives in lane p & 127, slot p >> 7
+    GardnerLane L[2];
+    int my_k[2];
+#pragma unroll
+    for (int l = 0; l < 2; l++) {
+        const int p = tid + l * PDT_GTM_THREADS;
+        L[l].ns = L[l].prev = L[l].half = L[l].q_last = 0;
+        L[l].i_last = L[l].count = 0;
+        L[l].k = 0;
+        L[l].active = false;
+        my_k[l] = 0;
+        if (p < n_slots) {
+            if (c >= 1) {                                   // chunk 0: the single start state is cell 0, all zero
+                my_k[l] = (int)cand[j0 + p];
+                gardner_entry_from_candidate(in, P, D, c, my_k[l], L[l].ns, L[l].prev, L[l].half);
+            }
+            own[p] = (unsigned short)p;
+            extra[p] = 0;
+        }
+    }
+    // positions beyond n_alive shadow position 0 so that every lane stays inside the staged windows
+    if (tid == 0) { x_ns[0] = L[0].ns; x_prev[0] = L[0].prev; x_half[0] = L[0].half; }
+    __syncthreads();
+#pragma unroll
+    for (int l = 0; l < 2; l++)
+        if (tid + l * PDT_GTM_THREADS >= n_alive) { L[l].ns = x_ns[0]; L[l].prev = x_prev[0]; L[l].half = x_half[0]; }
+
+    int wbase = 0;
+    float enter_hi = step + 1.2f;                 // upper bound of ns when entering the window
+    for (;;) {
+        // ---- stage [wbase, wbase + WIN)
+        __syncthreads();
+        for (int t0 = 0; t0 < WIN; t0 += PDT_GTM_THREADS * 8) {
+            float r[8];
+#pragma unroll
+            for (int u = 0; u < 8; u++) {
+                const int t = t0 + u * PDT_GTM_THREADS + tid;
+                const int idx = wbase + t;
+                r[u] = (t < WIN && idx < n_cur) ? in[base + idx] : 0.0f;
+            }
+#pragma unroll
+            for (int u = 0; u < 8; u++) {
+                const int t = t0 + u * PDT_GTM_THREADS + tid;
+                const int idx = wbase + t;
+                if (t < WIN) {
+                    if (idx >= n_cur && idx < n_cur + margin)
+                        r[u] = gardner_beyond(in, (const float *)nullptr, P, c, (long long)n_cur, (long long)idx);
+                    win[t] = r[u];
+                }
+            }
+        }
+        __syncthreads();
+        const int wend = wbase + WIN;
+        const bool last_window = (wend - margin >= n_cur);
+        const float stop = last_window ? nT : (float)(wend - margin);    // lanes leave the window at rint(ns) >= stop
+        const float *wrel = win - wbase;          // indexed with chunk-relative indices
+        const bool two = n_alive > PDT_GTM_THREADS;                       // block-uniform
+        const int waves_on = two ? (PDT_GTM_THREADS / 64) : ((n_alive + 63) >> 6);
+        if (wave < waves_on) {
+            if (wbase == 0) {
+                // first symbol: the mid-point index is the stale one of the previous chunk (Q3)
+#pragma unroll
+                for (int l = 0; l < 2; l++) {
+                    const float rn = __builtin_rintf(L[l].ns);
+                    if (rn < nT) {
+                        const unsigned i_cur = (unsigned)rn;
+                        const unsigned i_half = (unsigned)__builtin_rintf(L[l].half);
+                        const float cur = win[i_cur];
+                        float mid;
+                        if (i_half < (unsigned)WIN) mid = win[i_half];
+                        else mid = (i_half < (unsigned)n_cur) ? in[base + i_half]
+                                                              : gardner_beyond(in, (const float *)nullptr, P, c, (long long)n_cur, (long long)i_half);
+                        const float err = __builtin_amdgcn_fmed3f(kp * (cur - L[l].prev) * mid, -lim, lim);
+                        L[l].ns = L[l].ns - err;
+                        L[l].q_last = L[l].ns;
+                        L[l].half = L[l].ns + hs;
+                        L[l].ns = L[l].ns + step;
+                        L[l].prev = cur;
+                        L[l].i_last = i_cur;
+                        L[l].count = 1;
+                    }
+                }
+            }
+            if (L[0].count >= 1 && L[1].count >= 1) {
+                int k_min = (int)((stop - 4.0f - enter_hi) / (step + 0.101f)) - 1;
+                if (k_min < 0) k_min = 0;
+                if (two) {
+                    for (int it = 0; it < k_min; it++) {
+                        gardner_lane_step(L[0], wrel, kp, lim, hs, step);
+                        gardner_lane_step(L[1], wrel, kp, lim, hs, step);
+                    }
+                    L[0].count += (unsigned)k_min;
+                    L[1].count += (unsigned)k_min;
+                    gardner_lane_tail(L[0], wrel, stop, kp, lim, hs, step);
+                    gardner_lane_tail(L[1], wrel, stop, kp, lim, hs, step);
+                } else {
+                    for (int it = 0; it < k_min; it++) gardner_lane_step(L[0], wrel, kp, lim, hs, step);
+                    L[0].count += (unsigned)k_min;
+                    gardner_lane_tail(L[0], wrel, stop, kp, lim, hs, step);
+                }
+            }
+        }
+        if (last_window) break;
+        enter_hi = stop + step + 1.2f;
+        wbase = wend - margin - back;
+        if (n_alive <= 64) continue;
+        // ---- merge identical trajectories (the sample window is dead until the next staging)
+        __syncthreads();
+#pragma unroll
+        for (int l = 0; l < 2; l++) {
+            const int p = tid + l * PDT_GTM_THREADS;
+            if (p < n_alive) { x_ns[p] = L[l].ns; x_prev[p] = L[l].prev; x_half[p] = L[l].half; x_cnt[p] = L[l].count; }
+        }
+        for (int t = tid; t < PDT_GTM_HASH; t += PDT_GTM_THREADS) htab[t] = 0xffffffffu;
+        __syncthreads();
+        bool surv[2];
+#pragma unroll
+        for (int l = 0; l < 2; l++) {
+            const int p = tid + l * PDT_GTM_THREADS;
+            surv[l] = false;
+            if (p < n_alive) {
+                const unsigned a = __float_as_uint(L[l].ns), b = __float_as_uint(L[l].half), d = __float_as_uint(L[l].prev);
+                unsigned h = (a * 2654435761u) ^ (b * 40503u) ^ (d * 2246822519u);
+                h = (h >> 7) & (PDT_GTM_HASH - 1);
+                for (;;) {
+                    const unsigned old = atomicCAS(&htab[h], 0xffffffffu, (unsigned)p);
+                    if (old == 0xffffffffu) { dupof[p] = (unsigned short)p; surv[l] = true; break; }
+                    if (__float_as_uint(x_ns[old]) == a && __float_as_uint(x_half[old]) == b && __float_as_uint(x_prev[old]) == d) {
+                        dupof[p] = (unsigned short)old;
+                        break;
+                    }
+                    h = (h + 1) & (PDT_GTM_HASH - 1);
+                }
+            }
+        }
+        // survivors get consecutive new positions: slot-0 survivors of wave 0, wave 1, then slot-1 survivors
+        unsigned long long bal[2];
+        bal[0] = __ballot(surv[0]);
+        bal[1] = __ballot(surv[1]);
+        if ((tid & 63) == 0) {
+            s_wcnt[wave] = (unsigned)__popcll(bal[0]);
+            s_wcnt[PDT_GTM_THREADS / 64 + wave] = (unsigned)__popcll(bal[1]);
+        }
+        __syncthreads();
+        // every original candidate follows its carrier to the survivor and books the count difference
+#pragma unroll
+        for (int l = 0; l < 2; l++) {
+            const int q = tid + l * PDT_GTM_THREADS;
+            if (q < n_slots) {
+                const unsigned o = own[q];
+                const unsigned dd = dupof[o];
+                if (dd != o) {
+                    extra[q] += (int)x_cnt[o] - (int)x_cnt[dd];
+                    own[q] = (unsigned short)dd;
+                }
+            }
+        }
+        unsigned before[2] = {0, 0};
+        unsigned total = 0;
+        for (int g = 0; g < 2 * (PDT_GTM_THREADS / 64); g++) {
+            const unsigned v = s_wcnt[g];
+            if (g < wave) before[0] += v;
+            if (g < PDT_GTM_THREADS / 64 + wave) before[1] += v;
+            total += v;
+        }
+        const unsigned long long lt = (1ull << (tid & 63)) - 1ull;
+        unsigned np[2];
+        np[0] = before[0] + (unsigned)__popcll(bal[0] & lt);
+        np[1] = before[1] + (unsigned)__popcll(bal[1] & lt);
+#pragma unroll
+        for (int l = 0; l < 2; l++)
+            if (surv[l]) newidx[tid + l * PDT_GTM_THREADS] = (unsigned short)np[l];
+        __syncthreads();
+        // move the surviving states to their new positions (all reads of the old arrays are done)
+#pragma unroll
+        for (int l = 0; l < 2; l++) {
+            if (surv[l]) {
+                const unsigned q = np[l];
+                x_ns[q] = L[l].ns; x_prev[q] = L[l].prev; x_half[q] = L[l].half; x_q[q] = L[l].q_last;
+                x_cnt[q] = L[l].count; x_il[q] = L[l].i_last;
+            }
+            const int q = tid + l * PDT_GTM_THREADS;
+            if (q < n_slots) own[q] = newidx[own[q]];
+        }
+        __syncthreads();
+        n_alive = (int)total;
+#pragma unroll
+        for (int l = 0; l < 2; l++) {
+            const int p = tid + l * PDT_GTM_THREADS;
+            const int src = (p < n_alive) ? p : 0;
+            L[l].ns = x_ns[src]; L[l].prev = x_prev[src]; L[l].half = x_half[src]; L[l].q_last = x_q[src];
+            L[l].count = x_cnt[src]; L[l].i_last = x_il[src];
+        }
+    }
+    // ---- exit states of the survivors, then one table cell per original candidate
+    __syncthreads();
+#pragma unroll
+    for (int l = 0; l < 2; l++) {
+        const int p = tid + l * PDT_GTM_THREADS;
+        if (p < n_alive) { x_q[p] = L[l].q_last; x_il[p] = L[l].i_last; x_cnt[p] = L[l].count; }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int l = 0; l < 2; l++) {
+        const int q = tid + l * PDT_GTM_THREADS;
+        if (q < n_slots) {
+            const unsigned o = own[q];
+            const unsigned cnt = (unsigned)((int)x_cnt[o] + extra[q]);
+            const unsigned cell = gardner_encode_exit(D, x_q[o], x_il[o], cnt);
+            if (cell == PDT_GTAB_MISS) atomicAdd(&stats[0], 1u);  // exit outside the enumerated domain (never expected)
+            row[my_k[l]] = cell;
+        }
+    }
+}
+
 // level 2: follow the chain  k_{c+1} = table_c[k_c]  (k_0 = 0).  A chain of n dependent HBM lookups
 // would cost ~0.5 us each, so it is cut into segments of G chunks:
 //   k_gardner_segmap   composes, for every tabulated entry state of a segment's first chunk, the G
