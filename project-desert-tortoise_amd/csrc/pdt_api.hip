@@ -85,7 +85,7 @@ struct pdt_ctx {
     hipEvent_t ev0 = nullptr, ev1 = nullptr, ev_fork = nullptr, ev_join = nullptr;
     hipStream_t stream2 = nullptr;     // side stream: block-parallel PLL phase runs beside the sequential acquisition
 
-    DevBuf pcm, pll, lock, fir, agc, sym, symidx, bits, bitsym, hits, frames, taps, mag, seams_pll, seams_agc, scal, lockinfo, term, seams_ema, gtable, gentries, gcand, gmfirst, stiles, gsegmap, gsegstart, gbands, gclist, agc_maps, pll_head, taps_rot;
+    DevBuf pcm, pll, lock, fir, agc, sym, symidx, bits, bitsym, hits, frames, taps, mag, seams_pll, seams_agc, scal, lockinfo, term, seams_ema, gtable, gentries, gcand, gmfirst, stiles, gsegmap, gsegstart, gbands, gclist, agc_maps, pll_head, taps_rot, pll_scratch;
     long long gcand_key = -1;          // (chunk_out, step) the candidate list on the device was built for
     bool force_sequential_gardner = false;
     int gardner_mode = 0;              // 0 sequential, 1 state table (last run)
@@ -179,6 +179,28 @@ template <typename T> PllParams<T> make_pll_params(const pdt_ctx *ctx)
     }
     P.max_freq = (T)(2.0 * M_PI * (double)freqRange / (double)Fs);
     P.min_freq = (T)(-2.0 * M_PI * (double)freqRange / (double)Fs);
+    {
+        // sweep gate |pi/2 - averagePhase| < 0.05 (CarrierTrackingPLL.c:236, evaluated as there: the difference
+        // narrowed to DT, fabs, compared as double) is a monotone function of averagePhase on either side of
+        // pi/2: bisect the two edges over the ordered bit patterns so that the kernels need two compares only
+        auto gate = [](T av) { return (double)std::fabs((T)(M_PI / 2.0 - (double)av)) < 0.05; };
+        typedef typename std::conditional<sizeof(T) == 4, uint32_t, uint64_t>::type U;
+        auto bits = [](T v) { U u; memcpy(&u, &v, sizeof u); return u; };
+        auto val = [](U u) { T v; memcpy(&v, &u, sizeof v); return v; };
+        const T mid = (T)(M_PI / 2.0);
+        U in_lo = bits(mid), out_lo = bits((T)1.0);          // gate(mid) true, gate(1.0) false
+        while (in_lo - out_lo > 1) {
+            const U m = out_lo + (in_lo - out_lo) / 2;
+            if (gate(val(m))) in_lo = m; else out_lo = m;
+        }
+        U in_hi = bits(mid), out_hi = bits((T)2.5);
+        while (out_hi - in_hi > 1) {
+            const U m = in_hi + (out_hi - in_hi) / 2;
+            if (gate(val(m))) in_hi = m; else out_hi = m;
+        }
+        P.cond_lo = val(in_lo);
+        P.cond_hi = val(in_hi);
+    }
     P.sweep0 = (T)(0.2 * (2.0 * M_PI / (double)Fs));
     P.avg0 = (T)(M_PI / 2.0);
     P.phase0 = (T)0.1;
@@ -273,7 +295,7 @@ template <typename T> int run_capture(pdt_ctx *ctx, uint64_t n)
     // ---- block-parallel geometry (any values give the same output; they only move time around)
     const double fs_d = (double)ctx->cfg.sample_rate;
     auto round4 = [](long long v) { return (v + 3) / 4 * 4; };
-    long long Bp = ctx->cfg.pll_block ? ctx->cfg.pll_block : (long long)((argos ? 4.0 : 0.1) * fs_d);
+    long long Bp = ctx->cfg.pll_block ? ctx->cfg.pll_block : (long long)((argos ? 4.0 : 0.05) * fs_d);
     long long Wp = ctx->cfg.pll_warm ? ctx->cfg.pll_warm : (long long)((argos ? 8.0 : 0.3) * fs_d);
     long long Wacq = (long long)(0.02 * fs_d);             // acquisition-gain stage of the warm-up
     long long Ba = ctx->cfg.agc_block ? ctx->cfg.agc_block : (long long)((argos ? 1.0 : 0.0625) * fs_d * interp);
@@ -393,10 +415,13 @@ template <typename T> int run_capture(pdt_ctx *ctx, uint64_t n)
     if (N > 0) {
         const long long grid = grid_pll;
         // the sequential head (true state from the lock onwards, ~W samples) also runs beside k_pll_phase
-        // its length: until the true state has forgotten the acquisition (time constant of the critically
-        // damped tracking loop = 2 / alpha samples; 40 of them to agree in 24 bits, 90 in 53), at most the warm-up
+        // its length: until the true state has (nearly) forgotten the acquisition -- time constant of the critically
+        // damped tracking loop = 2 / alpha samples; 30 of them for 24 bits (measured: 28 suffice on every test
+        // capture, 40 never needed), 90 for 53 bits; a block that still disagrees afterwards is simply re-run
         const double tau_trk = 2.0 / (double)PP.alpha_trk;
-        const long long Hd = std::min<long long>(Wp, (long long)((sizeof(T) == 4 ? 40.0 : 90.0) * tau_trk));
+        double head_taus = (sizeof(T) == 4) ? 30.0 : 90.0;
+        if (const char *e = getenv("PDT_HEAD_TAUS")) head_taus = atof(e);      // tuning experiments
+        const long long Hd = std::min<long long>(Wp, (long long)(head_taus * tau_trk));
         const long long head_blocks = Hd / Bp + 3;
         if ((rc = ctx->pll_head.ensure((size_t)(head_blocks * Bp + 64) * sizeof(T) + (size_t)head_blocks * sizeof(PllSeam<T>) +
                                        sizeof(PllHeadInfo<T>) + 64)))
@@ -404,6 +429,7 @@ template <typename T> int run_capture(pdt_ctx *ctx, uint64_t n)
         PllHeadInfo<T> *d_hinfo = (PllHeadInfo<T> *)ctx->pll_head.p;
         PllSeam<T> *d_hseams = (PllSeam<T> *)((unsigned char *)ctx->pll_head.p + 64);
         T *d_hphi = (T *)((unsigned char *)d_hseams + (((size_t)head_blocks * sizeof(PllSeam<T>) + 63) & ~(size_t)63));
+        if ((rc = ctx->pll_scratch.ensure((size_t)(PDT_FIX_THREADS / 64) * (size_t)(((Bp + 63) & ~63ll) + 64) * sizeof(T)))) return rc;
         L.begin("pll_head");
         if (slow_wrap)
             hipLaunchKernelGGL((k_pll_head<T, true>), dim3(1), dim3(64), 0, st, d_theta, N, PP, d_info, Bp, Hd, d_hphi, d_hseams,
@@ -415,13 +441,13 @@ template <typename T> int run_capture(pdt_ctx *ctx, uint64_t n)
         HIP_TRY(hipStreamWaitEvent(st, ctx->ev_join, 0));                  // join
         L.begin("pll_fix");
         if (slow_wrap)
-            hipLaunchKernelGGL((k_pll_fix<T, true>), dim3(1), dim3(64), 0, st, d_theta, N, PP, d_info, Bp, d_phi,
+            hipLaunchKernelGGL((k_pll_fix<T, true>), dim3(1), dim3(PDT_FIX_THREADS), 0, st, d_theta, N, PP, d_info, Bp, d_phi,
                                (PllSeam<T> *)ctx->seams_pll.p, (const T *)d_hphi, (const PllSeam<T> *)d_hseams,
-                               (const PllHeadInfo<T> *)d_hinfo, d_sc->counters);
+                               (const PllHeadInfo<T> *)d_hinfo, (T *)ctx->pll_scratch.p, d_sc->counters);
         else
-            hipLaunchKernelGGL((k_pll_fix<T, false>), dim3(1), dim3(64), 0, st, d_theta, N, PP, d_info, Bp, d_phi,
+            hipLaunchKernelGGL((k_pll_fix<T, false>), dim3(1), dim3(PDT_FIX_THREADS), 0, st, d_theta, N, PP, d_info, Bp, d_phi,
                                (PllSeam<T> *)ctx->seams_pll.p, (const T *)d_hphi, (const PllSeam<T> *)d_hseams,
-                               (const PllHeadInfo<T> *)d_hinfo, d_sc->counters);
+                               (const PllHeadInfo<T> *)d_hinfo, (T *)ctx->pll_scratch.p, d_sc->counters);
         L.end();
         (void)grid;
         L.begin("pll_mix");
@@ -876,7 +902,7 @@ void pdt_close(pdt_ctx *ctx)
     DevBuf *bufs[] = { &ctx->pcm, &ctx->pll, &ctx->lock, &ctx->fir, &ctx->agc, &ctx->sym, &ctx->symidx, &ctx->bits, &ctx->bitsym,
                        &ctx->hits, &ctx->frames, &ctx->taps, &ctx->mag, &ctx->seams_pll, &ctx->seams_agc, &ctx->scal, &ctx->lockinfo,
                        &ctx->term, &ctx->seams_ema, &ctx->gtable, &ctx->gentries, &ctx->gcand,
-                       &ctx->gmfirst, &ctx->stiles, &ctx->gsegmap, &ctx->gsegstart, &ctx->gbands, &ctx->gclist, &ctx->agc_maps, &ctx->pll_head, &ctx->taps_rot };
+                       &ctx->gmfirst, &ctx->stiles, &ctx->gsegmap, &ctx->gsegstart, &ctx->gbands, &ctx->gclist, &ctx->agc_maps, &ctx->pll_head, &ctx->taps_rot, &ctx->pll_scratch };
     for (DevBuf *b : bufs) b->release();
     if (ctx->ev0) (void)hipEventDestroy(ctx->ev0);
     if (ctx->ev1) (void)hipEventDestroy(ctx->ev1);

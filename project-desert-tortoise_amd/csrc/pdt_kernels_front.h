@@ -27,6 +27,7 @@ template <typename T> struct PllParams {
     T alpha_wide, beta_wide;   // warm-up only: 8x the acquisition bandwidth (pulls in a kHz-off frequency guess)
     T max_freq, min_freq;
     T sweep0, avg0, phase0;
+    T cond_lo, cond_hi;   // |pi/2 - averagePhase| < 0.05 (evaluated the reference's way) <=> cond_lo <= averagePhase <= cond_hi
     int want_lock;   // 1 = lockSignalStreamOut != NULL (ARGOS)
 };
 
@@ -280,6 +281,16 @@ template <typename T> __device__ __forceinline__ void pll_sweep_step(T &fr, T &s
     else if (fr >= 0) sw = Real<T>::abs(sw);
     else sw = -Real<T>::abs(sw);
 }
+// the same step as selects (no exec-mask branches), applied only when `on`
+template <typename T> __device__ __forceinline__ void pll_sweep_sel(T &fr, T &sw, T maxf, T minf, bool on)
+{
+    const T f2 = fr + sw;
+    const T mag = Real<T>::abs(sw);
+    const T by_sign = (f2 >= 0) ? mag : -mag;
+    const T s2 = (f2 >= maxf || f2 <= minf) ? -sw : by_sign;
+    fr = on ? f2 : fr;
+    sw = on ? s2 : sw;
+}
 
 template <typename T, bool SLOW>
 __global__ void __launch_bounds__(64) k_pll_acquire_fast(IqSrc pcm, const T *__restrict__ theta, long long n, PllParams<T> P,
@@ -290,17 +301,26 @@ __global__ void __launch_bounds__(64) k_pll_acquire_fast(IqSrc pcm, const T *__r
     const T avg_alpha = (T)0.00005;
     const double k_avg = 1.0 - (double)avg_alpha, k_lock = 1.0 - (double)P.lock_alpha;
     T phase = P.phase0, freq = 0, avg = P.avg0, locksig = 0, sweep = P.sweep0;
-    bool hyp = (double)Real<T>::abs((T)(PDT_PI / 2.0 - (double)avg)) < 0.05;   // sweep condition assumed for the next sample
+    bool hyp = avg >= P.cond_lo && avg <= P.cond_hi;   // sweep condition assumed for the next sample
     long long lock_at = -1;
     T freq_at_lock = 0, avg_at_lock = P.avg0;
     long long i0 = 0;
     // per-lane inputs of the current batch and of the one after it
     T th_l = 0, a_l = 0, b_l = 0, th_n = 0, a_n = 0, b_n = 0;
     long long i_next = -1;     // batch start th_n/a_n/b_n were loaded for
+    T p_o = 0, p_ls = 0;       // outputs of the previous batch, not yet stored
+    long long p_i0 = 0;
+    int p_done = 0;
     if (lane < PDT_ACQ_NB && lane < n) {
         th_l = theta[lane];
         IqSample<T>::get(pcm, lane, a_l, b_l);
     }
+#ifdef PDT_ACQ_PROF
+    long long pc[5] = {0, 0, 0, 0, 0}, pt = clock64(), nbatch = 0;
+#define PDT_ACQ_TICK(k) { const long long now_ = clock64(); pc[k] += now_ - pt; pt = now_; }
+#else
+#define PDT_ACQ_TICK(k)
+#endif
     while (i0 < n && lock_at < 0) {
         const int nb = (int)((n - i0 < PDT_ACQ_NB) ? (n - i0) : PDT_ACQ_NB);
         i_next = i0 + PDT_ACQ_NB;
@@ -308,6 +328,12 @@ __global__ void __launch_bounds__(64) k_pll_acquire_fast(IqSrc pcm, const T *__r
             th_n = theta[i_next + lane];
             IqSample<T>::get(pcm, i_next + lane, a_n, b_n);
         }
+        if (lane < p_done) {
+            out[p_i0 + lane] = p_o;
+            if (lock_out) lock_out[p_i0 + lane] = p_ls;
+        }
+        p_done = 0;
+        PDT_ACQ_TICK(0)
         // ---- pass 1: loop filter; lane k keeps phase before / after sample k, freq before the sweep
         // step, and the sweep increment before it
         T phi_l = 0, phn_l = 0, fpre_l = 0, swb_l = 0;
@@ -321,9 +347,10 @@ __global__ void __launch_bounds__(64) k_pll_acquire_fast(IqSrc pcm, const T *__r
                 phn_l = mine ? ph : phn_l;
                 fpre_l = mine ? fr : fpre_l;
                 swb_l = mine ? sw : swb_l;
-                if (hyp) pll_sweep_step(fr, sw, P.max_freq, P.min_freq);
+                pll_sweep_sel(fr, sw, P.max_freq, P.min_freq, hyp);
             }
         }
+        PDT_ACQ_TICK(1)
         // ---- pass 2: per-sample work (lane k <-> sample k)
         T t_l = 0, u_l = 0, o_l = 0;
         {
@@ -340,27 +367,34 @@ __global__ void __launch_bounds__(64) k_pll_acquire_fast(IqSrc pcm, const T *__r
             const T re = a_l * inv, im = b_l * inv;
             u_l = P.lock_alpha * (re * t_real + im * t_imag);
         }
+        PDT_ACQ_TICK(2)
         // ---- pass 3: EMAs, sweep condition, lock test
         int done = nb;            // samples of this batch that stand
         bool flip = false;
         T ls_l = 0;
         {
-            T av = avg, ls = locksig;
-            int k = 0;
-            for (; k < nb; k++) {
+            // every sample of the batch is evaluated (no branch in the loop); the first sample whose sweep
+            // condition contradicts the hypothesis or whose lock detector crosses the threshold ends the
+            // batch, and the EMA values of that sample are picked up from the lane that kept them
+            T av = avg, ls = locksig, av_l = 0;
+            unsigned ev_flip = 0, ev_lock = 0;
+            for (int k = 0; k < nb; k++) {
                 av = (T)((double)av * k_avg + (double)lane_get(t_l, k));
                 ls = (T)((double)ls * k_lock + (double)lane_get(u_l, k));
-                ls_l = (lane == k) ? ls : ls_l;
-                const bool cond = (double)Real<T>::abs((T)(PDT_PI / 2.0 - (double)av)) < 0.05;
-                if (cond != hyp || ls > P.lock_thr) {
-                    flip = cond != hyp;
-                    break;
-                }
+                const bool mine = lane == k;
+                ls_l = mine ? ls : ls_l;
+                av_l = mine ? av : av_l;
+                const bool cond = av >= P.cond_lo && av <= P.cond_hi;
+                ev_flip |= (cond != hyp) ? (1u << k) : 0u;
+                ev_lock |= (ls > P.lock_thr) ? (1u << k) : 0u;
             }
-            avg = av;
-            locksig = ls;
-            if (k < nb) {
+            ev_flip = (unsigned)__builtin_amdgcn_readfirstlane((int)ev_flip);
+            ev_lock = (unsigned)__builtin_amdgcn_readfirstlane((int)ev_lock);
+            const unsigned ev = ev_flip | ev_lock;
+            if (ev) {
                 // sample k ends the batch: its sweep step is taken with its own (true) condition
+                const int k = __builtin_ctz(ev);
+                flip = (ev_flip >> k) & 1u;
                 const bool cond = flip ? !hyp : hyp;
                 T fr = lane_get(fpre_l, k), sw = lane_get(swb_l, k);
                 if (cond) pll_sweep_step(fr, sw, P.max_freq, P.min_freq);
@@ -369,13 +403,17 @@ __global__ void __launch_bounds__(64) k_pll_acquire_fast(IqSrc pcm, const T *__r
                 sweep = sw;
                 hyp = cond;
                 done = k + 1;
-                if (ls > P.lock_thr) {
+                avg = lane_get(av_l, k);
+                locksig = lane_get(ls_l, k);
+                if ((ev_lock >> k) & 1u) {
                     lock_at = i0 + k;
                     freq_at_lock = freq;
-                    avg_at_lock = av;
+                    avg_at_lock = avg;
                 }
             } else {
                 // the whole batch stands: adopt the state after its last sample
+                avg = av;
+                locksig = ls;
                 const int kl = nb - 1;
                 T fr = lane_get(fpre_l, kl), sw = lane_get(swb_l, kl);
                 if (hyp) pll_sweep_step(fr, sw, P.max_freq, P.min_freq);
@@ -384,10 +422,8 @@ __global__ void __launch_bounds__(64) k_pll_acquire_fast(IqSrc pcm, const T *__r
                 sweep = sw;
             }
         }
-        if (lane < done) {
-            out[i0 + lane] = o_l;
-            if (lock_out) lock_out[i0 + lane] = ls_l;
-        }
+        PDT_ACQ_TICK(3)
+        p_o = o_l; p_ls = ls_l; p_i0 = i0; p_done = done;
         i0 += done;
         if (i0 == i_next) {
             th_l = th_n; a_l = a_n; b_l = b_n;
@@ -395,6 +431,15 @@ __global__ void __launch_bounds__(64) k_pll_acquire_fast(IqSrc pcm, const T *__r
             th_l = theta[i0 + lane];
             IqSample<T>::get(pcm, i0 + lane, a_l, b_l);
         }
+        PDT_ACQ_TICK(4)
+    }
+#ifdef PDT_ACQ_PROF
+    if (lane == 0)
+        printf("acquire: %lld samples; cycles top %lld pass1 %lld pass2 %lld pass3 %lld tail %lld\n", i0, pc[0], pc[1], pc[2], pc[3], pc[4]);
+#endif
+    if (lane < p_done) {
+        out[p_i0 + lane] = p_o;
+        if (lock_out) lock_out[p_i0 + lane] = p_ls;
     }
     if (lane == 0) {
         PllState<T> st;
@@ -652,19 +697,32 @@ template <> __device__ __forceinline__ bool bits_equal<double>(double x, double 
     return __double_as_longlong(x) == __double_as_longlong(y);
 }
 
-// Seam validation + repair.  One wavefront scans 64 seams per round trip (a seam is healthy when
-// the previous block's end state equals, bit for bit, the state this block reached at its
-// official start after its warm-up); a mismatching block is re-run from the true state by the
-// whole wave in lock step (uniform work, lane 0's stores count), after which the scan resumes at
-// the following seam so that a changed end state is compared again.
+// Seam validation + repair.  A seam is healthy when the previous block's end state equals, bit for bit,
+// the state this block reached at its official start after its warm-up.  One workgroup of 16 wavefronts
+// works in rounds: all seams not yet final are checked in parallel; the first (up to 16) unhealthy blocks
+// are re-run at the same time, one wavefront each, from their predecessors' end states INTO A SCRATCH
+// buffer; the re-runs are then committed in order for as long as each leaves its block's end state
+// unchanged (the usual case: the re-run merges with the old trajectory inside the block), because only
+// then is the next one's starting state known to be final.  The first re-run that changes its end
+// state is committed too -- everything before it is final -- and the following seam is examined again
+// in the next round.  So isolated unhealthy seams cost one block walk in total, a cascade costs one
+// walk per block as a sequential pass would, and a healthy block is never overwritten from a state
+// that is not known to be the true one.
+#define PDT_FIX_THREADS 1024
+#define PDT_FIX_LIST 64
 template <typename T, bool SLOW>
-__global__ void __launch_bounds__(64) k_pll_fix(const T *__restrict__ theta, long long n, PllParams<T> P,
+__global__ void __launch_bounds__(PDT_FIX_THREADS) k_pll_fix(const T *__restrict__ theta, long long n, PllParams<T> P,
                                                  const PllLockInfo<T> *__restrict__ info, long long B, T *__restrict__ phi,
                                                  PllSeam<T> *__restrict__ seams, const T *__restrict__ phi_head,
                                                  const PllSeam<T> *__restrict__ seams_head,
-                                                 const PllHeadInfo<T> *__restrict__ hinfo,
+                                                 const PllHeadInfo<T> *__restrict__ hinfo, T *__restrict__ scratch,
                                                  unsigned *__restrict__ counters /* [0]=blocks [1]=fixes */)
 {
+    constexpr int NW = PDT_FIX_THREADS / 64;
+    __shared__ long long s_bad[PDT_FIX_LIST];
+    __shared__ T s_end[NW][2];
+    __shared__ unsigned s_nbad;
+    __shared__ long long s_min;
     const long long lock_at = info->lock_sample;
     if (lock_at < 0) {
         if (threadIdx.x == 0) { counters[0] = 0; counters[1] = 0; }
@@ -674,42 +732,92 @@ __global__ void __launch_bounds__(64) k_pll_fix(const T *__restrict__ theta, lon
     const PllHeadInfo<T> hi = *hinfo;
     const long long j0 = hi.j0;                                     // block that contains the lock
     const long long nb_abs = (n + B - 1) / B;                       // absolute block count
+    const long long BS = (B + 63) & ~63ll;                          // scratch stride per wavefront
     // graft the head's true phases and seam records over the block-parallel ones
-    for (long long i = hi.s0 + threadIdx.x; i < hi.s1; i += 64) phi[i] = phi_head[i - (hi.s0 & ~3ll)];
-    for (long long k = threadIdx.x; k < hi.nblk; k += 64) seams[j0 + k] = seams_head[k];
-    __threadfence_block();
+    for (long long i = hi.s0 + threadIdx.x; i < hi.s1; i += PDT_FIX_THREADS) phi[i] = phi_head[i - (hi.s0 & ~3ll)];
+    for (long long k = threadIdx.x; k < hi.nblk; k += PDT_FIX_THREADS) seams[j0 + k] = seams_head[k];
+    __threadfence();
     __syncthreads();
     unsigned fixes = 0;
-    long long r = j0 + hi.nblk;                                     // first seam that needs checking
-    if (hi.nblk == 0) r = nb_abs;
-    while (r < nb_abs) {
-        const long long mine = r + threadIdx.x;
-        bool bad = false;
-        if (mine < nb_abs) {
-            const PllSeam<T> prev = seams[mine - 1];
-            const PllSeam<T> cur = seams[mine];
-            bad = !(bits_equal(prev.phase1, cur.phase0) && bits_equal(prev.freq1, cur.freq0));
-        }
-        const unsigned long long mask = __ballot(bad);
-        if (mask == 0) { r += 64; continue; }
-        const long long rb = r + (long long)__builtin_ctzll(mask);       // first unhealthy seam
-        fixes++;
-        const PllSeam<T> prev = seams[rb - 1];
-        T phase = prev.phase1, freq = prev.freq1;
-        const long long start = rb * B;
-        const long long end = ((rb + 1) * B < n) ? (rb + 1) * B : n;
-        if (threadIdx.x == 0) {
-            pll_phase_range<T, true, SLOW, 32>(theta, phi, start, end, phase, freq, P.alpha_trk, P.beta_trk, P.max_freq, P.min_freq);
-            PllSeam<T> upd;
-            upd.phase0 = prev.phase1;
-            upd.freq0 = prev.freq1;
-            upd.phase1 = phase;
-            upd.freq1 = freq;
-            seams[rb] = upd;
-        }
-        __threadfence_block();
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    long long from = (hi.nblk > 0) ? j0 + hi.nblk : nb_abs;         // seams before `from` are final
+    for (;;) {
+        if (threadIdx.x == 0) { s_nbad = 0; s_min = nb_abs; }
         __syncthreads();
-        r = rb + 1;
+        for (long long r = from + threadIdx.x; r < nb_abs; r += PDT_FIX_THREADS) {
+            const PllSeam<T> prev = seams[r - 1];
+            const PllSeam<T> cur = seams[r];
+            if (!(bits_equal(prev.phase1, cur.phase0) && bits_equal(prev.freq1, cur.freq0))) {
+                const unsigned slot = atomicAdd(&s_nbad, 1u);
+                if (slot < PDT_FIX_LIST) s_bad[slot] = r;
+                atomicMin((unsigned long long *)&s_min, (unsigned long long)r);
+            }
+        }
+        __syncthreads();
+        unsigned nbad = s_nbad;
+        if (nbad == 0) break;
+        if (nbad > PDT_FIX_LIST) {
+            // too many to order: take only the first one this round
+            nbad = 1;
+            __syncthreads();
+            if (threadIdx.x == 0) s_bad[0] = s_min;
+            __syncthreads();
+        } else {
+            // ascending order (tiny list: rank sort by the first threads)
+            long long mine = 0;
+            unsigned rank = 0;
+            if (threadIdx.x < nbad) {
+                mine = s_bad[threadIdx.x];
+                for (unsigned q = 0; q < nbad; q++) rank += (s_bad[q] < mine) ? 1u : 0u;
+            }
+            __syncthreads();
+            if (threadIdx.x < nbad) s_bad[rank] = mine;
+            __syncthreads();
+            if (nbad > (unsigned)NW) nbad = NW;
+        }
+        // re-run into the scratch buffer
+        if ((unsigned)wave < nbad && lane == 0) {
+            const long long rb = s_bad[wave];
+            const PllSeam<T> prev = seams[rb - 1];
+            T phase = prev.phase1, freq = prev.freq1;
+            const long long start = rb * B;
+            const long long end = ((rb + 1) * B < n) ? (rb + 1) * B : n;
+            // scratch index = sample index - (start rounded down to 4): vector stores stay aligned
+            pll_phase_range<T, true, SLOW, 32>(theta, scratch + (long long)wave * BS - (start & ~3ll), start, end, phase, freq,
+                                               P.alpha_trk, P.beta_trk, P.max_freq, P.min_freq);
+            s_end[wave][0] = phase;
+            s_end[wave][1] = freq;
+        }
+        __threadfence();
+        __syncthreads();
+        // commit in order while the end states stand
+        unsigned ncommit = 0;
+        for (unsigned q = 0; q < nbad; q++) {
+            ncommit = q + 1;
+            const PllSeam<T> old = seams[s_bad[q]];
+            if (!(bits_equal(old.phase1, s_end[q][0]) && bits_equal(old.freq1, s_end[q][1]))) break;
+        }
+        __syncthreads();
+        for (unsigned q = 0; q < ncommit; q++) {
+            const long long rb = s_bad[q];
+            const long long start = rb * B;
+            const long long end = ((rb + 1) * B < n) ? (rb + 1) * B : n;
+            const T *src = scratch + (long long)q * BS - (start & ~3ll);
+            for (long long i = start + threadIdx.x; i < end; i += PDT_FIX_THREADS) phi[i] = src[i];
+            if (threadIdx.x == 0) {
+                const PllSeam<T> prev = seams[rb - 1];
+                PllSeam<T> upd;
+                upd.phase0 = prev.phase1;
+                upd.freq0 = prev.freq1;
+                upd.phase1 = s_end[q][0];
+                upd.freq1 = s_end[q][1];
+                seams[rb] = upd;
+            }
+        }
+        fixes += ncommit;
+        from = s_bad[ncommit - 1] + 1;
+        __threadfence();
+        __syncthreads();
     }
     if (threadIdx.x == 0) {
         counters[0] = (unsigned)((S < n) ? nb_abs - j0 : 0);
