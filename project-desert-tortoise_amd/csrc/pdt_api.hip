@@ -480,9 +480,9 @@ template <typename T> int run_capture(pdt_ctx *ctx, uint64_t n)
                                d_fir, opt);
         } else {
             const int K = ntaps / interp;
-            const int rs = (interp == 3) ? 4 : interp;
-            const size_t sh_rt = (size_t)(65 * (K + 1) + 3 + K * K * rs + 64 * K * interp) * sizeof(T);
-            const unsigned grid_rt = (unsigned)((N + 64ll * K - 1) / (64ll * K));
+            const size_t sh_rt = (size_t)(65 * (K + 1) + 3 + 64 * K * interp) * sizeof(T);
+            const long long tiles_rt = (N + 64ll * K - 1) / (64ll * K);
+            const unsigned grid_rt = (unsigned)std::min<long long>(tiles_rt, 256ll * 6);   // persistent workgroups, 6 per CU
             bool done = false;
             if (K == 26 && sh_rt <= 64000 && ctx->taps_rot.p && !getenv("PDT_FIR_GENERIC")) {
                 done = true;

@@ -976,70 +976,71 @@ __global__ void __launch_bounds__(PDT_FIR_THREADS) k_fir_interp(const T *__restr
 // wavefront takes one residue c = M mod K at a time, lane j computing the INTERP outputs of
 // M = m0 + c + K*j.  Ring slot t then holds input m0 + K*j + t (t <= c) or m0 + K*(j-1) + t (t > c),
 // every lane of the wavefront walks the slots 0..K-1 in the reference's order, and the tap of slot
-// t is the same for all lanes: it comes from a table rotated per residue, s_rot[c][t][r] =
-// h[N-1-r-((c-t) mod K)*INTERP] (built once on the host), read with one broadcast LDS load at an
-// immediate offset.  The
+// t is the same for all lanes: it comes from a table rotated per residue, rot[c][t][r] =
+// h[N-1-r-((c-t) mod K)*INTERP] (built once on the host) and is fetched with scalar loads into
+// SGPRs (broadcast LDS reads of the taps made the kernel LDS-bandwidth bound).  The
 // slot loop is fully unrolled; each staged input is read once for INTERP multiply-adds (separate
 // multiply and add, as the reference).  Outputs go through LDS and leave with coalesced stores.
 // HBM traffic = the algorithmic 4 B in + 4*INTERP B out per input sample.
 template <typename T, int INTERP, int K>
 __global__ void __launch_bounds__(PDT_FIR_THREADS) k_fir_interp_rt(const T *__restrict__ in, long long n_in,
-                                                                    const T *__restrict__ rot /* host-built s_rot */,
+                                                                    const T *__restrict__ rot /* host-built rotated taps */,
                                                                     T *__restrict__ out)
 {
     extern __shared__ __align__(16) unsigned char smem_raw[];
     constexpr int TI = 64 * K;                               // inputs (= values of M) per workgroup
     constexpr int RS = (INTERP == 3) ? 4 : INTERP;           // row stride of the tap table (16-byte rows for INTERP 3)
     constexpr int LS = K + 1;                                // padded row of K inputs: lanes hit distinct banks
-    constexpr int NROT = K * K * RS;
-    T *s_rot = reinterpret_cast<T *>(smem_raw);              // rotated taps
-    T *s_out = s_rot + NROT;                                 // TI * INTERP outputs
+    T *s_out = reinterpret_cast<T *>(smem_raw);              // TI * INTERP outputs
     T *s_in = s_out + TI * INTERP;                           // 65 rows of K inputs: row q = inputs m0 + K*(q-1) ..
-    const long long m0 = (long long)blockIdx.x * TI;         // multiple of K
-    if (m0 >= n_in) return;
-    for (int t = threadIdx.x; t < 65 * K; t += PDT_FIR_THREADS) {
-        const long long m = m0 - K + t;
-        const int q = t / K;
-        s_in[q * LS + (t - q * K)] = (m >= 0 && m < n_in) ? in[m] : (T)0;
-    }
-    for (int e = threadIdx.x; e < NROT; e += PDT_FIR_THREADS) s_rot[e] = rot[e];
-    __syncthreads();
     const int wave = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6);
     const int j = threadIdx.x & 63;
-    for (int c = wave; c < K; c += PDT_FIR_THREADS / 64) {
-        const T *w1 = s_in + (j + 1) * LS;                   // slot t <= c: input m0 + K*j + t
-        const T *w0 = s_in + j * LS;                         // slot t >  c: input m0 + K*(j-1) + t
-        const T *h = s_rot + c * K * RS;
-        T y[INTERP];
-#pragma unroll
-        for (int r = 0; r < INTERP; r++) y[r] = 0;
-        T x[K];                                              // the lane's ring, all reads in flight together
-#pragma unroll
-        for (int t = 0; t < K; t++) x[t] = (t <= c) ? w1[t] : w0[t];
-        T hv[K][INTERP];                                     // ... and the residue's taps (broadcast reads)
-#pragma unroll
-        for (int t = 0; t < K; t++)
-#pragma unroll
-            for (int r = 0; r < INTERP; r++) hv[t][r] = h[t * RS + r];
-#pragma unroll
-        for (int t = 0; t < K; t++) {
-#pragma unroll
-            for (int r = 0; r < INTERP; r++) y[r] = y[r] + hv[t][r] * x[t];
-        }
-#pragma unroll
-        for (int r = 0; r < INTERP; r++) s_out[(c + K * j) * INTERP + r] = y[r];
-    }
-    __syncthreads();
-    const long long g0 = m0 * INTERP;
     const long long n_out = n_in * INTERP;
-    constexpr int n_tile = TI * INTERP;                      // multiple of 4; g0 is a multiple of 4 as well
-    if (g0 + n_tile <= n_out) {
-        constexpr int VN = Vec16<T>::N;
-        for (int t = threadIdx.x * VN; t < n_tile; t += PDT_FIR_THREADS * VN)
-            *reinterpret_cast<Vec16<T> *>(out + g0 + t) = *reinterpret_cast<const Vec16<T> *>(s_out + t);
-    } else {
-        for (int t = threadIdx.x; t < n_tile; t += PDT_FIR_THREADS)
-            if (g0 + t < n_out) out[g0 + t] = s_out[t];
+    constexpr int n_tile = TI * INTERP;                      // multiple of 4
+    const long long n_tiles = (n_in + TI - 1) / TI;
+    // persistent workgroups: the tap table is loaded once, then tile after tile
+    for (long long tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
+        const long long m0 = tile * TI;                      // multiple of K
+        __syncthreads();                                     // previous tile's outputs have left s_out / s_in
+        for (int t = threadIdx.x; t < 65 * K; t += PDT_FIR_THREADS) {
+            const long long m = m0 - K + t;
+            const int q = t / K;
+            s_in[q * LS + (t - q * K)] = (m >= 0 && m < n_in) ? in[m] : (T)0;
+        }
+        __syncthreads();
+        for (int c = wave; c < K; c += PDT_FIR_THREADS / 64) {
+            const T *w1 = s_in + (j + 1) * LS;                   // slot t <= c: input m0 + K*j + t
+            const T *w0 = s_in + j * LS;                         // slot t >  c: input m0 + K*(j-1) + t
+            const T *h = rot + c * K * RS;                       // wave-uniform address: scalar loads into SGPRs
+            T y[INTERP];
+#pragma unroll
+            for (int r = 0; r < INTERP; r++) y[r] = 0;
+            T x[K];                                              // the lane's ring, all reads in flight together
+#pragma unroll
+            for (int t = 0; t < K; t++) x[t] = (t <= c) ? w1[t] : w0[t];
+            T hv[K][INTERP];                                     // ... and the residue's taps (scalar registers)
+#pragma unroll
+            for (int t = 0; t < K; t++)
+#pragma unroll
+                for (int r = 0; r < INTERP; r++) hv[t][r] = h[t * RS + r];
+#pragma unroll
+            for (int t = 0; t < K; t++) {
+#pragma unroll
+                for (int r = 0; r < INTERP; r++) y[r] = y[r] + hv[t][r] * x[t];
+            }
+#pragma unroll
+            for (int r = 0; r < INTERP; r++) s_out[(c + K * j) * INTERP + r] = y[r];
+        }
+        __syncthreads();
+        const long long g0 = m0 * INTERP;                    // multiple of 4
+        if (g0 + n_tile <= n_out) {
+            constexpr int VN = Vec16<T>::N;
+            for (int t = threadIdx.x * VN; t < n_tile; t += PDT_FIR_THREADS * VN)
+                *reinterpret_cast<Vec16<T> *>(out + g0 + t) = *reinterpret_cast<const Vec16<T> *>(s_out + t);
+        } else {
+            for (int t = threadIdx.x; t < n_tile; t += PDT_FIR_THREADS)
+                if (g0 + t < n_out) out[g0 + t] = s_out[t];
+        }
     }
 }
 
