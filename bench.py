@@ -61,24 +61,51 @@ def gather_frames(frames: np.ndarray, device: torch.device):
     return [o[: c * rec].cpu().numpy().view(frames.dtype) for o, c in zip(out, counts)]
 
 
-# algorithmic bytes per input sample of each kernel group, interp = 3 at 50 ksps:
-# what the stage must read + write if its input and output are materialised once.
+# Algorithmic bytes per step of each kernel group: what the group must read
+# and write if its input and output streams are materialised exactly once (f = 4-byte float, interp = 3 at
+# 50 ksps).  The serial pieces (acquisition, head, seam repair, chain) move only a few KB: 0.
 def stage_bytes(n: int, interp: int, nsym: int, nbits: int):
     f = 4
     return {
-        "static_gain": 4 * 10000,
-        "pll_theta": (4 + f) * n,
+        "static_gain": 4 * 10000,                        # first chunk of int16 I/Q
+        "pll_theta": (4 + f) * n,                        # I/Q in, theta out
         "pll_acquire": 0,
-        "pll_phase": (f + f) * n,
+        "pll_phase": (f + f) * n,                        # theta in, phase out
+        "pll_head": 0,
         "pll_fix": 0,
-        "pll_mix": (4 + f + f) * n,
-        "fir": (f + f * interp) * n,
+        "pll_mix": (4 + f + f) * n,                      # I/Q + phase in, mixed sample out
+        "fir": (f + f * interp) * n,                     # 4 B in + 4*interp B out per input sample
         "agc_block": 2 * f * interp * n,
         "agc_fix": 0,
-        "gardner": f * interp * n + 12 * nsym,
+        "gardner_table": f * interp * n,                 # the AGC stream, once
+        "gardner_chain": 0,
+        "gardner": f * interp * n + 12 * nsym,           # the AGC stream + symbol value/index out
         "manchester": 2 * f * nsym + 5 * nbits,
         "bytesync": 2 * nbits,
     }
+
+
+# kernel group -> the kernel that dominates it (name as rocprofv3 / tools/pmc_traffic.py print it)
+GROUP_KERNEL = {
+    "pll_phase": "k_pll_phase<float, false>", "pll_acquire": "k_pll_acquire_fast<float, false>",
+    "pll_head": "k_pll_head<float, false>", "pll_fix": "k_pll_fix<float, false>", "pll_theta": "k_pll_theta<float>",
+    "pll_mix": "k_pll_mix<float, false>", "fir": "k_fir_interp_rt<float, 3, 26>", "agc_block": "k_agc_block<float>",
+    "gardner_table": "k_gardner_table_merge<2048>", "gardner": "k_gardner<float, 2048, 256>",
+    "static_gain": "k_static_gain<float>", "manchester": "k_manch_emit<float>", "bytesync": "k_sync_frames_tiles",
+}
+
+
+def pmc_traffic(kernel: str):
+    """HBM bytes per launch of `kernel` from the committed rocprofv3 counter passes (FETCH_SIZE x2 + WRITE_SIZE,
+    see tools/pmc_traffic.py and profiles/r1/README.md); None when the kernel is not in the file."""
+    path = os.path.join(ROOT, "profiles", "r1", "pmc_hbm_traffic_bench_c2.json")
+    try:
+        for row in json.load(open(path)):
+            if row["kernel"] == kernel:
+                return int(row["hbm_bytes"])
+    except (OSError, ValueError, KeyError):
+        pass
+    return None
 
 
 def cpu_baseline(iq: np.ndarray):
@@ -173,9 +200,11 @@ def main():
             stages[k] = {"ms": round(per, 4), "alg_bytes": sb.get(k, 0), "GBps": round(gbs, 2),
                          "frac_hbm": round(gbs / HBM_PEAK_GBS, 6)}
         dom = max(stages, key=lambda k: stages[k]["ms"])
-        front = ["pll_theta", "pll_phase", "pll_fix", "pll_mix", "fir"]
-        front_ms = sum(stages[k]["ms"] for k in front if k in stages)
+        # FIR+PLL stage (north-star target): critical path through the two concurrent streams
+        g = lambda k: stages.get(k, {"ms": 0.0})["ms"]
+        front_ms = g("pll_theta") + max(g("pll_phase"), g("pll_acquire") + g("pll_head")) + g("pll_fix") + g("pll_mix") + g("fir")
         front_bytes = (4 + 4 * st.interp) * n            # fused FIR+PLL stage: 4 B in + 4*interp B out per sample
+        hbm_bound = ["pll_theta", "pll_mix", "fir"]      # the groups that are pure streaming kernels
         out = {
             "metric": "IQ Msamples/s end-to-end (WAV->minorframes), 1-GPU + %HBM roofline",
             "value": round(value, 3),
@@ -192,16 +221,25 @@ def main():
             "config": {"workload": f"synthetic {FS // 1000} ksps complex-IQ capture, {args.seconds:g} s ({n} samples) per GPU, "
                                    "POES chain, chunk 10000, input resident in HBM",
                        "samples_per_gpu": n, "captures": world, "parallelism": f"1 capture per GPU x{world}"},
-            "roofline": {"bound": "hbm", "kernel": dom, "achieved": stages[dom]["GBps"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": stages[dom]["frac_hbm"], "traffic": None,
-                         "note": "serial symbol chain on one wavefront: latency-bound, not bandwidth-bound"},
+            "roofline": {"bound": "hbm", "kernel": GROUP_KERNEL.get(dom, dom), "group": dom,
+                         "achieved": stages[dom]["GBps"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": stages[dom]["frac_hbm"], "traffic": pmc_traffic(GROUP_KERNEL.get(dom, dom)),
+                         "alg_bytes": stages[dom]["alg_bytes"], "ms": stages[dom]["ms"],
+                         "note": "achieved = algorithmic bytes / live HIP-event duration of the group's launch; this kernel "
+                                 "walks exact sequential recurrences (one lane per block + warm-up replay), so it is bound by "
+                                 "dependent-instruction latency, not by HBM; traffic = FETCH_SIZE x2 + WRITE_SIZE per launch "
+                                 "from profiles/r1 (warm-up replays re-read the stream)"},
+            "streaming_kernels": {k: {"GBps": stages[k]["GBps"], "frac_hbm": stages[k]["frac_hbm"], "traffic": pmc_traffic(GROUP_KERNEL[k])}
+                                  for k in hbm_bound if k in stages},
             "pipeline_hbm_frac": round(4 * n / (ms_step * 1e-3) / 1e9 / HBM_PEAK_GBS, 6),
             "fir_pll_stage": {"ms": round(front_ms, 4), "alg_bytes": front_bytes,
                               "GBps": round(front_bytes / (front_ms * 1e-3) / 1e9, 2) if front_ms else None,
-                              "frac_hbm": round(front_bytes / (front_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 6) if front_ms else None},
+                              "frac_hbm": round(front_bytes / (front_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 6) if front_ms else None,
+                              "note": "critical path: theta + max(phase, acquire + head) + fix + mix + fir"},
             "stages": stages,
             "frames_per_capture": [int(len(g)) for g in gathered],
             "pll_seam_fixes": int(st.pll_seam_fixes), "agc_seam_fixes": int(st.agc_seam_fixes),
+            "gardner_walked": int(st.gardner_walked), "gardner_candidates": int(st.gardner_candidates),
             "lock_sample": int(st.lock_sample),
         }
         if not args.no_cpu:

@@ -587,6 +587,7 @@ template <typename T> int run_capture(pdt_ctx *ctx, uint64_t n)
             if ((rc = ctx->gbands.ensure((size_t)n_tab * sizeof(GardnerBand)))) return rc;
             L.begin("gardner_table");
             if ((rc = ctx->gclist.ensure((size_t)n_tab * PDT_GTAB_LIST * sizeof(unsigned)))) return rc;
+            HIP_TRY(hipMemsetAsync(ctx->gtable.p, 0xff, (size_t)n_tab * (size_t)(2 * GD.n_q) * sizeof(unsigned), st));   // PDT_GTAB_MISS
             hipLaunchKernelGGL(k_gardner_scout, dim3((unsigned)n_tab), dim3(64), 0, st, (const float *)d_agc, GP, GD, n_tab,
                                (const int *)ctx->gmfirst.p, (const unsigned *)ctx->gcand.p, (unsigned *)ctx->gtable.p,
                                (GardnerBand *)ctx->gbands.p, (unsigned *)ctx->gclist.p, d_sc->gstats);

@@ -368,7 +368,7 @@ __device__ __forceinline__ void gardner_lane_tail(GardnerLane &L, const float *w
 // been running far longer -- ends on or within a few grid points of one of them.  The chunk's
 // candidate list is the union of the neighbourhoods [m - pad, m + pad] of the scouts' end points m;
 // when the scouts end more than 1.5 samples apart (no timing lock) the full domain is tabulated.
-// Also clears the chunk's table row.
+// (The table itself is preset to "not tabulated" by a memset before this kernel.)
 struct GardnerBand { int j_lo, j_hi, listed; };   // candidates [j_lo, j_hi) of cand_k, or of the chunk's own list
 #define PDT_GTAB_LIST 2048                        // capacity of a chunk's candidate list
 
@@ -387,8 +387,6 @@ __global__ void __launch_bounds__(64) k_gardner_scout(const float *__restrict__ 
     const int n_cur = (int)C;
     const int tail_n = (C < PDT_GTAB_TAIL) ? (int)C : PDT_GTAB_TAIL;
     const int lane = threadIdx.x;
-    unsigned *row = table + (size_t)c * (size_t)(2 * D.n_q);
-    for (int t = lane; t < 2 * D.n_q; t += 64) row[t] = PDT_GTAB_MISS;
     GardnerBand bd;
     bd.j_lo = 0;
     bd.j_hi = (c == 0) ? 1 : D.n_cand;
