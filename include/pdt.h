@@ -37,6 +37,10 @@
  *   pdt_demod_f32       the same loop over GetComplexRawChunk (wave.c:413-540): RAW float32 captures
  *   pdt_frames          the fprintf stream of ByteSync.c, as records
  *   pdt_format_frames   the text ByteSync.c writes to the output file
+ *   pdt_tip_check       the downstream frame validation the reference keeps in MATLAB:
+ *                       standalone_matlab/Functionized/checkParity.m:1-92 (five even-parity checks per TIP
+ *                       minor frame) and daytimeDecode.m:1-40 (minor-frame counter, spacecraft id, day,
+ *                       millisecond of day, T0) -- SURVEY 8f #2
  *   pdt_make_lpf        MakeLPFIR (LowPassFilter.c:127-175)
  *   pdt_wav_parse_header ReadWavHeader (wave.c:303-378)
  */
@@ -174,6 +178,36 @@ uint64_t pdt_stage_len(const pdt_ctx *ctx, int stage);
  * pdt_format_frames.  (The reference ships exactly such a bit-string harness, commented out, at
  * POESTIPdemod/ByteSync.c:6-14.)                                                                  */
 int      pdt_stage_bytesync(pdt_ctx *ctx, const uint8_t *bits_host, uint64_t nbits);
+
+/* Frame validation of the POES minor frames of the last pdt_demod_* call (a per-frame kernel and a
+ * reduction on the GPU; the reference does this offline in MATLAB from the text file).  MATLAB is
+ * 1-indexed: its minorFrames(frame, w) is bytes[w-1] here.                                          */
+typedef struct pdt_tip_frame {
+    uint16_t minor_id;     /* 9-bit minor-frame counter ((bytes[4] & 1) << 8) | bytes[5]   (daytimeDecode.m:4)      */
+    uint8_t  spacecraft;   /* bytes[2]: 8 = NOAA-15, 13 = NOAA-18, 15 = NOAA-19            (daytimeDecode.m:16,82-93) */
+    uint8_t  parity;       /* bit g set = even-parity check g failed; g = 0..4 covers bytes 2-18, 19-35, 36-52,
+                              53-69, 70-86 against bits 5,4,3,2,1 of bytes[103]             (checkParity.m:20-86)  */
+    uint8_t  checked;      /* 1 = complete frame (only whole frames are rows of the reference's matrix)            */
+    uint8_t  has_time;     /* 1 = minor_id == 0: day / day_ms are valid                     (daytimeDecode.m:18)    */
+    uint16_t day;          /* (bytes[8] << 1) + ((bytes[9] | 128) >> 7), as the reference computes it (:19)         */
+    int32_t  day_ms;       /* ((bytes[9] & 7) << 24) + (bytes[10] << 16) + (bytes[11] << 8) + bytes[12];
+                              -1 when not below 86 400 000                                  (:22-29)               */
+} pdt_tip_frame;
+
+typedef struct pdt_tip_summary {
+    uint64_t frames_checked, good_frames;   /* "<good> out of <checked> Error Free Frames"  (checkParity.m:91)      */
+    uint64_t good_chunks, bad_chunks;       /* zeros / ones of the parity matrix            (checkParity.m:92)      */
+    int32_t  spacecraft;                    /* mode of the spacecraft ids, -1 = no frame    (daytimeDecode.m:82)    */
+    int32_t  day;                           /* mode of the day numbers of the major-frame starts, -1 = none (:95)   */
+    int64_t  t0_ms;                         /* mode(round(day_ms - 1000 * frame time)) over the positive ones,
+                                               -1 = none (capture start in spacecraft ms of day, :34-36)            */
+    uint64_t time_frames;                   /* frames with minor_id == 0                                             */
+} pdt_tip_summary;
+
+/* Runs the validation kernels on the frames of the last pdt_demod_* call (POES contexts only). */
+int      pdt_tip_check(pdt_ctx *ctx, pdt_tip_summary *out);
+/* Per-frame records of the last pdt_tip_check, in frame order; returns the number copied. */
+uint64_t pdt_tip_frames(const pdt_ctx *ctx, pdt_tip_frame *out, uint64_t max_frames);
 
 /* Per-kernel device times of the last call (cfg.profile = 1). Returns the entry count. */
 int      pdt_kernel_times(const pdt_ctx *ctx, pdt_kernel_time *out, int max_entries);

@@ -23,6 +23,20 @@ class OrcFrame(C.Structure):
                 ("complete", C.c_uint8), ("pad", C.c_uint8), ("bytes", C.c_uint8 * 104)]
 
 
+class OrcTipFrame(C.Structure):
+    _fields_ = [("minor_id", C.c_uint16), ("spacecraft", C.c_uint8), ("parity", C.c_uint8), ("checked", C.c_uint8),
+                ("has_time", C.c_uint8), ("day", C.c_uint16), ("day_ms", C.c_int32)]
+
+
+class OrcTipSummary(C.Structure):
+    _fields_ = [("frames_checked", C.c_uint64), ("good_frames", C.c_uint64), ("good_chunks", C.c_uint64),
+                ("bad_chunks", C.c_uint64), ("spacecraft", C.c_int32), ("day", C.c_int32), ("t0_ms", C.c_int64),
+                ("time_frames", C.c_uint64)]
+
+
+TIP_DTYPE = np.dtype([("minor_id", "<u2"), ("spacecraft", "u1"), ("parity", "u1"), ("checked", "u1"), ("has_time", "u1"),
+                      ("day", "<u2"), ("day_ms", "<i4")])
+
 _lib = None
 
 
@@ -163,3 +177,27 @@ class Oracle:
         a, b, c = C.c_uint64(), C.c_uint64(), C.c_uint64()
         f = self._L.orc_totals(self._h, C.byref(a), C.byref(b), C.byref(c))
         return a.value, b.value, c.value, f
+
+
+def tip_check(frames):
+    """frames: list of (time, bytes-like of 104, complete) or an array of OrcFrame -> (summary dict, records array).
+    Restatement of the reference's MATLAB checkParity.m / daytimeDecode.m (oracle_tip.c)."""
+    L = lib()
+    L.orc_tip_check.restype = None
+    L.orc_tip_check.argtypes = [C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p]
+    n = len(frames)
+    arr = (OrcFrame * max(n, 1))()
+    for i, fr in enumerate(frames):
+        if isinstance(fr, OrcFrame):
+            arr[i] = fr
+        else:
+            t, b, complete = fr
+            arr[i].time = float(t)
+            arr[i].nbytes = len(b)
+            arr[i].complete = 1 if complete else 0
+            for k, v in enumerate(bytes(b)[:104]):
+                arr[i].bytes[k] = v
+    out = np.zeros(max(n, 1), dtype=TIP_DTYPE)
+    sm = OrcTipSummary()
+    L.orc_tip_check(C.byref(arr), n, out.ctypes.data, C.byref(sm))
+    return {k: int(getattr(sm, k)) for k, _ in OrcTipSummary._fields_}, out[:n]

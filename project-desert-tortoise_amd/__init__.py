@@ -90,6 +90,16 @@ class Stats(C.Structure):
     ]
 
 
+class TipSummary(C.Structure):
+    _fields_ = [("frames_checked", C.c_uint64), ("good_frames", C.c_uint64), ("good_chunks", C.c_uint64),
+                ("bad_chunks", C.c_uint64), ("spacecraft", C.c_int32), ("day", C.c_int32), ("t0_ms", C.c_int64),
+                ("time_frames", C.c_uint64)]
+
+
+TIP_DTYPE = np.dtype([("minor_id", "<u2"), ("spacecraft", "u1"), ("parity", "u1"), ("checked", "u1"), ("has_time", "u1"),
+                      ("day", "<u2"), ("day_ms", "<i4")])        # == pdt_tip_frame (12 bytes)
+
+
 class KernelTime(C.Structure):
     _fields_ = [("name", C.c_char * 32), ("launches", C.c_uint32), ("total_ms", C.c_double)]
 
@@ -99,7 +109,7 @@ ABI_SYMBOLS = [
     "pdt_abi_version", "pdt_strerror", "pdt_device_count", "pdt_open", "pdt_close", "pdt_set_stream",
     "pdt_demod_pcm16", "pdt_demod_device", "pdt_demod_f32", "pdt_demod_device_f32", "pdt_num_frames", "pdt_frames", "pdt_get_stats",
     "pdt_format_frames", "pdt_read_stage", "pdt_stage_len", "pdt_kernel_times", "pdt_make_lpf",
-    "pdt_wav_parse_header", "pdt_time_axis", "pdt_stage_bytesync",
+    "pdt_wav_parse_header", "pdt_time_axis", "pdt_stage_bytesync", "pdt_tip_check", "pdt_tip_frames",
 ]
 
 _lib = None
@@ -145,6 +155,9 @@ def lib():
     L.pdt_time_axis.argtypes = [C.c_int, C.c_uint32, C.c_uint64]
     L.pdt_time_axis.restype = C.c_double
     L.pdt_stage_bytesync.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64]
+    L.pdt_tip_check.argtypes = [C.c_void_p, C.POINTER(TipSummary)]
+    L.pdt_tip_frames.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64]
+    L.pdt_tip_frames.restype = C.c_uint64
     if L.pdt_abi_version() != 1:
         raise PdtError("libpdt.so ABI version mismatch")
     _lib = L
@@ -280,6 +293,17 @@ class Demodulator:
                 _check(int(got), "pdt_read_stage")
             out = out[:got]
         return out
+
+    def tip_check(self):
+        """Frame validation of the last demodulation (the reference's MATLAB checkParity.m / daytimeDecode.m,
+        on the GPU): (summary dict, per-frame structured array)."""
+        sm = TipSummary()
+        _check(self._L.pdt_tip_check(self._h, C.byref(sm)), "pdt_tip_check")
+        n = self._L.pdt_num_frames(self._h)
+        rec = np.zeros(n, dtype=TIP_DTYPE)
+        if n:
+            self._L.pdt_tip_frames(self._h, rec.ctypes.data, n)
+        return {k: int(getattr(sm, k)) for k, _ in TipSummary._fields_}, rec
 
     def kernel_times(self) -> dict[str, tuple[int, float]]:
         n = self._L.pdt_kernel_times(self._h, None, 0)

@@ -85,7 +85,7 @@ struct pdt_ctx {
     hipEvent_t ev0 = nullptr, ev1 = nullptr, ev_fork = nullptr, ev_join = nullptr;
     hipStream_t stream2 = nullptr;     // side stream: block-parallel PLL phase runs beside the sequential acquisition
 
-    DevBuf pcm, pll, lock, fir, agc, sym, symidx, bits, bitsym, hits, frames, taps, mag, seams_pll, seams_agc, scal, lockinfo, term, seams_ema, gtable, gentries, gcand, gmfirst, stiles, gsegmap, gsegstart, gbands, gclist, agc_maps, pll_head, taps_rot, pll_scratch;
+    DevBuf pcm, pll, lock, fir, agc, sym, symidx, bits, bitsym, hits, frames, taps, mag, seams_pll, seams_agc, scal, lockinfo, term, seams_ema, gtable, gentries, gcand, gmfirst, stiles, gsegmap, gsegstart, gbands, gclist, agc_maps, pll_head, taps_rot, pll_scratch, tip;
     long long gcand_key = -1;          // (chunk_out, step) the candidate list on the device was built for
     bool force_sequential_gardner = false;
     int gardner_mode = 0;              // 0 sequential, 1 state table (last run)
@@ -96,6 +96,9 @@ struct pdt_ctx {
     // results
     uint64_t n_samples = 0, n_out = 0;
     std::vector<pdt_frame> frames_host;
+    std::vector<pdt_tip_frame> tip_host;
+    uint32_t frames_on_device = 0;      // FrameRec records of the last demodulation still in ctx->frames
+    bool have_frames = false;           // a demodulation (or stage-level byte sync) has run
     pdt_stats stats;
     std::vector<pdt_kernel_time> ktimes;
     std::vector<KTimer> timers;
@@ -707,6 +710,9 @@ template <typename T> int run_capture(pdt_ctx *ctx, uint64_t n)
 
     // ---- time stamps (host): SURVEY Appendix B Q1/Q2/Q4
     ctx->frames_host.resize(sc.nframes);
+    ctx->frames_on_device = sc.nframes;
+    ctx->have_frames = true;
+    ctx->tip_host.clear();
     for (unsigned f = 0; f < sc.nframes; f++) {
         pdt_frame &o = ctx->frames_host[f];
         const FrameRec &r = recs[f];
@@ -903,7 +909,7 @@ void pdt_close(pdt_ctx *ctx)
     DevBuf *bufs[] = { &ctx->pcm, &ctx->pll, &ctx->lock, &ctx->fir, &ctx->agc, &ctx->sym, &ctx->symidx, &ctx->bits, &ctx->bitsym,
                        &ctx->hits, &ctx->frames, &ctx->taps, &ctx->mag, &ctx->seams_pll, &ctx->seams_agc, &ctx->scal, &ctx->lockinfo,
                        &ctx->term, &ctx->seams_ema, &ctx->gtable, &ctx->gentries, &ctx->gcand,
-                       &ctx->gmfirst, &ctx->stiles, &ctx->gsegmap, &ctx->gsegstart, &ctx->gbands, &ctx->gclist, &ctx->agc_maps, &ctx->pll_head, &ctx->taps_rot, &ctx->pll_scratch };
+                       &ctx->gmfirst, &ctx->stiles, &ctx->gsegmap, &ctx->gsegstart, &ctx->gbands, &ctx->gclist, &ctx->agc_maps, &ctx->pll_head, &ctx->taps_rot, &ctx->pll_scratch, &ctx->tip };
     for (DevBuf *b : bufs) b->release();
     if (ctx->ev0) (void)hipEventDestroy(ctx->ev0);
     if (ctx->ev1) (void)hipEventDestroy(ctx->ev1);
@@ -1013,6 +1019,9 @@ int pdt_stage_bytesync(pdt_ctx *ctx, const uint8_t *bits_host, uint64_t nbits)
     std::vector<FrameRec> recs(sc.nframes);
     if (sc.nframes) HIP_TRY(hipMemcpy(recs.data(), ctx->frames.p, (size_t)sc.nframes * sizeof(FrameRec), hipMemcpyDeviceToHost));
     ctx->frames_host.resize(sc.nframes);
+    ctx->frames_on_device = sc.nframes;
+    ctx->have_frames = true;
+    ctx->tip_host.clear();
     for (unsigned f = 0; f < sc.nframes; f++) {
         pdt_frame &o = ctx->frames_host[f];
         memset(&o, 0, sizeof o);
@@ -1030,6 +1039,74 @@ int pdt_stage_bytesync(pdt_ctx *ctx, const uint8_t *bits_host, uint64_t nbits)
     ctx->stats.sync_overflow = sc.sync_overflow;
     memset(ctx->stage_len, 0, sizeof ctx->stage_len);
     return PDT_OK;
+}
+
+// ---------------------------------------------------------------- frame validation
+static_assert(sizeof(pdt_tip_frame) == sizeof(pdt::TipFrame) && sizeof(pdt_tip_frame) == 12, "pdt_tip_frame layout");
+
+int pdt_tip_check(pdt_ctx *ctx, pdt_tip_summary *out)
+{
+    if (!ctx || !out) return PDT_ERR_ARG;
+    if (ctx->cfg.mode != PDT_MODE_POES) return PDT_ERR_ARG;             // TIP minor frames only
+    if (hipSetDevice(ctx->cfg.device) != hipSuccess) return PDT_ERR_NOGPU;
+    const unsigned nf = ctx->frames_on_device;
+    if (!ctx->have_frames || nf != ctx->frames_host.size()) return PDT_ERR_STATE;   // nothing demodulated yet
+    memset(out, 0, sizeof *out);
+    out->spacecraft = -1;
+    out->day = -1;
+    out->t0_ms = -1;
+    ctx->tip_host.assign(nf, pdt_tip_frame{});
+    if (nf == 0) return PDT_OK;
+    int rc;
+    if ((rc = ctx->tip.ensure(sizeof(TipCounters) + (size_t)nf * sizeof(TipFrame)))) return rc;
+    TipCounters *d_cnt = (TipCounters *)ctx->tip.p;
+    TipFrame *d_rec = (TipFrame *)(d_cnt + 1);
+    hipStream_t st = ctx->stream;
+    HIP_TRY(hipMemsetAsync(d_cnt, 0, sizeof(TipCounters), st));
+    hipLaunchKernelGGL(k_tip_check, dim3((nf + 255) / 256), dim3(256), 0, st, (const FrameRec *)ctx->frames.p, nf, d_rec, d_cnt);
+    HIP_TRY(hipGetLastError());
+    TipCounters cnt;
+    HIP_TRY(hipMemcpyAsync(&cnt, d_cnt, sizeof cnt, hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipMemcpyAsync(ctx->tip_host.data(), d_rec, (size_t)nf * sizeof(TipFrame), hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipStreamSynchronize(st));
+    out->frames_checked = cnt.frames_checked;
+    out->good_frames = cnt.good_frames;
+    out->bad_chunks = cnt.bad_chunks;
+    out->good_chunks = 5 * cnt.frames_checked - cnt.bad_chunks;
+    out->time_frames = cnt.time_frames;
+    // MATLAB mode(): most frequent value, the smallest one on ties
+    unsigned best = 0;
+    for (int v = 0; v < 256; v++) if (cnt.hist_sc[v] > best) { best = cnt.hist_sc[v]; out->spacecraft = v; }
+    best = 0;
+    for (int v = 0; v < 512; v++) if (cnt.hist_day[v] > best) { best = cnt.hist_day[v]; out->day = v; }
+    // T0 = spacecraft ms of day minus the local frame time (daytimeDecode.m:26,34); frameTime is what the text
+    // file holds ("%.5f"); the time stamps live on the host (pdt_timeaxis.h), so this small reduction does too
+    std::vector<double> t0;
+    for (unsigned f = 0; f < nf; f++) {
+        const pdt_tip_frame &r = ctx->tip_host[f];
+        if (r.has_time && r.day_ms >= 0) {
+            const double t = round(ctx->frames_host[f].time * 1e5) / 1e5;
+            const double v = (double)r.day_ms - t * 1000.0;
+            if (v > 0) t0.push_back(round(v));
+        }
+    }
+    std::sort(t0.begin(), t0.end());
+    size_t best_n = 0;
+    for (size_t i = 0; i < t0.size();) {
+        size_t j = i;
+        while (j < t0.size() && t0[j] == t0[i]) j++;
+        if (j - i > best_n) { best_n = j - i; out->t0_ms = (int64_t)t0[i]; }
+        i = j;
+    }
+    return PDT_OK;
+}
+
+uint64_t pdt_tip_frames(const pdt_ctx *ctx, pdt_tip_frame *out, uint64_t max_frames)
+{
+    if (!ctx) return 0;
+    const uint64_t n = std::min<uint64_t>(max_frames, ctx->tip_host.size());
+    if (out && n) memcpy(out, ctx->tip_host.data(), (size_t)n * sizeof(pdt_tip_frame));
+    return n;
 }
 
 uint64_t pdt_num_frames(const pdt_ctx *ctx) { return ctx ? ctx->frames_host.size() : 0; }

@@ -1662,4 +1662,60 @@ __global__ void k_iota(unsigned *__restrict__ bitsym, long long *__restrict__ sy
     if (i < n) { bitsym[i] = (unsigned)i; symidx[i] = i; }
 }
 
+// ------------------------------------------------------------------------------------------
+// Frame validation (reference: standalone_matlab/Functionized/checkParity.m:1-92,
+// daytimeDecode.m:1-40; MATLAB's minorFrames(frame, w) is bytes[w-1]).  One thread per frame;
+// the summary counters and the two histograms MATLAB's mode() needs are accumulated with atomics.
+// ------------------------------------------------------------------------------------------
+struct TipFrame {            // == pdt_tip_frame
+    unsigned short minor_id;
+    unsigned char spacecraft, parity, checked, has_time;
+    unsigned short day;
+    int day_ms;
+};
+struct TipCounters {
+    unsigned long long frames_checked, good_frames, bad_chunks, time_frames;
+    unsigned hist_sc[256];
+    unsigned hist_day[512];
+};
+
+__global__ void __launch_bounds__(256) k_tip_check(const FrameRec *__restrict__ frames, unsigned nframes,
+                                                    TipFrame *__restrict__ out, TipCounters *__restrict__ cnt)
+{
+    const unsigned f = blockIdx.x * blockDim.x + threadIdx.x;
+    if (f >= nframes) return;
+    const FrameRec &fr = frames[f];
+    TipFrame o;
+    o.minor_id = 0; o.spacecraft = 0; o.parity = 0; o.checked = 0; o.has_time = 0; o.day = 0; o.day_ms = 0;
+    if (fr.complete && fr.nbytes == 104) {
+        const unsigned char *b = fr.bytes;
+        o.checked = 1;
+        // five groups of 17 bytes starting at byte 2; parity bits 5..1 of byte 103 (checkParity.m:20-86)
+        unsigned bad = 0;
+#pragma unroll
+        for (int g = 0; g < 5; g++) {
+            unsigned ones = 0;
+            for (int w = 0; w < 17; w++) ones += (unsigned)__popc((unsigned)b[2 + 17 * g + w]);
+            const unsigned bit = ((unsigned)b[103] >> (5 - g)) & 1u;
+            bad |= ((ones & 1u) != bit) ? (1u << g) : 0u;
+        }
+        o.parity = (unsigned char)bad;
+        o.minor_id = (unsigned short)(((b[4] & 1u) << 8) | b[5]);                  // daytimeDecode.m:4
+        o.spacecraft = b[2];                                                       // :16
+        atomicAdd(&cnt->frames_checked, 1ull);
+        if (bad == 0) atomicAdd(&cnt->good_frames, 1ull);
+        atomicAdd(&cnt->bad_chunks, (unsigned long long)__popc(bad));
+        atomicAdd(&cnt->hist_sc[o.spacecraft], 1u);
+        if (o.minor_id == 0) {                                                     // :18-31
+            o.has_time = 1;
+            o.day = (unsigned short)(((unsigned)b[8] << 1) + (((unsigned)b[9] | 128u) >> 7));
+            const int ms = (int)(((unsigned)(b[9] & 7u) << 24) + ((unsigned)b[10] << 16) + ((unsigned)b[11] << 8) + (unsigned)b[12]);
+            o.day_ms = (ms < 86400000) ? ms : -1;
+            atomicAdd(&cnt->time_frames, 1ull);
+            atomicAdd(&cnt->hist_day[o.day], 1u);
+        }
+    }
+    out[f] = o;
+}
+
 }  // namespace pdt

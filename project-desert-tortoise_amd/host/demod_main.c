@@ -16,7 +16,8 @@
  *   output name minorFrames_YYYYMMDD_HHMMSS.txt / packets_YYYYMMDD_HHMMSS.txt   main.c:289 / ARGOS main.c:213
  *   "Normalization Factor: %f", " : PLL locked at %0.2fHz"                  main.c:388, CarrierTrackingPLL.c:269
  *   output removed when no frame was found             main.c:508-512
- * Additions: -o <file> chooses the output name (tests), -d <n> picks the GPU.
+ * Additions: -o <file> chooses the output name (tests), -d <n> picks the GPU, -q (POES) prints the frame
+ * validation the reference keeps in MATLAB (checkParity.m:91-92, daytimeDecode.m:36,82-95) after decoding.
  * Not reproduced: the per-chunk "\r" progress line (there are no chunks on the GPU; one
  * summary line is printed instead).  RAW float32 input (".raw", -s mandatory) is supported for POES
  * exactly as in POESTIPdemod/main.c:313-339.
@@ -41,7 +42,7 @@
 #else
 #define MODE PDT_MODE_POES
 #define DEFAULT_CHUNKSIZE 10000
-#define OPTS "s:rn:c:o:d:"
+#define OPTS "s:rn:c:o:d:q"
 #define BANNER "Project Desert Tortoise: Wave file NOAA TIP Demodulator (MI355X build)\n"
 #define PREFIX "minorFrames"
 #define UNIT "Frames"
@@ -58,7 +59,7 @@ int main(int argc, char **argv)
 {
     unsigned long chunkSize = DEFAULT_CHUNKSIZE;
     double normFactor = 0, sampleRate = 0;
-    int outputRawFiles = 0, device = 0, c;
+    int outputRawFiles = 0, device = 0, quality = 0, c;
     const char *outOverride = NULL;
     char outFileName[1100];
 
@@ -86,6 +87,9 @@ int main(int argc, char **argv)
             break;
         case 'd':
             device = atoi(optarg);
+            break;
+        case 'q':
+            quality = 1;
             break;
         case '?':
             if (optopt == 's' || optopt == 'c' || optopt == 'n')
@@ -235,6 +239,25 @@ int main(int argc, char **argv)
     printf("100.0%% %0.3f Ks : %llu Sym : %llu Bits : %llu " UNIT "   (GPU %.3f ms)\n", st.samples / 1000.0,
            (unsigned long long)st.symbols, (unsigned long long)st.bits, (unsigned long long)st.frames, st.gpu_ms);
 
+#ifndef PDT_ARGOS
+    if (quality) {
+        pdt_tip_summary q;
+        if (pdt_tip_check(ctx, &q) == PDT_OK) {
+            const char *name = q.spacecraft == 8 ? "NOAA-15" : q.spacecraft == 13 ? "NOAA-18" : q.spacecraft == 15 ? "NOAA-19" : "A UFO!";
+            printf("\n%llu out of %llu Error Free Frames\n\n", (unsigned long long)q.good_frames, (unsigned long long)q.frames_checked);
+            printf("%llu Good Chunks and %llu Bad Chunks\n\n", (unsigned long long)q.good_chunks, (unsigned long long)q.bad_chunks);
+            if (q.t0_ms >= 0) {
+                const double h = (double)q.t0_ms / 3600000.0;
+                const int hh = (int)h, mm = (int)((h - hh) * 60.0);
+                printf("T0 Best Guess: %lld which is %d:%d:%g\n", (long long)q.t0_ms, hh, mm, ((h - hh) * 60.0 - mm) * 60.0);
+            }
+            printf("Spacecraft: %d=>%s\n", q.spacecraft, name);
+            if (q.day >= 0) printf("Julean Day: %d \n", q.day);
+        }
+    }
+#else
+    (void)quality;
+#endif
     time_t t2 = time(NULL);
     struct tm tm2 = *localtime(&t2);
     printf("\nThat took %d seconds!\n", (tm2.tm_min * 60 + tm2.tm_sec) - (tm.tm_min * 60 + tm.tm_sec));

@@ -1,0 +1,107 @@
+"""Frame validation on the GPU (pdt_tip_check) against the oracle's restatement of the
+reference's MATLAB checkParity.m / daytimeDecode.m: bit-exact per-frame records and summary."""
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+
+
+def oracle_from_gpu_frames(orc, frames):
+    return orc.tip_check([(float(f["time"]), bytes(f["bytes"][: int(f["nbytes"])]), bool(f["complete"])) for f in frames])
+
+
+def compare(pdt, orc, d):
+    frames = d.frames_array()
+    want_sm, want = oracle_from_gpu_frames(orc, frames)
+    got_sm, got = d.tip_check()
+    assert got_sm == want_sm
+    assert got.dtype == want.dtype and np.array_equal(got.view(np.uint8), want.view(np.uint8))
+    return got_sm, got
+
+
+def test_real_capture(pdt, orc):
+    rate, iq = pdt.read_wav(os.path.join(HERE, "golden", "5sec_clip.wav"))
+    with pdt.Demodulator(pdt.MODE_POES, rate) as d:
+        d.demod(iq)
+        sm, rec = compare(pdt, orc, d)
+    assert sm["frames_checked"] == 47 and sm["good_frames"] == 47 and sm["bad_chunks"] == 0
+    assert sm["spacecraft"] == 8                       # NOAA-15
+    assert rec["checked"][-1] == 0                     # partial last frame
+
+
+def test_synthetic_capture_random_payload(pdt, orc):
+    """The synthetic generator fills frames with pseudo-random bytes: parity bits are right by chance only, so both
+    outcomes of every check occur; minor-frame counters / time fields are random too."""
+    iq = pdt.synth_capture(0, 50000, 60.0, seed=99)
+    with pdt.Demodulator(pdt.MODE_POES, 50000) as d:
+        d.demod(iq)
+        sm, rec = compare(pdt, orc, d)
+    assert sm["frames_checked"] >= 598
+    assert 0 < sm["bad_chunks"] < 5 * sm["frames_checked"]
+    assert 0 < sm["good_chunks"]
+
+
+def test_crafted_bitstream_with_time_frames(pdt, orc):
+    """Frames built bit by bit (sync word + 813 payload bits) through the stage-level entry: major-frame starts
+    with valid and invalid ms-of-day, all spacecraft ids, single-bit errors in every parity group."""
+    rng = np.random.default_rng(5)
+    sync = "1110110111100010000"
+
+    def frame_bits(b):                      # bytes 0,1 are the literal ED E2; byte 2 has 5 payload bits after the sync
+        bits = "".join(f"{x:08b}" for x in b)
+        return sync + bits[19:]
+
+    frames = []
+    for i in range(400):
+        b = bytearray(rng.integers(0, 256, 104, dtype=np.uint8).tobytes())
+        b[0], b[1] = 0xED, 0xE2
+        b[2] = (b[2] & 0x1F)                # only 5 bits of byte 2 follow the sync word (first_bits = 5): 0b000xxxxx
+        if i % 7 == 0:
+            b[4] &= 0xFE; b[5] = 0          # minor frame 0
+            if i % 14 == 0:
+                ms = int(rng.integers(0, 86400000))
+                b[9] = (b[9] & 0xF8) | ((ms >> 24) & 7); b[10] = (ms >> 16) & 255; b[11] = (ms >> 8) & 255; b[12] = ms & 255
+            else:
+                b[9] |= 7; b[10] = 0xFF     # >= 86 400 000
+        # make the five parities right, then break one group in some frames
+        p = 0
+        for g in range(5):
+            ones = sum(bin(x).count("1") for x in b[2 + 17 * g: 19 + 17 * g])
+            p |= (ones & 1) << (5 - g)
+        b[103] = (b[103] & 0xC1) | p
+        if i % 5 == 0:
+            b[2 + 17 * (i % 5) + 3] ^= 0x40
+        if i % 11 == 0:
+            g = i % 5
+            b[2 + 17 * g + 9] ^= 0x02
+        frames.append(bytes(b))
+    s = "".join(rng.choice(["0", "1"], size=77)) + "".join(frame_bits(b) for b in frames) + sync + "0101"
+    bits = np.frombuffer(s.encode(), dtype=np.uint8).copy()
+    with pdt.Demodulator(pdt.MODE_POES, 50000) as d:
+        d.bytesync(bits)
+        sm, rec = compare(pdt, orc, d)
+    assert sm["frames_checked"] == 400 and sm["time_frames"] >= 40
+    assert 0 < sm["good_frames"] < 400
+    assert np.any(rec["day_ms"] == -1) and np.any(rec["day_ms"] > 0)
+
+
+def test_errors_and_cli(pdt, orc, tmp_path):
+    with pdt.Demodulator(pdt.MODE_POES, 50000) as d:
+        with pytest.raises(pdt.PdtError):
+            d.tip_check()                                   # nothing demodulated yet
+    with pdt.Demodulator(pdt.MODE_ARGOS, 32000) as d:
+        d.demod(np.zeros((5000, 2), dtype=np.int16))
+        with pytest.raises(pdt.PdtError):
+            d.tip_check()                                   # ARGOS packets are not TIP frames
+    out = tmp_path / "mf.txt"
+    r = subprocess.run([os.path.join(ROOT, "bin", "demodPOES"), "-q", "-o", str(out), os.path.join(HERE, "golden", "5sec_clip.wav")],
+                       capture_output=True, text=True, check=True)
+    assert "47 out of 47 Error Free Frames" in r.stdout
+    assert "235 Good Chunks and 0 Bad Chunks" in r.stdout
+    assert "Spacecraft: 8=>NOAA-15" in r.stdout
