@@ -536,7 +536,7 @@ template <typename T> int run_capture(pdt_ctx *ctx, uint64_t n)
     // single-wavefront sequential chain.
     bool use_table = false;
     GardnerDomain GD;
-    GD.q_min = 0; GD.u = 0; GD.n_q = 0; GD.n_cand = 0; GD.pad_q = 0;
+    GD.q_min = 0; GD.u = 0; GD.n_q = 0; GD.n_cand = 0; GD.pad_q = 0; GD.idx_bits = 20;
     if constexpr (std::is_same<T, float>::value) {
         const int table_len = 1 << 22;     // the table kernel walks the chunk in LDS windows: no size limit of its own
         const float nT = (float)chunk_out, stepf = (float)GP.step;
@@ -549,11 +549,15 @@ template <typename T> int run_capture(pdt_ctx *ctx, uint64_t n)
             const int n_q = (int)ceilf((stepf + 1.8f) / u);
             const float q_max = q_min + (float)n_q * u;
             const double max_count = (double)chunk_out / ((double)stepf - 0.11) + 2.0;
-            if (q_min >= ldexpf(1.0f, e - 1) && q_max < ldexpf(1.0f, e) && 2 * (long long)n_q < (1 << 20) && max_count < 4095.0) {
+            int idx_bits = 1;
+            while ((1ll << idx_bits) < 2 * (long long)n_q) idx_bits++;
+            if (q_min >= ldexpf(1.0f, e - 1) && q_max < ldexpf(1.0f, e) && idx_bits <= 20 &&
+                max_count < (double)((1u << (32 - idx_bits)) - 2u) && max_count < 65000.0) {
                 use_table = true;
                 GD.q_min = q_min;
                 GD.u = u;
                 GD.n_q = n_q;
+                GD.idx_bits = idx_bits;
                 const double pad = ctx->cfg.gardner_band_pad > 0 ? ctx->cfg.gardner_band_pad : 1.0 / 8.0;
                 GD.pad_q = std::max(2, (int)(pad / (double)u));
             }

@@ -280,7 +280,8 @@ struct GardnerDomain {
     float u;           // grid spacing (ulp of the binade that contains the chunk end)
     int n_q;           // number of q values; table row = 2 * n_q cells (two choices of the last pick)
     int n_cand;        // consistent (q, pick) combinations, listed in cand_k in increasing q
-    int pad_q;         // candidates are tabulated this many grid points beyond the scouts' hull (default 1/2 sample)
+    int pad_q;         // candidates are tabulated within this many grid points of a scout's end point
+    int idx_bits;      // table cell = candidate index (low idx_bits bits) | symbol count of the chunk (the rest)
 };
 
 #define PDT_GTAB_TAIL 4096           // samples of the previous chunk the scouts run over
@@ -306,14 +307,15 @@ __device__ __forceinline__ void gardner_entry_from_candidate(const float *__rest
     prev = in[(c - 1) * P.chunk_out + i_last];
 }
 
-// exit state -> table cell (20-bit candidate index | 12-bit symbol count); MISS if outside the domain
+// exit state -> table cell (candidate index | symbol count, split at D.idx_bits); MISS if outside the domain
 __device__ __forceinline__ unsigned gardner_encode_exit(const GardnerDomain &D, float q_last, unsigned i_last, unsigned count)
 {
     const float mf = (q_last - D.q_min) / D.u;               // exact small integer for in-domain states
     const int m = (int)mf;
     const int v = (int)i_last - (int)floorf(q_last);
-    const bool ok = (count > 0) && (mf == (float)m) && (m >= 0) && (m < D.n_q) && (v == 0 || v == 1) && (count < 4096u);
-    return ok ? (((unsigned)(2 * m + v)) | (count << 20)) : PDT_GTAB_MISS;
+    const bool ok = (count > 0) && (mf == (float)m) && (m >= 0) && (m < D.n_q) && (v == 0 || v == 1) &&
+                    (count < (1u << (32 - D.idx_bits)) - 1u);
+    return ok ? (((unsigned)(2 * m + v)) | (count << D.idx_bits)) : PDT_GTAB_MISS;
 }
 
 
@@ -920,8 +922,8 @@ __global__ void __launch_bounds__(1024) k_gardner_segmap(const unsigned *__restr
         for (int g = 0; g < G; g++) {
             const unsigned cell = table[(size_t)(c0 + g) * stride + k];
             if (cell == PDT_GTAB_MISS) { ok = false; break; }
-            k = cell & 0xfffffu;
-            total += cell >> 20;
+            k = cell & ((1u << D.idx_bits) - 1u);
+            total += cell >> D.idx_bits;
         }
         GardnerSegCell sc;
         sc.next = ok ? k : PDT_GTAB_MISS;
@@ -987,8 +989,8 @@ __global__ void __launch_bounds__(PDT_GARDNER_THREADS) k_gardner_chain(const flo
                 continue;
             }
         }
-        key = cell & 0xfffffu;
-        off += (long long)(cell >> 20);
+        key = cell & ((1u << D.idx_bits) - 1u);
+        off += (long long)(cell >> D.idx_bits);
         have_key = true;
         c++;
     }
@@ -1016,8 +1018,8 @@ __global__ void __launch_bounds__(64) k_gardner_segfill(const float *__restrict_
             s_key[g] = k;
             s_off[g] = off;
             const unsigned cell = table[(size_t)(c0 + g) * stride + k];
-            k = cell & 0xfffffu;
-            off += (long long)(cell >> 20);
+            k = cell & ((1u << D.idx_bits) - 1u);
+            off += (long long)(cell >> D.idx_bits);
         }
     }
     __syncthreads();
