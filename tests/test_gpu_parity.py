@@ -255,6 +255,27 @@ def test_ten_minute_capture_matches_oracle(pdt, orc):
         assert d.stats().frames == len(o.frames()) >= 5990
 
 
+def test_250ksps_capture_matches_oracle(pdt, orc):
+    """BASELINE configs[2]/[4] geometry (250 ksps, interp 1, 26 taps) on a 2-minute, 30 000 000-sample capture:
+    bit-exact output file vs the CPU oracle, every transmitted frame in order.  (tools/c3_check.py runs the
+    10-minute / 150 M-sample version against the reference's own objects.)"""
+    fs, secs, seed = 250000, 120.0, 31
+    iq = pdt.synth_capture(0, fs, secs, seed=seed)
+    o = orc.Oracle(orc.POES, fs, iq, keep_stages=False)
+    par = pdt.synth_params(0, fs, 1000.0, seed)
+    with pdt.Demodulator(pdt.MODE_POES, fs) as d:
+        d.demod(iq)
+        assert d.text() == o.text()
+        fr = d.frames_array()
+        st = d.stats()
+    assert st.interp == 1 and st.ntaps == 26 and st.gardner_parallel == 1
+    complete = fr[fr["complete"] == 1]
+    assert len(complete) >= 1190
+    sent = {bytes(pdt.synth_poes_frame(par, k)): k for k in range(0, 1210)}
+    idx = [sent.get(bytes(f["bytes"])) for f in complete]
+    assert all(i is not None for i in idx) and idx == list(range(idx[0], idx[0] + len(idx)))
+
+
 def test_cli_demodpoes(pdt, tmp_path):
     exe = os.path.join(ROOT, "bin", "demodPOES")
     out = tmp_path / "mf.txt"
