@@ -29,7 +29,8 @@
  *                       StaticGain (AGC.c:48-75), CarrierTrackPLL (CarrierTrackingPLL.c:54-278),
  *                       LowPassFilterInterp / LowPassFilter (LowPassFilter.c:13-71,76-125),
  *                       NormalizingAGC (AGC.c:78-132), Squelch (AGC.c:24-46),
- *                       GardenerClockRecovery (GardenerClockRecovery.c:5-114),
+ *                       GardenerClockRecovery (GardenerClockRecovery.c:5-114) or, on request,
+ *                       MMClockRecovery (MMClockRecovery.c:5-83),
  *                       ManchesterDecode (ManchesterDecode.c:10-100),
  *                       ByteSyncOnSyncword (POESTIPdemod/ByteSync.c:16-150) /
  *                       FindSyncWords (ARGOSdemod/ByteSync.c:17-150)
@@ -56,6 +57,7 @@ extern "C" {
 #define PDT_ABI_VERSION 1
 
 enum { PDT_MODE_POES = 0, PDT_MODE_ARGOS = 1 };
+enum { PDT_SAMPLER_GARDNER = 0, PDT_SAMPLER_MM = 1 };
 
 enum {
     PDT_OK = 0,
@@ -98,6 +100,12 @@ typedef struct pdt_config {
      * symbols, so a wider pad costs little).  Smaller = less work, more chunks
      * walked serially; the result never depends on it.                                            */
     double   gardner_band_pad;
+    /* Symbol sampler: 0 = GardenerClockRecovery (what the reference runs); 1 = MMClockRecovery
+     * (common/MMClockRecovery.c:5-83) at the same call site -- the switch the reference keeps commented out
+     * (ARGOSdemod/main.c:277) -- with stepRange / kp below (0 = that call's values, 3 and 0.15).          */
+    int32_t  sampler;
+    int32_t  reserved;
+    double   mm_step_range, mm_kp;
 } pdt_config;
 
 typedef struct pdt_frame {

@@ -119,13 +119,17 @@ class Oracle:
     objects), MATH_PORTABLE = the plain-double evaluation the HIP kernels use."""
 
     def __init__(self, mode: int, sample_rate: int, iq: np.ndarray, chunk: int = 0, norm_override: float = 0.0,
-                 keep_stages: bool = True, math_mode: int = MATH_LIBM):
+                 keep_stages: bool = True, math_mode: int = MATH_LIBM, sampler: int = 0, mm_range: float = 3.0,
+                 mm_kp: float = 0.15):
         L = lib()
         L.orc_set_math_mode(math_mode)
         self._L = L
         self.mode = mode
         self.dtype = np.float64 if mode == ARGOS else np.float32
         self._h = L.orc_open(mode, sample_rate, chunk, norm_override, int(keep_stages))
+        L.orc_set_sampler.argtypes = [C.c_void_p, C.c_int, C.c_double, C.c_double]
+        L.orc_set_sampler.restype = None
+        L.orc_set_sampler(self._h, sampler, mm_range, mm_kp)      # 1 = MMClockRecovery instead of Gardner
         if np.asarray(iq).dtype.kind == "f":                     # RAW float32 capture
             a = np.ascontiguousarray(iq, dtype="<f4").reshape(-1)
             L.orc_run_f32(self._h, a.ctypes.data, a.size // 2)

@@ -20,7 +20,9 @@
 #define SIN(x) sinf(x)
 #define HYPOT(x, y) orc_hypotf((x), (y))
 #define RINT(x) rintf(x)
+#define RINT_MM(x) rintf(x)                 /* MMClockRecovery.c:25,28: rint() through tgmath.h on a float */
 #include "oracle_dsp_tmpl.inc"
+#undef RINT_MM
 #undef DT
 #undef SFX
 #undef SINCOS
@@ -41,7 +43,9 @@
 #define SIN(x) sin(x)
 #define HYPOT(x, y) orc_hypot((x), (y))
 #define RINT(x) rint(x)
+#define RINT_MM(x) ((double)rintf((float)(x)))  /* MMClockRecovery.c:55,58: the double build calls rintf (sic) */
 #include "oracle_dsp_tmpl.inc"
+#undef RINT_MM
 #undef DT
 #undef SFX
 #undef SINCOS

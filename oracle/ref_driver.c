@@ -46,6 +46,7 @@
 #include "CarrierTrackPLL.h"
 #include "LowPassFilter.h"
 #include "GardenerClockRecovery.h"
+#include "MMClockRecovery.h"
 #include "ManchesterDecode.h"
 #ifdef ARGOS
 int FindSyncWords(unsigned char *, DT *, unsigned long, char *, unsigned int, FILE *);
@@ -74,8 +75,13 @@ int main(int argc, char **argv)
 #endif
     DT normFactor = 0, sampleRate = 0;
     const char *dump = NULL;
+    int use_mm = 0;              /* -M: MMClockRecovery at the sampler's call site (ARGOSdemod/main.c:277, commented out there) */
+    DT mmRange = 3, mmKp = 0.15;
     int c;
-    while ((c = getopt(argc, argv, "c:n:s:d:")) != -1) {
+    while ((c = getopt(argc, argv, "c:n:s:d:MR:K:")) != -1) {
+        if (c == 'M') { use_mm = 1; continue; }
+        if (c == 'R') { mmRange = atof(optarg); continue; }
+        if (c == 'K') { mmKp = atof(optarg); continue; }
         if (c == 'c') chunk = atoi(optarg);
         else if (c == 'n') normFactor = atof(optarg);
         else if (c == 's') sampleRate = atof(optarg);
@@ -168,7 +174,10 @@ int main(int argc, char **argv)
         NormalizingAGC(dataStreamReal, nSamples, normFactor, (79.5775) * (2.0 * M_PI / Fs), (159.1549) * (2.0 * M_PI / Fs));
         Squelch(dataStreamReal, lockSignalStream, nSamples, (0.15));
         dput(dagc, dataStreamReal, sizeof(DT), nSamples);
-        nSymbols = GardenerClockRecovery(dataStreamReal, waveDataTime, nSamples, dataStreamSymbols, Fs, (400 * 2.0), (0.1), (3.0));
+        if (use_mm)
+            nSymbols = MMClockRecovery(dataStreamReal, waveDataTime, nSamples, dataStreamSymbols, Fs, (400 * 2.0), mmRange, mmKp);
+        else
+            nSymbols = GardenerClockRecovery(dataStreamReal, waveDataTime, nSamples, dataStreamSymbols, Fs, (400 * 2.0), (0.1), (3.0));
         dput(dsym, dataStreamSymbols, sizeof(DT), nSymbols);
         dput(dsymt, waveDataTime, sizeof(DT), nSymbols);
         nBits = ManchesterDecode(dataStreamSymbols, waveDataTime, nSymbols, dataStreamBits, (0.5));
@@ -185,8 +194,12 @@ int main(int argc, char **argv)
         NormalizingAGC(dataStreamLPF, nSamples * interp, normFactor, (79.5775) * (2.0 * M_PI / (Fs * interp)),
                        (159.1549) * (2.0 * M_PI / (Fs * interp)));
         dput(dagc, dataStreamLPF, sizeof(DT), nSamples * interp);
-        nSymbols = GardenerClockRecovery(dataStreamLPF, dataStreamLPFTime, nSamples * interp, dataStreamSymbols,
-                                         Fs * interp, (8320 * 2 + 0.3), (0.1), (3.0));
+        if (use_mm)
+            nSymbols = MMClockRecovery(dataStreamLPF, dataStreamLPFTime, nSamples * interp, dataStreamSymbols,
+                                       Fs * interp, (8320 * 2 + 0.3), mmRange, mmKp);
+        else
+            nSymbols = GardenerClockRecovery(dataStreamLPF, dataStreamLPFTime, nSamples * interp, dataStreamSymbols,
+                                             Fs * interp, (8320 * 2 + 0.3), (0.1), (3.0));
         dput(dsym, dataStreamSymbols, sizeof(DT), nSymbols);
         dput(dsymt, dataStreamLPFTime, sizeof(DT), nSymbols);
         nBits = ManchesterDecode(dataStreamSymbols, dataStreamLPFTime, nSymbols, dataStreamBits, 1.0);

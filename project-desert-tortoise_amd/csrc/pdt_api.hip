@@ -319,7 +319,12 @@ template <typename T> int run_capture(pdt_ctx *ctx, uint64_t n)
     const long long nb_agc = (n_out + Ba - 1) / Ba + 1;
 
     // ---- capacities
-    const double min_step = (double)GP.step - 0.25;
+    double min_step = (double)GP.step - 0.25;
+    if (ctx->cfg.sampler == PDT_SAMPLER_MM) {
+        const double rg = ctx->cfg.mm_step_range != 0 ? ctx->cfg.mm_step_range : 3.0;
+        if (!(rg >= 0) || rg >= (double)baud * 0.5) return PDT_ERR_ARG;        // stepMax must stay positive and finite
+        min_step = (double)(int)fsi / ((double)baud + rg) * 0.999;
+    }
     const long long n_chunks = chunk_out > 0 ? (n_out + chunk_out - 1) / chunk_out : 0;
     const long long sym_cap = (long long)((double)n_out / min_step) + n_chunks + 64;
     const long long bit_cap = sym_cap;
@@ -534,13 +539,14 @@ template <typename T> int run_capture(pdt_ctx *ctx, uint64_t n)
     // ---- Gardner: exact parallel evaluation through boundary-state tables when the chunk geometry
     // allows it (float build, chunk fits the LDS window, boundary states in one binade), otherwise the
     // single-wavefront sequential chain.
+    const bool use_mm = ctx->cfg.sampler == PDT_SAMPLER_MM;
     bool use_table = false;
     GardnerDomain GD;
     GD.q_min = 0; GD.u = 0; GD.n_q = 0; GD.n_cand = 0; GD.pad_q = 0; GD.idx_bits = 20;
     if constexpr (std::is_same<T, float>::value) {
         const int table_len = 1 << 22;     // the table kernel walks the chunk in LDS windows: no size limit of its own
         const float nT = (float)chunk_out, stepf = (float)GP.step;
-        if (!argos && !ctx->force_sequential_gardner && n_chunks >= 4 && chunk_out >= 256 &&
+        if (!argos && !use_mm && !ctx->force_sequential_gardner && n_chunks >= 4 && chunk_out >= 256 &&
             chunk_out + 2 * (long long)stepf + 24 <= table_len && 8 * (long long)stepf + 256 < PDT_GTAB_WIN && chunk_out < (1 << 22)) {
             int e;
             (void)frexpf(nT - stepf - 1.0f, &e);                              // value in [2^(e-1), 2^e)
@@ -637,6 +643,20 @@ template <typename T> int run_capture(pdt_ctx *ctx, uint64_t n)
                                (const GardnerEntry<float> *)ctx->gentries.p);
             L.end();
         }
+    } else if (use_mm) {
+        // MMClockRecovery at the sampler's call site: sequential, one wavefront
+        MmParams<T> MP;
+        const T rangeT = (T)(ctx->cfg.mm_step_range != 0 ? ctx->cfg.mm_step_range : 3.0);     // ARGOSdemod/main.c:277
+        MP.kp = (T)(ctx->cfg.mm_kp != 0 ? ctx->cfg.mm_kp : 0.15);
+        MP.step0 = (T)(int)fsi / baud;                                                        // MMClockRecovery.c:20
+        MP.step_max = (T)(int)fsi / (baud - rangeT);                                          // :9
+        MP.step_min = (T)(int)fsi / (baud + rangeT);                                          // :10
+        MP.n_total = n_out;
+        MP.chunk_out = chunk_out;
+        L.begin("gardner");
+        hipLaunchKernelGGL((k_mm<T, 8192, 1024>), dim3(1), dim3(PDT_GARDNER_THREADS), 0, st, (const T *)d_agc, MP, d_sym, d_symidx,
+                           &d_sc->nsym, sym_cap);
+        L.end();
     } else {
         L.begin("gardner");
         hipLaunchKernelGGL((k_gardner<T, GardnerLds<T>::LEN, GardnerLds<T>::OUT>), dim3(1), dim3(PDT_GARDNER_THREADS), 0, st, d_agc, d_lock, GP, d_sym, d_symidx,

@@ -253,6 +253,89 @@ __global__ void __launch_bounds__(PDT_GARDNER_THREADS) k_gardner(const T *__rest
 }
 
 // ------------------------------------------------------------------------------------------
+// Mueller & Muller clock recovery (reference: common/MMClockRecovery.c:5-83), the alternative sampler
+// the reference keeps at the same call site behind a comment (ARGOSdemod/main.c:277).  State
+// (nextSample, stepSize, sampleLast) has two free floats, so there is no small boundary-state domain to
+// tabulate: one wavefront walks the capture, chunk by chunk, like the sequential Gardner kernel.
+// ------------------------------------------------------------------------------------------
+template <typename T> struct MmParams {
+    T step0, step_max, step_min, kp;   // Fs/baud, Fs/(baud - stepRange), Fs/(baud + stepRange)
+    long long n_total, chunk_out;
+};
+// the reference rounds the sampling instant with rint() in the float build and with rintf() -- after
+// narrowing to float -- in the double build (MMClockRecovery.c:25 vs :55)
+template <typename T> __device__ __forceinline__ T mm_rint(T x);
+template <> __device__ __forceinline__ float mm_rint<float>(float x) { return __builtin_rintf(x); }
+template <> __device__ __forceinline__ double mm_rint<double>(double x) { return (double)__builtin_rintf((float)x); }
+
+template <typename T, int LEN, int OUT>
+__global__ void __launch_bounds__(PDT_GARDNER_THREADS) k_mm(const T *__restrict__ in, MmParams<T> P, T *__restrict__ sym,
+                                                             long long *__restrict__ symidx,
+                                                             unsigned long long *__restrict__ nsym_out, long long sym_cap)
+{
+    __shared__ T win[LEN];
+    __shared__ T o_val[OUT];
+    __shared__ unsigned o_idx[OUT];
+    const int lane = threadIdx.x;
+    const long long C = P.chunk_out;
+    const long long n_chunks = (C > 0) ? (P.n_total + C - 1) / C : 0;
+    T next = 0, step = P.step0, last = 0;
+    long long count = 0;
+    for (long long c = 0; c < n_chunks; c++) {
+        const long long base = c * C;
+        const unsigned n_cur = (unsigned)((P.n_total - base < C) ? (P.n_total - base) : C);
+        const T nT = (T)n_cur;
+        unsigned wbase = 0;
+        bool chunk_done = false;
+        while (!chunk_done) {
+            __syncthreads();
+            {
+                const unsigned avail = (n_cur > wbase) ? n_cur - wbase : 0u;
+                const int n_data = (int)((avail < (unsigned)LEN) ? avail : (unsigned)LEN);
+                const T *src = in + base + wbase;
+                for (int t = lane; t < n_data; t += PDT_GARDNER_THREADS) win[t] = src[t];
+            }
+            __syncthreads();
+            const unsigned wend = wbase + (unsigned)LEN;
+            int nout = 0;
+            for (;;) {
+                const T rn = mm_rint<T>(next);
+                const int in_chunk = uniform<int>((int)(rn < nT));
+                if (!in_chunk) { chunk_done = true; break; }
+                const unsigned i_abs = uniform<unsigned>((unsigned)rn);
+                if (i_abs - wbase >= (unsigned)LEN || nout >= OUT) break;      // new window / flush
+                const T cur = win[i_abs - wbase];
+                o_val[nout] = cur;
+                o_idx[nout] = i_abs;
+                nout++;
+                const T err = (T)((last > 0) - (last < 0)) * cur - (T)((cur > 0) - (cur < 0)) * last;     // :37 / :67
+                step = step + P.kp * err;
+                step = (step > P.step_max) ? P.step_max : step;
+                step = (step < P.step_min) ? P.step_min : step;
+                next = next + step;
+                last = cur;
+            }
+            __syncthreads();
+            for (int t = lane; t < nout; t += PDT_GARDNER_THREADS) {
+                const long long k = count + t;
+                if (k < sym_cap) {
+                    sym[k] = o_val[t];
+                    symidx[k] = base + (long long)o_idx[t];
+                }
+            }
+            count += nout;
+            if (!chunk_done) {
+                const unsigned cur_i = uniform<unsigned>((unsigned)mm_rint<T>(next));
+                if (cur_i - wbase >= (unsigned)LEN) wbase = cur_i;
+            }
+            (void)wend;
+        }
+        next = next - nT;                              // roll over to the next chunk (:80)
+    }
+    if (threadIdx.x == 0) *nsym_out = (unsigned long long)count;
+}
+
+// ------------------------------------------------------------------------------------------
 // Exact parallel Gardner ("boundary-state table" method, float only)
 //
 // The sampler state that crosses a chunk boundary is (ns, prev, half).  All three are functions

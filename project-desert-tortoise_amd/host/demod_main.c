@@ -17,7 +17,8 @@
  *   "Normalization Factor: %f", " : PLL locked at %0.2fHz"                  main.c:388, CarrierTrackingPLL.c:269
  *   output removed when no frame was found             main.c:508-512
  * Additions: -o <file> chooses the output name (tests), -d <n> picks the GPU, -q (POES) prints the frame
- * validation the reference keeps in MATLAB (checkParity.m:91-92, daytimeDecode.m:36,82-95) after decoding.
+ * validation the reference keeps in MATLAB (checkParity.m:91-92, daytimeDecode.m:36,82-95) after decoding,
+ * -m selects MMClockRecovery (the sampler the reference keeps commented out at ARGOSdemod/main.c:277).
  * Not reproduced: the per-chunk "\r" progress line (there are no chunks on the GPU; one
  * summary line is printed instead).  RAW float32 input (".raw", -s mandatory) is supported for POES
  * exactly as in POESTIPdemod/main.c:313-339.
@@ -35,14 +36,14 @@
 #ifdef PDT_ARGOS
 #define MODE PDT_MODE_ARGOS
 #define DEFAULT_CHUNKSIZE 2400
-#define OPTS "rn:c:o:d:"
+#define OPTS "rn:c:o:d:m"
 #define BANNER "Project Desert Tortoise: Wave file ARGOS Demodulator (MI355X build)\n"
 #define PREFIX "packets"
 #define UNIT "Packets"
 #else
 #define MODE PDT_MODE_POES
 #define DEFAULT_CHUNKSIZE 10000
-#define OPTS "s:rn:c:o:d:q"
+#define OPTS "s:rn:c:o:d:qm"
 #define BANNER "Project Desert Tortoise: Wave file NOAA TIP Demodulator (MI355X build)\n"
 #define PREFIX "minorFrames"
 #define UNIT "Frames"
@@ -59,7 +60,7 @@ int main(int argc, char **argv)
 {
     unsigned long chunkSize = DEFAULT_CHUNKSIZE;
     double normFactor = 0, sampleRate = 0;
-    int outputRawFiles = 0, device = 0, quality = 0, c;
+    int outputRawFiles = 0, device = 0, quality = 0, sampler = 0, c;
     const char *outOverride = NULL;
     char outFileName[1100];
 
@@ -90,6 +91,10 @@ int main(int argc, char **argv)
             break;
         case 'q':
             quality = 1;
+            break;
+        case 'm':                                       /* MMClockRecovery instead of Gardner (ARGOSdemod/main.c:277) */
+            sampler = PDT_SAMPLER_MM;
+            printf("Using M&M clock recovery\n");
             break;
         case '?':
             if (optopt == 's' || optopt == 'c' || optopt == 'n')
@@ -209,6 +214,7 @@ int main(int argc, char **argv)
     cfg.chunk = chunkSize;
     cfg.norm_override = normFactor;
     cfg.device = device;
+    cfg.sampler = sampler;
     pdt_ctx *ctx = NULL;
     int rc = pdt_open(&cfg, &ctx);
     if (rc != PDT_OK) {

@@ -38,7 +38,7 @@ def test_library_contains_gfx950_code_object(pdt):
 
 def test_struct_layouts_match_header(pdt):
     assert C.sizeof(pdt.Frame) == 136
-    assert C.sizeof(pdt.Config) == 56
+    assert C.sizeof(pdt.Config) == 80
     assert pdt.FRAME_DTYPE.itemsize == 136
 
 

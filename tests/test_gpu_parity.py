@@ -276,6 +276,35 @@ def test_250ksps_capture_matches_oracle(pdt, orc):
     assert all(i is not None for i in idx) and idx == list(range(idx[0], idx[0] + len(idx)))
 
 
+@pytest.mark.parametrize("rg,kp", [(0.0, 0.0), (9.0, 0.05)])
+def test_mm_clock_recovery_poes(pdt, orc, clip, rg, kp):
+    """MMClockRecovery as the sampler (cfg.sampler = 1); every stage against the oracle, whose M&M
+    restatement is checked against the reference's own object in tests/test_oracle_ref.py."""
+    rate, iq = clip
+    o = orc.Oracle(orc.POES, rate, iq, sampler=1, mm_range=rg or 3.0, mm_kp=kp or 0.15)
+    with pdt.Demodulator(pdt.MODE_POES, rate, sampler=pdt.SAMPLER_MM, mm_step_range=rg, mm_kp=kp) as d:
+        d.demod(iq)
+        assert d.stats().gardner_parallel == 0
+        check_all_stages(pdt, orc, d, o)
+    iq2 = pdt.synth_capture(0, 50000, 12.0, seed=8)
+    o2 = orc.Oracle(orc.POES, 50000, iq2, chunk=3333, sampler=1, mm_range=rg or 3.0, mm_kp=kp or 0.15)
+    with pdt.Demodulator(pdt.MODE_POES, 50000, chunk=3333, sampler=pdt.SAMPLER_MM, mm_step_range=rg, mm_kp=kp) as d:
+        d.demod(iq2)
+        check_all_stages(pdt, orc, d, o2)
+
+
+def test_mm_clock_recovery_argos(pdt, orc):
+    iq = pdt.synth_capture(1, 32000, 14.0, f0_hz=150.0, seed=23)
+    for chunk in (0, 1000):
+        o = orc.Oracle(orc.ARGOS, 32000, iq, chunk=chunk, sampler=1, math_mode=orc.MATH_PORTABLE)
+        with pdt.Demodulator(pdt.MODE_ARGOS, 32000, chunk=chunk, sampler=pdt.SAMPLER_MM) as d:
+            d.demod(iq)
+            check_all_stages(pdt, orc, d, o)
+            assert d.stats().frames >= 5
+    with pytest.raises(pdt.PdtError):
+        pdt.Demodulator(pdt.MODE_POES, 50000, sampler=pdt.SAMPLER_MM, mm_step_range=1e9).demod(np.zeros((20000, 2), dtype=np.int16))
+
+
 def test_cli_demodpoes(pdt, tmp_path):
     exe = os.path.join(ROOT, "bin", "demodPOES")
     out = tmp_path / "mf.txt"

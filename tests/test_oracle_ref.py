@@ -132,3 +132,26 @@ def test_raw_float32_input(orc, pdt, tmp_path, scale):
     if scale == 1.0:
         # the same samples as a WAV give the same file
         assert text == orc.Oracle(orc.POES, 50000, iq, keep_stages=False).text()
+
+
+@pytest.mark.parametrize("mode,chunk,rng_kp", [("poes", 10000, (3.0, 0.15)), ("poes", 3333, (9.0, 0.05)), ("argos", 2400, (3.0, 0.15)),
+                                               ("argos", 1000, (1.0, 0.3))])
+def test_mm_clock_recovery_all_stages(orc, pdt, clip, tmp_path, mode, chunk, rng_kp):
+    """MMClockRecovery (common/MMClockRecovery.c:5-83) at the sampler's call site -- the one-line
+    switch the reference keeps commented out (ARGOSdemod/main.c:277).  Restatement vs the reference's own object,
+    every stage, for the defaults of that call (stepRange 3, kp 0.15) and another pair."""
+    rg, kp = rng_kp
+    extra = ["-c", str(chunk), "-M", "-R", str(rg), "-K", str(kp)]
+    if mode == "poes":
+        rate, iq = clip
+        text, dump = run_ref(REF_POES, os.path.join(GOLDEN, "5sec_clip.wav"), tmp_path, extra)
+        o = orc.Oracle(orc.POES, rate, iq, chunk=chunk, sampler=1, mm_range=rg, mm_kp=kp)
+    else:
+        iq = pdt.synth_capture(1, 32000, 9.0, f0_hz=140.0, seed=21)
+        wav = tmp_path / "a.wav"
+        pdt.write_wav(str(wav), 32000, iq)
+        text, dump = run_ref(REF_ARGOS, wav, tmp_path, extra)
+        o = orc.Oracle(orc.ARGOS, 32000, iq, chunk=chunk, sampler=1, mm_range=rg, mm_kp=kp)
+    compare_all(o, dump)
+    assert o.text() == text
+    assert len(o.stage(orc.ST_SYM)) > 1000
