@@ -36,6 +36,8 @@
  *                       FindSyncWords (ARGOSdemod/ByteSync.c:17-150)
  *   pdt_demod_device    same, input already resident in HBM (bench / multi-capture)
  *   pdt_demod_f32       the same loop over GetComplexRawChunk (wave.c:413-540): RAW float32 captures
+ *   pdt_stream_*        the same loop fed block by block, as POESTIPdemodPortAudio/main.c:324-393 is by
+ *                       Pa_ReadStream (the sound-card side itself is out of scope)
  *   pdt_frames          the fprintf stream of ByteSync.c, as records
  *   pdt_format_frames   the text ByteSync.c writes to the output file
  *   pdt_tip_check       the downstream frame validation the reference keeps in MATLAB:
@@ -165,6 +167,25 @@ int  pdt_demod_device(pdt_ctx *ctx, const void *iq_device, uint64_t nframes);
  * POES only -- ARGOSdemod/main.c:238-241 refuses RAW files.                                       */
 int  pdt_demod_f32(pdt_ctx *ctx, const float *iq_host, uint64_t nframes);
 int  pdt_demod_device_f32(pdt_ctx *ctx, const void *iq_device, uint64_t nframes);
+
+/* Streaming front end: feed a capture piece by piece, as the reference's real-time twin
+ * does with 2 400-frame sound-card blocks (POESTIPdemodPortAudio/main.c:324-393), and collect minor frames
+ * as they become final.  The reference chain is causal per chunk and prints frames as their bits arrive;
+ * here every push that completes at least one more reference chunk demodulates EVERYTHING received so far
+ * again (the whole chain takes a few milliseconds for an hour of 48 ksps audio) and reports the frames that
+ * are new and lie safely before the end of the data.  Guarantee: the frames reported by the pushes followed
+ * by those of pdt_stream_end are exactly the frames of one pdt_demod_* call on the whole capture.
+ *   pdt_stream_begin      forget any accumulated input (the sample format is fixed by the first push)
+ *   pdt_stream_push_*     append nframes I,Q pairs; *new_frames = frames that became final with this push
+ *   pdt_stream_end        the capture is over: demodulate all of it (short last chunk included) and report
+ *                         the remaining frames; afterwards pdt_frames / pdt_get_stats / pdt_format_frames
+ *                         describe the whole capture
+ *   pdt_stream_frames     the frames reported by the last push / end, in order                              */
+int      pdt_stream_begin(pdt_ctx *ctx);
+int      pdt_stream_push_pcm16(pdt_ctx *ctx, const int16_t *iq_host, uint64_t nframes, uint64_t *new_frames);
+int      pdt_stream_push_f32(pdt_ctx *ctx, const float *iq_host, uint64_t nframes, uint64_t *new_frames);
+int      pdt_stream_end(pdt_ctx *ctx, uint64_t *new_frames);
+uint64_t pdt_stream_frames(const pdt_ctx *ctx, pdt_frame *out, uint64_t max_frames);
 
 /* Results of the last pdt_demod_* call. */
 uint64_t pdt_num_frames(const pdt_ctx *ctx);

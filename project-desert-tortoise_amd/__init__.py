@@ -115,6 +115,7 @@ ABI_SYMBOLS = [
     "pdt_demod_pcm16", "pdt_demod_device", "pdt_demod_f32", "pdt_demod_device_f32", "pdt_num_frames", "pdt_frames", "pdt_get_stats",
     "pdt_format_frames", "pdt_read_stage", "pdt_stage_len", "pdt_kernel_times", "pdt_make_lpf",
     "pdt_wav_parse_header", "pdt_time_axis", "pdt_stage_bytesync", "pdt_tip_check", "pdt_tip_frames",
+    "pdt_stream_begin", "pdt_stream_push_pcm16", "pdt_stream_push_f32", "pdt_stream_end", "pdt_stream_frames",
 ]
 
 _lib = None
@@ -160,6 +161,12 @@ def lib():
     L.pdt_time_axis.argtypes = [C.c_int, C.c_uint32, C.c_uint64]
     L.pdt_time_axis.restype = C.c_double
     L.pdt_stage_bytesync.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64]
+    L.pdt_stream_begin.argtypes = [C.c_void_p]
+    L.pdt_stream_push_pcm16.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64, C.POINTER(C.c_uint64)]
+    L.pdt_stream_push_f32.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64, C.POINTER(C.c_uint64)]
+    L.pdt_stream_end.argtypes = [C.c_void_p, C.POINTER(C.c_uint64)]
+    L.pdt_stream_frames.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64]
+    L.pdt_stream_frames.restype = C.c_uint64
     L.pdt_tip_check.argtypes = [C.c_void_p, C.POINTER(TipSummary)]
     L.pdt_tip_frames.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64]
     L.pdt_tip_frames.restype = C.c_uint64
@@ -298,6 +305,34 @@ class Demodulator:
                 _check(int(got), "pdt_read_stage")
             out = out[:got]
         return out
+
+    # ---- streaming front end: push blocks, collect frames as they become final
+    def stream_begin(self):
+        _check(self._L.pdt_stream_begin(self._h), "pdt_stream_begin")
+        return self
+
+    def _stream_new(self, n: int) -> np.ndarray:
+        buf = np.zeros(n, dtype=FRAME_DTYPE)
+        if n:
+            self._L.pdt_stream_frames(self._h, buf.ctypes.data, n)
+        return buf
+
+    def stream_push(self, iq: np.ndarray) -> np.ndarray:
+        """Append a block (int16 or float32 I,Q pairs); returns the frames that became final with it."""
+        n = C.c_uint64(0)
+        if np.asarray(iq).dtype.kind == "f":
+            a = np.ascontiguousarray(iq, dtype="<f4").reshape(-1)
+            _check(self._L.pdt_stream_push_f32(self._h, a.ctypes.data, a.size // 2, C.byref(n)), "pdt_stream_push_f32")
+        else:
+            a = np.ascontiguousarray(iq, dtype="<i2").reshape(-1)
+            _check(self._L.pdt_stream_push_pcm16(self._h, a.ctypes.data, a.size // 2, C.byref(n)), "pdt_stream_push_pcm16")
+        return self._stream_new(n.value)
+
+    def stream_end(self) -> np.ndarray:
+        """The capture is over: returns the remaining frames; text()/stats()/frames_array() then describe all of it."""
+        n = C.c_uint64(0)
+        _check(self._L.pdt_stream_end(self._h, C.byref(n)), "pdt_stream_end")
+        return self._stream_new(n.value)
 
     def tip_check(self):
         """Frame validation of the last demodulation (the reference's MATLAB checkParity.m / daytimeDecode.m,

@@ -86,6 +86,7 @@ struct pdt_ctx {
     hipStream_t stream2 = nullptr;     // side stream: block-parallel PLL phase runs beside the sequential acquisition
 
     DevBuf pcm, pll, lock, fir, agc, sym, symidx, bits, bitsym, hits, frames, taps, mag, seams_pll, seams_agc, scal, lockinfo, term, seams_ema, gtable, gentries, gcand, gmfirst, stiles, gsegmap, gsegstart, gbands, gclist, agc_maps, pll_head, taps_rot, pll_scratch, tip;
+    // (stream_in is declared with the streaming state below)
     long long gcand_key = -1;          // (chunk_out, step) the candidate list on the device was built for
     bool force_sequential_gardner = false;
     int gardner_mode = 0;              // 0 sequential, 1 state table (last run)
@@ -99,6 +100,11 @@ struct pdt_ctx {
     std::vector<pdt_tip_frame> tip_host;
     uint32_t frames_on_device = 0;      // FrameRec records of the last demodulation still in ctx->frames
     bool have_frames = false;           // a demodulation (or stage-level byte sync) has run
+    // streaming front end: everything received so far (device), what has been reported
+    DevBuf stream_in;
+    uint64_t stream_n = 0, stream_done_chunks = 0, stream_reported = 0;
+    int stream_fmt = -1;                // -1 = no push yet, 0 = pcm16, 1 = float32
+    std::vector<pdt_frame> stream_new;
     pdt_stats stats;
     std::vector<pdt_kernel_time> ktimes;
     std::vector<KTimer> timers;
@@ -933,7 +939,7 @@ void pdt_close(pdt_ctx *ctx)
     DevBuf *bufs[] = { &ctx->pcm, &ctx->pll, &ctx->lock, &ctx->fir, &ctx->agc, &ctx->sym, &ctx->symidx, &ctx->bits, &ctx->bitsym,
                        &ctx->hits, &ctx->frames, &ctx->taps, &ctx->mag, &ctx->seams_pll, &ctx->seams_agc, &ctx->scal, &ctx->lockinfo,
                        &ctx->term, &ctx->seams_ema, &ctx->gtable, &ctx->gentries, &ctx->gcand,
-                       &ctx->gmfirst, &ctx->stiles, &ctx->gsegmap, &ctx->gsegstart, &ctx->gbands, &ctx->gclist, &ctx->agc_maps, &ctx->pll_head, &ctx->taps_rot, &ctx->pll_scratch, &ctx->tip };
+                       &ctx->gmfirst, &ctx->stiles, &ctx->gsegmap, &ctx->gsegstart, &ctx->gbands, &ctx->gclist, &ctx->agc_maps, &ctx->pll_head, &ctx->taps_rot, &ctx->pll_scratch, &ctx->tip, &ctx->stream_in };
     for (DevBuf *b : bufs) b->release();
     if (ctx->ev0) (void)hipEventDestroy(ctx->ev0);
     if (ctx->ev1) (void)hipEventDestroy(ctx->ev1);
@@ -1063,6 +1069,107 @@ int pdt_stage_bytesync(pdt_ctx *ctx, const uint8_t *bits_host, uint64_t nbits)
     ctx->stats.sync_overflow = sc.sync_overflow;
     memset(ctx->stage_len, 0, sizeof ctx->stage_len);
     return PDT_OK;
+}
+
+// ---------------------------------------------------------------- streaming front end
+int pdt_stream_begin(pdt_ctx *ctx)
+{
+    if (!ctx) return PDT_ERR_ARG;
+    ctx->stream_n = 0;
+    ctx->stream_done_chunks = 0;
+    ctx->stream_reported = 0;
+    ctx->stream_fmt = -1;
+    ctx->stream_new.clear();
+    return PDT_OK;
+}
+
+// demodulate the first n samples of the accumulated input and report the frames that are new and whose
+// source position lies before `final_before` (input samples); everything when final_before < 0
+static int stream_run(pdt_ctx *ctx, uint64_t n, long long final_before, uint64_t *new_frames)
+{
+    ctx->pcm_dev = ctx->stream_in.p;
+    ctx->pcm_fmt = ctx->stream_fmt;
+    int rc = demod_common(ctx, n);
+    if (rc) return rc;
+    const std::vector<pdt_frame> &all = ctx->frames_host;
+    uint64_t upto = all.size();
+    if (final_before >= 0) {
+        // frames are ordered; a frame is final when it is complete and even its last bit was sampled before the
+        // limit (time_src = interpolated-sample index of the bit that completed the sync word)
+        const double per_bit = 2.0 * (double)ctx->interp * (double)ctx->cfg.sample_rate / (ctx->cfg.mode == PDT_MODE_ARGOS ? 800.0 : 16640.0);
+        const double span = (ctx->cfg.mode == PDT_MODE_ARGOS ? 56.0 : 813.0) * per_bit + 64.0 * (double)ctx->interp;
+        upto = ctx->stream_reported;
+        while (upto < all.size() && all[upto].complete &&
+               (double)all[upto].time_src + span < (double)final_before * (double)ctx->interp)
+            upto++;
+    }
+    ctx->stream_new.assign(all.begin() + (std::ptrdiff_t)std::min<uint64_t>(ctx->stream_reported, upto), all.begin() + (std::ptrdiff_t)upto);
+    ctx->stream_reported = std::max<uint64_t>(ctx->stream_reported, upto);
+    if (new_frames) *new_frames = ctx->stream_new.size();
+    return PDT_OK;
+}
+
+static int stream_push(pdt_ctx *ctx, const void *host, uint64_t nframes, int fmt, uint64_t *new_frames)
+{
+    if (!ctx || (!host && nframes)) return PDT_ERR_ARG;
+    if (fmt == 1 && ctx->cfg.mode != PDT_MODE_POES) return PDT_ERR_FORMAT;
+    if (ctx->stream_fmt >= 0 && ctx->stream_fmt != fmt) return PDT_ERR_STATE;
+    HIP_TRY(hipSetDevice(ctx->cfg.device));
+    ctx->stream_fmt = fmt;
+    const size_t fb = fmt ? 8 : 4;
+    const uint64_t total = ctx->stream_n + nframes;
+    if ((size_t)total * fb + 16 > ctx->stream_in.cap) {              // grow, keeping what is there
+        DevBuf bigger;
+        int rc = bigger.ensure(((size_t)total * fb + 16) * 2);
+        if (rc) return rc;
+        if (ctx->stream_n) HIP_TRY(hipMemcpyAsync(bigger.p, ctx->stream_in.p, (size_t)ctx->stream_n * fb, hipMemcpyDeviceToDevice, ctx->stream));
+        HIP_TRY(hipStreamSynchronize(ctx->stream));
+        ctx->stream_in.release();
+        ctx->stream_in = bigger;
+    }
+    if (nframes)
+        HIP_TRY(hipMemcpyAsync((unsigned char *)ctx->stream_in.p + (size_t)ctx->stream_n * fb, host, (size_t)nframes * fb,
+                               hipMemcpyHostToDevice, ctx->stream));
+    ctx->stream_n = total;
+    ctx->stream_new.clear();
+    if (new_frames) *new_frames = 0;
+    const uint64_t chunk = ctx->cfg.chunk;
+    const uint64_t chunks = total / chunk;
+    if (chunks == ctx->stream_done_chunks || chunks < 3) return PDT_OK;   // nothing new that could be final
+    ctx->stream_done_chunks = chunks;
+    // whole chunks only (a partial chunk would be treated as the capture's short last chunk), and only frames
+    // that end a chunk before the end of that prefix are final
+    return stream_run(ctx, chunks * chunk, (long long)((chunks - 1) * chunk), new_frames);
+}
+
+int pdt_stream_push_pcm16(pdt_ctx *ctx, const int16_t *iq_host, uint64_t nframes, uint64_t *new_frames)
+{
+    return stream_push(ctx, iq_host, nframes, 0, new_frames);
+}
+
+int pdt_stream_push_f32(pdt_ctx *ctx, const float *iq_host, uint64_t nframes, uint64_t *new_frames)
+{
+    return stream_push(ctx, iq_host, nframes, 1, new_frames);
+}
+
+int pdt_stream_end(pdt_ctx *ctx, uint64_t *new_frames)
+{
+    if (!ctx) return PDT_ERR_ARG;
+    if (ctx->stream_fmt < 0) {                       // nothing was pushed: an empty capture
+        ctx->stream_fmt = 0;
+        int rc = ctx->stream_in.ensure(64);
+        if (rc) return rc;
+    }
+    HIP_TRY(hipSetDevice(ctx->cfg.device));
+    return stream_run(ctx, ctx->stream_n, -1, new_frames);
+}
+
+uint64_t pdt_stream_frames(const pdt_ctx *ctx, pdt_frame *out, uint64_t max_frames)
+{
+    if (!ctx) return 0;
+    const uint64_t n = std::min<uint64_t>(max_frames, ctx->stream_new.size());
+    if (out && n) memcpy(out, ctx->stream_new.data(), (size_t)n * sizeof(pdt_frame));
+    return n;
 }
 
 // ---------------------------------------------------------------- frame validation
