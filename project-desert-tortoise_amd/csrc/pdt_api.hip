@@ -307,7 +307,7 @@ template <typename T> int run_capture(pdt_ctx *ctx, uint64_t n)
     long long Bp = ctx->cfg.pll_block ? ctx->cfg.pll_block : (long long)((argos ? 4.0 : 0.05) * fs_d);
     long long Wp = ctx->cfg.pll_warm ? ctx->cfg.pll_warm : (long long)((argos ? 8.0 : 0.3) * fs_d);
     long long Wacq = (long long)(0.02 * fs_d);             // acquisition-gain stage of the warm-up
-    long long Ba = ctx->cfg.agc_block ? ctx->cfg.agc_block : (long long)((argos ? 1.0 : 0.0625) * fs_d * interp);
+    long long Ba = ctx->cfg.agc_block ? ctx->cfg.agc_block : (long long)((argos ? 0.125 : 0.0625) * fs_d * interp);
     long long Wa = ctx->cfg.agc_warm ? ctx->cfg.agc_warm : (long long)((argos ? 8.0 : 1.0) * fs_d * interp);
     Bp = std::max<long long>(64, round4(Bp));
     Ba = std::max<long long>(64, round4(Ba));
@@ -355,7 +355,12 @@ template <typename T> int run_capture(pdt_ctx *ctx, uint64_t n)
     if ((rc = ctx->seams_pll.ensure((size_t)nb_pll * sizeof(PllSeam<T>)))) return rc;
     if ((rc = ctx->seams_agc.ensure((size_t)nb_agc * sizeof(AgcSeam<T>)))) return rc;
     if (argos && (rc = ctx->term.ensure((size_t)(N + 1) * sizeof(T)))) return rc;
-    if (argos && (rc = ctx->seams_ema.ensure((size_t)nb_pll * sizeof(EmaSeam<T>)))) return rc;
+    // lock-detector EMA (ARGOS): a pure contraction with factor 1 - lockSigAlpha per sample, so its own, much
+    // shorter geometry: 45 time constants of warm-up agree in 53 bits (20 in 24), blocks a quarter of that
+    const long long We = round4((long long)((sizeof(T) == 8 ? 45.0 : 20.0) / (double)PP.lock_alpha) + 64);
+    const long long Be = std::max<long long>(64, round4(We / 4));
+    const long long nb_ema = N / Be + 2;
+    if (argos && (rc = ctx->seams_ema.ensure((size_t)nb_ema * sizeof(EmaSeam<T>)))) return rc;
     if ((rc = ctx->scal.ensure(sizeof(DevScalars)))) return rc;
     if ((rc = ctx->lockinfo.ensure(sizeof(PllLockInfo<T>)))) return rc;
 
@@ -474,10 +479,10 @@ template <typename T> int run_capture(pdt_ctx *ctx, uint64_t n)
         L.end();
         if (argos) {
             L.begin("lock_ema");
-            hipLaunchKernelGGL(k_lock_ema<T>, dim3((unsigned)grid), dim3(64), 0, st, (const T *)ctx->term.p, N, PP.lock_alpha,
-                               d_info, Bp, Wp, d_lock, (EmaSeam<T> *)ctx->seams_ema.p);
+            hipLaunchKernelGGL(k_lock_ema<T>, dim3((unsigned)((nb_ema + 63) / 64)), dim3(64), 0, st, (const T *)ctx->term.p, N, PP.lock_alpha,
+                               d_info, Be, We, d_lock, (EmaSeam<T> *)ctx->seams_ema.p);
             hipLaunchKernelGGL(k_lock_ema_fix<T>, dim3(1), dim3(64), 0, st, (const T *)ctx->term.p, N, PP.lock_alpha, d_info,
-                               Bp, d_lock, (EmaSeam<T> *)ctx->seams_ema.p, &d_sc->counters[1]);
+                               Be, d_lock, (EmaSeam<T> *)ctx->seams_ema.p, &d_sc->counters[1]);
             L.end();
         }
     }
