@@ -424,11 +424,18 @@ template <typename T> int run_capture(pdt_ctx *ctx, uint64_t n)
     L.begin("pll_acquire");
     if (getenv("PDT_ACQUIRE_SIMPLE"))       // plain one-lane form, kept for A/B checks
         hipLaunchKernelGGL(k_pll_acquire<T>, dim3(1), dim3(64), 0, st, d_pcm, N, PP, d_pll, d_lock, d_info);
-    else if (slow_wrap)
-        hipLaunchKernelGGL((k_pll_acquire_fast<T, true>), dim3(1), dim3(64), 0, st, d_pcm, (const T *)d_theta, N, PP, d_pll, d_lock,
+    else if (getenv("PDT_ACQUIRE_ONEWAVE")) {   // single-wavefront batched form, kept for A/B checks
+        if (slow_wrap)
+            hipLaunchKernelGGL((k_pll_acquire_fast<T, true>), dim3(1), dim3(64), 0, st, d_pcm, (const T *)d_theta, N, PP, d_pll, d_lock,
+                               d_info);
+        else
+            hipLaunchKernelGGL((k_pll_acquire_fast<T, false>), dim3(1), dim3(64), 0, st, d_pcm, (const T *)d_theta, N, PP, d_pll, d_lock,
+                               d_info);
+    } else if (slow_wrap)
+        hipLaunchKernelGGL((k_pll_acquire_pipe<T, true>), dim3(1), dim3(128), 0, st, d_pcm, (const T *)d_theta, N, PP, d_pll, d_lock,
                            d_info);
     else
-        hipLaunchKernelGGL((k_pll_acquire_fast<T, false>), dim3(1), dim3(64), 0, st, d_pcm, (const T *)d_theta, N, PP, d_pll, d_lock,
+        hipLaunchKernelGGL((k_pll_acquire_pipe<T, false>), dim3(1), dim3(128), 0, st, d_pcm, (const T *)d_theta, N, PP, d_pll, d_lock,
                            d_info);
     L.end();
     if (N > 0) {

@@ -451,6 +451,180 @@ __global__ void __launch_bounds__(64) k_pll_acquire_fast(IqSrc pcm, const T *__r
     }
 }
 
+// Acquisition, pipelined over two wavefronts.  The loop filter of a batch (pass 1 of
+// k_pll_acquire_fast) depends on the detector passes (2 and 3) only through the two rare events "sweep gate
+// flipped" and "locked"; so wavefront 0 runs the loop filter of batch t while wavefront 1 evaluates
+// the detectors of batch t-1 from the per-sample states wavefront 0 left in LDS.  When wavefront 1
+// reports an event inside batch t-1, the speculative batch t is dropped and wavefront 0 resumes from
+// the corrected state after the event sample.  Same arithmetic per sample, half the time per batch.
+template <typename T> struct AcqSlot {
+    T phi[PDT_ACQ_NB], phn[PDT_ACQ_NB], fpre[PDT_ACQ_NB], swb[PDT_ACQ_NB];
+    long long i0;
+    int nb, valid, hyp;
+    T ph_end, fr_end, sw_end;         // loop-filter state after the whole batch under the hypothesis
+};
+template <typename T> struct AcqVerdict {
+    int event;                         // 0 = the batch stands, 1 = it ended early at sample k
+    int k, hyp, locked;
+    T phase, freq, sweep;              // loop-filter state after sample k (sweep step taken with the true gate)
+};
+
+template <typename T, bool SLOW>
+__global__ void __launch_bounds__(128) k_pll_acquire_pipe(IqSrc pcm, const T *__restrict__ theta, long long n, PllParams<T> P,
+                                                          T *__restrict__ out, T *__restrict__ lock_out,
+                                                          PllLockInfo<T> *__restrict__ info)
+{
+    __shared__ AcqSlot<T> slot[2];
+    __shared__ AcqVerdict<T> verdict;
+    const int wave = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
+    const T avg_alpha = (T)0.00005;
+    const double k_avg = 1.0 - (double)avg_alpha, k_lock = 1.0 - (double)P.lock_alpha;
+    // wavefront 0: loop-filter state; wavefront 1: detector state
+    T phase = P.phase0, freq = 0, sweep = P.sweep0;
+    T avg = P.avg0, locksig = 0;
+    bool hyp = avg >= P.cond_lo && avg <= P.cond_hi;
+    long long i_prod = 0;              // next sample the loop filter will take
+    long long i_pre = -1;              // start of the batch th_pre was loaded for
+    T th_pre = 0;
+    long long lock_at = -1;
+    T freq_at_lock = 0, avg_at_lock = P.avg0;
+    T fin_phase = P.phase0, fin_freq = 0, fin_sweep = P.sweep0;      // loop-filter state at the end (kept by wavefront 1)
+    if (threadIdx.x < 2) slot[threadIdx.x].valid = 0;
+    if (threadIdx.x == 0) verdict.event = 0;
+    __syncthreads();
+    for (int t = 0;; t++) {
+        AcqSlot<T> &mine = slot[t & 1];
+        AcqSlot<T> &theirs = slot[(t & 1) ^ 1];
+        const bool have_prev = theirs.valid != 0;
+        const bool produce = i_prod < n;
+        if (!have_prev && !produce) break;
+        if (wave == 0) {
+            // ---- loop filter of the batch starting at i_prod
+            if (produce) {
+                const int nb = (int)((n - i_prod < PDT_ACQ_NB) ? (n - i_prod) : PDT_ACQ_NB);
+                // theta of this batch was requested one batch ago (unless an event moved the start)
+                T th_l = th_pre;
+                if (i_pre != i_prod) th_l = (lane < nb) ? theta[i_prod + lane] : (T)0;
+                i_pre = i_prod + nb;
+                if (lane < PDT_ACQ_NB && i_pre + lane < n) th_pre = theta[i_pre + lane];
+                T ph = phase, fr = freq, sw = sweep;
+                T phi_l = 0, phn_l = 0, fpre_l = 0, swb_l = 0;
+                for (int k = 0; k < nb; k++) {
+                    const T th = lane_get(th_l, k);
+                    const bool me = lane == k;
+                    phi_l = me ? ph : phi_l;
+                    pll_phase_step<T, SLOW>(th, ph, fr, P.alpha_acq, P.beta_acq, P.max_freq, P.min_freq);
+                    phn_l = me ? ph : phn_l;
+                    fpre_l = me ? fr : fpre_l;
+                    swb_l = me ? sw : swb_l;
+                    pll_sweep_sel(fr, sw, P.max_freq, P.min_freq, hyp);
+                }
+                if (lane < nb) { mine.phi[lane] = phi_l; mine.phn[lane] = phn_l; mine.fpre[lane] = fpre_l; mine.swb[lane] = swb_l; }
+                if (lane == 0) {
+                    mine.i0 = i_prod; mine.nb = nb; mine.hyp = hyp ? 1 : 0; mine.valid = 1;
+                    mine.ph_end = ph; mine.fr_end = fr; mine.sw_end = sw;
+                }
+            } else if (lane == 0) {
+                mine.valid = 0;
+            }
+        } else {
+            // ---- detectors of the previous batch
+            if (have_prev) {
+                const long long i0 = theirs.i0;
+                const int nb = theirs.nb;
+                const bool h = theirs.hyp != 0;
+                T t_l = 0, u_l = 0, o_l = 0;
+                if (lane < nb) {
+                    T a_l, b_l, t_real, t_imag;
+                    IqSample<T>::get(pcm, i0 + lane, a_l, b_l);
+                    Real<T>::sincos(theirs.phi[lane], t_imag, t_real);
+                    const T c = t_real, d = -t_imag;
+                    const T o_re = a_l * c - b_l * d;
+                    const T o_im = a_l * d + b_l * c;
+                    o_l = o_im;
+                    const T ph = arctan2_ref(o_im, o_re);
+                    t_l = avg_alpha * Real<T>::abs(ph);
+                    const T mag2 = a_l * a_l + b_l * b_l;
+                    const T inv = (T)q_rsqrt((float)mag2);
+                    const T re = a_l * inv, im = b_l * inv;
+                    u_l = P.lock_alpha * (re * t_real + im * t_imag);
+                }
+                T av = avg, ls = locksig, av_l = 0, ls_l = 0;
+                unsigned ev_flip = 0, ev_lock = 0;
+                for (int k = 0; k < nb; k++) {
+                    av = (T)((double)av * k_avg + (double)lane_get(t_l, k));
+                    ls = (T)((double)ls * k_lock + (double)lane_get(u_l, k));
+                    const bool me = lane == k;
+                    ls_l = me ? ls : ls_l;
+                    av_l = me ? av : av_l;
+                    const bool cond = av >= P.cond_lo && av <= P.cond_hi;
+                    ev_flip |= (cond != h) ? (1u << k) : 0u;
+                    ev_lock |= (ls > P.lock_thr) ? (1u << k) : 0u;
+                }
+                ev_flip = (unsigned)__builtin_amdgcn_readfirstlane((int)ev_flip);
+                ev_lock = (unsigned)__builtin_amdgcn_readfirstlane((int)ev_lock);
+                const unsigned ev = ev_flip | ev_lock;
+                int done = nb;
+                if (ev) {
+                    const int k = __builtin_ctz(ev);
+                    const bool cond = ((ev_flip >> k) & 1u) ? !h : h;
+                    T fr = theirs.fpre[k], sw = theirs.swb[k];
+                    if (cond) pll_sweep_step(fr, sw, P.max_freq, P.min_freq);
+                    done = k + 1;
+                    avg = lane_get(av_l, k);
+                    locksig = lane_get(ls_l, k);
+                    fin_phase = theirs.phn[k]; fin_freq = fr; fin_sweep = sw;
+                    if ((ev_lock >> k) & 1u) {
+                        lock_at = i0 + k;
+                        freq_at_lock = fr;
+                        avg_at_lock = avg;
+                    }
+                    if (lane == 0) {
+                        verdict.event = 1; verdict.k = k; verdict.hyp = cond ? 1 : 0; verdict.locked = (int)((ev_lock >> k) & 1u);
+                        verdict.phase = fin_phase; verdict.freq = fr; verdict.sweep = sw;
+                    }
+                } else {
+                    avg = av;
+                    locksig = ls;
+                    fin_phase = theirs.ph_end; fin_freq = theirs.fr_end; fin_sweep = theirs.sw_end;
+                    if (lane == 0) verdict.event = 0;
+                }
+                if (lane < done) {
+                    out[i0 + lane] = o_l;
+                    if (lock_out) lock_out[i0 + lane] = ls_l;
+                }
+            } else if (lane == 0) {
+                verdict.event = 0;
+            }
+        }
+        __syncthreads();
+        // ---- hand-over
+        const AcqVerdict<T> v = verdict;
+        const bool ended = have_prev && v.event && v.locked;
+        if (have_prev && v.event) {
+            // the previous batch ended early at sample k: drop the speculative batch and resume after it
+            i_prod = theirs.i0 + v.k + 1;
+            phase = v.phase; freq = v.freq; sweep = v.sweep;
+            hyp = v.hyp != 0;
+            if (threadIdx.x == 0) mine.valid = 0;
+        } else if (produce) {
+            i_prod = mine.i0 + mine.nb;
+            phase = mine.ph_end; freq = mine.fr_end; sweep = mine.sw_end;
+        }
+        __syncthreads();
+        if (ended) break;
+    }
+    if (wave == 1 && lane == 0) {
+        PllState<T> st;
+        st.phase = fin_phase; st.freq = fin_freq; st.avg_phase = avg; st.locksig = locksig; st.sweep = fin_sweep;
+        info->lock_sample = lock_at;
+        info->st = st;
+        info->freq_at_lock = freq_at_lock;
+        info->avg_at_lock = avg_at_lock;
+    }
+}
+
 template <typename T> struct PllSeam {
     T phase0, freq0;   // state at the block's official start (after warm-up)
     T phase1, freq1;   // state after the block's last sample
