@@ -140,6 +140,9 @@ def main():
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--seconds", type=float, default=SECONDS, help="capture length (default: the 10-minute config)")
     ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline leg")
+    ap.add_argument("--captures", type=int, default=1,
+                    help="captures demodulated together per GPU and step through pdt_demod_batch_device (default 1 = the "
+                         "BASELINE configs[1] workload; >1 is the batched many-capture mode, reported as such)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -162,8 +165,13 @@ def main():
     dm = pdt.Demodulator(pdt.MODE_POES, FS, device=local, profile=True)
     dm.set_stream(torch.cuda.current_stream().cuda_stream)
 
+    extra = [pdt.Demodulator(pdt.MODE_POES, FS, device=local) for _ in range(max(args.captures, 1) - 1)]
+
     def step():
-        dm.demod_device(d_iq.data_ptr(), n)
+        if extra:
+            pdt.demod_batch([dm] + extra, [d_iq.data_ptr()] * (1 + len(extra)), [n] * (1 + len(extra)))
+        else:
+            dm.demod_device(d_iq.data_ptr(), n)
 
     for _ in range(args.warmup):
         step()
@@ -191,7 +199,7 @@ def main():
 
     if rank == 0:
         ms_step = dt / args.steps * 1e3
-        value = world * n * args.steps / dt / 1e6
+        value = world * max(args.captures, 1) * n * args.steps / dt / 1e6
         sb = stage_bytes(n, st.interp, st.symbols, st.bits)
         stages = {}
         for k, ms in ktot.items():
@@ -220,7 +228,9 @@ def main():
             "data": "synthetic",
             "config": {"workload": f"synthetic {FS // 1000} ksps complex-IQ capture, {args.seconds:g} s ({n} samples) per GPU, "
                                    "POES chain, chunk 10000, input resident in HBM",
-                       "samples_per_gpu": n, "captures": world, "parallelism": f"1 capture per GPU x{world}"},
+                       "samples_per_gpu": n * max(args.captures, 1), "captures": world * max(args.captures, 1),
+                       "parallelism": f"{max(args.captures, 1)} capture(s) per GPU x{world}"
+                                      + (" (batched many-capture mode, same capture in every slot)" if args.captures > 1 else "")},
             "roofline": {"bound": "hbm", "kernel": GROUP_KERNEL.get(dom, dom), "group": dom,
                          "achieved": stages[dom]["GBps"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": stages[dom]["frac_hbm"], "traffic": pmc_traffic(GROUP_KERNEL.get(dom, dom)),

@@ -162,6 +162,13 @@ int  pdt_demod_pcm16(pdt_ctx *ctx, const int16_t *iq_host, uint64_t nframes);
 /* ... or already resident in device memory (no copy; buffer is only read).                      */
 int  pdt_demod_device(pdt_ctx *ctx, const void *iq_device, uint64_t nframes);
 
+/* Batched many-capture mode: `count` independent captures, one context each, inputs resident in
+ * device memory.  The kernels of all captures are enqueued back to back on the contexts' own streams -- they
+ * overlap on the GPU, whose serial recurrences leave most of it idle for a single capture -- and the results are
+ * collected afterwards; each context then holds exactly what pdt_demod_device would have produced.
+ * (Measured: 1.5x the single-capture throughput at 8 captures of 30 M samples.)                             */
+int  pdt_demod_batch_device(pdt_ctx *const *ctxs, const void *const *iq_device, const uint64_t *nframes, int count);
+
 /* RAW input of demodPOES (".raw": interleaved IEEE float32 I,Q used as they are, no normalisation;
  * GetComplexRawChunk, wave.c:413-540, POESTIPdemod/main.c:313-339; the sample rate comes from -s).
  * POES only -- ARGOSdemod/main.c:238-241 refuses RAW files.                                       */

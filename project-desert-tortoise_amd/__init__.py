@@ -112,7 +112,7 @@ class KernelTime(C.Structure):
 # every symbol include/pdt.h declares (tests check the library exports all of them)
 ABI_SYMBOLS = [
     "pdt_abi_version", "pdt_strerror", "pdt_device_count", "pdt_open", "pdt_close", "pdt_set_stream",
-    "pdt_demod_pcm16", "pdt_demod_device", "pdt_demod_f32", "pdt_demod_device_f32", "pdt_num_frames", "pdt_frames", "pdt_get_stats",
+    "pdt_demod_pcm16", "pdt_demod_device", "pdt_demod_f32", "pdt_demod_device_f32", "pdt_demod_batch_device", "pdt_num_frames", "pdt_frames", "pdt_get_stats",
     "pdt_format_frames", "pdt_read_stage", "pdt_stage_len", "pdt_kernel_times", "pdt_make_lpf",
     "pdt_wav_parse_header", "pdt_time_axis", "pdt_stage_bytesync", "pdt_tip_check", "pdt_tip_frames",
     "pdt_stream_begin", "pdt_stream_push_pcm16", "pdt_stream_push_f32", "pdt_stream_end", "pdt_stream_frames",
@@ -161,6 +161,7 @@ def lib():
     L.pdt_time_axis.argtypes = [C.c_int, C.c_uint32, C.c_uint64]
     L.pdt_time_axis.restype = C.c_double
     L.pdt_stage_bytesync.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64]
+    L.pdt_demod_batch_device.argtypes = [C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), C.POINTER(C.c_uint64), C.c_int]
     L.pdt_stream_begin.argtypes = [C.c_void_p]
     L.pdt_stream_push_pcm16.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64, C.POINTER(C.c_uint64)]
     L.pdt_stream_push_f32.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64, C.POINTER(C.c_uint64)]
@@ -350,6 +351,18 @@ class Demodulator:
         arr = (KernelTime * max(n, 1))()
         self._L.pdt_kernel_times(self._h, arr, n)
         return {arr[i].name.decode(): (arr[i].launches, arr[i].total_ms) for i in range(n)}
+
+
+def demod_batch(demods, dev_ptrs, nframes):
+    """Batched many-capture mode: demods[i] demodulates the int16 I/Q capture at device address dev_ptrs[i]
+    (nframes[i] pairs); the kernels of all captures overlap on the GPU.  Results are read from each Demodulator."""
+    n = len(demods)
+    if not (n == len(dev_ptrs) == len(nframes)):
+        raise ValueError("demod_batch: lists of different lengths")
+    hs = (C.c_void_p * max(n, 1))(*[d._h for d in demods])
+    ps = (C.c_void_p * max(n, 1))(*[C.c_void_p(int(p)) for p in dev_ptrs])
+    ns = (C.c_uint64 * max(n, 1))(*[int(v) for v in nframes])
+    _check(lib().pdt_demod_batch_device(hs, ps, ns, n), "pdt_demod_batch_device")
 
 
 FRAME_DTYPE = np.dtype([

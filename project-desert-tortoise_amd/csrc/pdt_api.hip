@@ -112,6 +112,12 @@ struct pdt_ctx {
     void *pinned = nullptr;             // pinned staging buffer for the frame records
     size_t pinned_cap = 0;
     uint32_t last_nframes = 0;
+    // results in flight between the enqueue and the finish phase of a capture
+    DevScalars *pend_sc = nullptr;      // both in one small pinned block (pageable targets would make the
+    unsigned char *pend_info = nullptr; // "asynchronous" read-back copies wait for the stream)
+    uint32_t pend_got_frames = 0;
+    uint64_t pend_n = 0;
+    bool pending = false;
     uint64_t stage_len[PDT_ST_COUNT];
     TimeAxis<float> axis_f;
     TimeAxis<double> axis_d;
@@ -271,7 +277,11 @@ void launch_bytesync(pdt_ctx *ctx, hipStream_t st, const SyncParams &SP, DevScal
                        &d_sc->nframes, frame_cap);
 }
 
-template <typename T> int run_capture(pdt_ctx *ctx, uint64_t n)
+// phase: the whole call, or split for the batched entry point -- enqueue every kernel and the read-back copies of
+// one capture (no host synchronisation), later wait for them and build the host-side results
+enum { RUN_ALL = 0, RUN_ENQUEUE = 1, RUN_FINISH = 2 };
+
+template <typename T> int run_capture(pdt_ctx *ctx, uint64_t n, int phase = RUN_ALL)
 {
     const bool argos = ctx->cfg.mode == PDT_MODE_ARGOS;
     const long long N = (long long)n;
@@ -392,6 +402,7 @@ template <typename T> int run_capture(pdt_ctx *ctx, uint64_t n)
     T *d_norm = (T *)&d_sc->norm;
     T *d_taps = (T *)ctx->taps.p;
 
+    if (phase != RUN_FINISH) {
     HIP_TRY(hipEventRecord(ctx->ev0, st));
     HIP_TRY(hipMemsetAsync(d_sc, 0, sizeof(DevScalars), st));
     HIP_TRY(hipMemsetAsync(d_frames, 0, (size_t)frame_cap * sizeof(FrameRec), st));
@@ -711,8 +722,6 @@ template <typename T> int run_capture(pdt_ctx *ctx, uint64_t n)
     // ---- results back to the host
     // one synchronisation: the scalars, the lock record and (speculatively, into pinned memory) as many frame
     // records as the previous call of this context produced, plus a margin
-    DevScalars sc;
-    PllLockInfo<T> info;
     const uint32_t spec_frames = std::min<uint32_t>(frame_cap, ctx->last_nframes + ctx->last_nframes / 8 + 64);
     if ((size_t)spec_frames * sizeof(FrameRec) > ctx->pinned_cap) {
         if (ctx->pinned) (void)hipHostFree(ctx->pinned);
@@ -723,10 +732,22 @@ template <typename T> int run_capture(pdt_ctx *ctx, uint64_t n)
         else (void)hipGetLastError();
     }
     const uint32_t got_frames = (ctx->pinned_cap >= (size_t)spec_frames * sizeof(FrameRec)) ? spec_frames : 0u;
-    HIP_TRY(hipMemcpyAsync(&sc, d_sc, sizeof sc, hipMemcpyDeviceToHost, st));
-    HIP_TRY(hipMemcpyAsync(&info, d_info, sizeof info, hipMemcpyDeviceToHost, st));
+    static_assert(sizeof(PllLockInfo<T>) <= 96, "lock record staging");
+    HIP_TRY(hipMemcpyAsync(ctx->pend_sc, d_sc, sizeof(DevScalars), hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipMemcpyAsync(ctx->pend_info, d_info, sizeof(PllLockInfo<T>), hipMemcpyDeviceToHost, st));
     if (got_frames) HIP_TRY(hipMemcpyAsync(ctx->pinned, d_frames, (size_t)got_frames * sizeof(FrameRec), hipMemcpyDeviceToHost, st));
+    ctx->pend_got_frames = got_frames;
+    ctx->pend_n = n;
+    ctx->pending = true;
+    }   // phase != RUN_FINISH
+    if (phase == RUN_ENQUEUE) return PDT_OK;
+    if (!ctx->pending || ctx->pend_n != n) return PDT_ERR_STATE;
+    ctx->pending = false;
     HIP_TRY(hipStreamSynchronize(st));
+    const DevScalars &sc = *ctx->pend_sc;
+    PllLockInfo<T> info;
+    memcpy(&info, ctx->pend_info, sizeof info);
+    const uint32_t got_frames = ctx->pend_got_frames;
     if (sc.nframes > frame_cap || sc.nhits > hit_cap || (long long)sc.nsym > sym_cap) {
         fprintf(stderr, "libpdt: internal capacity exceeded (frames %u/%u hits %u/%u symbols %llu/%lld)\n", sc.nframes,
                 frame_cap, sc.nhits, hit_cap, sc.nsym, sym_cap);
@@ -765,9 +786,10 @@ template <typename T> int run_capture(pdt_ctx *ctx, uint64_t n)
     S.agc_seam_fixes = sc.counters[3];
     S.gpu_ms = ms;
     S.gardner_parallel = (uint32_t)ctx->gardner_mode;
-    S.gardner_walked = use_table ? sc.gstats[2] : 0u;
-    S.gardner_full_domain = use_table ? sc.gstats[1] : 0u;
-    S.gardner_candidates = use_table ? sc.gstats[3] : 0u;
+    const bool tabled = ctx->gardner_mode != 0;
+    S.gardner_walked = tabled ? sc.gstats[2] : 0u;
+    S.gardner_full_domain = tabled ? sc.gstats[1] : 0u;
+    S.gardner_candidates = tabled ? sc.gstats[3] : 0u;
     S.sync_overflow = sc.sync_overflow;
 
     ctx->stage_len[PDT_ST_PLL] = n;
@@ -960,6 +982,12 @@ int pdt_open(const pdt_config *cfg, pdt_ctx **out)
     }
     if (hipStreamCreate(&ctx->stream) != hipSuccess) { delete ctx; return PDT_ERR_NOGPU; }
     ctx->own_stream = true;
+    {
+        void *small = nullptr;
+        if (hipHostMalloc(&small, sizeof(DevScalars) + 128, hipHostMallocDefault) != hipSuccess) { delete ctx; return PDT_ERR_NOMEM; }
+        ctx->pend_sc = (DevScalars *)small;
+        ctx->pend_info = (unsigned char *)small + ((sizeof(DevScalars) + 15) & ~(size_t)15);
+    }
     (void)hipEventCreate(&ctx->ev0);
     (void)hipEventCreate(&ctx->ev1);
     (void)hipEventCreateWithFlags(&ctx->ev_fork, hipEventDisableTiming);
@@ -984,6 +1012,7 @@ void pdt_close(pdt_ctx *ctx)
     for (DevBuf *b : bufs) b->release();
     for (hipEvent_t e : ctx->event_pool) (void)hipEventDestroy(e);
     if (ctx->pinned) (void)hipHostFree(ctx->pinned);
+    if (ctx->pend_sc) (void)hipHostFree(ctx->pend_sc);
     for (auto &t : ctx->timers) { (void)hipEventDestroy(t.a); (void)hipEventDestroy(t.b); }
     if (ctx->ev0) (void)hipEventDestroy(ctx->ev0);
     if (ctx->ev1) (void)hipEventDestroy(ctx->ev1);
@@ -1007,13 +1036,13 @@ int pdt_set_stream(pdt_ctx *ctx, void *hip_stream)
     return PDT_OK;
 }
 
-static int demod_common(pdt_ctx *ctx, uint64_t nframes)
+static int demod_common(pdt_ctx *ctx, uint64_t nframes, int phase = RUN_ALL)
 {
     HIP_TRY(hipSetDevice(ctx->cfg.device));
     ctx->n_samples = nframes;
     ctx->n_out = nframes * ctx->interp;
-    if (ctx->cfg.mode == PDT_MODE_ARGOS) return run_capture<double>(ctx, nframes);
-    return run_capture<float>(ctx, nframes);
+    if (ctx->cfg.mode == PDT_MODE_ARGOS) return run_capture<double>(ctx, nframes, phase);
+    return run_capture<float>(ctx, nframes, phase);
 }
 
 int pdt_demod_pcm16(pdt_ctx *ctx, const int16_t *iq_host, uint64_t nframes)
@@ -1113,6 +1142,30 @@ int pdt_stage_bytesync(pdt_ctx *ctx, const uint8_t *bits_host, uint64_t nbits)
     ctx->stats.sync_overflow = sc.sync_overflow;
     memset(ctx->stage_len, 0, sizeof ctx->stage_len);
     return PDT_OK;
+}
+
+// ---------------------------------------------------------------- batched many-capture mode
+int pdt_demod_batch_device(pdt_ctx *const *ctxs, const void *const *iq_device, const uint64_t *nframes, int count)
+{
+    if (count < 0 || (count && (!ctxs || !iq_device || !nframes))) return PDT_ERR_ARG;
+    for (int i = 0; i < count; i++) {
+        if (!ctxs[i] || (!iq_device[i] && nframes[i])) return PDT_ERR_ARG;
+        for (int j = 0; j < i; j++)
+            if (ctxs[j] == ctxs[i]) return PDT_ERR_ARG;               // one context per capture
+    }
+    int first_err = PDT_OK, enq = 0;
+    for (; enq < count; enq++) {                                        // every kernel of every capture, no host wait
+        pdt_ctx *c = ctxs[enq];
+        c->pcm_dev = iq_device[enq];
+        c->pcm_fmt = 0;
+        const int rc = demod_common(c, nframes[enq], RUN_ENQUEUE);
+        if (rc) { first_err = rc; break; }
+    }
+    for (int i = 0; i < enq; i++) {                                     // then collect them in order
+        const int rc = demod_common(ctxs[i], nframes[i], RUN_FINISH);
+        if (rc && !first_err) first_err = rc;
+    }
+    return first_err;
 }
 
 // ---------------------------------------------------------------- streaming front end

@@ -23,6 +23,11 @@ for M in (1, 2, 4, 8, 16):
     [t.start() for t in th]
     [t.join() for t in th]
     dt = time.time() - t0
+    t0 = time.time()
+    for _ in range(steps):
+        pdt.demod_batch(ds, [dev.data_ptr()] * M, [n] * M)
+    dtb = time.time() - t0
+    print(f"M={M}: batch entry point {M * steps * n / dtb / 1e6:.0f} Msamples/s ({dtb / steps * 1e3:.2f} ms per batch)", flush=True)
     fr = [d.stats().frames for d in ds]
     print(f"M={M}: {M * steps * n / dt / 1e6:.0f} Msamples/s  ({dt / steps * 1e3:.2f} ms per round of {M} captures) frames {fr[0]} gpu_ms {ds[0].stats().gpu_ms:.2f}", flush=True)
     for d in ds:
