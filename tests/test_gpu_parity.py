@@ -255,6 +255,24 @@ def test_ten_minute_capture_matches_oracle(pdt, orc):
         assert d.stats().frames == len(o.frames()) >= 5990
 
 
+@pytest.mark.parametrize("mult", [5, 10])
+def test_weak_signal_repair_cascades(pdt, orc, mult):
+    """Noise scaled up 5x / 10x (6 dB / 0 dB SNR): the tracking loop stops being contracting, many seams fail their
+    bitwise check and are re-run in cascades -- every stage must still equal the oracle."""
+    import ctypes as C
+    fs, secs = 50000, 20.0
+    p = pdt.synth_params(0, fs, 1000.0, 77)
+    p.noise_gain = int(p.noise_gain * mult)
+    n = int(round(secs * fs))
+    iq = np.zeros((n, 2), dtype="<i2")
+    pdt.synth_lib().pdt_synth_fill(C.byref(p), 0, n, iq.ctypes.data)
+    o = orc.Oracle(orc.POES, fs, iq)
+    with pdt.Demodulator(pdt.MODE_POES, fs) as d:
+        d.demod(iq)
+        check_all_stages(pdt, orc, d, o)
+        assert d.stats().pll_seam_fixes >= 5          # the repair path really ran
+
+
 def test_250ksps_capture_matches_oracle(pdt, orc):
     """BASELINE configs[2]/[4] geometry (250 ksps, interp 1, 26 taps) on a 2-minute, 30 000 000-sample capture:
     bit-exact output file vs the CPU oracle, every transmitted frame in order.  (tools/c3_check.py runs the
