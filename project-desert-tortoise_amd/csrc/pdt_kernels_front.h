@@ -992,6 +992,42 @@ __global__ void __launch_bounds__(PDT_FIX_THREADS) k_pll_fix(const T *__restrict
         from = s_bad[ncommit - 1] + 1;
         __threadfence();
         __syncthreads();
+        // cascade: when the last committed re-run changed its block's end state, the following blocks will fail
+        // one after the other until the true trajectory merges with the stored one (on weak signals that can be
+        // most of the capture); walk them right here, in place -- everything before them is final --
+        // instead of paying a scan + synchronisation round for each
+        {
+            const long long rl = s_bad[ncommit - 1];
+            if (threadIdx.x == 0) {
+                long long r = rl + 1;
+                unsigned extra = 0;
+                while (r < nb_abs) {
+                    const PllSeam<T> prev = seams[r - 1];
+                    const PllSeam<T> cur = seams[r];
+                    if (bits_equal(prev.phase1, cur.phase0) && bits_equal(prev.freq1, cur.freq0)) break;
+                    T phase = prev.phase1, freq = prev.freq1;
+                    const long long start = r * B;
+                    const long long end = ((r + 1) * B < n) ? (r + 1) * B : n;
+                    pll_phase_range<T, true, SLOW, 32>(theta, phi, start, end, phase, freq, P.alpha_trk, P.beta_trk, P.max_freq,
+                                                       P.min_freq);
+                    PllSeam<T> upd;
+                    upd.phase0 = prev.phase1;
+                    upd.freq0 = prev.freq1;
+                    upd.phase1 = phase;
+                    upd.freq1 = freq;
+                    seams[r] = upd;
+                    extra++;
+                    r++;
+                }
+                s_min = r;
+                s_nbad = extra;
+            }
+            __threadfence();
+            __syncthreads();
+            from = s_min;
+            fixes += s_nbad;
+            __syncthreads();
+        }
     }
     if (threadIdx.x == 0) {
         counters[0] = (unsigned)((S < n) ? nb_abs - j0 : 0);
