@@ -9,11 +9,14 @@ namespace pdt {
 // Gardner clock recovery (reference: common/GardenerClockRecovery.c:5-114)
 //
 // The sampler is a leak-free integrator of a data-dependent, clipped error with
-// nearest-sample picks: perturbed trajectories do not re-merge, so
-// this stage is a true sequential chain over the symbols of one capture.  One lane
-// walks it; the other lanes of the workgroup only stage the current reference chunk
-// (chunk-relative coordinates are part of the arithmetic: float spacing depends on
-// the position inside the chunk) into LDS with coalesced loads.
+// nearest-sample picks: there is no contraction to lean on as in the PLL / AGC, and in double
+// precision or odd chunk geometries this stage is a true sequential chain over the symbols of one
+// capture -- one lane walks it (k_gardner, sequential mode); the other lanes of the workgroup only
+// stage the current reference chunk (chunk-relative coordinates are part of the arithmetic: float
+// spacing depends on the position inside the chunk) into LDS with coalesced loads.
+// The float build normally goes through the exact parallel scheme further down (boundary-state
+// tables), which uses the one regularity there is: trajectories that pick the same samples receive
+// the same corrections and merge exactly.
 // ------------------------------------------------------------------------------------------
 template <typename T> struct GardnerParams {
     T step, kp, lim;

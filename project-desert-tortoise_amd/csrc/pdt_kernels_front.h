@@ -102,7 +102,9 @@ template <typename T> __device__ __forceinline__ T pll_locksig(T a, T b, T t_rea
     return (T)((double)locksig * (1.0 - (double)lock_alpha) + (double)(lock_alpha * (re * t_real + im * t_imag)));
 }
 
-// Acquisition: strictly sequential until the one-time lock event (Q9).  One lane.
+// Acquisition, plain form: the reference iteration sample by sample on one lane until the one-time lock
+// event (Q9).  Kept as the readable statement of the iteration and for A/B runs (PDT_ACQUIRE_SIMPLE); the
+// product path is k_pll_acquire_pipe below.
 template <typename T>
 __global__ void __launch_bounds__(64) k_pll_acquire(IqSrc pcm, long long n, PllParams<T> P,
                                                      T *__restrict__ out, T *__restrict__ lock_out,
