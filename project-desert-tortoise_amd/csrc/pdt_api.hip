@@ -331,6 +331,15 @@ template <typename T> int run_capture(pdt_ctx *ctx, uint64_t n, int phase = RUN_
     long long Wa = ctx->cfg.agc_warm ? ctx->cfg.agc_warm : (long long)((argos ? 8.0 : 1.0) * fs_d * interp);
     Bp = std::max<long long>(64, round4(Bp));
     Ba = std::max<long long>(64, round4(Ba));
+    // POES with the register-tiled FIR: AGC blocks made of whole FIR tiles (64 * 26 inputs), so that the FIR kernel can
+    // deliver the AGC's affine tile maps itself (0 = not fused: explicit block size, ARGOS, generic FIR)
+    long long agc_tiles_per_block = 0, fused_tiles = 0;
+    if (!argos && !ctx->cfg.agc_block && ntaps == 26 * interp && ctx->taps_rot.p && !getenv("PDT_FIR_GENERIC") &&
+        !getenv("PDT_AGC_UNFUSED")) {
+        const long long tile_out = 64ll * 26 * interp;
+        agc_tiles_per_block = std::max<long long>(1, (Ba + tile_out / 2) / tile_out);
+        Ba = agc_tiles_per_block * tile_out;
+    }
     Wp = round4(Wp);
     Wa = round4(Wa);
     Wacq = round4(Wacq);
@@ -529,6 +538,13 @@ template <typename T> int run_capture(pdt_ctx *ctx, uint64_t n, int phase = RUN_
             const int K = ntaps / interp;
             const size_t sh_rt = (size_t)(65 * (K + 1) + 3 + 64 * K * interp) * sizeof(T);
             const long long tiles_rt = (N + 64ll * K - 1) / (64ll * K);
+            // the AGC's affine tile maps are folded into this kernel when the AGC blocks are whole FIR tiles
+            AgcMap *fir_tile_maps = nullptr;
+            if (agc_tiles_per_block > 0) {
+                if ((rc = ctx->agc_maps.ensure((size_t)(tiles_rt + 1) * sizeof(AgcMap) + (size_t)(nb_agc + 1) * sizeof(double)))) return rc;
+                fir_tile_maps = (AgcMap *)ctx->agc_maps.p;
+                fused_tiles = tiles_rt;
+            }
             const unsigned grid_rt = (unsigned)std::min<long long>(tiles_rt, 256ll * 6);   // persistent workgroups, 6 per CU
             bool done = false;
             if (K == 26 && sh_rt <= 64000 && ctx->taps_rot.p && !getenv("PDT_FIR_GENERIC")) {
@@ -536,13 +552,15 @@ template <typename T> int run_capture(pdt_ctx *ctx, uint64_t n, int phase = RUN_
                 switch (interp) {
 #define PDT_FIR_CASE(I)                                                                                                       \
     case I:                                                                                                                   \
-        hipLaunchKernelGGL((k_fir_interp_rt<T, I, 26>), dim3(grid_rt), dim3(PDT_FIR_THREADS), sh_rt, st, d_pll, N, (const T *)ctx->taps_rot.p, d_fir); \
+        hipLaunchKernelGGL((k_fir_interp_rt<T, I, 26>), dim3(grid_rt), dim3(PDT_FIR_THREADS), sh_rt, st, d_pll, N, (const T *)ctx->taps_rot.p, d_fir, \
+                           fir_tile_maps, AP.decay);                                                                                    \
         break;
                     PDT_FIR_CASE(1) PDT_FIR_CASE(2) PDT_FIR_CASE(3) PDT_FIR_CASE(4) PDT_FIR_CASE(5) PDT_FIR_CASE(6)
 #undef PDT_FIR_CASE
                 default: done = false;
                 }
             }
+            if (!done) fused_tiles = 0;
             if (!done) {                                       // any other interpolation factor: generic form
                 const size_t sh = (size_t)(ntaps + tile / interp + K + 8) * sizeof(T);
                 hipLaunchKernelGGL(k_fir_interp<T>, dim3((unsigned)grid), dim3(PDT_FIR_THREADS), sh, st, d_pll, N, interp, K,
@@ -556,16 +574,18 @@ template <typename T> int run_capture(pdt_ctx *ctx, uint64_t n, int phase = RUN_
     if (n_out > 0) {
         const long long nb = (n_out + Ba - 1) / Ba;
         const long long grid = (nb + 63) / 64;
-        if ((rc = ctx->agc_maps.ensure((size_t)(nb + 1) * (sizeof(AgcMap) + sizeof(double))))) return rc;
+        const bool fused = fused_tiles > 0;                    // tile maps already written by the FIR kernel
+        if (!fused && (rc = ctx->agc_maps.ensure((size_t)(nb + 1) * (sizeof(AgcMap) + sizeof(double))))) return rc;
         AgcMap *d_maps = (AgcMap *)ctx->agc_maps.p;
-        double *d_guess = (double *)(d_maps + nb + 1);
+        double *d_guess = (double *)(d_maps + (fused ? fused_tiles : nb) + 1);
         // warm-up length in gain time constants: the affine guess is off by the accumulated float rounding of
         // the true recurrence only, so a few time constants make the trajectories agree to the last bit
         double agc_K = (sizeof(T) == 4) ? 11.0 : 34.0;
         if (const char *e = getenv("PDT_AGC_K")) agc_K = atof(e);
         L.begin("agc_block");
-        hipLaunchKernelGGL(k_agc_affine<T>, dim3((unsigned)nb), dim3(256), 0, st, d_fir, n_out, AP.decay, Ba, d_maps);
-        hipLaunchKernelGGL(k_agc_guess<T>, dim3(1), dim3(1024), 0, st, (const AgcMap *)d_maps, nb, (const T *)d_norm, d_guess);
+        if (!fused) hipLaunchKernelGGL(k_agc_affine<T>, dim3((unsigned)nb), dim3(256), 0, st, d_fir, n_out, AP.decay, Ba, d_maps);
+        hipLaunchKernelGGL(k_agc_guess<T>, dim3(1), dim3(1024), 0, st, (const AgcMap *)d_maps, nb, (const T *)d_norm, d_guess,
+                           fused ? (int)agc_tiles_per_block : 1, fused ? fused_tiles : nb);
         hipLaunchKernelGGL(k_agc_block<T>, dim3((unsigned)grid), dim3(64), 0, st, d_fir, n_out, AP, d_norm, Ba, Wa,
                            (const double *)d_guess, d_lock, d_agc, (AgcSeam<T> *)ctx->seams_agc.p, agc_K);
         L.end();

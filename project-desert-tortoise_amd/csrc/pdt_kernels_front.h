@@ -1134,6 +1134,9 @@ __global__ void __launch_bounds__(64) k_lock_ema_fix(const T *__restrict__ term,
     if (threadIdx.x == 0) *fixes_out += fixes;
 }
 
+// decay branch of one AGC step as an affine map of the gain, g -> A g + B (see the AGC section below)
+struct AgcMap { double A, B; };
+
 // ------------------------------------------------------------------------------------------
 // FIR (reference: common/LowPassFilter.c:13-71 interpolating, :76-125 in place)
 // ------------------------------------------------------------------------------------------
@@ -1197,7 +1200,8 @@ __global__ void __launch_bounds__(PDT_FIR_THREADS) k_fir_interp(const T *__restr
 template <typename T, int INTERP, int K>
 __global__ void __launch_bounds__(PDT_FIR_THREADS) k_fir_interp_rt(const T *__restrict__ in, long long n_in,
                                                                     const T *__restrict__ rot /* host-built rotated taps */,
-                                                                    T *__restrict__ out)
+                                                                    T *__restrict__ out, AgcMap *__restrict__ tile_maps,
+                                                                    T agc_decay)
 {
     extern __shared__ __align__(16) unsigned char smem_raw[];
     constexpr int TI = 64 * K;                               // inputs (= values of M) per workgroup
@@ -1245,6 +1249,46 @@ __global__ void __launch_bounds__(PDT_FIR_THREADS) k_fir_interp_rt(const T *__re
         }
         __syncthreads();
         const long long g0 = m0 * INTERP;                    // multiple of 4
+        if (tile_maps) {
+            // fused: the AGC's affine model of this tile (k_agc_affine's job) while its outputs are still in LDS.
+            // Every thread composes PER consecutive outputs in order, the 256 partial maps are reduced in
+            // order -- shuffles inside a wavefront, LDS across the four -- and thread 0 writes the tile map.
+            constexpr int PER = (n_tile + PDT_FIR_THREADS - 1) / PDT_FIR_THREADS;
+            const int cnt = (int)((n_out - g0 < n_tile) ? (n_out - g0) : n_tile);
+            const double r = (double)agc_decay;
+            double A = 1.0, Bc = 0.0;
+            const int i0 = threadIdx.x * PER;
+#pragma unroll 4
+            for (int u = 0; u < PER; u++) {
+                const int i = i0 + u;
+                if (i < cnt) {
+                    const double a = 1.0 - r * (double)Real<T>::abs(s_out[i]);
+                    A = a * A;
+                    Bc = a * Bc + r;
+                }
+            }
+            for (int d = 1; d < 64; d <<= 1) {               // ordered: lane i absorbs lanes i+1 .. i+2d-1
+                const double Ar = __shfl_down(A, d), Br = __shfl_down(Bc, d);
+                if (((threadIdx.x & 63) & (2 * d - 1)) == 0) {
+                    Bc = Ar * Bc + Br;
+                    A = Ar * A;
+                }
+            }
+            double *s_red = reinterpret_cast<double *>(s_in);            // the input rows are no longer needed
+            if ((threadIdx.x & 63) == 0) { s_red[2 * wave] = A; s_red[2 * wave + 1] = Bc; }
+            __syncthreads();
+            if (threadIdx.x == 0) {
+                double tA = 1.0, tB = 0.0;
+                for (int w = 0; w < PDT_FIR_THREADS / 64; w++) {
+                    tB = s_red[2 * w] * tB + s_red[2 * w + 1];
+                    tA = s_red[2 * w] * tA;
+                }
+                AgcMap m;
+                m.A = tA;
+                m.B = tB;
+                tile_maps[tile] = m;
+            }
+        }
         if (g0 + n_tile <= n_out) {
             constexpr int VN = Vec16<T>::N;
             for (int t = threadIdx.x * VN; t < n_tile; t += PDT_FIR_THREADS * VN)
@@ -1466,7 +1510,7 @@ __device__ __forceinline__ void agc_range(const T *__restrict__ in, const T *__r
 // That is only a GUESS: each block still replays a warm-up with the exact float recurrence and
 // its seam is verified bitwise; but a guess this close cuts the warm-up from ~45 to ~14 time
 // constants.
-struct AgcMap { double A, B; };
+// (struct AgcMap is declared with the FIR kernels above: the register-tiled FIR folds its tile maps)
 
 #define PDT_AFF_TILE 8192
 template <typename T>
@@ -1534,16 +1578,30 @@ __global__ void __launch_bounds__(256) k_agc_affine(const T *__restrict__ in, lo
 // LDS (affine maps form a monoid), then every thread replays its slice from its prefix.
 template <typename T>
 __global__ void __launch_bounds__(1024) k_agc_guess(const AgcMap *__restrict__ maps, long long nb, const T *__restrict__ norm,
-                                                     double *__restrict__ guesses)
+                                                     double *__restrict__ guesses, int maps_per_block, long long n_maps)
 {
     __shared__ double sA[1024], sB[1024];
     const long long per = (nb + 1023) / 1024;
     long long j0 = (long long)threadIdx.x * per, j1 = j0 + per;
     if (j0 > nb) j0 = nb;
     if (j1 > nb) j1 = nb;
+    // map of block j = its maps_per_block consecutive (FIR-tile) maps composed in order (1 = maps are block maps)
+    auto block_map = [&](long long j) {
+        AgcMap bm;
+        bm.A = 1.0; bm.B = 0.0;
+        for (int q = 0; q < maps_per_block; q++) {
+            const long long t = j * maps_per_block + q;
+            if (t < n_maps) {
+                const AgcMap m = maps[t];
+                bm.B = m.A * bm.B + m.B;
+                bm.A = m.A * bm.A;
+            }
+        }
+        return bm;
+    };
     double A = 1.0, Bc = 0.0;
     for (long long j = j0; j < j1; j++) {
-        const AgcMap m = maps[j];
+        const AgcMap m = block_map(j);
         Bc = m.A * Bc + m.B;
         A = m.A * A;
     }
@@ -1571,7 +1629,7 @@ __global__ void __launch_bounds__(1024) k_agc_guess(const AgcMap *__restrict__ m
         if (!(gg > 1e-4)) gg = 1e-4;                // keep the model sane where the real AGC would clamp
         if (gg > 5000.0) gg = 5000.0;
         guesses[j] = gg;
-        const AgcMap m = maps[j];
+        const AgcMap m = block_map(j);
         g = m.A * g + m.B;
     }
 }
