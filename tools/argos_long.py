@@ -1,0 +1,20 @@
+"""A long ARGOS capture: kernel-group times and the reference CPU path on the same input (run on a GPU box)."""
+import importlib, os, subprocess, sys, tempfile, time
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+pdt = importlib.import_module("project-desert-tortoise_amd")
+secs = float(os.environ.get("PDT_SECS", "300"))
+iq = pdt.synth_capture(1, 32000, secs, f0_hz=150.0, seed=5)
+d = pdt.Demodulator(pdt.MODE_ARGOS, 32000, profile=True)
+d.demod(iq); d.demod(iq)
+s = d.stats(); kt = d.kernel_times()
+print(f"ARGOS {len(iq)} samples: {s.frames} packets, gpu_ms {s.gpu_ms:.1f} ({len(iq) / s.gpu_ms / 1e3:.0f} Msamples/s), pll fixes {s.pll_seam_fixes}/{s.pll_blocks}, agc fixes {s.agc_seam_fixes}/{s.agc_blocks}")
+print("  " + " ".join(f"{k} {v[1]:.2f}" for k, v in kt.items()), flush=True)
+ref = os.path.join(ROOT, "oracle", "_ref", "ref_demodARGOS")
+if os.path.exists(ref):
+    with tempfile.TemporaryDirectory() as tmp:
+        wav = os.path.join(tmp, "a.wav"); out = os.path.join(tmp, "o.txt")
+        pdt.write_wav(wav, 32000, iq)
+        t0 = time.time(); subprocess.run([ref, wav, out], check=True, capture_output=True); dt = time.time() - t0
+        text = open(out, "rb").read()
+    print(f"reference CPU: {dt:.2f} s ({len(iq) / dt / 1e6:.2f} Msamples/s); packet file identical: {text == d.text()} ({len(text)} bytes)")
