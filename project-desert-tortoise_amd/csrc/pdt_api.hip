@@ -324,7 +324,7 @@ template <typename T> int run_capture(pdt_ctx *ctx, uint64_t n, int phase = RUN_
     // ---- block-parallel geometry (any values give the same output; they only move time around)
     const double fs_d = (double)ctx->cfg.sample_rate;
     auto round4 = [](long long v) { return (v + 3) / 4 * 4; };
-    long long Bp = ctx->cfg.pll_block ? ctx->cfg.pll_block : (long long)((argos ? 4.0 : 0.05) * fs_d);
+    long long Bp = ctx->cfg.pll_block ? ctx->cfg.pll_block : (long long)((argos ? 0.5 : 0.05) * fs_d);
     long long Wp = ctx->cfg.pll_warm ? ctx->cfg.pll_warm : (long long)((argos ? 8.0 : 0.3) * fs_d);
     long long Wacq = (long long)(0.02 * fs_d);             // acquisition-gain stage of the warm-up
     long long Ba = ctx->cfg.agc_block ? ctx->cfg.agc_block : (long long)((argos ? 0.125 : 0.0625) * fs_d * interp);
@@ -718,7 +718,7 @@ template <typename T> int run_capture(pdt_ctx *ctx, uint64_t n, int phase = RUN_
         L.end();
     } else {
         L.begin("gardner");
-        hipLaunchKernelGGL((k_gardner<T, GardnerLds<T>::LEN, GardnerLds<T>::OUT>), dim3(1), dim3(PDT_GARDNER_THREADS), 0, st, d_agc, d_lock, GP, d_sym, d_symidx,
+        hipLaunchKernelGGL((k_gardner<T, GardnerLds<T>::LEN, GardnerLds<T>::OUT>), dim3(1), dim3(256), 0, st, d_agc, d_lock, GP, d_sym, d_symidx,
                            &d_sc->nsym, sym_cap, (const GardnerEntry<T> *)nullptr);
         L.end();
     }

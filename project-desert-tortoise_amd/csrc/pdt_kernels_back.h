@@ -93,6 +93,8 @@ __device__ __forceinline__ long long gardner_walk_chunk(const T *__restrict__ in
                                                         long long *__restrict__ symidx, long long count0, long long sym_cap)
 {
     const int lane = threadIdx.x;
+    const int NT = (int)blockDim.x;            // 64 in the per-chunk kernels; 256 in the sequential kernel, where every
+                                               // wavefront walks the same trajectory and all of them stage and flush
     T ns = S.ns, prev = S.prev, half = S.half, q_last = S.q_last;
     unsigned i_last = S.i_last;
     const T hs = (T)((double)P.step / 2.0);       // exact: step/2 is representable
@@ -115,17 +117,17 @@ __device__ __forceinline__ long long gardner_walk_chunk(const T *__restrict__ in
             const int n_data = (int)((avail < (unsigned)LEN) ? avail : (unsigned)LEN);
             const T *src = in + base + wbase;
             int t = lane;
-            for (; t + 7 * PDT_GARDNER_THREADS < n_data; t += 8 * PDT_GARDNER_THREADS) {
+            for (; t + 7 * NT < n_data; t += 8 * NT) {
                 T r[8];
 #pragma unroll
-                for (int u = 0; u < 8; u++) r[u] = src[t + u * PDT_GARDNER_THREADS];
+                for (int u = 0; u < 8; u++) r[u] = src[t + u * NT];
 #pragma unroll
-                for (int u = 0; u < 8; u++) win[t + u * PDT_GARDNER_THREADS] = r[u];
+                for (int u = 0; u < 8; u++) win[t + u * NT] = r[u];
             }
-            for (; t < n_data; t += PDT_GARDNER_THREADS) win[t] = src[t];
+            for (; t < n_data; t += NT) win[t] = src[t];
             int n_tail = n_data + 2 * (int)step + 24;          // furthest look-ahead of the mid-point
             if (n_tail > LEN) n_tail = LEN;
-            for (int q = n_data + lane; q < n_tail; q += PDT_GARDNER_THREADS)
+            for (int q = n_data + lane; q < n_tail; q += NT)
                 win[q] = gardner_beyond(in, lock, P, c, (long long)n_cur, (long long)(wbase + (unsigned)q));
             n_staged = n_tail;
         }
@@ -193,7 +195,7 @@ __device__ __forceinline__ long long gardner_walk_chunk(const T *__restrict__ in
         // ---- flush staged symbols with coalesced stores
         if (EMIT) {
             __syncthreads();
-            for (int t = lane; t < nout; t += PDT_GARDNER_THREADS) {
+            for (int t = lane; t < nout; t += NT) {
                 const long long k = count + t;
                 if (k < sym_cap) {
                     sym[k] = o_val[t];
@@ -224,7 +226,7 @@ template <typename T> struct GardnerEntry {
 // sequential mode (entries == nullptr): one wavefront walks every chunk in order.
 // parallel mode: block b owns chunk b and starts from the tabulated entry state.
 template <typename T, int LEN, int OUT>
-__global__ void __launch_bounds__(PDT_GARDNER_THREADS) k_gardner(const T *__restrict__ in, const T *__restrict__ lock,
+__global__ void __launch_bounds__(256) k_gardner(const T *__restrict__ in, const T *__restrict__ lock,
                                                                   GardnerParams<T> P, T *__restrict__ sym,
                                                                   long long *__restrict__ symidx,
                                                                   unsigned long long *__restrict__ nsym_out,
