@@ -1065,6 +1065,42 @@ __global__ void __launch_bounds__(256) k_pll_mix(IqSrc pcm, const T *__restrict_
 // in double and narrowed like the reference (:220).  Same block/warm-up/seam scheme.
 template <typename T> struct EmaSeam { T v0, v1; };
 
+// the EMA over [i0, i1) with the software-pipelined 16-byte loads of the other stream walkers
+template <typename T, bool STORE>
+__device__ __forceinline__ void ema_range(const T *__restrict__ term, T *__restrict__ out, long long i0, long long i1, T &L, double k)
+{
+    constexpr int VN = Vec16<T>::N;
+    long long i = i0;
+    for (; i < i1 && (i % VN) != 0; i++) {
+        L = (T)((double)L * k + (double)term[i]);
+        if (STORE) out[i] = L;
+    }
+    if (i + PDT_PF * VN <= i1) {
+        Vec16<T> buf[PDT_PF];
+#pragma unroll
+        for (int u = 0; u < PDT_PF; u++) buf[u] = *reinterpret_cast<const Vec16<T> *>(term + i + u * VN);
+        for (; i + PDT_PF * VN <= i1; i += PDT_PF * VN) {
+#pragma unroll
+            for (int u = 0; u < PDT_PF; u++) {
+                Vec16<T> yv;
+#pragma unroll
+                for (int w = 0; w < VN; w++) {
+                    L = (T)((double)L * k + (double)buf[u].v[w]);
+                    yv.v[w] = L;
+                }
+                if (STORE) *reinterpret_cast<Vec16<T> *>(out + i + u * VN) = yv;
+                long long q = i + (PDT_PF + u) * VN;      // reload after the last use (see pll_phase_range)
+                asm volatile("" : "+v"(q));
+                buf[u] = *reinterpret_cast<const Vec16<T> *>(term + q);
+            }
+        }
+    }
+    for (; i < i1; i++) {
+        L = (T)((double)L * k + (double)term[i]);
+        if (STORE) out[i] = L;
+    }
+}
+
 template <typename T>
 __global__ void __launch_bounds__(64) k_lock_ema(const T *__restrict__ term, long long n, T lock_alpha,
                                                   const PllLockInfo<T> *__restrict__ info, long long B, long long W,
@@ -1082,13 +1118,10 @@ __global__ void __launch_bounds__(64) k_lock_ema(const T *__restrict__ term, lon
     T L = info->st.locksig;
     if (ws < S) ws = S;
     const double k = 1.0 - (double)lock_alpha;
-    for (long long i = ws; i < start; i++) L = (T)((double)L * k + (double)term[i]);
+    ema_range<T, false>(term, lock_out, ws, start, L, k);
     EmaSeam<T> sm;
     sm.v0 = L;
-    for (long long i = start; i < end; i++) {
-        L = (T)((double)L * k + (double)term[i]);
-        lock_out[i] = L;
-    }
+    ema_range<T, true>(term, lock_out, start, end, L, k);
     sm.v1 = L;
     seams[j - S / B] = sm;
 }
