@@ -275,7 +275,7 @@ def test_weak_signal_repair_cascades(pdt, orc, mult):
 
 def test_250ksps_capture_matches_oracle(pdt, orc):
     """BASELINE configs[2]/[4] geometry (250 ksps, interp 1, 26 taps) on a 2-minute, 30 000 000-sample capture:
-    bit-exact output file vs the CPU oracle, every transmitted frame in order.  (tools/c3_check.py runs the
+    bit-exact output file vs the CPU oracle, every transmitted frame in order.  (tests/tools/c3_check.py runs the
     10-minute / 150 M-sample version against the reference's own objects.)"""
     fs, secs, seed = 250000, 120.0, 31
     iq = pdt.synth_capture(0, fs, secs, seed=seed)

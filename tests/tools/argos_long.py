@@ -1,6 +1,6 @@
 """A long ARGOS capture: kernel-group times and the reference CPU path on the same input (run on a GPU box)."""
 import importlib, os, subprocess, sys, tempfile, time
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 pdt = importlib.import_module("project-desert-tortoise_amd")
 secs = float(os.environ.get("PDT_SECS", "300"))

@@ -2,7 +2,7 @@
 CPU objects (oracle/_ref/ref_demodPOES) -- byte-identical minor-frame file; run on a GPU box."""
 import importlib, os, subprocess, sys, tempfile, time
 import numpy as np
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 pdt = importlib.import_module("project-desert-tortoise_amd")
 rate = int(os.environ.get("PDT_RATE", "250000"))

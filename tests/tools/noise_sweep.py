@@ -3,7 +3,7 @@ repair / fallback paths are exercised (run on a GPU box)."""
 import ctypes as C
 import importlib, os, sys, time
 import numpy as np
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 pdt = importlib.import_module("project-desert-tortoise_amd")
 from oracle import binding as orc
