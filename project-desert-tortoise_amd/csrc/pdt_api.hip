@@ -718,8 +718,15 @@ template <typename T> int run_capture(pdt_ctx *ctx, uint64_t n, int phase = RUN_
         L.end();
     } else {
         L.begin("gardner");
-        hipLaunchKernelGGL((k_gardner<T, GardnerLds<T>::LEN, GardnerLds<T>::OUT>), dim3(1), dim3(256), 0, st, d_agc, d_lock, GP, d_sym, d_symidx,
-                           &d_sc->nsym, sym_cap, (const GardnerEntry<T> *)nullptr);
+        constexpr int SMALL_LEN = 32768 / (int)sizeof(T), SMALL_OUT = 1024;    // two 32 KiB windows
+        const long long small_need = chunk_out + 2 * (long long)GP.step + 24;
+        const double small_syms = (double)chunk_out / ((double)GP.step - 0.25) + 4.0;
+        if (small_need <= SMALL_LEN && small_syms < SMALL_OUT && !getenv("PDT_GARDNER_ONEBUF"))
+            hipLaunchKernelGGL((k_gardner_small<T, SMALL_LEN, SMALL_OUT>), dim3(1), dim3(256), 0, st, (const T *)d_agc, (const T *)d_lock, GP,
+                               d_sym, d_symidx, &d_sc->nsym, sym_cap);
+        else
+            hipLaunchKernelGGL((k_gardner<T, GardnerLds<T>::LEN, GardnerLds<T>::OUT>), dim3(1), dim3(256), 0, st, d_agc, d_lock, GP, d_sym, d_symidx,
+                               &d_sc->nsym, sym_cap, (const GardnerEntry<T> *)nullptr);
         L.end();
     }
 

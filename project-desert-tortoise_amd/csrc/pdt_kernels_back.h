@@ -257,6 +257,113 @@ __global__ void __launch_bounds__(256) k_gardner(const T *__restrict__ in, const
     if (threadIdx.x == 0 && (!entries || c_end == n_chunks)) *nsym_out = (unsigned long long)count;
 }
 
+// Sequential sampler for small reference chunks (ARGOS: 2 400 samples, 60 symbols per chunk): with one window per
+// chunk the walk of a chunk takes less time than staging it, so the staging is taken off the walker's
+// path -- wavefronts 1..3 fill the second LDS buffer with chunk c+1 (data + the past-the-end values of
+// Q3/Q16) while wavefront 0 walks chunk c out of the first, then the buffers swap.  The walk is the
+// single-window case of gardner_walk_chunk, statement for statement.
+template <typename T, int LEN, int OUT>
+__global__ void __launch_bounds__(256) k_gardner_small(const T *__restrict__ in, const T *__restrict__ lock, GardnerParams<T> P,
+                                                        T *__restrict__ sym, long long *__restrict__ symidx,
+                                                        unsigned long long *__restrict__ nsym_out, long long sym_cap)
+{
+    __shared__ T win[2][LEN];
+    __shared__ T o_val[OUT];
+    __shared__ unsigned o_idx[OUT];
+    const int tid = threadIdx.x;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int lane = tid & 63;
+    const long long C = P.chunk_out;
+    const long long n_chunks = (P.n_total + C - 1) / C;
+    const T hs = (T)((double)P.step / 2.0);
+    const T kp = P.kp, lim = P.lim, step = P.step;
+    const T adv = step + (T)0.101;
+    const int tail = 2 * (int)step + 24;               // furthest look-ahead of the mid-point
+    T ns = 0, prev = 0, half = 0;
+    long long count = 0;
+
+    auto stage = [&](long long c, T *buf, int first, int stride) {
+        const long long base = c * C;
+        const int n_cur = (int)((P.n_total - base < C) ? (P.n_total - base) : C);
+        for (int t = first; t < n_cur; t += stride) buf[t] = in[base + t];
+        int n_tail = n_cur + tail;
+        if (n_tail > LEN) n_tail = LEN;
+        for (int q = n_cur + first; q < n_tail; q += stride)
+            buf[q] = gardner_beyond(in, lock, P, c, (long long)n_cur, (long long)q);
+    };
+    if (n_chunks > 0) stage(0, win[0], tid, 256);
+    __syncthreads();
+    for (long long c = 0; c < n_chunks; c++) {
+        const T *w = win[c & 1];
+        const long long base = c * C;
+        const int n_cur = (int)((P.n_total - base < C) ? (P.n_total - base) : C);
+        int n_staged = n_cur + tail;
+        if (n_staged > LEN) n_staged = LEN;
+        int nout = 0;
+        if (wave != 0) {
+            if (c + 1 < n_chunks) stage(c + 1, win[(c + 1) & 1], tid - 64, 192);
+        } else {
+            const T nT = (T)n_cur;
+            for (;;) {
+                // ---- checked step
+                const T rn = Real<T>::rint(ns);
+                const int in_chunk = uniform<int>((int)(rn < nT));
+                if (!in_chunk) break;
+                if (nout >= OUT) break;                                      // cannot happen: OUT covers a whole chunk
+                const unsigned i_abs = uniform<unsigned>((unsigned)rn);
+                const unsigned h_abs = uniform<unsigned>((unsigned)Real<T>::rint(half));
+                const T cur = w[i_abs];
+                T mid;
+                if (h_abs < (unsigned)n_staged) mid = w[h_abs];
+                else mid = (h_abs < (unsigned)n_cur) ? in[base + h_abs] : gardner_beyond(in, lock, P, c, (long long)n_cur, (long long)h_abs);
+                o_val[nout] = cur;
+                o_idx[nout] = i_abs;
+                nout++;
+                {
+                    T err = kp * (cur - prev) * mid;
+                    err = (err > lim) ? lim : ((err < -lim) ? -lim : err);
+                    ns = ns - err;
+                    half = ns + hs;
+                    ns = ns + step;
+                    prev = cur;
+                }
+                // ---- check-free batch
+                const T room = (T)n_cur - (T)2 - ns;
+                int K = (room > (T)0) ? (int)(room / adv) : 0;
+                K = uniform<int>(K);
+                if (K > OUT - nout) K = OUT - nout;
+                for (int k = 0; k < K; k++) {
+                    const T rnk = Real<T>::rint(ns);
+                    const T rhk = Real<T>::rint(half);
+                    const T c_k = w[(int)rnk];
+                    const T m_k = w[(int)rhk];
+                    o_val[nout + k] = c_k;
+                    o_idx[nout + k] = (unsigned)rnk;
+                    T err = kp * (c_k - prev) * m_k;
+                    err = (err > lim) ? lim : ((err < -lim) ? -lim : err);
+                    ns = ns - err;
+                    half = ns + hs;
+                    ns = ns + step;
+                    prev = c_k;
+                }
+                nout += K;
+            }
+            // the walker flushes its own symbols (at most a few per lane)
+            for (int t = lane; t < nout; t += 64) {
+                const long long k = count + t;
+                if (k < sym_cap) {
+                    sym[k] = o_val[t];
+                    symidx[k] = base + (long long)o_idx[t];
+                }
+            }
+            ns = ns - nT;                              // roll over; `half` is deliberately not (Q3)
+        }
+        count += uniform<int>(nout);                   // only wavefront 0's copy matters
+        __syncthreads();
+    }
+    if (tid == 0) *nsym_out = (unsigned long long)count;
+}
+
 // ------------------------------------------------------------------------------------------
 // Mueller & Muller clock recovery (reference: common/MMClockRecovery.c:5-83), the alternative sampler
 // the reference keeps at the same call site behind a comment (ARGOSdemod/main.c:277).  State
