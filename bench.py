@@ -153,10 +153,19 @@ def main():
             raise SystemExit("launch with: python -m torch.distributed.run --nproc-per-node N bench.py --gpus N ...")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (there is no CPU implementation of the product path)")
+    # PDT_BENCH_BACKEND=gloo: dry run of the multi-rank logic on a box with fewer GPUs than ranks (ranks share
+    # devices, collectives on host tensors); the real runs use RCCL, one rank per GPU
+    backend = os.environ.get("PDT_BENCH_BACKEND", "nccl")
+    if backend != "nccl":
+        local = local % torch.cuda.device_count()
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
+    cdev = dev if backend == "nccl" else torch.device("cpu")              # where collective payloads live
     if world > 1:
-        dist.init_process_group("nccl", device_id=dev)
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)
+        else:
+            dist.init_process_group(backend)
 
     pdt = importlib.import_module("project-desert-tortoise_amd")
     n = int(round(args.seconds * FS))
@@ -189,13 +198,13 @@ def main():
         dist.barrier()
     dt = time.perf_counter() - t0
     if world > 1:
-        t = torch.tensor([dt], dtype=torch.float64, device=dev)
+        t = torch.tensor([dt], dtype=torch.float64, device=cdev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
 
     st = dm.stats()
     frames = dm.frames_array()
-    gathered = gather_frames(frames, dev) if world > 1 else [frames]
+    gathered = gather_frames(frames, cdev) if world > 1 else [frames]
 
     if rank == 0:
         ms_step = dt / args.steps * 1e3
