@@ -338,6 +338,7 @@ template <typename T> int run_capture(pdt_ctx *ctx, uint64_t n, int phase = RUN_
         !getenv("PDT_AGC_UNFUSED")) {
         const long long tile_out = 64ll * 26 * interp;
         agc_tiles_per_block = std::max<long long>(1, (Ba + tile_out / 2) / tile_out);
+        if (const char *e = getenv("PDT_AGC_TPB")) agc_tiles_per_block = std::max(1, atoi(e));      // tuning experiments
         Ba = agc_tiles_per_block * tile_out;
     }
     Wp = round4(Wp);
