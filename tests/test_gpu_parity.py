@@ -255,6 +255,27 @@ def test_ten_minute_capture_matches_oracle(pdt, orc):
         assert d.stats().frames == len(o.frames()) >= 5990
 
 
+@pytest.mark.parametrize("switch", ["PDT_ACQUIRE_SIMPLE", "PDT_ACQUIRE_ONEWAVE", "PDT_GTAB_NOMERGE", "PDT_FIR_GENERIC",
+                                    "PDT_AGC_UNFUSED", "PDT_GARDNER_ONEBUF"])
+def test_alternative_kernels_agree(pdt, orc, clip, switch):
+    """The older / generic kernel variants kept behind environment switches (tools/README.md) -- some of them are the
+    fallbacks other geometries take -- give the same bits as the default path."""
+    rate, iq = clip
+    o = orc.Oracle(orc.POES, rate, iq)
+    a = pdt.synth_capture(1, 32000, 8.0, f0_hz=150.0, seed=31)
+    oa = orc.Oracle(orc.ARGOS, 32000, a, math_mode=orc.MATH_PORTABLE)
+    os.environ[switch] = "1"
+    try:
+        with pdt.Demodulator(pdt.MODE_POES, rate) as d:
+            d.demod(iq)
+            check_all_stages(pdt, orc, d, o)
+        with pdt.Demodulator(pdt.MODE_ARGOS, 32000) as d:
+            d.demod(a)
+            check_all_stages(pdt, orc, d, oa)
+    finally:
+        del os.environ[switch]
+
+
 @pytest.mark.parametrize("mult", [5, 10])
 def test_weak_signal_repair_cascades(pdt, orc, mult):
     """Noise scaled up 5x / 10x (6 dB / 0 dB SNR): the tracking loop stops being contracting, many seams fail their
