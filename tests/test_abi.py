@@ -40,6 +40,18 @@ def test_struct_layouts_match_header(pdt):
     assert C.sizeof(pdt.Frame) == 136
     assert C.sizeof(pdt.Config) == 80
     assert pdt.FRAME_DTYPE.itemsize == 136
+    assert pdt.TIP_DTYPE.itemsize == 12 and C.sizeof(pdt.TipSummary) == 56
+    # the header itself must compile as plain C and agree on the sizes
+    import tempfile
+    src = ('#include "pdt.h"\nint main(void){return (sizeof(pdt_config)==80 && sizeof(pdt_frame)==136 && sizeof(pdt_tip_frame)==12 '
+           '&& sizeof(pdt_tip_summary)==56 && sizeof(pdt_stats)>0) ? 0 : 1;}\n')
+    with tempfile.TemporaryDirectory() as tmp:
+        cfile = os.path.join(tmp, "abi.c")
+        open(cfile, "w").write(src)
+        exe = os.path.join(tmp, "abi")
+        subprocess.run(["gcc", "-std=c99", "-Wall", "-Wextra", "-pedantic", "-Werror", "-I", os.path.join(ROOT, "include"), "-o", exe, cfile],
+                       check=True)
+        assert subprocess.run([exe]).returncode == 0
 
 
 def test_no_gpu_fails_loudly(pdt, gpu_available):
