@@ -326,6 +326,17 @@ template <typename T> int run_capture(pdt_ctx *ctx, uint64_t n, int phase = RUN_
     auto round4 = [](long long v) { return (v + 3) / 4 * 4; };
     long long Bp = ctx->cfg.pll_block ? ctx->cfg.pll_block : (long long)((argos ? 0.5 : 0.05) * fs_d);
     long long Wp = ctx->cfg.pll_warm ? ctx->cfg.pll_warm : (long long)((argos ? 8.0 : 0.3) * fs_d);
+    if (!ctx->cfg.pll_warm && !argos) {
+        // Measured (tools/pll_geom.py, 50 ksps): the probability that a block has not merged bit for bit after a
+        // warm-up of W samples falls like 200 exp(-W / 2.82 tau), tau = 2 / alpha_trk the tracking loop's time
+        // constant.  Aim at fewer than ~1/2 unhealthy seam per capture: short captures get away with less than 0.3 s,
+        // hour-long ones need a little more (a repair costs a block walk and cascades).
+        const double tau = 2.0 / (double)PP.alpha_trk;
+        const double nb = std::max(1.0, (double)N / (double)std::max<long long>(1, Bp));
+        double w = 2.82 * tau * log(400.0 * nb);
+        if (const char *e = getenv("PDT_PLL_WARM_SCALE")) w *= atof(e);         // tuning experiments
+        Wp = (long long)std::min(std::max(w, 0.15 * fs_d), 0.6 * fs_d);
+    }
     long long Wacq = (long long)(0.02 * fs_d);             // acquisition-gain stage of the warm-up
     long long Ba = ctx->cfg.agc_block ? ctx->cfg.agc_block : (long long)((argos ? 0.125 : 0.0625) * fs_d * interp);
     long long Wa = ctx->cfg.agc_warm ? ctx->cfg.agc_warm : (long long)((argos ? 8.0 : 1.0) * fs_d * interp);
