@@ -1127,7 +1127,7 @@ __global__ void __launch_bounds__(1024) k_gardner_segmap(const unsigned *__restr
     }
 }
 
-__global__ void __launch_bounds__(PDT_GARDNER_THREADS) k_gardner_chain(const float *__restrict__ in, GardnerParams<float> P,
+__global__ void __launch_bounds__(256) k_gardner_chain(const float *__restrict__ in, GardnerParams<float> P,
                                                                         GardnerDomain D, long long n_chunks,
                                                                         const unsigned *__restrict__ table,
                                                                         const GardnerSegCell *__restrict__ segmap, int G,
