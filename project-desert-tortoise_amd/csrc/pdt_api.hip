@@ -58,6 +58,7 @@ struct DevBuf {
 struct KTimer {
     std::string name;
     hipEvent_t a, b;
+    bool shared_a = false;      // a is the previous group's b (returned to the pool once)
 };
 
 // device-side scalar block shared by all stages of one run
@@ -147,33 +148,50 @@ int poes_interp(uint32_t rate) { return (int)rint(150000.0 / (double)(float)rate
 class Launcher {
   public:
     Launcher(pdt_ctx *c) : ctx(c) {}
+    // profile mode: one event per group boundary -- a group that starts right where the previous one ended on
+    // the same stream shares that event (every recorded event is a small gap in the stream)
     void begin(const char *name, hipStream_t s = nullptr)
     {
         if (!ctx->cfg.profile) return;
         KTimer t;
         t.name = name;
-        // events are recycled across calls (creating and destroying ~30 of them per capture costs ~0.1 ms of host time)
-        if (ctx->event_pool.size() >= 2) {
-            t.a = ctx->event_pool.back(); ctx->event_pool.pop_back();
-            t.b = ctx->event_pool.back(); ctx->event_pool.pop_back();
-        } else {
-            (void)hipEventCreate(&t.a);
-            (void)hipEventCreate(&t.b);
-        }
         cur = s ? s : ctx->stream;
-        (void)hipEventRecord(t.a, cur);
+        if (have_last && last_stream == cur) {
+            t.a = last_b;
+            t.shared_a = true;
+        } else {
+            t.a = take();
+            t.shared_a = false;
+            (void)hipEventRecord(t.a, cur);
+        }
+        t.b = take();
         ctx->timers.push_back(t);
         open_idx = ctx->timers.size() - 1;
+        have_last = false;
     }
     void end()
     {
         if (!ctx->cfg.profile) return;
         (void)hipEventRecord(ctx->timers[open_idx].b, cur);
+        last_b = ctx->timers[open_idx].b;
+        last_stream = cur;
+        have_last = true;
     }
+    // work enqueued outside any group (copies, memsets, stream waits) breaks the sharing
+    void gap() { have_last = false; }
 
   private:
+    hipEvent_t take()
+    {
+        hipEvent_t e;
+        if (!ctx->event_pool.empty()) { e = ctx->event_pool.back(); ctx->event_pool.pop_back(); }
+        else (void)hipEventCreate(&e);
+        return e;
+    }
     pdt_ctx *ctx;
-    hipStream_t cur = nullptr;
+    hipStream_t cur = nullptr, last_stream = nullptr;
+    hipEvent_t last_b = nullptr;
+    bool have_last = false;
     size_t open_idx = 0;
 };
 
@@ -507,6 +525,7 @@ template <typename T> int run_capture(pdt_ctx *ctx, uint64_t n, int phase = RUN_
                                d_hinfo, head_blocks);
         L.end();
         HIP_TRY(hipStreamWaitEvent(st, ctx->ev_join, 0));                  // join
+        L.gap();                                                           // (the wait is not part of pll_fix)
         L.begin("pll_fix");
         if (slow_wrap)
             hipLaunchKernelGGL((k_pll_fix<T, true>), dim3(1), dim3(PDT_FIX_THREADS), 0, st, d_theta, N, PP, d_info, Bp, d_phi,
@@ -892,7 +911,7 @@ template <typename T> int run_capture(pdt_ctx *ctx, uint64_t n, int phase = RUN_
             k.total_ms = tms;
             ctx->ktimes.push_back(k);
         }
-        ctx->event_pool.push_back(t.a);
+        if (!t.shared_a) ctx->event_pool.push_back(t.a);
         ctx->event_pool.push_back(t.b);
     }
     ctx->timers.clear();
@@ -1053,7 +1072,7 @@ void pdt_close(pdt_ctx *ctx)
     for (hipEvent_t e : ctx->event_pool) (void)hipEventDestroy(e);
     if (ctx->pinned) (void)hipHostFree(ctx->pinned);
     if (ctx->pend_sc) (void)hipHostFree(ctx->pend_sc);
-    for (auto &t : ctx->timers) { (void)hipEventDestroy(t.a); (void)hipEventDestroy(t.b); }
+    for (auto &t : ctx->timers) { if (!t.shared_a) (void)hipEventDestroy(t.a); (void)hipEventDestroy(t.b); }
     if (ctx->ev0) (void)hipEventDestroy(ctx->ev0);
     if (ctx->ev1) (void)hipEventDestroy(ctx->ev1);
     if (ctx->ev_fork) (void)hipEventDestroy(ctx->ev_fork);
