@@ -86,7 +86,7 @@ struct pdt_ctx {
     hipEvent_t ev0 = nullptr, ev1 = nullptr, ev_fork = nullptr, ev_join = nullptr;
     hipStream_t stream2 = nullptr;     // side stream: block-parallel PLL phase runs beside the sequential acquisition
 
-    DevBuf pcm, pll, lock, fir, agc, sym, symidx, bits, bitsym, hits, frames, taps, mag, seams_pll, seams_agc, scal, lockinfo, term, seams_ema, gtable, gentries, gcand, gmfirst, stiles, gsegmap, gsegstart, gbands, gclist, agc_maps, pll_head, taps_rot, pll_scratch, tip;
+    DevBuf pcm, pll, lock, fir, agc, sym, symidx, bits, bitsym, hits, frames, taps, mag, seams_pll, seams_agc, scal, lockinfo, term, seams_ema, gtable, gentries, gcand, gmfirst, stiles, gsegmap, gsegstart, gbands, gclist, agc_maps, pll_head, taps_rot, pll_scratch, tip, sync_scr;
     // (stream_in is declared with the streaming state below)
     long long gcand_key = -1;          // (chunk_out, step) the candidate list on the device was built for
     bool force_sequential_gardner = false;
@@ -284,7 +284,7 @@ void launch_bytesync(pdt_ctx *ctx, hipStream_t st, const SyncParams &SP, DevScal
     hipLaunchKernelGGL(k_sync_hits_tile, dim3((unsigned)n_stiles), dim3(256), 0, st, d_bits, &d_sc->nbits, SP, d_stiles,
                        &d_sc->sync_overflow);
     hipLaunchKernelGGL(k_sync_frames_tiles, dim3(1), dim3(PDT_SYNC_THREADS), 0, st, (const SyncTile *)d_stiles, &d_sc->nbits, SP, d_hits, hit_cap,
-                       d_frames, &d_sc->nframes, frame_cap, &d_sc->sync_overflow);
+                       d_frames, &d_sc->nframes, frame_cap, &d_sc->sync_overflow, (unsigned *)ctx->sync_scr.p);
     // generic path (atomic append + sort), only when a tile overflowed
     const long long grid = (bit_cap + 255) / 256;
     hipLaunchKernelGGL(k_sync_hits, dim3((unsigned)grid), dim3(256), 0, st, d_bits, &d_sc->nbits, SP, d_hits, &d_sc->nhits, hit_cap,
@@ -408,6 +408,7 @@ template <typename T> int run_capture(pdt_ctx *ctx, uint64_t n, int phase = RUN_
     if ((rc = ctx->bits.ensure((size_t)bit_cap))) return rc;
     if ((rc = ctx->bitsym.ensure((size_t)bit_cap * sizeof(unsigned)))) return rc;
     if ((rc = ctx->hits.ensure((size_t)hit_cap * sizeof(unsigned) + (size_t)n_tiles * sizeof(ManchTile)))) return rc;
+    if ((rc = ctx->sync_scr.ensure((2 * ((size_t)hit_cap + 1) + hit_cap / 32 + 2) * sizeof(unsigned)))) return rc;
     if ((rc = ctx->frames.ensure((size_t)frame_cap * sizeof(FrameRec)))) return rc;
     if ((rc = ctx->stiles.ensure((size_t)((bit_cap + 4095) / 4096 + 1) * sizeof(SyncTile)))) return rc;
     if ((rc = ctx->mag.ensure((size_t)(n0 + 1) * sizeof(T)))) return rc;
@@ -1067,7 +1068,7 @@ void pdt_close(pdt_ctx *ctx)
     DevBuf *bufs[] = { &ctx->pcm, &ctx->pll, &ctx->lock, &ctx->fir, &ctx->agc, &ctx->sym, &ctx->symidx, &ctx->bits, &ctx->bitsym,
                        &ctx->hits, &ctx->frames, &ctx->taps, &ctx->mag, &ctx->seams_pll, &ctx->seams_agc, &ctx->scal, &ctx->lockinfo,
                        &ctx->term, &ctx->seams_ema, &ctx->gtable, &ctx->gentries, &ctx->gcand,
-                       &ctx->gmfirst, &ctx->stiles, &ctx->gsegmap, &ctx->gsegstart, &ctx->gbands, &ctx->gclist, &ctx->agc_maps, &ctx->pll_head, &ctx->taps_rot, &ctx->pll_scratch, &ctx->tip, &ctx->stream_in };
+                       &ctx->gmfirst, &ctx->stiles, &ctx->gsegmap, &ctx->gsegstart, &ctx->gbands, &ctx->gclist, &ctx->agc_maps, &ctx->pll_head, &ctx->taps_rot, &ctx->pll_scratch, &ctx->tip, &ctx->stream_in, &ctx->sync_scr };
     for (DevBuf *b : bufs) b->release();
     for (hipEvent_t e : ctx->event_pool) (void)hipEventDestroy(e);
     if (ctx->pinned) (void)hipHostFree(ctx->pinned);
@@ -1161,6 +1162,7 @@ int pdt_stage_bytesync(pdt_ctx *ctx, const uint8_t *bits_host, uint64_t nbits)
     if ((rc = ctx->bitsym.ensure((size_t)bit_cap * sizeof(unsigned)))) return rc;
     if ((rc = ctx->symidx.ensure((size_t)bit_cap * sizeof(long long)))) return rc;
     if ((rc = ctx->hits.ensure((size_t)hit_cap * sizeof(unsigned)))) return rc;
+    if ((rc = ctx->sync_scr.ensure((2 * ((size_t)hit_cap + 1) + hit_cap / 32 + 2) * sizeof(unsigned)))) return rc;
     if ((rc = ctx->frames.ensure((size_t)frame_cap * sizeof(FrameRec)))) return rc;
     if ((rc = ctx->stiles.ensure((size_t)((bit_cap + 4095) / 4096 + 1) * sizeof(SyncTile)))) return rc;
     if ((rc = ctx->scal.ensure(sizeof(DevScalars)))) return rc;

@@ -1669,7 +1669,8 @@ __global__ void __launch_bounds__(PDT_SYNC_THREADS) k_sync_frames_tiles(const Sy
                                                             const unsigned long long *__restrict__ nbits_p, SyncParams P,
                                                             unsigned *__restrict__ dense, unsigned dense_cap,
                                                             FrameRec *__restrict__ frames, unsigned *__restrict__ nframes,
-                                                            unsigned frame_cap, const unsigned *__restrict__ overflow)
+                                                            unsigned frame_cap, const unsigned *__restrict__ overflow,
+                                                            unsigned *__restrict__ gscr /* 2 (dense_cap + 1) + dense_cap / 32 + 2 words */)
 {
     if (*overflow) return;                       // the generic path handles this capture
     const long long nbits = (long long)*nbits_p;
@@ -1766,44 +1767,61 @@ __global__ void __launch_bounds__(PDT_SYNC_THREADS) k_sync_frames_tiles(const Sy
         if (threadIdx.x == PDT_SYNC_THREADS - 1) *nframes = incl;
         return;
     }
-    // ---- (B') serial filter over the dense, sorted list, staged through LDS
-    unsigned nf = 0;
-    unsigned next_free = 0;                            // bit indices are < 2^31
-    for (unsigned b0 = 0; b0 < nh; b0 += PDT_SYNC_BATCH) {
-        const unsigned cnt = (nh - b0 < PDT_SYNC_BATCH) ? nh - b0 : PDT_SYNC_BATCH;
+    // ---- (B'') more hits than the LDS version holds (captures longer than ~14 minutes): the same successor links /
+    // pointer doubling with the link tables and the mark bits in global memory.  One workgroup, so every hand-over is
+    // a fence + barrier; each thread owns a contiguous slice of hits, and since the successor index is monotone in the
+    // hit index the links of a slice are found with one binary search and a forward scan.
+    {
+        unsigned *J0 = gscr, *J1 = gscr + (size_t)dense_cap + 1, *mark = gscr + 2 * ((size_t)dense_cap + 1);
+        const unsigned per = (nh + PDT_SYNC_THREADS - 1) / PDT_SYNC_THREADS;
+        const unsigned a0 = threadIdx.x * per, a1 = (a0 + per < nh) ? a0 + per : nh;
+        for (unsigned w = threadIdx.x; w < nh / 32 + 1; w += PDT_SYNC_THREADS) mark[w] = (w == 0) ? 1u : 0u;
+        if (a0 < nh) {
+            const unsigned want0 = (dense[a0] >> 1) + P.span;
+            unsigned lo = a0 + 1, hi = nh;
+            while (lo < hi) {
+                const unsigned mid = (lo + hi) >> 1;
+                if ((dense[mid] >> 1) >= want0) hi = mid; else lo = mid + 1;
+            }
+            unsigned ptr = lo;
+            for (unsigned i = a0; i < a1; i++) {
+                const unsigned want = (dense[i] >> 1) + P.span;
+                if (ptr < i + 1) ptr = i + 1;
+                while (ptr < nh && (dense[ptr] >> 1) < want) ptr++;
+                J0[i] = ptr;
+            }
+        }
+        if (threadIdx.x == 0) J0[nh] = nh;
+        __threadfence();
         __syncthreads();
-        for (unsigned t = threadIdx.x; t < ((cnt + 7u) & ~7u); t += PDT_SYNC_THREADS) s_hits[t] = (t < cnt) ? dense[b0 + t] : 0xffffffffu;
-        __syncthreads();
-        if (threadIdx.x == 0) {
-            // accepted hits are written back in place (LDS), the records go out afterwards in parallel
-            unsigned na = 0;
-            for (unsigned i = 0; i < cnt; i += 8) {
-                unsigned v[8];
-#pragma unroll
-                for (int u = 0; u < 8; u++) v[u] = s_hits[i + u];
-#pragma unroll
-                for (int u = 0; u < 8; u++) {
-                    const unsigned pos = v[u] >> 1;
-                    const bool take = (v[u] != 0xffffffffu) && (pos >= next_free);
-                    if (take) {
-                        s_hits[na++] = v[u];
-                        next_free = pos + P.span;
-                    }
+        unsigned *Jc = J0, *Jn = J1;
+        for (unsigned reach = 1; reach < nh; reach <<= 1) {
+            for (unsigned i = a0; i < a1; i++) {
+                const unsigned jm = Jc[i];
+                if (jm < nh && ((mark[i >> 5] >> (i & 31)) & 1u)) atomicOr(&mark[jm >> 5], 1u << (jm & 31));
+                Jn[i] = Jc[jm];
+            }
+            if (threadIdx.x == 0) Jn[nh] = nh;
+            __threadfence();
+            __syncthreads();
+            unsigned *tmp = Jc; Jc = Jn; Jn = tmp;
+        }
+        unsigned mine = 0;
+        for (unsigned i = a0; i < a1; i++) mine += (mark[i >> 5] >> (i & 31)) & 1u;
+        const unsigned incl = sync_block_scan(mine, s_scan);
+        unsigned at = incl - mine;
+        for (unsigned i = a0; i < a1; i++) {
+            if ((mark[i >> 5] >> (i & 31)) & 1u) {
+                if (at < frame_cap) {
+                    const unsigned v = dense[i];
+                    frames[at].bit_index = (long long)(v >> 1);
+                    frames[at].inverted = (unsigned char)(v & 1u);
                 }
-            }
-            s_scan[0] = na;
-        }
-        __syncthreads();
-        const unsigned na = s_scan[0];
-        for (unsigned t = threadIdx.x; t < na; t += PDT_SYNC_THREADS) {
-            if (nf + t < frame_cap) {
-                frames[nf + t].bit_index = (long long)(s_hits[t] >> 1);
-                frames[nf + t].inverted = (unsigned char)(s_hits[t] & 1u);
+                at++;
             }
         }
-        nf += na;
+        if (threadIdx.x == PDT_SYNC_THREADS - 1) *nframes = incl;
     }
-    if (threadIdx.x == 0) *nframes = nf;
 }
 
 __global__ void __launch_bounds__(128) k_frame_pack(const unsigned char *__restrict__ bits,

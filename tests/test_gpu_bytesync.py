@@ -93,3 +93,19 @@ def test_random_bit_soup(pdt, orc):
     for n in (5000, 100000, 1_000_000):
         check(pdt, orc, pdt.MODE_POES, rand_bits(rng, n))
         check(pdt, orc, pdt.MODE_ARGOS, rand_bits(rng, n))
+
+
+def test_more_hits_than_the_lds_filter_holds(pdt, orc):
+    """> 8190 sync hits (a capture longer than ~14 minutes): the successor-link / pointer-doubling filter runs out of
+    global memory instead of LDS.  9 500 frames, some of them overlapping candidates and inverse ones."""
+    rng = np.random.default_rng(11)
+    parts = [rand_bits(rng, 333)]
+    for i in range(9500):
+        body = rand_bits(rng, 813)
+        if i % 97 == 0:
+            body = body[:400] + SYNC_POES + body[419:]          # a sync word inside an open frame: ignored
+        parts.append((inv(SYNC_POES) if i % 41 == 0 else SYNC_POES) + (inv(body) if i % 41 == 0 else body))
+        if i % 13 == 0:
+            parts.append(rand_bits(rng, int(rng.integers(1, 50))))
+    ov, n = check(pdt, orc, pdt.MODE_POES, "".join(parts))
+    assert n >= 9500 and ov == 0
