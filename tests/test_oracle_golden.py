@@ -95,3 +95,20 @@ def test_empty_and_tiny_inputs(orc):
         o = orc.Oracle(orc.POES, 50000, iq, keep_stages=False)
         assert o.text() == b""
         assert o.totals()[0] == n
+
+
+def test_cross_check_against_the_older_builds_sample_output():
+    """SURVEY 4 cross-check (not a golden): POESTIPdemod/minorFrame.txt is the sample output an OLDER build of the
+    reference produced from the bundled 5sec_clip.wav (six-decimal times, older time base).  Today's reference --
+    and so the oracle and the GPU path -- gives the same frames from the second one on, byte for byte, except
+    byte 22 of two frames (01->51, 03->5B).  Any wider drift in the restatement would show up here."""
+    old = [l.split() for l in open(os.path.join(GOLDEN, "old_build_minorFrame.txt")).read().splitlines() if l.strip()]
+    new = [l.split() for l in golden_text("clip.c10000.txt").decode().splitlines() if l.strip()]
+    assert len(old) == 47 and len(new) == 48
+    diffs = []
+    for k, o in enumerate(old):
+        n = new[k + 1]
+        assert len(o) == len(n)
+        assert abs(float(o[0]) - float(n[0])) < 0.01           # older time base, same 0.1 s frame slot
+        diffs += [(k, i - 1, a, b) for i, (a, b) in enumerate(zip(o, n)) if i > 0 and a != b]
+    assert diffs == [(16, 22, "01", "51"), (36, 22, "03", "5B")]
