@@ -21,7 +21,8 @@
  * md5 d3c496d003a29eeee061c01b00ce025c; tests/test_oracle_ref.py checks this
  * harness reproduces it, which pins the restated loop to the real program.
  *
- * usage: ref_demod{POES,ARGOS} [-c chunk] [-n gain] [-s kHz] [-d dumpprefix] in.wav out.txt
+ * usage: ref_demod{POES,ARGOS} [-c chunk] [-n gain] [-s kHz] [-d dumpprefix] [-M -R r -K k] in.wav out.txt
+ *        ref_demod{POES,ARGOS} -B [-c piece] bits.txt out.txt
  *   -d prefix : additionally dump every stage's per-chunk output, concatenated
  *               over chunks, to <prefix>.{pll,fir,agc,sym,symt,bits,bitt,lock}
  *               and per-chunk counts to <prefix>.counts (text).
@@ -78,8 +79,10 @@ int main(int argc, char **argv)
     int use_mm = 0;              /* -M: MMClockRecovery at the sampler's call site (ARGOSdemod/main.c:277, commented out there) */
     DT mmRange = 3, mmKp = 0.15;
     int c;
-    while ((c = getopt(argc, argv, "c:n:s:d:MR:K:")) != -1) {
+    int bits_only = 0;           /* -B: in.wav is a text file of '0'/'1'; run only the reference's byte synchroniser on it */
+    while ((c = getopt(argc, argv, "c:n:s:d:MR:K:B")) != -1) {
         if (c == 'M') { use_mm = 1; continue; }
+        if (c == 'B') { bits_only = 1; continue; }
         if (c == 'R') { mmRange = atof(optarg); continue; }
         if (c == 'K') { mmKp = atof(optarg); continue; }
         if (c == 'c') chunk = atoi(optarg);
@@ -89,6 +92,30 @@ int main(int argc, char **argv)
         else return 2;
     }
     if (argc - optind < 2) { fprintf(stderr, "usage: %s [opts] in.wav out.txt\n", argv[0]); return 2; }
+
+    if (bits_only) {
+        /* the reference's own (commented-out) harness, POESTIPdemod/ByteSync.c:6-14: a literal bit string handed to the
+         * synchroniser; here in pieces of `chunk` bits as the demodulator's loop hands them over, bit k stamped with time k */
+        FILE *bf = fopen(argv[optind], "rb"), *out = fopen(argv[optind + 1], "w");
+        if (!bf || !out) { fprintf(stderr, "cannot open files\n"); return 1; }
+        unsigned char *bits = malloc(chunk);
+        DT *t = malloc(sizeof(DT) * chunk);
+        unsigned long k = 0, frames = 0, n;
+        int ch = 0;
+        while (ch != EOF) {
+            n = 0;
+            while (n < chunk && (ch = fgetc(bf)) != EOF)
+                if (ch == '0' || ch == '1') { bits[n] = (unsigned char)ch; t[n] = (DT)(k++); n++; }
+#ifdef ARGOS
+            frames += FindSyncWords(bits, t, n, "0001011110000", 13, out);
+#else
+            frames += ByteSyncOnSyncword(bits, t, n, "1110110111100010000", 19, out);
+#endif
+        }
+        fclose(out);
+        fprintf(stderr, "bits %lu frames %lu\n", k, frames);
+        return 0;
+    }
 
     /* allocation order as in the reference main (heap layout matters for the
      * reads one-past-the-chunk) */

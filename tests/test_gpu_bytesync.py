@@ -109,3 +109,15 @@ def test_more_hits_than_the_lds_filter_holds(pdt, orc):
             parts.append(rand_bits(rng, int(rng.integers(1, 50))))
     ov, n = check(pdt, orc, pdt.MODE_POES, "".join(parts))
     assert n >= 9500 and ov == 0
+
+
+@pytest.mark.parametrize("piece", [4160, 77])
+def test_the_references_own_harness_bits(pdt, orc, piece):
+    """The literal bit string of the reference's commented-out harness (POESTIPdemod/ByteSync.c:6-14) against the
+    frames the reference's ByteSync object printed for it (tests/golden/make_bytesync_vector.py)."""
+    from conftest import golden_text
+    bitstr = golden_text("bytesync_harness_bits.txt").strip().decode()
+    check(pdt, orc, pdt.MODE_POES, bitstr, piece)
+    with pdt.Demodulator(pdt.MODE_POES, 50000) as d:
+        d.bytesync(to_bits(bitstr))
+        assert d.text() == golden_text("bytesync_harness_frames.txt")

@@ -112,3 +112,13 @@ def test_cross_check_against_the_older_builds_sample_output():
         assert abs(float(o[0]) - float(n[0])) < 0.01           # older time base, same 0.1 s frame slot
         diffs += [(k, i - 1, a, b) for i, (a, b) in enumerate(zip(o, n)) if i > 0 and a != b]
     assert diffs == [(16, 22, "01", "51"), (36, 22, "03", "5B")]
+
+
+@pytest.mark.parametrize("piece", [4160, 1000, 77, 19137])
+def test_bytesync_on_the_references_own_harness_bits(orc, piece):
+    """Known answer for the synchroniser alone: the literal bit string of the reference's commented-out harness
+    (POESTIPdemod/ByteSync.c:6-14), frames produced by the reference's ByteSync object (make_bytesync_vector.py)."""
+    bits = np.frombuffer(golden_text("bytesync_harness_bits.txt").strip(), dtype=np.uint8)
+    text, frames = orc.bytesync(orc.POES, bits, piece)
+    assert text == golden_text("bytesync_harness_frames.txt")
+    assert len(frames) == 23 and all(f[4] for f in frames)
