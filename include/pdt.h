@@ -84,6 +84,8 @@ enum {
     PDT_ST_COUNT
 };
 
+enum { PDT_CHAIN_FILE = 0, PDT_CHAIN_LIVE = 1 };
+
 typedef struct pdt_config {
     int32_t  mode;            /* PDT_MODE_POES / PDT_MODE_ARGOS                                   */
     uint32_t sample_rate;     /* Hz, the WAV header value (after the -s override, Q6)             */
@@ -106,7 +108,12 @@ typedef struct pdt_config {
      * (common/MMClockRecovery.c:5-83) at the same call site -- the switch the reference keeps commented out
      * (ARGOSdemod/main.c:277) -- with stepRange / kp below (0 = that call's values, 3 and 0.15).          */
     int32_t  sampler;
-    int32_t  reserved;
+    /* Chain variant: 0 = the file programs (POESTIPdemod / ARGOSdemod, what BASELINE measures); 1 = the sound-card
+     * twin POESTIPdemodPortAudio (main.c:41-65,324-393): same stage functions, acquisition gain 198.9437, lock threshold
+     * 0.10, the lock signal kept and Squelch(0.05) applied between PLL and FIR, Manchester threshold 0.75; default
+     * chunk 2400 (its block size).  Feed it float32 frames at 48 kHz to be the twin.  POES only (the ARGOS twin is
+     * the float build of the ARGOS chain): PDT_ERR_ARG otherwise.                                                     */
+    int32_t  chain;
     double   mm_step_range, mm_kp;
 } pdt_config;
 

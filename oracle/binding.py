@@ -120,7 +120,7 @@ class Oracle:
 
     def __init__(self, mode: int, sample_rate: int, iq: np.ndarray, chunk: int = 0, norm_override: float = 0.0,
                  keep_stages: bool = True, math_mode: int = MATH_LIBM, sampler: int = 0, mm_range: float = 3.0,
-                 mm_kp: float = 0.15):
+                 mm_kp: float = 0.15, chain: int = 0):
         L = lib()
         L.orc_set_math_mode(math_mode)
         self._L = L
@@ -130,6 +130,11 @@ class Oracle:
         L.orc_set_sampler.argtypes = [C.c_void_p, C.c_int, C.c_double, C.c_double]
         L.orc_set_sampler.restype = None
         L.orc_set_sampler(self._h, sampler, mm_range, mm_kp)      # 1 = MMClockRecovery instead of Gardner
+        if chain:                                                 # 1 = the sound-card twin's constants / stage order
+            L.orc_set_chain.argtypes = [C.c_void_p, C.c_int]
+            L.orc_set_chain.restype = C.c_int
+            if L.orc_set_chain(self._h, chain) != 0:
+                raise ValueError("the oracle restates the live chain for POES only")
         if np.asarray(iq).dtype.kind == "f":                     # RAW float32 capture
             a = np.ascontiguousarray(iq, dtype="<f4").reshape(-1)
             L.orc_run_f32(self._h, a.ctypes.data, a.size // 2)

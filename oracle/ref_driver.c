@@ -23,6 +23,7 @@
  *
  * usage: ref_demod{POES,ARGOS} [-c chunk] [-n gain] [-s kHz] [-d dumpprefix] [-M -R r -K k] in.wav out.txt
  *        ref_demod{POES,ARGOS} -B [-c piece] bits.txt out.txt
+ *        ref_demodPOES -L -s kHz [-c block] in.raw out.txt        (sound-card twin's composition)
  *   -d prefix : additionally dump every stage's per-chunk output, concatenated
  *               over chunks, to <prefix>.{pll,fir,agc,sym,symt,bits,bitt,lock}
  *               and per-chunk counts to <prefix>.counts (text).
@@ -79,8 +80,11 @@ int main(int argc, char **argv)
     int use_mm = 0;              /* -M: MMClockRecovery at the sampler's call site (ARGOSdemod/main.c:277, commented out there) */
     DT mmRange = 3, mmKp = 0.15;
     int c;
+    int live = 0;                /* -L: the sound-card twin's composition (POESTIPdemodPortAudio/main.c:324-393) over a
+                                    float32 file: the twin's constants, lock stream kept, Squelch between PLL and FIR */
     int bits_only = 0;           /* -B: in.wav is a text file of '0'/'1'; run only the reference's byte synchroniser on it */
-    while ((c = getopt(argc, argv, "c:n:s:d:MR:K:B")) != -1) {
+    while ((c = getopt(argc, argv, "c:n:s:d:MR:K:BL")) != -1) {
+        if (c == 'L') { live = 1; continue; }
         if (c == 'M') { use_mm = 1; continue; }
         if (c == 'B') { bits_only = 1; continue; }
         if (c == 'R') { mmRange = atof(optarg); continue; }
@@ -128,6 +132,8 @@ int main(int argc, char **argv)
     DT *dataStreamReal = malloc(sizeof(DT) * chunk);
 #ifdef ARGOS
     DT *lockSignalStream = malloc(sizeof(DT) * chunk);
+#else
+    DT *lockSignalStream = live ? malloc(sizeof(DT) * chunk) : NULL;   /* the file program has none; the twin allocates it after dataStreamReal */
 #endif
     DT *dataStreamSymbols = malloc(sizeof(DT) * chunk);
     unsigned char *dataStreamBits = malloc(chunk);
@@ -213,6 +219,12 @@ int main(int argc, char **argv)
         totalFrames += FindSyncWords(dataStreamBits, waveDataTime, nBits, "0001011110000", 13, out);
 #else
         /* POESTIPdemod/main.c:413-454 */
+        if (live) {                                             /* POESTIPdemodPortAudio/main.c:41-57,367,370 */
+            CarrierTrackPLL(waveData, dataStreamReal, lockSignalStream, nSamples, Fs, (4500.0), (0.10),
+                            0.3979 * (2.0 * M_PI / Fs), 198.9437 * (2.0 * M_PI / Fs), 10.3451 * (2.0 * M_PI / Fs));
+            dput(dlock, lockSignalStream, sizeof(DT), nSamples);
+            Squelch(dataStreamReal, lockSignalStream, nSamples, (0.05));
+        } else
         CarrierTrackPLL(waveData, dataStreamReal, NULL, nSamples, Fs, (4500.0), (0.08),
                         0.3979 * (2.0 * M_PI / Fs), 127.3240 * (2.0 * M_PI / Fs), 10.3451 * (2.0 * M_PI / Fs));
         dput(dpll, dataStreamReal, sizeof(DT), nSamples);
@@ -229,7 +241,7 @@ int main(int argc, char **argv)
                                              Fs * interp, (8320 * 2 + 0.3), (0.1), (3.0));
         dput(dsym, dataStreamSymbols, sizeof(DT), nSymbols);
         dput(dsymt, dataStreamLPFTime, sizeof(DT), nSymbols);
-        nBits = ManchesterDecode(dataStreamSymbols, dataStreamLPFTime, nSymbols, dataStreamBits, 1.0);
+        nBits = ManchesterDecode(dataStreamSymbols, dataStreamLPFTime, nSymbols, dataStreamBits, live ? (0.75) : 1.0);   /* twin: main.c:65,393 */
         dput(dbits, dataStreamBits, 1, nBits);
         dput(dbitt, dataStreamLPFTime, sizeof(DT), nBits);
         totalFrames += ByteSyncOnSyncword(dataStreamBits, dataStreamLPFTime, nBits, "1110110111100010000", 19, out);

@@ -29,6 +29,7 @@ LIBSYNTH_PATH = os.path.join(_HERE, "synth", "libpdtsynth.so")
 
 MODE_POES, MODE_ARGOS = 0, 1
 SAMPLER_GARDNER, SAMPLER_MM = 0, 1
+CHAIN_FILE, CHAIN_LIVE = 0, 1          # CHAIN_LIVE: the sound-card twin's constants and stage order (POES)
 ST_PLL, ST_LOCK, ST_FIR, ST_AGC, ST_SYM, ST_SYMIDX, ST_BITS, ST_BITSYM = range(8)
 
 
@@ -50,7 +51,7 @@ class Config(C.Structure):
         ("agc_warm", C.c_uint32),
         ("gardner_band_pad", C.c_double),
         ("sampler", C.c_int32),
-        ("reserved", C.c_int32),
+        ("chain", C.c_int32),
         ("mm_step_range", C.c_double),
         ("mm_kp", C.c_double),
     ]
@@ -217,11 +218,11 @@ class Demodulator:
 
     def __init__(self, mode: int, sample_rate: int, chunk: int = 0, norm_override: float = 0.0, device: int = 0,
                  profile: bool = False, pll_block: int = 0, pll_warm: int = 0, agc_block: int = 0, agc_warm: int = 0,
-                 gardner_band_pad: float = 0.0, sampler: int = 0, mm_step_range: float = 0.0, mm_kp: float = 0.0):
+                 gardner_band_pad: float = 0.0, sampler: int = 0, mm_step_range: float = 0.0, mm_kp: float = 0.0, chain: int = 0):
         self._L = lib()
         self.mode = mode
         cfg = Config(mode, sample_rate, chunk, norm_override, device, int(profile), pll_block, pll_warm, agc_block,
-                     agc_warm, gardner_band_pad, sampler, 0, mm_step_range, mm_kp)
+                     agc_warm, gardner_band_pad, sampler, chain, mm_step_range, mm_kp)
         self._h = C.c_void_p()
         _check(self._L.pdt_open(C.byref(cfg), C.byref(self._h)), "pdt_open")
         self.dtype = np.float64 if mode == MODE_ARGOS else np.float32

@@ -201,12 +201,13 @@ template <typename T> PllParams<T> make_pll_params(const pdt_ctx *ctx)
     PllParams<T> P;
     const T Fs = (T)ctx->cfg.sample_rate;
     const bool argos = ctx->cfg.mode == PDT_MODE_ARGOS;
+    const bool live = !argos && ctx->cfg.chain == PDT_CHAIN_LIVE;        // POESTIPdemodPortAudio/main.c:41-57
     const T freqRange = argos ? (T)550.0 : (T)4500.0;
     const double w = 2.0 * M_PI / (double)Fs;
-    const T bw_acq = (T)((argos ? 16.0 : 127.3240) * w);
+    const T bw_acq = (T)((argos ? 16.0 : live ? 198.9437 : 127.3240) * w);
     const T bw_trk = (T)((argos ? 16.0 : 10.3451) * w);
     P.Fs = Fs;
-    P.lock_thr = argos ? (T)0.1 : (T)0.08;
+    P.lock_thr = argos ? (T)0.1 : live ? (T)0.10 : (T)0.08;
     P.lock_alpha = (T)((argos ? 3.1831 : 0.3979) * w);
     const T damp = (T)0.999;
     const T four = 4, one = 1, two = 2;
@@ -247,7 +248,7 @@ template <typename T> PllParams<T> make_pll_params(const pdt_ctx *ctx)
     P.sweep0 = (T)(0.2 * (2.0 * M_PI / (double)Fs));
     P.avg0 = (T)(M_PI / 2.0);
     P.phase0 = (T)0.1;
-    P.want_lock = argos ? 1 : 0;
+    P.want_lock = (argos || live) ? 1 : 0;
     return P;
 }
 
@@ -302,6 +303,10 @@ enum { RUN_ALL = 0, RUN_ENQUEUE = 1, RUN_FINISH = 2 };
 template <typename T> int run_capture(pdt_ctx *ctx, uint64_t n, int phase = RUN_ALL)
 {
     const bool argos = ctx->cfg.mode == PDT_MODE_ARGOS;
+    // the sound-card twin's chain (POESTIPdemodPortAudio/main.c:324-393): the twin's constants, the lock signal kept and
+    // Squelch between PLL and FIR
+    const bool live = !argos && ctx->cfg.chain == PDT_CHAIN_LIVE;
+    const bool need_lock = argos || live;
     const long long N = (long long)n;
     const int interp = (int)ctx->interp;
     const int ntaps = (int)ctx->ntaps;
@@ -336,7 +341,7 @@ template <typename T> int run_capture(pdt_ctx *ctx, uint64_t n, int phase = RUN_
         GP.argos_field_bits = ((req + 8 + 15) & ~15ull) | 1ull;
         GP.argos_even = ((req + 8) % 16) != 0;
     }
-    const T manch_thr = argos ? (T)0.5 : (T)1.0;                               // main.c:445 / ARGOS main.c:282
+    const T manch_thr = argos ? (T)0.5 : live ? (T)0.75 : (T)1.0;              // main.c:445 / ARGOS main.c:282 / twin :65,393
     const SyncParams SP = make_sync_params(argos);
 
     // ---- block-parallel geometry (any values give the same output; they only move time around)
@@ -400,7 +405,7 @@ template <typename T> int run_capture(pdt_ctx *ctx, uint64_t n, int phase = RUN_
 
     int rc;
     if ((rc = ctx->pll.ensure((size_t)(N + 1) * sizeof(T)))) return rc;
-    if (argos && (rc = ctx->lock.ensure((size_t)(N + 1) * sizeof(T)))) return rc;
+    if (need_lock && (rc = ctx->lock.ensure((size_t)(N + 1) * sizeof(T)))) return rc;
     if ((rc = ctx->fir.ensure((size_t)(n_out + 1) * sizeof(T)))) return rc;
     if ((rc = ctx->agc.ensure((size_t)(n_out + 1) * sizeof(T)))) return rc;
     if ((rc = ctx->sym.ensure((size_t)sym_cap * sizeof(T)))) return rc;
@@ -414,13 +419,13 @@ template <typename T> int run_capture(pdt_ctx *ctx, uint64_t n, int phase = RUN_
     if ((rc = ctx->mag.ensure((size_t)(n0 + 1) * sizeof(T)))) return rc;
     if ((rc = ctx->seams_pll.ensure((size_t)nb_pll * sizeof(PllSeam<T>)))) return rc;
     if ((rc = ctx->seams_agc.ensure((size_t)nb_agc * sizeof(AgcSeam<T>)))) return rc;
-    if (argos && (rc = ctx->term.ensure((size_t)(N + 1) * sizeof(T)))) return rc;
+    if (need_lock && (rc = ctx->term.ensure((size_t)(N + 1) * sizeof(T)))) return rc;
     // lock-detector EMA (ARGOS): a pure contraction with factor 1 - lockSigAlpha per sample, so its own, much
     // shorter geometry: 45 time constants of warm-up agree in 53 bits (20 in 24), blocks a quarter of that
     const long long We = round4((long long)((sizeof(T) == 8 ? 45.0 : 20.0) / (double)PP.lock_alpha) + 64);
     const long long Be = std::max<long long>(64, round4(We / 4));
     const long long nb_ema = N / Be + 2;
-    if (argos && (rc = ctx->seams_ema.ensure((size_t)nb_ema * sizeof(EmaSeam<T>)))) return rc;
+    if (need_lock && (rc = ctx->seams_ema.ensure((size_t)nb_ema * sizeof(EmaSeam<T>)))) return rc;
     if ((rc = ctx->scal.ensure(sizeof(DevScalars)))) return rc;
     if ((rc = ctx->lockinfo.ensure(sizeof(PllLockInfo<T>)))) return rc;
 
@@ -428,7 +433,7 @@ template <typename T> int run_capture(pdt_ctx *ctx, uint64_t n, int phase = RUN_
     d_pcm.p = ctx->pcm_dev;
     d_pcm.fmt = ctx->pcm_fmt;
     T *d_pll = (T *)ctx->pll.p;
-    T *d_lock = argos ? (T *)ctx->lock.p : nullptr;
+    T *d_lock = need_lock ? (T *)ctx->lock.p : nullptr;
     T *d_fir = (T *)ctx->fir.p;
     T *d_agc = (T *)ctx->agc.p;
     T *d_sym = (T *)ctx->sym.p;
@@ -539,19 +544,24 @@ template <typename T> int run_capture(pdt_ctx *ctx, uint64_t n, int phase = RUN_
         L.end();
         (void)grid;
         L.begin("pll_mix");
-        if (argos)
+        if (need_lock)
             hipLaunchKernelGGL((k_pll_mix<T, true>), dim3((unsigned)((N + 255) / 256)), dim3(256), 0, st, d_pcm, d_phi, N, PP,
                                d_info, d_pll, (T *)ctx->term.p);
         else
             hipLaunchKernelGGL((k_pll_mix<T, false>), dim3((unsigned)((N + 255) / 256)), dim3(256), 0, st, d_pcm, d_phi, N, PP,
                                d_info, d_pll, (T *)nullptr);
         L.end();
-        if (argos) {
+        if (need_lock) {
             L.begin("lock_ema");
             hipLaunchKernelGGL(k_lock_ema<T>, dim3((unsigned)((nb_ema + 63) / 64)), dim3(64), 0, st, (const T *)ctx->term.p, N, PP.lock_alpha,
                                d_info, Be, We, d_lock, (EmaSeam<T> *)ctx->seams_ema.p);
             hipLaunchKernelGGL(k_lock_ema_fix<T>, dim3(1), dim3(64), 0, st, (const T *)ctx->term.p, N, PP.lock_alpha, d_info,
                                Be, d_lock, (EmaSeam<T> *)ctx->seams_ema.p, &d_sc->counters[1]);
+            L.end();
+        }
+        if (live) {                                            // twin main.c:370, DSP_SQLCH_THRESH 0.05 (:55)
+            L.begin("squelch");
+            hipLaunchKernelGGL(k_squelch<T>, dim3((unsigned)((N + 1023) / 1024)), dim3(256), 0, st, d_pll, (const T *)d_lock, N, (T)0.05);
             L.end();
         }
     }
@@ -853,7 +863,7 @@ template <typename T> int run_capture(pdt_ctx *ctx, uint64_t n, int phase = RUN_
     S.sync_overflow = sc.sync_overflow;
 
     ctx->stage_len[PDT_ST_PLL] = n;
-    ctx->stage_len[PDT_ST_LOCK] = argos ? n : 0;
+    ctx->stage_len[PDT_ST_LOCK] = need_lock ? n : 0;
     ctx->stage_len[PDT_ST_FIR] = (uint64_t)n_out;
     ctx->stage_len[PDT_ST_AGC] = (uint64_t)n_out;
     ctx->stage_len[PDT_ST_SYM] = sc.nsym;
@@ -1002,6 +1012,9 @@ int pdt_open(const pdt_config *cfg, pdt_ctx **out)
     if (!cfg || !out) return PDT_ERR_ARG;
     if (cfg->mode != PDT_MODE_POES && cfg->mode != PDT_MODE_ARGOS) return PDT_ERR_ARG;
     if (!cfg->sample_rate) return PDT_ERR_ARG;
+    if (cfg->chain != PDT_CHAIN_FILE && cfg->chain != PDT_CHAIN_LIVE) return PDT_ERR_ARG;
+    // the ARGOS twin is the float build of the ARGOS chain (ARGOSdemodPortAudio/config.h): not provided
+    if (cfg->chain == PDT_CHAIN_LIVE && cfg->mode == PDT_MODE_ARGOS) return PDT_ERR_ARG;
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) {
         (void)hipGetLastError();
@@ -1012,7 +1025,7 @@ int pdt_open(const pdt_config *cfg, pdt_ctx **out)
     HIP_TRY(hipSetDevice(cfg->device));
     pdt_ctx *ctx = new pdt_ctx();
     ctx->cfg = *cfg;
-    if (!ctx->cfg.chunk) ctx->cfg.chunk = cfg->mode == PDT_MODE_ARGOS ? 2400 : 10000;
+    if (!ctx->cfg.chunk) ctx->cfg.chunk = (cfg->mode == PDT_MODE_ARGOS || cfg->chain == PDT_CHAIN_LIVE) ? 2400 : 10000;
     ctx->elem = cfg->mode == PDT_MODE_ARGOS ? 8 : 4;
     int nt = 0, ip = 0;
     int rc = pdt_make_lpf(cfg->mode, cfg->sample_rate, nullptr, &nt, &ip);

@@ -1167,6 +1167,20 @@ __global__ void __launch_bounds__(64) k_lock_ema_fix(const T *__restrict__ term,
     if (threadIdx.x == 0) *fixes_out += fixes;
 }
 
+// Squelch on its own (common/AGC.c:24-46): x[i] = 0 where lock[i] < thr.  The file programs apply it after the AGC (fused
+// into k_agc_block); the sound-card twin applies it between PLL and FIR (POESTIPdemodPortAudio/main.c:370).
+// Elementwise, 4 samples per thread.
+template <typename T>
+__global__ void __launch_bounds__(256) k_squelch(T *__restrict__ x, const T *__restrict__ lock, long long n, T thr)
+{
+    const long long i0 = ((long long)blockIdx.x * 256 + threadIdx.x) * 4;
+#pragma unroll
+    for (int u = 0; u < 4; u++) {
+        const long long i = i0 + u;
+        if (i < n && lock[i] < thr) x[i] = 0;
+    }
+}
+
 // decay branch of one AGC step as an affine map of the gain, g -> A g + B (see the AGC section below)
 struct AgcMap { double A, B; };
 

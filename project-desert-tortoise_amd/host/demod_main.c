@@ -18,7 +18,11 @@
  *   output removed when no frame was found             main.c:508-512
  * Additions: -o <file> chooses the output name (tests), -d <n> picks the GPU, -q (POES) prints the frame
  * validation the reference keeps in MATLAB (checkParity.m:91-92, daytimeDecode.m:36,82-95) after decoding,
- * -m selects MMClockRecovery (the sampler the reference keeps commented out at ARGOSdemod/main.c:277).
+ * -m selects MMClockRecovery (the sampler the reference keeps commented out at ARGOSdemod/main.c:277),
+ * -l (POES) runs the sound-card twin's chain (POESTIPdemodPortAudio/main.c:41-65,324-393: its PLL constants,
+ * Squelch between PLL and FIR, Manchester threshold 0.75, blocks of 2400); with the file name "-" it is the twin's
+ * loop itself, reading float32 I,Q blocks from standard input (e.g. a sound-card recorder's pipe, -s 48) until
+ * end of file and appending every minor frame to the output as soon as it is final.
  * Not reproduced: the per-chunk "\r" progress line (there are no chunks on the GPU; one
  * summary line is printed instead).  RAW float32 input (".raw", -s mandatory) is supported for POES
  * exactly as in POESTIPdemod/main.c:313-339.
@@ -43,7 +47,7 @@
 #else
 #define MODE PDT_MODE_POES
 #define DEFAULT_CHUNKSIZE 10000
-#define OPTS "s:rn:c:o:d:qm"
+#define OPTS "s:rn:c:o:d:qml"
 #define BANNER "Project Desert Tortoise: Wave file NOAA TIP Demodulator (MI355X build)\n"
 #define PREFIX "minorFrames"
 #define UNIT "Frames"
@@ -56,11 +60,89 @@ static const char *get_filename_ext(const char *filename)
     return dot + 1;
 }
 
+#ifndef PDT_ARGOS
+static void put_frames(FILE *out, const pdt_frame *f, uint64_t n)
+{
+    for (uint64_t k = 0; k < n; k++) {                                /* POESTIPdemod/ByteSync.c:62-69,96-101 */
+        fprintf(out, f[k].inverted ? "%.5fi " : "%.5f ", f[k].time);
+        for (unsigned b = 0; b < f[k].nbytes; b++) fprintf(out, "%.2X ", f[k].bytes[b]);
+        if (f[k].complete) fprintf(out, "\n");
+    }
+    fflush(out);
+}
+
+/* The twin's loop (POESTIPdemodPortAudio/main.c:324-393) with standard input as the sound card: blocks of `chunk`
+ * float32 I,Q frames until end of file (there: until a key is hit); frames are appended as they become final. */
+static int live_loop(FILE *in, FILE *out, const char *outFileName, double sampleRate, unsigned long chunk, double normFactor,
+                     int device, int sampler)
+{
+    if (sampleRate < 1) sampleRate = 48.0;                            /* twin: SAMPLE_RATE 48000 (main.c:27) */
+    pdt_config cfg;
+    memset(&cfg, 0, sizeof cfg);
+    cfg.mode = PDT_MODE_POES;
+    cfg.sample_rate = (uint32_t)(sampleRate * 1000.0);
+    cfg.chunk = chunk;
+    cfg.norm_override = normFactor;
+    cfg.device = device;
+    cfg.sampler = sampler;
+    cfg.chain = PDT_CHAIN_LIVE;
+    pdt_ctx *ctx = NULL;
+    int rc = pdt_open(&cfg, &ctx);
+    if (rc != PDT_OK) {
+        printf("GPU demodulator unavailable: %s\n", pdt_strerror(rc));
+        fclose(out);
+        remove(outFileName);
+        return 1;
+    }
+    float *block = (float *)malloc(sizeof(float) * 2 * chunk);
+    pdt_frame *fr = NULL;
+    uint64_t cap = 0, total = 0, samples = 0, fresh = 0;
+    if (!block || pdt_stream_begin(ctx) != PDT_OK) {
+        printf("Error in malloc\n");
+        return 1;
+    }
+    for (;;) {
+        const size_t got = fread(block, 2 * sizeof(float), chunk, in);
+        if (got) {
+            rc = pdt_stream_push_f32(ctx, block, got, &fresh);
+        } else {
+            rc = pdt_stream_end(ctx, &fresh);
+        }
+        if (rc != PDT_OK) {
+            printf("Demodulation failed: %s\n", pdt_strerror(rc));
+            return 1;
+        }
+        if (fresh > cap) {
+            cap = fresh + 64;
+            fr = (pdt_frame *)realloc(fr, cap * sizeof *fr);
+            if (!fr) return 1;
+        }
+        if (fresh) put_frames(out, fr, pdt_stream_frames(ctx, fr, fresh));
+        total += fresh;
+        samples += got;
+        if (!got) break;
+        printf("\r%0.1fKsps :%0.3f Sec: %llu Frames", sampleRate, (double)samples / (sampleRate * 1000.0), (unsigned long long)total);
+        fflush(stdout);
+    }
+    pdt_stats st;
+    pdt_get_stats(ctx, &st);
+    if (st.lock_sample >= 0) printf("\n : PLL locked at %0.2fHz", st.lock_freq_hz);
+    printf("\nNormalization Factor: %f\n%llu samples, %llu " UNIT "\n", st.norm_factor, (unsigned long long)samples,
+           (unsigned long long)total);
+    fclose(out);
+    if (total == 0) remove(outFileName);
+    free(block);
+    free(fr);
+    pdt_close(ctx);
+    return 0;
+}
+#endif
+
 int main(int argc, char **argv)
 {
     unsigned long chunkSize = DEFAULT_CHUNKSIZE;
     double normFactor = 0, sampleRate = 0;
-    int outputRawFiles = 0, device = 0, quality = 0, sampler = 0, c;
+    int outputRawFiles = 0, device = 0, quality = 0, sampler = 0, live = 0, chunkGiven = 0, c;
     const char *outOverride = NULL;
     char outFileName[1100];
 
@@ -81,6 +163,7 @@ int main(int argc, char **argv)
             break;
         case 'c':
             chunkSize = (unsigned long)atoi(optarg);
+            chunkGiven = 1;
             if (chunkSize != DEFAULT_CHUNKSIZE) printf("Override: Using %ld chunkSize\n", chunkSize);
             break;
         case 'o':
@@ -91,6 +174,10 @@ int main(int argc, char **argv)
             break;
         case 'q':
             quality = 1;
+            break;
+        case 'l':                                       /* the sound-card twin's chain */
+            live = 1;
+            printf("Using the live (sound card) chain\n");
             break;
         case 'm':                                       /* MMClockRecovery instead of Gardner (ARGOSdemod/main.c:277) */
             sampler = PDT_SAMPLER_MM;
@@ -108,7 +195,8 @@ int main(int argc, char **argv)
             abort();
         }
     }
-    if (chunkSize == DEFAULT_CHUNKSIZE) printf("Using default %ld chunkSize\n", chunkSize);
+    if (live && !chunkGiven) chunkSize = 2400;          /* POESTIPdemodPortAudio/main.c:34 */
+    if (chunkSize == (live ? 2400 : DEFAULT_CHUNKSIZE)) printf("Using default %ld chunkSize\n", chunkSize);
     if (optind >= argc) {
         printf("No wave file specified\n");
         return 1;
@@ -116,7 +204,8 @@ int main(int argc, char **argv)
     const char *inFileName = argv[optind];
     printf("%s\n", inFileName);
     printf("Opening IO files..\n");
-    FILE *in = fopen(inFileName, "rb");
+    const int from_stdin = live && strcmp(inFileName, "-") == 0;
+    FILE *in = from_stdin ? stdin : fopen(inFileName, "rb");
 
     time_t t = time(NULL);
     struct tm tm = *localtime(&t);
@@ -139,6 +228,9 @@ int main(int argc, char **argv)
         fclose(raw);
     }
 
+#ifndef PDT_ARGOS
+    if (from_stdin) return live_loop(in, out, outFileName, sampleRate, chunkSize, normFactor, device, sampler);
+#endif
     int is_raw = 0;
     if (strcasecmp(get_filename_ext(inFileName), "wav") != 0) {
 #ifdef PDT_ARGOS
@@ -215,6 +307,7 @@ int main(int argc, char **argv)
     cfg.norm_override = normFactor;
     cfg.device = device;
     cfg.sampler = sampler;
+    cfg.chain = live ? PDT_CHAIN_LIVE : PDT_CHAIN_FILE;
     pdt_ctx *ctx = NULL;
     int rc = pdt_open(&cfg, &ctx);
     if (rc != PDT_OK) {

@@ -1,0 +1,85 @@
+"""the sound-card twin's chain (POESTIPdemodPortAudio/main.c:324-393) on the GPU -- float32 blocks
+of 2400 frames at 48 kHz, the twin's PLL constants, Squelch between PLL and FIR, Manchester threshold 0.75 --
+against the oracle (which tests/test_oracle_ref.py pins on the reference's stage objects called in the twin's order)."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+STAGES = ["ST_PLL", "ST_LOCK", "ST_FIR", "ST_AGC", "ST_SYM", "ST_BITS"]
+
+
+def live_capture(pdt, fs, secs, seed, f0, scale=1.0):
+    iq = pdt.synth_capture(0, fs, secs, f0_hz=f0, seed=seed)
+    return (iq.astype(np.float32) / np.float32(32768.0)) * np.float32(scale)
+
+
+@pytest.mark.parametrize("fs,chunk,secs,seed,f0,scale", [(48000, 0, 6.0, 41, 900.0, 1.0), (48000, 2400, 20.0, 42, -2800.0, 0.02),
+                                                         (48000, 1000, 5.0, 43, 300.0, 1.0), (50000, 10000, 8.0, 44, 1500.0, 3.0),
+                                                         (48000, 2400, 60.0, 45, 2100.0, 0.3)])
+def test_live_chain_matches_oracle(pdt, orc, fs, chunk, secs, seed, f0, scale):
+    raw = live_capture(pdt, fs, secs, seed, f0, scale)
+    o = orc.Oracle(orc.POES, fs, raw, chunk=chunk or 2400, chain=1)
+    with pdt.Demodulator(pdt.MODE_POES, fs, chunk=chunk, chain=pdt.CHAIN_LIVE) as d:
+        d.demod_raw(raw)
+        for name in STAGES:
+            got = d.stage(getattr(pdt, name))
+            exp = o.stage(getattr(orc, name))
+            assert got.tobytes() == exp.tobytes(), f"stage {name} differs"
+        assert d.text() == o.text() and len(o.text()) > 0
+        assert d.stats().lock_sample == o.lock_sample
+
+
+def test_live_stream_in_blocks_of_2400(pdt, orc):
+    """The twin's own shape: blocks of 2400 float32 frames pushed as they arrive; frames come out once, in order,
+    while the stream is still running."""
+    raw = live_capture(pdt, 48000, 12.0, 51, 700.0)
+    o = orc.Oracle(orc.POES, 48000, raw, chunk=2400, chain=1, keep_stages=False)
+    with pdt.Demodulator(pdt.MODE_POES, 48000, chain=pdt.CHAIN_LIVE) as d:
+        d.stream_begin()
+        parts = []
+        for k in range(0, len(raw), 2400):
+            parts.append(d.stream_push(raw[k:k + 2400]))
+        early = sum(len(x) for x in parts)
+        parts.append(d.stream_end())
+        got = np.concatenate(parts)
+        assert d.text() == o.text()
+        assert got.tobytes() == d.frames_array().tobytes()
+        assert early >= len(got) - 4 and len(got) > 100
+
+
+def test_live_noise_only_is_squelched(pdt, orc):
+    rng = np.random.default_rng(3)
+    raw = (rng.standard_normal((96000, 2)) * 0.01).astype(np.float32)
+    o = orc.Oracle(orc.POES, 48000, raw, chunk=2400, chain=1)
+    with pdt.Demodulator(pdt.MODE_POES, 48000, chain=pdt.CHAIN_LIVE) as d:
+        d.demod_raw(raw)
+        assert d.stage(pdt.ST_PLL).tobytes() == o.stage(orc.ST_PLL).tobytes()
+        assert d.stage(pdt.ST_AGC).tobytes() == o.stage(orc.ST_AGC).tobytes()
+        assert d.text() == o.text()
+
+
+def test_live_chain_is_poes_only(pdt):
+    with pytest.raises(pdt.PdtError):
+        pdt.Demodulator(pdt.MODE_ARGOS, 48000, chain=pdt.CHAIN_LIVE)
+
+
+def test_cli_live_loop_from_a_pipe_and_from_a_file(pdt, orc, tmp_path):
+    """bin/demodPOES -l: with "-" the twin's loop itself (standard input as the sound card), with a .raw file the
+    same chain in one go; both write the oracle's file."""
+    import os
+    import subprocess
+    from conftest import ROOT
+    raw = live_capture(pdt, 48000, 9.0, 61, 1200.0)
+    want = orc.Oracle(orc.POES, 48000, raw, chunk=2400, chain=1, keep_stages=False).text()
+    exe = os.path.join(ROOT, "bin", "demodPOES")
+    out = tmp_path / "piped.txt"
+    r = subprocess.run([exe, "-l", "-s", "48", "-o", str(out), "-"], input=raw.tobytes(), capture_output=True)
+    assert r.returncode == 0, r.stdout.decode()
+    assert out.read_bytes() == want and b"PLL locked at" in r.stdout
+    path = tmp_path / "cap.raw"
+    raw.tofile(path)
+    out2 = tmp_path / "file.txt"
+    r = subprocess.run([exe, "-l", "-s", "48", "-o", str(out2), str(path)], capture_output=True)
+    assert r.returncode == 0, r.stdout.decode()
+    assert out2.read_bytes() == want

@@ -155,3 +155,27 @@ def test_mm_clock_recovery_all_stages(orc, pdt, clip, tmp_path, mode, chunk, rng
     compare_all(o, dump)
     assert o.text() == text
     assert len(o.stage(orc.ST_SYM)) > 1000
+
+
+@pytest.mark.parametrize("fs,chunk,seed,f0,scale", [(48000, 2400, 31, 900.0, 1.0), (48000, 2400, 32, -2800.0, 0.02), (48000, 1000, 33, 300.0, 1.0),
+                                                    (50000, 10000, 34, 1500.0, 3.0)])
+def test_live_chain_all_stages(orc, pdt, tmp_path, fs, chunk, seed, f0, scale):
+    """the sound-card twin's chain (POESTIPdemodPortAudio/main.c:324-393) -- float32 blocks of
+    2400 frames at 48 kHz, acquisition gain 198.9437, lock threshold 0.10, Squelch(0.05) between PLL and FIR,
+    Manchester threshold 0.75.  The twin cannot be built here (PortAudio); its stage functions are the common
+    objects, which oracle/ref_driver.c -L calls in the twin's order with the twin's constants."""
+    iq = pdt.synth_capture(0, fs, 5.0, f0_hz=f0, seed=seed)
+    raw = (iq.astype(np.float32) / np.float32(32768.0)) * np.float32(scale)
+    path = tmp_path / "live.raw"
+    raw.tofile(path)
+    text, dump = run_ref(REF_POES, path, tmp_path, ["-L", "-s", str(fs / 1000.0), "-c", str(chunk)])
+    o = orc.Oracle(orc.POES, fs, raw, chunk=chunk, chain=1)
+    for name, sid in STAGES.items():
+        ref = open(f"{dump}.{name}", "rb").read()
+        assert o.stage(sid).tobytes() == ref, f"stage {name}: restatement differs from the reference objects"
+    assert o.text() == text and len(text) > 0
+    # the squelch really acts before the lock: the PLL output starts as zeros
+    pll = o.stage(orc.ST_PLL)
+    assert o.lock_sample > 0 and not pll[: min(o.lock_sample, 200)].any() and pll[o.lock_sample + 5000:].any()
+    # and it is not the file chain
+    assert o.stage(orc.ST_PLL).tobytes() != orc.Oracle(orc.POES, fs, raw, chunk=chunk).stage(orc.ST_PLL).tobytes()
