@@ -157,12 +157,14 @@ __device__ __forceinline__ void sincos_portable(double x, double &sv, double &cv
 template <typename T> struct Real;
 template <> struct Real<double> {
     static __device__ __forceinline__ double abs(double v) { return __builtin_fabs(v); }
+    static __device__ __forceinline__ double max(double a, double b) { return __builtin_fmax(a, b); }
     static __device__ __forceinline__ double rint(double v) { return __builtin_rint(v); }
     static __device__ __forceinline__ void sincos(double p, double &s, double &c) { sincos_portable(p, s, c); }
     static __device__ __forceinline__ double hypot(double x, double y) { return __builtin_sqrt(x * x + y * y); }
 };
 template <> struct Real<float> {
     static __device__ __forceinline__ float abs(float v) { return __builtin_fabsf(v); }
+    static __device__ __forceinline__ float max(float a, float b) { return __builtin_fmaxf(a, b); }
     static __device__ __forceinline__ float rint(float v) { return __builtin_rintf(v); }
     static __device__ __forceinline__ void sincos(float p, float &s, float &c) { sincosf_glibc(p, s, c); }
     static __device__ __forceinline__ float hypot(float x, float y) { return hypotf_glibc(x, y); }

@@ -641,6 +641,27 @@ template <typename T> struct alignas(16) Vec16 {
     T v[N];
 };
 
+// Look-ahead ring of a lane-per-block stream walker, hand-issued.  Every lane streams its own block, so its loads
+// cannot coalesce and must be issued far ahead; left to the compiler, the re-loads of an unrolled register ring are
+// moved around freely (hoisted above the arithmetic, sunk across the back edge) and the loop header waits for all of
+// them: each trip then exposes a memory latency.  Here the data in flight never live in compiler-visible registers:
+// ring_issue sends 16 bytes per lane from global memory straight into LDS (slot base + 16 * lane), ring_wait<N> is
+// an explicit `s_waitcnt vmcnt(N)` (the counter covers loads and stores, oldest first, so N = number of ring
+// requests known to be younger is always enough), and the walker then reads its own 16 bytes of the slot with an
+// ordinary LDS load.  Both carry a memory clobber: the compiler keeps LDS reads behind the wait that guards them.
+#define PDT_RING_SLOT 1024        // bytes per slot: 64 lanes x 16
+__device__ __forceinline__ void ring_issue(const void *g, unsigned lds_slot_addr)
+{
+    // (s_nop: wait state between writing M0 and the LDS-direct load that uses it.  M0 is reserved by the compiler, which
+    // loads it immediately before each of its own uses and never keeps a value in it: tests/test_abi.py checks that the
+    // kernels using this contain no other reference to m0.)
+    asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" : : "v"(g), "s"(lds_slot_addr) : "memory");
+}
+template <int N> __device__ __forceinline__ void ring_wait()
+{
+    asm volatile("s_waitcnt vmcnt(%0)" : : "n"(N) : "memory");
+}
+
 // run the recurrence over [i0, i1), optionally storing the pre-update phase of every sample;
 // 16-byte vector loads/stores on the aligned body (each lane streams its own block)
 template <typename T, bool STORE, bool SLOW, int PF = PDT_PF>
@@ -1488,11 +1509,49 @@ template <typename T> __device__ __forceinline__ T agc_step(T x, T &gain, const 
 template <typename T> struct AgcSeam { T g0, g1; };
 
 // run the AGC over [i0, i1) with 16-byte vector loads/stores on the aligned body
-template <typename T, bool STORE>
-__device__ __forceinline__ void agc_range(const T *__restrict__ in, const T *__restrict__ lock, T *__restrict__ out,
-                                          long long i0, long long i1, T &gain, const AgcParams<T> &P)
+// look-ahead depth (16-byte vectors per lane) of the AGC walkers' LDS ring: 256 samples, about 1.7 us of calm arithmetic
+#ifndef PDT_AGC_PF
+#define PDT_AGC_PF 64
+#endif
+// A lone wavefront issues about one instruction every four clocks whatever the dependences, so a walker's pace is its
+// instruction count.  The exact step costs ten vector instructions (two of them selects behind compares, four the
+// range clamps); over a CALM batch of 16 samples -- every |x| <= 1, the gain in [2.5, 4000] at its start, decay <= 0.04
+// -- none of the three conditionals can act and four instructions remain:
+//   * |x| g <= g and rounding is monotone, so err = fl(|fl(x g)| - 1) lies in [-1, g - 1] and |err| > g is false
+//     (g >= 1.3 throughout, below): the decay branch;
+//   * one step moves the gain into [g - (g - 1) decay, g + decay] (up to rounding), so over 16 steps it stays within
+//     [0.52 g0, g0 + 0.64], i.e. inside [1.3, 4001]: neither clamp;
+//   * a NaN sample gives gain = NaN on either path (the compare and both clamp tests are false for NaN), an infinite one
+//     fails the |x| <= 1 test, a NaN gain fails the range test.
+// Everything else runs the exact step, as before.
+template <typename T, int NB>
+__device__ __forceinline__ bool agc_calm(const Vec16<T> *b, T gain, T decay)
 {
     constexpr int VN = Vec16<T>::N;
+    T xm = 0;
+#pragma unroll
+    for (int k = 0; k < NB; k++)
+#pragma unroll
+        for (int w = 0; w < VN; w++) xm = Real<T>::max(xm, Real<T>::abs(b[k].v[w]));
+    return (decay > (T)0) & (decay <= (T)0.04) & (gain >= (T)2.5) & (gain <= (T)4000) & (xm <= (T)1);
+}
+
+template <typename T> __device__ __forceinline__ T agc_step_calm(T x, T &gain, T decay)
+{
+    x = x * gain;
+    const T err = Real<T>::abs(x) - (T)1.0;
+    gain = gain - err * decay;
+    return x;
+}
+
+template <typename T, bool STORE, int PF = PDT_AGC_PF>
+__device__ __forceinline__ void agc_range(const T *__restrict__ in, const T *__restrict__ lock, T *__restrict__ out,
+                                          long long i0, long long i1, T &gain, const AgcParams<T> &P, unsigned char *ring)
+{
+    constexpr int VN = Vec16<T>::N;
+    constexpr int NB = 16 / VN;            // vectors per 16-sample batch
+    constexpr int NBATCH = PF / NB;        // batches the ring holds
+    static_assert(PF % NB == 0 && NBATCH >= 3, "the look-ahead ring holds whole batches");
     long long i = i0;
     for (; i < i1 && (i % VN) != 0; i++) {
         T y = agc_step(in[i], gain, P);
@@ -1501,30 +1560,54 @@ __device__ __forceinline__ void agc_range(const T *__restrict__ in, const T *__r
             out[i] = y;
         }
     }
-    if (i + PDT_PF * VN <= i1) {           // software pipeline, see pll_phase_range
-        Vec16<T> buf[PDT_PF];
+    const long long nbt = (i1 - i) / 16;   // whole batches
+    if (nbt > 0) {
+        // ring in LDS (see ring_issue): batch k of the range lives in ring batch k % NBATCH; the loads run NBATCH
+        // batches ahead of the arithmetic (up to PF vectors past i1: slack of the device buffers), the LDS reads one
+        const unsigned ring0 = (unsigned)(size_t)ring;
+        const unsigned char *mine = ring + 16 * (threadIdx.x & 63);
 #pragma unroll
-        for (int u = 0; u < PDT_PF; u++) buf[u] = *reinterpret_cast<const Vec16<T> *>(in + i + u * VN);
-        for (; i + PDT_PF * VN <= i1; i += PDT_PF * VN) {
+        for (int u = 0; u < PF; u++) ring_issue(in + i + u * VN, ring0 + u * PDT_RING_SLOT);
+        ring_wait<PF - NB>();
+        Vec16<T> xb[NB], xn[NB];
 #pragma unroll
-            for (int u = 0; u < PDT_PF; u++) {
-                Vec16<T> yv;
+        for (int k = 0; k < NB; k++) xb[k] = *reinterpret_cast<const Vec16<T> *>(mine + k * PDT_RING_SLOT);
+        int rb = 0;                        // ring batch of the current batch
+        for (long long bt = 0; bt < nbt; bt++, i += 16) {
+            const int rnext = (rb + 1 == NBATCH) ? 0 : rb + 1;
+            // requests younger than the next batch's: NBATCH - 2 batches (the current batch's slots are re-issued below)
+            ring_wait<PF - 2 * NB>();
 #pragma unroll
-                for (int w = 0; w < VN; w++) yv.v[w] = agc_step(buf[u].v[w], gain, P);
+            for (int k = 0; k < NB; k++) xn[k] = *reinterpret_cast<const Vec16<T> *>(mine + (rnext * NB + k) * PDT_RING_SLOT);
+            Vec16<T> yv[NB];
+            if (agc_calm<T, NB>(xb, gain, P.decay)) {
+#pragma unroll
+                for (int k = 0; k < NB; k++)
+#pragma unroll
+                    for (int w = 0; w < VN; w++) yv[k].v[w] = agc_step_calm(xb[k].v[w], gain, P.decay);
+            } else {
+#pragma unroll
+                for (int k = 0; k < NB; k++)
+#pragma unroll
+                    for (int w = 0; w < VN; w++) yv[k].v[w] = agc_step(xb[k].v[w], gain, P);
+            }
+#pragma unroll
+            for (int k = 0; k < NB; k++) {
                 if (STORE) {
                     if (P.squelch) {
-                        const Vec16<T> lv = *reinterpret_cast<const Vec16<T> *>(lock + i + u * VN);
+                        const Vec16<T> lv = *reinterpret_cast<const Vec16<T> *>(lock + i + k * VN);
 #pragma unroll
                         for (int w = 0; w < VN; w++)
-                            if (lv.v[w] < P.squelch_thr) yv.v[w] = 0;
+                            if (lv.v[w] < P.squelch_thr) yv[k].v[w] = 0;
                     }
-                    *reinterpret_cast<Vec16<T> *>(out + i + u * VN) = yv;
+                    *reinterpret_cast<Vec16<T> *>(out + i + k * VN) = yv[k];
                 }
-                long long q = i + (PDT_PF + u) * VN;      // reload after the last use (see pll_phase_range)
-                asm volatile("" : "+v"(q));
-                buf[u] = *reinterpret_cast<const Vec16<T> *>(in + q);
+                ring_issue(in + i + (PF + k) * VN, ring0 + (unsigned)(rb * NB + k) * PDT_RING_SLOT);
+                xb[k] = xn[k];
             }
+            rb = rnext;
         }
+        ring_wait<0>();
     }
     for (; i + VN <= i1; i += VN) {
         const Vec16<T> xv = *reinterpret_cast<const Vec16<T> *>(in + i);
@@ -1687,6 +1770,7 @@ __global__ void __launch_bounds__(64) k_agc_block(const T *__restrict__ in, long
                                                    const double *__restrict__ guesses, const T *__restrict__ lock,
                                                    T *__restrict__ out, AgcSeam<T> *__restrict__ seams, double K)
 {
+    __shared__ __attribute__((aligned(16))) unsigned char ring[PDT_AGC_PF * PDT_RING_SLOT];
     const long long j = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     const long long start = j * B;
     if (start >= n) return;
@@ -1710,10 +1794,10 @@ __global__ void __launch_bounds__(64) k_agc_block(const T *__restrict__ in, long
             gain = (T)g0;
         }
     }
-    agc_range<T, false>(in, lock, out, ws, start, gain, P);
+    agc_range<T, false>(in, lock, out, ws, start, gain, P, ring);
     AgcSeam<T> sm;
     sm.g0 = gain;
-    agc_range<T, true>(in, lock, out, start, end, gain, P);
+    agc_range<T, true>(in, lock, out, start, end, gain, P, ring);
     sm.g1 = gain;
     seams[j] = sm;
 }
@@ -1724,6 +1808,7 @@ __global__ void __launch_bounds__(64) k_agc_fix(const T *__restrict__ in, long l
                                                  AgcSeam<T> *__restrict__ seams, unsigned *__restrict__ counters)
 {
     // same wave-parallel seam scan as k_pll_fix
+    __shared__ __attribute__((aligned(16))) unsigned char ring[PDT_AGC_PF * PDT_RING_SLOT];
     const long long nb = (n + B - 1) / B;
     unsigned fixes = 0;
     long long r = 1;
@@ -1740,7 +1825,7 @@ __global__ void __launch_bounds__(64) k_agc_fix(const T *__restrict__ in, long l
             T gain = g_true;
             const long long start = rb * B;
             const long long end = (start + B < n) ? start + B : n;
-            agc_range<T, true>(in, lock, out, start, end, gain, P);
+            agc_range<T, true>(in, lock, out, start, end, gain, P, ring);
             seams[rb].g0 = g_true;
             seams[rb].g1 = gain;
         }
