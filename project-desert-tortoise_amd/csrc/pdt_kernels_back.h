@@ -172,7 +172,39 @@ __device__ __forceinline__ long long gardner_walk_chunk(const T *__restrict__ in
             const T wb = (T)wbase;
             T *ov = o_val + nout;
             unsigned *oi = o_idx + nout;
-            for (int k = 0; k < K; k++) {
+            int k = 0;
+            if constexpr (sizeof(T) == 4) if (n_cur < (1u << 22) - 4096u) {
+                // float: the wavefronts of a capture's chunks fill the chip's issue slots (about one instruction per four
+                // clocks per wavefront), so the loop is written for instruction count: round-to-nearest-even through the
+                // 1.5 * 2^23 bias (index = mantissa bits, exact for 0 <= x < 2^22, as in the table kernel), the clip as one
+                // median (the value the two-sided select gives for every non-NaN error), four symbols per trip
+                const int bias = 0x4B400000 + (int)wbase;
+                auto one = [&](int kk) {
+                    const int bn = __float_as_int((float)ns + 12582912.0f);
+                    const int bh = __float_as_int((float)half + 12582912.0f);
+                    const float c_k = (float)win[bn - bias];
+                    const float m_k = (float)win[bh - bias];
+                    i_last = (unsigned)(bn - 0x4B400000);
+                    if (EMIT) {
+                        ov[kk] = (T)c_k;
+                        oi[kk] = i_last;
+                    }
+                    const float err = __builtin_amdgcn_fmed3f((float)kp * (c_k - (float)prev) * m_k, -(float)lim, (float)lim);
+                    ns = (T)((float)ns - err);
+                    q_last = ns;
+                    half = (T)((float)ns + (float)hs);
+                    ns = (T)((float)ns + (float)step);
+                    prev = (T)c_k;
+                };
+                for (; k + 4 <= K; k += 4) {
+                    one(k);
+                    one(k + 1);
+                    one(k + 2);
+                    one(k + 3);
+                }
+                for (; k < K; k++) one(k);
+            }
+            for (; k < K; k++) {
                 const T rnk = Real<T>::rint(ns);
                 const T rhk = Real<T>::rint(half);
                 const T c_k = win[(int)(rnk - wb)];
