@@ -246,7 +246,7 @@ def main():
                          "alg_bytes": stages[dom]["alg_bytes"], "ms": stages[dom]["ms"],
                          "note": "achieved = algorithmic bytes / live HIP-event duration of the group's launch; this kernel "
                                  "walks exact sequential recurrences (one lane per block + warm-up replay), so it is bound by "
-                                 "dependent-instruction latency, not by HBM; traffic = FETCH_SIZE x2 + WRITE_SIZE per launch "
+                                 "instruction issue of its few wavefronts (19 vector instructions per step, DESIGN 4.2), not by HBM; traffic = FETCH_SIZE x2 + WRITE_SIZE per launch "
                                  "from profiles/r1 (warm-up replays re-read the stream)"},
             "streaming_kernels": {k: {"GBps": stages[k]["GBps"], "frac_hbm": stages[k]["frac_hbm"], "traffic": pmc_traffic(GROUP_KERNEL[k])}
                                   for k in hbm_bound if k in stages},
