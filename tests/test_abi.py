@@ -94,3 +94,33 @@ def test_cli_binaries_fail_without_gpu(gpu_available):
                            text=True)
         assert r.returncode == 1 and "GPU demodulator unavailable" in r.stdout
         assert not os.path.exists("/tmp/pdt_cli_test.txt")
+
+
+def test_hand_issued_lds_loads_are_the_only_users_of_m0(pdt, tmp_path):
+    """The AGC walkers issue their look-ahead ring by hand (ring_issue in csrc/pdt_kernels_front.h): `s_mov_b32 m0` +
+    `global_load_lds_dwordx4`, without telling the compiler that M0 is overwritten.  That is only sound while the compiler
+    keeps no value of its own in M0 inside those kernels: check the shipped code object."""
+    llvm = "/opt/rocm/lib/llvm/bin"
+    tools = [os.path.join(llvm, t) for t in ("llvm-objcopy", "clang-offload-bundler", "llvm-objdump")]
+    if not all(os.path.exists(t) for t in tools):
+        pytest.skip("ROCm LLVM tools not installed")
+    fat, co = str(tmp_path / "fat.bin"), str(tmp_path / "dev.co")
+    subprocess.run([tools[0], "--dump-section", f".hip_fatbin={fat}", pdt.LIBPDT_PATH], check=True)
+    subprocess.run([tools[1], "--type=o", "--unbundle", "--targets=hipv4-amdgcn-amd-amdhsa--gfx950", f"--input={fat}", f"--output={co}"],
+                   check=True, capture_output=True)
+    dis = subprocess.run([tools[2], "-d", co], check=True, capture_output=True, text=True).stdout
+    kernel, per_kernel = None, {}
+    for line in dis.splitlines():
+        m = re.match(r"^[0-9a-f]+ <(\S+)>:", line)
+        if m:
+            kernel = m.group(1)
+            continue
+        if "global_load_lds" in line:
+            per_kernel.setdefault(kernel, [0, 0])[0] += 1
+        if re.search(r"\bm0\b", line):
+            assert "s_mov_b32 m0," in line, f"{kernel}: unexpected use of m0: {line.strip()}"
+            per_kernel.setdefault(kernel, [0, 0])[1] += 1
+    assert per_kernel, "no hand-issued LDS loads found: is the ring still there?"
+    for k, (loads, movs) in per_kernel.items():
+        assert "k_agc_" in k, f"m0 / LDS-direct load in an unexpected kernel: {k}"
+        assert loads == movs and loads > 0, f"{k}: {loads} LDS-direct loads but {movs} writes of m0"
