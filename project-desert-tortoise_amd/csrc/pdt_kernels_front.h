@@ -552,20 +552,19 @@ __global__ void __launch_bounds__(128) k_pll_acquire_pipe(IqSrc pcm, const T *__
                     const T re = a_l * inv, im = b_l * inv;
                     u_l = P.lock_alpha * (re * t_real + im * t_imag);
                 }
+                // the serial part is the two EMAs only (a wavefront's pace is its instruction count); the sweep gate and
+                // the lock test of sample k are evaluated afterwards by lane k, which kept the EMA values of that sample
                 T av = avg, ls = locksig, av_l = 0, ls_l = 0;
-                unsigned ev_flip = 0, ev_lock = 0;
                 for (int k = 0; k < nb; k++) {
                     av = (T)((double)av * k_avg + (double)lane_get(t_l, k));
                     ls = (T)((double)ls * k_lock + (double)lane_get(u_l, k));
                     const bool me = lane == k;
                     ls_l = me ? ls : ls_l;
                     av_l = me ? av : av_l;
-                    const bool cond = av >= P.cond_lo && av <= P.cond_hi;
-                    ev_flip |= (cond != h) ? (1u << k) : 0u;
-                    ev_lock |= (ls > P.lock_thr) ? (1u << k) : 0u;
                 }
-                ev_flip = (unsigned)__builtin_amdgcn_readfirstlane((int)ev_flip);
-                ev_lock = (unsigned)__builtin_amdgcn_readfirstlane((int)ev_lock);
+                const bool cond_l = av_l >= P.cond_lo && av_l <= P.cond_hi;
+                const unsigned ev_flip = (unsigned)__ballot(lane < nb && cond_l != h);
+                const unsigned ev_lock = (unsigned)__ballot(lane < nb && ls_l > P.lock_thr);
                 const unsigned ev = ev_flip | ev_lock;
                 int done = nb;
                 if (ev) {
@@ -720,29 +719,57 @@ __device__ __forceinline__ void pll_phase_range(const T *__restrict__ theta, T *
     }
 }
 
+// NS consecutive IQ samples of one lane with 16-byte loads (4 PCM16 pairs / 2 float pairs per load; the address need only
+// be 4- resp. 8-byte aligned).  Same conversion as IqSample<float>::get.  A lane-per-block access touches one cache line
+// per lane whatever its width, so the wide form is a quarter (half) of the load instructions.
+template <int FMT, int NS>
+__device__ __forceinline__ void iq_block(const void *p, long long i, float (&a)[NS], float (&b)[NS])
+{
+    if (FMT == 0) {
+        struct __attribute__((packed, aligned(4))) Q { int v[4]; };
+#pragma unroll
+        for (int q = 0; q < NS / 4; q++) {
+            const Q w = *reinterpret_cast<const Q *>(reinterpret_cast<const int *>(p) + i + 4 * q);
+#pragma unroll
+            for (int e = 0; e < 4; e++) {
+                a[4 * q + e] = (float)(short)(w.v[e] & 0xffff) / 32768.0f;
+                b[4 * q + e] = (float)(short)(w.v[e] >> 16) / 32768.0f;
+            }
+        }
+    } else {
+        struct __attribute__((packed, aligned(8))) Q { float v[4]; };
+#pragma unroll
+        for (int q = 0; q < NS / 2; q++) {
+            const Q w = *reinterpret_cast<const Q *>(reinterpret_cast<const float2 *>(p) + i + 2 * q);
+            a[2 * q] = w.v[0]; b[2 * q] = w.v[1];
+            a[2 * q + 1] = w.v[2]; b[2 * q + 1] = w.v[3];
+        }
+    }
+}
+
 // Data-derived starting guess for a warm-up that begins at sample ws (any guess is legal --
 // exactness comes from the seam check -- but a PM signal has a second stable lock point pi
 // away from the carrier, and Doppler moves the carrier far from its value at lock, so the
 // guess must land in the right basin): frequency from the lag-L autocorrelation angle,
 // phase from the coherent sum of the de-rotated samples (the +-m modulation averages to
 // cos m > 0 along the carrier).
-template <typename T>
-__device__ __forceinline__ void pll_guess(IqSrc pcm, long long ws, long long n, int lag, T fallback_freq,
-                                          T &phase, T &freq)
+template <typename T, int FMT>
+__device__ __forceinline__ void pll_guess_fmt(IqSrc pcm, long long ws, long long n, int lag, T fallback_freq,
+                                              T &phase, T &freq)
 {
     const int K = 1024, KP = 96;
     float rr = 0, ri = 0;
     long long cnt = 0;
     if (ws + K + lag <= n) {
-        for (int k0 = 0; k0 < K; k0 += 8) {              // 16 independent loads in flight
-            float a0[8], b0[8], a1[8], b1[8];
+        // 32 samples and their lagged partners per trip, 16-byte loads, all of them in flight together: every trip exposes
+        // one memory latency (the sums keep their sample order, so the guess does not depend on the batch length)
+        constexpr int GB = 32;
+        for (int k0 = 0; k0 < K; k0 += GB) {
+            float a0[GB], b0[GB], a1[GB], b1[GB];
+            iq_block<FMT, GB>(pcm.p, ws + k0, a0, b0);
+            iq_block<FMT, GB>(pcm.p, ws + k0 + lag, a1, b1);
 #pragma unroll
-            for (int u = 0; u < 8; u++) {
-                IqSample<float>::get(pcm, ws + k0 + u, a0[u], b0[u]);
-                IqSample<float>::get(pcm, ws + k0 + u + lag, a1[u], b1[u]);
-            }
-#pragma unroll
-            for (int u = 0; u < 8; u++) {
+            for (int u = 0; u < GB; u++) {
                 rr += a1[u] * a0[u] + b1[u] * b0[u];      // x1 * conj(x0)
                 ri += b1[u] * a0[u] - a1[u] * b0[u];
             }
@@ -753,12 +780,12 @@ __device__ __forceinline__ void pll_guess(IqSrc pcm, long long ws, long long n, 
     if (cnt >= 64 && (rr != 0 || ri != 0)) f = atan2f(ri, rr) / (float)lag;
     float sr = 0, si = 0;
     if (ws + KP <= n) {
-        for (int k0 = 0; k0 < KP; k0 += 8) {
-            float a0[8], b0[8];
+        constexpr int PB = 32;
+        for (int k0 = 0; k0 < KP; k0 += PB) {
+            float a0[PB], b0[PB];
+            iq_block<FMT, PB>(pcm.p, ws + k0, a0, b0);
 #pragma unroll
-            for (int u = 0; u < 8; u++) IqSample<float>::get(pcm, ws + k0 + u, a0[u], b0[u]);
-#pragma unroll
-            for (int u = 0; u < 8; u++) {
+            for (int u = 0; u < PB; u++) {
                 float sn, cs;
                 __sincosf(f * (float)(k0 + u), &sn, &cs);
                 sr += a0[u] * cs + b0[u] * sn;            // x * e^{-j f k}
@@ -772,6 +799,13 @@ __device__ __forceinline__ void pll_guess(IqSrc pcm, long long ws, long long n, 
     if (f < 0 && ph > 0) ph -= 6.28318530718f;
     phase = (T)ph;
     freq = (T)f;
+}
+
+template <typename T>
+__device__ __forceinline__ void pll_guess(IqSrc pcm, long long ws, long long n, int lag, T fallback_freq, T &phase, T &freq)
+{
+    if (pcm.fmt == 0) pll_guess_fmt<T, 0>(pcm, ws, n, lag, fallback_freq, phase, freq);
+    else pll_guess_fmt<T, 1>(pcm, ws, n, lag, fallback_freq, phase, freq);
 }
 
 // Blocks are aligned to absolute multiples of B: block j covers [j*B, min(n, (j+1)*B)).
@@ -816,14 +850,29 @@ __global__ void __launch_bounds__(64) k_pll_phase(IqSrc pcm, const T *__restrict
     const long long vote0 = (w_acq > 160) ? a1 - 128 : a1;
     pll_phase_range<T, false, SLOW>(theta, phi, a0, vote0, phase, freq, P.alpha_acq, P.beta_acq, P.max_freq, P.min_freq);
     int far = 0, seen = 0;
-    for (long long i = vote0; i < a1; i++) {
-        const T th = theta[i];
-        T d = th - phase;
-        if (d > (T)PDT_PI) d -= (T)(2 * PDT_PI);
-        if (d < (T)-PDT_PI) d += (T)(2 * PDT_PI);
-        far += (Real<T>::abs(d) > (T)(PDT_PI / 2)) ? 1 : 0;
-        seen++;
-        pll_phase_step<T, SLOW>(th, phase, freq, P.alpha_acq, P.beta_acq, P.max_freq, P.min_freq);
+    {
+        auto vote = [&](T th) {
+            T d = th - phase;
+            if (d > (T)PDT_PI) d -= (T)(2 * PDT_PI);
+            if (d < (T)-PDT_PI) d += (T)(2 * PDT_PI);
+            far += (Real<T>::abs(d) > (T)(PDT_PI / 2)) ? 1 : 0;
+            seen++;
+            pll_phase_step<T, SLOW>(th, phase, freq, P.alpha_acq, P.beta_acq, P.max_freq, P.min_freq);
+        };
+        // 32 samples per trip (one exposed memory latency each) instead of one
+        constexpr int VN = Vec16<T>::N, VB = 32 / VN;
+        long long i = vote0;
+        for (; i < a1 && (i % VN) != 0; i++) vote(theta[i]);
+        for (; i + 32 <= a1; i += 32) {
+            Vec16<T> tv[VB];
+#pragma unroll
+            for (int u = 0; u < VB; u++) tv[u] = *reinterpret_cast<const Vec16<T> *>(theta + i + u * VN);
+#pragma unroll
+            for (int u = 0; u < VB; u++)
+#pragma unroll
+                for (int w = 0; w < VN; w++) vote(tv[u].v[w]);
+        }
+        for (; i < a1; i++) vote(theta[i]);
     }
     if (2 * far > seen) {
         phase = (phase > 0) ? phase - (T)PDT_PI : phase + (T)PDT_PI;     // stays inside (-2pi, 2pi)
