@@ -489,6 +489,8 @@ __global__ void __launch_bounds__(128) k_pll_acquire_pipe(IqSrc pcm, const T *__
     long long i_prod = 0;              // next sample the loop filter will take
     long long i_pre = -1;              // start of the batch th_pre was loaded for
     T th_pre = 0;
+    long long iq_pre = -1;             // (wavefront 1) start of the batch a_pre / b_pre were loaded for
+    T a_pre = 0, b_pre = 0;
     long long lock_at = -1;
     T freq_at_lock = 0, avg_at_lock = P.avg0;
     T fin_phase = P.phase0, fin_freq = 0, fin_sweep = P.sweep0;      // loop-filter state at the end (kept by wavefront 1)
@@ -537,9 +539,17 @@ __global__ void __launch_bounds__(128) k_pll_acquire_pipe(IqSrc pcm, const T *__
                 const int nb = theirs.nb;
                 const bool h = theirs.hyp != 0;
                 T t_l = 0, u_l = 0, o_l = 0;
+                // the IQ samples of this batch were requested one batch ago (unless an event moved the start); those of
+                // the batch wavefront 0 is filtering now are requested here
+                T a_l = a_pre, b_l = b_pre;
+                if (iq_pre != i0 && lane < nb) IqSample<T>::get(pcm, i0 + lane, a_l, b_l);
+                iq_pre = -1;
+                if (produce) {
+                    iq_pre = i_prod;
+                    if (lane < PDT_ACQ_NB && i_prod + lane < n) IqSample<T>::get(pcm, i_prod + lane, a_pre, b_pre);
+                }
                 if (lane < nb) {
-                    T a_l, b_l, t_real, t_imag;
-                    IqSample<T>::get(pcm, i0 + lane, a_l, b_l);
+                    T t_real, t_imag;
                     Real<T>::sincos(theirs.phi[lane], t_imag, t_real);
                     const T c = t_real, d = -t_imag;
                     const T o_re = a_l * c - b_l * d;
