@@ -459,8 +459,11 @@ __global__ void __launch_bounds__(64) k_pll_acquire_fast(IqSrc pcm, const T *__r
 // the detectors of batch t-1 from the per-sample states wavefront 0 left in LDS.  When wavefront 1
 // reports an event inside batch t-1, the speculative batch t is dropped and wavefront 0 resumes from
 // the corrected state after the event sample.  Same arithmetic per sample, half the time per batch.
+#ifndef PDT_ACQP_NB
+#define PDT_ACQP_NB 64      // samples per batch of the two-wavefront pipeline (one per lane)
+#endif
 template <typename T> struct AcqSlot {
-    T phi[PDT_ACQ_NB], phn[PDT_ACQ_NB], fpre[PDT_ACQ_NB], swb[PDT_ACQ_NB];
+    T phi[PDT_ACQP_NB], phn[PDT_ACQP_NB], fpre[PDT_ACQP_NB], swb[PDT_ACQP_NB];
     long long i0;
     int nb, valid, hyp;
     T ph_end, fr_end, sw_end;         // loop-filter state after the whole batch under the hypothesis
@@ -506,12 +509,12 @@ __global__ void __launch_bounds__(128) k_pll_acquire_pipe(IqSrc pcm, const T *__
         if (wave == 0) {
             // ---- loop filter of the batch starting at i_prod
             if (produce) {
-                const int nb = (int)((n - i_prod < PDT_ACQ_NB) ? (n - i_prod) : PDT_ACQ_NB);
+                const int nb = (int)((n - i_prod < PDT_ACQP_NB) ? (n - i_prod) : PDT_ACQP_NB);
                 // theta of this batch was requested one batch ago (unless an event moved the start)
                 T th_l = th_pre;
                 if (i_pre != i_prod) th_l = (lane < nb) ? theta[i_prod + lane] : (T)0;
                 i_pre = i_prod + nb;
-                if (lane < PDT_ACQ_NB && i_pre + lane < n) th_pre = theta[i_pre + lane];
+                if (lane < PDT_ACQP_NB && i_pre + lane < n) th_pre = theta[i_pre + lane];
                 T ph = phase, fr = freq, sw = sweep;
                 T phi_l = 0, phn_l = 0, fpre_l = 0, swb_l = 0;
                 for (int k = 0; k < nb; k++) {
@@ -546,7 +549,7 @@ __global__ void __launch_bounds__(128) k_pll_acquire_pipe(IqSrc pcm, const T *__
                 iq_pre = -1;
                 if (produce) {
                     iq_pre = i_prod;
-                    if (lane < PDT_ACQ_NB && i_prod + lane < n) IqSample<T>::get(pcm, i_prod + lane, a_pre, b_pre);
+                    if (lane < PDT_ACQP_NB && i_prod + lane < n) IqSample<T>::get(pcm, i_prod + lane, a_pre, b_pre);
                 }
                 if (lane < nb) {
                     T t_real, t_imag;
@@ -573,26 +576,26 @@ __global__ void __launch_bounds__(128) k_pll_acquire_pipe(IqSrc pcm, const T *__
                     av_l = me ? av : av_l;
                 }
                 const bool cond_l = av_l >= P.cond_lo && av_l <= P.cond_hi;
-                const unsigned ev_flip = (unsigned)__ballot(lane < nb && cond_l != h);
-                const unsigned ev_lock = (unsigned)__ballot(lane < nb && ls_l > P.lock_thr);
-                const unsigned ev = ev_flip | ev_lock;
+                const unsigned long long ev_flip = __ballot(lane < nb && cond_l != h);
+                const unsigned long long ev_lock = __ballot(lane < nb && ls_l > P.lock_thr);
+                const unsigned long long ev = ev_flip | ev_lock;
                 int done = nb;
                 if (ev) {
-                    const int k = __builtin_ctz(ev);
-                    const bool cond = ((ev_flip >> k) & 1u) ? !h : h;
+                    const int k = __builtin_ctzll(ev);
+                    const bool cond = ((ev_flip >> k) & 1ull) ? !h : h;
                     T fr = theirs.fpre[k], sw = theirs.swb[k];
                     if (cond) pll_sweep_step(fr, sw, P.max_freq, P.min_freq);
                     done = k + 1;
                     avg = lane_get(av_l, k);
                     locksig = lane_get(ls_l, k);
                     fin_phase = theirs.phn[k]; fin_freq = fr; fin_sweep = sw;
-                    if ((ev_lock >> k) & 1u) {
+                    if ((ev_lock >> k) & 1ull) {
                         lock_at = i0 + k;
                         freq_at_lock = fr;
                         avg_at_lock = avg;
                     }
                     if (lane == 0) {
-                        verdict.event = 1; verdict.k = k; verdict.hyp = cond ? 1 : 0; verdict.locked = (int)((ev_lock >> k) & 1u);
+                        verdict.event = 1; verdict.k = k; verdict.hyp = cond ? 1 : 0; verdict.locked = (int)((ev_lock >> k) & 1ull);
                         verdict.phase = fin_phase; verdict.freq = fr; verdict.sweep = sw;
                     }
                 } else {
