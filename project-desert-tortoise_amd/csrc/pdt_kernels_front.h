@@ -517,7 +517,8 @@ __global__ void __launch_bounds__(128) k_pll_acquire_pipe(IqSrc pcm, const T *__
                 if (lane < PDT_ACQP_NB && i_pre + lane < n) th_pre = theta[i_pre + lane];
                 T ph = phase, fr = freq, sw = sweep;
                 T phi_l = 0, phn_l = 0, fpre_l = 0, swb_l = 0;
-                for (int k = 0; k < nb; k++) {
+                // (four samples per trip: a taken branch costs a lone wavefront as much as nine instructions)
+                auto filt = [&](int k) {
                     const T th = lane_get(th_l, k);
                     const bool me = lane == k;
                     phi_l = me ? ph : phi_l;
@@ -526,7 +527,10 @@ __global__ void __launch_bounds__(128) k_pll_acquire_pipe(IqSrc pcm, const T *__
                     fpre_l = me ? fr : fpre_l;
                     swb_l = me ? sw : swb_l;
                     pll_sweep_sel(fr, sw, P.max_freq, P.min_freq, hyp);
-                }
+                };
+                int k = 0;
+                for (; k + 4 <= nb; k += 4) { filt(k); filt(k + 1); filt(k + 2); filt(k + 3); }
+                for (; k < nb; k++) filt(k);
                 if (lane < nb) { mine.phi[lane] = phi_l; mine.phn[lane] = phn_l; mine.fpre[lane] = fpre_l; mine.swb[lane] = swb_l; }
                 if (lane == 0) {
                     mine.i0 = i_prod; mine.nb = nb; mine.hyp = hyp ? 1 : 0; mine.valid = 1;
@@ -568,13 +572,16 @@ __global__ void __launch_bounds__(128) k_pll_acquire_pipe(IqSrc pcm, const T *__
                 // the serial part is the two EMAs only (a wavefront's pace is its instruction count); the sweep gate and
                 // the lock test of sample k are evaluated afterwards by lane k, which kept the EMA values of that sample
                 T av = avg, ls = locksig, av_l = 0, ls_l = 0;
-                for (int k = 0; k < nb; k++) {
+                auto ema = [&](int k) {
                     av = (T)((double)av * k_avg + (double)lane_get(t_l, k));
                     ls = (T)((double)ls * k_lock + (double)lane_get(u_l, k));
                     const bool me = lane == k;
                     ls_l = me ? ls : ls_l;
                     av_l = me ? av : av_l;
-                }
+                };
+                int k = 0;
+                for (; k + 4 <= nb; k += 4) { ema(k); ema(k + 1); ema(k + 2); ema(k + 3); }
+                for (; k < nb; k++) ema(k);
                 const bool cond_l = av_l >= P.cond_lo && av_l <= P.cond_hi;
                 const unsigned long long ev_flip = __ballot(lane < nb && cond_l != h);
                 const unsigned long long ev_lock = __ballot(lane < nb && ls_l > P.lock_thr);
