@@ -722,7 +722,11 @@ template <typename T> int run_capture(pdt_ctx *ctx, uint64_t n, int phase = RUN_
                 }
             }
             L.end();
-            const int G = 32;                                                  // chunks per chain segment
+            // chunks per chain segment: the chain hops one segment per ~1 us of dependent L2 look-ups, the composite maps and
+            // the re-trace of a segment take G such look-ups each but run in parallel over the segments
+            // (at most 64: k_gardner_segfill re-traces a segment with one lane per chunk)
+            int G = (n_chunks < 8000) ? 32 : 64;
+            if (const char *e = getenv("PDT_GSEG")) G = std::min(64, std::max(2, atoi(e)));   // tuning experiments
             const long long n_seg = (n_chunks + G - 1) / G;
             if ((rc = ctx->gsegmap.ensure((size_t)n_seg * (size_t)(2 * GD.n_q) * sizeof(GardnerSegCell)))) return rc;
             if ((rc = ctx->gsegstart.ensure((size_t)n_seg * sizeof(GardnerSegStart)))) return rc;
