@@ -76,3 +76,47 @@ def test_unwrap_f32_exhaustive():
         refn = (xn.astype(np.float64) + two_pi).astype(np.float32)
         emun = (xn + hi) - d
         assert np.array_equal(refn.view(np.uint32), emun.view(np.uint32))
+
+
+def test_agc_calm_batch_needs_no_conditional():
+    """The GPU's AGC walkers replace the exact step (AGC.c:98-131: rate select, two range clamps) by
+    gain -= (|x*gain| - 1) * decay over 16-sample batches that pass agc_calm (csrc/pdt_kernels_front.h): every |x| <= 1,
+    gain in [2.5, 4000] at the start of the batch, decay <= 0.04.  DESIGN 4 gives the argument; this replays both
+    forms in float32 on 400 000 random calm batches (edge values included) and demands identical bits, and that no
+    conditional of the exact step ever acts."""
+    rng = np.random.default_rng(7)
+    nb = 400_000
+    f32 = np.float32
+    gain = np.exp(rng.uniform(np.log(2.5), np.log(4000.0), nb)).astype(f32)
+    gain[:2000] = f32(2.5)
+    gain[2000:4000] = f32(4000.0)
+    decay = np.exp(rng.uniform(np.log(1e-5), np.log(0.04), nb)).astype(f32)
+    decay[:1000] = f32(0.04)
+    attack = (decay * f32(0.5)).astype(f32)
+    x = rng.uniform(-1.0, 1.0, (16, nb)).astype(f32)
+    x[:, 4000:6000] = f32(1.0)
+    x[:, 6000:8000] = f32(-1.0)
+    x[:, 8000:9000] = f32(0.0)
+    x[rng.integers(0, 16, 5000), rng.integers(0, nb, 5000)] = f32(1.0)
+    g_exact, g_calm = gain.copy(), gain.copy()
+    acted = np.zeros(nb, dtype=bool)
+    for i in range(16):
+        # exact step (float32 at every operation, as the reference compiled for floats)
+        y = (x[i] * g_exact).astype(f32)
+        err = (np.abs(y) - f32(1.0)).astype(f32)
+        att = np.abs(err) > g_exact
+        rate = np.where(att, attack, decay).astype(f32)
+        g = (g_exact - (err * rate).astype(f32)).astype(f32)
+        low, high = g < f32(0), g > f32(5000)
+        acted |= att | low | high
+        g = np.where(low, f32(10e-5), g)
+        g = np.where(high, f32(5000), g).astype(f32)
+        g_exact = g
+        # calm step
+        yc = (x[i] * g_calm).astype(f32)
+        ec = (np.abs(yc) - f32(1.0)).astype(f32)
+        g_calm = (g_calm - (ec * decay).astype(f32)).astype(f32)
+        assert yc.tobytes() == y.tobytes()
+    assert not acted.any()
+    assert g_calm.tobytes() == g_exact.tobytes()
+    assert g_exact.min() >= 1.3 and g_exact.max() <= 4001.0          # the bounds the argument uses
