@@ -81,6 +81,8 @@ enum {
     PDT_ST_SYMIDX,      /* global interpolated-sample index each symbol was taken at, int64    */
     PDT_ST_BITS,        /* Manchester bits, '0'/'1'                  uint8 per bit              */
     PDT_ST_BITSYM,      /* global symbol index each bit's time stamp comes from, uint32         */
+    PDT_ST_AGC_RAW,     /* NormalizingAGC output BEFORE Squelch (only after pdt_keep_presquelch): what ARGOSdemod -r
+                           writes to output.raw (ARGOSdemod/main.c:273-274); equal to PDT_ST_AGC for POES     */
     PDT_ST_COUNT
 };
 
@@ -162,6 +164,9 @@ void pdt_close(pdt_ctx *ctx);
 
 /* Use an existing HIP stream (hipStream_t passed as void*) for all work; NULL = own stream. */
 int  pdt_set_stream(pdt_ctx *ctx, void *hip_stream);
+/* Also keep the AGC output before Squelch (stage PDT_ST_AGC_RAW) in the following pdt_demod_* calls: the stream the
+ * reference's `-r` option dumps (ARGOSdemod/main.c:171-180,273-274).  Costs one more stream-sized buffer.            */
+int  pdt_keep_presquelch(pdt_ctx *ctx, int enable);
 
 /* Demodulate one whole capture: nframes interleaved little-endian int16 I,Q pairs
  * in host memory (copied to the GPU) ...                                                        */

@@ -182,7 +182,7 @@ int main(int argc, char **argv)
     FILE *dpll = dopen(dump, "pll"), *dfir = dopen(dump, "fir"), *dagc = dopen(dump, "agc"),
          *dsym = dopen(dump, "sym"), *dsymt = dopen(dump, "symt"), *dbits = dopen(dump, "bits"),
          *dbitt = dopen(dump, "bitt"), *dcnt = dopen(dump, "counts"), *dlock = dopen(dump, "lock"),
-         *dtaps = dopen(dump, "taps"), *diq = dopen(dump, "iq"), *dtime = dopen(dump, "time");
+         *dtaps = dopen(dump, "taps"), *diq = dopen(dump, "iq"), *dtime = dopen(dump, "time"), *dagcraw = dopen(dump, "agcraw");
     dput(dtaps, filterCoeffs, sizeof(DT), N);
 
     unsigned long i = 0, nSamples, nSymbols, nBits, totalFrames = 0;
@@ -205,6 +205,7 @@ int main(int argc, char **argv)
         LowPassFilter(dataStreamReal, nSamples, filterCoeffs, 50);
         dput(dfir, dataStreamReal, sizeof(DT), nSamples);
         NormalizingAGC(dataStreamReal, nSamples, normFactor, (79.5775) * (2.0 * M_PI / Fs), (159.1549) * (2.0 * M_PI / Fs));
+        dput(dagcraw, dataStreamReal, sizeof(DT), nSamples);    /* what -r writes to output.raw (ARGOSdemod/main.c:273-274) */
         Squelch(dataStreamReal, lockSignalStream, nSamples, (0.15));
         dput(dagc, dataStreamReal, sizeof(DT), nSamples);
         if (use_mm)

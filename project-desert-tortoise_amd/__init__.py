@@ -30,7 +30,7 @@ LIBSYNTH_PATH = os.path.join(_HERE, "synth", "libpdtsynth.so")
 MODE_POES, MODE_ARGOS = 0, 1
 SAMPLER_GARDNER, SAMPLER_MM = 0, 1
 CHAIN_FILE, CHAIN_LIVE = 0, 1          # CHAIN_LIVE: the sound-card twin's constants and stage order (POES)
-ST_PLL, ST_LOCK, ST_FIR, ST_AGC, ST_SYM, ST_SYMIDX, ST_BITS, ST_BITSYM = range(8)
+ST_PLL, ST_LOCK, ST_FIR, ST_AGC, ST_SYM, ST_SYMIDX, ST_BITS, ST_BITSYM, ST_AGC_RAW = range(9)
 
 
 class PdtError(RuntimeError):
@@ -117,6 +117,7 @@ ABI_SYMBOLS = [
     "pdt_format_frames", "pdt_read_stage", "pdt_stage_len", "pdt_kernel_times", "pdt_make_lpf",
     "pdt_wav_parse_header", "pdt_time_axis", "pdt_stage_bytesync", "pdt_tip_check", "pdt_tip_frames",
     "pdt_stream_begin", "pdt_stream_push_pcm16", "pdt_stream_push_f32", "pdt_stream_end", "pdt_stream_frames",
+    "pdt_keep_presquelch",
 ]
 
 _lib = None
@@ -243,6 +244,11 @@ class Demodulator:
 
     def __exit__(self, *a):
         self.close()
+
+    def keep_presquelch(self, enable: bool = True):
+        """Also keep the AGC output before Squelch (stage ST_AGC_RAW): what the reference's -r option dumps."""
+        _check(self._L.pdt_keep_presquelch(self._h, int(enable)), "pdt_keep_presquelch")
+        return self
 
     def set_stream(self, stream_handle: int):
         _check(self._L.pdt_set_stream(self._h, C.c_void_p(stream_handle)), "pdt_set_stream")

@@ -86,7 +86,8 @@ struct pdt_ctx {
     hipEvent_t ev0 = nullptr, ev1 = nullptr, ev_fork = nullptr, ev_join = nullptr;
     hipStream_t stream2 = nullptr;     // side stream: block-parallel PLL phase runs beside the sequential acquisition
 
-    DevBuf pcm, pll, lock, fir, agc, sym, symidx, bits, bitsym, hits, frames, taps, mag, seams_pll, seams_agc, scal, lockinfo, term, seams_ema, gtable, gentries, gcand, gmfirst, stiles, gsegmap, gsegstart, gbands, gclist, agc_maps, pll_head, taps_rot, pll_scratch, tip, sync_scr;
+    DevBuf pcm, pll, lock, fir, agc, sym, symidx, bits, bitsym, hits, frames, taps, mag, seams_pll, seams_agc, scal, lockinfo, term, seams_ema, gtable, gentries, gcand, gmfirst, stiles, gsegmap, gsegstart, gbands, gclist, agc_maps, pll_head, taps_rot, pll_scratch, tip, sync_scr, agc_raw;
+    bool keep_agc_raw = false;   // pdt_keep_presquelch: also keep the AGC output before Squelch (stage PDT_ST_AGC_RAW)
     // (stream_in is declared with the streaming state below)
     long long gcand_key = -1;          // (chunk_out, step) the candidate list on the device was built for
     bool force_sequential_gardner = false;
@@ -325,6 +326,7 @@ template <typename T> int run_capture(pdt_ctx *ctx, uint64_t n, int phase = RUN_
     AP.decay = (T)(159.1549 * (2.0 * M_PI / (double)fsi));
     AP.squelch = argos ? 1 : 0;
     AP.squelch_thr = (T)0.15;                                                  // ARGOSdemod/main.c:46,276
+    AP.raw_out = nullptr;
     GardnerParams<T> GP;
     const T baud = argos ? (T)(400 * 2.0) : (T)(8320 * 2 + 0.3);              // main.c:90 / ARGOS main.c:64
     GP.step = (T)(int)fsi / baud;                                              // GardenerClockRecovery.c:19
@@ -408,6 +410,8 @@ template <typename T> int run_capture(pdt_ctx *ctx, uint64_t n, int phase = RUN_
     if (need_lock && (rc = ctx->lock.ensure((size_t)(N + 1) * sizeof(T)))) return rc;
     if ((rc = ctx->fir.ensure((size_t)(n_out + 1) * sizeof(T)))) return rc;
     if ((rc = ctx->agc.ensure((size_t)(n_out + 1) * sizeof(T)))) return rc;
+    if (ctx->keep_agc_raw && (rc = ctx->agc_raw.ensure((size_t)(n_out + 1) * sizeof(T)))) return rc;
+    if (ctx->keep_agc_raw) AP.raw_out = (T *)ctx->agc_raw.p;
     if ((rc = ctx->sym.ensure((size_t)sym_cap * sizeof(T)))) return rc;
     if ((rc = ctx->symidx.ensure((size_t)sym_cap * sizeof(long long)))) return rc;
     if ((rc = ctx->bits.ensure((size_t)bit_cap))) return rc;
@@ -870,6 +874,7 @@ template <typename T> int run_capture(pdt_ctx *ctx, uint64_t n, int phase = RUN_
     ctx->stage_len[PDT_ST_LOCK] = need_lock ? n : 0;
     ctx->stage_len[PDT_ST_FIR] = (uint64_t)n_out;
     ctx->stage_len[PDT_ST_AGC] = (uint64_t)n_out;
+    ctx->stage_len[PDT_ST_AGC_RAW] = ctx->keep_agc_raw ? (uint64_t)n_out : 0;
     ctx->stage_len[PDT_ST_SYM] = sc.nsym;
     ctx->stage_len[PDT_ST_SYMIDX] = sc.nsym;
     ctx->stage_len[PDT_ST_BITS] = sc.nbits;
@@ -1085,7 +1090,7 @@ void pdt_close(pdt_ctx *ctx)
     DevBuf *bufs[] = { &ctx->pcm, &ctx->pll, &ctx->lock, &ctx->fir, &ctx->agc, &ctx->sym, &ctx->symidx, &ctx->bits, &ctx->bitsym,
                        &ctx->hits, &ctx->frames, &ctx->taps, &ctx->mag, &ctx->seams_pll, &ctx->seams_agc, &ctx->scal, &ctx->lockinfo,
                        &ctx->term, &ctx->seams_ema, &ctx->gtable, &ctx->gentries, &ctx->gcand,
-                       &ctx->gmfirst, &ctx->stiles, &ctx->gsegmap, &ctx->gsegstart, &ctx->gbands, &ctx->gclist, &ctx->agc_maps, &ctx->pll_head, &ctx->taps_rot, &ctx->pll_scratch, &ctx->tip, &ctx->stream_in, &ctx->sync_scr };
+                       &ctx->gmfirst, &ctx->stiles, &ctx->gsegmap, &ctx->gsegstart, &ctx->gbands, &ctx->gclist, &ctx->agc_maps, &ctx->pll_head, &ctx->taps_rot, &ctx->pll_scratch, &ctx->tip, &ctx->stream_in, &ctx->sync_scr, &ctx->agc_raw };
     for (DevBuf *b : bufs) b->release();
     for (hipEvent_t e : ctx->event_pool) (void)hipEventDestroy(e);
     if (ctx->pinned) (void)hipHostFree(ctx->pinned);
@@ -1110,6 +1115,14 @@ int pdt_set_stream(pdt_ctx *ctx, void *hip_stream)
         if (hipStreamCreate(&ctx->stream) != hipSuccess) return PDT_ERR_NOGPU;
         ctx->own_stream = true;
     }
+    return PDT_OK;
+}
+
+int pdt_keep_presquelch(pdt_ctx *ctx, int enable)
+{
+    if (!ctx) return PDT_ERR_ARG;
+    ctx->keep_agc_raw = enable != 0;
+    if (!enable) ctx->stage_len[PDT_ST_AGC_RAW] = 0;
     return PDT_OK;
 }
 
@@ -1472,6 +1485,7 @@ int64_t pdt_read_stage(const pdt_ctx *ctx, int stage, uint64_t first, uint64_t c
     case PDT_ST_LOCK: src = ctx->lock.p; break;
     case PDT_ST_FIR: src = ctx->fir.p; break;
     case PDT_ST_AGC: src = ctx->agc.p; break;
+    case PDT_ST_AGC_RAW: src = ctx->agc_raw.p; break;
     case PDT_ST_SYM: src = ctx->sym.p; break;
     case PDT_ST_SYMIDX: src = ctx->symidx.p; es = 8; break;
     case PDT_ST_BITS: src = ctx->bits.p; es = 1; break;

@@ -1559,7 +1559,12 @@ __global__ void __launch_bounds__(256) k_static_gain(IqSrc pcm, long long n0, T 
 // ------------------------------------------------------------------------------------------
 // NormalizingAGC (+Squelch) (reference: common/AGC.c:78-132, :24-46)
 // ------------------------------------------------------------------------------------------
-template <typename T> struct AgcParams { T attack, decay; T squelch_thr; int squelch; };
+template <typename T> struct AgcParams {
+    T attack, decay;
+    T squelch_thr;
+    int squelch;
+    T *raw_out;      // optional: the AGC output before Squelch (what ARGOSdemod -r dumps, main.c:273-274); nullptr = not kept
+};
 
 template <typename T> __device__ __forceinline__ T agc_step(T x, T &gain, const AgcParams<T> &P)
 {
@@ -1625,6 +1630,7 @@ __device__ __forceinline__ void agc_range(const T *__restrict__ in, const T *__r
     for (; i < i1 && (i % VN) != 0; i++) {
         T y = agc_step(in[i], gain, P);
         if (STORE) {
+            if (P.raw_out) P.raw_out[i] = y;
             if (P.squelch && lock[i] < P.squelch_thr) y = 0;
             out[i] = y;
         }
@@ -1663,6 +1669,7 @@ __device__ __forceinline__ void agc_range(const T *__restrict__ in, const T *__r
 #pragma unroll
             for (int k = 0; k < NB; k++) {
                 if (STORE) {
+                    if (P.raw_out) *reinterpret_cast<Vec16<T> *>(P.raw_out + i + k * VN) = yv[k];
                     if (P.squelch) {
                         const Vec16<T> lv = *reinterpret_cast<const Vec16<T> *>(lock + i + k * VN);
 #pragma unroll
@@ -1684,6 +1691,7 @@ __device__ __forceinline__ void agc_range(const T *__restrict__ in, const T *__r
 #pragma unroll
         for (int w = 0; w < VN; w++) yv.v[w] = agc_step(xv.v[w], gain, P);
         if (STORE) {
+            if (P.raw_out) *reinterpret_cast<Vec16<T> *>(P.raw_out + i) = yv;
             if (P.squelch) {
                 const Vec16<T> lv = *reinterpret_cast<const Vec16<T> *>(lock + i);
 #pragma unroll
@@ -1696,6 +1704,7 @@ __device__ __forceinline__ void agc_range(const T *__restrict__ in, const T *__r
     for (; i < i1; i++) {
         T y = agc_step(in[i], gain, P);
         if (STORE) {
+            if (P.raw_out) P.raw_out[i] = y;
             if (P.squelch && lock[i] < P.squelch_thr) y = 0;
             out[i] = y;
         }

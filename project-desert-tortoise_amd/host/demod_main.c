@@ -10,7 +10,8 @@
  *   options -s <kHz> -r -n <gain> -c <chunk>           POESTIPdemod/main.c:185-234
  *           -r -n -c                                   ARGOSdemod/main.c:121-164
  *   -s with a WAV overrides the rate with the kHz number taken as Hz (Q6)   main.c:343-344
- *   -r opens/creates an empty output.raw (all writes are commented out)     main.c:299-307
+ *   -r POES: opens/creates an empty output.raw (all writes are commented out)   main.c:299-307
+ *      ARGOS: output.raw receives the AGC output before Squelch (doubles)      ARGOSdemod/main.c:171-180,273-274
  *   44-byte canonical header, no chunk walk            common/wave.c:303-378
  *   every byte after the header is sample data (while(!feof))               main.c:373
  *   output name minorFrames_YYYYMMDD_HHMMSS.txt / packets_YYYYMMDD_HHMMSS.txt   main.c:289 / ARGOS main.c:213
@@ -316,6 +317,9 @@ int main(int argc, char **argv)
         remove(outFileName);
         exit(1);
     }
+#ifdef PDT_ARGOS
+    if (outputRawFiles) pdt_keep_presquelch(ctx, 1);                 /* -r: the AGC output before Squelch, ARGOSdemod/main.c:273-274 */
+#endif
     rc = is_raw ? pdt_demod_f32(ctx, (const float *)samples, nframes) : pdt_demod_pcm16(ctx, (const int16_t *)samples, nframes);
     if (rc != PDT_OK) {
         printf("Demodulation failed: %s\n", pdt_strerror(rc));
@@ -323,6 +327,25 @@ int main(int argc, char **argv)
         remove(outFileName);
         exit(1);
     }
+#ifdef PDT_ARGOS
+    if (rc == PDT_OK && outputRawFiles) {
+        /* ARGOSdemod -r: every chunk's post-AGC, pre-Squelch doubles, appended to output.raw (main.c:171-180,273-274) */
+        FILE *raw = fopen("output.raw", "wb");
+        const uint64_t total = pdt_stage_len(ctx, PDT_ST_AGC_RAW), piece = 1u << 20;
+        double *tmp = (double *)malloc((size_t)piece * sizeof(double));
+        if (!raw || !tmp) {
+            printf("Error opening output file\n");
+            exit(1);
+        }
+        for (uint64_t at = 0; at < total; at += piece) {
+            const int64_t got = pdt_read_stage(ctx, PDT_ST_AGC_RAW, at, piece, tmp);
+            if (got <= 0) break;
+            fwrite(tmp, sizeof(double), (size_t)got, raw);
+        }
+        fclose(raw);
+        free(tmp);
+    }
+#endif
     pdt_stats st;
     pdt_get_stats(ctx, &st);
     if (normFactor == 0) printf("Normalization Factor: %f\n", st.norm_factor);

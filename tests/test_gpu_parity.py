@@ -182,6 +182,31 @@ def test_cli_demodargos(pdt, tmp_path, golden):
     assert golden_text("argos_32000.txt").decode() in r.stdout          # packets are mirrored to stdout (ARGOSdemod/ByteSync.c)
 
 
+@pytest.mark.parametrize("chunk,kw", [(0, {}), (1000, {}), (0, dict(agc_block=256, agc_warm=256))])
+def test_argos_presquelch_stream_and_cli_raw_dump(pdt, orc, tmp_path, chunk, kw):
+    """ARGOSdemod -r (main.c:171-180,273-274): output.raw receives the AGC output BEFORE Squelch, chunk after chunk.
+    The stream is kept on request (pdt_keep_presquelch, stage ST_AGC_RAW) and must equal the oracle's, which
+    tests/test_oracle_ref.py compares with the reference's own objects; the host program writes it with -r."""
+    iq = pdt.synth_capture(1, 32000, 10.0, f0_hz=150.0, seed=77)
+    o = orc.Oracle(orc.ARGOS, 32000, iq, chunk=chunk, math_mode=orc.MATH_PORTABLE)
+    want = o.stage(orc.ST_AGC_RAW)
+    assert len(want) == len(iq) and (want != o.stage(orc.ST_AGC)).any()          # the squelch does act on this capture
+    with pdt.Demodulator(pdt.MODE_ARGOS, 32000, chunk=chunk, **kw) as d:
+        d.demod(iq)
+        assert d.stage(pdt.ST_AGC_RAW).size == 0                                  # not kept unless asked for
+        d.keep_presquelch().demod(iq)
+        assert d.stage(pdt.ST_AGC_RAW).tobytes() == want.tobytes()
+        check_all_stages(pdt, orc, d, o)
+    if chunk == 0 and not kw:
+        wav = tmp_path / "a.wav"
+        pdt.write_wav(str(wav), 32000, iq)
+        r = subprocess.run([os.path.join(ROOT, "bin", "demodARGOS"), "-r", "-o", str(tmp_path / "p.txt"), str(wav)], capture_output=True,
+                           text=True, cwd=str(tmp_path))
+        assert r.returncode == 0, r.stdout + r.stderr
+        assert (tmp_path / "output.raw").read_bytes() == want.tobytes()
+        assert (tmp_path / "p.txt").read_bytes() == o.text()
+
+
 @pytest.mark.parametrize("scale", [1.0, 37.5, 0.004])
 def test_raw_float32_input(pdt, orc, tmp_path, scale):
     """RAW float32 captures (pdt_demod_f32): bit-exact vs the oracle's RAW path, through the CLI too."""
