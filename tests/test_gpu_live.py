@@ -83,3 +83,18 @@ def test_cli_live_loop_from_a_pipe_and_from_a_file(pdt, orc, tmp_path):
     r = subprocess.run([exe, "-l", "-s", "48", "-o", str(out2), str(path)], capture_output=True)
     assert r.returncode == 0, r.stdout.decode()
     assert out2.read_bytes() == want
+
+
+def test_live_chain_on_the_real_clip(pdt, orc, clip):
+    """The reference's bundled NOAA-15 clip (real signal, 50 ksps) through the twin's chain: every stage equals the oracle,
+    and the frames are good TIP frames (the chain differs from the file program's, the satellite's data do not)."""
+    rate, iq = clip
+    raw = iq.astype(np.float32) / np.float32(32768.0)
+    o = orc.Oracle(orc.POES, rate, raw, chunk=2400, chain=1)
+    with pdt.Demodulator(pdt.MODE_POES, rate, chain=pdt.CHAIN_LIVE) as d:
+        d.demod_raw(raw)
+        for name in STAGES:
+            assert d.stage(getattr(pdt, name)).tobytes() == o.stage(getattr(orc, name)).tobytes(), f"stage {name} differs"
+        assert d.text() == o.text()
+        summary, _ = d.tip_check()
+        assert summary["frames_checked"] >= 40 and summary["good_frames"] >= summary["frames_checked"] - 2
