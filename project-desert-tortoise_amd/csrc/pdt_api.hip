@@ -1050,7 +1050,7 @@ int pdt_open(const pdt_config *cfg, pdt_ctx **out)
     }
     if (cfg->mode == PDT_MODE_POES && nt == 26 * ip) {
         // tap table of the register-tiled FIR, rotated per ring residue: rot[c][t][r] = h[N-1-r-((c-t) mod K)*interp]
-        const int K = 26, rs = (ip == 3) ? 4 : ip;
+        const int K = 26, rs = ip;                  // rows of `interp` taps, one residue = K * interp consecutive floats
         std::vector<float> rot((size_t)K * K * rs, 0.0f);
         const float *h = (const float *)ctx->taps_host.data();
         for (int c = 0; c < K; c++)

@@ -1342,7 +1342,7 @@ __global__ void __launch_bounds__(PDT_FIR_THREADS) k_fir_interp_rt(const T *__re
 {
     extern __shared__ __align__(16) unsigned char smem_raw[];
     constexpr int TI = 64 * K;                               // inputs (= values of M) per workgroup
-    constexpr int RS = (INTERP == 3) ? 4 : INTERP;           // row stride of the tap table (16-byte rows for INTERP 3)
+    constexpr int RS = INTERP;                               // row stride of the tap table
     constexpr int LS = K + 1;                                // padded row of K inputs: lanes hit distinct banks
     T *s_out = reinterpret_cast<T *>(smem_raw);              // TI * INTERP outputs
     T *s_in = s_out + TI * INTERP;                           // 65 rows of K inputs: row q = inputs m0 + K*(q-1) ..
@@ -1371,11 +1371,15 @@ __global__ void __launch_bounds__(PDT_FIR_THREADS) k_fir_interp_rt(const T *__re
             T x[K];                                              // the lane's ring, all reads in flight together
 #pragma unroll
             for (int t = 0; t < K; t++) x[t] = (t <= c) ? w1[t] : w0[t];
-            T hv[K][INTERP];                                     // ... and the residue's taps (scalar registers)
+            // ... and the residue's taps: one block copy from a wave-uniform address = a handful of wide scalar loads
+            // (fetched row by row the compiler issued two narrow loads and a wait per row: a third of the kernel's instructions)
+            struct TapBlock { T v[K * INTERP]; };
+            const TapBlock tb = *reinterpret_cast<const TapBlock *>(h);
+            T hv[K][INTERP];
 #pragma unroll
             for (int t = 0; t < K; t++)
 #pragma unroll
-                for (int r = 0; r < INTERP; r++) hv[t][r] = h[t * RS + r];
+                for (int r = 0; r < INTERP; r++) hv[t][r] = tb.v[t * RS + r];
 #pragma unroll
             for (int t = 0; t < K; t++) {
 #pragma unroll
