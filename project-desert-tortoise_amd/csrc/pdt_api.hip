@@ -468,7 +468,7 @@ template <typename T> int run_capture(pdt_ctx *ctx, uint64_t n, int phase = RUN_
     T *d_phi = d_agc;
     if (N > 0) {
         L.begin("pll_theta");
-        hipLaunchKernelGGL(k_pll_theta<T>, dim3((unsigned)((N + 255) / 256)), dim3(256), 0, st, d_pcm, N, d_theta);
+        hipLaunchKernelGGL(k_pll_theta<T>, dim3((unsigned)((N + 1023) / 1024)), dim3(256), 0, st, d_pcm, N, d_theta);   // 4 samples per thread
         L.end();
     }
     // fork: the block-parallel phase recurrence (side stream) runs beside the sequential acquisition
@@ -549,10 +549,10 @@ template <typename T> int run_capture(pdt_ctx *ctx, uint64_t n, int phase = RUN_
         (void)grid;
         L.begin("pll_mix");
         if (need_lock)
-            hipLaunchKernelGGL((k_pll_mix<T, true>), dim3((unsigned)((N + 255) / 256)), dim3(256), 0, st, d_pcm, d_phi, N, PP,
+            hipLaunchKernelGGL((k_pll_mix<T, true>), dim3((unsigned)((N + 1023) / 1024)), dim3(256), 0, st, d_pcm, d_phi, N, PP,
                                d_info, d_pll, (T *)ctx->term.p);
         else
-            hipLaunchKernelGGL((k_pll_mix<T, false>), dim3((unsigned)((N + 255) / 256)), dim3(256), 0, st, d_pcm, d_phi, N, PP,
+            hipLaunchKernelGGL((k_pll_mix<T, false>), dim3((unsigned)((N + 1023) / 1024)), dim3(256), 0, st, d_pcm, d_phi, N, PP,
                                d_info, d_pll, (T *)nullptr);
         L.end();
         if (need_lock) {

@@ -65,6 +65,35 @@ template <typename T> struct IqSample {
     }
 };
 
+// NS consecutive IQ samples with 16-byte loads (4 PCM16 pairs / 2 float pairs per load; the address need only be
+// 4- resp. 8-byte aligned).  Same conversion as IqSample<T>::get.  A lane-per-block access touches one cache line per lane
+// whatever its width, so the wide form is a quarter (half) of the load instructions; the elementwise kernels use it to
+// take four samples per thread.
+template <typename T, int FMT, int NS>
+__device__ __forceinline__ void iq_block(const void *p, long long i, T (&a)[NS], T (&b)[NS])
+{
+    if (FMT == 0) {
+        struct __attribute__((packed, aligned(4))) Q { int v[4]; };
+#pragma unroll
+        for (int q = 0; q < NS / 4; q++) {
+            const Q w = *reinterpret_cast<const Q *>(reinterpret_cast<const int *>(p) + i + 4 * q);
+#pragma unroll
+            for (int e = 0; e < 4; e++) {
+                a[4 * q + e] = (T)(short)(w.v[e] & 0xffff) / (T)32768;
+                b[4 * q + e] = (T)(short)(w.v[e] >> 16) / (T)32768;
+            }
+        }
+    } else {
+        struct __attribute__((packed, aligned(8))) Q { float v[4]; };
+#pragma unroll
+        for (int q = 0; q < NS / 2; q++) {
+            const Q w = *reinterpret_cast<const Q *>(reinterpret_cast<const float2 *>(p) + i + 2 * q);
+            a[2 * q] = (T)w.v[0]; b[2 * q] = (T)w.v[1];
+            a[2 * q + 1] = (T)w.v[2]; b[2 * q + 1] = (T)w.v[3];
+        }
+    }
+}
+
 // shared part of one PLL iteration: mix, error, loop update, wrap, clamp (:106-188)
 template <typename T>
 __device__ __forceinline__ void pll_core(T a, T b, T &phase, T &freq, T alpha, T beta, T maxf, T minf, T &o_re, T &o_im,
@@ -166,11 +195,24 @@ __global__ void __launch_bounds__(64) k_pll_acquire(IqSrc pcm, long long n, PllP
 template <typename T>
 __global__ void __launch_bounds__(256) k_pll_theta(IqSrc pcm, long long n, T *__restrict__ theta)
 {
-    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    // four samples per thread: one 16-byte load of IQ, one (two for double) 16-byte store
+    const long long i = ((long long)blockIdx.x * blockDim.x + threadIdx.x) * 4;
     if (i >= n) return;
-    T a, b;
-    IqSample<T>::get(pcm, i, a, b);
-    theta[i] = arctan2_ref(b, a);                                       // :128
+    if (i + 4 <= n) {
+        T a[4], b[4];
+        if (pcm.fmt == 0) iq_block<T, 0, 4>(pcm.p, i, a, b);
+        else iq_block<T, 1, 4>(pcm.p, i, a, b);
+        struct alignas(16) Out { T v[4]; } o;
+#pragma unroll
+        for (int e = 0; e < 4; e++) o.v[e] = arctan2_ref(b[e], a[e]);   // :128
+        *reinterpret_cast<Out *>(theta + i) = o;                        // i is a multiple of 4, theta a device allocation
+    } else {
+        for (long long k = i; k < n; k++) {
+            T a, b;
+            IqSample<T>::get(pcm, k, a, b);
+            theta[k] = arctan2_ref(b, a);
+        }
+    }
 }
 
 // Comparisons of a DT value with the double constants pi / 2pi, as the reference writes them
@@ -739,34 +781,6 @@ __device__ __forceinline__ void pll_phase_range(const T *__restrict__ theta, T *
     }
 }
 
-// NS consecutive IQ samples of one lane with 16-byte loads (4 PCM16 pairs / 2 float pairs per load; the address need only
-// be 4- resp. 8-byte aligned).  Same conversion as IqSample<float>::get.  A lane-per-block access touches one cache line
-// per lane whatever its width, so the wide form is a quarter (half) of the load instructions.
-template <int FMT, int NS>
-__device__ __forceinline__ void iq_block(const void *p, long long i, float (&a)[NS], float (&b)[NS])
-{
-    if (FMT == 0) {
-        struct __attribute__((packed, aligned(4))) Q { int v[4]; };
-#pragma unroll
-        for (int q = 0; q < NS / 4; q++) {
-            const Q w = *reinterpret_cast<const Q *>(reinterpret_cast<const int *>(p) + i + 4 * q);
-#pragma unroll
-            for (int e = 0; e < 4; e++) {
-                a[4 * q + e] = (float)(short)(w.v[e] & 0xffff) / 32768.0f;
-                b[4 * q + e] = (float)(short)(w.v[e] >> 16) / 32768.0f;
-            }
-        }
-    } else {
-        struct __attribute__((packed, aligned(8))) Q { float v[4]; };
-#pragma unroll
-        for (int q = 0; q < NS / 2; q++) {
-            const Q w = *reinterpret_cast<const Q *>(reinterpret_cast<const float2 *>(p) + i + 2 * q);
-            a[2 * q] = w.v[0]; b[2 * q] = w.v[1];
-            a[2 * q + 1] = w.v[2]; b[2 * q + 1] = w.v[3];
-        }
-    }
-}
-
 // Data-derived starting guess for a warm-up that begins at sample ws (any guess is legal --
 // exactness comes from the seam check -- but a PM signal has a second stable lock point pi
 // away from the carrier, and Doppler moves the carrier far from its value at lock, so the
@@ -786,8 +800,8 @@ __device__ __forceinline__ void pll_guess_fmt(IqSrc pcm, long long ws, long long
         constexpr int GB = 32;
         for (int k0 = 0; k0 < K; k0 += GB) {
             float a0[GB], b0[GB], a1[GB], b1[GB];
-            iq_block<FMT, GB>(pcm.p, ws + k0, a0, b0);
-            iq_block<FMT, GB>(pcm.p, ws + k0 + lag, a1, b1);
+            iq_block<float, FMT, GB>(pcm.p, ws + k0, a0, b0);
+            iq_block<float, FMT, GB>(pcm.p, ws + k0 + lag, a1, b1);
 #pragma unroll
             for (int u = 0; u < GB; u++) {
                 rr += a1[u] * a0[u] + b1[u] * b0[u];      // x1 * conj(x0)
@@ -803,7 +817,7 @@ __device__ __forceinline__ void pll_guess_fmt(IqSrc pcm, long long ws, long long
         constexpr int PB = 32;
         for (int k0 = 0; k0 < KP; k0 += PB) {
             float a0[PB], b0[PB];
-            iq_block<FMT, PB>(pcm.p, ws + k0, a0, b0);
+            iq_block<float, FMT, PB>(pcm.p, ws + k0, a0, b0);
 #pragma unroll
             for (int u = 0; u < PB; u++) {
                 float sn, cs;
@@ -1136,18 +1150,44 @@ __global__ void __launch_bounds__(256) k_pll_mix(IqSrc pcm, const T *__restrict_
 {
     const long long lock_at = info->lock_sample;
     if (lock_at < 0) return;
-    const long long i = lock_at + 1 + (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    // four samples per thread; the first sample (lock + 1) has no particular alignment, so the 16-byte accesses are
+    // declared 4-byte (8-byte) aligned
+    const long long i = lock_at + 1 + ((long long)blockIdx.x * blockDim.x + threadIdx.x) * 4;
     if (i >= n) return;
-    T a, b, t_real, t_imag;
-    IqSample<T>::get(pcm, i, a, b);
-    Real<T>::sincos(phi[i], t_imag, t_real);
-    const T c = t_real, d = -t_imag;
-    out[i] = a * d + b * c;
-    if (LOCKSIG) {
-        const T mag2 = a * a + b * b;
-        const T inv = (T)q_rsqrt((float)mag2);
-        const T re = a * inv, im = b * inv;
-        lock_term[i] = P.lock_alpha * (re * t_real + im * t_imag);
+    auto one = [&](T a, T b, T ph, T &o, T &lt) {
+        T t_real, t_imag;
+        Real<T>::sincos(ph, t_imag, t_real);
+        const T c = t_real, d = -t_imag;
+        o = a * d + b * c;
+        if (LOCKSIG) {
+            const T mag2 = a * a + b * b;
+            const T inv = (T)q_rsqrt((float)mag2);
+            const T re = a * inv, im = b * inv;
+            lt = P.lock_alpha * (re * t_real + im * t_imag);
+        }
+    };
+    if (i + 4 <= n) {
+        struct __attribute__((packed, aligned(sizeof(T)))) Quad { T v[4]; };
+        T a[4], b[4];
+        if (pcm.fmt == 0) iq_block<T, 0, 4>(pcm.p, i, a, b);
+        else iq_block<T, 1, 4>(pcm.p, i, a, b);
+        const Quad ph = *reinterpret_cast<const Quad *>(phi + i);
+        Quad o, lt;
+#pragma unroll
+        for (int e = 0; e < 4; e++) {
+            lt.v[e] = 0;
+            one(a[e], b[e], ph.v[e], o.v[e], lt.v[e]);
+        }
+        *reinterpret_cast<Quad *>(out + i) = o;
+        if (LOCKSIG) *reinterpret_cast<Quad *>(lock_term + i) = lt;
+    } else {
+        for (long long k = i; k < n; k++) {
+            T a, b, o, lt = 0;
+            IqSample<T>::get(pcm, k, a, b);
+            one(a, b, phi[k], o, lt);
+            out[k] = o;
+            if (LOCKSIG) lock_term[k] = lt;
+        }
     }
 }
 
