@@ -1413,13 +1413,21 @@ __global__ void __launch_bounds__(PDT_FIR_THREADS) k_fir_interp_rt(const T *__re
             for (int t = 0; t < K; t++) x[t] = (t <= c) ? w1[t] : w0[t];
             // ... and the residue's taps: one block copy from a wave-uniform address = a handful of wide scalar loads
             // (fetched row by row the compiler issued two narrow loads and a wait per row: a third of the kernel's instructions)
+            // (with a single tap per row the compiler's own element loads were measured a little faster)
             struct TapBlock { T v[K * INTERP]; };
-            const TapBlock tb = *reinterpret_cast<const TapBlock *>(h);
             T hv[K][INTERP];
+            if constexpr (INTERP >= 2) {
+                const TapBlock tb = *reinterpret_cast<const TapBlock *>(h);
 #pragma unroll
-            for (int t = 0; t < K; t++)
+                for (int t = 0; t < K; t++)
 #pragma unroll
-                for (int r = 0; r < INTERP; r++) hv[t][r] = tb.v[t * RS + r];
+                    for (int r = 0; r < INTERP; r++) hv[t][r] = tb.v[t * RS + r];
+            } else {
+#pragma unroll
+                for (int t = 0; t < K; t++)
+#pragma unroll
+                    for (int r = 0; r < INTERP; r++) hv[t][r] = h[t * RS + r];
+            }
 #pragma unroll
             for (int t = 0; t < K; t++) {
 #pragma unroll
