@@ -73,6 +73,7 @@ struct DevScalars {
     unsigned gstats[4];     // boundary-state tables: [0] exits outside the domain, [1] full-domain chunks,
                             //                        [2] chunks the chain had to walk, [3] unused
     double norm;            // storage for the normalisation factor (float or double)
+    long long agc_first_bad; // first AGC seam that does not close (k_agc_scan -> k_agc_fix)
 };
 
 }  // namespace
@@ -636,8 +637,9 @@ template <typename T> int run_capture(pdt_ctx *ctx, uint64_t n, int phase = RUN_
                            (const double *)d_guess, d_lock, d_agc, (AgcSeam<T> *)ctx->seams_agc.p, agc_K);
         L.end();
         L.begin("agc_fix");
+        hipLaunchKernelGGL(k_agc_scan<T>, dim3(1), dim3(1024), 0, st, n_out, Ba, (const AgcSeam<T> *)ctx->seams_agc.p, &d_sc->agc_first_bad);
         hipLaunchKernelGGL(k_agc_fix<T>, dim3(1), dim3(64), 0, st, d_fir, n_out, AP, Ba, d_lock, d_agc,
-                           (AgcSeam<T> *)ctx->seams_agc.p, d_sc->counters);
+                           (AgcSeam<T> *)ctx->seams_agc.p, d_sc->counters, (const long long *)&d_sc->agc_first_bad);
         L.end();
     }
 
