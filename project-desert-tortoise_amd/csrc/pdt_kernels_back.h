@@ -1282,6 +1282,60 @@ template <typename T> __device__ __forceinline__ bool manch_resync(const T *sym,
     return sgn(pp) == sgn(p) && Real<T>::abs(pp) > thr && Real<T>::abs(p) > thr;
 }
 
+// ---- helpers of the Manchester tile kernels: the tile's symbols are staged once in LDS (coalesced loads; one pad word
+// per 16 so that threads walking 16 consecutive symbols each hit distinct banks), and the two cross-thread
+// prefixes (last resync position, emitted count) are block scans instead of one thread's loop over 256 entries.
+#define PDT_MANCH_LDS ((PDT_TILE + 2) + (PDT_TILE + 2) / 16 + 1)
+__device__ __forceinline__ int manch_at(int k) { return k + (k >> 4); }
+// s_sym[manch_at(k)] = sym[t0 - 2 + k], k in [0, PDT_TILE + 2); 0 outside [0, nsym)
+template <typename T>
+__device__ __forceinline__ void manch_stage(const T *__restrict__ sym, long long t0, long long nsym, T *s_sym)
+{
+    for (int k = threadIdx.x; k < PDT_TILE + 2; k += PDT_TILE_THREADS) {
+        const long long gi = t0 - 2 + k;
+        s_sym[manch_at(k)] = (gi >= 0 && gi < nsym) ? sym[gi] : (T)0;
+    }
+}
+// resync test of tile-relative symbol j (manch_resync on the staged copy)
+template <typename T> __device__ __forceinline__ bool manch_resync_lds(const T *s_sym, int j, T thr)
+{
+    const T pp = s_sym[manch_at(j)];
+    const T p = s_sym[manch_at(j + 1)];
+    return sgn(pp) == sgn(p) && Real<T>::abs(pp) > thr && Real<T>::abs(p) > thr;
+}
+// exclusive block scans over the 256 threads (4 wavefronts); s_w: 4 ints of LDS
+__device__ __forceinline__ int manch_scan_max_excl(int v, int *s_w)
+{
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    int inc = v;
+    for (int d = 1; d < 64; d <<= 1) {
+        const int o = __shfl_up(inc, d);
+        if (lane >= d) inc = (o > inc) ? o : inc;
+    }
+    if (lane == 63) s_w[wave] = inc;
+    __syncthreads();
+    int ex = __shfl_up(inc, 1);
+    if (lane == 0) ex = -1;
+    for (int w = 0; w < wave; w++) ex = (s_w[w] > ex) ? s_w[w] : ex;
+    __syncthreads();
+    return ex;
+}
+__device__ __forceinline__ unsigned manch_scan_add_excl(unsigned v, unsigned *s_w)
+{
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    unsigned inc = v;
+    for (int d = 1; d < 64; d <<= 1) {
+        const unsigned o = __shfl_up(inc, d);
+        if (lane >= d) inc += o;
+    }
+    if (lane == 63) s_w[wave] = inc;
+    __syncthreads();
+    unsigned ex = inc - v;
+    for (int w = 0; w < wave; w++) ex += s_w[w];
+    __syncthreads();
+    return ex;
+}
+
 struct ManchTile {
     int last_r_parity;      // parity of the last resync position in the tile, -1 = none
     unsigned first_r;       // tile-relative index of the first resync position, PDT_TILE = none
@@ -1301,33 +1355,26 @@ __global__ void __launch_bounds__(PDT_TILE_THREADS) k_manch_tile(const T *__rest
     const long long t0 = (long long)blockIdx.x * PDT_TILE;
     if (t0 >= nsym) return;
     __shared__ int s_last[PDT_TILE];     // tile-relative index of last R at or before i, -1 none
+    __shared__ T s_sym[PDT_MANCH_LDS];
     __shared__ unsigned s_first;
     __shared__ unsigned s_cnt[3];
+    __shared__ int s_w[4];
     if (threadIdx.x == 0) { s_first = PDT_TILE; s_cnt[0] = s_cnt[1] = s_cnt[2] = 0; }
+    manch_stage(sym, t0, nsym, s_sym);
     __syncthreads();
     const int per = PDT_TILE / PDT_TILE_THREADS;            // 16 consecutive symbols per thread
     const int lo = threadIdx.x * per;
     int last = -1;
     for (int u = 0; u < per; u++) {
         const long long i = t0 + lo + u;
-        if (i < nsym && manch_resync(sym, i, thr)) last = lo + u;
+        if (i < nsym && manch_resync_lds(s_sym, lo + u, thr)) last = lo + u;
         s_last[lo + u] = last;
     }
-    __syncthreads();
-    // propagate across threads: thread t needs the last R of all previous threads
+    // propagate across threads: thread t needs the last R of all previous threads (positions grow with t: a max scan)
     __shared__ int s_tlast[PDT_TILE_THREADS];
-    s_tlast[threadIdx.x] = last;
+    const int carry = manch_scan_max_excl(last, s_w);
+    s_tlast[threadIdx.x] = carry;
     __syncthreads();
-    if (threadIdx.x == 0) {
-        int run = -1;
-        for (int t = 0; t < PDT_TILE_THREADS; t++) {
-            const int v = s_tlast[t];
-            s_tlast[t] = run;            // exclusive prefix
-            if (v >= 0) run = v;
-        }
-    }
-    __syncthreads();
-    const int carry = s_tlast[threadIdx.x];
     unsigned c_b0 = 0, c_b1 = 0, c_a = 0;
     unsigned my_first = PDT_TILE;
     for (int u = 0; u < per; u++) {
@@ -1447,28 +1494,21 @@ __global__ void __launch_bounds__(PDT_TILE_THREADS) k_manch_emit(const T *__rest
     const long long t0 = (long long)blockIdx.x * PDT_TILE;
     if (t0 >= nsym) return;
     const ManchTile mt = tiles[blockIdx.x];
-    __shared__ int s_tlast[PDT_TILE_THREADS];
-    __shared__ unsigned s_tcnt[PDT_TILE_THREADS];
+    __shared__ T s_sym[PDT_MANCH_LDS];
+    __shared__ int s_wi[4];
+    __shared__ unsigned s_wu[4];
+    manch_stage(sym, t0, nsym, s_sym);
+    __syncthreads();
     const int per = PDT_TILE / PDT_TILE_THREADS;
     const int lo = threadIdx.x * per;
     // pass 1: per-thread last-R and (given the carry) emitted count -- two sweeps over 16 symbols
     int last = -1;
+    unsigned rs_mask = 0;                 // resync test of the thread's 16 symbols, kept for the second sweep
     for (int u = 0; u < per; u++) {
         const long long i = t0 + lo + u;
-        if (i < nsym && manch_resync(sym, i, thr)) last = lo + u;
+        if (i < nsym && manch_resync_lds(s_sym, lo + u, thr)) { last = lo + u; rs_mask |= 1u << u; }
     }
-    s_tlast[threadIdx.x] = last;
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        int run = -1;
-        for (int t = 0; t < PDT_TILE_THREADS; t++) {
-            const int v = s_tlast[t];
-            s_tlast[t] = run;
-            if (v >= 0) run = v;
-        }
-    }
-    __syncthreads();
-    const int carry = s_tlast[threadIdx.x];
+    const int carry = manch_scan_max_excl(last, s_wi);
     unsigned clock = (carry >= 0) ? (unsigned)((t0 + carry) & 1) : mt.clock_in;
     unsigned emit_mask = 0;
     unsigned my_cnt = 0;
@@ -1476,26 +1516,15 @@ __global__ void __launch_bounds__(PDT_TILE_THREADS) k_manch_emit(const T *__rest
         const long long i = t0 + lo + u;
         if (i >= nsym) break;
         const unsigned q = (unsigned)(i & 1);
-        if (manch_resync(sym, i, thr)) clock = q;
+        if (rs_mask & (1u << u)) clock = q;
         if (q == clock) { emit_mask |= 1u << u; my_cnt++; }
     }
-    s_tcnt[threadIdx.x] = my_cnt;
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        unsigned run = 0;
-        for (int t = 0; t < PDT_TILE_THREADS; t++) {
-            const unsigned v = s_tcnt[t];
-            s_tcnt[t] = run;
-            run += v;
-        }
-    }
-    __syncthreads();
-    unsigned long long o = mt.out_base + s_tcnt[threadIdx.x];
+    unsigned long long o = mt.out_base + manch_scan_add_excl(my_cnt, s_wu);
     for (int u = 0; u < per; u++) {
         if (!(emit_mask & (1u << u))) continue;
         const long long i = t0 + lo + u;
-        const T p = (i >= 1) ? sym[i - 1] : (T)0;
-        const T cur = sym[i];
+        const T p = s_sym[manch_at(lo + u + 1)];          // sym[i - 1] (0 before the stream start)
+        const T cur = s_sym[manch_at(lo + u + 2)];        // sym[i]
         unsigned char bit;
         if (Real<T>::abs(p) > Real<T>::abs(cur))
             bit = (p > 0) ? '1' : '0';
