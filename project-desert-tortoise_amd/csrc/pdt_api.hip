@@ -743,7 +743,8 @@ template <typename T> int run_capture(pdt_ctx *ctx, uint64_t n, int phase = RUN_
             hipLaunchKernelGGL(k_gardner_chain, dim3(1), dim3(256), 0, st,      // 4 wavefronts: a walked chunk is staged 4x faster
                                (const float *)d_agc, GP, GD, n_chunks,
                                (const unsigned *)ctx->gtable.p, (const GardnerSegCell *)ctx->gsegmap.p, G,
-                               (GardnerSegStart *)ctx->gsegstart.p, (GardnerEntry<float> *)ctx->gentries.p, d_sc->gstats);
+                               (GardnerSegStart *)ctx->gsegstart.p, (GardnerEntry<float> *)ctx->gentries.p, d_sc->gstats,
+                               (const GardnerBand *)ctx->gbands.p, n_tab);
             hipLaunchKernelGGL(k_gardner_segfill, dim3((unsigned)n_seg), dim3(64), 0, st, (const float *)d_agc, GP, GD, n_chunks,
                                (const unsigned *)ctx->gtable.p, G, (const GardnerSegStart *)ctx->gsegstart.p,
                                (GardnerEntry<float> *)ctx->gentries.p);

@@ -699,14 +699,11 @@ __global__ void __launch_bounds__(64) k_gardner_scout(const float *__restrict__ 
             bd.j_lo = 0;
             bd.j_hi = total;
             bd.listed = 1;
-        } else if (lane == 0) {
-            atomicAdd(&stats[1], 1u);
         }
     }
-    if (lane == 0) {
-        bands[c] = bd;
-        atomicAdd(&stats[3], (unsigned)(bd.j_hi - bd.j_lo));
-    }
+    // (no global counters here: 3 000 atomics on one address drained for 0.1 ms after the last wavefront had finished;
+    // k_gardner_chain sums the candidates and the full-domain chunks from the bands)
+    if (lane == 0) bands[c] = bd;
 }
 
 // level 1: block (c, p) runs slice p (2 x THREADS candidates) of chunk c's candidate list, window by
@@ -1165,9 +1162,25 @@ __global__ void __launch_bounds__(256) k_gardner_chain(const float *__restrict__
                                                                         const GardnerSegCell *__restrict__ segmap, int G,
                                                                         GardnerSegStart *__restrict__ segstart,
                                                                         GardnerEntry<float> *__restrict__ entries,
-                                                                        unsigned *__restrict__ stats /* [2] walked chunks */)
+                                                                        unsigned *__restrict__ stats /* [2] walked chunks */,
+                                                                        const GardnerBand *__restrict__ bands, long long n_tab)
 {
     __shared__ float win[GardnerLds<float>::LEN];
+    {   // statistics of the scouts: candidates evaluated ([3]) and chunks tabulated over the full domain ([1])
+        __shared__ unsigned s_sum[2];
+        if (threadIdx.x < 2) s_sum[threadIdx.x] = 0;
+        __syncthreads();
+        unsigned cand = 0, full = 0;
+        for (long long k = threadIdx.x; k < n_tab; k += blockDim.x) {
+            const GardnerBand b = bands[k];
+            cand += (unsigned)(b.j_hi - b.j_lo);
+            full += (k >= 1 && !b.listed) ? 1u : 0u;
+        }
+        atomicAdd(&s_sum[0], cand);
+        atomicAdd(&s_sum[1], full);
+        __syncthreads();
+        if (threadIdx.x == 0) { stats[3] = s_sum[0]; stats[1] = s_sum[1]; }
+    }
     const size_t stride = (size_t)(2 * D.n_q);
     GardnerState<float> S;
     S.ns = 0; S.prev = 0; S.half = 0; S.q_last = 0; S.i_last = 0;
