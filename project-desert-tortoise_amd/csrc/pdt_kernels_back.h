@@ -1405,10 +1405,21 @@ __global__ void __launch_bounds__(PDT_TILE_THREADS) k_manch_tile(const T *__rest
             c_a += (q == cm);
         }
     }
-    atomicAdd(&s_cnt[0], c_b0);
-    atomicAdd(&s_cnt[1], c_b1);
-    atomicAdd(&s_cnt[2], c_a);
-    atomicMin(&s_first, my_first);
+    // tile totals: wavefront reductions by shuffles, then one LDS atomic per wavefront (256 threads each adding to the
+    // same four words took longer than the rest of the kernel)
+    for (int d = 32; d >= 1; d >>= 1) {
+        c_b0 += __shfl_xor(c_b0, d);
+        c_b1 += __shfl_xor(c_b1, d);
+        c_a += __shfl_xor(c_a, d);
+        const unsigned of = __shfl_xor(my_first, d);
+        my_first = (of < my_first) ? of : my_first;
+    }
+    if ((threadIdx.x & 63) == 0) {
+        atomicAdd(&s_cnt[0], c_b0);
+        atomicAdd(&s_cnt[1], c_b1);
+        atomicAdd(&s_cnt[2], c_a);
+        atomicMin(&s_first, my_first);
+    }
     __syncthreads();
     if (threadIdx.x == 0) {
         ManchTile mt;
