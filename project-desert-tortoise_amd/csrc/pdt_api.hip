@@ -492,6 +492,9 @@ template <typename T> int run_capture(pdt_ctx *ctx, uint64_t n, int phase = RUN_
         L.end();
         HIP_TRY(hipEventRecord(ctx->ev_join, ctx->stream2));
     }
+    // the serial kernels (acquisition, head) ask for SIMDs of their own while the block-parallel kernel beside them
+    // leaves some free (1 024 SIMDs; it runs one wavefront per 64 blocks)
+    const bool serial_excl = grid_pll <= 768 && !getenv("PDT_NO_EXCL");
     L.begin("pll_acquire");
     if (getenv("PDT_ACQUIRE_SIMPLE"))       // plain one-lane form, kept for A/B checks
         hipLaunchKernelGGL(k_pll_acquire<T>, dim3(1), dim3(64), 0, st, d_pcm, N, PP, d_pll, d_lock, d_info);
@@ -504,6 +507,9 @@ template <typename T> int run_capture(pdt_ctx *ctx, uint64_t n, int phase = RUN_
                                d_info);
     } else if (slow_wrap)
         hipLaunchKernelGGL((k_pll_acquire_pipe<T, true>), dim3(1), dim3(128), 0, st, d_pcm, (const T *)d_theta, N, PP, d_pll, d_lock,
+                           d_info);
+    else if (serial_excl)
+        hipLaunchKernelGGL((k_pll_acquire_pipe<T, false, true>), dim3(1), dim3(128), 0, st, d_pcm, (const T *)d_theta, N, PP, d_pll, d_lock,
                            d_info);
     else
         hipLaunchKernelGGL((k_pll_acquire_pipe<T, false>), dim3(1), dim3(128), 0, st, d_pcm, (const T *)d_theta, N, PP, d_pll, d_lock,
@@ -530,6 +536,9 @@ template <typename T> int run_capture(pdt_ctx *ctx, uint64_t n, int phase = RUN_
         L.begin("pll_head");
         if (slow_wrap)
             hipLaunchKernelGGL((k_pll_head<T, true>), dim3(1), dim3(64), 0, st, d_theta, N, PP, d_info, Bp, Hd, d_hphi, d_hseams,
+                               d_hinfo, head_blocks);
+        else if (serial_excl)
+            hipLaunchKernelGGL((k_pll_head<T, false, true>), dim3(1), dim3(64), 0, st, d_theta, N, PP, d_info, Bp, Hd, d_hphi, d_hseams,
                                d_hinfo, head_blocks);
         else
             hipLaunchKernelGGL((k_pll_head<T, false>), dim3(1), dim3(64), 0, st, d_theta, N, PP, d_info, Bp, Hd, d_hphi, d_hseams,

@@ -516,13 +516,17 @@ template <typename T> struct AcqVerdict {
     T phase, freq, sweep;              // loop-filter state after sample k (sweep step taken with the true gate)
 };
 
-template <typename T, bool SLOW>
+template <typename T, bool SLOW, bool EXCL = false>
 __global__ void __launch_bounds__(128) k_pll_acquire_pipe(IqSrc pcm, const T *__restrict__ theta, long long n, PllParams<T> P,
                                                           T *__restrict__ out, T *__restrict__ lock_out,
                                                           PllLockInfo<T> *__restrict__ info)
 {
     __shared__ AcqSlot<T> slot[2];
     __shared__ AcqVerdict<T> verdict;
+    // EXCL: claim a whole SIMD's register file per wavefront (256 + 256 registers), so that the dispatcher can only put
+    // these serial wavefronts on SIMDs that hold no wavefront of the concurrent block-parallel kernel -- sharing issue
+    // slots with one costs them up to 15 %.  Only requested while that kernel leaves SIMDs free (the host decides).
+    if (EXCL) asm volatile("" ::: "v255", "a255");
     const int wave = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6);
     const int lane = threadIdx.x & 63;
     const T avg_alpha = (T)0.00005;
@@ -932,12 +936,13 @@ __global__ void __launch_bounds__(64) k_pll_phase(IqSrc pcm, const T *__restrict
 // the block-parallel results before it validates the later seams.
 template <typename T> struct PllHeadInfo { long long s0, s1, j0, nblk; };
 
-template <typename T, bool SLOW>
+template <typename T, bool SLOW, bool EXCL = false>
 __global__ void __launch_bounds__(64) k_pll_head(const T *__restrict__ theta, long long n, PllParams<T> P,
                                                   const PllLockInfo<T> *__restrict__ info, long long B, long long W,
                                                   T *__restrict__ phi_head, PllSeam<T> *__restrict__ seams_head,
                                                   PllHeadInfo<T> *__restrict__ hinfo, long long max_blocks)
 {
+    if (EXCL) asm volatile("" ::: "v255", "a255");       // a SIMD of its own, see k_pll_acquire_pipe
     if (blockIdx.x != 0 || threadIdx.x != 0) return;
     const long long lock_at = info->lock_sample;
     PllHeadInfo<T> hi;
