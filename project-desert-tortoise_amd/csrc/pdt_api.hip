@@ -78,8 +78,32 @@ struct DevScalars {
 
 }  // namespace
 
+// Developer switches (A/B runs of older kernel variants, tuning sweeps).  Read from the environment ONCE, when the
+// context is opened; the demodulation calls never look at the environment.
+struct Tuning {
+    double pll_warm_scale = 1.0, head_taus = 0.0, agc_k = 0.0;
+    int agc_tpb = 0, gseg = 0, acquire_mode = 0;      // acquire_mode: 0 = two-wavefront pipeline, 1 = plain one-lane, 2 = one wavefront
+    bool fir_generic = false, agc_unfused = false, no_excl = false, gtab_nomerge = false, gardner_onebuf = false;
+    void load()
+    {
+        if (const char *e = getenv("PDT_PLL_WARM_SCALE")) pll_warm_scale = atof(e);
+        if (const char *e = getenv("PDT_HEAD_TAUS")) head_taus = atof(e);
+        if (const char *e = getenv("PDT_AGC_K")) agc_k = atof(e);
+        if (const char *e = getenv("PDT_AGC_TPB")) agc_tpb = std::max(1, atoi(e));
+        if (const char *e = getenv("PDT_GSEG")) gseg = std::min(64, std::max(2, atoi(e)));
+        if (getenv("PDT_ACQUIRE_SIMPLE")) acquire_mode = 1;
+        else if (getenv("PDT_ACQUIRE_ONEWAVE")) acquire_mode = 2;
+        fir_generic = getenv("PDT_FIR_GENERIC") != nullptr;
+        agc_unfused = getenv("PDT_AGC_UNFUSED") != nullptr;
+        no_excl = getenv("PDT_NO_EXCL") != nullptr;
+        gtab_nomerge = getenv("PDT_GTAB_NOMERGE") != nullptr;
+        gardner_onebuf = getenv("PDT_GARDNER_ONEBUF") != nullptr;
+    }
+};
+
 struct pdt_ctx {
     pdt_config cfg;
+    Tuning tune;
     int elem;                 // sizeof(DT)
     uint32_t interp, ntaps;
     hipStream_t stream = nullptr;
@@ -360,7 +384,7 @@ template <typename T> int run_capture(pdt_ctx *ctx, uint64_t n, int phase = RUN_
         const double tau = 2.0 / (double)PP.alpha_trk;
         const double nb = std::max(1.0, (double)N / (double)std::max<long long>(1, Bp));
         double w = 2.82 * tau * log(400.0 * nb);
-        if (const char *e = getenv("PDT_PLL_WARM_SCALE")) w *= atof(e);         // tuning experiments
+        w *= ctx->tune.pll_warm_scale;
         Wp = (long long)std::min(std::max(w, 0.15 * fs_d), 0.6 * fs_d);
     }
     long long Wacq = (long long)(0.02 * fs_d);             // acquisition-gain stage of the warm-up
@@ -371,11 +395,11 @@ template <typename T> int run_capture(pdt_ctx *ctx, uint64_t n, int phase = RUN_
     // POES with the register-tiled FIR: AGC blocks made of whole FIR tiles (64 * 26 inputs), so that the FIR kernel can
     // deliver the AGC's affine tile maps itself (0 = not fused: explicit block size, ARGOS, generic FIR)
     long long agc_tiles_per_block = 0, fused_tiles = 0;
-    if (!argos && !ctx->cfg.agc_block && ntaps == 26 * interp && ctx->taps_rot.p && !getenv("PDT_FIR_GENERIC") &&
-        !getenv("PDT_AGC_UNFUSED")) {
+    if (!argos && !ctx->cfg.agc_block && ntaps == 26 * interp && ctx->taps_rot.p && !ctx->tune.fir_generic &&
+        !ctx->tune.agc_unfused) {
         const long long tile_out = 64ll * 26 * interp;
         agc_tiles_per_block = std::max<long long>(1, (Ba + tile_out / 2) / tile_out);
-        if (const char *e = getenv("PDT_AGC_TPB")) agc_tiles_per_block = std::max(1, atoi(e));      // tuning experiments
+        if (ctx->tune.agc_tpb) agc_tiles_per_block = ctx->tune.agc_tpb;
         Ba = agc_tiles_per_block * tile_out;
     }
     Wp = round4(Wp);
@@ -401,7 +425,9 @@ template <typename T> int run_capture(pdt_ctx *ctx, uint64_t n, int phase = RUN_
     const long long n_chunks = chunk_out > 0 ? (n_out + chunk_out - 1) / chunk_out : 0;
     const long long sym_cap = (long long)((double)n_out / min_step) + n_chunks + 64;
     const long long bit_cap = sym_cap;
-    const uint32_t hit_cap = next_pow2((uint32_t)(bit_cap / 64 + 4096));
+    // worst legal hit density: the ARGOS word overlaps itself by 3 bits (one hit per 10 bits), the POES word followed by
+    // its inverse by 3 (one per 16) -- e.g. a repeated sync-word test pattern; the reference decodes such streams
+    const uint32_t hit_cap = next_pow2((uint32_t)(bit_cap / 10 + 4096));
     const uint32_t frame_cap = (uint32_t)(bit_cap / SP.span + 16);
     const long long n_tiles = (sym_cap + PDT_TILE - 1) / PDT_TILE;
     const long long n0 = std::min<long long>(chunk, N);
@@ -494,11 +520,11 @@ template <typename T> int run_capture(pdt_ctx *ctx, uint64_t n, int phase = RUN_
     }
     // the serial kernels (acquisition, head) ask for SIMDs of their own while the block-parallel kernel beside them
     // leaves some free (1 024 SIMDs; it runs one wavefront per 64 blocks)
-    const bool serial_excl = grid_pll <= 768 && !getenv("PDT_NO_EXCL");
+    const bool serial_excl = grid_pll <= 768 && !ctx->tune.no_excl;
     L.begin("pll_acquire");
-    if (getenv("PDT_ACQUIRE_SIMPLE"))       // plain one-lane form, kept for A/B checks
+    if (ctx->tune.acquire_mode == 1)        // plain one-lane form, kept for A/B checks
         hipLaunchKernelGGL(k_pll_acquire<T>, dim3(1), dim3(64), 0, st, d_pcm, N, PP, d_pll, d_lock, d_info);
-    else if (getenv("PDT_ACQUIRE_ONEWAVE")) {   // single-wavefront batched form, kept for A/B checks
+    else if (ctx->tune.acquire_mode == 2) {   // single-wavefront batched form, kept for A/B checks
         if (slow_wrap)
             hipLaunchKernelGGL((k_pll_acquire_fast<T, true>), dim3(1), dim3(64), 0, st, d_pcm, (const T *)d_theta, N, PP, d_pll, d_lock,
                                d_info);
@@ -523,7 +549,7 @@ template <typename T> int run_capture(pdt_ctx *ctx, uint64_t n, int phase = RUN_
         // capture, 40 never needed), 90 for 53 bits; a block that still disagrees afterwards is simply re-run
         const double tau_trk = 2.0 / (double)PP.alpha_trk;
         double head_taus = (sizeof(T) == 4) ? 30.0 : 90.0;
-        if (const char *e = getenv("PDT_HEAD_TAUS")) head_taus = atof(e);      // tuning experiments
+        if (ctx->tune.head_taus > 0) head_taus = ctx->tune.head_taus;
         const long long Hd = std::min<long long>(Wp, (long long)(head_taus * tau_trk));
         const long long head_blocks = Hd / Bp + 3;
         if ((rc = ctx->pll_head.ensure((size_t)(head_blocks * Bp + 64) * sizeof(T) + (size_t)head_blocks * sizeof(PllSeam<T>) +
@@ -603,7 +629,7 @@ template <typename T> int run_capture(pdt_ctx *ctx, uint64_t n, int phase = RUN_
             }
             const unsigned grid_rt = (unsigned)std::min<long long>(tiles_rt, 256ll * 6);   // persistent workgroups, 6 per CU
             bool done = false;
-            if (K == 26 && sh_rt <= 64000 && ctx->taps_rot.p && !getenv("PDT_FIR_GENERIC")) {
+            if (K == 26 && sh_rt <= 64000 && ctx->taps_rot.p && !ctx->tune.fir_generic) {
                 done = true;
                 switch (interp) {
 #define PDT_FIR_CASE(I)                                                                                                       \
@@ -637,7 +663,7 @@ template <typename T> int run_capture(pdt_ctx *ctx, uint64_t n, int phase = RUN_
         // warm-up length in gain time constants: the affine guess is off by the accumulated float rounding of
         // the true recurrence only, so a few time constants make the trajectories agree to the last bit
         double agc_K = (sizeof(T) == 4) ? 11.0 : 34.0;
-        if (const char *e = getenv("PDT_AGC_K")) agc_K = atof(e);
+        if (ctx->tune.agc_k > 0) agc_K = ctx->tune.agc_k;
         L.begin("agc_block");
         if (!fused) hipLaunchKernelGGL(k_agc_affine<T>, dim3((unsigned)nb), dim3(256), 0, st, d_fir, n_out, AP.decay, Ba, d_maps);
         hipLaunchKernelGGL(k_agc_guess<T>, dim3(1), dim3(1024), 0, st, (const AgcMap *)d_maps, nb, (const T *)d_norm, d_guess,
@@ -722,7 +748,7 @@ template <typename T> int run_capture(pdt_ctx *ctx, uint64_t n, int phase = RUN_
                                (GardnerBand *)ctx->gbands.p, (unsigned *)ctx->gclist.p, d_sc->gstats);
             {
                 // locked chunks carry 100-300 candidates that merge quickly: see k_gardner_table_merge
-                if (getenv("PDT_GTAB_NOMERGE")) {
+                if (ctx->tune.gtab_nomerge) {
                     constexpr int TT = PDT_GTAB_THREADS, TW = PDT_GTAB_WIN;
                     const unsigned parts = (unsigned)((GD.n_cand + 2 * TT - 1) / (2 * TT));
                     hipLaunchKernelGGL((k_gardner_table<TT, TW>), dim3((unsigned)n_tab, parts), dim3(TT), 0, st, (const float *)d_agc, GP,
@@ -741,7 +767,7 @@ template <typename T> int run_capture(pdt_ctx *ctx, uint64_t n, int phase = RUN_
             // the re-trace of a segment take G such look-ups each but run in parallel over the segments
             // (at most 64: k_gardner_segfill re-traces a segment with one lane per chunk)
             int G = (n_chunks < 8000) ? 32 : 64;
-            if (const char *e = getenv("PDT_GSEG")) G = std::min(64, std::max(2, atoi(e)));   // tuning experiments
+            if (ctx->tune.gseg) G = ctx->tune.gseg;
             const long long n_seg = (n_chunks + G - 1) / G;
             if ((rc = ctx->gsegmap.ensure((size_t)n_seg * (size_t)(2 * GD.n_q) * sizeof(GardnerSegCell)))) return rc;
             if ((rc = ctx->gsegstart.ensure((size_t)n_seg * sizeof(GardnerSegStart)))) return rc;
@@ -784,7 +810,7 @@ template <typename T> int run_capture(pdt_ctx *ctx, uint64_t n, int phase = RUN_
         constexpr int SMALL_LEN = 32768 / (int)sizeof(T), SMALL_OUT = 1024;    // two 32 KiB windows
         const long long small_need = chunk_out + 2 * (long long)GP.step + 24;
         const double small_syms = (double)chunk_out / ((double)GP.step - 0.25) + 4.0;
-        if (small_need <= SMALL_LEN && small_syms < SMALL_OUT && !getenv("PDT_GARDNER_ONEBUF"))
+        if (small_need <= SMALL_LEN && small_syms < SMALL_OUT && !ctx->tune.gardner_onebuf)
             hipLaunchKernelGGL((k_gardner_small<T, SMALL_LEN, SMALL_OUT>), dim3(1), dim3(256), 0, st, (const T *)d_agc, (const T *)d_lock, GP,
                                d_sym, d_symidx, &d_sc->nsym, sym_cap);
         else
@@ -1046,18 +1072,19 @@ int pdt_open(const pdt_config *cfg, pdt_ctx **out)
     HIP_TRY(hipSetDevice(cfg->device));
     pdt_ctx *ctx = new pdt_ctx();
     ctx->cfg = *cfg;
+    ctx->tune.load();
     if (!ctx->cfg.chunk) ctx->cfg.chunk = (cfg->mode == PDT_MODE_ARGOS || cfg->chain == PDT_CHAIN_LIVE) ? 2400 : 10000;
     ctx->elem = cfg->mode == PDT_MODE_ARGOS ? 8 : 4;
     int nt = 0, ip = 0;
     int rc = pdt_make_lpf(cfg->mode, cfg->sample_rate, nullptr, &nt, &ip);
-    if (rc) { delete ctx; return rc; }
+    if (rc) { pdt_close(ctx); return rc; }
     ctx->interp = (uint32_t)ip;
     ctx->ntaps = (uint32_t)nt;
     ctx->taps_host.resize((size_t)nt * ctx->elem);
     pdt_make_lpf(cfg->mode, cfg->sample_rate, ctx->taps_host.data(), nullptr, nullptr);
-    if ((rc = ctx->taps.ensure(ctx->taps_host.size()))) { delete ctx; return rc; }
+    if ((rc = ctx->taps.ensure(ctx->taps_host.size()))) { pdt_close(ctx); return rc; }
     if (hipMemcpy(ctx->taps.p, ctx->taps_host.data(), ctx->taps_host.size(), hipMemcpyHostToDevice) != hipSuccess) {
-        delete ctx;
+        pdt_close(ctx);
         return PDT_ERR_NOGPU;
     }
     if (cfg->mode == PDT_MODE_POES && nt == 26 * ip) {
@@ -1068,17 +1095,17 @@ int pdt_open(const pdt_config *cfg, pdt_ctx **out)
         for (int c = 0; c < K; c++)
             for (int t = 0; t < K; t++)
                 for (int r = 0; r < ip; r++) rot[((size_t)c * K + t) * rs + r] = h[nt - 1 - r - ((c - t + K) % K) * ip];
-        if ((rc = ctx->taps_rot.ensure(rot.size() * sizeof(float)))) { delete ctx; return rc; }
+        if ((rc = ctx->taps_rot.ensure(rot.size() * sizeof(float)))) { pdt_close(ctx); return rc; }
         if (hipMemcpy(ctx->taps_rot.p, rot.data(), rot.size() * sizeof(float), hipMemcpyHostToDevice) != hipSuccess) {
-            delete ctx;
+            pdt_close(ctx);
             return PDT_ERR_NOGPU;
         }
     }
-    if (hipStreamCreate(&ctx->stream) != hipSuccess) { delete ctx; return PDT_ERR_NOGPU; }
+    if (hipStreamCreate(&ctx->stream) != hipSuccess) { ctx->stream = nullptr; pdt_close(ctx); return PDT_ERR_NOGPU; }
     ctx->own_stream = true;
     {
         void *small = nullptr;
-        if (hipHostMalloc(&small, sizeof(DevScalars) + 128, hipHostMallocDefault) != hipSuccess) { delete ctx; return PDT_ERR_NOMEM; }
+        if (hipHostMalloc(&small, sizeof(DevScalars) + 128, hipHostMallocDefault) != hipSuccess) { pdt_close(ctx); return PDT_ERR_NOMEM; }
         ctx->pend_sc = (DevScalars *)small;
         ctx->pend_info = (unsigned char *)small + ((sizeof(DevScalars) + 15) & ~(size_t)15);
     }
@@ -1086,7 +1113,7 @@ int pdt_open(const pdt_config *cfg, pdt_ctx **out)
     (void)hipEventCreate(&ctx->ev1);
     (void)hipEventCreateWithFlags(&ctx->ev_fork, hipEventDisableTiming);
     (void)hipEventCreateWithFlags(&ctx->ev_join, hipEventDisableTiming);
-    if (hipStreamCreateWithFlags(&ctx->stream2, hipStreamNonBlocking) != hipSuccess) { delete ctx; return PDT_ERR_NOGPU; }
+    if (hipStreamCreateWithFlags(&ctx->stream2, hipStreamNonBlocking) != hipSuccess) { ctx->stream2 = nullptr; pdt_close(ctx); return PDT_ERR_NOGPU; }
     memset(&ctx->stats, 0, sizeof ctx->stats);
     memset(ctx->stage_len, 0, sizeof ctx->stage_len);
     ctx->axis_f.init((float)(1.0 / (double)(float)cfg->sample_rate));        // wave.c:96-97
@@ -1120,6 +1147,7 @@ void pdt_close(pdt_ctx *ctx)
 int pdt_set_stream(pdt_ctx *ctx, void *hip_stream)
 {
     if (!ctx) return PDT_ERR_ARG;
+    HIP_TRY(hipSetDevice(ctx->cfg.device));
     if (ctx->own_stream && ctx->stream) (void)hipStreamDestroy(ctx->stream);
     ctx->own_stream = false;
     ctx->stream = (hipStream_t)hip_stream;
@@ -1355,6 +1383,7 @@ int pdt_stream_push_f32(pdt_ctx *ctx, const float *iq_host, uint64_t nframes, ui
 int pdt_stream_end(pdt_ctx *ctx, uint64_t *new_frames)
 {
     if (!ctx) return PDT_ERR_ARG;
+    HIP_TRY(hipSetDevice(ctx->cfg.device));
     if (ctx->stream_fmt < 0) {                       // nothing was pushed: an empty capture
         ctx->stream_fmt = 0;
         int rc = ctx->stream_in.ensure(64);
