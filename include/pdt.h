@@ -34,6 +34,8 @@
  *                       ManchesterDecode (ManchesterDecode.c:10-100),
  *                       ByteSyncOnSyncword (POESTIPdemod/ByteSync.c:16-150) /
  *                       FindSyncWords (ARGOSdemod/ByteSync.c:17-150)
+ *   pdt_demod_fd        same, reading the capture file itself: the fread loops of GetComplexWaveChunk / GetComplexRawChunk
+ *                       (wave.c:126-172, 483-537) become a threaded read into pinned memory overlapped with the copy to HBM
  *   pdt_demod_device    same, input already resident in HBM (bench / multi-capture)
  *   pdt_demod_f32       the same loop over GetComplexRawChunk (wave.c:413-540): RAW float32 captures
  *   pdt_stream_*        the same loop fed block by block, as POESTIPdemodPortAudio/main.c:324-393 is by
@@ -87,6 +89,7 @@ enum {
 };
 
 enum { PDT_CHAIN_FILE = 0, PDT_CHAIN_LIVE = 1 };
+enum { PDT_FMT_PCM16 = 0, PDT_FMT_F32 = 1 };   /* interleaved little-endian int16 I,Q pairs / IEEE float32 I,Q pairs */
 
 typedef struct pdt_config {
     int32_t  mode;            /* PDT_MODE_POES / PDT_MODE_ARGOS                                   */
@@ -171,6 +174,12 @@ int  pdt_keep_presquelch(pdt_ctx *ctx, int enable);
 /* Demodulate one whole capture: nframes interleaved little-endian int16 I,Q pairs
  * in host memory (copied to the GPU) ...                                                        */
 int  pdt_demod_pcm16(pdt_ctx *ctx, const int16_t *iq_host, uint64_t nframes);
+/* ... or straight from the file the caller opened (what GetComplexWaveChunk / GetComplexRawChunk do with their FILE*,
+ * wave.c:59-175,413-540, once per chunk): nframes I,Q pairs of `sample_format` starting at byte_offset (44 for the
+ * canonical WAV header ReadWavHeader accepts, 0 for RAW).  The library reads the file in 4 MiB spans with a few host
+ * threads into pinned memory and copies them to the GPU while the next spans are being read, so a capture is in HBM about
+ * as soon as the page cache and the PCIe link allow.  PDT_ERR_FORMAT when the file ends early.                         */
+int  pdt_demod_fd(pdt_ctx *ctx, int fd, uint64_t byte_offset, uint64_t nframes, int sample_format);
 /* ... or already resident in device memory (no copy; buffer is only read).                      */
 int  pdt_demod_device(pdt_ctx *ctx, const void *iq_device, uint64_t nframes);
 
@@ -213,6 +222,9 @@ int      pdt_get_stats(const pdt_ctx *ctx, pdt_stats *out);
 /* Text exactly as the reference writes it to minorFrames_*.txt / packets_*.txt.
  * Returns the number of bytes needed; writes at most `cap` bytes.                               */
 uint64_t pdt_format_frames(const pdt_ctx *ctx, char *buf, uint64_t cap);
+/* The same text for any array of frame records (e.g. the records of several captures gathered on one rank); host only, no
+ * context and no GPU needed.  POESTIPdemod/ByteSync.c:62-69,96-101, ARGOSdemod/ByteSync.c:62-70,99-103.                 */
+uint64_t pdt_format_records(const pdt_frame *frames, uint64_t nframes, char *buf, uint64_t cap);
 
 /* Copy an intermediate stream back to the host (elements [first, first+count)); returns the
  * number of elements copied, or a negative error.  Element type per the PDT_ST_* table;

@@ -80,6 +80,7 @@ int main(int argc, char **argv)
     double dt = (t1.tv_sec - t0.tv_sec) + 1e-9 * (t1.tv_nsec - t0.tv_nsec);
     fprintf(stderr, "samples %zu frames %zu norm %.9g lock@%ld %.2fHz", nframes, orc_num_frames(p), orc_norm_factor(p),
             orc_lock_sample(p), orc_lock_freq_hz(p));
+    fprintf(stderr, " dsp_seconds %.6f", dt);
     if (timing) fprintf(stderr, " time %.3fs %.3f Msamples/s", dt, nframes / dt / 1e6);
     fprintf(stderr, "\n");
     orc_close(p);

@@ -35,6 +35,7 @@
 #include <math.h>
 #include <unistd.h>
 #include <strings.h>
+#include <time.h>
 
 #ifdef ARGOS
 #define DECIMAL_TYPE double
@@ -55,6 +56,15 @@ int FindSyncWords(unsigned char *, DT *, unsigned long, char *, unsigned int, FI
 #else
 int ByteSyncOnSyncword(unsigned char *, DT *, unsigned long, char *, unsigned int, FILE *);
 #endif
+
+/* bench.py's cpu_baseline leg: seconds spent in the DSP stages (everything after the chunk has been read and converted),
+ * printed beside the totals so that a DSP-only rate can be quoted next to the end-to-end one */
+static double now_s(void)
+{
+    struct timespec ts;
+    clock_gettime(CLOCK_MONOTONIC, &ts);
+    return (double)ts.tv_sec + 1e-9 * (double)ts.tv_nsec;
+}
 
 static FILE *dopen(const char *prefix, const char *ext)
 {
@@ -186,6 +196,7 @@ int main(int argc, char **argv)
     dput(dtaps, filterCoeffs, sizeof(DT), N);
 
     unsigned long i = 0, nSamples, nSymbols, nBits, totalFrames = 0;
+    double dsp_s = 0, t_dsp;
     while (!feof(in)) {
         nSamples = is_raw ? GetComplexRawChunk(in, header, waveData, waveDataTime, chunk)
                           : GetComplexWaveChunk(in, header, waveData, waveDataTime, chunk);
@@ -196,6 +207,7 @@ int main(int argc, char **argv)
         i += nSamples;
         dput(diq, waveData, sizeof(DT complex), nSamples);
         dput(dtime, waveDataTime, sizeof(DT), nSamples);
+        t_dsp = now_s();
 #ifdef ARGOS
         /* ARGOSdemod/main.c:265-284 */
         CarrierTrackPLL(waveData, dataStreamReal, lockSignalStream, nSamples, Fs, (550.0), (0.1),
@@ -247,11 +259,12 @@ int main(int argc, char **argv)
         dput(dbitt, dataStreamLPFTime, sizeof(DT), nBits);
         totalFrames += ByteSyncOnSyncword(dataStreamBits, dataStreamLPFTime, nBits, "1110110111100010000", 19, out);
 #endif
+        dsp_s += now_s() - t_dsp;
         if (dcnt) fprintf(dcnt, "%lu %lu %lu\n", nSamples, nSymbols, nBits);
     }
     fclose(in);
     fclose(out);
     if (totalFrames == 0) remove(argv[optind + 1]);             /* main.c:508-512 */
-    fprintf(stderr, "samples %lu frames %lu norm %.9g\n", i, totalFrames, (double)normFactor);
+    fprintf(stderr, "samples %lu frames %lu norm %.9g dsp_seconds %.6f\n", i, totalFrames, (double)normFactor, dsp_s);
     return 0;
 }

@@ -117,7 +117,7 @@ ABI_SYMBOLS = [
     "pdt_format_frames", "pdt_read_stage", "pdt_stage_len", "pdt_kernel_times", "pdt_make_lpf",
     "pdt_wav_parse_header", "pdt_time_axis", "pdt_stage_bytesync", "pdt_tip_check", "pdt_tip_frames",
     "pdt_stream_begin", "pdt_stream_push_pcm16", "pdt_stream_push_f32", "pdt_stream_end", "pdt_stream_frames",
-    "pdt_keep_presquelch",
+    "pdt_keep_presquelch", "pdt_demod_fd", "pdt_format_records",
 ]
 
 _lib = None
@@ -146,6 +146,9 @@ def lib():
     L.pdt_demod_device.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64]
     L.pdt_demod_f32.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64]
     L.pdt_demod_device_f32.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64]
+    L.pdt_demod_fd.argtypes = [C.c_void_p, C.c_int, C.c_uint64, C.c_uint64, C.c_int]
+    L.pdt_format_records.argtypes = [C.c_void_p, C.c_uint64, C.c_char_p, C.c_uint64]
+    L.pdt_format_records.restype = C.c_uint64
     L.pdt_num_frames.argtypes = [C.c_void_p]
     L.pdt_num_frames.restype = C.c_uint64
     L.pdt_frames.argtypes = [C.c_void_p, C.POINTER(Frame), C.c_uint64]
@@ -265,6 +268,12 @@ class Demodulator:
         _check(self._L.pdt_demod_f32(self._h, a.ctypes.data, a.size // 2), "pdt_demod_f32")
         return self
 
+    def demod_file(self, fd: int, byte_offset: int, nframes: int, fmt: int = 0):
+        """The capture straight from an open file (descriptor `fd`): nframes I,Q pairs from byte_offset (44 after the
+        canonical WAV header, 0 for RAW); fmt 0 = int16 pairs, 1 = float32 pairs."""
+        _check(self._L.pdt_demod_fd(self._h, fd, byte_offset, nframes, fmt), "pdt_demod_fd")
+        return self
+
     def demod_device(self, dev_ptr: int, nframes: int):
         """Input already resident in HBM (e.g. ``tensor.data_ptr()`` of an int16 torch tensor)."""
         _check(self._L.pdt_demod_device(self._h, C.c_void_p(dev_ptr), nframes), "pdt_demod_device")
@@ -380,7 +389,17 @@ assert FRAME_DTYPE.itemsize == C.sizeof(Frame)
 
 
 def format_frames(frames: np.ndarray) -> bytes:
-    """Text of a (possibly gathered) frame array, same rules as ``pdt_format_frames``."""
+    """Text of a (possibly gathered) frame array: ``pdt_format_records`` (host-only C, no GPU needed)."""
+    a = np.ascontiguousarray(frames, dtype=FRAME_DTYPE)
+    L = lib()
+    n = L.pdt_format_records(a.ctypes.data, len(a), None, 0)
+    buf = C.create_string_buffer(n + 1)
+    L.pdt_format_records(a.ctypes.data, len(a), buf, n)
+    return buf.raw[:n]
+
+
+def format_frames_py(frames: np.ndarray) -> bytes:
+    """The same text through Python's own "%.5f" / "%.2X" (the reference's printf formats); used by the tests."""
     out = []
     for f in frames:
         out.append((b"%.5fi " if f["inverted"] else b"%.5f ") % f["time"])

@@ -6,8 +6,12 @@
 #include <stdlib.h>
 #include <string.h>
 
+#include <unistd.h>
+
 #include <algorithm>
+#include <atomic>
 #include <string>
+#include <thread>
 #include <type_traits>
 #include <vector>
 
@@ -76,6 +80,114 @@ struct DevScalars {
     long long agc_first_bad; // first AGC seam that does not close (k_agc_scan -> k_agc_fix)
 };
 
+// ---------------------------------------------------------------- launch plans
+// Every kernel of pdt_kernels_*.h is a __device__ body; it is entered through k_run, which reads the body's
+// arguments from a device array of argument packs indexed by blockIdx.z = the capture.  A demodulation call first
+// records its launches, memsets, stream fork/joins and read-back copies as a PLAN (host only); the plan is then
+// executed -- alone (grid.z = 1) or zipped with the plans of other captures of the same shape (grid.z = M): ONE launch per
+// stage for the whole batch, so that the serial, few-wavefront kernels of all captures run side by side instead of queueing
+// behind each other on the hardware queues (batched many-capture mode).
+template <typename... A> struct Pack {};
+template <typename H, typename... R> struct Pack<H, R...> { H h; Pack<R...> r; };
+template <typename Sig> struct BodyTraits;
+template <typename... P> struct BodyTraits<void (*)(P...)> { using pack = Pack<P...>; };
+
+template <auto Body, typename... Done>
+__device__ __forceinline__ void call_body(const Pack<> &, Done... d) { Body(d...); }
+template <auto Body, typename H, typename... R, typename... Done>
+__device__ __forceinline__ void call_body(const Pack<H, R...> &p, Done... d) { call_body<Body>(p.r, d..., p.h); }
+
+template <auto Body, int TB>
+__global__ void __launch_bounds__(TB) k_run(const typename BodyTraits<decltype(Body)>::pack *__restrict__ packs)
+{
+    call_body<Body>(packs[blockIdx.z]);
+}
+
+inline void pack_fill(Pack<> &) {}
+template <typename H, typename... R, typename A0, typename... AR> void pack_fill(Pack<H, R...> &p, A0 &&a0, AR &&...ar)
+{
+    p.h = (H)a0;
+    pack_fill(p.r, ar...);
+}
+
+typedef void (*GoFn)(dim3, dim3, size_t, hipStream_t, const void *);
+enum { OP_LAUNCH, OP_MEMSET, OP_FORK, OP_JOIN_RECORD, OP_JOIN_WAIT, OP_TBEGIN, OP_TEND, OP_TGAP, OP_D2H, OP_H2D, OP_EV0, OP_EV1 };
+struct PlanOp {
+    int op = OP_LAUNCH, side = 0;
+    GoFn go = nullptr;
+    dim3 grid, block;
+    size_t shmem = 0, pack_off = 0, pack_size = 0;
+    void *dst = nullptr;
+    const void *src = nullptr;
+    int value = 0;
+    size_t bytes = 0;
+    const char *name = nullptr;
+};
+struct Plan {
+    std::vector<PlanOp> ops;
+    std::vector<unsigned char> packs;
+    hipStream_t side_stream = nullptr;             // the context's second stream (launch sites name streams, the plan keeps sides)
+    void clear() { ops.clear(); packs.clear(); }
+    int side_of(hipStream_t s) const { return (side_stream && s == side_stream) ? 1 : 0; }
+    template <auto Body, int TB, typename... A> void launch(const char *kname, dim3 grid, dim3 block, size_t shmem, int side, A &&...args)
+    {
+        using PackT = typename BodyTraits<decltype(Body)>::pack;
+        static_assert(std::is_trivially_copyable<PackT>::value, "kernel arguments travel as plain bytes");
+        PackT pk;
+        memset((void *)&pk, 0, sizeof pk);
+        pack_fill(pk, args...);
+        PlanOp o;
+        o.op = OP_LAUNCH;
+        o.name = kname;
+        o.side = side;
+        o.grid = grid;
+        o.block = block;
+        o.shmem = shmem;
+        o.pack_off = (packs.size() + 15) & ~(size_t)15;
+        o.pack_size = sizeof(PackT);               // the stride k_run indexes the batch's packs with
+        static_assert(alignof(PackT) <= 16, "pack alignment");
+        packs.resize(o.pack_off + o.pack_size, 0);
+        memcpy(packs.data() + o.pack_off, &pk, sizeof pk);
+        o.go = [](dim3 g, dim3 b, size_t sh, hipStream_t st, const void *dp) {
+            hipLaunchKernelGGL((k_run<Body, TB>), g, b, sh, st, (const PackT *)dp);
+        };
+        ops.push_back(o);
+    }
+    void simple(int op, int side = 0, const char *name = nullptr)
+    {
+        PlanOp o;
+        o.op = op; o.side = side; o.name = name;
+        ops.push_back(o);
+    }
+    void memset_async(void *dst, int value, size_t bytes, int side = 0)
+    {
+        PlanOp o;
+        o.op = OP_MEMSET; o.side = side; o.dst = dst; o.value = value; o.bytes = bytes;
+        ops.push_back(o);
+    }
+    void copy(int op, void *dst, const void *src, size_t bytes)
+    {
+        PlanOp o;
+        o.op = op; o.dst = dst; o.src = src; o.bytes = bytes;
+        ops.push_back(o);
+    }
+    // two plans can share their launches when they are the same sequence of operations with the same kernels, block
+    // shapes and LDS sizes (grids may differ: the larger one is launched and every body checks its own bounds)
+    bool same_shape(const Plan &o) const
+    {
+        if (ops.size() != o.ops.size() || packs.size() != o.packs.size()) return false;
+        for (size_t i = 0; i < ops.size(); i++) {
+            const PlanOp &a = ops[i], &b = o.ops[i];
+            if (a.op != b.op || a.side != b.side || a.go != b.go || a.block.x != b.block.x || a.block.y != b.block.y ||
+                a.shmem != b.shmem || a.pack_off != b.pack_off || a.pack_size != b.pack_size)
+                return false;
+        }
+        return true;
+    }
+};
+#define PDT_LAUNCH(TB, KERNEL, grid, block, shmem, stream, ...) \
+    PL.launch<&KERNEL, TB>(#KERNEL, grid, block, shmem, PL.side_of(stream), __VA_ARGS__)
+
 }  // namespace
 
 // Developer switches (A/B runs of older kernel variants, tuning sweeps).  Read from the environment ONCE, when the
@@ -83,7 +195,7 @@ struct DevScalars {
 struct Tuning {
     double pll_warm_scale = 1.0, head_taus = 0.0, agc_k = 0.0;
     int agc_tpb = 0, gseg = 0, acquire_mode = 0;      // acquire_mode: 0 = two-wavefront pipeline, 1 = plain one-lane, 2 = one wavefront
-    bool fir_generic = false, agc_unfused = false, no_excl = false, gtab_nomerge = false, gardner_onebuf = false;
+    bool fir_generic = false, agc_unfused = false, no_excl = false, gtab_nomerge = false, gardner_onebuf = false, debug_sync = false;
     void load()
     {
         if (const char *e = getenv("PDT_PLL_WARM_SCALE")) pll_warm_scale = atof(e);
@@ -98,6 +210,7 @@ struct Tuning {
         no_excl = getenv("PDT_NO_EXCL") != nullptr;
         gtab_nomerge = getenv("PDT_GTAB_NOMERGE") != nullptr;
         gardner_onebuf = getenv("PDT_GARDNER_ONEBUF") != nullptr;
+        debug_sync = getenv("PDT_DEBUG_SYNC") != nullptr;
     }
 };
 
@@ -128,6 +241,18 @@ struct pdt_ctx {
     uint32_t frames_on_device = 0;      // FrameRec records of the last demodulation still in ctx->frames
     bool have_frames = false;           // a demodulation (or stage-level byte sync) has run
     // streaming front end: everything received so far (device), what has been reported
+    Plan plan;                          // the operations of the demodulation call being issued
+    DevBuf packs_dev;                   // argument packs of the plan(s) being executed (this context leads the batch)
+    void *packs_pin = nullptr;          // pinned staging of the same
+    size_t packs_pin_cap = 0;
+    pdt_ctx *leader = nullptr;          // context whose streams / events carried the last execution
+    // host -> HBM ingest of a capture (file or memory): pinned slots filled by a few host threads, copies on a stream of their own
+    void *ingest_pin = nullptr;
+    size_t ingest_pin_cap = 0;
+    hipStream_t copy_stream = nullptr;
+    hipEvent_t ev_ingest = nullptr;
+    std::vector<hipEvent_t> ingest_ev;
+    double ingest_ms = 0;               // host wall time of the last ingest (issue of the last copy)
     DevBuf stream_in;
     uint64_t stream_n = 0, stream_done_chunks = 0, stream_reported = 0;
     int stream_fmt = -1;                // -1 = no push yet, 0 = pcm16, 1 = float32
@@ -221,6 +346,101 @@ class Launcher {
     size_t open_idx = 0;
 };
 
+// run_capture records its timer groups into the plan; the Launcher above turns them into events when the plan runs
+struct PlanGroups {
+    Plan &pl;
+    bool on;
+    void begin(const char *name, hipStream_t s = nullptr) { if (on) pl.simple(OP_TBEGIN, pl.side_of(s), name); }
+    void end() { if (on) pl.simple(OP_TEND); }
+    void gap() { if (on) pl.simple(OP_TGAP); }
+};
+
+
+// Run the plans of M contexts (all of one shape, see Plan::same_shape) as one sequence of operations on the streams of
+// ctxs[0]: each launch covers the M captures through grid.z, memsets and copies are issued per capture.  No host wait.
+int execute_plans(pdt_ctx *const *ctxs, int M)
+{
+    pdt_ctx *L0 = ctxs[0];
+    HIP_TRY(hipSetDevice(L0->cfg.device));
+    const Plan &P0 = L0->plan;
+    for (int m = 1; m < M; m++)
+        if (!P0.same_shape(ctxs[m]->plan)) return PDT_ERR_STATE;
+    const size_t per = P0.packs.size();
+    const size_t total = per * (size_t)M;
+    int rc;
+    if ((rc = L0->packs_dev.ensure(total + 64))) return rc;
+    if (total + 64 > L0->packs_pin_cap) {
+        if (L0->packs_pin) (void)hipHostFree(L0->packs_pin);
+        L0->packs_pin = nullptr;
+        L0->packs_pin_cap = 0;
+        const size_t want = 2 * total + 4096;
+        if (hipHostMalloc(&L0->packs_pin, want, hipHostMallocDefault) != hipSuccess) { (void)hipGetLastError(); return PDT_ERR_NOMEM; }
+        L0->packs_pin_cap = want;
+    }
+    // pack of capture m for the launch at offset `off`: M * off + m * size
+    unsigned char *pin = (unsigned char *)L0->packs_pin;
+    for (const PlanOp &o : P0.ops) {
+        if (o.op != OP_LAUNCH) continue;
+        for (int m = 0; m < M; m++)
+            memcpy(pin + (size_t)M * o.pack_off + (size_t)m * o.pack_size, ctxs[m]->plan.packs.data() + o.pack_off, o.pack_size);
+    }
+    hipStream_t st[2] = { L0->stream, L0->stream2 };
+    if (total) HIP_TRY(hipMemcpyAsync(L0->packs_dev.p, pin, total, hipMemcpyHostToDevice, st[0]));
+    Launcher T(L0);
+    const unsigned char *dev = (const unsigned char *)L0->packs_dev.p;
+    for (size_t i = 0; i < P0.ops.size(); i++) {
+        const PlanOp &o = P0.ops[i];
+        switch (o.op) {
+        case OP_LAUNCH: {
+            dim3 g = o.grid;
+            for (int m = 1; m < M; m++) {
+                const dim3 gm = ctxs[m]->plan.ops[i].grid;
+                g.x = std::max(g.x, gm.x);
+                g.y = std::max(g.y, gm.y);
+            }
+            g.z = (unsigned)M;
+            o.go(g, o.block, o.shmem, st[o.side], dev + (size_t)M * o.pack_off);
+            if (L0->tune.debug_sync) {                                  // developer switch: find the launch that faults
+                const hipError_t e = hipStreamSynchronize(st[o.side]);
+                fprintf(stderr, "libpdt: [%zu] %s grid (%u,%u,%u) block %u lds %zu: %s\n", i, o.name, g.x, g.y, g.z, o.block.x, o.shmem,
+                        hipGetErrorString(e));
+            }
+            break;
+        }
+        case OP_MEMSET:
+            for (int m = 0; m < M; m++) {
+                const PlanOp &om = ctxs[m]->plan.ops[i];
+                if (om.bytes) HIP_TRY(hipMemsetAsync(om.dst, om.value, om.bytes, st[om.side]));
+            }
+            T.gap();
+            break;
+        case OP_D2H:
+        case OP_H2D:
+            for (int m = 0; m < M; m++) {
+                const PlanOp &om = ctxs[m]->plan.ops[i];
+                if (om.bytes)
+                    HIP_TRY(hipMemcpyAsync(om.dst, om.src, om.bytes, o.op == OP_D2H ? hipMemcpyDeviceToHost : hipMemcpyHostToDevice, st[0]));
+            }
+            T.gap();
+            break;
+        case OP_FORK:
+            HIP_TRY(hipEventRecord(L0->ev_fork, st[0]));
+            HIP_TRY(hipStreamWaitEvent(st[1], L0->ev_fork, 0));
+            break;
+        case OP_JOIN_RECORD: HIP_TRY(hipEventRecord(L0->ev_join, st[1])); break;
+        case OP_JOIN_WAIT: HIP_TRY(hipStreamWaitEvent(st[0], L0->ev_join, 0)); break;
+        case OP_TBEGIN: T.begin(o.name, st[o.side]); break;
+        case OP_TEND: T.end(); break;
+        case OP_TGAP: T.gap(); break;
+        case OP_EV0: HIP_TRY(hipEventRecord(L0->ev0, st[0])); break;
+        case OP_EV1: HIP_TRY(hipEventRecord(L0->ev1, st[0])); break;
+        }
+    }
+    HIP_TRY(hipGetLastError());
+    for (int m = 0; m < M; m++) ctxs[m]->leader = L0;
+    return PDT_OK;
+}
+
 template <typename T> PllParams<T> make_pll_params(const pdt_ctx *ctx)
 {
     // call-site constants: POESTIPdemod/main.c:32-46,413 / ARGOSdemod/main.c:33-44,265
@@ -298,7 +518,7 @@ SyncParams make_sync_params(bool argos)
     return SP;
 }
 
-void launch_bytesync(pdt_ctx *ctx, hipStream_t st, const SyncParams &SP, DevScalars *d_sc, long long bit_cap, uint32_t hit_cap,
+void launch_bytesync(pdt_ctx *ctx, Plan &PL, hipStream_t st, const SyncParams &SP, DevScalars *d_sc, long long bit_cap, uint32_t hit_cap,
                      uint32_t frame_cap)
 {
     unsigned char *d_bits = (unsigned char *)ctx->bits.p;
@@ -308,17 +528,17 @@ void launch_bytesync(pdt_ctx *ctx, hipStream_t st, const SyncParams &SP, DevScal
     FrameRec *d_frames = (FrameRec *)ctx->frames.p;
     const long long n_stiles = (bit_cap + 4095) / 4096;
     SyncTile *d_stiles = (SyncTile *)ctx->stiles.p;
-    hipLaunchKernelGGL(k_sync_hits_tile, dim3((unsigned)n_stiles), dim3(256), 0, st, d_bits, &d_sc->nbits, SP, d_stiles,
+    PDT_LAUNCH(256, k_sync_hits_tile, dim3((unsigned)n_stiles), dim3(256), 0, st, d_bits, &d_sc->nbits, SP, d_stiles,
                        &d_sc->sync_overflow);
-    hipLaunchKernelGGL(k_sync_frames_tiles, dim3(1), dim3(PDT_SYNC_THREADS), 0, st, (const SyncTile *)d_stiles, &d_sc->nbits, SP, d_hits, hit_cap,
+    PDT_LAUNCH(PDT_SYNC_THREADS, k_sync_frames_tiles, dim3(1), dim3(PDT_SYNC_THREADS), 0, st, (const SyncTile *)d_stiles, &d_sc->nbits, SP, d_hits, hit_cap,
                        d_frames, &d_sc->nframes, frame_cap, &d_sc->sync_overflow, (unsigned *)ctx->sync_scr.p);
     // generic path (atomic append + sort), only when a tile overflowed
     const long long grid = (bit_cap + 255) / 256;
-    hipLaunchKernelGGL(k_sync_hits, dim3((unsigned)grid), dim3(256), 0, st, d_bits, &d_sc->nbits, SP, d_hits, &d_sc->nhits, hit_cap,
+    PDT_LAUNCH(256, k_sync_hits, dim3((unsigned)grid), dim3(256), 0, st, d_bits, &d_sc->nbits, SP, d_hits, &d_sc->nhits, hit_cap,
                        &d_sc->sync_overflow);
-    hipLaunchKernelGGL(k_sync_frames, dim3(1), dim3(256), 0, st, d_hits, &d_sc->nhits, hit_cap, SP, d_frames, &d_sc->nframes,
+    PDT_LAUNCH(256, k_sync_frames, dim3(1), dim3(256), 0, st, d_hits, &d_sc->nhits, hit_cap, SP, d_frames, &d_sc->nframes,
                        frame_cap, &d_sc->sync_overflow);
-    hipLaunchKernelGGL(k_frame_pack, dim3(frame_cap), dim3(128), 0, st, d_bits, &d_sc->nbits, d_bitsym, d_symidx, SP, d_frames,
+    PDT_LAUNCH(128, k_frame_pack, dim3(frame_cap), dim3(128), 0, st, d_bits, &d_sc->nbits, d_bitsym, d_symidx, SP, d_frames,
                        &d_sc->nframes, frame_cap);
 }
 
@@ -340,7 +560,8 @@ template <typename T> int run_capture(pdt_ctx *ctx, uint64_t n, int phase = RUN_
     const long long chunk = (long long)ctx->cfg.chunk;
     const long long chunk_out = chunk * interp;
     hipStream_t st = ctx->stream;
-    Launcher L(ctx);
+    Plan &PL = ctx->plan;
+    PlanGroups L{PL, ctx->cfg.profile != 0};
 
     // ---- parameters
     const T Fs = (T)ctx->cfg.sample_rate;
@@ -479,13 +700,15 @@ template <typename T> int run_capture(pdt_ctx *ctx, uint64_t n, int phase = RUN_
     T *d_taps = (T *)ctx->taps.p;
 
     if (phase != RUN_FINISH) {
-    HIP_TRY(hipEventRecord(ctx->ev0, st));
-    HIP_TRY(hipMemsetAsync(d_sc, 0, sizeof(DevScalars), st));
-    HIP_TRY(hipMemsetAsync(d_frames, 0, (size_t)frame_cap * sizeof(FrameRec), st));
+    PL.clear();
+    PL.side_stream = ctx->stream2;
+    PL.simple(OP_EV0);
+    PL.memset_async(d_sc, 0, sizeof(DevScalars));
+    PL.memset_async(d_frames, 0, (size_t)frame_cap * sizeof(FrameRec));
 
     // ---- StaticGain over the first chunk (main.c:384-389)
     L.begin("static_gain");
-    hipLaunchKernelGGL(k_static_gain<T>, dim3(1), dim3(256), 0, st, d_pcm, n0, (T *)ctx->mag.p, (T)1.0,
+    PDT_LAUNCH(256, k_static_gain<T>, dim3(1), dim3(256), 0, st, d_pcm, n0, (T *)ctx->mag.p, (T)1.0,
                        ctx->cfg.norm_override, d_norm);
     L.end();
 
@@ -495,7 +718,7 @@ template <typename T> int run_capture(pdt_ctx *ctx, uint64_t n, int phase = RUN_
     T *d_phi = d_agc;
     if (N > 0) {
         L.begin("pll_theta");
-        hipLaunchKernelGGL(k_pll_theta<T>, dim3((unsigned)((N + 1023) / 1024)), dim3(256), 0, st, d_pcm, N, d_theta);   // 4 samples per thread
+        PDT_LAUNCH(256, k_pll_theta<T>, dim3((unsigned)((N + 1023) / 1024)), dim3(256), 0, st, d_pcm, N, d_theta);   // 4 samples per thread
         L.end();
     }
     // fork: the block-parallel phase recurrence (side stream) runs beside the sequential acquisition
@@ -506,39 +729,38 @@ template <typename T> int run_capture(pdt_ctx *ctx, uint64_t n, int phase = RUN_
                                                                 (double)PP.alpha_wide + (double)PP.beta_wide});
     const bool slow_wrap = worst >= 2.0 * M_PI - 0.05;
     if (N > 0) {
-        HIP_TRY(hipEventRecord(ctx->ev_fork, st));
-        HIP_TRY(hipStreamWaitEvent(ctx->stream2, ctx->ev_fork, 0));
+        PL.simple(OP_FORK);
         L.begin("pll_phase", ctx->stream2);
         if (slow_wrap)
-            hipLaunchKernelGGL((k_pll_phase<T, true>), dim3((unsigned)grid_pll), dim3(64), 0, ctx->stream2, d_pcm, d_theta, N, PP, Bp,
+            PDT_LAUNCH(64, (k_pll_phase<T, true>), dim3((unsigned)grid_pll), dim3(64), 0, ctx->stream2, d_pcm, d_theta, N, PP, Bp,
                                Wacq, Wp, lag, d_phi, (PllSeam<T> *)ctx->seams_pll.p);
         else
-            hipLaunchKernelGGL((k_pll_phase<T, false>), dim3((unsigned)grid_pll), dim3(64), 0, ctx->stream2, d_pcm, d_theta, N, PP, Bp,
+            PDT_LAUNCH(64, (k_pll_phase<T, false>), dim3((unsigned)grid_pll), dim3(64), 0, ctx->stream2, d_pcm, d_theta, N, PP, Bp,
                                Wacq, Wp, lag, d_phi, (PllSeam<T> *)ctx->seams_pll.p);
         L.end();
-        HIP_TRY(hipEventRecord(ctx->ev_join, ctx->stream2));
+        PL.simple(OP_JOIN_RECORD);
     }
     // the serial kernels (acquisition, head) ask for SIMDs of their own while the block-parallel kernel beside them
     // leaves some free (1 024 SIMDs; it runs one wavefront per 64 blocks)
     const bool serial_excl = grid_pll <= 768 && !ctx->tune.no_excl;
     L.begin("pll_acquire");
     if (ctx->tune.acquire_mode == 1)        // plain one-lane form, kept for A/B checks
-        hipLaunchKernelGGL(k_pll_acquire<T>, dim3(1), dim3(64), 0, st, d_pcm, N, PP, d_pll, d_lock, d_info);
+        PDT_LAUNCH(64, k_pll_acquire<T>, dim3(1), dim3(64), 0, st, d_pcm, N, PP, d_pll, d_lock, d_info);
     else if (ctx->tune.acquire_mode == 2) {   // single-wavefront batched form, kept for A/B checks
         if (slow_wrap)
-            hipLaunchKernelGGL((k_pll_acquire_fast<T, true>), dim3(1), dim3(64), 0, st, d_pcm, (const T *)d_theta, N, PP, d_pll, d_lock,
+            PDT_LAUNCH(64, (k_pll_acquire_fast<T, true>), dim3(1), dim3(64), 0, st, d_pcm, (const T *)d_theta, N, PP, d_pll, d_lock,
                                d_info);
         else
-            hipLaunchKernelGGL((k_pll_acquire_fast<T, false>), dim3(1), dim3(64), 0, st, d_pcm, (const T *)d_theta, N, PP, d_pll, d_lock,
+            PDT_LAUNCH(64, (k_pll_acquire_fast<T, false>), dim3(1), dim3(64), 0, st, d_pcm, (const T *)d_theta, N, PP, d_pll, d_lock,
                                d_info);
     } else if (slow_wrap)
-        hipLaunchKernelGGL((k_pll_acquire_pipe<T, true>), dim3(1), dim3(128), 0, st, d_pcm, (const T *)d_theta, N, PP, d_pll, d_lock,
+        PDT_LAUNCH(128, (k_pll_acquire_pipe<T, true>), dim3(1), dim3(128), 0, st, d_pcm, (const T *)d_theta, N, PP, d_pll, d_lock,
                            d_info);
     else if (serial_excl)
-        hipLaunchKernelGGL((k_pll_acquire_pipe<T, false, true>), dim3(1), dim3(128), 0, st, d_pcm, (const T *)d_theta, N, PP, d_pll, d_lock,
+        PDT_LAUNCH(128, (k_pll_acquire_pipe<T, false, true>), dim3(1), dim3(128), 0, st, d_pcm, (const T *)d_theta, N, PP, d_pll, d_lock,
                            d_info);
     else
-        hipLaunchKernelGGL((k_pll_acquire_pipe<T, false>), dim3(1), dim3(128), 0, st, d_pcm, (const T *)d_theta, N, PP, d_pll, d_lock,
+        PDT_LAUNCH(128, (k_pll_acquire_pipe<T, false>), dim3(1), dim3(128), 0, st, d_pcm, (const T *)d_theta, N, PP, d_pll, d_lock,
                            d_info);
     L.end();
     if (N > 0) {
@@ -561,47 +783,47 @@ template <typename T> int run_capture(pdt_ctx *ctx, uint64_t n, int phase = RUN_
         if ((rc = ctx->pll_scratch.ensure((size_t)(PDT_FIX_THREADS / 64) * (size_t)(((Bp + 63) & ~63ll) + 64) * sizeof(T)))) return rc;
         L.begin("pll_head");
         if (slow_wrap)
-            hipLaunchKernelGGL((k_pll_head<T, true>), dim3(1), dim3(64), 0, st, d_theta, N, PP, d_info, Bp, Hd, d_hphi, d_hseams,
+            PDT_LAUNCH(64, (k_pll_head<T, true>), dim3(1), dim3(64), 0, st, d_theta, N, PP, d_info, Bp, Hd, d_hphi, d_hseams,
                                d_hinfo, head_blocks);
         else if (serial_excl)
-            hipLaunchKernelGGL((k_pll_head<T, false, true>), dim3(1), dim3(64), 0, st, d_theta, N, PP, d_info, Bp, Hd, d_hphi, d_hseams,
+            PDT_LAUNCH(64, (k_pll_head<T, false, true>), dim3(1), dim3(64), 0, st, d_theta, N, PP, d_info, Bp, Hd, d_hphi, d_hseams,
                                d_hinfo, head_blocks);
         else
-            hipLaunchKernelGGL((k_pll_head<T, false>), dim3(1), dim3(64), 0, st, d_theta, N, PP, d_info, Bp, Hd, d_hphi, d_hseams,
+            PDT_LAUNCH(64, (k_pll_head<T, false>), dim3(1), dim3(64), 0, st, d_theta, N, PP, d_info, Bp, Hd, d_hphi, d_hseams,
                                d_hinfo, head_blocks);
         L.end();
-        HIP_TRY(hipStreamWaitEvent(st, ctx->ev_join, 0));                  // join
+        PL.simple(OP_JOIN_WAIT);                                           // join
         L.gap();                                                           // (the wait is not part of pll_fix)
         L.begin("pll_fix");
         if (slow_wrap)
-            hipLaunchKernelGGL((k_pll_fix<T, true>), dim3(1), dim3(PDT_FIX_THREADS), 0, st, d_theta, N, PP, d_info, Bp, d_phi,
+            PDT_LAUNCH(PDT_FIX_THREADS, (k_pll_fix<T, true>), dim3(1), dim3(PDT_FIX_THREADS), 0, st, d_theta, N, PP, d_info, Bp, d_phi,
                                (PllSeam<T> *)ctx->seams_pll.p, (const T *)d_hphi, (const PllSeam<T> *)d_hseams,
                                (const PllHeadInfo<T> *)d_hinfo, (T *)ctx->pll_scratch.p, d_sc->counters);
         else
-            hipLaunchKernelGGL((k_pll_fix<T, false>), dim3(1), dim3(PDT_FIX_THREADS), 0, st, d_theta, N, PP, d_info, Bp, d_phi,
+            PDT_LAUNCH(PDT_FIX_THREADS, (k_pll_fix<T, false>), dim3(1), dim3(PDT_FIX_THREADS), 0, st, d_theta, N, PP, d_info, Bp, d_phi,
                                (PllSeam<T> *)ctx->seams_pll.p, (const T *)d_hphi, (const PllSeam<T> *)d_hseams,
                                (const PllHeadInfo<T> *)d_hinfo, (T *)ctx->pll_scratch.p, d_sc->counters);
         L.end();
         (void)grid;
         L.begin("pll_mix");
         if (need_lock)
-            hipLaunchKernelGGL((k_pll_mix<T, true>), dim3((unsigned)((N + 1023) / 1024)), dim3(256), 0, st, d_pcm, d_phi, N, PP,
+            PDT_LAUNCH(256, (k_pll_mix<T, true>), dim3((unsigned)((N + 1023) / 1024)), dim3(256), 0, st, d_pcm, d_phi, N, PP,
                                d_info, d_pll, (T *)ctx->term.p);
         else
-            hipLaunchKernelGGL((k_pll_mix<T, false>), dim3((unsigned)((N + 1023) / 1024)), dim3(256), 0, st, d_pcm, d_phi, N, PP,
+            PDT_LAUNCH(256, (k_pll_mix<T, false>), dim3((unsigned)((N + 1023) / 1024)), dim3(256), 0, st, d_pcm, d_phi, N, PP,
                                d_info, d_pll, (T *)nullptr);
         L.end();
         if (need_lock) {
             L.begin("lock_ema");
-            hipLaunchKernelGGL(k_lock_ema<T>, dim3((unsigned)((nb_ema + 63) / 64)), dim3(64), 0, st, (const T *)ctx->term.p, N, PP.lock_alpha,
+            PDT_LAUNCH(64, k_lock_ema<T>, dim3((unsigned)((nb_ema + 63) / 64)), dim3(64), 0, st, (const T *)ctx->term.p, N, PP.lock_alpha,
                                d_info, Be, We, d_lock, (EmaSeam<T> *)ctx->seams_ema.p);
-            hipLaunchKernelGGL(k_lock_ema_fix<T>, dim3(1), dim3(64), 0, st, (const T *)ctx->term.p, N, PP.lock_alpha, d_info,
+            PDT_LAUNCH(64, k_lock_ema_fix<T>, dim3(1), dim3(64), 0, st, (const T *)ctx->term.p, N, PP.lock_alpha, d_info,
                                Be, d_lock, (EmaSeam<T> *)ctx->seams_ema.p, &d_sc->counters[1]);
             L.end();
         }
         if (live) {                                            // twin main.c:370, DSP_SQLCH_THRESH 0.05 (:55)
             L.begin("squelch");
-            hipLaunchKernelGGL(k_squelch<T>, dim3((unsigned)((N + 1023) / 1024)), dim3(256), 0, st, d_pll, (const T *)d_lock, N, (T)0.05);
+            PDT_LAUNCH(256, k_squelch<T>, dim3((unsigned)((N + 1023) / 1024)), dim3(256), 0, st, d_pll, (const T *)d_lock, N, (T)0.05);
             L.end();
         }
     }
@@ -614,7 +836,7 @@ template <typename T> int run_capture(pdt_ctx *ctx, uint64_t n, int phase = RUN_
         L.begin("fir");
         if (argos) {
             const size_t sh = (size_t)(ntaps + tile + ntaps + 8) * sizeof(T);
-            hipLaunchKernelGGL(k_fir_plain<T>, dim3((unsigned)grid), dim3(PDT_FIR_THREADS), sh, st, d_pll, N, ntaps, d_taps,
+            PDT_LAUNCH(PDT_FIR_THREADS, k_fir_plain<T>, dim3((unsigned)grid), dim3(PDT_FIR_THREADS), sh, st, d_pll, N, ntaps, d_taps,
                                d_fir, opt);
         } else {
             const int K = ntaps / interp;
@@ -634,7 +856,7 @@ template <typename T> int run_capture(pdt_ctx *ctx, uint64_t n, int phase = RUN_
                 switch (interp) {
 #define PDT_FIR_CASE(I)                                                                                                       \
     case I:                                                                                                                   \
-        hipLaunchKernelGGL((k_fir_interp_rt<T, I, 26>), dim3(grid_rt), dim3(PDT_FIR_THREADS), sh_rt, st, d_pll, N, (const T *)ctx->taps_rot.p, d_fir, \
+        PDT_LAUNCH(PDT_FIR_THREADS, (k_fir_interp_rt<T, I, 26>), dim3(grid_rt), dim3(PDT_FIR_THREADS), sh_rt, st, d_pll, N, (const T *)ctx->taps_rot.p, d_fir, \
                            fir_tile_maps, AP.decay);                                                                                    \
         break;
                     PDT_FIR_CASE(1) PDT_FIR_CASE(2) PDT_FIR_CASE(3) PDT_FIR_CASE(4) PDT_FIR_CASE(5) PDT_FIR_CASE(6)
@@ -645,7 +867,7 @@ template <typename T> int run_capture(pdt_ctx *ctx, uint64_t n, int phase = RUN_
             if (!done) fused_tiles = 0;
             if (!done) {                                       // any other interpolation factor: generic form
                 const size_t sh = (size_t)(ntaps + tile / interp + K + 8) * sizeof(T);
-                hipLaunchKernelGGL(k_fir_interp<T>, dim3((unsigned)grid), dim3(PDT_FIR_THREADS), sh, st, d_pll, N, interp, K,
+                PDT_LAUNCH(PDT_FIR_THREADS, k_fir_interp<T>, dim3((unsigned)grid), dim3(PDT_FIR_THREADS), sh, st, d_pll, N, interp, K,
                                    d_taps, d_fir, opt);
             }
         }
@@ -665,15 +887,15 @@ template <typename T> int run_capture(pdt_ctx *ctx, uint64_t n, int phase = RUN_
         double agc_K = (sizeof(T) == 4) ? 11.0 : 34.0;
         if (ctx->tune.agc_k > 0) agc_K = ctx->tune.agc_k;
         L.begin("agc_block");
-        if (!fused) hipLaunchKernelGGL(k_agc_affine<T>, dim3((unsigned)nb), dim3(256), 0, st, d_fir, n_out, AP.decay, Ba, d_maps);
-        hipLaunchKernelGGL(k_agc_guess<T>, dim3(1), dim3(1024), 0, st, (const AgcMap *)d_maps, nb, (const T *)d_norm, d_guess,
+        if (!fused) PDT_LAUNCH(256, k_agc_affine<T>, dim3((unsigned)nb), dim3(256), 0, st, d_fir, n_out, AP.decay, Ba, d_maps);
+        PDT_LAUNCH(1024, k_agc_guess<T>, dim3(1), dim3(1024), 0, st, (const AgcMap *)d_maps, nb, (const T *)d_norm, d_guess,
                            fused ? (int)agc_tiles_per_block : 1, fused ? fused_tiles : nb);
-        hipLaunchKernelGGL(k_agc_block<T>, dim3((unsigned)grid), dim3(64), 0, st, d_fir, n_out, AP, d_norm, Ba, Wa,
+        PDT_LAUNCH(64, k_agc_block<T>, dim3((unsigned)grid), dim3(64), 0, st, d_fir, n_out, AP, d_norm, Ba, Wa,
                            (const double *)d_guess, d_lock, d_agc, (AgcSeam<T> *)ctx->seams_agc.p, agc_K);
         L.end();
         L.begin("agc_fix");
-        hipLaunchKernelGGL(k_agc_scan<T>, dim3(1), dim3(1024), 0, st, n_out, Ba, (const AgcSeam<T> *)ctx->seams_agc.p, &d_sc->agc_first_bad);
-        hipLaunchKernelGGL(k_agc_fix<T>, dim3(1), dim3(64), 0, st, d_fir, n_out, AP, Ba, d_lock, d_agc,
+        PDT_LAUNCH(1024, k_agc_scan<T>, dim3(1), dim3(1024), 0, st, n_out, Ba, (const AgcSeam<T> *)ctx->seams_agc.p, &d_sc->agc_first_bad);
+        PDT_LAUNCH(64, k_agc_fix<T>, dim3(1), dim3(64), 0, st, d_fir, n_out, AP, Ba, d_lock, d_agc,
                            (AgcSeam<T> *)ctx->seams_agc.p, d_sc->counters, (const long long *)&d_sc->agc_first_bad);
         L.end();
     }
@@ -742,8 +964,8 @@ template <typename T> int run_capture(pdt_ctx *ctx, uint64_t n, int phase = RUN_
             if ((rc = ctx->gbands.ensure((size_t)n_tab * sizeof(GardnerBand)))) return rc;
             L.begin("gardner_table");
             if ((rc = ctx->gclist.ensure((size_t)n_tab * PDT_GTAB_LIST * sizeof(unsigned)))) return rc;
-            HIP_TRY(hipMemsetAsync(ctx->gtable.p, 0xff, (size_t)n_tab * (size_t)(2 * GD.n_q) * sizeof(unsigned), st));   // PDT_GTAB_MISS
-            hipLaunchKernelGGL(k_gardner_scout, dim3((unsigned)n_tab), dim3(64), 0, st, (const float *)d_agc, GP, GD, n_tab,
+            PL.memset_async(ctx->gtable.p, 0xff, (size_t)n_tab * (size_t)(2 * GD.n_q) * sizeof(unsigned));   // PDT_GTAB_MISS
+            PDT_LAUNCH(64, k_gardner_scout, dim3((unsigned)n_tab), dim3(64), 0, st, (const float *)d_agc, GP, GD, n_tab,
                                (const int *)ctx->gmfirst.p, (const unsigned *)ctx->gcand.p, (unsigned *)ctx->gtable.p,
                                (GardnerBand *)ctx->gbands.p, (unsigned *)ctx->gclist.p, d_sc->gstats);
             {
@@ -751,12 +973,12 @@ template <typename T> int run_capture(pdt_ctx *ctx, uint64_t n, int phase = RUN_
                 if (ctx->tune.gtab_nomerge) {
                     constexpr int TT = PDT_GTAB_THREADS, TW = PDT_GTAB_WIN;
                     const unsigned parts = (unsigned)((GD.n_cand + 2 * TT - 1) / (2 * TT));
-                    hipLaunchKernelGGL((k_gardner_table<TT, TW>), dim3((unsigned)n_tab, parts), dim3(TT), 0, st, (const float *)d_agc, GP,
+                    PDT_LAUNCH(PDT_GTAB_THREADS, (k_gardner_table<TT, TW>), dim3((unsigned)n_tab, parts), dim3(TT), 0, st, (const float *)d_agc, GP,
                                        GD, n_tab, (const unsigned *)ctx->gcand.p, (const GardnerBand *)ctx->gbands.p,
                                        (const unsigned *)ctx->gclist.p, (unsigned *)ctx->gtable.p, d_sc->gstats);
                 } else {
                     const unsigned parts = (unsigned)((GD.n_cand + PDT_GTM_SLOTS - 1) / PDT_GTM_SLOTS);
-                    hipLaunchKernelGGL((k_gardner_table_merge<PDT_GTAB_WIN>), dim3((unsigned)n_tab, parts), dim3(PDT_GTM_THREADS), 0, st,
+                    PDT_LAUNCH(PDT_GTM_THREADS, (k_gardner_table_merge<PDT_GTAB_WIN>), dim3((unsigned)n_tab, parts), dim3(PDT_GTM_THREADS), 0, st,
                                        (const float *)d_agc, GP, GD, n_tab, (const unsigned *)ctx->gcand.p,
                                        (const GardnerBand *)ctx->gbands.p, (const unsigned *)ctx->gclist.p,
                                        (unsigned *)ctx->gtable.p, d_sc->gstats);
@@ -772,21 +994,21 @@ template <typename T> int run_capture(pdt_ctx *ctx, uint64_t n, int phase = RUN_
             if ((rc = ctx->gsegmap.ensure((size_t)n_seg * (size_t)(2 * GD.n_q) * sizeof(GardnerSegCell)))) return rc;
             if ((rc = ctx->gsegstart.ensure((size_t)n_seg * sizeof(GardnerSegStart)))) return rc;
             L.begin("gardner_chain");
-            HIP_TRY(hipMemsetAsync(ctx->gsegstart.p, 0, (size_t)n_seg * sizeof(GardnerSegStart), st));
-            hipLaunchKernelGGL(k_gardner_segmap, dim3((unsigned)n_seg), dim3(1024), 0, st, (const unsigned *)ctx->gtable.p, GD, n_chunks,
+            PL.memset_async(ctx->gsegstart.p, 0, (size_t)n_seg * sizeof(GardnerSegStart));
+            PDT_LAUNCH(1024, k_gardner_segmap, dim3((unsigned)n_seg), dim3(1024), 0, st, (const unsigned *)ctx->gtable.p, GD, n_chunks,
                                G, (GardnerSegCell *)ctx->gsegmap.p);
-            hipLaunchKernelGGL(k_gardner_chain, dim3(1), dim3(256), 0, st,      // 4 wavefronts: a walked chunk is staged 4x faster
+            PDT_LAUNCH(256, k_gardner_chain, dim3(1), dim3(256), 0, st,      // 4 wavefronts: a walked chunk is staged 4x faster
                                (const float *)d_agc, GP, GD, n_chunks,
                                (const unsigned *)ctx->gtable.p, (const GardnerSegCell *)ctx->gsegmap.p, G,
                                (GardnerSegStart *)ctx->gsegstart.p, (GardnerEntry<float> *)ctx->gentries.p, d_sc->gstats,
                                (const GardnerBand *)ctx->gbands.p, n_tab);
-            hipLaunchKernelGGL(k_gardner_segfill, dim3((unsigned)n_seg), dim3(64), 0, st, (const float *)d_agc, GP, GD, n_chunks,
+            PDT_LAUNCH(64, k_gardner_segfill, dim3((unsigned)n_seg), dim3(64), 0, st, (const float *)d_agc, GP, GD, n_chunks,
                                (const unsigned *)ctx->gtable.p, G, (const GardnerSegStart *)ctx->gsegstart.p,
                                (GardnerEntry<float> *)ctx->gentries.p);
             L.end();
             L.begin("gardner");
             // per-chunk emission: small LDS windows so that every chunk of a 10-minute capture is resident at once
-            hipLaunchKernelGGL((k_gardner<float, PDT_GEMIT_LEN, PDT_GEMIT_OUT>), dim3((unsigned)n_chunks), dim3(PDT_GARDNER_THREADS), 0, st, (const float *)d_agc,
+            PDT_LAUNCH(256, (k_gardner<float, PDT_GEMIT_LEN, PDT_GEMIT_OUT>), dim3((unsigned)n_chunks), dim3(PDT_GARDNER_THREADS), 0, st, (const float *)d_agc,
                                (const float *)d_lock, GP, (float *)d_sym, d_symidx, &d_sc->nsym, sym_cap,
                                (const GardnerEntry<float> *)ctx->gentries.p);
             L.end();
@@ -802,7 +1024,7 @@ template <typename T> int run_capture(pdt_ctx *ctx, uint64_t n, int phase = RUN_
         MP.n_total = n_out;
         MP.chunk_out = chunk_out;
         L.begin("gardner");
-        hipLaunchKernelGGL((k_mm<T, 8192, 1024>), dim3(1), dim3(PDT_GARDNER_THREADS), 0, st, (const T *)d_agc, MP, d_sym, d_symidx,
+        PDT_LAUNCH(PDT_GARDNER_THREADS, (k_mm<T, 8192, 1024>), dim3(1), dim3(PDT_GARDNER_THREADS), 0, st, (const T *)d_agc, MP, d_sym, d_symidx,
                            &d_sc->nsym, sym_cap);
         L.end();
     } else {
@@ -811,29 +1033,28 @@ template <typename T> int run_capture(pdt_ctx *ctx, uint64_t n, int phase = RUN_
         const long long small_need = chunk_out + 2 * (long long)GP.step + 24;
         const double small_syms = (double)chunk_out / ((double)GP.step - 0.25) + 4.0;
         if (small_need <= SMALL_LEN && small_syms < SMALL_OUT && !ctx->tune.gardner_onebuf)
-            hipLaunchKernelGGL((k_gardner_small<T, SMALL_LEN, SMALL_OUT>), dim3(1), dim3(256), 0, st, (const T *)d_agc, (const T *)d_lock, GP,
+            PDT_LAUNCH(256, (k_gardner_small<T, SMALL_LEN, SMALL_OUT>), dim3(1), dim3(256), 0, st, (const T *)d_agc, (const T *)d_lock, GP,
                                d_sym, d_symidx, &d_sc->nsym, sym_cap);
         else
-            hipLaunchKernelGGL((k_gardner<T, GardnerLds<T>::LEN, GardnerLds<T>::OUT>), dim3(1), dim3(256), 0, st, d_agc, d_lock, GP, d_sym, d_symidx,
+            PDT_LAUNCH(256, (k_gardner<T, GardnerLds<T>::LEN, GardnerLds<T>::OUT>), dim3(1), dim3(256), 0, st, d_agc, d_lock, GP, d_sym, d_symidx,
                                &d_sc->nsym, sym_cap, (const GardnerEntry<T> *)nullptr);
         L.end();
     }
 
     // ---- Manchester
     L.begin("manchester");
-    hipLaunchKernelGGL(k_manch_tile<T>, dim3((unsigned)n_tiles), dim3(PDT_TILE_THREADS), 0, st, d_sym, &d_sc->nsym, manch_thr,
+    PDT_LAUNCH(PDT_TILE_THREADS, k_manch_tile<T>, dim3((unsigned)n_tiles), dim3(PDT_TILE_THREADS), 0, st, d_sym, &d_sc->nsym, manch_thr,
                        d_tiles);
-    hipLaunchKernelGGL(k_manch_scan, dim3(1), dim3(1024), 0, st, d_tiles, &d_sc->nsym, &d_sc->nbits);
-    hipLaunchKernelGGL(k_manch_emit<T>, dim3((unsigned)n_tiles), dim3(PDT_TILE_THREADS), 0, st, d_sym, &d_sc->nsym, manch_thr,
+    PDT_LAUNCH(1024, k_manch_scan, dim3(1), dim3(1024), 0, st, d_tiles, &d_sc->nsym, &d_sc->nbits);
+    PDT_LAUNCH(PDT_TILE_THREADS, k_manch_emit<T>, dim3((unsigned)n_tiles), dim3(PDT_TILE_THREADS), 0, st, d_sym, &d_sc->nsym, manch_thr,
                        d_tiles, d_bits, d_bitsym, bit_cap);
     L.end();
 
     // ---- byte sync
     L.begin("bytesync");
-    launch_bytesync(ctx, st, SP, d_sc, bit_cap, hit_cap, frame_cap);
+    launch_bytesync(ctx, PL, st, SP, d_sc, bit_cap, hit_cap, frame_cap);
     L.end();
-    HIP_TRY(hipEventRecord(ctx->ev1, st));
-    HIP_TRY(hipGetLastError());
+    PL.simple(OP_EV1);
 
     // ---- results back to the host
     // one synchronisation: the scalars, the lock record and (speculatively, into pinned memory) as many frame
@@ -849,17 +1070,22 @@ template <typename T> int run_capture(pdt_ctx *ctx, uint64_t n, int phase = RUN_
     }
     const uint32_t got_frames = (ctx->pinned_cap >= (size_t)spec_frames * sizeof(FrameRec)) ? spec_frames : 0u;
     static_assert(sizeof(PllLockInfo<T>) <= 96, "lock record staging");
-    HIP_TRY(hipMemcpyAsync(ctx->pend_sc, d_sc, sizeof(DevScalars), hipMemcpyDeviceToHost, st));
-    HIP_TRY(hipMemcpyAsync(ctx->pend_info, d_info, sizeof(PllLockInfo<T>), hipMemcpyDeviceToHost, st));
-    if (got_frames) HIP_TRY(hipMemcpyAsync(ctx->pinned, d_frames, (size_t)got_frames * sizeof(FrameRec), hipMemcpyDeviceToHost, st));
+    PL.copy(OP_D2H, ctx->pend_sc, d_sc, sizeof(DevScalars));
+    PL.copy(OP_D2H, ctx->pend_info, d_info, sizeof(PllLockInfo<T>));
+    if (got_frames) PL.copy(OP_D2H, ctx->pinned, d_frames, (size_t)got_frames * sizeof(FrameRec));
     ctx->pend_got_frames = got_frames;
     ctx->pend_n = n;
     ctx->pending = true;
+    if (phase == RUN_ALL) {
+        pdt_ctx *self = ctx;
+        if ((rc = execute_plans(&self, 1))) return rc;
+    }
     }   // phase != RUN_FINISH
     if (phase == RUN_ENQUEUE) return PDT_OK;
     if (!ctx->pending || ctx->pend_n != n) return PDT_ERR_STATE;
     ctx->pending = false;
-    HIP_TRY(hipStreamSynchronize(st));
+    pdt_ctx *lead = ctx->leader ? ctx->leader : ctx;
+    HIP_TRY(hipStreamSynchronize(lead->stream));
     const DevScalars &sc = *ctx->pend_sc;
     PllLockInfo<T> info;
     memcpy(&info, ctx->pend_info, sizeof info);
@@ -879,7 +1105,7 @@ template <typename T> int run_capture(pdt_ctx *ctx, uint64_t n, int phase = RUN_
     ctx->last_nframes = sc.nframes;
 
     float ms = 0;
-    (void)hipEventElapsedTime(&ms, ctx->ev0, ctx->ev1);
+    (void)hipEventElapsedTime(&ms, lead->ev0, lead->ev1);
 
     T norm_val;
     memcpy(&norm_val, &sc.norm, sizeof(T));
@@ -973,6 +1199,88 @@ template <typename T> int run_capture(pdt_ctx *ctx, uint64_t n, int phase = RUN_
         ctx->event_pool.push_back(t.b);
     }
     ctx->timers.clear();
+    return PDT_OK;
+}
+
+
+// ---------------------------------------------------------------- host -> HBM ingest
+// The capture (a file the caller opened, or host memory) is cut into 4 MiB spans.  A few host threads bring the spans into
+// pinned slots -- pread from the page cache resp. memcpy, ~5 GB/s per thread -- and queue one asynchronous copy per span on a
+// copy stream; a slot is refilled when its previous copy has completed.  The demodulation stream then waits for the last
+// copy.  (One pageable hipMemcpy of the whole capture runs at a fraction of the link rate and cannot start before the file
+// has been read.)  Small captures take the plain copy.
+struct IngestSrc {
+    const unsigned char *mem = nullptr;   // host memory, or
+    int fd = -1;                          // an open file ...
+    uint64_t off = 0;                     // ... and the byte offset of the first sample
+};
+constexpr size_t PDT_INGEST_SPAN = 4u << 20;
+constexpr int PDT_INGEST_SLOTS = 2;      // per thread
+
+int ingest_capture(pdt_ctx *ctx, const IngestSrc &src, size_t bytes, void *dst)
+{
+    if (!bytes) return PDT_OK;
+    const size_t nspans = (bytes + PDT_INGEST_SPAN - 1) / PDT_INGEST_SPAN;
+    if (src.mem && nspans <= 2) {
+        HIP_TRY(hipMemcpyAsync(dst, src.mem, bytes, hipMemcpyHostToDevice, ctx->stream));
+        return PDT_OK;
+    }
+    unsigned hw = std::thread::hardware_concurrency();
+    int T = (int)std::min<size_t>(std::min<unsigned>(hw ? hw : 4u, 8u), nspans);
+    if (T < 1) T = 1;
+    const size_t need = (size_t)T * PDT_INGEST_SLOTS * PDT_INGEST_SPAN;
+    if (need > ctx->ingest_pin_cap) {
+        if (ctx->ingest_pin) (void)hipHostFree(ctx->ingest_pin);
+        ctx->ingest_pin = nullptr;
+        ctx->ingest_pin_cap = 0;
+        if (hipHostMalloc(&ctx->ingest_pin, need, hipHostMallocDefault) != hipSuccess) { (void)hipGetLastError(); return PDT_ERR_NOMEM; }
+        ctx->ingest_pin_cap = need;
+    }
+    if (!ctx->copy_stream) HIP_TRY(hipStreamCreateWithFlags(&ctx->copy_stream, hipStreamNonBlocking));
+    if (!ctx->ev_ingest) HIP_TRY(hipEventCreateWithFlags(&ctx->ev_ingest, hipEventDisableTiming));
+    while (ctx->ingest_ev.size() < (size_t)T * PDT_INGEST_SLOTS) {
+        hipEvent_t e;
+        HIP_TRY(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+        ctx->ingest_ev.push_back(e);
+    }
+    // the destination may still be read by work queued earlier on the demodulation stream
+    HIP_TRY(hipEventRecord(ctx->ev_ingest, ctx->stream));
+    HIP_TRY(hipStreamWaitEvent(ctx->copy_stream, ctx->ev_ingest, 0));
+    std::atomic<int> failed{0};
+    auto worker = [&](int t) {
+        if (hipSetDevice(ctx->cfg.device) != hipSuccess) { failed = 1; return; }
+        int round = 0;
+        for (size_t k = (size_t)t; k < nspans && !failed; k += (size_t)T, round++) {
+            const int slot = t * PDT_INGEST_SLOTS + (round % PDT_INGEST_SLOTS);
+            unsigned char *pin = (unsigned char *)ctx->ingest_pin + (size_t)slot * PDT_INGEST_SPAN;
+            const size_t at = k * PDT_INGEST_SPAN;
+            const size_t len = std::min(PDT_INGEST_SPAN, bytes - at);
+            if (round >= PDT_INGEST_SLOTS && hipEventSynchronize(ctx->ingest_ev[(size_t)slot]) != hipSuccess) { failed = 1; return; }
+            if (src.mem) {
+                memcpy(pin, src.mem + at, len);
+            } else {
+                size_t got = 0;
+                while (got < len) {
+                    const ssize_t r = pread(src.fd, pin + got, len - got, (off_t)(src.off + at + got));
+                    if (r <= 0) { failed = 2; return; }
+                    got += (size_t)r;
+                }
+            }
+            if (hipMemcpyAsync((unsigned char *)dst + at, pin, len, hipMemcpyHostToDevice, ctx->copy_stream) != hipSuccess ||
+                hipEventRecord(ctx->ingest_ev[(size_t)slot], ctx->copy_stream) != hipSuccess) {
+                failed = 1;
+                return;
+            }
+        }
+    };
+    std::vector<std::thread> pool;
+    for (int t = 1; t < T; t++) pool.emplace_back(worker, t);
+    worker(0);
+    for (auto &th : pool) th.join();
+    if (failed == 2) return PDT_ERR_FORMAT;                // the file is shorter than announced
+    if (failed) { (void)hipGetLastError(); return PDT_ERR_NOGPU; }
+    HIP_TRY(hipEventRecord(ctx->ev_ingest, ctx->copy_stream));
+    HIP_TRY(hipStreamWaitEvent(ctx->stream, ctx->ev_ingest, 0));
     return PDT_OK;
 }
 
@@ -1129,10 +1437,15 @@ void pdt_close(pdt_ctx *ctx)
     DevBuf *bufs[] = { &ctx->pcm, &ctx->pll, &ctx->lock, &ctx->fir, &ctx->agc, &ctx->sym, &ctx->symidx, &ctx->bits, &ctx->bitsym,
                        &ctx->hits, &ctx->frames, &ctx->taps, &ctx->mag, &ctx->seams_pll, &ctx->seams_agc, &ctx->scal, &ctx->lockinfo,
                        &ctx->term, &ctx->seams_ema, &ctx->gtable, &ctx->gentries, &ctx->gcand,
-                       &ctx->gmfirst, &ctx->stiles, &ctx->gsegmap, &ctx->gsegstart, &ctx->gbands, &ctx->gclist, &ctx->agc_maps, &ctx->pll_head, &ctx->taps_rot, &ctx->pll_scratch, &ctx->tip, &ctx->stream_in, &ctx->sync_scr, &ctx->agc_raw };
+                       &ctx->gmfirst, &ctx->stiles, &ctx->gsegmap, &ctx->gsegstart, &ctx->gbands, &ctx->gclist, &ctx->agc_maps, &ctx->pll_head, &ctx->taps_rot, &ctx->pll_scratch, &ctx->tip, &ctx->stream_in, &ctx->sync_scr, &ctx->agc_raw, &ctx->packs_dev };
     for (DevBuf *b : bufs) b->release();
     for (hipEvent_t e : ctx->event_pool) (void)hipEventDestroy(e);
     if (ctx->pinned) (void)hipHostFree(ctx->pinned);
+    if (ctx->packs_pin) (void)hipHostFree(ctx->packs_pin);
+    if (ctx->ingest_pin) (void)hipHostFree(ctx->ingest_pin);
+    for (hipEvent_t e : ctx->ingest_ev) (void)hipEventDestroy(e);
+    if (ctx->ev_ingest) (void)hipEventDestroy(ctx->ev_ingest);
+    if (ctx->copy_stream) (void)hipStreamDestroy(ctx->copy_stream);
     if (ctx->pend_sc) (void)hipHostFree(ctx->pend_sc);
     for (auto &t : ctx->timers) { if (!t.shared_a) (void)hipEventDestroy(t.a); (void)hipEventDestroy(t.b); }
     if (ctx->ev0) (void)hipEventDestroy(ctx->ev0);
@@ -1181,9 +1494,28 @@ int pdt_demod_pcm16(pdt_ctx *ctx, const int16_t *iq_host, uint64_t nframes)
     HIP_TRY(hipSetDevice(ctx->cfg.device));
     int rc = ctx->pcm.ensure((size_t)nframes * 4 + 16);
     if (rc) return rc;
-    if (nframes) HIP_TRY(hipMemcpyAsync(ctx->pcm.p, iq_host, (size_t)nframes * 4, hipMemcpyHostToDevice, ctx->stream));
+    IngestSrc src;
+    src.mem = (const unsigned char *)iq_host;
+    if ((rc = ingest_capture(ctx, src, (size_t)nframes * 4, ctx->pcm.p))) return rc;
     ctx->pcm_dev = ctx->pcm.p;
     ctx->pcm_fmt = 0;
+    return demod_common(ctx, nframes);
+}
+
+int pdt_demod_fd(pdt_ctx *ctx, int fd, uint64_t byte_offset, uint64_t nframes, int sample_format)
+{
+    if (!ctx || fd < 0 || (sample_format != PDT_FMT_PCM16 && sample_format != PDT_FMT_F32)) return PDT_ERR_ARG;
+    if (sample_format == PDT_FMT_F32 && ctx->cfg.mode != PDT_MODE_POES) return PDT_ERR_FORMAT;   // ARGOSdemod/main.c:238-241
+    HIP_TRY(hipSetDevice(ctx->cfg.device));
+    const size_t fb = sample_format == PDT_FMT_F32 ? 8 : 4;
+    int rc = ctx->pcm.ensure((size_t)nframes * fb + 16);
+    if (rc) return rc;
+    IngestSrc src;
+    src.fd = fd;
+    src.off = byte_offset;
+    if ((rc = ingest_capture(ctx, src, (size_t)nframes * fb, ctx->pcm.p))) return rc;
+    ctx->pcm_dev = ctx->pcm.p;
+    ctx->pcm_fmt = sample_format == PDT_FMT_F32 ? 1 : 0;
     return demod_common(ctx, nframes);
 }
 
@@ -1202,7 +1534,9 @@ int pdt_demod_f32(pdt_ctx *ctx, const float *iq_host, uint64_t nframes)
     HIP_TRY(hipSetDevice(ctx->cfg.device));
     int rc = ctx->pcm.ensure((size_t)nframes * 8 + 16);
     if (rc) return rc;
-    if (nframes) HIP_TRY(hipMemcpyAsync(ctx->pcm.p, iq_host, (size_t)nframes * 8, hipMemcpyHostToDevice, ctx->stream));
+    IngestSrc src;
+    src.mem = (const unsigned char *)iq_host;
+    if ((rc = ingest_capture(ctx, src, (size_t)nframes * 8, ctx->pcm.p))) return rc;
     ctx->pcm_dev = ctx->pcm.p;
     ctx->pcm_fmt = 1;
     return demod_common(ctx, nframes);
@@ -1241,14 +1575,23 @@ int pdt_stage_bytesync(pdt_ctx *ctx, const uint8_t *bits_host, uint64_t nbits)
     DevScalars sc;
     memset(&sc, 0, sizeof sc);
     sc.nbits = nbits;
-    HIP_TRY(hipMemcpyAsync(d_sc, &sc, sizeof sc, hipMemcpyHostToDevice, st));
-    if (nbits) HIP_TRY(hipMemcpyAsync(ctx->bits.p, bits_host, (size_t)nbits, hipMemcpyHostToDevice, st));
-    HIP_TRY(hipMemsetAsync(ctx->frames.p, 0, (size_t)frame_cap * sizeof(FrameRec), st));
-    hipLaunchKernelGGL(k_iota, dim3((unsigned)((bit_cap + 255) / 256)), dim3(256), 0, st, (unsigned *)ctx->bitsym.p,
-                       (long long *)ctx->symidx.p, bit_cap);
-    launch_bytesync(ctx, st, SP, d_sc, bit_cap, hit_cap, frame_cap);
-    HIP_TRY(hipMemcpyAsync(&sc, d_sc, sizeof sc, hipMemcpyDeviceToHost, st));
+    Plan &PL = ctx->plan;
+    PL.clear();
+    PL.side_stream = ctx->stream2;
+    PL.copy(OP_H2D, d_sc, &sc, sizeof sc);
+    if (nbits) PL.copy(OP_H2D, ctx->bits.p, bits_host, (size_t)nbits);
+    PL.memset_async(ctx->frames.p, 0, (size_t)frame_cap * sizeof(FrameRec));
+    PDT_LAUNCH(256, k_iota, dim3((unsigned)((bit_cap + 255) / 256)), dim3(256), 0, st, (unsigned *)ctx->bitsym.p,
+               (long long *)ctx->symidx.p, bit_cap);
+    launch_bytesync(ctx, PL, st, SP, d_sc, bit_cap, hit_cap, frame_cap);
+    DevScalars *back = ctx->pend_sc;                                  // pinned
+    PL.copy(OP_D2H, back, d_sc, sizeof sc);
+    {
+        pdt_ctx *self = ctx;
+        if ((rc = execute_plans(&self, 1))) return rc;
+    }
     HIP_TRY(hipStreamSynchronize(st));
+    sc = *back;
     if (sc.nframes > frame_cap || (sc.sync_overflow && sc.nhits > hit_cap)) return PDT_ERR_STATE;
     std::vector<FrameRec> recs(sc.nframes);
     if (sc.nframes) HIP_TRY(hipMemcpy(recs.data(), ctx->frames.p, (size_t)sc.nframes * sizeof(FrameRec), hipMemcpyDeviceToHost));
@@ -1285,14 +1628,33 @@ int pdt_demod_batch_device(pdt_ctx *const *ctxs, const void *const *iq_device, c
             if (ctxs[j] == ctxs[i]) return PDT_ERR_ARG;               // one context per capture
     }
     int first_err = PDT_OK, enq = 0;
-    for (; enq < count; enq++) {                                        // every kernel of every capture, no host wait
+    for (; enq < count; enq++) {                                        // the plan of every capture (host only)
         pdt_ctx *c = ctxs[enq];
         c->pcm_dev = iq_device[enq];
         c->pcm_fmt = 0;
         const int rc = demod_common(c, nframes[enq], RUN_ENQUEUE);
         if (rc) { first_err = rc; break; }
     }
+    // captures whose plans have the same shape (same mode, rate, chunk geometry, code path) and live on the same GPU
+    // share their launches: one launch per stage for the whole group, the capture index in blockIdx.z
+    std::vector<char> done((size_t)enq, 0);
+    for (int i = 0; i < enq; i++) {
+        if (done[(size_t)i]) continue;
+        std::vector<pdt_ctx *> group{ctxs[i]};
+        done[(size_t)i] = 1;
+        for (int j = i + 1; j < enq && (int)group.size() < 65535; j++)
+            if (!done[(size_t)j] && ctxs[j]->cfg.device == ctxs[i]->cfg.device && ctxs[i]->plan.same_shape(ctxs[j]->plan)) {
+                group.push_back(ctxs[j]);
+                done[(size_t)j] = 1;
+            }
+        const int rc = execute_plans(group.data(), (int)group.size());
+        if (rc) {
+            if (!first_err) first_err = rc;
+            for (pdt_ctx *c : group) c->pending = false;
+        }
+    }
     for (int i = 0; i < enq; i++) {                                     // then collect them in order
+        if (!ctxs[i]->pending) continue;
         const int rc = demod_common(ctxs[i], nframes[i], RUN_FINISH);
         if (rc && !first_err) first_err = rc;
     }
@@ -1422,12 +1784,18 @@ int pdt_tip_check(pdt_ctx *ctx, pdt_tip_summary *out)
     TipCounters *d_cnt = (TipCounters *)ctx->tip.p;
     TipFrame *d_rec = (TipFrame *)(d_cnt + 1);
     hipStream_t st = ctx->stream;
-    HIP_TRY(hipMemsetAsync(d_cnt, 0, sizeof(TipCounters), st));
-    hipLaunchKernelGGL(k_tip_check, dim3((nf + 255) / 256), dim3(256), 0, st, (const FrameRec *)ctx->frames.p, nf, d_rec, d_cnt);
-    HIP_TRY(hipGetLastError());
+    Plan &PL = ctx->plan;
+    PL.clear();
+    PL.side_stream = ctx->stream2;
+    PL.memset_async(d_cnt, 0, sizeof(TipCounters));
+    PDT_LAUNCH(256, k_tip_check, dim3((nf + 255) / 256), dim3(256), 0, st, (const FrameRec *)ctx->frames.p, nf, d_rec, d_cnt);
     TipCounters cnt;
-    HIP_TRY(hipMemcpyAsync(&cnt, d_cnt, sizeof cnt, hipMemcpyDeviceToHost, st));
-    HIP_TRY(hipMemcpyAsync(ctx->tip_host.data(), d_rec, (size_t)nf * sizeof(TipFrame), hipMemcpyDeviceToHost, st));
+    PL.copy(OP_D2H, &cnt, d_cnt, sizeof cnt);
+    PL.copy(OP_D2H, ctx->tip_host.data(), d_rec, (size_t)nf * sizeof(TipFrame));
+    {
+        pdt_ctx *self = ctx;
+        if ((rc = execute_plans(&self, 1))) return rc;
+    }
     HIP_TRY(hipStreamSynchronize(st));
     out->frames_checked = cnt.frames_checked;
     out->good_frames = cnt.good_frames;
@@ -1486,25 +1854,71 @@ int pdt_get_stats(const pdt_ctx *ctx, pdt_stats *out)
     return PDT_OK;
 }
 
+// "%.5f" of a non-negative double without printf: value * 10^5 rounded to nearest, ties to even, on the EXACT binary value
+// -- what glibc prints.  x = m * 2^e with a 53-bit m; m * 100000 fits 70 bits.  Returns the number of characters.
+static int format_time5(double x, char *out)
+{
+    if (!(x >= 0.0) || x >= 1e15) return snprintf(out, 48, "%.5f", x);
+    uint64_t bits;
+    memcpy(&bits, &x, sizeof bits);
+    const int be = (int)((bits >> 52) & 0x7ff);
+    uint64_t m = bits & ((1ull << 52) - 1);
+    int e;
+    if (be == 0) e = -1074; else { m |= 1ull << 52; e = be - 1075; }
+    unsigned __int128 N = (unsigned __int128)m * 100000u;
+    unsigned __int128 q;
+    if (e >= 0) {
+        q = N << e;                                   // x < 1e15: no overflow
+    } else {
+        const int sh = -e;
+        if (sh >= 120) q = 0;                         // x * 1e5 < 2^-49: rounds to zero
+        else {
+            q = N >> sh;
+            const unsigned __int128 rem = N & (((unsigned __int128)1 << sh) - 1), half = (unsigned __int128)1 << (sh - 1);
+            if (rem > half || (rem == half && (q & 1))) q++;
+        }
+    }
+    const uint64_t ip = (uint64_t)(q / 100000u);
+    unsigned fp = (unsigned)(q % 100000u);
+    char tmp[24];
+    int n = 0;
+    uint64_t v = ip;
+    do { tmp[n++] = (char)('0' + v % 10); v /= 10; } while (v);
+    int w = 0;
+    while (n) out[w++] = tmp[--n];
+    out[w++] = '.';
+    for (int d = 4; d >= 0; d--) { out[w + d] = (char)('0' + fp % 10); fp /= 10; }
+    return w + 5;
+}
+
+uint64_t pdt_format_records(const pdt_frame *frames, uint64_t nframes, char *buf, uint64_t cap)
+{
+    // ByteSync.c:96-99,126-129 ("%.5f " / "%.5fi "), :62,100-101 ("%.2X "), :66-70 (newline after the last byte)
+    static const char hex[] = "0123456789ABCDEF";
+    uint64_t need = 0;
+    char line[64 + 3 * 104 + 2];
+    for (uint64_t k = 0; k < nframes; k++) {
+        const pdt_frame &f = frames[k];
+        int w = format_time5(f.time, line);
+        if (f.inverted) line[w++] = 'i';
+        line[w++] = ' ';
+        const unsigned nb = f.nbytes > 104 ? 104u : f.nbytes;
+        for (unsigned b = 0; b < nb; b++) {
+            line[w++] = hex[f.bytes[b] >> 4];
+            line[w++] = hex[f.bytes[b] & 15];
+            line[w++] = ' ';
+        }
+        if (f.complete) line[w++] = '\n';
+        if (buf && need < cap) memcpy(buf + need, line, (size_t)std::min<uint64_t>((uint64_t)w, cap - need));
+        need += (uint64_t)w;
+    }
+    return need;
+}
+
 uint64_t pdt_format_frames(const pdt_ctx *ctx, char *buf, uint64_t cap)
 {
     if (!ctx) return 0;
-    const bool argos = ctx->cfg.mode == PDT_MODE_ARGOS;
-    std::string s;
-    s.reserve(ctx->frames_host.size() * 330);
-    char tmp[64];
-    for (const pdt_frame &f : ctx->frames_host) {
-        snprintf(tmp, sizeof tmp, f.inverted ? "%.5fi " : "%.5f ", f.time);   // ByteSync.c:96-99,126-129
-        s += tmp;
-        for (unsigned b = 0; b < f.nbytes; b++) {
-            snprintf(tmp, sizeof tmp, "%.2X ", f.bytes[b]);                   // ByteSync.c:62,100-101
-            s += tmp;
-        }
-        if (f.complete) s += "\n";                                            // ByteSync.c:66-70
-    }
-    (void)argos;
-    if (buf && cap) memcpy(buf, s.data(), (size_t)std::min<uint64_t>(cap, s.size()));
-    return s.size();
+    return pdt_format_records(ctx->frames_host.data(), ctx->frames_host.size(), buf, cap);
 }
 
 uint64_t pdt_stage_len(const pdt_ctx *ctx, int stage)

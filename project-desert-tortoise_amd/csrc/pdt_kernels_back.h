@@ -258,7 +258,7 @@ template <typename T> struct GardnerEntry {
 // sequential mode (entries == nullptr): one wavefront walks every chunk in order.
 // parallel mode: block b owns chunk b and starts from the tabulated entry state.
 template <typename T, int LEN, int OUT>
-__global__ void __launch_bounds__(256) k_gardner(const T *__restrict__ in, const T *__restrict__ lock,
+__device__ __forceinline__ void k_gardner(const T *__restrict__ in, const T *__restrict__ lock,
                                                                   GardnerParams<T> P, T *__restrict__ sym,
                                                                   long long *__restrict__ symidx,
                                                                   unsigned long long *__restrict__ nsym_out,
@@ -295,7 +295,7 @@ __global__ void __launch_bounds__(256) k_gardner(const T *__restrict__ in, const
 // Q3/Q16) while wavefront 0 walks chunk c out of the first, then the buffers swap.  The walk is the
 // single-window case of gardner_walk_chunk, statement for statement.
 template <typename T, int LEN, int OUT>
-__global__ void __launch_bounds__(256) k_gardner_small(const T *__restrict__ in, const T *__restrict__ lock, GardnerParams<T> P,
+__device__ __forceinline__ void k_gardner_small(const T *__restrict__ in, const T *__restrict__ lock, GardnerParams<T> P,
                                                         T *__restrict__ sym, long long *__restrict__ symidx,
                                                         unsigned long long *__restrict__ nsym_out, long long sym_cap)
 {
@@ -413,7 +413,7 @@ template <> __device__ __forceinline__ float mm_rint<float>(float x) { return __
 template <> __device__ __forceinline__ double mm_rint<double>(double x) { return (double)__builtin_rintf((float)x); }
 
 template <typename T, int LEN, int OUT>
-__global__ void __launch_bounds__(PDT_GARDNER_THREADS) k_mm(const T *__restrict__ in, MmParams<T> P, T *__restrict__ sym,
+__device__ __forceinline__ void k_mm(const T *__restrict__ in, MmParams<T> P, T *__restrict__ sym,
                                                              long long *__restrict__ symidx,
                                                              unsigned long long *__restrict__ nsym_out, long long sym_cap)
 {
@@ -601,7 +601,7 @@ __device__ __forceinline__ void gardner_lane_tail(GardnerLane &L, const float *w
 struct GardnerBand { int j_lo, j_hi, listed; };   // candidates [j_lo, j_hi) of cand_k, or of the chunk's own list
 #define PDT_GTAB_LIST 2048                        // capacity of a chunk's candidate list
 
-__global__ void __launch_bounds__(64) k_gardner_scout(const float *__restrict__ in, GardnerParams<float> P, GardnerDomain D,
+__device__ __forceinline__ void k_gardner_scout(const float *__restrict__ in, GardnerParams<float> P, GardnerDomain D,
                                                        long long n_tab_chunks, const int *__restrict__ m_first,
                                                        const unsigned *__restrict__ cand_k, unsigned *__restrict__ table,
                                                        GardnerBand *__restrict__ bands, unsigned *__restrict__ clist,
@@ -831,7 +831,7 @@ __device__ __forceinline__ void gardner_table_block(float *win, const float *__r
 }
 
 template <int THREADS, int WIN>
-__global__ void __launch_bounds__(THREADS) k_gardner_table(const float *__restrict__ in, GardnerParams<float> P,
+__device__ __forceinline__ void k_gardner_table(const float *__restrict__ in, GardnerParams<float> P,
                                                             GardnerDomain D, long long n_tab_chunks,
                                                             const unsigned *__restrict__ cand_k,
                                                             const GardnerBand *__restrict__ bands,
@@ -866,7 +866,7 @@ __global__ void __launch_bounds__(THREADS) k_gardner_table(const float *__restri
 #define PDT_GTM_SLOTS 256
 #define PDT_GTM_HASH 512
 template <int WIN>
-__global__ void __launch_bounds__(PDT_GTM_THREADS) k_gardner_table_merge(const float *__restrict__ in, GardnerParams<float> P,
+__device__ __forceinline__ void k_gardner_table_merge(const float *__restrict__ in, GardnerParams<float> P,
                                                                           GardnerDomain D, long long n_tab_chunks,
                                                                           const unsigned *__restrict__ cand_k,
                                                                           const GardnerBand *__restrict__ bands,
@@ -1133,7 +1133,7 @@ __global__ void __launch_bounds__(PDT_GTM_THREADS) k_gardner_table_merge(const f
 struct GardnerSegCell { unsigned next, count; };
 struct GardnerSegStart { unsigned key; unsigned hopped; long long offset; };
 
-__global__ void __launch_bounds__(1024) k_gardner_segmap(const unsigned *__restrict__ table, GardnerDomain D, long long n_chunks,
+__device__ __forceinline__ void k_gardner_segmap(const unsigned *__restrict__ table, GardnerDomain D, long long n_chunks,
                                                           int G, GardnerSegCell *__restrict__ segmap)
 {
     const long long s = blockIdx.x;
@@ -1156,7 +1156,7 @@ __global__ void __launch_bounds__(1024) k_gardner_segmap(const unsigned *__restr
     }
 }
 
-__global__ void __launch_bounds__(256) k_gardner_chain(const float *__restrict__ in, GardnerParams<float> P,
+__device__ __forceinline__ void k_gardner_chain(const float *__restrict__ in, GardnerParams<float> P,
                                                                         GardnerDomain D, long long n_chunks,
                                                                         const unsigned *__restrict__ table,
                                                                         const GardnerSegCell *__restrict__ segmap, int G,
@@ -1237,7 +1237,7 @@ __global__ void __launch_bounds__(256) k_gardner_chain(const float *__restrict__
     if (threadIdx.x == 0) stats[2] = walked;
 }
 
-__global__ void __launch_bounds__(64) k_gardner_segfill(const float *__restrict__ in, GardnerParams<float> P, GardnerDomain D,
+__device__ __forceinline__ void k_gardner_segfill(const float *__restrict__ in, GardnerParams<float> P, GardnerDomain D,
                                                          long long n_chunks, const unsigned *__restrict__ table, int G,
                                                          const GardnerSegStart *__restrict__ segstart,
                                                          GardnerEntry<float> *__restrict__ entries)
@@ -1360,7 +1360,7 @@ struct ManchTile {
 
 // block-wide inclusive max-scan of (position of last flagged symbol) in LDS
 template <typename T>
-__global__ void __launch_bounds__(PDT_TILE_THREADS) k_manch_tile(const T *__restrict__ sym,
+__device__ __forceinline__ void k_manch_tile(const T *__restrict__ sym,
                                                                   const unsigned long long *__restrict__ nsym_p, T thr,
                                                                   ManchTile *__restrict__ tiles)
 {
@@ -1452,7 +1452,7 @@ __device__ __forceinline__ ManchMap manch_compose(const ManchMap &f, const Manch
     return r;
 }
 
-__global__ void __launch_bounds__(1024) k_manch_scan(ManchTile *__restrict__ tiles, const unsigned long long *__restrict__ nsym_p,
+__device__ __forceinline__ void k_manch_scan(ManchTile *__restrict__ tiles, const unsigned long long *__restrict__ nsym_p,
                                                       unsigned long long *__restrict__ nbits_out)
 {
     __shared__ ManchMap s_map[1024];
@@ -1508,7 +1508,7 @@ __global__ void __launch_bounds__(1024) k_manch_scan(ManchTile *__restrict__ til
 }
 
 template <typename T>
-__global__ void __launch_bounds__(PDT_TILE_THREADS) k_manch_emit(const T *__restrict__ sym,
+__device__ __forceinline__ void k_manch_emit(const T *__restrict__ sym,
                                                                   const unsigned long long *__restrict__ nsym_p, T thr,
                                                                   const ManchTile *__restrict__ tiles,
                                                                   unsigned char *__restrict__ bits,
@@ -1583,7 +1583,7 @@ struct SyncParams {
     unsigned prefix;               // literal bytes printed first: 2 POES (ED E2), 0 ARGOS
 };
 
-__global__ void __launch_bounds__(256) k_sync_hits(const unsigned char *__restrict__ bits,
+__device__ __forceinline__ void k_sync_hits(const unsigned char *__restrict__ bits,
                                                     const unsigned long long *__restrict__ nbits_p, SyncParams P,
                                                     unsigned *__restrict__ hits, unsigned *__restrict__ nhits,
                                                     unsigned hit_cap, const unsigned *__restrict__ only_if)
@@ -1619,7 +1619,7 @@ struct SyncTile {
     unsigned hits[31];     // (bit index << 1) | inverse
 };
 
-__global__ void __launch_bounds__(256) k_sync_hits_tile(const unsigned char *__restrict__ bits,
+__device__ __forceinline__ void k_sync_hits_tile(const unsigned char *__restrict__ bits,
                                                          const unsigned long long *__restrict__ nbits_p, SyncParams P,
                                                          SyncTile *__restrict__ tiles, unsigned *__restrict__ overflow)
 {
@@ -1677,7 +1677,7 @@ struct FrameRec {
 };
 
 // single workgroup: sort the (sparse, unordered) hit list, then walk it sequentially
-__global__ void __launch_bounds__(256) k_sync_frames(unsigned *__restrict__ hits, const unsigned *__restrict__ nhits_p,
+__device__ __forceinline__ void k_sync_frames(unsigned *__restrict__ hits, const unsigned *__restrict__ nhits_p,
                                                       unsigned hit_cap, SyncParams P, FrameRec *__restrict__ frames,
                                                       unsigned *__restrict__ nframes, unsigned frame_cap,
                                                       const unsigned *__restrict__ only_if)
@@ -1750,7 +1750,7 @@ __device__ __forceinline__ unsigned sync_block_scan(unsigned v, unsigned *s_scan
     return s_scan[threadIdx.x];
 }
 
-__global__ void __launch_bounds__(PDT_SYNC_THREADS) k_sync_frames_tiles(const SyncTile *__restrict__ tiles,
+__device__ __forceinline__ void k_sync_frames_tiles(const SyncTile *__restrict__ tiles,
                                                             const unsigned long long *__restrict__ nbits_p, SyncParams P,
                                                             unsigned *__restrict__ dense, unsigned dense_cap,
                                                             FrameRec *__restrict__ frames, unsigned *__restrict__ nframes,
@@ -1909,7 +1909,7 @@ __global__ void __launch_bounds__(PDT_SYNC_THREADS) k_sync_frames_tiles(const Sy
     }
 }
 
-__global__ void __launch_bounds__(128) k_frame_pack(const unsigned char *__restrict__ bits,
+__device__ __forceinline__ void k_frame_pack(const unsigned char *__restrict__ bits,
                                                      const unsigned long long *__restrict__ nbits_p,
                                                      const unsigned *__restrict__ bitsym,
                                                      const long long *__restrict__ symidx, SyncParams P,
@@ -1956,7 +1956,7 @@ __global__ void __launch_bounds__(128) k_frame_pack(const unsigned char *__restr
 }
 
 // identity index maps for the stage-level byte-sync entry (time stamp of bit k = k)
-__global__ void k_iota(unsigned *__restrict__ bitsym, long long *__restrict__ symidx, long long n)
+__device__ __forceinline__ void k_iota(unsigned *__restrict__ bitsym, long long *__restrict__ symidx, long long n)
 {
     const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n) { bitsym[i] = (unsigned)i; symidx[i] = i; }
@@ -1979,7 +1979,7 @@ struct TipCounters {
     unsigned hist_day[512];
 };
 
-__global__ void __launch_bounds__(256) k_tip_check(const FrameRec *__restrict__ frames, unsigned nframes,
+__device__ __forceinline__ void k_tip_check(const FrameRec *__restrict__ frames, unsigned nframes,
                                                     TipFrame *__restrict__ out, TipCounters *__restrict__ cnt)
 {
     const unsigned f = blockIdx.x * blockDim.x + threadIdx.x;

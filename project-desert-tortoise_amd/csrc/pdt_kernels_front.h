@@ -135,7 +135,7 @@ template <typename T> __device__ __forceinline__ T pll_locksig(T a, T b, T t_rea
 // event (Q9).  Kept as the readable statement of the iteration and for A/B runs (PDT_ACQUIRE_SIMPLE); the
 // product path is k_pll_acquire_pipe below.
 template <typename T>
-__global__ void __launch_bounds__(64) k_pll_acquire(IqSrc pcm, long long n, PllParams<T> P,
+__device__ __forceinline__ void k_pll_acquire(IqSrc pcm, long long n, PllParams<T> P,
                                                      T *__restrict__ out, T *__restrict__ lock_out,
                                                      PllLockInfo<T> *__restrict__ info)
 {
@@ -193,7 +193,7 @@ __global__ void __launch_bounds__(64) k_pll_acquire(IqSrc pcm, long long n, PllP
 // reference; only the order in which *independent* iterations' pieces run is changed.
 
 template <typename T>
-__global__ void __launch_bounds__(256) k_pll_theta(IqSrc pcm, long long n, T *__restrict__ theta)
+__device__ __forceinline__ void k_pll_theta(IqSrc pcm, long long n, T *__restrict__ theta)
 {
     // four samples per thread: one 16-byte load of IQ, one (two for double) 16-byte store
     const long long i = ((long long)blockIdx.x * blockDim.x + threadIdx.x) * 4;
@@ -337,7 +337,7 @@ template <typename T> __device__ __forceinline__ void pll_sweep_sel(T &fr, T &sw
 }
 
 template <typename T, bool SLOW>
-__global__ void __launch_bounds__(64) k_pll_acquire_fast(IqSrc pcm, const T *__restrict__ theta, long long n, PllParams<T> P,
+__device__ __forceinline__ void k_pll_acquire_fast(IqSrc pcm, const T *__restrict__ theta, long long n, PllParams<T> P,
                                                           T *__restrict__ out, T *__restrict__ lock_out,
                                                           PllLockInfo<T> *__restrict__ info)
 {
@@ -517,7 +517,7 @@ template <typename T> struct AcqVerdict {
 };
 
 template <typename T, bool SLOW, bool EXCL = false>
-__global__ void __launch_bounds__(128) k_pll_acquire_pipe(IqSrc pcm, const T *__restrict__ theta, long long n, PllParams<T> P,
+__device__ __forceinline__ void k_pll_acquire_pipe(IqSrc pcm, const T *__restrict__ theta, long long n, PllParams<T> P,
                                                           T *__restrict__ out, T *__restrict__ lock_out,
                                                           PllLockInfo<T> *__restrict__ info)
 {
@@ -858,7 +858,7 @@ __device__ __forceinline__ void pll_guess(IqSrc pcm, long long ws, long long n, 
 // state, and k_pll_fix validates every later seam against that chain; phases computed for
 // samples before the lock are simply never used.
 template <typename T, bool SLOW>
-__global__ void __launch_bounds__(64) k_pll_phase(IqSrc pcm, const T *__restrict__ theta, long long n,
+__device__ __forceinline__ void k_pll_phase(IqSrc pcm, const T *__restrict__ theta, long long n,
                                                    PllParams<T> P, long long B, long long Wacq, long long Wtrk, int lag,
                                                    T *__restrict__ phi, PllSeam<T> *__restrict__ seams)
 {
@@ -937,7 +937,7 @@ __global__ void __launch_bounds__(64) k_pll_phase(IqSrc pcm, const T *__restrict
 template <typename T> struct PllHeadInfo { long long s0, s1, j0, nblk; };
 
 template <typename T, bool SLOW, bool EXCL = false>
-__global__ void __launch_bounds__(64) k_pll_head(const T *__restrict__ theta, long long n, PllParams<T> P,
+__device__ __forceinline__ void k_pll_head(const T *__restrict__ theta, long long n, PllParams<T> P,
                                                   const PllLockInfo<T> *__restrict__ info, long long B, long long W,
                                                   T *__restrict__ phi_head, PllSeam<T> *__restrict__ seams_head,
                                                   PllHeadInfo<T> *__restrict__ hinfo, long long max_blocks)
@@ -996,7 +996,7 @@ template <> __device__ __forceinline__ bool bits_equal<double>(double x, double 
 #define PDT_FIX_THREADS 1024
 #define PDT_FIX_LIST 64
 template <typename T, bool SLOW>
-__global__ void __launch_bounds__(PDT_FIX_THREADS) k_pll_fix(const T *__restrict__ theta, long long n, PllParams<T> P,
+__device__ __forceinline__ void k_pll_fix(const T *__restrict__ theta, long long n, PllParams<T> P,
                                                  const PllLockInfo<T> *__restrict__ info, long long B, T *__restrict__ phi,
                                                  PllSeam<T> *__restrict__ seams, const T *__restrict__ phi_head,
                                                  const PllSeam<T> *__restrict__ seams_head,
@@ -1149,7 +1149,7 @@ __global__ void __launch_bounds__(PDT_FIX_THREADS) k_pll_fix(const T *__restrict
 // elementwise mix for the samples after the lock (:106-113), and the lock-detector input
 // term lockSigAlpha*(re*t_real + im*t_imag) (:194-220) when the lock stream is wanted
 template <typename T, bool LOCKSIG>
-__global__ void __launch_bounds__(256) k_pll_mix(IqSrc pcm, const T *__restrict__ phi, long long n,
+__device__ __forceinline__ void k_pll_mix(IqSrc pcm, const T *__restrict__ phi, long long n,
                                                   PllParams<T> P, const PllLockInfo<T> *__restrict__ info,
                                                   T *__restrict__ out, T *__restrict__ lock_term)
 {
@@ -1237,7 +1237,7 @@ __device__ __forceinline__ void ema_range(const T *__restrict__ term, T *__restr
 }
 
 template <typename T>
-__global__ void __launch_bounds__(64) k_lock_ema(const T *__restrict__ term, long long n, T lock_alpha,
+__device__ __forceinline__ void k_lock_ema(const T *__restrict__ term, long long n, T lock_alpha,
                                                   const PllLockInfo<T> *__restrict__ info, long long B, long long W,
                                                   T *__restrict__ lock_out, EmaSeam<T> *__restrict__ seams)
 {
@@ -1262,7 +1262,7 @@ __global__ void __launch_bounds__(64) k_lock_ema(const T *__restrict__ term, lon
 }
 
 template <typename T>
-__global__ void __launch_bounds__(64) k_lock_ema_fix(const T *__restrict__ term, long long n, T lock_alpha,
+__device__ __forceinline__ void k_lock_ema_fix(const T *__restrict__ term, long long n, T lock_alpha,
                                                       const PllLockInfo<T> *__restrict__ info, long long B,
                                                       T *__restrict__ lock_out, EmaSeam<T> *__restrict__ seams,
                                                       unsigned *__restrict__ fixes_out)
@@ -1306,7 +1306,7 @@ __global__ void __launch_bounds__(64) k_lock_ema_fix(const T *__restrict__ term,
 // into k_agc_block); the sound-card twin applies it between PLL and FIR (POESTIPdemodPortAudio/main.c:370).
 // Elementwise, 4 samples per thread.
 template <typename T>
-__global__ void __launch_bounds__(256) k_squelch(T *__restrict__ x, const T *__restrict__ lock, long long n, T thr)
+__device__ __forceinline__ void k_squelch(T *__restrict__ x, const T *__restrict__ lock, long long n, T thr)
 {
     const long long i0 = ((long long)blockIdx.x * 256 + threadIdx.x) * 4;
 #pragma unroll
@@ -1329,7 +1329,7 @@ struct AgcMap { double A, B; };
 // tap h[N-1-(g - m*interp)]; inputs before the stream start are +0.
 #define PDT_FIR_THREADS 256
 template <typename T>
-__global__ void __launch_bounds__(PDT_FIR_THREADS) k_fir_interp(const T *__restrict__ in, long long n_in, int interp, int K,
+__device__ __forceinline__ void k_fir_interp(const T *__restrict__ in, long long n_in, int interp, int K,
                                                                  const T *__restrict__ taps, T *__restrict__ out,
                                                                  int outs_per_thread)
 {
@@ -1380,7 +1380,7 @@ __global__ void __launch_bounds__(PDT_FIR_THREADS) k_fir_interp(const T *__restr
 // multiply and add, as the reference).  Outputs go through LDS and leave with coalesced stores.
 // HBM traffic = the algorithmic 4 B in + 4*INTERP B out per input sample.
 template <typename T, int INTERP, int K>
-__global__ void __launch_bounds__(PDT_FIR_THREADS) k_fir_interp_rt(const T *__restrict__ in, long long n_in,
+__device__ __forceinline__ void k_fir_interp_rt(const T *__restrict__ in, long long n_in,
                                                                     const T *__restrict__ rot /* host-built rotated taps */,
                                                                     T *__restrict__ out, AgcMap *__restrict__ tile_maps,
                                                                     T agc_decay)
@@ -1496,7 +1496,7 @@ __global__ void __launch_bounds__(PDT_FIR_THREADS) k_fir_interp_rt(const T *__re
 
 // In-place form (ARGOS): y[i] = sum_{k<N} h[k] * x[i-(N-1-k)], oldest first.
 template <typename T>
-__global__ void __launch_bounds__(PDT_FIR_THREADS) k_fir_plain(const T *__restrict__ in, long long n, int N,
+__device__ __forceinline__ void k_fir_plain(const T *__restrict__ in, long long n, int N,
                                                                 const T *__restrict__ taps, T *__restrict__ out,
                                                                 int outs_per_thread)
 {
@@ -1530,7 +1530,7 @@ __global__ void __launch_bounds__(PDT_FIR_THREADS) k_fir_plain(const T *__restri
 // Magnitudes in parallel, the 2-op recurrence on one lane.
 // ------------------------------------------------------------------------------------------
 template <typename T>
-__global__ void __launch_bounds__(256) k_static_gain(IqSrc pcm, long long n0, T *__restrict__ mag_scratch,
+__device__ __forceinline__ void k_static_gain(IqSrc pcm, long long n0, T *__restrict__ mag_scratch,
                                                       T desired, double override_norm, T *__restrict__ norm_out)
 {
     if (override_norm != 0.0) {
@@ -1779,7 +1779,7 @@ __device__ __forceinline__ void agc_range(const T *__restrict__ in, const T *__r
 
 #define PDT_AFF_TILE 8192
 template <typename T>
-__global__ void __launch_bounds__(256) k_agc_affine(const T *__restrict__ in, long long n, T decay, long long Bk,
+__device__ __forceinline__ void k_agc_affine(const T *__restrict__ in, long long n, T decay, long long Bk,
                                                      AgcMap *__restrict__ maps)
 {
     // one workgroup per AGC block: tiles of 8192 samples are staged in LDS with coalesced loads,
@@ -1842,7 +1842,7 @@ __global__ void __launch_bounds__(256) k_agc_affine(const T *__restrict__ in, lo
 // initial gain: one workgroup, each thread composes a contiguous slice, the slices are scanned in
 // LDS (affine maps form a monoid), then every thread replays its slice from its prefix.
 template <typename T>
-__global__ void __launch_bounds__(1024) k_agc_guess(const AgcMap *__restrict__ maps, long long nb, const T *__restrict__ norm,
+__device__ __forceinline__ void k_agc_guess(const AgcMap *__restrict__ maps, long long nb, const T *__restrict__ norm,
                                                      double *__restrict__ guesses, int maps_per_block, long long n_maps)
 {
     __shared__ double sA[1024], sB[1024];
@@ -1900,7 +1900,7 @@ __global__ void __launch_bounds__(1024) k_agc_guess(const AgcMap *__restrict__ m
 }
 
 template <typename T>
-__global__ void __launch_bounds__(64) k_agc_block(const T *__restrict__ in, long long n, AgcParams<T> P,
+__device__ __forceinline__ void k_agc_block(const T *__restrict__ in, long long n, AgcParams<T> P,
                                                    const T *__restrict__ norm, long long B, long long W,
                                                    const double *__restrict__ guesses, const T *__restrict__ lock,
                                                    T *__restrict__ out, AgcSeam<T> *__restrict__ seams, double K)
@@ -1941,7 +1941,7 @@ __global__ void __launch_bounds__(64) k_agc_block(const T *__restrict__ in, long
 // always there is none, and k_agc_fix then has nothing to scan (alone, its single wavefront took 64 seams per round trip
 // to memory: 0.05 ms on 9 000 blocks).
 template <typename T>
-__global__ void __launch_bounds__(1024) k_agc_scan(long long n, long long B, const AgcSeam<T> *__restrict__ seams,
+__device__ __forceinline__ void k_agc_scan(long long n, long long B, const AgcSeam<T> *__restrict__ seams,
                                                    long long *__restrict__ first_bad)
 {
     __shared__ unsigned long long s_first;
@@ -1958,7 +1958,7 @@ __global__ void __launch_bounds__(1024) k_agc_scan(long long n, long long B, con
 }
 
 template <typename T>
-__global__ void __launch_bounds__(64) k_agc_fix(const T *__restrict__ in, long long n, AgcParams<T> P, long long B,
+__device__ __forceinline__ void k_agc_fix(const T *__restrict__ in, long long n, AgcParams<T> P, long long B,
                                                  const T *__restrict__ lock, T *__restrict__ out,
                                                  AgcSeam<T> *__restrict__ seams, unsigned *__restrict__ counters,
                                                  const long long *__restrict__ first_bad)

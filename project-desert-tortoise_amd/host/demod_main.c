@@ -283,22 +283,12 @@ int main(int argc, char **argv)
         rate = (uint32_t)(sampleRate * 1000.0);                      /* main.c:329: entered in kHz */
     }
 
-    /* the reference reads until EOF, not header.data_size */
+    /* the reference reads until EOF, not header.data_size; the library reads the file itself (threaded reads into pinned
+     * memory overlapped with the copy to the GPU: pdt_demod_fd) */
     fseek(in, 0, SEEK_END);
     long fsz = ftell(in);
-    fseek(in, data_offset, SEEK_SET);
     const size_t frame_bytes = is_raw ? 8 : 4;
     uint64_t nframes = fsz > data_offset ? (uint64_t)(fsz - data_offset) / frame_bytes : 0;
-    void *samples = malloc(nframes * frame_bytes + 16);
-    if (!samples) {
-        printf("Error in malloc\n");
-        exit(1);
-    }
-    if (fread(samples, frame_bytes, nframes, in) != nframes) {
-        printf("Error reading samples\n");
-        exit(1);
-    }
-    fclose(in);
 
     pdt_config cfg;
     memset(&cfg, 0, sizeof cfg);
@@ -320,7 +310,8 @@ int main(int argc, char **argv)
 #ifdef PDT_ARGOS
     if (outputRawFiles) pdt_keep_presquelch(ctx, 1);                 /* -r: the AGC output before Squelch, ARGOSdemod/main.c:273-274 */
 #endif
-    rc = is_raw ? pdt_demod_f32(ctx, (const float *)samples, nframes) : pdt_demod_pcm16(ctx, (const int16_t *)samples, nframes);
+    rc = pdt_demod_fd(ctx, fileno(in), (uint64_t)data_offset, nframes, is_raw ? PDT_FMT_F32 : PDT_FMT_PCM16);
+    fclose(in);
     if (rc != PDT_OK) {
         printf("Demodulation failed: %s\n", pdt_strerror(rc));
         fclose(out);
@@ -394,7 +385,6 @@ int main(int argc, char **argv)
         printf("\nAll done! Closing files and exiting.\nENJOY YOUR BITS AND HAVE A NICE DAY\n");
     }
     free(text);
-    free(samples);
     pdt_close(ctx);
     return 0;
 }

@@ -124,3 +124,26 @@ def test_hand_issued_lds_loads_are_the_only_users_of_m0(pdt, tmp_path):
     for k, (loads, movs) in per_kernel.items():
         assert "k_agc_" in k, f"m0 / LDS-direct load in an unexpected kernel: {k}"
         assert loads == movs and loads > 0, f"{k}: {loads} LDS-direct loads but {movs} writes of m0"
+
+
+def test_format_records_equals_printf(pdt):
+    """pdt_format_records prints "%.5f" without printf (exact decimal rounding of the binary value): compare with Python's
+    printf-style formatting (== glibc's) on float32-derived stamps, arbitrary doubles, ties and extremes."""
+    import numpy as np
+    rng = np.random.default_rng(5)
+    times = np.concatenate([
+        rng.random(20000).astype(np.float32).astype(np.float64) * 600.0,           # float-built time stamps (POES)
+        rng.random(20000) * 4000.0,                                                # double stamps (ARGOS)
+        np.array([0.0, 0.5e-5, 1.5e-5, 2.5e-5, 0.000005, 0.000015, 0.125, 128.0, 512.0, 1024.0, 3600.0, 99999.999995,
+                  1e-300, 5e-324, 1e14, 0.28009, 4.98649, 2.675, 1.0000049999999999, 123456.789015]),
+        (np.arange(0, 4000, dtype=np.float64) + 0.5) / 1e5,                        # decimal ties as doubles (mostly inexact)
+        np.ldexp(np.arange(1, 2000, dtype=np.float64), -17),                        # exact binary fractions incl. true ties
+    ])
+    fr = np.zeros(len(times), dtype=pdt.FRAME_DTYPE)
+    fr["time"] = times
+    fr["nbytes"] = rng.integers(0, 105, len(times))
+    fr["bytes"] = rng.integers(0, 256, (len(times), 104))
+    fr["inverted"] = rng.integers(0, 2, len(times))
+    fr["complete"] = rng.integers(0, 2, len(times))
+    assert pdt.format_frames(fr) == pdt.format_frames_py(fr)
+    assert pdt.format_frames(fr[:0]) == b""
