@@ -176,7 +176,7 @@ int  pdt_keep_presquelch(pdt_ctx *ctx, int enable);
 int  pdt_demod_pcm16(pdt_ctx *ctx, const int16_t *iq_host, uint64_t nframes);
 /* ... or straight from the file the caller opened (what GetComplexWaveChunk / GetComplexRawChunk do with their FILE*,
  * wave.c:59-175,413-540, once per chunk): nframes I,Q pairs of `sample_format` starting at byte_offset (44 for the
- * canonical WAV header ReadWavHeader accepts, 0 for RAW).  The library reads the file in 4 MiB spans with a few host
+ * canonical WAV header ReadWavHeader accepts, 0 for RAW).  The library reads the file in 2 MiB spans with a few host
  * threads into pinned memory and copies them to the GPU while the next spans are being read, so a capture is in HBM about
  * as soon as the page cache and the PCIe link allow.  PDT_ERR_FORMAT when the file ends early.                         */
 int  pdt_demod_fd(pdt_ctx *ctx, int fd, uint64_t byte_offset, uint64_t nframes, int sample_format);

@@ -305,9 +305,9 @@ class Demodulator:
         return s
 
     def text(self) -> bytes:
-        n = self._L.pdt_format_frames(self._h, None, 0)
-        buf = C.create_string_buffer(n + 1)
-        self._L.pdt_format_frames(self._h, buf, n)
+        cap = int(self._L.pdt_num_frames(self._h)) * 352 + 64          # a line is at most 24 + 3 * 104 + 1 characters
+        buf = C.create_string_buffer(cap)
+        n = self._L.pdt_format_frames(self._h, buf, cap)
         return buf.raw[:n]
 
     def stage(self, st: int, first: int = 0, count: int | None = None) -> np.ndarray:

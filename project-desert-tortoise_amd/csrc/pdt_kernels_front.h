@@ -1409,7 +1409,12 @@ __device__ __forceinline__ void k_fir_interp_rt(const T *__restrict__ in, long l
         for (int c = wave; c < K; c += PDT_FIR_THREADS / 64) {
             const T *w1 = s_in + (j + 1) * LS;                   // slot t <= c: input m0 + K*j + t
             const T *w0 = s_in + j * LS;                         // slot t >  c: input m0 + K*(j-1) + t
-            const T *h = rot + c * K * RS;                       // wave-uniform address: scalar loads into SGPRs
+            // wave-uniform address, read-only table: constant address space, so that the loads are scalar loads into SGPRs
+            // whatever the compiler can prove about the stores around them
+            // (each residue's K * INTERP taps start on a 64-byte boundary: the loads can be as wide as the ISA has them)
+            constexpr int CS = (K * INTERP + 15) & ~15;
+            const __attribute__((address_space(4))) T *h =
+                (const __attribute__((address_space(4))) T *)__builtin_assume_aligned(rot + c * CS, 64);
             T y[INTERP];
 #pragma unroll
             for (int r = 0; r < INTERP; r++) y[r] = 0;
@@ -1419,20 +1424,11 @@ __device__ __forceinline__ void k_fir_interp_rt(const T *__restrict__ in, long l
             // ... and the residue's taps: one block copy from a wave-uniform address = a handful of wide scalar loads
             // (fetched row by row the compiler issued two narrow loads and a wait per row: a third of the kernel's instructions)
             // (with a single tap per row the compiler's own element loads were measured a little faster)
-            struct TapBlock { T v[K * INTERP]; };
             T hv[K][INTERP];
-            if constexpr (INTERP >= 2) {
-                const TapBlock tb = *reinterpret_cast<const TapBlock *>(h);
 #pragma unroll
-                for (int t = 0; t < K; t++)
+            for (int t = 0; t < K; t++)
 #pragma unroll
-                    for (int r = 0; r < INTERP; r++) hv[t][r] = tb.v[t * RS + r];
-            } else {
-#pragma unroll
-                for (int t = 0; t < K; t++)
-#pragma unroll
-                    for (int r = 0; r < INTERP; r++) hv[t][r] = h[t * RS + r];
-            }
+                for (int r = 0; r < INTERP; r++) hv[t][r] = h[t * RS + r];
 #pragma unroll
             for (int t = 0; t < K; t++) {
 #pragma unroll

@@ -11,6 +11,8 @@ the bytes of wide coalesced streaming reads -- it is doubled here ("FETCH_correc
 as reported.  Values are averages per launch.
 """
 import csv, glob, json, os, re, sys
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+from kname import kernel_name
 from collections import defaultdict
 
 
@@ -20,7 +22,7 @@ def per_kernel(d, counter):
     for r in csv.DictReader(open(f)):
         if r["Counter_Name"] != counter:
             continue
-        name = re.sub(r"\(.*", "", r["Kernel_Name"]).replace("void ", "").replace("pdt::", "")
+        name = kernel_name(r["Kernel_Name"])
         tot[name] += float(r["Counter_Value"])
         cnt[name] += 1
     return {k: tot[k] / cnt[k] for k in tot}, cnt
