@@ -636,7 +636,8 @@ template <typename T> int run_capture(pdt_ctx *ctx, uint64_t n, int phase = RUN_
     long long Wacq = (long long)(0.02 * fs_d);             // acquisition-gain stage of the warm-up
     long long Ba = ctx->cfg.agc_block ? ctx->cfg.agc_block : (long long)((argos ? 0.125 : 0.0625) * fs_d * interp);
     long long Wa = ctx->cfg.agc_warm ? ctx->cfg.agc_warm : (long long)((argos ? 8.0 : 1.0) * fs_d * interp);
-    Bp = std::max<long long>(64, round4(Bp));
+    Bp = std::min<long long>(Bp, std::max<long long>(N, 1));   // (one block at most: the LT layout keeps 64 blocks per tile)
+    Bp = std::max<long long>(64, (Bp + 63) / 64 * 64);         // whole transposition groups of the LT layout (pdt_kernels_front.h)
     Ba = std::max<long long>(64, round4(Ba));
     // POES with the register-tiled FIR: AGC blocks made of whole FIR tiles (64 * 26 inputs), so that the FIR kernel can
     // deliver the AGC's affine tile maps itself (0 = not fused: explicit block size, ARGOS, generic FIR)
@@ -681,8 +682,12 @@ template <typename T> int run_capture(pdt_ctx *ctx, uint64_t n, int phase = RUN_
     int rc;
     if ((rc = ctx->pll.ensure((size_t)(N + 1) * sizeof(T)))) return rc;
     if (need_lock && (rc = ctx->lock.ensure((size_t)(N + 1) * sizeof(T)))) return rc;
-    if ((rc = ctx->fir.ensure((size_t)(n_out + 1) * sizeof(T)))) return rc;
-    if ((rc = ctx->agc.ensure((size_t)(n_out + 1) * sizeof(T)))) return rc;
+    // theta and the phases live in the FIR / AGC buffers before those are written, in the lane-tiled layout: whole tiles of
+    // 64 blocks, plus the rows the walkers' look-ahead loads may touch past a tile
+    const long long lt_tiles = (N / Bp + 1 + 63) / 64;
+    const long long lt_elems = lt_tiles * 64 * Bp + 48 * 64 * (16 / (long long)sizeof(T)) + 64;
+    if ((rc = ctx->fir.ensure((size_t)(std::max(n_out, lt_elems) + 1) * sizeof(T)))) return rc;
+    if ((rc = ctx->agc.ensure((size_t)(std::max(n_out, lt_elems) + 1) * sizeof(T)))) return rc;
     if (ctx->keep_agc_raw && (rc = ctx->agc_raw.ensure((size_t)(n_out + 1) * sizeof(T)))) return rc;
     if (ctx->keep_agc_raw) AP.raw_out = (T *)ctx->agc_raw.p;
     if ((rc = ctx->sym.ensure((size_t)sym_cap * sizeof(T)))) return rc;
@@ -741,9 +746,10 @@ template <typename T> int run_capture(pdt_ctx *ctx, uint64_t n, int phase = RUN_
     // theta and phase live in the (not yet used) FIR and AGC buffers.
     T *d_theta = d_fir;
     T *d_phi = d_agc;
+    const long long lt_groups = lt_tiles * (Bp / (16 * (16 / (long long)sizeof(T))));      // workgroups of the transposing kernels
     if (N > 0) {
         L.begin("pll_theta");
-        PDT_LAUNCH(256, k_pll_theta<T>, dim3((unsigned)((N + 1023) / 1024)), dim3(256), 0, st, d_pcm, N, d_theta);   // 4 samples per thread
+        PDT_LAUNCH(256, k_pll_theta<T>, dim3((unsigned)lt_groups), dim3(256), 0, st, d_pcm, N, Bp, d_theta);
         L.end();
     }
     // fork: the block-parallel phase recurrence (side stream) runs beside the sequential acquisition
@@ -773,19 +779,19 @@ template <typename T> int run_capture(pdt_ctx *ctx, uint64_t n, int phase = RUN_
         PDT_LAUNCH(64, k_pll_acquire<T>, dim3(1), dim3(64), 0, st, d_pcm, N, PP, d_pll, d_lock, d_info);
     else if (ctx->tune.acquire_mode == 2) {   // single-wavefront batched form, kept for A/B checks
         if (slow_wrap)
-            PDT_LAUNCH(64, (k_pll_acquire_fast<T, true>), dim3(1), dim3(64), 0, st, d_pcm, (const T *)d_theta, N, PP, d_pll, d_lock,
+            PDT_LAUNCH(64, (k_pll_acquire_fast<T, true>), dim3(1), dim3(64), 0, st, d_pcm, N, PP, d_pll, d_lock,
                                d_info);
         else
-            PDT_LAUNCH(64, (k_pll_acquire_fast<T, false>), dim3(1), dim3(64), 0, st, d_pcm, (const T *)d_theta, N, PP, d_pll, d_lock,
+            PDT_LAUNCH(64, (k_pll_acquire_fast<T, false>), dim3(1), dim3(64), 0, st, d_pcm, N, PP, d_pll, d_lock,
                                d_info);
     } else if (slow_wrap)
-        PDT_LAUNCH(128, (k_pll_acquire_pipe<T, true>), dim3(1), dim3(128), 0, st, d_pcm, (const T *)d_theta, N, PP, d_pll, d_lock,
+        PDT_LAUNCH(128, (k_pll_acquire_pipe<T, true>), dim3(1), dim3(128), 0, st, d_pcm, N, PP, d_pll, d_lock,
                            d_info);
     else if (serial_excl)
-        PDT_LAUNCH(128, (k_pll_acquire_pipe<T, false, true>), dim3(1), dim3(128), 0, st, d_pcm, (const T *)d_theta, N, PP, d_pll, d_lock,
+        PDT_LAUNCH(128, (k_pll_acquire_pipe<T, false, true>), dim3(1), dim3(128), 0, st, d_pcm, N, PP, d_pll, d_lock,
                            d_info);
     else
-        PDT_LAUNCH(128, (k_pll_acquire_pipe<T, false>), dim3(1), dim3(128), 0, st, d_pcm, (const T *)d_theta, N, PP, d_pll, d_lock,
+        PDT_LAUNCH(128, (k_pll_acquire_pipe<T, false>), dim3(1), dim3(128), 0, st, d_pcm, N, PP, d_pll, d_lock,
                            d_info);
     L.end();
     if (N > 0) {
@@ -832,10 +838,10 @@ template <typename T> int run_capture(pdt_ctx *ctx, uint64_t n, int phase = RUN_
         (void)grid;
         L.begin("pll_mix");
         if (need_lock)
-            PDT_LAUNCH(256, (k_pll_mix<T, true>), dim3((unsigned)((N + 1023) / 1024)), dim3(256), 0, st, d_pcm, d_phi, N, PP,
+            PDT_LAUNCH(256, (k_pll_mix<T, true>), dim3((unsigned)lt_groups), dim3(256), 0, st, d_pcm, d_phi, N, Bp, PP,
                                d_info, d_pll, (T *)ctx->term.p);
         else
-            PDT_LAUNCH(256, (k_pll_mix<T, false>), dim3((unsigned)((N + 1023) / 1024)), dim3(256), 0, st, d_pcm, d_phi, N, PP,
+            PDT_LAUNCH(256, (k_pll_mix<T, false>), dim3((unsigned)lt_groups), dim3(256), 0, st, d_pcm, d_phi, N, Bp, PP,
                                d_info, d_pll, (T *)nullptr);
         L.end();
         if (need_lock) {

@@ -192,26 +192,81 @@ __device__ __forceinline__ void k_pll_acquire(IqSrc pcm, long long n, PllParams<
 // The float operations and their order are exactly those of one loop iteration of the
 // reference; only the order in which *independent* iterations' pieces run is changed.
 
-template <typename T>
-__device__ __forceinline__ void k_pll_theta(IqSrc pcm, long long n, T *__restrict__ theta)
+template <typename T> struct alignas(16) Vec16 {
+    static constexpr int N = 16 / sizeof(T);
+    T v[N];
+};
+
+// Lane-tiled ("LT") layout of the theta and phase streams.  The (phase, freq) recurrence is walked one lane per block of B
+// samples, 64 consecutive blocks per wavefront, all lanes at the same offset inside their blocks.  In natural order a
+// wavefront's 16-byte loads then touch 64 different cache lines -- 64 clocks of the CU's texture-address path per load, which
+// is what bounds the walkers as soon as a few of them share a CU (a batch of captures, an hour-long capture).  So the
+// streams the walkers touch are kept transposed: tile w = blocks [64 w, 64 w + 64); its vector row q holds, lane after lane,
+// the q-th 16-byte vector of each of the 64 blocks.  A wavefront in lock step reads / writes 1 KiB of consecutive bytes per
+// instruction.  The elementwise kernels on either side (theta, mix) transpose through LDS, coalesced on both faces.
+template <typename T> struct Lt {
+    static constexpr int VN = 16 / sizeof(T);       // elements per 16-byte vector
+    static constexpr int ROW = 64 * VN;             // elements per row
+    static constexpr int RG = 16;                   // rows a transposing workgroup handles (B is a multiple of RG * VN)
+    // element index of natural sample i
+    static __host__ __device__ __forceinline__ long long index(long long i, long long B)
+    {
+        const long long j = i / B, p = i - j * B;
+        return (j >> 6) * (64 * B) + (p / VN) * ROW + (j & 63) * VN + (p % VN);
+    }
+};
+
+template <typename T> __device__ __forceinline__ void iq_vec(IqSrc pcm, long long i, T (&a)[Lt<T>::VN], T (&b)[Lt<T>::VN])
 {
-    // four samples per thread: one 16-byte load of IQ, one (two for double) 16-byte store
-    const long long i = ((long long)blockIdx.x * blockDim.x + threadIdx.x) * 4;
-    if (i >= n) return;
-    if (i + 4 <= n) {
-        T a[4], b[4];
+    constexpr int VN = Lt<T>::VN;
+    if constexpr (VN == 4) {
         if (pcm.fmt == 0) iq_block<T, 0, 4>(pcm.p, i, a, b);
         else iq_block<T, 1, 4>(pcm.p, i, a, b);
-        struct alignas(16) Out { T v[4]; } o;
-#pragma unroll
-        for (int e = 0; e < 4; e++) o.v[e] = arctan2_ref(b[e], a[e]);   // :128
-        *reinterpret_cast<Out *>(theta + i) = o;                        // i is a multiple of 4, theta a device allocation
     } else {
-        for (long long k = i; k < n; k++) {
-            T a, b;
-            IqSample<T>::get(pcm, k, a, b);
-            theta[k] = arctan2_ref(b, a);
+#pragma unroll
+        for (int e = 0; e < VN; e++) IqSample<T>::get(pcm, i + e, a[e], b[e]);
+    }
+}
+
+// theta_i = arctan2(Im x_i, Re x_i) (:128), written in the LT layout.  One workgroup = RG rows of one tile: the I/Q of
+// 64 lane-rows x RG vectors is read in runs of RG * 16 sample bytes, transposed through LDS, and leaves as RG KiB of
+// consecutive bytes.
+template <typename T>
+__device__ __forceinline__ void k_pll_theta(IqSrc pcm, long long n, long long B, T *__restrict__ theta_lt)
+{
+    constexpr int VN = Lt<T>::VN, ROW = Lt<T>::ROW, RG = Lt<T>::RG;
+    __shared__ Vec16<T> s_v[64 * (RG + 1)];
+    const long long groups = B / (VN * RG);
+    const long long w = (long long)blockIdx.x / groups, g = (long long)blockIdx.x - w * groups;
+    if ((w << 6) * B >= n) return;
+#pragma unroll
+    for (int pass = 0; pass < 4; pass++) {
+        const int l = pass * 16 + ((int)threadIdx.x >> 4), qd = (int)threadIdx.x & 15;
+        const long long i = ((w << 6) + l) * B + (g * RG + qd) * VN;
+        Vec16<T> o;
+        if (i + VN <= n) {
+            T a[VN], b[VN];
+            iq_vec<T>(pcm, i, a, b);
+#pragma unroll
+            for (int e = 0; e < VN; e++) o.v[e] = arctan2_ref(b[e], a[e]);
+        } else {
+#pragma unroll
+            for (int e = 0; e < VN; e++) {
+                o.v[e] = 0;
+                if (i + e < n) {
+                    T a, b;
+                    IqSample<T>::get(pcm, i + e, a, b);
+                    o.v[e] = arctan2_ref(b, a);
+                }
+            }
         }
+        s_v[l * (RG + 1) + qd] = o;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int pass = 0; pass < 4; pass++) {
+        const int qd = pass * 4 + ((int)threadIdx.x >> 6), l = (int)threadIdx.x & 63;
+        *reinterpret_cast<Vec16<T> *>(theta_lt + (w << 6) * B + (g * RG + qd) * ROW + l * VN) = s_v[l * (RG + 1) + qd];
     }
 }
 
@@ -307,6 +362,14 @@ __device__ __forceinline__ void pll_phase_step(T th, T &phase, T &freq, T alpha,
 // (CarrierTrackingPLL.c:102-275); only independent pieces of different samples are interleaved.
 // Lane <-> uniform traffic is v_readlane / v_cndmask only: no LDS, no barriers, and the only
 // memory operations are one coalesced load of theta and IQ per batch (issued one batch ahead).
+// theta of one sample, as k_pll_theta computes it (the acquisition reads a few thousand samples in natural order; the theta
+// stream itself is kept in the block-parallel kernel's LT layout)
+template <typename T> __device__ __forceinline__ T theta_of(IqSrc pcm, long long i)
+{
+    T a, b;
+    IqSample<T>::get(pcm, i, a, b);
+    return arctan2_ref(b, a);
+}
 #define PDT_ACQ_NB 32
 __device__ __forceinline__ float lane_get(float v, int k) { return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), k)); }
 __device__ __forceinline__ double lane_get(double v, int k)
@@ -337,7 +400,7 @@ template <typename T> __device__ __forceinline__ void pll_sweep_sel(T &fr, T &sw
 }
 
 template <typename T, bool SLOW>
-__device__ __forceinline__ void k_pll_acquire_fast(IqSrc pcm, const T *__restrict__ theta, long long n, PllParams<T> P,
+__device__ __forceinline__ void k_pll_acquire_fast(IqSrc pcm, long long n, PllParams<T> P,
                                                           T *__restrict__ out, T *__restrict__ lock_out,
                                                           PllLockInfo<T> *__restrict__ info)
 {
@@ -356,8 +419,8 @@ __device__ __forceinline__ void k_pll_acquire_fast(IqSrc pcm, const T *__restric
     long long p_i0 = 0;
     int p_done = 0;
     if (lane < PDT_ACQ_NB && lane < n) {
-        th_l = theta[lane];
         IqSample<T>::get(pcm, lane, a_l, b_l);
+        th_l = arctan2_ref(b_l, a_l);
     }
 #ifdef PDT_ACQ_PROF
     long long pc[5] = {0, 0, 0, 0, 0}, pt = clock64(), nbatch = 0;
@@ -369,8 +432,8 @@ __device__ __forceinline__ void k_pll_acquire_fast(IqSrc pcm, const T *__restric
         const int nb = (int)((n - i0 < PDT_ACQ_NB) ? (n - i0) : PDT_ACQ_NB);
         i_next = i0 + PDT_ACQ_NB;
         if (lane < PDT_ACQ_NB && i_next + lane < n) {
-            th_n = theta[i_next + lane];
             IqSample<T>::get(pcm, i_next + lane, a_n, b_n);
+            th_n = arctan2_ref(b_n, a_n);
         }
         if (lane < p_done) {
             out[p_i0 + lane] = p_o;
@@ -472,8 +535,8 @@ __device__ __forceinline__ void k_pll_acquire_fast(IqSrc pcm, const T *__restric
         if (i0 == i_next) {
             th_l = th_n; a_l = a_n; b_l = b_n;
         } else if (lane < PDT_ACQ_NB && i0 + lane < n) {
-            th_l = theta[i0 + lane];
             IqSample<T>::get(pcm, i0 + lane, a_l, b_l);
+            th_l = arctan2_ref(b_l, a_l);
         }
         PDT_ACQ_TICK(4)
     }
@@ -517,7 +580,7 @@ template <typename T> struct AcqVerdict {
 };
 
 template <typename T, bool SLOW, bool EXCL = false>
-__device__ __forceinline__ void k_pll_acquire_pipe(IqSrc pcm, const T *__restrict__ theta, long long n, PllParams<T> P,
+__device__ __forceinline__ void k_pll_acquire_pipe(IqSrc pcm, long long n, PllParams<T> P,
                                                           T *__restrict__ out, T *__restrict__ lock_out,
                                                           PllLockInfo<T> *__restrict__ info)
 {
@@ -558,9 +621,9 @@ __device__ __forceinline__ void k_pll_acquire_pipe(IqSrc pcm, const T *__restric
                 const int nb = (int)((n - i_prod < PDT_ACQP_NB) ? (n - i_prod) : PDT_ACQP_NB);
                 // theta of this batch was requested one batch ago (unless an event moved the start)
                 T th_l = th_pre;
-                if (i_pre != i_prod) th_l = (lane < nb) ? theta[i_prod + lane] : (T)0;
+                if (i_pre != i_prod) th_l = (lane < nb) ? theta_of<T>(pcm, i_prod + lane) : (T)0;
                 i_pre = i_prod + nb;
-                if (lane < PDT_ACQP_NB && i_pre + lane < n) th_pre = theta[i_pre + lane];
+                if (lane < PDT_ACQP_NB && i_pre + lane < n) th_pre = theta_of<T>(pcm, i_pre + lane);
                 T ph = phase, fr = freq, sw = sweep;
                 T phi_l = 0, phn_l = 0, fpre_l = 0, swb_l = 0;
                 // (four samples per trip: a taken branch costs a lone wavefront as much as nine instructions)
@@ -701,11 +764,6 @@ template <typename T> struct PllSeam {
 #define PDT_PF 8   // look-ahead depth (vectors per lane) of the lane-per-block stream walkers
 #endif
 
-template <typename T> struct alignas(16) Vec16 {
-    static constexpr int N = 16 / sizeof(T);
-    T v[N];
-};
-
 // Look-ahead ring of a lane-per-block stream walker, hand-issued.  Every lane streams its own block, so its loads
 // cannot coalesce and must be issued far ahead; left to the compiler, the re-loads of an unrolled register ring are
 // moved around freely (hoisted above the arithmetic, sunk across the back edge) and the loop header waits for all of
@@ -727,61 +785,108 @@ template <int N> __device__ __forceinline__ void ring_wait()
     asm volatile("s_waitcnt vmcnt(%0)" : : "n"(N) : "memory");
 }
 
-// run the recurrence over [i0, i1), optionally storing the pre-update phase of every sample;
-// 16-byte vector loads/stores on the aligned body (each lane streams its own block)
-template <typename T, bool STORE, bool SLOW, int PF = PDT_PF>
-__device__ __forceinline__ void pll_phase_range(const T *__restrict__ theta, T *__restrict__ phi, long long i0, long long i1,
-                                                T &phase, T &freq, T alpha, T beta, T maxf, T minf)
+// run the recurrence over the natural samples [i0, i1) of the LT theta stream, optionally storing the pre-update phase of
+// every sample -- into the LT phase stream (OUT_LT: out is its base) or into a linear buffer indexed by the natural sample
+// index (out[i]; the single-lane walkers of the head and of the seam repairs).  Block by block: inside a block a lane's
+// consecutive 16-byte vectors are one row (ROW elements) apart.  VOTE also counts, over the range, the samples whose
+// detector error lies beyond +-pi/2 (the basin vote of the warm-up).
+template <typename T, bool STORE, bool SLOW, bool OUT_LT, int PF = PDT_PF, bool VOTE = false>
+__device__ __forceinline__ void pll_phase_range(const T *__restrict__ theta_lt, T *__restrict__ out, long long B, long long i0,
+                                                long long i1, T &phase, T &freq, T alpha, T beta, T maxf, T minf,
+                                                int *far = nullptr, int *seen = nullptr)
 {
-    constexpr int VN = Vec16<T>::N;
+    constexpr int VN = Lt<T>::VN, ROW = Lt<T>::ROW;
+    constexpr int OSTR = OUT_LT ? ROW : VN;
+    auto step = [&](T th) {
+        if (VOTE) {
+            T d = th - phase;
+            if (d > (T)PDT_PI) d -= (T)(2 * PDT_PI);
+            if (d < (T)-PDT_PI) d += (T)(2 * PDT_PI);
+            *far += (Real<T>::abs(d) > (T)(PDT_PI / 2)) ? 1 : 0;
+            *seen += 1;
+        }
+        pll_phase_step<T, SLOW>(th, phase, freq, alpha, beta, maxf, minf);
+    };
     long long i = i0;
-    for (; i < i1 && (i % VN) != 0; i++) {
-        if (STORE) phi[i] = phase;
-        pll_phase_step<T, SLOW>(theta[i], phase, freq, alpha, beta, maxf, minf);
-    }
-    // (On gfx9 stores share the vmcnt counter with loads, so waiting for a look-ahead load also waits
-    // for every older store: the single-lane walkers of the head and the seam repairs use PF = 32 to
-    // give their stores ~2 us to retire.)
-    // Software pipeline: PF vectors per lane are always in flight; each register set is
-    // re-loaded right after it has been consumed and is next needed PF-1 vectors later, so the
-    // recurrence never waits on memory.  (Look-ahead loads run past i1 by < 4 KiB: every stream
-    // buffer is allocated with that much slack.  The opaque offset stops the compiler from
-    // sinking the look-ahead load back to its use.)
-    if (i + PF * VN <= i1) {
-        Vec16<T> buf[PF];
+    while (i < i1) {
+        const long long j = i / B, p0 = i - j * B;
+        const long long seg_end = ((j + 1) * B < i1) ? (j + 1) * B : i1;
+        long long cnt = seg_end - i;                       // samples of this block still to walk
+        int e = (int)(p0 % VN);
+        const long long lt_off = (j >> 6) * (64 * B) + (p0 / VN) * ROW + (j & 63) * VN;    // vector that holds sample i
+        const T *tp = theta_lt + lt_off;
+        T *op = nullptr;
+        if (STORE) op = OUT_LT ? out + lt_off : out + (i - e);
+        if (e != 0) {                                      // leading partial vector
+            for (; e < VN && cnt > 0; e++, cnt--) {
+                if (STORE) op[e] = phase;
+                step(tp[e]);
+            }
+            tp += ROW;
+            if (STORE) op += OSTR;
+        }
+        long long nv = cnt / VN;                           // whole vectors
+        cnt -= nv * VN;
+        // Software pipeline: PF vectors per lane are always in flight; each register set is re-loaded right after it has
+        // been consumed and is next needed PF-1 vectors later, so the recurrence never waits on memory.  (Look-ahead loads
+        // run up to PF rows past the segment: every LT buffer is allocated with that much slack.  The opaque offset stops
+        // the compiler from sinking the look-ahead load back to its use.)  On gfx9 stores share the vmcnt counter with
+        // loads, so waiting for a look-ahead load also waits for every older store: the single-lane walkers use PF = 32.
+        if (nv >= PF) {
+            Vec16<T> buf[PF];
 #pragma unroll
-        for (int u = 0; u < PF; u++) buf[u] = *reinterpret_cast<const Vec16<T> *>(theta + i + u * VN);
-        for (; i + PF * VN <= i1; i += PF * VN) {
+            for (int u = 0; u < PF; u++) buf[u] = *reinterpret_cast<const Vec16<T> *>(tp + (long long)u * ROW);
+            long long v = 0;
+            for (; v + PF <= nv; v += PF) {
+#pragma unroll
+                for (int u = 0; u < PF; u++) {
+                    Vec16<T> pv;
+#pragma unroll
+                    for (int w = 0; w < VN; w++) {
+                        pv.v[w] = phase;
+                        step(buf[u].v[w]);
+                    }
+                    if (STORE) *reinterpret_cast<Vec16<T> *>(op + (v + u) * OSTR) = pv;
+                    // reload the slot only after its last use: the new value can then live in the same
+                    // registers (a reload issued earlier is copied at the loop end, behind a full wait)
+                    long long q = (v + PF + u) * ROW;
+                    asm volatile("" : "+v"(q));
+                    buf[u] = *reinterpret_cast<const Vec16<T> *>(tp + q);
+                }
+            }
+            // the ring now holds vectors v .. v + PF - 1: the remaining nv - v (< PF) of them are already here
+            const int rest = (int)(nv - v);
 #pragma unroll
             for (int u = 0; u < PF; u++) {
+                if (u < rest) {
+                    Vec16<T> pv;
+#pragma unroll
+                    for (int w = 0; w < VN; w++) {
+                        pv.v[w] = phase;
+                        step(buf[u].v[w]);
+                    }
+                    if (STORE) *reinterpret_cast<Vec16<T> *>(op + (v + u) * OSTR) = pv;
+                }
+            }
+        } else {
+            for (long long v = 0; v < nv; v++) {
+                const Vec16<T> tv = *reinterpret_cast<const Vec16<T> *>(tp + v * ROW);
                 Vec16<T> pv;
 #pragma unroll
                 for (int w = 0; w < VN; w++) {
                     pv.v[w] = phase;
-                    pll_phase_step<T, SLOW>(buf[u].v[w], phase, freq, alpha, beta, maxf, minf);
+                    step(tv.v[w]);
                 }
-                if (STORE) *reinterpret_cast<Vec16<T> *>(phi + i + u * VN) = pv;
-                // reload the slot only after its last use: the new value can then live in the same
-                // registers (a reload issued earlier is copied at the loop end, behind a full wait)
-                long long q = i + (PF + u) * VN;
-                asm volatile("" : "+v"(q));
-                buf[u] = *reinterpret_cast<const Vec16<T> *>(theta + q);
+                if (STORE) *reinterpret_cast<Vec16<T> *>(op + v * OSTR) = pv;
             }
         }
-    }
-    for (; i + VN <= i1; i += VN) {
-        const Vec16<T> tv = *reinterpret_cast<const Vec16<T> *>(theta + i);
-        Vec16<T> pv;
-#pragma unroll
-        for (int w = 0; w < VN; w++) {
-            pv.v[w] = phase;
-            pll_phase_step<T, SLOW>(tv.v[w], phase, freq, alpha, beta, maxf, minf);
+        tp += nv * ROW;
+        if (STORE) op += nv * OSTR;
+        for (int t = 0; t < (int)cnt; t++) {               // trailing partial vector
+            if (STORE) op[t] = phase;
+            step(tp[t]);
         }
-        if (STORE) *reinterpret_cast<Vec16<T> *>(phi + i) = pv;
-    }
-    for (; i < i1; i++) {
-        if (STORE) phi[i] = phase;
-        pll_phase_step<T, SLOW>(theta[i], phase, freq, alpha, beta, maxf, minf);
+        i = seg_end;
     }
 }
 
@@ -880,48 +985,26 @@ __device__ __forceinline__ void k_pll_phase(IqSrc pcm, const T *__restrict__ the
     pll_guess(pcm, ws, n, lag, (T)0, phase, freq);
     if (freq > P.max_freq) freq = P.max_freq;
     if (freq < P.min_freq) freq = P.min_freq;
-    pll_phase_range<T, false, SLOW>(theta, phi, ws, ws + w_wide, phase, freq, P.alpha_wide, P.beta_wide, P.max_freq, P.min_freq);
+    pll_phase_range<T, false, SLOW, true>(theta, phi, B, ws, ws + w_wide, phase, freq, P.alpha_wide, P.beta_wide, P.max_freq, P.min_freq);
     // acquisition-gain stage; its last 128 samples vote on which of the two stable lock points we
     // fell into: at the carrier the detector error sits at +-m (|err| < pi/2), at the false point
     // pi away it sits at +-(pi - m) (|err| > pi/2)
     const long long a0 = ws + w_wide, a1 = a0 + w_acq;
     const long long vote0 = (w_acq > 160) ? a1 - 128 : a1;
-    pll_phase_range<T, false, SLOW>(theta, phi, a0, vote0, phase, freq, P.alpha_acq, P.beta_acq, P.max_freq, P.min_freq);
+    pll_phase_range<T, false, SLOW, true>(theta, phi, B, a0, vote0, phase, freq, P.alpha_acq, P.beta_acq, P.max_freq, P.min_freq);
     int far = 0, seen = 0;
-    {
-        auto vote = [&](T th) {
-            T d = th - phase;
-            if (d > (T)PDT_PI) d -= (T)(2 * PDT_PI);
-            if (d < (T)-PDT_PI) d += (T)(2 * PDT_PI);
-            far += (Real<T>::abs(d) > (T)(PDT_PI / 2)) ? 1 : 0;
-            seen++;
-            pll_phase_step<T, SLOW>(th, phase, freq, P.alpha_acq, P.beta_acq, P.max_freq, P.min_freq);
-        };
-        // 32 samples per trip (one exposed memory latency each) instead of one
-        constexpr int VN = Vec16<T>::N, VB = 32 / VN;
-        long long i = vote0;
-        for (; i < a1 && (i % VN) != 0; i++) vote(theta[i]);
-        for (; i + 32 <= a1; i += 32) {
-            Vec16<T> tv[VB];
-#pragma unroll
-            for (int u = 0; u < VB; u++) tv[u] = *reinterpret_cast<const Vec16<T> *>(theta + i + u * VN);
-#pragma unroll
-            for (int u = 0; u < VB; u++)
-#pragma unroll
-                for (int w = 0; w < VN; w++) vote(tv[u].v[w]);
-        }
-        for (; i < a1; i++) vote(theta[i]);
-    }
+    pll_phase_range<T, false, SLOW, true, PDT_PF, true>(theta, phi, B, vote0, a1, phase, freq, P.alpha_acq, P.beta_acq, P.max_freq,
+                                                        P.min_freq, &far, &seen);
     if (2 * far > seen) {
         phase = (phase > 0) ? phase - (T)PDT_PI : phase + (T)PDT_PI;     // stays inside (-2pi, 2pi)
         if (freq >= 0 && phase < 0) phase += (T)(2 * PDT_PI);
         if (freq < 0 && phase > 0) phase -= (T)(2 * PDT_PI);
     }
-    pll_phase_range<T, false, SLOW>(theta, phi, a1, start, phase, freq, P.alpha_trk, P.beta_trk, P.max_freq, P.min_freq);
+    pll_phase_range<T, false, SLOW, true>(theta, phi, B, a1, start, phase, freq, P.alpha_trk, P.beta_trk, P.max_freq, P.min_freq);
     PllSeam<T> sm;
     sm.phase0 = phase;
     sm.freq0 = freq;
-    pll_phase_range<T, true, SLOW>(theta, phi, start, end, phase, freq, P.alpha_trk, P.beta_trk, P.max_freq, P.min_freq);
+    pll_phase_range<T, true, SLOW, true>(theta, phi, B, start, end, phase, freq, P.alpha_trk, P.beta_trk, P.max_freq, P.min_freq);
     sm.phase1 = phase;
     sm.freq1 = freq;
     seams[j] = sm;
@@ -960,8 +1043,8 @@ __device__ __forceinline__ void k_pll_head(const T *__restrict__ theta, long lon
             sm.phase0 = phase;
             sm.freq0 = freq;
             // phi_head is indexed from the 16-byte aligned sample at or below S (vector stores stay aligned)
-            pll_phase_range<T, true, SLOW, 32>(theta, phi_head - (S & ~3ll), pos, end, phase, freq, P.alpha_trk, P.beta_trk,
-                                               P.max_freq, P.min_freq);
+            pll_phase_range<T, true, SLOW, false, 32>(theta, phi_head - (S & ~3ll), B, pos, end, phase, freq, P.alpha_trk, P.beta_trk,
+                                                      P.max_freq, P.min_freq);
             sm.phase1 = phase;
             sm.freq1 = freq;
             seams_head[k] = sm;
@@ -1019,7 +1102,7 @@ __device__ __forceinline__ void k_pll_fix(const T *__restrict__ theta, long long
     const long long nb_abs = (n + B - 1) / B;                       // absolute block count
     const long long BS = (B + 63) & ~63ll;                          // scratch stride per wavefront
     // graft the head's true phases and seam records over the block-parallel ones
-    for (long long i = hi.s0 + threadIdx.x; i < hi.s1; i += PDT_FIX_THREADS) phi[i] = phi_head[i - (hi.s0 & ~3ll)];
+    for (long long i = hi.s0 + threadIdx.x; i < hi.s1; i += PDT_FIX_THREADS) phi[Lt<T>::index(i, B)] = phi_head[i - (hi.s0 & ~3ll)];
     for (long long k = threadIdx.x; k < hi.nblk; k += PDT_FIX_THREADS) seams[j0 + k] = seams_head[k];
     __threadfence();
     __syncthreads();
@@ -1068,8 +1151,8 @@ __device__ __forceinline__ void k_pll_fix(const T *__restrict__ theta, long long
             const long long start = rb * B;
             const long long end = ((rb + 1) * B < n) ? (rb + 1) * B : n;
             // scratch index = sample index - (start rounded down to 4): vector stores stay aligned
-            pll_phase_range<T, true, SLOW, 32>(theta, scratch + (long long)wave * BS - (start & ~3ll), start, end, phase, freq,
-                                               P.alpha_trk, P.beta_trk, P.max_freq, P.min_freq);
+            pll_phase_range<T, true, SLOW, false, 32>(theta, scratch + (long long)wave * BS - (start & ~3ll), B, start, end, phase, freq,
+                                                      P.alpha_trk, P.beta_trk, P.max_freq, P.min_freq);
             s_end[wave][0] = phase;
             s_end[wave][1] = freq;
         }
@@ -1088,7 +1171,7 @@ __device__ __forceinline__ void k_pll_fix(const T *__restrict__ theta, long long
             const long long start = rb * B;
             const long long end = ((rb + 1) * B < n) ? (rb + 1) * B : n;
             const T *src = scratch + (long long)q * BS - (start & ~3ll);
-            for (long long i = start + threadIdx.x; i < end; i += PDT_FIX_THREADS) phi[i] = src[i];
+            for (long long i = start + threadIdx.x; i < end; i += PDT_FIX_THREADS) phi[Lt<T>::index(i, B)] = src[i];
             if (threadIdx.x == 0) {
                 const PllSeam<T> prev = seams[rb - 1];
                 PllSeam<T> upd;
@@ -1119,8 +1202,8 @@ __device__ __forceinline__ void k_pll_fix(const T *__restrict__ theta, long long
                     T phase = prev.phase1, freq = prev.freq1;
                     const long long start = r * B;
                     const long long end = ((r + 1) * B < n) ? (r + 1) * B : n;
-                    pll_phase_range<T, true, SLOW, 32>(theta, phi, start, end, phase, freq, P.alpha_trk, P.beta_trk, P.max_freq,
-                                                       P.min_freq);
+                    pll_phase_range<T, true, SLOW, true, 32>(theta, phi, B, start, end, phase, freq, P.alpha_trk, P.beta_trk, P.max_freq,
+                                                             P.min_freq);
                     PllSeam<T> upd;
                     upd.phase0 = prev.phase1;
                     upd.freq0 = prev.freq1;
@@ -1147,18 +1230,29 @@ __device__ __forceinline__ void k_pll_fix(const T *__restrict__ theta, long long
 }
 
 // elementwise mix for the samples after the lock (:106-113), and the lock-detector input
-// term lockSigAlpha*(re*t_real + im*t_imag) (:194-220) when the lock stream is wanted
+// term lockSigAlpha*(re*t_real + im*t_imag) (:194-220) when the lock stream is wanted.  The phases arrive in the LT
+// layout: a workgroup takes RG rows of one tile (coalesced), transposes them through LDS and then works along the 64
+// lane-rows in natural order -- I/Q in, mixed samples out, both in runs of RG * 16 bytes.
 template <typename T, bool LOCKSIG>
-__device__ __forceinline__ void k_pll_mix(IqSrc pcm, const T *__restrict__ phi, long long n,
+__device__ __forceinline__ void k_pll_mix(IqSrc pcm, const T *__restrict__ phi_lt, long long n, long long B,
                                                   PllParams<T> P, const PllLockInfo<T> *__restrict__ info,
                                                   T *__restrict__ out, T *__restrict__ lock_term)
 {
+    constexpr int VN = Lt<T>::VN, ROW = Lt<T>::ROW, RG = Lt<T>::RG;
+    __shared__ Vec16<T> s_v[64 * (RG + 1)];
     const long long lock_at = info->lock_sample;
     if (lock_at < 0) return;
-    // four samples per thread; the first sample (lock + 1) has no particular alignment, so the 16-byte accesses are
-    // declared 4-byte (8-byte) aligned
-    const long long i = lock_at + 1 + ((long long)blockIdx.x * blockDim.x + threadIdx.x) * 4;
-    if (i >= n) return;
+    const long long S = lock_at + 1;
+    const long long groups = B / (VN * RG);
+    const long long w = (long long)blockIdx.x / groups, g = (long long)blockIdx.x - w * groups;
+    if ((w << 6) * B >= n) return;
+    if (((w << 6) + 63) * B + (g * RG + RG) * VN <= S) return;            // everything here precedes the lock
+#pragma unroll
+    for (int pass = 0; pass < 4; pass++) {
+        const int qd = pass * 4 + ((int)threadIdx.x >> 6), l = (int)threadIdx.x & 63;
+        s_v[l * (RG + 1) + qd] = *reinterpret_cast<const Vec16<T> *>(phi_lt + (w << 6) * B + (g * RG + qd) * ROW + l * VN);
+    }
+    __syncthreads();
     auto one = [&](T a, T b, T ph, T &o, T &lt) {
         T t_real, t_imag;
         Real<T>::sincos(ph, t_imag, t_real);
@@ -1171,27 +1265,35 @@ __device__ __forceinline__ void k_pll_mix(IqSrc pcm, const T *__restrict__ phi, 
             lt = P.lock_alpha * (re * t_real + im * t_imag);
         }
     };
-    if (i + 4 <= n) {
-        struct __attribute__((packed, aligned(sizeof(T)))) Quad { T v[4]; };
-        T a[4], b[4];
-        if (pcm.fmt == 0) iq_block<T, 0, 4>(pcm.p, i, a, b);
-        else iq_block<T, 1, 4>(pcm.p, i, a, b);
-        const Quad ph = *reinterpret_cast<const Quad *>(phi + i);
-        Quad o, lt;
 #pragma unroll
-        for (int e = 0; e < 4; e++) {
-            lt.v[e] = 0;
-            one(a[e], b[e], ph.v[e], o.v[e], lt.v[e]);
-        }
-        *reinterpret_cast<Quad *>(out + i) = o;
-        if (LOCKSIG) *reinterpret_cast<Quad *>(lock_term + i) = lt;
-    } else {
-        for (long long k = i; k < n; k++) {
-            T a, b, o, lt = 0;
-            IqSample<T>::get(pcm, k, a, b);
-            one(a, b, phi[k], o, lt);
-            out[k] = o;
-            if (LOCKSIG) lock_term[k] = lt;
+    for (int pass = 0; pass < 4; pass++) {
+        const int l = pass * 16 + ((int)threadIdx.x >> 4), qd = (int)threadIdx.x & 15;
+        const long long i = ((w << 6) + l) * B + (g * RG + qd) * VN;
+        if (i >= n || i + VN <= S) continue;
+        const Vec16<T> ph = s_v[l * (RG + 1) + qd];
+        if (i >= S && i + VN <= n) {
+            T a[VN], b[VN];
+            iq_vec<T>(pcm, i, a, b);
+            Vec16<T> o, lt;
+#pragma unroll
+            for (int e = 0; e < VN; e++) {
+                lt.v[e] = 0;
+                one(a[e], b[e], ph.v[e], o.v[e], lt.v[e]);
+            }
+            *reinterpret_cast<Vec16<T> *>(out + i) = o;                     // i is a multiple of VN
+            if (LOCKSIG) *reinterpret_cast<Vec16<T> *>(lock_term + i) = lt;
+        } else {
+#pragma unroll
+            for (int e = 0; e < VN; e++) {
+                const long long k = i + e;
+                if (k >= S && k < n) {
+                    T a, b, o, lt = 0;
+                    IqSample<T>::get(pcm, k, a, b);
+                    one(a, b, ph.v[e], o, lt);
+                    out[k] = o;
+                    if (LOCKSIG) lock_term[k] = lt;
+                }
+            }
         }
     }
 }
