@@ -219,7 +219,7 @@ struct Plan {
 // context is opened; the demodulation calls never look at the environment.
 struct Tuning {
     double pll_warm_scale = 1.0, head_taus = 0.0, agc_k = 0.0;
-    int agc_tpb = 0, gseg = 0, acquire_mode = 0;      // acquire_mode: 0 = two-wavefront pipeline, 1 = plain one-lane, 2 = one wavefront
+    int agc_tpb = 0, gseg = 0, acquire_mode = 0, pll_block = 0;      // acquire_mode: 0 = two-wavefront pipeline, 1 = plain one-lane, 2 = one wavefront
     bool fir_generic = false, agc_unfused = false, no_excl = false, gtab_nomerge = false, gardner_onebuf = false, debug_sync = false;
     void load()
     {
@@ -227,6 +227,7 @@ struct Tuning {
         if (const char *e = getenv("PDT_HEAD_TAUS")) head_taus = atof(e);
         if (const char *e = getenv("PDT_AGC_K")) agc_k = atof(e);
         if (const char *e = getenv("PDT_AGC_TPB")) agc_tpb = std::max(1, atoi(e));
+        if (const char *e = getenv("PDT_PLL_BLOCK")) pll_block = atoi(e);
         if (const char *e = getenv("PDT_GSEG")) gseg = std::min(64, std::max(2, atoi(e)));
         if (getenv("PDT_ACQUIRE_SIMPLE")) acquire_mode = 1;
         else if (getenv("PDT_ACQUIRE_ONEWAVE")) acquire_mode = 2;
@@ -271,6 +272,7 @@ struct pdt_ctx {
     void *packs_pin = nullptr;          // pinned staging of the same
     size_t packs_pin_cap = 0;
     pdt_ctx *leader = nullptr;          // context whose streams / events carried the last execution
+    int batch_hint = 1;                 // captures demodulated together with this one (sizes the block-parallel geometry)
     // host -> HBM ingest of a capture (file or memory): pinned slots filled by a few host threads, copies on a stream of their own
     void *ingest_pin = nullptr;
     size_t ingest_pin_cap = 0;
@@ -636,6 +638,15 @@ template <typename T> int run_capture(pdt_ctx *ctx, uint64_t n, int phase = RUN_
     long long Wacq = (long long)(0.02 * fs_d);             // acquisition-gain stage of the warm-up
     long long Ba = ctx->cfg.agc_block ? ctx->cfg.agc_block : (long long)((argos ? 0.125 : 0.0625) * fs_d * interp);
     long long Wa = ctx->cfg.agc_warm ? ctx->cfg.agc_warm : (long long)((argos ? 8.0 : 1.0) * fs_d * interp);
+    if (!ctx->cfg.pll_block) {
+        // One walker wavefront saturates the vector ALU of its SIMD (a wave64 instruction occupies the 16 lanes for 4 clocks), so
+        // a second one on the same SIMD doubles the time of both: keep the walkers of everything that runs together -- this
+        // capture, or the whole batch -- under ~one per SIMD (240 groups of four; the rest is left to the serial kernels).
+        const long long groups_max = 240;
+        const long long share = std::max<long long>(1, groups_max / std::max(1, ctx->batch_hint));
+        const long long b_min = (N + share * 256 - 1) / (share * 256);
+        Bp = std::max(Bp, b_min);
+    }
     Bp = std::min<long long>(Bp, std::max<long long>(N, 1));   // (one block at most: the LT layout keeps 64 blocks per tile)
     Bp = std::max<long long>(64, (Bp + 63) / 64 * 64);         // whole transposition groups of the LT layout (pdt_kernels_front.h)
     Ba = std::max<long long>(64, round4(Ba));
@@ -753,7 +764,10 @@ template <typename T> int run_capture(pdt_ctx *ctx, uint64_t n, int phase = RUN_
         L.end();
     }
     // fork: the block-parallel phase recurrence (side stream) runs beside the sequential acquisition
-    const long long grid_pll = (nb_pll + 63) / 64;
+    // workgroups of four wavefronts: the dispatcher spreads a workgroup's wavefronts over the four SIMDs of a CU, so the
+    // walkers are balanced over the SIMDs by construction (single-wavefront groups piled up on some SIMDs once there were
+    // more than ~1000 of them: 250 ksps hour-long captures, batches)
+    const long long grid_pll = (nb_pll + 255) / 256;
     // a single +-2pi correction per step is exact as long as one step cannot move the phase by 2pi
     const double worst = (double)PP.max_freq + M_PI * std::max({(double)PP.alpha_acq + (double)PP.beta_acq,
                                                                 (double)PP.alpha_trk + (double)PP.beta_trk,
@@ -763,17 +777,17 @@ template <typename T> int run_capture(pdt_ctx *ctx, uint64_t n, int phase = RUN_
         PL.simple(OP_FORK);
         L.begin("pll_phase", ctx->stream2);
         if (slow_wrap)
-            PDT_LAUNCH(64, (k_pll_phase<T, true>), dim3((unsigned)grid_pll), dim3(64), 0, ctx->stream2, d_pcm, d_theta, N, PP, Bp,
+            PDT_LAUNCH(256, (k_pll_phase<T, true>), dim3((unsigned)grid_pll), dim3(256), 0, ctx->stream2, d_pcm, d_theta, N, PP, Bp,
                                Wacq, Wp, lag, d_phi, (PllSeam<T> *)ctx->seams_pll.p);
         else
-            PDT_LAUNCH(64, (k_pll_phase<T, false>), dim3((unsigned)grid_pll), dim3(64), 0, ctx->stream2, d_pcm, d_theta, N, PP, Bp,
+            PDT_LAUNCH(256, (k_pll_phase<T, false>), dim3((unsigned)grid_pll), dim3(256), 0, ctx->stream2, d_pcm, d_theta, N, PP, Bp,
                                Wacq, Wp, lag, d_phi, (PllSeam<T> *)ctx->seams_pll.p);
         L.end();
         PL.simple(OP_JOIN_RECORD);
     }
     // the serial kernels (acquisition, head) ask for SIMDs of their own while the block-parallel kernel beside them
     // leaves some free (1 024 SIMDs; it runs one wavefront per 64 blocks)
-    const bool serial_excl = grid_pll <= 768 && !ctx->tune.no_excl;
+    const bool serial_excl = 4 * grid_pll <= 960 && !ctx->tune.no_excl;
     L.begin("pll_acquire");
     if (ctx->tune.acquire_mode == 1)        // plain one-lane form, kept for A/B checks
         PDT_LAUNCH(64, k_pll_acquire<T>, dim3(1), dim3(64), 0, st, d_pcm, N, PP, d_pll, d_lock, d_info);
@@ -1412,6 +1426,7 @@ int pdt_open(const pdt_config *cfg, pdt_ctx **out)
     pdt_ctx *ctx = new pdt_ctx();
     ctx->cfg = *cfg;
     ctx->tune.load();
+    if (ctx->tune.pll_block && !ctx->cfg.pll_block) ctx->cfg.pll_block = (uint32_t)ctx->tune.pll_block;
     if (!ctx->cfg.chunk) ctx->cfg.chunk = (cfg->mode == PDT_MODE_ARGOS || cfg->chain == PDT_CHAIN_LIVE) ? 2400 : 10000;
     ctx->elem = cfg->mode == PDT_MODE_ARGOS ? 8 : 4;
     int nt = 0, ip = 0;
@@ -1523,6 +1538,7 @@ int pdt_keep_presquelch(pdt_ctx *ctx, int enable)
 
 static int demod_common(pdt_ctx *ctx, uint64_t nframes, int phase = RUN_ALL)
 {
+    if (phase == RUN_ALL) ctx->batch_hint = 1;
     HIP_TRY(hipSetDevice(ctx->cfg.device));
     ctx->n_samples = nframes;
     ctx->n_out = nframes * ctx->interp;
@@ -1672,6 +1688,8 @@ int pdt_demod_batch_device(pdt_ctx *const *ctxs, const void *const *iq_device, c
     int first_err = PDT_OK, enq = 0;
     for (; enq < count; enq++) {                                        // the plan of every capture (host only)
         pdt_ctx *c = ctxs[enq];
+        c->batch_hint = 0;
+        for (int k = 0; k < count; k++) c->batch_hint += (ctxs[k]->cfg.device == c->cfg.device) ? 1 : 0;
         c->pcm_dev = iq_device[enq];
         c->pcm_fmt = 0;
         const int rc = demod_common(c, nframes[enq], RUN_ENQUEUE);

@@ -1,0 +1,32 @@
+"""Long-running GPU checks: the randomised configuration sweep with a fixed seed, and -- behind PDT_TEST_FULL=1, it costs
+a minute of one host core -- BASELINE configs[2] at full size against the reference's own CPU objects."""
+import os
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+
+
+def test_fuzz_fixed_seed():
+    """50 random configurations (sample rate, chunk size, length incl. empty, carrier offset, noise, block geometry, sampler,
+    streaming block size): every stage bit-identical to the oracle.  tests/tools/fuzz.py, seed 20260929."""
+    r = subprocess.run([sys.executable, os.path.join(HERE, "tools", "fuzz.py"), "50", "20260929"], capture_output=True, text=True)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
+    assert "50/50 identical" in r.stdout
+
+
+@pytest.mark.skipif(not os.environ.get("PDT_TEST_FULL"), reason="set PDT_TEST_FULL=1: 900 M samples, ~65 s of reference CPU time")
+def test_configs2_full_size_against_the_reference_objects():
+    """250 ksps x 60 min = 900 000 000 samples (3.6 GB of I/Q): output file byte-identical to the reference's own objects."""
+    ref = os.path.join(ROOT, "oracle", "_ref", "ref_demodPOES")
+    if not os.path.exists(ref):
+        pytest.skip("oracle/_ref was not built (no reference tree when the library was built)")
+    env = dict(os.environ, PDT_SECS="3600", PDT_RATE="250000")
+    r = subprocess.run([sys.executable, os.path.join(HERE, "tools", "c3_check.py")], capture_output=True, text=True, env=env)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
+    assert "output identical: True" in r.stdout

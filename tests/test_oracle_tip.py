@@ -80,3 +80,11 @@ def test_unchecked_words_and_parity_bits():
     for shift in (7, 6, 0):                                        # CPU flags and the unchecked sixth group
         bad = bytearray(b); bad[103] ^= 1 << shift
         assert orc.tip_check([(t, bytes(bad), c)])[1]["parity"][0] == 0
+
+
+def test_hand_derived_known_answers():
+    """tests/tip_kat.py: nine frames whose expected records were derived by hand from checkParity.m / daytimeDecode.m --
+    the pin of the oracle's restatement that does not depend on the oracle itself (there is no MATLAB here)."""
+    import tip_kat
+    sm, rec = orc.tip_check([(t, b, True) for _, t, b, _ in tip_kat.VECTORS])
+    tip_kat.check(rec, sm)
