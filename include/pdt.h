@@ -39,7 +39,9 @@
  *   pdt_demod_device    same, input already resident in HBM (bench / multi-capture)
  *   pdt_demod_f32       the same loop over GetComplexRawChunk (wave.c:413-540): RAW float32 captures
  *   pdt_stream_*        the same loop fed block by block, as POESTIPdemodPortAudio/main.c:324-393 is by
- *                       Pa_ReadStream (the sound-card side itself is out of scope)
+ *                       Pa_ReadStream (the sound-card side itself is out of scope); the function-local statics that carry
+ *                       each stage from chunk to chunk there (CarrierTrackingPLL.c:60-75, LowPassFilter.c:21-27, AGC.c:83-84,
+ *                       GardenerClockRecovery.c:11-15, ManchesterDecode.c:16-21, ByteSync.c:18-22) are the carried state here
  *   pdt_frames          the fprintf stream of ByteSync.c, as records
  *   pdt_format_frames   the text ByteSync.c writes to the output file
  *   pdt_tip_check       the downstream frame validation the reference keeps in MATLAB:
@@ -196,24 +198,29 @@ int  pdt_demod_batch_device(pdt_ctx *const *ctxs, const void *const *iq_device, 
 int  pdt_demod_f32(pdt_ctx *ctx, const float *iq_host, uint64_t nframes);
 int  pdt_demod_device_f32(pdt_ctx *ctx, const void *iq_device, uint64_t nframes);
 
-/* Streaming front end: feed a capture piece by piece, as the reference's real-time twin
- * does with 2 400-frame sound-card blocks (POESTIPdemodPortAudio/main.c:324-393), and collect minor frames
- * as they become final.  The reference chain is causal per chunk and prints frames as their bits arrive;
- * here every push that completes at least one more reference chunk demodulates EVERYTHING received so far
- * again (the whole chain takes a few milliseconds for an hour of 48 ksps audio) and reports the frames that
- * are new and lie safely before the end of the data.  Guarantee: the frames reported by the pushes followed
- * by those of pdt_stream_end are exactly the frames of one pdt_demod_* call on the whole capture.
- *   pdt_stream_begin      forget any accumulated input (the sample format is fixed by the first push)
+/* Streaming front end: feed a capture piece by piece, as the reference's real-time twin does with
+ * 2 400-frame sound-card blocks (POESTIPdemodPortAudio/main.c:324-393), and collect minor frames as they become final.
+ * Like the reference's chunk loop, every stage carries its state from one piece of work to the next: whenever a push
+ * completes one or more reference chunks, exactly those new chunks are demodulated -- PLL phase / frequency / lock state,
+ * the FIR's last inputs, AGC gain, sampler state (nextSample, halfSample, prev), Manchester history and clock phase, the
+ * byte synchroniser's last bits and open frame all continue from where the previous segment ended -- and the frames
+ * completed by these chunks are reported.  Cost per push depends on the push, not on the length of the stream; the device
+ * keeps a bounded window of the input (the PLL's warm-up history, see pdt_stream_retained) and nothing else of the past.
+ * Guarantee: the frames reported by the pushes followed by those of pdt_stream_end are exactly the frames of one
+ * pdt_demod_* call on the whole capture.
+ *   pdt_stream_begin      forget any stream in progress (the sample format is fixed by the first push)
  *   pdt_stream_push_*     append nframes I,Q pairs; *new_frames = frames that became final with this push
- *   pdt_stream_end        the capture is over: demodulate all of it (short last chunk included) and report
- *                         the remaining frames; afterwards pdt_frames / pdt_get_stats / pdt_format_frames
- *                         describe the whole capture
- *   pdt_stream_frames     the frames reported by the last push / end, in order                              */
+ *   pdt_stream_end        the capture is over: demodulate the short last chunk, report the remaining frames (a frame cut
+ *                         by the end stays partial, Q11); afterwards pdt_frames / pdt_get_stats / pdt_format_frames
+ *                         describe the whole stream
+ *   pdt_stream_frames     the frames reported by the last push / end, in order
+ *   pdt_stream_retained   input samples the device currently holds (history + not yet demodulated)                  */
 int      pdt_stream_begin(pdt_ctx *ctx);
 int      pdt_stream_push_pcm16(pdt_ctx *ctx, const int16_t *iq_host, uint64_t nframes, uint64_t *new_frames);
 int      pdt_stream_push_f32(pdt_ctx *ctx, const float *iq_host, uint64_t nframes, uint64_t *new_frames);
 int      pdt_stream_end(pdt_ctx *ctx, uint64_t *new_frames);
 uint64_t pdt_stream_frames(const pdt_ctx *ctx, pdt_frame *out, uint64_t max_frames);
+uint64_t pdt_stream_retained(const pdt_ctx *ctx);
 
 /* Results of the last pdt_demod_* call. */
 uint64_t pdt_num_frames(const pdt_ctx *ctx);

@@ -117,7 +117,7 @@ ABI_SYMBOLS = [
     "pdt_format_frames", "pdt_read_stage", "pdt_stage_len", "pdt_kernel_times", "pdt_make_lpf",
     "pdt_wav_parse_header", "pdt_time_axis", "pdt_stage_bytesync", "pdt_tip_check", "pdt_tip_frames",
     "pdt_stream_begin", "pdt_stream_push_pcm16", "pdt_stream_push_f32", "pdt_stream_end", "pdt_stream_frames",
-    "pdt_keep_presquelch", "pdt_demod_fd", "pdt_format_records",
+    "pdt_keep_presquelch", "pdt_demod_fd", "pdt_format_records", "pdt_stream_retained",
 ]
 
 _lib = None
@@ -173,6 +173,8 @@ def lib():
     L.pdt_stream_end.argtypes = [C.c_void_p, C.POINTER(C.c_uint64)]
     L.pdt_stream_frames.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64]
     L.pdt_stream_frames.restype = C.c_uint64
+    L.pdt_stream_retained.argtypes = [C.c_void_p]
+    L.pdt_stream_retained.restype = C.c_uint64
     L.pdt_tip_check.argtypes = [C.c_void_p, C.POINTER(TipSummary)]
     L.pdt_tip_frames.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64]
     L.pdt_tip_frames.restype = C.c_uint64
@@ -350,6 +352,10 @@ class Demodulator:
         n = C.c_uint64(0)
         _check(self._L.pdt_stream_end(self._h, C.byref(n)), "pdt_stream_end")
         return self._stream_new(n.value)
+
+    def stream_retained(self) -> int:
+        """Input samples the device currently holds for the stream (history + not yet demodulated): bounded."""
+        return int(self._L.pdt_stream_retained(self._h))
 
     def tip_check(self):
         """Frame validation of the last demodulation (the reference's MATLAB checkParity.m / daytimeDecode.m,

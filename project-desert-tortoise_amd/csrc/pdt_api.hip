@@ -51,6 +51,22 @@ struct DevBuf {
         cap = want;
         return PDT_OK;
     }
+    // grow, keeping the first `keep` bytes (the windows of a stream hold history the next segment reads)
+    int ensure_keep(size_t bytes, size_t keep)
+    {
+        if (bytes <= cap) return PDT_OK;
+        void *np = nullptr;
+        const size_t want = bytes + bytes / 4 + 4096;
+        if (hipMalloc(&np, want) != hipSuccess) {
+            (void)hipGetLastError();
+            return PDT_ERR_NOMEM;
+        }
+        if (p && keep) (void)hipMemcpy(np, p, std::min(keep, cap), hipMemcpyDeviceToDevice);
+        if (p) (void)hipFree(p);
+        p = np;
+        cap = want;
+        return PDT_OK;
+    }
     void release()
     {
         if (p) (void)hipFree(p);
@@ -240,9 +256,46 @@ struct Tuning {
     }
 };
 
+// A stream is demodulated segment by segment (whole reference chunks).  Between segments every stage's exact state is
+// carried here -- T values as doubles (exact for float and double) -- and the device keeps a bounded window of the input
+// and of the few streams a later segment looks back on.
+struct StreamCarry {
+    bool active = false;          // run_capture works on a window of a stream
+    bool final_seg = false;       // the stream ends with this segment (short last chunk, partial frame reported)
+    long long first = 0;          // local index of the first new input sample (a multiple of the chunk)
+    uint64_t origin = 0;          // global sample index of local sample 0 (a multiple of lcm(chunk, FIR ring length))
+    // StaticGain / AGC
+    bool have_norm = false;
+    double norm_factor = 0, gain = 0;
+    // PLL
+    bool locked = false;
+    double phase = 0, freq = 0, avg = 0, locksig = 0, sweep = 0;
+    int64_t lock_sample = -1;     // global
+    double lock_freq_hz = 0, avg_at_lock = 0;
+    // symbol sampler (Gardner: nextSample, prev, halfSample; M&M: nextSample, stepSize, sampleLast)
+    bool have_sampler = false;
+    double sa = 0, sb = 0, sc = 0;
+    // Manchester
+    double sym_m2 = 0, sym_m1 = 0;
+    unsigned clockmod = 0;
+    uint64_t nsym_total = 0;
+    // byte sync: the last bits (from the sync word of a frame still open, else the last len-1), their time sources
+    std::vector<unsigned char> kept_bits;
+    std::vector<long long> kept_src;           // global interpolated-sample index per kept bit
+    uint64_t bit_base = 0;                     // global index of kept_bits[0]
+    uint64_t nbits_total = 0;
+    long long next_free = 0;                   // global bit index before which no new frame may open
+    bool have_pending = false;                 // an incomplete frame at the end of the last segment
+    pdt_frame pending;
+    // per segment, filled by run_capture for the stream code
+    std::vector<pdt_frame> seg_frames;
+    uint64_t seg_new_symbols = 0, seg_new_bits = 0;
+};
+
 struct pdt_ctx {
     pdt_config cfg;
     Tuning tune;
+    StreamCarry sc;
     int elem;                 // sizeof(DT)
     uint32_t interp, ntaps;
     hipStream_t stream = nullptr;
@@ -280,10 +333,12 @@ struct pdt_ctx {
     hipEvent_t ev_ingest = nullptr;
     std::vector<hipEvent_t> ingest_ev;
     double ingest_ms = 0;               // host wall time of the last ingest (issue of the last copy)
-    DevBuf stream_in;
-    uint64_t stream_n = 0, stream_done_chunks = 0, stream_reported = 0;
+    DevBuf stream_in, seg_dev, lt_theta, lt_phi;          // input window of the stream; small device block for the segment's carried-out state
+    uint64_t stream_have = 0, stream_done = 0;   // samples in the window / of them already demodulated (local indices)
+    uint64_t stream_total = 0;          // samples pushed since pdt_stream_begin
     int stream_fmt = -1;                // -1 = no push yet, 0 = pcm16, 1 = float32
     std::vector<pdt_frame> stream_new;
+    unsigned char *seg_pin = nullptr;   // pinned staging for the small per-segment transfers (part of the pend_sc block)
     pdt_stats stats;
     std::vector<pdt_kernel_time> ktimes;
     std::vector<KTimer> timers;
@@ -521,6 +576,9 @@ template <typename T> PllParams<T> make_pll_params(const pdt_ctx *ctx)
     P.sweep0 = (T)(0.2 * (2.0 * M_PI / (double)Fs));
     P.avg0 = (T)(M_PI / 2.0);
     P.phase0 = (T)0.1;
+    P.freq0 = 0;
+    P.locksig0 = 0;
+    P.i0 = 0;
     P.want_lock = (argos || live) ? 1 : 0;
     return P;
 }
@@ -546,7 +604,7 @@ SyncParams make_sync_params(bool argos)
 }
 
 void launch_bytesync(pdt_ctx *ctx, Plan &PL, hipStream_t st, const SyncParams &SP, DevScalars *d_sc, long long bit_cap, uint32_t hit_cap,
-                     uint32_t frame_cap)
+                     uint32_t frame_cap, long long min_pos = 0)
 {
     unsigned char *d_bits = (unsigned char *)ctx->bits.p;
     unsigned *d_bitsym = (unsigned *)ctx->bitsym.p;
@@ -556,13 +614,13 @@ void launch_bytesync(pdt_ctx *ctx, Plan &PL, hipStream_t st, const SyncParams &S
     const long long n_stiles = (bit_cap + 4095) / 4096;
     SyncTile *d_stiles = (SyncTile *)ctx->stiles.p;
     PDT_LAUNCH(256, k_sync_hits_tile, dim3((unsigned)n_stiles), dim3(256), 0, st, d_bits, &d_sc->nbits, SP, d_stiles,
-                       &d_sc->sync_overflow);
+                       &d_sc->sync_overflow, min_pos);
     PDT_LAUNCH(PDT_SYNC_THREADS, k_sync_frames_tiles, dim3(1), dim3(PDT_SYNC_THREADS), 0, st, (const SyncTile *)d_stiles, &d_sc->nbits, SP, d_hits, hit_cap,
                        d_frames, &d_sc->nframes, frame_cap, &d_sc->sync_overflow, (unsigned *)ctx->sync_scr.p);
     // generic path (atomic append + sort), only when a tile overflowed
     const long long grid = (bit_cap + 255) / 256;
     PDT_LAUNCH(256, k_sync_hits, dim3((unsigned)grid), dim3(256), 0, st, d_bits, &d_sc->nbits, SP, d_hits, &d_sc->nhits, hit_cap,
-                       &d_sc->sync_overflow);
+                       &d_sc->sync_overflow, min_pos);
     PDT_LAUNCH(256, k_sync_frames, dim3(1), dim3(256), 0, st, d_hits, &d_sc->nhits, hit_cap, SP, d_frames, &d_sc->nframes,
                        frame_cap, &d_sc->sync_overflow);
     PDT_LAUNCH(128, k_frame_pack, dim3(frame_cap), dim3(128), 0, st, d_bits, &d_sc->nbits, d_bitsym, d_symidx, SP, d_frames,
@@ -589,10 +647,18 @@ template <typename T> int run_capture(pdt_ctx *ctx, uint64_t n, int phase = RUN_
     hipStream_t st = ctx->stream;
     Plan &PL = ctx->plan;
     PlanGroups L{PL, ctx->cfg.profile != 0};
+    // stream segment: the window [0, n) holds history before `first`; every stage starts at `first` from the carried state
+    StreamCarry *seg = ctx->sc.active ? &ctx->sc : nullptr;
+    const long long first = seg ? seg->first : 0;
+    const long long first_out = first * interp;
 
     // ---- parameters
     const T Fs = (T)ctx->cfg.sample_rate;
     PllParams<T> PP = make_pll_params<T>(ctx);
+    if (seg && first > 0 && !seg->locked) {          // the acquisition goes on where the last segment left it
+        PP.phase0 = (T)seg->phase; PP.freq0 = (T)seg->freq; PP.avg0 = (T)seg->avg; PP.locksig0 = (T)seg->locksig;
+        PP.sweep0 = (T)seg->sweep; PP.i0 = first;
+    }
     AgcParams<T> AP;
     const T fsi = Fs * (T)interp;                                              // POESTIPdemod/main.c:429
     AP.attack = (T)(79.5775 * (2.0 * M_PI / (double)fsi));
@@ -654,7 +720,7 @@ template <typename T> int run_capture(pdt_ctx *ctx, uint64_t n, int phase = RUN_
     // deliver the AGC's affine tile maps itself (0 = not fused: explicit block size, ARGOS, generic FIR)
     long long agc_tiles_per_block = 0, fused_tiles = 0;
     if (!argos && !ctx->cfg.agc_block && ntaps == 26 * interp && ctx->taps_rot.p && !ctx->tune.fir_generic &&
-        !ctx->tune.agc_unfused) {
+        !ctx->tune.agc_unfused && !seg) {
         const long long tile_out = 64ll * 26 * interp;
         agc_tiles_per_block = std::max<long long>(1, (Ba + tile_out / 2) / tile_out);
         if (ctx->tune.agc_tpb) agc_tiles_per_block = ctx->tune.agc_tpb;
@@ -671,7 +737,7 @@ template <typename T> int run_capture(pdt_ctx *ctx, uint64_t n, int phase = RUN_
     lag = std::max(1, std::min(lag, (int)(fs_d / (2.2 * f_lim))));
     lag = std::min(lag, 64);
     const long long nb_pll = N / Bp + 2;
-    const long long nb_agc = (n_out + Ba - 1) / Ba + 1;
+    const long long nb_agc = (n_out - first_out + Ba - 1) / Ba + 1;
 
     // ---- capacities
     double min_step = (double)GP.step - 0.25;
@@ -681,7 +747,7 @@ template <typename T> int run_capture(pdt_ctx *ctx, uint64_t n, int phase = RUN_
         min_step = (double)(int)fsi / ((double)baud + rg) * 0.999;
     }
     const long long n_chunks = chunk_out > 0 ? (n_out + chunk_out - 1) / chunk_out : 0;
-    const long long sym_cap = (long long)((double)n_out / min_step) + n_chunks + 64;
+    const long long sym_cap = (long long)((double)n_out / min_step) + n_chunks + 64 + (seg ? 2 * PDT_SEG_KEEP : 0);
     const long long bit_cap = sym_cap;
     // worst legal hit density: the ARGOS word overlaps itself by 3 bits (one hit per 10 bits), the POES word followed by
     // its inverse by 3 (one per 16) -- e.g. a repeated sync-word test pattern; the reference decodes such streams
@@ -691,14 +757,26 @@ template <typename T> int run_capture(pdt_ctx *ctx, uint64_t n, int phase = RUN_
     const long long n0 = std::min<long long>(chunk, N);
 
     int rc;
+    if (seg) {
+        // the windows of a stream keep what earlier segments wrote (FIR history, stale reads of the sampler's chunk seams)
+        if ((rc = ctx->pll.ensure_keep((size_t)(N + 1) * sizeof(T), (size_t)first * sizeof(T)))) return rc;
+        if (need_lock && (rc = ctx->lock.ensure_keep((size_t)(N + 1) * sizeof(T), (size_t)first * sizeof(T)))) return rc;
+    }
     if ((rc = ctx->pll.ensure((size_t)(N + 1) * sizeof(T)))) return rc;
     if (need_lock && (rc = ctx->lock.ensure((size_t)(N + 1) * sizeof(T)))) return rc;
     // theta and the phases live in the FIR / AGC buffers before those are written, in the lane-tiled layout: whole tiles of
     // 64 blocks, plus the rows the walkers' look-ahead loads may touch past a tile
     const long long lt_tiles = (N / Bp + 1 + 63) / 64;
     const long long lt_elems = lt_tiles * 64 * Bp + 48 * 64 * (16 / (long long)sizeof(T)) + 64;
-    if ((rc = ctx->fir.ensure((size_t)(std::max(n_out, lt_elems) + 1) * sizeof(T)))) return rc;
-    if ((rc = ctx->agc.ensure((size_t)(std::max(n_out, lt_elems) + 1) * sizeof(T)))) return rc;
+    if (seg) {
+        // ... so theta and the phases get buffers of their own there (the AGC window must survive the PLL)
+        if ((rc = ctx->agc.ensure_keep((size_t)(n_out + 1) * sizeof(T), (size_t)first_out * sizeof(T)))) return rc;
+        if ((rc = ctx->lt_theta.ensure((size_t)(lt_elems + 1) * sizeof(T)))) return rc;
+        if ((rc = ctx->lt_phi.ensure((size_t)(lt_elems + 1) * sizeof(T)))) return rc;
+        if ((rc = ctx->seg_dev.ensure(sizeof(SegTail<T>) + 256))) return rc;
+    }
+    if ((rc = ctx->fir.ensure((size_t)((seg ? n_out : std::max(n_out, lt_elems)) + 1) * sizeof(T)))) return rc;
+    if ((rc = ctx->agc.ensure((size_t)((seg ? n_out : std::max(n_out, lt_elems)) + 1) * sizeof(T)))) return rc;
     if (ctx->keep_agc_raw && (rc = ctx->agc_raw.ensure((size_t)(n_out + 1) * sizeof(T)))) return rc;
     if (ctx->keep_agc_raw) AP.raw_out = (T *)ctx->agc_raw.p;
     if ((rc = ctx->sym.ensure((size_t)sym_cap * sizeof(T)))) return rc;
@@ -748,15 +826,24 @@ template <typename T> int run_capture(pdt_ctx *ctx, uint64_t n, int phase = RUN_
     PL.memset_async(d_frames, 0, (size_t)frame_cap * sizeof(FrameRec));
 
     // ---- StaticGain over the first chunk (main.c:384-389)
-    L.begin("static_gain");
-    PDT_LAUNCH(256, k_static_gain<T>, dim3(1), dim3(256), 0, st, d_pcm, n0, (T *)ctx->mag.p, (T)1.0,
-                       ctx->cfg.norm_override, d_norm);
-    L.end();
+    // per-segment staging in pinned memory (lives until the plan has run): [0] AGC gain, [64] lock record, [256] two
+    // history symbols, [512] kept bits
+    unsigned char *spin = ctx->seg_pin;
+    if (seg && seg->have_norm) {
+        const T g = (T)seg->gain;                    // the AGC goes on from its gain at the end of the last segment
+        memcpy(spin, &g, sizeof g);
+        PL.copy(OP_H2D, d_norm, spin, sizeof(T));
+    } else {
+        L.begin("static_gain");
+        PDT_LAUNCH(256, k_static_gain<T>, dim3(1), dim3(256), 0, st, d_pcm, n0, (T *)ctx->mag.p, (T)1.0,
+                           ctx->cfg.norm_override, d_norm);
+        L.end();
+    }
 
     // ---- PLL: sequential acquisition, then theta / block-parallel phase recurrence / seam repair / mix.
     // theta and phase live in the (not yet used) FIR and AGC buffers.
-    T *d_theta = d_fir;
-    T *d_phi = d_agc;
+    T *d_theta = seg ? (T *)ctx->lt_theta.p : d_fir;
+    T *d_phi = seg ? (T *)ctx->lt_phi.p : d_agc;
     const long long lt_groups = lt_tiles * (Bp / (16 * (16 / (long long)sizeof(T))));      // workgroups of the transposing kernels
     if (N > 0) {
         L.begin("pll_theta");
@@ -789,7 +876,18 @@ template <typename T> int run_capture(pdt_ctx *ctx, uint64_t n, int phase = RUN_
     // leaves some free (1 024 SIMDs; it runs one wavefront per 64 blocks)
     const bool serial_excl = 4 * grid_pll <= 960 && !ctx->tune.no_excl;
     L.begin("pll_acquire");
-    if (ctx->tune.acquire_mode == 1)        // plain one-lane form, kept for A/B checks
+    if (seg && seg->locked) {
+        // the lock happened in an earlier segment: the kernels that start "after the lock" start at `first` with the carried
+        // true state (the head walks the first samples, the block-parallel results are validated against it as ever)
+        PllLockInfo<T> li;
+        memset(&li, 0, sizeof li);
+        li.lock_sample = first - 1;
+        li.st.phase = (T)seg->phase; li.st.freq = (T)seg->freq; li.st.avg_phase = (T)seg->avg;
+        li.st.locksig = (T)seg->locksig; li.st.sweep = (T)seg->sweep;
+        li.freq_at_lock = 0; li.avg_at_lock = (T)seg->avg_at_lock;
+        memcpy(spin + 64, &li, sizeof li);
+        PL.copy(OP_H2D, d_info, spin + 64, sizeof li);
+    } else if (ctx->tune.acquire_mode == 1)        // plain one-lane form, kept for A/B checks
         PDT_LAUNCH(64, k_pll_acquire<T>, dim3(1), dim3(64), 0, st, d_pcm, N, PP, d_pll, d_lock, d_info);
     else if (ctx->tune.acquire_mode == 2) {   // single-wavefront batched form, kept for A/B checks
         if (slow_wrap)
@@ -919,9 +1017,17 @@ template <typename T> int run_capture(pdt_ctx *ctx, uint64_t n, int phase = RUN_
         L.end();
     }
 
-    // ---- AGC (+Squelch)
-    if (n_out > 0) {
-        const long long nb = (n_out + Ba - 1) / Ba;
+    // ---- AGC (+Squelch); in a stream segment over the new outputs only, from the carried gain (*d_norm)
+    long long agc_last_block = -1;
+    if (n_out - first_out > 0) {
+        const long long na = n_out - first_out;
+        const T *a_in = d_fir + first_out;
+        T *a_out = d_agc + first_out;
+        const T *a_lock = d_lock ? d_lock + first_out : nullptr;       // (indexed like the outputs: interp is 1 where it is read)
+        AgcParams<T> APs = AP;
+        if (APs.raw_out) APs.raw_out += first_out;
+        const long long nb = (na + Ba - 1) / Ba;
+        agc_last_block = nb - 1;
         const long long grid = (nb + 63) / 64;
         const bool fused = fused_tiles > 0;                    // tile maps already written by the FIR kernel
         if (!fused && (rc = ctx->agc_maps.ensure((size_t)(nb + 1) * (sizeof(AgcMap) + sizeof(double))))) return rc;
@@ -932,15 +1038,15 @@ template <typename T> int run_capture(pdt_ctx *ctx, uint64_t n, int phase = RUN_
         double agc_K = (sizeof(T) == 4) ? 11.0 : 34.0;
         if (ctx->tune.agc_k > 0) agc_K = ctx->tune.agc_k;
         L.begin("agc_block");
-        if (!fused) PDT_LAUNCH(256, k_agc_affine<T>, dim3((unsigned)nb), dim3(256), 0, st, d_fir, n_out, AP.decay, Ba, d_maps);
+        if (!fused) PDT_LAUNCH(256, k_agc_affine<T>, dim3((unsigned)nb), dim3(256), 0, st, a_in, na, APs.decay, Ba, d_maps);
         PDT_LAUNCH(1024, k_agc_guess<T>, dim3(1), dim3(1024), 0, st, (const AgcMap *)d_maps, nb, (const T *)d_norm, d_guess,
                            fused ? (int)agc_tiles_per_block : 1, fused ? fused_tiles : nb);
-        PDT_LAUNCH(64, k_agc_block<T>, dim3((unsigned)grid), dim3(64), 0, st, d_fir, n_out, AP, d_norm, Ba, Wa,
-                           (const double *)d_guess, d_lock, d_agc, (AgcSeam<T> *)ctx->seams_agc.p, agc_K);
+        PDT_LAUNCH(64, k_agc_block<T>, dim3((unsigned)grid), dim3(64), 0, st, a_in, na, APs, d_norm, Ba, Wa,
+                           (const double *)d_guess, a_lock, a_out, (AgcSeam<T> *)ctx->seams_agc.p, agc_K);
         L.end();
         L.begin("agc_fix");
-        PDT_LAUNCH(1024, k_agc_scan<T>, dim3(1), dim3(1024), 0, st, n_out, Ba, (const AgcSeam<T> *)ctx->seams_agc.p, &d_sc->agc_first_bad);
-        PDT_LAUNCH(64, k_agc_fix<T>, dim3(1), dim3(64), 0, st, d_fir, n_out, AP, Ba, d_lock, d_agc,
+        PDT_LAUNCH(1024, k_agc_scan<T>, dim3(1), dim3(1024), 0, st, na, Ba, (const AgcSeam<T> *)ctx->seams_agc.p, &d_sc->agc_first_bad);
+        PDT_LAUNCH(64, k_agc_fix<T>, dim3(1), dim3(64), 0, st, a_in, na, APs, Ba, a_lock, a_out,
                            (AgcSeam<T> *)ctx->seams_agc.p, d_sc->counters, (const long long *)&d_sc->agc_first_bad);
         L.end();
     }
@@ -955,7 +1061,7 @@ template <typename T> int run_capture(pdt_ctx *ctx, uint64_t n, int phase = RUN_
     if constexpr (std::is_same<T, float>::value) {
         const int table_len = 1 << 22;     // the table kernel walks the chunk in LDS windows: no size limit of its own
         const float nT = (float)chunk_out, stepf = (float)GP.step;
-        if (!argos && !use_mm && !ctx->force_sequential_gardner && n_chunks >= 4 && chunk_out >= 256 &&
+        if (!argos && !use_mm && !ctx->force_sequential_gardner && !seg && n_chunks >= 4 && chunk_out >= 256 &&
             chunk_out + 2 * (long long)stepf + 24 <= table_len && 8 * (long long)stepf + 256 < PDT_GTAB_WIN && chunk_out < (1 << 22)) {
             int e;
             (void)frexpf(nT - stepf - 1.0f, &e);                              // value in [2^(e-1), 2^e)
@@ -979,6 +1085,35 @@ template <typename T> int run_capture(pdt_ctx *ctx, uint64_t n, int phase = RUN_
         }
     }
     ctx->gardner_mode = use_table ? 1 : 0;
+    // stream segment: the sequential samplers go on from the carried state at chunk first / chunk; the symbol buffer starts
+    // with the two symbols the Manchester stage looks back on, placed so that local and global symbol parities agree
+    SamplerCarry<T> carry_in;
+    carry_in.a = 0; carry_in.b = 0; carry_in.c = 0; carry_in.c_first = 0; carry_in.count0 = 0;
+    SegTail<T> *d_tail = seg ? (SegTail<T> *)ctx->seg_dev.p : nullptr;
+    SamplerCarry<T> *d_carry_out = seg ? &d_tail->sampler : nullptr;
+    long long sym_pad = 0;
+    unsigned clock0 = 0;
+    unsigned long long bit0 = 0;
+    long long sync_min_pos = 0;
+    if (seg) {
+        sym_pad = 2 + (long long)(seg->nsym_total & 1u);
+        carry_in.c_first = chunk > 0 ? first / chunk : 0;
+        carry_in.count0 = sym_pad;
+        if (seg->have_sampler) { carry_in.a = (T)seg->sa; carry_in.b = (T)seg->sb; carry_in.c = (T)seg->sc; }
+        T hist[4] = { 0, 0, 0, 0 };
+        hist[sym_pad - 2] = (T)seg->sym_m2;
+        hist[sym_pad - 1] = (T)seg->sym_m1;
+        memcpy(spin + 256, hist, sizeof hist);
+        PL.copy(OP_H2D, d_sym, spin + 256, (size_t)sym_pad * sizeof(T));
+        clock0 = seg->clockmod;
+        bit0 = seg->kept_bits.size();
+        if (bit0) {
+            memcpy(spin + 512, seg->kept_bits.data(), (size_t)bit0);
+            PL.copy(OP_H2D, d_bits, spin + 512, (size_t)bit0);
+            PL.memset_async(d_bitsym, 0, (size_t)bit0 * sizeof(unsigned));
+        }
+        sync_min_pos = std::max<long long>(0, seg->next_free - (long long)seg->bit_base);
+    }
     if (use_table) {
         if constexpr (std::is_same<T, float>::value) {
             // consistent (q, last pick) combinations: the last pick is rint(q + err), |err| <= 0.1
@@ -1055,7 +1190,7 @@ template <typename T> int run_capture(pdt_ctx *ctx, uint64_t n, int phase = RUN_
             // per-chunk emission: small LDS windows so that every chunk of a 10-minute capture is resident at once
             PDT_LAUNCH(256, (k_gardner<float, PDT_GEMIT_LEN, PDT_GEMIT_OUT>), dim3((unsigned)n_chunks), dim3(PDT_GARDNER_THREADS), 0, st, (const float *)d_agc,
                                (const float *)d_lock, GP, (float *)d_sym, d_symidx, &d_sc->nsym, sym_cap,
-                               (const GardnerEntry<float> *)ctx->gentries.p);
+                               (const GardnerEntry<float> *)ctx->gentries.p, SamplerCarry<float>{0, 0, 0, 0, 0}, (SamplerCarry<float> *)nullptr);
             L.end();
         }
     } else if (use_mm) {
@@ -1069,36 +1204,47 @@ template <typename T> int run_capture(pdt_ctx *ctx, uint64_t n, int phase = RUN_
         MP.n_total = n_out;
         MP.chunk_out = chunk_out;
         L.begin("gardner");
+        if (seg && !seg->have_sampler) carry_in.b = MP.step0;                 // (the M&M state starts at stepSize = Fs / baud, MMClockRecovery.c:20)
         PDT_LAUNCH(PDT_GARDNER_THREADS, (k_mm<T, 8192, 1024>), dim3(1), dim3(PDT_GARDNER_THREADS), 0, st, (const T *)d_agc, MP, d_sym, d_symidx,
-                           &d_sc->nsym, sym_cap);
+                           &d_sc->nsym, sym_cap, carry_in, seg ? 1 : 0, d_carry_out);
         L.end();
     } else {
         L.begin("gardner");
         constexpr int SMALL_LEN = 32768 / (int)sizeof(T), SMALL_OUT = 1024;    // two 32 KiB windows
         const long long small_need = chunk_out + 2 * (long long)GP.step + 24;
         const double small_syms = (double)chunk_out / ((double)GP.step - 0.25) + 4.0;
-        if (small_need <= SMALL_LEN && small_syms < SMALL_OUT && !ctx->tune.gardner_onebuf)
+        if (small_need <= SMALL_LEN && small_syms < SMALL_OUT && !ctx->tune.gardner_onebuf && !seg)
             PDT_LAUNCH(256, (k_gardner_small<T, SMALL_LEN, SMALL_OUT>), dim3(1), dim3(256), 0, st, (const T *)d_agc, (const T *)d_lock, GP,
                                d_sym, d_symidx, &d_sc->nsym, sym_cap);
         else
             PDT_LAUNCH(256, (k_gardner<T, GardnerLds<T>::LEN, GardnerLds<T>::OUT>), dim3(1), dim3(256), 0, st, d_agc, d_lock, GP, d_sym, d_symidx,
-                               &d_sc->nsym, sym_cap, (const GardnerEntry<T> *)nullptr);
+                               &d_sc->nsym, sym_cap, (const GardnerEntry<T> *)nullptr, carry_in, d_carry_out);
         L.end();
     }
 
     // ---- Manchester
     L.begin("manchester");
     PDT_LAUNCH(PDT_TILE_THREADS, k_manch_tile<T>, dim3((unsigned)n_tiles), dim3(PDT_TILE_THREADS), 0, st, d_sym, &d_sc->nsym, manch_thr,
-                       d_tiles);
-    PDT_LAUNCH(1024, k_manch_scan, dim3(1), dim3(1024), 0, st, d_tiles, &d_sc->nsym, &d_sc->nbits);
+                       d_tiles, sym_pad);
+    PDT_LAUNCH(1024, k_manch_scan, dim3(1), dim3(1024), 0, st, d_tiles, &d_sc->nsym, &d_sc->nbits, sym_pad, clock0, bit0,
+                       seg ? &d_tail->clock : (unsigned *)nullptr);
     PDT_LAUNCH(PDT_TILE_THREADS, k_manch_emit<T>, dim3((unsigned)n_tiles), dim3(PDT_TILE_THREADS), 0, st, d_sym, &d_sc->nsym, manch_thr,
-                       d_tiles, d_bits, d_bitsym, bit_cap);
+                       d_tiles, d_bits, d_bitsym, bit_cap, sym_pad);
     L.end();
 
     // ---- byte sync
     L.begin("bytesync");
-    launch_bytesync(ctx, PL, st, SP, d_sc, bit_cap, hit_cap, frame_cap);
+    launch_bytesync(ctx, PL, st, SP, d_sc, bit_cap, hit_cap, frame_cap, sync_min_pos);
     L.end();
+    if (seg) {
+        // everything the next segment starts from, in one record
+        const long long last_pll = (N > 0) ? (N - 1) / Bp : -1;
+        PDT_LAUNCH(256, (k_seg_tail<T, PllSeam<T>, AgcSeam<T>>), dim3(1), dim3(256), 0, st, (const PllSeam<T> *)ctx->seams_pll.p, last_pll,
+                   (const T *)d_lock, N, (const AgcSeam<T> *)ctx->seams_agc.p, agc_last_block, (const T *)d_sym, &d_sc->nsym,
+                   (const unsigned char *)d_bits, (const unsigned *)d_bitsym, (const long long *)d_symidx, &d_sc->nbits,
+                   (long long)bit0, d_tail);
+        PL.copy(OP_D2H, spin + 4096, d_tail, sizeof(SegTail<T>));
+    }
     PL.simple(OP_EV1);
 
     // ---- results back to the host
@@ -1152,6 +1298,125 @@ template <typename T> int run_capture(pdt_ctx *ctx, uint64_t n, int phase = RUN_
     float ms = 0;
     (void)hipEventElapsedTime(&ms, lead->ev0, lead->ev1);
 
+    // time stamp of the bit whose symbol was taken at global interpolated-sample index g, in a capture of n_all samples
+    // 
+    auto frame_time = [&](long long g, long long n_all) -> double {
+        if (argos) return ctx->axis_d.at((uint64_t)g + 1);                   // waveDataTime[i] = (i+1)-th partial sum
+        const long long c = g / chunk_out, rr = g % chunk_out;
+        const long long j = rr / interp + 1;                                  // Q2: time of the *next* input sample
+        const long long ns_c = std::min<long long>(chunk, n_all - c * chunk);
+        if (j < ns_c) return (double)ctx->axis_f.at((uint64_t)(c * chunk + j + 1));
+        if (ns_c == chunk || c == 0) return 0.0;                              // one past the array: never-written zero
+        return (double)ctx->axis_f.at((uint64_t)((c - 1) * chunk + j + 1));   // stale value of the previous chunk
+    };
+
+    if (seg) {
+        // ---- stream segment: hand the new frames to the stream code, carry every stage's state to the next segment
+        SegTail<T> tail;
+        memcpy(&tail, ctx->seg_pin + 4096, sizeof tail);
+        const long long org_out = (long long)seg->origin * interp;
+        const long long n_all = (long long)seg->origin + N;                   // samples of the stream so far
+        const long long kept = (long long)seg->kept_bits.size();
+        const long long sym_pad = 2 + (long long)(seg->nsym_total & 1u);
+        const long long nbits_loc = (long long)sc.nbits;
+        if ((long long)sc.nsym < sym_pad || nbits_loc < kept) return PDT_ERR_STATE;
+        const uint64_t new_syms = sc.nsym - (uint64_t)sym_pad, new_bits = (uint64_t)(nbits_loc - kept);
+        // PLL
+        if (!seg->locked && info.lock_sample >= 0) {
+            seg->locked = true;
+            seg->lock_sample = info.lock_sample + (long long)seg->origin;
+            seg->lock_freq_hz = (double)(info.freq_at_lock * Fs) / (2.0 * M_PI);
+            seg->avg_at_lock = (double)info.avg_at_lock;
+        }
+        if (N > first || first == 0) {
+            if (seg->locked && N > 0) {
+                seg->phase = (double)tail.pll_phase;
+                seg->freq = (double)tail.pll_freq;
+                if (info.lock_sample == N - 1) {                              // locked on the very last sample: nothing walked after it
+                    seg->phase = (double)info.st.phase;
+                    seg->freq = (double)info.st.freq;
+                }
+                seg->locksig = need_lock ? (double)tail.locksig : (double)info.st.locksig;
+                seg->avg = (double)info.st.avg_phase;
+                seg->sweep = (double)info.st.sweep;
+            } else if (N > 0) {
+                seg->phase = (double)info.st.phase; seg->freq = (double)info.st.freq; seg->avg = (double)info.st.avg_phase;
+                seg->locksig = (double)info.st.locksig; seg->sweep = (double)info.st.sweep;
+            }
+        }
+        // StaticGain / AGC
+        if (!seg->have_norm && N > 0) {
+            T nv;
+            memcpy(&nv, &sc.norm, sizeof(T));
+            seg->norm_factor = (double)nv;
+            seg->gain = (double)nv;
+            seg->have_norm = true;
+        }
+        if (n_out - first_out > 0) seg->gain = (double)tail.agc_gain;
+        // sampler, Manchester
+        seg->sa = (double)tail.sampler.a; seg->sb = (double)tail.sampler.b; seg->sc = (double)tail.sampler.c;
+        seg->have_sampler = true;
+        if (sc.nsym >= 1) { seg->sym_m2 = (double)tail.sym_m2; seg->sym_m1 = (double)tail.sym_m1; }
+        seg->clockmod = tail.clock;
+        seg->nsym_total += new_syms;
+        seg->nbits_total += new_bits;
+        seg->seg_new_symbols = new_syms;
+        seg->seg_new_bits = new_bits;
+        // bits the device kept: local indices [b0, nbits_loc)
+        const long long b0 = nbits_loc - (long long)tail.nkeep;
+        auto src_of = [&](long long pos) -> long long {                      // global interpolated-sample index behind local bit pos
+            if (pos < kept) return seg->kept_src[(size_t)pos];
+            return tail.src[pos - b0] + org_out;
+        };
+        // frames
+        seg->seg_frames.clear();
+        long long open_pos = -1;
+        bool pend = false;
+        for (unsigned f = 0; f < sc.nframes; f++) {
+            const FrameRec &r = recs[f];
+            if (!r.complete && !seg->final_seg) { open_pos = r.bit_index; }
+            pdt_frame o;
+            memset(&o, 0, sizeof o);
+            o.bit_index = r.bit_index + (long long)seg->bit_base;
+            o.inverted = r.inverted;
+            o.nbytes = r.nbytes;
+            o.complete = r.complete;
+            memcpy(o.bytes, r.bytes, 104);
+            const long long g = (r.bit_index < kept) ? seg->kept_src[(size_t)r.bit_index] : r.time_src + org_out;
+            o.time_src = g;
+            o.time = frame_time(g, n_all);
+            if (!r.complete && !seg->final_seg) {
+                seg->pending = o;                                             // reported when it completes (or at the stream's end)
+                pend = true;
+                break;
+            }
+            seg->seg_frames.push_back(o);
+            seg->next_free = std::max<long long>(seg->next_free, o.bit_index + (long long)SP.span);
+        }
+        seg->have_pending = pend;
+        // what the next segment sees of these bits: from the sync word of the open frame, else the last len - 1
+        long long keep_from = std::max<long long>(0, nbits_loc - (long long)(SP.len - 1));
+        if (open_pos >= 0) keep_from = std::max<long long>(0, open_pos - (long long)(SP.len - 1));
+        if (keep_from < b0) return PDT_ERR_STATE;                             // (an open frame is shorter than the kept tail)
+        std::vector<unsigned char> nb((size_t)(nbits_loc - keep_from));
+        std::vector<long long> ns((size_t)(nbits_loc - keep_from));
+        for (long long q = keep_from; q < nbits_loc; q++) {
+            nb[(size_t)(q - keep_from)] = tail.bits[q - b0];
+            ns[(size_t)(q - keep_from)] = src_of(q);
+        }
+        seg->kept_bits.swap(nb);
+        seg->kept_src.swap(ns);
+        seg->bit_base += (uint64_t)keep_from;
+        ctx->stats.gpu_ms = ms;
+        // timers of the segment are dropped (profile mode describes whole captures)
+        for (auto &t : ctx->timers) {
+            if (!t.shared_a) ctx->event_pool.push_back(t.a);
+            ctx->event_pool.push_back(t.b);
+        }
+        ctx->timers.clear();
+        return PDT_OK;
+    }
+
     T norm_val;
     memcpy(&norm_val, &sc.norm, sizeof(T));
     pdt_stats &S = ctx->stats;
@@ -1204,20 +1469,7 @@ template <typename T> int run_capture(pdt_ctx *ctx, uint64_t n, int phase = RUN_
         o.nbytes = r.nbytes;
         o.complete = r.complete;
         memcpy(o.bytes, r.bytes, 104);
-        const long long g = r.time_src;
-        if (argos) {
-            o.time = ctx->axis_d.at((uint64_t)g + 1);                         // waveDataTime[i] = (i+1)-th partial sum
-        } else {
-            const long long c = g / chunk_out, rr = g % chunk_out;
-            const long long j = rr / interp + 1;                              // Q2: time of the *next* input sample
-            const long long ns_c = std::min<long long>(chunk, N - c * chunk);
-            if (j < ns_c)
-                o.time = (double)ctx->axis_f.at((uint64_t)(c * chunk + j + 1));
-            else if (ns_c == chunk || c == 0)
-                o.time = 0.0;                                                 // one past the array: never-written zero
-            else
-                o.time = (double)ctx->axis_f.at((uint64_t)((c - 1) * chunk + j + 1));   // stale value of the previous chunk
-        }
+        o.time = frame_time(r.time_src, N);
     }
 
     // ---- per-kernel timings
@@ -1460,9 +1712,10 @@ int pdt_open(const pdt_config *cfg, pdt_ctx **out)
     ctx->own_stream = true;
     {
         void *small = nullptr;
-        if (hipHostMalloc(&small, sizeof(DevScalars) + 128, hipHostMallocDefault) != hipSuccess) { pdt_close(ctx); return PDT_ERR_NOMEM; }
+        if (hipHostMalloc(&small, sizeof(DevScalars) + 128 + 32768, hipHostMallocDefault) != hipSuccess) { pdt_close(ctx); return PDT_ERR_NOMEM; }
         ctx->pend_sc = (DevScalars *)small;
         ctx->pend_info = (unsigned char *)small + ((sizeof(DevScalars) + 15) & ~(size_t)15);
+        ctx->seg_pin = ctx->pend_info + 128;          // 4 KiB up (kept bits, history symbols, lock record, gain), the rest down (SegTail)
     }
     (void)hipEventCreate(&ctx->ev0);
     (void)hipEventCreate(&ctx->ev1);
@@ -1494,7 +1747,7 @@ void pdt_close(pdt_ctx *ctx)
     DevBuf *bufs[] = { &ctx->pcm, &ctx->pll, &ctx->lock, &ctx->fir, &ctx->agc, &ctx->sym, &ctx->symidx, &ctx->bits, &ctx->bitsym,
                        &ctx->hits, &ctx->frames, &ctx->taps, &ctx->mag, &ctx->seams_pll, &ctx->seams_agc, &ctx->scal, &ctx->lockinfo,
                        &ctx->term, &ctx->seams_ema, &ctx->gtable, &ctx->gentries, &ctx->gcand,
-                       &ctx->gmfirst, &ctx->stiles, &ctx->gsegmap, &ctx->gsegstart, &ctx->gbands, &ctx->gclist, &ctx->agc_maps, &ctx->pll_head, &ctx->taps_rot, &ctx->pll_scratch, &ctx->tip, &ctx->stream_in, &ctx->sync_scr, &ctx->agc_raw, &ctx->packs_dev };
+                       &ctx->gmfirst, &ctx->stiles, &ctx->gsegmap, &ctx->gsegstart, &ctx->gbands, &ctx->gclist, &ctx->agc_maps, &ctx->pll_head, &ctx->taps_rot, &ctx->pll_scratch, &ctx->tip, &ctx->stream_in, &ctx->sync_scr, &ctx->agc_raw, &ctx->packs_dev, &ctx->seg_dev, &ctx->lt_theta, &ctx->lt_phi };
     for (DevBuf *b : bufs) b->release();
     for (hipEvent_t e : ctx->event_pool) (void)hipEventDestroy(e);
     if (ctx->pinned) (void)hipHostFree(ctx->pinned);
@@ -1725,37 +1978,119 @@ int pdt_demod_batch_device(pdt_ctx *const *ctxs, const void *const *iq_device, c
 int pdt_stream_begin(pdt_ctx *ctx)
 {
     if (!ctx) return PDT_ERR_ARG;
-    ctx->stream_n = 0;
-    ctx->stream_done_chunks = 0;
-    ctx->stream_reported = 0;
+    ctx->sc = StreamCarry();
+    ctx->stream_have = 0;
+    ctx->stream_done = 0;
+    ctx->stream_total = 0;
     ctx->stream_fmt = -1;
     ctx->stream_new.clear();
+    ctx->frames_host.clear();
+    ctx->tip_host.clear();
+    ctx->frames_on_device = 0;
+    memset(&ctx->stats, 0, sizeof ctx->stats);
+    memset(ctx->stage_len, 0, sizeof ctx->stage_len);
+    ctx->stats.lock_sample = -1;
     return PDT_OK;
 }
 
-// demodulate the first n samples of the accumulated input and report the frames that are new and whose
-// source position lies before `final_before` (input samples); everything when final_before < 0
-static int stream_run(pdt_ctx *ctx, uint64_t n, long long final_before, uint64_t *new_frames)
+// history a segment keeps in front of its new samples: the longest PLL warm-up (0.6 s of signal at most; the ARGOS build
+// warms up for 8 s), the starting guess, and slack for the look-ahead of the block walkers
+static uint64_t stream_history(const pdt_ctx *ctx)
 {
+    const double fs = (double)ctx->cfg.sample_rate;
+    const double w = ctx->cfg.pll_warm ? (double)ctx->cfg.pll_warm : (ctx->cfg.mode == PDT_MODE_ARGOS ? 8.0 : 0.6) * fs;
+    return (uint64_t)(w + 0.03 * fs) + 8192;
+}
+
+// local origin alignment: reference chunks (sampler seams), and for the interpolating FIR its ring of 26 inputs, whose
+// phase decides the order of every output's accumulation
+static uint64_t stream_align(const pdt_ctx *ctx)
+{
+    const uint64_t chunk = ctx->cfg.chunk;
+    if (ctx->cfg.mode == PDT_MODE_ARGOS) return chunk;
+    uint64_t a = chunk, b = 26;
+    while (b) { const uint64_t t = a % b; a = b; b = t; }
+    return chunk / a * 26;
+}
+
+// Demodulate the samples [stream_done, upto) of the window (whole chunks, or everything at the end of the stream) from the
+// carried state, append the frames that became final to frames_host / stream_new, then let the window slide.
+static int stream_segment(pdt_ctx *ctx, uint64_t upto, bool final_seg)
+{
+    StreamCarry &C = ctx->sc;
+    C.active = true;
+    C.final_seg = final_seg;
+    C.first = (long long)ctx->stream_done;
     ctx->pcm_dev = ctx->stream_in.p;
     ctx->pcm_fmt = ctx->stream_fmt;
-    int rc = demod_common(ctx, n);
+    const int rc = demod_common(ctx, upto);
+    C.active = false;
     if (rc) return rc;
-    const std::vector<pdt_frame> &all = ctx->frames_host;
-    uint64_t upto = all.size();
-    if (final_before >= 0) {
-        // frames are ordered; a frame is final when it is complete and even its last bit was sampled before the
-        // limit (time_src = interpolated-sample index of the bit that completed the sync word)
-        const double per_bit = 2.0 * (double)ctx->interp * (double)ctx->cfg.sample_rate / (ctx->cfg.mode == PDT_MODE_ARGOS ? 800.0 : 16640.0);
-        const double span = (ctx->cfg.mode == PDT_MODE_ARGOS ? 56.0 : 813.0) * per_bit + 64.0 * (double)ctx->interp;
-        upto = ctx->stream_reported;
-        while (upto < all.size() && all[upto].complete &&
-               (double)all[upto].time_src + span < (double)final_before * (double)ctx->interp)
-            upto++;
+    for (const pdt_frame &f : C.seg_frames) {
+        ctx->frames_host.push_back(f);
+        ctx->stream_new.push_back(f);
     }
-    ctx->stream_new.assign(all.begin() + (std::ptrdiff_t)std::min<uint64_t>(ctx->stream_reported, upto), all.begin() + (std::ptrdiff_t)upto);
-    ctx->stream_reported = std::max<uint64_t>(ctx->stream_reported, upto);
-    if (new_frames) *new_frames = ctx->stream_new.size();
+    ctx->stream_done = upto;
+    ctx->have_frames = true;
+    ctx->frames_on_device = 0;                      // (the device holds the last segment's records only)
+    pdt_stats &S = ctx->stats;
+    S.samples = C.origin + upto;
+    S.out_samples = S.samples * ctx->interp;
+    S.symbols = C.nsym_total;
+    S.bits = C.nbits_total;
+    S.frames = ctx->frames_host.size();
+    S.lock_sample = C.lock_sample;
+    S.lock_freq_hz = C.lock_freq_hz;
+    S.avg_phase = C.avg_at_lock;
+    S.norm_factor = C.norm_factor;
+    S.interp = ctx->interp;
+    S.ntaps = ctx->ntaps;
+    if (final_seg) return PDT_OK;
+    // ---- slide the window: the new origin is the largest aligned position that leaves the history in front of the next
+    // new sample; the input window and the tails later segments look back on move with it
+    const uint64_t hist = stream_history(ctx), align = stream_align(ctx);
+    const uint64_t done_g = C.origin + ctx->stream_done;
+    const uint64_t new_origin = done_g > hist ? (done_g - hist) / align * align : 0;
+    if (new_origin > C.origin) {
+        const uint64_t d = new_origin - C.origin;
+        const size_t fb = ctx->stream_fmt ? 8 : 4, es = (size_t)ctx->elem;
+        const uint32_t ip = ctx->interp;
+        const bool need_lock = ctx->cfg.mode == PDT_MODE_ARGOS || ctx->cfg.chain == PDT_CHAIN_LIVE;
+        const uint64_t chunk = ctx->cfg.chunk;
+        // (source and destination overlap: through a scratch buffer)
+        auto slide = [&](DevBuf &buf, size_t elem, uint64_t src_first, uint64_t count) -> int {
+            if (!count || !buf.p) return PDT_OK;
+            int r = ctx->mag.ensure((size_t)count * elem + 64);
+            if (r) return r;
+            HIP_TRY(hipMemcpyAsync(ctx->mag.p, (unsigned char *)buf.p + (size_t)src_first * elem, (size_t)count * elem, hipMemcpyDeviceToDevice, ctx->stream));
+            HIP_TRY(hipMemcpyAsync((unsigned char *)buf.p + (size_t)(src_first - d) * elem, ctx->mag.p, (size_t)count * elem, hipMemcpyDeviceToDevice, ctx->stream));
+            return PDT_OK;
+        };
+        int r;
+        // input: everything from the new origin on
+        if ((r = slide(ctx->stream_in, fb, d, ctx->stream_have - d))) return r;
+        // PLL output: the FIR looks 25 inputs back; lock signal / AGC output: the sampler's stale reads reach one chunk back
+        const uint64_t keep_pll = std::min<uint64_t>(ctx->stream_done - d, 256);
+        {
+            // these windows are indexed like the input (x interp for the AGC output): move [done - keep, done) down by d
+            auto slide_tail = [&](DevBuf &buf, uint64_t scale, uint64_t keep) -> int {
+                if (!buf.p) return PDT_OK;
+                const uint64_t end = ctx->stream_done * scale, dd = d * scale;
+                const uint64_t k = std::min<uint64_t>(keep, end - dd);
+                int r2 = ctx->mag.ensure((size_t)k * es + 64);
+                if (r2) return r2;
+                HIP_TRY(hipMemcpyAsync(ctx->mag.p, (unsigned char *)buf.p + (size_t)(end - k) * es, (size_t)k * es, hipMemcpyDeviceToDevice, ctx->stream));
+                HIP_TRY(hipMemcpyAsync((unsigned char *)buf.p + (size_t)(end - k - dd) * es, ctx->mag.p, (size_t)k * es, hipMemcpyDeviceToDevice, ctx->stream));
+                return PDT_OK;
+            };
+            if ((r = slide_tail(ctx->pll, 1, keep_pll))) return r;
+            if (need_lock && (r = slide_tail(ctx->lock, 1, chunk + 256))) return r;
+            if ((r = slide_tail(ctx->agc, ip, (chunk + 256) * ip))) return r;
+        }
+        C.origin = new_origin;
+        ctx->stream_have -= d;
+        ctx->stream_done -= d;
+    }
     return PDT_OK;
 }
 
@@ -1767,29 +2102,26 @@ static int stream_push(pdt_ctx *ctx, const void *host, uint64_t nframes, int fmt
     HIP_TRY(hipSetDevice(ctx->cfg.device));
     ctx->stream_fmt = fmt;
     const size_t fb = fmt ? 8 : 4;
-    const uint64_t total = ctx->stream_n + nframes;
-    if ((size_t)total * fb + 16 > ctx->stream_in.cap) {              // grow, keeping what is there
-        DevBuf bigger;
-        int rc = bigger.ensure(((size_t)total * fb + 16) * 2);
-        if (rc) return rc;
-        if (ctx->stream_n) HIP_TRY(hipMemcpyAsync(bigger.p, ctx->stream_in.p, (size_t)ctx->stream_n * fb, hipMemcpyDeviceToDevice, ctx->stream));
-        HIP_TRY(hipStreamSynchronize(ctx->stream));
-        ctx->stream_in.release();
-        ctx->stream_in = bigger;
-    }
-    if (nframes)
-        HIP_TRY(hipMemcpyAsync((unsigned char *)ctx->stream_in.p + (size_t)ctx->stream_n * fb, host, (size_t)nframes * fb,
-                               hipMemcpyHostToDevice, ctx->stream));
-    ctx->stream_n = total;
     ctx->stream_new.clear();
     if (new_frames) *new_frames = 0;
+    // append to the window (it grows only with the size of the pushes, not with the length of the stream)
+    int rc = ctx->stream_in.ensure_keep(((size_t)(ctx->stream_have + nframes) + 64) * fb, (size_t)ctx->stream_have * fb);
+    if (rc) return rc;
+    if (nframes)
+        HIP_TRY(hipMemcpyAsync((unsigned char *)ctx->stream_in.p + (size_t)ctx->stream_have * fb, host, (size_t)nframes * fb,
+                               hipMemcpyHostToDevice, ctx->stream));
+    ctx->stream_have += nframes;
+    ctx->stream_total += nframes;
     const uint64_t chunk = ctx->cfg.chunk;
-    const uint64_t chunks = total / chunk;
-    if (chunks == ctx->stream_done_chunks || chunks < 3) return PDT_OK;   // nothing new that could be final
-    ctx->stream_done_chunks = chunks;
-    // whole chunks only (a partial chunk would be treated as the capture's short last chunk), and only frames
-    // that end a chunk before the end of that prefix are final
-    return stream_run(ctx, chunks * chunk, (long long)((chunks - 1) * chunk), new_frames);
+    const uint64_t whole = (ctx->sc.origin + ctx->stream_have) / chunk * chunk - ctx->sc.origin;   // local end of the complete chunks
+    if (whole > ctx->stream_done) {
+        rc = stream_segment(ctx, whole, false);
+        if (rc) return rc;
+    } else if (nframes) {
+        HIP_TRY(hipStreamSynchronize(ctx->stream));      // the caller's buffer is free to be reused when this returns
+    }
+    if (new_frames) *new_frames = ctx->stream_new.size();
+    return PDT_OK;
 }
 
 int pdt_stream_push_pcm16(pdt_ctx *ctx, const int16_t *iq_host, uint64_t nframes, uint64_t *new_frames)
@@ -1811,9 +2143,22 @@ int pdt_stream_end(pdt_ctx *ctx, uint64_t *new_frames)
         int rc = ctx->stream_in.ensure(64);
         if (rc) return rc;
     }
-    HIP_TRY(hipSetDevice(ctx->cfg.device));
-    return stream_run(ctx, ctx->stream_n, -1, new_frames);
+    ctx->stream_new.clear();
+    int rc = PDT_OK;
+    if (ctx->stream_have > ctx->stream_done || ctx->stream_total == 0) {
+        rc = stream_segment(ctx, ctx->stream_have, true);            // the short last chunk
+    } else if (ctx->sc.have_pending) {
+        // the stream ended on a chunk boundary inside a frame: the reference leaves that frame partial (Q11)
+        ctx->frames_host.push_back(ctx->sc.pending);
+        ctx->stream_new.push_back(ctx->sc.pending);
+        ctx->sc.have_pending = false;
+        ctx->stats.frames = ctx->frames_host.size();
+    }
+    if (new_frames) *new_frames = ctx->stream_new.size();
+    return rc;
 }
+
+uint64_t pdt_stream_retained(const pdt_ctx *ctx) { return ctx ? ctx->stream_have : 0; }
 
 uint64_t pdt_stream_frames(const pdt_ctx *ctx, pdt_frame *out, uint64_t max_frames)
 {

@@ -255,7 +255,16 @@ template <typename T> struct GardnerEntry {
     long long offset;        // symbols emitted before this chunk
 };
 
-// sequential mode (entries == nullptr): one wavefront walks every chunk in order.
+// State a sequential sampler is entered with / leaves behind when a stream is demodulated segment by segment: the sampler
+// state after the last full chunk before c_first, and the number of symbols that already sit in the symbol buffer (the two
+// history symbols the Manchester stage needs).  A whole capture is {0, 0, 0, 0, 0}.
+template <typename T> struct SamplerCarry {
+    T a, b, c;               // Gardner: nextSample, prev, halfSample; M&M: nextSample, stepSize, sampleLast
+    long long c_first;       // first chunk to walk
+    long long count0;        // symbols already in the buffer: output starts there, the count includes them
+};
+
+// sequential mode (entries == nullptr): one wavefront walks the chunks from `carry.c_first` on, in order.
 // parallel mode: block b owns chunk b and starts from the tabulated entry state.
 template <typename T, int LEN, int OUT>
 __device__ __forceinline__ void k_gardner(const T *__restrict__ in, const T *__restrict__ lock,
@@ -263,7 +272,8 @@ __device__ __forceinline__ void k_gardner(const T *__restrict__ in, const T *__r
                                                                   long long *__restrict__ symidx,
                                                                   unsigned long long *__restrict__ nsym_out,
                                                                   long long sym_cap,
-                                                                  const GardnerEntry<T> *__restrict__ entries)
+                                                                  const GardnerEntry<T> *__restrict__ entries,
+                                                                  SamplerCarry<T> carry, SamplerCarry<T> *__restrict__ carry_out)
 {
     __shared__ T win[LEN];
     __shared__ T o_val[OUT];
@@ -271,9 +281,9 @@ __device__ __forceinline__ void k_gardner(const T *__restrict__ in, const T *__r
     const long long C = P.chunk_out;
     const long long n_chunks = (P.n_total + C - 1) / C;
     GardnerState<T> S;
-    S.ns = 0; S.prev = 0; S.half = 0; S.q_last = 0; S.i_last = 0;
-    long long count = 0;
-    long long c_begin = 0, c_end = n_chunks;
+    S.ns = carry.a; S.prev = carry.b; S.half = carry.c; S.q_last = 0; S.i_last = 0;
+    long long count = carry.count0;
+    long long c_begin = carry.c_first, c_end = n_chunks;
     if (entries) {
         c_begin = blockIdx.x;
         c_end = c_begin + 1;
@@ -287,6 +297,11 @@ __device__ __forceinline__ void k_gardner(const T *__restrict__ in, const T *__r
     for (long long c = c_begin; c < c_end; c++)
         count += gardner_walk_chunk<T, true, LEN, OUT>(in, lock, P, c, S, win, o_val, o_idx, sym, symidx, count, sym_cap);
     if (threadIdx.x == 0 && (!entries || c_end == n_chunks)) *nsym_out = (unsigned long long)count;
+    if (threadIdx.x == 0 && !entries && carry_out) {
+        SamplerCarry<T> o;
+        o.a = S.ns; o.b = S.prev; o.c = S.half; o.c_first = c_end; o.count0 = count;
+        *carry_out = o;
+    }
 }
 
 // Sequential sampler for small reference chunks (ARGOS: 2 400 samples, 60 symbols per chunk): with one window per
@@ -415,7 +430,8 @@ template <> __device__ __forceinline__ double mm_rint<double>(double x) { return
 template <typename T, int LEN, int OUT>
 __device__ __forceinline__ void k_mm(const T *__restrict__ in, MmParams<T> P, T *__restrict__ sym,
                                                              long long *__restrict__ symidx,
-                                                             unsigned long long *__restrict__ nsym_out, long long sym_cap)
+                                                             unsigned long long *__restrict__ nsym_out, long long sym_cap,
+                                                             SamplerCarry<T> carry, int have_carry, SamplerCarry<T> *__restrict__ carry_out)
 {
     __shared__ T win[LEN];
     __shared__ T o_val[OUT];
@@ -424,8 +440,9 @@ __device__ __forceinline__ void k_mm(const T *__restrict__ in, MmParams<T> P, T 
     const long long C = P.chunk_out;
     const long long n_chunks = (C > 0) ? (P.n_total + C - 1) / C : 0;
     T next = 0, step = P.step0, last = 0;
-    long long count = 0;
-    for (long long c = 0; c < n_chunks; c++) {
+    long long count = 0, c_first = 0;
+    if (have_carry) { next = carry.a; step = carry.b; last = carry.c; count = carry.count0; c_first = carry.c_first; }
+    for (long long c = c_first; c < n_chunks; c++) {
         const long long base = c * C;
         const unsigned n_cur = (unsigned)((P.n_total - base < C) ? (P.n_total - base) : C);
         const T nT = (T)n_cur;
@@ -477,6 +494,11 @@ __device__ __forceinline__ void k_mm(const T *__restrict__ in, MmParams<T> P, T 
         next = next - nT;                              // roll over to the next chunk (:80)
     }
     if (threadIdx.x == 0) *nsym_out = (unsigned long long)count;
+    if (threadIdx.x == 0 && carry_out) {
+        SamplerCarry<T> o;
+        o.a = next; o.b = step; o.c = last; o.c_first = n_chunks; o.count0 = count;
+        *carry_out = o;
+    }
 }
 
 // ------------------------------------------------------------------------------------------
@@ -1362,10 +1384,12 @@ struct ManchTile {
 template <typename T>
 __device__ __forceinline__ void k_manch_tile(const T *__restrict__ sym,
                                                                   const unsigned long long *__restrict__ nsym_p, T thr,
-                                                                  ManchTile *__restrict__ tiles)
+                                                                  ManchTile *__restrict__ tiles, long long i0)
 {
+    // (i0: first symbol to decide -- 0 for a capture; in a stream segment the symbols before it are the history the
+    // decisions look back on, and their index parity equals that of their position in the whole stream)
     const long long nsym = (long long)*nsym_p;
-    const long long t0 = (long long)blockIdx.x * PDT_TILE;
+    const long long t0 = i0 + (long long)blockIdx.x * PDT_TILE;
     if (t0 >= nsym) return;
     __shared__ int s_last[PDT_TILE];     // tile-relative index of last R at or before i, -1 none
     __shared__ T s_sym[PDT_MANCH_LDS];
@@ -1453,14 +1477,15 @@ __device__ __forceinline__ ManchMap manch_compose(const ManchMap &f, const Manch
 }
 
 __device__ __forceinline__ void k_manch_scan(ManchTile *__restrict__ tiles, const unsigned long long *__restrict__ nsym_p,
-                                                      unsigned long long *__restrict__ nbits_out)
+                                                      unsigned long long *__restrict__ nbits_out, long long i0, unsigned clock0,
+                                                      unsigned long long bit0, unsigned *__restrict__ clock_out)
 {
     __shared__ ManchMap s_map[1024];
     __shared__ unsigned s_clock;
     __shared__ unsigned long long s_base;
     const long long nsym = (long long)*nsym_p;
-    const long long nt = (nsym + PDT_TILE - 1) / PDT_TILE;
-    if (threadIdx.x == 0) { s_clock = 0; s_base = 0; }
+    const long long nt = (nsym > i0) ? (nsym - i0 + PDT_TILE - 1) / PDT_TILE : 0;
+    if (threadIdx.x == 0) { s_clock = clock0; s_base = bit0; }      // bit0: bits carried in front of this segment's
     __syncthreads();
     for (long long t0 = 0; t0 < nt; t0 += 1024) {
         const long long mine = t0 + threadIdx.x;
@@ -1504,7 +1529,10 @@ __device__ __forceinline__ void k_manch_scan(ManchTile *__restrict__ tiles, cons
         }
         __syncthreads();
     }
-    if (threadIdx.x == 0) *nbits_out = s_base;
+    if (threadIdx.x == 0) {
+        *nbits_out = s_base;
+        if (clock_out) *clock_out = s_clock;
+    }
 }
 
 template <typename T>
@@ -1512,10 +1540,10 @@ __device__ __forceinline__ void k_manch_emit(const T *__restrict__ sym,
                                                                   const unsigned long long *__restrict__ nsym_p, T thr,
                                                                   const ManchTile *__restrict__ tiles,
                                                                   unsigned char *__restrict__ bits,
-                                                                  unsigned *__restrict__ bitsym, long long bit_cap)
+                                                                  unsigned *__restrict__ bitsym, long long bit_cap, long long i0)
 {
     const long long nsym = (long long)*nsym_p;
-    const long long t0 = (long long)blockIdx.x * PDT_TILE;
+    const long long t0 = i0 + (long long)blockIdx.x * PDT_TILE;
     if (t0 >= nsym) return;
     const ManchTile mt = tiles[blockIdx.x];
     __shared__ T s_sym[PDT_MANCH_LDS];
@@ -1586,12 +1614,12 @@ struct SyncParams {
 __device__ __forceinline__ void k_sync_hits(const unsigned char *__restrict__ bits,
                                                     const unsigned long long *__restrict__ nbits_p, SyncParams P,
                                                     unsigned *__restrict__ hits, unsigned *__restrict__ nhits,
-                                                    unsigned hit_cap, const unsigned *__restrict__ only_if)
+                                                    unsigned hit_cap, const unsigned *__restrict__ only_if, long long min_pos)
 {
     if (only_if && *only_if == 0) return;            // generic path: only when the tile path overflowed
     const long long nbits = (long long)*nbits_p;
     const long long b = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (b >= nbits) return;
+    if (b >= nbits || b < min_pos) return;           // (min_pos: a stream segment's window begins inside a frame already reported)
     unsigned long long w = 0;
     for (unsigned k = 0; k < P.len; k++) {
         const long long idx = b - (long long)(P.len - 1) + k;
@@ -1621,7 +1649,7 @@ struct SyncTile {
 
 __device__ __forceinline__ void k_sync_hits_tile(const unsigned char *__restrict__ bits,
                                                          const unsigned long long *__restrict__ nbits_p, SyncParams P,
-                                                         SyncTile *__restrict__ tiles, unsigned *__restrict__ overflow)
+                                                         SyncTile *__restrict__ tiles, unsigned *__restrict__ overflow, long long min_pos)
 {
     const long long nbits = (long long)*nbits_p;
     const long long t0 = (long long)blockIdx.x * 4096;
@@ -1646,6 +1674,7 @@ __device__ __forceinline__ void k_sync_hits_tile(const unsigned char *__restrict
         unsigned kind = 0;
         if (w == P.pattern) kind = 1;
         else if (P.allow_inverse && w == (~P.pattern & mask)) kind = 2;
+        if (b < min_pos) kind = 0;
         if (kind) {
             const unsigned slot = atomicAdd(&s_n, 1u);
             if (slot < 64) s_hits[slot] = ((unsigned)b << 1) | (kind - 1);
@@ -1952,6 +1981,46 @@ __device__ __forceinline__ void k_frame_pack(const unsigned char *__restrict__ b
         frames[f].complete = (unsigned char)(done == P.nbytes);
         frames[f].pad = 0;
         frames[f].time_src = symidx[bitsym[pos]];
+    }
+}
+
+// What a stream segment hands to the next one, gathered at the end of the segment's kernels into one record (one copy back).
+#define PDT_SEG_KEEP 1024
+template <typename T> struct SegTail {
+    SamplerCarry<T> sampler;          // written by the sampler kernel
+    T pll_phase, pll_freq;            // PLL state after the window's last sample (seam record of its last block)
+    T locksig;                        // lock-detector value of the last sample (when that stream is kept)
+    T agc_gain;                       // AGC gain after the window's last output
+    T sym_m2, sym_m1;                 // the last two symbols
+    unsigned clock;                   // Manchester clockmod after the last symbol (written by k_manch_scan)
+    unsigned nkeep;                   // valid entries below = min(bits, PDT_SEG_KEEP), the LAST bits of the segment
+    long long src[PDT_SEG_KEEP];      // local interpolated-sample index each came from
+    unsigned char bits[PDT_SEG_KEEP];
+};
+
+template <typename T, typename SeamP, typename SeamA>
+__device__ __forceinline__ void k_seg_tail(const SeamP *__restrict__ seams_pll, long long last_pll, const T *__restrict__ lock,
+                                           long long n, const SeamA *__restrict__ seams_agc, long long last_agc,
+                                           const T *__restrict__ sym, const unsigned long long *__restrict__ nsym_p,
+                                           const unsigned char *__restrict__ bits, const unsigned *__restrict__ bitsym,
+                                           const long long *__restrict__ symidx, const unsigned long long *__restrict__ nbits_p,
+                                           long long first_bit_with_source, SegTail<T> *__restrict__ out)
+{
+    const long long nsym = (long long)*nsym_p, nbits = (long long)*nbits_p;
+    if (threadIdx.x == 0) {
+        if (last_pll >= 0) { out->pll_phase = seams_pll[last_pll].phase1; out->pll_freq = seams_pll[last_pll].freq1; }
+        out->locksig = (lock && n > 0) ? lock[n - 1] : (T)0;
+        out->agc_gain = (last_agc >= 0) ? seams_agc[last_agc].g1 : (T)0;
+        out->sym_m2 = (nsym >= 2) ? sym[nsym - 2] : (T)0;
+        out->sym_m1 = (nsym >= 1) ? sym[nsym - 1] : (T)0;
+        out->nkeep = (unsigned)((nbits < PDT_SEG_KEEP) ? nbits : PDT_SEG_KEEP);
+    }
+    const long long keep = (nbits < PDT_SEG_KEEP) ? nbits : PDT_SEG_KEEP;
+    const long long b0 = nbits - keep;
+    for (long long k = threadIdx.x; k < keep; k += blockDim.x) {
+        out->bits[k] = bits[b0 + k];
+        // (bits before first_bit_with_source were carried in from the previous segment: the host knows their sources)
+        out->src[k] = (b0 + k >= first_bit_with_source) ? symidx[bitsym[b0 + k]] : -1;
     }
 }
 

@@ -27,6 +27,8 @@ template <typename T> struct PllParams {
     T alpha_wide, beta_wide;   // warm-up only: 8x the acquisition bandwidth (pulls in a kHz-off frequency guess)
     T max_freq, min_freq;
     T sweep0, avg0, phase0;
+    T freq0, locksig0;   // the rest of the acquisition's starting state, and the sample it starts at: the reference's first-call
+    long long i0;        // values (0, 0, sample 0) for a capture, the carried state when a stream continues before the lock
     T cond_lo, cond_hi;   // |pi/2 - averagePhase| < 0.05 (evaluated the reference's way) <=> cond_lo <= averagePhase <= cond_hi
     int want_lock;   // 1 = lockSignalStreamOut != NULL (ARGOS)
 };
@@ -142,14 +144,14 @@ __device__ __forceinline__ void k_pll_acquire(IqSrc pcm, long long n, PllParams<
     if (threadIdx.x != 0 || blockIdx.x != 0) return;
     PllState<T> s;
     s.phase = P.phase0;
-    s.freq = 0;
+    s.freq = P.freq0;
     s.avg_phase = P.avg0;
-    s.locksig = 0;
+    s.locksig = P.locksig0;
     s.sweep = P.sweep0;
     const T avg_alpha = (T)0.00005;
     long long lock_at = -1;
     T freq_at_lock = 0, avg_at_lock = P.avg0;
-    long long i = 0;
+    long long i = P.i0;
     for (; i < n; i++) {
         T a, b, o_re, o_im, t_real, t_imag;
         IqSample<T>::get(pcm, i, a, b);
@@ -407,19 +409,19 @@ __device__ __forceinline__ void k_pll_acquire_fast(IqSrc pcm, long long n, PllPa
     const int lane = threadIdx.x;
     const T avg_alpha = (T)0.00005;
     const double k_avg = 1.0 - (double)avg_alpha, k_lock = 1.0 - (double)P.lock_alpha;
-    T phase = P.phase0, freq = 0, avg = P.avg0, locksig = 0, sweep = P.sweep0;
+    T phase = P.phase0, freq = P.freq0, avg = P.avg0, locksig = P.locksig0, sweep = P.sweep0;
     bool hyp = avg >= P.cond_lo && avg <= P.cond_hi;   // sweep condition assumed for the next sample
     long long lock_at = -1;
     T freq_at_lock = 0, avg_at_lock = P.avg0;
-    long long i0 = 0;
+    long long i0 = P.i0;
     // per-lane inputs of the current batch and of the one after it
     T th_l = 0, a_l = 0, b_l = 0, th_n = 0, a_n = 0, b_n = 0;
     long long i_next = -1;     // batch start th_n/a_n/b_n were loaded for
     T p_o = 0, p_ls = 0;       // outputs of the previous batch, not yet stored
     long long p_i0 = 0;
     int p_done = 0;
-    if (lane < PDT_ACQ_NB && lane < n) {
-        IqSample<T>::get(pcm, lane, a_l, b_l);
+    if (lane < PDT_ACQ_NB && i0 + lane < n) {
+        IqSample<T>::get(pcm, i0 + lane, a_l, b_l);
         th_l = arctan2_ref(b_l, a_l);
     }
 #ifdef PDT_ACQ_PROF
@@ -595,17 +597,17 @@ __device__ __forceinline__ void k_pll_acquire_pipe(IqSrc pcm, long long n, PllPa
     const T avg_alpha = (T)0.00005;
     const double k_avg = 1.0 - (double)avg_alpha, k_lock = 1.0 - (double)P.lock_alpha;
     // wavefront 0: loop-filter state; wavefront 1: detector state
-    T phase = P.phase0, freq = 0, sweep = P.sweep0;
-    T avg = P.avg0, locksig = 0;
+    T phase = P.phase0, freq = P.freq0, sweep = P.sweep0;
+    T avg = P.avg0, locksig = P.locksig0;
     bool hyp = avg >= P.cond_lo && avg <= P.cond_hi;
-    long long i_prod = 0;              // next sample the loop filter will take
+    long long i_prod = P.i0;           // next sample the loop filter will take
     long long i_pre = -1;              // start of the batch th_pre was loaded for
     T th_pre = 0;
     long long iq_pre = -1;             // (wavefront 1) start of the batch a_pre / b_pre were loaded for
     T a_pre = 0, b_pre = 0;
     long long lock_at = -1;
     T freq_at_lock = 0, avg_at_lock = P.avg0;
-    T fin_phase = P.phase0, fin_freq = 0, fin_sweep = P.sweep0;      // loop-filter state at the end (kept by wavefront 1)
+    T fin_phase = P.phase0, fin_freq = P.freq0, fin_sweep = P.sweep0;      // loop-filter state at the end (kept by wavefront 1)
     if (threadIdx.x < 2) slot[threadIdx.x].valid = 0;
     if (threadIdx.x == 0) verdict.event = 0;
     __syncthreads();

@@ -1,5 +1,7 @@
 """Streaming front end (pdt_stream_*): pushing a capture block by block yields, in order and exactly
-once, the frames of one whole-capture demodulation -- the guarantee stated in include/pdt.h."""
+once, the frames of one whole-capture demodulation -- the guarantee stated in include/pdt.h -- with every stage's state
+carried from segment to segment (cost per push independent of the stream's length, bounded device window).  The expected
+frames come from the ORACLE (CPU restatement of the reference's chunk loop), not from another run of the HIP path."""
 import numpy as np
 import pytest
 
@@ -79,3 +81,101 @@ def test_empty_stream(pdt):
     with pdt.Demodulator(pdt.MODE_POES, 50000) as d:
         d.stream_begin()
         assert len(d.stream_end()) == 0 and d.stats().frames == 0
+
+
+def oracle_frames(pdt, orc, mode, omode, fs, iq, **kw):
+    o = orc.Oracle(omode, fs, iq, **kw)
+    return o, o.text()
+
+
+@pytest.mark.parametrize("blocks", [[2400], [10000], [1, 77, 9999, 30011], [250000], [12345, 3]])
+def test_stream_against_the_oracle(pdt, orc, clip, blocks):
+    """The reference's own capture pushed in various block patterns (cycled): text and totals equal the oracle's."""
+    rate, iq = clip
+    o = orc.Oracle(orc.POES, rate, iq)
+    with pdt.Demodulator(pdt.MODE_POES, rate) as d:
+        d.stream_begin()
+        i = k = 0
+        got = []
+        while i < len(iq):
+            b = blocks[k % len(blocks)]
+            got.append(d.stream_push(iq[i:i + b]))
+            i += b
+            k += 1
+        got.append(d.stream_end())
+        fr = np.concatenate(got)
+        assert pdt.format_frames(fr) == o.text() == d.text()
+        s = d.stats()
+        ns, nsym, nbits, nfr = o.totals()
+        assert (s.samples, s.symbols, s.bits, s.frames) == (ns, nsym, nbits, nfr)
+        assert s.lock_sample == o.lock_sample and f"{s.lock_freq_hz:0.2f}" == f"{o.lock_freq_hz:0.2f}"
+        assert np.float32(s.norm_factor) == np.float32(o.norm_factor)
+
+
+def test_long_stream_has_flat_cost_and_a_bounded_window(pdt, orc):
+    """Four minutes at 50 ksps in sound-card blocks of 2 400 frames (5 000 pushes): identical to the oracle; the device
+    window stops growing after the first second; the time per push does not grow with the position in the stream."""
+    import time
+    fs, secs = 50000, 240.0
+    iq = pdt.synth_capture(0, fs, secs, seed=77)
+    o = orc.Oracle(orc.POES, fs, iq, keep_stages=False)
+    with pdt.Demodulator(pdt.MODE_POES, fs) as d:
+        d.stream_begin()
+        got, retained, dt = [], [], []
+        for i in range(0, len(iq), 2400):
+            t0 = time.perf_counter()
+            got.append(d.stream_push(iq[i:i + 2400]))
+            dt.append(time.perf_counter() - t0)
+            retained.append(d.stream_retained())
+        got.append(d.stream_end())
+        assert pdt.format_frames(np.concatenate(got)) == o.text()
+    assert max(retained) < 0.7 * fs + 200000 and max(retained[len(retained) // 2:]) <= max(retained[:len(retained) // 2])
+    q = len(dt) // 4
+    first, last = np.median(dt[q:2 * q]), np.median(dt[3 * q:])
+    assert last < 1.5 * first, (first, last)
+
+
+def test_lock_in_a_later_segment_weak_signal_and_mm(pdt, orc):
+    import ctypes as C
+    fs = 50000
+    # (a) two seconds of noise before the signal starts: the acquisition state crosses many segment boundaries
+    sig = pdt.synth_capture(0, fs, 12.0, seed=5)
+    rng = np.random.default_rng(3)
+    noise = rng.integers(-300, 300, size=(2 * fs + 1234, 2)).astype(np.int16)
+    iq = np.concatenate([noise, sig])
+    o = orc.Oracle(orc.POES, fs, iq)
+    assert o.lock_sample > len(noise)
+    with pdt.Demodulator(pdt.MODE_POES, fs) as d:
+        got, _, _ = stream_all(d, iq, 2400)
+        assert pdt.format_frames(got) == o.text() and d.stats().lock_sample == o.lock_sample
+    # (b) weak signal (seam repairs in every segment that is long enough to have seams), big and small pushes mixed
+    p = pdt.synth_params(0, fs, 1000.0, 78)
+    p.noise_gain = int(p.noise_gain * 6)
+    n = 20 * fs
+    weak = np.zeros((n, 2), dtype="<i2")
+    pdt.synth_lib().pdt_synth_fill(C.byref(p), 0, n, weak.ctypes.data)
+    o = orc.Oracle(orc.POES, fs, weak)
+    with pdt.Demodulator(pdt.MODE_POES, fs) as d:
+        d.stream_begin()
+        parts, i = [], 0
+        for b in [300000, 2400, 2400, 150001, 7, 400000, 99999]:
+            parts.append(d.stream_push(weak[i:i + b])); i += b
+        parts.append(d.stream_push(weak[i:]))
+        parts.append(d.stream_end())
+        assert pdt.format_frames(np.concatenate(parts)) == o.text()
+    # (c) the M&M sampler's state (nextSample, stepSize, sampleLast) is carried as well
+    iq = pdt.synth_capture(0, fs, 8.0, seed=9)
+    o = orc.Oracle(orc.POES, fs, iq, chunk=3333, sampler=1, mm_range=3.0, mm_kp=0.15)
+    with pdt.Demodulator(pdt.MODE_POES, fs, chunk=3333, sampler=pdt.SAMPLER_MM) as d:
+        got, _, _ = stream_all(d, iq, 5000)
+        assert pdt.format_frames(got) == o.text()
+
+
+def test_argos_stream_against_the_oracle(pdt, orc):
+    a = pdt.synth_capture(1, 32000, 20.0, f0_hz=130.0, seed=19)
+    o = orc.Oracle(orc.ARGOS, 32000, a, math_mode=orc.MATH_PORTABLE)
+    with pdt.Demodulator(pdt.MODE_ARGOS, 32000) as d:
+        got, _, _ = stream_all(d, a, 2400)
+        assert pdt.format_frames(got) == o.text() and len(got) >= 10
+        got, _, _ = stream_all(d, a, 50000)
+        assert pdt.format_frames(got) == o.text()
