@@ -117,7 +117,7 @@ ABI_SYMBOLS = [
     "pdt_format_frames", "pdt_read_stage", "pdt_stage_len", "pdt_kernel_times", "pdt_make_lpf",
     "pdt_wav_parse_header", "pdt_time_axis", "pdt_stage_bytesync", "pdt_tip_check", "pdt_tip_frames",
     "pdt_stream_begin", "pdt_stream_push_pcm16", "pdt_stream_push_f32", "pdt_stream_end", "pdt_stream_frames",
-    "pdt_keep_presquelch", "pdt_demod_fd", "pdt_format_records", "pdt_stream_retained",
+    "pdt_keep_presquelch", "pdt_demod_fd", "pdt_format_records", "pdt_stream_retained", "pdt_host_math",
 ]
 
 _lib = None
@@ -173,6 +173,7 @@ def lib():
     L.pdt_stream_end.argtypes = [C.c_void_p, C.POINTER(C.c_uint64)]
     L.pdt_stream_frames.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64]
     L.pdt_stream_frames.restype = C.c_uint64
+    L.pdt_host_math.argtypes = [C.c_int, C.c_void_p, C.c_uint64, C.c_void_p, C.c_void_p]
     L.pdt_stream_retained.argtypes = [C.c_void_p]
     L.pdt_stream_retained.restype = C.c_uint64
     L.pdt_tip_check.argtypes = [C.c_void_p, C.POINTER(TipSummary)]
@@ -197,6 +198,15 @@ def make_lpf(mode: int, sample_rate: int) -> tuple[np.ndarray, int]:
     taps = np.zeros(nt.value, dtype=np.float64 if mode == MODE_ARGOS else np.float32)
     _check(L.pdt_make_lpf(mode, sample_rate, taps.ctypes.data, None, None), "pdt_make_lpf")
     return taps, ip.value
+
+
+def host_math(fn: int, x: np.ndarray):
+    """pdt_host_math: the library's own sincos / sin / cos / sincosf / hypot / hypotf evaluated on the host (test hook)."""
+    a = np.ascontiguousarray(x, dtype=np.float64)
+    n = len(a) // 2 if fn in (4, 5) else len(a)
+    o0, o1 = np.zeros(n), np.zeros(n)
+    _check(lib().pdt_host_math(fn, a.ctypes.data, n, o0.ctypes.data, o1.ctypes.data), "pdt_host_math")
+    return o0, o1
 
 
 def time_axis(mode: int, sample_rate: int, m: int) -> float:

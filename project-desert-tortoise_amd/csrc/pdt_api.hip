@@ -360,7 +360,9 @@ struct pdt_ctx {
 namespace {
 
 // ---------------------------------------------------------------- FIR taps (LowPassFilter.c:127-175)
-// Evaluated on the host exactly like the reference does (libm sinf/sin + cos), once per context.
+// Evaluated on the host with the operations the reference performs (sinf / sin of the sinc argument, cos in the Blackman
+// window) -- through this library's own restatements of those C-library functions (pdt_device_math.h), so that the taps do
+// not depend on the libm of the machine the library runs on.
 template <typename T> void make_lpf(T *h, int N, T Fc, T Fs, int interp)
 {
     const T Tt = (T)(1.0 / (double)Fs);
@@ -368,10 +370,17 @@ template <typename T> void make_lpf(T *h, int N, T Fc, T Fs, int interp)
     const T tou = (T)((N - 1.0) / 2.0);
     for (int n = 0; n < N; n++) {
         const T arg = wc * ((T)n - tou);
-        const T sv = (sizeof(T) == 4) ? (T)sinf((float)arg) : (T)sin((double)arg);
+        T sv;
+        if (sizeof(T) == 4) {
+            float sf, cf;
+            sincosf_glibc((float)arg, sf, cf);          // sinf: the sine half of glibc's shared sinf / sincosf evaluation
+            sv = (T)sf;
+        } else {
+            sv = (T)sin_glibc((double)arg);
+        }
         T hd = (T)((double)sv / (M_PI * (double)((T)n - tou)));
         if (((T)n == tou) && ((N / 2) * 2 != N)) hd = (T)((double)wc / M_PI);
-        const T wn = (T)(0.42 - 0.5 * cos((2 * M_PI * n) / (N - 1)) + 0.08 * cos((4 * M_PI * n) / (N - 1)));
+        const T wn = (T)(0.42 - 0.5 * cos_glibc((2 * M_PI * n) / (N - 1)) + 0.08 * cos_glibc((4 * M_PI * n) / (N - 1)));
         h[n] = hd * wn * (T)interp;
     }
 }
@@ -1610,6 +1619,26 @@ int pdt_device_count(void)
         return 0;
     }
     return n;
+}
+
+// Host evaluation of the library's own restatements of the C-library functions the reference calls (test hook: the CPU
+// tests compare them with the C library of the machine, bit for bit).  fn: 0 sincos(x) -> out0 sin, out1 cos; 1 sin; 2 cos;
+// 3 sincosf((float)x) widened; 4 hypot(x[2i], x[2i+1]) -> out0[i]; 5 hypotf of the pair, widened.
+int pdt_host_math(int fn, const double *x, uint64_t n, double *out0, double *out1)
+{
+    if (!x || !out0) return PDT_ERR_ARG;
+    for (uint64_t i = 0; i < n; i++) {
+        switch (fn) {
+        case 0: { double sv, cv; sincos_glibc(x[i], sv, cv); out0[i] = sv; if (out1) out1[i] = cv; break; }
+        case 1: out0[i] = sin_glibc(x[i]); break;
+        case 2: out0[i] = cos_glibc(x[i]); break;
+        case 3: { float sf, cf; sincosf_glibc((float)x[i], sf, cf); out0[i] = sf; if (out1) out1[i] = cf; break; }
+        case 4: out0[i] = hypot_glibc(x[2 * i], x[2 * i + 1]); break;
+        case 5: out0[i] = hypotf_glibc((float)x[2 * i], (float)x[2 * i + 1]); break;
+        default: return PDT_ERR_ARG;
+        }
+    }
+    return PDT_OK;
 }
 
 int pdt_make_lpf(int mode, uint32_t sample_rate, void *taps_out, int *ntaps, int *interp)

@@ -1,4 +1,4 @@
-// pdt_device_math.h -- gfx950 device-side scalar math for the PLL / AGC stages.
+// pdt_device_math.h -- scalar math of the PLL / AGC stages on gfx950, and (the same functions, host side) of the tap generator.
 //
 // Every routine reproduces, operation for operation, what the reference's CPU
 // build evaluates (x86-64, gcc -O2, no contraction, glibc 2.35 libm), so that a
@@ -16,10 +16,14 @@ namespace pdt {
 
 #define PDT_PI 3.14159265358979323846
 
+__host__ __device__ __forceinline__ uint32_t bits_of(float v) { uint32_t u; __builtin_memcpy(&u, &v, 4); return u; }
+__host__ __device__ __forceinline__ uint64_t bits_of(double v) { uint64_t u; __builtin_memcpy(&u, &v, 8); return u; }
+__host__ __device__ __forceinline__ float float_of(uint32_t u) { float v; __builtin_memcpy(&v, &u, 4); return v; }
+
 // ---- sincosf: glibc 2.35 algorithm (reference call site CarrierTrackingPLL.c:106-107)
 struct SinCosPoly { double c0, c1, c2, c3, c4, s1, s2, s3; };
 
-__device__ __forceinline__ void sincosf_eval(double x, double x2, bool neg, int n, float &sinv, float &cosv)
+__host__ __device__ __forceinline__ void sincosf_eval(double x, double x2, bool neg, int n, float &sinv, float &cosv)
 {
     // coefficients of the +cos table; the -cos table negates the c's
     const double c0 = neg ? -0x1p0 : 0x1p0;
@@ -44,10 +48,10 @@ __device__ __forceinline__ void sincosf_eval(double x, double x2, bool neg, int 
 }
 
 // valid for |y| < 120 (the PLL phase lives in (-2pi, 2pi])
-__device__ __forceinline__ void sincosf_glibc(float y, float &sinv, float &cosv)
+__host__ __device__ __forceinline__ void sincosf_glibc(float y, float &sinv, float &cosv)
 {
     const double x = (double)y;
-    const uint32_t top = (__float_as_uint(y) >> 20) & 0x7ffu;
+    const uint32_t top = (bits_of(y) >> 20) & 0x7ffu;
     if (top < 0x3f4u) {
         if (top < 0x398u) {
             sinv = y;
@@ -65,7 +69,7 @@ __device__ __forceinline__ void sincosf_glibc(float y, float &sinv, float &cosv)
 }
 
 // ---- arctan2 approximation of CarrierTrackingPLL.c:15-40
-__device__ __forceinline__ float arctan2_ref(float y, float x)
+__host__ __device__ __forceinline__ float arctan2_ref(float y, float x)
 {
     const float abs_y = (float)((double)__builtin_fabsf(y) + 1e-10);
     float r;
@@ -81,7 +85,7 @@ __device__ __forceinline__ float arctan2_ref(float y, float x)
     return (y < 0) ? -angle : angle;
 }
 
-__device__ __forceinline__ double arctan2_ref(double y, double x)
+__host__ __device__ __forceinline__ double arctan2_ref(double y, double x)
 {
     const double abs_y = __builtin_fabs(y) + 1e-10;
     double r, base;
@@ -97,77 +101,191 @@ __device__ __forceinline__ double arctan2_ref(double y, double x)
 }
 
 // ---- Q_rsqrt of CarrierTrackingPLL.c:43-52 (always float, also in the double build)
-__device__ __forceinline__ float q_rsqrt(float x)
+__host__ __device__ __forceinline__ float q_rsqrt(float x)
 {
     const float xhalf = 0.5f * x;
-    int32_t i = __float_as_int(x);
+    int32_t i = (int32_t)bits_of(x);
     i = 0x5f3759df - (i >> 1);
-    x = __int_as_float(i);
+    x = float_of((uint32_t)i);
     x = x * (1.5f - xhalf * x * x);
     x = x * (1.5f - xhalf * x * x);
     return x;
 }
 
 // ---- cabsf as glibc 2.35 computes it for finite inputs (AGC.c:57,65)
-__device__ __forceinline__ float hypotf_glibc(float x, float y)
+__host__ __device__ __forceinline__ float hypotf_glibc(float x, float y)
 {
     return (float)__builtin_sqrt((double)x * (double)x + (double)y * (double)y);
 }
 
-// ---- double-precision sine/cosine for the ARGOS chain: plain IEEE double operations only
-// (Cody-Waite reduction by pi/2 in two steps, fdlibm/musl minimax kernels).  The reference calls
-// glibc's table-driven sincos() here (CarrierTrackingPLL.c:134-135); this evaluation differs from
-// it in the last bit of ~3% of arguments, which the contracting stages absorb -- the oracle has a
-// matching "portable" mode that is checked against the reference's bit/packet output.
-__device__ __forceinline__ double ksin_d(double x, double y)
+// ---- double-precision sin / cos / sincos as glibc 2.35 computes them (reference call sites CarrierTrackingPLL.c:134-135,
+// LowPassFilter.c:148,163).  glibc's dbl-64 routines are the IBM Accurate Mathematical Library's: |x| is split at a multiple
+// of 1/128 (adding and subtracting 1.5 * 2^45), sin / cos of that multiple come from a double-double table, the remainder
+// goes through short Taylor polynomials, and the pieces are combined with the angle-addition formulas; arguments beyond
+// 2.426 are first reduced by pi/2 against a 4-piece constant (136 bits).  Restated from the published algorithm (the
+// source is not in the reference tree); plain IEEE double operations in the order written there, no fused operation --
+// bit-identical to the C library on every argument tried (tests/test_own_math.py: sincos, sin, cos over all ranges).
+#if defined(__HIP_DEVICE_COMPILE__)
+__device__ const double kSinCosTab[440] = {
+#include "pdt_sincostab.h"
+};
+#else
+static const double kSinCosTab[440] = {
+#include "pdt_sincostab.h"
+};
+#endif
+
+namespace ibm {
+constexpr double sn3 = -1.66666666666664880952546298448555E-01, sn5 = 8.33333214285722277379541354343671E-03,
+                 cs2 = 4.99999999999999999999950396842453E-01, cs4 = -4.16666666666664434524222570944589E-02,
+                 cs6 = 1.38888874007937613028114285595617E-03;
+constexpr double s1 = -0x1.5555555555555p-3, s2 = 0x1.1111111110ECEp-7, s3 = -0x1.A01A019DB08B8p-13, s4 = 0x1.71DE27B9A7ED9p-19,
+                 s5 = -0x1.ADDFFC2FCDF59p-26;
+constexpr double big = 0x1.8p45, hp0 = 0x1.921FB54442D18p0, hp1 = 0x1.1A62633145C07p-54;
+constexpr double mp1 = 0x1.921FB58000000p0, mp2 = -0x1.DDE973C000000p-27, pp3 = -0x1.CB3B398000000p-55, pp4 = -0x1.d747f23e32ed7p-83;
+constexpr double hpinv = 0x1.45F306DC9C883p-1, toint = 0x1.8p52;
+
+// F: the build glibc's x86-64 dispatcher picks on an FMA-capable CPU.  Measured against the C library here (tests/
+// test_own_math.py): sincos() is the plain build -- no fused operation -- while the stand-alone sin() and cos() are the FMA
+// build, in which the compiler has contracted every a * b + c of the source into one fused operation (they differ from
+// sincos() in ~0.07 % of arguments).  F = true reproduces that contraction.
+template <bool F> __host__ __device__ __forceinline__ double ma(double a, double b, double c) { return F ? __builtin_fma(a, b, c) : a * b + c; }
+template <bool F> __host__ __device__ __forceinline__ double ms(double a, double b, double c) { return F ? __builtin_fma(-a, b, c) : c - a * b; }   // c - a*b
+
+template <bool F> __host__ __device__ __forceinline__ double do_sin(double x, double dx)
 {
-    const double S1 = -1.66666666666666324348e-01, S2 = 8.33333333332248946124e-03, S3 = -1.98412698298579493134e-04,
-                 S4 = 2.75573137070700676789e-06, S5 = -2.50507602534068634195e-08, S6 = 1.58969099521155010221e-10;
-    const double z = x * x, w = z * z;
-    const double r = S2 + z * (S3 + z * S4) + z * w * (S5 + z * S6);
-    const double v = z * x;
-    return x - ((z * (0.5 * y - v * r) - y) - v * S1);
+    const double xold = x;
+    if (__builtin_fabs(x) < 0.126) {
+        const double xx = x * x;
+        const double poly = ma<F>(ma<F>(ma<F>(ma<F>(s5, xx, s4), xx, s3), xx, s2), xx, s1);
+        const double d = F ? __builtin_fma(poly, x, -(0.5 * dx)) : poly * x - 0.5 * dx;
+        const double t = ma<F>(d, xx, dx);
+        return x + t;
+    }
+    if (x <= 0) dx = -dx;
+    const double ux = big + __builtin_fabs(x);
+    x = __builtin_fabs(x) - (ux - big);
+    const int k = (int)(uint32_t)bits_of(ux) * 4;
+    const double xx = x * x;
+    const double s = x + ma<F>(x * xx, ma<F>(xx, sn5, sn3), dx);
+    const double c2 = ma<F>(xx, ma<F>(xx, cs6, cs4), cs2);
+    const double c = F ? __builtin_fma(x, dx, xx * c2) : x * dx + xx * c2;
+    const double sn = kSinCosTab[k], ssn = kSinCosTab[k + 1], cs = kSinCosTab[k + 2], ccs = kSinCosTab[k + 3];
+    const double cor = ma<F>(cs, s, ms<F>(sn, c, ma<F>(s, ccs, ssn)));
+    return __builtin_copysign(sn + cor, xold);
 }
-__device__ __forceinline__ double kcos_d(double x, double y)
+template <bool F> __host__ __device__ __forceinline__ double do_cos(double x, double dx)
 {
-    const double C1 = 4.16666666666666019037e-02, C2 = -1.38888888888741095749e-03, C3 = 2.48015872894767294178e-05,
-                 C4 = -2.75573143513906633035e-07, C5 = 2.08757232129817482790e-09, C6 = -1.13596475577881948265e-11;
-    const double z = x * x, w0 = z * z;
-    const double r = z * (C1 + z * (C2 + z * C3)) + (w0 * w0) * (C4 + z * (C5 + z * C6));
-    const double hz = 0.5 * z;
-    const double w = 1.0 - hz;
-    return w + (((1.0 - w) - hz) + (z * r - x * y));
+    if (x < 0) dx = -dx;
+    const double ux = big + __builtin_fabs(x);
+    x = __builtin_fabs(x) - (ux - big) + dx;
+    const int k = (int)(uint32_t)bits_of(ux) * 4;
+    const double xx = x * x;
+    const double s = ma<F>(x * xx, ma<F>(xx, sn5, sn3), x);
+    const double c = xx * ma<F>(xx, ma<F>(xx, cs6, cs4), cs2);
+    const double sn = kSinCosTab[k], ssn = kSinCosTab[k + 1], cs = kSinCosTab[k + 2], ccs = kSinCosTab[k + 3];
+    const double cor = ms<F>(sn, s, ms<F>(cs, c, ms<F>(s, ssn, ccs)));
+    return cs + cor;
 }
-__device__ __forceinline__ void sincos_portable(double x, double &sv, double &cv)
+// |x| < 105414350: quadrant, and the reduced argument as a + da
+template <bool F> __host__ __device__ __forceinline__ int reduce(double x, double &a, double &da)
 {
-    const double fn = __builtin_rint(x * 6.36619772367581382433e-01);
-    const int n = (int)fn;
-    const double t2 = x - fn * 1.57079632673412561417e+00;
-    double w = fn * 6.07710050630396597660e-11;
-    const double t = t2 - w;
-    w = fn * 2.02226624879595063154e-21 - ((t2 - t) - w);
-    const double y0 = t - w;
-    const double y1 = (t - y0) - w;
-    const double s = ksin_d(y0, y1), c = kcos_d(y0, y1);
-    const int q = n & 3;
-    sv = (q == 0) ? s : ((q == 1) ? c : ((q == 2) ? -s : -c));
-    cv = (q == 0) ? c : ((q == 1) ? -s : ((q == 2) ? -c : s));
+    const double t = ma<F>(x, hpinv, toint);
+    const double xn = t - toint;
+    const double y = ms<F>(xn, mp2, ms<F>(xn, mp1, x));
+    const int n = (int)(bits_of(t) & 3u);
+    const double t2 = ms<F>(xn, pp3, y);
+    double db = ms<F>(xn, pp3, y - t2);
+    const double b = ms<F>(xn, pp4, t2);
+    db += ms<F>(xn, pp4, t2 - b);
+    a = b;
+    da = db;
+    return n;
+}
+template <bool F> __host__ __device__ __forceinline__ double do_sincos(double a, double da, int n)
+{
+    const double r = (n & 1) ? do_cos<F>(a, da) : do_sin<F>(a, da);
+    return (n & 2) ? -r : r;
+}
+}  // namespace ibm
+
+// sincos(x): valid for |x| < 105414350 (the PLL phase lives in (-2 pi, 2 pi])
+__host__ __device__ __forceinline__ void sincos_glibc(double x, double &sv, double &cv)
+{
+    const uint32_t k = (uint32_t)(bits_of(x) >> 32) & 0x7fffffffu;
+    if (k < 0x400368fdu) {
+        if (k < 0x3e400000u) { sv = x; cv = 1.0; return; }
+        if (k < 0x3feb6000u) { sv = ibm::do_sin<false>(x, 0); cv = ibm::do_cos<false>(x, 0); return; }
+        const double y = ibm::hp0 - __builtin_fabs(x), a = y + ibm::hp1, da = (y - a) + ibm::hp1;
+        sv = __builtin_copysign(ibm::do_cos<false>(a, da), x);
+        cv = ibm::do_sin<false>(a, da);
+        return;
+    }
+    double a, da;
+    const int n = ibm::reduce<false>(x, a, da);
+    sv = ibm::do_sincos<false>(a, da, n);
+    cv = ibm::do_sincos<false>(a, da, n + 1);
+}
+// sin(x) / cos(x) as separate calls (the tap generator): the same pieces, dispatched as s_sin.c does, FMA build
+__host__ __device__ __forceinline__ double sin_glibc(double x)
+{
+    const uint32_t k = (uint32_t)(bits_of(x) >> 32) & 0x7fffffffu;
+    if (k < 0x3e500000u) return x;
+    if (k < 0x3feb6000u) return ibm::do_sin<true>(x, 0);
+    if (k < 0x400368fdu) return __builtin_copysign(ibm::do_cos<true>(ibm::hp0 - __builtin_fabs(x), ibm::hp1), x);
+    double a, da;
+    const int n = ibm::reduce<true>(x, a, da);
+    return ibm::do_sincos<true>(a, da, n);
+}
+__host__ __device__ __forceinline__ double cos_glibc(double x)
+{
+    const uint32_t k = (uint32_t)(bits_of(x) >> 32) & 0x7fffffffu;
+    if (k < 0x3e400000u) return 1.0;
+    if (k < 0x3feb6000u) return ibm::do_cos<true>(x, 0);
+    if (k < 0x400368fdu) {
+        const double y = ibm::hp0 - __builtin_fabs(x), a = y + ibm::hp1, da = (y - a) + ibm::hp1;
+        return ibm::do_sin<true>(a, da);
+    }
+    double a, da;
+    const int n = ibm::reduce<true>(x, a, da);
+    return ibm::do_sincos<true>(a, da, n + 1);
+}
+
+// ---- cabs (double) as glibc 2.35 computes it for the magnitudes that occur (|x|, |y| <= 1): e_hypot.c, the variant
+// without a fused multiply-add (AGC.c:57,65 in the double build)
+__host__ __device__ __forceinline__ double hypot_glibc(double x, double y)
+{
+    double ax = __builtin_fabs(x), ay = __builtin_fabs(y);
+    if (ax < ay) { const double t = ax; ax = ay; ay = t; }
+    if (ay <= ax * 0x1p-54) return ax + ay;
+    double h = __builtin_sqrt(ax * ax + ay * ay), t1, t2;
+    if (h <= 2.0 * ay) {
+        const double delta = h - ay;
+        t1 = ax * (2.0 * delta - ax);
+        t2 = (delta - 2.0 * (ax - ay)) * delta;
+    } else {
+        const double delta = h - ax;
+        t1 = 2.0 * delta * (ax - 2.0 * ay);
+        t2 = (4.0 * delta - ay) * ay + delta * delta;
+    }
+    h -= (t1 + t2) / (2.0 * h);
+    return h;
 }
 
 template <typename T> struct Real;
 template <> struct Real<double> {
-    static __device__ __forceinline__ double abs(double v) { return __builtin_fabs(v); }
-    static __device__ __forceinline__ double max(double a, double b) { return __builtin_fmax(a, b); }
-    static __device__ __forceinline__ double rint(double v) { return __builtin_rint(v); }
-    static __device__ __forceinline__ void sincos(double p, double &s, double &c) { sincos_portable(p, s, c); }
-    static __device__ __forceinline__ double hypot(double x, double y) { return __builtin_sqrt(x * x + y * y); }
+    static __host__ __device__ __forceinline__ double abs(double v) { return __builtin_fabs(v); }
+    static __host__ __device__ __forceinline__ double max(double a, double b) { return __builtin_fmax(a, b); }
+    static __host__ __device__ __forceinline__ double rint(double v) { return __builtin_rint(v); }
+    static __host__ __device__ __forceinline__ void sincos(double p, double &s, double &c) { sincos_glibc(p, s, c); }
+    static __host__ __device__ __forceinline__ double hypot(double x, double y) { return hypot_glibc(x, y); }
 };
 template <> struct Real<float> {
-    static __device__ __forceinline__ float abs(float v) { return __builtin_fabsf(v); }
-    static __device__ __forceinline__ float max(float a, float b) { return __builtin_fmaxf(a, b); }
-    static __device__ __forceinline__ float rint(float v) { return __builtin_rintf(v); }
-    static __device__ __forceinline__ void sincos(float p, float &s, float &c) { sincosf_glibc(p, s, c); }
-    static __device__ __forceinline__ float hypot(float x, float y) { return hypotf_glibc(x, y); }
+    static __host__ __device__ __forceinline__ float abs(float v) { return __builtin_fabsf(v); }
+    static __host__ __device__ __forceinline__ float max(float a, float b) { return __builtin_fmaxf(a, b); }
+    static __host__ __device__ __forceinline__ float rint(float v) { return __builtin_rintf(v); }
+    static __host__ __device__ __forceinline__ void sincos(float p, float &s, float &c) { sincosf_glibc(p, s, c); }
+    static __host__ __device__ __forceinline__ float hypot(float x, float y) { return hypotf_glibc(x, y); }
 };
 
 }  // namespace pdt

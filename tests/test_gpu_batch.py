@@ -71,8 +71,8 @@ def test_batch_mixed_modes(pdt, orc):
     a = pdt.synth_capture(1, 32000, 10.0, f0_hz=140.0, seed=12)
     a2 = pdt.synth_capture(1, 32000, 13.0, f0_hz=110.0, seed=13)
     op = orc.Oracle(orc.POES, 50000, p)
-    oa = orc.Oracle(orc.ARGOS, 32000, a, math_mode=orc.MATH_PORTABLE)
-    oa2 = orc.Oracle(orc.ARGOS, 32000, a2, math_mode=orc.MATH_PORTABLE)
+    oa = orc.Oracle(orc.ARGOS, 32000, a, math_mode=orc.MATH_LIBM)
+    oa2 = orc.Oracle(orc.ARGOS, 32000, a2, math_mode=orc.MATH_LIBM)
     with pdt.Demodulator(pdt.MODE_POES, 50000) as d0, pdt.Demodulator(pdt.MODE_ARGOS, 32000) as d1, \
             pdt.Demodulator(pdt.MODE_ARGOS, 32000) as d2:
         tp, ta, ta2 = to_dev(p), to_dev(a), to_dev(a2)

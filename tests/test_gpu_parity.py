@@ -141,7 +141,7 @@ def test_argos_all_stages(pdt, orc, golden, seed, f0, secs, chunk):
     tests/test_oracle_ref.py ties to the reference's packet output), incl. the lock-signal stream,
     Squelch, the heap-adjacency reads of the Gardner seam (Q16) and odd/even/huge chunk sizes."""
     iq = pdt.synth_capture(1, 32000, secs, f0_hz=f0, seed=seed)
-    o = orc.Oracle(orc.ARGOS, 32000, iq, chunk=chunk, math_mode=orc.MATH_PORTABLE)
+    o = orc.Oracle(orc.ARGOS, 32000, iq, chunk=chunk, math_mode=orc.MATH_LIBM)
     with pdt.Demodulator(pdt.MODE_ARGOS, 32000, chunk=chunk) as d:
         d.demod(iq)
         check_all_stages(pdt, orc, d, o)
@@ -156,7 +156,7 @@ def test_argos_all_stages(pdt, orc, golden, seed, f0, secs, chunk):
 
 def test_argos_block_geometry_and_short_inputs(pdt, orc):
     iq = pdt.synth_capture(1, 32000, 8.0, f0_hz=120.0, seed=5)
-    o = orc.Oracle(orc.ARGOS, 32000, iq, math_mode=orc.MATH_PORTABLE)
+    o = orc.Oracle(orc.ARGOS, 32000, iq, math_mode=orc.MATH_LIBM)
     for kw in (dict(pll_block=8000, pll_warm=16000, agc_block=8000, agc_warm=16000),
                dict(pll_block=256, pll_warm=256, agc_block=256, agc_warm=256)):
         with pdt.Demodulator(pdt.MODE_ARGOS, 32000, **kw) as d:
@@ -164,7 +164,7 @@ def test_argos_block_geometry_and_short_inputs(pdt, orc):
             check_all_stages(pdt, orc, d, o)
     for n in (0, 3, 2399, 2400, 2401, 4800):
         part = iq[:n]
-        o2 = orc.Oracle(orc.ARGOS, 32000, part, math_mode=orc.MATH_PORTABLE)
+        o2 = orc.Oracle(orc.ARGOS, 32000, part, math_mode=orc.MATH_LIBM)
         with pdt.Demodulator(pdt.MODE_ARGOS, 32000) as d:
             d.demod(part)
             check_all_stages(pdt, orc, d, o2)
@@ -188,7 +188,7 @@ def test_argos_presquelch_stream_and_cli_raw_dump(pdt, orc, tmp_path, chunk, kw)
     The stream is kept on request (pdt_keep_presquelch, stage ST_AGC_RAW) and must equal the oracle's, which
     tests/test_oracle_ref.py compares with the reference's own objects; the host program writes it with -r."""
     iq = pdt.synth_capture(1, 32000, 10.0, f0_hz=150.0, seed=77)
-    o = orc.Oracle(orc.ARGOS, 32000, iq, chunk=chunk, math_mode=orc.MATH_PORTABLE)
+    o = orc.Oracle(orc.ARGOS, 32000, iq, chunk=chunk, math_mode=orc.MATH_LIBM)
     want = o.stage(orc.ST_AGC_RAW)
     assert len(want) == len(iq) and (want != o.stage(orc.ST_AGC)).any()          # the squelch does act on this capture
     with pdt.Demodulator(pdt.MODE_ARGOS, 32000, chunk=chunk, **kw) as d:
@@ -288,7 +288,7 @@ def test_alternative_kernels_agree(pdt, orc, clip, switch):
     rate, iq = clip
     o = orc.Oracle(orc.POES, rate, iq)
     a = pdt.synth_capture(1, 32000, 8.0, f0_hz=150.0, seed=31)
-    oa = orc.Oracle(orc.ARGOS, 32000, a, math_mode=orc.MATH_PORTABLE)
+    oa = orc.Oracle(orc.ARGOS, 32000, a, math_mode=orc.MATH_LIBM)
     os.environ[switch] = "1"
     try:
         with pdt.Demodulator(pdt.MODE_POES, rate) as d:
@@ -362,7 +362,7 @@ def test_mm_clock_recovery_poes(pdt, orc, clip, rg, kp):
 def test_mm_clock_recovery_argos(pdt, orc):
     iq = pdt.synth_capture(1, 32000, 14.0, f0_hz=150.0, seed=23)
     for chunk in (0, 1000):
-        o = orc.Oracle(orc.ARGOS, 32000, iq, chunk=chunk, sampler=1, math_mode=orc.MATH_PORTABLE)
+        o = orc.Oracle(orc.ARGOS, 32000, iq, chunk=chunk, sampler=1, math_mode=orc.MATH_LIBM)
         with pdt.Demodulator(pdt.MODE_ARGOS, 32000, chunk=chunk, sampler=pdt.SAMPLER_MM) as d:
             d.demod(iq)
             check_all_stages(pdt, orc, d, o)

@@ -173,7 +173,7 @@ def test_lock_in_a_later_segment_weak_signal_and_mm(pdt, orc):
 
 def test_argos_stream_against_the_oracle(pdt, orc):
     a = pdt.synth_capture(1, 32000, 20.0, f0_hz=130.0, seed=19)
-    o = orc.Oracle(orc.ARGOS, 32000, a, math_mode=orc.MATH_PORTABLE)
+    o = orc.Oracle(orc.ARGOS, 32000, a, math_mode=orc.MATH_LIBM)
     with pdt.Demodulator(pdt.MODE_ARGOS, 32000) as d:
         got, _, _ = stream_all(d, a, 2400)
         assert pdt.format_frames(got) == o.text() and len(got) >= 10

@@ -40,7 +40,7 @@ for case in range(n_cases):
                   agc_block=int(rng.integers(64, 12000)), agc_warm=int(rng.integers(0, 40000)))
     if rng.random() < 0.2:
         kw["gardner_band_pad"] = float(rng.choice([1 / 512, 1 / 64, 0.5]))
-    o = orc.Oracle(omode, fs, iq, chunk=chunk, sampler=sampler, math_mode=orc.MATH_PORTABLE if argos else orc.MATH_LIBM)
+    o = orc.Oracle(omode, fs, iq, chunk=chunk, sampler=sampler, math_mode=orc.MATH_LIBM)
     d = pdt.Demodulator(mode, fs, chunk=chunk, sampler=sampler, **kw)
     d.demod(iq)
     ok = d.text() == o.text()

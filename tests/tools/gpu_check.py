@@ -30,7 +30,7 @@ def compare(name, a, b):
 def run(label, mode, rate, iq, chunk=0, **kw):
     print(f"== {label}: {len(iq)} samples @ {rate} Hz chunk {chunk or 'default'}")
     t0 = time.time()
-    o = orc.Oracle(mode, rate, iq, chunk=chunk, math_mode=orc.MATH_PORTABLE)
+    o = orc.Oracle(mode, rate, iq, chunk=chunk, math_mode=orc.MATH_LIBM)
     t1 = time.time()
     d = pdt.Demodulator(mode, rate, chunk=chunk, profile=True, **kw)
     d.demod(iq)
