@@ -234,13 +234,15 @@ struct Plan {
 // Developer switches (A/B runs of older kernel variants, tuning sweeps).  Read from the environment ONCE, when the
 // context is opened; the demodulation calls never look at the environment.
 struct Tuning {
-    double pll_warm_scale = 1.0, head_taus = 0.0, agc_k = 0.0;
+    double pll_warm_scale = 1.0, head_taus = 0.0, agc_k = 0.0, pll_warm_s = 0.0, agc_warm_s = 0.0;
     int agc_tpb = 0, gseg = 0, acquire_mode = 0, pll_block = 0;      // acquire_mode: 0 = two-wavefront pipeline, 1 = plain one-lane, 2 = one wavefront
     bool fir_generic = false, agc_unfused = false, no_excl = false, gtab_nomerge = false, gardner_onebuf = false, debug_sync = false;
     void load()
     {
         if (const char *e = getenv("PDT_PLL_WARM_SCALE")) pll_warm_scale = atof(e);
         if (const char *e = getenv("PDT_HEAD_TAUS")) head_taus = atof(e);
+        if (const char *e = getenv("PDT_PLL_WARM_S")) pll_warm_s = atof(e);
+        if (const char *e = getenv("PDT_AGC_WARM_S")) agc_warm_s = atof(e);
         if (const char *e = getenv("PDT_AGC_K")) agc_k = atof(e);
         if (const char *e = getenv("PDT_AGC_TPB")) agc_tpb = std::max(1, atoi(e));
         if (const char *e = getenv("PDT_PLL_BLOCK")) pll_block = atoi(e);
@@ -698,7 +700,11 @@ template <typename T> int run_capture(pdt_ctx *ctx, uint64_t n, int phase = RUN_
     const double fs_d = (double)ctx->cfg.sample_rate;
     auto round4 = [](long long v) { return (v + 3) / 4 * 4; };
     long long Bp = ctx->cfg.pll_block ? ctx->cfg.pll_block : (long long)((argos ? 0.5 : 0.05) * fs_d);
-    long long Wp = ctx->cfg.pll_warm ? ctx->cfg.pll_warm : (long long)((argos ? 8.0 : 0.3) * fs_d);
+    // (ARGOS: the loops only contract while a burst is on the air -- between bursts the detector sees noise and two close
+    // trajectories are kicked apart as fast as they are pulled together -- so a warm-up must contain one whole burst: 2 s cover
+    // a 1.5 s repetition period + one 0.36 s burst; measured on the 5-minute capture: 8 / 4 / 2 / 1 s -> 0 / 0 / 0 / 192 repaired
+    // seams.  Sparser transmissions fall back on the seam repairs, as ever.)
+    long long Wp = ctx->cfg.pll_warm ? ctx->cfg.pll_warm : (long long)((argos ? 2.0 : 0.3) * fs_d);
     if (!ctx->cfg.pll_warm && !argos) {
         // Measured (tools/pll_geom.py, 50 ksps): the probability that a block has not merged bit for bit after a
         // warm-up of W samples falls like 200 exp(-W / 2.82 tau), tau = 2 / alpha_trk the tracking loop's time
@@ -712,7 +718,7 @@ template <typename T> int run_capture(pdt_ctx *ctx, uint64_t n, int phase = RUN_
     }
     long long Wacq = (long long)(0.02 * fs_d);             // acquisition-gain stage of the warm-up
     long long Ba = ctx->cfg.agc_block ? ctx->cfg.agc_block : (long long)((argos ? 0.125 : 0.0625) * fs_d * interp);
-    long long Wa = ctx->cfg.agc_warm ? ctx->cfg.agc_warm : (long long)((argos ? 8.0 : 1.0) * fs_d * interp);
+    long long Wa = ctx->cfg.agc_warm ? ctx->cfg.agc_warm : (long long)((argos ? 2.0 : 1.0) * fs_d * interp);
     if (!ctx->cfg.pll_block) {
         // One walker wavefront saturates the vector ALU of its SIMD (a wave64 instruction occupies the 16 lanes for 4 clocks), so
         // a second one on the same SIMD doubles the time of both: keep the walkers of everything that runs together -- this
@@ -1708,6 +1714,8 @@ int pdt_open(const pdt_config *cfg, pdt_ctx **out)
     ctx->cfg = *cfg;
     ctx->tune.load();
     if (ctx->tune.pll_block && !ctx->cfg.pll_block) ctx->cfg.pll_block = (uint32_t)ctx->tune.pll_block;
+    if (ctx->tune.pll_warm_s > 0 && !ctx->cfg.pll_warm) ctx->cfg.pll_warm = (uint32_t)(ctx->tune.pll_warm_s * cfg->sample_rate);
+    if (ctx->tune.agc_warm_s > 0 && !ctx->cfg.agc_warm) ctx->cfg.agc_warm = (uint32_t)(ctx->tune.agc_warm_s * cfg->sample_rate);
     if (!ctx->cfg.chunk) ctx->cfg.chunk = (cfg->mode == PDT_MODE_ARGOS || cfg->chain == PDT_CHAIN_LIVE) ? 2400 : 10000;
     ctx->elem = cfg->mode == PDT_MODE_ARGOS ? 8 : 4;
     int nt = 0, ip = 0;
@@ -2027,7 +2035,7 @@ int pdt_stream_begin(pdt_ctx *ctx)
 static uint64_t stream_history(const pdt_ctx *ctx)
 {
     const double fs = (double)ctx->cfg.sample_rate;
-    const double w = ctx->cfg.pll_warm ? (double)ctx->cfg.pll_warm : (ctx->cfg.mode == PDT_MODE_ARGOS ? 8.0 : 0.6) * fs;
+    const double w = ctx->cfg.pll_warm ? (double)ctx->cfg.pll_warm : (ctx->cfg.mode == PDT_MODE_ARGOS ? 2.0 : 0.6) * fs;
     return (uint64_t)(w + 0.03 * fs) + 8192;
 }
 

@@ -329,15 +329,38 @@ __device__ __forceinline__ void k_gardner_small(const T *__restrict__ in, const 
     T ns = 0, prev = 0, half = 0;
     long long count = 0;
 
+    // squelched stretches (ARGOS: three quarters of a capture) are exact zeros: there cur - prev = 0, the error term is +-0
+    // whatever the mid-point sample is, and the sampler just adds its step -- such chunks take a loop without the error
+    // arithmetic.  s_nz[b] = the staged chunk in buffer b holds a non-zero sample.
+    __shared__ int s_nz[2];
     auto stage = [&](long long c, T *buf, int first, int stride) {
         const long long base = c * C;
         const int n_cur = (int)((P.n_total - base < C) ? (P.n_total - base) : C);
-        for (int t = first; t < n_cur; t += stride) buf[t] = in[base + t];
+        int nz = 0;
+        int t = first;
+        for (; t + 7 * stride < n_cur; t += 8 * stride) {            // eight loads in flight per thread: one memory latency per chunk
+            T r[8];
+#pragma unroll
+            for (int u = 0; u < 8; u++) r[u] = in[base + t + u * stride];
+#pragma unroll
+            for (int u = 0; u < 8; u++) {
+                nz |= (r[u] != (T)0) ? 1 : 0;
+                buf[t + u * stride] = r[u];
+            }
+        }
+        for (; t < n_cur; t += stride) {
+            const T v = in[base + t];
+            nz |= (v != (T)0) ? 1 : 0;
+            buf[t] = v;
+        }
+        if (nz) atomicOr(&s_nz[c & 1], 1);
         int n_tail = n_cur + tail;
         if (n_tail > LEN) n_tail = LEN;
         for (int q = n_cur + first; q < n_tail; q += stride)
             buf[q] = gardner_beyond(in, lock, P, c, (long long)n_cur, (long long)q);
     };
+    if (tid < 2) s_nz[tid] = 0;
+    __syncthreads();
     if (n_chunks > 0) stage(0, win[0], tid, 256);
     __syncthreads();
     for (long long c = 0; c < n_chunks; c++) {
@@ -347,10 +370,27 @@ __device__ __forceinline__ void k_gardner_small(const T *__restrict__ in, const 
         int n_staged = n_cur + tail;
         if (n_staged > LEN) n_staged = LEN;
         int nout = 0;
+        const bool calm = s_nz[c & 1] == 0;       // (read by every wavefront before the barrier at the end of this iteration)
         if (wave != 0) {
             if (c + 1 < n_chunks) stage(c + 1, win[(c + 1) & 1], tid - 64, 192);
         } else {
             const T nT = (T)n_cur;
+            if (calm && prev == (T)0) {
+                // every sample of the chunk is zero and so is the previous symbol: err = clip(kp * (0 - 0) * mid) = +-0,
+                // nextSample - err = nextSample: only the additions of the reference step remain (GardenerClockRecovery.c:52-63)
+                for (;;) {
+                    const T rn = Real<T>::rint(ns);
+                    const int in_chunk = uniform<int>((int)(rn < nT));
+                    if (!in_chunk || nout >= OUT) break;
+                    const unsigned i_abs = uniform<unsigned>((unsigned)rn);
+                    o_val[nout] = w[i_abs];
+                    o_idx[nout] = i_abs;
+                    nout++;
+                    half = ns + hs;
+                    ns = ns + step;
+                }
+                prev = (nout > 0) ? w[o_idx[nout - 1]] : prev;
+            } else
             for (;;) {
                 // ---- checked step
                 const T rn = Real<T>::rint(ns);
@@ -406,6 +446,8 @@ __device__ __forceinline__ void k_gardner_small(const T *__restrict__ in, const 
             ns = ns - nT;                              // roll over; `half` is deliberately not (Q3)
         }
         count += uniform<int>(nout);                   // only wavefront 0's copy matters
+        __syncthreads();
+        if (tid == 0) s_nz[c & 1] = 0;                 // this buffer is restaged (chunk c + 2) in the next iteration
         __syncthreads();
     }
     if (tid == 0) *nsym_out = (unsigned long long)count;
