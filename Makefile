@@ -10,11 +10,16 @@ CFLAGS   := -O2 -Wall -ffp-contract=off
 CSRC     := $(PKG)/csrc
 LIBPDT   := $(CSRC)/libpdt.so
 LIBSYNTH := $(PKG)/synth/libpdtsynth.so
+LIBGATHER := $(CSRC)/libpdtgather.so
 
-all: $(LIBPDT) $(LIBSYNTH) bin/synth_wav bin/demodPOES bin/demodARGOS oracle
+all: $(LIBPDT) $(LIBSYNTH) $(LIBGATHER) bin/synth_wav bin/demodPOES bin/demodARGOS bin/demodMulti oracle
 
-$(LIBPDT): $(CSRC)/pdt_api.hip $(CSRC)/pdt_kernels_front.h $(CSRC)/pdt_kernels_back.h $(CSRC)/pdt_device_math.h $(CSRC)/pdt_timeaxis.h include/pdt.h
+$(LIBPDT): $(CSRC)/pdt_api.hip $(CSRC)/pdt_kernels_front.h $(CSRC)/pdt_kernels_back.h $(CSRC)/pdt_device_math.h $(CSRC)/pdt_sincostab.h $(CSRC)/pdt_timeaxis.h include/pdt.h
 	$(HIPCC) $(HIPFLAGS) -shared -o $@ $(CSRC)/pdt_api.hip
+
+# RCCL gather of frame records (multi-GPU launcher): a library of its own, so that libpdt.so does not depend on RCCL
+$(LIBGATHER): $(CSRC)/pdt_gather.hip include/pdt_gather.h include/pdt.h $(LIBPDT)
+	$(HIPCC) --offload-arch=$(ARCH) -O2 -std=c++17 -fPIC -Wall -shared -o $@ $(CSRC)/pdt_gather.hip -L$(CSRC) -lpdt -lrccl -Wl,-rpath,'$$ORIGIN'
 
 $(LIBSYNTH): $(PKG)/synth/pdt_synth.c $(PKG)/synth/pdt_synth.h
 	$(CC) $(CFLAGS) -fPIC -shared -o $@ $(PKG)/synth/pdt_synth.c -lm
@@ -31,11 +36,15 @@ bin/demodARGOS: $(PKG)/host/demod_main.c include/pdt.h $(LIBPDT)
 	mkdir -p bin
 	$(CC) $(CFLAGS) -DPDT_ARGOS -Iinclude -o $@ $(PKG)/host/demod_main.c -L$(CSRC) -lpdt -Wl,-rpath,'$$ORIGIN/../$(CSRC)'
 
+bin/demodMulti: $(PKG)/host/demod_multi.c include/pdt.h include/pdt_gather.h $(LIBPDT) $(LIBGATHER)
+	mkdir -p bin
+	$(CC) $(CFLAGS) -Iinclude -o $@ $(PKG)/host/demod_multi.c -L$(CSRC) -lpdtgather -lpdt -lpthread -Wl,-rpath,'$$ORIGIN/../$(CSRC)'
+
 oracle:
 	$(MAKE) -C oracle
 
 clean:
-	rm -f $(LIBPDT) $(LIBSYNTH) bin/*
+	rm -f $(LIBPDT) $(LIBSYNTH) $(LIBGATHER) bin/*
 	$(MAKE) -C oracle clean
 
 .PHONY: all oracle clean

@@ -165,6 +165,7 @@ const char *pdt_strerror(int code);
 int  pdt_device_count(void);
 
 int  pdt_open(const pdt_config *cfg, pdt_ctx **out);
+int  pdt_get_device(const pdt_ctx *ctx);          /* the HIP device ordinal the context lives on */
 void pdt_close(pdt_ctx *ctx);
 
 /* Use an existing HIP stream (hipStream_t passed as void*) for all work; NULL = own stream. */

@@ -1617,6 +1617,8 @@ const char *pdt_strerror(int code)
     }
 }
 
+int pdt_get_device(const pdt_ctx *ctx) { return ctx ? ctx->cfg.device : -1; }
+
 int pdt_device_count(void)
 {
     int n = 0;

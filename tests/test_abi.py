@@ -43,7 +43,7 @@ def test_struct_layouts_match_header(pdt):
     assert pdt.TIP_DTYPE.itemsize == 12 and C.sizeof(pdt.TipSummary) == 56
     # the header itself must compile as plain C and agree on the sizes
     import tempfile
-    src = ('#include "pdt.h"\nint main(void){return (sizeof(pdt_config)==80 && sizeof(pdt_frame)==136 && sizeof(pdt_tip_frame)==12 '
+    src = ('#include "pdt.h"\n#include "pdt_gather.h"\nint main(void){return (sizeof(pdt_config)==80 && sizeof(pdt_frame)==136 && sizeof(pdt_tip_frame)==12 '
            '&& sizeof(pdt_tip_summary)==56 && sizeof(pdt_stats)>0) ? 0 : 1;}\n')
     with tempfile.TemporaryDirectory() as tmp:
         cfile = os.path.join(tmp, "abi.c")
@@ -147,3 +147,14 @@ def test_format_records_equals_printf(pdt):
     fr["complete"] = rng.integers(0, 2, len(times))
     assert pdt.format_frames(fr) == pdt.format_frames_py(fr)
     assert pdt.format_frames(fr[:0]) == b""
+
+
+def test_gather_library_exports_its_entry_point(pdt):
+    """include/pdt_gather.h: the RCCL gather of frame records lives in a library of its own (libpdt.so has no RCCL dependency)."""
+    path = os.path.join(os.path.dirname(pdt.LIBPDT_PATH), "libpdtgather.so")
+    assert os.path.exists(path), "run `make`"
+    needed = subprocess.run(["readelf", "-d", path], capture_output=True, text=True).stdout
+    assert "librccl" in needed and "libpdt.so" in needed
+    assert "librccl" not in subprocess.run(["readelf", "-d", pdt.LIBPDT_PATH], capture_output=True, text=True).stdout
+    syms = subprocess.run(["nm", "-D", "--defined-only", path], capture_output=True, text=True).stdout
+    assert " T pdt_gather_frames" in syms
