@@ -235,7 +235,7 @@ struct Plan {
 // context is opened; the demodulation calls never look at the environment.
 struct Tuning {
     double pll_warm_scale = 1.0, head_taus = 0.0, agc_k = 0.0, pll_warm_s = 0.0, agc_warm_s = 0.0;
-    int agc_tpb = 0, gseg = 0, acquire_mode = 0, pll_block = 0;      // acquire_mode: 0 = two-wavefront pipeline, 1 = plain one-lane, 2 = one wavefront
+    int agc_tpb = 0, gseg = 0, acquire_mode = 0, pll_block = 0, fix_passes = 2;      // acquire_mode: 0 = two-wavefront pipeline, 1 = plain one-lane, 2 = one wavefront
     bool fir_generic = false, agc_unfused = false, no_excl = false, gtab_nomerge = false, gardner_onebuf = false, debug_sync = false;
     void load()
     {
@@ -246,6 +246,7 @@ struct Tuning {
         if (const char *e = getenv("PDT_AGC_K")) agc_k = atof(e);
         if (const char *e = getenv("PDT_AGC_TPB")) agc_tpb = std::max(1, atoi(e));
         if (const char *e = getenv("PDT_PLL_BLOCK")) pll_block = atoi(e);
+        if (const char *e = getenv("PDT_FIX_PASSES")) fix_passes = atoi(e);
         if (const char *e = getenv("PDT_GSEG")) gseg = std::min(64, std::max(2, atoi(e)));
         if (getenv("PDT_ACQUIRE_SIMPLE")) acquire_mode = 1;
         else if (getenv("PDT_ACQUIRE_ONEWAVE")) acquire_mode = 2;
@@ -890,6 +891,7 @@ template <typename T> int run_capture(pdt_ctx *ctx, uint64_t n, int phase = RUN_
     // the serial kernels (acquisition, head) ask for SIMDs of their own while the block-parallel kernel beside them
     // leaves some free (1 024 SIMDs; it runs one wavefront per 64 blocks)
     const bool serial_excl = 4 * grid_pll <= 960 && !ctx->tune.no_excl;
+    long long fix_regions = 1, fix_region_blocks = 0;
     L.begin("pll_acquire");
     if (seg && seg->locked) {
         // the lock happened in an earlier segment: the kernels that start "after the lock" start at `first` with the carried
@@ -938,7 +940,12 @@ template <typename T> int run_capture(pdt_ctx *ctx, uint64_t n, int phase = RUN_
         PllHeadInfo<T> *d_hinfo = (PllHeadInfo<T> *)ctx->pll_head.p;
         PllSeam<T> *d_hseams = (PllSeam<T> *)((unsigned char *)ctx->pll_head.p + 64);
         T *d_hphi = (T *)((unsigned char *)d_hseams + (((size_t)head_blocks * sizeof(PllSeam<T>) + 63) & ~(size_t)63));
-        if ((rc = ctx->pll_scratch.ensure((size_t)(PDT_FIX_THREADS / 64) * (size_t)(((Bp + 63) & ~63ll) + 64) * sizeof(T)))) return rc;
+        // seam repairs: regions of the capture are validated and repaired side by side before the final in-order pass
+        // (k_pll_fix); every region workgroup has scratch for its 16 concurrent block re-runs
+        const long long nb_fix = (N + Bp - 1) / Bp;
+        fix_regions = (nb_fix >= 128) ? std::min<long long>(64, nb_fix / 16) : 1;
+        fix_region_blocks = (nb_fix + fix_regions - 1) / fix_regions;
+        if ((rc = ctx->pll_scratch.ensure((size_t)(fix_regions + 2) * (size_t)(PDT_FIX_THREADS / 64) * (size_t)(((Bp + 63) & ~63ll) + 64) * sizeof(T)))) return rc;
         L.begin("pll_head");
         if (slow_wrap)
             PDT_LAUNCH(64, (k_pll_head<T, true>), dim3(1), dim3(64), 0, st, d_theta, N, PP, d_info, Bp, Hd, d_hphi, d_hseams,
@@ -953,14 +960,27 @@ template <typename T> int run_capture(pdt_ctx *ctx, uint64_t n, int phase = RUN_
         PL.simple(OP_JOIN_WAIT);                                           // join
         L.gap();                                                           // (the wait is not part of pll_fix)
         L.begin("pll_fix");
-        if (slow_wrap)
-            PDT_LAUNCH(PDT_FIX_THREADS, (k_pll_fix<T, true>), dim3(1), dim3(PDT_FIX_THREADS), 0, st, d_theta, N, PP, d_info, Bp, d_phi,
+        {
+            // graft the head, two optimistic region passes (region boundaries half a region apart), the final pass
+            auto fix = [&](int mode, unsigned grid, long long rb, long long ro) {
+                if (slow_wrap)
+                    PDT_LAUNCH(PDT_FIX_THREADS, (k_pll_fix<T, true>), dim3(grid), dim3(PDT_FIX_THREADS), 0, st, d_theta, N, PP, d_info, Bp, d_phi,
                                (PllSeam<T> *)ctx->seams_pll.p, (const T *)d_hphi, (const PllSeam<T> *)d_hseams,
-                               (const PllHeadInfo<T> *)d_hinfo, (T *)ctx->pll_scratch.p, d_sc->counters);
-        else
-            PDT_LAUNCH(PDT_FIX_THREADS, (k_pll_fix<T, false>), dim3(1), dim3(PDT_FIX_THREADS), 0, st, d_theta, N, PP, d_info, Bp, d_phi,
+                               (const PllHeadInfo<T> *)d_hinfo, (T *)ctx->pll_scratch.p, d_sc->counters, mode, rb, ro);
+                else
+                    PDT_LAUNCH(PDT_FIX_THREADS, (k_pll_fix<T, false>), dim3(grid), dim3(PDT_FIX_THREADS), 0, st, d_theta, N, PP, d_info, Bp, d_phi,
                                (PllSeam<T> *)ctx->seams_pll.p, (const T *)d_hphi, (const PllSeam<T> *)d_hseams,
-                               (const PllHeadInfo<T> *)d_hinfo, (T *)ctx->pll_scratch.p, d_sc->counters);
+                               (const PllHeadInfo<T> *)d_hinfo, (T *)ctx->pll_scratch.p, d_sc->counters, mode, rb, ro);
+            };
+            fix(0, 1, 0, 0);
+            if (fix_regions > 1) {
+                for (int pass = 0; pass < ctx->tune.fix_passes; pass++) {
+                    if (pass & 1) fix(1, (unsigned)fix_regions + 1, fix_region_blocks, fix_region_blocks / 2);
+                    else fix(1, (unsigned)fix_regions, fix_region_blocks, 0);
+                }
+            }
+            fix(2, 1, 0, 0);
+        }
         L.end();
         (void)grid;
         L.begin("pll_mix");

@@ -1090,16 +1090,25 @@ __device__ __forceinline__ void k_pll_fix(const T *__restrict__ theta, long long
                                                  PllSeam<T> *__restrict__ seams, const T *__restrict__ phi_head,
                                                  const PllSeam<T> *__restrict__ seams_head,
                                                  const PllHeadInfo<T> *__restrict__ hinfo, T *__restrict__ scratch,
-                                                 unsigned *__restrict__ counters /* [0]=blocks [1]=fixes */)
+                                                 unsigned *__restrict__ counters /* [0]=blocks [1]=fixes */, int mode,
+                                                 long long region_blocks, long long region_offset)
 {
+    // mode 0: graft the head's phases and seam records over the block-parallel ones, nothing else (one workgroup);
+    // mode 1: region pass -- workgroup g validates and repairs the seams of its own region of `region_blocks` blocks, taking the
+    //         end state of the block before its region as true.  Optimistic: a repair in the region to the left that changes that
+    //         state invalidates the assumption, which a later pass (other region boundaries, or the final pass) finds, because a
+    //         block re-run from state X records X as its start state and the seam check compares exactly that.  On a healthy
+    //         capture every region just finds its seams closed; on a weak signal, where seams fail in runs that must be walked
+    //         one block after the other, the runs of all regions are walked side by side;
+    // mode 2: final pass over all seams (one workgroup): whatever is still open is repaired in order, as before.
     constexpr int NW = PDT_FIX_THREADS / 64;
     __shared__ long long s_bad[PDT_FIX_LIST];
-    __shared__ T s_end[NW][2];
+    __shared__ T s_end[NW][2], s_beg[NW][2];
     __shared__ unsigned s_nbad;
     __shared__ long long s_min;
     const long long lock_at = info->lock_sample;
     if (lock_at < 0) {
-        if (threadIdx.x == 0) { counters[0] = 0; counters[1] = 0; }
+        if (threadIdx.x == 0 && mode == 2) counters[0] = 0;
         return;
     }
     const long long S = lock_at + 1;
@@ -1107,18 +1116,26 @@ __device__ __forceinline__ void k_pll_fix(const T *__restrict__ theta, long long
     const long long j0 = hi.j0;                                     // block that contains the lock
     const long long nb_abs = (n + B - 1) / B;                       // absolute block count
     const long long BS = (B + 63) & ~63ll;                          // scratch stride per wavefront
-    // graft the head's true phases and seam records over the block-parallel ones
-    for (long long i = hi.s0 + threadIdx.x; i < hi.s1; i += PDT_FIX_THREADS) phi[Lt<T>::index(i, B)] = phi_head[i - (hi.s0 & ~3ll)];
-    for (long long k = threadIdx.x; k < hi.nblk; k += PDT_FIX_THREADS) seams[j0 + k] = seams_head[k];
-    __threadfence();
-    __syncthreads();
+    if (mode == 0) {
+        for (long long i = hi.s0 + threadIdx.x; i < hi.s1; i += PDT_FIX_THREADS) phi[Lt<T>::index(i, B)] = phi_head[i - (hi.s0 & ~3ll)];
+        for (long long k = threadIdx.x; k < hi.nblk; k += PDT_FIX_THREADS) seams[j0 + k] = seams_head[k];
+        return;
+    }
     unsigned fixes = 0;
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     long long from = (hi.nblk > 0) ? j0 + hi.nblk : nb_abs;         // seams before `from` are final
+    long long r_hi = nb_abs;                                        // seams [from, r_hi) are this workgroup's
+    if (mode == 1) {
+        const long long r_lo = (long long)blockIdx.x * region_blocks - region_offset;
+        r_hi = (r_lo + region_blocks < nb_abs) ? r_lo + region_blocks : nb_abs;
+        if (from < r_lo) from = r_lo;
+        if (from < 1) from = 1;
+        scratch += (long long)blockIdx.x * NW * BS;
+    }
     for (;;) {
-        if (threadIdx.x == 0) { s_nbad = 0; s_min = nb_abs; }
+        if (threadIdx.x == 0) { s_nbad = 0; s_min = r_hi; }
         __syncthreads();
-        for (long long r = from + threadIdx.x; r < nb_abs; r += PDT_FIX_THREADS) {
+        for (long long r = from + threadIdx.x; r < r_hi; r += PDT_FIX_THREADS) {
             const PllSeam<T> prev = seams[r - 1];
             const PllSeam<T> cur = seams[r];
             if (!(bits_equal(prev.phase1, cur.phase0) && bits_equal(prev.freq1, cur.freq0))) {
@@ -1154,6 +1171,8 @@ __device__ __forceinline__ void k_pll_fix(const T *__restrict__ theta, long long
             const long long rb = s_bad[wave];
             const PllSeam<T> prev = seams[rb - 1];
             T phase = prev.phase1, freq = prev.freq1;
+            s_beg[wave][0] = phase;                 // the state this re-run really started from: that, and not a later reading
+            s_beg[wave][1] = freq;                  // of the neighbour's record (another region may be rewriting it), is recorded
             const long long start = rb * B;
             const long long end = ((rb + 1) * B < n) ? (rb + 1) * B : n;
             // scratch index = sample index - (start rounded down to 4): vector stores stay aligned
@@ -1179,10 +1198,9 @@ __device__ __forceinline__ void k_pll_fix(const T *__restrict__ theta, long long
             const T *src = scratch + (long long)q * BS - (start & ~3ll);
             for (long long i = start + threadIdx.x; i < end; i += PDT_FIX_THREADS) phi[Lt<T>::index(i, B)] = src[i];
             if (threadIdx.x == 0) {
-                const PllSeam<T> prev = seams[rb - 1];
                 PllSeam<T> upd;
-                upd.phase0 = prev.phase1;
-                upd.freq0 = prev.freq1;
+                upd.phase0 = s_beg[q][0];
+                upd.freq0 = s_beg[q][1];
                 upd.phase1 = s_end[q][0];
                 upd.freq1 = s_end[q][1];
                 seams[rb] = upd;
@@ -1201,7 +1219,7 @@ __device__ __forceinline__ void k_pll_fix(const T *__restrict__ theta, long long
             if (threadIdx.x == 0) {
                 long long r = rl + 1;
                 unsigned extra = 0;
-                while (r < nb_abs) {
+                while (r < r_hi) {
                     const PllSeam<T> prev = seams[r - 1];
                     const PllSeam<T> cur = seams[r];
                     if (bits_equal(prev.phase1, cur.phase0) && bits_equal(prev.freq1, cur.freq0)) break;
@@ -1230,8 +1248,8 @@ __device__ __forceinline__ void k_pll_fix(const T *__restrict__ theta, long long
         }
     }
     if (threadIdx.x == 0) {
-        counters[0] = (unsigned)((S < n) ? nb_abs - j0 : 0);
-        counters[1] = fixes;
+        if (mode == 2) counters[0] = (unsigned)((S < n) ? nb_abs - j0 : 0);
+        if (fixes) atomicAdd(&counters[1], fixes);
     }
 }
 

@@ -386,3 +386,26 @@ def test_cli_demodpoes(pdt, tmp_path):
     r = subprocess.run([exe, "-o", str(out2), str(silent)], capture_output=True, text=True)
     assert r.returncode == 0 and not out2.exists()
     assert "None bits found" in r.stdout
+
+
+def test_pass_shaped_snr_profile(pdt, orc):
+    """A pass as a receiver sees it: 20 dB SNR in the middle, falling to about 0 dB at acquisition and loss of signal (noise
+    scaled x10 at both ends, in steps).  The weak ends are where the block-parallel PLL stops merging and the seam repairs
+    (region passes + final pass) carry the result: every stage equal to the oracle, and the repairs really ran."""
+    import ctypes as C
+    fs, seg_s = 50000, 6.0
+    n = int(fs * seg_s)
+    parts = []
+    for k, mult in enumerate([10, 7, 4, 2, 1, 1, 2, 4, 7, 10]):
+        p = pdt.synth_params(0, fs, 1000.0, 4711)
+        p.noise_gain = int(p.noise_gain * mult)
+        iq = np.zeros((n, 2), dtype="<i2")
+        pdt.synth_lib().pdt_synth_fill(C.byref(p), k * n, n, iq.ctypes.data)          # one continuous signal, noise level per segment
+        parts.append(iq)
+    cap = np.concatenate(parts)
+    o = orc.Oracle(orc.POES, fs, cap)
+    with pdt.Demodulator(pdt.MODE_POES, fs) as d:
+        d.demod(cap)
+        check_all_stages(pdt, orc, d, o)
+        s = d.stats()
+        assert s.pll_seam_fixes >= 10 and s.frames >= 400
