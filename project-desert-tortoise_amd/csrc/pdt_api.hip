@@ -709,11 +709,11 @@ template <typename T> int run_capture(pdt_ctx *ctx, uint64_t n, int phase = RUN_
     if (!ctx->cfg.pll_warm && !argos) {
         // Measured (tools/pll_geom.py, 50 ksps): the probability that a block has not merged bit for bit after a
         // warm-up of W samples falls like 200 exp(-W / 2.82 tau), tau = 2 / alpha_trk the tracking loop's time
-        // constant.  Aim at fewer than ~1/2 unhealthy seam per capture: short captures get away with less than 0.3 s,
-        // hour-long ones need a little more (a repair costs a block walk and cascades).
+        // constant.  Aim at ~0.1 unhealthy seam per capture (a repair costs a sequential block walk, ~0.2 ms, against ~0.08 ms
+        // for the extra 1.6 tau of warm-up): short captures get away with less than 0.3 s, hour-long ones need a little more.
         const double tau = 2.0 / (double)PP.alpha_trk;
         const double nb = std::max(1.0, (double)N / (double)std::max<long long>(1, Bp));
-        double w = 2.82 * tau * log(400.0 * nb);
+        double w = 2.82 * tau * log(2000.0 * nb);      // 200 nb exp(-w / 2.82 tau) = 0.1 expected unhealthy seams per capture
         w *= ctx->tune.pll_warm_scale;
         Wp = (long long)std::min(std::max(w, 0.15 * fs_d), 0.6 * fs_d);
     }

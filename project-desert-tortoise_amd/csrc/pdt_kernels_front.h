@@ -906,7 +906,10 @@ template <typename T, int FMT>
 __device__ __forceinline__ void pll_guess_fmt(IqSrc pcm, long long ws, long long n, int lag, T fallback_freq,
                                               T &phase, T &freq)
 {
-    const int K = 1024, KP = 96;
+#ifndef PDT_GUESS_K
+#define PDT_GUESS_K 512    // samples of the autocorrelation behind the frequency guess (1024 / 512 / 256: phase kernel 1.15 / 1.12 / 1.10 ms, same seam statistics)
+#endif
+    const int K = PDT_GUESS_K, KP = 96;
     float rr = 0, ri = 0;
     long long cnt = 0;
     if (ws + K + lag <= n) {
