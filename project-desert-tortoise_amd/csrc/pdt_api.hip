@@ -236,7 +236,7 @@ struct Plan {
 struct Tuning {
     double pll_warm_scale = 1.0, head_taus = 0.0, agc_k = 0.0, pll_warm_s = 0.0, agc_warm_s = 0.0;
     int agc_tpb = 0, gseg = 0, acquire_mode = 0, pll_block = 0, fix_passes = 2;      // acquire_mode: 0 = two-wavefront pipeline, 1 = plain one-lane, 2 = one wavefront
-    bool fir_generic = false, agc_unfused = false, no_excl = false, gtab_nomerge = false, gardner_onebuf = false, debug_sync = false;
+    bool fir_generic = false, agc_unfused = false, no_excl = false, gtab_nomerge = false, gardner_onebuf = false, gardner_noring = false, ema_noguess = false, debug_sync = false;
     void load()
     {
         if (const char *e = getenv("PDT_PLL_WARM_SCALE")) pll_warm_scale = atof(e);
@@ -255,6 +255,8 @@ struct Tuning {
         no_excl = getenv("PDT_NO_EXCL") != nullptr;
         gtab_nomerge = getenv("PDT_GTAB_NOMERGE") != nullptr;
         gardner_onebuf = getenv("PDT_GARDNER_ONEBUF") != nullptr;
+        gardner_noring = getenv("PDT_GARDNER_NORING") != nullptr;
+        ema_noguess = getenv("PDT_EMA_NOGUESS") != nullptr;
         debug_sync = getenv("PDT_DEBUG_SYNC") != nullptr;
     }
 };
@@ -306,7 +308,7 @@ struct pdt_ctx {
     hipEvent_t ev0 = nullptr, ev1 = nullptr, ev_fork = nullptr, ev_join = nullptr;
     hipStream_t stream2 = nullptr;     // side stream: block-parallel PLL phase runs beside the sequential acquisition
 
-    DevBuf pcm, pll, lock, fir, agc, sym, symidx, bits, bitsym, hits, frames, taps, mag, seams_pll, seams_agc, scal, lockinfo, term, seams_ema, gtable, gentries, gcand, gmfirst, stiles, gsegmap, gsegstart, gbands, gclist, agc_maps, pll_head, taps_rot, pll_scratch, tip, sync_scr, agc_raw;
+    DevBuf pcm, pll, lock, fir, agc, sym, symidx, bits, bitsym, hits, frames, taps, mag, seams_pll, seams_agc, scal, lockinfo, term, seams_ema, gtable, gentries, gcand, gmfirst, stiles, gsegmap, gsegstart, gbands, gclist, gneed, agc_maps, pll_head, taps_rot, pll_scratch, tip, sync_scr, agc_raw;
     bool keep_agc_raw = false;   // pdt_keep_presquelch: also keep the AGC output before Squelch (stage PDT_ST_AGC_RAW)
     // (stream_in is declared with the streaming state below)
     long long gcand_key = -1;          // (chunk_out, step) the candidate list on the device was built for
@@ -809,10 +811,18 @@ template <typename T> int run_capture(pdt_ctx *ctx, uint64_t n, int phase = RUN_
     if (need_lock && (rc = ctx->term.ensure((size_t)(N + 1) * sizeof(T)))) return rc;
     // lock-detector EMA (ARGOS): a pure contraction with factor 1 - lockSigAlpha per sample, so its own, much
     // shorter geometry: 45 time constants of warm-up agree in 53 bits (20 in 24), blocks a quarter of that
-    const long long We = round4((long long)((sizeof(T) == 8 ? 45.0 : 20.0) / (double)PP.lock_alpha) + 64);
-    const long long Be = std::max<long long>(64, round4(We / 4));
+    // With the affine guess of the state at every block boundary (k_lock_ema_zero / _guess) 16 time constants do.
+    const bool ema_guess = !ctx->tune.ema_noguess;
+    long long We = round4((long long)((sizeof(T) == 8 ? 45.0 : 20.0) / (double)PP.lock_alpha) + 64);
+    long long Be = std::max<long long>(64, round4(We / 4));
+    if (ema_guess) {
+        Be = std::max<long long>(64, round4((long long)(1.0 / (double)PP.lock_alpha)));
+        We = 16 * Be;                  // a difference of D ulps survives n steps with probability ~ D (1 - alpha)^n; D is a few tens
+    }
     const long long nb_ema = N / Be + 2;
-    if (need_lock && (rc = ctx->seams_ema.ensure((size_t)nb_ema * sizeof(EmaSeam<T>)))) return rc;
+    if (need_lock && (rc = ctx->seams_ema.ensure((size_t)nb_ema * (sizeof(EmaSeam<T>) + 2 * sizeof(double))))) return rc;
+    double *d_ema_zresp = need_lock ? (double *)((EmaSeam<T> *)ctx->seams_ema.p + nb_ema) : nullptr;
+    double *d_ema_guess = need_lock ? d_ema_zresp + nb_ema : nullptr;
     if ((rc = ctx->scal.ensure(sizeof(DevScalars)))) return rc;
     if ((rc = ctx->lockinfo.ensure(sizeof(PllLockInfo<T>)))) return rc;
 
@@ -993,8 +1003,14 @@ template <typename T> int run_capture(pdt_ctx *ctx, uint64_t n, int phase = RUN_
         L.end();
         if (need_lock) {
             L.begin("lock_ema");
+            if (ema_guess) {
+                PDT_LAUNCH(64, k_lock_ema_zero<T>, dim3((unsigned)((nb_ema + 63) / 64)), dim3(64), 0, st, (const T *)ctx->term.p, N,
+                                   PP.lock_alpha, d_info, Be, d_ema_zresp);
+                PDT_LAUNCH(1024, k_lock_ema_guess<T>, dim3(1), dim3(1024), 0, st, (const double *)d_ema_zresp, N, PP.lock_alpha, d_info, Be,
+                                   pow(1.0 - (double)PP.lock_alpha, (double)Be), d_ema_guess);
+            }
             PDT_LAUNCH(64, k_lock_ema<T>, dim3((unsigned)((nb_ema + 63) / 64)), dim3(64), 0, st, (const T *)ctx->term.p, N, PP.lock_alpha,
-                               d_info, Be, We, d_lock, (EmaSeam<T> *)ctx->seams_ema.p);
+                               d_info, Be, We, d_lock, (EmaSeam<T> *)ctx->seams_ema.p, (const double *)(ema_guess ? d_ema_guess : nullptr));
             PDT_LAUNCH(64, k_lock_ema_fix<T>, dim3(1), dim3(64), 0, st, (const T *)ctx->term.p, N, PP.lock_alpha, d_info,
                                Be, d_lock, (EmaSeam<T> *)ctx->seams_ema.p, &d_sc->counters[1]);
             L.end();
@@ -1248,7 +1264,20 @@ template <typename T> int run_capture(pdt_ctx *ctx, uint64_t n, int phase = RUN_
         constexpr int SMALL_LEN = 32768 / (int)sizeof(T), SMALL_OUT = 1024;    // two 32 KiB windows
         const long long small_need = chunk_out + 2 * (long long)GP.step + 24;
         const double small_syms = (double)chunk_out / ((double)GP.step - 0.25) + 4.0;
-        if (small_need <= SMALL_LEN && small_syms < SMALL_OUT && !ctx->tune.gardner_onebuf && !seg)
+        constexpr int RING_LEN = 20480 / (int)sizeof(T), RING_NB = 6, RING_OUT = 256;   // six 20 KiB buffers
+        if (small_need <= RING_LEN && small_syms < RING_OUT && chunk_out >= 4 * (long long)GP.step + 8 && n_chunks >= 8 && !seg &&
+            !ctx->tune.gardner_onebuf && !ctx->tune.gardner_noring) {
+            const size_t need_bytes = ((size_t)n_chunks + 64 + 15) & ~(size_t)15;
+            if ((rc = ctx->gneed.ensure(need_bytes + (size_t)n_chunks * sizeof(CalmEntry<T>)))) return rc;
+            CalmEntry<T> *d_calm = (CalmEntry<T> *)((char *)ctx->gneed.p + need_bytes);
+            PDT_LAUNCH(256, k_chunk_need<T>, dim3((unsigned)n_chunks), dim3(256), 0, st, (const T *)d_agc, n_out, chunk_out, n_chunks,
+                               (unsigned char *)ctx->gneed.p);
+            PDT_LAUNCH(64 * (RING_NB + 1), (k_gardner_ring<T, RING_LEN, RING_NB, RING_OUT>), dim3(1), dim3(64 * (RING_NB + 1)), 0, st,
+                               (const T *)d_agc, (const T *)d_lock, GP, (const unsigned char *)ctx->gneed.p, d_sym, d_symidx, &d_sc->nsym,
+                               sym_cap, d_calm);
+            PDT_LAUNCH(256, k_calm_emit<T>, dim3((unsigned)((n_chunks + 255) / 256)), dim3(256), 0, st, (const unsigned char *)ctx->gneed.p,
+                               (const CalmEntry<T> *)d_calm, GP, d_sym, d_symidx, sym_cap);
+        } else if (small_need <= SMALL_LEN && small_syms < SMALL_OUT && !ctx->tune.gardner_onebuf && !seg)
             PDT_LAUNCH(256, (k_gardner_small<T, SMALL_LEN, SMALL_OUT>), dim3(1), dim3(256), 0, st, (const T *)d_agc, (const T *)d_lock, GP,
                                d_sym, d_symidx, &d_sc->nsym, sym_cap);
         else

@@ -5,6 +5,12 @@
 
 namespace pdt {
 
+// one 16-byte vector of samples
+template <typename T> struct alignas(16) Vec16 {
+    static constexpr int N = 16 / sizeof(T);
+    T v[N];
+};
+
 // ------------------------------------------------------------------------------------------
 // Gardner clock recovery (reference: common/GardenerClockRecovery.c:5-114)
 //
@@ -70,6 +76,17 @@ template <> __device__ __forceinline__ unsigned uniform<unsigned>(unsigned v)
 {
     return (unsigned)__builtin_amdgcn_readfirstlane((int)v);
 }
+
+// neither NaN nor infinity
+__device__ __forceinline__ bool is_finite_bits(float v) { return (__float_as_int(v) & 0x7f800000) != 0x7f800000; }
+__device__ __forceinline__ bool is_finite_bits(double v) { return (__double2hiint(v) & 0x7ff00000) != 0x7ff00000; }
+// rint(x) as an integer, read out of the mantissa of x + 1.5 * 2^(mantissa bits): the addition rounds to nearest-even at the
+// integer position exactly as rint does (float: 0 <= x < 2^22; double: |x| < 2^31)
+__device__ __forceinline__ int rint_index(float x) { return __float_as_int(x + 12582912.0f) - 0x4B400000; }
+__device__ __forceinline__ int rint_index(double x) { return __double2loint(x + 6755399441055744.0); }
+// (e > lim) ? lim : ((e < -lim) ? -lim : e) for every e that is not a NaN
+__device__ __forceinline__ float clip_finite(float e, float lim) { return __builtin_amdgcn_fmed3f(e, -lim, lim); }
+__device__ __forceinline__ double clip_finite(double e, double lim) { return __builtin_fmin(__builtin_fmax(e, -lim), lim); }
 
 template <typename T> struct GardnerState {
     T ns, prev, half;      // sampler state (identical in every lane of the wavefront)
@@ -453,6 +470,298 @@ __device__ __forceinline__ void k_gardner_small(const T *__restrict__ in, const 
     if (tid == 0) *nsym_out = (unsigned long long)count;
 }
 
+// need[c] = 1 when chunk c has to be walked sample by sample: a sample of chunk c or of chunk c - 1 is not +0.0.  In every
+// other chunk all picks are +0.0 and so is the symbol before its first one: cur - prev = 0, the error term is +-0 whatever the
+// mid-point sample is (finite: AGC output, lock signal or the heap's size field), nextSample - err = nextSample
+// (GardenerClockRecovery.c:52-63) -- the sampler only adds its step.  One workgroup per chunk.
+template <typename T>
+__device__ __forceinline__ void k_chunk_need(const T *__restrict__ in, long long n_total, long long C, long long n_chunks,
+                                             unsigned char *__restrict__ need)
+{
+    const long long c = blockIdx.x;
+    if (c >= n_chunks) return;
+    long long i0 = (c > 0 ? c - 1 : 0) * C, i1 = (c + 1) * C;
+    if (i1 > n_total) i1 = n_total;
+    int nz = 0;
+    for (long long i = i0 + threadIdx.x; i < i1; i += blockDim.x) {
+        const T v = in[i];
+        if constexpr (sizeof(T) == 8) nz |= (__double_as_longlong((double)v) != 0ll) ? 1 : 0;
+        else nz |= (__float_as_int((float)v) != 0) ? 1 : 0;
+    }
+    nz = __syncthreads_or(nz);
+    if (threadIdx.x == 0) need[c] = nz ? 1 : 0;
+}
+
+// where a chunk without a walk starts: sampling instant (chunk-relative) and number of symbols before it
+template <typename T> struct CalmEntry {
+    T ns;
+    long long count;
+};
+
+// symbols of the chunks the ring sampler did not walk: value +0.0 at rint(nextSample), nextSample advancing by the step
+// from the entry the walker noted.  One lane per chunk.
+template <typename T>
+__device__ __forceinline__ void k_calm_emit(const unsigned char *__restrict__ need, const CalmEntry<T> *__restrict__ calm,
+                                            GardnerParams<T> P, T *__restrict__ sym, long long *__restrict__ symidx,
+                                            long long sym_cap)
+{
+    const long long C = P.chunk_out;
+    const long long n_chunks = (P.n_total + C - 1) / C;
+    const long long c = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= n_chunks || need[c] != 0) return;
+    const long long base = c * C;
+    const T nT = (T)((P.n_total - base < C) ? (P.n_total - base) : C);
+    T ns = calm[c].ns;
+    long long k = calm[c].count;
+    for (;;) {
+        const T rn = Real<T>::rint(ns);
+        if (!(rn < nT)) break;
+        if (k < sym_cap) {
+            sym[k] = (T)0;
+            symidx[k] = base + (long long)(unsigned)rn;
+        }
+        k++;
+        ns = ns + P.step;
+    }
+}
+
+// Sequential sampler for small reference chunks with a ring of NB staged chunks (ARGOS: 2 400 samples, 60 symbols per
+// chunk, 70 % of them squelched).  Wavefront 0 walks; wavefront 1 + s stages every NB-th chunk that needs a walk
+// (k_chunk_need) into buffer s, several chunks ahead of the walker, so that the memory latency of a chunk (the whole cost of
+// the two-buffer kernel above: 6.7 us per chunk) is hidden behind NB walks; chunks that need no walk are never read.
+// Hand-over through two counters per buffer in LDS (uses staged / uses consumed), release / acquire at workgroup scope.
+template <typename T, int LEN, int NB, int OUT>
+__device__ __forceinline__ void k_gardner_ring(const T *__restrict__ in, const T *__restrict__ lock, GardnerParams<T> P,
+                                               const unsigned char *__restrict__ need, T *__restrict__ sym,
+                                               long long *__restrict__ symidx, unsigned long long *__restrict__ nsym_out,
+                                               long long sym_cap, CalmEntry<T> *__restrict__ calm)
+{
+    __shared__ __align__(16) T win[NB][LEN];
+    __shared__ T o_val[OUT];
+    __shared__ unsigned o_idx[OUT];
+    __shared__ int s_ready[NB], s_done[NB], s_bad[NB];      // s_bad: the staged chunk holds a NaN or an infinity
+    constexpr int VN = 16 / (int)sizeof(T);
+    const int tid = threadIdx.x;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int lane = tid & 63;
+    const long long C = P.chunk_out;
+    const long long n_chunks = (P.n_total + C - 1) / C;
+    const int tail = 2 * (int)P.step + 24;               // furthest look-ahead of the mid-point
+    if (tid < NB) { s_ready[tid] = 0; s_done[tid] = 0; }
+    __syncthreads();
+    if (wave > NB) return;
+
+    if (wave != 0) {
+        // ---- stager of buffer s
+        const int s = wave - 1;
+        T *buf = win[s];
+        int j = 0;                                       // chunks in need of a walk seen so far
+        for (long long c0 = 0; c0 < n_chunks; c0 += 64) {
+            unsigned long long m = __ballot(c0 + lane < n_chunks && need[c0 + lane] != 0);
+            while (m) {
+                const int b = __builtin_ctzll(m);
+                m &= m - 1;
+                const int mine = (j % NB) == s;
+                const int use = j / NB;
+                j++;
+                if (!mine) continue;
+                while (__hip_atomic_load(&s_done[s], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) != use) __builtin_amdgcn_s_sleep(4);
+                const long long c = c0 + b;
+                const long long base = c * C;
+                const int n_cur = (int)((P.n_total - base < C) ? (P.n_total - base) : C);
+                int bad = 0;
+                auto put = [&](T *dst, T v) {
+                    bad |= is_finite_bits(v) ? 0 : 1;
+                    *dst = v;
+                };
+                if ((C % VN) == 0) {
+                    const int nv = n_cur / VN;                                     // whole 16-byte vectors, all in flight together
+                    const Vec16<T> *src = reinterpret_cast<const Vec16<T> *>(in + base);
+                    Vec16<T> *dst = reinterpret_cast<Vec16<T> *>(buf);
+                    int t = lane;
+                    for (; t + 9 * 64 < nv; t += 10 * 64) {
+                        Vec16<T> r[10];
+#pragma unroll
+                        for (int u = 0; u < 10; u++) r[u] = src[t + u * 64];
+#pragma unroll
+                        for (int u = 0; u < 10; u++) {
+#pragma unroll
+                            for (int e = 0; e < VN; e++) bad |= is_finite_bits(r[u].v[e]) ? 0 : 1;
+                            dst[t + u * 64] = r[u];
+                        }
+                    }
+                    for (; t < nv; t += 64) {
+                        const Vec16<T> r = src[t];
+#pragma unroll
+                        for (int e = 0; e < VN; e++) bad |= is_finite_bits(r.v[e]) ? 0 : 1;
+                        dst[t] = r;
+                    }
+                    for (int q = nv * VN + lane; q < n_cur; q += 64) put(buf + q, in[base + q]);
+                } else {
+                    for (int q = lane; q < n_cur; q += 64) put(buf + q, in[base + q]);
+                }
+                int n_tail = n_cur + tail;
+                if (n_tail > LEN) n_tail = LEN;
+                for (int q = n_cur + lane; q < n_tail; q += 64)
+                    put(buf + q, gardner_beyond(in, lock, P, c, (long long)n_cur, (long long)q));
+                if (lane == 0) s_bad[s] = 0;
+                if (bad) s_bad[s] = 1;
+                __hip_atomic_store(&s_ready[s], use + 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+            }
+        }
+        return;
+    }
+
+    // ---- the walker
+    __builtin_amdgcn_s_setprio(3);
+    const T hs = (T)((double)P.step / 2.0);
+    const T kp = P.kp, lim = P.lim, step = P.step;
+    const T adv = step + (T)0.101;
+    T ns = 0, prev = 0, half = 0;
+    long long count = 0;
+    int jn = 0;                                          // walked chunks so far
+    for (long long c0 = 0; c0 < n_chunks; c0 += 64) {
+        const unsigned long long mask = __ballot(c0 + lane < n_chunks && need[c0 + lane] != 0);
+        const int nb = (int)((n_chunks - c0 < 64) ? (n_chunks - c0) : 64);
+        for (int b = 0; b < nb; b++) {
+            const long long c = c0 + b;
+            const long long base = c * C;
+            const int n_cur = (int)((P.n_total - base < C) ? (P.n_total - base) : C);
+            const T nT = (T)n_cur;
+            int nout = 0;
+            if (!((mask >> b) & 1ull)) {
+                // only the additions of the reference step remain; every pick is +0.0.  The walker notes where the chunk
+                // starts (sampling instant, symbol count); k_calm_emit writes its symbols afterwards, all chunks in parallel
+                if (lane == 0) {
+                    CalmEntry<T> e;
+                    e.ns = ns;
+                    e.count = count;
+                    calm[c] = e;
+                }
+                for (;;) {
+                    const T rn = Real<T>::rint(ns);
+                    const int in_chunk = uniform<int>((int)(rn < nT));
+                    if (!in_chunk) break;
+                    nout++;
+                    T before = ns;
+                    ns = ns + step;
+                    // check-free batch: K more steps stay inside the chunk
+                    const T room = nT - (T)2 - ns;
+                    int K = (room > (T)0) ? (int)(room / adv) : 0;
+                    K = uniform<int>(K);
+                    if (K > 0) {
+                        int k = 0;
+                        for (; k + 8 < K; k += 8) {
+#pragma unroll
+                            for (int u = 0; u < 8; u++) ns = ns + step;
+                        }
+                        for (; k + 1 < K; k++) ns = ns + step;
+                        before = ns;
+                        ns = ns + step;
+                        nout += K;
+                    }
+                    half = before + hs;
+                }
+                prev = (nout > 0) ? (T)0 : prev;
+            } else {
+                const int s = jn % NB, use = jn / NB;
+                jn++;
+                while (__hip_atomic_load(&s_ready[s], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) != use + 1) __builtin_amdgcn_s_sleep(1);
+                const T *w = win[s];
+                const bool exact = s_bad[s] != 0 || n_cur >= (1 << 22) - 4096;
+                int n_staged = n_cur + tail;
+                if (n_staged > LEN) n_staged = LEN;
+                for (;;) {
+                    // ---- checked step
+                    const T rn = Real<T>::rint(ns);
+                    const int in_chunk = uniform<int>((int)(rn < nT));
+                    if (!in_chunk) break;
+                    if (nout >= OUT) break;                                      // cannot happen: OUT covers a whole chunk
+                    const unsigned i_abs = uniform<unsigned>((unsigned)rn);
+                    const unsigned h_abs = uniform<unsigned>((unsigned)Real<T>::rint(half));
+                    const T cur = w[i_abs];
+                    T mid;
+                    if (h_abs < (unsigned)n_staged) mid = w[h_abs];
+                    else mid = (h_abs < (unsigned)n_cur) ? in[base + h_abs] : gardner_beyond(in, lock, P, c, (long long)n_cur, (long long)h_abs);
+                    o_val[nout] = cur;
+                    o_idx[nout] = i_abs;
+                    nout++;
+                    {
+                        T err = kp * (cur - prev) * mid;
+                        err = (err > lim) ? lim : ((err < -lim) ? -lim : err);
+                        ns = ns - err;
+                        half = ns + hs;
+                        ns = ns + step;
+                        prev = cur;
+                    }
+                    // ---- check-free batch
+                    const T room = (T)n_cur - (T)2 - ns;
+                    int K = (room > (T)0) ? (int)(room / adv) : 0;
+                    K = uniform<int>(K);
+                    if (K > OUT - nout) K = OUT - nout;
+                    T *ov = o_val + nout;
+                    unsigned *oi = o_idx + nout;
+                    int k = 0;
+                    if (!exact) {
+                        // A lone wavefront pays the full latency of every dependent instruction (16 clocks for a double-precision
+                        // add or multiply, ~50 for the LDS read; 190 per symbol): the loop is written for the length of the
+                        // dependent chain.  The rounded index comes out of the mantissa (rint_index: one add instead of round +
+                        // convert); the clip is max / min (the value the reference's two-sided select gives for every non-NaN
+                        // error; the stager has looked at every value of this buffer); four symbols per trip with immediate
+                        // store offsets.  Tried and slower: both samples of step k + 1 fetched by the 64 lanes during step k and
+                        // picked with v_readlane (readfirstlane / readlane and their wait states cost more than the LDS latency
+                        // they replace: 102 vs 80 ns per symbol); the clip folded into the update as a select between
+                        // nextSample - e, nextSample - lim, nextSample + lim (two f64 compares: 96 ns).
+                        auto one = [&](int kk) {
+                            const int ic = rint_index(ns), ih = rint_index(half);
+                            const T c_k = w[ic], m_k = w[ih];
+                            ov[kk] = c_k;
+                            oi[kk] = (unsigned)ic;
+                            const T err = clip_finite(kp * (c_k - prev) * m_k, lim);
+                            ns = ns - err;
+                            half = ns + hs;
+                            ns = ns + step;
+                            prev = c_k;
+                        };
+                        for (; k + 4 <= K; k += 4) {
+                            one(k);
+                            one(k + 1);
+                            one(k + 2);
+                            one(k + 3);
+                        }
+                    }
+                    for (; k < K; k++) {
+                        const T rnk = Real<T>::rint(ns);
+                        const T rhk = Real<T>::rint(half);
+                        const T c_k = w[(int)rnk];
+                        const T m_k = w[(int)rhk];
+                        ov[k] = c_k;
+                        oi[k] = (unsigned)rnk;
+                        T err = kp * (c_k - prev) * m_k;
+                        err = (err > lim) ? lim : ((err < -lim) ? -lim : err);
+                        ns = ns - err;
+                        half = ns + hs;
+                        ns = ns + step;
+                        prev = c_k;
+                    }
+                    nout += K;
+                }
+                __hip_atomic_store(&s_done[s], use + 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+                for (int t = lane; t < nout; t += 64) {
+                    const long long k = count + t;
+                    if (k < sym_cap) {
+                        sym[k] = o_val[t];
+                        symidx[k] = base + (long long)o_idx[t];
+                    }
+                }
+            }
+            count += nout;
+            ns = ns - nT;                              // roll over; `half` is deliberately not (Q3)
+        }
+    }
+    if (lane == 0) *nsym_out = (unsigned long long)count;
+}
+
 // ------------------------------------------------------------------------------------------
 // Mueller & Muller clock recovery (reference: common/MMClockRecovery.c:5-83), the alternative sampler
 // the reference keeps at the same call site behind a comment (ARGOSdemod/main.c:277).  State
@@ -609,13 +918,6 @@ __device__ __forceinline__ unsigned gardner_encode_exit(const GardnerDomain &D, 
     return ok ? (((unsigned)(2 * m + v)) | (count << D.idx_bits)) : PDT_GTAB_MISS;
 }
 
-
-// rint(x) as an integer for 0 <= x < 2^22: adding 1.5*2^23 makes the FPU round x to an integer
-// (nearest-even, exactly like rintf) and leaves it in the low mantissa bits
-__device__ __forceinline__ int rint_index(float x)
-{
-    return __float_as_int(x + 12582912.0f) - 0x4B400000;
-}
 
 // one candidate trajectory carried by a lane
 struct GardnerLane {

@@ -194,11 +194,6 @@ __device__ __forceinline__ void k_pll_acquire(IqSrc pcm, long long n, PllParams<
 // The float operations and their order are exactly those of one loop iteration of the
 // reference; only the order in which *independent* iterations' pieces run is changed.
 
-template <typename T> struct alignas(16) Vec16 {
-    static constexpr int N = 16 / sizeof(T);
-    T v[N];
-};
-
 // Lane-tiled ("LT") layout of the theta and phase streams.  The (phase, freq) recurrence is walked one lane per block of B
 // samples, 64 consecutive blocks per wavefront, all lanes at the same offset inside their blocks.  In natural order a
 // wavefront's 16-byte loads then touch 64 different cache lines -- 64 clocks of the CU's texture-address path per load, which
@@ -1330,7 +1325,8 @@ __device__ __forceinline__ void k_pll_mix(IqSrc pcm, const T *__restrict__ phi_l
 template <typename T> struct EmaSeam { T v0, v1; };
 
 // the EMA over [i0, i1) with the software-pipelined 16-byte loads of the other stream walkers
-template <typename T, bool STORE>
+// (32 vectors of look-ahead: one lane alone waits ~0.6 us for a load and spends 13 ns on a double-precision step)
+template <typename T, bool STORE, int PF = 32>
 __device__ __forceinline__ void ema_range(const T *__restrict__ term, T *__restrict__ out, long long i0, long long i1, T &L, double k)
 {
     constexpr int VN = Vec16<T>::N;
@@ -1339,13 +1335,13 @@ __device__ __forceinline__ void ema_range(const T *__restrict__ term, T *__restr
         L = (T)((double)L * k + (double)term[i]);
         if (STORE) out[i] = L;
     }
-    if (i + PDT_PF * VN <= i1) {
-        Vec16<T> buf[PDT_PF];
+    if (i + PF * VN <= i1) {
+        Vec16<T> buf[PF];
 #pragma unroll
-        for (int u = 0; u < PDT_PF; u++) buf[u] = *reinterpret_cast<const Vec16<T> *>(term + i + u * VN);
-        for (; i + PDT_PF * VN <= i1; i += PDT_PF * VN) {
+        for (int u = 0; u < PF; u++) buf[u] = *reinterpret_cast<const Vec16<T> *>(term + i + u * VN);
+        for (; i + PF * VN <= i1; i += PF * VN) {
 #pragma unroll
-            for (int u = 0; u < PDT_PF; u++) {
+            for (int u = 0; u < PF; u++) {
                 Vec16<T> yv;
 #pragma unroll
                 for (int w = 0; w < VN; w++) {
@@ -1353,7 +1349,7 @@ __device__ __forceinline__ void ema_range(const T *__restrict__ term, T *__restr
                     yv.v[w] = L;
                 }
                 if (STORE) *reinterpret_cast<Vec16<T> *>(out + i + u * VN) = yv;
-                long long q = i + (PDT_PF + u) * VN;      // reload after the last use (see pll_phase_range)
+                long long q = i + (PF + u) * VN;      // reload after the last use (see pll_phase_range)
                 asm volatile("" : "+v"(q));
                 buf[u] = *reinterpret_cast<const Vec16<T> *>(term + q);
             }
@@ -1365,10 +1361,12 @@ __device__ __forceinline__ void ema_range(const T *__restrict__ term, T *__restr
     }
 }
 
+// Response of every block to a zero start state: with it the state at every block boundary follows from the state at the lock
+// by composing affine maps (k_lock_ema_guess) -- not bit for bit (the true recurrence rounds at every sample), but to a few
+// tens of ulps, so that a walker started from it agrees with the truth after 8 time constants instead of 45.
 template <typename T>
-__device__ __forceinline__ void k_lock_ema(const T *__restrict__ term, long long n, T lock_alpha,
-                                                  const PllLockInfo<T> *__restrict__ info, long long B, long long W,
-                                                  T *__restrict__ lock_out, EmaSeam<T> *__restrict__ seams)
+__device__ __forceinline__ void k_lock_ema_zero(const T *__restrict__ term, long long n, T lock_alpha,
+                                                const PllLockInfo<T> *__restrict__ info, long long B, double *__restrict__ zresp)
 {
     const long long lock_at = info->lock_sample;
     if (lock_at < 0) return;
@@ -1378,16 +1376,88 @@ __device__ __forceinline__ void k_lock_ema(const T *__restrict__ term, long long
     if (start >= n) return;
     if (start < S) start = S;
     const long long end = ((j + 1) * B < n) ? (j + 1) * B : n;
+    T L = 0;
+    ema_range<T, false>(term, (T *)nullptr, start, end, L, 1.0 - (double)lock_alpha);
+    zresp[j - S / B] = (double)L;
+}
+
+// guess[r] = approximate state in front of block r (r counted from the block that holds the lock): guess[r + 1] =
+// k^len(r) guess[r] + zresp[r].  One workgroup: every thread composes the maps of a run of blocks, a scan over the threads'
+// composites gives each run its start value, the thread walks its run again.
+template <typename T>
+__device__ __forceinline__ void k_lock_ema_guess(const double *__restrict__ zresp, long long n, T lock_alpha,
+                                                 const PllLockInfo<T> *__restrict__ info, long long B, double kB,
+                                                 double *__restrict__ guess)
+{
+    __shared__ double s_a[1024], s_b[1024];
+    const long long lock_at = info->lock_sample;
+    if (lock_at < 0) return;
+    const long long S = lock_at + 1;
+    const long long j0 = S / B;
+    const long long nb = (S < n) ? ((n - 1) / B - j0 + 1) : 0;
+    const double k = 1.0 - (double)lock_alpha;
+    const double k0 = pow(k, (double)((j0 + 1) * B - S));             // block 0 starts at the lock, not at a block boundary
+    const int t = threadIdx.x, NT = blockDim.x;
+    const long long per = (nb + NT - 1) / NT;
+    const long long r0 = (long long)t * per, r1 = (r0 + per < nb) ? r0 + per : nb;
+    double A = 1.0, Bv = 0.0;
+    for (long long r = r0; r < r1; r++) {
+        const double a = (r == 0) ? k0 : kB;
+        A = a * A;
+        Bv = a * Bv + zresp[r];
+    }
+    s_a[t] = A;
+    s_b[t] = Bv;
+    __syncthreads();
+    for (int d = 1; d < NT; d <<= 1) {                                  // inclusive scan of affine maps, later o earlier
+        double pa = 1.0, pb = 0.0;
+        if (t >= d) { pa = s_a[t - d]; pb = s_b[t - d]; }
+        __syncthreads();
+        if (t >= d) {
+            s_b[t] = s_a[t] * pb + s_b[t];
+            s_a[t] = s_a[t] * pa;
+        }
+        __syncthreads();
+    }
+    const double L0 = (double)info->st.locksig;
+    double g = (t == 0) ? L0 : s_a[t - 1] * L0 + s_b[t - 1];
+    for (long long r = r0; r < r1; r++) {
+        guess[r] = g;
+        g = ((r == 0) ? k0 : kB) * g + zresp[r];
+    }
+}
+
+template <typename T>
+__device__ __forceinline__ void k_lock_ema(const T *__restrict__ term, long long n, T lock_alpha,
+                                                  const PllLockInfo<T> *__restrict__ info, long long B, long long W,
+                                                  T *__restrict__ lock_out, EmaSeam<T> *__restrict__ seams,
+                                                  const double *__restrict__ guess)
+{
+    const long long lock_at = info->lock_sample;
+    if (lock_at < 0) return;
+    const long long S = lock_at + 1;
+    const long long j0 = S / B;
+    const long long j = j0 + (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    long long start = j * B;
+    if (start >= n) return;
+    if (start < S) start = S;
+    const long long end = ((j + 1) * B < n) ? (j + 1) * B : n;
     long long ws = start - W;
     T L = info->st.locksig;
     if (ws < S) ws = S;
+    else if (guess) {                                  // W is a whole number of blocks: start the warm-up from the guess there
+        const long long jw = ws / B;
+        L = (T)guess[jw - j0];
+        ws = jw * B;
+        if (ws < S) { ws = S; L = info->st.locksig; }
+    }
     const double k = 1.0 - (double)lock_alpha;
     ema_range<T, false>(term, lock_out, ws, start, L, k);
     EmaSeam<T> sm;
     sm.v0 = L;
     ema_range<T, true>(term, lock_out, start, end, L, k);
     sm.v1 = L;
-    seams[j - S / B] = sm;
+    seams[j - j0] = sm;
 }
 
 template <typename T>
