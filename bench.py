@@ -183,6 +183,7 @@ def main():
                     help="workload (default: c2 = BASELINE configs[1] on one GPU, c3 = the per-GPU capture of configs[4] on several)")
     ap.add_argument("--seconds", type=float, default=None, help="capture length override (parity / smoke runs)")
     ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline, e2e and CLI legs")
+    ap.add_argument("--e2e-only", action="store_true", help="developer runs: keep the in-process e2e leg, skip the CLI and CPU legs")
     ap.add_argument("--captures", type=int, default=1,
                     help="captures demodulated together per GPU and step through pdt_demod_batch_device (default 1 = the "
                          "BASELINE workload; >1 is the batched many-capture mode, reported as such)")
@@ -363,6 +364,9 @@ def main():
                               "text_identical_to_resident_run": bool(e2e_text == gpu_text)}
                 # ---- the C host program itself
                 exe = os.path.join(ROOT, "bin", "demodARGOS" if kind else "demodPOES")
+                if args.e2e_only:
+                    print(json.dumps(out), flush=True)
+                    return
                 if os.path.exists(exe):
                     cli_out = os.path.join(tmp, "cli_out.txt")
                     t1 = time.perf_counter()
