@@ -236,7 +236,7 @@ struct Plan {
 struct Tuning {
     double pll_warm_scale = 1.0, head_taus = 0.0, agc_k = 0.0, pll_warm_s = 0.0, agc_warm_s = 0.0;
     int ingest_threads = 0, ingest_span_mb = 0, agc_tpb = 0, gseg = 0, acquire_mode = 0, pll_block = 0, fix_passes = 2;      // acquire_mode: 0 = two-wavefront pipeline, 1 = plain one-lane, 2 = one wavefront
-    bool fir_generic = false, agc_unfused = false, no_excl = false, gtab_nomerge = false, gardner_onebuf = false, gardner_noring = false, ema_noguess = false, debug_sync = false;
+    bool fir_generic = false, agc_unfused = false, no_excl = false, gtab_nomerge = false, gardner_onebuf = false, gardner_noring = false, gardner_sequential = false, ema_noguess = false, debug_sync = false;
     void load()
     {
         if (const char *e = getenv("PDT_PLL_WARM_SCALE")) pll_warm_scale = atof(e);
@@ -259,6 +259,7 @@ struct Tuning {
         gardner_onebuf = getenv("PDT_GARDNER_ONEBUF") != nullptr;
         gardner_noring = getenv("PDT_GARDNER_NORING") != nullptr;
         ema_noguess = getenv("PDT_EMA_NOGUESS") != nullptr;
+        gardner_sequential = getenv("PDT_GARDNER_SEQUENTIAL") != nullptr;
         debug_sync = getenv("PDT_DEBUG_SYNC") != nullptr;
     }
 };
@@ -314,7 +315,6 @@ struct pdt_ctx {
     bool keep_agc_raw = false;   // pdt_keep_presquelch: also keep the AGC output before Squelch (stage PDT_ST_AGC_RAW)
     // (stream_in is declared with the streaming state below)
     long long gcand_key = -1;          // (chunk_out, step) the candidate list on the device was built for
-    bool force_sequential_gardner = false;
     int gardner_mode = 0;              // 0 sequential, 1 state table (last run)
     const void *pcm_dev = nullptr;     // input actually used (own copy or caller's buffer)
     int pcm_fmt = 0;                   // 0 = int16 pairs, 1 = float32 pairs
@@ -1114,7 +1114,7 @@ template <typename T> int run_capture(pdt_ctx *ctx, uint64_t n, int phase = RUN_
     if constexpr (std::is_same<T, float>::value) {
         const int table_len = 1 << 22;     // the table kernel walks the chunk in LDS windows: no size limit of its own
         const float nT = (float)chunk_out, stepf = (float)GP.step;
-        if (!argos && !use_mm && !ctx->force_sequential_gardner && !seg && n_chunks >= 4 && chunk_out >= 256 &&
+        if (!argos && !use_mm && !ctx->tune.gardner_sequential && !seg && n_chunks >= 4 && chunk_out >= 256 &&
             chunk_out + 2 * (long long)stepf + 24 <= table_len && 8 * (long long)stepf + 256 < PDT_GTAB_WIN && chunk_out < (1 << 22)) {
             int e;
             (void)frexpf(nT - stepf - 1.0f, &e);                              // value in [2^(e-1), 2^e)

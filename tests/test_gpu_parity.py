@@ -281,7 +281,8 @@ def test_ten_minute_capture_matches_oracle(pdt, orc):
 
 
 @pytest.mark.parametrize("switch", ["PDT_ACQUIRE_SIMPLE", "PDT_ACQUIRE_ONEWAVE", "PDT_GTAB_NOMERGE", "PDT_FIR_GENERIC",
-                                    "PDT_AGC_UNFUSED", "PDT_GARDNER_ONEBUF"])
+                                    "PDT_AGC_UNFUSED", "PDT_GARDNER_ONEBUF", "PDT_GARDNER_NORING", "PDT_EMA_NOGUESS",
+                                    "PDT_GARDNER_SEQUENTIAL"])
 def test_alternative_kernels_agree(pdt, orc, clip, switch):
     """The older / generic kernel variants kept behind environment switches (tools/README.md) -- some of them are the
     fallbacks other geometries take -- give the same bits as the default path."""
@@ -299,6 +300,29 @@ def test_alternative_kernels_agree(pdt, orc, clip, switch):
             check_all_stages(pdt, orc, d, oa)
     finally:
         del os.environ[switch]
+
+
+@pytest.mark.parametrize("chunk", [601, 2399, 2400, 1200])
+def test_ring_sampler_chunk_shapes(pdt, orc, chunk):
+    """The ring sampler (k_gardner_ring: staged chunks several ahead of the walker, squelched chunks never read): odd chunk
+    sizes (no 16-byte staging), a capture of zeros only (no chunk is walked), a capture whose squelch never closes for long,
+    and the float build on a POES capture (PDT_GARDNER_SEQUENTIAL keeps it off the boundary-state tables)."""
+    a = pdt.synth_capture(1, 32000, 21.0, f0_hz=-140.0, seed=77)
+    for iq in (a, np.zeros_like(a[: 32000 * 4]), np.ascontiguousarray(np.tile(a[int(2.0 * 32000):int(2.9 * 32000)], (12, 1)))):
+        o = orc.Oracle(orc.ARGOS, 32000, iq, chunk=chunk, math_mode=orc.MATH_LIBM)
+        with pdt.Demodulator(pdt.MODE_ARGOS, 32000, chunk=chunk) as d:
+            d.demod(iq)
+            check_all_stages(pdt, orc, d, o)
+    p = pdt.synth_capture(0, 50000, 3.0, seed=78)
+    o = orc.Oracle(orc.POES, 50000, p, chunk=chunk)
+    os.environ["PDT_GARDNER_SEQUENTIAL"] = "1"
+    try:
+        with pdt.Demodulator(pdt.MODE_POES, 50000, chunk=chunk) as d:
+            d.demod(p)
+            check_all_stages(pdt, orc, d, o)
+            assert d.stats().frames > 20
+    finally:
+        del os.environ["PDT_GARDNER_SEQUENTIAL"]
 
 
 @pytest.mark.parametrize("mult", [5, 10])
