@@ -235,7 +235,7 @@ struct Plan {
 // context is opened; the demodulation calls never look at the environment.
 struct Tuning {
     double pll_warm_scale = 1.0, head_taus = 0.0, agc_k = 0.0, pll_warm_s = 0.0, agc_warm_s = 0.0;
-    int ingest_threads = 0, ingest_span_mb = 0, agc_tpb = 0, gseg = 0, acquire_mode = 0, pll_block = 0, fix_passes = 2;      // acquire_mode: 0 = two-wavefront pipeline, 1 = plain one-lane, 2 = one wavefront
+    int ingest_threads = 0, ingest_span_mb = 0, fir_wg_per_cu = 0, agc_tpb = 0, gseg = 0, acquire_mode = 0, pll_block = 0, fix_passes = 2;      // acquire_mode: 0 = two-wavefront pipeline, 1 = plain one-lane, 2 = one wavefront
     bool fir_generic = false, agc_unfused = false, no_excl = false, gtab_nomerge = false, gardner_onebuf = false, gardner_noring = false, gardner_sequential = false, ema_noguess = false, debug_sync = false;
     void load()
     {
@@ -246,6 +246,7 @@ struct Tuning {
         if (const char *e = getenv("PDT_AGC_K")) agc_k = atof(e);
         if (const char *e = getenv("PDT_AGC_TPB")) agc_tpb = std::max(1, atoi(e));
         if (const char *e = getenv("PDT_PLL_BLOCK")) pll_block = atoi(e);
+        if (const char *e = getenv("PDT_FIR_WG_PER_CU")) fir_wg_per_cu = std::min(4096, std::max(1, atoi(e)));
         if (const char *e = getenv("PDT_INGEST_THREADS")) ingest_threads = std::min(128, std::max(1, atoi(e)));
         if (const char *e = getenv("PDT_INGEST_SPAN_MB")) ingest_span_mb = std::min(256, std::max(1, atoi(e)));
         if (const char *e = getenv("PDT_FIX_PASSES")) fix_passes = atoi(e);
@@ -1041,11 +1042,14 @@ template <typename T> int run_capture(pdt_ctx *ctx, uint64_t n, int phase = RUN_
             // the AGC's affine tile maps are folded into this kernel when the AGC blocks are whole FIR tiles
             AgcMap *fir_tile_maps = nullptr;
             if (agc_tiles_per_block > 0) {
-                if ((rc = ctx->agc_maps.ensure((size_t)(tiles_rt + 1) * sizeof(AgcMap) + (size_t)(nb_agc + 1) * sizeof(double)))) return rc;
+                if ((rc = ctx->agc_maps.ensure((size_t)(tiles_rt + 1) * sizeof(AgcMap) + (size_t)(nb_agc + 2) * (sizeof(double) + sizeof(AgcMap))))) return rc;
                 fir_tile_maps = (AgcMap *)ctx->agc_maps.p;
                 fused_tiles = tiles_rt;
             }
-            const unsigned grid_rt = (unsigned)std::min<long long>(tiles_rt, 256ll * 6);   // persistent workgroups, 6 per CU
+            // workgroups take tiles round robin; 32 per CU measured best (c3: 3.9 / 3.7 / 3.2 / 3.1 / 3.1 ms at 4 / 8 / 16 / 32 / 64):
+            // the taps come by scalar loads per residue, nothing is kept across tiles, and a finer grain balances the tail
+            const long long fir_tpb = ctx->tune.fir_wg_per_cu > 0 ? ctx->tune.fir_wg_per_cu : 32;
+            const unsigned grid_rt = (unsigned)std::min<long long>(tiles_rt, 256ll * fir_tpb);
             bool done = false;
             if (K == 26 && sh_rt <= 64000 && ctx->taps_rot.p && !ctx->tune.fir_generic) {
                 done = true;
@@ -1092,6 +1096,12 @@ template <typename T> int run_capture(pdt_ctx *ctx, uint64_t n, int phase = RUN_
         if (ctx->tune.agc_k > 0) agc_K = ctx->tune.agc_k;
         L.begin("agc_block");
         if (!fused) PDT_LAUNCH(256, k_agc_affine<T>, dim3((unsigned)nb), dim3(256), 0, st, a_in, na, APs.decay, Ba, d_maps);
+        if (fused && agc_tiles_per_block > 1) {
+            AgcMap *d_bmaps = (AgcMap *)(d_guess + nb + 1);
+            PDT_LAUNCH(256, k_agc_blockmaps, dim3((unsigned)((nb + 255) / 256)), dim3(256), 0, st, (const AgcMap *)d_maps, nb,
+                               (int)agc_tiles_per_block, fused_tiles, d_bmaps);
+            PDT_LAUNCH(1024, k_agc_guess<T>, dim3(1), dim3(1024), 0, st, (const AgcMap *)d_bmaps, nb, (const T *)d_norm, d_guess, 1, nb);
+        } else
         PDT_LAUNCH(1024, k_agc_guess<T>, dim3(1), dim3(1024), 0, st, (const AgcMap *)d_maps, nb, (const T *)d_norm, d_guess,
                            fused ? (int)agc_tiles_per_block : 1, fused ? fused_tiles : nb);
         PDT_LAUNCH(64, k_agc_block<T>, dim3((unsigned)grid), dim3(64), 0, st, a_in, na, APs, d_norm, Ba, Wa,
@@ -1197,7 +1207,7 @@ template <typename T> int run_capture(pdt_ctx *ctx, uint64_t n, int phase = RUN_
             if ((rc = ctx->gbands.ensure((size_t)n_tab * sizeof(GardnerBand)))) return rc;
             L.begin("gardner_table");
             if ((rc = ctx->gclist.ensure((size_t)n_tab * PDT_GTAB_LIST * sizeof(unsigned)))) return rc;
-            PL.memset_async(ctx->gtable.p, 0xff, (size_t)n_tab * (size_t)(2 * GD.n_q) * sizeof(unsigned));   // PDT_GTAB_MISS
+            // (the table is never initialised as a whole -- 12 GB for an hour at 250 ksps: every look-up checks the chunk's band)
             PDT_LAUNCH(64, k_gardner_scout, dim3((unsigned)n_tab), dim3(64), 0, st, (const float *)d_agc, GP, GD, n_tab,
                                (const int *)ctx->gmfirst.p, (const unsigned *)ctx->gcand.p, (unsigned *)ctx->gtable.p,
                                (GardnerBand *)ctx->gbands.p, (unsigned *)ctx->gclist.p, d_sc->gstats);
@@ -1229,7 +1239,7 @@ template <typename T> int run_capture(pdt_ctx *ctx, uint64_t n, int phase = RUN_
             L.begin("gardner_chain");
             PL.memset_async(ctx->gsegstart.p, 0, (size_t)n_seg * sizeof(GardnerSegStart));
             PDT_LAUNCH(1024, k_gardner_segmap, dim3((unsigned)n_seg), dim3(1024), 0, st, (const unsigned *)ctx->gtable.p, GD, n_chunks,
-                               G, (GardnerSegCell *)ctx->gsegmap.p);
+                               G, (GardnerSegCell *)ctx->gsegmap.p, (const GardnerBand *)ctx->gbands.p);
             PDT_LAUNCH(256, k_gardner_chain, dim3(1), dim3(256), 0, st,      // 4 wavefronts: a walked chunk is staged 4x faster
                                (const float *)d_agc, GP, GD, n_chunks,
                                (const unsigned *)ctx->gtable.p, (const GardnerSegCell *)ctx->gsegmap.p, G,

@@ -964,7 +964,12 @@ __device__ __forceinline__ void gardner_lane_tail(GardnerLane &L, const float *w
 // candidate list is the union of the neighbourhoods [m - pad, m + pad] of the scouts' end points m;
 // when the scouts end more than 1.5 samples apart (no timing lock) the full domain is tabulated.
 // (The table itself is preset to "not tabulated" by a memset before this kernel.)
-struct GardnerBand { int j_lo, j_hi, listed; };   // candidates [j_lo, j_hi) of cand_k, or of the chunk's own list
+// candidates [j_lo, j_hi) of cand_k, or of the chunk's own list; [k_lo, k_hi] = the keys a look-up in this chunk's table row
+// may ask for: the row is not initialised outside it (nor at keys inside it that are no candidates: those are unreachable)
+struct GardnerBand { int j_lo, j_hi, listed; unsigned k_lo, k_hi; };
+// table cell of chunk c for entry key `key`, PDT_GTAB_MISS outside the chunk's band
+__device__ __forceinline__ unsigned gardner_cell(const unsigned *__restrict__ table, size_t stride, const GardnerBand &b,
+                                                 long long c, unsigned key);
 #define PDT_GTAB_LIST 2048                        // capacity of a chunk's candidate list
 
 __device__ __forceinline__ void k_gardner_scout(const float *__restrict__ in, GardnerParams<float> P, GardnerDomain D,
@@ -986,6 +991,8 @@ __device__ __forceinline__ void k_gardner_scout(const float *__restrict__ in, Ga
     bd.j_lo = 0;
     bd.j_hi = (c == 0) ? 1 : D.n_cand;
     bd.listed = 0;
+    bd.k_lo = (c == 0) ? 0u : cand_k[0];                    // chunk 0: the single start state is cell 0 of its row
+    bd.k_hi = (c == 0) ? 0u : cand_k[bd.j_hi - 1];
     if (c >= 1) {
         const float hs = (float)((double)P.step / 2.0);
         const float kp = P.kp, lim = P.lim, step = P.step, nT = (float)n_cur;
@@ -1065,6 +1072,14 @@ __device__ __forceinline__ void k_gardner_scout(const float *__restrict__ in, Ga
             bd.j_lo = 0;
             bd.j_hi = total;
             bd.listed = 1;
+            // the listed keys lie in [k_lo, k_hi]; the table kernel writes the listed ones, every other key of that range
+            // must read as a miss: clear the range (a few thousand cells; the whole table is never initialised)
+            int last = 0;
+            for (int j = 0; j < 64; j++) last = (s_hi[j] > 0) ? j : last;
+            bd.k_lo = cand_k[s_lo[0]];
+            bd.k_hi = cand_k[s_lo[last] + s_hi[last] - 1];
+            unsigned *row = table + (size_t)c * (size_t)(2 * D.n_q);
+            for (unsigned k = bd.k_lo + (unsigned)lane; k <= bd.k_hi; k += 64u) row[k] = PDT_GTAB_MISS;
         }
     }
     // (no global counters here: 3 000 atomics on one address drained for 0.1 ms after the last wavefront had finished;
@@ -1486,6 +1501,13 @@ __device__ __forceinline__ void k_gardner_table_merge(const float *__restrict__ 
     }
 }
 
+__device__ __forceinline__ unsigned gardner_cell(const unsigned *__restrict__ table, size_t stride, const GardnerBand &b,
+                                                 long long c, unsigned key)
+{
+    const unsigned cell = table[(size_t)c * stride + key];          // valid address for every key < 2 n_q; content only inside the band
+    return (key >= b.k_lo && key <= b.k_hi) ? cell : PDT_GTAB_MISS;
+}
+
 // level 2: follow the chain  k_{c+1} = table_c[k_c]  (k_0 = 0).  A chain of n dependent HBM lookups
 // would cost ~0.5 us each, so it is cut into segments of G chunks:
 //   k_gardner_segmap   composes, for every tabulated entry state of a segment's first chunk, the G
@@ -1500,17 +1522,26 @@ struct GardnerSegCell { unsigned next, count; };
 struct GardnerSegStart { unsigned key; unsigned hopped; long long offset; };
 
 __device__ __forceinline__ void k_gardner_segmap(const unsigned *__restrict__ table, GardnerDomain D, long long n_chunks,
-                                                          int G, GardnerSegCell *__restrict__ segmap)
+                                                          int G, GardnerSegCell *__restrict__ segmap,
+                                                          const GardnerBand *__restrict__ bands)
 {
     const long long s = blockIdx.x;
     const long long c0 = s * G;
     if (c0 + G > n_chunks - 1) return;                  // only whole segments whose chunks all have a table row
     const size_t stride = (size_t)(2 * D.n_q);
-    for (int k0 = threadIdx.x; k0 < 2 * D.n_q; k0 += 1024) {
-        unsigned k = (unsigned)k0, total = 0;
+    __shared__ unsigned s_klo[64], s_khi[64];
+    if ((int)threadIdx.x < G) {
+        const GardnerBand b = bands[c0 + threadIdx.x];
+        s_klo[threadIdx.x] = b.k_lo;
+        s_khi[threadIdx.x] = b.k_hi;
+    }
+    __syncthreads();
+    // entry keys of the segment's first chunk: its band only (everything else is a miss before the first step)
+    for (unsigned k0 = s_klo[0] + threadIdx.x; k0 <= s_khi[0]; k0 += 1024u) {
+        unsigned k = k0, total = 0;
         bool ok = true;
         for (int g = 0; g < G; g++) {
-            const unsigned cell = table[(size_t)(c0 + g) * stride + k];
+            const unsigned cell = (k >= s_klo[g] && k <= s_khi[g]) ? table[(size_t)(c0 + g) * stride + k] : PDT_GTAB_MISS;
             if (cell == PDT_GTAB_MISS) { ok = false; break; }
             k = cell & ((1u << D.idx_bits) - 1u);
             total += cell >> D.idx_bits;
@@ -1558,8 +1589,10 @@ __device__ __forceinline__ void k_gardner_chain(const float *__restrict__ in, Ga
         // ---- hop over a whole segment
         if (have_key && (c % G) == 0 && c + G <= n_chunks - 1) {
             const long long s = c / G;
+            // (both loads issued together: the cell's address is valid whatever the key, its content only inside the band)
+            const GardnerBand b0 = bands[c];
             const GardnerSegCell sc = segmap[(size_t)s * stride + key];
-            const unsigned nxt = uniform<unsigned>(sc.next);
+            const unsigned nxt = uniform<unsigned>((key >= b0.k_lo && key <= b0.k_hi) ? sc.next : PDT_GTAB_MISS);
             if (nxt != PDT_GTAB_MISS) {
                 if (threadIdx.x == 0) {
                     GardnerSegStart ss;
@@ -1580,7 +1613,7 @@ __device__ __forceinline__ void k_gardner_chain(const float *__restrict__ in, Ga
             entries[c] = e;
         }
         if (c + 1 >= n_chunks) break;
-        unsigned cell = have_key ? table[(size_t)c * stride + key] : PDT_GTAB_MISS;
+        unsigned cell = have_key ? gardner_cell(table, stride, bands[c], c, key) : PDT_GTAB_MISS;
         cell = uniform<unsigned>(cell);
         if (cell == PDT_GTAB_MISS) {
             const long long cnt = gardner_walk_chunk<float, false, GardnerLds<float>::LEN, GardnerLds<float>::OUT>(
@@ -2155,12 +2188,37 @@ __device__ __forceinline__ void k_sync_frames_tiles(const SyncTile *__restrict__
     }
     __threadfence_block();
     __syncthreads();
-    const unsigned nh = (s_base < dense_cap) ? s_base : dense_cap;
-    if (nh <= PDT_SYNC_BATCH - 2) {                    // both link tables (nh + 1 u16 entries each) fit the staging array
-        // ---- (B) parallel: successor links, then pointer doubling from hit 0
+    const unsigned nh_all = (s_base < dense_cap) ? s_base : dense_cap;
+    // ---- (B), (C) in batches of hits that fit the LDS tables (one batch up to ~14 minutes of POES; an hour takes five): a
+    // batch is entered at its first hit at or after the end of the last frame accepted so far -- the one fact it needs
+    // from its predecessors -- and leaves the end of its own last frame behind.
+    __shared__ unsigned s_last, s_nf;
+    __shared__ long long s_next_free;
+    if (threadIdx.x == 0) { s_nf = 0; s_next_free = 0; }
+    __syncthreads();
+    constexpr unsigned BATCH = PDT_SYNC_BATCH - 2;       // both link tables (nh + 1 u16 entries each) fit the staging array
+    for (unsigned b0 = 0; b0 < nh_all; b0 += BATCH) {
+        const unsigned nh = (nh_all - b0 < BATCH) ? (nh_all - b0) : BATCH;
+        const unsigned *dn = dense + b0;
         constexpr int PER = PDT_SYNC_BATCH / PDT_SYNC_THREADS;       // 8 hits per thread
-        for (unsigned i = threadIdx.x; i < nh; i += PDT_SYNC_THREADS) s_hits[i] = dense[i] >> 1;
-        for (unsigned i = threadIdx.x; i < PDT_SYNC_BATCH / 32; i += PDT_SYNC_THREADS) s_mark[i] = (i == 0 && nh > 0) ? 1u : 0u;
+        __syncthreads();
+        for (unsigned i = threadIdx.x; i < nh; i += PDT_SYNC_THREADS) s_hits[i] = dn[i] >> 1;
+        for (unsigned i = threadIdx.x; i < PDT_SYNC_BATCH / 32; i += PDT_SYNC_THREADS) s_mark[i] = 0u;
+        if (threadIdx.x == 0) s_last = 0xffffffffu;
+        __syncthreads();
+        // entry: first hit of the batch that does not fall into the frame still open
+        const long long nfree = s_next_free;
+        unsigned entry;
+        {
+            unsigned lo = 0, hi = nh;
+            while (lo < hi) {
+                const unsigned mid = (lo + hi) >> 1;
+                if ((long long)s_hits[mid] >= nfree) hi = mid; else lo = mid + 1;
+            }
+            entry = lo;
+        }
+        if (entry >= nh) continue;                        // (uniform) the whole batch lies inside an open frame
+        if (threadIdx.x == 0) s_mark[entry >> 5] = 1u << (entry & 31);
         __syncthreads();
         unsigned succ[PER];
 #pragma unroll
@@ -2203,83 +2261,38 @@ __device__ __forceinline__ void k_sync_frames_tiles(const SyncTile *__restrict__
         }
         // ---- (C) ordered compaction of the marked hits (thread t owns hits [8t, 8t+8))
         const unsigned i0 = threadIdx.x * PER;
-        unsigned mine = 0;
+        unsigned mine = 0, my_last = 0xffffffffu;
 #pragma unroll
         for (int k = 0; k < PER; k++) {
             const unsigned i = i0 + k;
-            mine += (i < nh && ((s_mark[i >> 5] >> (i & 31)) & 1u)) ? 1u : 0u;
+            if (i < nh && ((s_mark[i >> 5] >> (i & 31)) & 1u)) { mine++; my_last = i; }
         }
         const unsigned incl = sync_block_scan(mine, s_scan);
-        unsigned at = incl - mine;
+        const unsigned fbase = s_nf;
+        unsigned at = fbase + incl - mine;
         for (int k = 0; k < PER; k++) {
             const unsigned i = i0 + k;
             if (i < nh && ((s_mark[i >> 5] >> (i & 31)) & 1u)) {
                 if (at < frame_cap) {
-                    const unsigned v = dense[i];
+                    const unsigned v = dn[i];
                     frames[at].bit_index = (long long)(v >> 1);
                     frames[at].inverted = (unsigned char)(v & 1u);
                 }
                 at++;
             }
         }
-        if (threadIdx.x == PDT_SYNC_THREADS - 1) *nframes = incl;
-        return;
-    }
-    // ---- (B'') more hits than the LDS version holds (captures longer than ~14 minutes): the same successor links /
-    // pointer doubling with the link tables and the mark bits in global memory.  One workgroup, so every hand-over is
-    // a fence + barrier; each thread owns a contiguous slice of hits, and since the successor index is monotone in the
-    // hit index the links of a slice are found with one binary search and a forward scan.
-    {
-        unsigned *J0 = gscr, *J1 = gscr + (size_t)dense_cap + 1, *mark = gscr + 2 * ((size_t)dense_cap + 1);
-        const unsigned per = (nh + PDT_SYNC_THREADS - 1) / PDT_SYNC_THREADS;
-        const unsigned a0 = threadIdx.x * per, a1 = (a0 + per < nh) ? a0 + per : nh;
-        for (unsigned w = threadIdx.x; w < nh / 32 + 1; w += PDT_SYNC_THREADS) mark[w] = (w == 0) ? 1u : 0u;
-        if (a0 < nh) {
-            const unsigned want0 = (dense[a0] >> 1) + P.span;
-            unsigned lo = a0 + 1, hi = nh;
-            while (lo < hi) {
-                const unsigned mid = (lo + hi) >> 1;
-                if ((dense[mid] >> 1) >= want0) hi = mid; else lo = mid + 1;
-            }
-            unsigned ptr = lo;
-            for (unsigned i = a0; i < a1; i++) {
-                const unsigned want = (dense[i] >> 1) + P.span;
-                if (ptr < i + 1) ptr = i + 1;
-                while (ptr < nh && (dense[ptr] >> 1) < want) ptr++;
-                J0[i] = ptr;
-            }
-        }
-        if (threadIdx.x == 0) J0[nh] = nh;
-        __threadfence();
+        // the thread that owns the last marked hit publishes where its frame ends
+        if (mine > 0 && incl == s_scan[PDT_SYNC_THREADS - 1]) s_last = my_last;      // (several threads may tie only with mine == 0)
         __syncthreads();
-        unsigned *Jc = J0, *Jn = J1;
-        for (unsigned reach = 1; reach < nh; reach <<= 1) {
-            for (unsigned i = a0; i < a1; i++) {
-                const unsigned jm = Jc[i];
-                if (jm < nh && ((mark[i >> 5] >> (i & 31)) & 1u)) atomicOr(&mark[jm >> 5], 1u << (jm & 31));
-                Jn[i] = Jc[jm];
-            }
-            if (threadIdx.x == 0) Jn[nh] = nh;
-            __threadfence();
-            __syncthreads();
-            unsigned *tmp = Jc; Jc = Jn; Jn = tmp;
+        if (threadIdx.x == 0) {
+            s_nf = fbase + s_scan[PDT_SYNC_THREADS - 1];
+            if (s_last != 0xffffffffu) s_next_free = (long long)(dn[s_last] >> 1) + (long long)P.span;
         }
-        unsigned mine = 0;
-        for (unsigned i = a0; i < a1; i++) mine += (mark[i >> 5] >> (i & 31)) & 1u;
-        const unsigned incl = sync_block_scan(mine, s_scan);
-        unsigned at = incl - mine;
-        for (unsigned i = a0; i < a1; i++) {
-            if ((mark[i >> 5] >> (i & 31)) & 1u) {
-                if (at < frame_cap) {
-                    const unsigned v = dense[i];
-                    frames[at].bit_index = (long long)(v >> 1);
-                    frames[at].inverted = (unsigned char)(v & 1u);
-                }
-                at++;
-            }
-        }
-        if (threadIdx.x == PDT_SYNC_THREADS - 1) *nframes = incl;
+        __syncthreads();
     }
+    __syncthreads();
+    if (threadIdx.x == 0) *nframes = s_nf;
+    (void)gscr;
 }
 
 __device__ __forceinline__ void k_frame_pack(const unsigned char *__restrict__ bits,

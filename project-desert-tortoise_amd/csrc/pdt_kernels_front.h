@@ -12,6 +12,8 @@
 // block is re-run from the true state.  By induction over blocks the output is
 // exactly the sequential result.
 #pragma once
+#include <type_traits>
+#include <utility>
 #include "pdt_device_math.h"
 
 namespace pdt {
@@ -1566,6 +1568,16 @@ __device__ __forceinline__ void k_fir_interp(const T *__restrict__ in, long long
     }
 }
 
+// f(integral_constant<c>) for c = W, W + STEP, ... < K
+template <int W, int STEP, int K, int I = 0, typename F>
+__device__ __forceinline__ void fir_residues(F &f)
+{
+    if constexpr (W + STEP * I < K) {
+        f(std::integral_constant<int, W + STEP * I>{});
+        fir_residues<W, STEP, K, I + 1>(f);
+    }
+}
+
 // Register-tiled interpolating form (K = taps per polyphase branch and INTERP known at compile time).
 // The accumulation ORDER of an output depends on M mod K (the ring rotates), so the work is laid
 // out by residue class: a workgroup owns 64*K consecutive inputs starting at a multiple of K, and a
@@ -1605,9 +1617,13 @@ __device__ __forceinline__ void k_fir_interp_rt(const T *__restrict__ in, long l
             s_in[q * LS + (t - q * K)] = (m >= 0 && m < n_in) ? in[m] : (T)0;
         }
         __syncthreads();
-        for (int c = wave; c < K; c += PDT_FIR_THREADS / 64) {
-            const T *w1 = s_in + (j + 1) * LS;                   // slot t <= c: input m0 + K*j + t
-            const T *w0 = s_in + j * LS;                         // slot t >  c: input m0 + K*(j-1) + t
+        // The residue is a compile-time constant of each copy of the body (26 copies; wavefront w takes residues w, w + 4, ...):
+        // which of the lane's two rows slot t is read from, the LDS offsets and the tap addresses are then all immediates.
+        // With a run-time residue every read cost a scalar compare + select and a vector add for its address: 110 vector
+        // and 69 scalar instructions per 64 outputs at INTERP 1 (PMC) against the 52 of the arithmetic.
+        const T *w0 = s_in + j * LS;                             // slot t >  c: input m0 + K*(j-1) + t; t <= c: one row further
+        auto residue = [&](auto cc) {
+            constexpr int c = decltype(cc)::value;
             // wave-uniform address, read-only table: constant address space, so that the loads are scalar loads into SGPRs
             // whatever the compiler can prove about the stores around them
             // (each residue's K * INTERP taps start on a 64-byte boundary: the loads can be as wide as the ISA has them)
@@ -1619,10 +1635,8 @@ __device__ __forceinline__ void k_fir_interp_rt(const T *__restrict__ in, long l
             for (int r = 0; r < INTERP; r++) y[r] = 0;
             T x[K];                                              // the lane's ring, all reads in flight together
 #pragma unroll
-            for (int t = 0; t < K; t++) x[t] = (t <= c) ? w1[t] : w0[t];
+            for (int t = 0; t < K; t++) x[t] = w0[(t <= c) ? LS + t : t];
             // ... and the residue's taps: one block copy from a wave-uniform address = a handful of wide scalar loads
-            // (fetched row by row the compiler issued two narrow loads and a wait per row: a third of the kernel's instructions)
-            // (with a single tap per row the compiler's own element loads were measured a little faster)
             T hv[K][INTERP];
 #pragma unroll
             for (int t = 0; t < K; t++)
@@ -1635,7 +1649,13 @@ __device__ __forceinline__ void k_fir_interp_rt(const T *__restrict__ in, long l
             }
 #pragma unroll
             for (int r = 0; r < INTERP; r++) s_out[(c + K * j) * INTERP + r] = y[r];
-        }
+        };
+        constexpr int NWV = PDT_FIR_THREADS / 64;
+        static_assert(NWV == 4, "the residue dispatch below is written for four wavefronts");
+        if (wave == 0) fir_residues<0, NWV, K>(residue);
+        else if (wave == 1) fir_residues<1, NWV, K>(residue);
+        else if (wave == 2) fir_residues<2, NWV, K>(residue);
+        else fir_residues<3, NWV, K>(residue);
         __syncthreads();
         const long long g0 = m0 * INTERP;                    // multiple of 4
         if (tile_maps) {
@@ -2031,6 +2051,26 @@ __device__ __forceinline__ void k_agc_affine(const T *__restrict__ in, long long
         m.B = runB;
         maps[j] = m;
     }
+}
+
+// map of AGC block j = its maps_per_block consecutive FIR-tile maps composed in order.  One thread per block (an hour at
+// 250 ksps has 540 000 tile maps: composed inside k_agc_guess's single workgroup they cost 1.6 ms of dependent loads).
+__device__ __forceinline__ void k_agc_blockmaps(const AgcMap *__restrict__ maps, long long nb, int maps_per_block, long long n_maps,
+                                                AgcMap *__restrict__ bmaps)
+{
+    const long long j = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= nb) return;
+    AgcMap bm;
+    bm.A = 1.0; bm.B = 0.0;
+    for (int q = 0; q < maps_per_block; q++) {
+        const long long t = j * maps_per_block + q;
+        if (t < n_maps) {
+            const AgcMap m = maps[t];
+            bm.B = m.A * bm.B + m.B;
+            bm.A = m.A * bm.A;
+        }
+    }
+    bmaps[j] = bm;
 }
 
 // gain at every block boundary = exclusive prefix composition of the block maps applied to the

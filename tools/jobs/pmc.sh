@@ -5,7 +5,7 @@ R=$PWD
 OUT=$R/gpurun_out/pmc_$1
 rm -rf $OUT; mkdir -p $OUT
 cd /tmp
-rocprofv3 --kernel-trace --pmc $2 --output-format csv -d $OUT -o p -- python $R/bench.py --steps 2 --warmup 1 --no-cpu > /dev/null 2>&1
+rocprofv3 --kernel-trace --pmc $2 --output-format csv -d $OUT -o p -- python $R/bench.py --config ${CFG:-c2} --steps 2 --warmup 1 --no-cpu > /dev/null 2>&1
 cd $R
 python - <<PY
 import csv, glob, collections
