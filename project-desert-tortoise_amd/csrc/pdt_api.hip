@@ -234,13 +234,14 @@ struct Plan {
 // Developer switches (A/B runs of older kernel variants, tuning sweeps).  Read from the environment ONCE, when the
 // context is opened; the demodulation calls never look at the environment.
 struct Tuning {
-    double pll_warm_scale = 1.0, head_taus = 0.0, agc_k = 0.0, pll_warm_s = 0.0, agc_warm_s = 0.0;
+    double band_pad = 0.0, pll_warm_scale = 1.0, head_taus = 0.0, agc_k = 0.0, pll_warm_s = 0.0, agc_warm_s = 0.0;
     int ingest_threads = 0, ingest_span_mb = 0, fir_wg_per_cu = 0, agc_tpb = 0, gseg = 0, acquire_mode = 0, pll_block = 0, fix_passes = 2;      // acquire_mode: 0 = two-wavefront pipeline, 1 = plain one-lane, 2 = one wavefront
     bool fir_generic = false, agc_unfused = false, no_excl = false, gtab_nomerge = false, gardner_onebuf = false, gardner_noring = false, gardner_sequential = false, ema_noguess = false, debug_sync = false;
     void load()
     {
         if (const char *e = getenv("PDT_PLL_WARM_SCALE")) pll_warm_scale = atof(e);
         if (const char *e = getenv("PDT_HEAD_TAUS")) head_taus = atof(e);
+        if (const char *e = getenv("PDT_BAND_PAD")) band_pad = atof(e);
         if (const char *e = getenv("PDT_PLL_WARM_S")) pll_warm_s = atof(e);
         if (const char *e = getenv("PDT_AGC_WARM_S")) agc_warm_s = atof(e);
         if (const char *e = getenv("PDT_AGC_K")) agc_k = atof(e);
@@ -1142,7 +1143,7 @@ template <typename T> int run_capture(pdt_ctx *ctx, uint64_t n, int phase = RUN_
                 GD.u = u;
                 GD.n_q = n_q;
                 GD.idx_bits = idx_bits;
-                const double pad = ctx->cfg.gardner_band_pad > 0 ? ctx->cfg.gardner_band_pad : 1.0 / 8.0;
+                const double pad = ctx->cfg.gardner_band_pad > 0 ? ctx->cfg.gardner_band_pad : (ctx->tune.band_pad > 0 ? ctx->tune.band_pad : 1.0 / 8.0);
                 GD.pad_q = std::max(2, (int)(pad / (double)u));
             }
         }
