@@ -1177,6 +1177,10 @@ template <typename T> int run_capture(pdt_ctx *ctx, uint64_t n, int phase = RUN_
             PL.memset_async(d_bitsym, 0, (size_t)bit0 * sizeof(unsigned));
         }
         sync_min_pos = std::max<long long>(0, seg->next_free - (long long)seg->bit_base);
+        // The search treats the bits in front of local bit 0 as the zeros the reference's ring starts with -- true at the start
+        // of the stream only.  Later the kept bits are the last len - 1 (or more) of the previous segment: a sync word that ends
+        // inside them was looked at there with its real bits, and one that ends further on lies entirely inside this segment.
+        if (seg->bit_base > 0) sync_min_pos = std::max<long long>(sync_min_pos, (long long)SP.len - 1);
     }
     if (use_table) {
         if constexpr (std::is_same<T, float>::value) {
@@ -1485,6 +1489,14 @@ template <typename T> int run_capture(pdt_ctx *ctx, uint64_t n, int phase = RUN_
         seg->kept_src.swap(ns);
         seg->bit_base += (uint64_t)keep_from;
         ctx->stats.gpu_ms = ms;
+        // pdt_read_stage after a push: the segment's own arrays, window-local (PLL / FIR / AGC from the window's origin; symbols
+        // behind the two or three history symbols; bits behind the kept ones) -- a debugging aid, see tools/probes/stream_debug.py
+        ctx->stage_len[PDT_ST_PLL] = (uint64_t)N;
+        ctx->stage_len[PDT_ST_LOCK] = need_lock ? (uint64_t)N : 0;
+        ctx->stage_len[PDT_ST_FIR] = ctx->stage_len[PDT_ST_AGC] = (uint64_t)n_out;
+        ctx->stage_len[PDT_ST_AGC_RAW] = 0;
+        ctx->stage_len[PDT_ST_SYM] = ctx->stage_len[PDT_ST_SYMIDX] = sc.nsym;
+        ctx->stage_len[PDT_ST_BITS] = ctx->stage_len[PDT_ST_BITSYM] = sc.nbits;
         // timers of the segment are dropped (profile mode describes whole captures)
         for (auto &t : ctx->timers) {
             if (!t.shared_a) ctx->event_pool.push_back(t.a);

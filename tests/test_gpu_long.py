@@ -20,6 +20,17 @@ def test_fuzz_fixed_seed():
     assert "50/50 identical" in r.stdout
 
 
+def test_fuzz_case_that_found_the_stream_sync_bug():
+    """Case 298 of seed 77 (ARGOS, chunk 777, pushes of 12 345 samples): a segment that began with the last ten bits of the
+    sync word behind other bits reported a frame there -- the search took the bits in front of the segment's first kept bit
+    for the zeros the reference's ring starts with.  Fixed by not accepting a sync word that would begin in front of the kept
+    bits once the stream is under way."""
+    r = subprocess.run([sys.executable, os.path.join(HERE, "tools", "fuzz.py"), "300", "77", "298"], capture_output=True, text=True,
+                       env=dict(os.environ, FUZZ_BLOCKS="777,1554,12345"))
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
+    assert r.stdout.count("streamed frames identical True") == 3 and "FAIL" not in r.stdout
+
+
 @pytest.mark.skipif(not os.environ.get("PDT_TEST_FULL"), reason="set PDT_TEST_FULL=1: 900 M samples, ~65 s of reference CPU time")
 def test_configs2_full_size_against_the_reference_objects():
     """250 ksps x 60 min = 900 000 000 samples (3.6 GB of I/Q): output file byte-identical to the reference's own objects."""

@@ -179,3 +179,19 @@ def test_argos_stream_against_the_oracle(pdt, orc):
         assert pdt.format_frames(got) == o.text() and len(got) >= 10
         got, _, _ = stream_all(d, a, 50000)
         assert pdt.format_frames(got) == o.text()
+
+
+def test_tiny_segments_do_not_invent_sync_words(pdt, orc):
+    """Segments of one 777-sample chunk (ten bits each): many segments begin in the middle of a sync word.  The frames are
+    those of the oracle (a sync word is recognised in the segment that holds its last bit, with its real first bits)."""
+    a = pdt.synth_capture(1, 32000, 12.0, f0_hz=-57.0, seed=298)
+    o = orc.Oracle(orc.ARGOS, 32000, a, chunk=777, math_mode=orc.MATH_LIBM)
+    with pdt.Demodulator(pdt.MODE_ARGOS, 32000, chunk=777) as d:
+        for block in (777, 1554, 3000):
+            got, _, _ = stream_all(d, a, block)
+            assert pdt.format_frames(got) == o.text() and len(got) >= 5
+    p = pdt.synth_capture(0, 50000, 4.0, seed=299)
+    o = orc.Oracle(orc.POES, 50000, p, chunk=260)
+    with pdt.Demodulator(pdt.MODE_POES, 50000, chunk=260) as d:
+        got, _, _ = stream_all(d, p, 260)
+        assert pdt.format_frames(got) == o.text() and len(got) >= 30

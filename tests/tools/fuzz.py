@@ -10,6 +10,7 @@ from oracle import binding as orc
 
 n_cases = int(sys.argv[1]) if len(sys.argv) > 1 else 40
 rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 1)
+only = int(sys.argv[3]) if len(sys.argv) > 3 else -1          # replay the draws, run just this case and say which stage differs
 bad = 0
 t_start = time.time()
 for case in range(n_cases):
@@ -40,6 +41,9 @@ for case in range(n_cases):
                   agc_block=int(rng.integers(64, 12000)), agc_warm=int(rng.integers(0, 40000)))
     if rng.random() < 0.2:
         kw["gardner_band_pad"] = float(rng.choice([1 / 512, 1 / 64, 0.5]))
+    if only >= 0 and case != only:
+        rng.choice([2400, 5000, 12345, 777, 300, 1554])                              # (the streaming block size drawn further down)
+        continue
     o = orc.Oracle(omode, fs, iq, chunk=chunk, sampler=sampler, math_mode=orc.MATH_LIBM)
     d = pdt.Demodulator(mode, fs, chunk=chunk, sampler=sampler, **kw)
     d.demod(iq)
@@ -47,12 +51,32 @@ for case in range(n_cases):
     for sg, so in ((pdt.ST_PLL, orc.ST_PLL), (pdt.ST_FIR, orc.ST_FIR), (pdt.ST_AGC, orc.ST_AGC), (pdt.ST_SYM, orc.ST_SYM),
                    (pdt.ST_SYMIDX, orc.ST_SYMIDX), (pdt.ST_BITS, orc.ST_BITS)):
         a, b = d.stage(sg), o.stage(so)
-        ok = ok and len(a) == len(b) and a.tobytes() == np.asarray(b, dtype=a.dtype).tobytes()
+        same = len(a) == len(b) and a.tobytes() == np.asarray(b, dtype=a.dtype).tobytes()
+        if only >= 0 and not same:
+            bb = np.asarray(b, dtype=a.dtype)
+            m = min(len(a), len(bb))
+            diff = np.nonzero(a[:m].view(np.uint8).reshape(m, -1) != bb[:m].view(np.uint8).reshape(m, -1))[0]
+            print(f"  stage {sg}: lengths {len(a)} / {len(bb)}, {len(np.unique(diff))} elements differ, first at {diff[0] if len(diff) else None}")
+        ok = ok and same
     # streaming must give the same frames as the one-shot call
     want = d.frames_array().tobytes()
     d.stream_begin()
-    blk = int(rng.choice([2400, 5000, 12345]))
+    blk = int(rng.choice([2400, 5000, 12345, 777, 300, 1554]))
     parts = [d.stream_push(iq[i:i + blk]) for i in range(0, len(iq), blk)] + [d.stream_end()]
+    if only >= 0:
+        for b2 in [int(x) for x in os.environ.get("FUZZ_BLOCKS", "").split(",") if x]:
+            d.stream_begin()
+            pp = [d.stream_push(iq[i:i + b2]) for i in range(0, len(iq), b2)] + [d.stream_end()]
+            got = np.concatenate(pp)
+            print(f"  block {b2}: streamed frames identical {got.tobytes() == want}", [int(f["bit_index"]) for f in got])
+        print("  text identical", d.text() == o.text(), "; streaming identical", np.concatenate(parts).tobytes() == want, "block", blk)
+        if d.text() != o.text():
+            print("  gpu text:\n" + d.text().decode(errors="replace") + "  oracle text:\n" + o.text().decode(errors="replace"))
+            fr = np.frombuffer(want, dtype=pdt.FRAME_DTYPE)
+            st = np.concatenate(parts)
+            print("  one-shot frames (bit_index, nbytes, complete):", [(int(f["bit_index"]), int(f["nbytes"]), int(f["complete"])) for f in fr])
+            print("  streamed frames:", [(int(f["bit_index"]), int(f["nbytes"]), int(f["complete"])) for f in st])
+            print("  bits", d.stats().bits, "symbols", d.stats().symbols)
     ok = ok and np.concatenate(parts).tobytes() == want
     s = d.stats()
     d.close()
