@@ -235,7 +235,7 @@ struct Plan {
 // context is opened; the demodulation calls never look at the environment.
 struct Tuning {
     double band_pad = 0.0, pll_warm_scale = 1.0, head_taus = 0.0, agc_k = 0.0, pll_warm_s = 0.0, agc_warm_s = 0.0;
-    int ingest_threads = 0, ingest_span_mb = 0, fir_wg_per_cu = 0, agc_tpb = 0, gseg = 0, acquire_mode = 0, pll_block = 0, fix_passes = 2;      // acquire_mode: 0 = two-wavefront pipeline, 1 = plain one-lane, 2 = one wavefront
+    int ingest_threads = 0, ingest_span_mb = 0, ingest_streams = 0, fir_wg_per_cu = 0, agc_tpb = 0, gseg = 0, acquire_mode = 0, pll_block = 0, fix_passes = 2;      // acquire_mode: 0 = two-wavefront pipeline, 1 = plain one-lane, 2 = one wavefront
     bool fir_generic = false, agc_unfused = false, no_excl = false, gtab_nomerge = false, gardner_onebuf = false, gardner_noring = false, gardner_sequential = false, ema_noguess = false, debug_sync = false;
     void load()
     {
@@ -250,6 +250,7 @@ struct Tuning {
         if (const char *e = getenv("PDT_FIR_WG_PER_CU")) fir_wg_per_cu = std::min(4096, std::max(1, atoi(e)));
         if (const char *e = getenv("PDT_INGEST_THREADS")) ingest_threads = std::min(128, std::max(1, atoi(e)));
         if (const char *e = getenv("PDT_INGEST_SPAN_MB")) ingest_span_mb = std::min(256, std::max(1, atoi(e)));
+        if (const char *e = getenv("PDT_INGEST_STREAMS")) ingest_streams = std::min(4, std::max(1, atoi(e)));
         if (const char *e = getenv("PDT_FIX_PASSES")) fix_passes = atoi(e);
         if (const char *e = getenv("PDT_GSEG")) gseg = std::min(64, std::max(2, atoi(e)));
         if (getenv("PDT_ACQUIRE_SIMPLE")) acquire_mode = 1;
@@ -338,8 +339,8 @@ struct pdt_ctx {
     // host -> HBM ingest of a capture (file or memory): pinned slots filled by a few host threads, copies on a stream of their own
     void *ingest_pin = nullptr;
     size_t ingest_pin_cap = 0;
-    hipStream_t copy_stream = nullptr;
-    hipEvent_t ev_ingest = nullptr;
+    hipStream_t copy_stream = nullptr, copy_streams_more[3] = { nullptr, nullptr, nullptr };   // span copies go round robin over them
+    hipEvent_t ev_ingest = nullptr, ev_ingest_more[3] = { nullptr, nullptr, nullptr };
     std::vector<hipEvent_t> ingest_ev;
     double ingest_ms = 0;               // host wall time of the last ingest (issue of the last copy)
     DevBuf stream_in, seg_dev, lt_theta, lt_phi;          // input window of the stream; small device block for the segment's carried-out state
@@ -1628,6 +1629,15 @@ int ingest_capture(pdt_ctx *ctx, const IngestSrc &src, size_t bytes, void *dst)
     }
     if (!ctx->copy_stream) HIP_TRY(hipStreamCreateWithFlags(&ctx->copy_stream, hipStreamNonBlocking));
     if (!ctx->ev_ingest) HIP_TRY(hipEventCreateWithFlags(&ctx->ev_ingest, hipEventDisableTiming));
+    // copy streams in use: hour-long captures spread their span copies over four (3.6 GB: 123 -> 107 ms for the whole call,
+    // ~51 GB/s from the page cache to HBM); ten-minute captures are no faster for it
+    const int NS = std::min(4, std::max(1, ctx->tune.ingest_streams > 0 ? ctx->tune.ingest_streams : (bytes >= ((size_t)512 << 20) ? 4 : 1)));
+    hipStream_t cs[4] = { ctx->copy_stream, nullptr, nullptr, nullptr };
+    for (int q = 1; q < NS; q++) {
+        if (!ctx->copy_streams_more[q - 1]) HIP_TRY(hipStreamCreateWithFlags(&ctx->copy_streams_more[q - 1], hipStreamNonBlocking));
+        if (!ctx->ev_ingest_more[q - 1]) HIP_TRY(hipEventCreateWithFlags(&ctx->ev_ingest_more[q - 1], hipEventDisableTiming));
+        cs[q] = ctx->copy_streams_more[q - 1];
+    }
     while (ctx->ingest_ev.size() < (size_t)T * PDT_INGEST_SLOTS) {
         hipEvent_t e;
         HIP_TRY(hipEventCreateWithFlags(&e, hipEventDisableTiming));
@@ -1635,7 +1645,7 @@ int ingest_capture(pdt_ctx *ctx, const IngestSrc &src, size_t bytes, void *dst)
     }
     // the destination may still be read by work queued earlier on the demodulation stream
     HIP_TRY(hipEventRecord(ctx->ev_ingest, ctx->stream));
-    HIP_TRY(hipStreamWaitEvent(ctx->copy_stream, ctx->ev_ingest, 0));
+    for (int q = 0; q < NS; q++) HIP_TRY(hipStreamWaitEvent(cs[q], ctx->ev_ingest, 0));
     std::atomic<int> failed{0};
     auto worker = [&](int t) {
         if (hipSetDevice(ctx->cfg.device) != hipSuccess) { failed = 1; return; }
@@ -1656,8 +1666,9 @@ int ingest_capture(pdt_ctx *ctx, const IngestSrc &src, size_t bytes, void *dst)
                     got += (size_t)r;
                 }
             }
-            if (hipMemcpyAsync((unsigned char *)dst + at, pin, len, hipMemcpyHostToDevice, ctx->copy_stream) != hipSuccess ||
-                hipEventRecord(ctx->ingest_ev[(size_t)slot], ctx->copy_stream) != hipSuccess) {
+            hipStream_t mine = cs[t % NS];
+            if (hipMemcpyAsync((unsigned char *)dst + at, pin, len, hipMemcpyHostToDevice, mine) != hipSuccess ||
+                hipEventRecord(ctx->ingest_ev[(size_t)slot], mine) != hipSuccess) {
                 failed = 1;
                 return;
             }
@@ -1671,6 +1682,10 @@ int ingest_capture(pdt_ctx *ctx, const IngestSrc &src, size_t bytes, void *dst)
     if (failed) { (void)hipGetLastError(); return PDT_ERR_NOGPU; }
     HIP_TRY(hipEventRecord(ctx->ev_ingest, ctx->copy_stream));
     HIP_TRY(hipStreamWaitEvent(ctx->stream, ctx->ev_ingest, 0));
+    for (int q = 1; q < NS; q++) {
+        HIP_TRY(hipEventRecord(ctx->ev_ingest_more[q - 1], cs[q]));
+        HIP_TRY(hipStreamWaitEvent(ctx->stream, ctx->ev_ingest_more[q - 1], 0));
+    }
     return PDT_OK;
 }
 
@@ -1873,6 +1888,10 @@ void pdt_close(pdt_ctx *ctx)
     for (hipEvent_t e : ctx->ingest_ev) (void)hipEventDestroy(e);
     if (ctx->ev_ingest) (void)hipEventDestroy(ctx->ev_ingest);
     if (ctx->copy_stream) (void)hipStreamDestroy(ctx->copy_stream);
+    for (int q = 0; q < 3; q++) {
+        if (ctx->ev_ingest_more[q]) (void)hipEventDestroy(ctx->ev_ingest_more[q]);
+        if (ctx->copy_streams_more[q]) (void)hipStreamDestroy(ctx->copy_streams_more[q]);
+    }
     if (ctx->pend_sc) (void)hipHostFree(ctx->pend_sc);
     for (auto &t : ctx->timers) { if (!t.shared_a) (void)hipEventDestroy(t.a); (void)hipEventDestroy(t.b); }
     if (ctx->ev0) (void)hipEventDestroy(ctx->ev0);
