@@ -236,7 +236,7 @@ struct Plan {
 struct Tuning {
     double band_pad = 0.0, pll_warm_scale = 1.0, head_taus = 0.0, agc_k = 0.0, pll_warm_s = 0.0, agc_warm_s = 0.0;
     int ingest_threads = 0, ingest_span_mb = 0, ingest_streams = 0, fir_wg_per_cu = 0, agc_tpb = 0, gseg = 0, acquire_mode = 0, pll_block = 0, fix_passes = 2;      // acquire_mode: 0 = two-wavefront pipeline, 1 = plain one-lane, 2 = one wavefront
-    bool fir_generic = false, agc_unfused = false, no_excl = false, gtab_nomerge = false, gardner_onebuf = false, gardner_noring = false, gardner_sequential = false, ema_noguess = false, debug_sync = false;
+    bool fir_generic = false, agc_unfused = false, no_excl = false, gtab_nomerge = false, gardner_onebuf = false, gardner_noring = false, gardner_sequential = false, seg_sequential = false, ema_noguess = false, debug_sync = false;
     void load()
     {
         if (const char *e = getenv("PDT_PLL_WARM_SCALE")) pll_warm_scale = atof(e);
@@ -263,6 +263,7 @@ struct Tuning {
         gardner_noring = getenv("PDT_GARDNER_NORING") != nullptr;
         ema_noguess = getenv("PDT_EMA_NOGUESS") != nullptr;
         gardner_sequential = getenv("PDT_GARDNER_SEQUENTIAL") != nullptr;
+        seg_sequential = getenv("PDT_SEG_SEQUENTIAL") != nullptr;
         debug_sync = getenv("PDT_DEBUG_SYNC") != nullptr;
     }
 };
@@ -1126,7 +1127,9 @@ template <typename T> int run_capture(pdt_ctx *ctx, uint64_t n, int phase = RUN_
     if constexpr (std::is_same<T, float>::value) {
         const int table_len = 1 << 22;     // the table kernel walks the chunk in LDS windows: no size limit of its own
         const float nT = (float)chunk_out, stepf = (float)GP.step;
-        if (!argos && !use_mm && !ctx->tune.gardner_sequential && !seg && n_chunks >= 4 && chunk_out >= 256 &&
+        const long long seg_c_first = (seg && chunk > 0) ? first / chunk : 0;
+        if (!argos && !use_mm && !ctx->tune.gardner_sequential && n_chunks - seg_c_first >= 4 && chunk_out >= 256 &&
+            !(seg && ctx->tune.seg_sequential) &&
             chunk_out + 2 * (long long)stepf + 24 <= table_len && 8 * (long long)stepf + 256 < PDT_GTAB_WIN && chunk_out < (1 << 22)) {
             int e;
             (void)frexpf(nT - stepf - 1.0f, &e);                              // value in [2^(e-1), 2^e)
@@ -1208,6 +1211,9 @@ template <typename T> int run_capture(pdt_ctx *ctx, uint64_t n, int phase = RUN_
                 ctx->gcand_key = key;
             }
             const long long n_tab = n_chunks - 1;
+            SamplerCarry<float> tab_carry;                   // where the chain starts: chunk, state, symbols already in the buffer
+            tab_carry.a = (float)carry_in.a; tab_carry.b = (float)carry_in.b; tab_carry.c = (float)carry_in.c;
+            tab_carry.c_first = carry_in.c_first; tab_carry.count0 = carry_in.count0;
             if ((rc = ctx->gtable.ensure((size_t)n_tab * (size_t)(2 * GD.n_q) * sizeof(unsigned)))) return rc;
             if ((rc = ctx->gentries.ensure((size_t)n_chunks * sizeof(GardnerEntry<float>)))) return rc;
             if ((rc = ctx->gbands.ensure((size_t)n_tab * sizeof(GardnerBand)))) return rc;
@@ -1250,7 +1256,7 @@ template <typename T> int run_capture(pdt_ctx *ctx, uint64_t n, int phase = RUN_
                                (const float *)d_agc, GP, GD, n_chunks,
                                (const unsigned *)ctx->gtable.p, (const GardnerSegCell *)ctx->gsegmap.p, G,
                                (GardnerSegStart *)ctx->gsegstart.p, (GardnerEntry<float> *)ctx->gentries.p, d_sc->gstats,
-                               (const GardnerBand *)ctx->gbands.p, n_tab);
+                               (const GardnerBand *)ctx->gbands.p, n_tab, tab_carry, (seg && seg->have_sampler) ? 1 : 0);
             PDT_LAUNCH(64, k_gardner_segfill, dim3((unsigned)n_seg), dim3(64), 0, st, (const float *)d_agc, GP, GD, n_chunks,
                                (const unsigned *)ctx->gtable.p, G, (const GardnerSegStart *)ctx->gsegstart.p,
                                (GardnerEntry<float> *)ctx->gentries.p);
@@ -1259,7 +1265,7 @@ template <typename T> int run_capture(pdt_ctx *ctx, uint64_t n, int phase = RUN_
             // per-chunk emission: small LDS windows so that every chunk of a 10-minute capture is resident at once
             PDT_LAUNCH(256, (k_gardner<float, PDT_GEMIT_LEN, PDT_GEMIT_OUT>), dim3((unsigned)n_chunks), dim3(PDT_GARDNER_THREADS), 0, st, (const float *)d_agc,
                                (const float *)d_lock, GP, (float *)d_sym, d_symidx, &d_sc->nsym, sym_cap,
-                               (const GardnerEntry<float> *)ctx->gentries.p, SamplerCarry<float>{0, 0, 0, 0, 0}, (SamplerCarry<float> *)nullptr);
+                               (const GardnerEntry<float> *)ctx->gentries.p, tab_carry, (SamplerCarry<float> *)d_carry_out);
             L.end();
         }
     } else if (use_mm) {

@@ -304,7 +304,7 @@ __device__ __forceinline__ void k_gardner(const T *__restrict__ in, const T *__r
     if (entries) {
         c_begin = blockIdx.x;
         c_end = c_begin + 1;
-        if (c_begin >= n_chunks) return;
+        if (c_begin >= n_chunks || c_begin < carry.c_first) return;      // (a stream segment: the chunks in front are history)
         const GardnerEntry<T> e = entries[c_begin];
         S.ns = e.ns;
         S.prev = e.prev;
@@ -314,7 +314,7 @@ __device__ __forceinline__ void k_gardner(const T *__restrict__ in, const T *__r
     for (long long c = c_begin; c < c_end; c++)
         count += gardner_walk_chunk<T, true, LEN, OUT>(in, lock, P, c, S, win, o_val, o_idx, sym, symidx, count, sym_cap);
     if (threadIdx.x == 0 && (!entries || c_end == n_chunks)) *nsym_out = (unsigned long long)count;
-    if (threadIdx.x == 0 && !entries && carry_out) {
+    if (threadIdx.x == 0 && carry_out && (!entries || c_end == n_chunks)) {
         SamplerCarry<T> o;
         o.a = S.ns; o.b = S.prev; o.c = S.half; o.c_first = c_end; o.count0 = count;
         *carry_out = o;
@@ -1560,7 +1560,8 @@ __device__ __forceinline__ void k_gardner_chain(const float *__restrict__ in, Ga
                                                                         GardnerSegStart *__restrict__ segstart,
                                                                         GardnerEntry<float> *__restrict__ entries,
                                                                         unsigned *__restrict__ stats /* [2] walked chunks */,
-                                                                        const GardnerBand *__restrict__ bands, long long n_tab)
+                                                                        const GardnerBand *__restrict__ bands, long long n_tab,
+                                                                        SamplerCarry<float> carry, int have_carry)
 {
     __shared__ float win[GardnerLds<float>::LEN];
     {   // statistics of the scouts: candidates evaluated ([3]) and chunks tabulated over the full domain ([1])
@@ -1581,10 +1582,16 @@ __device__ __forceinline__ void k_gardner_chain(const float *__restrict__ in, Ga
     const size_t stride = (size_t)(2 * D.n_q);
     GardnerState<float> S;
     S.ns = 0; S.prev = 0; S.half = 0; S.q_last = 0; S.i_last = 0;
-    long long off = 0;
+    long long off = carry.count0;
     unsigned walked = 0, key = 0;
     bool have_key = true;                                // chunk 0: the single start state is cell 0 of row 0
-    long long c = 0;
+    long long c = carry.c_first;
+    if (have_carry) {
+        // a stream segment goes on from the sampler state the previous one left: not a tabulated boundary state as such, so the
+        // first chunk is walked and the chain takes to the tables from its exit on
+        S.ns = carry.a; S.prev = carry.b; S.half = carry.c;
+        have_key = false;
+    }
     while (c < n_chunks) {
         // ---- hop over a whole segment
         if (have_key && (c % G) == 0 && c + G <= n_chunks - 1) {

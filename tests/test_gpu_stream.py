@@ -195,3 +195,26 @@ def test_tiny_segments_do_not_invent_sync_words(pdt, orc):
     with pdt.Demodulator(pdt.MODE_POES, 50000, chunk=260) as d:
         got, _, _ = stream_all(d, p, 260)
         assert pdt.format_frames(got) == o.text() and len(got) >= 30
+
+
+def test_large_pushes_take_the_table_sampler(pdt, orc):
+    """Pushes of many chunks go through the boundary-state tables, entered with the carried sampler state (the chain walks the
+    segment's first chunk and takes to the tables from its exit on): same frames as the oracle, and much faster than the
+    sequential sampler of small pushes (PDT_SEG_SEQUENTIAL keeps that one)."""
+    import os, time
+    iq = pdt.synth_capture(0, 50000, 40.0, seed=41)
+    o = orc.Oracle(orc.POES, 50000, iq)
+    times = {}
+    for env in ("", "1"):
+        if env:
+            os.environ["PDT_SEG_SEQUENTIAL"] = env
+        try:
+            with pdt.Demodulator(pdt.MODE_POES, 50000) as d:
+                for block in (500000, 333333, 123457):
+                    t0 = time.perf_counter()
+                    got, _, _ = stream_all(d, iq, block)
+                    times[(env, block)] = time.perf_counter() - t0
+                    assert pdt.format_frames(got) == o.text() and len(got) >= 390
+        finally:
+            os.environ.pop("PDT_SEG_SEQUENTIAL", None)
+    assert times[("", 500000)] < 0.6 * times[("1", 500000)], times
