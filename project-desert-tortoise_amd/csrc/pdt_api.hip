@@ -10,6 +10,8 @@
 
 #include <algorithm>
 #include <atomic>
+#include <chrono>
+#include <memory>
 #include <string>
 #include <thread>
 #include <type_traits>
@@ -235,8 +237,8 @@ struct Plan {
 // context is opened; the demodulation calls never look at the environment.
 struct Tuning {
     double band_pad = 0.0, pll_warm_scale = 1.0, head_taus = 0.0, agc_k = 0.0, pll_warm_s = 0.0, agc_warm_s = 0.0;
-    int ingest_threads = 0, ingest_span_mb = 0, ingest_streams = 0, fir_wg_per_cu = 0, agc_tpb = 0, gseg = 0, acquire_mode = 0, pll_block = 0, fix_passes = 2;      // acquire_mode: 0 = two-wavefront pipeline, 1 = plain one-lane, 2 = one wavefront
-    bool fir_generic = false, agc_unfused = false, no_excl = false, gtab_nomerge = false, gardner_onebuf = false, gardner_noring = false, gardner_sequential = false, seg_sequential = false, ema_noguess = false, debug_sync = false;
+    int ingest_threads = 0, ingest_span_mb = 0, ingest_streams = 0, overlap_segments = 0, overlap_min_mb = 0, fir_wg_per_cu = 0, agc_tpb = 0, gseg = 0, acquire_mode = 0, pll_block = 0, fix_passes = 2;      // acquire_mode: 0 = two-wavefront pipeline, 1 = plain one-lane, 2 = one wavefront
+    bool fir_generic = false, agc_unfused = false, no_excl = false, gtab_nomerge = false, gardner_onebuf = false, gardner_noring = false, gardner_sequential = false, seg_sequential = false, no_overlap = false, debug_overlap = false, ema_noguess = false, debug_sync = false;
     void load()
     {
         if (const char *e = getenv("PDT_PLL_WARM_SCALE")) pll_warm_scale = atof(e);
@@ -264,6 +266,10 @@ struct Tuning {
         ema_noguess = getenv("PDT_EMA_NOGUESS") != nullptr;
         gardner_sequential = getenv("PDT_GARDNER_SEQUENTIAL") != nullptr;
         seg_sequential = getenv("PDT_SEG_SEQUENTIAL") != nullptr;
+        no_overlap = getenv("PDT_NO_OVERLAP") != nullptr;
+        debug_overlap = getenv("PDT_DEBUG_OVERLAP") != nullptr;
+        if (const char *e = getenv("PDT_OVERLAP_SEGMENTS")) overlap_segments = std::min(64, std::max(1, atoi(e)));
+        if (const char *e = getenv("PDT_OVERLAP_MIN_MB")) overlap_min_mb = std::min(1 << 20, std::max(1, atoi(e)));
         debug_sync = getenv("PDT_DEBUG_SYNC") != nullptr;
     }
 };
@@ -274,6 +280,7 @@ struct Tuning {
 struct StreamCarry {
     bool active = false;          // run_capture works on a window of a stream
     bool final_seg = false;       // the stream ends with this segment (short last chunk, partial frame reported)
+    bool in_place = false;        // the whole capture has its place in the window (pdt_demod_fd of a large file): never slides
     long long first = 0;          // local index of the first new input sample (a multiple of the chunk)
     uint64_t origin = 0;          // global sample index of local sample 0 (a multiple of lcm(chunk, FIR ring length))
     // StaticGain / AGC
@@ -342,7 +349,8 @@ struct pdt_ctx {
     size_t ingest_pin_cap = 0;
     hipStream_t copy_stream = nullptr, copy_streams_more[3] = { nullptr, nullptr, nullptr };   // span copies go round robin over them
     hipEvent_t ev_ingest = nullptr, ev_ingest_more[3] = { nullptr, nullptr, nullptr };
-    std::vector<hipEvent_t> ingest_ev;
+    std::vector<hipEvent_t> ingest_ev, span_ev;      // per pinned slot; per span (overlapped ingest)
+    double stream_gpu_ms = 0;
     double ingest_ms = 0;               // host wall time of the last ingest (issue of the last copy)
     DevBuf stream_in, seg_dev, lt_theta, lt_phi;          // input window of the stream; small device block for the segment's carried-out state
     uint64_t stream_have = 0, stream_done = 0;   // samples in the window / of them already demodulated (local indices)
@@ -1610,14 +1618,24 @@ struct IngestSrc {
 constexpr size_t PDT_INGEST_SPAN_DEFAULT = 2u << 20;
 constexpr int PDT_INGEST_SLOTS = 2;      // per thread
 
-int ingest_capture(pdt_ctx *ctx, const IngestSrc &src, size_t bytes, void *dst)
+// An ingest that goes on in the background: every span has an event of its own and a flag that says the event has been
+// recorded; the caller makes its stream wait for the spans of a prefix (ingest_wait_prefix) and starts work on it while the
+// rest still arrives, and joins the threads at the end (ingest_join).
+struct IngestJob {
+    std::vector<std::thread> pool;
+    std::unique_ptr<std::atomic<int>[]> submitted;
+    std::atomic<int> failed{0};
+    size_t nspans = 0, span = 0, waited = 0;
+};
+
+int ingest_capture(pdt_ctx *ctx, const IngestSrc &src, size_t bytes, void *dst, IngestJob *job = nullptr)
 {
     if (!bytes) return PDT_OK;
     // (hour-long captures: 8 MiB spans -- fewer, larger copies: 3.6 GB in 75-95 ms against 110 with 2 MiB spans)
     const size_t PDT_INGEST_SPAN = ctx->tune.ingest_span_mb > 0 ? ((size_t)ctx->tune.ingest_span_mb << 20)
                                    : (bytes >= ((size_t)512 << 20) ? 4 * PDT_INGEST_SPAN_DEFAULT : PDT_INGEST_SPAN_DEFAULT);
     const size_t nspans = (bytes + PDT_INGEST_SPAN - 1) / PDT_INGEST_SPAN;
-    if (src.mem && nspans <= 2) {
+    if (src.mem && nspans <= 2 && !job) {
         HIP_TRY(hipMemcpyAsync(dst, src.mem, bytes, hipMemcpyHostToDevice, ctx->stream));
         return PDT_OK;
     }
@@ -1652,8 +1670,24 @@ int ingest_capture(pdt_ctx *ctx, const IngestSrc &src, size_t bytes, void *dst)
     // the destination may still be read by work queued earlier on the demodulation stream
     HIP_TRY(hipEventRecord(ctx->ev_ingest, ctx->stream));
     for (int q = 0; q < NS; q++) HIP_TRY(hipStreamWaitEvent(cs[q], ctx->ev_ingest, 0));
-    std::atomic<int> failed{0};
-    auto worker = [&](int t) {
+    std::atomic<int> failed_here{0};
+    std::atomic<int> &failed = job ? job->failed : failed_here;
+    if (job) {
+        while (ctx->span_ev.size() < nspans) {
+            hipEvent_t e;
+            HIP_TRY(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+            ctx->span_ev.push_back(e);
+        }
+        job->submitted.reset(new std::atomic<int>[nspans]);
+        for (size_t k = 0; k < nspans; k++) job->submitted[k].store(0);
+        job->nspans = nspans;
+        job->span = PDT_INGEST_SPAN;
+        job->waited = 0;
+    }
+    // (the background form copies what the lambda needs: it outlives this call)
+    const IngestSrc src_c = src;
+    auto worker = [ctx, src_c, bytes, dst, nspans, T, NS, cs, PDT_INGEST_SPAN, job, &failed](int t) {
+        const IngestSrc &src = src_c;
         if (hipSetDevice(ctx->cfg.device) != hipSuccess) { failed = 1; return; }
         int round = 0;
         for (size_t k = (size_t)t; k < nspans && !failed; k += (size_t)T, round++) {
@@ -1678,8 +1712,16 @@ int ingest_capture(pdt_ctx *ctx, const IngestSrc &src, size_t bytes, void *dst)
                 failed = 1;
                 return;
             }
+            if (job) {
+                if (hipEventRecord(ctx->span_ev[k], mine) != hipSuccess) { failed = 1; return; }
+                job->submitted[k].store(1, std::memory_order_release);
+            }
         }
     };
+    if (job) {
+        for (int t = 0; t < T; t++) job->pool.emplace_back(worker, t);
+        return PDT_OK;
+    }
     std::vector<std::thread> pool;
     for (int t = 1; t < T; t++) pool.emplace_back(worker, t);
     worker(0);
@@ -1692,6 +1734,29 @@ int ingest_capture(pdt_ctx *ctx, const IngestSrc &src, size_t bytes, void *dst)
         HIP_TRY(hipEventRecord(ctx->ev_ingest_more[q - 1], cs[q]));
         HIP_TRY(hipStreamWaitEvent(ctx->stream, ctx->ev_ingest_more[q - 1], 0));
     }
+    return PDT_OK;
+}
+
+// make `stream` wait for every span that holds a byte below `upto_bytes`
+int ingest_wait_prefix(pdt_ctx *ctx, IngestJob &job, size_t upto_bytes, hipStream_t stream)
+{
+    const size_t need = std::min(job.nspans, (upto_bytes + job.span - 1) / job.span);
+    for (; job.waited < need; job.waited++) {
+        while (!job.submitted[job.waited].load(std::memory_order_acquire)) {
+            if (job.failed) return job.failed == 2 ? PDT_ERR_FORMAT : PDT_ERR_NOGPU;
+            std::this_thread::yield();
+        }
+        HIP_TRY(hipStreamWaitEvent(stream, ctx->span_ev[job.waited], 0));
+    }
+    return PDT_OK;
+}
+
+int ingest_join(IngestJob &job)
+{
+    for (auto &th : job.pool) th.join();
+    job.pool.clear();
+    if (job.failed == 2) return PDT_ERR_FORMAT;
+    if (job.failed) { (void)hipGetLastError(); return PDT_ERR_NOGPU; }
     return PDT_OK;
 }
 
@@ -1894,6 +1959,7 @@ void pdt_close(pdt_ctx *ctx)
     for (hipEvent_t e : ctx->ingest_ev) (void)hipEventDestroy(e);
     if (ctx->ev_ingest) (void)hipEventDestroy(ctx->ev_ingest);
     if (ctx->copy_stream) (void)hipStreamDestroy(ctx->copy_stream);
+    for (hipEvent_t e : ctx->span_ev) (void)hipEventDestroy(e);
     for (int q = 0; q < 3; q++) {
         if (ctx->ev_ingest_more[q]) (void)hipEventDestroy(ctx->ev_ingest_more[q]);
         if (ctx->copy_streams_more[q]) (void)hipStreamDestroy(ctx->copy_streams_more[q]);
@@ -1955,17 +2021,27 @@ int pdt_demod_pcm16(pdt_ctx *ctx, const int16_t *iq_host, uint64_t nframes)
     return demod_common(ctx, nframes);
 }
 
+static int demod_overlapped(pdt_ctx *ctx, const IngestSrc &src, uint64_t nframes, int fmt);
+// hour-long POES captures: the chain starts on the part of the capture that has arrived (demod_overlapped)
+static bool overlap_ingest(const pdt_ctx *ctx, uint64_t nframes, size_t fb)
+{
+    return !ctx->tune.no_overlap && ctx->cfg.mode == PDT_MODE_POES && ctx->cfg.sampler != PDT_SAMPLER_MM && ctx->cfg.chain != PDT_CHAIN_LIVE &&
+           (size_t)nframes * fb >= ((size_t)(ctx->tune.overlap_min_mb > 0 ? ctx->tune.overlap_min_mb : 512) << 20) && ctx->cfg.chunk > 0 &&
+           nframes / ctx->cfg.chunk >= 64;
+}
+
 int pdt_demod_fd(pdt_ctx *ctx, int fd, uint64_t byte_offset, uint64_t nframes, int sample_format)
 {
     if (!ctx || fd < 0 || (sample_format != PDT_FMT_PCM16 && sample_format != PDT_FMT_F32)) return PDT_ERR_ARG;
     if (sample_format == PDT_FMT_F32 && ctx->cfg.mode != PDT_MODE_POES) return PDT_ERR_FORMAT;   // ARGOSdemod/main.c:238-241
     HIP_TRY(hipSetDevice(ctx->cfg.device));
     const size_t fb = sample_format == PDT_FMT_F32 ? 8 : 4;
-    int rc = ctx->pcm.ensure((size_t)nframes * fb + 16);
-    if (rc) return rc;
     IngestSrc src;
     src.fd = fd;
     src.off = byte_offset;
+    if (overlap_ingest(ctx, nframes, fb)) return demod_overlapped(ctx, src, nframes, sample_format == PDT_FMT_F32 ? 1 : 0);
+    int rc = ctx->pcm.ensure((size_t)nframes * fb + 16);
+    if (rc) return rc;
     if ((rc = ingest_capture(ctx, src, (size_t)nframes * fb, ctx->pcm.p))) return rc;
     ctx->pcm_dev = ctx->pcm.p;
     ctx->pcm_fmt = sample_format == PDT_FMT_F32 ? 1 : 0;
@@ -2132,6 +2208,7 @@ int pdt_stream_begin(pdt_ctx *ctx)
     memset(&ctx->stats, 0, sizeof ctx->stats);
     memset(ctx->stage_len, 0, sizeof ctx->stage_len);
     ctx->stats.lock_sample = -1;
+    ctx->stream_gpu_ms = 0;
     return PDT_OK;
 }
 
@@ -2163,7 +2240,8 @@ static int stream_segment(pdt_ctx *ctx, uint64_t upto, bool final_seg)
     C.active = true;
     C.final_seg = final_seg;
     C.first = (long long)ctx->stream_done;
-    ctx->pcm_dev = ctx->stream_in.p;
+    // (in place: the window is a view into the resident capture -- it "slides" by moving its base, not its samples)
+    ctx->pcm_dev = (const unsigned char *)ctx->stream_in.p + (C.in_place ? (size_t)C.origin * (ctx->stream_fmt ? 8 : 4) : 0);
     ctx->pcm_fmt = ctx->stream_fmt;
     const int rc = demod_common(ctx, upto);
     C.active = false;
@@ -2187,10 +2265,14 @@ static int stream_segment(pdt_ctx *ctx, uint64_t upto, bool final_seg)
     S.norm_factor = C.norm_factor;
     S.interp = ctx->interp;
     S.ntaps = ctx->ntaps;
+    ctx->stream_gpu_ms += S.gpu_ms;
+    S.gpu_ms = ctx->stream_gpu_ms;
     if (final_seg) return PDT_OK;
     // ---- slide the window: the new origin is the largest aligned position that leaves the history in front of the next
     // new sample; the input window and the tails later segments look back on move with it
-    const uint64_t hist = stream_history(ctx), align = stream_align(ctx);
+    uint64_t align = stream_align(ctx);
+    if (C.in_place && (align & 3)) align *= (align & 1) ? 4 : 2;     // the view's base stays 16-byte aligned
+    const uint64_t hist = stream_history(ctx);
     const uint64_t done_g = C.origin + ctx->stream_done;
     const uint64_t new_origin = done_g > hist ? (done_g - hist) / align * align : 0;
     if (new_origin > C.origin) {
@@ -2210,7 +2292,7 @@ static int stream_segment(pdt_ctx *ctx, uint64_t upto, bool final_seg)
         };
         int r;
         // input: everything from the new origin on
-        if ((r = slide(ctx->stream_in, fb, d, ctx->stream_have - d))) return r;
+        if (!C.in_place && (r = slide(ctx->stream_in, fb, d, ctx->stream_have - d))) return r;
         // PLL output: the FIR looks 25 inputs back; lock signal / AGC output: the sampler's stale reads reach one chunk back
         const uint64_t keep_pll = std::min<uint64_t>(ctx->stream_done - d, 256);
         {
@@ -2234,6 +2316,50 @@ static int stream_segment(pdt_ctx *ctx, uint64_t upto, bool final_seg)
         ctx->stream_done -= d;
     }
     return PDT_OK;
+}
+
+// A large capture from a file or from host memory: the spans arrive in the background (ingest_capture with a job) straight into
+// the stream window, which holds the whole capture and never slides; the chain runs over it in a few segments with carried
+// state (exactly the streaming path), each as soon as its samples are there.  What the call leaves behind is what
+// pdt_stream_end leaves: frames and statistics; the stage arrays are those of the last segment.
+static int demod_overlapped(pdt_ctx *ctx, const IngestSrc &src, uint64_t nframes, int fmt)
+{
+    const size_t fb = fmt ? 8 : 4;
+    int rc = pdt_stream_begin(ctx);
+    if (rc) return rc;
+    ctx->stream_fmt = fmt;
+    if ((rc = ctx->stream_in.ensure(((size_t)nframes + 64) * fb))) return rc;
+    IngestJob job;
+    if ((rc = ingest_capture(ctx, src, (size_t)nframes * fb, ctx->stream_in.p, &job))) { (void)ingest_join(job); return rc; }
+    ctx->sc.in_place = true;
+    const uint64_t chunk = ctx->cfg.chunk;
+    // Four segments: every segment pays the latency floor of the block-parallel stages once more (a PLL warm-up is as long for a
+    // quarter of the capture as for all of it: ~7 ms at 250 ksps), so more of them cost more than they hide (3.6 GB: 108 ms
+    // without overlap, 102 / 132 / 144 ms with 4 / 6 / 8 segments).
+    const int K = ctx->tune.overlap_segments > 0 ? ctx->tune.overlap_segments : 4;
+    uint64_t done = 0;
+    for (int k = 1; k <= K && !rc; k++) {
+        const bool last = k == K;
+        const uint64_t upto = last ? nframes : (nframes / (uint64_t)K * (uint64_t)k) / chunk * chunk;
+        if (!last && (upto <= done || upto >= nframes)) continue;
+        const auto t0 = std::chrono::steady_clock::now();
+        if ((rc = ingest_wait_prefix(ctx, job, (size_t)upto * fb, ctx->stream))) break;
+        const auto t1 = std::chrono::steady_clock::now();
+        ctx->stream_have = upto - ctx->sc.origin;                   // (window-local, as the pushes keep it)
+        ctx->stream_total = upto;
+        const uint64_t win = upto - ctx->sc.origin;
+        rc = stream_segment(ctx, win, last);
+        if (ctx->tune.debug_overlap) {
+            const auto t2 = std::chrono::steady_clock::now();
+            fprintf(stderr, "segment %d: upto %llu window %llu: waited %.2f ms for the spans, segment %.2f ms (gpu %.2f)\n", k,
+                    (unsigned long long)upto, (unsigned long long)win, std::chrono::duration<double, std::milli>(t1 - t0).count(),
+                    std::chrono::duration<double, std::milli>(t2 - t1).count(), ctx->stats.gpu_ms);
+        }
+        done = upto;
+    }
+    ctx->sc.in_place = false;
+    const int rj = ingest_join(job);
+    return rc ? rc : rj;
 }
 
 static int stream_push(pdt_ctx *ctx, const void *host, uint64_t nframes, int fmt, uint64_t *new_frames)

@@ -218,3 +218,31 @@ def test_large_pushes_take_the_table_sampler(pdt, orc):
         finally:
             os.environ.pop("PDT_SEG_SEQUENTIAL", None)
     assert times[("", 500000)] < 0.6 * times[("1", 500000)], times
+
+
+def test_file_ingest_overlapped_with_the_chain(pdt, orc, tmp_path):
+    """pdt_demod_fd on a large file runs the chain in a few segments over the part of the capture that has arrived (the streaming
+    path, in place).  PDT_OVERLAP_MIN_MB brings the threshold down to this test's size: same text as the oracle, and as the plain call."""
+    import os
+    iq = pdt.synth_capture(0, 250000, 12.0, seed=61)                     # 3 M samples, 300 chunks
+    o = orc.Oracle(orc.POES, 250000, iq)
+    wav = str(tmp_path / "cap.wav")
+    pdt.write_wav(wav, 250000, iq)
+    texts = {}
+    for segs in ("", "3", "7"):
+        if segs:
+            os.environ["PDT_OVERLAP_MIN_MB"] = "1"
+            os.environ["PDT_OVERLAP_SEGMENTS"] = segs
+        try:
+            with pdt.Demodulator(pdt.MODE_POES, 250000) as d:
+                fd = os.open(wav, os.O_RDONLY)
+                try:
+                    d.demod_file(fd, 44, len(iq), 0)
+                finally:
+                    os.close(fd)
+                texts[segs] = d.text()
+                assert d.stats().samples == len(iq) and d.stats().frames == len(o.frames())
+        finally:
+            os.environ.pop("PDT_OVERLAP_MIN_MB", None)
+            os.environ.pop("PDT_OVERLAP_SEGMENTS", None)
+    assert texts[""] == o.text() and texts["3"] == o.text() and texts["7"] == o.text()
