@@ -755,6 +755,15 @@ template <typename T> int run_capture(pdt_ctx *ctx, uint64_t n, int phase = RUN_
         !ctx->tune.agc_unfused && !seg) {
         const long long tile_out = 64ll * 26 * interp;
         agc_tiles_per_block = std::max<long long>(1, (Ba + tile_out / 2) / tile_out);
+        // a walker's look-ahead ring takes 64 KiB of LDS: two wavefronts per CU, 512 on the chip.  An hour at 250 ksps has more
+        // blocks than that (940 wavefronts = two rounds, the second one of a few stragglers): longer blocks, one round
+        // (4.2 -> 3.5 ms; tools/jobs/agc_tpb.sh).  (A batch shares the chip: no gain measured there.)
+        {
+            const long long tiles = (n_out + tile_out - 1) / tile_out;
+            const long long one_round = (tiles + 500ll * 64 - 1) / (500ll * 64);
+            if (ctx->batch_hint <= 1 && tiles / agc_tiles_per_block > 512ll * 64 && one_round <= 4 * agc_tiles_per_block)
+                agc_tiles_per_block = one_round;
+        }
         if (ctx->tune.agc_tpb) agc_tiles_per_block = ctx->tune.agc_tpb;
         Ba = agc_tiles_per_block * tile_out;
     }
