@@ -325,7 +325,7 @@ def main():
             "gardner_walked": int(st.gardner_walked), "gardner_candidates": int(st.gardner_candidates),
             "lock_sample": int(st.lock_sample),
         }
-        if not args.no_cpu:
+        if not args.no_cpu and world == 1:      # (the CPU baseline, e2e and CLI legs belong to the N = 1 line)
             shm = "/dev/shm" if os.path.isdir("/dev/shm") else None
             with tempfile.TemporaryDirectory(dir=shm) as tmp:
                 wav = os.path.join(tmp, f"{cfg}.wav")
