@@ -238,7 +238,7 @@ struct Plan {
 struct Tuning {
     double band_pad = 0.0, pll_warm_scale = 1.0, head_taus = 0.0, agc_k = 0.0, pll_warm_s = 0.0, agc_warm_s = 0.0;
     int ingest_threads = 0, ingest_span_mb = 0, ingest_streams = 0, overlap_segments = 0, overlap_min_mb = 0, fir_wg_per_cu = 0, agc_tpb = 0, gseg = 0, acquire_mode = 0, pll_block = 0, fix_passes = 2;      // acquire_mode: 0 = two-wavefront pipeline, 1 = plain one-lane, 2 = one wavefront
-    bool fir_generic = false, agc_unfused = false, no_excl = false, gtab_nomerge = false, gardner_onebuf = false, gardner_noring = false, gardner_sequential = false, seg_sequential = false, no_overlap = false, debug_overlap = false, ema_noguess = false, debug_sync = false;
+    bool fir_generic = false, agc_unfused = false, no_excl = false, gtab_nomerge = false, gardner_onebuf = false, gardner_noring = false, gardner_sequential = false, seg_sequential = false, no_overlap = false, debug_overlap = false, chain_one_range = false, ema_noguess = false, debug_sync = false;
     void load()
     {
         if (const char *e = getenv("PDT_PLL_WARM_SCALE")) pll_warm_scale = atof(e);
@@ -267,6 +267,7 @@ struct Tuning {
         gardner_sequential = getenv("PDT_GARDNER_SEQUENTIAL") != nullptr;
         seg_sequential = getenv("PDT_SEG_SEQUENTIAL") != nullptr;
         no_overlap = getenv("PDT_NO_OVERLAP") != nullptr;
+        chain_one_range = getenv("PDT_CHAIN_ONE_RANGE") != nullptr;
         debug_overlap = getenv("PDT_DEBUG_OVERLAP") != nullptr;
         if (const char *e = getenv("PDT_OVERLAP_SEGMENTS")) overlap_segments = std::min(64, std::max(1, atoi(e)));
         if (const char *e = getenv("PDT_OVERLAP_MIN_MB")) overlap_min_mb = std::min(1 << 20, std::max(1, atoi(e)));
@@ -322,7 +323,7 @@ struct pdt_ctx {
     hipEvent_t ev0 = nullptr, ev1 = nullptr, ev_fork = nullptr, ev_join = nullptr;
     hipStream_t stream2 = nullptr;     // side stream: block-parallel PLL phase runs beside the sequential acquisition
 
-    DevBuf pcm, pll, lock, fir, agc, sym, symidx, bits, bitsym, hits, frames, taps, mag, seams_pll, seams_agc, scal, lockinfo, term, seams_ema, gtable, gentries, gcand, gmfirst, stiles, gsegmap, gsegstart, gbands, gclist, gneed, agc_maps, pll_head, taps_rot, pll_scratch, tip, sync_scr, agc_raw;
+    DevBuf pcm, pll, lock, fir, agc, sym, symidx, bits, bitsym, hits, frames, taps, mag, seams_pll, seams_agc, scal, lockinfo, term, seams_ema, gtable, gentries, gcand, gmfirst, stiles, gsegmap, gsegstart, gbands, gclist, gneed, gchain, agc_maps, pll_head, taps_rot, pll_scratch, tip, sync_scr, agc_raw;
     bool keep_agc_raw = false;   // pdt_keep_presquelch: also keep the AGC output before Squelch (stage PDT_ST_AGC_RAW)
     // (stream_in is declared with the streaming state below)
     long long gcand_key = -1;          // (chunk_out, step) the candidate list on the device was built for
@@ -1269,21 +1270,44 @@ template <typename T> int run_capture(pdt_ctx *ctx, uint64_t n, int phase = RUN_
             PL.memset_async(ctx->gsegstart.p, 0, (size_t)n_seg * sizeof(GardnerSegStart));
             PDT_LAUNCH(1024, k_gardner_segmap, dim3((unsigned)n_seg), dim3(1024), 0, st, (const unsigned *)ctx->gtable.p, GD, n_chunks,
                                G, (GardnerSegCell *)ctx->gsegmap.p, (const GardnerBand *)ctx->gbands.p);
-            PDT_LAUNCH(256, k_gardner_chain, dim3(1), dim3(256), 0, st,      // 4 wavefronts: a walked chunk is staged 4x faster
-                               (const float *)d_agc, GP, GD, n_chunks,
-                               (const unsigned *)ctx->gtable.p, (const GardnerSegCell *)ctx->gsegmap.p, G,
-                               (GardnerSegStart *)ctx->gsegstart.p, (GardnerEntry<float> *)ctx->gentries.p, d_sc->gstats,
-                               (const GardnerBand *)ctx->gbands.p, n_tab, tab_carry, (seg && seg->have_sampler) ? 1 : 0);
-            PDT_LAUNCH(64, k_gardner_segfill, dim3((unsigned)n_seg), dim3(64), 0, st, (const float *)d_agc, GP, GD, n_chunks,
-                               (const unsigned *)ctx->gtable.p, G, (const GardnerSegStart *)ctx->gsegstart.p,
-                               (GardnerEntry<float> *)ctx->gentries.p);
+            // Long captures: the chain runs range by range; as soon as a range is through, its entry states and symbols are produced
+            // on the side stream (segfill, emission -- chip-wide kernels) while the single workgroup of the chain hops on
+            // (an hour at 250 ksps: chain 1.6 ms + emission 1.8 ms one after the other -> the emission behind the chain).
+            const int n_ranges = (!seg && n_chunks >= 8192 && !ctx->tune.chain_one_range) ? 4 : 1;
+            if ((rc = ctx->gchain.ensure(sizeof(GardnerChainState)))) return rc;
+            const bool side = n_ranges > 1;
+            hipStream_t st_emit = side ? ctx->stream2 : st;
             L.end();
-            L.begin("gardner");
-            // per-chunk emission: small LDS windows so that every chunk of a 10-minute capture is resident at once
-            PDT_LAUNCH(256, (k_gardner<float, PDT_GEMIT_LEN, PDT_GEMIT_OUT>), dim3((unsigned)n_chunks), dim3(PDT_GARDNER_THREADS), 0, st, (const float *)d_agc,
-                               (const float *)d_lock, GP, (float *)d_sym, d_symidx, &d_sc->nsym, sym_cap,
-                               (const GardnerEntry<float> *)ctx->gentries.p, tab_carry, (SamplerCarry<float> *)d_carry_out);
-            L.end();
+            long long c_lo = 0;
+            for (int r = 0; r < n_ranges; r++) {
+                const long long c_hi = (r == n_ranges - 1) ? n_chunks : (n_chunks * (r + 1) / n_ranges) / G * G;
+                L.begin("gardner_chain");
+                PDT_LAUNCH(256, k_gardner_chain, dim3(1), dim3(256), 0, st,      // 4 wavefronts: a walked chunk is staged 4x faster
+                                   (const float *)d_agc, GP, GD, n_chunks,
+                                   (const unsigned *)ctx->gtable.p, (const GardnerSegCell *)ctx->gsegmap.p, G,
+                                   (GardnerSegStart *)ctx->gsegstart.p, (GardnerEntry<float> *)ctx->gentries.p, d_sc->gstats,
+                                   (const GardnerBand *)ctx->gbands.p, n_tab, tab_carry, (seg && seg->have_sampler) ? 1 : 0, c_hi,
+                                   (GardnerChainState *)ctx->gchain.p, r == 0 ? 1 : 0);
+                L.end();
+                if (side) PL.simple(OP_FORK);
+                const long long s_lo = c_lo / G, s_hi = (c_hi + G - 1) / G;
+                L.begin("gardner", st_emit);
+                if (s_hi > s_lo)
+                    PDT_LAUNCH(64, k_gardner_segfill, dim3((unsigned)(s_hi - s_lo)), dim3(64), 0, st_emit, (const float *)d_agc, GP, GD, n_chunks,
+                                       (const unsigned *)ctx->gtable.p, G, (const GardnerSegStart *)ctx->gsegstart.p,
+                                       (GardnerEntry<float> *)ctx->gentries.p, s_lo);
+                // per-chunk emission: small LDS windows so that every chunk of a 10-minute capture is resident at once
+                if (c_hi > c_lo)
+                    PDT_LAUNCH(256, (k_gardner<float, PDT_GEMIT_LEN, PDT_GEMIT_OUT>), dim3((unsigned)(c_hi - c_lo)), dim3(PDT_GARDNER_THREADS), 0, st_emit,
+                                       (const float *)d_agc, (const float *)d_lock, GP, (float *)d_sym, d_symidx, &d_sc->nsym, sym_cap,
+                                       (const GardnerEntry<float> *)ctx->gentries.p, tab_carry, (SamplerCarry<float> *)d_carry_out, c_lo);
+                L.end();
+                c_lo = c_hi;
+            }
+            if (side) {
+                PL.simple(OP_JOIN_RECORD);
+                PL.simple(OP_JOIN_WAIT);
+            }
         }
     } else if (use_mm) {
         // MMClockRecovery at the sampler's call site: sequential, one wavefront
@@ -1323,7 +1347,7 @@ template <typename T> int run_capture(pdt_ctx *ctx, uint64_t n, int phase = RUN_
                                d_sym, d_symidx, &d_sc->nsym, sym_cap);
         else
             PDT_LAUNCH(256, (k_gardner<T, GardnerLds<T>::LEN, GardnerLds<T>::OUT>), dim3(1), dim3(256), 0, st, d_agc, d_lock, GP, d_sym, d_symidx,
-                               &d_sc->nsym, sym_cap, (const GardnerEntry<T> *)nullptr, carry_in, d_carry_out);
+                               &d_sc->nsym, sym_cap, (const GardnerEntry<T> *)nullptr, carry_in, d_carry_out, 0ll);
         L.end();
     }
 

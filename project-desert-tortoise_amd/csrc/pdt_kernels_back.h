@@ -290,7 +290,8 @@ __device__ __forceinline__ void k_gardner(const T *__restrict__ in, const T *__r
                                                                   unsigned long long *__restrict__ nsym_out,
                                                                   long long sym_cap,
                                                                   const GardnerEntry<T> *__restrict__ entries,
-                                                                  SamplerCarry<T> carry, SamplerCarry<T> *__restrict__ carry_out)
+                                                                  SamplerCarry<T> carry, SamplerCarry<T> *__restrict__ carry_out,
+                                                                  long long c_off /* parallel mode: chunk of block 0 */)
 {
     __shared__ T win[LEN];
     __shared__ T o_val[OUT];
@@ -302,7 +303,7 @@ __device__ __forceinline__ void k_gardner(const T *__restrict__ in, const T *__r
     long long count = carry.count0;
     long long c_begin = carry.c_first, c_end = n_chunks;
     if (entries) {
-        c_begin = blockIdx.x;
+        c_begin = blockIdx.x + c_off;
         c_end = c_begin + 1;
         if (c_begin >= n_chunks || c_begin < carry.c_first) return;      // (a stream segment: the chunks in front are history)
         const GardnerEntry<T> e = entries[c_begin];
@@ -1553,6 +1554,15 @@ __device__ __forceinline__ void k_gardner_segmap(const unsigned *__restrict__ ta
     }
 }
 
+// where the chain stands between two launches of k_gardner_chain (long captures run it range by range, so that the entry
+// states and the symbols of one range are produced -- segfill, emission, on the side stream -- while the chain hops on)
+struct GardnerChainState {
+    long long c, off;
+    unsigned key, walked, i_last;
+    int have_key;
+    float ns, prev, half, q_last;
+};
+
 __device__ __forceinline__ void k_gardner_chain(const float *__restrict__ in, GardnerParams<float> P,
                                                                         GardnerDomain D, long long n_chunks,
                                                                         const unsigned *__restrict__ table,
@@ -1561,10 +1571,12 @@ __device__ __forceinline__ void k_gardner_chain(const float *__restrict__ in, Ga
                                                                         GardnerEntry<float> *__restrict__ entries,
                                                                         unsigned *__restrict__ stats /* [2] walked chunks */,
                                                                         const GardnerBand *__restrict__ bands, long long n_tab,
-                                                                        SamplerCarry<float> carry, int have_carry)
+                                                                        SamplerCarry<float> carry, int have_carry,
+                                                                        long long c_stop /* a multiple of G, or n_chunks */,
+                                                                        GardnerChainState *__restrict__ state, int first)
 {
     __shared__ float win[GardnerLds<float>::LEN];
-    {   // statistics of the scouts: candidates evaluated ([3]) and chunks tabulated over the full domain ([1])
+    if (first) {   // statistics of the scouts: candidates evaluated ([3]) and chunks tabulated over the full domain ([1])
         __shared__ unsigned s_sum[2];
         if (threadIdx.x < 2) s_sum[threadIdx.x] = 0;
         __syncthreads();
@@ -1592,9 +1604,15 @@ __device__ __forceinline__ void k_gardner_chain(const float *__restrict__ in, Ga
         S.ns = carry.a; S.prev = carry.b; S.half = carry.c;
         have_key = false;
     }
-    while (c < n_chunks) {
+    if (!first) {
+        const GardnerChainState st = *state;
+        c = st.c; off = st.off; key = st.key; walked = st.walked; have_key = st.have_key != 0;
+        S.ns = st.ns; S.prev = st.prev; S.half = st.half; S.q_last = st.q_last; S.i_last = st.i_last;
+    }
+    bool finished = false;
+    while (c < n_chunks && c < c_stop) {
         // ---- hop over a whole segment
-        if (have_key && (c % G) == 0 && c + G <= n_chunks - 1) {
+        if (have_key && (c % G) == 0 && c + G <= n_chunks - 1 && c + G <= c_stop) {
             const long long s = c / G;
             // (both loads issued together: the cell's address is valid whatever the key, its content only inside the band)
             const GardnerBand b0 = bands[c];
@@ -1619,7 +1637,7 @@ __device__ __forceinline__ void k_gardner_chain(const float *__restrict__ in, Ga
             e.ns = S.ns; e.prev = S.prev; e.half = S.half; e.offset = off;
             entries[c] = e;
         }
-        if (c + 1 >= n_chunks) break;
+        if (c + 1 >= n_chunks) { finished = true; break; }
         unsigned cell = have_key ? gardner_cell(table, stride, bands[c], c, key) : PDT_GTAB_MISS;
         cell = uniform<unsigned>(cell);
         if (cell == PDT_GTAB_MISS) {
@@ -1640,15 +1658,21 @@ __device__ __forceinline__ void k_gardner_chain(const float *__restrict__ in, Ga
         have_key = true;
         c++;
     }
-    if (threadIdx.x == 0) stats[2] = walked;
+    if (threadIdx.x == 0) {
+        if (finished || c >= n_chunks) stats[2] = walked;
+        GardnerChainState st;
+        st.c = c; st.off = off; st.key = key; st.walked = walked; st.have_key = have_key ? 1 : 0;
+        st.ns = S.ns; st.prev = S.prev; st.half = S.half; st.q_last = S.q_last; st.i_last = S.i_last;
+        *state = st;
+    }
 }
 
 __device__ __forceinline__ void k_gardner_segfill(const float *__restrict__ in, GardnerParams<float> P, GardnerDomain D,
                                                          long long n_chunks, const unsigned *__restrict__ table, int G,
                                                          const GardnerSegStart *__restrict__ segstart,
-                                                         GardnerEntry<float> *__restrict__ entries)
+                                                         GardnerEntry<float> *__restrict__ entries, long long seg_first)
 {
-    const long long s = blockIdx.x;
+    const long long s = blockIdx.x + seg_first;
     const long long c0 = s * G;
     if (c0 + G > n_chunks - 1) return;
     const GardnerSegStart ss = segstart[s];
