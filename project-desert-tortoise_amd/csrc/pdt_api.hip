@@ -1006,7 +1006,7 @@ template <typename T> int run_capture(pdt_ctx *ctx, uint64_t n, int phase = RUN_
                                (PllSeam<T> *)ctx->seams_pll.p, (const T *)d_hphi, (const PllSeam<T> *)d_hseams,
                                (const PllHeadInfo<T> *)d_hinfo, (T *)ctx->pll_scratch.p, d_sc->counters, mode, rb, ro);
             };
-            fix(0, 1, 0, 0);
+            fix(0, 32, 0, 0);
             if (fix_regions > 1) {
                 for (int pass = 0; pass < ctx->tune.fix_passes; pass++) {
                     if (pass & 1) fix(1, (unsigned)fix_regions + 1, fix_region_blocks, fix_region_blocks / 2);
