@@ -237,7 +237,7 @@ struct Plan {
 // context is opened; the demodulation calls never look at the environment.
 struct Tuning {
     double band_pad = 0.0, pll_warm_scale = 1.0, head_taus = 0.0, agc_k = 0.0, pll_warm_s = 0.0, agc_warm_s = 0.0;
-    int ingest_threads = 0, ingest_span_mb = 0, ingest_streams = 0, overlap_segments = 0, overlap_min_mb = 0, fir_wg_per_cu = 0, agc_tpb = 0, gseg = 0, acquire_mode = 0, pll_block = 0, fix_passes = 2;      // acquire_mode: 0 = two-wavefront pipeline, 1 = plain one-lane, 2 = one wavefront
+    int scout_syms = 0, ingest_threads = 0, ingest_span_mb = 0, ingest_streams = 0, overlap_segments = 0, overlap_min_mb = 0, fir_wg_per_cu = 0, agc_tpb = 0, gseg = 0, acquire_mode = 0, pll_block = 0, fix_passes = 2;      // acquire_mode: 0 = two-wavefront pipeline, 1 = plain one-lane, 2 = one wavefront
     bool fir_generic = false, agc_unfused = false, no_excl = false, gtab_nomerge = false, gardner_onebuf = false, gardner_noring = false, gardner_sequential = false, seg_sequential = false, no_overlap = false, debug_overlap = false, chain_one_range = false, ema_noguess = false, debug_sync = false;
     void load()
     {
@@ -249,6 +249,7 @@ struct Tuning {
         if (const char *e = getenv("PDT_AGC_K")) agc_k = atof(e);
         if (const char *e = getenv("PDT_AGC_TPB")) agc_tpb = std::max(1, atoi(e));
         if (const char *e = getenv("PDT_PLL_BLOCK")) pll_block = atoi(e);
+        if (const char *e = getenv("PDT_SCOUT_SYMS")) scout_syms = std::max(16, atoi(e));
         if (const char *e = getenv("PDT_FIR_WG_PER_CU")) fir_wg_per_cu = std::min(4096, std::max(1, atoi(e)));
         if (const char *e = getenv("PDT_INGEST_THREADS")) ingest_threads = std::min(128, std::max(1, atoi(e)));
         if (const char *e = getenv("PDT_INGEST_SPAN_MB")) ingest_span_mb = std::min(256, std::max(1, atoi(e)));
@@ -1238,9 +1239,12 @@ template <typename T> int run_capture(pdt_ctx *ctx, uint64_t n, int phase = RUN_
             L.begin("gardner_table");
             if ((rc = ctx->gclist.ensure((size_t)n_tab * PDT_GTAB_LIST * sizeof(unsigned)))) return rc;
             // (the table is never initialised as a whole -- 12 GB for an hour at 250 ksps: every look-up checks the chunk's band)
+            // the scouts need symbols, not samples, to settle on the chunk's timing: the same number of them at every rate
+            const int scout_syms = ctx->tune.scout_syms > 0 ? ctx->tune.scout_syms : 455;
+            const int scout_tail = (int)std::min<long long>(PDT_GTAB_TAIL, std::max<long long>(256, (long long)((double)scout_syms * (double)GP.step) + 16));
             PDT_LAUNCH(64, k_gardner_scout, dim3((unsigned)n_tab), dim3(64), 0, st, (const float *)d_agc, GP, GD, n_tab,
                                (const int *)ctx->gmfirst.p, (const unsigned *)ctx->gcand.p, (unsigned *)ctx->gtable.p,
-                               (GardnerBand *)ctx->gbands.p, (unsigned *)ctx->gclist.p, d_sc->gstats);
+                               (GardnerBand *)ctx->gbands.p, (unsigned *)ctx->gclist.p, d_sc->gstats, scout_tail);
             {
                 // locked chunks carry 100-300 candidates that merge quickly: see k_gardner_table_merge
                 if (ctx->tune.gtab_nomerge) {

@@ -885,7 +885,9 @@ struct GardnerDomain {
     int idx_bits;      // table cell = candidate index (low idx_bits bits) | symbol count of the chunk (the rest)
 };
 
-#define PDT_GTAB_TAIL 4096           // samples of the previous chunk the scouts run over
+#ifndef PDT_GTAB_TAIL
+#define PDT_GTAB_TAIL 4096           // most samples of the previous chunk the scouts can run over (LDS)
+#endif
 #ifndef PDT_GTAB_THREADS
 #define PDT_GTAB_THREADS 64           // table kernel: threads per block (one or two candidates per lane)
 #endif
@@ -977,7 +979,8 @@ __device__ __forceinline__ void k_gardner_scout(const float *__restrict__ in, Ga
                                                        long long n_tab_chunks, const int *__restrict__ m_first,
                                                        const unsigned *__restrict__ cand_k, unsigned *__restrict__ table,
                                                        GardnerBand *__restrict__ bands, unsigned *__restrict__ clist,
-                                                       unsigned *__restrict__ stats /* [1] full-domain chunks [3] candidates */)
+                                                       unsigned *__restrict__ stats /* [1] full-domain chunks [3] candidates */,
+                                                       int tail_max /* samples of the previous chunk the scouts run over, <= PDT_GTAB_TAIL */)
 {
     __shared__ float tail[PDT_GTAB_TAIL];
     __shared__ int s_sorted[64], s_lo[64], s_hi[64], s_off[65];
@@ -986,7 +989,7 @@ __device__ __forceinline__ void k_gardner_scout(const float *__restrict__ in, Ga
     const long long C = P.chunk_out;
     const long long base = c * C;
     const int n_cur = (int)C;
-    const int tail_n = (C < PDT_GTAB_TAIL) ? (int)C : PDT_GTAB_TAIL;
+    const int tail_n = (C < tail_max) ? (int)C : tail_max;
     const int lane = threadIdx.x;
     GardnerBand bd;
     bd.j_lo = 0;
