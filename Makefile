@@ -30,11 +30,11 @@ bin/synth_wav: $(PKG)/synth/pdt_synth.c $(PKG)/synth/pdt_synth.h
 
 bin/demodPOES: $(PKG)/host/demod_main.c include/pdt.h $(LIBPDT)
 	mkdir -p bin
-	$(CC) $(CFLAGS) -Iinclude -o $@ $(PKG)/host/demod_main.c -L$(CSRC) -lpdt -Wl,-rpath,'$$ORIGIN/../$(CSRC)'
+	$(CC) $(CFLAGS) -Iinclude -o $@ $(PKG)/host/demod_main.c -L$(CSRC) -lpdt -lm -Wl,-rpath,'$$ORIGIN/../$(CSRC)'
 
 bin/demodARGOS: $(PKG)/host/demod_main.c include/pdt.h $(LIBPDT)
 	mkdir -p bin
-	$(CC) $(CFLAGS) -DPDT_ARGOS -Iinclude -o $@ $(PKG)/host/demod_main.c -L$(CSRC) -lpdt -Wl,-rpath,'$$ORIGIN/../$(CSRC)'
+	$(CC) $(CFLAGS) -DPDT_ARGOS -Iinclude -o $@ $(PKG)/host/demod_main.c -L$(CSRC) -lpdt -lm -Wl,-rpath,'$$ORIGIN/../$(CSRC)'
 
 bin/demodMulti: $(PKG)/host/demod_multi.c include/pdt.h include/pdt_gather.h $(LIBPDT) $(LIBGATHER)
 	mkdir -p bin

@@ -174,6 +174,27 @@ int  pdt_set_stream(pdt_ctx *ctx, void *hip_stream);
  * reference's `-r` option dumps (ARGOSdemod/main.c:171-180,273-274).  Costs one more stream-sized buffer.            */
 int  pdt_keep_presquelch(pdt_ctx *ctx, int enable);
 
+/* Also keep what the reference's chunk loop knows after every chunk, in the following pdt_demod_* calls (whole captures; not
+ * the streaming entry points): the value CarrierTrackPLL returns for the chunk -- averagePhase, the running mean of
+ * |arg(PLL output)| with alpha 0.00005, after the chunk's last sample (CarrierTrackingPLL.c:80,124,152,277), from which
+ * POESTIPdemod/main.c:461-481 prints its quality figure 10 log10((pi/2 - averagePhase)^2) -- and the return values of the
+ * sampler, the Manchester decoder and the byte synchroniser for that chunk (main.c:438,445,454-460), i.e. everything the
+ * "\r" progress line shows.  Before the lock the acquisition kernel delivers averagePhase as it goes; after it, one more
+ * block-parallel EMA over the whole capture (same scheme and the same bit-for-bit guarantee as the lock detector's stream).
+ * Costs two stream-sized buffers and ~0.15 us per 1000 samples of walker time; off by default.                            */
+int  pdt_keep_quality(pdt_ctx *ctx, int enable);
+typedef struct pdt_chunk_report {
+    uint64_t samples;     /* nSamples of the chunk (the last one may be short)                                          */
+    double   avg_phase;   /* CarrierTrackPLL's return value for this chunk, exactly (float widened for POES)            */
+    uint64_t symbols;     /* GardenerClockRecovery / MMClockRecovery return value                                       */
+    uint64_t bits;        /* ManchesterDecode return value                                                              */
+    uint64_t frames;      /* ByteSyncOnSyncword / FindSyncWords return value (sync words found in this chunk's bits)    */
+    double   time0;       /* waveDataTime[0] when the progress line is printed (ARGOS: after the in-place compactions)  */
+} pdt_chunk_report;
+/* Per-chunk reports of the last pdt_demod_* call, in chunk order; returns the number copied (out == NULL: the number
+ * available; 0 unless pdt_keep_quality was on).                                                                          */
+uint64_t pdt_chunk_reports(const pdt_ctx *ctx, pdt_chunk_report *out, uint64_t max_chunks);
+
 /* Demodulate one whole capture: nframes interleaved little-endian int16 I,Q pairs
  * in host memory (copied to the GPU) ...                                                        */
 int  pdt_demod_pcm16(pdt_ctx *ctx, const int16_t *iq_host, uint64_t nframes);

@@ -176,6 +176,12 @@ int main(int argc, char **argv)
 #endif
     }
     DT Fs = (DT)header.sample_rate;
+#ifdef ARGOS
+    long num_samples = (8 * header.data_size) / (header.channels * header.bits_per_sample);        /* ARGOSdemod/main.c:244 */
+#else
+    unsigned long num_samples = 44515000;                                                         /* main.c:337 */
+    if (!is_raw) num_samples = (8.0 * header.data_size) / (header.channels * header.bits_per_sample);   /* main.c:349 */
+#endif
 
 #ifdef ARGOS
     const int interp = 1, N = 50;
@@ -197,6 +203,14 @@ int main(int argc, char **argv)
 
     unsigned long i = 0, nSamples, nSymbols, nBits, totalFrames = 0;
     double dsp_s = 0, t_dsp;
+    /* the progress line of the chunk loop (POESTIPdemod/main.c:457-481, ARGOSdemod/main.c:286-296), written to <dump>.progress
+     * instead of the console; <dump>.avg = CarrierTrackPLL's return value of every pass of the loop */
+    FILE *dprog = dopen(dump, "progress"), *davg = dopen(dump, "avg");
+    unsigned long totalSymbols = 0, totalBits = 0, totalSamples = 0;
+    int nFrames = 0, totalFramesI = 0;
+    DT averagePhase = 0, percentComplete = 0;
+    char qualityString[20];
+    (void)qualityString;
     while (!feof(in)) {
         nSamples = is_raw ? GetComplexRawChunk(in, header, waveData, waveDataTime, chunk)
                           : GetComplexWaveChunk(in, header, waveData, waveDataTime, chunk);
@@ -210,7 +224,7 @@ int main(int argc, char **argv)
         t_dsp = now_s();
 #ifdef ARGOS
         /* ARGOSdemod/main.c:265-284 */
-        CarrierTrackPLL(waveData, dataStreamReal, lockSignalStream, nSamples, Fs, (550.0), (0.1),
+        averagePhase = CarrierTrackPLL(waveData, dataStreamReal, lockSignalStream, nSamples, Fs, (550.0), (0.1),
                         (3.1831) * (2.0 * M_PI / Fs), (16) * (2.0 * M_PI / Fs), (16) * (2.0 * M_PI / Fs));
         dput(dpll, dataStreamReal, sizeof(DT), nSamples);
         dput(dlock, lockSignalStream, sizeof(DT), nSamples);
@@ -229,16 +243,17 @@ int main(int argc, char **argv)
         nBits = ManchesterDecode(dataStreamSymbols, waveDataTime, nSymbols, dataStreamBits, (0.5));
         dput(dbits, dataStreamBits, 1, nBits);
         dput(dbitt, waveDataTime, sizeof(DT), nBits);
-        totalFrames += FindSyncWords(dataStreamBits, waveDataTime, nBits, "0001011110000", 13, out);
+        nFrames = FindSyncWords(dataStreamBits, waveDataTime, nBits, "0001011110000", 13, out);
+        totalFrames += nFrames;
 #else
         /* POESTIPdemod/main.c:413-454 */
         if (live) {                                             /* POESTIPdemodPortAudio/main.c:41-57,367,370 */
-            CarrierTrackPLL(waveData, dataStreamReal, lockSignalStream, nSamples, Fs, (4500.0), (0.10),
+            averagePhase = CarrierTrackPLL(waveData, dataStreamReal, lockSignalStream, nSamples, Fs, (4500.0), (0.10),
                             0.3979 * (2.0 * M_PI / Fs), 198.9437 * (2.0 * M_PI / Fs), 10.3451 * (2.0 * M_PI / Fs));
             dput(dlock, lockSignalStream, sizeof(DT), nSamples);
             Squelch(dataStreamReal, lockSignalStream, nSamples, (0.05));
         } else
-        CarrierTrackPLL(waveData, dataStreamReal, NULL, nSamples, Fs, (4500.0), (0.08),
+        averagePhase = CarrierTrackPLL(waveData, dataStreamReal, NULL, nSamples, Fs, (4500.0), (0.08),
                         0.3979 * (2.0 * M_PI / Fs), 127.3240 * (2.0 * M_PI / Fs), 10.3451 * (2.0 * M_PI / Fs));
         dput(dpll, dataStreamReal, sizeof(DT), nSamples);
         LowPassFilterInterp(waveDataTime, dataStreamReal, dataStreamLPF, dataStreamLPFTime, nSamples, filterCoeffs, N, interp);
@@ -257,10 +272,33 @@ int main(int argc, char **argv)
         nBits = ManchesterDecode(dataStreamSymbols, dataStreamLPFTime, nSymbols, dataStreamBits, live ? (0.75) : 1.0);   /* twin: main.c:65,393 */
         dput(dbits, dataStreamBits, 1, nBits);
         dput(dbitt, dataStreamLPFTime, sizeof(DT), nBits);
-        totalFrames += ByteSyncOnSyncword(dataStreamBits, dataStreamLPFTime, nBits, "1110110111100010000", 19, out);
+        nFrames = ByteSyncOnSyncword(dataStreamBits, dataStreamLPFTime, nBits, "1110110111100010000", 19, out);
+        totalFrames += nFrames;
 #endif
         dsp_s += now_s() - t_dsp;
         if (dcnt) fprintf(dcnt, "%lu %lu %lu\n", nSamples, nSymbols, nBits);
+        dput(davg, &averagePhase, sizeof(DT), 1);
+        totalBits += nBits;
+        totalFramesI += nFrames;
+        totalSymbols += nSymbols;
+        totalSamples += nSamples;
+        if (dprog && ((((DT)(i) / num_samples) * 100.0 - percentComplete > 0.15) || feof(in))) {
+            percentComplete = ((DT)(i) / num_samples) * 100.0;
+            fprintf(dprog, "\r");
+#ifdef ARGOS
+            fprintf(dprog, "%0.1f%% %0.3f Ks : %0.1f Sec: %ld Sym : %ld Bits : %d Packets", ((DT)(i) / num_samples) * 100.0,
+                    (totalSamples) / 1000.0, waveDataTime[0], totalSymbols, totalBits, totalFramesI);
+#else
+            fprintf(dprog, "%f\t", fabs((M_PI / 2.0) - averagePhase));
+            averagePhase = 10.0 * log10f(powf(fabs((M_PI / 2.0) - averagePhase), 2));   /* <tgmath.h> there: log10 of a float */
+            if (averagePhase > -4.3) snprintf(qualityString, 20, "%s%02.1fQ%s", "\x1b[32m", averagePhase, "\x1b[0m");
+            else if (averagePhase > -5) snprintf(qualityString, 20, "%s%02.1fQ%s", "\x1b[33m", averagePhase, "\x1b[0m");
+            else if (averagePhase > -6) snprintf(qualityString, 20, "%s%02.1fQ%s", "\x1b[33m", averagePhase, "\x1b[0m");
+            else snprintf(qualityString, 20, "%s%02.1fQ%s", "\x1b[31m", averagePhase, "\x1b[0m");
+            fprintf(dprog, "%0.1f%% %0.3f Ks : %0.1f Sec: %ld Sym : %ld Bits : %d Frames : %s   ", ((DT)(i) / num_samples) * 100.0,
+                    (totalSamples) / 1000.0, waveDataTime[0], totalSymbols, totalBits, totalFramesI, qualityString);
+#endif
+        }
     }
     fclose(in);
     fclose(out);

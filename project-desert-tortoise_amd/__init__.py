@@ -102,6 +102,10 @@ class TipSummary(C.Structure):
                 ("time_frames", C.c_uint64)]
 
 
+# == pdt_chunk_report (48 bytes): what the reference's chunk loop knows after every chunk
+CHUNK_DTYPE = np.dtype([("samples", "<u8"), ("avg_phase", "<f8"), ("symbols", "<u8"), ("bits", "<u8"), ("frames", "<u8"),
+                        ("time0", "<f8")])
+
 TIP_DTYPE = np.dtype([("minor_id", "<u2"), ("spacecraft", "u1"), ("parity", "u1"), ("checked", "u1"), ("has_time", "u1"),
                       ("day", "<u2"), ("day_ms", "<i4")])        # == pdt_tip_frame (12 bytes)
 
@@ -117,6 +121,7 @@ ABI_SYMBOLS = [
     "pdt_format_frames", "pdt_read_stage", "pdt_stage_len", "pdt_kernel_times", "pdt_make_lpf",
     "pdt_wav_parse_header", "pdt_time_axis", "pdt_stage_bytesync", "pdt_tip_check", "pdt_tip_frames",
     "pdt_stream_begin", "pdt_stream_push_pcm16", "pdt_stream_push_f32", "pdt_stream_end", "pdt_stream_frames",
+    "pdt_keep_quality", "pdt_chunk_reports",
     "pdt_keep_presquelch", "pdt_demod_fd", "pdt_format_records", "pdt_stream_retained", "pdt_host_math", "pdt_get_device",
 ]
 
@@ -176,6 +181,10 @@ def lib():
     L.pdt_host_math.argtypes = [C.c_int, C.c_void_p, C.c_uint64, C.c_void_p, C.c_void_p]
     L.pdt_stream_retained.argtypes = [C.c_void_p]
     L.pdt_stream_retained.restype = C.c_uint64
+    L.pdt_keep_quality.argtypes = [C.c_void_p, C.c_int]
+    L.pdt_keep_quality.restype = C.c_int
+    L.pdt_chunk_reports.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64]
+    L.pdt_chunk_reports.restype = C.c_uint64
     L.pdt_tip_check.argtypes = [C.c_void_p, C.POINTER(TipSummary)]
     L.pdt_tip_frames.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64]
     L.pdt_tip_frames.restype = C.c_uint64
@@ -264,6 +273,20 @@ class Demodulator:
         """Also keep the AGC output before Squelch (stage ST_AGC_RAW): what the reference's -r option dumps."""
         _check(self._L.pdt_keep_presquelch(self._h, int(enable)), "pdt_keep_presquelch")
         return self
+
+    def keep_quality(self, enable: bool = True):
+        """Also keep the per-chunk reports (CarrierTrackPLL's return value = averagePhase, symbol / bit / frame counts):
+        what the reference's progress line shows (POESTIPdemod/main.c:457-481)."""
+        _check(self._L.pdt_keep_quality(self._h, int(enable)), "pdt_keep_quality")
+        return self
+
+    def chunk_reports(self) -> np.ndarray:
+        n = int(self._L.pdt_chunk_reports(self._h, None, 0))
+        out = np.zeros(n, dtype=CHUNK_DTYPE)
+        if n:
+            got = int(self._L.pdt_chunk_reports(self._h, out.ctypes.data, n))
+            out = out[:got]
+        return out
 
     def set_stream(self, stream_handle: int):
         _check(self._L.pdt_set_stream(self._h, C.c_void_p(stream_handle)), "pdt_set_stream")

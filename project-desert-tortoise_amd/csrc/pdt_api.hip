@@ -326,6 +326,13 @@ struct pdt_ctx {
 
     DevBuf pcm, pll, lock, fir, agc, sym, symidx, bits, bitsym, hits, frames, taps, mag, seams_pll, seams_agc, scal, lockinfo, term, seams_ema, gtable, gentries, gcand, gmfirst, stiles, gsegmap, gsegstart, gbands, gclist, gneed, gchain, agc_maps, pll_head, taps_rot, pll_scratch, tip, sync_scr, agc_raw;
     bool keep_agc_raw = false;   // pdt_keep_presquelch: also keep the AGC output before Squelch (stage PDT_ST_AGC_RAW)
+    // pdt_keep_quality: the averagePhase stream (what CarrierTrackPLL returns, chunk by chunk) and the per-chunk counts
+    bool keep_quality = false;
+    DevBuf avgph, term_ap, seams_q, chunkinfo;
+    void *qual_pin = nullptr;
+    size_t qual_pin_cap = 0;
+    uint64_t pend_chunks = 0;           // ChunkInfo records in flight (0 = none asked for)
+    std::vector<pdt::ChunkInfo> chunk_host;
     // (stream_in is declared with the streaming state below)
     long long gcand_key = -1;          // (chunk_out, step) the candidate list on the device was built for
     int gardner_mode = 0;              // 0 sequential, 1 state table (last run)
@@ -822,6 +829,34 @@ template <typename T> int run_capture(pdt_ctx *ctx, uint64_t n, int phase = RUN_
     if ((rc = ctx->agc.ensure((size_t)((seg ? n_out : std::max(n_out, lt_elems)) + 1) * sizeof(T)))) return rc;
     if (ctx->keep_agc_raw && (rc = ctx->agc_raw.ensure((size_t)(n_out + 1) * sizeof(T)))) return rc;
     if (ctx->keep_agc_raw) AP.raw_out = (T *)ctx->agc_raw.p;
+    // quality figure (pdt_keep_quality; whole captures only): averagePhase is one more EMA of the lock detector's kind
+    // (CarrierTrackingPLL.c:80,124,152), alpha 0.00005 -> blocks of one time constant, 16 of warm-up behind the affine guess
+    const bool quality = ctx->keep_quality && !seg && N > 0;
+    const T avg_alpha = (T)0.00005;
+    const long long Bq = std::max<long long>(64, round4((long long)(1.0 / (double)avg_alpha)));
+    const long long Wq = 16 * Bq;
+    const long long nb_q = N / Bq + 2;
+    double *d_q_zresp = nullptr, *d_q_guess = nullptr;
+    if (quality) {
+        if ((rc = ctx->avgph.ensure((size_t)(N + 1) * sizeof(T)))) return rc;
+        if ((rc = ctx->term_ap.ensure((size_t)(N + 1) * sizeof(T)))) return rc;
+        if ((rc = ctx->seams_q.ensure((size_t)nb_q * (sizeof(EmaSeam<T>) + 2 * sizeof(double))))) return rc;
+        if ((rc = ctx->chunkinfo.ensure((size_t)(n_chunks + 1) * sizeof(ChunkInfo)))) return rc;
+        d_q_zresp = (double *)((EmaSeam<T> *)ctx->seams_q.p + nb_q);
+        d_q_guess = d_q_zresp + nb_q;
+        const size_t want = (size_t)(n_chunks + 1) * sizeof(ChunkInfo);
+        if (want > ctx->qual_pin_cap) {
+            if (ctx->qual_pin) (void)hipHostFree(ctx->qual_pin);
+            ctx->qual_pin = nullptr;
+            ctx->qual_pin_cap = 0;
+            if (hipHostMalloc(&ctx->qual_pin, want + want / 4, hipHostMallocDefault) != hipSuccess) {
+                (void)hipGetLastError();
+                return PDT_ERR_NOMEM;
+            }
+            ctx->qual_pin_cap = want + want / 4;
+        }
+    }
+    T *d_avgph = quality ? (T *)ctx->avgph.p : nullptr;
     if ((rc = ctx->sym.ensure((size_t)sym_cap * sizeof(T)))) return rc;
     if ((rc = ctx->symidx.ensure((size_t)sym_cap * sizeof(long long)))) return rc;
     if ((rc = ctx->bits.ensure((size_t)bit_cap))) return rc;
@@ -939,9 +974,9 @@ template <typename T> int run_capture(pdt_ctx *ctx, uint64_t n, int phase = RUN_
         li.freq_at_lock = 0; li.avg_at_lock = (T)seg->avg_at_lock;
         memcpy(spin + 64, &li, sizeof li);
         PL.copy(OP_H2D, d_info, spin + 64, sizeof li);
-    } else if (ctx->tune.acquire_mode == 1)        // plain one-lane form, kept for A/B checks
+    } else if (ctx->tune.acquire_mode == 1 && !quality)        // plain one-lane form, kept for A/B checks
         PDT_LAUNCH(64, k_pll_acquire<T>, dim3(1), dim3(64), 0, st, d_pcm, N, PP, d_pll, d_lock, d_info);
-    else if (ctx->tune.acquire_mode == 2) {   // single-wavefront batched form, kept for A/B checks
+    else if (ctx->tune.acquire_mode == 2 && !quality) {   // single-wavefront batched form, kept for A/B checks
         if (slow_wrap)
             PDT_LAUNCH(64, (k_pll_acquire_fast<T, true>), dim3(1), dim3(64), 0, st, d_pcm, N, PP, d_pll, d_lock,
                                d_info);
@@ -950,13 +985,13 @@ template <typename T> int run_capture(pdt_ctx *ctx, uint64_t n, int phase = RUN_
                                d_info);
     } else if (slow_wrap)
         PDT_LAUNCH(128, (k_pll_acquire_pipe<T, true>), dim3(1), dim3(128), 0, st, d_pcm, N, PP, d_pll, d_lock,
-                           d_info);
+                           d_info, d_avgph);
     else if (serial_excl)
         PDT_LAUNCH(128, (k_pll_acquire_pipe<T, false, true>), dim3(1), dim3(128), 0, st, d_pcm, N, PP, d_pll, d_lock,
-                           d_info);
+                           d_info, d_avgph);
     else
         PDT_LAUNCH(128, (k_pll_acquire_pipe<T, false>), dim3(1), dim3(128), 0, st, d_pcm, N, PP, d_pll, d_lock,
-                           d_info);
+                           d_info, d_avgph);
     L.end();
     if (N > 0) {
         const long long grid = grid_pll;
@@ -1038,6 +1073,22 @@ template <typename T> int run_capture(pdt_ctx *ctx, uint64_t n, int phase = RUN_
                                d_info, Be, We, d_lock, (EmaSeam<T> *)ctx->seams_ema.p, (const double *)(ema_guess ? d_ema_guess : nullptr));
             PDT_LAUNCH(64, k_lock_ema_fix<T>, dim3(1), dim3(64), 0, st, (const T *)ctx->term.p, N, PP.lock_alpha, d_info,
                                Be, d_lock, (EmaSeam<T> *)ctx->seams_ema.p, &d_sc->counters[1]);
+            L.end();
+        }
+        if (quality) {
+            // averagePhase after the lock: its input term from the phases (still in place), then the EMA like the lock detector's
+            L.begin("quality");
+            T *d_tap = (T *)ctx->term_ap.p;
+            PDT_LAUNCH(256, (k_pll_mix<T, false, true>), dim3((unsigned)lt_groups), dim3(256), 0, st, d_pcm, d_phi, N, Bp, PP,
+                               d_info, (T *)nullptr, d_tap);
+            PDT_LAUNCH(64, k_lock_ema_zero<T>, dim3((unsigned)((nb_q + 63) / 64)), dim3(64), 0, st, (const T *)d_tap, N,
+                               avg_alpha, d_info, Bq, d_q_zresp);
+            PDT_LAUNCH(1024, (k_lock_ema_guess<T, true>), dim3(1), dim3(1024), 0, st, (const double *)d_q_zresp, N, avg_alpha, d_info, Bq,
+                               pow(1.0 - (double)avg_alpha, (double)Bq), d_q_guess);
+            PDT_LAUNCH(64, (k_lock_ema<T, true>), dim3((unsigned)((nb_q + 63) / 64)), dim3(64), 0, st, (const T *)d_tap, N, avg_alpha,
+                               d_info, Bq, Wq, d_avgph, (EmaSeam<T> *)ctx->seams_q.p, (const double *)d_q_guess);
+            PDT_LAUNCH(64, k_lock_ema_fix<T>, dim3(1), dim3(64), 0, st, (const T *)d_tap, N, avg_alpha, d_info,
+                               Bq, d_avgph, (EmaSeam<T> *)ctx->seams_q.p, &d_sc->pad0_);
             L.end();
         }
         if (live) {                                            // twin main.c:370, DSP_SQLCH_THRESH 0.05 (:55)
@@ -1378,6 +1429,15 @@ template <typename T> int run_capture(pdt_ctx *ctx, uint64_t n, int phase = RUN_
                    (long long)bit0, d_tail);
         PL.copy(OP_D2H, spin + 4096, d_tail, sizeof(SegTail<T>));
     }
+    ctx->pend_chunks = 0;
+    if (ctx->keep_quality && !seg && n_chunks > 0) {
+        // (N > 0 here; a context without a PLL run -- never -- would leave avg_phase 0)
+        PDT_LAUNCH(256, k_chunk_info<T>, dim3((unsigned)((n_chunks + 255) / 256)), dim3(256), 0, st, (const T *)d_avgph, N, chunk, n_chunks,
+                           interp, (const long long *)d_symidx, (const unsigned long long *)&d_sc->nsym, (const unsigned *)d_bitsym,
+                           (const unsigned long long *)&d_sc->nbits, (ChunkInfo *)ctx->chunkinfo.p);
+        PL.copy(OP_D2H, ctx->qual_pin, ctx->chunkinfo.p, (size_t)n_chunks * sizeof(ChunkInfo));
+        ctx->pend_chunks = (uint64_t)n_chunks;
+    }
     PL.simple(OP_EV1);
 
     // ---- results back to the host
@@ -1427,6 +1487,12 @@ template <typename T> int run_capture(pdt_ctx *ctx, uint64_t n, int phase = RUN_
             HIP_TRY(hipMemcpy(recs.data() + have, d_frames + have, (size_t)(sc.nframes - have) * sizeof(FrameRec), hipMemcpyDeviceToHost));
     }
     ctx->last_nframes = sc.nframes;
+    ctx->chunk_host.clear();
+    if (ctx->pend_chunks && !seg) {
+        ctx->chunk_host.resize((size_t)ctx->pend_chunks);
+        memcpy(ctx->chunk_host.data(), ctx->qual_pin, (size_t)ctx->pend_chunks * sizeof(ChunkInfo));
+    }
+    ctx->pend_chunks = 0;
 
     float ms = 0;
     (void)hipEventElapsedTime(&ms, lead->ev0, lead->ev1);
@@ -1987,10 +2053,12 @@ void pdt_close(pdt_ctx *ctx)
     DevBuf *bufs[] = { &ctx->pcm, &ctx->pll, &ctx->lock, &ctx->fir, &ctx->agc, &ctx->sym, &ctx->symidx, &ctx->bits, &ctx->bitsym,
                        &ctx->hits, &ctx->frames, &ctx->taps, &ctx->mag, &ctx->seams_pll, &ctx->seams_agc, &ctx->scal, &ctx->lockinfo,
                        &ctx->term, &ctx->seams_ema, &ctx->gtable, &ctx->gentries, &ctx->gcand,
-                       &ctx->gmfirst, &ctx->stiles, &ctx->gsegmap, &ctx->gsegstart, &ctx->gbands, &ctx->gclist, &ctx->agc_maps, &ctx->pll_head, &ctx->taps_rot, &ctx->pll_scratch, &ctx->tip, &ctx->stream_in, &ctx->sync_scr, &ctx->agc_raw, &ctx->packs_dev, &ctx->seg_dev, &ctx->lt_theta, &ctx->lt_phi };
+                       &ctx->gmfirst, &ctx->stiles, &ctx->gsegmap, &ctx->gsegstart, &ctx->gbands, &ctx->gclist, &ctx->agc_maps, &ctx->pll_head, &ctx->taps_rot, &ctx->pll_scratch, &ctx->tip, &ctx->stream_in, &ctx->sync_scr, &ctx->agc_raw, &ctx->packs_dev, &ctx->seg_dev, &ctx->lt_theta, &ctx->lt_phi,
+                       &ctx->avgph, &ctx->term_ap, &ctx->seams_q, &ctx->chunkinfo };
     for (DevBuf *b : bufs) b->release();
     for (hipEvent_t e : ctx->event_pool) (void)hipEventDestroy(e);
     if (ctx->pinned) (void)hipHostFree(ctx->pinned);
+    if (ctx->qual_pin) (void)hipHostFree(ctx->qual_pin);
     if (ctx->packs_pin) (void)hipHostFree(ctx->packs_pin);
     if (ctx->ingest_pin) (void)hipHostFree(ctx->ingest_pin);
     for (hipEvent_t e : ctx->ingest_ev) (void)hipEventDestroy(e);
@@ -2024,6 +2092,44 @@ int pdt_set_stream(pdt_ctx *ctx, void *hip_stream)
         ctx->own_stream = true;
     }
     return PDT_OK;
+}
+
+int pdt_keep_quality(pdt_ctx *ctx, int enable)
+{
+    if (!ctx) return PDT_ERR_ARG;
+    ctx->keep_quality = enable != 0;
+    if (!enable) ctx->chunk_host.clear();
+    return PDT_OK;
+}
+
+uint64_t pdt_chunk_reports(const pdt_ctx *ctx, pdt_chunk_report *out, uint64_t max_chunks)
+{
+    if (!ctx) return 0;
+    const uint64_t nc = ctx->chunk_host.size();
+    if (!out) return nc;
+    const uint64_t m = std::min<uint64_t>(nc, max_chunks);
+    const bool argos = ctx->cfg.mode == PDT_MODE_ARGOS;
+    const uint64_t chunk = ctx->cfg.chunk;
+    uint64_t sym_prev = 0, bits_prev = 0;
+    size_t f = 0;
+    for (uint64_t c = 0; c < m; c++) {
+        const pdt::ChunkInfo &ci = ctx->chunk_host[(size_t)c];
+        pdt_chunk_report &o = out[c];
+        memset(&o, 0, sizeof o);
+        o.samples = std::min<uint64_t>(chunk, ctx->n_samples - c * chunk);
+        o.avg_phase = ci.avg_phase;
+        o.symbols = ci.sym_upto - sym_prev;
+        o.bits = ci.bits_upto - bits_prev;
+        // ByteSyncOnSyncword / FindSyncWords count a frame at the bit that completes its sync word (ByteSync.c:105,139)
+        while (f < ctx->frames_host.size() && (uint64_t)ctx->frames_host[f].bit_index < ci.bits_upto) { o.frames++; f++; }
+        // waveDataTime[0] as the progress line prints it: POES keeps the input time axis apart (main.c:424,438,445), ARGOS
+        // compacts the symbol and bit times into it (ARGOSdemod/main.c:278,282)
+        o.time0 = argos ? const_cast<pdt_ctx *>(ctx)->axis_d.at((uint64_t)ci.t0_src + 1)
+                        : (double)const_cast<pdt_ctx *>(ctx)->axis_f.at(c * chunk + 1);
+        sym_prev = ci.sym_upto;
+        bits_prev = ci.bits_upto;
+    }
+    return m;
 }
 
 int pdt_keep_presquelch(pdt_ctx *ctx, int enable)

@@ -2478,4 +2478,56 @@ __device__ __forceinline__ void k_tip_check(const FrameRec *__restrict__ frames,
     out[f] = o;
 }
 
+// ------------------------------------------------------------------------------------------
+// What the reference's chunk loop knows after every chunk (pdt_keep_quality; POESTIPdemod/main.c:413-481,
+// ARGOSdemod/main.c:265-294): CarrierTrackPLL's return value = averagePhase after the chunk's last sample
+// (CarrierTrackingPLL.c:277), the symbols and bits decided so far (the sums of GardenerClockRecovery's and ManchesterDecode's
+// return values) and where element 0 of the time array the progress line prints comes from.  One thread per chunk: the symbol
+// pick indices and the bits' symbol indices are ascending, so the counts are two binary searches.
+// ------------------------------------------------------------------------------------------
+struct ChunkInfo {
+    double avg_phase;
+    unsigned long long sym_upto, bits_upto;    // symbols / bits decided in chunks 0 .. c
+    long long t0_src;                          // ARGOS: global sample index behind waveDataTime[0] after the in-place compactions
+};
+
+template <typename T>
+__device__ __forceinline__ void k_chunk_info(const T *__restrict__ avg_stream, long long n, long long chunk, long long n_chunks,
+                                             int interp, const long long *__restrict__ symidx,
+                                             const unsigned long long *__restrict__ nsym_p, const unsigned *__restrict__ bitsym,
+                                             const unsigned long long *__restrict__ nbits_p, ChunkInfo *__restrict__ out)
+{
+    const long long c = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= n_chunks) return;
+    const long long nsym = (long long)*nsym_p, nbits = (long long)*nbits_p;
+    auto syms_before = [&](long long g) {              // symbols picked at an interpolated-sample index below g
+        long long lo = 0, hi = nsym;
+        while (lo < hi) {
+            const long long mid = (lo + hi) >> 1;
+            if (symidx[mid] < g) lo = mid + 1; else hi = mid;
+        }
+        return lo;
+    };
+    auto bits_before = [&](long long sidx) {           // bits whose time stamp comes from a symbol below sidx
+        long long lo = 0, hi = nbits;
+        while (lo < hi) {
+            const long long mid = (lo + hi) >> 1;
+            if ((long long)bitsym[mid] < sidx) lo = mid + 1; else hi = mid;
+        }
+        return lo;
+    };
+    const long long begin = c * chunk;
+    const long long end = ((c + 1) * chunk < n) ? (c + 1) * chunk : n;
+    const long long s0 = syms_before(begin * interp), s1 = syms_before(end * interp);
+    const long long b0 = bits_before(s0), b1 = bits_before(s1);
+    ChunkInfo o;
+    o.avg_phase = avg_stream ? (double)avg_stream[end - 1] : 0.0;
+    o.sym_upto = (unsigned long long)s1;
+    o.bits_upto = (unsigned long long)b1;
+    // Gardner compacts time[k] = time[pick k], Manchester time[j] = time[symbol of bit j] (GardenerClockRecovery.c:31,
+    // ManchesterDecode.c:86): element 0 ends up as the first bit's symbol's pick, else the first symbol's, else stays put
+    o.t0_src = (b1 > b0) ? symidx[bitsym[b0]] : (s1 > s0) ? symidx[s0] : begin * interp;
+    out[c] = o;
+}
+
 }  // namespace pdt

@@ -581,7 +581,7 @@ template <typename T> struct AcqVerdict {
 template <typename T, bool SLOW, bool EXCL = false>
 __device__ __forceinline__ void k_pll_acquire_pipe(IqSrc pcm, long long n, PllParams<T> P,
                                                           T *__restrict__ out, T *__restrict__ lock_out,
-                                                          PllLockInfo<T> *__restrict__ info)
+                                                          PllLockInfo<T> *__restrict__ info, T *__restrict__ avg_out = nullptr)
 {
     __shared__ AcqSlot<T> slot[2];
     __shared__ AcqVerdict<T> verdict;
@@ -722,6 +722,7 @@ __device__ __forceinline__ void k_pll_acquire_pipe(IqSrc pcm, long long n, PllPa
                 if (lane < done) {
                     out[i0 + lane] = o_l;
                     if (lock_out) lock_out[i0 + lane] = ls_l;
+                    if (avg_out) avg_out[i0 + lane] = av_l;            // averagePhase after this sample (:124,152; the value :277 returns)
                 }
             } else if (lane == 0) {
                 verdict.event = 0;
@@ -1259,7 +1260,9 @@ __device__ __forceinline__ void k_pll_fix(const T *__restrict__ theta, long long
 // term lockSigAlpha*(re*t_real + im*t_imag) (:194-220) when the lock stream is wanted.  The phases arrive in the LT
 // layout: a workgroup takes RG rows of one tile (coalesced), transposes them through LDS and then works along the 64
 // lane-rows in natural order -- I/Q in, mixed samples out, both in runs of RG * 16 bytes.
-template <typename T, bool LOCKSIG>
+// AVGTERM: instead of the mixed samples, only the input term of the averagePhase EMA, averagePhaseAlpha * |arctan2(out)|
+// (:117-124, :145-152), goes to lock_term -- the quality figure's stream after the lock (pdt_keep_quality).
+template <typename T, bool LOCKSIG, bool AVGTERM = false>
 __device__ __forceinline__ void k_pll_mix(IqSrc pcm, const T *__restrict__ phi_lt, long long n, long long B,
                                                   PllParams<T> P, const PllLockInfo<T> *__restrict__ info,
                                                   T *__restrict__ out, T *__restrict__ lock_term)
@@ -1284,6 +1287,10 @@ __device__ __forceinline__ void k_pll_mix(IqSrc pcm, const T *__restrict__ phi_l
         Real<T>::sincos(ph, t_imag, t_real);
         const T c = t_real, d = -t_imag;
         o = a * d + b * c;
+        if (AVGTERM) {
+            const T o_re = a * c - b * d;
+            lt = (T)0.00005 * Real<T>::abs(arctan2_ref(o, o_re));
+        }
         if (LOCKSIG) {
             const T mag2 = a * a + b * b;
             const T inv = (T)q_rsqrt((float)mag2);
@@ -1306,8 +1313,8 @@ __device__ __forceinline__ void k_pll_mix(IqSrc pcm, const T *__restrict__ phi_l
                 lt.v[e] = 0;
                 one(a[e], b[e], ph.v[e], o.v[e], lt.v[e]);
             }
-            *reinterpret_cast<Vec16<T> *>(out + i) = o;                     // i is a multiple of VN
-            if (LOCKSIG) *reinterpret_cast<Vec16<T> *>(lock_term + i) = lt;
+            if (!AVGTERM) *reinterpret_cast<Vec16<T> *>(out + i) = o;       // i is a multiple of VN
+            if (LOCKSIG || AVGTERM) *reinterpret_cast<Vec16<T> *>(lock_term + i) = lt;
         } else {
 #pragma unroll
             for (int e = 0; e < VN; e++) {
@@ -1316,8 +1323,8 @@ __device__ __forceinline__ void k_pll_mix(IqSrc pcm, const T *__restrict__ phi_l
                     T a, b, o, lt = 0;
                     IqSample<T>::get(pcm, k, a, b);
                     one(a, b, ph.v[e], o, lt);
-                    out[k] = o;
-                    if (LOCKSIG) lock_term[k] = lt;
+                    if (!AVGTERM) out[k] = o;
+                    if (LOCKSIG || AVGTERM) lock_term[k] = lt;
                 }
             }
         }
@@ -1388,7 +1395,7 @@ __device__ __forceinline__ void k_lock_ema_zero(const T *__restrict__ term, long
 // guess[r] = approximate state in front of block r (r counted from the block that holds the lock): guess[r + 1] =
 // k^len(r) guess[r] + zresp[r].  One workgroup: every thread composes the maps of a run of blocks, a scan over the threads'
 // composites gives each run its start value, the thread walks its run again.
-template <typename T>
+template <typename T, bool AVG = false>
 __device__ __forceinline__ void k_lock_ema_guess(const double *__restrict__ zresp, long long n, T lock_alpha,
                                                  const PllLockInfo<T> *__restrict__ info, long long B, double kB,
                                                  double *__restrict__ guess)
@@ -1423,7 +1430,7 @@ __device__ __forceinline__ void k_lock_ema_guess(const double *__restrict__ zres
         }
         __syncthreads();
     }
-    const double L0 = (double)info->st.locksig;
+    const double L0 = (double)(AVG ? info->st.avg_phase : info->st.locksig);
     double g = (t == 0) ? L0 : s_a[t - 1] * L0 + s_b[t - 1];
     for (long long r = r0; r < r1; r++) {
         guess[r] = g;
@@ -1431,7 +1438,7 @@ __device__ __forceinline__ void k_lock_ema_guess(const double *__restrict__ zres
     }
 }
 
-template <typename T>
+template <typename T, bool AVG = false>
 __device__ __forceinline__ void k_lock_ema(const T *__restrict__ term, long long n, T lock_alpha,
                                                   const PllLockInfo<T> *__restrict__ info, long long B, long long W,
                                                   T *__restrict__ lock_out, EmaSeam<T> *__restrict__ seams,
@@ -1447,13 +1454,14 @@ __device__ __forceinline__ void k_lock_ema(const T *__restrict__ term, long long
     if (start < S) start = S;
     const long long end = ((j + 1) * B < n) ? (j + 1) * B : n;
     long long ws = start - W;
-    T L = info->st.locksig;
+    const T L_lock = AVG ? info->st.avg_phase : info->st.locksig;
+    T L = L_lock;
     if (ws < S) ws = S;
     else if (guess) {                                  // W is a whole number of blocks: start the warm-up from the guess there
         const long long jw = ws / B;
         L = (T)guess[jw - j0];
         ws = jw * B;
-        if (ws < S) { ws = S; L = info->st.locksig; }
+        if (ws < S) { ws = S; L = L_lock; }
     }
     const double k = 1.0 - (double)lock_alpha;
     ema_range<T, false>(term, lock_out, ws, start, L, k);

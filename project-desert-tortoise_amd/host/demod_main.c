@@ -17,18 +17,20 @@
  *   output name minorFrames_YYYYMMDD_HHMMSS.txt / packets_YYYYMMDD_HHMMSS.txt   main.c:289 / ARGOS main.c:213
  *   "Normalization Factor: %f", " : PLL locked at %0.2fHz"                  main.c:388, CarrierTrackingPLL.c:269
  *   output removed when no frame was found             main.c:508-512
- * Additions: -o <file> chooses the output name (tests), -d <n> picks the GPU, -q (POES) prints the frame
+ * Additions: -o <file> chooses the output name (tests), -d <n> picks the GPU, -P drops the progress lines, -q (POES) prints the frame
  * validation the reference keeps in MATLAB (checkParity.m:91-92, daytimeDecode.m:36,82-95) after decoding,
  * -m selects MMClockRecovery (the sampler the reference keeps commented out at ARGOSdemod/main.c:277),
  * -l (POES) runs the sound-card twin's chain (POESTIPdemodPortAudio/main.c:41-65,324-393: its PLL constants,
  * Squelch between PLL and FIR, Manchester threshold 0.75, blocks of 2400); with the file name "-" it is the twin's
  * loop itself, reading float32 I,Q blocks from standard input (e.g. a sound-card recorder's pipe, -s 48) until
  * end of file and appending every minor frame to the output as soon as it is final.
- * Not reproduced: the per-chunk "\r" progress line (there are no chunks on the GPU; one
- * summary line is printed instead).  RAW float32 input (".raw", -s mandatory) is supported for POES
+ * The per-chunk "\r" progress line (main.c:461-481 with its quality figure, ARGOSdemod/main.c:290-296) is printed after the
+ * run, chunk by chunk from the library's per-chunk reports (pdt_keep_quality), with the reference's arithmetic and under the
+ * reference's condition (progress of more than 0.15 %, or end of file); one summary line follows.  RAW float32 input (".raw", -s mandatory) is supported for POES
  * exactly as in POESTIPdemod/main.c:313-339.
  */
 #include <ctype.h>
+#include <math.h>
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
@@ -41,18 +43,82 @@
 #ifdef PDT_ARGOS
 #define MODE PDT_MODE_ARGOS
 #define DEFAULT_CHUNKSIZE 2400
-#define OPTS "rn:c:o:d:m"
+#define OPTS "rn:c:o:d:mP"
 #define BANNER "Project Desert Tortoise: Wave file ARGOS Demodulator (MI355X build)\n"
 #define PREFIX "packets"
 #define UNIT "Packets"
 #else
 #define MODE PDT_MODE_POES
 #define DEFAULT_CHUNKSIZE 10000
-#define OPTS "s:rn:c:o:d:qml"
+#define OPTS "s:rn:c:o:d:qmlP"
 #define BANNER "Project Desert Tortoise: Wave file NOAA TIP Demodulator (MI355X build)\n"
 #define PREFIX "minorFrames"
 #define UNIT "Frames"
 #endif
+
+/* The reference's progress line, chunk by chunk (POESTIPdemod/main.c:457-481, ARGOSdemod/main.c:286-296).  The loop runs once
+ * more with zero samples when the data end exactly at a chunk boundary (fread does not set the end-of-file flag before it
+ * comes up short, wave.c:125; main.c:372): that pass prints the line again, feof() being true at last.                      */
+#define ANSI_COLOR_RED "\x1b[31m"
+#define ANSI_COLOR_GREEN "\x1b[32m"
+#define ANSI_COLOR_YELLOW "\x1b[33m"
+#define ANSI_COLOR_RESET "\x1b[0m"
+static void print_progress(pdt_ctx *ctx, long num_samples, unsigned long chunkSize)
+{
+    const uint64_t nc = pdt_chunk_reports(ctx, NULL, 0);
+    if (!nc) return;
+    pdt_chunk_report *r = (pdt_chunk_report *)malloc((size_t)nc * sizeof *r);
+    if (!r) return;
+    pdt_chunk_reports(ctx, r, nc);
+    unsigned long i = 0, totalSymbols = 0, totalBits = 0, totalSamples = 0;
+    int totalFrames = 0;
+#ifdef PDT_ARGOS
+    double percentComplete = 0;
+#else
+    float percentComplete = 0, averagePhase;
+    char qualityString[20];
+#endif
+    const int extra = r[nc - 1].samples == chunkSize;          /* the zero-sample pass at the end of the file */
+    for (uint64_t c = 0; c < nc + (uint64_t)extra; c++) {
+        const int last = c + 1 == nc + (uint64_t)extra;        /* feof(inFilePtr) */
+        const pdt_chunk_report *q = &r[c < nc ? c : nc - 1];
+        if (c < nc) {
+            i += q->samples;
+            totalBits += q->bits;
+            totalFrames += (int)q->frames;
+            totalSymbols += q->symbols;
+            totalSamples += q->samples;
+        }
+#ifdef PDT_ARGOS
+        if ((((double)(i) / num_samples) * 100.0 - percentComplete > 0.15) || last) {
+            percentComplete = ((double)(i) / num_samples) * 100.0;
+            printf("\r");
+            printf("%0.1f%% %0.3f Ks : %0.1f Sec: %ld Sym : %ld Bits : %d Packets", ((double)(i) / num_samples) * 100.0,
+                   (totalSamples) / 1000.0, q->time0, totalSymbols, totalBits, totalFrames);
+        }
+#else
+        if ((((float)(i) / num_samples) * 100.0 - percentComplete > 0.15) || last) {
+            percentComplete = ((float)(i) / num_samples) * 100.0;
+            averagePhase = (float)q->avg_phase;
+            printf("\r");
+            printf("%f\t", fabs(M_PI / 2.0 - averagePhase));
+            averagePhase = 10.0 * log10f(powf(fabs(M_PI / 2.0 - averagePhase), 2));
+            if (averagePhase > -4.3)
+                snprintf(qualityString, 20, "%s%02.1fQ%s", ANSI_COLOR_GREEN, averagePhase, ANSI_COLOR_RESET);
+            else if (averagePhase > -5)
+                snprintf(qualityString, 20, "%s%02.1fQ%s", ANSI_COLOR_YELLOW, averagePhase, ANSI_COLOR_RESET);
+            else if (averagePhase > -6)
+                snprintf(qualityString, 20, "%s%02.1fQ%s", ANSI_COLOR_YELLOW, averagePhase, ANSI_COLOR_RESET);
+            else
+                snprintf(qualityString, 20, "%s%02.1fQ%s", ANSI_COLOR_RED, averagePhase, ANSI_COLOR_RESET);
+            printf("%0.1f%% %0.3f Ks : %0.1f Sec: %ld Sym : %ld Bits : %d Frames : %s   ", ((float)(i) / num_samples) * 100.0,
+                   (totalSamples) / 1000.0, (float)q->time0, totalSymbols, totalBits, totalFrames, qualityString);
+        }
+#endif
+    }
+    printf("\n");
+    free(r);
+}
 
 static const char *get_filename_ext(const char *filename)
 {
@@ -143,7 +209,7 @@ int main(int argc, char **argv)
 {
     unsigned long chunkSize = DEFAULT_CHUNKSIZE;
     double normFactor = 0, sampleRate = 0;
-    int outputRawFiles = 0, device = 0, quality = 0, sampler = 0, live = 0, chunkGiven = 0, c;
+    int outputRawFiles = 0, device = 0, quality = 0, sampler = 0, live = 0, chunkGiven = 0, noProgress = 0, c;
     const char *outOverride = NULL;
     char outFileName[1100];
 
@@ -175,6 +241,9 @@ int main(int argc, char **argv)
             break;
         case 'q':
             quality = 1;
+            break;
+        case 'P':                                       /* no progress lines (and no averagePhase pass on the GPU) */
+            noProgress = 1;
             break;
         case 'l':                                       /* the sound-card twin's chain */
             live = 1;
@@ -254,6 +323,7 @@ int main(int argc, char **argv)
 
     uint32_t rate = 0, channels = 2, bits = 32, format = 1, data_bytes = 0;
     long data_offset = 0;
+    long num_samples = 44515000;                                     /* RAW: main.c:337 (progress bar only) */
     if (!is_raw) {
         uint8_t hdr[44];
         if (fread(hdr, 1, 44, in) != 44) {
@@ -277,7 +347,11 @@ int main(int argc, char **argv)
 #ifndef PDT_ARGOS
         if (sampleRate > 1) rate = (uint32_t)sampleRate;             /* main.c:343-344 (Q6) */
 #endif
-        long num_samples = (long)((8.0 * data_bytes) / (channels * bits));
+#ifdef PDT_ARGOS
+        num_samples = (long)((uint32_t)(8u * data_bytes) / (channels * bits));   /* ARGOSdemod/main.c:244, unsigned int arithmetic */
+#else
+        num_samples = (long)(unsigned long)((8.0 * data_bytes) / (channels * bits));   /* main.c:349 */
+#endif
         printf("Sample Rate %.2fKHz and %d bits per sample. Total samples %ld\n", (float)rate / 1000.0, bits, num_samples);
     } else {
         rate = (uint32_t)(sampleRate * 1000.0);                      /* main.c:329: entered in kHz */
@@ -310,6 +384,7 @@ int main(int argc, char **argv)
 #ifdef PDT_ARGOS
     if (outputRawFiles) pdt_keep_presquelch(ctx, 1);                 /* -r: the AGC output before Squelch, ARGOSdemod/main.c:273-274 */
 #endif
+    if (!noProgress) pdt_keep_quality(ctx, 1);                       /* the chunk loop's progress / quality line */
     rc = pdt_demod_fd(ctx, fileno(in), (uint64_t)data_offset, nframes, is_raw ? PDT_FMT_F32 : PDT_FMT_PCM16);
     fclose(in);
     if (rc != PDT_OK) {
@@ -341,6 +416,8 @@ int main(int argc, char **argv)
     pdt_get_stats(ctx, &st);
     if (normFactor == 0) printf("Normalization Factor: %f\n", st.norm_factor);
     if (st.lock_sample >= 0) printf(" : PLL locked at %0.2fHz\n", st.lock_freq_hz);
+
+    if (!noProgress && num_samples > 0) print_progress(ctx, num_samples, (unsigned long)chunkSize);
 
     uint64_t need = pdt_format_frames(ctx, NULL, 0);
     char *text = (char *)malloc(need + 1);
