@@ -9,6 +9,8 @@ for k in ("pll_block", "pll_warm", "agc_block", "agc_warm"):
         kw[k] = int(os.environ["PDT_" + k.upper()])
 iq = pdt.synth_capture(0, 50000, float(os.environ.get("PDT_SECS", "600")), seed=int(os.environ.get("PDT_SEED", "1234")))
 d = pdt.Demodulator(pdt.MODE_POES, 50000, profile=False, **kw)
+if os.environ.get("PDT_QUALITY"):          # per-chunk reports (averagePhase EMA after the lock + counts)
+    d.keep_quality()
 for _ in range(4):
     d.demod(iq)
 s = d.stats()
