@@ -268,6 +268,33 @@ uint64_t pdt_stage_len(const pdt_ctx *ctx, int stage);
  * POESTIPdemod/ByteSync.c:6-14.)                                                                  */
 int      pdt_stage_bytesync(pdt_ctx *ctx, const uint8_t *bits_host, uint64_t nbits);
 
+/* More stage-level entries: one stage of the chain on caller data in host memory (DT = float for POES
+ * contexts, double for ARGOS), through the kernels the whole-capture path uses, with the reference function's hidden
+ * `static` variables as an explicit state record the caller keeps -- so that per-chunk dumps of the reference can be
+ * replayed stage by stage, chunk after chunk.  state == NULL: a fresh stage, nothing carried out.  A zeroed record is the
+ * reference's state before its first call.                                                                           */
+typedef struct pdt_manchester_state {   /* ManchesterDecode.c:16-20 */
+    double   current, previous;         /* currentSample, prevSample after the last call (exact for float and double)  */
+    uint32_t clockmod;                  /* which symbol parity ends a bit                                              */
+    uint32_t even_odd;                  /* evenOddCounter (an unsigned char there: counted modulo 256)                 */
+} pdt_manchester_state;
+/* unsigned long ManchesterDecode(DT *dataStreamIn, DT *dataStreamTime, unsigned long nSymbols, unsigned char *bitStream,
+ * DT resyncThreshold) (ManchesterDecode.h:3): bits_out receives the '0'/'1' characters (room for nsymbols: after a
+ * resynchronisation consecutive symbols can both end a bit),
+ * *nbits_out their number (the return value); bit_symbol_out[j] (optional) = index idxi of the symbol whose time stamp the
+ * reference's in-place compaction gives bit j (:86).                                                                   */
+int      pdt_stage_manchester(pdt_ctx *ctx, const void *symbols_host, uint64_t nsymbols, double resync_threshold,
+                              pdt_manchester_state *state, uint8_t *bits_out, uint32_t *bit_symbol_out, uint64_t *nbits_out);
+typedef struct pdt_fir_state {          /* LowPassFilter.c:13-41 (interpolating form) / :76-100 (in place)               */
+    uint64_t count;                     /* inputs filtered so far: the interpolating form's ring position is count mod K */
+    double   history[64];               /* the last K inputs, oldest first; K = ntaps / interp (POES, 26) or ntaps (ARGOS, 50) */
+} pdt_fir_state;
+/* void LowPassFilterInterp(DT *inTime, DT *in, DT *out, DT *outTime, unsigned long n, DT *h, int N, int interp) with the
+ * context's taps and interpolation factor (LowPassFilter.h:4; POES), void LowPassFilter(DT *data, unsigned long n, DT *h,
+ * int N) (:6; ARGOS): n inputs -> n * interp outputs in out_host.  The time streams are closed-form here
+ * (pdt_time_axis).                                                                                                    */
+int      pdt_stage_fir(pdt_ctx *ctx, const void *in_host, uint64_t n, pdt_fir_state *state, void *out_host);
+
 /* Frame validation of the POES minor frames of the last pdt_demod_* call (a per-frame kernel and a
  * reduction on the GPU; the reference does this offline in MATLAB from the text file).  MATLAB is
  * 1-indexed: its minorFrames(frame, w) is bytes[w-1] here.                                          */

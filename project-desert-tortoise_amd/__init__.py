@@ -110,6 +110,16 @@ TIP_DTYPE = np.dtype([("minor_id", "<u2"), ("spacecraft", "u1"), ("parity", "u1"
                       ("day", "<u2"), ("day_ms", "<i4")])        # == pdt_tip_frame (12 bytes)
 
 
+class ManchesterState(C.Structure):
+    """pdt_manchester_state: ManchesterDecode's statics (a zeroed record = before the first call)"""
+    _fields_ = [("current", C.c_double), ("previous", C.c_double), ("clockmod", C.c_uint32), ("even_odd", C.c_uint32)]
+
+
+class FirState(C.Structure):
+    """pdt_fir_state: the low-pass filter's ring (a zeroed record = before the first call)"""
+    _fields_ = [("count", C.c_uint64), ("history", C.c_double * 64)]
+
+
 class KernelTime(C.Structure):
     _fields_ = [("name", C.c_char * 32), ("launches", C.c_uint32), ("total_ms", C.c_double)]
 
@@ -121,7 +131,7 @@ ABI_SYMBOLS = [
     "pdt_format_frames", "pdt_read_stage", "pdt_stage_len", "pdt_kernel_times", "pdt_make_lpf",
     "pdt_wav_parse_header", "pdt_time_axis", "pdt_stage_bytesync", "pdt_tip_check", "pdt_tip_frames",
     "pdt_stream_begin", "pdt_stream_push_pcm16", "pdt_stream_push_f32", "pdt_stream_end", "pdt_stream_frames",
-    "pdt_keep_quality", "pdt_chunk_reports",
+    "pdt_keep_quality", "pdt_chunk_reports", "pdt_stage_manchester", "pdt_stage_fir",
     "pdt_keep_presquelch", "pdt_demod_fd", "pdt_format_records", "pdt_stream_retained", "pdt_host_math", "pdt_get_device",
 ]
 
@@ -181,6 +191,10 @@ def lib():
     L.pdt_host_math.argtypes = [C.c_int, C.c_void_p, C.c_uint64, C.c_void_p, C.c_void_p]
     L.pdt_stream_retained.argtypes = [C.c_void_p]
     L.pdt_stream_retained.restype = C.c_uint64
+    L.pdt_stage_manchester.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64, C.c_double, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+    L.pdt_stage_manchester.restype = C.c_int
+    L.pdt_stage_fir.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p, C.c_void_p]
+    L.pdt_stage_fir.restype = C.c_int
     L.pdt_keep_quality.argtypes = [C.c_void_p, C.c_int]
     L.pdt_keep_quality.restype = C.c_int
     L.pdt_chunk_reports.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64]
@@ -246,6 +260,7 @@ class Demodulator:
                  gardner_band_pad: float = 0.0, sampler: int = 0, mm_step_range: float = 0.0, mm_kp: float = 0.0, chain: int = 0):
         self._L = lib()
         self.mode = mode
+        self.sample_rate = sample_rate
         cfg = Config(mode, sample_rate, chunk, norm_override, device, int(profile), pll_block, pll_warm, agc_block,
                      agc_warm, gardner_band_pad, sampler, chain, mm_step_range, mm_kp)
         self._h = C.c_void_p()
@@ -319,6 +334,32 @@ class Demodulator:
         b = np.ascontiguousarray(bits, dtype=np.uint8)
         _check(self._L.pdt_stage_bytesync(self._h, b.ctypes.data, b.size), "pdt_stage_bytesync")
         return self
+
+    def _dt(self):
+        return np.dtype("<f8") if self.mode == MODE_ARGOS else np.dtype("<f4")
+
+    def stage_manchester(self, symbols: np.ndarray, resync_threshold: float, state: "ManchesterState | None" = None):
+        """ManchesterDecode on these symbols alone (statics in `state`, updated in place): (bits '0'/'1', symbol index per bit)"""
+        a = np.ascontiguousarray(symbols, dtype=self._dt())
+        bits = np.zeros(a.size + 4, dtype=np.uint8)           # a resynchronisation can make consecutive symbols both end a bit
+        bsym = np.zeros(a.size + 4, dtype=np.uint32)
+        nb = C.c_uint64(0)
+        _check(self._L.pdt_stage_manchester(self._h, a.ctypes.data, a.size, float(resync_threshold),
+                                            C.addressof(state) if state is not None else None, bits.ctypes.data, bsym.ctypes.data,
+                                            C.addressof(nb)), "pdt_stage_manchester")
+        return bits[:nb.value], bsym[:nb.value]
+
+    def stage_fir(self, x: np.ndarray, state: "FirState | None" = None) -> np.ndarray:
+        """LowPassFilterInterp (POES) / LowPassFilter (ARGOS) on these inputs alone (ring in `state`, updated in place)"""
+        a = np.ascontiguousarray(x, dtype=self._dt())
+        out = np.zeros(a.size * self.stats_interp(), dtype=self._dt())
+        _check(self._L.pdt_stage_fir(self._h, a.ctypes.data, a.size, C.addressof(state) if state is not None else None,
+                                     out.ctypes.data), "pdt_stage_fir")
+        return out
+
+    def stats_interp(self) -> int:
+        taps, interp = make_lpf(self.mode, self.sample_rate)
+        return int(interp)
 
     def frames(self) -> list[Frame]:
         n = self._L.pdt_num_frames(self._h)

@@ -2290,6 +2290,176 @@ int pdt_stage_bytesync(pdt_ctx *ctx, const uint8_t *bits_host, uint64_t nbits)
     return PDT_OK;
 }
 
+// ---------------------------------------------------------------- stage-level entry points
+// One stage of the chain on caller data, the reference function's hidden statics as an explicit state record, so that the
+// per-chunk dumps of the reference (or of the oracle) can be replayed stage by stage through the kernels the whole-capture
+// path uses.
+extern "C++" {
+template <typename T> static int stage_manchester(pdt_ctx *ctx, const void *sym_host, uint64_t nsym, double thr_d,
+                                                  pdt_manchester_state *state, uint8_t *bits_out, uint32_t *bit_symbol_out,
+                                                  uint64_t *nbits_out)
+{
+    pdt_manchester_state fresh;
+    memset(&fresh, 0, sizeof fresh);
+    if (!state) state = &fresh;
+    // the two symbols the decisions look back on go in front, placed so that local and stream symbol parities agree
+    const long long pad = 2 + (long long)(state->even_odd & 1u);
+    const long long total = pad + (long long)nsym;
+    const long long sym_cap = total + 64, bit_cap = sym_cap;
+    const long long n_tiles = (sym_cap + PDT_TILE - 1) / PDT_TILE;
+    int rc;
+    if ((rc = ctx->sym.ensure((size_t)sym_cap * sizeof(T)))) return rc;
+    if ((rc = ctx->bits.ensure((size_t)bit_cap))) return rc;
+    if ((rc = ctx->bitsym.ensure((size_t)bit_cap * sizeof(unsigned)))) return rc;
+    if ((rc = ctx->hits.ensure((size_t)n_tiles * sizeof(ManchTile)))) return rc;
+    if ((rc = ctx->scal.ensure(sizeof(DevScalars)))) return rc;
+    hipStream_t st = ctx->stream;
+    T *d_sym = (T *)ctx->sym.p;
+    ManchTile *d_tiles = (ManchTile *)ctx->hits.p;
+    DevScalars *d_sc = (DevScalars *)ctx->scal.p;
+    DevScalars sc;
+    memset(&sc, 0, sizeof sc);
+    sc.nsym = (unsigned long long)total;
+    T hist[4] = { 0, 0, 0, 0 };
+    hist[pad - 2] = (T)state->previous;
+    hist[pad - 1] = (T)state->current;
+    const T thr = (T)thr_d;
+    Plan &PL = ctx->plan;
+    PL.clear();
+    PL.side_stream = ctx->stream2;
+    PL.copy(OP_H2D, d_sc, &sc, sizeof sc);
+    PL.copy(OP_H2D, d_sym, hist, (size_t)pad * sizeof(T));
+    if (nsym) PL.copy(OP_H2D, d_sym + pad, sym_host, (size_t)nsym * sizeof(T));
+    PDT_LAUNCH(PDT_TILE_THREADS, k_manch_tile<T>, dim3((unsigned)n_tiles), dim3(PDT_TILE_THREADS), 0, st, (const T *)d_sym,
+               (const unsigned long long *)&d_sc->nsym, thr, d_tiles, pad);
+    PDT_LAUNCH(1024, k_manch_scan, dim3(1), dim3(1024), 0, st, d_tiles, (const unsigned long long *)&d_sc->nsym, &d_sc->nbits, pad,
+               (unsigned)(state->clockmod & 1u), 0ull, &d_sc->pad0_);
+    PDT_LAUNCH(PDT_TILE_THREADS, k_manch_emit<T>, dim3((unsigned)n_tiles), dim3(PDT_TILE_THREADS), 0, st, (const T *)d_sym,
+               (const unsigned long long *)&d_sc->nsym, thr, d_tiles, (unsigned char *)ctx->bits.p, (unsigned *)ctx->bitsym.p, bit_cap, pad);
+    DevScalars *back = ctx->pend_sc;                                  // pinned
+    PL.copy(OP_D2H, back, d_sc, sizeof sc);
+    {
+        pdt_ctx *self = ctx;
+        if ((rc = execute_plans(&self, 1))) return rc;
+    }
+    HIP_TRY(hipStreamSynchronize(st));
+    sc = *back;
+    if ((long long)sc.nbits > bit_cap) return PDT_ERR_STATE;
+    if (sc.nbits && bits_out) HIP_TRY(hipMemcpy(bits_out, ctx->bits.p, (size_t)sc.nbits, hipMemcpyDeviceToHost));
+    if (sc.nbits && bit_symbol_out) {
+        HIP_TRY(hipMemcpy(bit_symbol_out, ctx->bitsym.p, (size_t)sc.nbits * sizeof(unsigned), hipMemcpyDeviceToHost));
+        for (uint64_t b = 0; b < sc.nbits; b++) bit_symbol_out[b] -= (uint32_t)pad;       // index into this call's symbols
+    }
+    if (nbits_out) *nbits_out = sc.nbits;
+    // ManchesterDecode.c:16-20: the statics after the call
+    const T *sy = (const T *)sym_host;
+    if (nsym >= 2) { state->previous = (double)sy[nsym - 2]; state->current = (double)sy[nsym - 1]; }
+    else if (nsym == 1) { state->previous = state->current; state->current = (double)sy[0]; }
+    state->clockmod = sc.pad0_;
+    state->even_odd = (uint32_t)((state->even_odd + nsym) & 0xffu);                       // unsigned char evenOddCounter
+    memset(ctx->stage_len, 0, sizeof ctx->stage_len);
+    return PDT_OK;
+}
+
+template <typename T> static int stage_fir(pdt_ctx *ctx, const void *in_host, uint64_t n, pdt_fir_state *state, void *out_host)
+{
+    pdt_fir_state fresh;
+    memset(&fresh, 0, sizeof fresh);
+    if (!state) state = &fresh;
+    const bool argos = ctx->cfg.mode == PDT_MODE_ARGOS;
+    const int interp = (int)ctx->interp, ntaps = (int)ctx->ntaps;
+    const int K = argos ? ntaps : ntaps / interp;                      // inputs an output looks back on
+    if (K < 1 || K > 64) return PDT_ERR_ARG;
+    // POES: the reference's ring keeps input m in slot m mod K and sums the slots in ascending order (LowPassFilter.c:43-70),
+    // so the local index of every input must equal its stream index modulo K: p zeros, the K last inputs, the new ones
+    const long long p = argos ? 0 : (long long)(state->count % (uint64_t)K);
+    const long long lead = p + K;
+    const long long N = lead + (long long)n, n_out = N * interp;
+    int rc;
+    if ((rc = ctx->pll.ensure((size_t)(N + 1) * sizeof(T)))) return rc;
+    if ((rc = ctx->fir.ensure((size_t)(n_out + 1) * sizeof(T)))) return rc;
+    hipStream_t st = ctx->stream;
+    T *d_in = (T *)ctx->pll.p, *d_out = (T *)ctx->fir.p, *d_taps = (T *)ctx->taps.p;
+    std::vector<T> head((size_t)lead, (T)0);
+    for (int i = 0; i < K; i++) head[(size_t)(p + i)] = (T)state->history[i];
+    Plan &PL = ctx->plan;
+    PL.clear();
+    PL.side_stream = ctx->stream2;
+    PL.copy(OP_H2D, d_in, head.data(), (size_t)lead * sizeof(T));
+    if (n) PL.copy(OP_H2D, d_in + lead, in_host, (size_t)n * sizeof(T));
+    const int opt = 8;
+    const long long tile = (long long)PDT_FIR_THREADS * opt;
+    const long long grid = (n_out + tile - 1) / tile;
+    if (argos) {
+        const size_t sh = (size_t)(ntaps + tile + ntaps + 8) * sizeof(T);
+        PDT_LAUNCH(PDT_FIR_THREADS, k_fir_plain<T>, dim3((unsigned)grid), dim3(PDT_FIR_THREADS), sh, st, (const T *)d_in, N, ntaps,
+                   (const T *)d_taps, d_out, opt);
+    } else {
+        const size_t sh_rt = (size_t)(65 * (K + 1) + 3 + 64 * K * interp) * sizeof(T);
+        const long long tiles_rt = (N + 64ll * K - 1) / (64ll * K);
+        const unsigned grid_rt = (unsigned)std::min<long long>(tiles_rt, 256ll * 32);
+        bool done = false;
+        if (K == 26 && sh_rt <= 64000 && ctx->taps_rot.p && !ctx->tune.fir_generic) {     // the kernel of the whole-capture path
+            done = true;
+            switch (interp) {
+#define PDT_FIR_CASE(I)                                                                                                       \
+    case I:                                                                                                                   \
+        PDT_LAUNCH(PDT_FIR_THREADS, (k_fir_interp_rt<T, I, 26>), dim3(grid_rt), dim3(PDT_FIR_THREADS), sh_rt, st, (const T *)d_in, N, (const T *)ctx->taps_rot.p, d_out, \
+                           (AgcMap *)nullptr, (T)0);                                                                          \
+        break;
+                PDT_FIR_CASE(1) PDT_FIR_CASE(2) PDT_FIR_CASE(3) PDT_FIR_CASE(4) PDT_FIR_CASE(5) PDT_FIR_CASE(6)
+#undef PDT_FIR_CASE
+            default: done = false;
+            }
+        }
+        if (!done) {
+            const size_t sh = (size_t)(ntaps + tile / interp + K + 8) * sizeof(T);
+            PDT_LAUNCH(PDT_FIR_THREADS, k_fir_interp<T>, dim3((unsigned)grid), dim3(PDT_FIR_THREADS), sh, st, (const T *)d_in, N, interp, K,
+                       (const T *)d_taps, d_out, opt);
+        }
+    }
+    {
+        pdt_ctx *self = ctx;
+        if ((rc = execute_plans(&self, 1))) return rc;
+    }
+    HIP_TRY(hipStreamSynchronize(st));
+    if (n && out_host)
+        HIP_TRY(hipMemcpy(out_host, d_out + lead * interp, (size_t)n * (size_t)interp * sizeof(T), hipMemcpyDeviceToHost));
+    // the ring after the call: the last K inputs, oldest first
+    const T *x = (const T *)in_host;
+    double nh[64];
+    for (int i = 0; i < K; i++) {
+        const long long src = (long long)n - K + i;                   // index into the new inputs, negative = older history
+        nh[i] = src >= 0 ? (double)x[src] : state->history[K + src];
+    }
+    memcpy(state->history, nh, sizeof(double) * (size_t)K);
+    state->count += n;
+    memset(ctx->stage_len, 0, sizeof ctx->stage_len);
+    return PDT_OK;
+}
+
+}  // extern "C++"
+
+int pdt_stage_manchester(pdt_ctx *ctx, const void *symbols_host, uint64_t nsymbols, double resync_threshold,
+                         pdt_manchester_state *state, uint8_t *bits_out, uint32_t *bit_symbol_out, uint64_t *nbits_out)
+{
+    if (!ctx || (!symbols_host && nsymbols) || nsymbols >= (1ull << 31)) return PDT_ERR_ARG;
+    if (nbits_out) *nbits_out = 0;
+    if (nsymbols == 0) return PDT_OK;                                 // the loop body never runs: nothing changes
+    HIP_TRY(hipSetDevice(ctx->cfg.device));
+    if (ctx->elem == 8)
+        return stage_manchester<double>(ctx, symbols_host, nsymbols, resync_threshold, state, bits_out, bit_symbol_out, nbits_out);
+    return stage_manchester<float>(ctx, symbols_host, nsymbols, resync_threshold, state, bits_out, bit_symbol_out, nbits_out);
+}
+
+int pdt_stage_fir(pdt_ctx *ctx, const void *in_host, uint64_t n, pdt_fir_state *state, void *out_host)
+{
+    if (!ctx || (!in_host && n) || n >= (1ull << 31)) return PDT_ERR_ARG;
+    HIP_TRY(hipSetDevice(ctx->cfg.device));
+    if (ctx->elem == 8) return stage_fir<double>(ctx, in_host, n, state, out_host);
+    return stage_fir<float>(ctx, in_host, n, state, out_host);
+}
+
 // ---------------------------------------------------------------- batched many-capture mode
 int pdt_demod_batch_device(pdt_ctx *const *ctxs, const void *const *iq_device, const uint64_t *nframes, int count)
 {

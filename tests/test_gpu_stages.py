@@ -1,0 +1,89 @@
+"""Stage-level entry points: the oracle's per-chunk dumps replayed stage by stage -- each chunk handed to ONE stage's
+kernels with the reference function's statics as an explicit state record (pdt_manchester_state, pdt_fir_state), chunk after
+chunk; the outputs must be the oracle's stage streams, the carried records what the reference's statics hold."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def chunks_of(n, chunk):
+    return [(a, min(a + chunk, n)) for a in range(0, n, chunk)]
+
+
+@pytest.mark.parametrize("fs,chunk", [(50000, 10000), (250000, 10000), (32000, 777), (100000, 1)])
+def test_fir_stage_replays_the_oracle_chunk_by_chunk(pdt, orc, fs, chunk):
+    secs = 2.0 if chunk > 1 else 0.004
+    iq = pdt.synth_capture(0, fs, secs, seed=41)
+    o = orc.Oracle(orc.POES, fs, iq, chunk=max(chunk, 64))
+    x = o.stage(orc.ST_PLL)                       # the FIR's input stream; the filter does not care where its chunks end
+    want = o.stage(orc.ST_FIR)
+    interp = o.interp
+    with pdt.Demodulator(pdt.MODE_POES, fs) as d:
+        st = pdt.FirState()
+        got = [d.stage_fir(x[a:b], st) for a, b in chunks_of(len(x), chunk)]
+        got = np.concatenate(got)
+        assert got.dtype == want.dtype and got.tobytes() == want.tobytes()
+        assert st.count == len(x)
+        K = 26
+        assert np.array_equal(np.array(st.history[:K], dtype=np.float32), x[-K:])
+        # without a state record every call is a fresh filter: the first chunk again
+        a, b = chunks_of(len(x), chunk)[0]
+        assert d.stage_fir(x[a:b]).tobytes() == want[:b * interp].tobytes()
+        assert len(d.stage_fir(x[:0], st)) == 0 and st.count == len(x)
+
+
+def test_fir_stage_argos(pdt, orc):
+    iq = pdt.synth_capture(1, 32000, 4.0, f0_hz=160.0, seed=42)
+    o = orc.Oracle(orc.ARGOS, 32000, iq)
+    x = o.stage(orc.ST_PLL)
+    want = o.stage(orc.ST_FIR)
+    with pdt.Demodulator(pdt.MODE_ARGOS, 32000) as d:
+        st = pdt.FirState()
+        got = np.concatenate([d.stage_fir(x[a:b], st) for a, b in chunks_of(len(x), 2400)])
+        assert got.dtype == want.dtype and got.tobytes() == want.tobytes()
+
+
+def manchester_replay(pdt, d, sym, symidx, chunk_out, thr):
+    """the symbols of every reference chunk (by pick index) through pdt_stage_manchester, statics carried in the record"""
+    st = pdt.ManchesterState()
+    which = symidx // chunk_out
+    bits, bsym, base = [], [], 0
+    for c in range(int(which.max()) + 1 if len(which) else 0):
+        s = sym[which == c]
+        b, k = d.stage_manchester(s, thr, st)
+        bits.append(b)
+        bsym.append(k.astype(np.int64) + base)
+        base += len(s)
+    return np.concatenate(bits), np.concatenate(bsym), st
+
+
+@pytest.mark.parametrize("fs,chunk", [(50000, 10000), (50000, 333), (250000, 10000)])
+def test_manchester_stage_replays_the_oracle_chunk_by_chunk(pdt, orc, fs, chunk):
+    iq = pdt.synth_capture(0, fs, 3.0, seed=43)
+    o = orc.Oracle(orc.POES, fs, iq, chunk=chunk)
+    sym, symidx = o.stage(orc.ST_SYM), o.stage(orc.ST_SYMIDX)
+    want_bits, symt, bitt = o.stage(orc.ST_BITS), o.stage(orc.ST_SYMT), o.stage(orc.ST_BITT)
+    with pdt.Demodulator(pdt.MODE_POES, fs, chunk=chunk) as d:
+        bits, bsym, st = manchester_replay(pdt, d, sym, symidx, chunk * o.interp, 1.0)
+        assert bits.tobytes() == want_bits.tobytes()
+        assert symt[bsym].tobytes() == bitt.tobytes()        # the time stamp each bit inherits (ManchesterDecode.c:86)
+        assert st.even_odd == len(sym) % 256 and st.current == float(sym[-1]) and st.previous == float(sym[-2])
+        # one call over everything = the same bits
+        b1, k1 = d.stage_manchester(sym, 1.0)
+        assert b1.tobytes() == want_bits.tobytes() and np.array_equal(k1.astype(np.int64), bsym)
+        # symbols one at a time across a stretch (every parity / pad combination)
+        st1 = pdt.ManchesterState()
+        few = np.concatenate([d.stage_manchester(sym[i:i + 1], 1.0, st1)[0] for i in range(300)])
+        b300, _ = d.stage_manchester(sym[:300], 1.0)
+        assert few.tobytes() == b300.tobytes()
+
+
+def test_manchester_stage_argos(pdt, orc):
+    iq = pdt.synth_capture(1, 32000, 8.0, f0_hz=160.0, seed=44)
+    o = orc.Oracle(orc.ARGOS, 32000, iq)
+    sym, symidx = o.stage(orc.ST_SYM), o.stage(orc.ST_SYMIDX)
+    with pdt.Demodulator(pdt.MODE_ARGOS, 32000) as d:
+        bits, bsym, _ = manchester_replay(pdt, d, sym, symidx, 2400, 0.5)
+        assert bits.tobytes() == o.stage(orc.ST_BITS).tobytes()
+        assert o.stage(orc.ST_SYMT)[bsym].tobytes() == o.stage(orc.ST_BITT).tobytes()
