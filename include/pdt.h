@@ -295,6 +295,21 @@ typedef struct pdt_fir_state {          /* LowPassFilter.c:13-41 (interpolating 
  * (pdt_time_axis).                                                                                                    */
 int      pdt_stage_fir(pdt_ctx *ctx, const void *in_host, uint64_t n, pdt_fir_state *state, void *out_host);
 
+typedef struct pdt_agc_state {          /* AGC.c:84-95 */
+    int32_t  started;                   /* 0 = the next call is the first one: its `initial` becomes the gain           */
+    int32_t  pad;
+    double   gain;                      /* the static gain after the last call                                          */
+} pdt_agc_state;
+/* void NormalizingAGC(DT *dataStreamIn, unsigned long nSamples, DT initial, DT attack_rate, DT decay_rate) (AGC.h:6): in place
+ * on data_host.  attack / decay 0 = the values the mains pass for this context's rate (POESTIPdemod/main.c:429-430,
+ * ARGOSdemod/main.c:270).  Evaluated block-parallel with validated seams like the whole-capture path (k_agc_affine / _guess /
+ * _block / _scan / _fix).                                                                                               */
+int      pdt_stage_agc(pdt_ctx *ctx, void *data_host, uint64_t n, double initial, double attack, double decay,
+                       pdt_agc_state *state);
+/* void Squelch(DT *dataStream, DT *squelchStreamIn, unsigned long nSamples, DT squelchThreshold) (AGC.h:8): in place; its only
+ * static (lastSquelch) feeds commented-out console output.                                                               */
+int      pdt_stage_squelch(pdt_ctx *ctx, void *data_host, const void *lock_host, uint64_t n, double threshold);
+
 /* Frame validation of the POES minor frames of the last pdt_demod_* call (a per-frame kernel and a
  * reduction on the GPU; the reference does this offline in MATLAB from the text file).  MATLAB is
  * 1-indexed: its minorFrames(frame, w) is bytes[w-1] here.                                          */

@@ -115,6 +115,11 @@ class ManchesterState(C.Structure):
     _fields_ = [("current", C.c_double), ("previous", C.c_double), ("clockmod", C.c_uint32), ("even_odd", C.c_uint32)]
 
 
+class AgcState(C.Structure):
+    """pdt_agc_state: NormalizingAGC's static gain (a zeroed record = before the first call)"""
+    _fields_ = [("started", C.c_int32), ("pad", C.c_int32), ("gain", C.c_double)]
+
+
 class FirState(C.Structure):
     """pdt_fir_state: the low-pass filter's ring (a zeroed record = before the first call)"""
     _fields_ = [("count", C.c_uint64), ("history", C.c_double * 64)]
@@ -131,7 +136,7 @@ ABI_SYMBOLS = [
     "pdt_format_frames", "pdt_read_stage", "pdt_stage_len", "pdt_kernel_times", "pdt_make_lpf",
     "pdt_wav_parse_header", "pdt_time_axis", "pdt_stage_bytesync", "pdt_tip_check", "pdt_tip_frames",
     "pdt_stream_begin", "pdt_stream_push_pcm16", "pdt_stream_push_f32", "pdt_stream_end", "pdt_stream_frames",
-    "pdt_keep_quality", "pdt_chunk_reports", "pdt_stage_manchester", "pdt_stage_fir",
+    "pdt_keep_quality", "pdt_chunk_reports", "pdt_stage_manchester", "pdt_stage_fir", "pdt_stage_agc", "pdt_stage_squelch",
     "pdt_keep_presquelch", "pdt_demod_fd", "pdt_format_records", "pdt_stream_retained", "pdt_host_math", "pdt_get_device",
 ]
 
@@ -193,6 +198,10 @@ def lib():
     L.pdt_stream_retained.restype = C.c_uint64
     L.pdt_stage_manchester.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64, C.c_double, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
     L.pdt_stage_manchester.restype = C.c_int
+    L.pdt_stage_agc.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64, C.c_double, C.c_double, C.c_double, C.c_void_p]
+    L.pdt_stage_agc.restype = C.c_int
+    L.pdt_stage_squelch.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64, C.c_double]
+    L.pdt_stage_squelch.restype = C.c_int
     L.pdt_stage_fir.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p, C.c_void_p]
     L.pdt_stage_fir.restype = C.c_int
     L.pdt_keep_quality.argtypes = [C.c_void_p, C.c_int]
@@ -356,6 +365,20 @@ class Demodulator:
         _check(self._L.pdt_stage_fir(self._h, a.ctypes.data, a.size, C.addressof(state) if state is not None else None,
                                      out.ctypes.data), "pdt_stage_fir")
         return out
+
+    def stage_agc(self, x: np.ndarray, initial: float, state: "AgcState | None" = None, attack: float = 0.0, decay: float = 0.0):
+        """NormalizingAGC on these samples alone (gain in `state`, updated in place); returns the output (the reference works in place)"""
+        a = np.array(x, dtype=self._dt(), copy=True)
+        _check(self._L.pdt_stage_agc(self._h, a.ctypes.data, a.size, float(initial), float(attack), float(decay),
+                                     C.addressof(state) if state is not None else None), "pdt_stage_agc")
+        return a
+
+    def stage_squelch(self, x: np.ndarray, lock: np.ndarray, threshold: float) -> np.ndarray:
+        a = np.array(x, dtype=self._dt(), copy=True)
+        l = np.ascontiguousarray(lock, dtype=self._dt())
+        assert a.size == l.size
+        _check(self._L.pdt_stage_squelch(self._h, a.ctypes.data, l.ctypes.data, a.size, float(threshold)), "pdt_stage_squelch")
+        return a
 
     def stats_interp(self) -> int:
         taps, interp = make_lpf(self.mode, self.sample_rate)

@@ -2438,7 +2438,116 @@ template <typename T> static int stage_fir(pdt_ctx *ctx, const void *in_host, ui
     return PDT_OK;
 }
 
+template <typename T> static int stage_agc(pdt_ctx *ctx, void *data_host, uint64_t n, double initial, double attack, double decay,
+                                           pdt_agc_state *state)
+{
+    pdt_agc_state fresh;
+    memset(&fresh, 0, sizeof fresh);
+    if (!state) state = &fresh;
+    const bool argos = ctx->cfg.mode == PDT_MODE_ARGOS;
+    const int interp = (int)ctx->interp;
+    const T Fs = (T)ctx->cfg.sample_rate;
+    const T fsi = Fs * (T)interp;                                              // POESTIPdemod/main.c:429
+    AgcParams<T> AP;
+    AP.attack = attack != 0 ? (T)attack : (T)(79.5775 * (2.0 * M_PI / (double)fsi));
+    AP.decay = decay != 0 ? (T)decay : (T)(159.1549 * (2.0 * M_PI / (double)fsi));
+    AP.squelch = 0;
+    AP.squelch_thr = 0;
+    AP.raw_out = nullptr;
+    const T gain0 = state->started ? (T)state->gain : (T)initial;              // AGC.c:91-95: `initial` counts on the first call only
+    state->started = 1;
+    if (n == 0) { state->gain = (double)gain0; return PDT_OK; }
+    // the whole-capture path's block geometry (any values give the same output)
+    const double fs_d = (double)ctx->cfg.sample_rate;
+    auto round4 = [](long long v) { return (v + 3) / 4 * 4; };
+    long long Ba = ctx->cfg.agc_block ? ctx->cfg.agc_block : (long long)((argos ? 0.125 : 0.0625) * fs_d * interp);
+    long long Wa = ctx->cfg.agc_warm ? ctx->cfg.agc_warm : (long long)((argos ? 2.0 : 1.0) * fs_d * interp);
+    Ba = std::max<long long>(64, round4(Ba));
+    Wa = round4(Wa);
+    const long long na = (long long)n, nb = (na + Ba - 1) / Ba, grid = (nb + 63) / 64;
+    int rc;
+    if ((rc = ctx->fir.ensure((size_t)(na + 1) * sizeof(T)))) return rc;
+    if ((rc = ctx->agc.ensure((size_t)(na + 1) * sizeof(T)))) return rc;
+    if ((rc = ctx->seams_agc.ensure((size_t)(nb + 1) * sizeof(AgcSeam<T>)))) return rc;
+    if ((rc = ctx->agc_maps.ensure((size_t)(nb + 1) * (sizeof(AgcMap) + sizeof(double))))) return rc;
+    if ((rc = ctx->scal.ensure(sizeof(DevScalars)))) return rc;
+    hipStream_t st = ctx->stream;
+    const T *a_in = (const T *)ctx->fir.p;
+    T *a_out = (T *)ctx->agc.p;
+    DevScalars *d_sc = (DevScalars *)ctx->scal.p;
+    T *d_norm = (T *)&d_sc->norm;
+    AgcMap *d_maps = (AgcMap *)ctx->agc_maps.p;
+    double *d_guess = (double *)(d_maps + nb + 1);
+    DevScalars sc;
+    memset(&sc, 0, sizeof sc);
+    memcpy(&sc.norm, &gain0, sizeof(T));
+    double agc_K = (sizeof(T) == 4) ? 11.0 : 34.0;
+    if (ctx->tune.agc_k > 0) agc_K = ctx->tune.agc_k;
+    Plan &PL = ctx->plan;
+    PL.clear();
+    PL.side_stream = ctx->stream2;
+    PL.copy(OP_H2D, d_sc, &sc, sizeof sc);
+    PL.copy(OP_H2D, ctx->fir.p, data_host, (size_t)na * sizeof(T));
+    PDT_LAUNCH(256, k_agc_affine<T>, dim3((unsigned)nb), dim3(256), 0, st, a_in, na, AP.decay, Ba, d_maps);
+    PDT_LAUNCH(1024, k_agc_guess<T>, dim3(1), dim3(1024), 0, st, (const AgcMap *)d_maps, nb, (const T *)d_norm, d_guess, 1, nb);
+    PDT_LAUNCH(64, k_agc_block<T>, dim3((unsigned)grid), dim3(64), 0, st, a_in, na, AP, d_norm, Ba, Wa, (const double *)d_guess,
+               (const T *)nullptr, a_out, (AgcSeam<T> *)ctx->seams_agc.p, agc_K);
+    PDT_LAUNCH(1024, k_agc_scan<T>, dim3(1), dim3(1024), 0, st, na, Ba, (const AgcSeam<T> *)ctx->seams_agc.p, &d_sc->agc_first_bad);
+    PDT_LAUNCH(64, k_agc_fix<T>, dim3(1), dim3(64), 0, st, a_in, na, AP, Ba, (const T *)nullptr, a_out, (AgcSeam<T> *)ctx->seams_agc.p,
+               d_sc->counters, (const long long *)&d_sc->agc_first_bad);
+    {
+        pdt_ctx *self = ctx;
+        if ((rc = execute_plans(&self, 1))) return rc;
+    }
+    HIP_TRY(hipStreamSynchronize(st));
+    HIP_TRY(hipMemcpy(data_host, a_out, (size_t)na * sizeof(T), hipMemcpyDeviceToHost));      // in place, as the reference
+    AgcSeam<T> last;
+    HIP_TRY(hipMemcpy(&last, (const AgcSeam<T> *)ctx->seams_agc.p + (nb - 1), sizeof last, hipMemcpyDeviceToHost));
+    state->gain = (double)last.g1;
+    memset(ctx->stage_len, 0, sizeof ctx->stage_len);
+    return PDT_OK;
+}
+
+template <typename T> static int stage_squelch(pdt_ctx *ctx, void *data_host, const void *lock_host, uint64_t n, double thr)
+{
+    if (n == 0) return PDT_OK;
+    int rc;
+    if ((rc = ctx->agc.ensure((size_t)(n + 4) * sizeof(T)))) return rc;
+    if ((rc = ctx->lock.ensure((size_t)(n + 4) * sizeof(T)))) return rc;
+    hipStream_t st = ctx->stream;
+    Plan &PL = ctx->plan;
+    PL.clear();
+    PL.side_stream = ctx->stream2;
+    PL.copy(OP_H2D, ctx->agc.p, data_host, (size_t)n * sizeof(T));
+    PL.copy(OP_H2D, ctx->lock.p, lock_host, (size_t)n * sizeof(T));
+    PDT_LAUNCH(256, k_squelch<T>, dim3((unsigned)((n + 1023) / 1024)), dim3(256), 0, st, (T *)ctx->agc.p, (const T *)ctx->lock.p, (long long)n,
+               (T)thr);
+    {
+        pdt_ctx *self = ctx;
+        if ((rc = execute_plans(&self, 1))) return rc;
+    }
+    HIP_TRY(hipStreamSynchronize(st));
+    HIP_TRY(hipMemcpy(data_host, ctx->agc.p, (size_t)n * sizeof(T), hipMemcpyDeviceToHost));
+    memset(ctx->stage_len, 0, sizeof ctx->stage_len);
+    return PDT_OK;
+}
 }  // extern "C++"
+
+int pdt_stage_agc(pdt_ctx *ctx, void *data_host, uint64_t n, double initial, double attack, double decay, pdt_agc_state *state)
+{
+    if (!ctx || (!data_host && n) || n >= (1ull << 31)) return PDT_ERR_ARG;
+    HIP_TRY(hipSetDevice(ctx->cfg.device));
+    if (ctx->elem == 8) return stage_agc<double>(ctx, data_host, n, initial, attack, decay, state);
+    return stage_agc<float>(ctx, data_host, n, initial, attack, decay, state);
+}
+
+int pdt_stage_squelch(pdt_ctx *ctx, void *data_host, const void *lock_host, uint64_t n, double threshold)
+{
+    if (!ctx || ((!data_host || !lock_host) && n) || n >= (1ull << 31)) return PDT_ERR_ARG;
+    HIP_TRY(hipSetDevice(ctx->cfg.device));
+    if (ctx->elem == 8) return stage_squelch<double>(ctx, data_host, lock_host, n, threshold);
+    return stage_squelch<float>(ctx, data_host, lock_host, n, threshold);
+}
 
 int pdt_stage_manchester(pdt_ctx *ctx, const void *symbols_host, uint64_t nsymbols, double resync_threshold,
                          pdt_manchester_state *state, uint8_t *bits_out, uint32_t *bit_symbol_out, uint64_t *nbits_out)

@@ -87,3 +87,43 @@ def test_manchester_stage_argos(pdt, orc):
         bits, bsym, _ = manchester_replay(pdt, d, sym, symidx, 2400, 0.5)
         assert bits.tobytes() == o.stage(orc.ST_BITS).tobytes()
         assert o.stage(orc.ST_SYMT)[bsym].tobytes() == o.stage(orc.ST_BITT).tobytes()
+
+
+@pytest.mark.parametrize("fs,chunk", [(50000, 10000), (250000, 10000), (50000, 777)])
+def test_agc_stage_replays_the_oracle_chunk_by_chunk(pdt, orc, fs, chunk):
+    iq = pdt.synth_capture(0, fs, 3.0, seed=45)
+    o = orc.Oracle(orc.POES, fs, iq, chunk=chunk)
+    x, want = o.stage(orc.ST_FIR), o.stage(orc.ST_AGC)
+    step = chunk * o.interp
+    with pdt.Demodulator(pdt.MODE_POES, fs, chunk=chunk) as d:
+        st = pdt.AgcState()
+        got = np.concatenate([d.stage_agc(x[a:b], o.norm_factor, st) for a, b in chunks_of(len(x), step)])
+        assert got.dtype == want.dtype and got.tobytes() == want.tobytes()
+        assert st.started == 1
+        # the carried gain is the reference's static: one more sample from it = the same sample in one go
+        whole = pdt.AgcState()
+        ref = d.stage_agc(x, o.norm_factor, whole)
+        assert ref.tobytes() == want.tobytes() and whole.gain == st.gain
+        # `initial` counts on the first call only (AGC.c:91-95)
+        st2 = pdt.AgcState()
+        a = d.stage_agc(x[:step], o.norm_factor, st2)
+        b = d.stage_agc(x[step:2 * step], 123.0, st2)
+        assert np.concatenate([a, b]).tobytes() == want[:2 * step].tobytes()
+    # tiny blocks with a warm-up far too short: every seam is repaired, same result
+    with pdt.Demodulator(pdt.MODE_POES, fs, chunk=chunk, agc_block=64, agc_warm=64) as d:
+        st = pdt.AgcState()
+        n = 20 * step
+        got = np.concatenate([d.stage_agc(x[a:b], o.norm_factor, st) for a, b in chunks_of(n, step)])
+        assert got.tobytes() == want[:n].tobytes()
+
+
+def test_agc_and_squelch_stages_argos(pdt, orc):
+    iq = pdt.synth_capture(1, 32000, 8.0, f0_hz=160.0, seed=46)
+    o = orc.Oracle(orc.ARGOS, 32000, iq)
+    x, raw, want, lock = o.stage(orc.ST_FIR), o.stage(orc.ST_AGC_RAW), o.stage(orc.ST_AGC), o.stage(orc.ST_LOCK)
+    with pdt.Demodulator(pdt.MODE_ARGOS, 32000) as d:
+        st = pdt.AgcState()
+        got = np.concatenate([d.stage_agc(x[a:b], o.norm_factor, st) for a, b in chunks_of(len(x), 2400)])
+        assert got.tobytes() == raw.tobytes()                                   # NormalizingAGC alone: what -r dumps
+        sq = np.concatenate([d.stage_squelch(got[a:b], lock[a:b], 0.15) for a, b in chunks_of(len(x), 2400)])
+        assert sq.tobytes() == want.tobytes()                                   # ... then Squelch (ARGOSdemod/main.c:276)
