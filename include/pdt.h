@@ -295,6 +295,25 @@ typedef struct pdt_fir_state {          /* LowPassFilter.c:13-41 (interpolating 
  * (pdt_time_axis).                                                                                                    */
 int      pdt_stage_fir(pdt_ctx *ctx, const void *in_host, uint64_t n, pdt_fir_state *state, void *out_host);
 
+typedef struct pdt_pll_state {          /* CarrierTrackingPLL.c:60-75 */
+    int32_t  started;                   /* 0 = the next call is the first one (firstLock == -2: the statics get their start values) */
+    int32_t  locked;                    /* firstLock >= 0: the one-time lock has happened, the tracking gains are in force   */
+    int64_t  lock_index;                /* firstLock: index, within the call that saw it, of the sample that declared the lock */
+    double   lock_freq_hz;              /* " : PLL locked at %0.2fHz" (:269)                                                  */
+    double   phase, freq;               /* d_phase, d_freq after the last sample                                              */
+    double   avg_phase;                 /* averagePhase (the return value)                                                    */
+    double   locksig;                   /* d_locksig                                                                          */
+    double   sweep;                     /* sweep (signed, :232-246); frozen at the lock                                       */
+} pdt_pll_state;
+/* DT CarrierTrackPLL(DT complex *complexDataIn, DT *realDataOut, DT *lockSignalStreamOut, unsigned int nSamples, DT Fs, ...)
+ * (CarrierTrackPLL.h:11) with the constants the context's main passes (POESTIPdemod/main.c:413-420; the twin's with
+ * PDT_CHAIN_LIVE): iq_host = n `float complex` values (pairs of float), out_host = realDataOut, lock_out_host (optional) =
+ * lockSignalStreamOut, *avg_phase_ret (optional) = the return value.  Runs the whole-capture path's PLL kernels (sequential
+ * acquisition, block-parallel tracking with validated seams, lock-detector and averagePhase EMAs) from the record's state and
+ * stops behind the PLL.  Float contexts only (PDT_ERR_FORMAT for ARGOS: its input would be `double complex`, a sample format
+ * the kernels do not read); not while a stream is open or with cfg.profile (PDT_ERR_STATE).                               */
+int      pdt_stage_pll(pdt_ctx *ctx, const void *iq_host, uint64_t n, pdt_pll_state *state, void *out_host, void *lock_out_host,
+                       double *avg_phase_ret);
 typedef struct pdt_agc_state {          /* AGC.c:84-95 */
     int32_t  started;                   /* 0 = the next call is the first one: its `initial` becomes the gain           */
     int32_t  pad;

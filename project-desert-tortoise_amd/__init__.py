@@ -115,6 +115,13 @@ class ManchesterState(C.Structure):
     _fields_ = [("current", C.c_double), ("previous", C.c_double), ("clockmod", C.c_uint32), ("even_odd", C.c_uint32)]
 
 
+class PllState(C.Structure):
+    """pdt_pll_state: CarrierTrackPLL's statics (a zeroed record = before the first call)"""
+    _fields_ = [("started", C.c_int32), ("locked", C.c_int32), ("lock_index", C.c_int64), ("lock_freq_hz", C.c_double),
+                ("phase", C.c_double), ("freq", C.c_double), ("avg_phase", C.c_double), ("locksig", C.c_double),
+                ("sweep", C.c_double)]
+
+
 class AgcState(C.Structure):
     """pdt_agc_state: NormalizingAGC's static gain (a zeroed record = before the first call)"""
     _fields_ = [("started", C.c_int32), ("pad", C.c_int32), ("gain", C.c_double)]
@@ -136,7 +143,7 @@ ABI_SYMBOLS = [
     "pdt_format_frames", "pdt_read_stage", "pdt_stage_len", "pdt_kernel_times", "pdt_make_lpf",
     "pdt_wav_parse_header", "pdt_time_axis", "pdt_stage_bytesync", "pdt_tip_check", "pdt_tip_frames",
     "pdt_stream_begin", "pdt_stream_push_pcm16", "pdt_stream_push_f32", "pdt_stream_end", "pdt_stream_frames",
-    "pdt_keep_quality", "pdt_chunk_reports", "pdt_stage_manchester", "pdt_stage_fir", "pdt_stage_agc", "pdt_stage_squelch",
+    "pdt_keep_quality", "pdt_chunk_reports", "pdt_stage_manchester", "pdt_stage_fir", "pdt_stage_agc", "pdt_stage_squelch", "pdt_stage_pll",
     "pdt_keep_presquelch", "pdt_demod_fd", "pdt_format_records", "pdt_stream_retained", "pdt_host_math", "pdt_get_device",
 ]
 
@@ -198,6 +205,8 @@ def lib():
     L.pdt_stream_retained.restype = C.c_uint64
     L.pdt_stage_manchester.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64, C.c_double, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
     L.pdt_stage_manchester.restype = C.c_int
+    L.pdt_stage_pll.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+    L.pdt_stage_pll.restype = C.c_int
     L.pdt_stage_agc.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64, C.c_double, C.c_double, C.c_double, C.c_void_p]
     L.pdt_stage_agc.restype = C.c_int
     L.pdt_stage_squelch.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64, C.c_double]
@@ -365,6 +374,18 @@ class Demodulator:
         _check(self._L.pdt_stage_fir(self._h, a.ctypes.data, a.size, C.addressof(state) if state is not None else None,
                                      out.ctypes.data), "pdt_stage_fir")
         return out
+
+    def stage_pll(self, iq: np.ndarray, state: "PllState | None" = None):
+        """CarrierTrackPLL on these complex samples alone (float32[n,2]; statics in `state`, updated in place):
+        (realDataOut, lockSignalStreamOut, return value)"""
+        a = np.ascontiguousarray(iq, dtype="<f4").reshape(-1)
+        n = a.size // 2
+        out = np.zeros(n, dtype="<f4")
+        lock = np.zeros(n, dtype="<f4")
+        ret = C.c_double(0)
+        _check(self._L.pdt_stage_pll(self._h, a.ctypes.data, n, C.addressof(state) if state is not None else None, out.ctypes.data,
+                                     lock.ctypes.data, C.addressof(ret)), "pdt_stage_pll")
+        return out, lock, ret.value
 
     def stage_agc(self, x: np.ndarray, initial: float, state: "AgcState | None" = None, attack: float = 0.0, decay: float = 0.0):
         """NormalizingAGC on these samples alone (gain in `state`, updated in place); returns the output (the reference works in place)"""

@@ -329,6 +329,12 @@ struct pdt_ctx {
     // pdt_keep_quality: the averagePhase stream (what CarrierTrackPLL returns, chunk by chunk) and the per-chunk counts
     bool keep_quality = false;
     DevBuf avgph, term_ap, seams_q, chunkinfo;
+    // pdt_stage_pll: the next run starts the PLL from this state, keeps the lock and averagePhase streams and stops after the PLL
+    struct PllInject {
+        bool active = false, started = false, locked = false;
+        double phase = 0, freq = 0, avg = 0, locksig = 0, sweep = 0;
+    } inj;
+    long long last_pll_block = 0;       // PLL block length of the last run (where the end state sits in seams_pll)
     void *qual_pin = nullptr;
     size_t qual_pin_cap = 0;
     uint64_t pend_chunks = 0;           // ChunkInfo records in flight (0 = none asked for)
@@ -674,7 +680,8 @@ template <typename T> int run_capture(pdt_ctx *ctx, uint64_t n, int phase = RUN_
     // the sound-card twin's chain (POESTIPdemodPortAudio/main.c:324-393): the twin's constants, the lock signal kept and
     // Squelch between PLL and FIR
     const bool live = !argos && ctx->cfg.chain == PDT_CHAIN_LIVE;
-    const bool need_lock = argos || live;
+    const bool inject = ctx->inj.active && !ctx->sc.active;          // pdt_stage_pll
+    const bool need_lock = argos || live || inject;
     const long long N = (long long)n;
     const int interp = (int)ctx->interp;
     const int ntaps = (int)ctx->ntaps;
@@ -692,6 +699,13 @@ template <typename T> int run_capture(pdt_ctx *ctx, uint64_t n, int phase = RUN_
     // ---- parameters
     const T Fs = (T)ctx->cfg.sample_rate;
     PllParams<T> PP = make_pll_params<T>(ctx);
+    if (inject) {
+        PP.want_lock = 1;
+        if (ctx->inj.started && !ctx->inj.locked) {  // the acquisition goes on from the caller's state record
+            PP.phase0 = (T)ctx->inj.phase; PP.freq0 = (T)ctx->inj.freq; PP.avg0 = (T)ctx->inj.avg; PP.locksig0 = (T)ctx->inj.locksig;
+            PP.sweep0 = (T)ctx->inj.sweep; PP.i0 = 0;
+        }
+    }
     if (seg && first > 0 && !seg->locked) {          // the acquisition goes on where the last segment left it
         PP.phase0 = (T)seg->phase; PP.freq0 = (T)seg->freq; PP.avg0 = (T)seg->avg; PP.locksig0 = (T)seg->locksig;
         PP.sweep0 = (T)seg->sweep; PP.i0 = first;
@@ -831,7 +845,7 @@ template <typename T> int run_capture(pdt_ctx *ctx, uint64_t n, int phase = RUN_
     if (ctx->keep_agc_raw) AP.raw_out = (T *)ctx->agc_raw.p;
     // quality figure (pdt_keep_quality; whole captures only): averagePhase is one more EMA of the lock detector's kind
     // (CarrierTrackingPLL.c:80,124,152), alpha 0.00005 -> blocks of one time constant, 16 of warm-up behind the affine guess
-    const bool quality = ctx->keep_quality && !seg && N > 0;
+    const bool quality = (ctx->keep_quality || inject) && !seg && N > 0;
     const T avg_alpha = (T)0.00005;
     const long long Bq = std::max<long long>(64, round4((long long)(1.0 / (double)avg_alpha)));
     const long long Wq = 16 * Bq;
@@ -963,7 +977,20 @@ template <typename T> int run_capture(pdt_ctx *ctx, uint64_t n, int phase = RUN_
     const bool serial_excl = 4 * grid_pll <= 960 && !ctx->tune.no_excl;
     long long fix_regions = 1, fix_region_blocks = 0;
     L.begin("pll_acquire");
-    if (seg && seg->locked) {
+    if (inject && ctx->inj.locked) {
+        // pdt_stage_pll after the lock: sample 0 is a dummy the caller put in front, "locked at sample 0" with the state record
+        // = the state after it; the kernels that start behind the lock do the rest
+        PllLockInfo<T> li;
+        memset(&li, 0, sizeof li);
+        li.lock_sample = 0;
+        li.st.phase = (T)ctx->inj.phase; li.st.freq = (T)ctx->inj.freq; li.st.avg_phase = (T)ctx->inj.avg;
+        li.st.locksig = (T)ctx->inj.locksig; li.st.sweep = (T)ctx->inj.sweep;
+        memcpy(spin + 64, &li, sizeof li);
+        PL.copy(OP_H2D, d_info, spin + 64, sizeof li);
+        PL.memset_async(d_pll, 0, sizeof(T));
+        PL.memset_async(d_lock, 0, sizeof(T));
+        PL.memset_async(d_avgph, 0, sizeof(T));
+    } else if (seg && seg->locked) {
         // the lock happened in an earlier segment: the kernels that start "after the lock" start at `first` with the carried
         // true state (the head walks the first samples, the block-parallel results are validated against it as ever)
         PllLockInfo<T> li;
@@ -1097,6 +1124,9 @@ template <typename T> int run_capture(pdt_ctx *ctx, uint64_t n, int phase = RUN_
             L.end();
         }
     }
+
+    const size_t ops_after_pll = PL.ops.size();
+    ctx->last_pll_block = Bp;
 
     // ---- FIR
     if (n_out > 0) {
@@ -1430,7 +1460,10 @@ template <typename T> int run_capture(pdt_ctx *ctx, uint64_t n, int phase = RUN_
         PL.copy(OP_D2H, spin + 4096, d_tail, sizeof(SegTail<T>));
     }
     ctx->pend_chunks = 0;
-    if (ctx->keep_quality && !seg && n_chunks > 0) {
+    if (inject) {
+        // the stage call ends behind the PLL: drop what was recorded for the later stages (their counters stay zero)
+        PL.ops.resize(ops_after_pll);
+    } else if (ctx->keep_quality && !seg && n_chunks > 0) {
         // (N > 0 here; a context without a PLL run -- never -- would leave avg_phase 0)
         PDT_LAUNCH(256, k_chunk_info<T>, dim3((unsigned)((n_chunks + 255) / 256)), dim3(256), 0, st, (const T *)d_avgph, N, chunk, n_chunks,
                            interp, (const long long *)d_symidx, (const unsigned long long *)&d_sc->nsym, (const unsigned *)d_bitsym,
@@ -2438,6 +2471,71 @@ template <typename T> static int stage_fir(pdt_ctx *ctx, const void *in_host, ui
     return PDT_OK;
 }
 
+template <typename T> static int stage_pll(pdt_ctx *ctx, const void *iq_host, uint64_t n, pdt_pll_state *state, void *out_host,
+                                           void *lock_out_host, double *avg_phase_ret)
+{
+    pdt_pll_state fresh;
+    memset(&fresh, 0, sizeof fresh);
+    if (!state) state = &fresh;
+    if (n == 0) {                                                     // the loop body never runs; :277 returns the static
+        if (avg_phase_ret) *avg_phase_ret = state->started ? state->avg_phase : 0.0;
+        return PDT_OK;
+    }
+    const bool was_locked = state->started && state->locked;
+    const uint64_t lead = was_locked ? 1 : 0;                         // a dummy sample in front stands for "locked before sample 0"
+    const uint64_t N = n + lead;
+    int rc = ctx->pcm.ensure((size_t)N * 8 + 16);
+    if (rc) return rc;
+    HIP_TRY(hipMemset(ctx->pcm.p, 0, 8));
+    HIP_TRY(hipMemcpy((char *)ctx->pcm.p + lead * 8, iq_host, (size_t)n * 8, hipMemcpyHostToDevice));
+    ctx->pcm_dev = ctx->pcm.p;
+    ctx->pcm_fmt = 1;                                                 // float pairs = `float complex`, taken as they are
+    ctx->inj.active = true;
+    ctx->inj.started = state->started != 0;
+    ctx->inj.locked = was_locked;
+    ctx->inj.phase = state->phase; ctx->inj.freq = state->freq; ctx->inj.avg = state->avg_phase;
+    ctx->inj.locksig = state->locksig; ctx->inj.sweep = state->sweep;
+    ctx->batch_hint = 1;
+    ctx->n_samples = N;
+    ctx->n_out = N * ctx->interp;
+    rc = run_capture<T>(ctx, N, RUN_ALL);
+    ctx->inj.active = false;
+    if (rc) return rc;
+    // outputs and the statics after the call, from the streams the run left on the device
+    if (out_host) HIP_TRY(hipMemcpy(out_host, (const T *)ctx->pll.p + lead, (size_t)n * sizeof(T), hipMemcpyDeviceToHost));
+    if (lock_out_host) HIP_TRY(hipMemcpy(lock_out_host, (const T *)ctx->lock.p + lead, (size_t)n * sizeof(T), hipMemcpyDeviceToHost));
+    T last_lock = 0, last_avg = 0;
+    HIP_TRY(hipMemcpy(&last_lock, (const T *)ctx->lock.p + (N - 1), sizeof(T), hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpy(&last_avg, (const T *)ctx->avgph.p + (N - 1), sizeof(T), hipMemcpyDeviceToHost));
+    PllLockInfo<T> info;
+    HIP_TRY(hipMemcpy(&info, ctx->lockinfo.p, sizeof info, hipMemcpyDeviceToHost));
+    state->started = 1;
+    if (info.lock_sample < 0) {                                       // still searching: the acquisition's state after the last sample
+        state->phase = (double)info.st.phase; state->freq = (double)info.st.freq; state->sweep = (double)info.st.sweep;
+    } else {
+        if (!was_locked) {
+            state->locked = 1;
+            state->lock_index = info.lock_sample;
+            state->lock_freq_hz = (double)(info.freq_at_lock * (T)ctx->cfg.sample_rate) / (2.0 * M_PI);   // CarrierTrackingPLL.c:269
+        }
+        state->sweep = (double)info.st.sweep;
+        if (info.lock_sample == (long long)N - 1) {                   // locked on the very last sample: nothing walked behind it
+            state->phase = (double)info.st.phase; state->freq = (double)info.st.freq;
+        } else {
+            PllSeam<T> sm;
+            const long long Bp = ctx->last_pll_block > 0 ? ctx->last_pll_block : 1;
+            HIP_TRY(hipMemcpy(&sm, (const PllSeam<T> *)ctx->seams_pll.p + ((long long)N - 1) / Bp, sizeof sm, hipMemcpyDeviceToHost));
+            state->phase = (double)sm.phase1; state->freq = (double)sm.freq1;
+        }
+    }
+    state->locksig = (double)last_lock;
+    state->avg_phase = (double)last_avg;
+    if (avg_phase_ret) *avg_phase_ret = (double)last_avg;
+    memset(ctx->stage_len, 0, sizeof ctx->stage_len);
+    ctx->frames_host.clear();
+    return PDT_OK;
+}
+
 template <typename T> static int stage_agc(pdt_ctx *ctx, void *data_host, uint64_t n, double initial, double attack, double decay,
                                            pdt_agc_state *state)
 {
@@ -2532,6 +2630,16 @@ template <typename T> static int stage_squelch(pdt_ctx *ctx, void *data_host, co
     return PDT_OK;
 }
 }  // extern "C++"
+
+int pdt_stage_pll(pdt_ctx *ctx, const void *iq_host, uint64_t n, pdt_pll_state *state, void *out_host, void *lock_out_host,
+                  double *avg_phase_ret)
+{
+    if (!ctx || (!iq_host && n) || n >= (1ull << 31)) return PDT_ERR_ARG;
+    if (ctx->elem != 4) return PDT_ERR_FORMAT;                        // float contexts only (the input is `float complex`)
+    if (ctx->cfg.profile || ctx->sc.active) return PDT_ERR_STATE;
+    HIP_TRY(hipSetDevice(ctx->cfg.device));
+    return stage_pll<float>(ctx, iq_host, n, state, out_host, lock_out_host, avg_phase_ret);
+}
 
 int pdt_stage_agc(pdt_ctx *ctx, void *data_host, uint64_t n, double initial, double attack, double decay, pdt_agc_state *state)
 {

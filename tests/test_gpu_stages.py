@@ -127,3 +127,74 @@ def test_agc_and_squelch_stages_argos(pdt, orc):
         assert got.tobytes() == raw.tobytes()                                   # NormalizingAGC alone: what -r dumps
         sq = np.concatenate([d.stage_squelch(got[a:b], lock[a:b], 0.15) for a, b in chunks_of(len(x), 2400)])
         assert sq.tobytes() == want.tobytes()                                   # ... then Squelch (ARGOSdemod/main.c:276)
+
+
+def as_complex_float(iq):
+    """the reference's sample conversion: value / 32768 in float (wave.c:127-172)"""
+    return (iq.astype(np.float32) / np.float32(32768.0)).astype("<f4")
+
+
+def pll_replay(pdt, d, x, chunk):
+    st = pdt.PllState()
+    outs, locks, rets = [], [], []
+    for a, b in chunks_of(len(x), chunk):
+        o, l, r = d.stage_pll(x[a:b], st)
+        outs.append(o); locks.append(l); rets.append(r)
+    return np.concatenate(outs), np.concatenate(locks), np.array(rets), st
+
+
+@pytest.mark.parametrize("chunk", [10000, 1000])
+def test_pll_stage_replays_the_clip_chunk_by_chunk(pdt, orc, clip, chunk):
+    """CarrierTrackPLL chunk after chunk with its statics in the caller's record: realDataOut = the oracle's PLL stream, the return
+    values = the reference's own (golden, made by its objects), the lock happens in the call and at the index the oracle says"""
+    import os
+    from conftest import GOLDEN
+    rate, iq = clip
+    x = as_complex_float(iq)
+    o = orc.Oracle(orc.POES, rate, iq, chunk=chunk)
+    want = o.stage(orc.ST_PLL)
+    avg_ref = np.fromfile(os.path.join(GOLDEN, f"clip.c{chunk}.avg.f32"), dtype="<f4")
+    with pdt.Demodulator(pdt.MODE_POES, rate, chunk=chunk) as d:
+        out, lock, rets, st = pll_replay(pdt, d, x, chunk)
+        assert out.tobytes() == want.tobytes()
+        assert rets.astype("<f4").tobytes() == avg_ref[:len(rets)].tobytes()
+        assert st.started == 1 and st.locked == 1
+        assert st.lock_index == o.lock_sample % chunk
+        assert f"{st.lock_freq_hz:0.2f}" == f"{o.lock_freq_hz:0.2f}"
+        # any other cut of the same stream: same outputs, same statics at the end
+        out2, lock2, rets2, st2 = pll_replay(pdt, d, x, 33333)
+        assert out2.tobytes() == want.tobytes() and lock2.tobytes() == lock.tobytes()
+        for f in ("phase", "freq", "avg_phase", "locksig", "sweep"):
+            assert getattr(st, f) == getattr(st2, f), f
+        # the whole-capture path afterwards is unaffected by the stage calls
+        d.demod(iq)
+        assert d.text() == o.text()
+
+
+def test_pll_stage_lock_stream_live_chain(pdt, orc):
+    """the twin's constants and its lock stream (POESTIPdemodPortAudio/main.c:367): lockSignalStreamOut chunk by chunk"""
+    fs = 48000
+    iq = pdt.synth_capture(0, fs, 4.0, f0_hz=-1500.0, seed=47)
+    x = as_complex_float(iq)
+    o = orc.Oracle(orc.POES, fs, x.reshape(-1, 2), chunk=2400, chain=1)       # float32 capture, as the sound card delivers
+    with pdt.Demodulator(pdt.MODE_POES, fs, chunk=2400, chain=1) as d:
+        out, lock, rets, st = pll_replay(pdt, d, x, 2400)
+        assert lock.tobytes() == o.stage(orc.ST_LOCK).tobytes()
+        # the oracle's PLL stream is the one after Squelch there; before it the two agree wherever the lock stream is above 0.05
+        want = o.stage(orc.ST_PLL)
+        keep = lock >= np.float32(0.05)
+        assert np.array_equal(out[keep].view(np.uint32), want[keep].view(np.uint32)) and not want[~keep].any()
+
+
+def test_pll_stage_never_locks_on_noise(pdt, orc):
+    rng = np.random.default_rng(48)
+    iq = np.clip(rng.normal(0, 3000, (60000, 2)), -32768, 32767).astype("<i2")
+    x = as_complex_float(iq)
+    o = orc.Oracle(orc.POES, 50000, iq)
+    with pdt.Demodulator(pdt.MODE_POES, 50000) as d:
+        out, lock, rets, st = pll_replay(pdt, d, x, 7777)
+        assert o.lock_sample < 0 and st.locked == 0
+        assert out.tobytes() == o.stage(orc.ST_PLL).tobytes()
+    with pdt.Demodulator(pdt.MODE_ARGOS, 32000) as d:
+        with pytest.raises(pdt.PdtError):
+            d.stage_pll(x[:100])
