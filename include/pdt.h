@@ -314,6 +314,23 @@ typedef struct pdt_pll_state {          /* CarrierTrackingPLL.c:60-75 */
  * the kernels do not read); not while a stream is open or with cfg.profile (PDT_ERR_STATE).                               */
 int      pdt_stage_pll(pdt_ctx *ctx, const void *iq_host, uint64_t n, pdt_pll_state *state, void *out_host, void *lock_out_host,
                        double *avg_phase_ret);
+typedef struct pdt_gardner_state {      /* GardenerClockRecovery.c:12-15 */
+    double   next_sample;               /* nextSample, rolled over by the chunk length at the end of the call (:113)          */
+    double   prev_bit;                  /* prevBit                                                                            */
+    double   half_sample;               /* halfSample: the mid-point INDEX of the next symbol, not rolled over (Q3)           */
+} pdt_gardner_state;
+/* unsigned long GardenerClockRecovery(DT *dataStreamIn, DT *dataStreamInTime, unsigned long numSamples, DT *dataStreamOut,
+ * int Fs, DT baud, DT stepRange, DT kp) (GardenerClockRecovery.h:3) with the context's rate / baud / limits (main.c:438,
+ * ARGOSdemod/main.c:278).  in_host is the caller's BUFFER: `capacity` elements of which the first n are this call's samples --
+ * the function reads a few elements past n (the stale mid-point index of the first symbol, the look-ahead of the last), i.e.
+ * whatever the buffer still holds there from earlier calls, zeros behind `capacity` (the mains over-allocate; fresh pages).
+ * ARGOS: neighbour_host (optional) = the `capacity` elements of the array the main allocated right behind the buffer
+ * (lockSignalStream, ARGOSdemod/main.c:169-176) -- with glibc's heap layout the reads past the buffer land there (Q16).
+ * out_host: the symbols (room for n / (step - 0.25) + 2), pick_out[k] (optional) = index of the sample symbol k was taken
+ * at (dataStreamInTime[k] = dataStreamInTime[pick_out[k]] is the in-place compaction), *nsym_out = the return value.
+ * Runs the sequential sampler kernel of the streaming path (one wavefront).                                              */
+int      pdt_stage_gardner(pdt_ctx *ctx, const void *in_host, uint64_t n, uint64_t capacity, const void *neighbour_host,
+                           pdt_gardner_state *state, void *out_host, uint64_t *pick_out, uint64_t *nsym_out);
 typedef struct pdt_agc_state {          /* AGC.c:84-95 */
     int32_t  started;                   /* 0 = the next call is the first one: its `initial` becomes the gain           */
     int32_t  pad;

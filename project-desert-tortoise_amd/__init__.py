@@ -122,6 +122,11 @@ class PllState(C.Structure):
                 ("sweep", C.c_double)]
 
 
+class GardnerState(C.Structure):
+    """pdt_gardner_state: GardenerClockRecovery's statics (a zeroed record = before the first call)"""
+    _fields_ = [("next_sample", C.c_double), ("prev_bit", C.c_double), ("half_sample", C.c_double)]
+
+
 class AgcState(C.Structure):
     """pdt_agc_state: NormalizingAGC's static gain (a zeroed record = before the first call)"""
     _fields_ = [("started", C.c_int32), ("pad", C.c_int32), ("gain", C.c_double)]
@@ -143,7 +148,7 @@ ABI_SYMBOLS = [
     "pdt_format_frames", "pdt_read_stage", "pdt_stage_len", "pdt_kernel_times", "pdt_make_lpf",
     "pdt_wav_parse_header", "pdt_time_axis", "pdt_stage_bytesync", "pdt_tip_check", "pdt_tip_frames",
     "pdt_stream_begin", "pdt_stream_push_pcm16", "pdt_stream_push_f32", "pdt_stream_end", "pdt_stream_frames",
-    "pdt_keep_quality", "pdt_chunk_reports", "pdt_stage_manchester", "pdt_stage_fir", "pdt_stage_agc", "pdt_stage_squelch", "pdt_stage_pll",
+    "pdt_keep_quality", "pdt_chunk_reports", "pdt_stage_manchester", "pdt_stage_fir", "pdt_stage_agc", "pdt_stage_squelch", "pdt_stage_pll", "pdt_stage_gardner",
     "pdt_keep_presquelch", "pdt_demod_fd", "pdt_format_records", "pdt_stream_retained", "pdt_host_math", "pdt_get_device",
 ]
 
@@ -207,6 +212,9 @@ def lib():
     L.pdt_stage_manchester.restype = C.c_int
     L.pdt_stage_pll.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
     L.pdt_stage_pll.restype = C.c_int
+    L.pdt_stage_gardner.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64, C.c_uint64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
+                                    C.c_void_p]
+    L.pdt_stage_gardner.restype = C.c_int
     L.pdt_stage_agc.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64, C.c_double, C.c_double, C.c_double, C.c_void_p]
     L.pdt_stage_agc.restype = C.c_int
     L.pdt_stage_squelch.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64, C.c_double]
@@ -386,6 +394,20 @@ class Demodulator:
         _check(self._L.pdt_stage_pll(self._h, a.ctypes.data, n, C.addressof(state) if state is not None else None, out.ctypes.data,
                                      lock.ctypes.data, C.addressof(ret)), "pdt_stage_pll")
         return out, lock, ret.value
+
+    def stage_gardner(self, buf: np.ndarray, n: int, state: "GardnerState | None" = None, neighbour: "np.ndarray | None" = None):
+        """GardenerClockRecovery on buf[:n]; `buf` is the caller's whole buffer (what lies behind n is read as it stands);
+        returns (symbols, pick index per symbol)"""
+        a = np.ascontiguousarray(buf, dtype=self._dt())
+        nb = np.ascontiguousarray(neighbour, dtype=self._dt()) if neighbour is not None else None
+        cap = int(n / 4) + 64
+        sym = np.zeros(cap, dtype=self._dt())
+        pick = np.zeros(cap, dtype=np.uint64)
+        ns = C.c_uint64(0)
+        _check(self._L.pdt_stage_gardner(self._h, a.ctypes.data, int(n), a.size, nb.ctypes.data if nb is not None else None,
+                                         C.addressof(state) if state is not None else None, sym.ctypes.data, pick.ctypes.data,
+                                         C.addressof(ns)), "pdt_stage_gardner")
+        return sym[:ns.value], pick[:ns.value]
 
     def stage_agc(self, x: np.ndarray, initial: float, state: "AgcState | None" = None, attack: float = 0.0, decay: float = 0.0):
         """NormalizingAGC on these samples alone (gain in `state`, updated in place); returns the output (the reference works in place)"""

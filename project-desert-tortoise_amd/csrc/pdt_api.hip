@@ -2536,6 +2536,88 @@ template <typename T> static int stage_pll(pdt_ctx *ctx, const void *iq_host, ui
     return PDT_OK;
 }
 
+template <typename T> static int stage_gardner(pdt_ctx *ctx, const void *in_host, uint64_t n, uint64_t capacity,
+                                               const void *neighbour_host, pdt_gardner_state *state, void *out_host,
+                                               uint64_t *pick_out, uint64_t *nsym_out)
+{
+    pdt_gardner_state fresh;
+    memset(&fresh, 0, sizeof fresh);
+    if (!state) state = &fresh;
+    const bool argos = ctx->cfg.mode == PDT_MODE_ARGOS;
+    const int interp = (int)ctx->interp;
+    const long long C = (long long)capacity, na = (long long)n;
+    // The sampler's reads past the chunk (Q3: the mid-point index is not rolled over with nextSample) see what the caller's
+    // buffer still holds behind element n -- for the kernels that is "the previous chunk of the stream": a stream of two
+    // chunks of C, the buffer as it stands and then its first n elements, walked from chunk 1 on.
+    const long long total = C + na;
+    const T Fs = (T)ctx->cfg.sample_rate;
+    const T fsi = Fs * (T)interp;
+    GardnerParams<T> GP;
+    const T baud = argos ? (T)(400 * 2.0) : (T)(8320 * 2 + 0.3);              // main.c:90 / ARGOS main.c:64
+    GP.step = (T)(int)fsi / baud;                                              // GardenerClockRecovery.c:19
+    GP.kp = (T)3.0;
+    GP.lim = (T)0.1;
+    GP.n_total = total;
+    GP.chunk_out = C;
+    GP.argos_heap = 0;
+    GP.argos_field_bits = 0;
+    GP.argos_even = 0;
+    if (argos && neighbour_host && (size_t)C * 8 < 128 * 1024) {              // Q16: the array malloc'd behind this one
+        const unsigned long long req = 8ull * (unsigned long long)C;
+        GP.argos_heap = 1;
+        GP.argos_field_bits = ((req + 8 + 15) & ~15ull) | 1ull;
+        GP.argos_even = ((req + 8) % 16) != 0;
+    }
+    const long long sym_cap = (long long)((double)na / ((double)GP.step - 0.25)) + 64;
+    int rc;
+    if ((rc = ctx->agc.ensure((size_t)(total + 1) * sizeof(T)))) return rc;
+    if ((rc = ctx->lock.ensure((size_t)(total + 1) * sizeof(T)))) return rc;
+    if ((rc = ctx->sym.ensure((size_t)sym_cap * sizeof(T)))) return rc;
+    if ((rc = ctx->symidx.ensure((size_t)sym_cap * sizeof(long long)))) return rc;
+    if ((rc = ctx->scal.ensure(sizeof(DevScalars)))) return rc;
+    if ((rc = ctx->seg_dev.ensure(sizeof(SegTail<T>) + 256))) return rc;
+    hipStream_t st = ctx->stream;
+    T *d_in = (T *)ctx->agc.p, *d_nb = (T *)ctx->lock.p;
+    DevScalars *d_sc = (DevScalars *)ctx->scal.p;
+    SegTail<T> *d_tail = (SegTail<T> *)ctx->seg_dev.p;
+    SamplerCarry<T> carry_in;
+    carry_in.a = (T)state->next_sample; carry_in.b = (T)state->prev_bit; carry_in.c = (T)state->half_sample;
+    carry_in.c_first = 1; carry_in.count0 = 0;
+    Plan &PL = ctx->plan;
+    PL.clear();
+    PL.side_stream = ctx->stream2;
+    PL.memset_async(d_sc, 0, sizeof(DevScalars));
+    PL.copy(OP_H2D, d_in, in_host, (size_t)C * sizeof(T));
+    if (na) PL.copy(OP_H2D, d_in + C, in_host, (size_t)na * sizeof(T));
+    if (GP.argos_heap) {
+        PL.copy(OP_H2D, d_nb, neighbour_host, (size_t)C * sizeof(T));
+        if (na) PL.copy(OP_H2D, d_nb + C, neighbour_host, (size_t)na * sizeof(T));
+    }
+    PDT_LAUNCH(256, (k_gardner<T, GardnerLds<T>::LEN, GardnerLds<T>::OUT>), dim3(1), dim3(256), 0, st, (const T *)d_in,
+               (const T *)(GP.argos_heap ? d_nb : nullptr), GP, (T *)ctx->sym.p, (long long *)ctx->symidx.p, &d_sc->nsym, sym_cap,
+               (const GardnerEntry<T> *)nullptr, carry_in, &d_tail->sampler, 0ll);
+    DevScalars *back = ctx->pend_sc;                                  // pinned
+    PL.copy(OP_D2H, back, d_sc, sizeof(DevScalars));
+    {
+        pdt_ctx *self = ctx;
+        if ((rc = execute_plans(&self, 1))) return rc;
+    }
+    HIP_TRY(hipStreamSynchronize(st));
+    const uint64_t nsym = back->nsym;
+    if ((long long)nsym > sym_cap) return PDT_ERR_STATE;
+    if (nsym && out_host) HIP_TRY(hipMemcpy(out_host, ctx->sym.p, (size_t)nsym * sizeof(T), hipMemcpyDeviceToHost));
+    if (nsym && pick_out) {
+        HIP_TRY(hipMemcpy(pick_out, ctx->symidx.p, (size_t)nsym * sizeof(long long), hipMemcpyDeviceToHost));
+        for (uint64_t k = 0; k < nsym; k++) pick_out[k] -= (uint64_t)C;                      // index into this call's samples
+    }
+    if (nsym_out) *nsym_out = nsym;
+    SamplerCarry<T> after;
+    HIP_TRY(hipMemcpy(&after, &d_tail->sampler, sizeof after, hipMemcpyDeviceToHost));
+    state->next_sample = (double)after.a; state->prev_bit = (double)after.b; state->half_sample = (double)after.c;
+    memset(ctx->stage_len, 0, sizeof ctx->stage_len);
+    return PDT_OK;
+}
+
 template <typename T> static int stage_agc(pdt_ctx *ctx, void *data_host, uint64_t n, double initial, double attack, double decay,
                                            pdt_agc_state *state)
 {
@@ -2639,6 +2721,16 @@ int pdt_stage_pll(pdt_ctx *ctx, const void *iq_host, uint64_t n, pdt_pll_state *
     if (ctx->cfg.profile || ctx->sc.active) return PDT_ERR_STATE;
     HIP_TRY(hipSetDevice(ctx->cfg.device));
     return stage_pll<float>(ctx, iq_host, n, state, out_host, lock_out_host, avg_phase_ret);
+}
+
+int pdt_stage_gardner(pdt_ctx *ctx, const void *in_host, uint64_t n, uint64_t capacity, const void *neighbour_host,
+                      pdt_gardner_state *state, void *out_host, uint64_t *pick_out, uint64_t *nsym_out)
+{
+    if (!ctx || !in_host || capacity == 0 || n > capacity || capacity >= (1ull << 30)) return PDT_ERR_ARG;
+    if (ctx->cfg.sampler != PDT_SAMPLER_GARDNER) return PDT_ERR_ARG;
+    HIP_TRY(hipSetDevice(ctx->cfg.device));
+    if (ctx->elem == 8) return stage_gardner<double>(ctx, in_host, n, capacity, neighbour_host, state, out_host, pick_out, nsym_out);
+    return stage_gardner<float>(ctx, in_host, n, capacity, neighbour_host, state, out_host, pick_out, nsym_out);
 }
 
 int pdt_stage_agc(pdt_ctx *ctx, void *data_host, uint64_t n, double initial, double attack, double decay, pdt_agc_state *state)

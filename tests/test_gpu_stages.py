@@ -198,3 +198,51 @@ def test_pll_stage_never_locks_on_noise(pdt, orc):
     with pdt.Demodulator(pdt.MODE_ARGOS, 32000) as d:
         with pytest.raises(pdt.PdtError):
             d.stage_pll(x[:100])
+
+
+def gardner_replay(pdt, d, x, C, lock=None):
+    """the reference's chunk loop around the sampler: one persistent buffer of C elements that every chunk overwrites from
+    index 0 (what lies behind the chunk's end stays), statics in the record"""
+    st = pdt.GardnerState()
+    buf = np.zeros(C, dtype=x.dtype)
+    nbuf = np.zeros(C, dtype=x.dtype) if lock is not None else None
+    syms, picks = [], []
+    for a, b in chunks_of(len(x), C):
+        buf[:b - a] = x[a:b]
+        if nbuf is not None:
+            nbuf[:b - a] = lock[a:b]
+        s, p = d.stage_gardner(buf, b - a, st, nbuf)
+        syms.append(s)
+        picks.append(p.astype(np.int64) + a)
+    return np.concatenate(syms), np.concatenate(picks), st
+
+
+@pytest.mark.parametrize("chunk", [10000, 333])
+def test_gardner_stage_replays_the_clip_chunk_by_chunk(pdt, orc, clip, chunk):
+    rate, iq = clip                                                   # 250 195 samples: a short last chunk (Q3's stale reads)
+    o = orc.Oracle(orc.POES, rate, iq, chunk=chunk)
+    x = o.stage(orc.ST_AGC)
+    with pdt.Demodulator(pdt.MODE_POES, rate, chunk=chunk) as d:
+        sym, pick, st = gardner_replay(pdt, d, x, chunk * o.interp)
+        assert sym.tobytes() == o.stage(orc.ST_SYM).tobytes()
+        assert np.array_equal(pick, o.stage(orc.ST_SYMIDX))
+        assert st.prev_bit == float(sym[-1])
+
+
+@pytest.mark.parametrize("fs", [250000, 32000])
+def test_gardner_stage_other_rates(pdt, orc, fs):
+    iq = pdt.synth_capture(0, fs, 2.0, seed=49)[:-123]
+    o = orc.Oracle(orc.POES, fs, iq)
+    with pdt.Demodulator(pdt.MODE_POES, fs) as d:
+        sym, pick, _ = gardner_replay(pdt, d, o.stage(orc.ST_AGC), 10000 * o.interp)
+        assert sym.tobytes() == o.stage(orc.ST_SYM).tobytes() and np.array_equal(pick, o.stage(orc.ST_SYMIDX))
+
+
+@pytest.mark.parametrize("chunk", [2400, 1001])
+def test_gardner_stage_argos_heap_neighbour(pdt, orc, chunk):
+    """ARGOS: the reads past the buffer land in the lock-signal array behind it (Q16), for both alignments of the size field"""
+    iq = pdt.synth_capture(1, 32000, 8.0, f0_hz=160.0, seed=50)[:-77]
+    o = orc.Oracle(orc.ARGOS, 32000, iq, chunk=chunk)
+    with pdt.Demodulator(pdt.MODE_ARGOS, 32000, chunk=chunk) as d:
+        sym, pick, _ = gardner_replay(pdt, d, o.stage(orc.ST_AGC), chunk, lock=o.stage(orc.ST_LOCK))
+        assert sym.tobytes() == o.stage(orc.ST_SYM).tobytes() and np.array_equal(pick, o.stage(orc.ST_SYMIDX))
