@@ -181,7 +181,9 @@ int  pdt_keep_presquelch(pdt_ctx *ctx, int enable);
  * sampler, the Manchester decoder and the byte synchroniser for that chunk (main.c:438,445,454-460), i.e. everything the
  * "\r" progress line shows.  Before the lock the acquisition kernel delivers averagePhase as it goes; after it, one more
  * block-parallel EMA over the whole capture (same scheme and the same bit-for-bit guarantee as the lock detector's stream).
- * Costs two stream-sized buffers and ~0.15 us per 1000 samples of walker time; off by default.                            */
+ * Costs two stream-sized buffers and the EMA walkers' time (16 time constants of 20 000 samples per block: ~6 ms whatever the
+ * capture's length); captures of 512 MiB and more are then ingested before the chain starts instead of segment by segment
+ * while they arrive (pdt_demod_fd).  Off by default.                                                                     */
 int  pdt_keep_quality(pdt_ctx *ctx, int enable);
 typedef struct pdt_chunk_report {
     uint64_t samples;     /* nSamples of the chunk (the last one may be short)                                          */
@@ -314,6 +316,10 @@ typedef struct pdt_pll_state {          /* CarrierTrackingPLL.c:60-75 */
  * the kernels do not read); not while a stream is open or with cfg.profile (PDT_ERR_STATE).                               */
 int      pdt_stage_pll(pdt_ctx *ctx, const void *iq_host, uint64_t n, pdt_pll_state *state, void *out_host, void *lock_out_host,
                        double *avg_phase_ret);
+/* DT StaticGain(DT complex *complexData, unsigned int nSamples, DT desiredLevel) (AGC.h:4, AGC.c:48-74): the gain the mains
+ * take from their first chunk (main.c:384-389, level 1.0).  The samples as the capture file holds them (PDT_FMT_PCM16: int16
+ * pairs, converted as wave.c:127-172 does; PDT_FMT_F32: float pairs as they are); stateless.                              */
+int      pdt_stage_static_gain(pdt_ctx *ctx, const void *iq_host, uint64_t n, int sample_format, double level, double *gain_out);
 typedef struct pdt_gardner_state {      /* GardenerClockRecovery.c:12-15 */
     double   next_sample;               /* nextSample, rolled over by the chunk length at the end of the call (:113)          */
     double   prev_bit;                  /* prevBit                                                                            */
@@ -331,6 +337,16 @@ typedef struct pdt_gardner_state {      /* GardenerClockRecovery.c:12-15 */
  * Runs the sequential sampler kernel of the streaming path (one wavefront).                                              */
 int      pdt_stage_gardner(pdt_ctx *ctx, const void *in_host, uint64_t n, uint64_t capacity, const void *neighbour_host,
                            pdt_gardner_state *state, void *out_host, uint64_t *pick_out, uint64_t *nsym_out);
+typedef struct pdt_mm_state {           /* MMClockRecovery.c:12-22 */
+    int32_t  started;                   /* 0 = the next call is the first one (stepSize = Fs / baud, :20)                     */
+    int32_t  pad;
+    double   next_sample, step_size, sample_last;   /* nextSample (rolled over, :80), stepSize, sampleLast                    */
+} pdt_mm_state;
+/* unsigned long MMClockRecovery(DT *dataStreamIn, DT *dataStreamInTime, unsigned long numSamples, DT *dataStreamOut, int Fs,
+ * DT baud, DT stepRange, DT kp) (MMClockRecovery.h:3) with the context's rate / baud and cfg.mm_step_range / mm_kp (0 = 3 and
+ * 0.15, the commented-out call of ARGOSdemod/main.c:277).  Outputs as pdt_stage_gardner's; this sampler never reads past n.  */
+int      pdt_stage_mm(pdt_ctx *ctx, const void *in_host, uint64_t n, pdt_mm_state *state, void *out_host, uint64_t *pick_out,
+                      uint64_t *nsym_out);
 typedef struct pdt_agc_state {          /* AGC.c:84-95 */
     int32_t  started;                   /* 0 = the next call is the first one: its `initial` becomes the gain           */
     int32_t  pad;

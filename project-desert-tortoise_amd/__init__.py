@@ -127,6 +127,12 @@ class GardnerState(C.Structure):
     _fields_ = [("next_sample", C.c_double), ("prev_bit", C.c_double), ("half_sample", C.c_double)]
 
 
+class MmState(C.Structure):
+    """pdt_mm_state: MMClockRecovery's statics (a zeroed record = before the first call)"""
+    _fields_ = [("started", C.c_int32), ("pad", C.c_int32), ("next_sample", C.c_double), ("step_size", C.c_double),
+                ("sample_last", C.c_double)]
+
+
 class AgcState(C.Structure):
     """pdt_agc_state: NormalizingAGC's static gain (a zeroed record = before the first call)"""
     _fields_ = [("started", C.c_int32), ("pad", C.c_int32), ("gain", C.c_double)]
@@ -148,7 +154,7 @@ ABI_SYMBOLS = [
     "pdt_format_frames", "pdt_read_stage", "pdt_stage_len", "pdt_kernel_times", "pdt_make_lpf",
     "pdt_wav_parse_header", "pdt_time_axis", "pdt_stage_bytesync", "pdt_tip_check", "pdt_tip_frames",
     "pdt_stream_begin", "pdt_stream_push_pcm16", "pdt_stream_push_f32", "pdt_stream_end", "pdt_stream_frames",
-    "pdt_keep_quality", "pdt_chunk_reports", "pdt_stage_manchester", "pdt_stage_fir", "pdt_stage_agc", "pdt_stage_squelch", "pdt_stage_pll", "pdt_stage_gardner",
+    "pdt_keep_quality", "pdt_chunk_reports", "pdt_stage_manchester", "pdt_stage_fir", "pdt_stage_agc", "pdt_stage_squelch", "pdt_stage_pll", "pdt_stage_gardner", "pdt_stage_static_gain", "pdt_stage_mm",
     "pdt_keep_presquelch", "pdt_demod_fd", "pdt_format_records", "pdt_stream_retained", "pdt_host_math", "pdt_get_device",
 ]
 
@@ -215,6 +221,10 @@ def lib():
     L.pdt_stage_gardner.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64, C.c_uint64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
                                     C.c_void_p]
     L.pdt_stage_gardner.restype = C.c_int
+    L.pdt_stage_static_gain.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64, C.c_int, C.c_double, C.c_void_p]
+    L.pdt_stage_static_gain.restype = C.c_int
+    L.pdt_stage_mm.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+    L.pdt_stage_mm.restype = C.c_int
     L.pdt_stage_agc.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64, C.c_double, C.c_double, C.c_double, C.c_void_p]
     L.pdt_stage_agc.restype = C.c_int
     L.pdt_stage_squelch.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64, C.c_double]
@@ -407,6 +417,26 @@ class Demodulator:
         _check(self._L.pdt_stage_gardner(self._h, a.ctypes.data, int(n), a.size, nb.ctypes.data if nb is not None else None,
                                          C.addressof(state) if state is not None else None, sym.ctypes.data, pick.ctypes.data,
                                          C.addressof(ns)), "pdt_stage_gardner")
+        return sym[:ns.value], pick[:ns.value]
+
+    def stage_static_gain(self, iq: np.ndarray, level: float = 1.0) -> float:
+        """StaticGain over these samples (int16[n,2] as the WAV holds them, or float32[n,2])"""
+        f32 = np.asarray(iq).dtype.kind == "f"
+        a = np.ascontiguousarray(iq, dtype="<f4" if f32 else "<i2").reshape(-1)
+        g = C.c_double(0)
+        _check(self._L.pdt_stage_static_gain(self._h, a.ctypes.data, a.size // 2, 1 if f32 else 0, float(level), C.addressof(g)),
+               "pdt_stage_static_gain")
+        return g.value
+
+    def stage_mm(self, x: np.ndarray, state: "MmState | None" = None):
+        """MMClockRecovery on these samples alone (statics in `state`, updated in place): (symbols, pick index per symbol)"""
+        a = np.ascontiguousarray(x, dtype=self._dt())
+        cap = int(a.size / 3) + 64
+        sym = np.zeros(cap, dtype=self._dt())
+        pick = np.zeros(cap, dtype=np.uint64)
+        ns = C.c_uint64(0)
+        _check(self._L.pdt_stage_mm(self._h, a.ctypes.data, a.size, C.addressof(state) if state is not None else None,
+                                    sym.ctypes.data, pick.ctypes.data, C.addressof(ns)), "pdt_stage_mm")
         return sym[:ns.value], pick[:ns.value]
 
     def stage_agc(self, x: np.ndarray, initial: float, state: "AgcState | None" = None, attack: float = 0.0, decay: float = 0.0):

@@ -2201,7 +2201,8 @@ static int demod_overlapped(pdt_ctx *ctx, const IngestSrc &src, uint64_t nframes
 // hour-long POES captures: the chain starts on the part of the capture that has arrived (demod_overlapped)
 static bool overlap_ingest(const pdt_ctx *ctx, uint64_t nframes, size_t fb)
 {
-    return !ctx->tune.no_overlap && ctx->cfg.mode == PDT_MODE_POES && ctx->cfg.sampler != PDT_SAMPLER_MM && ctx->cfg.chain != PDT_CHAIN_LIVE &&
+    // (per-chunk reports come from whole-capture runs only: with pdt_keep_quality the capture is ingested first)
+    return !ctx->tune.no_overlap && !ctx->keep_quality && ctx->cfg.mode == PDT_MODE_POES && ctx->cfg.sampler != PDT_SAMPLER_MM && ctx->cfg.chain != PDT_CHAIN_LIVE &&
            (size_t)nframes * fb >= ((size_t)(ctx->tune.overlap_min_mb > 0 ? ctx->tune.overlap_min_mb : 512) << 20) && ctx->cfg.chunk > 0 &&
            nframes / ctx->cfg.chunk >= 64;
 }
@@ -2618,6 +2619,97 @@ template <typename T> static int stage_gardner(pdt_ctx *ctx, const void *in_host
     return PDT_OK;
 }
 
+template <typename T> static int stage_static_gain(pdt_ctx *ctx, const void *iq_host, uint64_t n, int fmt, double level, double *gain_out)
+{
+    const size_t fb = fmt == PDT_FMT_F32 ? 8 : 4;
+    int rc;
+    if ((rc = ctx->pcm.ensure((size_t)n * fb + 16))) return rc;
+    if ((rc = ctx->mag.ensure((size_t)(n + 1) * sizeof(T)))) return rc;
+    if ((rc = ctx->scal.ensure(sizeof(DevScalars)))) return rc;
+    hipStream_t st = ctx->stream;
+    DevScalars *d_sc = (DevScalars *)ctx->scal.p;
+    IqSrc src;
+    src.p = ctx->pcm.p;
+    src.fmt = fmt == PDT_FMT_F32 ? 1 : 0;
+    Plan &PL = ctx->plan;
+    PL.clear();
+    PL.side_stream = ctx->stream2;
+    PL.memset_async(d_sc, 0, sizeof(DevScalars));
+    PL.copy(OP_H2D, ctx->pcm.p, iq_host, (size_t)n * fb);
+    PDT_LAUNCH(256, k_static_gain<T>, dim3(1), dim3(256), 0, st, src, (long long)n, (T *)ctx->mag.p, (T)level, 0.0, (T *)&d_sc->norm);
+    DevScalars *back = ctx->pend_sc;                                  // pinned
+    PL.copy(OP_D2H, back, d_sc, sizeof(DevScalars));
+    {
+        pdt_ctx *self = ctx;
+        if ((rc = execute_plans(&self, 1))) return rc;
+    }
+    HIP_TRY(hipStreamSynchronize(st));
+    T g;
+    memcpy(&g, &back->norm, sizeof(T));
+    if (gain_out) *gain_out = (double)g;
+    return PDT_OK;
+}
+
+template <typename T> static int stage_mm(pdt_ctx *ctx, const void *in_host, uint64_t n, pdt_mm_state *state, void *out_host,
+                                          uint64_t *pick_out, uint64_t *nsym_out)
+{
+    pdt_mm_state fresh;
+    memset(&fresh, 0, sizeof fresh);
+    if (!state) state = &fresh;
+    if (nsym_out) *nsym_out = 0;
+    const bool argos = ctx->cfg.mode == PDT_MODE_ARGOS;
+    const T Fs = (T)ctx->cfg.sample_rate;
+    const T fsi = Fs * (T)(int)ctx->interp;
+    const T baud = argos ? (T)(400 * 2.0) : (T)(8320 * 2 + 0.3);
+    MmParams<T> MP;
+    const T rangeT = (T)(ctx->cfg.mm_step_range != 0 ? ctx->cfg.mm_step_range : 3.0);     // ARGOSdemod/main.c:277
+    MP.kp = (T)(ctx->cfg.mm_kp != 0 ? ctx->cfg.mm_kp : 0.15);
+    MP.step0 = (T)(int)fsi / baud;                                                        // MMClockRecovery.c:20
+    MP.step_max = (T)(int)fsi / (baud - rangeT);                                          // :9
+    MP.step_min = (T)(int)fsi / (baud + rangeT);                                          // :10
+    MP.n_total = (long long)n;
+    MP.chunk_out = (long long)n;                                                          // one call = one chunk
+    if (!state->started) { state->started = 1; state->next_sample = 0; state->step_size = (double)MP.step0; state->sample_last = 0; }
+    if (n == 0) return PDT_OK;
+    const long long sym_cap = (long long)((double)n / ((double)MP.step_min * 0.999)) + 64;
+    int rc;
+    if ((rc = ctx->agc.ensure((size_t)(n + 1) * sizeof(T)))) return rc;
+    if ((rc = ctx->sym.ensure((size_t)sym_cap * sizeof(T)))) return rc;
+    if ((rc = ctx->symidx.ensure((size_t)sym_cap * sizeof(long long)))) return rc;
+    if ((rc = ctx->scal.ensure(sizeof(DevScalars)))) return rc;
+    if ((rc = ctx->seg_dev.ensure(sizeof(SegTail<T>) + 256))) return rc;
+    hipStream_t st = ctx->stream;
+    DevScalars *d_sc = (DevScalars *)ctx->scal.p;
+    SegTail<T> *d_tail = (SegTail<T> *)ctx->seg_dev.p;
+    SamplerCarry<T> carry_in;
+    carry_in.a = (T)state->next_sample; carry_in.b = (T)state->step_size; carry_in.c = (T)state->sample_last;
+    carry_in.c_first = 0; carry_in.count0 = 0;
+    Plan &PL = ctx->plan;
+    PL.clear();
+    PL.side_stream = ctx->stream2;
+    PL.memset_async(d_sc, 0, sizeof(DevScalars));
+    PL.copy(OP_H2D, ctx->agc.p, in_host, (size_t)n * sizeof(T));
+    PDT_LAUNCH(PDT_GARDNER_THREADS, (k_mm<T, 8192, 1024>), dim3(1), dim3(PDT_GARDNER_THREADS), 0, st, (const T *)ctx->agc.p, MP,
+               (T *)ctx->sym.p, (long long *)ctx->symidx.p, &d_sc->nsym, sym_cap, carry_in, 1, &d_tail->sampler);
+    DevScalars *back = ctx->pend_sc;                                  // pinned
+    PL.copy(OP_D2H, back, d_sc, sizeof(DevScalars));
+    {
+        pdt_ctx *self = ctx;
+        if ((rc = execute_plans(&self, 1))) return rc;
+    }
+    HIP_TRY(hipStreamSynchronize(st));
+    const uint64_t nsym = back->nsym;
+    if ((long long)nsym > sym_cap) return PDT_ERR_STATE;
+    if (nsym && out_host) HIP_TRY(hipMemcpy(out_host, ctx->sym.p, (size_t)nsym * sizeof(T), hipMemcpyDeviceToHost));
+    if (nsym && pick_out) HIP_TRY(hipMemcpy(pick_out, ctx->symidx.p, (size_t)nsym * sizeof(long long), hipMemcpyDeviceToHost));
+    if (nsym_out) *nsym_out = nsym;
+    SamplerCarry<T> after;
+    HIP_TRY(hipMemcpy(&after, &d_tail->sampler, sizeof after, hipMemcpyDeviceToHost));
+    state->next_sample = (double)after.a; state->step_size = (double)after.b; state->sample_last = (double)after.c;
+    memset(ctx->stage_len, 0, sizeof ctx->stage_len);
+    return PDT_OK;
+}
+
 template <typename T> static int stage_agc(pdt_ctx *ctx, void *data_host, uint64_t n, double initial, double attack, double decay,
                                            pdt_agc_state *state)
 {
@@ -2731,6 +2823,28 @@ int pdt_stage_gardner(pdt_ctx *ctx, const void *in_host, uint64_t n, uint64_t ca
     HIP_TRY(hipSetDevice(ctx->cfg.device));
     if (ctx->elem == 8) return stage_gardner<double>(ctx, in_host, n, capacity, neighbour_host, state, out_host, pick_out, nsym_out);
     return stage_gardner<float>(ctx, in_host, n, capacity, neighbour_host, state, out_host, pick_out, nsym_out);
+}
+
+int pdt_stage_static_gain(pdt_ctx *ctx, const void *iq_host, uint64_t n, int sample_format, double level, double *gain_out)
+{
+    if (!ctx || !iq_host || n == 0 || n >= (1ull << 31) || (sample_format != PDT_FMT_PCM16 && sample_format != PDT_FMT_F32)) return PDT_ERR_ARG;
+    HIP_TRY(hipSetDevice(ctx->cfg.device));
+    if (ctx->elem == 8) return stage_static_gain<double>(ctx, iq_host, n, sample_format, level, gain_out);
+    return stage_static_gain<float>(ctx, iq_host, n, sample_format, level, gain_out);
+}
+
+int pdt_stage_mm(pdt_ctx *ctx, const void *in_host, uint64_t n, pdt_mm_state *state, void *out_host, uint64_t *pick_out,
+                 uint64_t *nsym_out)
+{
+    if (!ctx || (!in_host && n) || n >= (1ull << 30)) return PDT_ERR_ARG;
+    {
+        const double rg = ctx->cfg.mm_step_range != 0 ? ctx->cfg.mm_step_range : 3.0;
+        const double baud = ctx->cfg.mode == PDT_MODE_ARGOS ? 800.0 : 16640.3;
+        if (!(rg >= 0) || rg >= baud * 0.5) return PDT_ERR_ARG;                            // stepMax must stay positive and finite
+    }
+    HIP_TRY(hipSetDevice(ctx->cfg.device));
+    if (ctx->elem == 8) return stage_mm<double>(ctx, in_host, n, state, out_host, pick_out, nsym_out);
+    return stage_mm<float>(ctx, in_host, n, state, out_host, pick_out, nsym_out);
 }
 
 int pdt_stage_agc(pdt_ctx *ctx, void *data_host, uint64_t n, double initial, double attack, double decay, pdt_agc_state *state)

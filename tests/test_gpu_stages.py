@@ -246,3 +246,35 @@ def test_gardner_stage_argos_heap_neighbour(pdt, orc, chunk):
     with pdt.Demodulator(pdt.MODE_ARGOS, 32000, chunk=chunk) as d:
         sym, pick, _ = gardner_replay(pdt, d, o.stage(orc.ST_AGC), chunk, lock=o.stage(orc.ST_LOCK))
         assert sym.tobytes() == o.stage(orc.ST_SYM).tobytes() and np.array_equal(pick, o.stage(orc.ST_SYMIDX))
+
+
+def test_static_gain_stage(pdt, orc, clip):
+    rate, iq = clip
+    o = orc.Oracle(orc.POES, rate, iq)
+    with pdt.Demodulator(pdt.MODE_POES, rate) as d:
+        assert np.float32(d.stage_static_gain(iq[:10000])) == np.float32(o.norm_factor)
+        assert np.float32(d.stage_static_gain(as_complex_float(iq[:10000]))) == np.float32(o.norm_factor)
+        o2 = orc.Oracle(orc.POES, rate, iq, chunk=777)
+        assert np.float32(d.stage_static_gain(iq[:777])) == np.float32(o2.norm_factor)
+    a = pdt.synth_capture(1, 32000, 1.0, seed=51)
+    oa = orc.Oracle(orc.ARGOS, 32000, a)
+    with pdt.Demodulator(pdt.MODE_ARGOS, 32000) as d:
+        assert d.stage_static_gain(a[:2400]) == oa.norm_factor
+
+
+@pytest.mark.parametrize("mode,fs,chunk", [(0, 50000, 10000), (0, 50000, 777), (1, 32000, 2400)])
+def test_mm_stage_replays_the_oracle_chunk_by_chunk(pdt, orc, mode, fs, chunk):
+    iq = pdt.synth_capture(mode, fs, 3.0 if mode == 0 else 8.0, seed=52)[:-31]
+    o = orc.Oracle(mode, fs, iq, chunk=chunk, sampler=1)
+    x = o.stage(orc.ST_AGC)
+    step = chunk * o.interp
+    with pdt.Demodulator(mode, fs, chunk=chunk, sampler=1) as d:
+        st = pdt.MmState()
+        syms, picks = [], []
+        for a, b in chunks_of(len(x), step):
+            s, p = d.stage_mm(x[a:b], st)
+            syms.append(s)
+            picks.append(p.astype(np.int64) + a)
+        assert np.concatenate(syms).tobytes() == o.stage(orc.ST_SYM).tobytes()
+        assert np.array_equal(np.concatenate(picks), o.stage(orc.ST_SYMIDX))
+        assert st.started == 1 and st.sample_last == float(syms[-1][-1])
