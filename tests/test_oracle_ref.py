@@ -179,3 +179,29 @@ def test_live_chain_all_stages(orc, pdt, tmp_path, fs, chunk, seed, f0, scale):
     assert o.lock_sample > 0 and not pll[: min(o.lock_sample, 200)].any() and pll[o.lock_sample + 5000:].any()
     # and it is not the file chain
     assert o.stage(orc.ST_PLL).tobytes() != orc.Oracle(orc.POES, fs, raw, chunk=chunk).stage(orc.ST_PLL).tobytes()
+
+
+@pytest.mark.parametrize("name,args", [("clip.c10000", ["-c", "10000"]), ("clip.c1000", ["-c", "1000"])])
+def test_progress_golden_is_what_the_reference_objects_print(tmp_path, name, args):
+    """tests/golden/*.progress / *.avg.* (the chunk loop's progress line and CarrierTrackPLL's return values, used by
+    tests/test_gpu_quality.py) are what the reference's objects produce here"""
+    text, dump = run_ref(REF_POES, os.path.join(GOLDEN, "5sec_clip.wav"), tmp_path, args)
+    assert open(f"{dump}.progress", "rb").read() == open(os.path.join(GOLDEN, name + ".progress"), "rb").read()
+    assert open(f"{dump}.avg", "rb").read() == open(os.path.join(GOLDEN, name + ".avg.f32"), "rb").read()
+    assert text == open(os.path.join(GOLDEN, name + ".txt"), "rb").read()
+
+
+def test_progress_golden_synthetic(pdt, tmp_path):
+    iq = pdt.synth_capture(0, 50000, 3.0, seed=1234)                  # 15 chunks exactly: the loop's extra pass
+    wav = tmp_path / "p.wav"
+    pdt.write_wav(str(wav), 50000, iq)
+    _, dump = run_ref(REF_POES, wav, tmp_path)
+    assert open(f"{dump}.progress", "rb").read() == open(os.path.join(GOLDEN, "poes_50000.progress"), "rb").read()
+    avg = np.fromfile(f"{dump}.avg", dtype="<f4")
+    assert len(avg) == 16 and avg[15].tobytes() == avg[14].tobytes()
+    a = pdt.synth_capture(1, 32000, 13.0, seed=99)
+    wav = tmp_path / "a.wav"
+    pdt.write_wav(str(wav), 32000, a)
+    _, dump = run_ref(REF_ARGOS, wav, tmp_path)
+    assert open(f"{dump}.progress", "rb").read() == open(os.path.join(GOLDEN, "argos_32000.progress"), "rb").read()
+    assert open(f"{dump}.avg", "rb").read() == open(os.path.join(GOLDEN, "argos_32000.avg.f64"), "rb").read()
