@@ -15,7 +15,7 @@ LIB = os.path.join(HERE, "liboracle.so")
 
 POES, ARGOS = 0, 1
 (ST_IQ, ST_TIME, ST_PLL, ST_LOCK, ST_FIR, ST_AGC, ST_SYM, ST_SYMT, ST_BITS, ST_BITT, ST_COUNTS, ST_TAPS,
- ST_SYMIDX, ST_AGC_RAW) = range(14)
+ ST_SYMIDX, ST_AGC_RAW, ST_AVG) = range(15)
 
 
 class OrcFrame(C.Structure):

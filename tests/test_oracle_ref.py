@@ -14,7 +14,7 @@ pytestmark = pytest.mark.skipif(not (os.path.exists(REF_POES) and os.path.exists
                                 reason="oracle/_ref not built (make -C oracle ref)")
 
 STAGES = {"pll": 2, "lock": 3, "fir": 4, "agc": 5, "sym": 6, "symt": 7, "bits": 8, "bitt": 9, "taps": 11, "iq": 0,
-          "time": 1, "agcraw": 13}          # agcraw: AGC output before Squelch (ARGOS), what -r writes to output.raw
+          "time": 1, "agcraw": 13, "avg": 14}          # agcraw: AGC output before Squelch (ARGOS), what -r writes to output.raw; avg: CarrierTrackPLL's return value per pass
 
 
 def run_ref(binary, wav, tmp_path, extra=()):
