@@ -1,0 +1,92 @@
+"""Randomised check of the per-chunk reports and of the stage-level entry points against the oracle: sample rates, chunk sizes,
+capture lengths (down to nothing), carrier offsets, noise levels, block geometries.  Per case: (1) pdt_keep_quality --
+CarrierTrackPLL's return value, the symbol and bit counts of every chunk; (2) the oracle's streams replayed chunk by chunk through
+pdt_stage_pll / _fir / _agc / _gardner / _manchester with the state records carried by the caller.
+Usage: python tests/tools/fuzz_quality.py [n_cases] [seed]"""
+import ctypes as C
+import importlib, os, sys, time
+import numpy as np
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+pdt = importlib.import_module("project-desert-tortoise_amd")
+from oracle import binding as orc
+from test_gpu_stages import chunks_of, as_complex_float, gardner_replay, manchester_replay, pll_replay
+
+n_cases = int(sys.argv[1]) if len(sys.argv) > 1 else 40
+rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 1)
+bad = 0
+t_start = time.time()
+for case in range(n_cases):
+    argos = rng.random() < 0.25
+    if argos:
+        fs = 32000
+        secs = float(rng.uniform(2.0, 10.0))
+        chunk = int(rng.choice([2400, 2400, 1000, 2401, 4800, 777]))
+        f0 = float(rng.uniform(-200, 200))
+        kind, mode, omode = 1, pdt.MODE_ARGOS, orc.ARGOS
+    else:
+        fs = int(rng.choice([50000, 50000, 48000, 250000, 100000, 32000, 18750]))
+        secs = float(rng.uniform(0.3, 6.0)) * (50000 / fs if fs > 50000 else 1.0)
+        chunk = int(rng.choice([10000, 10000, 1000, 3333, 25000, 260, 4096, int(rng.integers(300, 30000))]))
+        f0 = float(rng.uniform(-4000, 4000))
+        kind, mode, omode = 0, pdt.MODE_POES, orc.POES
+    p = pdt.synth_params(kind, fs, f0, int(rng.integers(1, 1 << 30)))
+    p.noise_gain = int(p.noise_gain * float(rng.choice([1, 1, 1, 2, 4, 7, 40])))
+    n = int(round(secs * fs))
+    iq = np.zeros((n, 2), dtype="<i2")
+    pdt.synth_lib().pdt_synth_fill(C.byref(p), 0, n, iq.ctypes.data)
+    if rng.random() < 0.15:
+        iq = iq[: int(rng.integers(0, min(n, 3 * chunk)))]                          # very short / empty captures
+    kw = {}
+    if rng.random() < 0.3:
+        kw = dict(pll_block=int(rng.integers(64, 6000)), pll_warm=int(rng.integers(0, 20000)),
+                  agc_block=int(rng.integers(64, 12000)), agc_warm=int(rng.integers(0, 40000)))
+    o = orc.Oracle(omode, fs, iq, chunk=chunk)
+    what = []
+    with pdt.Demodulator(mode, fs, chunk=chunk, **kw) as d:
+        d.keep_quality().demod(iq)
+        rep = d.chunk_reports()
+        nc = (len(iq) + chunk - 1) // chunk
+        avg = o.stage(orc.ST_AVG)
+        cnt = o.stage(orc.ST_COUNTS).reshape(-1, 3)
+        ok = len(rep) == nc and d.text() == o.text()
+        ok = ok and rep["avg_phase"].astype(avg.dtype).tobytes() == avg[:nc].tobytes()
+        ok = ok and np.array_equal(rep["samples"], cnt[:nc, 0]) and np.array_equal(rep["symbols"], cnt[:nc, 1]) and \
+            np.array_equal(rep["bits"], cnt[:nc, 2]) and rep["frames"].sum() == d.stats().frames
+        if not ok:
+            what.append("reports")
+        d.keep_quality(False)
+        interp = o.interp
+        if len(iq):
+            # ---- stage replays
+            if not argos:
+                out, lock, rets, st = pll_replay(pdt, d, as_complex_float(iq), chunk)
+                if out.tobytes() != o.stage(orc.ST_PLL).tobytes() or rets.astype("<f4").tobytes() != avg[:nc].tobytes():
+                    what.append("pll")
+            x = o.stage(orc.ST_PLL)
+            fst = pdt.FirState()
+            if np.concatenate([d.stage_fir(x[a:b], fst) for a, b in chunks_of(len(x), chunk)]).tobytes() != o.stage(orc.ST_FIR).tobytes():
+                what.append("fir")
+            x = o.stage(orc.ST_FIR)
+            ast = pdt.AgcState()
+            got = np.concatenate([d.stage_agc(x[a:b], o.norm_factor, ast) for a, b in chunks_of(len(x), chunk * interp)])
+            if got.tobytes() != (o.stage(orc.ST_AGC_RAW) if argos else o.stage(orc.ST_AGC)).tobytes():
+                what.append("agc")
+            sym, pick, _ = gardner_replay(pdt, d, o.stage(orc.ST_AGC), chunk * interp, lock=o.stage(orc.ST_LOCK) if argos else None)
+            if sym.tobytes() != o.stage(orc.ST_SYM).tobytes() or not np.array_equal(pick, o.stage(orc.ST_SYMIDX)):
+                what.append("gardner")
+            if len(o.stage(orc.ST_SYM)):
+                bits, bsym, _ = manchester_replay(pdt, d, o.stage(orc.ST_SYM), o.stage(orc.ST_SYMIDX), chunk * interp, 0.5 if argos else 1.0)
+                if bits.tobytes() != o.stage(orc.ST_BITS).tobytes():
+                    what.append("manchester")
+        # the whole-capture path after the stage calls: unchanged
+        d.demod(iq)
+        if d.text() != o.text():
+            what.append("demod-after")
+        s = d.stats()
+    bad += 1 if what else 0
+    print(f"{'FAIL ' + ','.join(what) if what else 'ok  '} case {case}: {'argos' if argos else 'poes'} fs {fs} n {len(iq)} chunk {chunk} f0 {f0:.0f} "
+          f"noise x{p.noise_gain} geom {kw} frames {s.frames} lock {s.lock_sample}", flush=True)
+print(f"{n_cases - bad}/{n_cases} identical in {time.time() - t_start:.0f} s")
+sys.exit(1 if bad else 0)
