@@ -183,6 +183,7 @@ def main():
                     help="workload (default: c2 = BASELINE configs[1] on one GPU, c3 = the per-GPU capture of configs[4] on several)")
     ap.add_argument("--seconds", type=float, default=None, help="capture length override (parity / smoke runs)")
     ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline, e2e and CLI legs")
+    ap.add_argument("--no-scale-ref", action="store_true", help="N = 1, default configuration: skip the c3 line kept for the scaling curve")
     ap.add_argument("--e2e-only", action="store_true", help="developer runs: keep the in-process e2e leg, skip the CLI and CPU legs")
     ap.add_argument("--captures", type=int, default=1,
                     help="captures demodulated together per GPU and step through pdt_demod_batch_device (default 1 = the "
@@ -391,6 +392,19 @@ def main():
                 else:
                     sample_text = gpu_text
                 out["parity_with_cpu_baseline"] = bool(cpu_text == sample_text)
+        if world == 1 and args.config is None and not args.no_cpu and not args.no_scale_ref and not args.seconds and ncap == 1:
+            # The multi-GPU lines (N > 1) demodulate one configs[4] capture per GPU (= c3), this N = 1 line the configuration the
+            # metric is quoted on (c2): so that a 1 -> N curve can be read like for like, the same c3 step on this one GPU is
+            # measured here as well (its own process, resident input, no CPU / e2e legs) and quoted beside the c2 value.
+            try:
+                r = subprocess.run([sys.executable, os.path.abspath(__file__), "--config", "c3", "--steps", "3", "--warmup", "1", "--no-cpu"],
+                                   capture_output=True, text=True, timeout=900)
+                ref = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+                out["weak_scaling_reference"] = {"workload": ref["config"]["workload"], "value": ref["value"], "unit": ref["unit"],
+                                                 "ms_per_step": ref["ms_per_step"], "n_gpus": 1,
+                                                 "note": "per-GPU workload of the N > 1 lines (one configs[4] capture per GPU), measured on this GPU"}
+            except Exception as e:                                             # (never fatal for the headline line)
+                out["weak_scaling_reference"] = {"error": str(e)[:200]}
         ok = out.get("parity_with_cpu_baseline", True) and out.get("e2e", {}).get("text_identical_to_resident_run", True)
         if not ok:
             sys.stderr.write("bench.py: the GPU output differs from the CPU baseline / between entry points -- no result line\n")
