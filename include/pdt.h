@@ -308,14 +308,15 @@ typedef struct pdt_pll_state {          /* CarrierTrackingPLL.c:60-75 */
     double   sweep;                     /* sweep (signed, :232-246); frozen at the lock                                       */
 } pdt_pll_state;
 /* DT CarrierTrackPLL(DT complex *complexDataIn, DT *realDataOut, DT *lockSignalStreamOut, unsigned int nSamples, DT Fs, ...)
- * (CarrierTrackPLL.h:11) with the constants the context's main passes (POESTIPdemod/main.c:413-420; the twin's with
- * PDT_CHAIN_LIVE): iq_host = n `float complex` values (pairs of float), out_host = realDataOut, lock_out_host (optional) =
- * lockSignalStreamOut, *avg_phase_ret (optional) = the return value.  Runs the whole-capture path's PLL kernels (sequential
- * acquisition, block-parallel tracking with validated seams, lock-detector and averagePhase EMAs) from the record's state and
- * stops behind the PLL.  Float contexts only (PDT_ERR_FORMAT for ARGOS: its input would be `double complex`, a sample format
- * the kernels do not read); not while a stream is open or with cfg.profile (PDT_ERR_STATE).                               */
-int      pdt_stage_pll(pdt_ctx *ctx, const void *iq_host, uint64_t n, pdt_pll_state *state, void *out_host, void *lock_out_host,
-                       double *avg_phase_ret);
+ * (CarrierTrackPLL.h:11) with the constants the context's main passes (POESTIPdemod/main.c:413-420, ARGOSdemod/main.c:265; the
+ * twin's with PDT_CHAIN_LIVE).  iq_host = n samples as the capture file holds them: PDT_FMT_PCM16 (int16 pairs, converted to
+ * `DT complex` as wave.c:127-172 does) or PDT_FMT_F32 (pairs of float = `float complex` as they are; float contexts only,
+ * PDT_ERR_FORMAT otherwise); out_host = realDataOut, lock_out_host (optional) = lockSignalStreamOut, *avg_phase_ret (optional)
+ * = the return value.  Runs the whole-capture path's PLL kernels (sequential acquisition, block-parallel tracking with
+ * validated seams, lock-detector and averagePhase EMAs) from the record's state and stops behind the PLL.  Not while a stream
+ * is open or with cfg.profile (PDT_ERR_STATE).                                                                            */
+int      pdt_stage_pll(pdt_ctx *ctx, const void *iq_host, uint64_t n, int sample_format, pdt_pll_state *state, void *out_host,
+                       void *lock_out_host, double *avg_phase_ret);
 /* DT StaticGain(DT complex *complexData, unsigned int nSamples, DT desiredLevel) (AGC.h:4, AGC.c:48-74): the gain the mains
  * take from their first chunk (main.c:384-389, level 1.0).  The samples as the capture file holds them (PDT_FMT_PCM16: int16
  * pairs, converted as wave.c:127-172 does; PDT_FMT_F32: float pairs as they are); stateless.                              */

@@ -216,7 +216,7 @@ def lib():
     L.pdt_stream_retained.restype = C.c_uint64
     L.pdt_stage_manchester.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64, C.c_double, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
     L.pdt_stage_manchester.restype = C.c_int
-    L.pdt_stage_pll.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+    L.pdt_stage_pll.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
     L.pdt_stage_pll.restype = C.c_int
     L.pdt_stage_gardner.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64, C.c_uint64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
                                     C.c_void_p]
@@ -394,15 +394,16 @@ class Demodulator:
         return out
 
     def stage_pll(self, iq: np.ndarray, state: "PllState | None" = None):
-        """CarrierTrackPLL on these complex samples alone (float32[n,2]; statics in `state`, updated in place):
-        (realDataOut, lockSignalStreamOut, return value)"""
-        a = np.ascontiguousarray(iq, dtype="<f4").reshape(-1)
+        """CarrierTrackPLL on these samples alone (float32[n,2] = `float complex`, or int16[n,2] as the WAV holds them; statics in
+        `state`, updated in place): (realDataOut, lockSignalStreamOut, return value)"""
+        f32 = np.asarray(iq).dtype.kind == "f"
+        a = np.ascontiguousarray(iq, dtype="<f4" if f32 else "<i2").reshape(-1)
         n = a.size // 2
-        out = np.zeros(n, dtype="<f4")
-        lock = np.zeros(n, dtype="<f4")
+        out = np.zeros(n, dtype=self._dt())
+        lock = np.zeros(n, dtype=self._dt())
         ret = C.c_double(0)
-        _check(self._L.pdt_stage_pll(self._h, a.ctypes.data, n, C.addressof(state) if state is not None else None, out.ctypes.data,
-                                     lock.ctypes.data, C.addressof(ret)), "pdt_stage_pll")
+        _check(self._L.pdt_stage_pll(self._h, a.ctypes.data, n, 1 if f32 else 0, C.addressof(state) if state is not None else None,
+                                     out.ctypes.data, lock.ctypes.data, C.addressof(ret)), "pdt_stage_pll")
         return out, lock, ret.value
 
     def stage_gardner(self, buf: np.ndarray, n: int, state: "GardnerState | None" = None, neighbour: "np.ndarray | None" = None):

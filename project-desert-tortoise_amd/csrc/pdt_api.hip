@@ -2472,9 +2472,10 @@ template <typename T> static int stage_fir(pdt_ctx *ctx, const void *in_host, ui
     return PDT_OK;
 }
 
-template <typename T> static int stage_pll(pdt_ctx *ctx, const void *iq_host, uint64_t n, pdt_pll_state *state, void *out_host,
+template <typename T> static int stage_pll(pdt_ctx *ctx, const void *iq_host, uint64_t n, int fmt, pdt_pll_state *state, void *out_host,
                                            void *lock_out_host, double *avg_phase_ret)
 {
+    const size_t fb = fmt == PDT_FMT_F32 ? 8 : 4;                     // bytes per I,Q pair
     pdt_pll_state fresh;
     memset(&fresh, 0, sizeof fresh);
     if (!state) state = &fresh;
@@ -2485,12 +2486,12 @@ template <typename T> static int stage_pll(pdt_ctx *ctx, const void *iq_host, ui
     const bool was_locked = state->started && state->locked;
     const uint64_t lead = was_locked ? 1 : 0;                         // a dummy sample in front stands for "locked before sample 0"
     const uint64_t N = n + lead;
-    int rc = ctx->pcm.ensure((size_t)N * 8 + 16);
+    int rc = ctx->pcm.ensure((size_t)N * fb + 16);
     if (rc) return rc;
     HIP_TRY(hipMemset(ctx->pcm.p, 0, 8));
-    HIP_TRY(hipMemcpy((char *)ctx->pcm.p + lead * 8, iq_host, (size_t)n * 8, hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy((char *)ctx->pcm.p + lead * fb, iq_host, (size_t)n * fb, hipMemcpyHostToDevice));
     ctx->pcm_dev = ctx->pcm.p;
-    ctx->pcm_fmt = 1;                                                 // float pairs = `float complex`, taken as they are
+    ctx->pcm_fmt = fmt == PDT_FMT_F32 ? 1 : 0;                        // float pairs = `float complex` as they are / int16 pairs, wave.c:127-172
     ctx->inj.active = true;
     ctx->inj.started = state->started != 0;
     ctx->inj.locked = was_locked;
@@ -2805,14 +2806,15 @@ template <typename T> static int stage_squelch(pdt_ctx *ctx, void *data_host, co
 }
 }  // extern "C++"
 
-int pdt_stage_pll(pdt_ctx *ctx, const void *iq_host, uint64_t n, pdt_pll_state *state, void *out_host, void *lock_out_host,
-                  double *avg_phase_ret)
+int pdt_stage_pll(pdt_ctx *ctx, const void *iq_host, uint64_t n, int sample_format, pdt_pll_state *state, void *out_host,
+                  void *lock_out_host, double *avg_phase_ret)
 {
-    if (!ctx || (!iq_host && n) || n >= (1ull << 31)) return PDT_ERR_ARG;
-    if (ctx->elem != 4) return PDT_ERR_FORMAT;                        // float contexts only (the input is `float complex`)
+    if (!ctx || (!iq_host && n) || n >= (1ull << 31) || (sample_format != PDT_FMT_PCM16 && sample_format != PDT_FMT_F32)) return PDT_ERR_ARG;
+    if (ctx->elem != 4 && sample_format == PDT_FMT_F32) return PDT_ERR_FORMAT;   // (double contexts: no `double complex` sample source)
     if (ctx->cfg.profile || ctx->sc.active) return PDT_ERR_STATE;
     HIP_TRY(hipSetDevice(ctx->cfg.device));
-    return stage_pll<float>(ctx, iq_host, n, state, out_host, lock_out_host, avg_phase_ret);
+    if (ctx->elem == 8) return stage_pll<double>(ctx, iq_host, n, sample_format, state, out_host, lock_out_host, avg_phase_ret);
+    return stage_pll<float>(ctx, iq_host, n, sample_format, state, out_host, lock_out_host, avg_phase_ret);
 }
 
 int pdt_stage_gardner(pdt_ctx *ctx, const void *in_host, uint64_t n, uint64_t capacity, const void *neighbour_host,

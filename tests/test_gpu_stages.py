@@ -197,7 +197,32 @@ def test_pll_stage_never_locks_on_noise(pdt, orc):
         assert out.tobytes() == o.stage(orc.ST_PLL).tobytes()
     with pdt.Demodulator(pdt.MODE_ARGOS, 32000) as d:
         with pytest.raises(pdt.PdtError):
-            d.stage_pll(x[:100])
+            d.stage_pll(x[:100])                                      # no `double complex` sample source
+
+
+@pytest.mark.parametrize("chunk", [2400, 1001])
+def test_pll_stage_argos_from_pcm16(pdt, orc, chunk):
+    """the double-precision build, fed the int16 pairs the WAV holds: realDataOut, the lock stream and the return values"""
+    iq = pdt.synth_capture(1, 32000, 9.0, f0_hz=-140.0, seed=53)[:-7]
+    o = orc.Oracle(orc.ARGOS, 32000, iq, chunk=chunk)
+    with pdt.Demodulator(pdt.MODE_ARGOS, 32000, chunk=chunk) as d:
+        out, lock, rets, st = pll_replay(pdt, d, iq, chunk)
+        assert out.tobytes() == o.stage(orc.ST_PLL).tobytes()
+        assert lock.tobytes() == o.stage(orc.ST_LOCK).tobytes()
+        avg = o.stage(orc.ST_AVG)
+        assert rets.tobytes() == avg[:len(rets)].tobytes()
+        assert st.locked == 1 and st.lock_index == o.lock_sample % chunk
+        out2, lock2, _, st2 = pll_replay(pdt, d, iq, 50000)
+        assert out2.tobytes() == out.tobytes() and lock2.tobytes() == lock.tobytes() and st2.phase == st.phase and st2.freq == st.freq
+
+
+def test_pll_stage_pcm16_poes(pdt, orc, clip):
+    rate, iq = clip
+    o = orc.Oracle(orc.POES, rate, iq)
+    with pdt.Demodulator(pdt.MODE_POES, rate) as d:
+        out, _, rets, _ = pll_replay(pdt, d, np.ascontiguousarray(iq), 10000)
+        assert out.tobytes() == o.stage(orc.ST_PLL).tobytes()
+        assert rets.astype("<f4").tobytes() == o.stage(orc.ST_AVG)[:len(rets)].tobytes()
 
 
 def gardner_replay(pdt, d, x, C, lock=None):

@@ -60,10 +60,12 @@ for case in range(n_cases):
         interp = o.interp
         if len(iq):
             # ---- stage replays
-            if not argos:
-                out, lock, rets, st = pll_replay(pdt, d, as_complex_float(iq), chunk)
-                if out.tobytes() != o.stage(orc.ST_PLL).tobytes() or rets.astype("<f4").tobytes() != avg[:nc].tobytes():
-                    what.append("pll")
+            src = iq if (argos or case % 2) else as_complex_float(iq)          # int16 pairs as the WAV holds them / `float complex`
+            out, lock, rets, st = pll_replay(pdt, d, src, chunk)
+            if out.tobytes() != o.stage(orc.ST_PLL).tobytes() or rets.astype(avg.dtype).tobytes() != avg[:nc].tobytes():
+                what.append("pll")
+            if argos and lock.tobytes() != o.stage(orc.ST_LOCK).tobytes():
+                what.append("pll-lock")
             x = o.stage(orc.ST_PLL)
             fst = pdt.FirState()
             if np.concatenate([d.stage_fir(x[a:b], fst) for a, b in chunks_of(len(x), chunk)]).tobytes() != o.stage(orc.ST_FIR).tobytes():
