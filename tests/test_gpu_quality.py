@@ -173,6 +173,14 @@ def test_batch_with_quality(pdt, clip):
         assert len(ds[1].chunk_reports()) == 13
         # causal: the first twelve (whole) chunks of the cut capture see what the full one sees
         assert ds[1].chunk_reports()["avg_phase"][:12].astype("<f4").tobytes() == avg_ref[:12].tobytes()
+        # a batch whose contexts differ in what they keep (plans of different shapes): every context still gets its own
+        text = [d.text() for d in ds]
+        ds[1].keep_quality(False)
+        pdt.demod_batch(ds, [t.data_ptr() for t in dev], [len(c) for c in caps])
+        check_reports(ds[0].chunk_reports(), avg_ref, None, "<f4")
+        assert len(ds[1].chunk_reports()) == 0
+        check_reports(ds[2].chunk_reports(), avg_ref, None, "<f4")
+        assert [d.text() for d in ds] == text
     finally:
         for d in ds:
             d.close()
