@@ -14,8 +14,9 @@ LIBGATHER := $(CSRC)/libpdtgather.so
 
 all: $(LIBPDT) $(LIBSYNTH) $(LIBGATHER) bin/synth_wav bin/demodPOES bin/demodARGOS bin/demodMulti oracle
 
-$(LIBPDT): $(CSRC)/pdt_api.hip $(CSRC)/pdt_kernels_front.h $(CSRC)/pdt_kernels_back.h $(CSRC)/pdt_device_math.h $(CSRC)/pdt_sincostab.h $(CSRC)/pdt_timeaxis.h include/pdt.h
-	$(HIPCC) $(HIPFLAGS) -shared -o $@ $(CSRC)/pdt_api.hip
+LIBPDT_SRC := $(CSRC)/pdt_api.hip $(CSRC)/pdt_kernels_front.h $(CSRC)/pdt_kernels_back.h $(CSRC)/pdt_device_math.h $(CSRC)/pdt_sincostab.h $(CSRC)/pdt_timeaxis.h include/pdt.h
+$(LIBPDT): $(LIBPDT_SRC)
+	$(HIPCC) $(HIPFLAGS) -DPDT_BUILD_TAG="\"$$(cat $(LIBPDT_SRC) | sha1sum | cut -c1-12)\"" -shared -o $@ $(CSRC)/pdt_api.hip
 
 # RCCL gather of frame records (multi-GPU launcher): a library of its own, so that libpdt.so does not depend on RCCL
 $(LIBGATHER): $(CSRC)/pdt_gather.hip include/pdt_gather.h include/pdt.h $(LIBPDT)

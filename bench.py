@@ -1,22 +1,32 @@
 #!/usr/bin/env python3
 """bench.py -- IQ Msamples/s of the demodulation hot path on N MI355X, with roofline, end-to-end and CPU figures.
 
-Contract (driver): ``python bench.py --gpus N --steps K --warmup W``; for N>1 it is launched by
-``python -m torch.distributed.run --nproc-per-node N ...`` with one rank per GPU.
+Contract (driver): ``python bench.py --gpus N --steps K --warmup W``.  For N > 1 the driver launches it as
+``python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N``; started by hand without that wrapper
+(no WORLD_SIZE in the environment) it re-executes itself under torch.distributed.run, one rank per GPU.
 
-Workloads (``--config``; BASELINE.json ``configs``):
-  c2    (default at N=1)  configs[1]: synthetic 50 ksps complex-IQ capture, 10 min (30 M samples, 120 MB), POES chain
-  c3    (default at N>1)  configs[2] / the per-GPU capture of configs[4]: 250 ksps, 60 min (900 M samples, 3.6 GB), POES
-  argos                   configs[3]: synthetic ARGOS capture, 32 ksps, 5 min (9.6 M samples), double precision chain
+Workloads (``--config``; BASELINE.json ``configs``) -- THE SAME default for every N, so that value(N) / value(1) is a
+like-for-like weak-scaling figure:
+  c3    (default)  configs[2] = the per-GPU capture of configs[4]: 250 ksps, 60 min (900 M samples, 3.6 GB), POES chain;
+                   the largest single-GPU configuration of BASELINE.json
+  c2               configs[1]: synthetic 50 ksps complex-IQ capture, 10 min (30 M samples, 120 MB), POES chain
+  argos            configs[3]: synthetic ARGOS capture, 32 ksps, 5 min (9.6 M samples), double precision chain
+  aos              (not in BASELINE) 250 ksps, 10 min, the first 60 s noise only: the receiver is switched
+                   on before the satellite rises, the PLL sweeps for a minute before its one-time lock
+  weak             (not in BASELINE) 250 ksps, 10 min at six times the noise amplitude (4.4 dB SNR in the sampled band)
 One "step" = one pass of the whole hot path (StaticGain, PLL, FIR, AGC, Gardner, Manchester, ByteSync, frame records +
-time stamps) over one capture that is already resident in HBM: that is ``value``.  With N GPUs every rank demodulates
-its own independent capture (different seed): weak scaling, no data-path collective; the decoded frame records are
-gathered on rank 0 with one padded all_gather (RCCL) after the timed region.
+time stamps) over one capture that is ALREADY RESIDENT IN HBM when the timed region starts: that is ``value``, and the
+``metric`` string says so.  The figure from the WAV file to the closed output file is ``e2e`` (N = 1).  With N GPUs every
+rank demodulates its own independent capture (different seed): weak scaling, no data-path collective; the decoded frame
+records are gathered on rank 0 with one padded all_gather (RCCL) after the timed region and checked there.
 
 The JSON line carries, besides the contract keys:
-  roofline     the kernel that dominates the step: algorithmic bytes / live HIP-event duration (libpdt's profile mode, on
-               the stream the kernels run on) against 8 TB/s; ``traffic`` from the committed rocprofv3 counter passes
+  roofline     the kernel group that dominates the step: algorithmic bytes / live HIP-event duration (libpdt's profile
+               mode, events on the stream the kernels run on) against 8 TB/s; ``traffic`` from the committed rocprofv3
+               counter passes, printed only when that file was measured with the build that is running (``build`` tags)
   stages       every kernel group: ms per step, algorithmic bytes per step, GB/s, fraction of 8 TB/s
+  fir_pll_stage  the north star's stage figure: 4 B in + 4 * interp B out per sample over the PLL + FIR critical path
+  parity       what was compared with what in THIS run (a failure is fatal: exit code 1, no JSON line)
   e2e          what the reference program does, timed: open the WAV (tmpfs) -> header -> pdt_demod_fd (threaded read into
                pinned memory, copy to HBM, all kernels, frame records back) -> text -> output file written and closed
   e2e_cli      wall time of the C host program bin/demodPOES|demodARGOS on the same file (process start and HIP
@@ -24,7 +34,8 @@ The JSON line carries, besides the contract keys:
   cpu_baseline the reference's own DSP objects (oracle/_ref, kind "reference") or the CPU restatement (kind "port"),
                single thread on this host, on a bounded sample of the same capture: DSP-only rate (``value``, comparable
                with the resident GPU number) and end-to-end rate (``e2e_value``: file read and text output included)
-The run fails (exit code 1, no JSON line) when the GPU's text differs from the CPU baseline's on the sample.
+  cpu_baseline_8proc  8 concurrent single-thread CPU processes, one capture each (BASELINE.md section 3, configs[4])
+  secondary    the c2 and argos workloads measured on the same GPU (resident step only), each a process of its own
 """
 from __future__ import annotations
 
@@ -35,14 +46,14 @@ import importlib
 import json
 import os
 import re
+import shutil
+import socket
 import subprocess
 import sys
 import tempfile
 import time
 
 import numpy as np
-import torch
-import torch.distributed as dist
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
@@ -50,17 +61,86 @@ sys.path.insert(0, ROOT)
 HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
 
 CONFIGS = {
-    #        kind  fs      seconds  cpu-sample seconds (bounded: ~10-30 s of one host core)
-    "c2":    (0,   50000,  600.0,   600.0),
-    "c3":    (0,   250000, 3600.0,  600.0),
-    "argos": (1,   32000,  300.0,   300.0),
+    #        kind  fs      seconds  cpu-sample s  noise-only lead s  noise gain x   BASELINE.json
+    "c2":    (0,   50000,  600.0,   600.0,        0.0,               1.0,           "configs[1]"),
+    "c3":    (0,   250000, 3600.0,  600.0,        0.0,               1.0,           "configs[2] (= one GPU's capture of configs[4])"),
+    "argos": (1,   32000,  300.0,   300.0,        0.0,               1.0,           "configs[3]"),
+    "aos":   (0,   250000, 600.0,   600.0,        60.0,              1.0,           "none (receiver on 60 s before the signal rises)"),
+    "weak":  (0,   250000, 600.0,   600.0,        0.0,               6.0,           "none (noise amplitude x6)"),
 }
-BASELINE_CONFIG = {"c2": "configs[1]", "c3": "configs[2] (= one GPU's capture of configs[4])", "argos": "configs[3]"}
+DEFAULT_CONFIG = "c3"
 
 
-def gather_frames(frames: np.ndarray, device: torch.device):
+# ---------------------------------------------------------------------------------------------------------------------------
+def relaunch_under_torchrun(n: int) -> None:
+    """`python bench.py --gpus N` without a launcher: become `python -m torch.distributed.run --nproc-per-node N bench.py ...`"""
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env.setdefault("OMP_NUM_THREADS", "1")
+    sys.stdout.flush()
+    os.execvpe(cmd[0], cmd, env)
+
+
+def capture_params(pdt, cfg: str, seed: int):
+    kind, fs, _, _, lead_s, noise_x, _ = CONFIGS[cfg]
+    p = pdt.synth_params(kind, fs, 1000.0 if kind == 0 else 120.0, seed)
+    p.signal_start = int(round(lead_s * fs))
+    p.noise_gain = int(round(p.noise_gain * noise_x))
+    return p
+
+
+def make_capture(pdt, p, n: int, threads: int, device=None, wav_path: str | None = None, fs: int = 0):
+    """The synthetic capture, generated slice by slice by a few host threads (every sample is a pure function of its
+    index) and handed on at once -- to HBM (`device`), to a WAV file (`wav_path`) or both -- so that the host never holds
+    more than one 256 MB slice of it, whatever the number of ranks on the node."""
+    import torch
+    S = pdt.synth_lib()
+    S.pdt_synth_sine_table()                                             # build the table before the threads start
+    slice_n = 1 << 26
+    piece = 1 << 21
+    d_iq = torch.empty(2 * n, dtype=torch.int16, device=device) if device is not None else None
+    f = None
+    if wav_path:
+        f = open(wav_path, "wb")
+        hdr = C.create_string_buffer(44)
+        S.pdt_synth_wav_header(hdr, fs, n)
+        f.write(hdr.raw)
+    buf = np.empty((min(slice_n, max(n, 1)), 2), dtype="<i2")
+    if device is not None:
+        try:
+            tbuf = torch.from_numpy(buf.reshape(-1)).pin_memory()       # (a pinned slice: the copy runs at PCIe speed)
+            buf = tbuf.numpy().reshape(-1, 2)
+        except RuntimeError:
+            tbuf = torch.from_numpy(buf.reshape(-1))
+    with cf.ThreadPoolExecutor(max(1, threads)) as ex:
+        for s0 in range(0, n, slice_n):
+            c0 = min(slice_n, n - s0)
+
+            def fill(off, s0=s0, c0=c0):
+                c = min(piece, c0 - off)
+                S.pdt_synth_fill(C.byref(p), s0 + off, c, buf[off:off + c].ctypes.data)
+
+            list(ex.map(fill, range(0, c0, piece)))
+            if d_iq is not None:
+                d_iq[2 * s0:2 * (s0 + c0)].copy_(tbuf[:2 * c0])
+                torch.cuda.synchronize()
+            if f:
+                f.write(memoryview(buf[:c0]).cast("B"))
+    if f:
+        f.close()
+    return d_iq
+
+
+def gather_frames(frames: np.ndarray, device):
     """All ranks contribute a (ragged) array of pdt_frame records; rank 0 gets the list per rank.
     Two collectives: counts (all_gather of one int64) and the records padded to the maximum."""
+    import torch
+    import torch.distributed as dist
     world = dist.get_world_size()
     rec = frames.dtype.itemsize
     n = torch.tensor([len(frames)], dtype=torch.int64, device=device)
@@ -78,23 +158,26 @@ def gather_frames(frames: np.ndarray, device: torch.device):
     return [o[: c * rec].cpu().numpy().view(frames.dtype) for o, c in zip(out, counts)]
 
 
-def synth_threaded(pdt, kind: int, fs: int, seconds: float, seed: int, threads: int) -> np.ndarray:
-    """The synthetic capture, generated in slices by a few host threads (every sample is a pure function of its index)."""
-    n = int(round(seconds * fs))
-    p = pdt.synth_params(kind, fs, 1000.0 if kind == 0 else 120.0, seed)
-    out = np.zeros((n, 2), dtype="<i2")
-    S = pdt.synth_lib()
-    S.pdt_synth_sine_table()                                             # build the table before the threads start
-    piece = 1 << 22
-    jobs = [(s, min(piece, n - s)) for s in range(0, n, piece)]
-
-    def fill(job):
-        s, c = job
-        S.pdt_synth_fill(C.byref(p), s, c, out[s:s + c].ctypes.data)
-
-    with cf.ThreadPoolExecutor(max(1, threads)) as ex:
-        list(ex.map(fill, jobs))
-    return out
+def transmitted_check(pdt, p, frames: np.ndarray, n: int, fs: int) -> dict:
+    """Size-independent property at full size: every complete decoded POES frame is one of the frames the generator
+    transmitted, they are consecutive, and all but the first few (acquisition) arrive."""
+    complete = frames[frames["complete"] == 1]
+    expect = int(n / fs * 10.0)                                          # 10 minor frames per second
+    if len(complete) == 0:
+        return {"ok": False, "complete": 0, "expected_about": expect}
+    first = None
+    head = bytes(complete[0]["bytes"])
+    start = int(p.signal_start * 10 // fs)
+    for k in range(start, start + 64):
+        if bytes(pdt.synth_poes_frame(p, k)) == head:
+            first = k
+            break
+    if first is None:
+        return {"ok": False, "complete": int(len(complete)), "expected_about": expect - start, "why": "first frame unknown"}
+    sent = np.stack([pdt.synth_poes_frame(p, first + i) for i in range(len(complete))])
+    same = bool(np.array_equal(sent, complete["bytes"]))
+    return {"ok": same and len(complete) >= expect - start - 12, "complete": int(len(complete)), "first_frame": first,
+            "expected_about": expect - start}
 
 
 # Algorithmic bytes per step of each kernel group (SURVEY 8d; DESIGN.md section 4): what the group must read
@@ -109,6 +192,7 @@ def stage_bytes(n: int, interp: int, nsym: int, nbits: int, f: int, chunk: int):
         "pll_head": 0,
         "pll_fix": 0,
         "pll_mix": (4 + f + f) * n,                      # I/Q + phase in, mixed sample out
+        "mix_fir": (4 + f + f * interp) * n,             # fused: I/Q + phase in, filtered (interpolated) stream out
         "lock_ema": 2 * f * n,
         "fir": (f + f * interp) * n,                     # f B in + f*interp B out per input sample
         "agc_block": 2 * f * interp * n,
@@ -128,6 +212,7 @@ def group_kernel(group: str, dt: str, interp: int) -> str:
         "pll_head": f"k_pll_head<{dt}, false, true>", "pll_fix": f"k_pll_fix<{dt}, false>", "pll_theta": f"k_pll_theta<{dt}>",
         "pll_mix": f"k_pll_mix<{dt}, {'true' if dt == 'double' else 'false'}>", "lock_ema": f"k_lock_ema<{dt}>",
         "fir": f"k_fir_interp_rt<{dt}, {interp}, 26>" if dt == "float" else f"k_fir_plain<{dt}>",
+        "mix_fir": f"k_mix_fir<{dt}, {interp}, 26>",
         "agc_block": f"k_agc_block<{dt}>", "gardner_table": "k_gardner_table_merge<2048>",
         "gardner": "k_gardner<float, 2048, 256>" if dt == "float" else "k_gardner_ring<double, 2560, 6, 256>",
         "static_gain": f"k_static_gain<{dt}>", "manchester": f"k_manch_emit<{dt}>", "bytesync": "k_sync_frames_tiles",
@@ -135,13 +220,19 @@ def group_kernel(group: str, dt: str, interp: int) -> str:
     }.get(group, group)
 
 
-def pmc_traffic(cfg: str, kernel: str):
-    """HBM bytes per launch of `kernel` from the committed rocprofv3 counter passes (FETCH_SIZE x2 + WRITE_SIZE,
-    see tools/pmc_traffic.py and profiles/r2/README.md); None when there is no such file or kernel."""
-    for rnd in ("r2", "r1"):
+def pmc_traffic(cfg: str, kernel: str, build: str):
+    """HBM bytes per launch of `kernel` from the committed rocprofv3 counter passes (FETCH_SIZE x2 + WRITE_SIZE, see
+    tools/pmc_traffic.py and profiles/r3/README.md) -- only from a file measured with the library build that is running now
+    (its `build` tag); otherwise None: a figure of another build says nothing about this one."""
+    for rnd in ("r3", "r2", "r1"):
         path = os.path.join(ROOT, "profiles", rnd, f"pmc_hbm_traffic_bench_{cfg}.json")
         try:
-            for row in json.load(open(path)):
+            doc = json.load(open(path))
+            rows = doc["kernels"] if isinstance(doc, dict) else doc
+            tag = doc.get("build") if isinstance(doc, dict) else None
+            if tag != build:
+                continue
+            for row in rows:
                 if row["kernel"] == kernel:
                     return int(row["hbm_bytes"])
         except (OSError, ValueError, KeyError):
@@ -149,29 +240,34 @@ def pmc_traffic(cfg: str, kernel: str):
     return None
 
 
-def cpu_baseline(pdt, kind: int, fs: int, wav: str, n_sample: int, tmp: str):
-    """The reference CPU path on this host: one thread, the first n_sample samples of the capture in `wav`."""
+def cpu_exe(kind: int):
     exe = "ref_demodARGOS" if kind else "ref_demodPOES"
     ref = os.path.join(ROOT, "oracle", "_ref", exe)
     port = os.path.join(ROOT, "oracle", "oracle_demod")
-    out = os.path.join(tmp, "cpu_out.txt")
     if os.path.exists(ref):
-        what, cmd = "reference", [ref, wav, out]
-    else:
-        if not os.path.exists(port):
-            subprocess.run(["make", "-C", os.path.join(ROOT, "oracle"), "liboracle.so", "oracle_demod"], check=True, capture_output=True)
-        what, cmd = "port", [port] + (["-a"] if kind else []) + [wav, out]
+        return "reference", [ref]
+    if not os.path.exists(port):
+        subprocess.run(["make", "-C", os.path.join(ROOT, "oracle"), "liboracle.so", "oracle_demod"], check=True, capture_output=True)
+    return "port", [port] + (["-a"] if kind else [])
+
+
+def cpu_baseline(kind: int, wavs: list[str], n_sample: int, tmp: str):
+    """The reference CPU path on this host, one thread per process: len(wavs) concurrent processes, one capture each.
+    Returns (per-process DSP seconds, wall seconds of the slowest, texts, kind)."""
+    what, cmd = cpu_exe(kind)
+    outs = [os.path.join(tmp, f"cpu_out_{i}.txt") for i in range(len(wavs))]
     t0 = time.perf_counter()
-    r = subprocess.run(cmd, check=True, capture_output=True, text=True)
-    dt = time.perf_counter() - t0
-    m = re.search(r"dsp_seconds ([0-9.]+)", r.stderr)
-    dsp = float(m.group(1)) if m else dt
-    text = open(out, "rb").read() if os.path.exists(out) else b""
-    return {"value": round(n_sample / dsp / 1e6, 3), "unit": "Msamples/s", "cores": 1, "kind": what,
-            "e2e_value": round(n_sample / dt / 1e6, 3),
-            "sample": f"the first {n_sample} samples of rank 0's capture as a WAV on tmpfs: {dsp:.2f} s in the DSP stages "
-                      f"(value), {dt:.2f} s wall for the whole program with file read and text output (e2e_value)",
-            "host_cpus": os.cpu_count()}, text
+    procs = [subprocess.Popen(cmd + [w, o], stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True) for w, o in zip(wavs, outs)]
+    dsp, walls = [], []
+    for p in procs:
+        _, err = p.communicate()
+        walls.append(time.perf_counter() - t0)
+        if p.returncode != 0:
+            raise RuntimeError(f"CPU baseline failed: {err[-500:]}")
+        m = re.search(r"dsp_seconds ([0-9.]+)", err)
+        dsp.append(float(m.group(1)) if m else walls[-1])
+    texts = [open(o, "rb").read() if os.path.exists(o) else b"" for o in outs]
+    return dsp, max(walls), texts, what
 
 
 def main():
@@ -179,23 +275,26 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--config", choices=sorted(CONFIGS), default=None,
-                    help="workload (default: c2 = BASELINE configs[1] on one GPU, c3 = the per-GPU capture of configs[4] on several)")
+    ap.add_argument("--config", choices=sorted(CONFIGS), default=DEFAULT_CONFIG,
+                    help=f"workload (default {DEFAULT_CONFIG} = BASELINE configs[2], the same for every N)")
     ap.add_argument("--seconds", type=float, default=None, help="capture length override (parity / smoke runs)")
     ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline, e2e and CLI legs")
-    ap.add_argument("--no-scale-ref", action="store_true", help="N = 1, default configuration: skip the c3 line kept for the scaling curve")
+    ap.add_argument("--no-secondary", action="store_true", help="N = 1: skip the c2 / argos records measured beside the headline")
     ap.add_argument("--e2e-only", action="store_true", help="developer runs: keep the in-process e2e leg, skip the CLI and CPU legs")
     ap.add_argument("--captures", type=int, default=1,
                     help="captures demodulated together per GPU and step through pdt_demod_batch_device (default 1 = the "
                          "BASELINE workload; >1 is the batched many-capture mode, reported as such)")
     args = ap.parse_args()
 
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        relaunch_under_torchrun(args.gpus)                                # does not return
+
+    import torch
+    import torch.distributed as dist
+
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("launch with: python -m torch.distributed.run --nproc-per-node N bench.py --gpus N ...")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (there is no CPU implementation of the product path)")
     # PDT_BENCH_BACKEND=gloo: dry run of the multi-rank logic on a box with fewer GPUs than ranks (ranks share
@@ -203,6 +302,8 @@ def main():
     backend = os.environ.get("PDT_BENCH_BACKEND", "nccl")
     if backend != "nccl":
         local = local % torch.cuda.device_count()
+    elif world > torch.cuda.device_count():
+        raise SystemExit(f"bench.py: {world} ranks but {torch.cuda.device_count()} GPU(s) visible")
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     cdev = dev if backend == "nccl" else torch.device("cpu")              # where collective payloads live
@@ -212,19 +313,34 @@ def main():
         else:
             dist.init_process_group(backend)
 
-    cfg = args.config or ("c2" if world == 1 else "c3")
-    kind, fs, seconds, cpu_seconds = CONFIGS[cfg]
+    cfg = args.config
+    kind, fs, seconds, cpu_seconds, lead_s, noise_x, baseline_cfg = CONFIGS[cfg]
     if args.seconds:
         seconds = args.seconds
         cpu_seconds = min(cpu_seconds, seconds)
     mode = 1 if kind else 0
     dt_name, fbytes = ("double", 8) if kind else ("float", 4)
+    legs = (not args.no_cpu) and world == 1 and args.captures == 1       # e2e / CLI / CPU legs belong to the N = 1 line
 
     pdt = importlib.import_module("project-desert-tortoise_amd")
+    build_tag = pdt.build_tag()
     n = int(round(seconds * fs))
     threads = max(1, min(32, (os.cpu_count() or 8) // max(1, world)))
-    iq = synth_threaded(pdt, kind, fs, seconds, 1234 + rank, threads)      # one independent capture per rank
-    d_iq = torch.from_numpy(iq.reshape(-1)).to(dev)                        # resident in HBM before timing
+    shm = "/dev/shm" if os.path.isdir("/dev/shm") else None
+    tmp = tempfile.mkdtemp(dir=shm, prefix="pdt_bench_") if (legs and rank == 0) else None
+    try:
+        run(args, pdt, torch, dist, rank, local, world, dev, cdev, cfg, kind, fs, seconds, cpu_seconds, baseline_cfg, mode, dt_name,
+            fbytes, legs, build_tag, n, threads, tmp)
+    finally:
+        if tmp:
+            shutil.rmtree(tmp, ignore_errors=True)
+
+
+def run(args, pdt, torch, dist, rank, local, world, dev, cdev, cfg, kind, fs, seconds, cpu_seconds, baseline_cfg, mode, dt_name,
+        fbytes, legs, build_tag, n, threads, tmp):
+    par = capture_params(pdt, cfg, 1234 + rank)                            # one independent capture per rank
+    wav = os.path.join(tmp, f"{cfg}.wav") if tmp else None
+    d_iq = make_capture(pdt, par, n, threads, device=dev, wav_path=wav, fs=fs)    # resident in HBM before timing
     dm = pdt.Demodulator(mode, fs, device=local, profile=True)
     dm.set_stream(torch.cuda.current_stream().cuda_stream)
     ncap = max(args.captures, 1)
@@ -283,11 +399,14 @@ def main():
         # FIR+PLL stage (north-star target): critical path through the two concurrent streams
         g = lambda k: stages.get(k, {"ms": 0.0})["ms"]
         front_ms = (g("pll_theta") + max(g("pll_phase"), g("pll_acquire") + g("pll_head")) + g("pll_fix") + g("pll_mix")
-                    + g("lock_ema") + g("fir"))
+                    + g("lock_ema") + g("fir") + g("mix_fir"))
         front_bytes = (4 + fbytes * st.interp) * n * ncap   # fused FIR+PLL stage: 4 B in + f*interp B out per sample
-        hbm_bound = ["pll_theta", "pll_mix", "fir"]         # the groups that are pure streaming kernels
+        hbm_bound = ["pll_theta", "pll_mix", "fir", "mix_fir"]   # the groups that are pure streaming kernels
+        traffic = pmc_traffic(cfg, dom_kernel, build_tag) if ncap == 1 else None
+        parity = {}
         out = {
-            "metric": "IQ Msamples/s end-to-end (WAV->minorframes), 1-GPU + %HBM roofline",
+            "metric": f"IQ Msamples/s, {cfg} capture resident in HBM -> minor-frame records (the whole hot path; the end-to-end "
+                      "figure WAV file -> minorframes file is `e2e`), per-GPU workload identical for every N + %HBM roofline",
             "value": round(value, 3),
             "unit": "Msamples/s",
             "n_gpus": world,
@@ -299,20 +418,22 @@ def main():
             "vs_baseline": None,
             "dtype": "f64" if kind else "f32",
             "data": "synthetic",
-            "config": {"workload": f"{cfg} = BASELINE {BASELINE_CONFIG[cfg]}: synthetic {fs / 1000:g} ksps complex-IQ capture, {seconds:g} s "
+            "build": build_tag,
+            "config": {"workload": f"{cfg} = BASELINE {baseline_cfg}: synthetic {fs / 1000:g} ksps complex-IQ capture, {seconds:g} s "
                                    f"({n} samples) per GPU, {'ARGOS' if kind else 'POES'} chain, chunk {chunk}, input resident in HBM "
-                                   "when the timed region starts (the end-to-end figure from the WAV file is `e2e`)",
+                                   "when the timed region starts",
                        "samples_per_gpu": n * ncap, "captures": world * ncap,
                        "parallelism": f"{ncap} capture(s) per GPU x{world}"
                                       + (" (batched many-capture mode: one launch per stage for all captures, same capture in every slot)" if ncap > 1 else "")},
             "roofline": {"bound": "hbm", "kernel": dom_kernel, "group": dom,
                          "achieved": stages[dom]["GBps"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": stages[dom]["frac_hbm"], "traffic": pmc_traffic(cfg, dom_kernel) if ncap == 1 else None,
+                         "frac": stages[dom]["frac_hbm"], "traffic": traffic,
                          "alg_bytes": stages[dom]["alg_bytes"], "ms": stages[dom]["ms"],
                          "note": "achieved = algorithmic bytes / live HIP-event duration of the group's launch; traffic = FETCH_SIZE x2 + "
-                                 "WRITE_SIZE per launch from the committed counter passes (profiles/)"},
+                                 "WRITE_SIZE per launch from the committed counter passes of this build (profiles/), null when the "
+                                 "committed passes belong to another build"},
             "streaming_kernels": {k: {"GBps": stages[k]["GBps"], "frac_hbm": stages[k]["frac_hbm"],
-                                      "traffic": pmc_traffic(cfg, group_kernel(k, dt_name, st.interp)) if ncap == 1 else None}
+                                      "traffic": pmc_traffic(cfg, group_kernel(k, dt_name, st.interp), build_tag) if ncap == 1 else None}
                                   for k in hbm_bound if k in stages},
             "pipeline_hbm_frac": round(4 * n * ncap / (ms_step * 1e-3) / 1e9 / HBM_PEAK_GBS, 6),
             "fir_pll_stage": {"ms": round(front_ms, 4), "alg_bytes": front_bytes,
@@ -326,89 +447,118 @@ def main():
             "gardner_walked": int(st.gardner_walked), "gardner_candidates": int(st.gardner_candidates),
             "lock_sample": int(st.lock_sample),
         }
-        if not args.no_cpu and world == 1:      # (the CPU baseline, e2e and CLI legs belong to the N = 1 line)
-            shm = "/dev/shm" if os.path.isdir("/dev/shm") else None
-            with tempfile.TemporaryDirectory(dir=shm) as tmp:
-                wav = os.path.join(tmp, f"{cfg}.wav")
-                pdt.write_wav(wav, fs, iq)
-                # ---- end to end, in process: what POESTIPdemod/main.c:284-512 does with the file
-                e2e_ms, split = [], []
-                with pdt.Demodulator(mode, fs, device=local) as de:
-                    for rep in range(3):
-                        outp = os.path.join(tmp, "e2e_out.txt")
-                        t1 = time.perf_counter()
-                        fd = os.open(wav, os.O_RDONLY)
-                        hdr = os.pread(fd, 44, 0)
-                        rate = int.from_bytes(hdr[24:28], "little")
-                        nfr = (os.fstat(fd).st_size - 44) // 4
-                        t2 = time.perf_counter()
-                        de.demod_file(fd, 44, nfr, 0)
-                        os.close(fd)
-                        t3 = time.perf_counter()
-                        text = de.text()
-                        t4 = time.perf_counter()
-                        with open(outp, "wb") as fo:
-                            fo.write(text)
-                        t5 = time.perf_counter()
-                        e2e_ms.append((t5 - t1) * 1e3)
-                        split.append({"open_header": round((t2 - t1) * 1e3, 3), "demod_fd": round((t3 - t2) * 1e3, 3),
-                                      "text": round((t4 - t3) * 1e3, 3), "write_close": round((t5 - t4) * 1e3, 3)})
-                        assert rate == fs and nfr == n
-                    e2e_text = text
-                    e2e_gpu_ms = de.stats().gpu_ms
-                best = min(e2e_ms)
-                out["e2e"] = {"ms": round(best, 3), "value": round(n / best / 1e3, 3), "unit": "Msamples/s", "runs_ms": [round(x, 3) for x in e2e_ms],
-                              "gpu_ms": round(e2e_gpu_ms, 3), "file_bytes": 44 + 4 * n, "split_ms": split[e2e_ms.index(best)],
-                              "includes": "open WAV on tmpfs, header, threaded pread into pinned memory + copies to HBM (pdt_demod_fd), "
-                                          "all kernels, frame records to the host, time stamps, text formatting, output file "
-                                          "written and closed; context already open (HIP initialised)",
-                              "text_identical_to_resident_run": bool(e2e_text == gpu_text)}
-                # ---- the C host program itself
-                exe = os.path.join(ROOT, "bin", "demodARGOS" if kind else "demodPOES")
-                if args.e2e_only:
-                    print(json.dumps(out), flush=True)
-                    return
-                if os.path.exists(exe):
-                    cli_out = os.path.join(tmp, "cli_out.txt")
+        # ---- full size, every rank: the decoded frames are the transmitted ones (POES; a size-independent property)
+        if kind == 0 and CONFIGS[cfg][5] == 1.0:                          # (a weak signal loses frames: the CPU sample is its gate)
+            tx = [transmitted_check(pdt, capture_params(pdt, cfg, 1234 + r), gathered[r], n, fs) for r in range(world)]
+            parity["frames_equal_transmitted_full_size"] = [t["ok"] for t in tx]
+            parity["frames_complete"] = [t.get("complete", 0) for t in tx]
+            if world > 1:
+                parity["gathered_rank0_equals_own"] = bool(pdt.format_frames(gathered[0]) == gpu_text)
+        if legs:
+            # ---- end to end, in process: what POESTIPdemod/main.c:284-512 does with the file
+            e2e_ms, split = [], []
+            with pdt.Demodulator(mode, fs, device=local) as de:
+                for rep in range(3):
+                    outp = os.path.join(tmp, "e2e_out.txt")
                     t1 = time.perf_counter()
-                    r = subprocess.run([exe, "-d", str(local), "-o", cli_out, wav], capture_output=True, text=True)
-                    cli_s = time.perf_counter() - t1
-                    cli_text = open(cli_out, "rb").read() if os.path.exists(cli_out) else b""
-                    out["e2e_cli"] = {"seconds": round(cli_s, 3), "value": round(n / cli_s / 1e6, 3), "unit": "Msamples/s", "rc": r.returncode,
-                                      "includes": "process start, HIP initialisation, everything of `e2e`",
-                                      "text_identical_to_resident_run": bool(cli_text == gpu_text)}
-                # ---- CPU baseline on a bounded sample
-                n_cpu = min(n, int(round(cpu_seconds * fs)))
-                cpu_wav = wav
-                if n_cpu < n:
-                    cpu_wav = os.path.join(tmp, f"{cfg}_sample.wav")
-                    pdt.write_wav(cpu_wav, fs, iq[:n_cpu])
-                base, cpu_text = cpu_baseline(pdt, kind, fs, cpu_wav, n_cpu, tmp)
-                out["cpu_baseline"] = base
-                if n_cpu < n:
-                    with pdt.Demodulator(mode, fs, device=local) as ds:
-                        ds.demod(iq[:n_cpu])
-                        sample_text = ds.text()
-                else:
-                    sample_text = gpu_text
-                out["parity_with_cpu_baseline"] = bool(cpu_text == sample_text)
-        if world == 1 and args.config is None and not args.no_cpu and not args.no_scale_ref and not args.seconds and ncap == 1:
-            # The multi-GPU lines (N > 1) demodulate one configs[4] capture per GPU (= c3), this N = 1 line the configuration the
-            # metric is quoted on (c2): so that a 1 -> N curve can be read like for like, the same c3 step on this one GPU is
-            # measured here as well (its own process, resident input, no CPU / e2e legs) and quoted beside the c2 value.
-            try:
-                r = subprocess.run([sys.executable, os.path.abspath(__file__), "--config", "c3", "--steps", "3", "--warmup", "1", "--no-cpu"],
-                                   capture_output=True, text=True, timeout=900)
-                ref = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
-                out["weak_scaling_reference"] = {"workload": ref["config"]["workload"], "value": ref["value"], "unit": ref["unit"],
-                                                 "ms_per_step": ref["ms_per_step"], "n_gpus": 1,
-                                                 "note": "per-GPU workload of the N > 1 lines (one configs[4] capture per GPU), measured on this GPU"}
-            except Exception as e:                                             # (never fatal for the headline line)
-                out["weak_scaling_reference"] = {"error": str(e)[:200]}
-        ok = out.get("parity_with_cpu_baseline", True) and out.get("e2e", {}).get("text_identical_to_resident_run", True)
-        if not ok:
-            sys.stderr.write("bench.py: the GPU output differs from the CPU baseline / between entry points -- no result line\n")
-            sys.stderr.write(json.dumps({k: out[k] for k in ("parity_with_cpu_baseline", "e2e", "e2e_cli") if k in out}) + "\n")
+                    fd = os.open(wav, os.O_RDONLY)
+                    hdr = os.pread(fd, 44, 0)
+                    rate = int.from_bytes(hdr[24:28], "little")
+                    nfr = (os.fstat(fd).st_size - 44) // 4
+                    t2 = time.perf_counter()
+                    de.demod_file(fd, 44, nfr, 0)
+                    os.close(fd)
+                    t3 = time.perf_counter()
+                    text = de.text()
+                    t4 = time.perf_counter()
+                    with open(outp, "wb") as fo:
+                        fo.write(text)
+                    t5 = time.perf_counter()
+                    e2e_ms.append((t5 - t1) * 1e3)
+                    split.append({"open_header": round((t2 - t1) * 1e3, 3), "demod_fd": round((t3 - t2) * 1e3, 3),
+                                  "text": round((t4 - t3) * 1e3, 3), "write_close": round((t5 - t4) * 1e3, 3)})
+                    assert rate == fs and nfr == n
+                e2e_text = text
+                e2e_gpu_ms = de.stats().gpu_ms
+            best = min(e2e_ms)
+            out["e2e"] = {"ms": round(best, 3), "value": round(n / best / 1e3, 3), "unit": "Msamples/s", "runs_ms": [round(x, 3) for x in e2e_ms],
+                          "gpu_ms": round(e2e_gpu_ms, 3), "file_bytes": 44 + 4 * n, "split_ms": split[e2e_ms.index(best)],
+                          "includes": "open WAV on tmpfs, header, threaded pread into pinned memory + copies to HBM (pdt_demod_fd), "
+                                      "all kernels, frame records to the host, time stamps, text formatting, output file "
+                                      "written and closed; context already open (HIP initialised)"}
+            parity["e2e_text_equals_resident_full_size"] = bool(e2e_text == gpu_text)
+            if args.e2e_only:
+                out["parity"] = parity
+                print(json.dumps(out), flush=True)
+                return
+            # ---- the C host program itself
+            exe = os.path.join(ROOT, "bin", "demodARGOS" if kind else "demodPOES")
+            if os.path.exists(exe):
+                cli_out = os.path.join(tmp, "cli_out.txt")
+                t1 = time.perf_counter()
+                r = subprocess.run([exe, "-d", str(local), "-o", cli_out, wav], capture_output=True, text=True)
+                cli_s = time.perf_counter() - t1
+                cli_text = open(cli_out, "rb").read() if os.path.exists(cli_out) else b""
+                out["e2e_cli"] = {"seconds": round(cli_s, 3), "value": round(n / cli_s / 1e6, 3), "unit": "Msamples/s", "rc": r.returncode,
+                                  "includes": "process start, HIP initialisation, everything of `e2e`, the reference's per-chunk "
+                                              "progress / quality lines (averagePhase EMA)"}
+                parity["cli_text_equals_resident_full_size"] = bool(cli_text == gpu_text)
+            os.unlink(wav)                                               # (3.6 GB of tmpfs back before the CPU legs)
+            # ---- CPU baseline on a bounded sample: the first n_cpu samples of this capture, one thread ...
+            n_cpu = min(n, int(round(cpu_seconds * fs)))
+            cpu_wav = os.path.join(tmp, "sample_0.wav")
+            make_capture(pdt, par, n_cpu, threads, wav_path=cpu_wav, fs=fs)
+            dsp, wall, texts, what = cpu_baseline(kind, [cpu_wav], n_cpu, tmp)
+            out["cpu_baseline"] = {"value": round(n_cpu / dsp[0] / 1e6, 3), "unit": "Msamples/s", "cores": 1, "kind": what,
+                                   "e2e_value": round(n_cpu / wall / 1e6, 3),
+                                   "sample": f"the first {n_cpu} samples ({n_cpu / fs:g} s) of rank 0's capture as a WAV on tmpfs: "
+                                             f"{dsp[0]:.2f} s in the DSP stages (value), {wall:.2f} s wall for the whole program with "
+                                             "file read and text output (e2e_value)",
+                                   "host_cpus": os.cpu_count()}
+            with pdt.Demodulator(mode, fs, device=local) as ds:
+                ds.demod_device(d_iq.data_ptr(), n_cpu)                 # the same samples, through the product path
+                parity["sample_text_equals_cpu_baseline"] = bool(ds.text() == texts[0])
+                parity["sample"] = f"first {n_cpu} samples, {len(texts[0])} bytes of text"
+                # ---- ... and 8 concurrent single-thread processes, one capture each (configs[4]'s CPU counterpart)
+                if kind == 0 and cfg == DEFAULT_CONFIG and not args.seconds:
+                    wavs, pars = [cpu_wav], [par]
+                    for r in range(1, 8):
+                        pr = capture_params(pdt, cfg, 1234 + r)
+                        w = os.path.join(tmp, f"sample_{r}.wav")
+                        make_capture(pdt, pr, n_cpu, threads, wav_path=w, fs=fs)
+                        wavs.append(w); pars.append(pr)
+                    dsp8, wall8, texts8, _ = cpu_baseline(kind, wavs, n_cpu, tmp)
+                    out["cpu_baseline_8proc"] = {"value": round(8 * n_cpu / wall8 / 1e6, 3), "unit": "Msamples/s", "cores": 8, "kind": what,
+                                                 "per_process_dsp_s": [round(x, 2) for x in dsp8], "wall_s": round(wall8, 2),
+                                                 "sample": f"8 concurrent single-thread processes, the first {n_cpu} samples of the 8 "
+                                                           "captures of configs[4] (seeds 1234..1241), whole program (file on tmpfs -> text)"}
+                    same8 = []
+                    for r in range(1, 8):
+                        d_r = make_capture(pdt, pars[r], n_cpu, threads, device=dev)
+                        ds.demod_device(d_r.data_ptr(), n_cpu)
+                        same8.append(bool(ds.text() == texts8[r]))
+                        del d_r
+                    parity["other_seeds_sample_text_equals_cpu"] = same8
+        out["parity"] = parity
+        out["parity_with_cpu_baseline"] = parity.get("sample_text_equals_cpu_baseline")
+        if legs and not args.no_secondary and cfg == DEFAULT_CONFIG and not args.seconds:
+            del d_iq
+            torch.cuda.empty_cache()
+            out["secondary"] = {}
+            for c2 in ("c2", "argos"):
+                try:
+                    r = subprocess.run([sys.executable, os.path.abspath(__file__), "--config", c2, "--steps", "10", "--warmup", "2",
+                                        "--no-secondary"], capture_output=True, text=True, timeout=900)
+                    ref = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+                    out["secondary"][c2] = {k: ref.get(k) for k in ("value", "unit", "ms_per_step", "dtype", "roofline", "fir_pll_stage",
+                                                                      "e2e", "e2e_cli", "cpu_baseline", "parity")}
+                    out["secondary"][c2]["workload"] = ref["config"]["workload"]
+                except Exception as e:                                     # (never fatal for the headline line)
+                    out["secondary"][c2] = {"error": (str(e) + " " + (r.stderr[-300:] if "r" in dir() else ""))[:500]}
+        bad = [k for k, v in parity.items() if v is False or (isinstance(v, list) and v and isinstance(v[0], bool) and not all(v))]
+        if bad:
+            sys.stderr.write("bench.py: parity failure -- no result line: " + json.dumps({k: parity[k] for k in bad}) + "\n")
+            sys.stderr.write(json.dumps({k: out[k] for k in ("parity", "e2e", "e2e_cli") if k in out}) + "\n")
             if world > 1:
                 dist.destroy_process_group()
             sys.exit(1)

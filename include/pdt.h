@@ -72,7 +72,8 @@ enum {
     PDT_ERR_NOMEM = -3,
     PDT_ERR_FORMAT = -4,    /* unsupported WAV format                        */
     PDT_ERR_RATE = -5,      /* sample rate gives interpolation factor 0 (Fs > 300 kHz, POESTIPdemod/main.c:347) */
-    PDT_ERR_STATE = -6      /* call sequence error                           */
+    PDT_ERR_STATE = -6,     /* call sequence error                           */
+    PDT_ERR_IO = -7         /* read error on the capture file (pdt_demod_fd) */
 };
 
 /* intermediate streams, in the order the reference produces them */
@@ -161,6 +162,9 @@ typedef struct pdt_kernel_time {
 typedef struct pdt_ctx pdt_ctx;
 
 int  pdt_abi_version(void);
+/* Identifies the build: the first 12 hex digits of the SHA-1 over the library's sources (csrc/, include/pdt.h), set by the
+ * Makefile.  Profiles committed under profiles/ record it, so that a figure measured with another build is never quoted. */
+const char *pdt_build_tag(void);
 const char *pdt_strerror(int code);
 int  pdt_device_count(void);
 
@@ -204,7 +208,13 @@ int  pdt_demod_pcm16(pdt_ctx *ctx, const int16_t *iq_host, uint64_t nframes);
  * wave.c:59-175,413-540, once per chunk): nframes I,Q pairs of `sample_format` starting at byte_offset (44 for the
  * canonical WAV header ReadWavHeader accepts, 0 for RAW).  The library reads the file in 2 MiB spans with a few host
  * threads into pinned memory and copies them to the GPU while the next spans are being read, so a capture is in HBM about
- * as soon as the page cache and the PCIe link allow.  PDT_ERR_FORMAT when the file ends early.                         */
+ * as soon as the page cache and the PCIe link allow.  PDT_ERR_FORMAT when the file ends early, PDT_ERR_IO on a read error
+ * (EINTR is retried).
+ * Large POES captures (512 MiB and more, Gardner sampler, no pdt_keep_quality): the chain starts before the last span has
+ * arrived and runs in four segments with carried state (the streaming path over the resident capture).  Frames, text and
+ * pdt_get_stats' counts then describe the whole capture as ever; but pdt_read_stage / pdt_stage_len describe the LAST
+ * SEGMENT only (window-local indices), the pll / agc seam counters and gpu_ms are the last segment's, and no stream is left
+ * open behind the call.                                                                                                */
 int  pdt_demod_fd(pdt_ctx *ctx, int fd, uint64_t byte_offset, uint64_t nframes, int sample_format);
 /* ... or already resident in device memory (no copy; buffer is only read).                      */
 int  pdt_demod_device(pdt_ctx *ctx, const void *iq_device, uint64_t nframes);
@@ -232,7 +242,10 @@ int  pdt_demod_device_f32(pdt_ctx *ctx, const void *iq_device, uint64_t nframes)
  * keeps a bounded window of the input (the PLL's warm-up history, see pdt_stream_retained) and nothing else of the past.
  * Guarantee: the frames reported by the pushes followed by those of pdt_stream_end are exactly the frames of one
  * pdt_demod_* call on the whole capture.
- *   pdt_stream_begin      forget any stream in progress (the sample format is fixed by the first push)
+ *   pdt_stream_begin      forget any stream in progress (the sample format is fixed by the first push); optional: the first
+ *                         push after pdt_open / pdt_stream_end opens a new stream by itself.  While a stream is open (first
+ *                         push .. pdt_stream_end / pdt_stream_begin) the stage buffers hold the tails the next push continues
+ *                         from: every pdt_demod_* and pdt_stage_* entry returns PDT_ERR_STATE
  *   pdt_stream_push_*     append nframes I,Q pairs; *new_frames = frames that became final with this push
  *   pdt_stream_end        the capture is over: demodulate the short last chunk, report the remaining frames (a frame cut
  *                         by the end stays partial, Q11); afterwards pdt_frames / pdt_get_stats / pdt_format_frames
@@ -313,8 +326,8 @@ typedef struct pdt_pll_state {          /* CarrierTrackingPLL.c:60-75 */
  * `DT complex` as wave.c:127-172 does) or PDT_FMT_F32 (pairs of float = `float complex` as they are; float contexts only,
  * PDT_ERR_FORMAT otherwise); out_host = realDataOut, lock_out_host (optional) = lockSignalStreamOut, *avg_phase_ret (optional)
  * = the return value.  Runs the whole-capture path's PLL kernels (sequential acquisition, block-parallel tracking with
- * validated seams, lock-detector and averagePhase EMAs) from the record's state and stops behind the PLL.  Not while a stream
- * is open or with cfg.profile (PDT_ERR_STATE).                                                                            */
+ * validated seams, lock-detector and averagePhase EMAs) from the record's state and stops behind the PLL.  Not with
+ * cfg.profile (PDT_ERR_STATE; like every stage entry, not while a stream is open).                                                                          */
 int      pdt_stage_pll(pdt_ctx *ctx, const void *iq_host, uint64_t n, int sample_format, pdt_pll_state *state, void *out_host,
                        void *lock_out_host, double *avg_phase_ret);
 /* DT StaticGain(DT complex *complexData, unsigned int nSamples, DT desiredLevel) (AGC.h:4, AGC.c:48-74): the gain the mains

@@ -149,7 +149,7 @@ class KernelTime(C.Structure):
 
 # every symbol include/pdt.h declares (tests check the library exports all of them)
 ABI_SYMBOLS = [
-    "pdt_abi_version", "pdt_strerror", "pdt_device_count", "pdt_open", "pdt_close", "pdt_set_stream",
+    "pdt_abi_version", "pdt_build_tag", "pdt_strerror", "pdt_device_count", "pdt_open", "pdt_close", "pdt_set_stream",
     "pdt_demod_pcm16", "pdt_demod_device", "pdt_demod_f32", "pdt_demod_device_f32", "pdt_demod_batch_device", "pdt_num_frames", "pdt_frames", "pdt_get_stats",
     "pdt_format_frames", "pdt_read_stage", "pdt_stage_len", "pdt_kernel_times", "pdt_make_lpf",
     "pdt_wav_parse_header", "pdt_time_axis", "pdt_stage_bytesync", "pdt_tip_check", "pdt_tip_frames",
@@ -173,6 +173,7 @@ def lib():
         )
     L = C.CDLL(LIBPDT_PATH)
     L.pdt_abi_version.restype = C.c_int
+    L.pdt_build_tag.restype = C.c_char_p
     L.pdt_strerror.restype = C.c_char_p
     L.pdt_strerror.argtypes = [C.c_int]
     L.pdt_device_count.restype = C.c_int
@@ -247,6 +248,11 @@ def lib():
 def _check(rc: int, what: str):
     if rc != 0:
         raise PdtError(f"{what}: {lib().pdt_strerror(rc).decode()} ({rc})")
+
+
+def build_tag() -> str:
+    """pdt_build_tag: which sources the loaded libpdt.so was built from (profiles/ files carry the same tag)"""
+    return lib().pdt_build_tag().decode()
 
 
 def make_lpf(mode: int, sample_rate: int) -> tuple[np.ndarray, int]:
@@ -591,6 +597,7 @@ class SynthParams(C.Structure):
     _fields_ = [
         ("kind", C.c_uint32), ("sample_rate", C.c_uint32), ("carrier_step", C.c_uint32), ("phase0", C.c_uint32),
         ("mod_index", C.c_uint32), ("amplitude", C.c_int32), ("noise_gain", C.c_int32), ("seed", C.c_uint64),
+        ("signal_start", C.c_uint64),
     ]
 
 

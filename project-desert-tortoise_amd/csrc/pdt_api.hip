@@ -6,6 +6,7 @@
 #include <stdlib.h>
 #include <string.h>
 
+#include <errno.h>
 #include <unistd.h>
 
 #include <algorithm>
@@ -371,6 +372,7 @@ struct pdt_ctx {
     uint64_t stream_have = 0, stream_done = 0;   // samples in the window / of them already demodulated (local indices)
     uint64_t stream_total = 0;          // samples pushed since pdt_stream_begin
     int stream_fmt = -1;                // -1 = no push yet, 0 = pcm16, 1 = float32
+    bool stream_open = false;           // between the first push and pdt_stream_end / _begin: the stage buffers hold the tails the next push continues from
     std::vector<pdt_frame> stream_new;
     unsigned char *seg_pin = nullptr;   // pinned staging for the small per-segment transfers (part of the pend_sc block)
     pdt_stats stats;
@@ -1838,7 +1840,8 @@ int ingest_capture(pdt_ctx *ctx, const IngestSrc &src, size_t bytes, void *dst, 
                 size_t got = 0;
                 while (got < len) {
                     const ssize_t r = pread(src.fd, pin + got, len - got, (off_t)(src.off + at + got));
-                    if (r <= 0) { failed = 2; return; }
+                    if (r < 0 && errno == EINTR) continue;
+                    if (r <= 0) { failed = r == 0 ? 2 : 3; return; }      // 2: the file ends early; 3: read error
                     got += (size_t)r;
                 }
             }
@@ -1863,6 +1866,7 @@ int ingest_capture(pdt_ctx *ctx, const IngestSrc &src, size_t bytes, void *dst, 
     worker(0);
     for (auto &th : pool) th.join();
     if (failed == 2) return PDT_ERR_FORMAT;                // the file is shorter than announced
+    if (failed == 3) return PDT_ERR_IO;
     if (failed) { (void)hipGetLastError(); return PDT_ERR_NOGPU; }
     HIP_TRY(hipEventRecord(ctx->ev_ingest, ctx->copy_stream));
     HIP_TRY(hipStreamWaitEvent(ctx->stream, ctx->ev_ingest, 0));
@@ -1879,7 +1883,7 @@ int ingest_wait_prefix(pdt_ctx *ctx, IngestJob &job, size_t upto_bytes, hipStrea
     const size_t need = std::min(job.nspans, (upto_bytes + job.span - 1) / job.span);
     for (; job.waited < need; job.waited++) {
         while (!job.submitted[job.waited].load(std::memory_order_acquire)) {
-            if (job.failed) return job.failed == 2 ? PDT_ERR_FORMAT : PDT_ERR_NOGPU;
+            if (job.failed) return job.failed == 2 ? PDT_ERR_FORMAT : job.failed == 3 ? PDT_ERR_IO : PDT_ERR_NOGPU;
             std::this_thread::yield();
         }
         HIP_TRY(hipStreamWaitEvent(stream, ctx->span_ev[job.waited], 0));
@@ -1892,6 +1896,7 @@ int ingest_join(IngestJob &job)
     for (auto &th : job.pool) th.join();
     job.pool.clear();
     if (job.failed == 2) return PDT_ERR_FORMAT;
+    if (job.failed == 3) return PDT_ERR_IO;
     if (job.failed) { (void)hipGetLastError(); return PDT_ERR_NOGPU; }
     return PDT_OK;
 }
@@ -1902,6 +1907,10 @@ int ingest_join(IngestJob &job)
 extern "C" {
 
 int pdt_abi_version(void) { return PDT_ABI_VERSION; }
+#ifndef PDT_BUILD_TAG
+#define PDT_BUILD_TAG "untagged"
+#endif
+const char *pdt_build_tag(void) { return PDT_BUILD_TAG; }
 
 const char *pdt_strerror(int code)
 {
@@ -1913,6 +1922,7 @@ const char *pdt_strerror(int code)
     case PDT_ERR_FORMAT: return "unsupported WAV format (need 16-bit PCM, 2 channels)";
     case PDT_ERR_RATE: return "sample rate too high: interpolation factor would be 0";
     case PDT_ERR_STATE: return "call sequence / internal capacity error";
+    case PDT_ERR_IO: return "read error on the capture file";
     default: return "unknown error";
     }
 }
@@ -2186,6 +2196,7 @@ static int demod_common(pdt_ctx *ctx, uint64_t nframes, int phase = RUN_ALL)
 int pdt_demod_pcm16(pdt_ctx *ctx, const int16_t *iq_host, uint64_t nframes)
 {
     if (!ctx || (!iq_host && nframes)) return PDT_ERR_ARG;
+    if (ctx->stream_open) return PDT_ERR_STATE;                      // pdt_stream_end / pdt_stream_begin first
     HIP_TRY(hipSetDevice(ctx->cfg.device));
     int rc = ctx->pcm.ensure((size_t)nframes * 4 + 16);
     if (rc) return rc;
@@ -2216,6 +2227,7 @@ int pdt_demod_fd(pdt_ctx *ctx, int fd, uint64_t byte_offset, uint64_t nframes, i
     IngestSrc src;
     src.fd = fd;
     src.off = byte_offset;
+    if (ctx->stream_open) return PDT_ERR_STATE;
     if (overlap_ingest(ctx, nframes, fb)) return demod_overlapped(ctx, src, nframes, sample_format == PDT_FMT_F32 ? 1 : 0);
     int rc = ctx->pcm.ensure((size_t)nframes * fb + 16);
     if (rc) return rc;
@@ -2228,6 +2240,7 @@ int pdt_demod_fd(pdt_ctx *ctx, int fd, uint64_t byte_offset, uint64_t nframes, i
 int pdt_demod_device(pdt_ctx *ctx, const void *iq_device, uint64_t nframes)
 {
     if (!ctx || (!iq_device && nframes)) return PDT_ERR_ARG;
+    if (ctx->stream_open) return PDT_ERR_STATE;                      // pdt_stream_end / pdt_stream_begin first
     ctx->pcm_dev = iq_device;
     ctx->pcm_fmt = 0;
     return demod_common(ctx, nframes);
@@ -2236,6 +2249,7 @@ int pdt_demod_device(pdt_ctx *ctx, const void *iq_device, uint64_t nframes)
 int pdt_demod_f32(pdt_ctx *ctx, const float *iq_host, uint64_t nframes)
 {
     if (!ctx || (!iq_host && nframes)) return PDT_ERR_ARG;
+    if (ctx->stream_open) return PDT_ERR_STATE;                      // pdt_stream_end / pdt_stream_begin first
     if (ctx->cfg.mode != PDT_MODE_POES) return PDT_ERR_FORMAT;       // ARGOSdemod/main.c:238-241: "RAW files not yet supported"
     HIP_TRY(hipSetDevice(ctx->cfg.device));
     int rc = ctx->pcm.ensure((size_t)nframes * 8 + 16);
@@ -2251,6 +2265,7 @@ int pdt_demod_f32(pdt_ctx *ctx, const float *iq_host, uint64_t nframes)
 int pdt_demod_device_f32(pdt_ctx *ctx, const void *iq_device, uint64_t nframes)
 {
     if (!ctx || (!iq_device && nframes)) return PDT_ERR_ARG;
+    if (ctx->stream_open) return PDT_ERR_STATE;                      // pdt_stream_end / pdt_stream_begin first
     if (ctx->cfg.mode != PDT_MODE_POES) return PDT_ERR_FORMAT;
     ctx->pcm_dev = iq_device;
     ctx->pcm_fmt = 1;
@@ -2261,6 +2276,7 @@ int pdt_stage_bytesync(pdt_ctx *ctx, const uint8_t *bits_host, uint64_t nbits)
 {
     if (!ctx || (!bits_host && nbits)) return PDT_ERR_ARG;
     if (nbits >= (1ull << 31)) return PDT_ERR_ARG;
+    if (ctx->stream_open) return PDT_ERR_STATE;              // (the stage buffers carry an open stream's tails)
     HIP_TRY(hipSetDevice(ctx->cfg.device));
     const bool argos = ctx->cfg.mode == PDT_MODE_ARGOS;
     const SyncParams SP = make_sync_params(argos);
@@ -2811,7 +2827,7 @@ int pdt_stage_pll(pdt_ctx *ctx, const void *iq_host, uint64_t n, int sample_form
 {
     if (!ctx || (!iq_host && n) || n >= (1ull << 31) || (sample_format != PDT_FMT_PCM16 && sample_format != PDT_FMT_F32)) return PDT_ERR_ARG;
     if (ctx->elem != 4 && sample_format == PDT_FMT_F32) return PDT_ERR_FORMAT;   // (double contexts: no `double complex` sample source)
-    if (ctx->cfg.profile || ctx->sc.active) return PDT_ERR_STATE;
+    if (ctx->cfg.profile || ctx->stream_open) return PDT_ERR_STATE;
     HIP_TRY(hipSetDevice(ctx->cfg.device));
     if (ctx->elem == 8) return stage_pll<double>(ctx, iq_host, n, sample_format, state, out_host, lock_out_host, avg_phase_ret);
     return stage_pll<float>(ctx, iq_host, n, sample_format, state, out_host, lock_out_host, avg_phase_ret);
@@ -2822,6 +2838,7 @@ int pdt_stage_gardner(pdt_ctx *ctx, const void *in_host, uint64_t n, uint64_t ca
 {
     if (!ctx || !in_host || capacity == 0 || n > capacity || capacity >= (1ull << 30)) return PDT_ERR_ARG;
     if (ctx->cfg.sampler != PDT_SAMPLER_GARDNER) return PDT_ERR_ARG;
+    if (ctx->stream_open) return PDT_ERR_STATE;              // (the stage buffers carry an open stream's tails)
     HIP_TRY(hipSetDevice(ctx->cfg.device));
     if (ctx->elem == 8) return stage_gardner<double>(ctx, in_host, n, capacity, neighbour_host, state, out_host, pick_out, nsym_out);
     return stage_gardner<float>(ctx, in_host, n, capacity, neighbour_host, state, out_host, pick_out, nsym_out);
@@ -2830,6 +2847,7 @@ int pdt_stage_gardner(pdt_ctx *ctx, const void *in_host, uint64_t n, uint64_t ca
 int pdt_stage_static_gain(pdt_ctx *ctx, const void *iq_host, uint64_t n, int sample_format, double level, double *gain_out)
 {
     if (!ctx || !iq_host || n == 0 || n >= (1ull << 31) || (sample_format != PDT_FMT_PCM16 && sample_format != PDT_FMT_F32)) return PDT_ERR_ARG;
+    if (ctx->stream_open) return PDT_ERR_STATE;              // (the stage buffers carry an open stream's tails)
     HIP_TRY(hipSetDevice(ctx->cfg.device));
     if (ctx->elem == 8) return stage_static_gain<double>(ctx, iq_host, n, sample_format, level, gain_out);
     return stage_static_gain<float>(ctx, iq_host, n, sample_format, level, gain_out);
@@ -2844,6 +2862,7 @@ int pdt_stage_mm(pdt_ctx *ctx, const void *in_host, uint64_t n, pdt_mm_state *st
         const double baud = ctx->cfg.mode == PDT_MODE_ARGOS ? 800.0 : 16640.3;
         if (!(rg >= 0) || rg >= baud * 0.5) return PDT_ERR_ARG;                            // stepMax must stay positive and finite
     }
+    if (ctx->stream_open) return PDT_ERR_STATE;              // (the stage buffers carry an open stream's tails)
     HIP_TRY(hipSetDevice(ctx->cfg.device));
     if (ctx->elem == 8) return stage_mm<double>(ctx, in_host, n, state, out_host, pick_out, nsym_out);
     return stage_mm<float>(ctx, in_host, n, state, out_host, pick_out, nsym_out);
@@ -2852,6 +2871,7 @@ int pdt_stage_mm(pdt_ctx *ctx, const void *in_host, uint64_t n, pdt_mm_state *st
 int pdt_stage_agc(pdt_ctx *ctx, void *data_host, uint64_t n, double initial, double attack, double decay, pdt_agc_state *state)
 {
     if (!ctx || (!data_host && n) || n >= (1ull << 31)) return PDT_ERR_ARG;
+    if (ctx->stream_open) return PDT_ERR_STATE;              // (the stage buffers carry an open stream's tails)
     HIP_TRY(hipSetDevice(ctx->cfg.device));
     if (ctx->elem == 8) return stage_agc<double>(ctx, data_host, n, initial, attack, decay, state);
     return stage_agc<float>(ctx, data_host, n, initial, attack, decay, state);
@@ -2860,6 +2880,7 @@ int pdt_stage_agc(pdt_ctx *ctx, void *data_host, uint64_t n, double initial, dou
 int pdt_stage_squelch(pdt_ctx *ctx, void *data_host, const void *lock_host, uint64_t n, double threshold)
 {
     if (!ctx || ((!data_host || !lock_host) && n) || n >= (1ull << 31)) return PDT_ERR_ARG;
+    if (ctx->stream_open) return PDT_ERR_STATE;              // (the stage buffers carry an open stream's tails)
     HIP_TRY(hipSetDevice(ctx->cfg.device));
     if (ctx->elem == 8) return stage_squelch<double>(ctx, data_host, lock_host, n, threshold);
     return stage_squelch<float>(ctx, data_host, lock_host, n, threshold);
@@ -2871,6 +2892,7 @@ int pdt_stage_manchester(pdt_ctx *ctx, const void *symbols_host, uint64_t nsymbo
     if (!ctx || (!symbols_host && nsymbols) || nsymbols >= (1ull << 31)) return PDT_ERR_ARG;
     if (nbits_out) *nbits_out = 0;
     if (nsymbols == 0) return PDT_OK;                                 // the loop body never runs: nothing changes
+    if (ctx->stream_open) return PDT_ERR_STATE;              // (the stage buffers carry an open stream's tails)
     HIP_TRY(hipSetDevice(ctx->cfg.device));
     if (ctx->elem == 8)
         return stage_manchester<double>(ctx, symbols_host, nsymbols, resync_threshold, state, bits_out, bit_symbol_out, nbits_out);
@@ -2880,6 +2902,7 @@ int pdt_stage_manchester(pdt_ctx *ctx, const void *symbols_host, uint64_t nsymbo
 int pdt_stage_fir(pdt_ctx *ctx, const void *in_host, uint64_t n, pdt_fir_state *state, void *out_host)
 {
     if (!ctx || (!in_host && n) || n >= (1ull << 31)) return PDT_ERR_ARG;
+    if (ctx->stream_open) return PDT_ERR_STATE;              // (the stage buffers carry an open stream's tails)
     HIP_TRY(hipSetDevice(ctx->cfg.device));
     if (ctx->elem == 8) return stage_fir<double>(ctx, in_host, n, state, out_host);
     return stage_fir<float>(ctx, in_host, n, state, out_host);
@@ -2891,6 +2914,7 @@ int pdt_demod_batch_device(pdt_ctx *const *ctxs, const void *const *iq_device, c
     if (count < 0 || (count && (!ctxs || !iq_device || !nframes))) return PDT_ERR_ARG;
     for (int i = 0; i < count; i++) {
         if (!ctxs[i] || (!iq_device[i] && nframes[i])) return PDT_ERR_ARG;
+        if (ctxs[i]->stream_open) return PDT_ERR_STATE;
         for (int j = 0; j < i; j++)
             if (ctxs[j] == ctxs[i]) return PDT_ERR_ARG;               // one context per capture
     }
@@ -2939,6 +2963,7 @@ int pdt_stream_begin(pdt_ctx *ctx)
     ctx->stream_done = 0;
     ctx->stream_total = 0;
     ctx->stream_fmt = -1;
+    ctx->stream_open = false;
     ctx->stream_new.clear();
     ctx->frames_host.clear();
     ctx->tip_host.clear();
@@ -3097,6 +3122,11 @@ static int demod_overlapped(pdt_ctx *ctx, const IngestSrc &src, uint64_t nframes
     }
     ctx->sc.in_place = false;
     const int rj = ingest_join(job);
+    // the stream machinery was borrowed: leave no stream behind (a later push starts a new one), keep frames and statistics
+    ctx->sc = StreamCarry();
+    ctx->stream_have = ctx->stream_done = ctx->stream_total = 0;
+    ctx->stream_fmt = -1;
+    ctx->stream_open = false;
     return rc ? rc : rj;
 }
 
@@ -3104,6 +3134,11 @@ static int stream_push(pdt_ctx *ctx, const void *host, uint64_t nframes, int fmt
 {
     if (!ctx || (!host && nframes)) return PDT_ERR_ARG;
     if (fmt == 1 && ctx->cfg.mode != PDT_MODE_POES) return PDT_ERR_FORMAT;
+    if (!ctx->stream_open) {                         // the first push opens a stream (as if pdt_stream_begin had been called)
+        int rb = pdt_stream_begin(ctx);
+        if (rb) return rb;
+        ctx->stream_open = true;
+    }
     if (ctx->stream_fmt >= 0 && ctx->stream_fmt != fmt) return PDT_ERR_STATE;
     HIP_TRY(hipSetDevice(ctx->cfg.device));
     ctx->stream_fmt = fmt;
@@ -3144,6 +3179,7 @@ int pdt_stream_end(pdt_ctx *ctx, uint64_t *new_frames)
 {
     if (!ctx) return PDT_ERR_ARG;
     HIP_TRY(hipSetDevice(ctx->cfg.device));
+    ctx->stream_open = false;                        // (whatever happens below, the stream is over)
     if (ctx->stream_fmt < 0) {                       // nothing was pushed: an empty capture
         ctx->stream_fmt = 0;
         int rc = ctx->stream_in.ensure(64);
@@ -3267,9 +3303,10 @@ int pdt_get_stats(const pdt_ctx *ctx, pdt_stats *out)
 
 // "%.5f" of a non-negative double without printf: value * 10^5 rounded to nearest, ties to even, on the EXACT binary value
 // -- what glibc prints.  x = m * 2^e with a 53-bit m; m * 100000 fits 70 bits.  Returns the number of characters.
+enum { PDT_TIME5_MAX = 336 };
 static int format_time5(double x, char *out)
 {
-    if (!(x >= 0.0) || x >= 1e15) return snprintf(out, 48, "%.5f", x);
+    if (!(x >= 0.0) || x >= 1e15) return snprintf(out, PDT_TIME5_MAX, "%.5f", x);   // (never the reference's range; DBL_MAX prints 315 characters)
     uint64_t bits;
     memcpy(&bits, &x, sizeof bits);
     const int be = (int)((bits >> 52) & 0x7ff);
@@ -3307,7 +3344,7 @@ uint64_t pdt_format_records(const pdt_frame *frames, uint64_t nframes, char *buf
     // ByteSync.c:96-99,126-129 ("%.5f " / "%.5fi "), :62,100-101 ("%.2X "), :66-70 (newline after the last byte)
     static const char hex[] = "0123456789ABCDEF";
     uint64_t need = 0;
-    char line[64 + 3 * 104 + 2];
+    char line[PDT_TIME5_MAX + 4 + 3 * 104 + 2];
     for (uint64_t k = 0; k < nframes; k++) {
         const pdt_frame &f = frames[k];
         int w = format_time5(f.time, line);

@@ -24,7 +24,7 @@
 
 typedef struct job {
     const char *path;
-    int device, mode, rc;
+    int device, mode, rc, started;
     unsigned long chunk;
     pdt_ctx *ctx;
     uint64_t nframes;
@@ -95,55 +95,65 @@ int main(int argc, char **argv)
             j->device = k;
             j->mode = mode;
             j->chunk = chunk;
-            pthread_create(&th[w0 + k], NULL, run_job, j);
+            j->started = pthread_create(&th[w0 + k], NULL, run_job, j) == 0;
+            if (!j->started) j->rc = PDT_ERR_NOMEM;                /* (no thread: this capture fails, the others go on) */
         }
-        for (int k = 0; k < wn; k++) pthread_join(th[w0 + k], NULL);
+        for (int k = 0; k < wn; k++)
+            if (jobs[w0 + k].started) pthread_join(th[w0 + k], NULL);
+        /* the captures that were demodulated: only those take part in the gather; a failed capture costs its own output */
         pdt_ctx **ctxs = (pdt_ctx **)calloc((size_t)wn, sizeof(pdt_ctx *));
-        int ok = 1;
+        int *who = (int *)calloc((size_t)wn, sizeof(int));
+        int good = 0;
         for (int k = 0; k < wn; k++) {
-            ctxs[k] = jobs[w0 + k].ctx;
             if (jobs[w0 + k].rc != PDT_OK) {
                 printf("%s: %s\n", jobs[w0 + k].path, pdt_strerror(jobs[w0 + k].rc));
-                ok = 0;
                 failed++;
+            } else {
+                who[good] = w0 + k;
+                ctxs[good++] = jobs[w0 + k].ctx;
             }
         }
-        if (ok) {
+        if (good) {
             pdt_frame *all = NULL;
-            uint64_t *counts = (uint64_t *)calloc((size_t)wn, sizeof(uint64_t));
-            const int rc = pdt_gather_frames(ctxs, wn, 0, &all, counts);          /* RCCL: counts, then padded records */
-            if (rc != PDT_OK) {
-                printf("gather failed: %s\n", pdt_strerror(rc));
-                failed += wn;
-            } else {
-                uint64_t at = 0;
-                for (int k = 0; k < wn; k++) {
-                    const job *j = &jobs[w0 + k];
-                    char name[1200];
-                    snprintf(name, sizeof name, "%s.frames.txt", j->path);
-                    const uint64_t need = pdt_format_records(all + at, counts[k], NULL, 0);
-                    char *text = (char *)malloc(need + 1);
-                    pdt_format_records(all + at, counts[k], text, need);
-                    if (counts[k]) {
+            uint64_t *counts = (uint64_t *)calloc((size_t)good, sizeof(uint64_t));
+            int rc = counts ? pdt_gather_frames(ctxs, good, 0, &all, counts) : PDT_ERR_NOMEM;   /* RCCL: counts, then padded records */
+            if (rc != PDT_OK) printf("gather failed (%s): every capture's frames are taken from its own context\n", pdt_strerror(rc));
+            uint64_t at = 0;
+            for (int k = 0; k < good; k++) {
+                const job *j = &jobs[who[k]];
+                char name[1200];
+                snprintf(name, sizeof name, "%s.frames.txt", j->path);
+                const uint64_t nfr = rc == PDT_OK ? counts[k] : pdt_num_frames(j->ctx);
+                const uint64_t need = rc == PDT_OK ? pdt_format_records(all + at, nfr, NULL, 0) : pdt_format_frames(j->ctx, NULL, 0);
+                char *text = (char *)malloc(need + 1);
+                int wrote = text != NULL;
+                if (text) {
+                    if (rc == PDT_OK) pdt_format_records(all + at, nfr, text, need);
+                    else pdt_format_frames(j->ctx, text, need);
+                    if (nfr) {
                         FILE *f = fopen(name, "w");
-                        if (f) { fwrite(text, 1, need, f); fclose(f); }
+                        wrote = f && fwrite(text, 1, need, f) == need;
+                        if (f && fclose(f) != 0) wrote = 0;
                     } else {
                         remove(name);                                              /* no frame, no file (main.c:508-512) */
                     }
                     free(text);
-                    pdt_stats st;
-                    pdt_get_stats(j->ctx, &st);
-                    printf("GPU %d: %s: %0.3f Ks : %llu Sym : %llu Bits : %llu %s  (%.1f ms on the GPU, %.3f s with file read)\n", j->device,
-                           j->path, st.samples / 1000.0, (unsigned long long)st.symbols, (unsigned long long)st.bits,
-                           (unsigned long long)counts[k], mode == PDT_MODE_ARGOS ? "Packets" : "Frames", st.gpu_ms, j->seconds);
-                    samples_all += st.samples;
-                    at += counts[k];
                 }
+                if (!wrote) { printf("%s: could not be written\n", name); failed++; }
+                pdt_stats st;
+                pdt_get_stats(j->ctx, &st);
+                printf("GPU %d: %s: %0.3f Ks : %llu Sym : %llu Bits : %llu %s  (%.1f ms on the GPU, %.3f s with file read)\n", j->device,
+                       j->path, st.samples / 1000.0, (unsigned long long)st.symbols, (unsigned long long)st.bits,
+                       (unsigned long long)nfr, mode == PDT_MODE_ARGOS ? "Packets" : "Frames", st.gpu_ms, j->seconds);
+                if (wrote) samples_all += st.samples;
+                if (rc == PDT_OK) at += counts[k];
             }
             free(all);
             free(counts);
         }
-        for (int k = 0; k < wn; k++) pdt_close(ctxs[k]);
+        free(who);
+        for (int k = 0; k < wn; k++)
+            if (jobs[w0 + k].ctx) pdt_close(jobs[w0 + k].ctx);
         free(ctxs);
     }
     const double dt = now_s() - t_all;

@@ -42,6 +42,8 @@ typedef struct pdt_synth_params {
     int32_t  amplitude;     /* carrier amplitude, int16 units (9830 = 0.3 FS)             */
     int32_t  noise_gain;    /* Q16 multiplier applied to the 4-uniform Irwin-Hall sum     */
     uint64_t seed;          /* payload + noise seed                                       */
+    uint64_t signal_start;  /* samples before this index are noise only (carrier off): a  */
+                            /* receiver switched on before the satellite rises; 0 = none  */
 } pdt_synth_params;
 
 PDT_SYNTH_FN uint64_t pdt_synth_mix(uint64_t z)
@@ -99,7 +101,7 @@ PDT_SYNTH_FN void pdt_synth_sample(const pdt_synth_params *p, const int16_t *sin
                                    int16_t *q_out)
 {
     uint32_t theta = (uint32_t)(n * (uint64_t)p->carrier_step) + p->phase0;
-    int32_t amp = p->amplitude;
+    int32_t amp = n < p->signal_start ? 0 : p->amplitude;
     if (p->kind == 0) {
         uint64_t k = (n * 16640ull) / p->sample_rate;     /* Manchester symbol index */
         uint64_t bit = k >> 1;

@@ -135,7 +135,9 @@ def test_format_records_equals_printf(pdt):
         rng.random(20000).astype(np.float32).astype(np.float64) * 600.0,           # float-built time stamps (POES)
         rng.random(20000) * 4000.0,                                                # double stamps (ARGOS)
         np.array([0.0, 0.5e-5, 1.5e-5, 2.5e-5, 0.000005, 0.000015, 0.125, 128.0, 512.0, 1024.0, 3600.0, 99999.999995,
-                  1e-300, 5e-324, 1e14, 0.28009, 4.98649, 2.675, 1.0000049999999999, 123456.789015]),
+                  1e-300, 5e-324, 1e14, 0.28009, 4.98649, 2.675, 1.0000049999999999, 123456.789015,
+                  # beyond the integer path (printf fallback): up to 315 characters of time stamp must fit the line buffer
+                  9.99999999999999e14, 1e15, 1e58, 1e300, 1.7976931348623157e308, np.inf, -1.0, np.nan]),
         (np.arange(0, 4000, dtype=np.float64) + 0.5) / 1e5,                        # decimal ties as doubles (mostly inexact)
         np.ldexp(np.arange(1, 2000, dtype=np.float64), -17),                        # exact binary fractions incl. true ties
     ])

@@ -1,0 +1,89 @@
+"""bench.py as the driver runs it, on a shortened capture (the full-size line is the driver's): the JSON contract, the parity
+gate of the line, and -- when the box has more than one GPU -- the N > 1 launch without a wrapper, one rank per GPU over RCCL,
+with every rank's gathered frames checked.  On a one-GPU box the multi-GPU tests skip (there is nothing to run them on); the
+N > 1 logic is covered on CPU by tests/test_gather_gloo.py and by the two-ranks-on-one-GPU dry run below."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+from conftest import ROOT
+
+pytestmark = pytest.mark.gpu
+
+CONTRACT = ["metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline",
+            "dtype", "data", "config", "roofline"]
+
+
+def run_bench(*args, env=None, timeout=900):
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + list(args), capture_output=True, text=True, timeout=timeout,
+                       env=dict(os.environ, **(env or {})))
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert r.returncode == 0 and lines, r.stdout[-2000:] + r.stderr[-3000:]
+    return json.loads(lines[-1])
+
+
+def test_default_workload_shortened_one_gpu():
+    d = run_bench("--gpus", "1", "--steps", "2", "--warmup", "1", "--seconds", "40", "--no-secondary")
+    for k in CONTRACT + ["cpu_baseline", "e2e", "parity"]:
+        assert k in d, k
+    assert d["n_gpus"] == 1 and d["steps"] == 2 and d["config"]["workload"].startswith("c3 = BASELINE configs[2]")
+    assert "resident in HBM" in d["metric"] and d["dtype"] == "f32" and d["scaling"] == "weak"
+    p = d["parity"]
+    assert p["sample_text_equals_cpu_baseline"] is True and p["e2e_text_equals_resident_full_size"] is True
+    assert p["cli_text_equals_resident_full_size"] is True and p["frames_equal_transmitted_full_size"] == [True]
+    assert d["cpu_baseline"]["cores"] == 1 and d["cpu_baseline"]["kind"] in ("reference", "port")
+    assert set(d["roofline"]) >= {"bound", "achieved", "peak", "unit", "frac", "traffic"}
+
+
+@pytest.mark.parametrize("cfg", ["aos", "weak"])
+def test_prelock_and_weak_signal_workloads(cfg):
+    """The captures the reference meets at both ends of a pass: a minute of noise before the signal rises (the PLL sweeps,
+    CarrierTrackingPLL.c:232-246, then its one-time lock), and a low signal-to-noise ratio -- same parity gate."""
+    d = run_bench("--config", cfg, "--steps", "1", "--warmup", "1", "--seconds", "90", "--no-secondary")
+    assert d["parity"]["sample_text_equals_cpu_baseline"] is True
+    if cfg == "aos":
+        assert d["lock_sample"] >= 60 * 250000
+
+
+def test_two_ranks_share_one_gpu_dry_run():
+    """The multi-rank code path (barriers, max over ranks, ragged gather, per-rank check) with the collectives on gloo:
+    two ranks, both on GPU 0."""
+    d = run_bench("--gpus", "2", "--steps", "1", "--warmup", "1", "--seconds", "30", env={"PDT_BENCH_BACKEND": "gloo"})
+    assert d["n_gpus"] == 2 and len(d["per_rank_ms"]) == 2 and len(d["frames_per_capture"]) == 2
+    assert d["parity"]["frames_equal_transmitted_full_size"] == [True, True]
+    assert d["parity"]["gathered_rank0_equals_own"] is True
+
+
+def n_gpus():
+    import importlib
+    return importlib.import_module("project-desert-tortoise_amd").lib().pdt_device_count()
+
+
+def test_multi_gpu_bench_over_rccl():
+    """`python bench.py --gpus N` (no launcher) on every GPU of the box: one rank and one capture per GPU, RCCL gather."""
+    n = n_gpus()
+    if n < 2:
+        pytest.skip("one GPU on this box: RCCL with more than one rank cannot run here")
+    d = run_bench("--gpus", str(n), "--steps", "2", "--warmup", "1", "--seconds", "60")
+    assert d["n_gpus"] == n and len(d["per_rank_ms"]) == n
+    assert d["parity"]["frames_equal_transmitted_full_size"] == [True] * n
+
+
+def test_multi_gpu_demodmulti_against_oracle(pdt, orc, tmp_path):
+    """bin/demodMulti -g N on N distinct captures, one per GPU: every output file identical to the oracle's text."""
+    n = n_gpus()
+    if n < 2:
+        pytest.skip("one GPU on this box")
+    caps = []
+    for k in range(n):
+        iq = pdt.synth_capture(0, 250000, 8.0 + k, seed=500 + k)
+        path = tmp_path / f"cap{k}.wav"
+        pdt.write_wav(str(path), 250000, iq)
+        caps.append((str(path), orc.Oracle(orc.POES, 250000, iq).text()))
+    r = subprocess.run([os.path.join(ROOT, "bin", "demodMulti"), "-g", str(n)] + [c[0] for c in caps], capture_output=True, text=True)
+    assert r.returncode == 0, r.stdout + r.stderr
+    for path, want in caps:
+        assert open(path + ".frames.txt", "rb").read() == want

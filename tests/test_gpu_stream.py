@@ -246,3 +246,26 @@ def test_file_ingest_overlapped_with_the_chain(pdt, orc, tmp_path):
             os.environ.pop("PDT_OVERLAP_MIN_MB", None)
             os.environ.pop("PDT_OVERLAP_SEGMENTS", None)
     assert texts[""] == o.text() and texts["3"] == o.text() and texts["7"] == o.text()
+
+
+def test_stage_and_whole_capture_entries_are_refused_while_a_stream_is_open(pdt, clip):
+    """The stage buffers hold the tails an open stream continues from: every pdt_stage_* / pdt_demod_* entry
+    returns PDT_ERR_STATE between the first push and pdt_stream_end, and the stream is not disturbed by the attempt."""
+    rate, iq = clip
+    with pdt.Demodulator(pdt.MODE_POES, rate) as ref:
+        ref.demod(iq)
+        want = ref.frames_array()
+    with pdt.Demodulator(pdt.MODE_POES, rate) as d:
+        parts = [d.stream_push(iq[:60000])]                           # no pdt_stream_begin: the first push opens the stream
+        for call in (lambda: d.demod(iq[:20000]), lambda: d.stage_fir(np.zeros(100, np.float32)),
+                     lambda: d.stage_agc(np.ones(100, np.float32), 1.0), lambda: d.stage_pll(iq[:1000]),
+                     lambda: d.stage_manchester(np.ones(64, np.float32), 1.0), lambda: d.bytesync(np.full(100, 48, np.uint8)),
+                     lambda: d.stage_static_gain(iq[:1000]), lambda: d.stage_squelch(np.ones(8, np.float32), np.ones(8, np.float32), 0.1)):
+            with pytest.raises(pdt.PdtError, match="call sequence"):
+                call()
+        parts.append(d.stream_push(iq[60000:]))
+        parts.append(d.stream_end())
+        assert np.concatenate(parts).tobytes() == want.tobytes()
+        d.demod(iq[:20000])                                           # the stream is over: whole-capture calls work again
+        parts = [d.stream_push(iq[:123456]), d.stream_push(iq[123456:]), d.stream_end()]     # and so does a new stream, without begin
+        assert np.concatenate(parts).tobytes() == want.tobytes()
