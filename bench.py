@@ -130,7 +130,7 @@ def make_capture(pdt, p, n: int, threads: int, device=None, wav_path: str | None
                 d_iq[2 * s0:2 * (s0 + c0)].copy_(tbuf[:2 * c0])
                 torch.cuda.synchronize()
             if f:
-                f.write(memoryview(buf[:c0]).cast("B"))
+                f.write(buf[:c0].reshape(-1).view(np.uint8))
     if f:
         f.close()
     return d_iq
