@@ -159,25 +159,18 @@ def gather_frames(frames: np.ndarray, device):
 
 
 def transmitted_check(pdt, p, frames: np.ndarray, n: int, fs: int) -> dict:
-    """Size-independent property at full size: every complete decoded POES frame is one of the frames the generator
-    transmitted, they are consecutive, and all but the first few (acquisition) arrive."""
+    """Size-independent property at full size: the complete decoded POES frames are frames the generator transmitted, in
+    ascending order, and nearly all of the transmitted ones arrive (the frame during which the PLL locks, and a frame hit by a
+    noise peak once in an hour, may be damaged: at most 0.5 % unmatched)."""
     complete = frames[frames["complete"] == 1]
-    expect = int(n / fs * 10.0)                                          # 10 minor frames per second
-    if len(complete) == 0:
-        return {"ok": False, "complete": 0, "expected_about": expect}
-    first = None
-    head = bytes(complete[0]["bytes"])
     start = int(p.signal_start * 10 // fs)
-    for k in range(start, start + 64):
-        if bytes(pdt.synth_poes_frame(p, k)) == head:
-            first = k
-            break
-    if first is None:
-        return {"ok": False, "complete": int(len(complete)), "expected_about": expect - start, "why": "first frame unknown"}
-    sent = np.stack([pdt.synth_poes_frame(p, first + i) for i in range(len(complete))])
-    same = bool(np.array_equal(sent, complete["bytes"]))
-    return {"ok": same and len(complete) >= expect - start - 12, "complete": int(len(complete)), "first_frame": first,
-            "expected_about": expect - start}
+    expect = int(n / fs * 10.0) - start                                  # 10 minor frames per second of signal
+    sent = {bytes(pdt.synth_poes_frame(p, k)): k for k in range(start, start + expect + 2)}
+    idx = [sent.get(bytes(b)) for b in complete["bytes"]]
+    got = [k for k in idx if k is not None]
+    ok = (len(got) >= expect - 12 and len(idx) - len(got) <= max(2, len(idx) // 200)
+          and all(b > a for a, b in zip(got, got[1:])))
+    return {"ok": bool(ok), "complete": int(len(complete)), "matched": len(got), "expected_about": expect}
 
 
 # Algorithmic bytes per step of each kernel group (SURVEY 8d; DESIGN.md section 4): what the group must read
@@ -451,7 +444,7 @@ def run(args, pdt, torch, dist, rank, local, world, dev, cdev, cfg, kind, fs, se
         if kind == 0 and CONFIGS[cfg][5] == 1.0:                          # (a weak signal loses frames: the CPU sample is its gate)
             tx = [transmitted_check(pdt, capture_params(pdt, cfg, 1234 + r), gathered[r], n, fs) for r in range(world)]
             parity["frames_equal_transmitted_full_size"] = [t["ok"] for t in tx]
-            parity["frames_complete"] = [t.get("complete", 0) for t in tx]
+            parity["frames_complete_matched_expected"] = [[t["complete"], t["matched"], t["expected_about"]] for t in tx]
             if world > 1:
                 parity["gathered_rank0_equals_own"] = bool(pdt.format_frames(gathered[0]) == gpu_text)
         if legs:
