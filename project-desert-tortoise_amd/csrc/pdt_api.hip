@@ -238,7 +238,7 @@ struct Plan {
 // context is opened; the demodulation calls never look at the environment.
 struct Tuning {
     double band_pad = 0.0, pll_warm_scale = 1.0, head_taus = 0.0, agc_k = 0.0, pll_warm_s = 0.0, agc_warm_s = 0.0;
-    int scout_syms = 0, ingest_threads = 0, ingest_span_mb = 0, ingest_streams = 0, overlap_segments = 0, overlap_min_mb = 0, fir_wg_per_cu = 0, agc_tpb = 0, gseg = 0, acquire_mode = 0, pll_block = 0, fix_passes = 2;      // acquire_mode: 0 = two-wavefront pipeline, 1 = plain one-lane, 2 = one wavefront
+    int scout_syms = 0, gspan = 0, ingest_threads = 0, ingest_span_mb = 0, ingest_streams = 0, overlap_segments = 0, overlap_min_mb = 0, fir_wg_per_cu = 0, agc_tpb = 0, gseg = 0, acquire_mode = 0, pll_block = 0, fix_passes = 2;      // acquire_mode: 0 = two-wavefront pipeline, 1 = plain one-lane, 2 = one wavefront
     bool fir_generic = false, agc_unfused = false, no_excl = false, gtab_nomerge = false, gardner_onebuf = false, gardner_noring = false, gardner_sequential = false, seg_sequential = false, no_overlap = false, debug_overlap = false, chain_one_range = false, ema_noguess = false, debug_sync = false;
     void load()
     {
@@ -257,6 +257,7 @@ struct Tuning {
         if (const char *e = getenv("PDT_INGEST_STREAMS")) ingest_streams = std::min(4, std::max(1, atoi(e)));
         if (const char *e = getenv("PDT_FIX_PASSES")) fix_passes = atoi(e);
         if (const char *e = getenv("PDT_GSEG")) gseg = std::min(64, std::max(2, atoi(e)));
+        if (const char *e = getenv("PDT_GSPAN")) gspan = std::min(256, std::max(1, atoi(e)));
         if (getenv("PDT_ACQUIRE_SIMPLE")) acquire_mode = 1;
         else if (getenv("PDT_ACQUIRE_ONEWAVE")) acquire_mode = 2;
         fir_generic = getenv("PDT_FIR_GENERIC") != nullptr;
@@ -1225,7 +1226,7 @@ template <typename T> int run_capture(pdt_ctx *ctx, uint64_t n, int phase = RUN_
     const bool use_mm = ctx->cfg.sampler == PDT_SAMPLER_MM;
     bool use_table = false;
     GardnerDomain GD;
-    GD.q_min = 0; GD.u = 0; GD.n_q = 0; GD.n_cand = 0; GD.pad_q = 0; GD.idx_bits = 20;
+    GD.q_min = 0; GD.u = 0; GD.n_q = 0; GD.n_cand = 0; GD.pad_q = 0; GD.idx_bits = 20; GD.span = 1;
     if constexpr (std::is_same<T, float>::value) {
         const int table_len = 1 << 22;     // the table kernel walks the chunk in LDS windows: no size limit of its own
         const float nT = (float)chunk_out, stepf = (float)GP.step;
@@ -1251,6 +1252,16 @@ template <typename T> int run_capture(pdt_ctx *ctx, uint64_t n, int phase = RUN_
                 GD.idx_bits = idx_bits;
                 const double pad = ctx->cfg.gardner_band_pad > 0 ? ctx->cfg.gardner_band_pad : (ctx->tune.band_pad > 0 ? ctx->tune.band_pad : 1.0 / 8.0);
                 GD.pad_q = std::max(2, (int)(pad / (double)u));
+                // Chunks per table row.  Many short chunks (an hour at 250 ksps: 90 000 of 666 symbols): the candidates of a chunk
+                // merge onto a handful of trajectories within it, so boundary states are tabulated in front of every span-th chunk
+                // only and the few distinct exits of a row's first chunk are walked on through the others (k_gardner_span):
+                // scouts, candidate walks and chain hops per span chunks instead of per chunk.  A row's symbol count must fit
+                // the table cell.  Stream segments keep one chunk per row (they are short, and enter with a carried state).
+                int span = ctx->tune.gspan > 0 ? ctx->tune.gspan : ((!seg && n_chunks >= 4096) ? 16 : 1);
+                if (seg) span = 1;
+                while (span > 1 && ((double)span * max_count >= (double)((1u << (32 - idx_bits)) - 2u) || (n_chunks - 1) / span < 4))
+                    span /= 2;
+                GD.span = span;
             }
         }
     }
@@ -1312,7 +1323,8 @@ template <typename T> int run_capture(pdt_ctx *ctx, uint64_t n, int phase = RUN_
                 HIP_TRY(hipStreamSynchronize(st));              // the host vectors die at the end of this scope
                 ctx->gcand_key = key;
             }
-            const long long n_tab = n_chunks - 1;
+            const long long n_tab = (n_chunks - 1) / GD.span;        // table rows: groups of span full chunks that have a successor
+            const long long n_groups = n_tab + 1;                    // ... and the group behind the last row (<= span chunks, the last may be short)
             SamplerCarry<float> tab_carry;                   // where the chain starts: chunk, state, symbols already in the buffer
             tab_carry.a = (float)carry_in.a; tab_carry.b = (float)carry_in.b; tab_carry.c = (float)carry_in.c;
             tab_carry.c_first = carry_in.c_first; tab_carry.count0 = carry_in.count0;
@@ -1343,34 +1355,38 @@ template <typename T> int run_capture(pdt_ctx *ctx, uint64_t n, int phase = RUN_
                                        (const GardnerBand *)ctx->gbands.p, (const unsigned *)ctx->gclist.p,
                                        (unsigned *)ctx->gtable.p, d_sc->gstats);
                 }
+                if (GD.span > 1)
+                    PDT_LAUNCH(64, (k_gardner_span<PDT_GTAB_WIN>), dim3((unsigned)n_tab), dim3(64), 0, st, (const float *)d_agc, GP, GD, n_tab,
+                                       (const unsigned *)ctx->gcand.p, (const GardnerBand *)ctx->gbands.p, (const unsigned *)ctx->gclist.p,
+                                       (unsigned *)ctx->gtable.p, d_sc->gstats);
             }
             L.end();
             // chunks per chain segment: the chain hops one segment per ~1 us of dependent L2 look-ups, the composite maps and
             // the re-trace of a segment take G such look-ups each but run in parallel over the segments
             // (at most 64: k_gardner_segfill re-traces a segment with one lane per chunk)
-            int G = (n_chunks < 8000) ? 32 : 64;
+            int G = (n_groups < 8000) ? 32 : 64;
             if (ctx->tune.gseg) G = ctx->tune.gseg;
-            const long long n_seg = (n_chunks + G - 1) / G;
+            const long long n_seg = (n_groups + G - 1) / G;
             if ((rc = ctx->gsegmap.ensure((size_t)n_seg * (size_t)(2 * GD.n_q) * sizeof(GardnerSegCell)))) return rc;
             if ((rc = ctx->gsegstart.ensure((size_t)n_seg * sizeof(GardnerSegStart)))) return rc;
             L.begin("gardner_chain");
             PL.memset_async(ctx->gsegstart.p, 0, (size_t)n_seg * sizeof(GardnerSegStart));
-            PDT_LAUNCH(1024, k_gardner_segmap, dim3((unsigned)n_seg), dim3(1024), 0, st, (const unsigned *)ctx->gtable.p, GD, n_chunks,
+            PDT_LAUNCH(1024, k_gardner_segmap, dim3((unsigned)n_seg), dim3(1024), 0, st, (const unsigned *)ctx->gtable.p, GD, n_groups,
                                G, (GardnerSegCell *)ctx->gsegmap.p, (const GardnerBand *)ctx->gbands.p);
             // Long captures: the chain runs range by range; as soon as a range is through, its entry states and symbols are produced
             // on the side stream (segfill, emission -- chip-wide kernels) while the single workgroup of the chain hops on
             // (an hour at 250 ksps: chain 1.6 ms + emission 1.8 ms one after the other -> the emission behind the chain).
-            const int n_ranges = (!seg && n_chunks >= 8192 && !ctx->tune.chain_one_range) ? 4 : 1;
+            const int n_ranges = (!seg && n_groups >= 8192 && !ctx->tune.chain_one_range) ? 4 : 1;
             if ((rc = ctx->gchain.ensure(sizeof(GardnerChainState)))) return rc;
             const bool side = n_ranges > 1;
             hipStream_t st_emit = side ? ctx->stream2 : st;
             L.end();
             long long c_lo = 0;
             for (int r = 0; r < n_ranges; r++) {
-                const long long c_hi = (r == n_ranges - 1) ? n_chunks : (n_chunks * (r + 1) / n_ranges) / G * G;
+                const long long c_hi = (r == n_ranges - 1) ? n_groups : (n_groups * (r + 1) / n_ranges) / G * G;      // (groups)
                 L.begin("gardner_chain");
                 PDT_LAUNCH(256, k_gardner_chain, dim3(1), dim3(256), 0, st,      // 4 wavefronts: a walked chunk is staged 4x faster
-                                   (const float *)d_agc, GP, GD, n_chunks,
+                                   (const float *)d_agc, GP, GD, n_groups,
                                    (const unsigned *)ctx->gtable.p, (const GardnerSegCell *)ctx->gsegmap.p, G,
                                    (GardnerSegStart *)ctx->gsegstart.p, (GardnerEntry<float> *)ctx->gentries.p, d_sc->gstats,
                                    (const GardnerBand *)ctx->gbands.p, n_tab, tab_carry, (seg && seg->have_sampler) ? 1 : 0, c_hi,
@@ -1380,14 +1396,14 @@ template <typename T> int run_capture(pdt_ctx *ctx, uint64_t n, int phase = RUN_
                 const long long s_lo = c_lo / G, s_hi = (c_hi + G - 1) / G;
                 L.begin("gardner", st_emit);
                 if (s_hi > s_lo)
-                    PDT_LAUNCH(64, k_gardner_segfill, dim3((unsigned)(s_hi - s_lo)), dim3(64), 0, st_emit, (const float *)d_agc, GP, GD, n_chunks,
+                    PDT_LAUNCH(64, k_gardner_segfill, dim3((unsigned)(s_hi - s_lo)), dim3(64), 0, st_emit, (const float *)d_agc, GP, GD, n_groups,
                                        (const unsigned *)ctx->gtable.p, G, (const GardnerSegStart *)ctx->gsegstart.p,
                                        (GardnerEntry<float> *)ctx->gentries.p, s_lo);
                 // per-chunk emission: small LDS windows so that every chunk of a 10-minute capture is resident at once
                 if (c_hi > c_lo)
                     PDT_LAUNCH(256, (k_gardner<float, PDT_GEMIT_LEN, PDT_GEMIT_OUT>), dim3((unsigned)(c_hi - c_lo)), dim3(PDT_GARDNER_THREADS), 0, st_emit,
                                        (const float *)d_agc, (const float *)d_lock, GP, (float *)d_sym, d_symidx, &d_sc->nsym, sym_cap,
-                                       (const GardnerEntry<float> *)ctx->gentries.p, tab_carry, (SamplerCarry<float> *)d_carry_out, c_lo);
+                                       (const GardnerEntry<float> *)ctx->gentries.p, tab_carry, (SamplerCarry<float> *)d_carry_out, c_lo, GD.span);
                 L.end();
                 c_lo = c_hi;
             }
@@ -1434,7 +1450,7 @@ template <typename T> int run_capture(pdt_ctx *ctx, uint64_t n, int phase = RUN_
                                d_sym, d_symidx, &d_sc->nsym, sym_cap);
         else
             PDT_LAUNCH(256, (k_gardner<T, GardnerLds<T>::LEN, GardnerLds<T>::OUT>), dim3(1), dim3(256), 0, st, d_agc, d_lock, GP, d_sym, d_symidx,
-                               &d_sc->nsym, sym_cap, (const GardnerEntry<T> *)nullptr, carry_in, d_carry_out, 0ll);
+                               &d_sc->nsym, sym_cap, (const GardnerEntry<T> *)nullptr, carry_in, d_carry_out, 0ll, 1);
         L.end();
     }
 
@@ -2613,7 +2629,7 @@ template <typename T> static int stage_gardner(pdt_ctx *ctx, const void *in_host
     }
     PDT_LAUNCH(256, (k_gardner<T, GardnerLds<T>::LEN, GardnerLds<T>::OUT>), dim3(1), dim3(256), 0, st, (const T *)d_in,
                (const T *)(GP.argos_heap ? d_nb : nullptr), GP, (T *)ctx->sym.p, (long long *)ctx->symidx.p, &d_sc->nsym, sym_cap,
-               (const GardnerEntry<T> *)nullptr, carry_in, &d_tail->sampler, 0ll);
+               (const GardnerEntry<T> *)nullptr, carry_in, &d_tail->sampler, 0ll, 1);
     DevScalars *back = ctx->pend_sc;                                  // pinned
     PL.copy(OP_D2H, back, d_sc, sizeof(DevScalars));
     {

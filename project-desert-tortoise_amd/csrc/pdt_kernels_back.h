@@ -291,7 +291,8 @@ __device__ __forceinline__ void k_gardner(const T *__restrict__ in, const T *__r
                                                                   long long sym_cap,
                                                                   const GardnerEntry<T> *__restrict__ entries,
                                                                   SamplerCarry<T> carry, SamplerCarry<T> *__restrict__ carry_out,
-                                                                  long long c_off /* parallel mode: chunk of block 0 */)
+                                                                  long long c_off /* parallel mode: group of block 0 */,
+                                                                  int span /* parallel mode: chunks per group (entries are per group); otherwise 1 */)
 {
     __shared__ T win[LEN];
     __shared__ T o_val[OUT];
@@ -303,10 +304,11 @@ __device__ __forceinline__ void k_gardner(const T *__restrict__ in, const T *__r
     long long count = carry.count0;
     long long c_begin = carry.c_first, c_end = n_chunks;
     if (entries) {
-        c_begin = blockIdx.x + c_off;
-        c_end = c_begin + 1;
+        const long long g = blockIdx.x + c_off;
+        c_begin = g * span;
+        c_end = (c_begin + span < n_chunks) ? c_begin + span : n_chunks;
         if (c_begin >= n_chunks || c_begin < carry.c_first) return;      // (a stream segment: the chunks in front are history)
-        const GardnerEntry<T> e = entries[c_begin];
+        const GardnerEntry<T> e = entries[g];
         S.ns = e.ns;
         S.prev = e.prev;
         S.half = e.half;
@@ -883,6 +885,8 @@ struct GardnerDomain {
     int n_cand;        // consistent (q, pick) combinations, listed in cand_k in increasing q
     int pad_q;         // candidates are tabulated within this many grid points of a scout's end point
     int idx_bits;      // table cell = candidate index (low idx_bits bits) | symbol count of the chunk (the rest)
+    int span;          // chunks per table row: boundary states are tabulated in front of every span-th chunk only (row r =
+                       // chunks [r span, (r + 1) span): entry key -> exit key after the last of them | symbols of all of them)
 };
 
 #ifndef PDT_GTAB_TAIL
@@ -984,8 +988,9 @@ __device__ __forceinline__ void k_gardner_scout(const float *__restrict__ in, Ga
 {
     __shared__ float tail[PDT_GTAB_TAIL];
     __shared__ int s_sorted[64], s_lo[64], s_hi[64], s_off[65];
-    const long long c = blockIdx.x;
-    if (c >= n_tab_chunks) return;
+    const long long r = blockIdx.x;                              // table row; its first chunk:
+    const long long c = r * D.span;
+    if (r >= n_tab_chunks) return;
     const long long C = P.chunk_out;
     const long long base = c * C;
     const int n_cur = (int)C;
@@ -1066,7 +1071,7 @@ __device__ __forceinline__ void k_gardner_scout(const float *__restrict__ in, Ga
         __syncthreads();
         const int total = s_off[64];
         if (locked && total <= PDT_GTAB_LIST) {
-            unsigned *mylist = clist + (size_t)c * PDT_GTAB_LIST;
+            unsigned *mylist = clist + (size_t)r * PDT_GTAB_LIST;
             for (int j = 0; j < 64; j++) {
                 const int nj = s_hi[j];
                 if (nj == 0) continue;
@@ -1082,25 +1087,20 @@ __device__ __forceinline__ void k_gardner_scout(const float *__restrict__ in, Ga
             for (int j = 0; j < 64; j++) last = (s_hi[j] > 0) ? j : last;
             bd.k_lo = cand_k[s_lo[0]];
             bd.k_hi = cand_k[s_lo[last] + s_hi[last] - 1];
-            unsigned *row = table + (size_t)c * (size_t)(2 * D.n_q);
+            unsigned *row = table + (size_t)r * (size_t)(2 * D.n_q);
             for (unsigned k = bd.k_lo + (unsigned)lane; k <= bd.k_hi; k += 64u) row[k] = PDT_GTAB_MISS;
         }
     }
     // (no global counters here: 3 000 atomics on one address drained for 0.1 ms after the last wavefront had finished;
     // k_gardner_chain sums the candidates and the full-domain chunks from the bands)
-    if (lane == 0) bands[c] = bd;
+    if (lane == 0) bands[r] = bd;
 }
 
-// level 1: block (c, p) runs slice p (2 x THREADS candidates) of chunk c's candidate list, window by
-// window (WIN floats of LDS at a time).  A lane carries NL = 1 or 2 interleaved trajectories (one when
-// the slice holds no more candidates than threads: half the instructions).  All lanes are within a
-// symbol of each other, so they cross the window seams together; inside a window every trajectory
-// takes at least k_min steps before it can reach the stop point (a step advances by at most
-// step + 0.1), so the bulk of the walk is a counted, wave-uniform loop without any per-lane test.
+// walk chunk c (a full one) with the NL trajectories every lane carries, window by window, up to the chunk's end (the roll-over
+// of the sampling instant is left to the caller).  The symbol counts go on from what they are.
 template <int THREADS, int WIN, int NL>
-__device__ __forceinline__ void gardner_table_block(float *win, const float *__restrict__ in, const GardnerParams<float> &P,
-                                                    const GardnerDomain &D, long long c, const unsigned *__restrict__ cand,
-                                                    int j0, int j_hi, unsigned *__restrict__ row, unsigned *__restrict__ stats)
+__device__ __forceinline__ void gardner_lanes_chunk(float *win, const float *__restrict__ in, const GardnerParams<float> &P,
+                                                    long long c, GardnerLane (&L)[NL])
 {
     const long long C = P.chunk_out;
     const long long base = c * C;
@@ -1109,31 +1109,9 @@ __device__ __forceinline__ void gardner_table_block(float *win, const float *__r
     const float kp = P.kp, lim = P.lim, step = P.step, nT = (float)n_cur;
     const int margin = 2 * (int)step + 24;          // look-ahead the staged data must cover past a stop point
     const int back = (int)step + 8;                 // a mid-point lies at most this far behind a stop point
-
-    GardnerLane L[NL];
-#pragma unroll
-    for (int l = 0; l < NL; l++) {
-        L[l].ns = L[l].prev = L[l].half = L[l].q_last = 0;
-        L[l].i_last = L[l].count = 0;
-        L[l].k = 0;
-        L[l].active = (j0 + l * THREADS + (int)threadIdx.x) < j_hi;
-        if (L[l].active && c >= 1) {
-            L[l].k = (int)cand[j0 + l * THREADS + threadIdx.x];
-            gardner_entry_from_candidate(in, P, D, c, L[l].k, L[l].ns, L[l].prev, L[l].half);
-        }
-    }
-    // idle slots shadow an active one of the block (their results are discarded) so that every lane
-    // stays inside the staged windows
-    {
-        __shared__ float s_ref[3];
-        if (threadIdx.x == 0) { s_ref[0] = L[0].ns; s_ref[1] = L[0].prev; s_ref[2] = L[0].half; }
-        __syncthreads();
-#pragma unroll
-        for (int l = 0; l < NL; l++)
-            if (!L[l].active) { L[l].ns = s_ref[0]; L[l].prev = s_ref[1]; L[l].half = s_ref[2]; }
-    }
     int wbase = 0;
     float enter_hi = step + 1.2f;                 // upper bound of ns when entering the window
+    bool all_started = true;
     for (;;) {
         // stage [wbase, wbase + WIN)
         __syncthreads();
@@ -1181,13 +1159,11 @@ __device__ __forceinline__ void gardner_table_block(float *win, const float *__r
                     L[l].ns = L[l].ns + step;
                     L[l].prev = cur;
                     L[l].i_last = i_cur;
-                    L[l].count = 1;
-                }
+                    L[l].count += 1;
+                } else
+                    all_started = false;
             }
         }
-        bool all_started = true;
-#pragma unroll
-        for (int l = 0; l < NL; l++) all_started = all_started && (L[l].count >= 1);
         if (all_started) {
             int k_min = (int)((stop - 4.0f - enter_hi) / (step + 0.101f)) - 1;
             if (k_min < 0) k_min = 0;
@@ -1205,6 +1181,42 @@ __device__ __forceinline__ void gardner_table_block(float *win, const float *__r
         enter_hi = stop + step + 1.2f;
         wbase = wend - margin - back;
     }
+}
+
+// level 1: block (r, p) runs slice p (2 x THREADS candidates) of row r's candidate list through the row's first chunk, window by
+// window (WIN floats of LDS at a time).  A lane carries NL = 1 or 2 interleaved trajectories (one when
+// the slice holds no more candidates than threads: half the instructions).  All lanes are within a
+// symbol of each other, so they cross the window seams together; inside a window every trajectory
+// takes at least k_min steps before it can reach the stop point (a step advances by at most
+// step + 0.1), so the bulk of the walk is a counted, wave-uniform loop without any per-lane test.
+template <int THREADS, int WIN, int NL>
+__device__ __forceinline__ void gardner_table_block(float *win, const float *__restrict__ in, const GardnerParams<float> &P,
+                                                    const GardnerDomain &D, long long c, const unsigned *__restrict__ cand,
+                                                    int j0, int j_hi, unsigned *__restrict__ row, unsigned *__restrict__ stats)
+{
+    GardnerLane L[NL];
+#pragma unroll
+    for (int l = 0; l < NL; l++) {
+        L[l].ns = L[l].prev = L[l].half = L[l].q_last = 0;
+        L[l].i_last = L[l].count = 0;
+        L[l].k = 0;
+        L[l].active = (j0 + l * THREADS + (int)threadIdx.x) < j_hi;
+        if (L[l].active && c >= 1) {
+            L[l].k = (int)cand[j0 + l * THREADS + threadIdx.x];
+            gardner_entry_from_candidate(in, P, D, c, L[l].k, L[l].ns, L[l].prev, L[l].half);
+        }
+    }
+    // idle slots shadow an active one of the block (their results are discarded) so that every lane
+    // stays inside the staged windows
+    {
+        __shared__ float s_ref[3];
+        if (threadIdx.x == 0) { s_ref[0] = L[0].ns; s_ref[1] = L[0].prev; s_ref[2] = L[0].half; }
+        __syncthreads();
+#pragma unroll
+        for (int l = 0; l < NL; l++)
+            if (!L[l].active) { L[l].ns = s_ref[0]; L[l].prev = s_ref[1]; L[l].half = s_ref[2]; }
+    }
+    gardner_lanes_chunk<THREADS, WIN, NL>(win, in, P, c, L);
 #pragma unroll
     for (int l = 0; l < NL; l++) {
         if (L[l].active) {
@@ -1225,14 +1237,15 @@ __device__ __forceinline__ void k_gardner_table(const float *__restrict__ in, Ga
                                                             unsigned *__restrict__ stats /* [0] bad */)
 {
     __shared__ float win[WIN];
-    const long long c = blockIdx.x;                 // chunk (always a full one)
-    if (c >= n_tab_chunks) return;
-    const GardnerBand bd = bands[c];
+    const long long r = blockIdx.x;                 // table row
+    if (r >= n_tab_chunks) return;
+    const long long c = r * D.span;                 // its first chunk (always a full one)
+    const GardnerBand bd = bands[r];
     const int j0 = bd.j_lo + (int)blockIdx.y * 2 * THREADS;
     const int j_hi = bd.j_hi;
     if (j0 >= j_hi) return;
     const unsigned *cand = bd.listed ? (clist + (size_t)blockIdx.x * PDT_GTAB_LIST) : cand_k;
-    unsigned *row = table + (size_t)c * (size_t)(2 * D.n_q);
+    unsigned *row = table + (size_t)r * (size_t)(2 * D.n_q);
     if (j_hi - j0 <= THREADS) gardner_table_block<THREADS, WIN, 1>(win, in, P, D, c, cand, j0, j_hi, row, stats);
     else gardner_table_block<THREADS, WIN, 2>(win, in, P, D, c, cand, j0, j_hi, row, stats);
 }
@@ -1270,14 +1283,15 @@ __device__ __forceinline__ void k_gardner_table_merge(const float *__restrict__ 
     unsigned *x_il = reinterpret_cast<unsigned *>(win + 5 * PDT_GTM_SLOTS);
     unsigned *htab = reinterpret_cast<unsigned *>(win + 6 * PDT_GTM_SLOTS);
 
-    const long long c = blockIdx.x;                 // chunk (always a full one)
-    if (c >= n_tab_chunks) return;
-    const GardnerBand bd = bands[c];
+    const long long r = blockIdx.x;                 // table row
+    if (r >= n_tab_chunks) return;
+    const long long c = r * D.span;                 // its first chunk (always a full one)
+    const GardnerBand bd = bands[r];
     const int j0 = bd.j_lo + (int)blockIdx.y * PDT_GTM_SLOTS;
     const int j_hi = bd.j_hi;
     if (j0 >= j_hi) return;
     const unsigned *cand = bd.listed ? (clist + (size_t)blockIdx.x * PDT_GTAB_LIST) : cand_k;
-    unsigned *row = table + (size_t)c * (size_t)(2 * D.n_q);
+    unsigned *row = table + (size_t)r * (size_t)(2 * D.n_q);
     const int tid = threadIdx.x;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const long long C = P.chunk_out;
@@ -1505,6 +1519,110 @@ __device__ __forceinline__ void k_gardner_table_merge(const float *__restrict__ 
     }
 }
 
+// Rows that span several chunks (D.span > 1).  k_gardner_table* has filled row r with the exits of the row's FIRST chunk.  The
+// candidates of a chunk collapse onto a handful of trajectories, so those cells hold only a few distinct exit keys: one
+// wavefront per row walks each distinct one on through the other span - 1 chunks (one lane each, every float operation that of
+// the sequential loop, the roll-over at every chunk end included) and rewrites the row's cells as
+// exit key after the row's last chunk | symbols of all its chunks.  Scouts and candidate walks are then needed in front of every
+// span-th chunk only, and the chain hops span chunks per look-up.
+// The cells are taken in key order, 64 at a time, until the set of distinct exits holds more than 64 keys; those are walked and
+// the cells seen so far rewritten, then the sweep goes on (a later cell whose exit was already walked is walked again: rare).
+#define PDT_GSPAN_KEYS 128
+#define PDT_GSPAN_HASH 256
+template <int WIN>
+__device__ __forceinline__ void k_gardner_span(const float *__restrict__ in, GardnerParams<float> P, GardnerDomain D,
+                                               long long n_rows, const unsigned *__restrict__ cand_k,
+                                               const GardnerBand *__restrict__ bands, const unsigned *__restrict__ clist,
+                                               unsigned *__restrict__ table, unsigned *__restrict__ stats /* [0] bad */)
+{
+    __shared__ __attribute__((aligned(16))) float win[WIN];
+    __shared__ unsigned s_key[PDT_GSPAN_KEYS], s_cell[PDT_GSPAN_KEYS], s_hash[PDT_GSPAN_HASH], s_hidx[PDT_GSPAN_HASH];
+    __shared__ unsigned s_n;
+    __shared__ float s_ref[3];
+    const long long r = blockIdx.x;
+    if (r >= n_rows || D.span <= 1) return;
+    const long long c0 = r * D.span;
+    const GardnerBand bd = bands[r];
+    const unsigned *cand = bd.listed ? (clist + (size_t)r * PDT_GTAB_LIST) : cand_k;
+    unsigned *row = table + (size_t)r * (size_t)(2 * D.n_q);
+    const int lane = threadIdx.x;
+    const unsigned kmask = (1u << D.idx_bits) - 1u;
+    const float nT = (float)P.chunk_out;
+    int pos = bd.j_lo;                                     // position in the row's candidate list
+    while (pos < bd.j_hi) {
+        // ---- the next cells' distinct exit keys
+        __syncthreads();
+        for (int t = lane; t < PDT_GSPAN_HASH; t += 64) s_hash[t] = 0xffffffffu;
+        if (lane == 0) s_n = 0;
+        __syncthreads();
+        int pos2 = pos;
+        for (;;) {
+            const int j = pos2 + lane;
+            unsigned cell = PDT_GTAB_MISS;
+            if (j < bd.j_hi) cell = row[(c0 == 0) ? 0u : cand[j]];          // (chunk 0: the single start state is cell 0)
+            if (cell != PDT_GTAB_MISS) {
+                const unsigned key = cell & kmask;
+                unsigned h = (key * 2654435761u) >> 24;          // 8 bits
+                for (;;) {
+                    const unsigned old = atomicCAS(&s_hash[h], 0xffffffffu, key);
+                    if (old == 0xffffffffu) {
+                        const unsigned idx = atomicAdd(&s_n, 1u);
+                        s_key[idx] = key;
+                        s_hidx[h] = idx;
+                        break;
+                    }
+                    if (old == key) break;
+                    h = (h + 1) & (PDT_GSPAN_HASH - 1);
+                }
+            }
+            __syncthreads();
+            pos2 += 64;
+            const unsigned n_now = s_n;
+            __syncthreads();
+            if (pos2 >= bd.j_hi || n_now + 64u > PDT_GSPAN_KEYS) break;
+        }
+        const int n_keys = (int)s_n;
+        // ---- walk them through chunks c0 + 1 .. c0 + span - 1, 64 at a time
+        for (int k0 = 0; k0 < n_keys; k0 += 64) {
+            GardnerLane L[1];
+            L[0].q_last = 0; L[0].i_last = 0; L[0].count = 0; L[0].k = 0;
+            L[0].active = (k0 + lane) < n_keys;
+            L[0].ns = L[0].prev = L[0].half = 0;
+            if (L[0].active) gardner_entry_from_candidate(in, P, D, c0 + 1, (int)s_key[k0 + lane], L[0].ns, L[0].prev, L[0].half);
+            __syncthreads();
+            if (lane == 0) { s_ref[0] = L[0].ns; s_ref[1] = L[0].prev; s_ref[2] = L[0].half; }
+            __syncthreads();
+            if (!L[0].active) { L[0].ns = s_ref[0]; L[0].prev = s_ref[1]; L[0].half = s_ref[2]; }   // idle lanes shadow lane 0
+            for (int g = 1; g < D.span; g++) {
+                gardner_lanes_chunk<64, WIN, 1>(win, in, P, c0 + g, L);
+                if (g + 1 < D.span) L[0].ns = L[0].ns - nT;           // roll over; `half` is deliberately not (Q3)
+            }
+            if (L[0].active) s_cell[k0 + lane] = gardner_encode_exit(D, L[0].q_last, L[0].i_last, L[0].count);
+        }
+        __syncthreads();
+        // ---- rewrite the cells of positions [pos, pos2)
+        for (int j = pos + lane; j < pos2 && j < bd.j_hi; j += 64) {
+            const unsigned k = (c0 == 0) ? 0u : cand[j];
+            const unsigned cell = row[k];
+            if (cell == PDT_GTAB_MISS) continue;
+            const unsigned key = cell & kmask;
+            unsigned h = (key * 2654435761u) >> 24;
+            int probes = 0;
+            while (s_hash[h] != key && probes < PDT_GSPAN_HASH) { h = (h + 1) & (PDT_GSPAN_HASH - 1); probes++; }
+            if (probes >= PDT_GSPAN_HASH) continue;                    // (cannot happen: every listed cell was hashed above)
+            const unsigned tail = s_cell[s_hidx[h]];
+            unsigned out = PDT_GTAB_MISS;
+            if (tail != PDT_GTAB_MISS) {
+                const unsigned cnt = (cell >> D.idx_bits) + (tail >> D.idx_bits);
+                if (cnt < (1u << (32 - D.idx_bits)) - 1u) out = (tail & kmask) | (cnt << D.idx_bits);
+            }
+            if (out == PDT_GTAB_MISS) atomicAdd(&stats[0], 1u);
+            row[k] = out;
+        }
+        pos = pos2;
+    }
+}
+
 __device__ __forceinline__ unsigned gardner_cell(const unsigned *__restrict__ table, size_t stride, const GardnerBand &b,
                                                  long long c, unsigned key)
 {
@@ -1525,13 +1643,14 @@ __device__ __forceinline__ unsigned gardner_cell(const unsigned *__restrict__ ta
 struct GardnerSegCell { unsigned next, count; };
 struct GardnerSegStart { unsigned key; unsigned hopped; long long offset; };
 
-__device__ __forceinline__ void k_gardner_segmap(const unsigned *__restrict__ table, GardnerDomain D, long long n_chunks,
+__device__ __forceinline__ void k_gardner_segmap(const unsigned *__restrict__ table, GardnerDomain D, long long n_groups,
                                                           int G, GardnerSegCell *__restrict__ segmap,
                                                           const GardnerBand *__restrict__ bands)
 {
+    // (everything here is in units of table rows = groups of D.span chunks; n_groups = rows + 1, the last group has no row)
     const long long s = blockIdx.x;
     const long long c0 = s * G;
-    if (c0 + G > n_chunks - 1) return;                  // only whole segments whose chunks all have a table row
+    if (c0 + G > n_groups - 1) return;                  // only whole segments whose groups all have a table row
     const size_t stride = (size_t)(2 * D.n_q);
     __shared__ unsigned s_klo[64], s_khi[64];
     if ((int)threadIdx.x < G) {
@@ -1567,7 +1686,7 @@ struct GardnerChainState {
 };
 
 __device__ __forceinline__ void k_gardner_chain(const float *__restrict__ in, GardnerParams<float> P,
-                                                                        GardnerDomain D, long long n_chunks,
+                                                                        GardnerDomain D, long long n_chunks /* groups of D.span chunks: `chunk` below = group */,
                                                                         const unsigned *__restrict__ table,
                                                                         const GardnerSegCell *__restrict__ segmap, int G,
                                                                         GardnerSegStart *__restrict__ segstart,
@@ -1634,7 +1753,7 @@ __device__ __forceinline__ void k_gardner_chain(const float *__restrict__ in, Ga
             }
         }
         // ---- one chunk
-        if (have_key && c >= 1) gardner_entry_from_candidate(in, P, D, c, (int)key, S.ns, S.prev, S.half);
+        if (have_key && c >= 1) gardner_entry_from_candidate(in, P, D, c * D.span, (int)key, S.ns, S.prev, S.half);
         if (threadIdx.x == 0) {
             GardnerEntry<float> e;
             e.ns = S.ns; e.prev = S.prev; e.half = S.half; e.offset = off;
@@ -1644,8 +1763,10 @@ __device__ __forceinline__ void k_gardner_chain(const float *__restrict__ in, Ga
         unsigned cell = have_key ? gardner_cell(table, stride, bands[c], c, key) : PDT_GTAB_MISS;
         cell = uniform<unsigned>(cell);
         if (cell == PDT_GTAB_MISS) {
-            const long long cnt = gardner_walk_chunk<float, false, GardnerLds<float>::LEN, GardnerLds<float>::OUT>(
-                in, (const float *)nullptr, P, c, S, win, (float *)nullptr, (unsigned *)nullptr, (float *)nullptr, (long long *)nullptr, 0, 0);
+            long long cnt = 0;                               // (a group that has a successor consists of full chunks)
+            for (long long cc = c * D.span; cc < (c + 1) * D.span; cc++)
+                cnt += gardner_walk_chunk<float, false, GardnerLds<float>::LEN, GardnerLds<float>::OUT>(
+                    in, (const float *)nullptr, P, cc, S, win, (float *)nullptr, (unsigned *)nullptr, (float *)nullptr, (long long *)nullptr, 0, 0);
             walked++;
             cell = gardner_encode_exit(D, S.q_last, S.i_last, (unsigned)cnt);
             if (cell == PDT_GTAB_MISS) {
@@ -1701,7 +1822,7 @@ __device__ __forceinline__ void k_gardner_segfill(const float *__restrict__ in, 
         const long long c = c0 + g;
         GardnerEntry<float> e;
         e.ns = 0; e.prev = 0; e.half = 0;
-        if (c >= 1) gardner_entry_from_candidate(in, P, D, c, (int)s_key[g], e.ns, e.prev, e.half);
+        if (c >= 1) gardner_entry_from_candidate(in, P, D, c * D.span, (int)s_key[g], e.ns, e.prev, e.half);
         e.offset = s_off[g];
         entries[c] = e;
     }

@@ -366,6 +366,28 @@ def test_250ksps_capture_matches_oracle(pdt, orc):
     assert all(i is not None for i in idx) and idx == list(range(idx[0], idx[0] + len(idx)))
 
 
+@pytest.mark.parametrize("fs,secs,chunk,span", [(250000, 12.0, 0, 4), (250000, 12.0, 0, 16), (250000, 9.0, 2500, 7),
+                                                (50000, 30.0, 1000, 16), (250000, 12.02, 0, 3), (100000, 6.0, 3000, 2)])
+def test_table_rows_spanning_several_chunks(pdt, orc, fs, secs, chunk, span):
+    """Boundary states tabulated in front of every span-th chunk only (k_gardner_span: what hour-long captures run by default,
+    forced here through PDT_GSPAN on short ones): every stage equals the oracle -- spans that do not divide the number of
+    chunks, a last group of one short chunk, small chunks."""
+    iq = pdt.synth_capture(0, fs, secs, seed=300 + span)
+    o = orc.Oracle(orc.POES, fs, iq, chunk=chunk)
+    os.environ["PDT_GSPAN"] = str(span)
+    try:
+        with pdt.Demodulator(pdt.MODE_POES, fs, chunk=chunk) as d:
+            d.demod(iq)
+            check_all_stages(pdt, orc, d, o)
+            st = d.stats()
+            assert st.gardner_parallel == 1 and st.frames > 20
+            n_chunks = -(-len(iq) // (chunk or 10000))
+            if chunk == 0:       # rows, not chunks, were tabulated (the default chunk: the scouts settle, every row has a short list)
+                assert st.gardner_candidates < 2100 * ((n_chunks - 1) // span + 1)
+    finally:
+        del os.environ["PDT_GSPAN"]
+
+
 @pytest.mark.parametrize("rg,kp", [(0.0, 0.0), (9.0, 0.05)])
 def test_mm_clock_recovery_poes(pdt, orc, clip, rg, kp):
     """MMClockRecovery as the sampler (cfg.sampler = 1); every stage against the oracle, whose M&M
