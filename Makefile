@@ -11,8 +11,9 @@ CSRC     := $(PKG)/csrc
 LIBPDT   := $(CSRC)/libpdt.so
 LIBSYNTH := $(PKG)/synth/libpdtsynth.so
 LIBGATHER := $(CSRC)/libpdtgather.so
+LIBCOMPAT := $(CSRC)/libpdt_compat_poes.so $(CSRC)/libpdt_compat_argos.so
 
-all: $(LIBPDT) $(LIBSYNTH) $(LIBGATHER) bin/synth_wav bin/demodPOES bin/demodARGOS bin/demodMulti oracle
+all: $(LIBPDT) $(LIBSYNTH) $(LIBGATHER) $(LIBCOMPAT) bin/synth_wav bin/demodPOES bin/demodARGOS bin/demodMulti oracle
 
 LIBPDT_SRC := $(CSRC)/pdt_api.hip $(CSRC)/pdt_kernels_front.h $(CSRC)/pdt_kernels_back.h $(CSRC)/pdt_device_math.h $(CSRC)/pdt_sincostab.h $(CSRC)/pdt_timeaxis.h include/pdt.h
 $(LIBPDT): $(LIBPDT_SRC)
@@ -21,6 +22,13 @@ $(LIBPDT): $(LIBPDT_SRC)
 # RCCL gather of frame records (multi-GPU launcher): a library of its own, so that libpdt.so does not depend on RCCL
 $(LIBGATHER): $(CSRC)/pdt_gather.hip include/pdt_gather.h include/pdt.h $(LIBPDT)
 	$(HIPCC) --offload-arch=$(ARCH) -O2 -std=c++17 -fPIC -Wall -shared -o $@ $(CSRC)/pdt_gather.hip -L$(CSRC) -lpdt -lrccl -Wl,-rpath,'$$ORIGIN'
+
+# the reference's stage functions with their own prototypes (common/*.h) over libpdt.so: what a main written against the
+# reference links instead of the reference's objects (float build = POESTIPdemod, double build = ARGOSdemod)
+$(CSRC)/libpdt_compat_poes.so: $(PKG)/host/pdt_compat.c include/pdt.h $(LIBPDT)
+	$(CC) $(CFLAGS) -fPIC -shared -Iinclude -o $@ $(PKG)/host/pdt_compat.c -L$(CSRC) -lpdt -lm -Wl,-rpath,'$$ORIGIN'
+$(CSRC)/libpdt_compat_argos.so: $(PKG)/host/pdt_compat.c include/pdt.h $(LIBPDT)
+	$(CC) $(CFLAGS) -DPDT_COMPAT_ARGOS -fPIC -shared -Iinclude -o $@ $(PKG)/host/pdt_compat.c -L$(CSRC) -lpdt -lm -Wl,-rpath,'$$ORIGIN'
 
 $(LIBSYNTH): $(PKG)/synth/pdt_synth.c $(PKG)/synth/pdt_synth.h
 	$(CC) $(CFLAGS) -fPIC -shared -o $@ $(PKG)/synth/pdt_synth.c -lm
@@ -45,7 +53,7 @@ oracle:
 	$(MAKE) -C oracle
 
 clean:
-	rm -f $(LIBPDT) $(LIBSYNTH) $(LIBGATHER) bin/*
+	rm -f $(LIBPDT) $(LIBSYNTH) $(LIBGATHER) $(LIBCOMPAT) bin/*
 	$(MAKE) -C oracle clean
 
 .PHONY: all oracle clean

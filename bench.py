@@ -205,7 +205,7 @@ def group_kernel(group: str, dt: str, interp: int) -> str:
         "pll_head": f"k_pll_head<{dt}, false, true>", "pll_fix": f"k_pll_fix<{dt}, false>", "pll_theta": f"k_pll_theta<{dt}>",
         "pll_mix": f"k_pll_mix<{dt}, {'true' if dt == 'double' else 'false'}>", "lock_ema": f"k_lock_ema<{dt}>",
         "fir": f"k_fir_interp_rt<{dt}, {interp}, 26>" if dt == "float" else f"k_fir_plain<{dt}>",
-        "mix_fir": f"k_mix_fir<{dt}, {interp}, 26>",
+        "mix_fir": "k_mix_fir<26, 0>",
         "agc_block": f"k_agc_block<{dt}>", "gardner_table": "k_gardner_table_merge<2048>",
         "gardner": "k_gardner<float, 2048, 256>" if dt == "float" else "k_gardner_ring<double, 2560, 6, 256>",
         "static_gain": f"k_static_gain<{dt}>", "manchester": f"k_manch_emit<{dt}>", "bytesync": "k_sync_frames_tiles",
@@ -334,10 +334,10 @@ def run(args, pdt, torch, dist, rank, local, world, dev, cdev, cfg, kind, fs, se
     par = capture_params(pdt, cfg, 1234 + rank)                            # one independent capture per rank
     wav = os.path.join(tmp, f"{cfg}.wav") if tmp else None
     d_iq = make_capture(pdt, par, n, threads, device=dev, wav_path=wav, fs=fs)    # resident in HBM before timing
-    dm = pdt.Demodulator(mode, fs, device=local, profile=True)
+    dm = pdt.Demodulator(mode, fs, device=local, profile=True).keep_pll(False)      # as the host programs run it
     dm.set_stream(torch.cuda.current_stream().cuda_stream)
     ncap = max(args.captures, 1)
-    extra = [pdt.Demodulator(mode, fs, device=local, profile=True) for _ in range(ncap - 1)]
+    extra = [pdt.Demodulator(mode, fs, device=local, profile=True).keep_pll(False) for _ in range(ncap - 1)]
 
     def step():
         if extra:
@@ -450,7 +450,7 @@ def run(args, pdt, torch, dist, rank, local, world, dev, cdev, cfg, kind, fs, se
         if legs:
             # ---- end to end, in process: what POESTIPdemod/main.c:284-512 does with the file
             e2e_ms, split = [], []
-            with pdt.Demodulator(mode, fs, device=local) as de:
+            with pdt.Demodulator(mode, fs, device=local).keep_pll(False) as de:
                 for rep in range(3):
                     outp = os.path.join(tmp, "e2e_out.txt")
                     t1 = time.perf_counter()

@@ -178,6 +178,13 @@ int  pdt_set_stream(pdt_ctx *ctx, void *hip_stream);
  * reference's `-r` option dumps (ARGOSdemod/main.c:171-180,273-274).  Costs one more stream-sized buffer.            */
 int  pdt_keep_presquelch(pdt_ctx *ctx, int enable);
 
+/* Whether the PLL output stream (stage PDT_ST_PLL = CarrierTrackPLL's realDataOut, CarrierTrackingPLL.c:113) is written out in
+ * the following pdt_demod_* calls.  At INTERP 1 (sample rates from 150 ksps up) the float chain mixes and filters in one kernel
+ * (k_mix_fir): nothing but the filter reads that stream, and with enable = 0 it never goes through HBM -- pdt_stage_len /
+ * pdt_read_stage of PDT_ST_PLL then report 0 samples / PDT_ERR_ARG.  On by default (every stage readable after a call); the
+ * host programs and the benchmark switch it off.  No effect on the other chains, which always keep the stream.           */
+int  pdt_keep_pll(pdt_ctx *ctx, int enable);
+
 /* Also keep what the reference's chunk loop knows after every chunk, in the following pdt_demod_* calls (whole captures; not
  * the streaming entry points): the value CarrierTrackPLL returns for the chunk -- averagePhase, the running mean of
  * |arg(PLL output)| with alpha 0.00005, after the chunk's last sample (CarrierTrackingPLL.c:80,124,152,277), from which
@@ -282,6 +289,11 @@ uint64_t pdt_stage_len(const pdt_ctx *ctx, int stage);
  * pdt_format_frames.  (The reference ships exactly such a bit-string harness, commented out, at
  * POESTIPdemod/ByteSync.c:6-14.)                                                                  */
 int      pdt_stage_bytesync(pdt_ctx *ctx, const uint8_t *bits_host, uint64_t nbits);
+/* The same when the string continues an earlier one (the synchronisers keep their last bits and an open frame in statics
+ * between calls, ByteSync.c:18-22): no sync word may COMPLETE before bit first_sync_end -- one that ends inside the bits the
+ * caller kept from the previous call was seen there, with the real bits in front of it instead of the zeros the ring starts
+ * with.  pdt_compat.c continues the reference's call-by-call state with this.                                            */
+int      pdt_stage_bytesync_from(pdt_ctx *ctx, const uint8_t *bits_host, uint64_t nbits, uint64_t first_sync_end);
 
 /* More stage-level entries: one stage of the chain on caller data in host memory (DT = float for POES
  * contexts, double for ARGOS), through the kernels the whole-capture path uses, with the reference function's hidden

@@ -155,7 +155,7 @@ ABI_SYMBOLS = [
     "pdt_wav_parse_header", "pdt_time_axis", "pdt_stage_bytesync", "pdt_tip_check", "pdt_tip_frames",
     "pdt_stream_begin", "pdt_stream_push_pcm16", "pdt_stream_push_f32", "pdt_stream_end", "pdt_stream_frames",
     "pdt_keep_quality", "pdt_chunk_reports", "pdt_stage_manchester", "pdt_stage_fir", "pdt_stage_agc", "pdt_stage_squelch", "pdt_stage_pll", "pdt_stage_gardner", "pdt_stage_static_gain", "pdt_stage_mm",
-    "pdt_keep_presquelch", "pdt_demod_fd", "pdt_format_records", "pdt_stream_retained", "pdt_host_math", "pdt_get_device",
+    "pdt_keep_presquelch", "pdt_keep_pll", "pdt_stage_bytesync_from", "pdt_demod_fd", "pdt_format_records", "pdt_stream_retained", "pdt_host_math", "pdt_get_device",
 ]
 
 _lib = None
@@ -234,6 +234,8 @@ def lib():
     L.pdt_stage_fir.restype = C.c_int
     L.pdt_keep_quality.argtypes = [C.c_void_p, C.c_int]
     L.pdt_keep_quality.restype = C.c_int
+    L.pdt_keep_pll.argtypes = [C.c_void_p, C.c_int]
+    L.pdt_keep_pll.restype = C.c_int
     L.pdt_chunk_reports.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64]
     L.pdt_chunk_reports.restype = C.c_uint64
     L.pdt_tip_check.argtypes = [C.c_void_p, C.POINTER(TipSummary)]
@@ -329,6 +331,11 @@ class Demodulator:
     def keep_presquelch(self, enable: bool = True):
         """Also keep the AGC output before Squelch (stage ST_AGC_RAW): what the reference's -r option dumps."""
         _check(self._L.pdt_keep_presquelch(self._h, int(enable)), "pdt_keep_presquelch")
+        return self
+
+    def keep_pll(self, enable: bool = True):
+        """Whether the PLL output stream (ST_PLL) is written out where mix and filter run as one kernel (on by default)."""
+        _check(self._L.pdt_keep_pll(self._h, int(enable)), "pdt_keep_pll")
         return self
 
     def keep_quality(self, enable: bool = True):

@@ -239,7 +239,7 @@ struct Plan {
 struct Tuning {
     double band_pad = 0.0, pll_warm_scale = 1.0, head_taus = 0.0, agc_k = 0.0, pll_warm_s = 0.0, agc_warm_s = 0.0;
     int scout_syms = 0, gspan = 0, ingest_threads = 0, ingest_span_mb = 0, ingest_streams = 0, overlap_segments = 0, overlap_min_mb = 0, fir_wg_per_cu = 0, agc_tpb = 0, gseg = 0, acquire_mode = 0, pll_block = 0, fix_passes = 2;      // acquire_mode: 0 = two-wavefront pipeline, 1 = plain one-lane, 2 = one wavefront
-    bool fir_generic = false, agc_unfused = false, no_excl = false, gtab_nomerge = false, gardner_onebuf = false, gardner_noring = false, gardner_sequential = false, seg_sequential = false, no_overlap = false, debug_overlap = false, chain_one_range = false, ema_noguess = false, debug_sync = false;
+    bool fir_generic = false, mix_unfused = false, agc_unfused = false, no_excl = false, gtab_nomerge = false, gardner_onebuf = false, gardner_noring = false, gardner_sequential = false, seg_sequential = false, no_overlap = false, debug_overlap = false, chain_one_range = false, ema_noguess = false, debug_sync = false;
     void load()
     {
         if (const char *e = getenv("PDT_PLL_WARM_SCALE")) pll_warm_scale = atof(e);
@@ -261,6 +261,7 @@ struct Tuning {
         if (getenv("PDT_ACQUIRE_SIMPLE")) acquire_mode = 1;
         else if (getenv("PDT_ACQUIRE_ONEWAVE")) acquire_mode = 2;
         fir_generic = getenv("PDT_FIR_GENERIC") != nullptr;
+        mix_unfused = getenv("PDT_MIX_UNFUSED") != nullptr;
         agc_unfused = getenv("PDT_AGC_UNFUSED") != nullptr;
         no_excl = getenv("PDT_NO_EXCL") != nullptr;
         gtab_nomerge = getenv("PDT_GTAB_NOMERGE") != nullptr;
@@ -330,6 +331,7 @@ struct pdt_ctx {
     bool keep_agc_raw = false;   // pdt_keep_presquelch: also keep the AGC output before Squelch (stage PDT_ST_AGC_RAW)
     // pdt_keep_quality: the averagePhase stream (what CarrierTrackPLL returns, chunk by chunk) and the per-chunk counts
     bool keep_quality = false;
+    bool keep_pll = true;        // pdt_keep_pll: the PLL output stream (stage PDT_ST_PLL) is written out although only the filter reads it
     DevBuf avgph, term_ap, seams_q, chunkinfo;
     // pdt_stage_pll: the next run starts the PLL from this state, keeps the lock and averagePhase streams and stops after the PLL
     struct PllInject {
@@ -773,10 +775,19 @@ template <typename T> int run_capture(pdt_ctx *ctx, uint64_t n, int phase = RUN_
     }
     Bp = std::min<long long>(Bp, std::max<long long>(N, 1));   // (one block at most: the LT layout keeps 64 blocks per tile)
     Bp = std::max<long long>(64, (Bp + 63) / 64 * 64);         // whole transposition groups of the LT layout (pdt_kernels_front.h)
+    // mix and filter in one kernel (k_mix_fir: the PLL output never goes through HBM): the float chain at INTERP 1 with the
+    // register-tiled taps; its runs and ring phases need blocks of a multiple of lcm(64, 208) = 832 samples
+    bool fuse_mix = false;
+    if constexpr (std::is_same<T, float>::value) {
+        fuse_mix = !argos && !live && !inject && !seg && interp == 1 && ntaps == 26 && ctx->taps_rot.p && !ctx->tune.fir_generic &&
+                   !ctx->tune.mix_unfused && N >= 832;
+        if (fuse_mix && !ctx->cfg.pll_block) Bp = (Bp + 831) / 832 * 832;
+        if (fuse_mix && Bp % 832 != 0) fuse_mix = false;
+    }
     Ba = std::max<long long>(64, round4(Ba));
     // POES with the register-tiled FIR: AGC blocks made of whole FIR tiles (64 * 26 inputs), so that the FIR kernel can
     // deliver the AGC's affine tile maps itself (0 = not fused: explicit block size, ARGOS, generic FIR)
-    long long agc_tiles_per_block = 0, fused_tiles = 0;
+    long long agc_tiles_per_block = 0, fused_tiles = 0, agc_maps_per_block = 0;
     if (!argos && !ctx->cfg.agc_block && ntaps == 26 * interp && ctx->taps_rot.p && !ctx->tune.fir_generic &&
         !ctx->tune.agc_unfused && !seg) {
         const long long tile_out = 64ll * 26 * interp;
@@ -1083,6 +1094,7 @@ template <typename T> int run_capture(pdt_ctx *ctx, uint64_t n, int phase = RUN_
         }
         L.end();
         (void)grid;
+        if (!fuse_mix) {
         L.begin("pll_mix");
         if (need_lock)
             PDT_LAUNCH(256, (k_pll_mix<T, true>), dim3((unsigned)lt_groups), dim3(256), 0, st, d_pcm, d_phi, N, Bp, PP,
@@ -1091,6 +1103,7 @@ template <typename T> int run_capture(pdt_ctx *ctx, uint64_t n, int phase = RUN_
             PDT_LAUNCH(256, (k_pll_mix<T, false>), dim3((unsigned)lt_groups), dim3(256), 0, st, d_pcm, d_phi, N, Bp, PP,
                                d_info, d_pll, (T *)nullptr);
         L.end();
+        }
         if (need_lock) {
             L.begin("lock_ema");
             if (ema_guess) {
@@ -1136,7 +1149,7 @@ template <typename T> int run_capture(pdt_ctx *ctx, uint64_t n, int phase = RUN_
         const int opt = 8;
         const long long tile = (long long)PDT_FIR_THREADS * opt;
         const long long grid = (n_out + tile - 1) / tile;
-        L.begin("fir");
+        L.begin(fuse_mix ? "mix_fir" : "fir");
         if (argos) {
             const size_t sh = (size_t)(ntaps + tile + ntaps + 8) * sizeof(T);
             PDT_LAUNCH(PDT_FIR_THREADS, k_fir_plain<T>, dim3((unsigned)grid), dim3(PDT_FIR_THREADS), sh, st, d_pll, N, ntaps, d_taps,
@@ -1157,7 +1170,27 @@ template <typename T> int run_capture(pdt_ctx *ctx, uint64_t n, int phase = RUN_
             const long long fir_tpb = ctx->tune.fir_wg_per_cu > 0 ? ctx->tune.fir_wg_per_cu : 32;
             const unsigned grid_rt = (unsigned)std::min<long long>(tiles_rt, 256ll * fir_tpb);
             bool done = false;
-            if (K == 26 && sh_rt <= 64000 && ctx->taps_rot.p && !ctx->tune.fir_generic) {
+            if constexpr (std::is_same<T, float>::value) if (fuse_mix) {
+                // one map per run of 208 outputs instead of one per FIR tile of 1 664 (AGC blocks are whole tiles = 8 runs each)
+                const long long runs_nat = (N + PDT_MF_RUN - 1) / PDT_MF_RUN;
+                AgcMap *run_maps = nullptr;
+                if (agc_tiles_per_block > 0) {
+                    if ((rc = ctx->agc_maps.ensure((size_t)(runs_nat + 1) * sizeof(AgcMap) + (size_t)(nb_agc + 2) * (sizeof(double) + sizeof(AgcMap))))) return rc;
+                    run_maps = (AgcMap *)ctx->agc_maps.p;
+                    fused_tiles = runs_nat;
+                    agc_maps_per_block = agc_tiles_per_block * (64 * 26 / PDT_MF_RUN);
+                }
+                if (d_pcm.fmt == 0)
+                    PDT_LAUNCH(256, (k_mix_fir<26, 0>), dim3((unsigned)(lt_tiles * (Bp / PDT_MF_RUN))), dim3(256), 0, st, d_pcm, (const float *)d_phi,
+                                       (const float *)d_pll, N, Bp, (const PllLockInfo<float> *)d_info, (const float *)ctx->taps_rot.p, (float *)d_fir,
+                                       ctx->keep_pll ? (float *)d_pll : (float *)nullptr, run_maps, (float)AP.decay);
+                else
+                    PDT_LAUNCH(256, (k_mix_fir<26, 1>), dim3((unsigned)(lt_tiles * (Bp / PDT_MF_RUN))), dim3(256), 0, st, d_pcm, (const float *)d_phi,
+                                       (const float *)d_pll, N, Bp, (const PllLockInfo<float> *)d_info, (const float *)ctx->taps_rot.p, (float *)d_fir,
+                                       ctx->keep_pll ? (float *)d_pll : (float *)nullptr, run_maps, (float)AP.decay);
+                done = true;
+            }
+            if (!done && K == 26 && sh_rt <= 64000 && ctx->taps_rot.p && !ctx->tune.fir_generic) {
                 done = true;
                 switch (interp) {
 #define PDT_FIR_CASE(I)                                                                                                       \
@@ -1202,14 +1235,15 @@ template <typename T> int run_capture(pdt_ctx *ctx, uint64_t n, int phase = RUN_
         if (ctx->tune.agc_k > 0) agc_K = ctx->tune.agc_k;
         L.begin("agc_block");
         if (!fused) PDT_LAUNCH(256, k_agc_affine<T>, dim3((unsigned)nb), dim3(256), 0, st, a_in, na, APs.decay, Ba, d_maps);
-        if (fused && agc_tiles_per_block > 1) {
+        if (agc_maps_per_block == 0) agc_maps_per_block = agc_tiles_per_block;        // (the FIR kernel's maps: one per tile)
+        if (fused && agc_maps_per_block > 1) {
             AgcMap *d_bmaps = (AgcMap *)(d_guess + nb + 1);
             PDT_LAUNCH(256, k_agc_blockmaps, dim3((unsigned)((nb + 255) / 256)), dim3(256), 0, st, (const AgcMap *)d_maps, nb,
-                               (int)agc_tiles_per_block, fused_tiles, d_bmaps);
+                               (int)agc_maps_per_block, fused_tiles, d_bmaps);
             PDT_LAUNCH(1024, k_agc_guess<T>, dim3(1), dim3(1024), 0, st, (const AgcMap *)d_bmaps, nb, (const T *)d_norm, d_guess, 1, nb);
         } else
         PDT_LAUNCH(1024, k_agc_guess<T>, dim3(1), dim3(1024), 0, st, (const AgcMap *)d_maps, nb, (const T *)d_norm, d_guess,
-                           fused ? (int)agc_tiles_per_block : 1, fused ? fused_tiles : nb);
+                           fused ? (int)agc_maps_per_block : 1, fused ? fused_tiles : nb);
         PDT_LAUNCH(64, k_agc_block<T>, dim3((unsigned)grid), dim3(64), 0, st, a_in, na, APs, d_norm, Ba, Wa,
                            (const double *)d_guess, a_lock, a_out, (AgcSeam<T> *)ctx->seams_agc.p, agc_K);
         L.end();
@@ -1702,7 +1736,7 @@ template <typename T> int run_capture(pdt_ctx *ctx, uint64_t n, int phase = RUN_
     S.gardner_candidates = tabled ? sc.gstats[3] : 0u;
     S.sync_overflow = sc.sync_overflow;
 
-    ctx->stage_len[PDT_ST_PLL] = n;
+    ctx->stage_len[PDT_ST_PLL] = (fuse_mix && !ctx->keep_pll) ? 0 : n;       // (k_mix_fir: the stream exists on request only)
     ctx->stage_len[PDT_ST_LOCK] = need_lock ? n : 0;
     ctx->stage_len[PDT_ST_FIR] = (uint64_t)n_out;
     ctx->stage_len[PDT_ST_AGC] = (uint64_t)n_out;
@@ -1957,7 +1991,8 @@ int pdt_device_count(void)
 
 // Host evaluation of the library's own restatements of the C-library functions the reference calls (test hook: the CPU
 // tests compare them with the C library of the machine, bit for bit).  fn: 0 sincos(x) -> out0 sin, out1 cos; 1 sin; 2 cos;
-// 3 sincosf((float)x) widened; 4 hypot(x[2i], x[2i+1]) -> out0[i]; 5 hypotf of the pair, widened.
+// 3 sincosf((float)x) widened; 4 hypot(x[2i], x[2i+1]) -> out0[i]; 5 hypotf of the pair, widened; 6 the branch-free form
+// of 3 (sincosf_flat: what the fused mix + FIR kernel evaluates).
 int pdt_host_math(int fn, const double *x, uint64_t n, double *out0, double *out1)
 {
     if (!x || !out0) return PDT_ERR_ARG;
@@ -1969,6 +2004,7 @@ int pdt_host_math(int fn, const double *x, uint64_t n, double *out0, double *out
         case 3: { float sf, cf; sincosf_glibc((float)x[i], sf, cf); out0[i] = sf; if (out1) out1[i] = cf; break; }
         case 4: out0[i] = hypot_glibc(x[2 * i], x[2 * i + 1]); break;
         case 5: out0[i] = hypotf_glibc((float)x[2 * i], (float)x[2 * i + 1]); break;
+        case 6: { float sf, cf; sincosf_flat((float)x[i], sf, cf); out0[i] = sf; if (out1) out1[i] = cf; break; }
         default: return PDT_ERR_ARG;
         }
     }
@@ -2191,6 +2227,13 @@ uint64_t pdt_chunk_reports(const pdt_ctx *ctx, pdt_chunk_report *out, uint64_t m
     return m;
 }
 
+int pdt_keep_pll(pdt_ctx *ctx, int enable)
+{
+    if (!ctx) return PDT_ERR_ARG;
+    ctx->keep_pll = enable != 0;
+    return PDT_OK;
+}
+
 int pdt_keep_presquelch(pdt_ctx *ctx, int enable)
 {
     if (!ctx) return PDT_ERR_ARG;
@@ -2290,6 +2333,11 @@ int pdt_demod_device_f32(pdt_ctx *ctx, const void *iq_device, uint64_t nframes)
 
 int pdt_stage_bytesync(pdt_ctx *ctx, const uint8_t *bits_host, uint64_t nbits)
 {
+    return pdt_stage_bytesync_from(ctx, bits_host, nbits, 0);
+}
+
+int pdt_stage_bytesync_from(pdt_ctx *ctx, const uint8_t *bits_host, uint64_t nbits, uint64_t first_sync_end)
+{
     if (!ctx || (!bits_host && nbits)) return PDT_ERR_ARG;
     if (nbits >= (1ull << 31)) return PDT_ERR_ARG;
     if (ctx->stream_open) return PDT_ERR_STATE;              // (the stage buffers carry an open stream's tails)
@@ -2321,7 +2369,7 @@ int pdt_stage_bytesync(pdt_ctx *ctx, const uint8_t *bits_host, uint64_t nbits)
     PL.memset_async(ctx->frames.p, 0, (size_t)frame_cap * sizeof(FrameRec));
     PDT_LAUNCH(256, k_iota, dim3((unsigned)((bit_cap + 255) / 256)), dim3(256), 0, st, (unsigned *)ctx->bitsym.p,
                (long long *)ctx->symidx.p, bit_cap);
-    launch_bytesync(ctx, PL, st, SP, d_sc, bit_cap, hit_cap, frame_cap);
+    launch_bytesync(ctx, PL, st, SP, d_sc, bit_cap, hit_cap, frame_cap, (long long)first_sync_end);
     DevScalars *back = ctx->pend_sc;                                  // pinned
     PL.copy(OP_D2H, back, d_sc, sizeof sc);
     {

@@ -68,6 +68,43 @@ __host__ __device__ __forceinline__ void sincosf_glibc(float y, float &sinv, flo
     }
 }
 
+// sincosf_glibc without its branches, for the kernels that evaluate it for every sample of a capture: every argument goes
+// through the quadrant reduction.  Same bits for every |y| < 120: below pi/4 the quadrant is 0 and the reduction hands back x
+// itself (fma(-0, pi/2, x) = x), which is all the routine's own shortcut for |y| < 0.5 saves; below 2^-12, where the routine
+// returns (y, 1) without evaluating anything, the polynomials round to exactly that (|x^3/6| < ulp(x)/4, x^2/2 < 2^-25).
+// The table with the negated cosine coefficients (quadrants 2, 3) becomes a negation of the result -- every
+// intermediate of that polynomial changes sign, rounding is symmetric --, the sign[] factor of the sine argument a flip of
+// its sign bit.  tests/test_own_math.py compares the two forms (and the C library) over the whole range.
+__host__ __device__ __forceinline__ void sincosf_flat(float y, float &sinv, float &cosv)
+{
+    const double x = (double)y;
+    const double r = x * 0x1.45f306dc9c883p+23;
+    const int n = ((int32_t)r + 0x800000) >> 24;
+    const double xr = __builtin_fma(-(double)n, 0x1.921fb54442d18p+0, x);
+    const double x2 = xr * xr;
+    uint64_t xb = bits_of(xr);
+    xb ^= (uint64_t)(((uint32_t)(n + 1) << 30) & 0x80000000u) << 32;         // quadrants 1, 2: the sine polynomial takes -x
+    double xs;
+    __builtin_memcpy(&xs, &xb, 8);
+    const double c1 = -0x1.ffffffd0c621cp-2, c2 = 0x1.55553e1068f19p-5, c3 = -0x1.6c087e89a359dp-10, c4 = 0x1.99343027bf8c3p-16;
+    const double s1 = -0x1.555545995a603p-3, s2 = 0x1.1107605230bc4p-7, s3 = -0x1.994eb3774cf24p-13;
+    const double x3 = xs * x2;
+    const double x4 = x2 * x2;
+    const double s1v = __builtin_fma(x2, s3, s2);
+    const double c2v = __builtin_fma(x2, c4, c3);
+    const double c1v = __builtin_fma(x2, c1, 0x1p0);
+    const double x5 = x2 * x3;
+    const double x6 = x2 * x4;
+    const double s = __builtin_fma(x3, s1, xs);
+    const double c = __builtin_fma(x4, c2, c1v);
+    float sv = (float)__builtin_fma(s1v, x5, s);
+    sv = (y == 0.0f) ? y : sv;                                                    // (sin(-0) = -0: the sums above give +0)
+    const float cp = (float)__builtin_fma(c2v, x6, c);
+    const float cv = float_of(bits_of(cp) ^ (((uint32_t)n << 30) & 0x80000000u));   // quadrants 2, 3: the negated table
+    sinv = (n & 1) ? cv : sv;
+    cosv = (n & 1) ? sv : cv;
+}
+
 // ---- arctan2 approximation of CarrierTrackingPLL.c:15-40
 __host__ __device__ __forceinline__ float arctan2_ref(float y, float x)
 {

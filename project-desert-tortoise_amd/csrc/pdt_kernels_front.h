@@ -1719,6 +1719,239 @@ __device__ __forceinline__ void k_fir_interp_rt(const T *__restrict__ in, long l
     }
 }
 
+// ------------------------------------------------------------------------------------------
+// Mix + FIR in one kernel (POES float build, INTERP 1 -- sample rates from 150 ksps up: the hour-long 250 ksps captures)
+//
+// After the lock the PLL output of sample i is Im(x_i e^{-j phi_i}) (CarrierTrackingPLL.c:106-113) and nothing but the filter
+// reads it (LowPassFilter.c:43-70).  Unfused, k_pll_mix writes that stream (4 B/sample) and k_fir_interp_rt reads it back;
+// here it only ever exists in LDS:
+//   * a workgroup takes one run of 208 positions (8 ring revolutions of K = 26) of each of the 64 blocks of an LT tile: the
+//     phases arrive as 59 whole rows of the tile (59 KiB of consecutive bytes: the run and 28 positions in front of it -- the
+//     filter's K - 1 = 25 older inputs, rounded to whole phase vectors), I/Q as 64 stretches of 944 bytes;
+//   * phase A transposes the phases into LDS (row = block), phase B replaces each by the mixed sample (branch-free sincosf,
+//     64 consecutive positions of a row per wavefront instruction; samples up to the lock come from the acquisition's
+//     output), optionally also writing it out (pdt_keep_pll);
+//   * phase C filters: lane = block, so all lanes of a wavefront are at the same ring phase (blocks and runs start at multiples
+//     of K: B is a multiple of lcm(64, 208) = 832) and take their taps -- rotated per residue on the host, as for
+//     k_fir_interp_rt -- from SGPRs; a wavefront computes the outputs s = 26 w + c and s + 104 of every row for the 26
+//     residues c in turn, the lane's ring of K inputs in registers, the two outputs of a lane side by side in packed
+//     arithmetic (v_pk_mul_f32 / v_pk_add_f32: per component exactly the separate multiply and add of the reference, in its
+//     slot order, starting from +0); 26 packed instructions per output against 52, and one LDS read per output;
+//   * phase D composes the AGC's affine map of every row's run (the guess of the gain at the AGC block boundaries: any
+//     grouping is legal there) and stores the outputs, 64 rows of 832 consecutive bytes.
+// HBM traffic: 4 B (I/Q) + 4 B (phase) in (+ 12 % for the runs' halos), 4 B out.
+// ------------------------------------------------------------------------------------------
+#define PDT_MF_RUN 208
+#define PDT_MF_HALO 28
+#define PDT_MF_COLS (PDT_MF_RUN + PDT_MF_HALO)
+#define PDT_MF_LSI 237                 // LDS row strides (odd: 64 rows at one column hit 64 banks)
+typedef float pdt_v2f __attribute__((ext_vector_type(2)));
+
+template <int K, int FMT>
+__device__ __forceinline__ void k_mix_fir(IqSrc pcm, const float *__restrict__ phi_lt, const float *__restrict__ pll_pre,
+                                          long long n, long long B, const PllLockInfo<float> *__restrict__ info,
+                                          const float *__restrict__ rot /* host-built rotated taps */, float *__restrict__ out,
+                                          float *__restrict__ pll_out /* nullptr: the PLL output is not kept */,
+                                          AgcMap *__restrict__ run_maps, float agc_decay)
+{
+    static_assert(PDT_MF_RUN == 8 * K && PDT_MF_HALO >= K - 1 && PDT_MF_HALO % 4 == 0, "run = 8 ring revolutions, halo = whole phase vectors");
+    // 59 KiB + 8 KiB: two workgroups per CU (one loads while the other computes)
+    __shared__ __attribute__((aligned(16))) float s_in[64 * PDT_MF_LSI];
+    __shared__ double s_maps[8 * 64 * 2];
+    const int lane = (int)threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6);
+    const long long runs = B / PDT_MF_RUN;
+    const long long w = (long long)blockIdx.x / runs, g = (long long)blockIdx.x - w * runs;
+    const long long p0 = g * PDT_MF_RUN;
+    const long long blk0 = w << 6;
+    if (blk0 * B + p0 >= n) return;                       // (the other rows of the tile lie further on)
+    const long long lock_at = info->lock_sample;
+    const long long S = (lock_at < 0) ? n : lock_at + 1;  // first sample mixed with a tracked phase
+
+    // ---- every global load of the workgroup is issued here, back to back: the I/Q words phase B will need (as they are in the
+    // capture: 4 or 8 bytes per sample), then (A) the phases of the run and its halo, transposed into LDS (row = block).
+    // Phase B's work list: a wavefront owns 16 rows x 236 columns = 59 x 64 (row, column) pairs, pair number 64 it + lane.
+    typedef typename std::conditional<FMT == 0, int, float2>::type Raw;
+    constexpr int NIT = 16 * PDT_MF_COLS / 64;
+    static_assert(NIT * 64 == 16 * PDT_MF_COLS, "a wavefront's share of phase B is whole instructions");
+    // interior workgroup: every sample it touches lies behind the lock and inside the capture (no test per sample)
+    const bool interior = (blk0 * B + p0 - PDT_MF_HALO >= S) && ((blk0 + 63) * B + p0 + PDT_MF_RUN <= n);
+    Raw raw[NIT];
+#pragma unroll
+    for (int it = 0; it < NIT; it++) {
+        const int idx = it * 64 + lane, rr = idx / PDT_MF_COLS, col = idx - rr * PDT_MF_COLS;
+        const long long i = (blk0 + wave * 16 + rr) * B + p0 - PDT_MF_HALO + col;
+        if constexpr (FMT == 0) raw[it] = 0;
+        else raw[it] = make_float2(0.0f, 0.0f);
+        if (interior) raw[it] = reinterpret_cast<const Raw *>(pcm.p)[i];       // (the other workgroups load as they go)
+    }
+    {
+        const float *tile = phi_lt + blk0 * B;
+        constexpr int NQ = (PDT_MF_COLS / 4 + 3) / 4;                  // phase vectors per wavefront
+        float4 v[NQ];
+#pragma unroll
+        for (int u = 0; u < NQ; u++) {
+            const int q = wave + 4 * u;
+            const long long p = p0 - PDT_MF_HALO + 4 * q;              // position of the vector's first sample in its block
+            const long long i0 = (blk0 + lane) * B + p;
+            v[u] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+            if (q < PDT_MF_COLS / 4 && (interior || (i0 >= 0 && i0 < n && i0 + 4 > S))) {
+                const float *src;
+                if (p >= 0) src = tile + (p >> 2) * 256 + lane * 4;
+                else if (lane > 0) src = tile + ((B + p) >> 2) * 256 + (lane - 1) * 4;        // the end of the block in front
+                else src = tile - 64 * B + ((B + p) >> 2) * 256 + 63 * 4;                     // ... which is the previous tile's last
+                v[u] = *reinterpret_cast<const float4 *>(src);
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < NQ; u++) {
+            const int q = wave + 4 * u;
+            if (q < PDT_MF_COLS / 4) {
+                float *d = s_in + lane * PDT_MF_LSI + 4 * q;
+                d[0] = v[u].x; d[1] = v[u].y; d[2] = v[u].z; d[3] = v[u].w;
+            }
+        }
+    }
+    __syncthreads();
+    // ---- B: phase -> mixed sample, in place
+    {
+        float *wrows = s_in + wave * 16 * PDT_MF_LSI;
+        auto mix = [&](const Raw &r, float ph) {
+            float a, b, sn, cs;
+            if constexpr (FMT == 0) {                                  // I | Q << 16, value / 32768 (wave.c:127-172)
+                a = (float)(short)(r & 0xffff) / 32768.0f;
+                b = (float)(short)(r >> 16) / 32768.0f;
+            } else {
+                a = r.x;
+                b = r.y;
+            }
+            sincosf_flat(ph, sn, cs);
+            const float c = cs, d = -sn;
+            return a * d + b * c;
+        };
+        if (interior) {
+#pragma unroll
+            for (int it = 0; it < NIT; it++) {
+                const int idx = it * 64 + lane, rr = idx / PDT_MF_COLS, col = idx - rr * PDT_MF_COLS;
+                float *cell = wrows + idx + rr;                        // rr * LSI + col, LSI = COLS + 1
+                const float x = mix(raw[it], *cell);
+                *cell = x;
+                if (pll_out && col >= PDT_MF_HALO) pll_out[(blk0 + wave * 16 + rr) * B + p0 - PDT_MF_HALO + col] = x;
+                if ((it & 3) == 3) __builtin_amdgcn_sched_barrier(0);  // four evaluations interleaved, not fifty-nine (registers)
+            }
+        } else {
+#pragma unroll 1
+            for (int it = 0; it < NIT; it++) {
+                const int idx = it * 64 + lane, rr = idx / PDT_MF_COLS, col = idx - rr * PDT_MF_COLS;
+                const long long i = (blk0 + wave * 16 + rr) * B + p0 - PDT_MF_HALO + col;
+                float *cell = wrows + idx + rr;
+                float x = 0.0f;
+                if (i >= S && i < n) {
+                    x = mix(reinterpret_cast<const Raw *>(pcm.p)[i], *cell);
+                    if (pll_out && col >= PDT_MF_HALO) pll_out[i] = x;
+                } else if (i >= 0 && i < n)
+                    x = pll_pre[i];                                    // up to the lock: the acquisition's output
+                *cell = x;
+            }
+        }
+    }
+    __syncthreads();
+    // ---- C: the filter
+    const long long row_base = (blk0 + lane) * B + p0;                    // natural index of this lane's output 0
+    const int n_valid = (int)((n - row_base >= PDT_MF_RUN) ? PDT_MF_RUN : ((n - row_base > 0) ? n - row_base : 0));
+    double mA[2] = {1.0, 1.0}, mB[2] = {0.0, 0.0};                        // AGC maps of this lane's two stretches of 26 outputs
+    const bool full_rows = (blk0 + 63) * B + p0 + PDT_MF_RUN <= n;        // every row's run lies inside the capture
+    {
+        float *xin = s_in + lane * PDT_MF_LSI + PDT_MF_HALO;              // xin[m] = input m of the run, m >= -HALO
+        const int s0 = wave * K;
+        constexpr int H2 = PDT_MF_RUN / 2;
+        const double rdec = (double)agc_decay;
+        pdt_v2f x[K], nx[K];
+        // the ring in front of output s0 (a multiple of K): slot t >= 1 holds input s0 - K + t; slot 0 is filled by residue 0.
+        // The K inputs that enter the ring while the wavefront works are taken now as well: the outputs then go where the
+        // inputs were (another wavefront's inputs, read before the barrier)
+        x[0].x = 0; x[0].y = 0;
+#pragma unroll
+        for (int t = 1; t < K; t++) { x[t].x = xin[s0 - K + t]; x[t].y = xin[s0 + H2 - K + t]; }
+#pragma unroll
+        for (int t = 0; t < K; t++) { nx[t].x = xin[s0 + t]; nx[t].y = xin[s0 + H2 + t]; }
+        __syncthreads();
+        auto residue = [&](auto cc) {
+            constexpr int c = decltype(cc)::value;
+            x[c] = nx[c];
+            constexpr int CS = (K + 15) & ~15;
+            const __attribute__((address_space(4))) float *h =
+                (const __attribute__((address_space(4))) float *)__builtin_assume_aligned(rot + c * CS, 64);
+            float hv[K];
+#pragma unroll
+            for (int t = 0; t < K; t++) hv[t] = h[t];
+            pdt_v2f y;
+            y.x = 0; y.y = 0;
+#pragma unroll
+            for (int t = 0; t < K; t++) {
+                pdt_v2f hh;
+                hh.x = hv[t]; hh.y = hv[t];
+                y = y + hh * x[t];
+            }
+            xin[s0 + c] = y.x;
+            xin[s0 + H2 + c] = y.y;
+            if (run_maps) {
+                // (the gain guess is free to round as it likes: fused operations, half the instructions)
+                const double a0 = __builtin_fma(-rdec, (double)__builtin_fabsf(y.x), 1.0);
+                const double a1 = __builtin_fma(-rdec, (double)__builtin_fabsf(y.y), 1.0);
+                if (full_rows) {
+                    mB[0] = __builtin_fma(a0, mB[0], rdec);
+                    mA[0] = a0 * mA[0];
+                    mB[1] = __builtin_fma(a1, mB[1], rdec);
+                    mA[1] = a1 * mA[1];
+                } else {
+                    if (s0 + c < n_valid) {
+                        mB[0] = __builtin_fma(a0, mB[0], rdec);
+                        mA[0] = a0 * mA[0];
+                    }
+                    if (s0 + H2 + c < n_valid) {
+                        mB[1] = __builtin_fma(a1, mB[1], rdec);
+                        mA[1] = a1 * mA[1];
+                    }
+                }
+            }
+        };
+        fir_residues<0, 1, K>(residue);
+    }
+    // ---- D: the rows' AGC maps (eight stretches each, in order), then the outputs
+    if (run_maps) {
+#pragma unroll
+        for (int hf = 0; hf < 2; hf++) {
+            s_maps[((hf * 4 + wave) * 64 + lane) * 2] = mA[hf];
+            s_maps[((hf * 4 + wave) * 64 + lane) * 2 + 1] = mB[hf];
+        }
+    }
+    __syncthreads();
+    if (run_maps && (int)threadIdx.x < 64 && row_base < n) {
+        double tA = 1.0, tB = 0.0;
+#pragma unroll
+        for (int sg = 0; sg < 8; sg++) {
+            const double A = s_maps[(sg * 64 + lane) * 2], Bc = s_maps[(sg * 64 + lane) * 2 + 1];
+            tB = A * tB + Bc;
+            tA = A * tA;
+        }
+        AgcMap m;
+        m.A = tA;
+        m.B = tB;
+        run_maps[row_base / PDT_MF_RUN] = m;
+    }
+#pragma unroll 4
+    for (int rr = 0; rr < 16; rr++) {
+        const int l = wave * 16 + rr;
+        const long long ob = (blk0 + l) * B + p0;
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            const int col = lane + 64 * k;
+            if (col < PDT_MF_RUN && ob + col < n) out[ob + col] = s_in[l * PDT_MF_LSI + PDT_MF_HALO + col];
+        }
+    }
+}
+
 // In-place form (ARGOS): y[i] = sum_{k<N} h[k] * x[i-(N-1-k)], oldest first.
 template <typename T>
 __device__ __forceinline__ void k_fir_plain(const T *__restrict__ in, long long n, int N,

@@ -384,6 +384,7 @@ int main(int argc, char **argv)
 #ifdef PDT_ARGOS
     if (outputRawFiles) pdt_keep_presquelch(ctx, 1);                 /* -r: the AGC output before Squelch, ARGOSdemod/main.c:273-274 */
 #endif
+    pdt_keep_pll(ctx, 0);                                            /* nothing here reads the PLL output stream */
     if (!noProgress) pdt_keep_quality(ctx, 1);                       /* the chunk loop's progress / quality line */
     rc = pdt_demod_fd(ctx, fileno(in), (uint64_t)data_offset, nframes, is_raw ? PDT_FMT_F32 : PDT_FMT_PCM16);
     fclose(in);

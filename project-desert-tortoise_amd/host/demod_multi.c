@@ -58,6 +58,7 @@ static void *run_job(void *arg)
     cfg.chunk = j->chunk;
     cfg.device = j->device;
     j->rc = pdt_open(&cfg, &j->ctx);
+    if (j->rc == PDT_OK) pdt_keep_pll(j->ctx, 0);                   /* nothing here reads the PLL output stream */
     if (j->rc == PDT_OK) {
         j->nframes = (uint64_t)(sb.st_size - 44) / 4;                                  /* to the end of the file (main.c:373) */
         j->rc = pdt_demod_fd(j->ctx, fd, 44, j->nframes, PDT_FMT_PCM16);

@@ -11,6 +11,8 @@ import subprocess
 import numpy as np
 import pytest
 
+from conftest import bits_equal
+
 from conftest import GOLDEN, ROOT, golden_text
 
 pytestmark = pytest.mark.gpu
@@ -386,6 +388,55 @@ def test_table_rows_spanning_several_chunks(pdt, orc, fs, secs, chunk, span):
                 assert st.gardner_candidates < 2100 * ((n_chunks - 1) // span + 1)
     finally:
         del os.environ["PDT_GSPAN"]
+
+
+@pytest.mark.parametrize("fs,secs,seed,kw", [(250000, 9.0, 41, {}), (200000, 3.3, 42, {}), (160000, 2.0, 43, {"chunk": 3333}),
+                                             (250000, 0.0301, 44, {}), (250000, 4.0, 45, {"pll_block": 1664}),
+                                             (250000, 4.0, 46, {"pll_block": 832, "pll_warm": 30000})])
+def test_mix_and_filter_in_one_kernel(pdt, orc, fs, secs, seed, kw):
+    """INTERP 1 captures take k_mix_fir (mix + FIR fused, the PLL output only in LDS): every stage equals the oracle -- with
+    the PLL stream kept (the default) and, in the lean mode the host programs use, without it; the unfused pair of kernels
+    behind PDT_MIX_UNFUSED gives the same bits.  Cases: lengths that end inside a run / a block / a tile, a capture shorter
+    than one block, the smallest legal block sizes (every run next to a block boundary, seams repaired)."""
+    iq = pdt.synth_capture(0, fs, secs, seed=seed)
+    chunk = kw.get("chunk", 0)
+    dkw = {k: v for k, v in kw.items() if k != "chunk"}
+    o = orc.Oracle(orc.POES, fs, iq, chunk=chunk)
+    with pdt.Demodulator(pdt.MODE_POES, fs, chunk=chunk, profile=True, **dkw) as d:
+        d.demod(iq)
+        check_all_stages(pdt, orc, d, o)
+        assert d.stats().interp == 1
+        assert "mix_fir" in d.kernel_times() and "pll_mix" not in d.kernel_times()
+        fir_kept = d.stage(pdt.ST_FIR)
+        d.keep_pll(False)
+        d.demod(iq)
+        assert d.text() == o.text()
+        assert bits_equal(d.stage(pdt.ST_FIR), fir_kept) and bits_equal(d.stage(pdt.ST_AGC), o.stage(orc.ST_AGC))
+        assert len(d.stage(pdt.ST_PLL)) == 0
+    os.environ["PDT_MIX_UNFUSED"] = "1"
+    try:
+        with pdt.Demodulator(pdt.MODE_POES, fs, chunk=chunk, profile=True, **dkw) as d:
+            d.demod(iq)
+            check_all_stages(pdt, orc, d, o)
+            assert "pll_mix" in d.kernel_times() and "mix_fir" not in d.kernel_times()
+    finally:
+        del os.environ["PDT_MIX_UNFUSED"]
+
+
+def test_mix_fir_noise_only_and_late_lock(pdt, orc):
+    """k_mix_fir takes the samples up to the lock from the acquisition's output: a capture that never locks (the whole
+    stream), and one whose signal rises after a second of noise (the lock far inside the capture)."""
+    fs = 250000
+    rng = np.random.default_rng(5)
+    noise = np.clip(np.rint(rng.normal(0, 900, (int(1.2 * fs), 2))), -32768, 32767).astype("<i2")
+    sig = pdt.synth_capture(0, fs, 3.0, seed=47)
+    for iq in (noise, np.ascontiguousarray(np.concatenate([noise[: fs], sig]))):
+        o = orc.Oracle(orc.POES, fs, iq)
+        with pdt.Demodulator(pdt.MODE_POES, fs, profile=True) as d:
+            d.demod(iq)
+            check_all_stages(pdt, orc, d, o)
+            assert "mix_fir" in d.kernel_times()
+    assert o.lock_sample > fs
 
 
 @pytest.mark.parametrize("rg,kp", [(0.0, 0.0), (9.0, 0.05)])

@@ -75,3 +75,26 @@ def test_hypot_equals_glibc(pdt):
     for i, (a, b) in enumerate(xy):
         assert libm.hypot(a, b) == h[i], (a, b)
         assert libm.hypotf(C.c_float(a), C.c_float(b)) == hf[i], (a, b)
+
+
+def test_branch_free_sincosf_equals_the_library_form(pdt):
+    """sincosf_flat (what k_mix_fir evaluates: no early-outs, the negated table as a sign flip) == sincosf_glibc == the C
+    library: a dense sample of the PLL's phase range, every float below 2^-11 in steps, the quadrant boundaries and their
+    neighbours, both zeros."""
+    rng = np.random.default_rng(11)
+    dense = rng.uniform(-7.0, 7.0, 400000).astype(np.float32)
+    wide = rng.uniform(-119.9, 119.9, 100000).astype(np.float32)
+    tiny = (np.arange(1, 0x39800000 + 0x400000, 9973, dtype=np.uint32)).view(np.float32)          # 0 < y < 2^-11
+    k = np.arange(-80, 81)
+    q = (k * (np.pi / 4)).astype(np.float32)
+    edges = np.concatenate([q, np.nextafter(q, np.float32(-1000.0)), np.nextafter(q, np.float32(1000.0))])
+    edges = np.concatenate([edges, np.array([0.0, -0.0, 0.5, -0.5, 2.0 ** -12, -(2.0 ** -12)], dtype=np.float32)])
+    x = np.concatenate([dense, wide, tiny, -tiny, edges]).astype(np.float64)
+    s3, c3 = pdt.host_math(3, x)
+    s6, c6 = pdt.host_math(6, x)
+    assert s3.astype(np.float32).tobytes() == s6.astype(np.float32).tobytes()
+    assert c3.astype(np.float32).tobytes() == c6.astype(np.float32).tobytes()
+    a, b = C.c_float(), C.c_float()
+    for i in range(0, len(x), 97):
+        libm.sincosf(C.c_float(x[i]), C.byref(a), C.byref(b))
+        assert np.float32(a.value).tobytes() == np.float32(s6[i]).tobytes() and np.float32(b.value).tobytes() == np.float32(c6[i]).tobytes(), x[i]
