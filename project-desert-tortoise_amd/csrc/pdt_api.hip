@@ -238,8 +238,8 @@ struct Plan {
 // context is opened; the demodulation calls never look at the environment.
 struct Tuning {
     double band_pad = 0.0, pll_warm_scale = 1.0, head_taus = 0.0, agc_k = 0.0, pll_warm_s = 0.0, agc_warm_s = 0.0;
-    int scout_syms = 0, gspan = 0, ingest_threads = 0, ingest_span_mb = 0, ingest_streams = 0, overlap_segments = 0, overlap_min_mb = 0, fir_wg_per_cu = 0, agc_tpb = 0, gseg = 0, acquire_mode = 0, pll_block = 0, fix_passes = 2;      // acquire_mode: 0 = two-wavefront pipeline, 1 = plain one-lane, 2 = one wavefront
-    bool fir_generic = false, mix_unfused = false, agc_unfused = false, no_excl = false, gtab_nomerge = false, gardner_onebuf = false, gardner_noring = false, gardner_sequential = false, seg_sequential = false, no_overlap = false, debug_overlap = false, chain_one_range = false, ema_noguess = false, debug_sync = false;
+    int scout_syms = 0, gspan = 0, gspan_cap = 0, ingest_threads = 0, ingest_span_mb = 0, ingest_streams = 0, overlap_segments = 0, overlap_min_mb = 0, fir_wg_per_cu = 0, agc_tpb = 0, gseg = 0, acquire_mode = 0, pll_block = 0, fix_passes = 2;      // acquire_mode: 0 = two-wavefront pipeline, 1 = plain one-lane, 2 = one wavefront
+    bool fir_generic = false, mix_unfused = false, quality_inline = false, agc_unfused = false, no_excl = false, gtab_nomerge = false, gardner_onebuf = false, gardner_noring = false, gardner_sequential = false, seg_sequential = false, no_overlap = false, debug_overlap = false, chain_one_range = false, ema_noguess = false, debug_sync = false;
     void load()
     {
         if (const char *e = getenv("PDT_PLL_WARM_SCALE")) pll_warm_scale = atof(e);
@@ -258,10 +258,12 @@ struct Tuning {
         if (const char *e = getenv("PDT_FIX_PASSES")) fix_passes = atoi(e);
         if (const char *e = getenv("PDT_GSEG")) gseg = std::min(64, std::max(2, atoi(e)));
         if (const char *e = getenv("PDT_GSPAN")) gspan = std::min(256, std::max(1, atoi(e)));
+        if (const char *e = getenv("PDT_GSPAN_CAP")) gspan_cap = std::max(64, atoi(e));          // (tests: rows that do not fit the key list)
         if (getenv("PDT_ACQUIRE_SIMPLE")) acquire_mode = 1;
         else if (getenv("PDT_ACQUIRE_ONEWAVE")) acquire_mode = 2;
         fir_generic = getenv("PDT_FIR_GENERIC") != nullptr;
         mix_unfused = getenv("PDT_MIX_UNFUSED") != nullptr;
+        quality_inline = getenv("PDT_QUALITY_INLINE") != nullptr;
         agc_unfused = getenv("PDT_AGC_UNFUSED") != nullptr;
         no_excl = getenv("PDT_NO_EXCL") != nullptr;
         gtab_nomerge = getenv("PDT_GTAB_NOMERGE") != nullptr;
@@ -327,7 +329,7 @@ struct pdt_ctx {
     hipEvent_t ev0 = nullptr, ev1 = nullptr, ev_fork = nullptr, ev_join = nullptr;
     hipStream_t stream2 = nullptr;     // side stream: block-parallel PLL phase runs beside the sequential acquisition
 
-    DevBuf pcm, pll, lock, fir, agc, sym, symidx, bits, bitsym, hits, frames, taps, mag, seams_pll, seams_agc, scal, lockinfo, term, seams_ema, gtable, gentries, gcand, gmfirst, stiles, gsegmap, gsegstart, gbands, gclist, gneed, gchain, agc_maps, pll_head, taps_rot, pll_scratch, tip, sync_scr, agc_raw;
+    DevBuf pcm, pll, lock, fir, agc, sym, symidx, bits, bitsym, hits, frames, taps, mag, seams_pll, seams_agc, scal, lockinfo, term, seams_ema, gtable, gentries, gcand, gmfirst, stiles, gsegmap, gsegstart, gbands, gclist, gneed, gchain, gspan_keys, gspan_tails, gspan_rows, gspan_items, gspan_ctl, agc_maps, pll_head, taps_rot, pll_scratch, tip, sync_scr, agc_raw;
     bool keep_agc_raw = false;   // pdt_keep_presquelch: also keep the AGC output before Squelch (stage PDT_ST_AGC_RAW)
     // pdt_keep_quality: the averagePhase stream (what CarrierTrackPLL returns, chunk by chunk) and the per-chunk counts
     bool keep_quality = false;
@@ -763,7 +765,10 @@ template <typename T> int run_capture(pdt_ctx *ctx, uint64_t n, int phase = RUN_
     }
     long long Wacq = (long long)(0.02 * fs_d);             // acquisition-gain stage of the warm-up
     long long Ba = ctx->cfg.agc_block ? ctx->cfg.agc_block : (long long)((argos ? 0.125 : 0.0625) * fs_d * interp);
-    long long Wa = ctx->cfg.agc_warm ? ctx->cfg.agc_warm : (long long)((argos ? 2.0 : 1.0) * fs_d * interp);
+    // (the cap of a block's warm-up, which is 11 gain time constants = 11 gain / decay samples: weak input -- the noise in front
+    // of a pass -- means a high gain and a long memory; capped at one second, every seam of a minute of noise failed its check
+    // and was repaired in order, 219 ms; eight seconds cover gains up to ~700)
+    long long Wa = ctx->cfg.agc_warm ? ctx->cfg.agc_warm : (long long)((argos ? 2.0 : 8.0) * fs_d * interp);
     if (!ctx->cfg.pll_block) {
         // One walker wavefront saturates the vector ALU of its SIMD (a wave64 instruction occupies the 16 lanes for 4 clocks), so
         // a second one on the same SIMD doubles the time of both: keep the walkers of everything that runs together -- this
@@ -990,6 +995,7 @@ template <typename T> int run_capture(pdt_ctx *ctx, uint64_t n, int phase = RUN_
     // leaves some free (1 024 SIMDs; it runs one wavefront per 64 blocks)
     const bool serial_excl = 4 * grid_pll <= 960 && !ctx->tune.no_excl;
     long long fix_regions = 1, fix_region_blocks = 0;
+    bool quality_side = false;            // the averagePhase EMA of pdt_keep_quality runs on the side stream
     L.begin("pll_acquire");
     if (inject && ctx->inj.locked) {
         // pdt_stage_pll after the lock: sample 0 is a dummy the caller put in front, "locked at sample 0" with the state record
@@ -1119,18 +1125,25 @@ template <typename T> int run_capture(pdt_ctx *ctx, uint64_t n, int phase = RUN_
             L.end();
         }
         if (quality) {
-            // averagePhase after the lock: its input term from the phases (still in place), then the EMA like the lock detector's
-            L.begin("quality");
+            // averagePhase after the lock: its input term from the phases (still in place), then the EMA like the lock detector's.
+            // Nothing later in the chain needs it (only k_chunk_info, at the very end): whole captures run it on the side stream,
+            // beside the filter, the AGC and the sampler; the chain only waits for the kernel that reads the phases (the AGC
+            // output will take their place).
+            quality_side = !inject && !ctx->tune.quality_inline;
+            hipStream_t sq = quality_side ? ctx->stream2 : st;
+            if (quality_side) PL.simple(OP_FORK);
+            L.begin("quality", sq);
             T *d_tap = (T *)ctx->term_ap.p;
-            PDT_LAUNCH(256, (k_pll_mix<T, false, true>), dim3((unsigned)lt_groups), dim3(256), 0, st, d_pcm, d_phi, N, Bp, PP,
+            PDT_LAUNCH(256, (k_pll_mix<T, false, true>), dim3((unsigned)lt_groups), dim3(256), 0, sq, d_pcm, d_phi, N, Bp, PP,
                                d_info, (T *)nullptr, d_tap);
-            PDT_LAUNCH(64, k_lock_ema_zero<T>, dim3((unsigned)((nb_q + 63) / 64)), dim3(64), 0, st, (const T *)d_tap, N,
+            if (quality_side) PL.simple(OP_JOIN_RECORD);
+            PDT_LAUNCH(64, k_lock_ema_zero<T>, dim3((unsigned)((nb_q + 63) / 64)), dim3(64), 0, sq, (const T *)d_tap, N,
                                avg_alpha, d_info, Bq, d_q_zresp);
-            PDT_LAUNCH(1024, (k_lock_ema_guess<T, true>), dim3(1), dim3(1024), 0, st, (const double *)d_q_zresp, N, avg_alpha, d_info, Bq,
+            PDT_LAUNCH(1024, (k_lock_ema_guess<T, true>), dim3(1), dim3(1024), 0, sq, (const double *)d_q_zresp, N, avg_alpha, d_info, Bq,
                                pow(1.0 - (double)avg_alpha, (double)Bq), d_q_guess);
-            PDT_LAUNCH(64, (k_lock_ema<T, true>), dim3((unsigned)((nb_q + 63) / 64)), dim3(64), 0, st, (const T *)d_tap, N, avg_alpha,
+            PDT_LAUNCH(64, (k_lock_ema<T, true>), dim3((unsigned)((nb_q + 63) / 64)), dim3(64), 0, sq, (const T *)d_tap, N, avg_alpha,
                                d_info, Bq, Wq, d_avgph, (EmaSeam<T> *)ctx->seams_q.p, (const double *)d_q_guess);
-            PDT_LAUNCH(64, k_lock_ema_fix<T>, dim3(1), dim3(64), 0, st, (const T *)d_tap, N, avg_alpha, d_info,
+            PDT_LAUNCH(64, k_lock_ema_fix<T>, dim3(1), dim3(64), 0, sq, (const T *)d_tap, N, avg_alpha, d_info,
                                Bq, d_avgph, (EmaSeam<T> *)ctx->seams_q.p, &d_sc->pad0_);
             L.end();
         }
@@ -1233,6 +1246,7 @@ template <typename T> int run_capture(pdt_ctx *ctx, uint64_t n, int phase = RUN_
         // the true recurrence only, so a few time constants make the trajectories agree to the last bit
         double agc_K = (sizeof(T) == 4) ? 11.0 : 34.0;
         if (ctx->tune.agc_k > 0) agc_K = ctx->tune.agc_k;
+        if (quality_side) PL.simple(OP_JOIN_WAIT);          // the phases (in the AGC output's buffer) have been read
         L.begin("agc_block");
         if (!fused) PDT_LAUNCH(256, k_agc_affine<T>, dim3((unsigned)nb), dim3(256), 0, st, a_in, na, APs.decay, Ba, d_maps);
         if (agc_maps_per_block == 0) agc_maps_per_block = agc_tiles_per_block;        // (the FIR kernel's maps: one per tile)
@@ -1292,7 +1306,7 @@ template <typename T> int run_capture(pdt_ctx *ctx, uint64_t n, int phase = RUN_
                 // scouts, candidate walks and chain hops per span chunks instead of per chunk.  A row's symbol count must fit
                 // the table cell.  Stream segments keep one chunk per row (they are short, and enter with a carried state).
                 int span = ctx->tune.gspan > 0 ? ctx->tune.gspan : ((!seg && n_chunks >= 4096) ? 16 : 1);
-                if (seg) span = 1;
+                if (seg || 2 * n_q > 32 * PDT_GSPAN_BITMAP_WORDS || 8 * (long long)stepf + 256 >= PDT_GSUB_WIN) span = 1;
                 while (span > 1 && ((double)span * max_count >= (double)((1u << (32 - idx_bits)) - 2u) || (n_chunks - 1) / span < 4))
                     span /= 2;
                 GD.span = span;
@@ -1389,10 +1403,30 @@ template <typename T> int run_capture(pdt_ctx *ctx, uint64_t n, int phase = RUN_
                                        (const GardnerBand *)ctx->gbands.p, (const unsigned *)ctx->gclist.p,
                                        (unsigned *)ctx->gtable.p, d_sc->gstats);
                 }
-                if (GD.span > 1)
-                    PDT_LAUNCH(64, (k_gardner_span<PDT_GTAB_WIN>), dim3((unsigned)n_tab), dim3(64), 0, st, (const float *)d_agc, GP, GD, n_tab,
-                                       (const unsigned *)ctx->gcand.p, (const GardnerBand *)ctx->gbands.p, (const unsigned *)ctx->gclist.p,
-                                       (unsigned *)ctx->gtable.p, d_sc->gstats);
+                if (GD.span > 1) {
+                    // the distinct exits of every row's first chunk, walked on through the row's other chunks (see k_gardner_span_keys)
+                    const unsigned cap_keys = ctx->tune.gspan_cap ? (unsigned)ctx->tune.gspan_cap
+                                                                  : (unsigned)std::min<long long>(std::max<long long>(n_tab * 128, 1ll << 20), 1ll << 28);
+                    const size_t cap_items = (size_t)cap_keys / PDT_GSUB_KEYS + (size_t)n_tab + 1;
+                    if ((rc = ctx->gspan_keys.ensure((size_t)cap_keys * sizeof(unsigned)))) return rc;
+                    if ((rc = ctx->gspan_tails.ensure((size_t)cap_keys * sizeof(unsigned)))) return rc;
+                    if ((rc = ctx->gspan_rows.ensure((size_t)n_tab * sizeof(GardnerSpanRow)))) return rc;
+                    if ((rc = ctx->gspan_items.ensure(cap_items * sizeof(GardnerSpanItem)))) return rc;
+                    if ((rc = ctx->gspan_ctl.ensure(sizeof(GardnerSpanCtl)))) return rc;
+                    PL.memset_async(ctx->gspan_ctl.p, 0, sizeof(GardnerSpanCtl));
+                    PDT_LAUNCH(256, k_gardner_span_keys, dim3((unsigned)n_tab), dim3(256), 0, st, GD, n_tab, (const unsigned *)ctx->gcand.p,
+                                       (GardnerBand *)ctx->gbands.p, (const unsigned *)ctx->gclist.p, (const unsigned *)ctx->gtable.p,
+                                       (unsigned *)ctx->gspan_keys.p, cap_keys, (GardnerSpanRow *)ctx->gspan_rows.p,
+                                       (GardnerSpanItem *)ctx->gspan_items.p, (GardnerSpanCtl *)ctx->gspan_ctl.p);
+                    const unsigned walkers = (unsigned)std::min<long long>(n_tab / PDT_GSUB + 64, 256ll * 16);     // persistent wavefronts (8 KiB of LDS each)
+                    PDT_LAUNCH(64, (k_gardner_span_walk<PDT_GSUB_WIN>), dim3(walkers), dim3(64), 0, st, (const float *)d_agc, GP, GD,
+                                       (const unsigned *)ctx->gspan_keys.p, (const GardnerSpanItem *)ctx->gspan_items.p,
+                                       (GardnerSpanCtl *)ctx->gspan_ctl.p, (unsigned *)ctx->gspan_tails.p);
+                    PDT_LAUNCH(128, k_gardner_span_join, dim3((unsigned)n_tab), dim3(128), 0, st, GD, n_tab, (const unsigned *)ctx->gcand.p,
+                                       (const GardnerBand *)ctx->gbands.p, (const unsigned *)ctx->gclist.p, (unsigned *)ctx->gtable.p,
+                                       (const unsigned *)ctx->gspan_keys.p, (const unsigned *)ctx->gspan_tails.p,
+                                       (const GardnerSpanRow *)ctx->gspan_rows.p, d_sc->gstats);
+                }
             }
             L.end();
             // chunks per chain segment: the chain hops one segment per ~1 us of dependent L2 look-ups, the composite maps and
@@ -1410,7 +1444,7 @@ template <typename T> int run_capture(pdt_ctx *ctx, uint64_t n, int phase = RUN_
             // Long captures: the chain runs range by range; as soon as a range is through, its entry states and symbols are produced
             // on the side stream (segfill, emission -- chip-wide kernels) while the single workgroup of the chain hops on
             // (an hour at 250 ksps: chain 1.6 ms + emission 1.8 ms one after the other -> the emission behind the chain).
-            const int n_ranges = (!seg && n_groups >= 8192 && !ctx->tune.chain_one_range) ? 4 : 1;
+            const int n_ranges = (!seg && n_groups >= 8192 && GD.span == 1 && !ctx->tune.chain_one_range) ? 4 : 1;
             if ((rc = ctx->gchain.ensure(sizeof(GardnerChainState)))) return rc;
             const bool side = n_ranges > 1;
             hipStream_t st_emit = side ? ctx->stream2 : st;
@@ -1517,6 +1551,10 @@ template <typename T> int run_capture(pdt_ctx *ctx, uint64_t n, int phase = RUN_
         PL.ops.resize(ops_after_pll);
     } else if (ctx->keep_quality && !seg && n_chunks > 0) {
         // (N > 0 here; a context without a PLL run -- never -- would leave avg_phase 0)
+        if (quality_side) {                                  // the averagePhase stream is complete
+            PL.simple(OP_JOIN_RECORD);
+            PL.simple(OP_JOIN_WAIT);
+        }
         PDT_LAUNCH(256, k_chunk_info<T>, dim3((unsigned)((n_chunks + 255) / 256)), dim3(256), 0, st, (const T *)d_avgph, N, chunk, n_chunks,
                            interp, (const long long *)d_symidx, (const unsigned long long *)&d_sc->nsym, (const unsigned *)d_bitsym,
                            (const unsigned long long *)&d_sc->nbits, (ChunkInfo *)ctx->chunkinfo.p);
@@ -2148,7 +2186,7 @@ void pdt_close(pdt_ctx *ctx)
     DevBuf *bufs[] = { &ctx->pcm, &ctx->pll, &ctx->lock, &ctx->fir, &ctx->agc, &ctx->sym, &ctx->symidx, &ctx->bits, &ctx->bitsym,
                        &ctx->hits, &ctx->frames, &ctx->taps, &ctx->mag, &ctx->seams_pll, &ctx->seams_agc, &ctx->scal, &ctx->lockinfo,
                        &ctx->term, &ctx->seams_ema, &ctx->gtable, &ctx->gentries, &ctx->gcand,
-                       &ctx->gmfirst, &ctx->stiles, &ctx->gsegmap, &ctx->gsegstart, &ctx->gbands, &ctx->gclist, &ctx->agc_maps, &ctx->pll_head, &ctx->taps_rot, &ctx->pll_scratch, &ctx->tip, &ctx->stream_in, &ctx->sync_scr, &ctx->agc_raw, &ctx->packs_dev, &ctx->seg_dev, &ctx->lt_theta, &ctx->lt_phi,
+                       &ctx->gmfirst, &ctx->stiles, &ctx->gsegmap, &ctx->gsegstart, &ctx->gbands, &ctx->gclist, &ctx->gspan_keys, &ctx->gspan_tails, &ctx->gspan_rows, &ctx->gspan_items, &ctx->gspan_ctl, &ctx->agc_maps, &ctx->pll_head, &ctx->taps_rot, &ctx->pll_scratch, &ctx->tip, &ctx->stream_in, &ctx->sync_scr, &ctx->agc_raw, &ctx->packs_dev, &ctx->seg_dev, &ctx->lt_theta, &ctx->lt_phi,
                        &ctx->avgph, &ctx->term_ap, &ctx->seams_q, &ctx->chunkinfo };
     for (DevBuf *b : bufs) b->release();
     for (hipEvent_t e : ctx->event_pool) (void)hipEventDestroy(e);

@@ -1520,106 +1520,337 @@ __device__ __forceinline__ void k_gardner_table_merge(const float *__restrict__ 
 }
 
 // Rows that span several chunks (D.span > 1).  k_gardner_table* has filled row r with the exits of the row's FIRST chunk.  The
-// candidates of a chunk collapse onto a handful of trajectories, so those cells hold only a few distinct exit keys: one
-// wavefront per row walks each distinct one on through the other span - 1 chunks (one lane each, every float operation that of
-// the sequential loop, the roll-over at every chunk end included) and rewrites the row's cells as
-// exit key after the row's last chunk | symbols of all its chunks.  Scouts and candidate walks are then needed in front of every
-// span-th chunk only, and the chain hops span chunks per look-up.
-// The cells are taken in key order, 64 at a time, until the set of distinct exits holds more than 64 keys; those are walked and
-// the cells seen so far rewritten, then the sweep goes on (a later cell whose exit was already walked is walked again: rare).
-#define PDT_GSPAN_KEYS 128
-#define PDT_GSPAN_HASH 256
-template <int WIN>
-__device__ __forceinline__ void k_gardner_span(const float *__restrict__ in, GardnerParams<float> P, GardnerDomain D,
-                                               long long n_rows, const unsigned *__restrict__ cand_k,
-                                               const GardnerBand *__restrict__ bands, const unsigned *__restrict__ clist,
-                                               unsigned *__restrict__ table, unsigned *__restrict__ stats /* [0] bad */)
+// candidates of a chunk collapse onto a handful of trajectories, so those cells hold only a few distinct exit keys (thousands
+// where the timing loop is not locked -- noise in front of a pass: the scouts then list the whole domain).  Three kernels:
+//   k_gardner_span_keys   one workgroup per row: the distinct exit keys of the row's cells (a bitmap of the key domain in LDS),
+//                         written in ascending order to a shared key list, and cut into work items of up to 64 keys;
+//   k_gardner_span_walk   persistent wavefronts take the work items (an atomic cursor): one lane per key walks the
+//                         other span - 1 chunks of its row -- every float operation that of the sequential loop, the roll-over at
+//                         every chunk end included -- and leaves, per key, the exit after the row's last chunk | symbols of those
+//                         chunks;
+//   k_gardner_span_join   one workgroup per row: every cell becomes  exit key after the row's last chunk | symbols of all its
+//                         chunks  (the key's place in the row's sorted key list by binary search).
+// Scouts and candidate walks are then needed in front of every span-th chunk only, and the chain hops span chunks per look-up.
+// A row whose keys do not fit the shared list any more is left untabulated (its band is emptied: the chain walks it).
+#define PDT_GSPAN_BITMAP_WORDS 8192              // 2 n_q <= 262 144 keys
+// (Measured at an hour of 250 ksps, 5 625 rows of ~20 distinct exits: one row per wavefront 2.7 ms; four rows per wavefront,
+// 16 keys each, 3.6 ms -- the walk of a lone wavefront is bound by the latency of its symbol step, ~600 clocks, not by issue slots,
+// so what counts is the number of resident wavefronts.  The same packing for the emission: 2.65 against 2.4 ms.)
+#define PDT_GSUB 1                                   // rows per wavefront
+#define PDT_GSUB_WIN 2048                            // LDS window (floats)
+#define PDT_GSUB_KEYS (64 / PDT_GSUB)                // keys per work item
+struct GardnerSpanRow { unsigned off, n; };     // the row's keys: [off, off + n) of the key list; n = ~0u: not tabulated
+struct GardnerSpanItem { unsigned row, first, cnt; };
+struct GardnerSpanCtl { unsigned keys, items, cursor, overflow; };
+
+__device__ __forceinline__ void k_gardner_span_keys(GardnerDomain D, long long n_rows, const unsigned *__restrict__ cand_k,
+                                                    GardnerBand *__restrict__ bands, const unsigned *__restrict__ clist,
+                                                    const unsigned *__restrict__ table, unsigned *__restrict__ keys,
+                                                    unsigned cap_keys, GardnerSpanRow *__restrict__ rows,
+                                                    GardnerSpanItem *__restrict__ items, GardnerSpanCtl *__restrict__ ctl)
 {
-    __shared__ __attribute__((aligned(16))) float win[WIN];
-    __shared__ unsigned s_key[PDT_GSPAN_KEYS], s_cell[PDT_GSPAN_KEYS], s_hash[PDT_GSPAN_HASH], s_hidx[PDT_GSPAN_HASH];
-    __shared__ unsigned s_n;
-    __shared__ float s_ref[3];
+    __shared__ unsigned s_bits[PDT_GSPAN_BITMAP_WORDS];
+    __shared__ unsigned s_scan[256];
+    __shared__ unsigned s_off, s_item;
     const long long r = blockIdx.x;
-    if (r >= n_rows || D.span <= 1) return;
+    if (r >= n_rows) return;
+    const long long c0 = r * D.span;
+    const GardnerBand bd = bands[r];
+    const unsigned *cand = bd.listed ? (clist + (size_t)r * PDT_GTAB_LIST) : cand_k;
+    const unsigned *row = table + (size_t)r * (size_t)(2 * D.n_q);
+    const int tid = threadIdx.x;
+    const int n_words = (2 * D.n_q + 31) >> 5;
+    const unsigned kmask = (1u << D.idx_bits) - 1u;
+    for (int t = tid; t < n_words; t += 256) s_bits[t] = 0u;
+    __syncthreads();
+    for (int j = bd.j_lo + tid; j < bd.j_hi; j += 256) {
+        const unsigned cell = row[(c0 == 0) ? 0u : cand[j]];            // (chunk 0: the single start state is cell 0)
+        if (cell != PDT_GTAB_MISS) {
+            const unsigned k1 = cell & kmask;
+            atomicOr(&s_bits[k1 >> 5], 1u << (k1 & 31u));
+        }
+    }
+    __syncthreads();
+    // every thread owns a contiguous range of words: count, scan, write in ascending key order
+    const int per = (n_words + 255) / 256;
+    const int w0 = tid * per, w1 = (w0 + per < n_words) ? w0 + per : n_words;
+    unsigned mine = 0;
+    for (int t = w0; t < w1; t++) mine += (unsigned)__popc(s_bits[t]);
+    s_scan[tid] = mine;
+    __syncthreads();
+    for (int d = 1; d < 256; d <<= 1) {
+        const unsigned v = (tid >= d) ? s_scan[tid - d] : 0u;
+        __syncthreads();
+        s_scan[tid] += v;
+        __syncthreads();
+    }
+    const unsigned total = s_scan[255];
+    if (tid == 0) {
+        unsigned off = atomicAdd(&ctl->keys, total);
+        if (off + total > cap_keys) {
+            off = ~0u;
+            atomicAdd(&ctl->overflow, 1u);
+        } else
+            s_item = atomicAdd(&ctl->items, (total + (unsigned)PDT_GSUB_KEYS - 1u) / (unsigned)PDT_GSUB_KEYS);
+        s_off = off;
+    }
+    __syncthreads();
+    const unsigned off = s_off;
+    if (off == ~0u) {
+        if (tid == 0) {
+            GardnerSpanRow rw;
+            rw.off = 0; rw.n = ~0u;
+            rows[r] = rw;
+            GardnerBand nb = bd;                                         // no key of this row is tabulated any more
+            nb.k_lo = 1u; nb.k_hi = 0u;
+            bands[r] = nb;
+        }
+        return;
+    }
+    unsigned at = off + s_scan[tid] - mine;
+    for (int t = w0; t < w1; t++) {
+        unsigned bits = s_bits[t];
+        while (bits) {
+            const int b = __ffs((int)bits) - 1;
+            bits &= bits - 1u;
+            keys[at++] = ((unsigned)t << 5) + (unsigned)b;
+        }
+    }
+    for (unsigned q = tid; q < (total + (unsigned)PDT_GSUB_KEYS - 1u) / (unsigned)PDT_GSUB_KEYS; q += 256u) {
+        GardnerSpanItem it;
+        it.row = (unsigned)r;
+        it.first = off + (unsigned)PDT_GSUB_KEYS * q;
+        it.cnt = (total - (unsigned)PDT_GSUB_KEYS * q < (unsigned)PDT_GSUB_KEYS) ? total - (unsigned)PDT_GSUB_KEYS * q : (unsigned)PDT_GSUB_KEYS;
+        items[s_item + q] = it;
+    }
+    if (tid == 0) {
+        GardnerSpanRow rw;
+        rw.off = off; rw.n = total;
+        rows[r] = rw;
+    }
+}
+
+// A wavefront as NSUB sub-groups of 64 / NSUB lanes, each sub-group in a chunk of its own (of another row / group): the
+// walk of a chunk by a wavefront costs the same whether one lane or all of them carry a trajectory, and a row has only a
+// handful -- so four rows share the instruction stream.  All chunks are full ones, so the window schedule (and with it every
+// loop bound) is the same for all sub-groups; only the window a lane reads from is its sub-group's.  EMIT: the sub-group's first
+// lane also stores every symbol (value, global sample index) at sym_at + its running count.
+template <int WIN, int NSUB, bool EMIT>
+__device__ __forceinline__ void gardner_sub_chunk(float *win, const float *__restrict__ in, const GardnerParams<float> &P,
+                                                  const long long (&c_sub)[NSUB], GardnerLane &L, float *__restrict__ sym,
+                                                  long long *__restrict__ symidx, long long sym_at, long long sym_cap)
+{
+    constexpr int SUBW = 64 / NSUB;
+    const int lane = (int)threadIdx.x;
+    const int mysub = lane / SUBW;
+    const bool leader = EMIT && (lane % SUBW) == 0 && L.active;
+    const long long C = P.chunk_out;
+    const int n_cur = (int)C;
+    const float hs = (float)((double)P.step / 2.0);
+    const float kp = P.kp, lim = P.lim, step = P.step, nT = (float)n_cur;
+    const int margin = 2 * (int)step + 24;          // look-ahead the staged data must cover past a stop point
+    const int back = (int)step + 8;                 // a mid-point lies at most this far behind a stop point
+    long long my_base = 0;
+#pragma unroll
+    for (int u = 0; u < NSUB; u++) my_base = (mysub == u) ? c_sub[u] * C : my_base;
+    int wbase = 0;
+    float enter_hi = step + 1.2f;                   // upper bound of ns when entering the window
+    auto emit = [&](float cur, unsigned i_cur) {
+        if (leader) {
+            const long long k = sym_at + (long long)L.count;
+            if (k < sym_cap) {
+                sym[k] = cur;
+                symidx[k] = my_base + (long long)i_cur;
+            }
+        }
+    };
+#pragma unroll 1
+    for (;;) {
+        __syncthreads();
+        if (wbase + WIN <= n_cur) {
+            // a window inside the chunk: 16-byte loads (the chunk's samples are 4-byte aligned only), no test
+            struct __attribute__((packed, aligned(4))) Q { float v[4]; };
+#pragma unroll
+            for (int u = 0; u < NSUB; u++) {
+                const float *src = in + c_sub[u] * C + wbase;
+                float *wu = win + u * WIN;
+#pragma unroll
+                for (int v = 0; v < WIN / 256; v++) {
+                    const int t = (v * 64 + lane) * 4;
+                    const Q r = *reinterpret_cast<const Q *>(src + t);
+                    *reinterpret_cast<float4 *>(wu + t) = make_float4(r.v[0], r.v[1], r.v[2], r.v[3]);
+                }
+            }
+        } else {
+            // the chunk's last window: the samples, then the few values the sampler can ask for past the end (Q3)
+#pragma unroll 1
+            for (int t = lane; t < NSUB * WIN; t += 64) {
+                const int u = t / WIN, tt = t - u * WIN;
+                long long cu = c_sub[0];
+#pragma unroll
+                for (int q = 1; q < NSUB; q++) cu = (u == q) ? c_sub[q] : cu;
+                const int idx = wbase + tt;
+                float r = 0.0f;
+                if (idx < n_cur) r = in[cu * C + idx];
+                else if (idx < n_cur + margin) r = gardner_beyond(in, (const float *)nullptr, P, cu, (long long)n_cur, (long long)idx);
+                win[t] = r;
+            }
+        }
+        __syncthreads();
+        const int wend = wbase + WIN;
+        const bool last_window = (wend - margin >= n_cur);
+        const float stop = last_window ? nT : (float)(wend - margin);    // lanes leave the window at rint(ns) >= stop
+        const float *wrel = win + mysub * WIN - wbase;                    // indexed with chunk-relative indices
+        if (wbase == 0) {
+            // first symbol: the mid-point index is the stale one of the previous chunk (Q3)
+            const float rn = __builtin_rintf(L.ns);
+            const unsigned i_cur = (unsigned)rn;
+            const unsigned i_half = (unsigned)__builtin_rintf(L.half);
+            const float cur = wrel[i_cur];
+            float mid;
+            if (i_half < (unsigned)WIN) mid = wrel[i_half];
+            else mid = (i_half < (unsigned)n_cur) ? in[my_base + i_half]
+                                                  : gardner_beyond(in, (const float *)nullptr, P, my_base / C, (long long)n_cur, (long long)i_half);
+            emit(cur, i_cur);
+            const float err = __builtin_amdgcn_fmed3f(kp * (cur - L.prev) * mid, -lim, lim);
+            L.ns = L.ns - err;
+            L.q_last = L.ns;
+            L.half = L.ns + hs;
+            L.ns = L.ns + step;
+            L.prev = cur;
+            L.i_last = i_cur;
+            L.count += 1;
+        }
+        int k_min = (int)((stop - 4.0f - enter_hi) / (step + 0.101f)) - 1;
+        if (k_min < 0) k_min = 0;
+        for (int it = 0; it < k_min; it++) {
+            if (EMIT) {
+                const int ic = rint_index(L.ns);
+                const float cur = wrel[ic];
+                const float mid = wrel[rint_index(L.half)];
+                emit(cur, (unsigned)ic);
+                const float err = __builtin_amdgcn_fmed3f(kp * (cur - L.prev) * mid, -lim, lim);
+                L.ns = L.ns - err;
+                L.half = L.ns + hs;
+                L.ns = L.ns + step;
+                L.prev = cur;
+                L.count += 1;
+            } else
+                gardner_lane_step(L, wrel, kp, lim, hs, step);
+        }
+        if (!EMIT) L.count += (unsigned)k_min;
+        for (;;) {
+            const float rn = __builtin_rintf(L.ns);
+            if (!(rn < stop)) break;
+            const float cur = wrel[(int)rn];
+            const float mid = wrel[rint_index(L.half)];
+            emit(cur, (unsigned)rn);
+            const float err = __builtin_amdgcn_fmed3f(kp * (cur - L.prev) * mid, -lim, lim);
+            L.ns = L.ns - err;
+            L.q_last = L.ns;
+            L.half = L.ns + hs;
+            L.ns = L.ns + step;
+            L.prev = cur;
+            L.i_last = (unsigned)rn;
+            L.count++;
+        }
+        if (last_window) break;
+        enter_hi = stop + step + 1.2f;
+        wbase = wend - margin - back;
+    }
+}
+
+
+template <int WIN>
+__device__ __forceinline__ void k_gardner_span_walk(const float *__restrict__ in, GardnerParams<float> P, GardnerDomain D,
+                                                    const unsigned *__restrict__ keys, const GardnerSpanItem *__restrict__ items,
+                                                    GardnerSpanCtl *__restrict__ ctl, unsigned *__restrict__ tails)
+{
+    __shared__ __attribute__((aligned(16))) float win[PDT_GSUB * WIN];
+    __shared__ float s_ref[3];
+    __shared__ unsigned s_next;
+    const int lane = threadIdx.x;
+    const int mysub = lane / PDT_GSUB_KEYS, sublane = lane % PDT_GSUB_KEYS;
+    const float nT = (float)P.chunk_out;
+    const unsigned n_items = ctl->items;                                 // (final: the key kernel has finished)
+    for (;;) {
+        __syncthreads();
+        if (lane == 0) s_next = atomicAdd(&ctl->cursor, (unsigned)PDT_GSUB);
+        __syncthreads();
+        const unsigned q0 = s_next;
+        if (q0 >= n_items) break;
+        // sub-group u takes item q0 + u; the ones past the end shadow item q0
+        long long c_sub[PDT_GSUB];
+        GardnerSpanItem mine = items[q0];
+#pragma unroll
+        for (int u = 0; u < PDT_GSUB; u++) {
+            const GardnerSpanItem it = (q0 + (unsigned)u < n_items) ? items[q0 + u] : items[q0];
+            c_sub[u] = (long long)it.row * D.span + 1;
+            if (mysub == u) {
+                mine = it;
+                if (q0 + (unsigned)u >= n_items) mine.cnt = 0;
+            }
+        }
+        GardnerLane L;
+        L.q_last = 0; L.i_last = 0; L.count = 0; L.k = 0;
+        L.active = (unsigned)sublane < mine.cnt;
+        L.ns = L.prev = L.half = 0;
+        long long my_c = 0;
+#pragma unroll
+        for (int u = 0; u < PDT_GSUB; u++) my_c = (mysub == u) ? c_sub[u] : my_c;
+        if (L.active) gardner_entry_from_candidate(in, P, D, my_c, (int)keys[mine.first + sublane], L.ns, L.prev, L.half);
+        if (lane == 0) { s_ref[0] = L.ns; s_ref[1] = L.prev; s_ref[2] = L.half; }       // (item q0's first key: always there)
+        __syncthreads();
+        // idle lanes start from that state, over their own sub-group's samples: whatever the samples, a symbol step advances by
+        // step +- 0.1, so they stay inside the staged windows like everybody else
+        if (!L.active) { L.ns = s_ref[0]; L.prev = s_ref[1]; L.half = s_ref[2]; }
+        for (int g = 1; g < D.span; g++) {
+            long long cc[PDT_GSUB];
+#pragma unroll
+            for (int u = 0; u < PDT_GSUB; u++) cc[u] = c_sub[u] + (g - 1);
+            gardner_sub_chunk<WIN, PDT_GSUB, false>(win, in, P, cc, L, nullptr, nullptr, 0, 0);
+            if (g + 1 < D.span) L.ns = L.ns - nT;                         // roll over; `half` is deliberately not (Q3)
+        }
+        if (L.active) tails[mine.first + sublane] = gardner_encode_exit(D, L.q_last, L.i_last, L.count);
+    }
+}
+
+__device__ __forceinline__ void k_gardner_span_join(GardnerDomain D, long long n_rows, const unsigned *__restrict__ cand_k,
+                                                    const GardnerBand *__restrict__ bands, const unsigned *__restrict__ clist,
+                                                    unsigned *__restrict__ table, const unsigned *__restrict__ keys,
+                                                    const unsigned *__restrict__ tails, const GardnerSpanRow *__restrict__ rows,
+                                                    unsigned *__restrict__ stats /* [0] bad */)
+{
+    const long long r = blockIdx.x;
+    if (r >= n_rows) return;
+    const GardnerSpanRow rw = rows[r];
+    if (rw.n == ~0u) return;
     const long long c0 = r * D.span;
     const GardnerBand bd = bands[r];
     const unsigned *cand = bd.listed ? (clist + (size_t)r * PDT_GTAB_LIST) : cand_k;
     unsigned *row = table + (size_t)r * (size_t)(2 * D.n_q);
-    const int lane = threadIdx.x;
     const unsigned kmask = (1u << D.idx_bits) - 1u;
-    const float nT = (float)P.chunk_out;
-    int pos = bd.j_lo;                                     // position in the row's candidate list
-    while (pos < bd.j_hi) {
-        // ---- the next cells' distinct exit keys
-        __syncthreads();
-        for (int t = lane; t < PDT_GSPAN_HASH; t += 64) s_hash[t] = 0xffffffffu;
-        if (lane == 0) s_n = 0;
-        __syncthreads();
-        int pos2 = pos;
-        for (;;) {
-            const int j = pos2 + lane;
-            unsigned cell = PDT_GTAB_MISS;
-            if (j < bd.j_hi) cell = row[(c0 == 0) ? 0u : cand[j]];          // (chunk 0: the single start state is cell 0)
-            if (cell != PDT_GTAB_MISS) {
-                const unsigned key = cell & kmask;
-                unsigned h = (key * 2654435761u) >> 24;          // 8 bits
-                for (;;) {
-                    const unsigned old = atomicCAS(&s_hash[h], 0xffffffffu, key);
-                    if (old == 0xffffffffu) {
-                        const unsigned idx = atomicAdd(&s_n, 1u);
-                        s_key[idx] = key;
-                        s_hidx[h] = idx;
-                        break;
-                    }
-                    if (old == key) break;
-                    h = (h + 1) & (PDT_GSPAN_HASH - 1);
-                }
-            }
-            __syncthreads();
-            pos2 += 64;
-            const unsigned n_now = s_n;
-            __syncthreads();
-            if (pos2 >= bd.j_hi || n_now + 64u > PDT_GSPAN_KEYS) break;
+    for (int j = bd.j_lo + (int)threadIdx.x; j < bd.j_hi; j += (int)blockDim.x) {
+        const unsigned k = (c0 == 0) ? 0u : cand[j];
+        const unsigned cell = row[k];
+        if (cell == PDT_GTAB_MISS) continue;
+        const unsigned k1 = cell & kmask;
+        unsigned lo = 0, hi = rw.n;                                      // first key >= k1 (it is there)
+        while (lo < hi) {
+            const unsigned mid = (lo + hi) >> 1;
+            if (keys[rw.off + mid] < k1) lo = mid + 1;
+            else hi = mid;
         }
-        const int n_keys = (int)s_n;
-        // ---- walk them through chunks c0 + 1 .. c0 + span - 1, 64 at a time
-        for (int k0 = 0; k0 < n_keys; k0 += 64) {
-            GardnerLane L[1];
-            L[0].q_last = 0; L[0].i_last = 0; L[0].count = 0; L[0].k = 0;
-            L[0].active = (k0 + lane) < n_keys;
-            L[0].ns = L[0].prev = L[0].half = 0;
-            if (L[0].active) gardner_entry_from_candidate(in, P, D, c0 + 1, (int)s_key[k0 + lane], L[0].ns, L[0].prev, L[0].half);
-            __syncthreads();
-            if (lane == 0) { s_ref[0] = L[0].ns; s_ref[1] = L[0].prev; s_ref[2] = L[0].half; }
-            __syncthreads();
-            if (!L[0].active) { L[0].ns = s_ref[0]; L[0].prev = s_ref[1]; L[0].half = s_ref[2]; }   // idle lanes shadow lane 0
-            for (int g = 1; g < D.span; g++) {
-                gardner_lanes_chunk<64, WIN, 1>(win, in, P, c0 + g, L);
-                if (g + 1 < D.span) L[0].ns = L[0].ns - nT;           // roll over; `half` is deliberately not (Q3)
-            }
-            if (L[0].active) s_cell[k0 + lane] = gardner_encode_exit(D, L[0].q_last, L[0].i_last, L[0].count);
-        }
-        __syncthreads();
-        // ---- rewrite the cells of positions [pos, pos2)
-        for (int j = pos + lane; j < pos2 && j < bd.j_hi; j += 64) {
-            const unsigned k = (c0 == 0) ? 0u : cand[j];
-            const unsigned cell = row[k];
-            if (cell == PDT_GTAB_MISS) continue;
-            const unsigned key = cell & kmask;
-            unsigned h = (key * 2654435761u) >> 24;
-            int probes = 0;
-            while (s_hash[h] != key && probes < PDT_GSPAN_HASH) { h = (h + 1) & (PDT_GSPAN_HASH - 1); probes++; }
-            if (probes >= PDT_GSPAN_HASH) continue;                    // (cannot happen: every listed cell was hashed above)
-            const unsigned tail = s_cell[s_hidx[h]];
-            unsigned out = PDT_GTAB_MISS;
+        unsigned out = PDT_GTAB_MISS;
+        if (lo < rw.n && keys[rw.off + lo] == k1) {
+            const unsigned tail = tails[rw.off + lo];
             if (tail != PDT_GTAB_MISS) {
                 const unsigned cnt = (cell >> D.idx_bits) + (tail >> D.idx_bits);
                 if (cnt < (1u << (32 - D.idx_bits)) - 1u) out = (tail & kmask) | (cnt << D.idx_bits);
             }
-            if (out == PDT_GTAB_MISS) atomicAdd(&stats[0], 1u);
-            row[k] = out;
         }
-        pos = pos2;
+        if (out == PDT_GTAB_MISS) atomicAdd(&stats[0], 1u);
+        row[k] = out;
     }
 }
 

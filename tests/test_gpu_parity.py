@@ -368,6 +368,30 @@ def test_250ksps_capture_matches_oracle(pdt, orc):
     assert all(i is not None for i in idx) and idx == list(range(idx[0], idx[0] + len(idx)))
 
 
+def test_spans_over_noise_and_overflowing_key_lists(pdt, orc):
+    """Rows whose scouts do not settle (noise in front of the signal: the whole boundary-state domain is listed, thousands of
+    distinct exits per row) go through the same three span kernels; with a key list too small for them (PDT_GSPAN_CAP) such rows
+    are left untabulated and the chain walks them."""
+    fs = 250000
+    rng = np.random.default_rng(15)
+    noise = np.clip(np.rint(rng.normal(0, 900, (int(1.0 * fs), 2))), -32768, 32767).astype("<i2")
+    iq = np.ascontiguousarray(np.concatenate([noise, pdt.synth_capture(0, fs, 5.0, seed=48)]))
+    o = orc.Oracle(orc.POES, fs, iq)
+    for env in ({"PDT_GSPAN": "8"}, {"PDT_GSPAN": "8", "PDT_GSPAN_CAP": "2000"}, {"PDT_GSPAN": "3"}):
+        os.environ.update(env)
+        try:
+            with pdt.Demodulator(pdt.MODE_POES, fs) as d:
+                d.demod(iq)
+                check_all_stages(pdt, orc, d, o)
+                st = d.stats()
+                assert st.gardner_parallel == 1 and st.gardner_full_domain > 0
+                if "PDT_GSPAN_CAP" in env:
+                    assert st.gardner_walked > 0
+        finally:
+            for k in env:
+                del os.environ[k]
+
+
 @pytest.mark.parametrize("fs,secs,chunk,span", [(250000, 12.0, 0, 4), (250000, 12.0, 0, 16), (250000, 9.0, 2500, 7),
                                                 (50000, 30.0, 1000, 16), (250000, 12.02, 0, 3), (100000, 6.0, 3000, 2)])
 def test_table_rows_spanning_several_chunks(pdt, orc, fs, secs, chunk, span):
