@@ -759,7 +759,11 @@ template <typename T> int run_capture(pdt_ctx *ctx, uint64_t n, int phase = RUN_
         // for the extra 1.6 tau of warm-up): short captures get away with less than 0.3 s, hour-long ones need a little more.
         const double tau = 2.0 / (double)PP.alpha_trk;
         const double nb = std::max(1.0, (double)N / (double)std::max<long long>(1, Bp));
-        double w = 2.82 * tau * log(2000.0 * nb);      // 200 nb exp(-w / 2.82 tau) = 0.1 expected unhealthy seams per capture
+        // 200 nb exp(-w / 2.82 tau) = 0.1 expected unhealthy seams per capture.  (Round 3, an hour of 250 ksps, 61 000 blocks:
+        // warm-up x1 / 0.85 / 0.7 / 0.55 -> 1 / 1 / 52 / 837 repairs, phase kernel 7.6 / 6.7 / 6.0 / 5.2 ms, repairs 1.4 / 1.2 / 2.0 /
+        // 10.0 ms -- but the law with 50 in place of 2000 (x0.8) turned the same capture at six times the noise from 26 repairs in
+        // 3 ms into 315 in 202 ms: where the loop barely contracts every open seam starts a cascade.  The long warm-up stays.)
+        double w = 2.82 * tau * log(2000.0 * nb);
         w *= ctx->tune.pll_warm_scale;
         Wp = (long long)std::min(std::max(w, 0.15 * fs_d), 0.6 * fs_d);
     }
@@ -1258,6 +1262,8 @@ template <typename T> int run_capture(pdt_ctx *ctx, uint64_t n, int phase = RUN_
         } else
         PDT_LAUNCH(1024, k_agc_guess<T>, dim3(1), dim3(1024), 0, st, (const AgcMap *)d_maps, nb, (const T *)d_norm, d_guess,
                            fused ? (int)agc_maps_per_block : 1, fused ? fused_tiles : nb);
+        // (Round 3: walkers that store only the gain in front of every 16-sample batch + a streaming kernel that applies them were
+        // slower, 4.2 against 3.3 ms at an hour of 250 ksps: the walkers are not held up by their output stores.)
         PDT_LAUNCH(64, k_agc_block<T>, dim3((unsigned)grid), dim3(64), 0, st, a_in, na, APs, d_norm, Ba, Wa,
                            (const double *)d_guess, a_lock, a_out, (AgcSeam<T> *)ctx->seams_agc.p, agc_K);
         L.end();
@@ -1458,7 +1464,9 @@ template <typename T> int run_capture(pdt_ctx *ctx, uint64_t n, int phase = RUN_
                                    (const unsigned *)ctx->gtable.p, (const GardnerSegCell *)ctx->gsegmap.p, G,
                                    (GardnerSegStart *)ctx->gsegstart.p, (GardnerEntry<float> *)ctx->gentries.p, d_sc->gstats,
                                    (const GardnerBand *)ctx->gbands.p, n_tab, tab_carry, (seg && seg->have_sampler) ? 1 : 0, c_hi,
-                                   (GardnerChainState *)ctx->gchain.p, r == 0 ? 1 : 0);
+                                   (GardnerChainState *)ctx->gchain.p, r == 0 ? 1 : 0,
+                                   (const unsigned *)(GD.span > 1 ? ctx->gspan_keys.p : nullptr), (const unsigned *)(GD.span > 1 ? ctx->gspan_tails.p : nullptr),
+                                   (const GardnerSpanRow *)(GD.span > 1 ? ctx->gspan_rows.p : nullptr));
                 L.end();
                 if (side) PL.simple(OP_FORK);
                 const long long s_lo = c_lo / G, s_hi = (c_hi + G - 1) / G;

@@ -1926,7 +1926,10 @@ __device__ __forceinline__ void k_gardner_chain(const float *__restrict__ in, Ga
                                                                         const GardnerBand *__restrict__ bands, long long n_tab,
                                                                         SamplerCarry<float> carry, int have_carry,
                                                                         long long c_stop /* a multiple of G, or n_chunks */,
-                                                                        GardnerChainState *__restrict__ state, int first)
+                                                                        GardnerChainState *__restrict__ state, int first,
+                                                                        const unsigned *__restrict__ span_keys /* D.span > 1: the rows' */,
+                                                                        const unsigned *__restrict__ span_tails /* distinct first-chunk exits */,
+                                                                        const GardnerSpanRow *__restrict__ span_rows /* and where they lead */)
 {
     __shared__ float win[GardnerLds<float>::LEN];
     if (first) {   // statistics of the scouts: candidates evaluated ([3]) and chunks tabulated over the full domain ([1])
@@ -1995,11 +1998,36 @@ __device__ __forceinline__ void k_gardner_chain(const float *__restrict__ in, Ga
         cell = uniform<unsigned>(cell);
         if (cell == PDT_GTAB_MISS) {
             long long cnt = 0;                               // (a group that has a successor consists of full chunks)
-            for (long long cc = c * D.span; cc < (c + 1) * D.span; cc++)
+            bool through = false;
+            for (long long cc = c * D.span; cc < (c + 1) * D.span && !through; cc++) {
                 cnt += gardner_walk_chunk<float, false, GardnerLds<float>::LEN, GardnerLds<float>::OUT>(
                     in, (const float *)nullptr, P, cc, S, win, (float *)nullptr, (unsigned *)nullptr, (float *)nullptr, (long long *)nullptr, 0, 0);
+                if (cc == c * D.span && D.span > 1 && span_rows && c < n_tab) {
+                    // a row of several chunks: once through its first chunk the trajectory is, as a rule, one of the handful the
+                    // span kernels walked on from there -- the rest of the row is then one look-up
+                    const GardnerSpanRow rw = span_rows[c];
+                    const unsigned c1 = gardner_encode_exit(D, S.q_last, S.i_last, (unsigned)cnt);
+                    if (rw.n != ~0u && rw.n > 0 && c1 != PDT_GTAB_MISS) {
+                        const unsigned k1 = c1 & ((1u << D.idx_bits) - 1u);
+                        unsigned lo = 0, hi = rw.n;
+                        while (lo < hi) {
+                            const unsigned mid = (lo + hi) >> 1;
+                            if (span_keys[rw.off + mid] < k1) lo = mid + 1;
+                            else hi = mid;
+                        }
+                        if (lo < rw.n && span_keys[rw.off + lo] == k1) {
+                            const unsigned tail = span_tails[rw.off + lo];
+                            const unsigned total = (unsigned)cnt + (tail >> D.idx_bits);
+                            if (tail != PDT_GTAB_MISS && total < (1u << (32 - D.idx_bits)) - 1u) {
+                                cell = uniform<unsigned>((tail & ((1u << D.idx_bits) - 1u)) | (total << D.idx_bits));
+                                through = true;
+                            }
+                        }
+                    }
+                }
+            }
             walked++;
-            cell = gardner_encode_exit(D, S.q_last, S.i_last, (unsigned)cnt);
+            if (!through) cell = gardner_encode_exit(D, S.q_last, S.i_last, (unsigned)cnt);
             if (cell == PDT_GTAB_MISS) {
                 // the exit is not a tabulated boundary state (irregular geometry): keep walking
                 off += cnt;

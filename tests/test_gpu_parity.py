@@ -392,6 +392,28 @@ def test_spans_over_noise_and_overflowing_key_lists(pdt, orc):
                 del os.environ[k]
 
 
+def test_chain_walks_into_a_row_and_takes_the_recorded_tail(pdt, orc):
+    """A row whose entry state lies outside the scouts' band (a very narrow band on a weak capture): the chain walks the row's
+    first chunk and, finding its exit among the distinct exits the span kernels walked on from, takes the rest of the row from
+    there -- same symbols as ever."""
+    import ctypes as C
+    fs, secs = 250000, 24.0
+    p = pdt.synth_params(0, fs, 1000.0, 91)
+    p.noise_gain = int(p.noise_gain * 4)
+    n = int(round(secs * fs))
+    iq = np.zeros((n, 2), dtype="<i2")
+    pdt.synth_lib().pdt_synth_fill(C.byref(p), 0, n, iq.ctypes.data)
+    o = orc.Oracle(orc.POES, fs, iq)
+    os.environ.update({"PDT_GSPAN": "4", "PDT_BAND_PAD": "0.002"})
+    try:
+        with pdt.Demodulator(pdt.MODE_POES, fs) as d:
+            d.demod(iq)
+            check_all_stages(pdt, orc, d, o)
+            assert d.stats().gardner_walked > 0, "no row entered outside its band on this capture: the path was not exercised"
+    finally:
+        del os.environ["PDT_GSPAN"], os.environ["PDT_BAND_PAD"]
+
+
 @pytest.mark.parametrize("fs,secs,chunk,span", [(250000, 12.0, 0, 4), (250000, 12.0, 0, 16), (250000, 9.0, 2500, 7),
                                                 (50000, 30.0, 1000, 16), (250000, 12.02, 0, 3), (100000, 6.0, 3000, 2)])
 def test_table_rows_spanning_several_chunks(pdt, orc, fs, secs, chunk, span):

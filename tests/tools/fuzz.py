@@ -30,6 +30,9 @@ for case in range(n_cases):
     p = pdt.synth_params(kind, fs, f0, int(rng.integers(1, 1 << 30)))
     p.noise_gain = int(p.noise_gain * float(rng.choice([1, 1, 1, 2, 4, 7])))
     n = int(round(secs * fs))
+    lead = float(rng.random())
+    if not argos and lead < 0.2:
+        p.signal_start = int(n * lead * 2.0)                   # noise in front of the signal (up to 40 % of the capture)
     iq = np.zeros((n, 2), dtype="<i2")
     pdt.synth_lib().pdt_synth_fill(C.byref(p), 0, n, iq.ctypes.data)
     if rng.random() < 0.15:
@@ -41,11 +44,15 @@ for case in range(n_cases):
                   agc_block=int(rng.integers(64, 12000)), agc_warm=int(rng.integers(0, 40000)))
     if rng.random() < 0.2:
         kw["gardner_band_pad"] = float(rng.choice([1 / 512, 1 / 64, 0.5]))
+    span = int(rng.choice([0, 0, 0, 2, 3, 4, 8, 16]))         # table rows of several chunks (what hour-long captures take by default)
     if only >= 0 and case != only:
         rng.choice([2400, 5000, 12345, 777, 300, 1554])                              # (the streaming block size drawn further down)
         continue
     o = orc.Oracle(omode, fs, iq, chunk=chunk, sampler=sampler, math_mode=orc.MATH_LIBM)
+    if span:
+        os.environ["PDT_GSPAN"] = str(span)
     d = pdt.Demodulator(mode, fs, chunk=chunk, sampler=sampler, **kw)
+    os.environ.pop("PDT_GSPAN", None)
     d.demod(iq)
     ok = d.text() == o.text()
     for sg, so in ((pdt.ST_PLL, orc.ST_PLL), (pdt.ST_FIR, orc.ST_FIR), (pdt.ST_AGC, orc.ST_AGC), (pdt.ST_SYM, orc.ST_SYM),
@@ -82,6 +89,6 @@ for case in range(n_cases):
     d.close()
     bad += 0 if ok else 1
     print(f"{'ok  ' if ok else 'FAIL'} case {case}: {'argos' if argos else 'poes'} fs {fs} n {len(iq)} chunk {chunk} f0 {f0:.0f} noise x{p.noise_gain} "
-          f"sampler {sampler} geom {kw} frames {s.frames} pllfix {s.pll_seam_fixes} par {s.gardner_parallel} walked {s.gardner_walked}", flush=True)
+          f"sampler {sampler} span {span} lead {p.signal_start} geom {kw} frames {s.frames} pllfix {s.pll_seam_fixes} par {s.gardner_parallel} walked {s.gardner_walked}", flush=True)
 print(f"{n_cases - bad}/{n_cases} identical in {time.time() - t_start:.0f} s")
 sys.exit(1 if bad else 0)
