@@ -160,3 +160,19 @@ def test_gather_library_exports_its_entry_point(pdt):
     assert "librccl" not in subprocess.run(["readelf", "-d", pdt.LIBPDT_PATH], capture_output=True, text=True).stdout
     syms = subprocess.run(["nm", "-D", "--defined-only", path], capture_output=True, text=True).stdout
     assert " T pdt_gather_frames" in syms
+
+
+def test_compat_libraries_export_the_reference_prototypes(pdt):
+    """libpdt_compat_{poes,argos}.so (host/pdt_compat.c): every live stage function of common/*.h and the per-program byte
+    synchroniser is there under the reference's own name (no compute call without a GPU: symbols only)."""
+    import ctypes
+    csrc = os.path.dirname(pdt.LIBPDT_PATH)
+    ctypes.CDLL(pdt.LIBPDT_PATH, mode=ctypes.RTLD_GLOBAL)
+    common = ["StaticGain", "NormalizingAGC", "Squelch", "CarrierTrackPLL", "LowPassFilterInterp", "LowPassFilter", "MakeLPFIR",
+              "GardenerClockRecovery", "MMClockRecovery", "sign", "ManchesterDecode"]
+    for name, own in (("libpdt_compat_poes.so", "ByteSyncOnSyncword"), ("libpdt_compat_argos.so", "FindSyncWords")):
+        path = os.path.join(csrc, name)
+        assert os.path.exists(path), f"{name} not built (make)"
+        lib = ctypes.CDLL(path)
+        for sym in common + [own]:
+            assert hasattr(lib, sym), f"{name}: {sym}"
