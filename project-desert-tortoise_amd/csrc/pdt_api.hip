@@ -239,7 +239,7 @@ struct Plan {
 struct Tuning {
     double band_pad = 0.0, pll_warm_scale = 1.0, head_taus = 0.0, agc_k = 0.0, pll_warm_s = 0.0, agc_warm_s = 0.0;
     int scout_syms = 0, gspan = 0, gspan_cap = 0, ingest_threads = 0, ingest_span_mb = 0, ingest_streams = 0, overlap_segments = 0, overlap_min_mb = 0, fir_wg_per_cu = 0, agc_tpb = 0, gseg = 0, acquire_mode = 0, pll_block = 0, fix_passes = 2;      // acquire_mode: 0 = two-wavefront pipeline, 1 = plain one-lane, 2 = one wavefront
-    bool fir_generic = false, mix_unfused = false, quality_inline = false, agc_unfused = false, no_excl = false, gtab_nomerge = false, gardner_onebuf = false, gardner_noring = false, gardner_sequential = false, seg_sequential = false, no_overlap = false, debug_overlap = false, chain_one_range = false, ema_noguess = false, debug_sync = false;
+    bool fir_generic = false, mix_unfused = false, quality_inline = false, gemit_groups = false, agc_unfused = false, no_excl = false, gtab_nomerge = false, gardner_onebuf = false, gardner_noring = false, gardner_sequential = false, seg_sequential = false, no_overlap = false, debug_overlap = false, chain_one_range = false, ema_noguess = false, debug_sync = false;
     void load()
     {
         if (const char *e = getenv("PDT_PLL_WARM_SCALE")) pll_warm_scale = atof(e);
@@ -264,6 +264,7 @@ struct Tuning {
         fir_generic = getenv("PDT_FIR_GENERIC") != nullptr;
         mix_unfused = getenv("PDT_MIX_UNFUSED") != nullptr;
         quality_inline = getenv("PDT_QUALITY_INLINE") != nullptr;
+        gemit_groups = getenv("PDT_GEMIT_GROUPS") != nullptr;
         agc_unfused = getenv("PDT_AGC_UNFUSED") != nullptr;
         no_excl = getenv("PDT_NO_EXCL") != nullptr;
         gtab_nomerge = getenv("PDT_GTAB_NOMERGE") != nullptr;
@@ -329,7 +330,7 @@ struct pdt_ctx {
     hipEvent_t ev0 = nullptr, ev1 = nullptr, ev_fork = nullptr, ev_join = nullptr;
     hipStream_t stream2 = nullptr;     // side stream: block-parallel PLL phase runs beside the sequential acquisition
 
-    DevBuf pcm, pll, lock, fir, agc, sym, symidx, bits, bitsym, hits, frames, taps, mag, seams_pll, seams_agc, scal, lockinfo, term, seams_ema, gtable, gentries, gcand, gmfirst, stiles, gsegmap, gsegstart, gbands, gclist, gneed, gchain, gspan_keys, gspan_tails, gspan_rows, gspan_items, gspan_ctl, agc_maps, pll_head, taps_rot, pll_scratch, tip, sync_scr, agc_raw;
+    DevBuf pcm, pll, lock, fir, agc, sym, symidx, bits, bitsym, hits, frames, taps, mag, seams_pll, seams_agc, scal, lockinfo, term, seams_ema, gtable, gentries, gcand, gmfirst, stiles, gsegmap, gsegstart, gbands, gclist, gneed, gchain, gspan_keys, gspan_tails, gspan_rows, gspan_items, gspan_ctl, gspan_recs, gcentries, gflags, agc_maps, pll_head, taps_rot, pll_scratch, tip, sync_scr, agc_raw;
     bool keep_agc_raw = false;   // pdt_keep_presquelch: also keep the AGC output before Squelch (stage PDT_ST_AGC_RAW)
     // pdt_keep_quality: the averagePhase stream (what CarrierTrackPLL returns, chunk by chunk) and the per-chunk counts
     bool keep_quality = false;
@@ -870,8 +871,12 @@ template <typename T> int run_capture(pdt_ctx *ctx, uint64_t n, int phase = RUN_
     // (CarrierTrackingPLL.c:80,124,152), alpha 0.00005 -> blocks of one time constant, 16 of warm-up behind the affine guess
     const bool quality = (ctx->keep_quality || inject) && !seg && N > 0;
     const T avg_alpha = (T)0.00005;
-    const long long Bq = std::max<long long>(64, round4((long long)(1.0 / (double)avg_alpha)));
-    const long long Wq = 16 * Bq;
+    // Blocks of one time constant for captures up to ~8 000 of them; longer captures get longer blocks (up to eight time
+    // constants), the warm-up stays 16 time constants: with one-time-constant blocks an hour at 250 ksps re-read its input 17
+    // times (61 GB, 18.7 ms -- and 59 ms beside the chain's kernels on the side stream); 45 000 blocks -> 8 192: 14 GB.
+    const long long tau_q = std::max<long long>(64, round4((long long)(1.0 / (double)avg_alpha)));
+    const long long Bq = std::max(tau_q, std::min(8 * tau_q, round4(N / 8192)));
+    const long long Wq = 16 * tau_q;
     const long long nb_q = N / Bq + 2;
     double *d_q_zresp = nullptr, *d_q_guess = nullptr;
     if (quality) {
@@ -1315,6 +1320,17 @@ template <typename T> int run_capture(pdt_ctx *ctx, uint64_t n, int phase = RUN_
                 if (seg || 2 * n_q > 32 * PDT_GSPAN_BITMAP_WORDS || 8 * (long long)stepf + 256 >= PDT_GSUB_WIN) span = 1;
                 while (span > 1 && ((double)span * max_count >= (double)((1u << (32 - idx_bits)) - 2u) || (n_chunks - 1) / span < 4))
                     span /= 2;
+                if (span >= 8 && !ctx->tune.gspan) {
+                    // the group behind the last row is walked by one wavefront, chunk after chunk (0.8 ms for 16 chunks): take the span
+                    // near the wanted one that leaves the fewest chunks there
+                    int best = span;
+                    long long best_left = n_chunks - ((n_chunks - 1) / span) * span;
+                    for (int sp = span - span / 4; sp <= span + span / 4; sp++) {
+                        const long long left = n_chunks - ((n_chunks - 1) / sp) * sp;
+                        if (left < best_left && (double)sp * max_count < (double)((1u << (32 - idx_bits)) - 2u)) { best = sp; best_left = left; }
+                    }
+                    span = best;
+                }
                 GD.span = span;
             }
         }
@@ -1416,6 +1432,7 @@ template <typename T> int run_capture(pdt_ctx *ctx, uint64_t n, int phase = RUN_
                     const size_t cap_items = (size_t)cap_keys / PDT_GSUB_KEYS + (size_t)n_tab + 1;
                     if ((rc = ctx->gspan_keys.ensure((size_t)cap_keys * sizeof(unsigned)))) return rc;
                     if ((rc = ctx->gspan_tails.ensure((size_t)cap_keys * sizeof(unsigned)))) return rc;
+                    if ((rc = ctx->gspan_recs.ensure((size_t)cap_keys * (size_t)(GD.span - 1) * sizeof(GardnerSpanRec)))) return rc;
                     if ((rc = ctx->gspan_rows.ensure((size_t)n_tab * sizeof(GardnerSpanRow)))) return rc;
                     if ((rc = ctx->gspan_items.ensure(cap_items * sizeof(GardnerSpanItem)))) return rc;
                     if ((rc = ctx->gspan_ctl.ensure(sizeof(GardnerSpanCtl)))) return rc;
@@ -1427,7 +1444,7 @@ template <typename T> int run_capture(pdt_ctx *ctx, uint64_t n, int phase = RUN_
                     const unsigned walkers = (unsigned)std::min<long long>(n_tab / PDT_GSUB + 64, 256ll * 16);     // persistent wavefronts (8 KiB of LDS each)
                     PDT_LAUNCH(64, (k_gardner_span_walk<PDT_GSUB_WIN>), dim3(walkers), dim3(64), 0, st, (const float *)d_agc, GP, GD,
                                        (const unsigned *)ctx->gspan_keys.p, (const GardnerSpanItem *)ctx->gspan_items.p,
-                                       (GardnerSpanCtl *)ctx->gspan_ctl.p, (unsigned *)ctx->gspan_tails.p);
+                                       (GardnerSpanCtl *)ctx->gspan_ctl.p, (unsigned *)ctx->gspan_tails.p, (GardnerSpanRec *)ctx->gspan_recs.p);
                     PDT_LAUNCH(128, k_gardner_span_join, dim3((unsigned)n_tab), dim3(128), 0, st, GD, n_tab, (const unsigned *)ctx->gcand.p,
                                        (const GardnerBand *)ctx->gbands.p, (const unsigned *)ctx->gclist.p, (unsigned *)ctx->gtable.p,
                                        (const unsigned *)ctx->gspan_keys.p, (const unsigned *)ctx->gspan_tails.p,
@@ -1476,10 +1493,27 @@ template <typename T> int run_capture(pdt_ctx *ctx, uint64_t n, int phase = RUN_
                                        (const unsigned *)ctx->gtable.p, G, (const GardnerSegStart *)ctx->gsegstart.p,
                                        (GardnerEntry<float> *)ctx->gentries.p, s_lo);
                 // per-chunk emission: small LDS windows so that every chunk of a 10-minute capture is resident at once
+                const unsigned char *d_flags = nullptr;
+                if (GD.span > 1 && 8 * (long long)GP.step + 256 < PDT_GEMIT_SUB_WIN && !ctx->tune.gemit_groups &&
+                    (double)PDT_GEMIT_SUB_WIN / ((double)GP.step - 0.2) + 2.0 < (double)PDT_GSUB_OUT) {
+                    // rows of several chunks: four CHUNKS per wavefront (k_gardner_emit_first / _rest); the groups these cannot resolve,
+                    // and the one behind the last row, go through the wavefront-per-group kernel below
+                    if ((rc = ctx->gcentries.ensure((size_t)n_chunks * sizeof(GardnerEntry<float>)))) return rc;
+                    if ((rc = ctx->gflags.ensure((size_t)n_groups + 64))) return rc;
+                    PL.memset_async(ctx->gflags.p, 1, (size_t)n_groups, PL.side_of(st_emit));
+                    PDT_LAUNCH(64, (k_gardner_emit_first<PDT_GEMIT_SUB_WIN>), dim3((unsigned)((n_tab + 3) / 4)), dim3(64), 0, st_emit, (const float *)d_agc, GP, GD,
+                                       n_tab, (const GardnerEntry<float> *)ctx->gentries.p, (const unsigned *)ctx->gspan_keys.p,
+                                       (const GardnerSpanRow *)ctx->gspan_rows.p, (const GardnerSpanRec *)ctx->gspan_recs.p,
+                                       (GardnerEntry<float> *)ctx->gcentries.p, (unsigned char *)ctx->gflags.p, (float *)d_sym, d_symidx, sym_cap);
+                    PDT_LAUNCH(64, (k_gardner_emit_rest<PDT_GEMIT_SUB_WIN>), dim3((unsigned)((n_tab * (GD.span - 1) + 3) / 4)), dim3(64), 0, st_emit,
+                                       (const float *)d_agc, GP, GD, n_tab, (const GardnerEntry<float> *)ctx->gcentries.p,
+                                       (const unsigned char *)ctx->gflags.p, (float *)d_sym, d_symidx, sym_cap);
+                    d_flags = (const unsigned char *)ctx->gflags.p;
+                }
                 if (c_hi > c_lo)
                     PDT_LAUNCH(256, (k_gardner<float, PDT_GEMIT_LEN, PDT_GEMIT_OUT>), dim3((unsigned)(c_hi - c_lo)), dim3(PDT_GARDNER_THREADS), 0, st_emit,
                                        (const float *)d_agc, (const float *)d_lock, GP, (float *)d_sym, d_symidx, &d_sc->nsym, sym_cap,
-                                       (const GardnerEntry<float> *)ctx->gentries.p, tab_carry, (SamplerCarry<float> *)d_carry_out, c_lo, GD.span);
+                                       (const GardnerEntry<float> *)ctx->gentries.p, tab_carry, (SamplerCarry<float> *)d_carry_out, c_lo, GD.span, d_flags);
                 L.end();
                 c_lo = c_hi;
             }
@@ -1526,7 +1560,7 @@ template <typename T> int run_capture(pdt_ctx *ctx, uint64_t n, int phase = RUN_
                                d_sym, d_symidx, &d_sc->nsym, sym_cap);
         else
             PDT_LAUNCH(256, (k_gardner<T, GardnerLds<T>::LEN, GardnerLds<T>::OUT>), dim3(1), dim3(256), 0, st, d_agc, d_lock, GP, d_sym, d_symidx,
-                               &d_sc->nsym, sym_cap, (const GardnerEntry<T> *)nullptr, carry_in, d_carry_out, 0ll, 1);
+                               &d_sc->nsym, sym_cap, (const GardnerEntry<T> *)nullptr, carry_in, d_carry_out, 0ll, 1, (const unsigned char *)nullptr);
         L.end();
     }
 
@@ -2194,7 +2228,7 @@ void pdt_close(pdt_ctx *ctx)
     DevBuf *bufs[] = { &ctx->pcm, &ctx->pll, &ctx->lock, &ctx->fir, &ctx->agc, &ctx->sym, &ctx->symidx, &ctx->bits, &ctx->bitsym,
                        &ctx->hits, &ctx->frames, &ctx->taps, &ctx->mag, &ctx->seams_pll, &ctx->seams_agc, &ctx->scal, &ctx->lockinfo,
                        &ctx->term, &ctx->seams_ema, &ctx->gtable, &ctx->gentries, &ctx->gcand,
-                       &ctx->gmfirst, &ctx->stiles, &ctx->gsegmap, &ctx->gsegstart, &ctx->gbands, &ctx->gclist, &ctx->gspan_keys, &ctx->gspan_tails, &ctx->gspan_rows, &ctx->gspan_items, &ctx->gspan_ctl, &ctx->agc_maps, &ctx->pll_head, &ctx->taps_rot, &ctx->pll_scratch, &ctx->tip, &ctx->stream_in, &ctx->sync_scr, &ctx->agc_raw, &ctx->packs_dev, &ctx->seg_dev, &ctx->lt_theta, &ctx->lt_phi,
+                       &ctx->gmfirst, &ctx->stiles, &ctx->gsegmap, &ctx->gsegstart, &ctx->gbands, &ctx->gclist, &ctx->gspan_keys, &ctx->gspan_tails, &ctx->gspan_rows, &ctx->gspan_items, &ctx->gspan_ctl, &ctx->gspan_recs, &ctx->gcentries, &ctx->gflags, &ctx->agc_maps, &ctx->pll_head, &ctx->taps_rot, &ctx->pll_scratch, &ctx->tip, &ctx->stream_in, &ctx->sync_scr, &ctx->agc_raw, &ctx->packs_dev, &ctx->seg_dev, &ctx->lt_theta, &ctx->lt_phi,
                        &ctx->avgph, &ctx->term_ap, &ctx->seams_q, &ctx->chunkinfo };
     for (DevBuf *b : bufs) b->release();
     for (hipEvent_t e : ctx->event_pool) (void)hipEventDestroy(e);
@@ -2723,7 +2757,7 @@ template <typename T> static int stage_gardner(pdt_ctx *ctx, const void *in_host
     }
     PDT_LAUNCH(256, (k_gardner<T, GardnerLds<T>::LEN, GardnerLds<T>::OUT>), dim3(1), dim3(256), 0, st, (const T *)d_in,
                (const T *)(GP.argos_heap ? d_nb : nullptr), GP, (T *)ctx->sym.p, (long long *)ctx->symidx.p, &d_sc->nsym, sym_cap,
-               (const GardnerEntry<T> *)nullptr, carry_in, &d_tail->sampler, 0ll, 1);
+               (const GardnerEntry<T> *)nullptr, carry_in, &d_tail->sampler, 0ll, 1, (const unsigned char *)nullptr);
     DevScalars *back = ctx->pend_sc;                                  // pinned
     PL.copy(OP_D2H, back, d_sc, sizeof(DevScalars));
     {

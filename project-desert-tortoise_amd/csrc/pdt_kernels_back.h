@@ -292,7 +292,8 @@ __device__ __forceinline__ void k_gardner(const T *__restrict__ in, const T *__r
                                                                   const GardnerEntry<T> *__restrict__ entries,
                                                                   SamplerCarry<T> carry, SamplerCarry<T> *__restrict__ carry_out,
                                                                   long long c_off /* parallel mode: group of block 0 */,
-                                                                  int span /* parallel mode: chunks per group (entries are per group); otherwise 1 */)
+                                                                  int span /* parallel mode: chunks per group (entries are per group); otherwise 1 */,
+                                                                  const unsigned char *__restrict__ flags /* parallel mode, optional: only the groups marked 1 */)
 {
     __shared__ T win[LEN];
     __shared__ T o_val[OUT];
@@ -305,6 +306,7 @@ __device__ __forceinline__ void k_gardner(const T *__restrict__ in, const T *__r
     long long c_begin = carry.c_first, c_end = n_chunks;
     if (entries) {
         const long long g = blockIdx.x + c_off;
+        if (flags && !flags[g]) return;                                      // (emitted chunk by chunk: k_gardner_emit_first / _rest)
         c_begin = g * span;
         c_end = (c_begin + span < n_chunks) ? c_begin + span : n_chunks;
         if (c_begin >= n_chunks || c_begin < carry.c_first) return;      // (a stream segment: the chunks in front are history)
@@ -1541,6 +1543,7 @@ __device__ __forceinline__ void k_gardner_table_merge(const float *__restrict__ 
 #define PDT_GSUB_KEYS (64 / PDT_GSUB)                // keys per work item
 struct GardnerSpanRow { unsigned off, n; };     // the row's keys: [off, off + n) of the key list; n = ~0u: not tabulated
 struct GardnerSpanItem { unsigned row, first, cnt; };
+struct GardnerSpanRec { float ns, prev, half; unsigned count; };   // sampler state in front of a chunk, symbols since the row's second chunk
 struct GardnerSpanCtl { unsigned keys, items, cursor, overflow; };
 
 __device__ __forceinline__ void k_gardner_span_keys(GardnerDomain D, long long n_rows, const unsigned *__restrict__ cand_k,
@@ -1635,15 +1638,21 @@ __device__ __forceinline__ void k_gardner_span_keys(GardnerDomain D, long long n
 // handful -- so four rows share the instruction stream.  All chunks are full ones, so the window schedule (and with it every
 // loop bound) is the same for all sub-groups; only the window a lane reads from is its sub-group's.  EMIT: the sub-group's first
 // lane also stores every symbol (value, global sample index) at sym_at + its running count.
+#define PDT_GSUB_OUT 64                               // symbols a sub-group can stage per window (WIN / (step - 0.1) + 2 must fit)
 template <int WIN, int NSUB, bool EMIT>
 __device__ __forceinline__ void gardner_sub_chunk(float *win, const float *__restrict__ in, const GardnerParams<float> &P,
                                                   const long long (&c_sub)[NSUB], GardnerLane &L, float *__restrict__ sym,
-                                                  long long *__restrict__ symidx, long long sym_at, long long sym_cap)
+                                                  long long *__restrict__ symidx, long long sym_at, long long sym_cap,
+                                                  float *o_val = nullptr, unsigned *o_idx = nullptr /* EMIT: LDS, NSUB x GSUB_OUT each */)
 {
     constexpr int SUBW = 64 / NSUB;
     const int lane = (int)threadIdx.x;
     const int mysub = lane / SUBW;
-    const bool leader = EMIT && (lane % SUBW) == 0 && L.active;
+    // EMIT: every lane of a sub-group carries the same trajectory; the symbols of a window are staged in LDS (all lanes write the
+    // same word: no mask) and leave with the sub-group's lanes side by side at the window's end
+    float *ov = o_val + mysub * PDT_GSUB_OUT;
+    unsigned *oi = o_idx + mysub * PDT_GSUB_OUT;
+    int nout = 0;
     const long long C = P.chunk_out;
     const int n_cur = (int)C;
     const float hs = (float)((double)P.step / 2.0);
@@ -1656,12 +1665,25 @@ __device__ __forceinline__ void gardner_sub_chunk(float *win, const float *__res
     int wbase = 0;
     float enter_hi = step + 1.2f;                   // upper bound of ns when entering the window
     auto emit = [&](float cur, unsigned i_cur) {
-        if (leader) {
-            const long long k = sym_at + (long long)L.count;
-            if (k < sym_cap) {
-                sym[k] = cur;
-                symidx[k] = my_base + (long long)i_cur;
-            }
+        if (EMIT) {
+            ov[nout] = cur;
+            oi[nout] = i_cur;
+            nout++;
+        }
+    };
+    auto flush = [&]() {
+        if (EMIT) {
+            // (the LDS words were written by this very wavefront, in program order: no barrier needed)
+            const long long k0 = sym_at + (long long)L.count - (long long)nout;
+            if (L.active)
+                for (int t = lane % SUBW; t < nout; t += SUBW) {
+                    const long long k = k0 + t;
+                    if (k < sym_cap) {
+                        sym[k] = ov[t];
+                        symidx[k] = my_base + (long long)oi[t];
+                    }
+                }
+            nout = 0;
         }
     };
 #pragma unroll 1
@@ -1723,6 +1745,7 @@ __device__ __forceinline__ void gardner_sub_chunk(float *win, const float *__res
         }
         int k_min = (int)((stop - 4.0f - enter_hi) / (step + 0.101f)) - 1;
         if (k_min < 0) k_min = 0;
+#pragma unroll 4
         for (int it = 0; it < k_min; it++) {
             if (EMIT) {
                 const int ic = rint_index(L.ns);
@@ -1754,6 +1777,7 @@ __device__ __forceinline__ void gardner_sub_chunk(float *win, const float *__res
             L.i_last = (unsigned)rn;
             L.count++;
         }
+        flush();
         if (last_window) break;
         enter_hi = stop + step + 1.2f;
         wbase = wend - margin - back;
@@ -1764,7 +1788,8 @@ __device__ __forceinline__ void gardner_sub_chunk(float *win, const float *__res
 template <int WIN>
 __device__ __forceinline__ void k_gardner_span_walk(const float *__restrict__ in, GardnerParams<float> P, GardnerDomain D,
                                                     const unsigned *__restrict__ keys, const GardnerSpanItem *__restrict__ items,
-                                                    GardnerSpanCtl *__restrict__ ctl, unsigned *__restrict__ tails)
+                                                    GardnerSpanCtl *__restrict__ ctl, unsigned *__restrict__ tails,
+                                                    GardnerSpanRec *__restrict__ recs /* per key: the state in front of each of those chunks */)
 {
     __shared__ __attribute__((aligned(16))) float win[PDT_GSUB * WIN];
     __shared__ float s_ref[3];
@@ -1808,11 +1833,119 @@ __device__ __forceinline__ void k_gardner_span_walk(const float *__restrict__ in
             long long cc[PDT_GSUB];
 #pragma unroll
             for (int u = 0; u < PDT_GSUB; u++) cc[u] = c_sub[u] + (g - 1);
+            if (L.active) {
+                GardnerSpanRec rc;
+                rc.ns = L.ns; rc.prev = L.prev; rc.half = L.half; rc.count = L.count;
+                recs[(size_t)(mine.first + sublane) * (size_t)(D.span - 1) + (size_t)(g - 1)] = rc;
+            }
             gardner_sub_chunk<WIN, PDT_GSUB, false>(win, in, P, cc, L, nullptr, nullptr, 0, 0);
             if (g + 1 < D.span) L.ns = L.ns - nT;                         // roll over; `half` is deliberately not (Q3)
         }
         if (L.active) tails[mine.first + sublane] = gardner_encode_exit(D, L.q_last, L.i_last, L.count);
     }
+}
+
+// ---- emission for rows of several chunks: four chunks per wavefront
+// The wavefront-per-group emission spends a whole wavefront's instruction stream on one trajectory.  Here a wavefront carries four
+// (quarter wavefronts, gardner_sub_chunk), and -- so that there are enough wavefronts to cover the latency of a symbol step --
+// the unit of work is a CHUNK, not a group: k_gardner_emit_first walks (and emits) the first chunk of every group from the
+// group's entry state (the chain's); its exit names the trajectory the span walkers recorded, whose states in front of the
+// group's other chunks become those chunks' entry states; k_gardner_emit_rest then takes all the other chunks, four to a
+// wavefront.  flags[g] = 1: the group could not be resolved (no table row, keys not listed, exit not among them) and goes
+// through the wavefront-per-group kernel.
+#define PDT_GEMIT_SUB_WIN 512
+template <int WIN>
+__device__ __forceinline__ void k_gardner_emit_first(const float *__restrict__ in, GardnerParams<float> P, GardnerDomain D,
+                                                     long long n_rows, const GardnerEntry<float> *__restrict__ entries,
+                                                     const unsigned *__restrict__ keys, const GardnerSpanRow *__restrict__ rows,
+                                                     const GardnerSpanRec *__restrict__ recs,
+                                                     GardnerEntry<float> *__restrict__ centries, unsigned char *__restrict__ flags,
+                                                     float *__restrict__ sym, long long *__restrict__ symidx, long long sym_cap)
+{
+    __shared__ __attribute__((aligned(16))) float win[4 * WIN];
+    const int lane = threadIdx.x;
+    const int mysub = lane >> 4;
+    const long long g0 = (long long)blockIdx.x * 4;
+    if (g0 >= n_rows) return;
+    long long c_sub[4];
+#pragma unroll
+    for (int u = 0; u < 4; u++) c_sub[u] = ((g0 + u < n_rows) ? g0 + u : g0) * D.span;      // (groups past the end shadow group g0)
+    const long long my_g = (g0 + mysub < n_rows) ? g0 + mysub : g0;
+    const GardnerEntry<float> e = entries[my_g];
+    GardnerLane L;
+    L.ns = e.ns; L.prev = e.prev; L.half = e.half; L.q_last = 0; L.i_last = 0; L.count = 0; L.k = 0;
+    L.active = g0 + mysub < n_rows;
+    __shared__ float o_val[4 * PDT_GSUB_OUT];
+    __shared__ unsigned o_idx[4 * PDT_GSUB_OUT];
+    gardner_sub_chunk<WIN, 4, true>(win, in, P, c_sub, L, sym, symidx, e.offset, sym_cap, o_val, o_idx);
+    if (L.active && (lane & 15) == 0) {
+        unsigned char flag = 1;
+        const GardnerSpanRow rw = rows[my_g];
+        const unsigned cell = gardner_encode_exit(D, L.q_last, L.i_last, L.count);
+        if (rw.n != ~0u && rw.n > 0 && cell != PDT_GTAB_MISS) {
+            const unsigned k1 = cell & ((1u << D.idx_bits) - 1u);
+            unsigned lo = 0, hi = rw.n;
+            while (lo < hi) {
+                const unsigned mid = (lo + hi) >> 1;
+                if (keys[rw.off + mid] < k1) lo = mid + 1;
+                else hi = mid;
+            }
+            if (lo < rw.n && keys[rw.off + lo] == k1) {
+                const GardnerSpanRec *rc = recs + (size_t)(rw.off + lo) * (size_t)(D.span - 1);
+                for (int q = 1; q < D.span; q++) {
+                    GardnerEntry<float> ce;
+                    ce.ns = rc[q - 1].ns; ce.prev = rc[q - 1].prev; ce.half = rc[q - 1].half;
+                    ce.offset = e.offset + (long long)L.count + (long long)rc[q - 1].count;
+                    centries[my_g * D.span + q] = ce;
+                }
+                flag = 0;
+            }
+        }
+        flags[my_g] = flag;
+    }
+}
+
+template <int WIN>
+__device__ __forceinline__ void k_gardner_emit_rest(const float *__restrict__ in, GardnerParams<float> P, GardnerDomain D,
+                                                    long long n_rows, const GardnerEntry<float> *__restrict__ centries,
+                                                    const unsigned char *__restrict__ flags, float *__restrict__ sym,
+                                                    long long *__restrict__ symidx, long long sym_cap)
+{
+    __shared__ __attribute__((aligned(16))) float win[4 * WIN];
+    const int lane = threadIdx.x;
+    const int mysub = lane >> 4;
+    const long long per = D.span - 1;                       // chunks of a group that are not its first
+    const long long total = n_rows * per;
+    const long long i0 = (long long)blockIdx.x * 4;
+    if (i0 >= total) return;
+    // the chunk of every sub-group; one whose group is flagged (or past the end) shadows a chunk that is walked -- if there is none
+    // in this wavefront, there is nothing to do
+    long long c_sub[4];
+    bool live[4];
+    long long c_any = -1;
+#pragma unroll
+    for (int u = 0; u < 4; u++) {
+        const long long i = i0 + u;
+        const long long g = (i < total) ? i / per : 0;
+        live[u] = i < total && !flags[g];
+        c_sub[u] = g * D.span + 1 + (i - g * per);
+        if (live[u] && c_any < 0) c_any = c_sub[u];
+    }
+    if (c_any < 0) return;
+#pragma unroll
+    for (int u = 0; u < 4; u++) c_sub[u] = live[u] ? c_sub[u] : c_any;
+    long long my_c = c_any;
+    bool mine_live = false;
+#pragma unroll
+    for (int u = 0; u < 4; u++)
+        if (mysub == u) { my_c = c_sub[u]; mine_live = live[u]; }
+    const GardnerEntry<float> e = centries[my_c];
+    GardnerLane L;
+    L.ns = e.ns; L.prev = e.prev; L.half = e.half; L.q_last = 0; L.i_last = 0; L.count = 0; L.k = 0;
+    L.active = mine_live;
+    __shared__ float o_val[4 * PDT_GSUB_OUT];
+    __shared__ unsigned o_idx[4 * PDT_GSUB_OUT];
+    gardner_sub_chunk<WIN, 4, true>(win, in, P, c_sub, L, sym, symidx, e.offset, sym_cap, o_val, o_idx);
 }
 
 __device__ __forceinline__ void k_gardner_span_join(GardnerDomain D, long long n_rows, const unsigned *__restrict__ cand_k,
@@ -1890,11 +2023,14 @@ __device__ __forceinline__ void k_gardner_segmap(const unsigned *__restrict__ ta
         s_khi[threadIdx.x] = b.k_hi;
     }
     __syncthreads();
-    // entry keys of the segment's first chunk: its band only (everything else is a miss before the first step)
+    // entry keys of the segment's first chunk: its band only (everything else is a miss before the first step).  A segment that
+    // starts on a row whose scouts did not settle (the whole domain listed: tens of thousands of keys, G dependent look-ups each)
+    // is not composed: the chain steps through it row by row
+    const bool wide = s_khi[0] - s_klo[0] > 4096u;
     for (unsigned k0 = s_klo[0] + threadIdx.x; k0 <= s_khi[0]; k0 += 1024u) {
         unsigned k = k0, total = 0;
-        bool ok = true;
-        for (int g = 0; g < G; g++) {
+        bool ok = !wide;
+        for (int g = 0; g < G && ok; g++) {
             const unsigned cell = (k >= s_klo[g] && k <= s_khi[g]) ? table[(size_t)(c0 + g) * stride + k] : PDT_GTAB_MISS;
             if (cell == PDT_GTAB_MISS) { ok = false; break; }
             k = cell & ((1u << D.idx_bits) - 1u);

@@ -371,13 +371,15 @@ def test_250ksps_capture_matches_oracle(pdt, orc):
 def test_spans_over_noise_and_overflowing_key_lists(pdt, orc):
     """Rows whose scouts do not settle (noise in front of the signal: the whole boundary-state domain is listed, thousands of
     distinct exits per row) go through the same three span kernels; with a key list too small for them (PDT_GSPAN_CAP) such rows
-    are left untabulated and the chain walks them."""
+    are left untabulated, the chain walks them and the wavefront-per-group kernel emits them; PDT_GEMIT_GROUPS: that kernel for
+    every group."""
     fs = 250000
     rng = np.random.default_rng(15)
     noise = np.clip(np.rint(rng.normal(0, 900, (int(1.0 * fs), 2))), -32768, 32767).astype("<i2")
     iq = np.ascontiguousarray(np.concatenate([noise, pdt.synth_capture(0, fs, 5.0, seed=48)]))
     o = orc.Oracle(orc.POES, fs, iq)
-    for env in ({"PDT_GSPAN": "8"}, {"PDT_GSPAN": "8", "PDT_GSPAN_CAP": "2000"}, {"PDT_GSPAN": "3"}):
+    for env in ({"PDT_GSPAN": "8"}, {"PDT_GSPAN": "8", "PDT_GSPAN_CAP": "2000"}, {"PDT_GSPAN": "3"},
+                {"PDT_GSPAN": "4", "PDT_GEMIT_GROUPS": "1"}):
         os.environ.update(env)
         try:
             with pdt.Demodulator(pdt.MODE_POES, fs) as d:
