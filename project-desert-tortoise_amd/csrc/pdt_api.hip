@@ -238,7 +238,7 @@ struct Plan {
 // context is opened; the demodulation calls never look at the environment.
 struct Tuning {
     double band_pad = 0.0, pll_warm_scale = 1.0, head_taus = 0.0, agc_k = 0.0, pll_warm_s = 0.0, agc_warm_s = 0.0;
-    int scout_syms = 0, gspan = 0, gspan_cap = 0, ingest_threads = 0, ingest_span_mb = 0, ingest_streams = 0, overlap_segments = 0, overlap_min_mb = 0, fir_wg_per_cu = 0, agc_tpb = 0, gseg = 0, acquire_mode = 0, pll_block = 0, fix_passes = 2;      // acquire_mode: 0 = two-wavefront pipeline, 1 = plain one-lane, 2 = one wavefront
+    int scout_syms = 0, gspan = 0, gspan_cap = 0, mf_waves = 8, ingest_threads = 0, ingest_span_mb = 0, ingest_streams = 0, overlap_segments = 0, overlap_min_mb = 0, fir_wg_per_cu = 0, agc_tpb = 0, gseg = 0, acquire_mode = 0, pll_block = 0, fix_passes = 2;      // acquire_mode: 0 = two-wavefront pipeline, 1 = plain one-lane, 2 = one wavefront
     bool fir_generic = false, mix_unfused = false, quality_inline = false, gemit_groups = false, agc_unfused = false, no_excl = false, gtab_nomerge = false, gardner_onebuf = false, gardner_noring = false, gardner_sequential = false, seg_sequential = false, no_overlap = false, debug_overlap = false, chain_one_range = false, ema_noguess = false, debug_sync = false;
     void load()
     {
@@ -258,6 +258,7 @@ struct Tuning {
         if (const char *e = getenv("PDT_FIX_PASSES")) fix_passes = atoi(e);
         if (const char *e = getenv("PDT_GSEG")) gseg = std::min(64, std::max(2, atoi(e)));
         if (const char *e = getenv("PDT_GSPAN")) gspan = std::min(256, std::max(1, atoi(e)));
+        if (const char *e = getenv("PDT_MF_WAVES")) mf_waves = atoi(e) == 4 ? 4 : 8;
         if (const char *e = getenv("PDT_GSPAN_CAP")) gspan_cap = std::max(64, atoi(e));          // (tests: rows that do not fit the key list)
         if (getenv("PDT_ACQUIRE_SIMPLE")) acquire_mode = 1;
         else if (getenv("PDT_ACQUIRE_ONEWAVE")) acquire_mode = 2;
@@ -1202,14 +1203,18 @@ template <typename T> int run_capture(pdt_ctx *ctx, uint64_t n, int phase = RUN_
                     fused_tiles = runs_nat;
                     agc_maps_per_block = agc_tiles_per_block * (64 * 26 / PDT_MF_RUN);
                 }
-                if (d_pcm.fmt == 0)
-                    PDT_LAUNCH(256, (k_mix_fir<26, 0>), dim3((unsigned)(lt_tiles * (Bp / PDT_MF_RUN))), dim3(256), 0, st, d_pcm, (const float *)d_phi,
-                                       (const float *)d_pll, N, Bp, (const PllLockInfo<float> *)d_info, (const float *)ctx->taps_rot.p, (float *)d_fir,
-                                       ctx->keep_pll ? (float *)d_pll : (float *)nullptr, run_maps, (float)AP.decay);
-                else
-                    PDT_LAUNCH(256, (k_mix_fir<26, 1>), dim3((unsigned)(lt_tiles * (Bp / PDT_MF_RUN))), dim3(256), 0, st, d_pcm, (const float *)d_phi,
-                                       (const float *)d_pll, N, Bp, (const PllLockInfo<float> *)d_info, (const float *)ctx->taps_rot.p, (float *)d_fir,
-                                       ctx->keep_pll ? (float *)d_pll : (float *)nullptr, run_maps, (float)AP.decay);
+                // eight wavefronts per workgroup (two workgroups per CU = four wavefronts per SIMD); PDT_MF_WAVES=4: the first form
+                const unsigned mf_grid = (unsigned)(lt_tiles * (Bp / PDT_MF_RUN));
+                float *mf_pll = ctx->keep_pll ? (float *)d_pll : (float *)nullptr;
+#define PDT_MF_ARGS d_pcm, (const float *)d_phi, (const float *)d_pll, N, Bp, (const PllLockInfo<float> *)d_info, (const float *)ctx->taps_rot.p, (float *)d_fir, mf_pll, run_maps, (float)AP.decay
+                if (ctx->tune.mf_waves == 4) {
+                    if (d_pcm.fmt == 0) PDT_LAUNCH(256, (k_mix_fir<26, 0, 4>), dim3(mf_grid), dim3(256), 0, st, PDT_MF_ARGS);
+                    else PDT_LAUNCH(256, (k_mix_fir<26, 1, 4>), dim3(mf_grid), dim3(256), 0, st, PDT_MF_ARGS);
+                } else {
+                    if (d_pcm.fmt == 0) PDT_LAUNCH(512, (k_mix_fir<26, 0, 8>), dim3(mf_grid), dim3(512), 0, st, PDT_MF_ARGS);
+                    else PDT_LAUNCH(512, (k_mix_fir<26, 1, 8>), dim3(mf_grid), dim3(512), 0, st, PDT_MF_ARGS);
+                }
+#undef PDT_MF_ARGS
                 done = true;
             }
             if (!done && K == 26 && sh_rt <= 64000 && ctx->taps_rot.p && !ctx->tune.fir_generic) {

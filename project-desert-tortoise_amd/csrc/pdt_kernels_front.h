@@ -1747,7 +1747,7 @@ __device__ __forceinline__ void k_fir_interp_rt(const T *__restrict__ in, long l
 #define PDT_MF_LSI 237                 // LDS row strides (odd: 64 rows at one column hit 64 banks)
 typedef float pdt_v2f __attribute__((ext_vector_type(2)));
 
-template <int K, int FMT>
+template <int K, int FMT, int NWV = 4>
 __device__ __forceinline__ void k_mix_fir(IqSrc pcm, const float *__restrict__ phi_lt, const float *__restrict__ pll_pre,
                                           long long n, long long B, const PllLockInfo<float> *__restrict__ info,
                                           const float *__restrict__ rot /* host-built rotated taps */, float *__restrict__ out,
@@ -1755,9 +1755,12 @@ __device__ __forceinline__ void k_mix_fir(IqSrc pcm, const float *__restrict__ p
                                           AgcMap *__restrict__ run_maps, float agc_decay)
 {
     static_assert(PDT_MF_RUN == 8 * K && PDT_MF_HALO >= K - 1 && PDT_MF_HALO % 4 == 0, "run = 8 ring revolutions, halo = whole phase vectors");
-    // 59 KiB + 8 KiB: two workgroups per CU (one loads while the other computes)
+    static_assert(NWV == 4 || NWV == 8, "four or eight wavefronts per workgroup");
+    constexpr int RPW = 64 / NWV;                         // rows a wavefront owns in phases B and D
+    constexpr int NSEG = 2 * NWV;                         // stretches of a row's run the AGC map is composed from
+    // 59 KiB + 8 (16) KiB: two workgroups per CU (one loads while the other computes)
     __shared__ __attribute__((aligned(16))) float s_in[64 * PDT_MF_LSI];
-    __shared__ double s_maps[8 * 64 * 2];
+    __shared__ double s_maps[NSEG * 64 * 2];
     const int lane = (int)threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6);
     const long long runs = B / PDT_MF_RUN;
@@ -1772,26 +1775,26 @@ __device__ __forceinline__ void k_mix_fir(IqSrc pcm, const float *__restrict__ p
     // capture: 4 or 8 bytes per sample), then (A) the phases of the run and its halo, transposed into LDS (row = block).
     // Phase B's work list: a wavefront owns 16 rows x 236 columns = 59 x 64 (row, column) pairs, pair number 64 it + lane.
     typedef typename std::conditional<FMT == 0, int, float2>::type Raw;
-    constexpr int NIT = 16 * PDT_MF_COLS / 64;
-    static_assert(NIT * 64 == 16 * PDT_MF_COLS, "a wavefront's share of phase B is whole instructions");
+    constexpr int NIT = (RPW * PDT_MF_COLS + 63) / 64;
+    constexpr bool RAGGED = NIT * 64 != RPW * PDT_MF_COLS;       // (eight wavefronts: the last instruction is half empty)
     // interior workgroup: every sample it touches lies behind the lock and inside the capture (no test per sample)
     const bool interior = (blk0 * B + p0 - PDT_MF_HALO >= S) && ((blk0 + 63) * B + p0 + PDT_MF_RUN <= n);
     Raw raw[NIT];
 #pragma unroll
     for (int it = 0; it < NIT; it++) {
         const int idx = it * 64 + lane, rr = idx / PDT_MF_COLS, col = idx - rr * PDT_MF_COLS;
-        const long long i = (blk0 + wave * 16 + rr) * B + p0 - PDT_MF_HALO + col;
+        const long long i = (blk0 + wave * RPW + rr) * B + p0 - PDT_MF_HALO + col;
         if constexpr (FMT == 0) raw[it] = 0;
         else raw[it] = make_float2(0.0f, 0.0f);
-        if (interior) raw[it] = reinterpret_cast<const Raw *>(pcm.p)[i];       // (the other workgroups load as they go)
+        if (interior && (!RAGGED || idx < RPW * PDT_MF_COLS)) raw[it] = reinterpret_cast<const Raw *>(pcm.p)[i];   // (the other workgroups load as they go)
     }
     {
         const float *tile = phi_lt + blk0 * B;
-        constexpr int NQ = (PDT_MF_COLS / 4 + 3) / 4;                  // phase vectors per wavefront
+        constexpr int NQ = (PDT_MF_COLS / 4 + NWV - 1) / NWV;          // phase vectors per wavefront
         float4 v[NQ];
 #pragma unroll
         for (int u = 0; u < NQ; u++) {
-            const int q = wave + 4 * u;
+            const int q = wave + NWV * u;
             const long long p = p0 - PDT_MF_HALO + 4 * q;              // position of the vector's first sample in its block
             const long long i0 = (blk0 + lane) * B + p;
             v[u] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
@@ -1805,7 +1808,7 @@ __device__ __forceinline__ void k_mix_fir(IqSrc pcm, const float *__restrict__ p
         }
 #pragma unroll
         for (int u = 0; u < NQ; u++) {
-            const int q = wave + 4 * u;
+            const int q = wave + NWV * u;
             if (q < PDT_MF_COLS / 4) {
                 float *d = s_in + lane * PDT_MF_LSI + 4 * q;
                 d[0] = v[u].x; d[1] = v[u].y; d[2] = v[u].z; d[3] = v[u].w;
@@ -1815,7 +1818,7 @@ __device__ __forceinline__ void k_mix_fir(IqSrc pcm, const float *__restrict__ p
     __syncthreads();
     // ---- B: phase -> mixed sample, in place
     {
-        float *wrows = s_in + wave * 16 * PDT_MF_LSI;
+        float *wrows = s_in + wave * RPW * PDT_MF_LSI;
         auto mix = [&](const Raw &r, float ph) {
             float a, b, sn, cs;
             if constexpr (FMT == 0) {                                  // I | Q << 16, value / 32768 (wave.c:127-172)
@@ -1834,17 +1837,19 @@ __device__ __forceinline__ void k_mix_fir(IqSrc pcm, const float *__restrict__ p
             for (int it = 0; it < NIT; it++) {
                 const int idx = it * 64 + lane, rr = idx / PDT_MF_COLS, col = idx - rr * PDT_MF_COLS;
                 float *cell = wrows + idx + rr;                        // rr * LSI + col, LSI = COLS + 1
+                if (RAGGED && idx >= RPW * PDT_MF_COLS) continue;
                 const float x = mix(raw[it], *cell);
                 *cell = x;
-                if (pll_out && col >= PDT_MF_HALO) pll_out[(blk0 + wave * 16 + rr) * B + p0 - PDT_MF_HALO + col] = x;
+                if (pll_out && col >= PDT_MF_HALO) pll_out[(blk0 + wave * RPW + rr) * B + p0 - PDT_MF_HALO + col] = x;
                 if ((it & 3) == 3) __builtin_amdgcn_sched_barrier(0);  // four evaluations interleaved, not fifty-nine (registers)
             }
         } else {
 #pragma unroll 1
             for (int it = 0; it < NIT; it++) {
                 const int idx = it * 64 + lane, rr = idx / PDT_MF_COLS, col = idx - rr * PDT_MF_COLS;
-                const long long i = (blk0 + wave * 16 + rr) * B + p0 - PDT_MF_HALO + col;
+                const long long i = (blk0 + wave * RPW + rr) * B + p0 - PDT_MF_HALO + col;
                 float *cell = wrows + idx + rr;
+                if (RAGGED && idx >= RPW * PDT_MF_COLS) continue;
                 float x = 0.0f;
                 if (i >= S && i < n) {
                     x = mix(reinterpret_cast<const Raw *>(pcm.p)[i], *cell);
@@ -1863,22 +1868,31 @@ __device__ __forceinline__ void k_mix_fir(IqSrc pcm, const float *__restrict__ p
     const bool full_rows = (blk0 + 63) * B + p0 + PDT_MF_RUN <= n;        // every row's run lies inside the capture
     {
         float *xin = s_in + lane * PDT_MF_LSI + PDT_MF_HALO;              // xin[m] = input m of the run, m >= -HALO
-        const int s0 = wave * K;
+        // four wavefronts: wavefront w takes the ring revolution that starts at output 26 w (and the one 104 further on), all 26
+        // residues; eight: half a revolution each -- residues 0..12 (even w) or 13..25 (odd w) of the revolution at 26 (w / 2)
+        const int s0 = (NWV == 4) ? wave * K : (wave >> 1) * K;
+        const bool upper = NWV == 8 && (wave & 1);                        // starts at residue 13
         constexpr int H2 = PDT_MF_RUN / 2;
         const double rdec = (double)agc_decay;
-        pdt_v2f x[K], nx[K];
+        constexpr int NRES = (NWV == 4) ? K : K / 2;                       // residues a wavefront takes
+        pdt_v2f x[K], nx[NRES];
         // the ring in front of output s0 (a multiple of K): slot t >= 1 holds input s0 - K + t; slot 0 is filled by residue 0.
         // The K inputs that enter the ring while the wavefront works are taken now as well: the outputs then go where the
         // inputs were (another wavefront's inputs, read before the barrier)
-        x[0].x = 0; x[0].y = 0;
+        // (in front of residue c0 the slots below c0 already hold this revolution's inputs)
 #pragma unroll
-        for (int t = 1; t < K; t++) { x[t].x = xin[s0 - K + t]; x[t].y = xin[s0 + H2 - K + t]; }
+        for (int t = 0; t < K; t++) {
+            const int m = (upper && t < K / 2) ? s0 + t : s0 - K + t;
+            x[t].x = xin[m];
+            x[t].y = xin[m + H2];
+        }
+        const int c0 = upper ? K / 2 : 0;
 #pragma unroll
-        for (int t = 0; t < K; t++) { nx[t].x = xin[s0 + t]; nx[t].y = xin[s0 + H2 + t]; }
+        for (int t = 0; t < NRES; t++) { nx[t].x = xin[s0 + c0 + t]; nx[t].y = xin[s0 + c0 + H2 + t]; }
         __syncthreads();
         auto residue = [&](auto cc) {
             constexpr int c = decltype(cc)::value;
-            x[c] = nx[c];
+            x[c] = nx[(NWV == 4) ? c : c % (K / 2)];
             constexpr int CS = (K + 15) & ~15;
             const __attribute__((address_space(4))) float *h =
                 (const __attribute__((address_space(4))) float *)__builtin_assume_aligned(rot + c * CS, 64);
@@ -1916,21 +1930,23 @@ __device__ __forceinline__ void k_mix_fir(IqSrc pcm, const float *__restrict__ p
                 }
             }
         };
-        fir_residues<0, 1, K>(residue);
+        if constexpr (NWV == 4) fir_residues<0, 1, K>(residue);
+        else if (upper) fir_residues<K / 2, 1, K>(residue);
+        else fir_residues<0, 1, K / 2>(residue);
     }
-    // ---- D: the rows' AGC maps (eight stretches each, in order), then the outputs
+    // ---- D: the rows' AGC maps (the stretches of each in the order of their outputs), then the outputs
     if (run_maps) {
 #pragma unroll
         for (int hf = 0; hf < 2; hf++) {
-            s_maps[((hf * 4 + wave) * 64 + lane) * 2] = mA[hf];
-            s_maps[((hf * 4 + wave) * 64 + lane) * 2 + 1] = mB[hf];
+            s_maps[((hf * NWV + wave) * 64 + lane) * 2] = mA[hf];
+            s_maps[((hf * NWV + wave) * 64 + lane) * 2 + 1] = mB[hf];
         }
     }
     __syncthreads();
     if (run_maps && (int)threadIdx.x < 64 && row_base < n) {
         double tA = 1.0, tB = 0.0;
 #pragma unroll
-        for (int sg = 0; sg < 8; sg++) {
+        for (int sg = 0; sg < NSEG; sg++) {
             const double A = s_maps[(sg * 64 + lane) * 2], Bc = s_maps[(sg * 64 + lane) * 2 + 1];
             tB = A * tB + Bc;
             tA = A * tA;
@@ -1941,8 +1957,8 @@ __device__ __forceinline__ void k_mix_fir(IqSrc pcm, const float *__restrict__ p
         run_maps[row_base / PDT_MF_RUN] = m;
     }
 #pragma unroll 4
-    for (int rr = 0; rr < 16; rr++) {
-        const int l = wave * 16 + rr;
+    for (int rr = 0; rr < RPW; rr++) {
+        const int l = wave * RPW + rr;
         const long long ob = (blk0 + l) * B + p0;
 #pragma unroll
         for (int k = 0; k < 4; k++) {
