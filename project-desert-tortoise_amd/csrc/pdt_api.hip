@@ -97,6 +97,8 @@ struct DevScalars {
                             //                        [2] chunks the chain had to walk, [3] unused
     double norm;            // storage for the normalisation factor (float or double)
     long long agc_first_bad; // first AGC seam that does not close (k_agc_scan -> k_agc_fix)
+    unsigned phase_groups_done;  // workgroups of k_pll_phase that have finished (a hint for k_pll_head: walk on while they run)
+    unsigned pad1_;
 };
 
 // ---------------------------------------------------------------- launch plans
@@ -994,10 +996,10 @@ template <typename T> int run_capture(pdt_ctx *ctx, uint64_t n, int phase = RUN_
         L.begin("pll_phase", ctx->stream2);
         if (slow_wrap)
             PDT_LAUNCH(256, (k_pll_phase<T, true>), dim3((unsigned)grid_pll), dim3(256), 0, ctx->stream2, d_pcm, d_theta, N, PP, Bp,
-                               Wacq, Wp, lag, d_phi, (PllSeam<T> *)ctx->seams_pll.p);
+                               Wacq, Wp, lag, d_phi, (PllSeam<T> *)ctx->seams_pll.p, &d_sc->phase_groups_done);
         else
             PDT_LAUNCH(256, (k_pll_phase<T, false>), dim3((unsigned)grid_pll), dim3(256), 0, ctx->stream2, d_pcm, d_theta, N, PP, Bp,
-                               Wacq, Wp, lag, d_phi, (PllSeam<T> *)ctx->seams_pll.p);
+                               Wacq, Wp, lag, d_phi, (PllSeam<T> *)ctx->seams_pll.p, &d_sc->phase_groups_done);
         L.end();
         PL.simple(OP_JOIN_RECORD);
     }
@@ -1060,7 +1062,15 @@ template <typename T> int run_capture(pdt_ctx *ctx, uint64_t n, int phase = RUN_
         double head_taus = (sizeof(T) == 4) ? 30.0 : 90.0;
         if (ctx->tune.head_taus > 0) head_taus = ctx->tune.head_taus;
         const long long Hd = std::min<long long>(Wp, (long long)(head_taus * tau_trk));
-        const long long head_blocks = Hd / Bp + 3;
+        // ... and further -- up to half as long again -- for as long as the block-parallel kernel beside it is still running: those
+        // blocks cost nothing, and the first block behind a 30-tau head fails its seam now and then (an hour at 250 ksps: one
+        // repair of two block walks, 1.6 ms; the head stopped 0.9 ms before the kernel beside it)
+        // Only where the kernel beside it is bound by HBM (its warm-ups re-read more than ~12 GB: hour-long captures) -- there it
+        // runs ~25 % longer than acquisition + head; elsewhere the two finish together and an extra block is a block too many
+        // (10 min at 50 ksps: +0.1 ms; 10 min at 250 ksps: +0.45 ms).
+        const bool head_slack = (double)nb_pll * (double)(Wp + Bp) * sizeof(T) >= 12e9 && !ctx->tune.head_taus;
+        const long long Hd_max = head_slack ? std::min<long long>(Wp, Hd + Hd / 2) : Hd;
+        const long long head_blocks = Hd_max / Bp + 3;
         if ((rc = ctx->pll_head.ensure((size_t)(head_blocks * Bp + 64) * sizeof(T) + (size_t)head_blocks * sizeof(PllSeam<T>) +
                                        sizeof(PllHeadInfo<T>) + 64)))
             return rc;
@@ -1076,13 +1086,13 @@ template <typename T> int run_capture(pdt_ctx *ctx, uint64_t n, int phase = RUN_
         L.begin("pll_head");
         if (slow_wrap)
             PDT_LAUNCH(64, (k_pll_head<T, true>), dim3(1), dim3(64), 0, st, d_theta, N, PP, d_info, Bp, Hd, d_hphi, d_hseams,
-                               d_hinfo, head_blocks);
+                               d_hinfo, head_blocks, Hd_max, (const unsigned *)&d_sc->phase_groups_done, (unsigned)grid_pll);
         else if (serial_excl)
             PDT_LAUNCH(64, (k_pll_head<T, false, true>), dim3(1), dim3(64), 0, st, d_theta, N, PP, d_info, Bp, Hd, d_hphi, d_hseams,
-                               d_hinfo, head_blocks);
+                               d_hinfo, head_blocks, Hd_max, (const unsigned *)&d_sc->phase_groups_done, (unsigned)grid_pll);
         else
             PDT_LAUNCH(64, (k_pll_head<T, false>), dim3(1), dim3(64), 0, st, d_theta, N, PP, d_info, Bp, Hd, d_hphi, d_hseams,
-                               d_hinfo, head_blocks);
+                               d_hinfo, head_blocks, Hd_max, (const unsigned *)&d_sc->phase_groups_done, (unsigned)grid_pll);
         L.end();
         PL.simple(OP_JOIN_WAIT);                                           // join
         L.gap();                                                           // (the wait is not part of pll_fix)

@@ -972,8 +972,13 @@ __device__ __forceinline__ void pll_guess(IqSrc pcm, long long ws, long long n, 
 template <typename T, bool SLOW>
 __device__ __forceinline__ void k_pll_phase(IqSrc pcm, const T *__restrict__ theta, long long n,
                                                    PllParams<T> P, long long B, long long Wacq, long long Wtrk, int lag,
-                                                   T *__restrict__ phi, PllSeam<T> *__restrict__ seams)
+                                                   T *__restrict__ phi, PllSeam<T> *__restrict__ seams,
+                                                   unsigned *__restrict__ groups_done /* += 1 per finished workgroup (k_pll_head's hint) */)
 {
+    struct Done {                                   // (counted on every way out of the kernel)
+        unsigned *p;
+        __device__ ~Done() { if (threadIdx.x == 0) atomicAdd(p, 1u); }
+    } done_{groups_done};
     const long long j = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     const long long start = j * B;
     if (start >= n) return;
@@ -1030,7 +1035,10 @@ template <typename T, bool SLOW, bool EXCL = false>
 __device__ __forceinline__ void k_pll_head(const T *__restrict__ theta, long long n, PllParams<T> P,
                                                   const PllLockInfo<T> *__restrict__ info, long long B, long long W,
                                                   T *__restrict__ phi_head, PllSeam<T> *__restrict__ seams_head,
-                                                  PllHeadInfo<T> *__restrict__ hinfo, long long max_blocks)
+                                                  PllHeadInfo<T> *__restrict__ hinfo, long long max_blocks,
+                                                  long long W_max /* >= W: walk on up to there while ... */,
+                                                  const unsigned *__restrict__ phase_done /* ... fewer than */,
+                                                  unsigned phase_groups /* workgroups of k_pll_phase have finished */)
 {
     if (EXCL) asm volatile("" ::: "v255", "a255");       // a SIMD of its own, see k_pll_acquire_pipe
     if (blockIdx.x != 0 || threadIdx.x != 0) return;
@@ -1042,9 +1050,15 @@ __device__ __forceinline__ void k_pll_head(const T *__restrict__ theta, long lon
         const long long j0 = S / B;
         long long j1 = (S + W + B - 1) / B;                 // first block that starts >= W after the lock
         if (j1 - j0 + 1 > max_blocks) j1 = j0 + max_blocks - 1;
+        long long j2 = (S + W_max + B - 1) / B;             // ... and the last one worth walking while the kernel beside us runs
+        if (j2 - j0 + 1 > max_blocks) j2 = j0 + max_blocks - 1;
+        if (j2 < j1) j2 = j1;
         T phase = info->st.phase, freq = info->st.freq;
         long long pos = S, k = 0;
-        for (long long j = j0; j <= j1 && pos < n; j++, k++) {
+        for (long long j = j0; j <= j2 && pos < n; j++, k++) {
+            // (beyond the mandatory stretch only while the block-parallel kernel is still at work: those blocks are free, and the
+            // seams they take over are the ones most likely to be open)
+            if (j > j1 && __hip_atomic_load(phase_done, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= phase_groups) break;
             const long long end = ((j + 1) * B < n) ? (j + 1) * B : n;
             PllSeam<T> sm;
             sm.phase0 = phase;
