@@ -428,7 +428,8 @@ int  pdt_wav_parse_header(const uint8_t hdr[44], uint32_t *sample_rate, uint32_t
 /* Test hook, host only: the library's own restatements of the C-library functions the reference calls (sincos / sin / cos /
  * sincosf / hypot / hypotf; CarrierTrackingPLL.c:106-107,134-135, LowPassFilter.c:148,163, AGC.c:57-67) evaluated on the host
  * over an array.  fn: 0 sincos -> out0 = sin, out1 = cos; 1 sin; 2 cos; 3 sincosf of (float)x, widened; 4 hypot of the pairs
- * (x[2i], x[2i+1]) -> out0[i]; 5 hypotf of the pairs.  The kernels run the same code on the device.                          */
+ * (x[2i], x[2i+1]) -> out0[i]; 5 hypotf of the pairs; 6 the branch-free sincosf of the fused mix + FIR kernel; 7 / 8 the error
+ * and phase wraps of one float PLL step (CarrierTrackingPLL.c:168-188) in their fused form.  The kernels run the same code.     */
 int  pdt_host_math(int fn, const double *x, uint64_t n, double *out0, double *out1);
 /* The reference's running-sum time axis (wave.c:91,96-97,167-168): value after m additions of Ts. */
 double pdt_time_axis(int mode, uint32_t sample_rate, uint64_t m);

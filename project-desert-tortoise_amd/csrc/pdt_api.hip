@@ -781,7 +781,9 @@ template <typename T> int run_capture(pdt_ctx *ctx, uint64_t n, int phase = RUN_
         // One walker wavefront saturates the vector ALU of its SIMD (a wave64 instruction occupies the 16 lanes for 4 clocks), so
         // a second one on the same SIMD doubles the time of both: keep the walkers of everything that runs together -- this
         // capture, or the whole batch -- under ~one per SIMD (240 groups of four; the rest is left to the serial kernels).
-        const long long groups_max = 240;
+        // (A capture on its own: 180 -- an hour at 250 ksps, where the warm-ups' re-reads press on HBM: blocks of 15 / 20 / 25 / 30 /
+        // 40 thousand samples -> phase kernel 7.6 / 6.9 / 6.8 / 7.7 / 8.3 ms.)
+        const long long groups_max = ctx->batch_hint > 1 ? 240 : 180;
         const long long share = std::max<long long>(1, groups_max / std::max(1, ctx->batch_hint));
         const long long b_min = (N + share * 256 - 1) / (share * 256);
         Bp = std::max(Bp, b_min);
@@ -2087,7 +2089,8 @@ int pdt_device_count(void)
 // Host evaluation of the library's own restatements of the C-library functions the reference calls (test hook: the CPU
 // tests compare them with the C library of the machine, bit for bit).  fn: 0 sincos(x) -> out0 sin, out1 cos; 1 sin; 2 cos;
 // 3 sincosf((float)x) widened; 4 hypot(x[2i], x[2i+1]) -> out0[i]; 5 hypotf of the pair, widened; 6 the branch-free form
-// of 3 (sincosf_flat: what the fused mix + FIR kernel evaluates).
+// of 3 (sincosf_flat: what the fused mix + FIR kernel evaluates); 7 / 8 the error and phase wraps of one float PLL step
+// (pll_wrap_error_f32 / pll_wrap_phase_f32), widened.
 int pdt_host_math(int fn, const double *x, uint64_t n, double *out0, double *out1)
 {
     if (!x || !out0) return PDT_ERR_ARG;
@@ -2100,6 +2103,8 @@ int pdt_host_math(int fn, const double *x, uint64_t n, double *out0, double *out
         case 4: out0[i] = hypot_glibc(x[2 * i], x[2 * i + 1]); break;
         case 5: out0[i] = hypotf_glibc((float)x[2 * i], (float)x[2 * i + 1]); break;
         case 6: { float sf, cf; sincosf_flat((float)x[i], sf, cf); out0[i] = sf; if (out1) out1[i] = cf; break; }
+        case 7: out0[i] = pll_wrap_error_f32((float)x[i]); break;
+        case 8: out0[i] = pll_wrap_phase_f32((float)x[i]); break;
         default: return PDT_ERR_ARG;
         }
     }

@@ -106,6 +106,33 @@ __host__ __device__ __forceinline__ void sincosf_flat(float y, float &sinv, floa
 }
 
 // ---- arctan2 approximation of CarrierTrackingPLL.c:15-40
+// The two wraps of one float PLL step (CarrierTrackingPLL.c:168-188) in the form the walkers evaluate.  hi = (float)(2pi) lies
+// above 2pi, d = hi - 2pi; x -+ hi is exact for pi <= |x| <= 4pi (Sterbenz) and adding -+d to it rounds once, to the float the
+// reference's double expression narrows to (every float of the range: tests/test_oracle_math.py::test_unwrap_f32_exhaustive).
+//   pll_wrap_error_f32: "if (d > M_PI) d -= 2 M_PI; else if (d < -M_PI) d += 2 M_PI" -- the promoted comparison is a float
+//       comparison with (float)pi (PiCmp); the sign is transferred once (s = +-1) and both corrections are fused multiply-adds
+//       with an exact product, i.e. the same two roundings as the subtraction and the addition they stand for.
+//   pll_wrap_phase_f32: "while (p > 2 M_PI) p -= 2 M_PI; while (p < -2 M_PI) p += 2 M_PI" for |p| < 4pi - 0.05 (one correction
+//       at most; the host selects the looping variant otherwise).  k = trunc(p * (float)(1 / 2pi)) is 0 below (float)(2pi) and
+//       +-1 from there on: (float)(2pi) times the constant rounds to exactly 1, its predecessor to 1 - 2^-24, and the rounded
+//       product is monotonic; fma(k, d, fma(k, -hi, p)) then IS the selected value: p itself for k = 0.  (For p = -0 it would
+//       return +0; a state of the loop is never -0: round-to-nearest sums give -0 only from (-0) + (-0), and the loop starts
+//       at +0.)
+// tests/test_own_math.py compares both with the plain forms over every float of their ranges.
+__host__ __device__ __forceinline__ float pll_wrap_error_f32(float x)
+{
+    const float hi = 6.2831854820251465f, d = 1.7484555314695172e-07f;
+    const float s = __builtin_copysignf(1.0f, x);
+    const float wrapped = __builtin_fmaf(s, d, __builtin_fmaf(s, -hi, x));
+    return (__builtin_fabsf(x) >= 3.14159274101257324f) ? wrapped : x;
+}
+__host__ __device__ __forceinline__ float pll_wrap_phase_f32(float p)
+{
+    const float hi = 6.2831854820251465f, d = 1.7484555314695172e-07f;
+    const float k = __builtin_truncf(p * 0.15915494309189535f);
+    return __builtin_fmaf(k, d, __builtin_fmaf(k, -hi, p));
+}
+
 __host__ __device__ __forceinline__ float arctan2_ref(float y, float x)
 {
     const float abs_y = (float)((double)__builtin_fabsf(y) + 1e-10);

@@ -331,6 +331,16 @@ template <> __device__ __forceinline__ float unwrap_2pi<float>(float x)
 template <typename T, bool SLOW_WRAP = false>
 __device__ __forceinline__ void pll_phase_step(T th, T &phase, T &freq, T alpha, T beta, T maxf, T minf)
 {
+    if constexpr (std::is_same<T, float>::value && !SLOW_WRAP) {
+        // float: 16 vector operations per step instead of 19 (the walkers are bound by instruction issue -- one wavefront per
+        // SIMD, 4 clocks per operation -- so the count is the time): both wraps as fused multiply-adds with exact products,
+        // pdt_device_math.h
+        const float err = pll_wrap_error_f32(th - phase);
+        const float f1 = freq + beta * err;
+        phase = pll_wrap_phase_f32(phase + f1 + alpha * err);
+        freq = PiAbs<float>::clamp(f1, minf, maxf);
+        return;
+    }
     const T diff = th - phase;
     const T wrapped = unwrap_2pi(diff);
     const T err = PiAbs<T>::ge_pi(diff) ? wrapped : diff;

@@ -98,3 +98,28 @@ def test_branch_free_sincosf_equals_the_library_form(pdt):
     for i in range(0, len(x), 97):
         libm.sincosf(C.c_float(x[i]), C.byref(a), C.byref(b))
         assert np.float32(a.value).tobytes() == np.float32(s6[i]).tobytes() and np.float32(b.value).tobytes() == np.float32(c6[i]).tobytes(), x[i]
+
+
+def _every_float(lo, hi):
+    a = np.arange(np.float32(lo).view(np.uint32), np.float32(hi).view(np.uint32) + 1, dtype=np.uint32).view(np.float32)
+    return np.concatenate([a, -a])
+
+
+def test_pll_wraps_in_fused_form_equal_the_reference_expressions(pdt):
+    """One float PLL step's two wraps as the walkers evaluate them (pll_wrap_error_f32: one sign transfer + two fused
+    multiply-adds; pll_wrap_phase_f32: k = trunc(p / 2pi), two fused multiply-adds, no select) against the reference's
+    expressions -- compare promoted to double, correct by -+2 M_PI in double, narrow (CarrierTrackingPLL.c:168-188) -- over EVERY
+    float of the ranges the corrections can fire in, plus a sample of the range they leave alone."""
+    rng = np.random.default_rng(5)
+    small = np.concatenate([rng.uniform(-3.2, 3.2, 200000).astype(np.float32), np.array([0.0, 1e-30, -1e-30, 3.1415925, -3.1415925], np.float32)])
+    x = np.concatenate([_every_float(3.0, 9.5), small])
+    xd = x.astype(np.float64)
+    ref = np.where(xd > np.pi, (xd - 2 * np.pi).astype(np.float32), np.where(xd < -np.pi, (xd + 2 * np.pi).astype(np.float32), x))
+    got, _ = pdt.host_math(7, xd)
+    assert got.astype(np.float32).tobytes() == ref.astype(np.float32).tobytes()
+    small = np.concatenate([rng.uniform(-6.3, 6.3, 200000).astype(np.float32), np.array([0.0, 1e-30, -1e-30, 6.283185, -6.283185], np.float32)])
+    x = np.concatenate([_every_float(6.0, 12.5), small])         # (the one-correction variant is selected for |p| < 4pi - 0.05)
+    xd = x.astype(np.float64)
+    ref = np.where(xd > 2 * np.pi, (xd - 2 * np.pi).astype(np.float32), np.where(xd < -2 * np.pi, (xd + 2 * np.pi).astype(np.float32), x))
+    got, _ = pdt.host_math(8, xd)
+    assert got.astype(np.float32).tobytes() == ref.astype(np.float32).tobytes()
