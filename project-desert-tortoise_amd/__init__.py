@@ -161,6 +161,31 @@ ABI_SYMBOLS = [
 _lib = None
 
 
+def _share_torch_hip_runtime():
+    """A PyTorch-ROCm wheel carries its own copy of the HIP runtime (torch/lib/libamdhip64.so, same SONAME as /opt/rocm's).
+    Loaded after libpdt.so has brought in the system copy, it is a second runtime in the process and finds no GPU ("No HIP
+    GPUs are available"); loaded first, libpdt.so's dependency resolves to it and both use one runtime -- the order `import
+    torch` before this package always gave.  Make the order irrelevant: when a torch with a bundled runtime is installed
+    (found without importing it), load that copy before libpdt.so.  Without torch nothing happens and libpdt.so uses the
+    system runtime, as the C programs do."""
+    import importlib.util
+    import sys
+    if "torch" in sys.modules:
+        return
+    try:
+        spec = importlib.util.find_spec("torch")
+    except (ImportError, ValueError):
+        return
+    if spec is None or not spec.submodule_search_locations:
+        return
+    path = os.path.join(list(spec.submodule_search_locations)[0], "lib", "libamdhip64.so")
+    if os.path.exists(path):
+        try:
+            C.CDLL(path, mode=C.RTLD_GLOBAL)
+        except OSError:
+            pass
+
+
 def lib():
     """Load libpdt.so (built in-tree by ``make`` / ``__graft_entry__.build()``); fail loudly if absent."""
     global _lib
@@ -171,6 +196,7 @@ def lib():
             f"{LIBPDT_PATH} is missing: build it with `make` (hipcc --offload-arch=gfx950). "
             "There is no CPU implementation to fall back to."
         )
+    _share_torch_hip_runtime()
     L = C.CDLL(LIBPDT_PATH)
     L.pdt_abi_version.restype = C.c_int
     L.pdt_build_tag.restype = C.c_char_p

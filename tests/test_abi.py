@@ -4,6 +4,7 @@ import ctypes as C
 import os
 import re
 import subprocess
+import sys
 
 import numpy as np
 import pytest
@@ -176,3 +177,19 @@ def test_compat_libraries_export_the_reference_prototypes(pdt):
         lib = ctypes.CDLL(path)
         for sym in common + [own]:
             assert hasattr(lib, sym), f"{name}: {sym}"
+
+
+def test_one_hip_runtime_whatever_the_import_order():
+    """A PyTorch-ROCm wheel brings its own libamdhip64; loaded after the system copy libpdt.so links, it is a second runtime in
+    the process and sees no GPU.  The binding loads torch's copy first when there is one (project-desert-tortoise_amd
+    ._share_torch_hip_runtime), so the package may be imported before torch: one runtime is mapped either way."""
+    code = (
+        "import importlib, sys\n"
+        "m = importlib.import_module('project-desert-tortoise_amd'); m.lib()\n"
+        "import torch\n"
+        "libs = sorted(set(l.split()[-1] for l in open('/proc/self/maps') if 'libamdhip64' in l))\n"
+        "print(len(libs), libs)\n"
+        "sys.exit(0 if len(libs) == 1 else 1)\n"
+    )
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, cwd=ROOT)
+    assert r.returncode == 0, r.stdout + r.stderr
