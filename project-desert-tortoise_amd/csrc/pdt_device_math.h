@@ -122,9 +122,25 @@ __host__ __device__ __forceinline__ void sincosf_flat(float y, float &sinv, floa
 __host__ __device__ __forceinline__ float pll_wrap_error_f32(float x)
 {
     const float hi = 6.2831854820251465f, d = 1.7484555314695172e-07f;
+#if defined(__HIP_DEVICE_COMPILE__)
+    // The same five operations in a fixed order: the compare first, the select last.  Left to the scheduler the compare lands
+    // right in front of the select (the step is one dependent chain, nothing else wants the slot) and the two wait states a
+    // vector compare needs before its mask is read cost an s_nop -- one issue slot of a lone wavefront's 17 per step.
+    float wrapped, s, r;
+    asm("v_cmp_ge_f32_e64 vcc, |%3|, %4\n\t"
+        "v_bfi_b32 %1, %5, 1.0, %3\n\t"
+        "v_fma_f32 %0, %1, %6, %3\n\t"
+        "v_fma_f32 %0, %1, %7, %0\n\t"
+        "v_cndmask_b32_e32 %2, %3, %0, vcc"
+        : "=&v"(wrapped), "=&v"(s), "=&v"(r)
+        : "v"(x), "s"(3.14159274101257324f), "s"(0x7fffffffu), "s"(-hi), "s"(d)
+        : "vcc");
+    return r;
+#else
     const float s = __builtin_copysignf(1.0f, x);
     const float wrapped = __builtin_fmaf(s, d, __builtin_fmaf(s, -hi, x));
     return (__builtin_fabsf(x) >= 3.14159274101257324f) ? wrapped : x;
+#endif
 }
 __host__ __device__ __forceinline__ float pll_wrap_phase_f32(float p)
 {

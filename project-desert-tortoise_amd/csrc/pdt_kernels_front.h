@@ -577,10 +577,11 @@ __device__ __forceinline__ void k_pll_acquire_fast(IqSrc pcm, long long n, PllPa
 #define PDT_ACQP_NB 64      // samples per batch of the two-wavefront pipeline (one per lane)
 #endif
 template <typename T> struct AcqSlot {
-    T phi[PDT_ACQP_NB], phn[PDT_ACQP_NB], fpre[PDT_ACQP_NB], swb[PDT_ACQP_NB];
+    T phi[PDT_ACQP_NB];               // phase used for sample k (the value before its update)
     long long i0;
     int nb, valid, hyp;
-    T ph_end, fr_end, sw_end;         // loop-filter state after the whole batch under the hypothesis
+    T ph_beg, fr_beg, sw_beg;         // loop-filter state in front of the batch (an event replays the filter from here)
+    T ph_end, fr_end, sw_end;         // ... and after the whole batch under the hypothesis
 };
 template <typename T> struct AcqVerdict {
     int event;                         // 0 = the batch stands, 1 = it ended early at sample k
@@ -634,24 +635,35 @@ __device__ __forceinline__ void k_pll_acquire_pipe(IqSrc pcm, long long n, PllPa
                 i_pre = i_prod + nb;
                 if (lane < PDT_ACQP_NB && i_pre + lane < n) th_pre = theta_of<T>(pcm, i_pre + lane);
                 T ph = phase, fr = freq, sw = sweep;
-                T phi_l = 0, phn_l = 0, fpre_l = 0, swb_l = 0;
-                // (four samples per trip: a taken branch costs a lone wavefront as much as nine instructions)
-                auto filt = [&](int k) {
+                T phi_l = 0;
+                // (four samples per trip: a taken branch costs a lone wavefront as much as nine instructions.  This loop is the
+                // pace of the acquisition -- a lone wavefront, every operation an issue slot -- so it keeps only what the
+                // detectors need of every sample, the phase it was mixed with: the states around an event sample are replayed
+                // from the front of the batch by the wavefront that finds the event (a handful per capture), and the sweep
+                // step is compiled in or out with the gate's hypothesis instead of selected per sample.)
+                auto filt_open = [&](int k) {
                     const T th = lane_get(th_l, k);
-                    const bool me = lane == k;
-                    phi_l = me ? ph : phi_l;
+                    phi_l = (lane == k) ? ph : phi_l;
                     pll_phase_step<T, SLOW>(th, ph, fr, P.alpha_acq, P.beta_acq, P.max_freq, P.min_freq);
-                    phn_l = me ? ph : phn_l;
-                    fpre_l = me ? fr : fpre_l;
-                    swb_l = me ? sw : swb_l;
-                    pll_sweep_sel(fr, sw, P.max_freq, P.min_freq, hyp);
+                    pll_sweep_sel(fr, sw, P.max_freq, P.min_freq, true);       // (the select form: no branches in the chain)
+                };
+                auto filt_closed = [&](int k) {
+                    const T th = lane_get(th_l, k);
+                    phi_l = (lane == k) ? ph : phi_l;
+                    pll_phase_step<T, SLOW>(th, ph, fr, P.alpha_acq, P.beta_acq, P.max_freq, P.min_freq);
                 };
                 int k = 0;
-                for (; k + 4 <= nb; k += 4) { filt(k); filt(k + 1); filt(k + 2); filt(k + 3); }
-                for (; k < nb; k++) filt(k);
-                if (lane < nb) { mine.phi[lane] = phi_l; mine.phn[lane] = phn_l; mine.fpre[lane] = fpre_l; mine.swb[lane] = swb_l; }
+                if (hyp) {
+                    for (; k + 4 <= nb; k += 4) { filt_open(k); filt_open(k + 1); filt_open(k + 2); filt_open(k + 3); }
+                    for (; k < nb; k++) filt_open(k);
+                } else {
+                    for (; k + 4 <= nb; k += 4) { filt_closed(k); filt_closed(k + 1); filt_closed(k + 2); filt_closed(k + 3); }
+                    for (; k < nb; k++) filt_closed(k);
+                }
+                if (lane < nb) mine.phi[lane] = phi_l;
                 if (lane == 0) {
                     mine.i0 = i_prod; mine.nb = nb; mine.hyp = hyp ? 1 : 0; mine.valid = 1;
+                    mine.ph_beg = phase; mine.fr_beg = freq; mine.sw_beg = sweep;
                     mine.ph_end = ph; mine.fr_end = fr; mine.sw_end = sw;
                 }
             } else if (lane == 0) {
@@ -708,12 +720,21 @@ __device__ __forceinline__ void k_pll_acquire_pipe(IqSrc pcm, long long n, PllPa
                 if (ev) {
                     const int k = __builtin_ctzll(ev);
                     const bool cond = ((ev_flip >> k) & 1ull) ? !h : h;
-                    T fr = theirs.fpre[k], sw = theirs.swb[k];
+                    // the loop filter again from the front of the batch up to the event sample: the gate kept its hypothesis
+                    // for the samples before it, the event sample takes the true one
+                    T rp = theirs.ph_beg, fr = theirs.fr_beg, sw = theirs.sw_beg;
+                    {
+                        const T thr_l = (lane < nb) ? arctan2_ref(b_l, a_l) : (T)0;        // theta_of of this lane's sample
+                        for (int q = 0; q <= k; q++) {
+                            pll_phase_step<T, SLOW>(lane_get(thr_l, q), rp, fr, P.alpha_acq, P.beta_acq, P.max_freq, P.min_freq);
+                            if (q < k && h) pll_sweep_step(fr, sw, P.max_freq, P.min_freq);
+                        }
+                    }
                     if (cond) pll_sweep_step(fr, sw, P.max_freq, P.min_freq);
                     done = k + 1;
                     avg = lane_get(av_l, k);
                     locksig = lane_get(ls_l, k);
-                    fin_phase = theirs.phn[k]; fin_freq = fr; fin_sweep = sw;
+                    fin_phase = rp; fin_freq = fr; fin_sweep = sw;
                     if ((ev_lock >> k) & 1ull) {
                         lock_at = i0 + k;
                         freq_at_lock = fr;
