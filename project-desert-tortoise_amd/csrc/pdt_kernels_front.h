@@ -822,8 +822,10 @@ template <int N> __device__ __forceinline__ void ring_wait()
 // consecutive 16-byte vectors are one row (ROW elements) apart.  VOTE also counts, over the range, the samples whose
 // detector error lies beyond +-pi/2 (the basin vote of the warm-up).
 #ifndef PDT_PLL_PF
-#define PDT_PLL_PF 24  // look-ahead of the block-parallel PLL walkers: every load is a fresh KiB from L2 / HBM (no line is touched twice),
-                       // measured 1.29 / 1.11 / 1.05 / 1.02 ms at 4 / 8 / 16 / 24 vectors (bench capture)
+#define PDT_PLL_PF 48  // look-ahead of the block-parallel PLL walkers: every load is a fresh KiB from L2 / HBM (no line is touched twice),
+                       // measured 1.29 / 1.11 / 1.05 / 1.02 ms at 4 / 8 / 16 / 24 vectors (bench capture); an hour at 250 ksps, where
+                       // the warm-ups' re-reads keep HBM at 4 TB/s and a load takes longer: 6.3 / 6.06 / 6.2 ms at 24 / 48 / 64 (the
+                       // ten-minute capture is indifferent: 0.85 / 0.84 / 0.88).  One wavefront per SIMD: the 192 registers are free.
 #endif
 template <typename T, bool STORE, bool SLOW, bool OUT_LT, int PF = PDT_PLL_PF, bool VOTE = false>
 __device__ __forceinline__ void pll_phase_range(const T *__restrict__ theta_lt, T *__restrict__ out, long long B, long long i0,
