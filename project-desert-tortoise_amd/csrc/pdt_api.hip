@@ -241,7 +241,7 @@ struct Plan {
 struct Tuning {
     double band_pad = 0.0, pll_warm_scale = 1.0, head_taus = 0.0, agc_k = 0.0, pll_warm_s = 0.0, agc_warm_s = 0.0;
     int scout_syms = 0, gspan = 0, gspan_cap = 0, mf_waves = 8, ingest_threads = 0, ingest_span_mb = 0, ingest_streams = 0, overlap_segments = 0, overlap_min_mb = 0, fir_wg_per_cu = 0, agc_tpb = 0, gseg = 0, acquire_mode = 0, pll_block = 0, fix_passes = 2;      // acquire_mode: 0 = two-wavefront pipeline, 1 = plain one-lane, 2 = one wavefront
-    bool fir_generic = false, mix_unfused = false, quality_inline = false, gemit_groups = false, agc_unfused = false, no_excl = false, gtab_nomerge = false, gardner_onebuf = false, gardner_noring = false, gardner_sequential = false, seg_sequential = false, no_overlap = false, debug_overlap = false, chain_one_range = false, ema_noguess = false, debug_sync = false;
+    bool fir_generic = false, mix_unfused = false, quality_inline = false, gemit_groups = false, agc_unfused = false, no_excl = false, gtab_nomerge = false, gardner_onebuf = false, gardner_noring = false, gardner_sequential = false, seg_sequential = false, agc_lanes = false, no_overlap = false, debug_overlap = false, chain_one_range = false, ema_noguess = false, debug_sync = false;
     void load()
     {
         if (const char *e = getenv("PDT_PLL_WARM_SCALE")) pll_warm_scale = atof(e);
@@ -269,6 +269,7 @@ struct Tuning {
         quality_inline = getenv("PDT_QUALITY_INLINE") != nullptr;
         gemit_groups = getenv("PDT_GEMIT_GROUPS") != nullptr;
         agc_unfused = getenv("PDT_AGC_UNFUSED") != nullptr;
+        agc_lanes = getenv("PDT_AGC_LANES") != nullptr;           // the per-lane walkers of rounds 1 - 3 (k_agc_block)
         no_excl = getenv("PDT_NO_EXCL") != nullptr;
         gtab_nomerge = getenv("PDT_GTAB_NOMERGE") != nullptr;
         gardner_onebuf = getenv("PDT_GARDNER_ONEBUF") != nullptr;
@@ -333,7 +334,7 @@ struct pdt_ctx {
     hipEvent_t ev0 = nullptr, ev1 = nullptr, ev_fork = nullptr, ev_join = nullptr;
     hipStream_t stream2 = nullptr;     // side stream: block-parallel PLL phase runs beside the sequential acquisition
 
-    DevBuf pcm, pll, lock, fir, agc, sym, symidx, bits, bitsym, hits, frames, taps, mag, seams_pll, seams_agc, scal, lockinfo, term, seams_ema, gtable, gentries, gcand, gmfirst, stiles, gsegmap, gsegstart, gbands, gclist, gneed, gchain, gspan_keys, gspan_tails, gspan_rows, gspan_items, gspan_ctl, gspan_recs, gcentries, gflags, agc_maps, pll_head, taps_rot, pll_scratch, tip, sync_scr, agc_raw;
+    DevBuf pcm, pll, lock, fir, agc, sym, symidx, bits, bitsym, hits, frames, taps, mag, seams_pll, seams_agc, scal, lockinfo, term, seams_ema, gtable, gentries, gcand, gmfirst, stiles, gsegmap, gsegstart, gbands, gclist, gneed, gchain, gspan_keys, gspan_tails, gspan_rows, gspan_items, gspan_ctl, gspan_recs, gcentries, gflags, agc_maps, pll_head, taps_rot, pll_scratch, tip, sync_scr, agc_raw, agc_ckpt;
     bool keep_agc_raw = false;   // pdt_keep_presquelch: also keep the AGC output before Squelch (stage PDT_ST_AGC_RAW)
     // pdt_keep_quality: the averagePhase stream (what CarrierTrackPLL returns, chunk by chunk) and the per-chunk counts
     bool keep_quality = false;
@@ -868,8 +869,9 @@ template <typename T> int run_capture(pdt_ctx *ctx, uint64_t n, int phase = RUN_
         if ((rc = ctx->lt_phi.ensure((size_t)(lt_elems + 1) * sizeof(T)))) return rc;
         if ((rc = ctx->seg_dev.ensure(sizeof(SegTail<T>) + 256))) return rc;
     }
-    if ((rc = ctx->fir.ensure((size_t)((seg ? n_out : std::max(n_out, lt_elems)) + 1) * sizeof(T)))) return rc;
-    if ((rc = ctx->agc.ensure((size_t)((seg ? n_out : std::max(n_out, lt_elems)) + 1) * sizeof(T)))) return rc;
+    // (+ Ba + 1024: the full-line AGC walkers read whole super-batches of a last, partial block and a few beyond it)
+    if ((rc = ctx->fir.ensure((size_t)((seg ? n_out : std::max(n_out, lt_elems)) + 1 + Ba + 1024) * sizeof(T)))) return rc;
+    if ((rc = ctx->agc.ensure((size_t)((seg ? n_out : std::max(n_out, lt_elems)) + 1 + Ba + 1024) * sizeof(T)))) return rc;
     if (ctx->keep_agc_raw && (rc = ctx->agc_raw.ensure((size_t)(n_out + 1) * sizeof(T)))) return rc;
     if (ctx->keep_agc_raw) AP.raw_out = (T *)ctx->agc_raw.p;
     // quality figure (pdt_keep_quality; whole captures only): averagePhase is one more EMA of the lock detector's kind
@@ -1286,13 +1288,40 @@ template <typename T> int run_capture(pdt_ctx *ctx, uint64_t n, int phase = RUN_
                            fused ? (int)agc_maps_per_block : 1, fused ? fused_tiles : nb);
         // (Round 3: walkers that store only the gain in front of every 16-sample batch + a streaming kernel that applies them were
         // slower, 4.2 against 3.3 ms at an hour of 250 ksps: the walkers are not held up by their output stores.)
+        // Round 4: the walkers move whole lines (k_agc_block_tr) wherever the FIR kernel delivered its tile maps -- float chain,
+        // no Squelch, no raw copy; the double build, stream segments and explicit block sizes keep the per-lane form.
+        bool agc_tr = false;
+        float *agc_ckpt = nullptr;
+        if constexpr (std::is_same<T, float>::value) {
+            agc_tr = fused && !ctx->tune.agc_lanes && !APs.squelch && !APs.raw_out && first_out == 0 && Ba % 32 == 0 &&
+                     agc_maps_per_block > 0 && Ba % agc_maps_per_block == 0;
+            if (agc_tr) {
+                const long long tile_len = 64ll * 26 * interp;                         // a FIR tile (= 8 runs of k_mix_fir)
+                const long long map_len = Ba / agc_maps_per_block;                     // samples per map
+                agc_tr = tile_len % 32 == 0 && tile_len % map_len == 0 && Ba % tile_len == 0;
+                if (agc_tr) {
+                    // (no slack of a whole block behind the time constants any more.  An hour at 250 ksps: K = 10 / 11 / 12 / 13 / 14 / 16
+                    // -> 4 / 3 / 0 / 0 / 0 / 0 open seams, walkers 1.76 / 1.80 / 1.84 / 1.86 / 1.91 / 2.06 ms; a minute of noise in front:
+                    // 3 / 1 / 2 / 1 / 1 / 0 and 12.1 ... 19.1 ms.  A seam that stays open is cheap since the repairs stop at the first
+                    // checkpoint they reproduce.)
+                    if (ctx->tune.agc_k <= 0) agc_K = 12.0;
+                    const size_t ck_bytes = (size_t)(nb + 64) * (size_t)(Ba / PDT_AGC_CKPT + 1) * sizeof(float);
+                    if ((rc = ctx->agc_ckpt.ensure(ck_bytes))) return rc;
+                    agc_ckpt = (float *)ctx->agc_ckpt.p;
+                    PDT_LAUNCH(64, (k_agc_block_tr<PDT_AGC_TR_R>), dim3((unsigned)grid), dim3(64), 0, st, (const float *)a_in, na, APs,
+                               (const float *)d_norm, Ba, Wa, (const double *)d_guess, (const AgcMap *)d_maps, (int)agc_maps_per_block,
+                               (int)(tile_len / map_len), fused_tiles, tile_len, (float *)a_out, (AgcSeam<float> *)ctx->seams_agc.p, agc_K, agc_ckpt);
+                }
+            }
+        }
+        if (!agc_tr)
         PDT_LAUNCH(64, k_agc_block<T>, dim3((unsigned)grid), dim3(64), 0, st, a_in, na, APs, d_norm, Ba, Wa,
                            (const double *)d_guess, a_lock, a_out, (AgcSeam<T> *)ctx->seams_agc.p, agc_K);
         L.end();
         L.begin("agc_fix");
         PDT_LAUNCH(1024, k_agc_scan<T>, dim3(1), dim3(1024), 0, st, na, Ba, (const AgcSeam<T> *)ctx->seams_agc.p, &d_sc->agc_first_bad);
         PDT_LAUNCH(64, k_agc_fix<T>, dim3(1), dim3(64), 0, st, a_in, na, APs, Ba, a_lock, a_out,
-                           (AgcSeam<T> *)ctx->seams_agc.p, d_sc->counters, (const long long *)&d_sc->agc_first_bad);
+                           (AgcSeam<T> *)ctx->seams_agc.p, d_sc->counters, (const long long *)&d_sc->agc_first_bad, (T *)agc_ckpt);
         L.end();
     }
 
@@ -2248,7 +2277,7 @@ void pdt_close(pdt_ctx *ctx)
     DevBuf *bufs[] = { &ctx->pcm, &ctx->pll, &ctx->lock, &ctx->fir, &ctx->agc, &ctx->sym, &ctx->symidx, &ctx->bits, &ctx->bitsym,
                        &ctx->hits, &ctx->frames, &ctx->taps, &ctx->mag, &ctx->seams_pll, &ctx->seams_agc, &ctx->scal, &ctx->lockinfo,
                        &ctx->term, &ctx->seams_ema, &ctx->gtable, &ctx->gentries, &ctx->gcand,
-                       &ctx->gmfirst, &ctx->stiles, &ctx->gsegmap, &ctx->gsegstart, &ctx->gbands, &ctx->gclist, &ctx->gspan_keys, &ctx->gspan_tails, &ctx->gspan_rows, &ctx->gspan_items, &ctx->gspan_ctl, &ctx->gspan_recs, &ctx->gcentries, &ctx->gflags, &ctx->agc_maps, &ctx->pll_head, &ctx->taps_rot, &ctx->pll_scratch, &ctx->tip, &ctx->stream_in, &ctx->sync_scr, &ctx->agc_raw, &ctx->packs_dev, &ctx->seg_dev, &ctx->lt_theta, &ctx->lt_phi,
+                       &ctx->gmfirst, &ctx->stiles, &ctx->gsegmap, &ctx->gsegstart, &ctx->gbands, &ctx->gclist, &ctx->gspan_keys, &ctx->gspan_tails, &ctx->gspan_rows, &ctx->gspan_items, &ctx->gspan_ctl, &ctx->gspan_recs, &ctx->gcentries, &ctx->gflags, &ctx->agc_maps, &ctx->pll_head, &ctx->taps_rot, &ctx->pll_scratch, &ctx->tip, &ctx->stream_in, &ctx->sync_scr, &ctx->agc_raw, &ctx->agc_ckpt, &ctx->packs_dev, &ctx->seg_dev, &ctx->lt_theta, &ctx->lt_phi,
                        &ctx->avgph, &ctx->term_ap, &ctx->seams_q, &ctx->chunkinfo };
     for (DevBuf *b : bufs) b->release();
     for (hipEvent_t e : ctx->event_pool) (void)hipEventDestroy(e);
@@ -2947,7 +2976,7 @@ template <typename T> static int stage_agc(pdt_ctx *ctx, void *data_host, uint64
                (const T *)nullptr, a_out, (AgcSeam<T> *)ctx->seams_agc.p, agc_K);
     PDT_LAUNCH(1024, k_agc_scan<T>, dim3(1), dim3(1024), 0, st, na, Ba, (const AgcSeam<T> *)ctx->seams_agc.p, &d_sc->agc_first_bad);
     PDT_LAUNCH(64, k_agc_fix<T>, dim3(1), dim3(64), 0, st, a_in, na, AP, Ba, (const T *)nullptr, a_out, (AgcSeam<T> *)ctx->seams_agc.p,
-               d_sc->counters, (const long long *)&d_sc->agc_first_bad);
+               d_sc->counters, (const long long *)&d_sc->agc_first_bad, (T *)nullptr);
     {
         pdt_ctx *self = ctx;
         if ((rc = execute_plans(&self, 1))) return rc;

@@ -2478,6 +2478,194 @@ __device__ __forceinline__ void k_agc_block(const T *__restrict__ in, long long 
     seams[j] = sm;
 }
 
+// ---- round 4: the same walk with full-line transfers.
+// What held k_agc_block up at an hour of 250 ksps (3.3 ms) was never its arithmetic (0.83 ms with its memory instructions
+// taken out, tools/probes/agc_mem_probe.hip) but the shape of its accesses: every lane streams its own block, so a wavefront's
+// 16-byte store touches 64 different lines, a sixth of each -- partial-line writes HBM takes at 2.1 TB/s (1.7 ms for the
+// stores alone), and loads and stores of that shape do not overlap (1.4 + 1.7 = 3.2 ms).  Here a wavefront still owns 64
+// consecutive blocks, one per lane, but samples move in SUPER-BATCHES of 32 per lane (128 B = one line per block), eight
+// lanes to a line: transfer instruction s (of 8) carries the blocks l with (l & 7) == s; its lane t moves piece (t & 7) of
+// block 8 (t >> 3) + s -- eight full lines per instruction -- to / from LDS slot s.  Slots are 1040 B apart, so that the
+// walker lane l finds piece p of its own block at (l & 7) * 1040 + (l >> 3) * 128 + 16 p and all 16-byte LDS accesses, on
+// the transfer face and on the walker face, are conflict-free.  Loads are LDS-direct, R super-batches ahead; outputs go
+// through one staging super-batch.  Same arithmetic, same 16-sample calm batches: the outputs are those of agc_range bit
+// for bit (10.8 GB in 1.84 ms = 5.9 TB/s in the probe; 1.47 ms with the tile-granular warm-up below).
+#define PDT_AGC_CKPT 1024     // samples between two gain checkpoints of a block (a multiple of 32)
+#define PDT_TR_SLOT 1040
+#define PDT_TR_SB (8 * PDT_TR_SLOT)
+#ifndef PDT_AGC_TR_R
+#define PDT_AGC_TR_R 4
+#endif
+typedef float pdt_f4 __attribute__((ext_vector_type(4)));
+
+// walk nsb super-batches from element e0 (= the place of lane 0's block start + rel0 in the stream; every lane walks the
+// same offsets of its own block).  STORE false = warm-up: a lane idles (keeps its gain) until rel reaches its own `from`.
+// PARTIAL = the wavefront holds blocks that end at n (or lie behind it): every stored piece is checked against n.
+// CLAMP = the walk reaches in front of the stream's first sample (long warm-ups of the first wavefronts): those lines are
+// wanted by idle lanes only and are fetched from sample 0 on instead.
+template <bool STORE, bool PARTIAL, bool CLAMP, int R>
+__device__ __forceinline__ void agc_range_tr(const float *__restrict__ in, float *__restrict__ out, long long e0, int rel0, long long nsb,
+                                             float &gain, int from, const AgcParams<float> &P, unsigned char *ring,
+                                             const unsigned (&voff)[8], long long n, long long B, long long jb0,
+                                             float *__restrict__ ckpt = nullptr)
+{
+    const int t = threadIdx.x & 63;
+    const unsigned ring0 = (unsigned)(size_t)ring;
+    const unsigned char *mine = ring + (t & 7) * PDT_TR_SLOT + (t >> 3) * 128;
+    unsigned char *stage_mine = ring + R * PDT_TR_SB + (t & 7) * PDT_TR_SLOT + (t >> 3) * 128;
+    const unsigned char *stage_row = ring + R * PDT_TR_SB + t * 16;
+    const char *gin = (const char *)(in + e0);
+    char *gout = (char *)(out + e0);
+    auto issue = [&](long long sb, int slot) {
+        const char *b = gin + sb * 128;
+#pragma unroll
+        for (int s = 0; s < 8; s++) {
+            unsigned vo = voff[s];
+            if (CLAMP) {
+                const long long e = e0 + sb * 32;                    // element the scalar base stands at (uniform)
+                if (e + (long long)(vo >> 2) < 0) vo = (unsigned)((4 * (t & 7) - e) * 4);
+            }
+            asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" : : "v"(vo), "s"(b),
+                         "s"(ring0 + slot * PDT_TR_SB + s * PDT_TR_SLOT) : "memory");
+        }
+    };
+#pragma unroll
+    for (int u = 0; u < R; u++) issue(u, u);         // (up to R super-batches past the range: slack of the device buffers)
+    int slot = 0;
+    int rel = rel0;
+    for (long long sb = 0; sb < nsb; sb++, rel += 32) {
+        // requests younger than this super-batch's loads: the loads of the R - 1 super-batches behind it (loads complete
+        // in order among themselves; the counter also holds the stores, so this never waits for too little)
+        ring_wait<(R - 1) * 8>();
+        Vec16<float> x[8], y[8];
+#pragma unroll
+        for (int p = 0; p < 8; p++) x[p] = *reinterpret_cast<const Vec16<float> *>(mine + slot * PDT_TR_SB + p * 16);
+#pragma unroll
+        for (int h = 0; h < 2; h++) {
+            float g = gain;
+            if (agc_calm<float, 4>(x + 4 * h, g, P.decay)) {
+#pragma unroll
+                for (int k = 0; k < 4; k++)
+#pragma unroll
+                    for (int w = 0; w < 4; w++) y[4 * h + k].v[w] = agc_step_calm(x[4 * h + k].v[w], g, P.decay);
+            } else {
+#pragma unroll
+                for (int k = 0; k < 4; k++)
+#pragma unroll
+                    for (int w = 0; w < 4; w++) y[4 * h + k].v[w] = agc_step(x[4 * h + k].v[w], g, P);
+            }
+            if (STORE) gain = g;
+            else gain = (rel + 16 * h >= from) ? g : gain;
+        }
+        if (STORE) {
+#pragma unroll
+            for (int p = 0; p < 8; p++) *reinterpret_cast<Vec16<float> *>(stage_mine + p * 16) = y[p];
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            char *ob = gout + sb * 128;
+#pragma unroll
+            for (int s = 0; s < 8; s++) {
+                const pdt_f4 v = *reinterpret_cast<const pdt_f4 *>(stage_row + s * PDT_TR_SLOT);
+                if (!PARTIAL) {
+                    asm volatile("global_store_dwordx4 %0, %1, %2" : : "v"(voff[s]), "v"(v), "s"(ob) : "memory");
+                } else {
+                    // (voff of a block behind the stream's end points at block 0: go by the block's real place)
+                    const long long bstart = (jb0 + 8 * (t >> 3) + s) * B;
+                    const long long pos = bstart + rel + 4 * (t & 7);
+                    const long long lim = n - pos;                   // elements of the stream from this piece on
+                    if (bstart < n) {
+                        if (lim >= 4) *reinterpret_cast<pdt_f4 *>(out + pos) = v;
+                        else
+                            for (int w = 0; w < 4; w++)
+                                if (w < lim) out[pos + w] = v[w];
+                    }
+                }
+            }
+        }
+        // the gain after every PDT_AGC_CKPT samples of the block: a seam repair stops at the first one it reproduces
+        if (STORE && ckpt && (sb & (PDT_AGC_CKPT / 32 - 1)) == PDT_AGC_CKPT / 32 - 1) ckpt[sb / (PDT_AGC_CKPT / 32)] = gain;
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");           // the slot's reads are done: it may be refilled
+        issue(sb + R, slot);
+        slot = (slot + 1 == R) ? 0 : slot + 1;
+    }
+    ring_wait<0>();
+}
+
+// Block-parallel AGC with full-line transfers (float, no Squelch, no raw copy; B a multiple of 32, streams on 128-byte
+// boundaries).  Warm-ups start at a tile boundary (tile_len samples, a multiple of 32, maps_per_tile of the FIR kernel's
+// affine maps to a tile, maps_per_block to a block) instead of a block boundary: the guess there is the block-boundary guess carried on through the tile maps in
+// double, so a walker replays K time constants and not a whole block (9 984 instead of 28 288 samples at an hour of
+// 250 ksps).  The lanes of a wavefront walk in step: the wavefront replays the longest warm-up among its lanes, a lane
+// idles until its own begins.
+template <int R>
+__device__ __forceinline__ void k_agc_block_tr(const float *__restrict__ in, long long n, AgcParams<float> P,
+                                               const float *__restrict__ norm, long long B, long long W,
+                                               const double *__restrict__ guesses, const AgcMap *__restrict__ tmaps,
+                                               int maps_per_block, int maps_per_tile, long long n_maps, long long tile_len,
+                                               float *__restrict__ out, AgcSeam<float> *__restrict__ seams, double K,
+                                               float *__restrict__ ckpt)
+{
+    __shared__ __attribute__((aligned(128))) unsigned char ring[(R + 1) * PDT_TR_SB];
+    const int t = threadIdx.x & 63;
+    const long long jb0 = (long long)blockIdx.x * 64;
+    if (jb0 * B >= n) return;
+    const long long j = jb0 + t;
+    const long long start = j * B;
+    const bool valid = start < n;
+    unsigned voff[8];
+#pragma unroll
+    for (int s = 0; s < 8; s++) {
+        // blocks of this wavefront that lie behind the stream's end transfer block 0's lines instead (never stored)
+        long long b = 8 * (t >> 3) + s;
+        if ((jb0 + b) * B >= n) b = 0;
+        voff[s] = (unsigned)((b * B + 4 * (t & 7)) * 4);
+    }
+    // the lane's own warm-up: K time constants of the guessed gain, in whole tiles, never more than W samples
+    long long ws = 0;
+    float gain = *norm;
+    if (valid && j >= 1) {
+        const double g_here = guesses[j];
+        double need = K * g_here / (double)P.decay;
+        if (need < 4096.0) need = 4096.0;
+        if (need > (double)W) need = (double)W;
+        const long long m = (long long)((need + (double)tile_len - 1.0) / (double)tile_len);
+        const long long q = (start - m * tile_len) / tile_len;       // tile the warm-up starts at (start is a tile boundary)
+        if (start - m * tile_len > 0 && q >= 1) {
+            ws = q * tile_len;
+            const long long jb = ws / B;                             // the block boundary at or in front of it: its guess,
+            double g = guesses[jb];                                  // carried on through the maps up to the tile
+            for (long long u = jb * maps_per_block; u < q * maps_per_tile; u++)
+                if (u < n_maps) {
+                    const AgcMap mp = tmaps[u];
+                    g = mp.A * g + mp.B;
+                }
+            if (!(g > 1e-4)) g = 1e-4;
+            if (g > 5000.0) g = 5000.0;
+            gain = (float)g;
+        }
+    }
+    const bool partial = (jb0 + 64) * B > n;
+    // longest warm-up of the wavefront (in samples before the block start; whole super-batches: starts and tiles are)
+    int back = valid ? (int)(start - ws) : 0;
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) {
+        const int o = __shfl_xor(back, d);
+        back = back > o ? back : o;
+    }
+    back = __builtin_amdgcn_readfirstlane(back);
+    const int from = valid ? -(int)(start - ws) : 0x7fffffff;        // rel at which this lane's warm-up begins
+    if (back > 0) {
+        if (jb0 * B >= back) agc_range_tr<false, false, false, R>(in, out, jb0 * B - back, -back, back / 32, gain, from, P, ring, voff, n, B, jb0);
+        else agc_range_tr<false, false, true, R>(in, out, jb0 * B - back, -back, back / 32, gain, from, P, ring, voff, n, B, jb0);
+    }
+    AgcSeam<float> sm;
+    sm.g0 = gain;
+    float *my_ckpt = (ckpt && valid) ? ckpt + j * (B / PDT_AGC_CKPT) : nullptr;
+    if (!partial) agc_range_tr<true, false, false, R>(in, out, jb0 * B, 0, B / 32, gain, 0, P, ring, voff, n, B, jb0, my_ckpt);
+    else agc_range_tr<true, true, false, R>(in, out, jb0 * B, 0, B / 32, gain, 0, P, ring, voff, n, B, jb0, my_ckpt);
+    sm.g1 = gain;
+    if (valid) seams[j] = sm;
+}
+
 // first seam that does not close (or the number of blocks): one workgroup, every thread a stride of seams.  Almost
 // always there is none, and k_agc_fix then has nothing to scan (alone, its single wavefront took 64 seams per round trip
 // to memory: 0.05 ms on 9 000 blocks).
@@ -2502,7 +2690,7 @@ template <typename T>
 __device__ __forceinline__ void k_agc_fix(const T *__restrict__ in, long long n, AgcParams<T> P, long long B,
                                                  const T *__restrict__ lock, T *__restrict__ out,
                                                  AgcSeam<T> *__restrict__ seams, unsigned *__restrict__ counters,
-                                                 const long long *__restrict__ first_bad)
+                                                 const long long *__restrict__ first_bad, T *__restrict__ ckpt = nullptr)
 {
     // same wave-parallel seam scan as k_pll_fix, from the first seam k_agc_scan found open
     __shared__ __attribute__((aligned(16))) unsigned char ring[PDT_AGC_PF * PDT_RING_SLOT];
@@ -2523,9 +2711,24 @@ __device__ __forceinline__ void k_agc_fix(const T *__restrict__ in, long long n,
             T gain = g_true;
             const long long start = rb * B;
             const long long end = (start + B < n) ? start + B : n;
+            bool merged = false;
+            if (ckpt) {
+                // (k_agc_block_tr left the gain after every PDT_AGC_CKPT samples behind: the re-run and the stored walk differ by
+                // the rounding noise of a start a few ulps off, so they agree again after a time constant or two -- from the
+                // first checkpoint the re-run reproduces, the rest of the block, its end state included, stands as stored)
+                const long long ncp = B / PDT_AGC_CKPT;
+                T *cp = ckpt + rb * ncp;
+                long long c = 0;
+                for (; c < ncp && start + (c + 1) * PDT_AGC_CKPT <= end; c++) {
+                    agc_range<T, true>(in, lock, out, start + c * PDT_AGC_CKPT, start + (c + 1) * PDT_AGC_CKPT, gain, P, ring);
+                    if (bits_equal(cp[c], gain)) { merged = true; break; }
+                    cp[c] = gain;
+                }
+                if (!merged) agc_range<T, true>(in, lock, out, start + c * PDT_AGC_CKPT, end, gain, P, ring);
+            } else
             agc_range<T, true>(in, lock, out, start, end, gain, P, ring);
             seams[rb].g0 = g_true;
-            seams[rb].g1 = gain;
+            if (!merged) seams[rb].g1 = gain;
         }
         __threadfence_block();
         __syncthreads();
