@@ -217,7 +217,7 @@ def pmc_traffic(cfg: str, kernel: str, build: str):
     """HBM bytes per launch of `kernel` from the committed rocprofv3 counter passes (FETCH_SIZE x2 + WRITE_SIZE, see
     tools/pmc_traffic.py and profiles/r3/README.md) -- only from a file measured with the library build that is running now
     (its `build` tag); otherwise None: a figure of another build says nothing about this one."""
-    for rnd in ("r3", "r2", "r1"):
+    for rnd in ("r4", "r3", "r2", "r1"):
         path = os.path.join(ROOT, "profiles", rnd, f"pmc_hbm_traffic_bench_{cfg}.json")
         try:
             doc = json.load(open(path))
@@ -231,6 +231,19 @@ def pmc_traffic(cfg: str, kernel: str, build: str):
         except (OSError, ValueError, KeyError):
             pass
     return None
+
+
+HBM_STREAM_GBS = 5800.0     # what streaming kernels reach on this chip (k_pll_theta, the AGC walkers: 5.8 - 6.0 TB/s of 8)
+
+
+def roofline_bound(ms: float, traffic, alg_bytes: int) -> str:
+    """What holds the dominant kernel up, from the evidence at hand: "hbm" when the bytes it moves (counter traffic of this
+    build if committed, its algorithmic bytes otherwise) take more than half its time at the rate streaming kernels reach
+    here, "latency" otherwise (a serial float recurrence on lone wavefronts: its time is a walk length x the step's pace)."""
+    moved = traffic if traffic else alg_bytes
+    if not ms or not moved:
+        return "latency"
+    return "hbm" if moved / (ms * 1e-3) / 1e9 >= 0.5 * HBM_STREAM_GBS else "latency"
 
 
 def cpu_exe(kind: int):
@@ -418,7 +431,7 @@ def run(args, pdt, torch, dist, rank, local, world, dev, cdev, cfg, kind, fs, se
                        "samples_per_gpu": n * ncap, "captures": world * ncap,
                        "parallelism": f"{ncap} capture(s) per GPU x{world}"
                                       + (" (batched many-capture mode: one launch per stage for all captures, same capture in every slot)" if ncap > 1 else "")},
-            "roofline": {"bound": "hbm", "kernel": dom_kernel, "group": dom,
+            "roofline": {"bound": roofline_bound(stages[dom]["ms"], traffic, stages[dom]["alg_bytes"]), "kernel": dom_kernel, "group": dom,
                          "achieved": stages[dom]["GBps"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": stages[dom]["frac_hbm"], "traffic": traffic,
                          "alg_bytes": stages[dom]["alg_bytes"], "ms": stages[dom]["ms"],
@@ -452,7 +465,7 @@ def run(args, pdt, torch, dist, rank, local, world, dev, cdev, cfg, kind, fs, se
             e2e_ms, split = [], []
             with pdt.Demodulator(mode, fs, device=local).keep_pll(False) as de:
                 for rep in range(3):
-                    outp = os.path.join(tmp, "e2e_out.txt")
+                    outp = os.path.join(tmp, f"e2e_out{rep}.txt")         # (a new file every time, as the host program's)
                     t1 = time.perf_counter()
                     fd = os.open(wav, os.O_RDONLY)
                     hdr = os.pread(fd, 44, 0)
@@ -462,23 +475,28 @@ def run(args, pdt, torch, dist, rank, local, world, dev, cdev, cfg, kind, fs, se
                     de.demod_file(fd, 44, nfr, 0)
                     os.close(fd)
                     t3 = time.perf_counter()
-                    text = de.text()
-                    t4 = time.perf_counter()
-                    with open(outp, "wb") as fo:
-                        fo.write(text)
+                    fo = os.open(outp, os.O_RDWR | os.O_CREAT | os.O_TRUNC, 0o644)
+                    de.write_frames(fo)                                 # pdt_write_frames: as bin/demodPOES writes its file
+                    os.close(fo)
                     t5 = time.perf_counter()
                     e2e_ms.append((t5 - t1) * 1e3)
                     split.append({"open_header": round((t2 - t1) * 1e3, 3), "demod_fd": round((t3 - t2) * 1e3, 3),
-                                  "text": round((t4 - t3) * 1e3, 3), "write_close": round((t5 - t4) * 1e3, 3)})
+                                  "text_write_close": round((t5 - t3) * 1e3, 3)})
                     assert rate == fs and nfr == n
-                e2e_text = text
+                e2e_text = open(outp, "rb").read()                       # (the parity legs compare the FILE's bytes)
+                assert e2e_text == de.text()
                 e2e_gpu_ms = de.stats().gpu_ms
             best = min(e2e_ms)
             out["e2e"] = {"ms": round(best, 3), "value": round(n / best / 1e3, 3), "unit": "Msamples/s", "runs_ms": [round(x, 3) for x in e2e_ms],
                           "gpu_ms": round(e2e_gpu_ms, 3), "file_bytes": 44 + 4 * n, "split_ms": split[e2e_ms.index(best)],
                           "includes": "open WAV on tmpfs, header, threaded pread into pinned memory + copies to HBM (pdt_demod_fd), "
-                                      "all kernels, frame records to the host, time stamps, text formatting, output file "
-                                      "written and closed; context already open (HIP initialised)"}
+                                      "all kernels, frame records to the host, time stamps, text formatted and written to the "
+                                      "output file (pdt_write_frames), file closed; context already open (HIP initialised)"}
+            # the figure BASELINE.json's metric names, beside `value` (which is the resident rate)
+            out["metric_e2e"] = ("IQ Msamples/s end-to-end (WAV file on tmpfs -> minorframes file closed), 1 GPU, in process, HIP "
+                                 "already initialised; `e2e_cli` is the C host program from process start")
+            out["value_e2e"] = out["e2e"]["value"]
+            out["ms_e2e"] = out["e2e"]["ms"]
             parity["e2e_text_equals_resident_full_size"] = bool(e2e_text == gpu_text)
             if args.e2e_only:
                 out["parity"] = parity
@@ -538,10 +556,11 @@ def run(args, pdt, torch, dist, rank, local, world, dev, cdev, cfg, kind, fs, se
             del d_iq
             torch.cuda.empty_cache()
             out["secondary"] = {}
-            for c2 in ("c2", "argos"):
+            for c2 in ("c2", "argos", "aos"):
                 try:
-                    r = subprocess.run([sys.executable, os.path.abspath(__file__), "--config", c2, "--steps", "10", "--warmup", "2",
-                                        "--no-secondary"], capture_output=True, text=True, timeout=900)
+                    r = subprocess.run([sys.executable, os.path.abspath(__file__), "--config", c2, "--steps", "3" if c2 == "aos" else "10",
+                                        "--warmup", "1" if c2 == "aos" else "2", "--no-secondary"] + (["--no-cpu"] if c2 == "aos" else []),
+                                       capture_output=True, text=True, timeout=900)
                     ref = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
                     out["secondary"][c2] = {k: ref.get(k) for k in ("value", "unit", "ms_per_step", "dtype", "roofline", "fir_pll_stage",
                                                                       "e2e", "e2e_cli", "cpu_baseline", "parity")}

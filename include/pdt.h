@@ -60,7 +60,13 @@
 extern "C" {
 #endif
 
-#define PDT_ABI_VERSION 1
+/* 2 (round 4): + pdt_write_frames / pdt_write_records.  Behaviour a client of version 1 should know about, all of it
+ * introduced under version 1 in round 3 without a bump: pdt_build_tag, pdt_keep_pll, pdt_stage_bytesync_from and the error
+ * code PDT_ERR_IO exist; every pdt_demod_* and pdt_stage_* entry returns PDT_ERR_STATE while a stream is open, and the first
+ * pdt_stream_push_* opens one by itself (resetting frames and statistics); pdt_demod_fd may demodulate a large file in
+ * segments while it is still being read (environment PDT_OVERLAP; off by default since version 2), after which
+ * pdt_read_stage / pdt_stage_len describe the last segment only.                                                      */
+#define PDT_ABI_VERSION 2
 
 enum { PDT_MODE_POES = 0, PDT_MODE_ARGOS = 1 };
 enum { PDT_SAMPLER_GARDNER = 0, PDT_SAMPLER_MM = 1 };
@@ -276,6 +282,12 @@ uint64_t pdt_format_frames(const pdt_ctx *ctx, char *buf, uint64_t cap);
 /* The same text for any array of frame records (e.g. the records of several captures gathered on one rank); host only, no
  * context and no GPU needed.  POESTIPdemod/ByteSync.c:62-69,96-101, ARGOSdemod/ByteSync.c:62-70,99-103.                 */
 uint64_t pdt_format_records(const pdt_frame *frames, uint64_t nframes, char *buf, uint64_t cap);
+/* The same text written to an open file descriptor, from the descriptor's position on (the reference's fprintf calls,
+ * ByteSync.c:62-101, all at once): slices of the frames are formatted and written side by side (pwrite) when the
+ * descriptor can seek, in order otherwise; the position ends behind the text.  *bytes_written may be NULL.
+ * PDT_ERR_IO when a write fails.  (ABI 2)                                                                         */
+int      pdt_write_frames(const pdt_ctx *ctx, int fd, uint64_t *bytes_written);
+int      pdt_write_records(const pdt_frame *frames, uint64_t nframes, int fd, uint64_t *bytes_written);
 
 /* Copy an intermediate stream back to the host (elements [first, first+count)); returns the
  * number of elements copied, or a negative error.  Element type per the PDT_ST_* table;

@@ -156,6 +156,7 @@ ABI_SYMBOLS = [
     "pdt_stream_begin", "pdt_stream_push_pcm16", "pdt_stream_push_f32", "pdt_stream_end", "pdt_stream_frames",
     "pdt_keep_quality", "pdt_chunk_reports", "pdt_stage_manchester", "pdt_stage_fir", "pdt_stage_agc", "pdt_stage_squelch", "pdt_stage_pll", "pdt_stage_gardner", "pdt_stage_static_gain", "pdt_stage_mm",
     "pdt_keep_presquelch", "pdt_keep_pll", "pdt_stage_bytesync_from", "pdt_demod_fd", "pdt_format_records", "pdt_stream_retained", "pdt_host_math", "pdt_get_device",
+    "pdt_write_frames", "pdt_write_records",
 ]
 
 _lib = None
@@ -267,7 +268,9 @@ def lib():
     L.pdt_tip_check.argtypes = [C.c_void_p, C.POINTER(TipSummary)]
     L.pdt_tip_frames.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64]
     L.pdt_tip_frames.restype = C.c_uint64
-    if L.pdt_abi_version() != 1:
+    L.pdt_write_frames.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.c_uint64)]
+    L.pdt_write_records.argtypes = [C.c_void_p, C.c_uint64, C.c_int, C.POINTER(C.c_uint64)]
+    if L.pdt_abi_version() != 2:
         raise PdtError("libpdt.so ABI version mismatch")
     _lib = L
     return L
@@ -521,6 +524,13 @@ class Demodulator:
         buf = C.create_string_buffer(cap)
         n = self._L.pdt_format_frames(self._h, buf, cap)
         return buf.raw[:n]
+
+    def write_frames(self, fd: int) -> int:
+        """The text of the last run written to an open file descriptor (``pdt_write_frames``: formatted and written in slices
+        by a few threads); returns the number of bytes."""
+        nb = C.c_uint64(0)
+        _check(self._L.pdt_write_frames(self._h, int(fd), C.byref(nb)), "pdt_write_frames")
+        return int(nb.value)
 
     def stage(self, st: int, first: int = 0, count: int | None = None) -> np.ndarray:
         total = self._L.pdt_stage_len(self._h, st)

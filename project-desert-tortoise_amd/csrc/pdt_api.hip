@@ -241,7 +241,7 @@ struct Plan {
 struct Tuning {
     double band_pad = 0.0, pll_warm_scale = 1.0, head_taus = 0.0, agc_k = 0.0, pll_warm_s = 0.0, agc_warm_s = 0.0;
     int scout_syms = 0, gspan = 0, gspan_cap = 0, mf_waves = 8, ingest_threads = 0, ingest_span_mb = 0, ingest_streams = 0, overlap_segments = 0, overlap_min_mb = 0, fir_wg_per_cu = 0, agc_tpb = 0, gseg = 0, acquire_mode = 0, pll_block = 0, fix_passes = 2;      // acquire_mode: 0 = two-wavefront pipeline, 1 = plain one-lane, 2 = one wavefront
-    bool fir_generic = false, mix_unfused = false, quality_inline = false, gemit_groups = false, agc_unfused = false, no_excl = false, gtab_nomerge = false, gardner_onebuf = false, gardner_noring = false, gardner_sequential = false, seg_sequential = false, agc_lanes = false, no_overlap = false, debug_overlap = false, chain_one_range = false, ema_noguess = false, debug_sync = false;
+    bool fir_generic = false, mix_unfused = false, quality_inline = false, gemit_groups = false, agc_unfused = false, no_excl = false, gtab_nomerge = false, gardner_onebuf = false, gardner_noring = false, gardner_sequential = false, seg_sequential = false, agc_lanes = false, overlap = false, debug_overlap = false, chain_one_range = false, ema_noguess = false, debug_sync = false;
     void load()
     {
         if (const char *e = getenv("PDT_PLL_WARM_SCALE")) pll_warm_scale = atof(e);
@@ -277,7 +277,7 @@ struct Tuning {
         ema_noguess = getenv("PDT_EMA_NOGUESS") != nullptr;
         gardner_sequential = getenv("PDT_GARDNER_SEQUENTIAL") != nullptr;
         seg_sequential = getenv("PDT_SEG_SEQUENTIAL") != nullptr;
-        no_overlap = getenv("PDT_NO_OVERLAP") != nullptr;
+        overlap = getenv("PDT_OVERLAP") != nullptr && getenv("PDT_NO_OVERLAP") == nullptr;
         chain_one_range = getenv("PDT_CHAIN_ONE_RANGE") != nullptr;
         debug_overlap = getenv("PDT_DEBUG_OVERLAP") != nullptr;
         if (const char *e = getenv("PDT_OVERLAP_SEGMENTS")) overlap_segments = std::min(64, std::max(1, atoi(e)));
@@ -1954,7 +1954,9 @@ int ingest_capture(pdt_ctx *ctx, const IngestSrc &src, size_t bytes, void *dst, 
         return PDT_OK;
     }
     unsigned hw = std::thread::hardware_concurrency();
-    const unsigned t_max = ctx->tune.ingest_threads > 0 ? (unsigned)ctx->tune.ingest_threads : 16u;
+    // (round 4, 3.6 GB from tmpfs: 4 / 6 / 8 / 12 / 16 threads -> 100 / 92 / 88 / 90 / 89 ms for the whole call; beside a chain that
+    // is launching kernels -- PDT_OVERLAP -- 8 / 16 / 24 / 32 -> 98 / 116 / 107 / 111: the readers contend with the launches)
+    const unsigned t_max = ctx->tune.ingest_threads > 0 ? (unsigned)ctx->tune.ingest_threads : 8u;
     int T = (int)std::min<size_t>(std::min<unsigned>(hw ? hw / 2u + 1u : 4u, t_max), nspans);
     if (T < 1) T = 1;
     const size_t need = (size_t)T * PDT_INGEST_SLOTS * PDT_INGEST_SPAN;
@@ -2401,7 +2403,11 @@ static int demod_overlapped(pdt_ctx *ctx, const IngestSrc &src, uint64_t nframes
 static bool overlap_ingest(const pdt_ctx *ctx, uint64_t nframes, size_t fb)
 {
     // (per-chunk reports come from whole-capture runs only: with pdt_keep_quality the capture is ingested first)
-    return !ctx->tune.no_overlap && !ctx->keep_quality && ctx->cfg.mode == PDT_MODE_POES && ctx->cfg.sampler != PDT_SAMPLER_MM && ctx->cfg.chain != PDT_CHAIN_LIVE &&
+    // Round 4: off unless PDT_OVERLAP is set.  Every segment pays the latency floor of the block-parallel stages again and runs
+    // the stream path's kernels (no fused mix + FIR, per-lane AGC walkers): with the whole-capture step at 19 ms the four
+    // segments cost 49 ms of GPU time and the ingest slows down beside them -- 3.6 GB file to frame file: 121 ms overlapped,
+    // 91 ms with the capture ingested first (profiles/r4).
+    return ctx->tune.overlap && !ctx->keep_quality && ctx->cfg.mode == PDT_MODE_POES && ctx->cfg.sampler != PDT_SAMPLER_MM && ctx->cfg.chain != PDT_CHAIN_LIVE &&
            (size_t)nframes * fb >= ((size_t)(ctx->tune.overlap_min_mb > 0 ? ctx->tune.overlap_min_mb : 512) << 20) && ctx->cfg.chunk > 0 &&
            nframes / ctx->cfg.chunk >= 64;
 }
@@ -3560,6 +3566,62 @@ uint64_t pdt_format_frames(const pdt_ctx *ctx, char *buf, uint64_t cap)
 {
     if (!ctx) return 0;
     return pdt_format_records(ctx->frames_host.data(), ctx->frames_host.size(), buf, cap);
+}
+
+// The reference writes its output file byte by byte while it demodulates (fprintf, ByteSync.c:62-101).  Here the text exists
+// only after the run: an hour of POES is 36 000 lines, 12 MB.  A few threads take a slice of the frames each: format it into a
+// buffer of their own and pwrite it at its place as soon as the sizes of the slices in front are known (the writes queue on
+// the inode, but behind the formatting of the other slices instead of after it).  Measured on the GPU box's tmpfs: formatting
+// 2.5 ms on one thread, the write 2.3 ms; a shared mapping of the file filled in place by all threads was slower (4.3 ms: the
+// page faults of a fresh tmpfs mapping cost more than the copy they save).  A descriptor that cannot seek takes the text in order.
+int pdt_write_records(const pdt_frame *frames, uint64_t nframes, int fd, uint64_t *bytes_written)
+{
+    if (bytes_written) *bytes_written = 0;
+    if (fd < 0 || (!frames && nframes)) return PDT_ERR_ARG;
+    if (!nframes) return PDT_OK;
+    const off_t at0 = lseek(fd, 0, SEEK_CUR);
+    const int T = at0 < 0 ? 1 : (int)std::max<uint64_t>(1, std::min<uint64_t>(6, nframes / 2048));
+    std::vector<uint64_t> first((size_t)T + 1);
+    for (int t = 0; t <= T; t++) first[(size_t)t] = nframes * (uint64_t)t / (uint64_t)T;
+    std::unique_ptr<std::atomic<long long>[]> size(new std::atomic<long long>[(size_t)T]);
+    for (int t = 0; t < T; t++) size[(size_t)t].store(-1);
+    std::atomic<int> bad{0};
+    auto work = [&](int t) {
+        const uint64_t a = first[(size_t)t], b = first[(size_t)t + 1];
+        std::unique_ptr<char[]> buf(new char[(size_t)(b - a) * (PDT_TIME5_MAX + 4 + 3 * 104 + 2)]);     // (not touched beyond the text)
+        const uint64_t sz = pdt_format_records(frames + a, b - a, buf.get(), ~0ull);
+        size[(size_t)t].store((long long)sz, std::memory_order_release);
+        uint64_t off = 0;
+        for (int u = 0; u < t; u++) {
+            long long v;
+            while ((v = size[(size_t)u].load(std::memory_order_acquire)) < 0) std::this_thread::yield();
+            off += (uint64_t)v;
+        }
+        size_t done = 0;
+        while (done < sz) {
+            const ssize_t r = at0 >= 0 ? pwrite(fd, buf.get() + done, sz - done, at0 + (off_t)off + (off_t)done)
+                                       : write(fd, buf.get() + done, sz - done);
+            if (r < 0 && errno == EINTR) continue;
+            if (r <= 0) { bad = 1; return; }
+            done += (size_t)r;
+        }
+    };
+    std::vector<std::thread> pool;
+    for (int t = 1; t < T; t++) pool.emplace_back(work, t);
+    work(0);
+    for (auto &th : pool) th.join();
+    if (bad) return PDT_ERR_IO;
+    uint64_t total = 0;
+    for (int t = 0; t < T; t++) total += (uint64_t)size[(size_t)t].load();
+    if (at0 >= 0) (void)lseek(fd, at0 + (off_t)total, SEEK_SET);
+    if (bytes_written) *bytes_written = total;
+    return PDT_OK;
+}
+
+int pdt_write_frames(const pdt_ctx *ctx, int fd, uint64_t *bytes_written)
+{
+    if (!ctx) return PDT_ERR_ARG;
+    return pdt_write_records(ctx->frames_host.data(), ctx->frames_host.size(), fd, bytes_written);
 }
 
 uint64_t pdt_stage_len(const pdt_ctx *ctx, int stage)

@@ -284,7 +284,7 @@ int main(int argc, char **argv)
     else
         snprintf(outFileName, sizeof outFileName, PREFIX "_%4d%02d%02d_%02d%02d%02d.txt", tm.tm_year + 1900, tm.tm_mon + 1,
                  tm.tm_mday, tm.tm_hour, tm.tm_min, tm.tm_sec);
-    FILE *out = fopen(outFileName, "w");
+    FILE *out = fopen(outFileName, "w+");
     if (!in || !out) {
         printf("Error opening output files\n");
         exit(1);
@@ -420,12 +420,19 @@ int main(int argc, char **argv)
 
     if (!noProgress && num_samples > 0) print_progress(ctx, num_samples, (unsigned long)chunkSize);
 
-    uint64_t need = pdt_format_frames(ctx, NULL, 0);
-    char *text = (char *)malloc(need + 1);
-    pdt_format_frames(ctx, text, need);
-    fwrite(text, 1, need, out);
+    char *text = NULL;
+    fflush(out);
+    if (pdt_write_frames(ctx, fileno(out), NULL) != PDT_OK) {        /* the minor frames / packets, all at once */
+        printf("Error writing output file\n");
+        exit(1);
+    }
 #ifdef PDT_ARGOS
-    fwrite(text, 1, need, stdout);                                   /* ARGOSdemod/ByteSync.c mirrors to stdout */
+    {
+        uint64_t need = pdt_format_frames(ctx, NULL, 0);
+        text = (char *)malloc(need + 1);
+        pdt_format_frames(ctx, text, need);
+        fwrite(text, 1, need, stdout);                               /* ARGOSdemod/ByteSync.c mirrors to stdout */
+    }
 #endif
     printf("100.0%% %0.3f Ks : %llu Sym : %llu Bits : %llu " UNIT "   (GPU %.3f ms)\n", st.samples / 1000.0,
            (unsigned long long)st.symbols, (unsigned long long)st.bits, (unsigned long long)st.frames, st.gpu_ms);

@@ -152,6 +152,47 @@ def test_format_records_equals_printf(pdt):
     assert pdt.format_frames(fr[:0]) == b""
 
 
+def test_write_records_equals_format_records(pdt, tmp_path):
+    """pdt_write_records (slices formatted and written side by side with pwrite) leaves exactly the bytes of
+    pdt_format_records in the file, from the descriptor's position on, and the position behind them; a descriptor that
+    cannot seek (a pipe) takes the text in order.  Host only."""
+    import numpy as np
+    L = pdt.lib()
+    assert L.pdt_abi_version() == 2
+    rng = np.random.default_rng(11)
+    for n in (0, 1, 7, 2048, 2049, 40000):
+        fr = np.zeros(n, dtype=pdt.FRAME_DTYPE)
+        fr["time"] = rng.random(n).astype(np.float32).astype(np.float64) * 3600.0
+        fr["nbytes"] = rng.integers(0, 105, n)
+        fr["bytes"] = rng.integers(0, 256, (n, 104))
+        fr["inverted"] = rng.integers(0, 2, n)
+        fr["complete"] = rng.integers(0, 2, n)
+        want = pdt.format_frames(fr)
+        path = str(tmp_path / f"w{n}.txt")
+        fd = os.open(path, os.O_RDWR | os.O_CREAT | os.O_TRUNC, 0o644)
+        os.write(fd, b"head\n")
+        nb = C.c_uint64(123)
+        assert L.pdt_write_records(fr.ctypes.data, n, fd, C.byref(nb)) == 0
+        assert nb.value == len(want)
+        assert os.lseek(fd, 0, os.SEEK_CUR) == 5 + len(want)
+        os.write(fd, b"tail")
+        os.close(fd)
+        assert open(path, "rb").read() == b"head\n" + want + b"tail"
+    r, w = os.pipe()
+    fr = fr[:300]
+    want = pdt.format_frames(fr)
+    import threading
+    got = []
+    th = threading.Thread(target=lambda: got.append(b"".join(iter(lambda: os.read(r, 1 << 16), b""))))
+    th.start()
+    assert L.pdt_write_records(fr.ctypes.data, len(fr), w, None) == 0
+    os.close(w)
+    th.join()
+    os.close(r)
+    assert got[0] == want
+    assert L.pdt_write_records(None, 3, 1, None) == -1          # PDT_ERR_ARG
+
+
 def test_gather_library_exports_its_entry_point(pdt):
     """include/pdt_gather.h: the RCCL gather of frame records lives in a library of its own (libpdt.so has no RCCL dependency)."""
     path = os.path.join(os.path.dirname(pdt.LIBPDT_PATH), "libpdtgather.so")
