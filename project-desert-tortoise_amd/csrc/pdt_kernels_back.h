@@ -1590,7 +1590,10 @@ __device__ __forceinline__ void k_gardner_span_keys(GardnerDomain D, long long n
     const unsigned total = s_scan[255];
     if (tid == 0) {
         unsigned off = atomicAdd(&ctl->keys, total);
-        if (off + total > cap_keys) {
+        if ((unsigned long long)off + total > cap_keys) {
+            // (the reservation is given back, so that the cursor stays near cap_keys however many rows fail: left to grow, a
+            // very long noise-only capture could wrap it around 2^32 and a later row would pass this test with a wrapped `off`)
+            atomicSub(&ctl->keys, total);
             off = ~0u;
             atomicAdd(&ctl->overflow, 1u);
         } else

@@ -827,11 +827,70 @@ template <int N> __device__ __forceinline__ void ring_wait()
                        // the warm-ups' re-reads keep HBM at 4 TB/s and a load takes longer: 6.3 / 6.06 / 6.2 ms at 24 / 48 / 64 (the
                        // ten-minute capture is indifferent: 0.85 / 0.84 / 0.88).  One wavefront per SIMD: the 192 registers are free.
 #endif
+// Round 4: the look-ahead of the block-parallel walkers and of the head as an LDS ring (`ring` != nullptr: RPF slots of 1 KiB
+// for this wavefront).  With the ring in registers the compiler's loop header waits for vmcnt(0) -- every trip of PF vectors
+// exposes one whole memory latency (the listing under profiles/r4: `s_waitcnt vmcnt(0)` at the top of the 48-vector loop; 27 %
+// of the kernel's wave cycles were memory waits at an hour of 250 ksps, where HBM is busy with the warm-ups' re-reads and a
+// load takes microseconds).  In the LT layout a wavefront's load is one KiB of consecutive bytes with lane l's 16 bytes at
+// l * 16: exactly where `global_load_lds_dwordx4` puts them.  Vector k + 1 is read from LDS while vector k is walked, after
+// `s_waitcnt vmcnt(RPF - 2)` (the loads younger than it; loads complete in order among themselves, the stores in the
+// counter only make the wait conservative), and slot k is refilled for vector k + RPF as soon as k has been walked.
+#ifndef PDT_PLL_RING_PF
+#define PDT_PLL_RING_PF 32
+#endif
+// Four steps of the float loop filter (pll_phase_step, the 16-operation form) as ONE block of machine code, with the refill
+// of the look-ahead slot the vector came from: `s_mov_b32 m0` first, the LDS-direct load last.  Why by hand: the walkers are
+// bound by instruction issue (tools/probes/pll_mem_probe.hip: 34 ns a step with theta in registers = 81 clocks = 20 issue
+// slots where the arithmetic is 16), and the compiler puts an `s_nop` behind every inline-assembly block it cannot look into
+// -- one slot per step with the error wrap as its own block, one more per vector behind the write of M0.  (Measured and not
+// used: the two products beta e and alpha e as one `v_pk_mul_f32` -- a packed f32 operation takes two issue slots, 8.5 clocks
+// dependent, tools/probes/lat_probe.hip.)  Same operations in the same order as pll_wrap_error_f32 / pll_wrap_phase_f32 /
+// pll_phase_step (pdt_device_math.h): every result is the one they give, the GPU suite compares the streams bit for bit.
+// p[k] = the phase after step k (p[3] is the new state; the phases BEFORE the steps -- what the kernels store -- are phase,
+// p[0], p[1], p[2]).
+__device__ __forceinline__ void pll_vec4_asm(const Vec16<float> &th, float phase, float &freq, float (&p)[4], float alpha, float beta,
+                                             float minf, float maxf_v, const void *refill, unsigned slot_addr)
+{
+    const float hi = 6.2831854820251465f, d = 1.7484555314695172e-07f;
+    float t1, t2, e, f1, fa, fb, fc;
+#define PDT_PLL_STEP(TH, P, F, PN, FN)                                  \
+    "v_sub_f32 %[e], " TH ", " P "\n\t"                                  \
+    "v_cmp_ge_f32_e64 vcc, |%[e]|, %[pi]\n\t"                           \
+    "v_bfi_b32 %[t1], %[mask], 1.0, %[e]\n\t"                           \
+    "v_fma_f32 %[t2], %[t1], %[nhi], %[e]\n\t"                          \
+    "v_fma_f32 %[t2], %[t1], %[d], %[t2]\n\t"                           \
+    "v_cndmask_b32_e32 %[e], %[e], %[t2], vcc\n\t"                      \
+    "v_mul_f32 %[t1], %[beta], %[e]\n\t"                                \
+    "v_add_f32 %[f1], " F ", %[t1]\n\t"                                  \
+    "v_add_f32 %[t2], " P ", %[f1]\n\t"                                  \
+    "v_mul_f32 %[t1], %[alpha], %[e]\n\t"                               \
+    "v_add_f32 %[t2], %[t2], %[t1]\n\t"                                 \
+    "v_mul_f32 %[t1], 0x3e22f983, %[t2]\n\t"                            \
+    "v_trunc_f32 %[t1], %[t1]\n\t"                                      \
+    "v_fma_f32 %[t2], %[t1], %[nhi], %[t2]\n\t"                         \
+    "v_fma_f32 " PN ", %[t1], %[d], %[t2]\n\t"                           \
+    "v_med3_f32 " FN ", %[f1], %[minf], %[maxf]\n\t"
+    asm volatile("s_mov_b32 m0, %[slot]\n\t"
+                 PDT_PLL_STEP("%[th0]", "%[ph]", "%[fr]", "%[p0]", "%[fa]")
+                 PDT_PLL_STEP("%[th1]", "%[p0]", "%[fa]", "%[p1]", "%[fb]")
+                 PDT_PLL_STEP("%[th2]", "%[p1]", "%[fb]", "%[p2]", "%[fc]")
+                 PDT_PLL_STEP("%[th3]", "%[p2]", "%[fc]", "%[p3]", "%[fr]")
+                 "global_load_lds_dwordx4 %[g], off"
+                 : [fr] "+v"(freq), [p0] "=&v"(p[0]), [p1] "=&v"(p[1]), [p2] "=&v"(p[2]), [p3] "=&v"(p[3]), [t1] "=&v"(t1), [t2] "=&v"(t2),
+                   [e] "=&v"(e), [f1] "=&v"(f1), [fa] "=&v"(fa), [fb] "=&v"(fb), [fc] "=&v"(fc)
+                 : [th0] "v"(th.v[0]), [th1] "v"(th.v[1]), [th2] "v"(th.v[2]), [th3] "v"(th.v[3]), [ph] "v"(phase),
+                   [pi] "s"(3.14159274101257324f), [mask] "s"(0x7fffffffu), [nhi] "s"(-hi), [d] "s"(d), [alpha] "s"(alpha), [beta] "s"(beta),
+                   [minf] "s"(minf), [maxf] "v"(maxf_v), [g] "v"(refill), [slot] "s"(slot_addr)
+                 : "vcc", "memory");
+#undef PDT_PLL_STEP
+}
+
 template <typename T, bool STORE, bool SLOW, bool OUT_LT, int PF = PDT_PLL_PF, bool VOTE = false>
 __device__ __forceinline__ void pll_phase_range(const T *__restrict__ theta_lt, T *__restrict__ out, long long B, long long i0,
                                                 long long i1, T &phase, T &freq, T alpha, T beta, T maxf, T minf,
-                                                int *far = nullptr, int *seen = nullptr)
+                                                int *far = nullptr, int *seen = nullptr, unsigned char *ring = nullptr)
 {
+    constexpr int RPF = PDT_PLL_RING_PF;
     constexpr int VN = Lt<T>::VN, ROW = Lt<T>::ROW;
     constexpr int OSTR = OUT_LT ? ROW : VN;
     auto step = [&](T th) {
@@ -869,7 +928,55 @@ __device__ __forceinline__ void pll_phase_range(const T *__restrict__ theta_lt, 
         // run up to PF rows past the segment: every LT buffer is allocated with that much slack.  The opaque offset stops
         // the compiler from sinking the look-ahead load back to its use.)  On gfx9 stores share the vmcnt counter with
         // loads, so waiting for a look-ahead load also waits for every older store: the single-lane walkers use PF = 32.
-        if (nv >= PF) {
+        if (ring && nv >= RPF) {
+            const unsigned ring0 = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(size_t)ring);   // (one ring per wavefront)
+            const unsigned char *mine = ring + 16 * (threadIdx.x & 63);
+#pragma unroll
+            for (int u = 0; u < RPF; u++) ring_issue(tp + (long long)u * ROW, ring0 + u * PDT_RING_SLOT);
+            ring_wait<RPF - 1>();
+            Vec16<T> cur = *reinterpret_cast<const Vec16<T> *>(mine), nxt;
+            long long v = 0;
+            for (; v + RPF <= nv; v += RPF) {
+#pragma unroll
+                for (int u = 0; u < RPF; u++) {
+                    ring_wait<RPF - 2>();
+                    nxt = *reinterpret_cast<const Vec16<T> *>(mine + ((u + 1) % RPF) * PDT_RING_SLOT);
+                    if constexpr (std::is_same<T, float>::value && !SLOW && !VOTE) {
+                        float pn[4];
+                        pll_vec4_asm(cur, phase, freq, pn, alpha, beta, minf, maxf, tp + (v + RPF + u) * ROW, ring0 + u * PDT_RING_SLOT);
+                        if (STORE) {
+                            Vec16<T> pv;
+                            pv.v[0] = phase; pv.v[1] = pn[0]; pv.v[2] = pn[1]; pv.v[3] = pn[2];
+                            *reinterpret_cast<Vec16<T> *>(op + (v + u) * OSTR) = pv;
+                        }
+                        phase = pn[3];
+                    } else {
+                        Vec16<T> pv;
+#pragma unroll
+                        for (int w = 0; w < VN; w++) {
+                            pv.v[w] = phase;
+                            step(cur.v[w]);
+                        }
+                        if (STORE) *reinterpret_cast<Vec16<T> *>(op + (v + u) * OSTR) = pv;
+                        ring_issue(tp + (v + RPF + u) * ROW, ring0 + u * PDT_RING_SLOT);
+                    }
+                    cur = nxt;
+                }
+            }
+            // the ring now holds vectors v .. v + RPF - 1 (cur = vector v): the remaining nv - v (< RPF) are already on their way
+            ring_wait<0>();
+            const int rest = (int)(nv - v);
+            for (int u = 0; u < rest; u++) {
+                if (u > 0) cur = *reinterpret_cast<const Vec16<T> *>(mine + u * PDT_RING_SLOT);
+                Vec16<T> pv;
+#pragma unroll
+                for (int w = 0; w < VN; w++) {
+                    pv.v[w] = phase;
+                    step(cur.v[w]);
+                }
+                if (STORE) *reinterpret_cast<Vec16<T> *>(op + (v + u) * OSTR) = pv;
+            }
+        } else if (nv >= PF) {
             Vec16<T> buf[PF];
 #pragma unroll
             for (int u = 0; u < PF; u++) buf[u] = *reinterpret_cast<const Vec16<T> *>(tp + (long long)u * ROW);
@@ -1008,6 +1115,16 @@ __device__ __forceinline__ void k_pll_phase(IqSrc pcm, const T *__restrict__ the
                                                    T *__restrict__ phi, PllSeam<T> *__restrict__ seams,
                                                    unsigned *__restrict__ groups_done /* += 1 per finished workgroup (k_pll_head's hint) */)
 {
+    // A SIMD of its own for every walker wavefront (the whole register file claimed, as k_pll_acquire_pipe and k_pll_head do):
+    // the acquisition's two wavefronts are placed first and take two SIMDs of a CU; a workgroup of this kernel that lands on
+    // the same CU would seat its four wavefronts on the two SIMDs left -- two walkers per SIMD, half the pace for as long as the
+    // acquisition runs, and the kernel ends with its slowest wavefront (round 4, kernel trace: 5.8 ms in the chain against
+    // 5.2 ms for the same body alone, tools/probes/pll_mem_probe.hip).  With the claim such a workgroup needs four empty SIMDs.
+    asm volatile("" ::: "v255", "a255");
+    // (`Done` counts a workgroup when its thread 0 leaves, not when its last walker does: the counter is a HINT for k_pll_head,
+    // which walks a few blocks further while it says this kernel is still at work.  How many blocks the head takes over -- and
+    // with it pll_seam_fixes and the two kernels' times -- therefore depends on timing; the result never does: every seam
+    // behind the head is validated by k_pll_fix whoever walked it.)
     struct Done {                                   // (counted on every way out of the kernel)
         unsigned *p;
         __device__ ~Done() { if (threadIdx.x == 0) atomicAdd(p, 1u); }
@@ -1030,6 +1147,9 @@ __device__ __forceinline__ void k_pll_phase(IqSrc pcm, const T *__restrict__ the
     pll_guess(pcm, ws, n, lag, (T)0, phase, freq);
     if (freq > P.max_freq) freq = P.max_freq;
     if (freq < P.min_freq) freq = P.min_freq;
+    // the look-ahead ring of this wavefront (pll_phase_range): the tracking warm-up and the block itself go through it
+    __shared__ __attribute__((aligned(16))) unsigned char ring_all[4 * PDT_PLL_RING_PF * PDT_RING_SLOT];
+    unsigned char *ring = ring_all + (threadIdx.x >> 6) * (PDT_PLL_RING_PF * PDT_RING_SLOT);
     pll_phase_range<T, false, SLOW, true>(theta, phi, B, ws, ws + w_wide, phase, freq, P.alpha_wide, P.beta_wide, P.max_freq, P.min_freq);
     // acquisition-gain stage; its last 128 samples vote on which of the two stable lock points we
     // fell into: at the carrier the detector error sits at +-m (|err| < pi/2), at the false point
@@ -1045,11 +1165,13 @@ __device__ __forceinline__ void k_pll_phase(IqSrc pcm, const T *__restrict__ the
         if (freq >= 0 && phase < 0) phase += (T)(2 * PDT_PI);
         if (freq < 0 && phase > 0) phase -= (T)(2 * PDT_PI);
     }
-    pll_phase_range<T, false, SLOW, true>(theta, phi, B, a1, start, phase, freq, P.alpha_trk, P.beta_trk, P.max_freq, P.min_freq);
+    pll_phase_range<T, false, SLOW, true>(theta, phi, B, a1, start, phase, freq, P.alpha_trk, P.beta_trk, P.max_freq, P.min_freq,
+                                          nullptr, nullptr, ring);
     PllSeam<T> sm;
     sm.phase0 = phase;
     sm.freq0 = freq;
-    pll_phase_range<T, true, SLOW, true>(theta, phi, B, start, end, phase, freq, P.alpha_trk, P.beta_trk, P.max_freq, P.min_freq);
+    pll_phase_range<T, true, SLOW, true>(theta, phi, B, start, end, phase, freq, P.alpha_trk, P.beta_trk, P.max_freq, P.min_freq,
+                                         nullptr, nullptr, ring);
     sm.phase1 = phase;
     sm.freq1 = freq;
     seams[j] = sm;
@@ -1074,6 +1196,7 @@ __device__ __forceinline__ void k_pll_head(const T *__restrict__ theta, long lon
                                                   unsigned phase_groups /* workgroups of k_pll_phase have finished */)
 {
     if (EXCL) asm volatile("" ::: "v255", "a255");       // a SIMD of its own, see k_pll_acquire_pipe
+    __shared__ __attribute__((aligned(16))) unsigned char ring[PDT_PLL_RING_PF * PDT_RING_SLOT];
     if (blockIdx.x != 0 || threadIdx.x != 0) return;
     const long long lock_at = info->lock_sample;
     PllHeadInfo<T> hi;
@@ -1098,7 +1221,7 @@ __device__ __forceinline__ void k_pll_head(const T *__restrict__ theta, long lon
             sm.freq0 = freq;
             // phi_head is indexed from the 16-byte aligned sample at or below S (vector stores stay aligned)
             pll_phase_range<T, true, SLOW, false, 32>(theta, phi_head - (S & ~3ll), B, pos, end, phase, freq, P.alpha_trk, P.beta_trk,
-                                                      P.max_freq, P.min_freq);
+                                                      P.max_freq, P.min_freq, nullptr, nullptr, ring);
             sm.phase1 = phase;
             sm.freq1 = freq;
             seams_head[k] = sm;
@@ -1795,10 +1918,11 @@ __device__ __forceinline__ void k_fir_interp_rt(const T *__restrict__ in, long l
 typedef float pdt_v2f __attribute__((ext_vector_type(2)));
 
 template <int K, int FMT, int NWV = 4>
-__device__ __forceinline__ void k_mix_fir(IqSrc pcm, const float *__restrict__ phi_lt, const float *__restrict__ pll_pre,
+__device__ __forceinline__ void k_mix_fir(IqSrc pcm, const float *__restrict__ phi_lt, const float *pll_pre /* may alias pll_out */,
                                           long long n, long long B, const PllLockInfo<float> *__restrict__ info,
                                           const float *__restrict__ rot /* host-built rotated taps */, float *__restrict__ out,
-                                          float *__restrict__ pll_out /* nullptr: the PLL output is not kept */,
+                                          float *pll_out /* nullptr: the PLL output is not kept; the host passes the same buffer as
+                                                            pll_pre (reads before the lock, writes behind it): no __restrict__ */,
                                           AgcMap *__restrict__ run_maps, float agc_decay)
 {
     static_assert(PDT_MF_RUN == 8 * K && PDT_MF_HALO >= K - 1 && PDT_MF_HALO % 4 == 0, "run = 8 ring revolutions, halo = whole phase vectors");

@@ -221,13 +221,20 @@ unsigned long GardenerClockRecovery(DT *dataStreamIn, DT *dataStreamInTime, unsi
      * whatever lies behind the caller's samples, in its buffer or behind it (Q16).  So does this one: the kernel is handed the
      * caller's memory up to the furthest index the sampler can form. */
     const double step = (double)Fs / (double)baud;
+    /* ... which is index numSamples + step + 1 at most (rint(nextSample) of the symbol that ends the loop, :59,:111; the stale
+     * mid-point index lies below it): this many elements are taken from the caller, as the reference takes them.  The kernel
+     * stages a little more than the sampler can ask for (its window margin): that rest is zeros, not the caller's heap. */
     const unsigned long reach = numSamples + 2 * (unsigned long)step + 24;
+    const unsigned long touch = numSamples + (unsigned long)step + 2;
     const unsigned long cap_sym = (unsigned long)((double)numSamples / (step - 0.25)) + 4;
     uint64_t *pick = malloc(sizeof(uint64_t) * cap_sym);
     DT *sym = malloc(sizeof(DT) * cap_sym);
-    if (!pick || !sym) die("malloc", PDT_ERR_NOMEM);
+    DT *win = calloc(reach, sizeof(DT));
+    if (!pick || !sym || !win) die("malloc", PDT_ERR_NOMEM);
+    memcpy(win, dataStreamIn, sizeof(DT) * (touch < reach ? touch : reach));
     uint64_t nsym = 0;
-    TRY(pdt_stage_gardner(c, dataStreamIn, numSamples, reach, NULL, &g_gardner, sym, pick, &nsym));
+    TRY(pdt_stage_gardner(c, win, numSamples, reach, NULL, &g_gardner, sym, pick, &nsym));
+    free(win);
     for (uint64_t k = 0; k < nsym; k++) {
         dataStreamOut[k] = sym[k];
         dataStreamInTime[k] = dataStreamInTime[pick[k]];                                     /* :30 (in place: pick[k] >= k) */

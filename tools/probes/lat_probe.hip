@@ -33,6 +33,14 @@ __global__ void __launch_bounds__(64) k(float a, float *out, uint64_t *clk, int 
                 if (MODE == 9) { REP64(asm volatile("v_rcp_f32 %0, %0" : "+v"(g));) }
                 if (MODE == 10) { REP64(asm volatile("v_mul_f32 %0, %0, %1\n v_add_f32 %0, %0, %1\n v_mul_f32 %0, %0, %1\n v_sub_f32 %0, %0, %1" : "+v"(g) : "v"(a));) }
                 if (MODE == 11) { REP64(asm volatile("s_mul_i32 s20, s20, 3" : : : "s20");) }
+                if (MODE == 12) { REP64(asm volatile("v_trunc_f32 %0, %0" : "+v"(g));) }
+                if (MODE == 13) { REP64(asm volatile("v_pk_mul_f32 %0, %0, %1 op_sel_hi:[0,1]" : "+v"(*(double *)&g) : "v"((double)a));) }
+                if (MODE == 14) { REP64(asm volatile("v_med3_f32 %0, %0, %1, %1" : "+v"(g) : "v"(a));) }
+                if (MODE == 15) { REP64(asm volatile("v_bfi_b32 %0, %1, 1.0, %0" : "+v"(g) : "v"(a));) }
+                if (MODE == 16) { REP64(asm volatile("v_fma_f32 %0, %0, %1, %1\n v_fma_f32 %0, %0, %1, %1\n v_fma_f32 %0, %0, %1, %1\n v_fma_f32 %0, %0, %1, %1" : "+v"(g) : "v"(a));) }
+                if (MODE == 17) { REP64(asm volatile("v_mul_f32 %0, 0x3e22f983, %0\n v_trunc_f32 %0, %0\n v_fma_f32 %0, %0, %1, %1\n v_fma_f32 %0, %0, %1, %0" : "+v"(g) : "v"(a));) }
+                if (MODE == 18) { REP64(asm volatile("v_cmp_ge_f32_e64 vcc, |%0|, %1\n v_bfi_b32 %2, %1, 1.0, %0\n v_fma_f32 %2, %2, %1, %0\n v_cndmask_b32_e32 %0, %0, %2, vcc" : "+v"(g), "+v"(h) : "v"(a) : "vcc");) }
+                if (MODE == 19) { REP64(asm volatile("v_add_f32 %0, %0, %1\n v_add_f32 %0, %0, %1\n v_add_f32 %0, %0, %1\n v_add_f32 %0, %0, %1" : "+v"(g) : "v"(a));) }
             }
             t1 = now();
             if (t1 - t0 < best) best = t1 - t0;
@@ -81,6 +89,14 @@ int main()
     run<8>("readfirstlane + v_mov (per pair /2)", 2, 64);
     run<9>("dependent v_rcp_f32", 1, 64);
     run<11>("dependent s_mul_i32", 1, 64);
+    run<12>("dependent v_trunc_f32 (+nop: -4.1)", 1, 64);
+    run<13>("dependent v_pk_mul_f32 (+nop)", 1, 64);
+    run<14>("dependent v_med3_f32 (+nop)", 1, 64);
+    run<15>("dependent v_bfi_b32 (+nop)", 1, 64);
+    run<16>("4 dependent v_fma_f32 per block (5 slots with nop)", 4, 64);
+    run<17>("mul-literal, trunc, fma, fma (phase wrap)", 4, 64);
+    run<18>("cmp, bfi, fma, cndmask", 4, 64);
+    run<19>("4 dependent v_add_f32", 4, 64);
     // one wavefront per SIMD on every CU, and two / four per SIMD
     for (int waves : {1024, 2048, 4096}) { run<0>("dependent v_mul_f32", 1, 64, waves); run<10>("mul add mul sub dependent", 4, 64, waves); }
     return 0;

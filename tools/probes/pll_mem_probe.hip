@@ -1,0 +1,139 @@
+// Round 4 probe: what paces the block-parallel PLL walkers at the c3 geometry (45 056 blocks of 19 968 samples, 110 000 of
+// tracking warm-up, 176 workgroups of four wavefronts)?  The library's own pll_phase_range over a synthetic LT theta stream:
+//   ring 0 / 1 : look-ahead in registers (the compiler's waits) / the LDS ring with hand-placed waits
+//   mem  0     : the same number of steps with theta in registers (no memory at all): the arithmetic pace
+// and the shader clock actually running while the kernel is at work (s_memtime against the 100 MHz constant clock).
+// hipcc --offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off -I project-desert-tortoise_amd/csrc -o tools/probes/pll_mem_probe tools/probes/pll_mem_probe.hip
+#include <hip/hip_runtime.h>
+#include <cstdio>
+#include <cstdint>
+#include "pdt_kernels_back.h"
+#include "pdt_kernels_front.h"
+using namespace pdt;
+
+__global__ void fill(float *x, long long n)
+{
+    long long i = blockIdx.x * 256ll + threadIdx.x;
+    for (; i < n; i += (long long)gridDim.x * 256) {
+        unsigned h = (unsigned)(i * 2654435761u) ^ (unsigned)(i >> 13);
+        h ^= h >> 15; h *= 0x2c1b3c6du; h ^= h >> 12;
+        x[i] = ((float)(h & 0xffff) / 65536.0f - 0.5f) * 6.2f;
+    }
+}
+
+// the library's whole kernel body (guess, wide-band and acquisition-gain stages, tracking warm-up, block) on the synthetic streams
+__global__ void __launch_bounds__(256) k_full(IqSrc pcm, const float *__restrict__ theta, float *__restrict__ phi, long long n, long long B,
+                                              long long Wacq, long long Wtrk, PllSeam<float> *seams, unsigned *done, int skip_guess,
+                                              unsigned long long *__restrict__ clk)
+{
+    PllParams<float> P;
+    P.alpha_trk = 1.0385e-3f; P.beta_trk = 5.4e-7f; P.alpha_acq = 1.3e-2f; P.beta_acq = 8.5e-5f; P.alpha_wide = 0.1f; P.beta_wide = 5e-3f;
+    P.max_freq = 0.12f; P.min_freq = -0.12f;
+    const unsigned long long c0 = wall_clock64();
+    if (skip_guess) pcm.p = nullptr;
+    k_pll_phase<float, false>(pcm, theta, skip_guess ? 0 : n, P, B, Wacq, Wtrk, 16, phi, seams, done);
+    if ((threadIdx.x & 63) == 0) clk[blockIdx.x * 4 + (threadIdx.x >> 6)] = wall_clock64() - c0;
+}
+
+template <bool RING, bool MEM, bool STORE>
+__global__ void __launch_bounds__(256) k_probe(const float *__restrict__ theta, float *__restrict__ phi, long long n, long long B, long long W,
+                                               float *__restrict__ gout, unsigned long long *__restrict__ clk)
+{
+    __shared__ __attribute__((aligned(16))) unsigned char ring_all[4 * PDT_PLL_RING_PF * PDT_RING_SLOT];
+    unsigned char *ring = RING ? ring_all + (threadIdx.x >> 6) * (PDT_PLL_RING_PF * PDT_RING_SLOT) : nullptr;
+    const long long j = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    const long long start = j * B;
+    if (start >= n) return;
+    const unsigned long long c0 = __builtin_readcyclecounter(), r0 = wall_clock64();
+    float phase = 0.1f + 1e-4f * (float)(j & 1023), freq = 0.01f;
+    const float alpha = 9.4e-4f, beta = 4.4e-7f, maxf = 0.12f, minf = -0.12f;
+    const long long ws = start >= W ? start - W : 0;
+    if (MEM) {
+        pll_phase_range<float, false, false, true>(theta, phi, B, ws, start, phase, freq, alpha, beta, maxf, minf, nullptr, nullptr, ring);
+        pll_phase_range<float, STORE, false, true>(theta, phi, B, start, start + B, phase, freq, alpha, beta, maxf, minf, nullptr, nullptr, ring);
+    } else {
+        float t0 = 0.3f + phase, t1 = -1.2f, t2 = 2.2f, t3 = -2.9f;
+        for (long long i = ws; i < start + B; i += 4) {
+            pll_phase_step<float, false>(t0, phase, freq, alpha, beta, maxf, minf);
+            pll_phase_step<float, false>(t1, phase, freq, alpha, beta, maxf, minf);
+            pll_phase_step<float, false>(t2, phase, freq, alpha, beta, maxf, minf);
+            pll_phase_step<float, false>(t3, phase, freq, alpha, beta, maxf, minf);
+            asm volatile("" : "+v"(t0), "+v"(t1), "+v"(t2), "+v"(t3));
+        }
+    }
+    gout[j] = phase + freq;
+    if ((threadIdx.x & 63) == 0) {
+        clk[2 * (j >> 6)] = __builtin_readcyclecounter() - c0;
+        clk[2 * (j >> 6) + 1] = wall_clock64() - r0;
+    }
+}
+
+template <bool RING, bool MEM, bool STORE>
+void run(const char *what, const float *theta, float *phi, long long n, long long B, long long W, int groups, float *g, unsigned long long *clk)
+{
+    hipEvent_t a, b;
+    (void)hipEventCreate(&a); (void)hipEventCreate(&b);
+    float best = 1e9f;
+    for (int r = 0; r < 3; r++) {
+        (void)hipEventRecord(a);
+        hipLaunchKernelGGL((k_probe<RING, MEM, STORE>), dim3(groups), dim3(256), 0, 0, theta, phi, n, B, W, g, clk);
+        (void)hipEventRecord(b);
+        (void)hipEventSynchronize(b);
+        float ms; (void)hipEventElapsedTime(&ms, a, b);
+        if (ms < best) best = ms;
+    }
+    static unsigned long long h[8192];
+    (void)hipMemcpy(h, clk, sizeof(unsigned long long) * 2 * groups * 4, hipMemcpyDeviceToHost);
+    double ghz = 0; int cnt = 0;
+    for (int w = 4; w < groups * 4; w++) if (h[2 * w + 1]) { ghz += (double)h[2 * w] / ((double)h[2 * w + 1] * 10.0); cnt++; }   // 100 MHz constant clock: 10 ns a tick
+    const double steps = (double)(B + W);
+    const double bytes = MEM ? ((double)(B + W) / B * n * 4 + (STORE ? n * 4.0 : 0)) : 0;
+    printf("%-56s B %6lld W %6lld groups %4d: %7.3f ms  %5.1f ns/step  shader clock %.2f GHz -> %5.1f clk/step   %.1f GB -> %.2f TB/s  (%s)\n", what, B, W, groups, best,
+           best * 1e6 / steps, cnt ? ghz / cnt : 0.0, best * 1e6 / steps * (cnt ? ghz / cnt : 0.0), bytes / 1e9, bytes / (best * 1e9), hipGetErrorString(hipGetLastError()));
+    fflush(stdout);
+}
+
+int main()
+{
+    const long long B = 19968, W = 110000 / 4 * 4;
+    const int groups = 176;
+    const long long n = B * 256 * groups;            // 899.7 M samples
+    float *theta, *phi, *g; unsigned long long *clk;
+    const long long slack = 64 * B + (1 << 20);
+    if (hipMalloc(&theta, (n + slack) * 4) != hipSuccess || hipMalloc(&phi, (n + slack) * 4) != hipSuccess) { printf("no memory\n"); return 1; }
+    (void)hipMalloc(&g, 1 << 22); (void)hipMalloc(&clk, 1 << 20);
+    hipLaunchKernelGGL(fill, dim3(4096), dim3(256), 0, 0, theta, n + slack);
+    (void)hipDeviceSynchronize();
+    setvbuf(stdout, nullptr, _IONBF, 0);
+    printf("PLL walker probe, %lld samples\n", n);
+    run<false, false, false>("no memory: theta in registers", theta, phi, n, B, W, groups, g, clk);
+    run<false, true, true>("look-ahead in registers (48 vectors), loads + stores", theta, phi, n, B, W, groups, g, clk);
+    run<true, true, true>("LDS ring (32 vectors), loads + stores", theta, phi, n, B, W, groups, g, clk);
+    run<true, true, false>("LDS ring, no stores", theta, phi, n, B, W, groups, g, clk);
+    run<false, true, false>("registers, no stores", theta, phi, n, B, W, groups, g, clk);
+    run<true, true, true>("LDS ring, warm-up 55 000", theta, phi, n, B, 55000, groups, g, clk);
+    {
+        void *pcm; unsigned *done; PllSeam<float> *seams;
+        (void)hipMalloc(&pcm, (n + slack) * 4); (void)hipMemset(pcm, 0x11, (n + slack) * 4);
+        (void)hipMalloc(&done, 64); (void)hipMalloc(&seams, sizeof(PllSeam<float>) * (n / B + 4096));
+        IqSrc src; src.p = pcm; src.fmt = 0;
+        hipEvent_t a, b; (void)hipEventCreate(&a); (void)hipEventCreate(&b);
+        for (int wt : {99328, 49664, 24832}) {
+            float best = 1e9f;
+            for (int r = 0; r < 3; r++) {
+                (void)hipEventRecord(a);
+                hipLaunchKernelGGL(k_full, dim3(177), dim3(256), 0, 0, src, theta, phi, n, B, 5000ll, (long long)wt, seams, done, 0, clk);
+                (void)hipEventRecord(b); (void)hipEventSynchronize(b);
+                float ms; (void)hipEventElapsedTime(&ms, a, b); if (ms < best) best = ms;
+            }
+            static unsigned long long h[1024];
+            (void)hipMemcpy(h, clk, 8 * 177 * 4, hipMemcpyDeviceToHost);
+            unsigned long long mn = ~0ull, mx = 0; for (int i = 0; i < 176 * 4; i++) { if (h[i] < mn) mn = h[i]; if (h[i] > mx) mx = h[i]; }
+            printf("the library's k_pll_phase body, tracking warm-up %6d: %7.3f ms; wavefronts take %.3f .. %.3f ms  (%s)\n", wt, best, mn * 1e-5, mx * 1e-5, hipGetErrorString(hipGetLastError()));
+        }
+    }
+    run<false, false, false>("no memory, 64 groups", theta, phi, n, B, W, 64, g, clk);
+    run<true, true, true>("LDS ring, 64 groups (a third of the lanes)", theta, phi, n, B, W, 64, g, clk);
+    run<true, true, true>("LDS ring, 256 groups", theta, phi, n + 80 * 256 * B > n + slack ? n : n, B, W, 176, g, clk);
+    return 0;
+}
