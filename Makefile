@@ -3,7 +3,10 @@
 PKG      := project-desert-tortoise_amd
 HIPCC    ?= /opt/rocm/bin/hipcc
 ARCH     ?= gfx950
-HIPFLAGS := --offload-arch=$(ARCH) -O3 -std=c++17 -ffp-contract=off -fPIC -Wall -Wno-unused-function
+# -fno-slp-vectorize: left to itself the compiler pairs independent float additions of the serial walkers (the sampler's
+# `half = ns + hs; ns = ns + step`) into v_pk_add_f32 -- a packed f32 operation occupies a lone wavefront for two issue slots and
+# draws an s_nop behind it (tools/probes/lat_probe.hip); the kernels that want packed arithmetic (the FIR) write it themselves
+HIPFLAGS := --offload-arch=$(ARCH) -O3 -std=c++17 -ffp-contract=off -fno-slp-vectorize -fPIC -Wall -Wno-unused-function
 CC       := gcc
 CFLAGS   := -O2 -Wall -ffp-contract=off
 

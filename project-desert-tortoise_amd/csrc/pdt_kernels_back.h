@@ -936,10 +936,22 @@ struct GardnerLane {
     bool active;
 };
 
+// wrel[rint(x)] for an LDS window `wrel` (indexed with chunk-relative sample indices) in three instructions: the magic add
+// (rint_index), one shift-add and the LDS read.  The integer image of the magic constant is folded into the window's byte
+// address once per window -- (asint(x + 1.5 * 2^23) << 2) + (wrel - (0x4B400000 << 2)), all modulo 2^32 -- where the plain form
+// spends a shift and a three-operand add per read.  (Round 4: the symbol step of the table / span / emission walkers went
+// from 19 to 14 issue slots with this and with the sampler's two additions kept out of a packed operation, Makefile.)
+typedef const __attribute__((address_space(3))) float pdt_lds_cf;
+__device__ __forceinline__ float lds_rel_at(const float *wrel, float x)
+{
+    const unsigned base = (unsigned)(size_t)wrel - (0x4B400000u << 2);
+    return *(pdt_lds_cf *)((__float_as_uint(x + 12582912.0f) << 2) + base);
+}
+
 __device__ __forceinline__ void gardner_lane_step(GardnerLane &L, const float *wrel, float kp, float lim, float hs, float step)
 {
-    const float cur = wrel[rint_index(L.ns)];
-    const float mid = wrel[rint_index(L.half)];
+    const float cur = lds_rel_at(wrel, L.ns);
+    const float mid = lds_rel_at(wrel, L.half);
     const float err = __builtin_amdgcn_fmed3f(kp * (cur - L.prev) * mid, -lim, lim);
     L.ns = L.ns - err;
     L.half = L.ns + hs;
@@ -1752,8 +1764,8 @@ __device__ __forceinline__ void gardner_sub_chunk(float *win, const float *__res
         for (int it = 0; it < k_min; it++) {
             if (EMIT) {
                 const int ic = rint_index(L.ns);
-                const float cur = wrel[ic];
-                const float mid = wrel[rint_index(L.half)];
+                const float cur = lds_rel_at(wrel, L.ns);
+                const float mid = lds_rel_at(wrel, L.half);
                 emit(cur, (unsigned)ic);
                 const float err = __builtin_amdgcn_fmed3f(kp * (cur - L.prev) * mid, -lim, lim);
                 L.ns = L.ns - err;
