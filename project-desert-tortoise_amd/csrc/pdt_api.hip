@@ -10,6 +10,7 @@
 #include <unistd.h>
 
 #include <algorithm>
+#include <functional>
 #include <atomic>
 #include <chrono>
 #include <memory>
@@ -1012,6 +1013,8 @@ template <typename T> int run_capture(pdt_ctx *ctx, uint64_t n, int phase = RUN_
     const bool serial_excl = 4 * grid_pll <= 960 && !ctx->tune.no_excl;
     long long fix_regions = 1, fix_region_blocks = 0;
     bool quality_side = false;            // the averagePhase EMA of pdt_keep_quality runs on the side stream
+    bool quality_term_fused = false, quality_after_fir = false;   // ... its input term written by k_mix_fir, its walkers launched behind that kernel
+    std::function<void(bool)> quality_walkers_late;   // (captures function-scope state only)
     L.begin("pll_acquire");
     if (inject && ctx->inj.locked) {
         // pdt_stage_pll after the lock: sample 0 is a dummy the caller put in front, "locked at sample 0" with the state record
@@ -1143,7 +1146,7 @@ template <typename T> int run_capture(pdt_ctx *ctx, uint64_t n, int phase = RUN_
                                    pow(1.0 - (double)PP.lock_alpha, (double)Be), d_ema_guess);
             }
             PDT_LAUNCH(64, k_lock_ema<T>, dim3((unsigned)((nb_ema + 63) / 64)), dim3(64), 0, st, (const T *)ctx->term.p, N, PP.lock_alpha,
-                               d_info, Be, We, d_lock, (EmaSeam<T> *)ctx->seams_ema.p, (const double *)(ema_guess ? d_ema_guess : nullptr));
+                               d_info, Be, We, d_lock, (EmaSeam<T> *)ctx->seams_ema.p, (const double *)(ema_guess ? d_ema_guess : nullptr), 0ll);
             PDT_LAUNCH(64, k_lock_ema_fix<T>, dim3(1), dim3(64), 0, st, (const T *)ctx->term.p, N, PP.lock_alpha, d_info,
                                Be, d_lock, (EmaSeam<T> *)ctx->seams_ema.p, &d_sc->counters[1]);
             L.end();
@@ -1154,23 +1157,31 @@ template <typename T> int run_capture(pdt_ctx *ctx, uint64_t n, int phase = RUN_
             // beside the filter, the AGC and the sampler; the chain only waits for the kernel that reads the phases (the AGC
             // output will take their place).
             quality_side = !inject && !ctx->tune.quality_inline;
+            // Round 4: where mix and filter are one kernel (k_mix_fir, eight wavefronts) that kernel writes the EMA's input term
+            // on its way; the walkers below are then launched behind it (quality_walkers, further down)
+            quality_term_fused = quality_side && fuse_mix && ctx->tune.mf_waves != 4 && std::is_same<T, float>::value;
+            }
+        quality_walkers_late = [&](bool term_here) {
             hipStream_t sq = quality_side ? ctx->stream2 : st;
             if (quality_side) PL.simple(OP_FORK);
             L.begin("quality", sq);
             T *d_tap = (T *)ctx->term_ap.p;
+            if (term_here)
             PDT_LAUNCH(256, (k_pll_mix<T, false, true>), dim3((unsigned)lt_groups), dim3(256), 0, sq, d_pcm, d_phi, N, Bp, PP,
                                d_info, (T *)nullptr, d_tap);
-            if (quality_side) PL.simple(OP_JOIN_RECORD);
-            PDT_LAUNCH(64, k_lock_ema_zero<T>, dim3((unsigned)((nb_q + 63) / 64)), dim3(64), 0, sq, (const T *)d_tap, N,
+            if (quality_side && term_here) PL.simple(OP_JOIN_RECORD);
+            PDT_LAUNCH(64, k_lock_ema_zero_wave<T>, dim3((unsigned)nb_q), dim3(64), 0, sq, (const T *)d_tap, N,
                                avg_alpha, d_info, Bq, d_q_zresp);
             PDT_LAUNCH(1024, (k_lock_ema_guess<T, true>), dim3(1), dim3(1024), 0, sq, (const double *)d_q_zresp, N, avg_alpha, d_info, Bq,
                                pow(1.0 - (double)avg_alpha, (double)Bq), d_q_guess);
             PDT_LAUNCH(64, (k_lock_ema<T, true>), dim3((unsigned)((nb_q + 63) / 64)), dim3(64), 0, sq, (const T *)d_tap, N, avg_alpha,
-                               d_info, Bq, Wq, d_avgph, (EmaSeam<T> *)ctx->seams_q.p, (const double *)d_q_guess);
+                               d_info, Bq, Wq, d_avgph, (EmaSeam<T> *)ctx->seams_q.p, (const double *)d_q_guess, (long long)chunk);
             PDT_LAUNCH(64, k_lock_ema_fix<T>, dim3(1), dim3(64), 0, sq, (const T *)d_tap, N, avg_alpha, d_info,
                                Bq, d_avgph, (EmaSeam<T> *)ctx->seams_q.p, &d_sc->pad0_);
             L.end();
-        }
+        };
+        if (quality && !quality_term_fused) quality_walkers_late(true);
+        quality_after_fir = quality && quality_term_fused;
         if (live) {                                            // twin main.c:370, DSP_SQLCH_THRESH 0.05 (:55)
             L.begin("squelch");
             PDT_LAUNCH(256, k_squelch<T>, dim3((unsigned)((N + 1023) / 1024)), dim3(256), 0, st, d_pll, (const T *)d_lock, N, (T)0.05);
@@ -1222,11 +1233,15 @@ template <typename T> int run_capture(pdt_ctx *ctx, uint64_t n, int phase = RUN_
                 float *mf_pll = ctx->keep_pll ? (float *)d_pll : (float *)nullptr;
 #define PDT_MF_ARGS d_pcm, (const float *)d_phi, (const float *)d_pll, N, Bp, (const PllLockInfo<float> *)d_info, (const float *)ctx->taps_rot.p, (float *)d_fir, mf_pll, run_maps, (float)AP.decay
                 if (ctx->tune.mf_waves == 4) {
-                    if (d_pcm.fmt == 0) PDT_LAUNCH(256, (k_mix_fir<26, 0, 4>), dim3(mf_grid), dim3(256), 0, st, PDT_MF_ARGS);
-                    else PDT_LAUNCH(256, (k_mix_fir<26, 1, 4>), dim3(mf_grid), dim3(256), 0, st, PDT_MF_ARGS);
+                    if (d_pcm.fmt == 0) PDT_LAUNCH(256, (k_mix_fir<26, 0, 4>), dim3(mf_grid), dim3(256), 0, st, PDT_MF_ARGS, (float *)nullptr);
+                    else PDT_LAUNCH(256, (k_mix_fir<26, 1, 4>), dim3(mf_grid), dim3(256), 0, st, PDT_MF_ARGS, (float *)nullptr);
+                } else if (quality_after_fir) {
+                    float *d_tap = (float *)ctx->term_ap.p;
+                    if (d_pcm.fmt == 0) PDT_LAUNCH(512, (k_mix_fir<26, 0, 8, true>), dim3(mf_grid), dim3(512), 0, st, PDT_MF_ARGS, d_tap);
+                    else PDT_LAUNCH(512, (k_mix_fir<26, 1, 8, true>), dim3(mf_grid), dim3(512), 0, st, PDT_MF_ARGS, d_tap);
                 } else {
-                    if (d_pcm.fmt == 0) PDT_LAUNCH(512, (k_mix_fir<26, 0, 8>), dim3(mf_grid), dim3(512), 0, st, PDT_MF_ARGS);
-                    else PDT_LAUNCH(512, (k_mix_fir<26, 1, 8>), dim3(mf_grid), dim3(512), 0, st, PDT_MF_ARGS);
+                    if (d_pcm.fmt == 0) PDT_LAUNCH(512, (k_mix_fir<26, 0, 8>), dim3(mf_grid), dim3(512), 0, st, PDT_MF_ARGS, (float *)nullptr);
+                    else PDT_LAUNCH(512, (k_mix_fir<26, 1, 8>), dim3(mf_grid), dim3(512), 0, st, PDT_MF_ARGS, (float *)nullptr);
                 }
 #undef PDT_MF_ARGS
                 done = true;
@@ -1254,6 +1269,9 @@ template <typename T> int run_capture(pdt_ctx *ctx, uint64_t n, int phase = RUN_
         L.end();
     }
 
+    // the averagePhase walkers, behind the kernel that wrote their input (side stream: nothing in the chain waits for them)
+    if (quality_after_fir) quality_walkers_late(false);
+
     // ---- AGC (+Squelch); in a stream segment over the new outputs only, from the carried gain (*d_norm)
     long long agc_last_block = -1;
     if (n_out - first_out > 0) {
@@ -1274,7 +1292,7 @@ template <typename T> int run_capture(pdt_ctx *ctx, uint64_t n, int phase = RUN_
         // the true recurrence only, so a few time constants make the trajectories agree to the last bit
         double agc_K = (sizeof(T) == 4) ? 11.0 : 34.0;
         if (ctx->tune.agc_k > 0) agc_K = ctx->tune.agc_k;
-        if (quality_side) PL.simple(OP_JOIN_WAIT);          // the phases (in the AGC output's buffer) have been read
+        if (quality_side && !quality_term_fused) PL.simple(OP_JOIN_WAIT);          // the phases (in the AGC output's buffer) have been read
         L.begin("agc_block");
         if (!fused) PDT_LAUNCH(256, k_agc_affine<T>, dim3((unsigned)nb), dim3(256), 0, st, a_in, na, APs.decay, Ba, d_maps);
         if (agc_maps_per_block == 0) agc_maps_per_block = agc_tiles_per_block;        // (the FIR kernel's maps: one per tile)

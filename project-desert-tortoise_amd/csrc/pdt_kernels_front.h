@@ -1505,41 +1505,92 @@ __device__ __forceinline__ void k_pll_mix(IqSrc pcm, const T *__restrict__ phi_l
 // in double and narrowed like the reference (:220).  Same block/warm-up/seam scheme.
 template <typename T> struct EmaSeam { T v0, v1; };
 
-// the EMA over [i0, i1) with the software-pipelined 16-byte loads of the other stream walkers
-// (32 vectors of look-ahead: one lane alone waits ~0.6 us for a load and spends 13 ns on a double-precision step)
-template <typename T, bool STORE, int PF = 32>
-__device__ __forceinline__ void ema_range(const T *__restrict__ term, T *__restrict__ out, long long i0, long long i1, T &L, double k)
+// the EMA over [i0, i1).  STORE 0: nothing is written (warm-ups, zero responses); 1: every value (the lock stream Squelch
+// reads); 2: only the value after the last sample of every chunk of `chunk` samples (the averagePhase the chunk loop prints,
+// CarrierTrackingPLL.c:277: k_chunk_info reads nothing else of that stream) -- the full stream was 3.6 GB of 16-byte stores per
+// lane at an hour of 250 ksps.  `ring` (PDT_EMA_PF KiB of LDS for this wavefront, or nullptr): the look-ahead as an LDS ring
+// with hand-placed waits (ring_issue; the register ring's loop header waits for every load in flight, so each trip of 32
+// vectors exposed a memory latency: ~35 ns a step where the arithmetic is 13).
+#define PDT_EMA_PF 32
+template <typename T, int STORE, int PF = 32>
+__device__ __forceinline__ void ema_range(const T *__restrict__ term, T *__restrict__ out, long long i0, long long i1, T &L, double k,
+                                          unsigned char *ring = nullptr, long long chunk = 0)
 {
     constexpr int VN = Vec16<T>::N;
     long long i = i0;
-    for (; i < i1 && (i % VN) != 0; i++) {
-        L = (T)((double)L * k + (double)term[i]);
-        if (STORE) out[i] = L;
-    }
-    if (i + PF * VN <= i1) {
+    // STORE 2: samples from i up to and including the next chunk end
+    long long togo = 0;
+    if (STORE == 2) togo = (i / chunk + 1) * chunk - i;
+    auto one = [&](T x, long long at) {
+        L = (T)((double)L * k + (double)x);
+        if (STORE == 1) out[at] = L;
+        if (STORE == 2) {
+            if (--togo == 0) {
+                out[at] = L;
+                togo = chunk;
+            }
+        }
+    };
+    for (; i < i1 && (i % VN) != 0; i++) one(term[i], i);
+    auto vec = [&](const Vec16<T> &x, long long at) {
+        if (STORE == 2) {
+            if (togo > VN) {                                   // no chunk ends inside this vector
+#pragma unroll
+                for (int w = 0; w < VN; w++) L = (T)((double)L * k + (double)x.v[w]);
+                togo -= VN;
+            } else {
+#pragma unroll
+                for (int w = 0; w < VN; w++) one(x.v[w], at + w);
+            }
+        } else {
+            Vec16<T> yv;
+#pragma unroll
+            for (int w = 0; w < VN; w++) {
+                L = (T)((double)L * k + (double)x.v[w]);
+                yv.v[w] = L;
+            }
+            if (STORE == 1) *reinterpret_cast<Vec16<T> *>(out + at) = yv;
+        }
+    };
+    if (ring && i + (long long)PDT_EMA_PF * VN <= i1) {
+        constexpr int RPF = PDT_EMA_PF;
+        const unsigned ring0 = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(size_t)ring);
+        const unsigned char *mine = ring + 16 * (threadIdx.x & 63);
+#pragma unroll
+        for (int u = 0; u < RPF; u++) ring_issue(term + i + u * VN, ring0 + u * PDT_RING_SLOT);
+        ring_wait<RPF - 1>();
+        Vec16<T> cur = *reinterpret_cast<const Vec16<T> *>(mine), nxt;
+        for (; i + RPF * VN <= i1; i += RPF * VN) {
+#pragma unroll
+            for (int u = 0; u < RPF; u++) {
+                ring_wait<RPF - 2>();
+                nxt = *reinterpret_cast<const Vec16<T> *>(mine + ((u + 1) % RPF) * PDT_RING_SLOT);
+                vec(cur, i + u * VN);
+                ring_issue(term + i + (RPF + u) * VN, ring0 + u * PDT_RING_SLOT);   // (up to RPF vectors past i1: slack of the buffers)
+                cur = nxt;
+            }
+        }
+        ring_wait<0>();
+        // the ring holds the RPF vectors from i on: what is left of the range (fewer than RPF whole vectors) is among them
+        for (int u = 0; i + VN <= i1; i += VN, u++) {
+            if (u > 0) cur = *reinterpret_cast<const Vec16<T> *>(mine + u * PDT_RING_SLOT);
+            vec(cur, i);
+        }
+    } else if (i + PF * VN <= i1) {
         Vec16<T> buf[PF];
 #pragma unroll
         for (int u = 0; u < PF; u++) buf[u] = *reinterpret_cast<const Vec16<T> *>(term + i + u * VN);
         for (; i + PF * VN <= i1; i += PF * VN) {
 #pragma unroll
             for (int u = 0; u < PF; u++) {
-                Vec16<T> yv;
-#pragma unroll
-                for (int w = 0; w < VN; w++) {
-                    L = (T)((double)L * k + (double)buf[u].v[w]);
-                    yv.v[w] = L;
-                }
-                if (STORE) *reinterpret_cast<Vec16<T> *>(out + i + u * VN) = yv;
+                vec(buf[u], i + u * VN);
                 long long q = i + (PF + u) * VN;      // reload after the last use (see pll_phase_range)
                 asm volatile("" : "+v"(q));
                 buf[u] = *reinterpret_cast<const Vec16<T> *>(term + q);
             }
         }
     }
-    for (; i < i1; i++) {
-        L = (T)((double)L * k + (double)term[i]);
-        if (STORE) out[i] = L;
-    }
+    for (; i < i1; i++) one(term[i], i);
 }
 
 // Response of every block to a zero start state: with it the state at every block boundary follows from the state at the lock
@@ -1558,8 +1609,55 @@ __device__ __forceinline__ void k_lock_ema_zero(const T *__restrict__ term, long
     if (start < S) start = S;
     const long long end = ((j + 1) * B < n) ? (j + 1) * B : n;
     T L = 0;
-    ema_range<T, false>(term, (T *)nullptr, start, end, L, 1.0 - (double)lock_alpha);
+    __shared__ __attribute__((aligned(16))) unsigned char ring[PDT_EMA_PF * PDT_RING_SLOT];
+    ema_range<T, 0>(term, (T *)nullptr, start, end, L, 1.0 - (double)lock_alpha, ring);
     zresp[j - S / B] = (double)L;
+}
+
+// The same zero responses, a WAVEFRONT per block (round 4; the averagePhase EMA's blocks are 110 000 samples at an hour of
+// 250 ksps: one lane per block walked them for 3 ms before the real walkers could start).  The response only steers a guess, so
+// it is taken as the linear functional it is in exact arithmetic, sum over i of term[i] k^(end - 1 - i), in double: lane l folds
+// the 16-byte vectors l, l + 64, ... of the block by Horner's rule with k^256 (coalesced KiB loads), weighs its sum with one
+// power of k, the lanes add up.  It differs from the rounded recurrence's response by that recurrence's own rounding noise
+// (tens of float ulps over a time constant), which is what the walkers' 16 time constants of warm-up are there to absorb.
+template <typename T>
+__device__ __forceinline__ void k_lock_ema_zero_wave(const T *__restrict__ term, long long n, T lock_alpha,
+                                                     const PllLockInfo<T> *__restrict__ info, long long B, double *__restrict__ zresp)
+{
+    constexpr int VN = Vec16<T>::N;
+    const long long lock_at = info->lock_sample;
+    if (lock_at < 0) return;
+    const long long S = lock_at + 1;
+    const long long j = S / B + (long long)blockIdx.x;
+    long long start = j * B;
+    if (start >= n) return;
+    if (start < S) start = S;
+    const long long end = ((j + 1) * B < n) ? (j + 1) * B : n;
+    const int lane = threadIdx.x & 63;
+    const double k = 1.0 - (double)lock_alpha, lnk = log(k);
+    double kv = 1.0;                                        // k^(64 VN): from one of a lane's vectors to its next
+    for (int u = 0; u < 64 * VN; u++) kv *= k;
+    const long long a0 = (start + VN - 1) / VN * VN;        // first aligned sample
+    const long long nv = (end > a0) ? (end - a0) / VN : 0;  // whole vectors
+    double A = 0.0;
+    long long v_last = -1;
+    for (long long v = lane; v < nv; v += 64) {
+        const Vec16<T> x = *reinterpret_cast<const Vec16<T> *>(term + a0 + v * VN);
+        double c = 0.0;
+#pragma unroll
+        for (int w = 0; w < VN; w++) c = c * k + (double)x.v[w];
+        A = A * kv + c;
+        v_last = v;
+    }
+    double R = 0.0;
+    if (v_last >= 0) R = A * exp(lnk * (double)(end - 1 - (a0 + v_last * VN + VN - 1)));
+    if (lane == 0) {                                        // the few samples in front of and behind the whole vectors
+        for (long long i = start; i < a0 && i < end; i++) R += (double)term[i] * exp(lnk * (double)(end - 1 - i));
+        for (long long i = a0 + nv * VN; i < end; i++) R += (double)term[i] * exp(lnk * (double)(end - 1 - i));
+    }
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) R += __shfl_xor(R, d);
+    if (lane == 0) zresp[j - S / B] = R;
 }
 
 // guess[r] = approximate state in front of block r (r counted from the block that holds the lock): guess[r + 1] =
@@ -1612,8 +1710,10 @@ template <typename T, bool AVG = false>
 __device__ __forceinline__ void k_lock_ema(const T *__restrict__ term, long long n, T lock_alpha,
                                                   const PllLockInfo<T> *__restrict__ info, long long B, long long W,
                                                   T *__restrict__ lock_out, EmaSeam<T> *__restrict__ seams,
-                                                  const double *__restrict__ guess)
+                                                  const double *__restrict__ guess,
+                                                  long long chunk /* AVG: store the value behind every chunk's last sample only */)
 {
+    __shared__ __attribute__((aligned(16))) unsigned char ring[PDT_EMA_PF * PDT_RING_SLOT];
     const long long lock_at = info->lock_sample;
     if (lock_at < 0) return;
     const long long S = lock_at + 1;
@@ -1634,10 +1734,14 @@ __device__ __forceinline__ void k_lock_ema(const T *__restrict__ term, long long
         if (ws < S) { ws = S; L = L_lock; }
     }
     const double k = 1.0 - (double)lock_alpha;
-    ema_range<T, false>(term, lock_out, ws, start, L, k);
+    ema_range<T, 0>(term, lock_out, ws, start, L, k, ring);
     EmaSeam<T> sm;
     sm.v0 = L;
-    ema_range<T, true>(term, lock_out, start, end, L, k);
+    if (AVG && chunk > 0) {
+        ema_range<T, 2>(term, lock_out, start, end, L, k, ring, chunk);
+        if (end == n) lock_out[n - 1] = L;                 // the short last chunk ends with the stream
+    } else
+        ema_range<T, 1>(term, lock_out, start, end, L, k, ring);
     sm.v1 = L;
     seams[j - j0] = sm;
 }
@@ -1917,13 +2021,17 @@ __device__ __forceinline__ void k_fir_interp_rt(const T *__restrict__ in, long l
 #define PDT_MF_LSI 237                 // LDS row strides (odd: 64 rows at one column hit 64 banks)
 typedef float pdt_v2f __attribute__((ext_vector_type(2)));
 
-template <int K, int FMT, int NWV = 4>
+// QT (round 4): the kernel also writes the input term of the averagePhase EMA, averagePhaseAlpha * |arctan2(out)|
+// (CarrierTrackingPLL.c:117-124), for every sample it mixes -- both components of the mixed sample are in registers here, so the
+// per-chunk reports (pdt_keep_quality) no longer need a second pass over phases and I/Q with its own sincosf (k_pll_mix<AVGTERM>,
+// 3 ms beside this kernel on the other stream: together they took 7 ms).
+template <int K, int FMT, int NWV = 4, bool QT = false>
 __device__ __forceinline__ void k_mix_fir(IqSrc pcm, const float *__restrict__ phi_lt, const float *pll_pre /* may alias pll_out */,
                                           long long n, long long B, const PllLockInfo<float> *__restrict__ info,
                                           const float *__restrict__ rot /* host-built rotated taps */, float *__restrict__ out,
                                           float *pll_out /* nullptr: the PLL output is not kept; the host passes the same buffer as
                                                             pll_pre (reads before the lock, writes behind it): no __restrict__ */,
-                                          AgcMap *__restrict__ run_maps, float agc_decay)
+                                          AgcMap *__restrict__ run_maps, float agc_decay, float *__restrict__ term_out = nullptr)
 {
     static_assert(PDT_MF_RUN == 8 * K && PDT_MF_HALO >= K - 1 && PDT_MF_HALO % 4 == 0, "run = 8 ring revolutions, halo = whole phase vectors");
     static_assert(NWV == 4 || NWV == 8, "four or eight wavefronts per workgroup");
@@ -1990,7 +2098,7 @@ __device__ __forceinline__ void k_mix_fir(IqSrc pcm, const float *__restrict__ p
     // ---- B: phase -> mixed sample, in place
     {
         float *wrows = s_in + wave * RPW * PDT_MF_LSI;
-        auto mix = [&](const Raw &r, float ph) {
+        auto mix = [&](const Raw &r, float ph, float &term) {
             float a, b, sn, cs;
             if constexpr (FMT == 0) {                                  // I | Q << 16, value / 32768 (wave.c:127-172)
                 a = (float)(short)(r & 0xffff) / 32768.0f;
@@ -2001,7 +2109,12 @@ __device__ __forceinline__ void k_mix_fir(IqSrc pcm, const float *__restrict__ p
             }
             sincosf_flat(ph, sn, cs);
             const float c = cs, d = -sn;
-            return a * d + b * c;
+            const float o = a * d + b * c;
+            if (QT) {
+                const float o_re = a * c - b * d;
+                term = 0.00005f * __builtin_fabsf(arctan2_ref(o, o_re));
+            }
+            return o;
         };
         if (interior) {
 #pragma unroll
@@ -2009,9 +2122,11 @@ __device__ __forceinline__ void k_mix_fir(IqSrc pcm, const float *__restrict__ p
                 const int idx = it * 64 + lane, rr = idx / PDT_MF_COLS, col = idx - rr * PDT_MF_COLS;
                 float *cell = wrows + idx + rr;                        // rr * LSI + col, LSI = COLS + 1
                 if (RAGGED && idx >= RPW * PDT_MF_COLS) continue;
-                const float x = mix(raw[it], *cell);
+                float tq = 0.0f;
+                const float x = mix(raw[it], *cell, tq);
                 *cell = x;
                 if (pll_out && col >= PDT_MF_HALO) pll_out[(blk0 + wave * RPW + rr) * B + p0 - PDT_MF_HALO + col] = x;
+                if (QT && col >= PDT_MF_HALO) term_out[(blk0 + wave * RPW + rr) * B + p0 - PDT_MF_HALO + col] = tq;
                 if ((it & 3) == 3) __builtin_amdgcn_sched_barrier(0);  // four evaluations interleaved, not fifty-nine (registers)
             }
         } else {
@@ -2023,8 +2138,10 @@ __device__ __forceinline__ void k_mix_fir(IqSrc pcm, const float *__restrict__ p
                 if (RAGGED && idx >= RPW * PDT_MF_COLS) continue;
                 float x = 0.0f;
                 if (i >= S && i < n) {
-                    x = mix(reinterpret_cast<const Raw *>(pcm.p)[i], *cell);
+                    float tq = 0.0f;
+                    x = mix(reinterpret_cast<const Raw *>(pcm.p)[i], *cell, tq);
                     if (pll_out && col >= PDT_MF_HALO) pll_out[i] = x;
+                    if (QT && col >= PDT_MF_HALO) term_out[i] = tq;
                 } else if (i >= 0 && i < n)
                     x = pll_pre[i];                                    // up to the lock: the acquisition's output
                 *cell = x;
