@@ -136,9 +136,29 @@ def make_capture(pdt, p, n: int, threads: int, device=None, wav_path: str | None
     return d_iq
 
 
+_gather_lib = None
+
+
+def gather_lib():
+    """libpdtgather.so: its two host-only functions state the exchange format (pdt_gather_plan / pdt_gather_unpad, include/
+    pdt_gather.h); bin/demodMulti's RCCL gather and this one (torch.distributed across processes) share them."""
+    global _gather_lib
+    if _gather_lib is None:
+        import ctypes as C
+        import importlib
+        pdt = importlib.import_module("project-desert-tortoise_amd")
+        C.CDLL(pdt.LIBPDT_PATH, mode=C.RTLD_GLOBAL)
+        L = C.CDLL(os.path.join(os.path.dirname(pdt.LIBPDT_PATH), "libpdtgather.so"))
+        L.pdt_gather_plan.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.c_uint64), C.c_void_p]
+        L.pdt_gather_unpad.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_uint64, C.c_uint64, C.c_void_p]
+        _gather_lib = L
+    return _gather_lib
+
+
 def gather_frames(frames: np.ndarray, device):
     """All ranks contribute a (ragged) array of pdt_frame records; rank 0 gets the list per rank.
     Two collectives: counts (all_gather of one int64) and the records padded to the maximum."""
+    import ctypes as C
     import torch
     import torch.distributed as dist
     world = dist.get_world_size()
@@ -146,8 +166,12 @@ def gather_frames(frames: np.ndarray, device):
     n = torch.tensor([len(frames)], dtype=torch.int64, device=device)
     counts = [torch.zeros_like(n) for _ in range(world)]
     dist.all_gather(counts, n)
-    counts = [int(c.item()) for c in counts]
-    nmax = max(max(counts), 1)
+    counts = np.array([int(c.item()) for c in counts], dtype=np.uint64)
+    L = gather_lib()
+    nmax = C.c_uint64(0)
+    offsets = np.zeros(world + 1, dtype=np.uint64)
+    assert L.pdt_gather_plan(counts.ctypes.data, world, C.byref(nmax), offsets.ctypes.data) == 0
+    nmax = int(nmax.value)
     buf = torch.zeros(nmax * rec, dtype=torch.uint8, device=device)
     if len(frames):
         buf[: len(frames) * rec] = torch.from_numpy(frames.view(np.uint8).reshape(-1).copy()).to(device)
@@ -155,7 +179,10 @@ def gather_frames(frames: np.ndarray, device):
     dist.all_gather(out, buf)
     if dist.get_rank() != 0:
         return None
-    return [o[: c * rec].cpu().numpy().view(frames.dtype) for o, c in zip(out, counts)]
+    padded = np.ascontiguousarray(torch.stack(out).cpu().numpy())                 # world x (nmax records)
+    flat = np.zeros(int(offsets[world]) * rec + 1, dtype=np.uint8)
+    assert L.pdt_gather_unpad(padded.ctypes.data, counts.ctypes.data, world, nmax, rec, flat.ctypes.data) == 0
+    return [flat[int(offsets[r]) * rec: int(offsets[r + 1]) * rec].view(frames.dtype) for r in range(world)]
 
 
 def transmitted_check(pdt, p, frames: np.ndarray, n: int, fs: int) -> dict:

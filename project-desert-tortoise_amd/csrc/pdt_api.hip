@@ -26,6 +26,8 @@
 
 using namespace pdt;
 
+static std::atomic<int> g_open_contexts{0};          // contexts alive in this process (pdt_open / pdt_close)
+
 #define HIP_TRY(expr)                                                                                  \
     do {                                                                                               \
         hipError_t e_ = (expr);                                                                        \
@@ -336,6 +338,7 @@ struct pdt_ctx {
     hipStream_t stream2 = nullptr;     // side stream: block-parallel PLL phase runs beside the sequential acquisition
 
     DevBuf pcm, pll, lock, fir, agc, sym, symidx, bits, bitsym, hits, frames, taps, mag, seams_pll, seams_agc, scal, lockinfo, term, seams_ema, gtable, gentries, gcand, gmfirst, stiles, gsegmap, gsegstart, gbands, gclist, gneed, gchain, gspan_keys, gspan_tails, gspan_rows, gspan_items, gspan_ctl, gspan_recs, gcentries, gflags, agc_maps, pll_head, taps_rot, pll_scratch, tip, sync_scr, agc_raw, agc_ckpt;
+    bool counted = false;        // this context is in g_open_contexts
     bool keep_agc_raw = false;   // pdt_keep_presquelch: also keep the AGC output before Squelch (stage PDT_ST_AGC_RAW)
     // pdt_keep_quality: the averagePhase stream (what CarrierTrackPLL returns, chunk by chunk) and the per-chunk counts
     bool keep_quality = false;
@@ -1974,7 +1977,10 @@ int ingest_capture(pdt_ctx *ctx, const IngestSrc &src, size_t bytes, void *dst, 
     unsigned hw = std::thread::hardware_concurrency();
     // (round 4, 3.6 GB from tmpfs: 4 / 6 / 8 / 12 / 16 threads -> 100 / 92 / 88 / 90 / 89 ms for the whole call; beside a chain that
     // is launching kernels -- PDT_OVERLAP -- 8 / 16 / 24 / 32 -> 98 / 116 / 107 / 111: the readers contend with the launches)
-    const unsigned t_max = ctx->tune.ingest_threads > 0 ? (unsigned)ctx->tune.ingest_threads : 8u;
+    // Several contexts of one process (bin/demodMulti: one per GPU) share the host's cores: half of them, divided by the open
+    // contexts, never fewer than two readers (8 GPUs on a 256-thread host: 8 each; on a 32-thread host: 2 each).
+    const unsigned share = std::max(2u, (hw ? hw / 2u : 8u) / (unsigned)std::max(1, g_open_contexts.load()));
+    const unsigned t_max = ctx->tune.ingest_threads > 0 ? (unsigned)ctx->tune.ingest_threads : std::min(8u, share);
     int T = (int)std::min<size_t>(std::min<unsigned>(hw ? hw / 2u + 1u : 4u, t_max), nspans);
     if (T < 1) T = 1;
     const size_t need = (size_t)T * PDT_INGEST_SLOTS * PDT_INGEST_SPAN;
@@ -2286,6 +2292,8 @@ int pdt_open(const pdt_config *cfg, pdt_ctx **out)
     memset(ctx->stage_len, 0, sizeof ctx->stage_len);
     ctx->axis_f.init((float)(1.0 / (double)(float)cfg->sample_rate));        // wave.c:96-97
     ctx->axis_d.init(1.0 / (double)cfg->sample_rate);
+    ctx->counted = true;
+    g_open_contexts.fetch_add(1);
     *out = ctx;
     return PDT_OK;
 }
@@ -2321,6 +2329,7 @@ void pdt_close(pdt_ctx *ctx)
     if (ctx->ev_join) (void)hipEventDestroy(ctx->ev_join);
     if (ctx->stream2) (void)hipStreamDestroy(ctx->stream2);
     if (ctx->own_stream && ctx->stream) (void)hipStreamDestroy(ctx->stream);
+    if (ctx->counted) g_open_contexts.fetch_sub(1);
     delete ctx;
 }
 

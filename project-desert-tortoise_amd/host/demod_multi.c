@@ -1,16 +1,23 @@
 /*
- * demod_multi.c -- demodMulti: several independent captures, one per GPU, frames gathered on one GPU with RCCL.
+ * demod_multi.c -- demodMulti: several independent captures over the GPUs of one node, frames gathered on one GPU with RCCL.
  *
  * The reference demodulates one capture per process (POESTIPdemod/main.c:143-531).  This host program is the multi-GPU
- * front of the port: capture i goes to GPU i (mod the number of GPUs), every capture is demodulated by its own context
- * (include/pdt.h, no collective on the data path) in its own thread; the decoded frame records of each wave of captures are
- * then gathered on the first GPU of the wave by libpdtgather (include/pdt_gather.h: all-gather of the counts + padded
- * all-gather of the records over xGMI), and this process writes one output file per capture -- the text
+ * front of the port: every GPU has one worker thread with one context (include/pdt.h; no collective on the data path) that
+ * takes the NEXT capture from a shared queue whenever it has finished one -- a GPU is never idle while captures are waiting
+ * (round 3 dealt the captures out in waves of one per GPU and joined every wave: a short capture's GPU waited for the longest
+ * one of its wave).  When the queue is empty the decoded frame records of every GPU's captures are gathered on the first GPU
+ * by libpdtgather (include/pdt_gather.h: ONE gatherer = one set of RCCL communicators for the whole run; all-gather of the
+ * counts + padded all-gather of the records over xGMI), and this process writes one output file per capture -- the text
  * POESTIPdemod/ByteSync.c:62-69,96-101 / ARGOSdemod/ByteSync.c:62-70,99-103 print -- next to the input: <capture>.frames.txt.
  *
  * usage: demodMulti [-a] [-c chunk] [-g ngpus] capture1.wav capture2.wav ...      (-a: ARGOS chain; default POES)
+ *
+ * Host budget at N GPUs: N worker threads + per context up to min(8, cores / 2N) reader threads while a file
+ * is being read (csrc/pdt_api.hip: ingest_capture) and 2 x 8 MiB of pinned staging per reader; frame records 136 B each
+ * (4.9 MB per capture-hour) on the host until they are written.
  */
 #include <pthread.h>
+#include <stdatomic.h>
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
@@ -22,14 +29,28 @@
 #include "pdt.h"
 #include "pdt_gather.h"
 
-typedef struct job {
+typedef struct capture {
     const char *path;
-    int device, mode, rc, started;
-    unsigned long chunk;
-    pdt_ctx *ctx;
-    uint64_t nframes;
+    int rc, device, order;          /* order: the how-manieth capture of its GPU it was */
+    uint64_t nsamples, nfr;
+    pdt_frame *frames;              /* host copy of the records (the context goes on to the next capture) */
+    pdt_stats st;
     double seconds;
-} job;
+} capture;
+
+typedef struct worker {
+    int device, mode, started;
+    unsigned long chunk;
+    pthread_t th;
+    pdt_ctx *ctx;
+    uint32_t ctx_rate;
+    int done;                       /* captures this GPU demodulated */
+    uint64_t nfr;                   /* frames of all of them */
+} worker;
+
+static capture *g_cap;
+static int g_ncap;
+static atomic_int g_next;
 
 static double now_s(void)
 {
@@ -38,33 +59,64 @@ static double now_s(void)
     return (double)ts.tv_sec + 1e-9 * (double)ts.tv_nsec;
 }
 
-static void *run_job(void *arg)
+static void run_capture(worker *w, capture *c)
 {
-    job *j = (job *)arg;
     const double t0 = now_s();
-    j->rc = PDT_ERR_FORMAT;
-    const int fd = open(j->path, O_RDONLY);
-    if (fd < 0) return NULL;
+    c->rc = PDT_ERR_FORMAT;
+    c->device = w->device;
+    c->order = w->done;
+    const int fd = open(c->path, O_RDONLY);
+    if (fd < 0) return;
     uint8_t hdr[44];
     struct stat sb;
-    if (pread(fd, hdr, 44, 0) != 44 || fstat(fd, &sb) != 0) { close(fd); return NULL; }
+    if (pread(fd, hdr, 44, 0) != 44 || fstat(fd, &sb) != 0) { close(fd); return; }
     uint32_t rate = 0, channels = 0, bits = 0, format = 0, data_bytes = 0;
     pdt_wav_parse_header(hdr, &rate, &channels, &bits, &format, &data_bytes);
-    if (channels != 2 || format != 1 || bits != 16) { close(fd); return NULL; }      /* ReadWavHeader's canonical PCM (wave.c:303-378) */
-    pdt_config cfg;
-    memset(&cfg, 0, sizeof cfg);
-    cfg.mode = j->mode;
-    cfg.sample_rate = rate;
-    cfg.chunk = j->chunk;
-    cfg.device = j->device;
-    j->rc = pdt_open(&cfg, &j->ctx);
-    if (j->rc == PDT_OK) pdt_keep_pll(j->ctx, 0);                   /* nothing here reads the PLL output stream */
-    if (j->rc == PDT_OK) {
-        j->nframes = (uint64_t)(sb.st_size - 44) / 4;                                  /* to the end of the file (main.c:373) */
-        j->rc = pdt_demod_fd(j->ctx, fd, 44, j->nframes, PDT_FMT_PCM16);
+    if (channels != 2 || format != 1 || bits != 16) { close(fd); return; }           /* ReadWavHeader's canonical PCM (wave.c:303-378) */
+    if (w->ctx && w->ctx_rate != rate) {                             /* a context is bound to a sample rate (taps, loop gains) */
+        pdt_close(w->ctx);
+        w->ctx = NULL;
+    }
+    c->rc = PDT_OK;
+    if (!w->ctx) {
+        pdt_config cfg;
+        memset(&cfg, 0, sizeof cfg);
+        cfg.mode = w->mode;
+        cfg.sample_rate = rate;
+        cfg.chunk = w->chunk;
+        cfg.device = w->device;
+        c->rc = pdt_open(&cfg, &w->ctx);
+        w->ctx_rate = rate;
+        if (c->rc == PDT_OK) pdt_keep_pll(w->ctx, 0);                /* nothing here reads the PLL output stream */
+        else w->ctx = NULL;
+    }
+    if (c->rc == PDT_OK) {
+        c->nsamples = (uint64_t)(sb.st_size - 44) / 4;               /* to the end of the file (main.c:373) */
+        c->rc = pdt_demod_fd(w->ctx, fd, 44, c->nsamples, PDT_FMT_PCM16);
     }
     close(fd);
-    j->seconds = now_s() - t0;
+    if (c->rc == PDT_OK) {
+        c->nfr = pdt_num_frames(w->ctx);
+        c->frames = (pdt_frame *)malloc((size_t)(c->nfr ? c->nfr : 1) * sizeof(pdt_frame));
+        if (!c->frames) c->rc = PDT_ERR_NOMEM;
+        else if (c->nfr) pdt_frames(w->ctx, c->frames, c->nfr);
+        pdt_get_stats(w->ctx, &c->st);
+    }
+    if (c->rc == PDT_OK) {
+        w->done++;
+        w->nfr += c->nfr;
+    }
+    c->seconds = now_s() - t0;
+}
+
+static void *run_worker(void *arg)
+{
+    worker *w = (worker *)arg;
+    for (;;) {
+        const int k = atomic_fetch_add(&g_next, 1);                  /* the next capture nobody has taken yet */
+        if (k >= g_ncap) break;
+        run_capture(w, &g_cap[k]);
+    }
     return NULL;
 }
 
@@ -82,84 +134,104 @@ int main(int argc, char **argv)
     if (n <= 0) { fprintf(stderr, "usage: %s [-a] [-c chunk] [-g ngpus] capture.wav ...\n", argv[0]); return 2; }
     if (ngpu <= 0) { printf("GPU demodulator unavailable: %s\n", pdt_strerror(PDT_ERR_NOGPU)); return 1; }
     if (ngpu > pdt_device_count()) ngpu = pdt_device_count();
-    printf("Project Desert Tortoise: %d capture(s) on %d MI355X GPU(s), one capture per GPU at a time\n", n, ngpu);
-    job *jobs = (job *)calloc((size_t)n, sizeof(job));
-    pthread_t *th = (pthread_t *)calloc((size_t)n, sizeof(pthread_t));
-    int failed = 0;
+    if (ngpu > n) ngpu = n;
+    printf("Project Desert Tortoise: %d capture(s) on %d MI355X GPU(s), every GPU takes the next capture when it is free\n", n, ngpu);
+    g_cap = (capture *)calloc((size_t)n, sizeof(capture));
+    g_ncap = n;
+    atomic_store(&g_next, 0);
+    worker *wk = (worker *)calloc((size_t)ngpu, sizeof(worker));
+    if (!g_cap || !wk) return 1;
+    for (int k = 0; k < n; k++) {
+        g_cap[k].path = argv[optind + k];
+        g_cap[k].rc = PDT_ERR_STATE;                                 /* (never taken: no worker could be started) */
+        g_cap[k].device = -1;
+    }
     const double t_all = now_s();
+    for (int d = 0; d < ngpu; d++) {
+        wk[d].device = d;
+        wk[d].mode = mode;
+        wk[d].chunk = chunk;
+        wk[d].started = pthread_create(&wk[d].th, NULL, run_worker, &wk[d]) == 0;
+    }
+    for (int d = 0; d < ngpu; d++)
+        if (wk[d].started) pthread_join(wk[d].th, NULL);
+    const double t_demod = now_s() - t_all;
+
+    /* ---- gather: rank i = GPU i's records, its captures in the order it took them; one gatherer for the run */
+    int failed = 0, ranks = 0;
+    int *devs = (int *)calloc((size_t)ngpu, sizeof(int));
+    pdt_frame **rec = (pdt_frame **)calloc((size_t)ngpu, sizeof(pdt_frame *));
+    uint64_t *cnt = (uint64_t *)calloc((size_t)ngpu, sizeof(uint64_t)), *got = (uint64_t *)calloc((size_t)ngpu, sizeof(uint64_t));
+    int *rank_of = (int *)calloc((size_t)ngpu, sizeof(int));
+    for (int d = 0; d < ngpu; d++) {
+        rank_of[d] = -1;
+        if (!wk[d].done) continue;                                   /* a GPU without a decoded capture takes no part */
+        rank_of[d] = ranks;
+        devs[ranks] = d;
+        cnt[ranks] = wk[d].nfr;
+        rec[ranks] = (pdt_frame *)malloc((size_t)(wk[d].nfr ? wk[d].nfr : 1) * sizeof(pdt_frame));
+        uint64_t at = 0;
+        for (int o = 0; o < wk[d].done && rec[ranks]; o++)          /* in the order the GPU took them */
+            for (int k = 0; k < n; k++)
+                if (g_cap[k].rc == PDT_OK && g_cap[k].device == d && g_cap[k].order == o) {
+                    memcpy(rec[ranks] + at, g_cap[k].frames, (size_t)g_cap[k].nfr * sizeof(pdt_frame));
+                    at += g_cap[k].nfr;
+                }
+        ranks++;
+    }
+    pdt_frame *all = NULL;
+    int grc = PDT_OK;
+    if (ranks) {
+        pdt_gatherer *g = NULL;
+        grc = pdt_gatherer_open(devs, ranks, &g);
+        if (grc == PDT_OK) grc = pdt_gatherer_gather(g, (const pdt_frame *const *)rec, cnt, 0, &all, got);   /* RCCL: counts, then padded records */
+        if (grc == PDT_OK)
+            for (int r = 0; r < ranks; r++)
+                if (got[r] != cnt[r]) grc = PDT_ERR_STATE;
+        if (grc != PDT_OK) printf("gather failed (%s): every capture's frames are taken from its own GPU's copy\n", pdt_strerror(grc));
+        pdt_gatherer_close(g);
+    }
+    /* ---- one output file per capture, from the gathered array */
+    uint64_t *rank_at = (uint64_t *)calloc((size_t)(ranks + 1), sizeof(uint64_t));
+    for (int r = 0; r < ranks; r++) rank_at[r + 1] = rank_at[r] + cnt[r];
     uint64_t samples_all = 0;
-    for (int w0 = 0; w0 < n; w0 += ngpu) {                       /* waves of one capture per GPU */
-        const int wn = (n - w0 < ngpu) ? n - w0 : ngpu;
-        for (int k = 0; k < wn; k++) {
-            job *j = &jobs[w0 + k];
-            j->path = argv[optind + w0 + k];
-            j->device = k;
-            j->mode = mode;
-            j->chunk = chunk;
-            j->started = pthread_create(&th[w0 + k], NULL, run_job, j) == 0;
-            if (!j->started) j->rc = PDT_ERR_NOMEM;                /* (no thread: this capture fails, the others go on) */
-        }
-        for (int k = 0; k < wn; k++)
-            if (jobs[w0 + k].started) pthread_join(th[w0 + k], NULL);
-        /* the captures that were demodulated: only those take part in the gather; a failed capture costs its own output */
-        pdt_ctx **ctxs = (pdt_ctx **)calloc((size_t)wn, sizeof(pdt_ctx *));
-        int *who = (int *)calloc((size_t)wn, sizeof(int));
-        int good = 0;
-        for (int k = 0; k < wn; k++) {
-            if (jobs[w0 + k].rc != PDT_OK) {
-                printf("%s: %s\n", jobs[w0 + k].path, pdt_strerror(jobs[w0 + k].rc));
-                failed++;
-            } else {
-                who[good] = w0 + k;
-                ctxs[good++] = jobs[w0 + k].ctx;
-            }
-        }
-        if (good) {
-            pdt_frame *all = NULL;
-            uint64_t *counts = (uint64_t *)calloc((size_t)good, sizeof(uint64_t));
-            int rc = counts ? pdt_gather_frames(ctxs, good, 0, &all, counts) : PDT_ERR_NOMEM;   /* RCCL: counts, then padded records */
-            if (rc != PDT_OK) printf("gather failed (%s): every capture's frames are taken from its own context\n", pdt_strerror(rc));
-            uint64_t at = 0;
-            for (int k = 0; k < good; k++) {
-                const job *j = &jobs[who[k]];
+    for (int d = 0; d < ngpu; d++) {
+        uint64_t at = rank_of[d] >= 0 ? rank_at[rank_of[d]] : 0;
+        for (int o = 0; o < wk[d].done; o++)
+            for (int k = 0; k < n; k++) {
+                capture *cp = &g_cap[k];
+                if (cp->rc != PDT_OK || cp->device != d || cp->order != o) continue;
+                const pdt_frame *src = (grc == PDT_OK && all) ? all + at : cp->frames;
+                at += cp->nfr;
                 char name[1200];
-                snprintf(name, sizeof name, "%s.frames.txt", j->path);
-                const uint64_t nfr = rc == PDT_OK ? counts[k] : pdt_num_frames(j->ctx);
-                const uint64_t need = rc == PDT_OK ? pdt_format_records(all + at, nfr, NULL, 0) : pdt_format_frames(j->ctx, NULL, 0);
-                char *text = (char *)malloc(need + 1);
-                int wrote = text != NULL;
-                if (text) {
-                    if (rc == PDT_OK) pdt_format_records(all + at, nfr, text, need);
-                    else pdt_format_frames(j->ctx, text, need);
-                    if (nfr) {
-                        FILE *f = fopen(name, "w");
-                        wrote = f && fwrite(text, 1, need, f) == need;
-                        if (f && fclose(f) != 0) wrote = 0;
-                    } else {
-                        remove(name);                                              /* no frame, no file (main.c:508-512) */
-                    }
-                    free(text);
+                snprintf(name, sizeof name, "%s.frames.txt", cp->path);
+                int wrote = 1;
+                if (cp->nfr) {
+                    const int fd = open(name, O_RDWR | O_CREAT | O_TRUNC, 0644);
+                    wrote = fd >= 0 && pdt_write_records(src, cp->nfr, fd, NULL) == PDT_OK;
+                    if (fd >= 0 && close(fd) != 0) wrote = 0;
+                } else {
+                    remove(name);                                    /* no frame, no file (main.c:508-512) */
                 }
                 if (!wrote) { printf("%s: could not be written\n", name); failed++; }
-                pdt_stats st;
-                pdt_get_stats(j->ctx, &st);
-                printf("GPU %d: %s: %0.3f Ks : %llu Sym : %llu Bits : %llu %s  (%.1f ms on the GPU, %.3f s with file read)\n", j->device,
-                       j->path, st.samples / 1000.0, (unsigned long long)st.symbols, (unsigned long long)st.bits,
-                       (unsigned long long)nfr, mode == PDT_MODE_ARGOS ? "Packets" : "Frames", st.gpu_ms, j->seconds);
-                if (wrote) samples_all += st.samples;
-                if (rc == PDT_OK) at += counts[k];
+                printf("GPU %d: %s: %0.3f Ks : %llu Sym : %llu Bits : %llu %s  (%.1f ms on the GPU, %.3f s with file read)\n", cp->device,
+                       cp->path, cp->st.samples / 1000.0, (unsigned long long)cp->st.symbols, (unsigned long long)cp->st.bits,
+                       (unsigned long long)cp->nfr, mode == PDT_MODE_ARGOS ? "Packets" : "Frames", cp->st.gpu_ms, cp->seconds);
+                if (wrote) samples_all += cp->st.samples;
             }
-            free(all);
-            free(counts);
-        }
-        free(who);
-        for (int k = 0; k < wn; k++)
-            if (jobs[w0 + k].ctx) pdt_close(jobs[w0 + k].ctx);
-        free(ctxs);
     }
+    for (int k = 0; k < n; k++)
+        if (g_cap[k].rc != PDT_OK) {
+            printf("%s: %s\n", g_cap[k].path, pdt_strerror(g_cap[k].rc));
+            failed++;
+        }
     const double dt = now_s() - t_all;
-    printf("%d capture(s), %.3f Msamples in %.3f s: %.1f Msamples/s\n", n - failed, samples_all / 1e6, dt, samples_all / dt / 1e6);
-    free(jobs);
-    free(th);
+    printf("%d capture(s), %.3f Msamples in %.3f s (%.3f s until the last GPU was done): %.1f Msamples/s\n", n - failed, samples_all / 1e6,
+           dt, t_demod, samples_all / dt / 1e6);
+    for (int d = 0; d < ngpu; d++)
+        if (wk[d].ctx) pdt_close(wk[d].ctx);
+    for (int r = 0; r < ranks; r++) free(rec[r]);
+    for (int k = 0; k < n; k++) free(g_cap[k].frames);
+    free(all); free(rank_at); free(rank_of); free(got); free(cnt); free(rec); free(devs); free(wk); free(g_cap);
     return failed ? 1 : 0;
 }

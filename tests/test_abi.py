@@ -201,7 +201,9 @@ def test_gather_library_exports_its_entry_point(pdt):
     assert "librccl" in needed and "libpdt.so" in needed
     assert "librccl" not in subprocess.run(["readelf", "-d", pdt.LIBPDT_PATH], capture_output=True, text=True).stdout
     syms = subprocess.run(["nm", "-D", "--defined-only", path], capture_output=True, text=True).stdout
-    assert " T pdt_gather_frames" in syms
+    for name in re.findall(r"\b(pdt_gather\w*)\s*\(", open(os.path.join(ROOT, "include", "pdt_gather.h")).read()):
+        assert f" T {name}" in syms, f"{name} declared in include/pdt_gather.h but not exported by libpdtgather.so"
+    assert " T pdt_gather_frames" in syms and " T pdt_gatherer_gather" in syms and " T pdt_gather_unpad" in syms
 
 
 def test_compat_libraries_export_the_reference_prototypes(pdt):

@@ -1,0 +1,104 @@
+"""bin/demodMulti's scheduling on a machine without a GPU: host/demod_multi.c linked against tests/fake_pdt.c (stand-ins for
+the library calls: a "capture" says how long its demodulation takes and how many frames it yields).  What is checked is the
+host logic of round 4: one worker per GPU taking the next capture from a shared queue (no waves), contexts reused from capture to
+capture (re-opened when the sample rate changes), ONE gatherer for the whole run, one output file per capture with that
+capture's records, failures confined to the capture they happen in."""
+import os
+import re
+import struct
+import subprocess
+
+import pytest
+
+from conftest import ROOT
+
+
+def wav(path, ms, frames, rate=250000, pad=4000, channels=2):
+    hdr = b"RIFF" + struct.pack("<I", 36 + pad) + b"WAVEfmt " + struct.pack("<IHHIIHH", 16, 1, channels, rate, rate * 4, 4, 16)
+    hdr += b"data" + struct.pack("<I", pad)
+    assert len(hdr) == 44
+    with open(path, "wb") as f:
+        f.write(hdr + struct.pack("<II", ms, frames) + bytes(pad - 8))
+
+
+def expected_text(nsamples, frames):
+    out = []
+    for k in range(frames):
+        b = lambda i: (nsamples * 7 + k * 13 + i) & 0xFF
+        out.append("%.5f %02X %02X %02X\n" % (k * 0.1, b(0), b(1), b(103)))
+    return "".join(out)
+
+
+@pytest.fixture(scope="module")
+def exe(tmp_path_factory):
+    out = str(tmp_path_factory.mktemp("multi") / "demodMulti_fake")
+    src = [os.path.join(ROOT, "project-desert-tortoise_amd", "host", "demod_multi.c"), os.path.join(ROOT, "tests", "fake_pdt.c")]
+    subprocess.run(["gcc", "-O1", "-Wall", "-I", os.path.join(ROOT, "include"), "-o", out] + src + ["-lpthread"], check=True)
+    return out
+
+
+def run(exe, files, devices, extra=()):
+    env = dict(os.environ, FAKE_DEVICES=str(devices))
+    r = subprocess.run([exe, *extra, *files], capture_output=True, text=True, env=env, timeout=120)
+    took = {}
+    for m in re.finditer(r"^GPU (\d+): (\S+):", r.stdout, re.M):
+        took[m.group(2)] = int(m.group(1))
+    return r, took
+
+
+def test_a_free_gpu_takes_the_next_capture(exe, tmp_path):
+    """One long capture and five short ones on two GPUs: the GPU that is not stuck with the long one demodulates all the
+    others (waves of one capture per GPU would have given it two and left it idle for most of the run)."""
+    files = []
+    for k, (ms, fr) in enumerate([(900, 5), (40, 3), (40, 0), (40, 7), (40, 2), (40, 4)]):
+        p = str(tmp_path / f"c{k}.wav")
+        wav(p, ms, fr, pad=4000 + 40 * k)
+        files.append(p)
+    r, took = run(exe, files, 2)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert set(took) == set(files)                                   # every capture once
+    long_gpu = took[files[0]]
+    assert [took[f] for f in files[1:]] == [1 - long_gpu] * 5
+    assert "1 gatherer(s)" in r.stderr and "2 context(s) opened, 2 closed" in r.stderr
+    for k, (ms, fr) in enumerate([(900, 5), (40, 3), (40, 0), (40, 7), (40, 2), (40, 4)]):
+        name = files[k] + ".frames.txt"
+        if fr == 0:
+            assert not os.path.exists(name)                          # no frame, no file (main.c:508-512)
+        else:
+            assert open(name).read() == expected_text((4000 + 40 * k) // 4, fr)
+    # the run lasts about as long as the long capture, not as long as three waves
+    secs = float(re.search(r"in ([0-9.]+) s", r.stdout).group(1))
+    assert secs < 1.5
+
+
+def test_more_gpus_than_captures_and_a_rate_change(exe, tmp_path):
+    a, b, c = (str(tmp_path / n) for n in ("a.wav", "b.wav", "c.wav"))
+    wav(a, 10, 2)
+    wav(b, 10, 3, rate=50000)
+    wav(c, 10, 1)
+    r, took = run(exe, [a, b, c], 8)
+    assert r.returncode == 0 and len(took) == 3
+    assert "on 3 MI355X GPU(s)" in r.stdout                          # no more workers than captures
+    r, took = run(exe, [a, b, c], 1)                                 # one GPU: its context is re-opened when the rate changes
+    assert r.returncode == 0 and set(took.values()) == {0}
+    assert "3 context(s) opened, 3 closed" in r.stderr
+    for p, n in ((a, 2), (b, 3), (c, 1)):
+        assert open(p + ".frames.txt").read() == expected_text(1000, n)
+
+
+def test_a_bad_capture_costs_only_itself(exe, tmp_path):
+    good, bad, missing = str(tmp_path / "g.wav"), str(tmp_path / "mono.wav"), str(tmp_path / "nothing.wav")
+    wav(good, 10, 4)
+    wav(bad, 10, 4, channels=1)
+    r, took = run(exe, [bad, good, missing], 2)
+    assert r.returncode == 1
+    assert list(took) == [good]
+    assert r.stdout.count("unsupported WAV format") == 2
+    assert open(good + ".frames.txt").read() == expected_text(1000, 4)
+
+
+def test_no_gpu(exe, tmp_path):
+    p = str(tmp_path / "x.wav")
+    wav(p, 1, 1)
+    r, _ = run(exe, [p], 0)
+    assert r.returncode == 1 and "GPU demodulator unavailable" in r.stdout
