@@ -125,7 +125,7 @@ class Oracle:
         L.orc_set_math_mode(math_mode)
         self._L = L
         self.mode = mode
-        self.dtype = np.float64 if mode == ARGOS else np.float32
+        self.dtype = np.float64 if (mode == ARGOS and not chain) else np.float32     # (the ARGOS twin is the float build)
         self._h = L.orc_open(mode, sample_rate, chunk, norm_override, int(keep_stages))
         L.orc_set_sampler.argtypes = [C.c_void_p, C.c_int, C.c_double, C.c_double]
         L.orc_set_sampler.restype = None
@@ -134,7 +134,7 @@ class Oracle:
             L.orc_set_chain.argtypes = [C.c_void_p, C.c_int]
             L.orc_set_chain.restype = C.c_int
             if L.orc_set_chain(self._h, chain) != 0:
-                raise ValueError("the oracle restates the live chain for POES only")
+                raise ValueError("orc_set_chain failed")
         if np.asarray(iq).dtype.kind == "f":                     # RAW float32 capture
             a = np.ascontiguousarray(iq, dtype="<f4").reshape(-1)
             L.orc_run_f32(self._h, a.ctypes.data, a.size // 2)

@@ -21,6 +21,8 @@
  * md5 d3c496d003a29eeee061c01b00ce025c; tests/test_oracle_ref.py checks this
  * harness reproduces it, which pins the restated loop to the real program.
  *
+ * (-DARGOS -DARGOS_FLOAT, linked against libref_argosf.so: the ARGOS sound-card twin's float build of the same loop,
+ *  ARGOSdemodPortAudio/main.c:266-329 -- its buffer order :58-65, its time stamps :285-286, its ByteSync.c)
  * usage: ref_demod{POES,ARGOS} [-c chunk] [-n gain] [-s kHz] [-d dumpprefix] [-M -R r -K k] in.wav out.txt
  *        ref_demod{POES,ARGOS} -B [-c piece] bits.txt out.txt
  *        ref_demodPOES -L -s kHz [-c block] in.raw out.txt        (sound-card twin's composition)
@@ -37,10 +39,10 @@
 #include <strings.h>
 #include <time.h>
 
-#ifdef ARGOS
+#if defined(ARGOS) && !defined(ARGOS_FLOAT)
 #define DECIMAL_TYPE double
 #else
-#define DECIMAL_TYPE float
+#define DECIMAL_TYPE float     /* POES; ARGOS_FLOAT: the ARGOS sound-card twin's build (ARGOSdemodPortAudio/config.h: USE_FLOATS 1) */
 #endif
 #define DT DECIMAL_TYPE
 
@@ -138,6 +140,10 @@ int main(int argc, char **argv)
 #endif
     char *inFileName = malloc(1024);
     DT complex *waveData = malloc(sizeof(DT complex) * chunk);
+#ifdef ARGOS_FLOAT
+    float *waveFrame = malloc(sizeof(float) * chunk * 2);      /* ARGOSdemodPortAudio/main.c:60: between waveData and waveDataTime */
+    (void)waveFrame;
+#endif
     DT *waveDataTime = malloc(sizeof(DT) * chunk);
     DT *dataStreamReal = malloc(sizeof(DT) * chunk);
 #ifdef ARGOS
@@ -219,6 +225,15 @@ int main(int argc, char **argv)
             printf("Normalization Factor: %f\n", normFactor);
         }
         i += nSamples;
+#ifdef ARGOS_FLOAT
+        {   /* the twin stamps its samples itself (ARGOSdemodPortAudio/main.c:285-286): Time += (1/Fs), all float */
+            static DT Time = 0;
+            for (unsigned long q = 0; q < nSamples; q++) {
+                Time += (1 / Fs);
+                waveDataTime[q] = Time;
+            }
+        }
+#endif
         dput(diq, waveData, sizeof(DT complex), nSamples);
         dput(dtime, waveDataTime, sizeof(DT), nSamples);
         t_dsp = now_s();

@@ -338,7 +338,8 @@ class Demodulator:
                      agc_warm, gardner_band_pad, sampler, chain, mm_step_range, mm_kp)
         self._h = C.c_void_p()
         _check(self._L.pdt_open(C.byref(cfg), C.byref(self._h)), "pdt_open")
-        self.dtype = np.float64 if mode == MODE_ARGOS else np.float32
+        self.chain = chain
+        self.dtype = np.float64 if (mode == MODE_ARGOS and not chain) else np.float32      # (the ARGOS twin is the float build)
 
     def close(self):
         if self._h:
@@ -414,7 +415,7 @@ class Demodulator:
         return self
 
     def _dt(self):
-        return np.dtype("<f8") if self.mode == MODE_ARGOS else np.dtype("<f4")
+        return np.dtype("<f8") if (self.mode == MODE_ARGOS and not self.chain) else np.dtype("<f4")
 
     def stage_manchester(self, symbols: np.ndarray, resync_threshold: float, state: "ManchesterState | None" = None):
         """ManchesterDecode on these symbols alone (statics in `state`, updated in place): (bits '0'/'1', symbol index per bit)"""

@@ -649,12 +649,13 @@ uint32_t next_pow2(uint32_t v)
     return p;
 }
 
-SyncParams make_sync_params(bool argos)
+SyncParams make_sync_params(bool argos, bool argos_twin = false)
 {
     SyncParams SP;
     if (argos) {
         SP.pattern = 0x02F0ull;   // "0001011110000"
         SP.len = 13; SP.allow_inverse = 0; SP.span = 56; SP.first_bits = 8; SP.nbytes = 7; SP.prefix = 0;
+        if (argos_twin) SP.allow_inverse = 1;                 // ARGOSdemodPortAudio/ByteSync.c:112: the inverse word is looked for too
     } else {
         SP.pattern = 0x76F10ull;  // "1110110111100010000"
         SP.len = 19; SP.allow_inverse = 1; SP.span = 813; SP.first_bits = 5; SP.nbytes = 102; SP.prefix = 2;
@@ -743,14 +744,17 @@ template <typename T> int run_capture(pdt_ctx *ctx, uint64_t n, int phase = RUN_
     GP.argos_heap = 0;
     GP.argos_field_bits = 0;
     GP.argos_even = 0;
-    if (argos && (size_t)chunk * 8 < 128 * 1024) {                            // Q16, below M_MMAP_THRESHOLD
-        const unsigned long long req = 8ull * (unsigned long long)chunk;
+    if (argos && (size_t)chunk * sizeof(T) < 128 * 1024) {                    // Q16, below M_MMAP_THRESHOLD
+        // (sizeof(T) = 4: the ARGOS sound-card twin, whose buffers are `chunk` floats, ARGOSdemodPortAudio/main.c:61-63)
+        const unsigned long long req = (unsigned long long)sizeof(T) * (unsigned long long)chunk;
+        const unsigned long long csz = (req + 8 + 15) & ~15ull;
         GP.argos_heap = 1;
-        GP.argos_field_bits = ((req + 8 + 15) & ~15ull) | 1ull;
-        GP.argos_even = ((req + 8) % 16) != 0;
+        GP.argos_field_bits = csz | 1ull;
+        GP.argos_even = (int)((csz - 8 - req) / sizeof(T));
     }
+    const bool argos_twin = argos && ctx->cfg.chain == PDT_CHAIN_LIVE;
     const T manch_thr = argos ? (T)0.5 : live ? (T)0.75 : (T)1.0;              // main.c:445 / ARGOS main.c:282 / twin :65,393
-    const SyncParams SP = make_sync_params(argos);
+    const SyncParams SP = make_sync_params(argos, argos_twin);
 
     // ---- block-parallel geometry (any values give the same output; they only move time around)
     const double fs_d = (double)ctx->cfg.sample_rate;
@@ -1732,6 +1736,7 @@ template <typename T> int run_capture(pdt_ctx *ctx, uint64_t n, int phase = RUN_
     // time stamp of the bit whose symbol was taken at global interpolated-sample index g, in a capture of n_all samples
     // 
     auto frame_time = [&](long long g, long long n_all) -> double {
+        if (argos && sizeof(T) == 4) return (double)ctx->axis_f.at((uint64_t)g + 1);     // the twin: float stamps (pdt_open)
         if (argos) return ctx->axis_d.at((uint64_t)g + 1);                   // waveDataTime[i] = (i+1)-th partial sum
         const long long c = g / chunk_out, rr = g % chunk_out;
         const long long j = rr / interp + 1;                                  // Q2: time of the *next* input sample
@@ -1809,7 +1814,7 @@ template <typename T> int run_capture(pdt_ctx *ctx, uint64_t n, int phase = RUN_
             pdt_frame o;
             memset(&o, 0, sizeof o);
             o.bit_index = r.bit_index + (long long)seg->bit_base;
-            o.inverted = r.inverted;
+            o.inverted = argos ? 0 : r.inverted;      // (the ARGOS twin re-inverts such a packet's bits but stamps it like any other)
             o.nbytes = r.nbytes;
             o.complete = r.complete;
             memcpy(o.bytes, r.bytes, 104);
@@ -1904,7 +1909,7 @@ template <typename T> int run_capture(pdt_ctx *ctx, uint64_t n, int phase = RUN_
         memset(&o, 0, sizeof o);
         o.bit_index = r.bit_index;
         o.time_src = r.time_src;
-        o.inverted = r.inverted;
+        o.inverted = argos ? 0 : r.inverted;          // ARGOSdemodPortAudio/ByteSync.c:128: "%.5f " for the inverse word as well
         o.nbytes = r.nbytes;
         o.complete = r.complete;
         memcpy(o.bytes, r.bytes, 104);
@@ -2219,8 +2224,8 @@ int pdt_open(const pdt_config *cfg, pdt_ctx **out)
     if (cfg->mode != PDT_MODE_POES && cfg->mode != PDT_MODE_ARGOS) return PDT_ERR_ARG;
     if (!cfg->sample_rate) return PDT_ERR_ARG;
     if (cfg->chain != PDT_CHAIN_FILE && cfg->chain != PDT_CHAIN_LIVE) return PDT_ERR_ARG;
-    // the ARGOS twin is the float build of the ARGOS chain (ARGOSdemodPortAudio/config.h): not provided
-    if (cfg->chain == PDT_CHAIN_LIVE && cfg->mode == PDT_MODE_ARGOS) return PDT_ERR_ARG;
+    // (ARGOS + PDT_CHAIN_LIVE = the ARGOS sound-card twin: the FLOAT build of the ARGOS chain, ARGOSdemodPortAudio/config.h;
+    // round 4)
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) {
         (void)hipGetLastError();
@@ -2236,13 +2241,17 @@ int pdt_open(const pdt_config *cfg, pdt_ctx **out)
     if (ctx->tune.pll_warm_s > 0 && !ctx->cfg.pll_warm) ctx->cfg.pll_warm = (uint32_t)(ctx->tune.pll_warm_s * cfg->sample_rate);
     if (ctx->tune.agc_warm_s > 0 && !ctx->cfg.agc_warm) ctx->cfg.agc_warm = (uint32_t)(ctx->tune.agc_warm_s * cfg->sample_rate);
     if (!ctx->cfg.chunk) ctx->cfg.chunk = (cfg->mode == PDT_MODE_ARGOS || cfg->chain == PDT_CHAIN_LIVE) ? 2400 : 10000;
-    ctx->elem = cfg->mode == PDT_MODE_ARGOS ? 8 : 4;
+    const bool argos_twin = cfg->mode == PDT_MODE_ARGOS && cfg->chain == PDT_CHAIN_LIVE;
+    ctx->elem = (cfg->mode == PDT_MODE_ARGOS && !argos_twin) ? 8 : 4;
     int nt = 0, ip = 0;
     int rc = pdt_make_lpf(cfg->mode, cfg->sample_rate, nullptr, &nt, &ip);
     if (rc) { pdt_close(ctx); return rc; }
     ctx->interp = (uint32_t)ip;
     ctx->ntaps = (uint32_t)nt;
     ctx->taps_host.resize((size_t)nt * ctx->elem);
+    if (argos_twin)           // MakeLPFIR(filterCoeffs, 50, 700, Fs, 1) in float (ARGOSdemodPortAudio/main.c:264)
+        make_lpf<float>((float *)ctx->taps_host.data(), 50, (float)700, (float)cfg->sample_rate, 1);
+    else
     pdt_make_lpf(cfg->mode, cfg->sample_rate, ctx->taps_host.data(), nullptr, nullptr);
     if ((rc = ctx->taps.ensure(ctx->taps_host.size()))) { pdt_close(ctx); return rc; }
     if (hipMemcpy(ctx->taps.p, ctx->taps_host.data(), ctx->taps_host.size(), hipMemcpyHostToDevice) != hipSuccess) {
@@ -2291,6 +2300,7 @@ int pdt_open(const pdt_config *cfg, pdt_ctx **out)
     memset(&ctx->stats, 0, sizeof ctx->stats);
     memset(ctx->stage_len, 0, sizeof ctx->stage_len);
     ctx->axis_f.init((float)(1.0 / (double)(float)cfg->sample_rate));        // wave.c:96-97
+    if (argos_twin) ctx->axis_f.init(1 / (float)cfg->sample_rate);           // "Time += (1/Fs)", all float (ARGOSdemodPortAudio/main.c:285)
     ctx->axis_d.init(1.0 / (double)cfg->sample_rate);
     ctx->counted = true;
     g_open_contexts.fetch_add(1);
@@ -2377,8 +2387,9 @@ uint64_t pdt_chunk_reports(const pdt_ctx *ctx, pdt_chunk_report *out, uint64_t m
         while (f < ctx->frames_host.size() && (uint64_t)ctx->frames_host[f].bit_index < ci.bits_upto) { o.frames++; f++; }
         // waveDataTime[0] as the progress line prints it: POES keeps the input time axis apart (main.c:424,438,445), ARGOS
         // compacts the symbol and bit times into it (ARGOSdemod/main.c:278,282)
-        o.time0 = argos ? const_cast<pdt_ctx *>(ctx)->axis_d.at((uint64_t)ci.t0_src + 1)
-                        : (double)const_cast<pdt_ctx *>(ctx)->axis_f.at(c * chunk + 1);
+        o.time0 = (argos && ctx->elem == 8) ? const_cast<pdt_ctx *>(ctx)->axis_d.at((uint64_t)ci.t0_src + 1)
+                  : argos ? (double)const_cast<pdt_ctx *>(ctx)->axis_f.at((uint64_t)ci.t0_src + 1)
+                          : (double)const_cast<pdt_ctx *>(ctx)->axis_f.at(c * chunk + 1);
         sym_prev = ci.sym_upto;
         bits_prev = ci.bits_upto;
     }
@@ -2406,8 +2417,8 @@ static int demod_common(pdt_ctx *ctx, uint64_t nframes, int phase = RUN_ALL)
     HIP_TRY(hipSetDevice(ctx->cfg.device));
     ctx->n_samples = nframes;
     ctx->n_out = nframes * ctx->interp;
-    if (ctx->cfg.mode == PDT_MODE_ARGOS) return run_capture<double>(ctx, nframes, phase);
-    return run_capture<float>(ctx, nframes, phase);
+    if (ctx->elem == 8) return run_capture<double>(ctx, nframes, phase);
+    return run_capture<float>(ctx, nframes, phase);                 // POES, both twins
 }
 
 int pdt_demod_pcm16(pdt_ctx *ctx, const int16_t *iq_host, uint64_t nframes)
@@ -2442,7 +2453,7 @@ static bool overlap_ingest(const pdt_ctx *ctx, uint64_t nframes, size_t fb)
 int pdt_demod_fd(pdt_ctx *ctx, int fd, uint64_t byte_offset, uint64_t nframes, int sample_format)
 {
     if (!ctx || fd < 0 || (sample_format != PDT_FMT_PCM16 && sample_format != PDT_FMT_F32)) return PDT_ERR_ARG;
-    if (sample_format == PDT_FMT_F32 && ctx->cfg.mode != PDT_MODE_POES) return PDT_ERR_FORMAT;   // ARGOSdemod/main.c:238-241
+    if (sample_format == PDT_FMT_F32 && ctx->elem != 4) return PDT_ERR_FORMAT;   // ARGOSdemod/main.c:238-241
     HIP_TRY(hipSetDevice(ctx->cfg.device));
     const size_t fb = sample_format == PDT_FMT_F32 ? 8 : 4;
     IngestSrc src;
@@ -2471,7 +2482,7 @@ int pdt_demod_f32(pdt_ctx *ctx, const float *iq_host, uint64_t nframes)
 {
     if (!ctx || (!iq_host && nframes)) return PDT_ERR_ARG;
     if (ctx->stream_open) return PDT_ERR_STATE;                      // pdt_stream_end / pdt_stream_begin first
-    if (ctx->cfg.mode != PDT_MODE_POES) return PDT_ERR_FORMAT;       // ARGOSdemod/main.c:238-241: "RAW files not yet supported"
+    if (ctx->elem != 4) return PDT_ERR_FORMAT;       // ARGOSdemod/main.c:238-241: "RAW files not yet supported"
     HIP_TRY(hipSetDevice(ctx->cfg.device));
     int rc = ctx->pcm.ensure((size_t)nframes * 8 + 16);
     if (rc) return rc;
@@ -2487,7 +2498,7 @@ int pdt_demod_device_f32(pdt_ctx *ctx, const void *iq_device, uint64_t nframes)
 {
     if (!ctx || (!iq_device && nframes)) return PDT_ERR_ARG;
     if (ctx->stream_open) return PDT_ERR_STATE;                      // pdt_stream_end / pdt_stream_begin first
-    if (ctx->cfg.mode != PDT_MODE_POES) return PDT_ERR_FORMAT;
+    if (ctx->elem != 4) return PDT_ERR_FORMAT;
     ctx->pcm_dev = iq_device;
     ctx->pcm_fmt = 1;
     return demod_common(ctx, nframes);
@@ -3359,7 +3370,7 @@ static int demod_overlapped(pdt_ctx *ctx, const IngestSrc &src, uint64_t nframes
 static int stream_push(pdt_ctx *ctx, const void *host, uint64_t nframes, int fmt, uint64_t *new_frames)
 {
     if (!ctx || (!host && nframes)) return PDT_ERR_ARG;
-    if (fmt == 1 && ctx->cfg.mode != PDT_MODE_POES) return PDT_ERR_FORMAT;
+    if (fmt == 1 && ctx->elem != 4) return PDT_ERR_FORMAT;
     if (!ctx->stream_open) {                         // the first push opens a stream (as if pdt_stream_begin had been called)
         int rb = pdt_stream_begin(ctx);
         if (rb) return rb;

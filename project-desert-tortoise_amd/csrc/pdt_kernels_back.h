@@ -30,7 +30,7 @@ template <typename T> struct GardnerParams {
     long long chunk_out;     // reference chunk size in interpolated samples (chunk * interp)
     int argos_heap;          // 1 = reproduce the ARGOS heap adjacency (Q16) for reads past the chunk
     unsigned long long argos_field_bits;   // malloc size field seen as a double
-    int argos_even;          // chunk even -> one 8-byte slack double before the size field
+    int argos_even;          // elements of malloc slack in front of that field (8-byte buffers: 1 when the chunk is even, else 0)
 };
 
 // value the reference would read at chunk-relative index idx >= n_cur of chunk c (Q3/Q16)
@@ -43,15 +43,17 @@ __device__ __forceinline__ T gardner_beyond(const T *__restrict__ in, const T *_
         return (c >= 1) ? in[(c - 1) * C + idx] : (T)0;
     if (!P.argos_heap) return (T)0;                // POES: over-allocated, never written -> zero pages
     long long k = idx - C;
-    if (P.argos_even) {
-        if (k == 0) return (T)0;
+    if (k < P.argos_even) return (T)0;             // malloc slack in front of the next chunk's size field (elements: 0 / 1 for
+    k -= P.argos_even;                             // 8-byte buffers, 0 .. 3 for the float build's 4-byte ones)
+    if (sizeof(T) == 8) {
+        if (k == 0) return (T)__longlong_as_double((long long)P.argos_field_bits);
         k -= 1;
+    } else {                                       // float build (the ARGOS sound-card twin): the 8-byte field is two elements
+        if (k == 0) return (T)__uint_as_float((unsigned)(P.argos_field_bits & 0xffffffffull));
+        if (k == 1) return (T)__uint_as_float((unsigned)(P.argos_field_bits >> 32));
+        k -= 2;
     }
-    if (k == 0) {
-        if (sizeof(T) == 8) return (T)__longlong_as_double((long long)P.argos_field_bits);
-        return (T)0;
-    }
-    k -= 1;                                        // index into the lock-signal array of the current chunk
+    // index into the lock-signal array of the current chunk
     if (k < n_cur) return lock[c * C + k];
     if (k < C) return (c >= 1) ? lock[(c - 1) * C + k] : (T)0;
     return (T)0;

@@ -43,7 +43,7 @@
 #ifdef PDT_ARGOS
 #define MODE PDT_MODE_ARGOS
 #define DEFAULT_CHUNKSIZE 2400
-#define OPTS "rn:c:o:d:mP"
+#define OPTS "s:rn:c:o:d:mlP"      /* -l (round 4): the sound-card twin's chain, -s its rate in kHz when the samples come from a pipe */
 #define BANNER "Project Desert Tortoise: Wave file ARGOS Demodulator (MI355X build)\n"
 #define PREFIX "packets"
 #define UNIT "Packets"
@@ -127,7 +127,6 @@ static const char *get_filename_ext(const char *filename)
     return dot + 1;
 }
 
-#ifndef PDT_ARGOS
 static void put_frames(FILE *out, const pdt_frame *f, uint64_t n)
 {
     for (uint64_t k = 0; k < n; k++) {                                /* POESTIPdemod/ByteSync.c:62-69,96-101 */
@@ -138,7 +137,7 @@ static void put_frames(FILE *out, const pdt_frame *f, uint64_t n)
     fflush(out);
 }
 
-/* The twin's loop (POESTIPdemodPortAudio/main.c:324-393) with standard input as the sound card: blocks of `chunk`
+/* The twin's loop (POESTIPdemodPortAudio/main.c:324-393, ARGOSdemodPortAudio/main.c:266-329) with standard input as the sound card: blocks of `chunk`
  * float32 I,Q frames until end of file (there: until a key is hit); frames are appended as they become final. */
 static int live_loop(FILE *in, FILE *out, const char *outFileName, double sampleRate, unsigned long chunk, double normFactor,
                      int device, int sampler)
@@ -146,7 +145,11 @@ static int live_loop(FILE *in, FILE *out, const char *outFileName, double sample
     if (sampleRate < 1) sampleRate = 48.0;                            /* twin: SAMPLE_RATE 48000 (main.c:27) */
     pdt_config cfg;
     memset(&cfg, 0, sizeof cfg);
+#ifdef PDT_ARGOS
+    cfg.mode = PDT_MODE_ARGOS;                                        /* + PDT_CHAIN_LIVE: the float build of the ARGOS chain */
+#else
     cfg.mode = PDT_MODE_POES;
+#endif
     cfg.sample_rate = (uint32_t)(sampleRate * 1000.0);
     cfg.chunk = chunk;
     cfg.norm_override = normFactor;
@@ -203,7 +206,6 @@ static int live_loop(FILE *in, FILE *out, const char *outFileName, double sample
     pdt_close(ctx);
     return 0;
 }
-#endif
 
 int main(int argc, char **argv)
 {
@@ -298,9 +300,7 @@ int main(int argc, char **argv)
         fclose(raw);
     }
 
-#ifndef PDT_ARGOS
     if (from_stdin) return live_loop(in, out, outFileName, sampleRate, chunkSize, normFactor, device, sampler);
-#endif
     int is_raw = 0;
     if (strcasecmp(get_filename_ext(inFileName), "wav") != 0) {
 #ifdef PDT_ARGOS

@@ -205,3 +205,24 @@ def test_progress_golden_synthetic(pdt, tmp_path):
     _, dump = run_ref(REF_ARGOS, wav, tmp_path)
     assert open(f"{dump}.progress", "rb").read() == open(os.path.join(GOLDEN, "argos_32000.progress"), "rb").read()
     assert open(f"{dump}.avg", "rb").read() == open(os.path.join(GOLDEN, "argos_32000.avg.f64"), "rb").read()
+
+
+REF_ARGOSF = os.path.join(ROOT, "oracle/_ref/ref_demodARGOSf")
+
+
+@pytest.mark.skipif(not os.path.exists(REF_ARGOSF), reason="oracle/_ref/ref_demodARGOSf not built")
+@pytest.mark.parametrize("fs,chunk,seed,f0,secs", [(48000, 2400, 21, 130.0, 9.0), (48000, 2401, 22, -75.0, 8.0), (48000, 2403, 24, 40.0, 8.0),
+                                                   (32000, 1000, 23, 160.0, 7.0), (48000, 2402, 25, 99.0, 8.0)])
+def test_argos_sound_card_twin_all_stages(orc, pdt, tmp_path, fs, chunk, seed, f0, secs):
+    """The ARGOS sound-card twin (ARGOSdemodPortAudio/main.c:266-329): the FLOAT build of the ARGOS chain's stage functions
+    (its config.h), its own ByteSync.c (inverse sync word enabled, no "i" on the stamp), its own time stamps and buffer order.
+    The restatement (chain = 1) equals those objects at every stage, the reads past the block included: chunk sizes whose
+    4-byte buffers leave 0, 1, 2 and 3 floats of malloc slack in front of the next chunk's size field."""
+    iq = pdt.synth_capture(1, fs, secs, f0_hz=f0, seed=seed)
+    wav = tmp_path / "a.wav"
+    pdt.write_wav(str(wav), fs, iq)
+    text, dump = run_ref(REF_ARGOSF, wav, tmp_path, ["-c", str(chunk)])
+    o = orc.Oracle(orc.ARGOS, fs, iq, chunk=chunk, chain=1)
+    assert o.dtype == np.float32
+    compare_all(o, dump)
+    assert o.text() == text and len(text) > 0
