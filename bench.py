@@ -263,10 +263,26 @@ def pmc_traffic(cfg: str, kernel: str, build: str):
 HBM_STREAM_GBS = 5800.0     # what streaming kernels reach on this chip (k_pll_theta, the AGC walkers: 5.8 - 6.0 TB/s of 8)
 
 
-def roofline_bound(ms: float, traffic, alg_bytes: int) -> str:
-    """What holds the dominant kernel up, from the evidence at hand: "hbm" when the bytes it moves (counter traffic of this
-    build if committed, its algorithmic bytes otherwise) take more than half its time at the rate streaming kernels reach
-    here, "latency" otherwise (a serial float recurrence on lone wavefronts: its time is a walk length x the step's pace)."""
+def sq_valu_active(cfg: str, kernel: str, build: str):
+    """Fraction of the kernel's wave cycles in which its wavefronts issue vector-ALU instructions, from the committed SQ counter
+    pass of this build (profiles/r4/sq_counters_bench_<cfg>.json: SQ_ACTIVE_INST_VALU / SQ_WAVE_CYCLES), or None."""
+    try:
+        doc = json.load(open(os.path.join(ROOT, "profiles", "r4", f"sq_counters_bench_{cfg}.json")))
+        if doc.get("build") != build:
+            return None
+        v = doc["kernels"][kernel]
+        return v["SQ_ACTIVE_INST_VALU"] / v["SQ_WAVE_CYCLES"]
+    except (OSError, ValueError, KeyError, ZeroDivisionError):
+        return None
+
+
+def roofline_bound(ms: float, traffic, alg_bytes: int, valu_active=None) -> str:
+    """What holds the dominant kernel up, from the evidence at hand: "issue" when the committed SQ pass of this build shows its
+    wavefronts issuing vector instructions in more than 60 % of their cycles (lone wavefronts per SIMD: the instruction count
+    of the serial step is the time); "hbm" when the bytes it moves (counter traffic of this build if committed, its algorithmic
+    bytes otherwise) take more than half its time at the rate streaming kernels reach here; "latency" otherwise."""
+    if valu_active is not None and valu_active >= 0.6:
+        return "issue"
     moved = traffic if traffic else alg_bytes
     if not ms or not moved:
         return "latency"
@@ -458,7 +474,8 @@ def run(args, pdt, torch, dist, rank, local, world, dev, cdev, cfg, kind, fs, se
                        "samples_per_gpu": n * ncap, "captures": world * ncap,
                        "parallelism": f"{ncap} capture(s) per GPU x{world}"
                                       + (" (batched many-capture mode: one launch per stage for all captures, same capture in every slot)" if ncap > 1 else "")},
-            "roofline": {"bound": roofline_bound(stages[dom]["ms"], traffic, stages[dom]["alg_bytes"]), "kernel": dom_kernel, "group": dom,
+            "roofline": {"bound": roofline_bound(stages[dom]["ms"], traffic, stages[dom]["alg_bytes"], sq_valu_active(cfg, dom_kernel, build_tag) if ncap == 1 else None),
+                         "valu_active": sq_valu_active(cfg, dom_kernel, build_tag) if ncap == 1 else None, "kernel": dom_kernel, "group": dom,
                          "achieved": stages[dom]["GBps"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": stages[dom]["frac_hbm"], "traffic": traffic,
                          "alg_bytes": stages[dom]["alg_bytes"], "ms": stages[dom]["ms"],
