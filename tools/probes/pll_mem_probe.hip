@@ -35,6 +35,22 @@ __global__ void __launch_bounds__(256) k_full(IqSrc pcm, const float *__restrict
     if ((threadIdx.x & 63) == 0) clk[blockIdx.x * 4 + (threadIdx.x >> 6)] = wall_clock64() - c0;
 }
 
+// a theta stream like a locked PM signal's: carrier at w rad/sample, +-0.6 rad of Manchester-like modulation, a little noise
+__global__ void fill_pm(float *x, long long n, long long B, float w)
+{
+    long long i = blockIdx.x * 256ll + threadIdx.x;
+    for (; i < n; i += (long long)gridDim.x * 256) {
+        // natural index of LT element i: tile, row, lane, element
+        const long long tile = i / (64 * B), r = i % (64 * B), row = r / 256, lane = (r % 256) / 4, e = r % 4;
+        const long long nat = (tile * 64 + lane) * B + row * 4 + e;
+        unsigned h = (unsigned)(nat * 2654435761u) ^ (unsigned)(nat >> 13);
+        h ^= h >> 15; h *= 0x2c1b3c6du; h ^= h >> 12;
+        double ph = (double)w * (double)nat + (((nat / 15) & 1) ? 0.6 : -0.6) + ((double)(h & 0xffff) / 65536.0 - 0.5) * 0.2;
+        ph = ph - 6.283185307179586 * floor(ph / 6.283185307179586 + 0.5);
+        x[i] = (float)ph;
+    }
+}
+
 template <bool RING, bool MEM, bool STORE>
 __global__ void __launch_bounds__(256) k_probe(const float *__restrict__ theta, float *__restrict__ phi, long long n, long long B, long long W,
                                                float *__restrict__ gout, unsigned long long *__restrict__ clk)
@@ -131,6 +147,24 @@ int main()
             unsigned long long mn = ~0ull, mx = 0; for (int i = 0; i < 176 * 4; i++) { if (h[i] < mn) mn = h[i]; if (h[i] > mx) mx = h[i]; }
             printf("the library's k_pll_phase body, tracking warm-up %6d: %7.3f ms; wavefronts take %.3f .. %.3f ms  (%s)\n", wt, best, mn * 1e-5, mx * 1e-5, hipGetErrorString(hipGetLastError()));
         }
+    }
+    {
+        hipLaunchKernelGGL(fill_pm, dim3(4096), dim3(256), 0, 0, theta, n + slack, B, 0.02f);
+        (void)hipDeviceSynchronize();
+        void *pcm; unsigned *done; PllSeam<float> *seams;
+        (void)hipMalloc(&pcm, (n + slack) * 4); (void)hipMemset(pcm, 0x11, (n + slack) * 4);
+        (void)hipMalloc(&done, 64); (void)hipMalloc(&seams, sizeof(PllSeam<float>) * (n / B + 4096));
+        IqSrc src; src.p = pcm; src.fmt = 0;
+        hipEvent_t a, b; (void)hipEventCreate(&a); (void)hipEventCreate(&b);
+        float best = 1e9f;
+        for (int r = 0; r < 3; r++) {
+            (void)hipEventRecord(a);
+            hipLaunchKernelGGL(k_full, dim3(177), dim3(256), 0, 0, src, theta, phi, n, B, 5000ll, 99328ll, seams, done, 0, clk);
+            (void)hipEventRecord(b); (void)hipEventSynchronize(b);
+            float ms; (void)hipEventElapsedTime(&ms, a, b); if (ms < best) best = ms;
+        }
+        printf("the library's k_pll_phase body on a PM-like theta stream (the loop locks), warm-up 99328: %7.3f ms\n", best);
+        run<true, true, true>("LDS ring on the PM-like stream", theta, phi, n, B, W, groups, g, clk);
     }
     run<false, false, false>("no memory, 64 groups", theta, phi, n, B, W, 64, g, clk);
     run<true, true, true>("LDS ring, 64 groups (a third of the lanes)", theta, phi, n, B, W, 64, g, clk);
