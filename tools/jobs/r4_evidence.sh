@@ -9,6 +9,7 @@ OUT=$R/gpurun_out/$TAG
 rm -rf $OUT; mkdir -p $OUT
 ( time timeout 1500 python -m pytest tests -m gpu -q ) > $OUT/pytest_gpu.log 2>&1; tail -4 $OUT/pytest_gpu.log
 timeout 1500 python tests/tools/fuzz.py 300 $SEED > $OUT/fuzz_300_seed$SEED.log 2>&1; tail -2 $OUT/fuzz_300_seed$SEED.log
+timeout 900 python tests/tools/fuzz_live.py 200 $((SEED + 100)) > $OUT/fuzz_live_200_seed$((SEED + 100)).log 2>&1; tail -1 $OUT/fuzz_live_200_seed$((SEED + 100)).log
 ( time timeout 1500 python bench.py --gpus 1 --steps 20 --warmup 5 ) > $OUT/bench_default_1gpu.json 2> $OUT/bench_default.err; tail -2 $OUT/bench_default.err
 for cfg in c2 argos aos weak; do
   timeout 900 python bench.py --config $cfg --steps 10 --warmup 3 --no-secondary > $OUT/bench_${cfg}_1gpu.json 2> $OUT/bench_$cfg.err; echo "$cfg rc=$?"
