@@ -35,6 +35,14 @@ __global__ void __launch_bounds__(256) k_full(IqSrc pcm, const float *__restrict
     if ((threadIdx.x & 63) == 0) clk[blockIdx.x * 4 + (threadIdx.x >> 6)] = wall_clock64() - c0;
 }
 
+__global__ void spin_long(uint64_t *c)
+{
+    asm volatile("" ::: "v255", "a255");
+    float g = 1.f;
+    for (int i = 0; i < 3000000; i++) asm volatile("v_mul_f32 %0, %0, %0" : "+v"(g));     // ~11 ms
+    c[0] = (uint64_t)g;
+}
+
 // a theta stream like a locked PM signal's: carrier at w rad/sample, +-0.6 rad of Manchester-like modulation, a little noise
 __global__ void fill_pm(float *x, long long n, long long B, float w)
 {
@@ -164,6 +172,44 @@ int main()
             float ms; (void)hipEventElapsedTime(&ms, a, b); if (ms < best) best = ms;
         }
         printf("the library's k_pll_phase body on a PM-like theta stream (the loop locks), warm-up 99328: %7.3f ms\n", best);
+        // ... and right behind a kernel that has just written the whole theta stream (as k_pll_theta has in the chain), and
+        // after a run of back-to-back launches without a pause (sustained clocks)
+        best = 1e9f;
+        float worst = 0;
+        for (int r = 0; r < 6; r++) {
+            hipLaunchKernelGGL(fill_pm, dim3(4096), dim3(256), 0, 0, theta, n + slack, B, 0.02f);
+            (void)hipEventRecord(a);
+            hipLaunchKernelGGL(k_full, dim3(177), dim3(256), 0, 0, src, theta, phi, n, B, 5000ll, 99328ll, seams, done, 0, clk);
+            (void)hipEventRecord(b);
+            hipLaunchKernelGGL(fill_pm, dim3(4096), dim3(256), 0, 0, phi, n + slack, B, 0.01f);     // (keep the chip busy behind it too)
+            (void)hipEventSynchronize(b);
+            float ms; (void)hipEventElapsedTime(&ms, a, b); if (ms < best) best = ms; if (ms > worst) worst = ms;
+        }
+        (void)hipDeviceSynchronize();
+        printf("the same, launched right behind a kernel that rewrites theta, six times without a pause: %7.3f .. %7.3f ms\n", best, worst);
+        // ... on a stream of the highest priority (the library's side stream), alone and beside a lone spinning wavefront on another
+        // stream (as the head walker is in the chain)
+        {
+            int least = 0, greatest = 0;
+            (void)hipDeviceGetStreamPriorityRange(&least, &greatest);
+            hipStream_t hi, lo;
+            (void)hipStreamCreateWithPriority(&hi, hipStreamNonBlocking, greatest);
+            (void)hipStreamCreateWithFlags(&lo, hipStreamNonBlocking);
+            uint64_t *sc; (void)hipMalloc(&sc, 64);
+            for (int beside = 0; beside < 2; beside++) {
+                best = 1e9f;
+                for (int r = 0; r < 3; r++) {
+                    (void)hipDeviceSynchronize();
+                    if (beside) hipLaunchKernelGGL(spin_long, dim3(1), dim3(64), 0, lo, sc);
+                    (void)hipEventRecord(a, hi);
+                    hipLaunchKernelGGL(k_full, dim3(177), dim3(256), 0, hi, src, theta, phi, n, B, 5000ll, 99328ll, seams, done, 0, clk);
+                    (void)hipEventRecord(b, hi); (void)hipEventSynchronize(b);
+                    float ms; (void)hipEventElapsedTime(&ms, a, b); if (ms < best) best = ms;
+                }
+                (void)hipDeviceSynchronize();
+                printf("the same on a stream of priority %d%s: %7.3f ms\n", greatest, beside ? ", a lone wavefront spinning on another stream" : "", best);
+            }
+        }
         run<true, true, true>("LDS ring on the PM-like stream", theta, phi, n, B, W, groups, g, clk);
     }
     run<false, false, false>("no memory, 64 groups", theta, phi, n, B, W, 64, g, clk);
