@@ -100,8 +100,7 @@ struct DevScalars {
                             //                        [2] chunks the chain had to walk, [3] unused
     double norm;            // storage for the normalisation factor (float or double)
     long long agc_first_bad; // first AGC seam that does not close (k_agc_scan -> k_agc_fix)
-    unsigned phase_groups_done;  // workgroups of k_pll_phase that have finished (a hint for k_pll_head: walk on while they run)
-    unsigned pad1_;
+    PllPhaseHint phase_hint;     // k_pll_phase -> k_pll_head: workgroups finished, the clock at its start (walk on while it runs)
 };
 
 // ---------------------------------------------------------------- launch plans
@@ -244,7 +243,7 @@ struct Plan {
 struct Tuning {
     double band_pad = 0.0, pll_warm_scale = 1.0, head_taus = 0.0, agc_k = 0.0, pll_warm_s = 0.0, agc_warm_s = 0.0;
     int scout_syms = 0, gspan = 0, gspan_cap = 0, mf_waves = 8, ingest_threads = 0, ingest_span_mb = 0, ingest_streams = 0, overlap_segments = 0, overlap_min_mb = 0, fir_wg_per_cu = 0, agc_tpb = 0, gseg = 0, acquire_mode = 0, pll_block = 0, fix_passes = 2;      // acquire_mode: 0 = two-wavefront pipeline, 1 = plain one-lane, 2 = one wavefront
-    bool fir_generic = false, mix_unfused = false, quality_inline = false, gemit_groups = false, agc_unfused = false, no_excl = false, gtab_nomerge = false, gardner_onebuf = false, gardner_noring = false, gardner_sequential = false, seg_sequential = false, agc_lanes = false, overlap = false, debug_overlap = false, chain_one_range = false, ema_noguess = false, debug_sync = false;
+    bool fir_generic = false, mix_unfused = false, quality_inline = false, gemit_groups = false, agc_unfused = false, no_excl = false, gtab_nomerge = false, gardner_onebuf = false, gardner_noring = false, gardner_sequential = false, seg_sequential = false, agc_lanes = false, overlap = false, debug_overlap = false, chain_one_range = false, ema_noguess = false, debug_sync = false, pll_noshort = false;
     void load()
     {
         if (const char *e = getenv("PDT_PLL_WARM_SCALE")) pll_warm_scale = atof(e);
@@ -286,6 +285,7 @@ struct Tuning {
         if (const char *e = getenv("PDT_OVERLAP_SEGMENTS")) overlap_segments = std::min(64, std::max(1, atoi(e)));
         if (const char *e = getenv("PDT_OVERLAP_MIN_MB")) overlap_min_mb = std::min(1 << 20, std::max(1, atoi(e)));
         debug_sync = getenv("PDT_DEBUG_SYNC") != nullptr;
+        pll_noshort = getenv("PDT_PLL_NOSHORT") != nullptr;
     }
 };
 
@@ -998,6 +998,9 @@ template <typename T> int run_capture(pdt_ctx *ctx, uint64_t n, int phase = RUN_
     // walkers are balanced over the SIMDs by construction (single-wavefront groups piled up on some SIMDs once there were
     // more than ~1000 of them: 250 ksps hour-long captures, batches)
     const long long grid_pll = (nb_pll + 255) / 256;
+    // one more workgroup for the walkers whose warm-up begins at sample 0 (k_pll_phase), when they fit into a wavefront
+    const int short_group = ((Wp + Bp - 1) / Bp <= 64 && nb_pll > 64 && !ctx->tune.pll_noshort) ? (int)grid_pll : -1;
+    const long long phase_groups = grid_pll + (short_group >= 0 ? 1 : 0);
     // a single +-2pi correction per step is exact as long as one step cannot move the phase by 2pi
     const double worst = (double)PP.max_freq + M_PI * std::max({(double)PP.alpha_acq + (double)PP.beta_acq,
                                                                 (double)PP.alpha_trk + (double)PP.beta_trk,
@@ -1007,11 +1010,11 @@ template <typename T> int run_capture(pdt_ctx *ctx, uint64_t n, int phase = RUN_
         PL.simple(OP_FORK);
         L.begin("pll_phase", ctx->stream2);
         if (slow_wrap)
-            PDT_LAUNCH(256, (k_pll_phase<T, true>), dim3((unsigned)grid_pll), dim3(256), 0, ctx->stream2, d_pcm, d_theta, N, PP, Bp,
-                               Wacq, Wp, lag, d_phi, (PllSeam<T> *)ctx->seams_pll.p, &d_sc->phase_groups_done);
+            PDT_LAUNCH(256, (k_pll_phase<T, true>), dim3((unsigned)phase_groups), dim3(256), 0, ctx->stream2, d_pcm, d_theta, N, PP, Bp,
+                               Wacq, Wp, lag, d_phi, (PllSeam<T> *)ctx->seams_pll.p, &d_sc->phase_hint, short_group);
         else
-            PDT_LAUNCH(256, (k_pll_phase<T, false>), dim3((unsigned)grid_pll), dim3(256), 0, ctx->stream2, d_pcm, d_theta, N, PP, Bp,
-                               Wacq, Wp, lag, d_phi, (PllSeam<T> *)ctx->seams_pll.p, &d_sc->phase_groups_done);
+            PDT_LAUNCH(256, (k_pll_phase<T, false>), dim3((unsigned)phase_groups), dim3(256), 0, ctx->stream2, d_pcm, d_theta, N, PP, Bp,
+                               Wacq, Wp, lag, d_phi, (PllSeam<T> *)ctx->seams_pll.p, &d_sc->phase_hint, short_group);
         L.end();
         PL.simple(OP_JOIN_RECORD);
     }
@@ -1100,13 +1103,16 @@ template <typename T> int run_capture(pdt_ctx *ctx, uint64_t n, int phase = RUN_
         L.begin("pll_head");
         if (slow_wrap)
             PDT_LAUNCH(64, (k_pll_head<T, true>), dim3(1), dim3(64), 0, st, d_theta, N, PP, d_info, Bp, Hd, d_hphi, d_hseams,
-                               d_hinfo, head_blocks, Hd_max, (const unsigned *)&d_sc->phase_groups_done, (unsigned)grid_pll);
+                               d_hinfo, head_blocks, Hd_max, (const PllPhaseHint *)&d_sc->phase_hint, (unsigned)phase_groups,
+                               ((Wacq / 4 + 3) & ~3ll) + Wacq + Wp + Bp);
         else if (serial_excl)
             PDT_LAUNCH(64, (k_pll_head<T, false, true>), dim3(1), dim3(64), 0, st, d_theta, N, PP, d_info, Bp, Hd, d_hphi, d_hseams,
-                               d_hinfo, head_blocks, Hd_max, (const unsigned *)&d_sc->phase_groups_done, (unsigned)grid_pll);
+                               d_hinfo, head_blocks, Hd_max, (const PllPhaseHint *)&d_sc->phase_hint, (unsigned)phase_groups,
+                               ((Wacq / 4 + 3) & ~3ll) + Wacq + Wp + Bp);
         else
             PDT_LAUNCH(64, (k_pll_head<T, false>), dim3(1), dim3(64), 0, st, d_theta, N, PP, d_info, Bp, Hd, d_hphi, d_hseams,
-                               d_hinfo, head_blocks, Hd_max, (const unsigned *)&d_sc->phase_groups_done, (unsigned)grid_pll);
+                               d_hinfo, head_blocks, Hd_max, (const PllPhaseHint *)&d_sc->phase_hint, (unsigned)phase_groups,
+                               ((Wacq / 4 + 3) & ~3ll) + Wacq + Wp + Bp);
         L.end();
         PL.simple(OP_JOIN_WAIT);                                           // join
         L.gap();                                                           // (the wait is not part of pll_fix)

@@ -1109,11 +1109,20 @@ __device__ __forceinline__ void pll_guess(IqSrc pcm, long long ws, long long n, 
 // stream).  k_pll_head then walks from the lock sample to the end of its block with the true
 // state, and k_pll_fix validates every later seam against that chain; phases computed for
 // samples before the lock are simply never used.
+// What k_pll_phase tells k_pll_head (which runs beside it and walks a few blocks further while that costs nothing): HINTS only.
+struct PllPhaseHint {
+    unsigned done;              // += 1 per finished workgroup
+    unsigned pad_;
+    unsigned long long t0;      // the constant 100 MHz clock when its first workgroup began (0 = not yet)
+};
+__device__ __forceinline__ unsigned long long pdt_wall_clock() { return wall_clock64(); }
+
 template <typename T, bool SLOW>
 __device__ __forceinline__ void k_pll_phase(IqSrc pcm, const T *__restrict__ theta, long long n,
                                                    PllParams<T> P, long long B, long long Wacq, long long Wtrk, int lag,
                                                    T *__restrict__ phi, PllSeam<T> *__restrict__ seams,
-                                                   unsigned *__restrict__ groups_done /* += 1 per finished workgroup (k_pll_head's hint) */)
+                                                   PllPhaseHint *__restrict__ hint /* k_pll_head's */,
+                                                   int short_group = -1 /* the workgroup that walks the blocks in front of Wtrk, or -1 */)
 {
     // A SIMD of its own for every walker wavefront (the whole register file claimed, as k_pll_acquire_pipe and k_pll_head do):
     // the acquisition's two wavefronts are placed first and take two SIMDs of a CU; a workgroup of this kernel that lands on
@@ -1128,8 +1137,25 @@ __device__ __forceinline__ void k_pll_phase(IqSrc pcm, const T *__restrict__ the
     struct Done {                                   // (counted on every way out of the kernel)
         unsigned *p;
         __device__ ~Done() { if (threadIdx.x == 0) atomicAdd(p, 1u); }
-    } done_{groups_done};
-    const long long j = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    } done_{&hint->done};
+    if (blockIdx.x == 0 && threadIdx.x == 0) __hip_atomic_store(&hint->t0, pdt_wall_clock(), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    // The blocks that begin less than Wtrk into the capture have a warm-up that starts at sample 0: their walkers cross the block
+    // boundaries -- where pll_phase_range starts a new segment -- at other steps than everybody else's, and a wavefront that
+    // holds both kinds runs every segment for the longer of the two: an hour at 250 ksps, Wtrk = 5 B + 2 192: wavefront 0 walked
+    // 6 B + B steps where the others walk Wtrk + B, and the kernel ended 0.7 ms after everybody else with it (round 4,
+    // tools/probes/pll_mem_probe.hip real).  Those few walkers get a wavefront of their own (workgroup `short_group`, one lane
+    // each: all of them aligned at sample 0, the longest walks ceil(Wtrk / B) B <= Wtrk + B steps); their lanes of wavefront 0
+    // stay idle.
+    long long j = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (short_group >= 0) {
+        const long long n_short = (Wtrk + B - 1) / B;         // (the launch makes sure that these fit into one wavefront)
+        if ((int)blockIdx.x == short_group) {
+            if ((long long)threadIdx.x >= n_short) return;
+            j = threadIdx.x;
+        } else if (j < n_short) {
+            return;
+        }
+    }
     const long long start = j * B;
     if (start >= n) return;
     const long long end = (start + B < n) ? start + B : n;
@@ -1192,8 +1218,9 @@ __device__ __forceinline__ void k_pll_head(const T *__restrict__ theta, long lon
                                                   T *__restrict__ phi_head, PllSeam<T> *__restrict__ seams_head,
                                                   PllHeadInfo<T> *__restrict__ hinfo, long long max_blocks,
                                                   long long W_max /* >= W: walk on up to there while ... */,
-                                                  const unsigned *__restrict__ phase_done /* ... fewer than */,
-                                                  unsigned phase_groups /* workgroups of k_pll_phase have finished */)
+                                                  const PllPhaseHint *__restrict__ hint /* ... fewer than */,
+                                                  unsigned phase_groups /* workgroups of k_pll_phase have finished, and */,
+                                                  long long phase_steps /* its walkers' steps say that it will run long enough */)
 {
     if (EXCL) asm volatile("" ::: "v255", "a255");       // a SIMD of its own, see k_pll_acquire_pipe
     __shared__ __attribute__((aligned(16))) unsigned char ring[PDT_PLL_RING_PF * PDT_RING_SLOT];
@@ -1211,11 +1238,25 @@ __device__ __forceinline__ void k_pll_head(const T *__restrict__ theta, long lon
         if (j2 < j1) j2 = j1;
         T phase = info->st.phase, freq = info->st.freq;
         long long pos = S, k = 0;
+        const unsigned long long t_begin = pdt_wall_clock();
         for (long long j = j0; j <= j2 && pos < n; j++, k++) {
-            // (beyond the mandatory stretch only while the block-parallel kernel is still at work: those blocks are free, and the
-            // seams they take over are the ones most likely to be open)
-            if (j > j1 && __hip_atomic_load(phase_done, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= phase_groups) break;
             const long long end = ((j + 1) * B < n) ? (j + 1) * B : n;
+            // (beyond the mandatory stretch only while the block-parallel kernel is still at work: those blocks are free, and the
+            // seams they take over are the ones most likely to be open -- and only if this block will be done before that kernel
+            // is: its walkers step at this walker's pace (a lone wavefront on its SIMD, the same loop), so the clock at which
+            // they began + phase_steps of the steps timed here is when they end; a block of an hour at 250 ksps is 1 ms, and
+            // before this test the head ended up to a block after the kernel it was keeping company: 6.05 against 5.62 ms.)
+            if (j > j1) {
+                if (__hip_atomic_load(&hint->done, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= phase_groups) break;
+                const unsigned long long t0 = __hip_atomic_load(&hint->t0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT), now = pdt_wall_clock();
+                if (t0 != 0 && now > t0 && pos > S) {
+                    const float per_step = (float)(now - t_begin) / (float)(pos - S);
+                    // (the walkers beside us share HBM with 700 others: ~5 % slower than this one; and the seam right behind the
+                    // mandatory stretch is the one that stays open now and then -- two block walks of repair -- so ending up to
+                    // a third of a block after them is still the better bet)
+                    if ((float)(now - t0) + per_step * (float)(end - pos) > per_step * (1.05f * (float)phase_steps + 0.3f * (float)B)) break;
+                }
+            }
             PllSeam<T> sm;
             sm.phase0 = phase;
             sm.freq0 = freq;

@@ -7,6 +7,13 @@
 #include <hip/hip_runtime.h>
 #include <cstdio>
 #include <cstdint>
+#include <cstdlib>
+#include <thread>
+#include <vector>
+#include <algorithm>
+#include "../../project-desert-tortoise_amd/synth/pdt_synth.h"
+#include <cstring>
+#include <type_traits>
 #include "pdt_kernels_back.h"
 #include "pdt_kernels_front.h"
 using namespace pdt;
@@ -24,15 +31,49 @@ __global__ void fill(float *x, long long n)
 // the library's whole kernel body (guess, wide-band and acquisition-gain stages, tracking warm-up, block) on the synthetic streams
 __global__ void __launch_bounds__(256) k_full(IqSrc pcm, const float *__restrict__ theta, float *__restrict__ phi, long long n, long long B,
                                               long long Wacq, long long Wtrk, PllSeam<float> *seams, unsigned *done, int skip_guess,
-                                              unsigned long long *__restrict__ clk)
+                                              unsigned long long *__restrict__ clk, int short_group = -1)
 {
     PllParams<float> P;
     P.alpha_trk = 1.0385e-3f; P.beta_trk = 5.4e-7f; P.alpha_acq = 1.3e-2f; P.beta_acq = 8.5e-5f; P.alpha_wide = 0.1f; P.beta_wide = 5e-3f;
     P.max_freq = 0.12f; P.min_freq = -0.12f;
     const unsigned long long c0 = wall_clock64();
     if (skip_guess) pcm.p = nullptr;
-    k_pll_phase<float, false>(pcm, theta, skip_guess ? 0 : n, P, B, Wacq, Wtrk, 16, phi, seams, done);
+    k_pll_phase<float, false>(pcm, theta, skip_guess ? 0 : n, P, B, Wacq, Wtrk, 16, phi, seams, (PllPhaseHint *)done, short_group);
     if ((threadIdx.x & 63) == 0) clk[blockIdx.x * 4 + (threadIdx.x >> 6)] = wall_clock64() - c0;
+}
+
+// the library's way in: the body's arguments come from a pack in device memory (pdt_api.hip, k_run), the gains are run-time values
+template <typename... A> struct Pack {};
+template <typename H, typename... R> struct Pack<H, R...> { H h; Pack<R...> r; };
+template <typename H> __device__ __forceinline__ H as_global(H v)
+{
+    if constexpr (std::is_pointer<H>::value) {
+        using E = typename std::remove_pointer<H>::type;
+        __attribute__((address_space(1))) E *g = (__attribute__((address_space(1))) E *)v;
+        asm("" : "+s"(g));
+        return (H)g;
+    } else {
+        return v;
+    }
+}
+__device__ __forceinline__ IqSrc as_global(IqSrc v) { v.p = as_global(v.p); return v; }
+typedef Pack<IqSrc, const float *, long long, PllParams<float>, long long, long long, long long, int, float *, PllSeam<float> *, unsigned *> PhasePack;
+__global__ void __launch_bounds__(256) k_packed(const PhasePack *__restrict__ packs)
+{
+    const PhasePack &p = packs[blockIdx.z];
+    k_pll_phase<float, false>(as_global(p.h), as_global(p.r.h), p.r.r.h, p.r.r.r.h, p.r.r.r.r.h, p.r.r.r.r.r.h, p.r.r.r.r.r.r.h, p.r.r.r.r.r.r.r.h,
+                              as_global(p.r.r.r.r.r.r.r.r.h), as_global(p.r.r.r.r.r.r.r.r.r.h), (PllPhaseHint *)as_global(p.r.r.r.r.r.r.r.r.r.r.h));
+}
+
+// a load like the chain's streaming kernels: every CU full, HBM at full rate and a few dozen FMAs per element
+__global__ void __launch_bounds__(256) burn(const float4 *__restrict__ x, float4 *__restrict__ y, long long n4, float a)
+{
+    for (long long i = blockIdx.x * 256ll + threadIdx.x; i < n4; i += (long long)gridDim.x * 256) {
+        float4 v = x[i];
+#pragma unroll
+        for (int k = 0; k < 24; k++) { v.x = v.x * a + v.y; v.y = v.y * a + v.z; v.z = v.z * a + v.w; v.w = v.w * a + v.x; }
+        y[i] = v;
+    }
 }
 
 __global__ void spin_long(uint64_t *c)
@@ -117,8 +158,52 @@ void run(const char *what, const float *theta, float *phi, long long n, long lon
     fflush(stdout);
 }
 
-int main()
+__global__ void __launch_bounds__(256) k_theta(IqSrc pcm, long long n, long long B, float *theta) { k_pll_theta<float>(pcm, n, B, theta); }
+
+// `real`: the benched capture itself (libpdtsynth's c3 stream, an hour at 250 ksps) through the library's k_pll_theta -- the walkers
+// on exactly the product's input
+static int real_capture()
 {
+    const long long B = 19968, n = 900000000ll, slack = 64 * B + (1 << 20);
+    pdt_synth_params sp; pdt_synth_default_params(&sp, 0, 250000, 1000.0, 1234); (void)pdt_synth_sine_table();
+    int16_t *h = (int16_t *)malloc((size_t)n * 4);
+    std::vector<std::thread> th;
+    for (int t = 0; t < 8; t++) th.emplace_back([&, t] { const long long c = (n + 7) / 8, s0 = t * c; if (s0 < n) pdt_synth_fill(&sp, s0, std::min(c, n - s0), h + 2 * s0); });
+    for (auto &t : th) t.join();
+    void *pcm; float *theta, *phi; unsigned *done; PllSeam<float> *seams; unsigned long long *clk;
+    (void)hipMalloc(&pcm, (size_t)(n + slack) * 4); (void)hipMemset(pcm, 0, (size_t)(n + slack) * 4);
+    (void)hipMemcpy(pcm, h, (size_t)n * 4, hipMemcpyHostToDevice); free(h);
+    (void)hipMalloc(&theta, (size_t)(n + slack) * 4); (void)hipMalloc(&phi, (size_t)(n + slack) * 4); (void)hipMalloc(&clk, 1 << 20);
+    (void)hipMemset(theta, 0, (size_t)(n + slack) * 4);
+    (void)hipMalloc(&done, 64); (void)hipMalloc(&seams, sizeof(PllSeam<float>) * (n / B + 4096));
+    IqSrc src; src.p = pcm; src.fmt = 0;
+    const long long tiles = (n / B + 1 + 63) / 64;
+    hipLaunchKernelGGL(k_theta, dim3((unsigned)(tiles * (B / 64))), dim3(256), 0, 0, src, n, B, theta);
+    hipEvent_t a, b; (void)hipEventCreate(&a); (void)hipEventCreate(&b);
+    for (int zero = 0; zero < 3; zero++) {
+        if (zero == 2) (void)hipMemset(theta, 0, (size_t)n * 4);
+        const int sg = zero == 1 ? 177 : -1;
+        (void)hipMemset(clk, 0, 8 * 178 * 4);
+        float best = 1e9f;
+        for (int r = 0; r < 3; r++) {
+            (void)hipEventRecord(a);
+            hipLaunchKernelGGL(k_full, dim3(sg >= 0 ? 178 : 177), dim3(256), 0, 0, src, theta, phi, n, B, 5000ll, 102032ll, seams, done, 0, clk, sg);
+            (void)hipEventRecord(b); (void)hipEventSynchronize(b);
+            float ms; (void)hipEventElapsedTime(&ms, a, b); if (ms < best) best = ms;
+        }
+        static unsigned long long hc[1024];
+        (void)hipMemcpy(hc, clk, 8 * 178 * 4, hipMemcpyDeviceToHost);
+        unsigned long long mn = ~0ull, mx = 0; int slowest = 0;
+        for (int i = 0; i < 178 * 4; i++) { if (hc[i] > 100 && hc[i] < mn) mn = hc[i]; if (hc[i] > mx) { mx = hc[i]; slowest = i; } }
+        printf("the library's k_pll_phase body on %s, warm-up 102032: %7.3f ms; wavefronts take %.3f .. %.3f ms (the slowest: %d)  (%s)\n",
+               zero == 2 ? "a theta stream of zeros" : zero == 1 ? "the same, the walkers in front of Wtrk in a wavefront of their own" : "the benched capture's theta", best, mn * 1e-5, mx * 1e-5, slowest, hipGetErrorString(hipGetLastError()));
+    }
+    return 0;
+}
+
+int main(int argc, char **argv)
+{
+    if (argc > 1 && !strcmp(argv[1], "real")) return real_capture();
     const long long B = 19968, W = 110000 / 4 * 4;
     const int groups = 176;
     const long long n = B * 256 * groups;            // 899.7 M samples
@@ -155,6 +240,56 @@ int main()
             unsigned long long mn = ~0ull, mx = 0; for (int i = 0; i < 176 * 4; i++) { if (h[i] < mn) mn = h[i]; if (h[i] > mx) mx = h[i]; }
             printf("the library's k_pll_phase body, tracking warm-up %6d: %7.3f ms; wavefronts take %.3f .. %.3f ms  (%s)\n", wt, best, mn * 1e-5, mx * 1e-5, hipGetErrorString(hipGetLastError()));
         }
+    }
+    {
+        void *pcm; unsigned *done; PllSeam<float> *seams; PhasePack *dp;
+        (void)hipMalloc(&pcm, (n + slack) * 4); (void)hipMemset(pcm, 0x11, (n + slack) * 4);
+        (void)hipMalloc(&done, 64); (void)hipMalloc(&seams, sizeof(PllSeam<float>) * (n / B + 4096)); (void)hipMalloc(&dp, sizeof(PhasePack));
+        PhasePack hp; memset(&hp, 0, sizeof hp);
+        PllParams<float> P; memset(&P, 0, sizeof P);
+        P.alpha_trk = 1.0385e-3f; P.beta_trk = 5.4e-7f; P.alpha_acq = 1.3e-2f; P.beta_acq = 8.5e-5f; P.alpha_wide = 0.1f; P.beta_wide = 5e-3f;
+        P.max_freq = 0.12f; P.min_freq = -0.12f;
+        hp.h.p = pcm; hp.h.fmt = 0; hp.r.h = theta; hp.r.r.h = n; hp.r.r.r.h = P; hp.r.r.r.r.h = B; hp.r.r.r.r.r.h = 5000; hp.r.r.r.r.r.r.h = 99328;
+        hp.r.r.r.r.r.r.r.h = 16; hp.r.r.r.r.r.r.r.r.h = phi; hp.r.r.r.r.r.r.r.r.r.h = seams; hp.r.r.r.r.r.r.r.r.r.r.h = done;
+        (void)hipMemcpy(dp, &hp, sizeof hp, hipMemcpyHostToDevice);
+        hipEvent_t a, b; (void)hipEventCreate(&a); (void)hipEventCreate(&b);
+        float best = 1e9f;
+        for (int r = 0; r < 3; r++) {
+            (void)hipEventRecord(a);
+            hipLaunchKernelGGL(k_packed, dim3(177), dim3(256), 0, 0, (const PhasePack *)dp);
+            (void)hipEventRecord(b); (void)hipEventSynchronize(b);
+            float ms; (void)hipEventElapsedTime(&ms, a, b); if (ms < best) best = ms;
+        }
+        printf("the same body entered the library's way (arguments from a pack in device memory, run-time gains): %7.3f ms  (%s)\n", best, hipGetErrorString(hipGetLastError()));
+        (void)hipFree(pcm); (void)hipFree(seams);
+    }
+    // does the PLACEMENT of the two streams matter?  (the walkers read theta and write phi at the same offsets at the same time;
+    // the kernel moves 25 GB -- theta six times over, phi once -- in 5 ms: as close to the HBM roof as to the issue roof)
+    {
+        unsigned char *arena; void *pcm; unsigned *done; PllSeam<float> *seams;
+        const size_t span = (size_t)(n + slack) * 4;
+        (void)hipMalloc(&pcm, span); (void)hipMemset(pcm, 0x11, span);
+        (void)hipMalloc(&done, 64); (void)hipMalloc(&seams, sizeof(PllSeam<float>) * (n / B + 4096));
+        if (hipMalloc(&arena, 2 * span + (256u << 20)) == hipSuccess) {
+            IqSrc src; src.p = pcm; src.fmt = 0;
+            hipEvent_t a, b; (void)hipEventCreate(&a); (void)hipEventCreate(&b);
+            const size_t base = ((span + (2u << 20) - 1) >> 21) << 21;          // phi = theta + a multiple of 2 MiB + delta
+            printf("theta at %p (from hipMalloc: %p, phi %p)\n", (void *)arena, (void *)theta, (void *)phi);
+            for (size_t delta : {(size_t)0, (size_t)256, (size_t)1024, (size_t)4096, (size_t)(64u << 10), (size_t)(1u << 20), (size_t)((1u << 20) + 4096 + 1024), (size_t)(32u << 20), (size_t)(128u << 20)}) {
+                float *th = (float *)arena, *ph = (float *)(arena + base + delta);
+                (void)hipMemcpy(th, theta, span, hipMemcpyDeviceToDevice);
+                float best = 1e9f;
+                for (int r = 0; r < 3; r++) {
+                    (void)hipEventRecord(a);
+                    hipLaunchKernelGGL(k_full, dim3(177), dim3(256), 0, 0, src, th, ph, n, B, 5000ll, 99328ll, seams, done, 0, clk);
+                    (void)hipEventRecord(b); (void)hipEventSynchronize(b);
+                    float ms; (void)hipEventElapsedTime(&ms, a, b); if (ms < best) best = ms;
+                }
+                printf("  phi - theta = %zu x 2 MiB + %9zu B: %7.3f ms\n", base >> 21, delta, best);
+            }
+            (void)hipFree(arena);
+        }
+        (void)hipFree(pcm); (void)hipFree(seams);
     }
     {
         hipLaunchKernelGGL(fill_pm, dim3(4096), dim3(256), 0, 0, theta, n + slack, B, 0.02f);
@@ -195,7 +330,23 @@ int main()
             hipStream_t hi, lo;
             (void)hipStreamCreateWithPriority(&hi, hipStreamNonBlocking, greatest);
             (void)hipStreamCreateWithFlags(&lo, hipStreamNonBlocking);
+            printf("stream priorities: least %d, greatest %d\n", least, greatest);
             uint64_t *sc; (void)hipMalloc(&sc, 64);
+            {
+                hipStream_t low;
+                (void)hipStreamCreateWithPriority(&low, hipStreamNonBlocking, least);
+                for (int which = 0; which < 2; which++) {
+                    best = 1e9f;
+                    for (int r = 0; r < 3; r++) {
+                        (void)hipDeviceSynchronize();
+                        (void)hipEventRecord(a, which ? low : lo);
+                        hipLaunchKernelGGL(k_full, dim3(177), dim3(256), 0, which ? low : lo, src, theta, phi, n, B, 5000ll, 99328ll, seams, done, 0, clk);
+                        (void)hipEventRecord(b, which ? low : lo); (void)hipEventSynchronize(b);
+                        float ms; (void)hipEventElapsedTime(&ms, a, b); if (ms < best) best = ms;
+                    }
+                    printf("the same on a stream %s: %7.3f ms\n", which ? "of the lowest priority" : "created without a priority (non-blocking)", best);
+                }
+            }
             for (int beside = 0; beside < 2; beside++) {
                 best = 1e9f;
                 for (int r = 0; r < 3; r++) {
@@ -209,6 +360,46 @@ int main()
                 (void)hipDeviceSynchronize();
                 printf("the same on a stream of priority %d%s: %7.3f ms\n", greatest, beside ? ", a lone wavefront spinning on another stream" : "", best);
             }
+        }
+        // ... and under a sustained load like the chain's: ~8 ms of full-rate streaming in front of every launch, 40 times over
+        // (does the power management lower the shader clock for an issue-bound kernel that follows HBM-bound ones?)
+        {
+            float first = 0, lo5 = 1e9f, hi5 = 0;
+            for (int r = 0; r < 40; r++) {
+                for (int c = 0; c < 6; c++) (void)hipMemcpyAsync(phi, theta, (size_t)n * 4, hipMemcpyDeviceToDevice, 0);
+                (void)hipEventRecord(a, 0);
+                hipLaunchKernelGGL(k_full, dim3(177), dim3(256), 0, 0, src, theta, phi, n, B, 5000ll, 99328ll, seams, done, 0, clk);
+                (void)hipEventRecord(b, 0);
+                if (r == 0 || r >= 20) {
+                    (void)hipEventSynchronize(b);
+                    float ms; (void)hipEventElapsedTime(&ms, a, b);
+                    if (r == 0) first = ms; else { if (ms < lo5) lo5 = ms; if (ms > hi5) hi5 = ms; }
+                }
+            }
+            (void)hipDeviceSynchronize();
+            printf("the same behind 6 device copies of theta each time, 40 rounds: first %7.3f ms, rounds 20..39 %7.3f .. %7.3f ms\n", first, lo5, hi5);
+        }
+        // ... and behind ~12 ms of a compute + HBM load on every CU, 40 rounds without a pause: the power management's answer
+        {
+            float *scratch; (void)hipMalloc(&scratch, (size_t)n * 4);
+            float first = 0, lo5 = 1e9f, hi5 = 0, burn_ms = 0;
+            hipEvent_t c; (void)hipEventCreate(&c);
+            for (int r = 0; r < 40; r++) {
+                (void)hipEventRecord(c, 0);
+                for (int k = 0; k < 5; k++) hipLaunchKernelGGL(burn, dim3(256 * 8), dim3(256), 0, 0, (const float4 *)theta, (float4 *)scratch, n / 4, 0.999f);
+                (void)hipEventRecord(a, 0);
+                hipLaunchKernelGGL(k_full, dim3(177), dim3(256), 0, 0, src, theta, phi, n, B, 5000ll, 99328ll, seams, done, 0, clk);
+                (void)hipEventRecord(b, 0);
+                if (r == 0 || r >= 20) {
+                    (void)hipEventSynchronize(b);
+                    float ms; (void)hipEventElapsedTime(&ms, a, b);
+                    if (r == 0) first = ms; else { if (ms < lo5) lo5 = ms; if (ms > hi5) hi5 = ms; }
+                    (void)hipEventElapsedTime(&burn_ms, c, a);
+                }
+            }
+            (void)hipDeviceSynchronize();
+            printf("the same behind %.1f ms of FMA + HBM load on every CU each time, 40 rounds: first %7.3f ms, rounds 20..39 %7.3f .. %7.3f ms\n", burn_ms, first, lo5, hi5);
+            (void)hipFree(scratch);
         }
         run<true, true, true>("LDS ring on the PM-like stream", theta, phi, n, B, W, groups, g, clk);
     }
