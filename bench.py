@@ -277,16 +277,19 @@ def sq_valu_active(cfg: str, kernel: str, build: str):
 
 
 def roofline_bound(ms: float, traffic, alg_bytes: int, valu_active=None) -> str:
-    """What holds the dominant kernel up, from the evidence at hand: "issue" when the committed SQ pass of this build shows its
-    wavefronts issuing vector instructions in more than 60 % of their cycles (lone wavefronts per SIMD: the instruction count
-    of the serial step is the time); "hbm" when the bytes it moves (counter traffic of this build if committed, its algorithmic
-    bytes otherwise) take more than half its time at the rate streaming kernels reach here; "latency" otherwise."""
+    """What holds the dominant kernel up, from the evidence at hand: "hbm" when the bytes it moves (counter traffic of this build
+    if committed, its algorithmic bytes otherwise) already go at 85 % of the rate streaming kernels reach here -- whatever else is
+    scarce, that roof is the nearest (k_pll_phase at c3: 27.7 GB of warm-up re-reads at 5.2 TB/s, with its wavefronts issuing in
+    79 % of their cycles as well); "issue" when the committed SQ pass of this build shows its wavefronts issuing vector
+    instructions in more than 60 % of their cycles (lone wavefronts per SIMD: the instruction count of the serial step is the
+    time); "hbm" again when the bytes take more than half its time at that rate; "latency" otherwise."""
+    moved = traffic if traffic else alg_bytes
+    rate = moved / (ms * 1e-3) / 1e9 if ms and moved else 0.0
+    if rate >= 0.85 * HBM_STREAM_GBS:
+        return "hbm"
     if valu_active is not None and valu_active >= 0.6:
         return "issue"
-    moved = traffic if traffic else alg_bytes
-    if not ms or not moved:
-        return "latency"
-    return "hbm" if moved / (ms * 1e-3) / 1e9 >= 0.5 * HBM_STREAM_GBS else "latency"
+    return "hbm" if rate >= 0.5 * HBM_STREAM_GBS else "latency"
 
 
 def cpu_exe(kind: int):

@@ -17,6 +17,8 @@ done
 timeout 600 python bench.py --config c2 --steps 6 --warmup 2 --captures 8 --no-cpu --no-secondary > $OUT/bench_c2_batch8_1gpu.json 2>> $OUT/bench_c2.err
 bash tools/jobs/r4_quality.sh > $OUT/quality_step_c3.txt 2>&1; tail -2 $OUT/quality_step_c3.txt
 for p in lat_probe agc_mem_probe pll_mem_probe; do [ -x tools/probes/$p ] && timeout 300 ./tools/probes/$p > $OUT/$p.txt 2>&1; done
+[ -x tools/probes/pll_mem_probe ] && timeout 300 ./tools/probes/pll_mem_probe real > $OUT/pll_mem_probe_real.txt 2>&1
+( timeout 300 python tools/probes/c3_notorch.py; timeout 300 python tools/probes/c3_notorch.py torch ) 2>&1 | grep -v amdgpu.ids > $OUT/c3_notorch.txt
 cd /tmp
 for cfg in c3 c2; do
   rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats_$cfg -o s -- python $R/bench.py --config $cfg --steps 4 --warmup 1 --no-cpu --no-secondary > $OUT/stats_$cfg.log 2>&1
