@@ -243,7 +243,7 @@ struct Plan {
 struct Tuning {
     double band_pad = 0.0, pll_warm_scale = 1.0, head_taus = 0.0, agc_k = 0.0, pll_warm_s = 0.0, agc_warm_s = 0.0;
     int scout_syms = 0, gspan = 0, gspan_cap = 0, mf_waves = 8, ingest_threads = 0, ingest_span_mb = 0, ingest_streams = 0, overlap_segments = 0, overlap_min_mb = 0, fir_wg_per_cu = 0, agc_tpb = 0, gseg = 0, acquire_mode = 0, pll_block = 0, fix_passes = 2;      // acquire_mode: 0 = two-wavefront pipeline, 1 = plain one-lane, 2 = one wavefront
-    bool fir_generic = false, mix_unfused = false, quality_inline = false, gemit_groups = false, agc_unfused = false, no_excl = false, gtab_nomerge = false, gardner_onebuf = false, gardner_noring = false, gardner_sequential = false, seg_sequential = false, agc_lanes = false, overlap = false, debug_overlap = false, chain_one_range = false, ema_noguess = false, debug_sync = false, pll_noshort = false;
+    bool fir_generic = false, mix_unfused = false, quality_inline = false, gemit_groups = false, agc_unfused = false, no_excl = false, gtab_nomerge = false, gardner_onebuf = false, gardner_noring = false, gardner_sequential = false, seg_sequential = false, agc_lanes = false, overlap = false, debug_overlap = false, chain_one_range = false, ema_noguess = false, debug_sync = false, pll_noshort = false, pll_nockpt = false, pll_noconsensus = false;
     void load()
     {
         if (const char *e = getenv("PDT_PLL_WARM_SCALE")) pll_warm_scale = atof(e);
@@ -286,6 +286,8 @@ struct Tuning {
         if (const char *e = getenv("PDT_OVERLAP_MIN_MB")) overlap_min_mb = std::min(1 << 20, std::max(1, atoi(e)));
         debug_sync = getenv("PDT_DEBUG_SYNC") != nullptr;
         pll_noshort = getenv("PDT_PLL_NOSHORT") != nullptr;
+        pll_nockpt = getenv("PDT_PLL_NOCKPT") != nullptr;
+        pll_noconsensus = getenv("PDT_PLL_NOCONSENSUS") != nullptr;
     }
 };
 
@@ -337,7 +339,7 @@ struct pdt_ctx {
     hipEvent_t ev0 = nullptr, ev1 = nullptr, ev_fork = nullptr, ev_join = nullptr;
     hipStream_t stream2 = nullptr;     // side stream: block-parallel PLL phase runs beside the sequential acquisition
 
-    DevBuf pcm, pll, lock, fir, agc, sym, symidx, bits, bitsym, hits, frames, taps, mag, seams_pll, seams_agc, scal, lockinfo, term, seams_ema, gtable, gentries, gcand, gmfirst, stiles, gsegmap, gsegstart, gbands, gclist, gneed, gchain, gspan_keys, gspan_tails, gspan_rows, gspan_items, gspan_ctl, gspan_recs, gcentries, gflags, agc_maps, pll_head, taps_rot, pll_scratch, tip, sync_scr, agc_raw, agc_ckpt;
+    DevBuf pcm, pll, lock, fir, agc, sym, symidx, bits, bitsym, hits, frames, taps, mag, seams_pll, seams_agc, scal, lockinfo, term, seams_ema, gtable, gentries, gcand, gmfirst, stiles, gsegmap, gsegstart, gbands, gclist, gneed, gchain, gspan_keys, gspan_tails, gspan_rows, gspan_items, gspan_ctl, gspan_recs, gcentries, gflags, agc_maps, pll_head, taps_rot, pll_scratch, tip, sync_scr, agc_raw, agc_ckpt, pll_ckpt;
     bool counted = false;        // this context is in g_open_contexts
     bool keep_agc_raw = false;   // pdt_keep_presquelch: also keep the AGC output before Squelch (stage PDT_ST_AGC_RAW)
     // pdt_keep_quality: the averagePhase stream (what CarrierTrackPLL returns, chunk by chunk) and the per-chunk counts
@@ -999,22 +1001,43 @@ template <typename T> int run_capture(pdt_ctx *ctx, uint64_t n, int phase = RUN_
     // more than ~1000 of them: 250 ksps hour-long captures, batches)
     const long long grid_pll = (nb_pll + 255) / 256;
     // one more workgroup for the walkers whose warm-up begins at sample 0 (k_pll_phase), when they fit into a wavefront
-    const int short_group = ((Wp + Bp - 1) / Bp <= 64 && nb_pll > 64 && !ctx->tune.pll_noshort) ? (int)grid_pll : -1;
+    // ... and when it pays: in place, wavefront 0 runs every segment of the tracking stage for the longer of its two kinds of lane --
+    // the early walkers' first segment is B - (wide + acquisition stage), everybody else's W mod B (a wavefront with few lanes
+    // is not faster, rather the opposite: ARGOS, W = 4 B, +0.3 ms with the extra workgroup)
+    bool short_pays = false;
+    {
+        const long long w0 = ((Wacq / 4 + 3) & ~3ll) + Wacq;
+        const long long a = (Wp % Bp) ? Wp % Bp : Bp, s_first = Bp - w0 % Bp;
+        short_pays = (s_first - a) * 50 > w0 + Wp + Bp;
+    }
+    const int short_group = (short_pays && (((Wacq / 4 + 3) & ~3ll) + Wacq + Wp + Bp - 1) / Bp <= 64 && nb_pll > 64 && !ctx->tune.pll_noshort) ? (int)grid_pll : -1;
+    // outliers behind the wide-band stage take their wavefront's median frequency (k_pll_phase): POES only -- an ARGOS capture holds
+    // many transmitters, each at its own offset
+    const T pll_consensus = (!argos && !ctx->tune.pll_noconsensus) ? (T)(2.0 * M_PI * 800.0 / fs_d) : (T)0;
     const long long phase_groups = grid_pll + (short_group >= 0 ? 1 : 0);
     // a single +-2pi correction per step is exact as long as one step cannot move the phase by 2pi
     const double worst = (double)PP.max_freq + M_PI * std::max({(double)PP.alpha_acq + (double)PP.beta_acq,
                                                                 (double)PP.alpha_trk + (double)PP.beta_trk,
                                                                 (double)PP.alpha_wide + (double)PP.beta_wide});
     const bool slow_wrap = worst >= 2.0 * M_PI - 0.05;
+    // the walkers' frequency checkpoints (pll_phase_range): with them a seam repair stops where it has merged with the stored
+    // trajectory.  All ones = a NaN no loop state equals: a checkpoint nobody wrote never matches.
+    T *d_ckpt = nullptr;
+    if (N > 0 && !ctx->tune.pll_nockpt) {
+        const size_t ck_bytes = (size_t)((nb_pll + 63) / 64 + 1) * (size_t)pll_ckpt_count(Bp) * 64 * sizeof(T);
+        if ((rc = ctx->pll_ckpt.ensure(ck_bytes))) return rc;
+        d_ckpt = (T *)ctx->pll_ckpt.p;
+        PL.memset_async(d_ckpt, 0xff, ck_bytes);
+    }
     if (N > 0) {
         PL.simple(OP_FORK);
         L.begin("pll_phase", ctx->stream2);
         if (slow_wrap)
             PDT_LAUNCH(256, (k_pll_phase<T, true>), dim3((unsigned)phase_groups), dim3(256), 0, ctx->stream2, d_pcm, d_theta, N, PP, Bp,
-                               Wacq, Wp, lag, d_phi, (PllSeam<T> *)ctx->seams_pll.p, &d_sc->phase_hint, short_group);
+                               Wacq, Wp, lag, d_phi, (PllSeam<T> *)ctx->seams_pll.p, &d_sc->phase_hint, short_group, d_ckpt, pll_consensus);
         else
             PDT_LAUNCH(256, (k_pll_phase<T, false>), dim3((unsigned)phase_groups), dim3(256), 0, ctx->stream2, d_pcm, d_theta, N, PP, Bp,
-                               Wacq, Wp, lag, d_phi, (PllSeam<T> *)ctx->seams_pll.p, &d_sc->phase_hint, short_group);
+                               Wacq, Wp, lag, d_phi, (PllSeam<T> *)ctx->seams_pll.p, &d_sc->phase_hint, short_group, d_ckpt, pll_consensus);
         L.end();
         PL.simple(OP_JOIN_RECORD);
     }
@@ -1099,7 +1122,8 @@ template <typename T> int run_capture(pdt_ctx *ctx, uint64_t n, int phase = RUN_
         const long long nb_fix = (N + Bp - 1) / Bp;
         fix_regions = (nb_fix >= 128) ? std::min<long long>(64, nb_fix / 16) : 1;
         fix_region_blocks = (nb_fix + fix_regions - 1) / fix_regions;
-        if ((rc = ctx->pll_scratch.ensure((size_t)(fix_regions + 2) * (size_t)(PDT_FIX_THREADS / 64) * (size_t)(((Bp + 63) & ~63ll) + 64) * sizeof(T)))) return rc;
+        if ((rc = ctx->pll_scratch.ensure((size_t)(fix_regions + 2) * (size_t)(PDT_FIX_THREADS / 64) *
+                                          (size_t)(((Bp + 63) & ~63ll) + ((pll_ckpt_count(Bp) + 63) & ~63ll) + 64) * sizeof(T)))) return rc;
         L.begin("pll_head");
         if (slow_wrap)
             PDT_LAUNCH(64, (k_pll_head<T, true>), dim3(1), dim3(64), 0, st, d_theta, N, PP, d_info, Bp, Hd, d_hphi, d_hseams,
@@ -1123,11 +1147,11 @@ template <typename T> int run_capture(pdt_ctx *ctx, uint64_t n, int phase = RUN_
                 if (slow_wrap)
                     PDT_LAUNCH(PDT_FIX_THREADS, (k_pll_fix<T, true>), dim3(grid), dim3(PDT_FIX_THREADS), 0, st, d_theta, N, PP, d_info, Bp, d_phi,
                                (PllSeam<T> *)ctx->seams_pll.p, (const T *)d_hphi, (const PllSeam<T> *)d_hseams,
-                               (const PllHeadInfo<T> *)d_hinfo, (T *)ctx->pll_scratch.p, d_sc->counters, mode, rb, ro);
+                               (const PllHeadInfo<T> *)d_hinfo, (T *)ctx->pll_scratch.p, d_sc->counters, mode, rb, ro, d_ckpt);
                 else
                     PDT_LAUNCH(PDT_FIX_THREADS, (k_pll_fix<T, false>), dim3(grid), dim3(PDT_FIX_THREADS), 0, st, d_theta, N, PP, d_info, Bp, d_phi,
                                (PllSeam<T> *)ctx->seams_pll.p, (const T *)d_hphi, (const PllSeam<T> *)d_hseams,
-                               (const PllHeadInfo<T> *)d_hinfo, (T *)ctx->pll_scratch.p, d_sc->counters, mode, rb, ro);
+                               (const PllHeadInfo<T> *)d_hinfo, (T *)ctx->pll_scratch.p, d_sc->counters, mode, rb, ro, d_ckpt);
             };
             fix(0, 32, 0, 0);
             if (fix_regions > 1) {
@@ -2321,7 +2345,7 @@ void pdt_close(pdt_ctx *ctx)
     DevBuf *bufs[] = { &ctx->pcm, &ctx->pll, &ctx->lock, &ctx->fir, &ctx->agc, &ctx->sym, &ctx->symidx, &ctx->bits, &ctx->bitsym,
                        &ctx->hits, &ctx->frames, &ctx->taps, &ctx->mag, &ctx->seams_pll, &ctx->seams_agc, &ctx->scal, &ctx->lockinfo,
                        &ctx->term, &ctx->seams_ema, &ctx->gtable, &ctx->gentries, &ctx->gcand,
-                       &ctx->gmfirst, &ctx->stiles, &ctx->gsegmap, &ctx->gsegstart, &ctx->gbands, &ctx->gclist, &ctx->gspan_keys, &ctx->gspan_tails, &ctx->gspan_rows, &ctx->gspan_items, &ctx->gspan_ctl, &ctx->gspan_recs, &ctx->gcentries, &ctx->gflags, &ctx->agc_maps, &ctx->pll_head, &ctx->taps_rot, &ctx->pll_scratch, &ctx->tip, &ctx->stream_in, &ctx->sync_scr, &ctx->agc_raw, &ctx->agc_ckpt, &ctx->packs_dev, &ctx->seg_dev, &ctx->lt_theta, &ctx->lt_phi,
+                       &ctx->gmfirst, &ctx->stiles, &ctx->gsegmap, &ctx->gsegstart, &ctx->gbands, &ctx->gclist, &ctx->gspan_keys, &ctx->gspan_tails, &ctx->gspan_rows, &ctx->gspan_items, &ctx->gspan_ctl, &ctx->gspan_recs, &ctx->gcentries, &ctx->gflags, &ctx->agc_maps, &ctx->pll_head, &ctx->taps_rot, &ctx->pll_scratch, &ctx->tip, &ctx->stream_in, &ctx->sync_scr, &ctx->agc_raw, &ctx->agc_ckpt, &ctx->pll_ckpt, &ctx->packs_dev, &ctx->seg_dev, &ctx->lt_theta, &ctx->lt_phi,
                        &ctx->avgph, &ctx->term_ap, &ctx->seams_q, &ctx->chunkinfo };
     for (DevBuf *b : bufs) b->release();
     for (hipEvent_t e : ctx->event_pool) (void)hipEventDestroy(e);

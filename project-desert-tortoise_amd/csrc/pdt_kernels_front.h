@@ -885,10 +885,23 @@ __device__ __forceinline__ void pll_vec4_asm(const Vec16<float> &th, float phase
 #undef PDT_PLL_STEP
 }
 
+// `ckl` (STORE, from a block's first sample, ring path only): this lane's column of the frequency checkpoints -- the loop
+// frequency in front of sample c * PDT_PLL_CKPT of the block goes to ckl[64 c] for every c >= 1 that begins a trip of the ring
+// loop (pll_ckpt_valid).  With the phase stream they let a seam repair see where its re-run has merged with the stored
+// trajectory (k_pll_fix): the state (phase, freq) is the whole memory of the loop.
+#define PDT_PLL_CKPT 1024
+template <typename T> __host__ __device__ __forceinline__ bool pll_ckpt_valid(long long c, long long len)
+{
+    return c >= 1 && c * PDT_PLL_CKPT + (long long)PDT_PLL_RING_PF * (16 / (long long)sizeof(T)) <= len;
+}
+// checkpoints per block (the stride of a tile's columns)
+__host__ __device__ __forceinline__ long long pll_ckpt_count(long long B) { return B / PDT_PLL_CKPT + 1; }
+
 template <typename T, bool STORE, bool SLOW, bool OUT_LT, int PF = PDT_PLL_PF, bool VOTE = false>
 __device__ __forceinline__ void pll_phase_range(const T *__restrict__ theta_lt, T *__restrict__ out, long long B, long long i0,
                                                 long long i1, T &phase, T &freq, T alpha, T beta, T maxf, T minf,
-                                                int *far = nullptr, int *seen = nullptr, unsigned char *ring = nullptr)
+                                                int *far = nullptr, int *seen = nullptr, unsigned char *ring = nullptr,
+                                                T *ckl = nullptr)
 {
     constexpr int RPF = PDT_PLL_RING_PF;
     constexpr int VN = Lt<T>::VN, ROW = Lt<T>::ROW;
@@ -937,6 +950,7 @@ __device__ __forceinline__ void pll_phase_range(const T *__restrict__ theta_lt, 
             Vec16<T> cur = *reinterpret_cast<const Vec16<T> *>(mine), nxt;
             long long v = 0;
             for (; v + RPF <= nv; v += RPF) {
+                if (STORE && ckl && v != 0 && (v & (PDT_PLL_CKPT / VN - 1)) == 0) ckl[(v / (PDT_PLL_CKPT / VN)) * 64] = freq;
 #pragma unroll
                 for (int u = 0; u < RPF; u++) {
                     ring_wait<RPF - 2>();
@@ -1122,7 +1136,10 @@ __device__ __forceinline__ void k_pll_phase(IqSrc pcm, const T *__restrict__ the
                                                    PllParams<T> P, long long B, long long Wacq, long long Wtrk, int lag,
                                                    T *__restrict__ phi, PllSeam<T> *__restrict__ seams,
                                                    PllPhaseHint *__restrict__ hint /* k_pll_head's */,
-                                                   int short_group = -1 /* the workgroup that walks the blocks in front of Wtrk, or -1 */)
+                                                   int short_group = -1 /* the workgroup that walks the blocks in front of Wtrk, or -1 */,
+                                                   T *__restrict__ ckpt = nullptr /* frequency checkpoints (pll_phase_range), or none */,
+                                                   T consensus = 0 /* > 0: a walker whose frequency behind the wide-band stage is further than this
+                                                                      from its wavefront's median takes the median */)
 {
     // A SIMD of its own for every walker wavefront (the whole register file claimed, as k_pll_acquire_pipe and k_pll_head do):
     // the acquisition's two wavefronts are placed first and take two SIMDs of a CU; a workgroup of this kernel that lands on
@@ -1144,11 +1161,12 @@ __device__ __forceinline__ void k_pll_phase(IqSrc pcm, const T *__restrict__ the
     // holds both kinds runs every segment for the longer of the two: an hour at 250 ksps, Wtrk = 5 B + 2 192: wavefront 0 walked
     // 6 B + B steps where the others walk Wtrk + B, and the kernel ended 0.7 ms after everybody else with it (round 4,
     // tools/probes/pll_mem_probe.hip real).  Those few walkers get a wavefront of their own (workgroup `short_group`, one lane
-    // each: all of them aligned at sample 0, the longest walks ceil(Wtrk / B) B <= Wtrk + B steps); their lanes of wavefront 0
-    // stay idle.
+    // each: all of them aligned at sample 0, the longest walks ceil(W / B) B <= W + B steps); their lanes of wavefront 0
+    // stay idle.  (W = the three stages together, since it is the tracking stage that a walker near the beginning shortens: below.)
+    const long long Wwide = (Wacq / 4 + 3) & ~3ll;
     long long j = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (short_group >= 0) {
-        const long long n_short = (Wtrk + B - 1) / B;         // (the launch makes sure that these fit into one wavefront)
+        const long long n_short = (Wwide + Wacq + Wtrk + B - 1) / B;   // (the launch makes sure that these fit into one wavefront)
         if ((int)blockIdx.x == short_group) {
             if ((long long)threadIdx.x >= n_short) return;
             j = threadIdx.x;
@@ -1159,14 +1177,15 @@ __device__ __forceinline__ void k_pll_phase(IqSrc pcm, const T *__restrict__ the
     const long long start = j * B;
     if (start >= n) return;
     const long long end = (start + B < n) ? start + B : n;
-    const long long Wwide = (Wacq / 4 + 3) & ~3ll;
     long long w_wide = Wwide, w_acq = Wacq, w_trk = Wtrk;
-    if (start < w_wide + w_acq + w_trk) {           // near the beginning of the capture: shrink the stages
-        w_trk = (start < w_trk) ? start : w_trk;
-        w_acq = (start - w_trk < w_acq) ? start - w_trk : w_acq;
-        w_wide = (start - w_trk - w_acq < w_wide) ? start - w_trk - w_acq : w_wide;
-        w_acq &= ~3ll;
-        w_wide &= ~3ll;
+    if (start < w_wide + w_acq + w_trk) {
+        // near the beginning of the capture the TRACKING stage is what gets shorter: a walker that goes from its guess straight
+        // into the narrow loop (round 3 shortened the wide-band and acquisition stages first) can sit at the frequency limit
+        // for good -- the seam then costs two whole block walks, and such a block lies right behind k_pll_head's stretch
+        // (c3 with 17 472-sample blocks: block 6, dfreq 0.108)
+        w_wide = (start < w_wide) ? (start & ~3ll) : w_wide;
+        w_acq = (start - w_wide < w_acq) ? ((start - w_wide) & ~3ll) : w_acq;
+        w_trk = start - w_wide - w_acq;
     }
     const long long ws = start - w_trk - w_acq - w_wide;
     T phase, freq;
@@ -1177,6 +1196,27 @@ __device__ __forceinline__ void k_pll_phase(IqSrc pcm, const T *__restrict__ the
     __shared__ __attribute__((aligned(16))) unsigned char ring_all[4 * PDT_PLL_RING_PF * PDT_RING_SLOT];
     unsigned char *ring = ring_all + (threadIdx.x >> 6) * (PDT_PLL_RING_PF * PDT_RING_SLOT);
     pll_phase_range<T, false, SLOW, true>(theta, phi, B, ws, ws + w_wide, phase, freq, P.alpha_wide, P.beta_wide, P.max_freq, P.min_freq);
+    // Consensus (round 4).  On a weak signal one walker in a few hundred leaves the wide-band stage so far from the carrier that
+    // the acquisition-gain stage runs it into the frequency limit, where the narrow tracking loop never finds back: its block
+    // and the next one are then walked again by k_pll_fix (10 minutes at 250 ksps with six times the noise: 13 such walkers of
+    // 11 269 were 26 repairs and 2.6 of the step's 10.9 ms).  The 64 blocks of a wavefront are seconds apart -- the carrier moves
+    // by tens of Hz per second at most -- so an outlier takes the wavefront's median frequency (any start state is legal: the
+    // seams are validated all the same).  tools/probes/pll_mem_probe.hip lost: 22 lost walkers -> 0.
+    if (consensus > (T)0) {
+        const bool part = w_wide == Wwide && Wwide > 0;                    // ran the whole stage
+        const unsigned long long pm = __ballot(part);
+        const int np = __popcll(pm);
+        if (np >= 8) {
+            T med = freq;
+            for (int k = 0; k < 64; k++) {
+                if (!((pm >> k) & 1ull)) continue;                         // (uniform)
+                const T c = __shfl(freq, k);
+                const int lt = __popcll(__ballot(part && freq < c)), le = __popcll(__ballot(part && freq <= c));
+                if (lt <= (np - 1) / 2 && le > (np - 1) / 2) med = c;
+            }
+            if (part && Real<T>::abs(freq - med) > consensus) freq = med;
+        }
+    }
     // acquisition-gain stage; its last 128 samples vote on which of the two stable lock points we
     // fell into: at the carrier the detector error sits at +-m (|err| < pi/2), at the false point
     // pi away it sits at +-(pi - m) (|err| > pi/2)
@@ -1197,10 +1237,15 @@ __device__ __forceinline__ void k_pll_phase(IqSrc pcm, const T *__restrict__ the
     sm.phase0 = phase;
     sm.freq0 = freq;
     pll_phase_range<T, true, SLOW, true>(theta, phi, B, start, end, phase, freq, P.alpha_trk, P.beta_trk, P.max_freq, P.min_freq,
-                                         nullptr, nullptr, ring);
+                                         nullptr, nullptr, ring, ckpt ? ckpt + ((j >> 6) * pll_ckpt_count(B)) * 64 + (j & 63) : nullptr);
     sm.phase1 = phase;
     sm.freq1 = freq;
     seams[j] = sm;
+#ifdef PDT_FIX_TRACE
+    if ((threadIdx.x & 63) == 0 || j < 8)
+        printf("k_pll_phase: group %d wavefront %d lane %d block %lld: stages %lld %lld %lld + %lld, %.3f ms\n", (int)blockIdx.x, (int)threadIdx.x >> 6,
+               (int)threadIdx.x & 63, j, w_wide, w_acq, w_trk, end - start, (double)(pdt_wall_clock() - __hip_atomic_load(&hint->t0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) * 1e-5);
+#endif
 }
 
 // The first samples after the lock cannot be block-parallel: the true state starts from the
@@ -1296,6 +1341,36 @@ template <> __device__ __forceinline__ bool bits_equal<double>(double x, double 
 // that is not known to be the true one.
 #define PDT_FIX_THREADS 1024
 #define PDT_FIX_LIST 64
+
+// One lane walks block [start, end) again from (phase, freq), piece by piece of PDT_PLL_CKPT samples.  In front of every piece
+// that begins at a checkpoint it compares its state with the stored trajectory's -- the phase stream holds the phase in front of
+// that sample, ck_old the frequency -- and stops when the two are equal bit for bit: from there on the stored samples ARE what
+// it would compute (round 4: an isolated open seam merges within a few loop time constants; the re-run used to walk the whole
+// block, 1 ms for an hour at 250 ksps, and the seam behind k_pll_head's stretch stays open now and then).  The frequencies it
+// passes go to ck_new (column stride ck_new_stride: the scratch list of a re-run, or ck_old itself when it writes in place).
+// Returns the number of samples walked; `merged` says that the block's recorded end state still holds.
+template <typename T, bool SLOW, bool OUT_LT>
+__device__ __forceinline__ long long pll_rewalk(const T *__restrict__ theta, T *out, long long B, long long start, long long end, T &phase,
+                                                T &freq, const PllParams<T> &P, const T *phi_old /* LT */, T *ck_old /* column, stride 64, or null */,
+                                                T *ck_new, long long ck_new_stride, bool &merged)
+{
+    const long long len = end - start;
+    merged = false;
+    long long p = 0;
+    while (p < len) {
+        const long long c = p / PDT_PLL_CKPT;
+        if (ck_old && pll_ckpt_valid<T>(c, len)) {
+            const T f_old = ck_old[c * 64];
+            const T p_old = phi_old[Lt<T>::index(start + p, B)];
+            if (bits_equal(p_old, phase) && bits_equal(f_old, freq)) { merged = true; break; }
+            ck_new[c * ck_new_stride] = freq;
+        }
+        const long long q = (p + PDT_PLL_CKPT < len) ? p + PDT_PLL_CKPT : len;
+        pll_phase_range<T, true, SLOW, OUT_LT, 32>(theta, out, B, start + p, start + q, phase, freq, P.alpha_trk, P.beta_trk, P.max_freq, P.min_freq);
+        p = q;
+    }
+    return p;
+}
 template <typename T, bool SLOW>
 __device__ __forceinline__ void k_pll_fix(const T *__restrict__ theta, long long n, PllParams<T> P,
                                                  const PllLockInfo<T> *__restrict__ info, long long B, T *__restrict__ phi,
@@ -1303,7 +1378,8 @@ __device__ __forceinline__ void k_pll_fix(const T *__restrict__ theta, long long
                                                  const PllSeam<T> *__restrict__ seams_head,
                                                  const PllHeadInfo<T> *__restrict__ hinfo, T *__restrict__ scratch,
                                                  unsigned *__restrict__ counters /* [0]=blocks [1]=fixes */, int mode,
-                                                 long long region_blocks, long long region_offset)
+                                                 long long region_blocks, long long region_offset,
+                                                 T *ckpt = nullptr /* k_pll_phase's frequency checkpoints, or none */)
 {
     // mode 0: graft the head's phases and seam records over the block-parallel ones, nothing else (one workgroup);
     // mode 1: region pass -- workgroup g validates and repairs the seams of its own region of `region_blocks` blocks, taking the
@@ -1316,6 +1392,7 @@ __device__ __forceinline__ void k_pll_fix(const T *__restrict__ theta, long long
     constexpr int NW = PDT_FIX_THREADS / 64;
     __shared__ long long s_bad[PDT_FIX_LIST];
     __shared__ T s_end[NW][2], s_beg[NW][2];
+    __shared__ long long s_len[NW];                                 // samples a re-run walked before it merged (or the block's)
     __shared__ unsigned s_nbad;
     __shared__ long long s_min;
     const long long lock_at = info->lock_sample;
@@ -1327,7 +1404,9 @@ __device__ __forceinline__ void k_pll_fix(const T *__restrict__ theta, long long
     const PllHeadInfo<T> hi = *hinfo;
     const long long j0 = hi.j0;                                     // block that contains the lock
     const long long nb_abs = (n + B - 1) / B;                       // absolute block count
-    const long long BS = (B + 63) & ~63ll;                          // scratch stride per wavefront
+    const long long NC = pll_ckpt_count(B);
+    const long long BS = ((B + 63) & ~63ll) + ((NC + 63) & ~63ll);  // scratch stride per wavefront: the block, then its checkpoints
+    auto ck_col = [&](long long blk) { return ckpt ? ckpt + ((blk >> 6) * NC) * 64 + (blk & 63) : (T *)nullptr; };
     if (mode == 0) {
         // (a few workgroups: the head of an hour at 250 ksps is 100 000 samples, 0.2 ms for a single one)
         const long long t0 = (long long)blockIdx.x * PDT_FIX_THREADS + threadIdx.x, tn = (long long)gridDim.x * PDT_FIX_THREADS;
@@ -1390,10 +1469,17 @@ __device__ __forceinline__ void k_pll_fix(const T *__restrict__ theta, long long
             const long long start = rb * B;
             const long long end = ((rb + 1) * B < n) ? (rb + 1) * B : n;
             // scratch index = sample index - (start rounded down to 4): vector stores stay aligned
-            pll_phase_range<T, true, SLOW, false, 32>(theta, scratch + (long long)wave * BS - (start & ~3ll), B, start, end, phase, freq,
-                                                      P.alpha_trk, P.beta_trk, P.max_freq, P.min_freq);
-            s_end[wave][0] = phase;
-            s_end[wave][1] = freq;
+            bool merged;
+            T *sc = scratch + (long long)wave * BS;
+            s_len[wave] = pll_rewalk<T, SLOW, false>(theta, sc - (start & ~3ll), B, start, end, phase, freq, P, phi, ck_col(rb),
+                                                     sc + ((B + 63) & ~63ll), 1, merged);
+#ifdef PDT_FIX_TRACE
+            printf("pll fix mode %d: seam %lld of %lld (head blocks %lld..%lld), walked %lld of %lld, merged %d; dphase %g dfreq %g\n", mode, rb, nb_abs, j0,
+                   j0 + hi.nblk - 1, s_len[wave], end - start, (int)merged, (double)(prev.phase1 - seams[rb].phase0), (double)(prev.freq1 - seams[rb].freq0));
+#endif
+            const PllSeam<T> old = seams[rb];
+            s_end[wave][0] = merged ? old.phase1 : phase;       // merged: the rest of the block, its end state included, stands
+            s_end[wave][1] = merged ? old.freq1 : freq;
         }
         __threadfence();
         __syncthreads();
@@ -1410,7 +1496,14 @@ __device__ __forceinline__ void k_pll_fix(const T *__restrict__ theta, long long
             const long long start = rb * B;
             const long long end = ((rb + 1) * B < n) ? (rb + 1) * B : n;
             const T *src = scratch + (long long)q * BS - (start & ~3ll);
-            for (long long i = start + threadIdx.x; i < end; i += PDT_FIX_THREADS) phi[Lt<T>::index(i, B)] = src[i];
+            const long long walked = s_len[q];
+            for (long long i = start + threadIdx.x; i < start + walked; i += PDT_FIX_THREADS) phi[Lt<T>::index(i, B)] = src[i];
+            if (ckpt) {                                             // the frequencies the re-run passed (it compared before it wrote)
+                const T *cks = scratch + (long long)q * BS + ((B + 63) & ~63ll);
+                T *col = ck_col(rb);
+                for (long long c = 1 + threadIdx.x; c * PDT_PLL_CKPT < walked; c += PDT_FIX_THREADS)
+                    if (pll_ckpt_valid<T>(c, end - start)) col[c * 64] = cks[c];
+            }
             if (threadIdx.x == 0) {
                 PllSeam<T> upd;
                 upd.phase0 = s_beg[q][0];
@@ -1440,13 +1533,14 @@ __device__ __forceinline__ void k_pll_fix(const T *__restrict__ theta, long long
                     T phase = prev.phase1, freq = prev.freq1;
                     const long long start = r * B;
                     const long long end = ((r + 1) * B < n) ? (r + 1) * B : n;
-                    pll_phase_range<T, true, SLOW, true, 32>(theta, phi, B, start, end, phase, freq, P.alpha_trk, P.beta_trk, P.max_freq,
-                                                             P.min_freq);
+                    bool merged;
+                    T *col = ck_col(r);
+                    (void)pll_rewalk<T, SLOW, true>(theta, phi, B, start, end, phase, freq, P, phi, col, col, 64, merged);
                     PllSeam<T> upd;
                     upd.phase0 = prev.phase1;
                     upd.freq0 = prev.freq1;
-                    upd.phase1 = phase;
-                    upd.freq1 = freq;
+                    upd.phase1 = merged ? cur.phase1 : phase;
+                    upd.freq1 = merged ? cur.freq1 : freq;
                     seams[r] = upd;
                     extra++;
                     r++;

@@ -1,6 +1,8 @@
 """Batched many-capture mode (pdt_demod_batch_device): several captures demodulated together -- one launch
 per stage for the whole batch, the capture index in blockIdx.z -- give, per context, exactly what the ORACLE computes for
 each capture alone: every intermediate stream, the text, the counters."""
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -55,15 +57,24 @@ def test_batch_of_equal_captures_and_weak_signal(pdt, orc):
     oracles = [orc.Oracle(orc.POES, fs, iq) for iq in caps]
     dev = [to_dev(iq) for iq in caps]
     torch.cuda.synchronize()
-    ds = [pdt.Demodulator(pdt.MODE_POES, fs) for _ in caps]
-    try:
-        pdt.demod_batch(ds, [t.data_ptr() for t in dev], [n] * len(caps))
-        for d, o in zip(ds, oracles):
-            check_all_stages(pdt, orc, d, o)
-        assert ds[2].stats().pll_seam_fixes + ds[5].stats().pll_seam_fixes >= 2
-    finally:
-        for d in ds:
-            d.close()
+    # (without the walkers' consensus -- round 4 -- the noisy slots lose walkers and their repairs really run; with it, the default,
+    # the same result with fewer of them)
+    for lone in (True, False):
+        if lone:
+            os.environ["PDT_PLL_NOCONSENSUS"] = "1"
+        try:
+            ds = [pdt.Demodulator(pdt.MODE_POES, fs) for _ in caps]
+        finally:
+            os.environ.pop("PDT_PLL_NOCONSENSUS", None)
+        try:
+            pdt.demod_batch(ds, [t.data_ptr() for t in dev], [n] * len(caps))
+            for d, o in zip(ds, oracles):
+                check_all_stages(pdt, orc, d, o)
+            if lone:
+                assert ds[2].stats().pll_seam_fixes + ds[5].stats().pll_seam_fixes >= 2
+        finally:
+            for d in ds:
+                d.close()
 
 
 def test_batch_mixed_modes(pdt, orc):

@@ -339,10 +339,21 @@ def test_weak_signal_repair_cascades(pdt, orc, mult):
     iq = np.zeros((n, 2), dtype="<i2")
     pdt.synth_lib().pdt_synth_fill(C.byref(p), 0, n, iq.ctypes.data)
     o = orc.Oracle(orc.POES, fs, iq)
+    # without the walkers' consensus (round 4: outliers behind the wide-band stage take their wavefront's median frequency) the
+    # lost walkers are all there: the repair path, cascades and checkpoint exits included, really runs
+    os.environ["PDT_PLL_NOCONSENSUS"] = "1"
+    try:
+        with pdt.Demodulator(pdt.MODE_POES, fs) as d:
+            d.demod(iq)
+            check_all_stages(pdt, orc, d, o)
+            lone = d.stats().pll_seam_fixes
+            assert lone >= 5
+    finally:
+        del os.environ["PDT_PLL_NOCONSENSUS"]
     with pdt.Demodulator(pdt.MODE_POES, fs) as d:
         d.demod(iq)
         check_all_stages(pdt, orc, d, o)
-        assert d.stats().pll_seam_fixes >= 5          # the repair path really ran
+        assert d.stats().pll_seam_fixes <= lone       # (x5: 9 -> 2 on the round's build; the result is the same either way)
 
 
 def test_250ksps_capture_matches_oracle(pdt, orc):
@@ -549,8 +560,18 @@ def test_pass_shaped_snr_profile(pdt, orc):
         parts.append(iq)
     cap = np.concatenate(parts)
     o = orc.Oracle(orc.POES, fs, cap)
-    with pdt.Demodulator(pdt.MODE_POES, fs) as d:
+    os.environ["PDT_PLL_NOCONSENSUS"] = "1"           # (the walkers on their own: the repairs really run)
+    try:
+        with pdt.Demodulator(pdt.MODE_POES, fs) as d:
+            d.demod(cap)
+            check_all_stages(pdt, orc, d, o)
+            s = d.stats()
+            lone = s.pll_seam_fixes
+            assert lone >= 10 and s.frames >= 400
+    finally:
+        del os.environ["PDT_PLL_NOCONSENSUS"]
+    with pdt.Demodulator(pdt.MODE_POES, fs) as d:     # with the wavefronts' consensus (the default): fewer lost walkers, same result
         d.demod(cap)
         check_all_stages(pdt, orc, d, o)
         s = d.stats()
-        assert s.pll_seam_fixes >= 10 and s.frames >= 400
+        assert s.pll_seam_fixes <= lone and s.frames >= 400

@@ -7,6 +7,7 @@
 #include <hip/hip_runtime.h>
 #include <cstdio>
 #include <cstdint>
+#include <cmath>
 #include <cstdlib>
 #include <thread>
 #include <vector>
@@ -201,8 +202,112 @@ static int real_capture()
     return 0;
 }
 
+// `lost`: where do walkers lose the carrier?  The benched weak capture (noise x6) or the strong one, the library's stages one by
+// one with the loop frequency of every walker recorded behind each: guess, wide-band, acquisition gain (+ vote), tracking warm-up.
+__global__ void __launch_bounds__(256) k_diag(IqSrc pcm, const float *__restrict__ theta, float *__restrict__ phi, long long n, long long B,
+                                              long long Wacq, long long Wtrk, PllParams<float> P, float *__restrict__ rec /* 8 per walker */,
+                                              int consensus)
+{
+    asm volatile("" ::: "v255", "a255");
+    const long long j = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    const long long start = j * B;
+    if (start >= n) return;
+    const long long Wwide = (Wacq / 4 + 3) & ~3ll;
+    if (start < Wwide + Wacq + Wtrk) return;
+    const long long ws = start - Wtrk - Wacq - Wwide;
+    float phase, freq;
+    pll_guess(pcm, ws, n, 16, 0.0f, phase, freq);
+    if (freq > P.max_freq) freq = P.max_freq;
+    if (freq < P.min_freq) freq = P.min_freq;
+    float *r = rec + j * 8;
+    r[0] = freq;
+    __shared__ __attribute__((aligned(16))) unsigned char ring_all[4 * PDT_PLL_RING_PF * PDT_RING_SLOT];
+    unsigned char *ring = ring_all + (threadIdx.x >> 6) * (PDT_PLL_RING_PF * PDT_RING_SLOT);
+    pll_phase_range<float, false, false, true>(theta, phi, B, ws, ws + Wwide, phase, freq, P.alpha_wide, P.beta_wide, P.max_freq, P.min_freq);
+    r[1] = freq;
+    if (consensus & 1) {                     // the wavefront's median frequency replaces an outlier's
+        float med;
+        { int below; med = freq; for (int k = 0; k < 64; k++) { const float c = __shfl(freq, k); below = __popcll(__ballot(freq < c)); if (below >= 28 && below <= 36) med = c; } }
+        if (__builtin_fabsf(freq - med) > 0.02f) freq = med;
+    }
+    const long long a0 = ws + Wwide, a1 = a0 + Wacq, vote0 = a1 - 128;
+    pll_phase_range<float, false, false, true>(theta, phi, B, a0, vote0, phase, freq, P.alpha_acq, P.beta_acq, P.max_freq, P.min_freq);
+    int far = 0, seen = 0;
+    pll_phase_range<float, false, false, true, PDT_PLL_PF, true>(theta, phi, B, vote0, a1, phase, freq, P.alpha_acq, P.beta_acq, P.max_freq, P.min_freq, &far, &seen);
+    r[2] = freq;
+    if (2 * far > seen) {
+        phase = (phase > 0) ? phase - (float)PDT_PI : phase + (float)PDT_PI;
+        if (freq >= 0 && phase < 0) phase += (float)(2 * PDT_PI);
+        if (freq < 0 && phase > 0) phase -= (float)(2 * PDT_PI);
+    }
+    r[5] = (float)far / (float)(seen ? seen : 1);
+    if (consensus & 2) {
+        float med;
+        { int below; med = freq; for (int k = 0; k < 64; k++) { const float c = __shfl(freq, k); below = __popcll(__ballot(freq < c)); if (below >= 28 && below <= 36) med = c; } }
+        if (__builtin_fabsf(freq - med) > 0.02f) freq = med;
+    }
+    pll_phase_range<float, false, false, true>(theta, phi, B, a1, start, phase, freq, P.alpha_trk, P.beta_trk, P.max_freq, P.min_freq, nullptr, nullptr, ring);
+    r[3] = freq;
+    r[4] = phase;
+}
+
+static int lost_walkers(int weak)
+{
+    const long long fs = 250000, n = weak ? 150000000ll : 900000000ll, B = weak ? 13312 : 19968, slack = 64 * B + (1 << 20);
+    const long long Wtrk = weak ? 91900 : 102032;
+    pdt_synth_params sp; pdt_synth_default_params(&sp, 0, (uint32_t)fs, 1000.0, 1234); (void)pdt_synth_sine_table();
+    if (weak) sp.noise_gain *= 6;
+    int16_t *h = (int16_t *)malloc((size_t)n * 4);
+    std::vector<std::thread> th;
+    for (int t = 0; t < 8; t++) th.emplace_back([&, t] { const long long c = (n + 7) / 8, s0 = t * c; if (s0 < n) pdt_synth_fill(&sp, s0, std::min(c, n - s0), h + 2 * s0); });
+    for (auto &t : th) t.join();
+    void *pcm; float *theta, *phi, *rec;
+    (void)hipMalloc(&pcm, (size_t)(n + slack) * 4); (void)hipMemset(pcm, 0, (size_t)(n + slack) * 4);
+    (void)hipMemcpy(pcm, h, (size_t)n * 4, hipMemcpyHostToDevice); free(h);
+    (void)hipMalloc(&theta, (size_t)(n + slack) * 4); (void)hipMalloc(&phi, (size_t)(n + slack) * 4);
+    (void)hipMemset(theta, 0, (size_t)(n + slack) * 4);
+    const long long nb = n / B + 1;
+    (void)hipMalloc(&rec, (size_t)(nb + 512) * 8 * 4);
+    IqSrc src; src.p = pcm; src.fmt = 0;
+    const long long tiles = (n / B + 1 + 63) / 64;
+    hipLaunchKernelGGL(k_theta, dim3((unsigned)(tiles * (B / 64))), dim3(256), 0, 0, src, n, B, theta);
+    PllParams<float> P; memset(&P, 0, sizeof P);
+    {
+        const double w = 2.0 * M_PI / (double)fs;
+        const float bw_acq = (float)(127.3240 * w), bw_trk = (float)(10.3451 * w), damp = 0.999f, bw_w = bw_acq * 8.0f;
+        P.alpha_acq = (4.0f * damp * bw_acq) / (1.0f + 2.0f * damp * bw_acq + bw_acq * bw_acq);
+        P.beta_acq = (4.0f * bw_acq * bw_acq) / (1.0f + 2.0f * damp * bw_acq + bw_acq * bw_acq);
+        P.alpha_trk = (float)((4.0 * 0.999 * (double)bw_trk) / (1.0 + 2.0 * 0.999 * (double)bw_trk + (double)(bw_trk * bw_trk)));
+        P.beta_trk = (float)((4.0 * (double)bw_trk * (double)bw_trk) / (1.0 + 2.0 * 0.999 * (double)bw_trk + (double)(bw_trk * bw_trk)));
+        P.alpha_wide = (4.0f * damp * bw_w) / (1.0f + 2.0f * damp * bw_w + bw_w * bw_w);
+        P.beta_wide = (4.0f * bw_w * bw_w) / (1.0f + 2.0f * damp * bw_w + bw_w * bw_w);
+        P.max_freq = (float)(2.0 * M_PI * 4500.0 / (double)fs); P.min_freq = -P.max_freq;
+    }
+    const float f_true = (float)(2.0 * M_PI * 1000.0 / (double)fs);
+    std::vector<float> hr((size_t)nb * 8);
+    for (int consensus = 0; consensus < 4; consensus++) {
+        (void)hipMemset(rec, 0, (size_t)nb * 8 * 4);
+        hipLaunchKernelGGL(k_diag, dim3((unsigned)((nb + 255) / 256)), dim3(256), 0, 0, src, theta, phi, n, B, 5000ll, Wtrk, P, rec, consensus);
+        (void)hipDeviceSynchronize();
+        (void)hipMemcpy(hr.data(), rec, (size_t)nb * 8 * 4, hipMemcpyDeviceToHost);
+        long long cnt[4] = {0, 0, 0, 0}, walkers = 0, votes = 0;
+        for (long long j = 0; j < nb; j++) {
+            const float *r = &hr[(size_t)j * 8];
+            if (r[0] == 0 && r[3] == 0) continue;
+            walkers++;
+            for (int k = 0; k < 4; k++) if (fabsf(r[k] - f_true) > 0.01f) cnt[k]++;
+            if (r[5] > 0.5f) votes++;
+        }
+        printf("%s capture, %lld walkers (B %lld, W %lld), consensus %d (1: behind the wide stage, 2: behind the acquisition stage): frequency more than 0.01 rad/sample (400 Hz) "
+               "from the carrier behind the guess %lld, the wide-band stage %lld, the acquisition-gain stage %lld, the tracking warm-up %lld; votes for the far point %lld  (%s)\n",
+               weak ? "weak" : "strong", walkers, B, Wtrk, consensus, cnt[0], cnt[1], cnt[2], cnt[3], votes, hipGetErrorString(hipGetLastError()));
+    }
+    return 0;
+}
+
 int main(int argc, char **argv)
 {
+    if (argc > 1 && !strcmp(argv[1], "lost")) return lost_walkers(argc > 2 && !strcmp(argv[2], "weak"));
     if (argc > 1 && !strcmp(argv[1], "real")) return real_capture();
     const long long B = 19968, W = 110000 / 4 * 4;
     const int groups = 176;
