@@ -98,6 +98,30 @@ def test_block_geometry_never_changes_the_result(pdt, orc, clip, kw):
             assert d.stats().pll_seam_fixes > 0 and d.stats().agc_seam_fixes > 0
 
 
+@pytest.mark.parametrize("switch", ["", "PDT_PLL_NOSHORT", "PDT_PLL_NOCKPT", "PDT_PLL_NOCONSENSUS"])
+def test_early_walkers_checkpoints_consensus_never_change_the_result(pdt, orc, switch):
+    """Round 4's additions to the block-parallel PLL, each switched off in turn, on a geometry where all of them act: 97 blocks
+    of 4 096 samples with a warm-up of five blocks and 512 samples -- the early walkers get their own workgroup (their first
+    tracking segment is 2 846 samples, everybody else's 512), the warm-up is short enough for open seams (re-runs that stop at
+    a checkpoint), and the noise (x4) loses a walker now and then (consensus)."""
+    import ctypes as C
+    fs = 50000
+    p = pdt.synth_params(0, fs, 1000.0, 4242)
+    p.noise_gain = int(p.noise_gain * 4)
+    n = 97 * 4096 + 1234
+    iq = np.zeros((n, 2), dtype="<i2")
+    pdt.synth_lib().pdt_synth_fill(C.byref(p), 0, n, iq.ctypes.data)
+    o = orc.Oracle(orc.POES, fs, iq)
+    if switch:
+        os.environ[switch] = "1"
+    try:
+        with pdt.Demodulator(pdt.MODE_POES, fs, pll_block=4096, pll_warm=5 * 4096 + 512) as d:
+            d.demod(iq)
+            check_all_stages(pdt, orc, d, o)
+    finally:
+        os.environ.pop(switch, None)
+
+
 @pytest.mark.parametrize("n", [0, 1, 5, 77, 9999, 10000, 10001, 20000, 25000])
 def test_short_and_ragged_captures(pdt, orc, clip, n):
     """empty input, less than one chunk, exact multiples of the chunk (Q7), ragged tail"""
