@@ -1646,7 +1646,7 @@ template <typename T> struct EmaSeam { T v0, v1; };
 // lane at an hour of 250 ksps.  `ring` (PDT_EMA_PF KiB of LDS for this wavefront, or nullptr): the look-ahead as an LDS ring
 // with hand-placed waits (ring_issue; the register ring's loop header waits for every load in flight, so each trip of 32
 // vectors exposed a memory latency: ~35 ns a step where the arithmetic is 13).
-#define PDT_EMA_PF 32
+#define PDT_EMA_PF 64
 template <typename T, int STORE, int PF = 32>
 __device__ __forceinline__ void ema_range(const T *__restrict__ term, T *__restrict__ out, long long i0, long long i1, T &L, double k,
                                           unsigned char *ring = nullptr, long long chunk = 0)
