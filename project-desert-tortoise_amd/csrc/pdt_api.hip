@@ -792,9 +792,12 @@ template <typename T> int run_capture(pdt_ctx *ctx, uint64_t n, int phase = RUN_
         // One walker wavefront saturates the vector ALU of its SIMD (a wave64 instruction occupies the 16 lanes for 4 clocks), so
         // a second one on the same SIMD doubles the time of both: keep the walkers of everything that runs together -- this
         // capture, or the whole batch -- under ~one per SIMD (240 groups of four; the rest is left to the serial kernels).
-        // (A capture on its own: 180 -- an hour at 250 ksps, where the warm-ups' re-reads press on HBM: blocks of 15 / 20 / 25 / 30 /
-        // 40 thousand samples -> phase kernel 7.6 / 6.9 / 6.8 / 7.7 / 8.3 ms.)
-        const long long groups_max = ctx->batch_hint > 1 ? 240 : 180;
+        // (A capture on its own, round 3: 180 -- an hour at 250 ksps, where the warm-ups' re-reads press on HBM: blocks of 15 / 20 /
+        // 25 / 30 / 40 thousand samples -> phase kernel 7.6 / 6.9 / 6.8 / 7.7 / 8.3 ms.)
+        // (Round 4, with wavefront 0 out of the way -- it had been walking 7 B steps and favoured short blocks: the kernel sits under
+        // the issue roof, (W + B) steps, and the HBM roof of its re-reads, W / B + 2 passes over the capture, at once; blocks of
+        // 20 / 22.5 / 24 / 25 / 28 thousand samples -> 5.55 / 5.45 / 5.27 / 5.25 / 5.29 ms: 150 groups.)
+        const long long groups_max = ctx->batch_hint > 1 ? 240 : 150;
         const long long share = std::max<long long>(1, groups_max / std::max(1, ctx->batch_hint));
         const long long b_min = (N + share * 256 - 1) / (share * 256);
         Bp = std::max(Bp, b_min);
