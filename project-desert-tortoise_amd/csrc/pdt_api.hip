@@ -1372,14 +1372,21 @@ template <typename T> int run_capture(pdt_ctx *ctx, uint64_t n, int phase = RUN_
                 }
             }
         }
-        if (!agc_tr)
-        PDT_LAUNCH(64, k_agc_block<T>, dim3((unsigned)grid), dim3(64), 0, st, a_in, na, APs, d_norm, Ba, Wa,
-                           (const double *)d_guess, a_lock, a_out, (AgcSeam<T> *)ctx->seams_agc.p, agc_K);
+        T *agc_ckpt_any = (T *)agc_ckpt;
+        if (!agc_tr) {
+            // the per-lane walkers of the double-precision build leave checkpoints too (blocks of at least two of them)
+            if (sizeof(T) == 8 && Ba >= 2 * PDT_AGC_CKPT) {
+                if ((rc = ctx->agc_ckpt.ensure((size_t)(nb + 64) * (size_t)(Ba / PDT_AGC_CKPT) * sizeof(T)))) return rc;
+                agc_ckpt_any = (T *)ctx->agc_ckpt.p;
+            }
+            PDT_LAUNCH(64, k_agc_block<T>, dim3((unsigned)grid), dim3(64), 0, st, a_in, na, APs, d_norm, Ba, Wa,
+                               (const double *)d_guess, a_lock, a_out, (AgcSeam<T> *)ctx->seams_agc.p, agc_K, agc_ckpt_any);
+        }
         L.end();
         L.begin("agc_fix");
         PDT_LAUNCH(1024, k_agc_scan<T>, dim3(1), dim3(1024), 0, st, na, Ba, (const AgcSeam<T> *)ctx->seams_agc.p, &d_sc->agc_first_bad);
         PDT_LAUNCH(64, k_agc_fix<T>, dim3(1), dim3(64), 0, st, a_in, na, APs, Ba, a_lock, a_out,
-                           (AgcSeam<T> *)ctx->seams_agc.p, d_sc->counters, (const long long *)&d_sc->agc_first_bad, (T *)agc_ckpt);
+                           (AgcSeam<T> *)ctx->seams_agc.p, d_sc->counters, (const long long *)&d_sc->agc_first_bad, agc_ckpt_any);
         L.end();
     }
 
@@ -3050,7 +3057,7 @@ template <typename T> static int stage_agc(pdt_ctx *ctx, void *data_host, uint64
     PDT_LAUNCH(256, k_agc_affine<T>, dim3((unsigned)nb), dim3(256), 0, st, a_in, na, AP.decay, Ba, d_maps);
     PDT_LAUNCH(1024, k_agc_guess<T>, dim3(1), dim3(1024), 0, st, (const AgcMap *)d_maps, nb, (const T *)d_norm, d_guess, 1, nb);
     PDT_LAUNCH(64, k_agc_block<T>, dim3((unsigned)grid), dim3(64), 0, st, a_in, na, AP, d_norm, Ba, Wa, (const double *)d_guess,
-               (const T *)nullptr, a_out, (AgcSeam<T> *)ctx->seams_agc.p, agc_K);
+               (const T *)nullptr, a_out, (AgcSeam<T> *)ctx->seams_agc.p, agc_K, (T *)nullptr);
     PDT_LAUNCH(1024, k_agc_scan<T>, dim3(1), dim3(1024), 0, st, na, Ba, (const AgcSeam<T> *)ctx->seams_agc.p, &d_sc->agc_first_bad);
     PDT_LAUNCH(64, k_agc_fix<T>, dim3(1), dim3(64), 0, st, a_in, na, AP, Ba, (const T *)nullptr, a_out, (AgcSeam<T> *)ctx->seams_agc.p,
                d_sc->counters, (const long long *)&d_sc->agc_first_bad, (T *)nullptr);

@@ -2816,11 +2816,14 @@ __device__ __forceinline__ void k_agc_guess(const AgcMap *__restrict__ maps, lon
     }
 }
 
+#define PDT_AGC_CKPT 1024     // samples between two gain checkpoints of a block (a multiple of 32)
 template <typename T>
 __device__ __forceinline__ void k_agc_block(const T *__restrict__ in, long long n, AgcParams<T> P,
                                                    const T *__restrict__ norm, long long B, long long W,
                                                    const double *__restrict__ guesses, const T *__restrict__ lock,
-                                                   T *__restrict__ out, AgcSeam<T> *__restrict__ seams, double K)
+                                                   T *__restrict__ out, AgcSeam<T> *__restrict__ seams, double K,
+                                                   T *__restrict__ ckpt /* the gain after every PDT_AGC_CKPT samples of a block
+                                                                           (B / PDT_AGC_CKPT per block: k_agc_fix), or none */)
 {
     __shared__ __attribute__((aligned(16))) unsigned char ring[PDT_AGC_PF * PDT_RING_SLOT];
     const long long j = (long long)blockIdx.x * blockDim.x + threadIdx.x;
@@ -2849,7 +2852,18 @@ __device__ __forceinline__ void k_agc_block(const T *__restrict__ in, long long 
     agc_range<T, false>(in, lock, out, ws, start, gain, P, ring);
     AgcSeam<T> sm;
     sm.g0 = gain;
-    agc_range<T, true>(in, lock, out, start, end, gain, P, ring);
+    if (ckpt) {
+        // (round 4, the double-precision build: ARGOS' one open seam per capture -- gains equal to nine digits -- cost a whole
+        // block walk of the slow f64 step, 0.46 of the step's 17.9 ms)
+        const long long ncp = B / PDT_AGC_CKPT;
+        long long at = start;
+        for (long long c = 0; c < ncp && at + PDT_AGC_CKPT <= end; c++, at += PDT_AGC_CKPT) {
+            agc_range<T, true>(in, lock, out, at, at + PDT_AGC_CKPT, gain, P, ring);
+            ckpt[j * ncp + c] = gain;
+        }
+        agc_range<T, true>(in, lock, out, at, end, gain, P, ring);
+    } else
+        agc_range<T, true>(in, lock, out, start, end, gain, P, ring);
     sm.g1 = gain;
     seams[j] = sm;
 }
@@ -2866,7 +2880,6 @@ __device__ __forceinline__ void k_agc_block(const T *__restrict__ in, long long 
 // the transfer face and on the walker face, are conflict-free.  Loads are LDS-direct, R super-batches ahead; outputs go
 // through one staging super-batch.  Same arithmetic, same 16-sample calm batches: the outputs are those of agc_range bit
 // for bit (10.8 GB in 1.84 ms = 5.9 TB/s in the probe; 1.47 ms with the tile-granular warm-up below).
-#define PDT_AGC_CKPT 1024     // samples between two gain checkpoints of a block (a multiple of 32)
 #define PDT_TR_SLOT 1040
 #define PDT_TR_SB (8 * PDT_TR_SLOT)
 #ifndef PDT_AGC_TR_R
