@@ -60,13 +60,14 @@
 extern "C" {
 #endif
 
-/* 2 (round 4): + pdt_write_frames / pdt_write_records.  Behaviour a client of version 1 should know about, all of it
+/* 3 (round 5): + pdt_demod_file (capture file in, frame text out, in one call); pdt_demod_fd / pdt_demod_file demodulate a
+ * large POES file in segments while it is still being read BY DEFAULT again (round 4: only on request), after which
+ * pdt_read_stage / pdt_stage_len describe the last segment only.
+ * 2 (round 4): + pdt_write_frames / pdt_write_records.  Behaviour a client of version 1 should know about, all of it
  * introduced under version 1 in round 3 without a bump: pdt_build_tag, pdt_keep_pll, pdt_stage_bytesync_from and the error
  * code PDT_ERR_IO exist; every pdt_demod_* and pdt_stage_* entry returns PDT_ERR_STATE while a stream is open, and the first
- * pdt_stream_push_* opens one by itself (resetting frames and statistics); pdt_demod_fd may demodulate a large file in
- * segments while it is still being read (environment PDT_OVERLAP; off by default since version 2), after which
- * pdt_read_stage / pdt_stage_len describe the last segment only.                                                      */
-#define PDT_ABI_VERSION 2
+ * pdt_stream_push_* opens one by itself (resetting frames and statistics).                                              */
+#define PDT_ABI_VERSION 3
 
 enum { PDT_MODE_POES = 0, PDT_MODE_ARGOS = 1 };
 enum { PDT_SAMPLER_GARDNER = 0, PDT_SAMPLER_MM = 1 };
@@ -224,11 +225,20 @@ int  pdt_demod_pcm16(pdt_ctx *ctx, const int16_t *iq_host, uint64_t nframes);
  * as soon as the page cache and the PCIe link allow.  PDT_ERR_FORMAT when the file ends early, PDT_ERR_IO on a read error
  * (EINTR is retried).
  * Large POES captures (512 MiB and more, Gardner sampler, no pdt_keep_quality): the chain starts before the last span has
- * arrived and runs in four segments with carried state (the streaming path over the resident capture).  Frames, text and
- * pdt_get_stats' counts then describe the whole capture as ever; but pdt_read_stage / pdt_stage_len describe the LAST
- * SEGMENT only (window-local indices), the pll / agc seam counters and gpu_ms are the last segment's, and no stream is left
- * open behind the call.                                                                                                */
+ * arrived and runs in three unequal segments with carried state (the streaming path over the resident capture; 64 / 22 /
+ * 14 % of the capture, cut where a segment can use the whole-capture kernels, so that only the last, small one is left to run
+ * when the last byte has arrived).  Frames, text and pdt_get_stats' counts then describe the whole capture as ever; but
+ * pdt_read_stage / pdt_stage_len describe the LAST SEGMENT only (window-local indices), the pll / agc seam counters and
+ * gpu_ms are the last segment's, and no stream is left open behind the call.                                          */
 int  pdt_demod_fd(pdt_ctx *ctx, int fd, uint64_t byte_offset, uint64_t nframes, int sample_format);
+/* The whole job of POESTIPdemod/main.c:373-492 / ARGOSdemod/main.c:250-306 in one call: capture file in (as pdt_demod_fd), the
+ * minor-frame / packet text out to the descriptor text_fd, from its position on -- the reference's ByteSync.c:62-101 writes
+ * that text with fprintf WHILE it demodulates, and so does this: where the capture is demodulated in segments (above) the
+ * text of a finished segment is formatted and written while the next segment runs, so that what is left behind the last
+ * kernel is the last segment's text alone.  Otherwise it is pdt_demod_fd followed by pdt_write_frames.  *text_bytes (may be
+ * NULL) = bytes written.  pdt_frames / pdt_get_stats / pdt_format_frames afterwards as after pdt_demod_fd.  (ABI 3)     */
+int  pdt_demod_file(pdt_ctx *ctx, int fd, uint64_t byte_offset, uint64_t nframes, int sample_format, int text_fd,
+                    uint64_t *text_bytes);
 /* ... or already resident in device memory (no copy; buffer is only read).                      */
 int  pdt_demod_device(pdt_ctx *ctx, const void *iq_device, uint64_t nframes);
 

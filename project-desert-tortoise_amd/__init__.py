@@ -156,8 +156,9 @@ ABI_SYMBOLS = [
     "pdt_stream_begin", "pdt_stream_push_pcm16", "pdt_stream_push_f32", "pdt_stream_end", "pdt_stream_frames",
     "pdt_keep_quality", "pdt_chunk_reports", "pdt_stage_manchester", "pdt_stage_fir", "pdt_stage_agc", "pdt_stage_squelch", "pdt_stage_pll", "pdt_stage_gardner", "pdt_stage_static_gain", "pdt_stage_mm",
     "pdt_keep_presquelch", "pdt_keep_pll", "pdt_stage_bytesync_from", "pdt_demod_fd", "pdt_format_records", "pdt_stream_retained", "pdt_host_math", "pdt_get_device",
-    "pdt_write_frames", "pdt_write_records",
+    "pdt_write_frames", "pdt_write_records", "pdt_demod_file",
 ]
+DEV_SYMBOLS = ["pdt_dev_set"]        # include/pdt_dev.h (test-only)
 
 _lib = None
 
@@ -270,7 +271,9 @@ def lib():
     L.pdt_tip_frames.restype = C.c_uint64
     L.pdt_write_frames.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.c_uint64)]
     L.pdt_write_records.argtypes = [C.c_void_p, C.c_uint64, C.c_int, C.POINTER(C.c_uint64)]
-    if L.pdt_abi_version() != 2:
+    L.pdt_dev_set.argtypes = [C.c_char_p, C.c_char_p]
+    L.pdt_demod_file.argtypes = [C.c_void_p, C.c_int, C.c_uint64, C.c_uint64, C.c_int, C.c_int, C.POINTER(C.c_uint64)]
+    if L.pdt_abi_version() != 3:
         raise PdtError("libpdt.so ABI version mismatch")
     _lib = L
     return L
@@ -325,6 +328,18 @@ def read_wav(path: str) -> tuple[int, np.ndarray]:
     return rate, np.frombuffer(data, dtype="<i2", count=2 * n).reshape(n, 2)
 
 
+def sync_dev_switches(L=None):
+    """Mirror the process's PDT_* environment variables into the library's developer-switch registry (``pdt_dev_set``,
+    include/pdt_dev.h: a TEST-ONLY entry -- the library itself never reads the environment, and the C host programs never
+    call this).  Called before every ``pdt_open`` of this binding, so tests and sweeps keep saying
+    ``os.environ["PDT_GSPAN"] = "4"`` around the opening of a context."""
+    L = L or lib()
+    L.pdt_dev_set(None, None)
+    for k, v in os.environ.items():
+        if k.startswith("PDT_"):
+            L.pdt_dev_set(k.encode(), v.encode())
+
+
 class Demodulator:
     """One capture -> minor frames / packets on one GPU (context of include/pdt.h)."""
 
@@ -337,6 +352,7 @@ class Demodulator:
         cfg = Config(mode, sample_rate, chunk, norm_override, device, int(profile), pll_block, pll_warm, agc_block,
                      agc_warm, gardner_band_pad, sampler, chain, mm_step_range, mm_kp)
         self._h = C.c_void_p()
+        sync_dev_switches(self._L)
         _check(self._L.pdt_open(C.byref(cfg), C.byref(self._h)), "pdt_open")
         self.chain = chain
         self.dtype = np.float64 if (mode == MODE_ARGOS and not chain) else np.float32      # (the ARGOS twin is the float build)
@@ -525,6 +541,13 @@ class Demodulator:
         buf = C.create_string_buffer(cap)
         n = self._L.pdt_format_frames(self._h, buf, cap)
         return buf.raw[:n]
+
+    def demod_file_text(self, fd: int, byte_offset: int, nframes: int, text_fd: int, fmt: int = 0) -> int:
+        """``pdt_demod_file``: capture file in, frame text out to ``text_fd`` in one call (a large POES file: in overlapped
+        segments, each segment's text written while the next one runs); returns the number of text bytes written."""
+        nb = C.c_uint64(0)
+        _check(self._L.pdt_demod_file(self._h, int(fd), byte_offset, nframes, fmt, int(text_fd), C.byref(nb)), "pdt_demod_file")
+        return int(nb.value)
 
     def write_frames(self, fd: int) -> int:
         """The text of the last run written to an open file descriptor (``pdt_write_frames``: formatted and written in slices

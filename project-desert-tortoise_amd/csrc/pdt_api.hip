@@ -7,19 +7,24 @@
 #include <string.h>
 
 #include <errno.h>
+#include <fcntl.h>
 #include <unistd.h>
 
 #include <algorithm>
 #include <functional>
+#include <map>
+#include <mutex>
 #include <atomic>
 #include <chrono>
 #include <memory>
+#include <new>
 #include <string>
 #include <thread>
 #include <type_traits>
 #include <vector>
 
 #include "../../include/pdt.h"
+#include "../../include/pdt_dev.h"
 #include "pdt_kernels_back.h"
 #include "pdt_kernels_front.h"
 #include "pdt_timeaxis.h"
@@ -238,56 +243,74 @@ struct Plan {
 
 }  // namespace
 
-// Developer switches (A/B runs of older kernel variants, tuning sweeps).  Read from the environment ONCE, when the
-// context is opened; the demodulation calls never look at the environment.
+// Developer switches (A/B runs of older kernel variants, tuning sweeps).  The library never reads the environment: the
+// switches come from a process-wide registry that only the TEST-ONLY entry pdt_dev_set fills (include/pdt_dev.h; the Python
+// binding used by tests/ and bench.py mirrors the PDT_* environment variables into it), and a context takes its copy ONCE,
+// when it is opened.
+static std::mutex g_dev_mu;
+static std::map<std::string, std::string> g_dev;
 struct Tuning {
     double band_pad = 0.0, pll_warm_scale = 1.0, head_taus = 0.0, agc_k = 0.0, pll_warm_s = 0.0, agc_warm_s = 0.0;
+    double overlap_split[8] = { 0, 0, 0, 0, 0, 0, 0, 0 };
     int scout_syms = 0, gspan = 0, gspan_cap = 0, mf_waves = 8, ingest_threads = 0, ingest_span_mb = 0, ingest_streams = 0, overlap_segments = 0, overlap_min_mb = 0, fir_wg_per_cu = 0, agc_tpb = 0, gseg = 0, acquire_mode = 0, pll_block = 0, fix_passes = 2;      // acquire_mode: 0 = two-wavefront pipeline, 1 = plain one-lane, 2 = one wavefront
-    bool fir_generic = false, mix_unfused = false, quality_inline = false, gemit_groups = false, agc_unfused = false, no_excl = false, gtab_nomerge = false, gardner_onebuf = false, gardner_noring = false, gardner_sequential = false, seg_sequential = false, agc_lanes = false, overlap = false, debug_overlap = false, chain_one_range = false, ema_noguess = false, debug_sync = false, pll_noshort = false, pll_nockpt = false, pll_noconsensus = false;
+    bool fir_generic = false, mix_unfused = false, quality_inline = false, gemit_groups = false, agc_unfused = false, no_excl = false, gtab_nomerge = false, gardner_onebuf = false, gardner_noring = false, gardner_sequential = false, seg_sequential = false, agc_lanes = false, overlap = true, debug_overlap = false, chain_one_range = false, ema_noguess = false, debug_sync = false, pll_noshort = false, pll_nockpt = false, pll_noconsensus = false, seg_plain = false;
     void load()
     {
-        if (const char *e = getenv("PDT_PLL_WARM_SCALE")) pll_warm_scale = atof(e);
-        if (const char *e = getenv("PDT_HEAD_TAUS")) head_taus = atof(e);
-        if (const char *e = getenv("PDT_BAND_PAD")) band_pad = atof(e);
-        if (const char *e = getenv("PDT_PLL_WARM_S")) pll_warm_s = atof(e);
-        if (const char *e = getenv("PDT_AGC_WARM_S")) agc_warm_s = atof(e);
-        if (const char *e = getenv("PDT_AGC_K")) agc_k = atof(e);
-        if (const char *e = getenv("PDT_AGC_TPB")) agc_tpb = std::max(1, atoi(e));
-        if (const char *e = getenv("PDT_PLL_BLOCK")) pll_block = atoi(e);
-        if (const char *e = getenv("PDT_SCOUT_SYMS")) scout_syms = std::max(16, atoi(e));
-        if (const char *e = getenv("PDT_FIR_WG_PER_CU")) fir_wg_per_cu = std::min(4096, std::max(1, atoi(e)));
-        if (const char *e = getenv("PDT_INGEST_THREADS")) ingest_threads = std::min(128, std::max(1, atoi(e)));
-        if (const char *e = getenv("PDT_INGEST_SPAN_MB")) ingest_span_mb = std::min(256, std::max(1, atoi(e)));
-        if (const char *e = getenv("PDT_INGEST_STREAMS")) ingest_streams = std::min(4, std::max(1, atoi(e)));
-        if (const char *e = getenv("PDT_FIX_PASSES")) fix_passes = atoi(e);
-        if (const char *e = getenv("PDT_GSEG")) gseg = std::min(64, std::max(2, atoi(e)));
-        if (const char *e = getenv("PDT_GSPAN")) gspan = std::min(256, std::max(1, atoi(e)));
-        if (const char *e = getenv("PDT_MF_WAVES")) mf_waves = atoi(e) == 4 ? 4 : 8;
-        if (const char *e = getenv("PDT_GSPAN_CAP")) gspan_cap = std::max(64, atoi(e));          // (tests: rows that do not fit the key list)
-        if (getenv("PDT_ACQUIRE_SIMPLE")) acquire_mode = 1;
-        else if (getenv("PDT_ACQUIRE_ONEWAVE")) acquire_mode = 2;
-        fir_generic = getenv("PDT_FIR_GENERIC") != nullptr;
-        mix_unfused = getenv("PDT_MIX_UNFUSED") != nullptr;
-        quality_inline = getenv("PDT_QUALITY_INLINE") != nullptr;
-        gemit_groups = getenv("PDT_GEMIT_GROUPS") != nullptr;
-        agc_unfused = getenv("PDT_AGC_UNFUSED") != nullptr;
-        agc_lanes = getenv("PDT_AGC_LANES") != nullptr;           // the per-lane walkers of rounds 1 - 3 (k_agc_block)
-        no_excl = getenv("PDT_NO_EXCL") != nullptr;
-        gtab_nomerge = getenv("PDT_GTAB_NOMERGE") != nullptr;
-        gardner_onebuf = getenv("PDT_GARDNER_ONEBUF") != nullptr;
-        gardner_noring = getenv("PDT_GARDNER_NORING") != nullptr;
-        ema_noguess = getenv("PDT_EMA_NOGUESS") != nullptr;
-        gardner_sequential = getenv("PDT_GARDNER_SEQUENTIAL") != nullptr;
-        seg_sequential = getenv("PDT_SEG_SEQUENTIAL") != nullptr;
-        overlap = getenv("PDT_OVERLAP") != nullptr && getenv("PDT_NO_OVERLAP") == nullptr;
-        chain_one_range = getenv("PDT_CHAIN_ONE_RANGE") != nullptr;
-        debug_overlap = getenv("PDT_DEBUG_OVERLAP") != nullptr;
-        if (const char *e = getenv("PDT_OVERLAP_SEGMENTS")) overlap_segments = std::min(64, std::max(1, atoi(e)));
-        if (const char *e = getenv("PDT_OVERLAP_MIN_MB")) overlap_min_mb = std::min(1 << 20, std::max(1, atoi(e)));
-        debug_sync = getenv("PDT_DEBUG_SYNC") != nullptr;
-        pll_noshort = getenv("PDT_PLL_NOSHORT") != nullptr;
-        pll_nockpt = getenv("PDT_PLL_NOCKPT") != nullptr;
-        pll_noconsensus = getenv("PDT_PLL_NOCONSENSUS") != nullptr;
+        std::lock_guard<std::mutex> lock(g_dev_mu);
+        if (g_dev.empty()) return;
+        auto get = [&](const char *n) -> const char * { auto it = g_dev.find(n); return it == g_dev.end() ? nullptr : it->second.c_str(); };
+        if (const char *e = get("PDT_PLL_WARM_SCALE")) pll_warm_scale = atof(e);
+        if (const char *e = get("PDT_HEAD_TAUS")) head_taus = atof(e);
+        if (const char *e = get("PDT_BAND_PAD")) band_pad = atof(e);
+        if (const char *e = get("PDT_PLL_WARM_S")) pll_warm_s = atof(e);
+        if (const char *e = get("PDT_AGC_WARM_S")) agc_warm_s = atof(e);
+        if (const char *e = get("PDT_AGC_K")) agc_k = atof(e);
+        if (const char *e = get("PDT_AGC_TPB")) agc_tpb = std::max(1, atoi(e));
+        if (const char *e = get("PDT_PLL_BLOCK")) pll_block = atoi(e);
+        if (const char *e = get("PDT_SCOUT_SYMS")) scout_syms = std::max(16, atoi(e));
+        if (const char *e = get("PDT_FIR_WG_PER_CU")) fir_wg_per_cu = std::min(4096, std::max(1, atoi(e)));
+        if (const char *e = get("PDT_INGEST_THREADS")) ingest_threads = std::min(128, std::max(1, atoi(e)));
+        if (const char *e = get("PDT_INGEST_SPAN_MB")) ingest_span_mb = std::min(256, std::max(1, atoi(e)));
+        if (const char *e = get("PDT_INGEST_STREAMS")) ingest_streams = std::min(4, std::max(1, atoi(e)));
+        if (const char *e = get("PDT_FIX_PASSES")) fix_passes = atoi(e);
+        if (const char *e = get("PDT_GSEG")) gseg = std::min(64, std::max(2, atoi(e)));
+        if (const char *e = get("PDT_GSPAN")) gspan = std::min(256, std::max(1, atoi(e)));
+        if (const char *e = get("PDT_MF_WAVES")) mf_waves = atoi(e) == 4 ? 4 : 8;
+        if (const char *e = get("PDT_GSPAN_CAP")) gspan_cap = std::max(64, atoi(e));          // (tests: rows that do not fit the key list)
+        if (get("PDT_ACQUIRE_SIMPLE")) acquire_mode = 1;
+        else if (get("PDT_ACQUIRE_ONEWAVE")) acquire_mode = 2;
+        fir_generic = get("PDT_FIR_GENERIC") != nullptr;
+        mix_unfused = get("PDT_MIX_UNFUSED") != nullptr;
+        quality_inline = get("PDT_QUALITY_INLINE") != nullptr;
+        gemit_groups = get("PDT_GEMIT_GROUPS") != nullptr;
+        agc_unfused = get("PDT_AGC_UNFUSED") != nullptr;
+        agc_lanes = get("PDT_AGC_LANES") != nullptr;           // the per-lane walkers of rounds 1 - 3 (k_agc_block)
+        no_excl = get("PDT_NO_EXCL") != nullptr;
+        gtab_nomerge = get("PDT_GTAB_NOMERGE") != nullptr;
+        gardner_onebuf = get("PDT_GARDNER_ONEBUF") != nullptr;
+        gardner_noring = get("PDT_GARDNER_NORING") != nullptr;
+        ema_noguess = get("PDT_EMA_NOGUESS") != nullptr;
+        gardner_sequential = get("PDT_GARDNER_SEQUENTIAL") != nullptr;
+        seg_sequential = get("PDT_SEG_SEQUENTIAL") != nullptr;
+        overlap = get("PDT_NO_OVERLAP") == nullptr;            // (round 4: off unless PDT_OVERLAP; round 5: on)
+        if (const char *e = get("PDT_OVERLAP_SPLIT")) {          // "0.64,0.22,0.14": the segments' fractions of the capture
+            int k = 0;
+            for (const char *q = e; *q && k < 8; k++) {
+                char *end = nullptr;
+                overlap_split[k] = strtod(q, &end);
+                if (end == q) break;
+                q = (*end == ',') ? end + 1 : end;
+            }
+        }
+        chain_one_range = get("PDT_CHAIN_ONE_RANGE") != nullptr;
+        debug_overlap = get("PDT_DEBUG_OVERLAP") != nullptr;
+        if (const char *e = get("PDT_OVERLAP_SEGMENTS")) overlap_segments = std::min(64, std::max(1, atoi(e)));
+        if (const char *e = get("PDT_OVERLAP_MIN_MB")) overlap_min_mb = std::min(1 << 20, std::max(1, atoi(e)));
+        debug_sync = get("PDT_DEBUG_SYNC") != nullptr;
+        pll_noshort = get("PDT_PLL_NOSHORT") != nullptr;
+        pll_nockpt = get("PDT_PLL_NOCKPT") != nullptr;
+        pll_noconsensus = get("PDT_PLL_NOCONSENSUS") != nullptr;
+        seg_plain = get("PDT_SEG_PLAIN") != nullptr;        // stream segments on the stream path's kernels only (A/B)
     }
 };
 
@@ -298,6 +321,7 @@ struct StreamCarry {
     bool active = false;          // run_capture works on a window of a stream
     bool final_seg = false;       // the stream ends with this segment (short last chunk, partial frame reported)
     bool in_place = false;        // the whole capture has its place in the window (pdt_demod_fd of a large file): never slides
+    uint64_t place_align = 0;     // in place: the grid the window's origin stays on (0 = stream_align)
     long long first = 0;          // local index of the first new input sample (a multiple of the chunk)
     uint64_t origin = 0;          // global sample index of local sample 0 (a multiple of lcm(chunk, FIR ring length))
     // StaticGain / AGC
@@ -806,9 +830,14 @@ template <typename T> int run_capture(pdt_ctx *ctx, uint64_t n, int phase = RUN_
     Bp = std::max<long long>(64, (Bp + 63) / 64 * 64);         // whole transposition groups of the LT layout (pdt_kernels_front.h)
     // mix and filter in one kernel (k_mix_fir: the PLL output never goes through HBM): the float chain at INTERP 1 with the
     // register-tiled taps; its runs and ring phases need blocks of a multiple of lcm(64, 208) = 832 samples
+    // A stream segment may take the whole-capture kernels (k_mix_fir, the FIR kernel's AGC maps, k_agc_block_tr, table rows of
+    // several chunks) when its first new sample sits where those kernels' units begin: a multiple of the mix + FIR kernel's run
+    // (208 outputs: the AGC maps) and of a 128-byte line of the output streams (32 floats).  Round 5: the overlapped ingest of
+    // an hour-long file cuts its segments there (demod_overlapped); a pushed stream gets there when its pushes happen to.
+    const bool seg_fast = seg && first_out % PDT_MF_RUN == 0 && first_out % 32 == 0 && !ctx->tune.seg_plain;
     bool fuse_mix = false;
     if constexpr (std::is_same<T, float>::value) {
-        fuse_mix = !argos && !live && !inject && !seg && interp == 1 && ntaps == 26 && ctx->taps_rot.p && !ctx->tune.fir_generic &&
+        fuse_mix = !argos && !live && !inject && (!seg || seg_fast) && interp == 1 && ntaps == 26 && ctx->taps_rot.p && !ctx->tune.fir_generic &&
                    !ctx->tune.mix_unfused && N >= 832;
         if (fuse_mix && !ctx->cfg.pll_block) Bp = (Bp + 831) / 832 * 832;
         if (fuse_mix && Bp % 832 != 0) fuse_mix = false;
@@ -818,14 +847,14 @@ template <typename T> int run_capture(pdt_ctx *ctx, uint64_t n, int phase = RUN_
     // deliver the AGC's affine tile maps itself (0 = not fused: explicit block size, ARGOS, generic FIR)
     long long agc_tiles_per_block = 0, fused_tiles = 0, agc_maps_per_block = 0;
     if (!argos && !ctx->cfg.agc_block && ntaps == 26 * interp && ctx->taps_rot.p && !ctx->tune.fir_generic &&
-        !ctx->tune.agc_unfused && !seg) {
+        !ctx->tune.agc_unfused && (!seg || (seg_fast && first_out % (64ll * 26 * interp) == 0) || (seg_fast && fuse_mix))) {
         const long long tile_out = 64ll * 26 * interp;
         agc_tiles_per_block = std::max<long long>(1, (Ba + tile_out / 2) / tile_out);
         // a walker's look-ahead ring takes 64 KiB of LDS: two wavefronts per CU, 512 on the chip.  An hour at 250 ksps has more
         // blocks than that (940 wavefronts = two rounds, the second one of a few stragglers): longer blocks, one round
         // (4.2 -> 3.5 ms; tools/jobs/agc_tpb.sh).  (A batch shares the chip: no gain measured there.)
         {
-            const long long tiles = (n_out + tile_out - 1) / tile_out;
+            const long long tiles = (n_out - first_out + tile_out - 1) / tile_out;
             const long long one_round = (tiles + 500ll * 64 - 1) / (500ll * 64);
             if (ctx->batch_hint <= 1 && tiles / agc_tiles_per_block > 512ll * 64 && one_round <= 4 * agc_tiles_per_block)
                 agc_tiles_per_block = one_round;
@@ -1270,18 +1299,20 @@ template <typename T> int run_capture(pdt_ctx *ctx, uint64_t n, int phase = RUN_
                 }
                 // eight wavefronts per workgroup (two workgroups per CU = four wavefronts per SIMD); PDT_MF_WAVES=4: the first form
                 const unsigned mf_grid = (unsigned)(lt_tiles * (Bp / PDT_MF_RUN));
-                float *mf_pll = ctx->keep_pll ? (float *)d_pll : (float *)nullptr;
+                // (a stream segment keeps the PLL output's tail: the next segment's filter starts from its last 25 samples)
+                float *mf_pll = (ctx->keep_pll || seg) ? (float *)d_pll : (float *)nullptr;
+                const long long mf_pll_from = (seg && !ctx->keep_pll) ? std::max<long long>(0, N - 256) : 0ll;
 #define PDT_MF_ARGS d_pcm, (const float *)d_phi, (const float *)d_pll, N, Bp, (const PllLockInfo<float> *)d_info, (const float *)ctx->taps_rot.p, (float *)d_fir, mf_pll, run_maps, (float)AP.decay
                 if (ctx->tune.mf_waves == 4) {
-                    if (d_pcm.fmt == 0) PDT_LAUNCH(256, (k_mix_fir<26, 0, 4>), dim3(mf_grid), dim3(256), 0, st, PDT_MF_ARGS, (float *)nullptr);
-                    else PDT_LAUNCH(256, (k_mix_fir<26, 1, 4>), dim3(mf_grid), dim3(256), 0, st, PDT_MF_ARGS, (float *)nullptr);
+                    if (d_pcm.fmt == 0) PDT_LAUNCH(256, (k_mix_fir<26, 0, 4>), dim3(mf_grid), dim3(256), 0, st, PDT_MF_ARGS, (float *)nullptr, mf_pll_from);
+                    else PDT_LAUNCH(256, (k_mix_fir<26, 1, 4>), dim3(mf_grid), dim3(256), 0, st, PDT_MF_ARGS, (float *)nullptr, mf_pll_from);
                 } else if (quality_after_fir) {
                     float *d_tap = (float *)ctx->term_ap.p;
-                    if (d_pcm.fmt == 0) PDT_LAUNCH(512, (k_mix_fir<26, 0, 8, true>), dim3(mf_grid), dim3(512), 0, st, PDT_MF_ARGS, d_tap);
-                    else PDT_LAUNCH(512, (k_mix_fir<26, 1, 8, true>), dim3(mf_grid), dim3(512), 0, st, PDT_MF_ARGS, d_tap);
+                    if (d_pcm.fmt == 0) PDT_LAUNCH(512, (k_mix_fir<26, 0, 8, true>), dim3(mf_grid), dim3(512), 0, st, PDT_MF_ARGS, d_tap, mf_pll_from);
+                    else PDT_LAUNCH(512, (k_mix_fir<26, 1, 8, true>), dim3(mf_grid), dim3(512), 0, st, PDT_MF_ARGS, d_tap, mf_pll_from);
                 } else {
-                    if (d_pcm.fmt == 0) PDT_LAUNCH(512, (k_mix_fir<26, 0, 8>), dim3(mf_grid), dim3(512), 0, st, PDT_MF_ARGS, (float *)nullptr);
-                    else PDT_LAUNCH(512, (k_mix_fir<26, 1, 8>), dim3(mf_grid), dim3(512), 0, st, PDT_MF_ARGS, (float *)nullptr);
+                    if (d_pcm.fmt == 0) PDT_LAUNCH(512, (k_mix_fir<26, 0, 8>), dim3(mf_grid), dim3(512), 0, st, PDT_MF_ARGS, (float *)nullptr, mf_pll_from);
+                    else PDT_LAUNCH(512, (k_mix_fir<26, 1, 8>), dim3(mf_grid), dim3(512), 0, st, PDT_MF_ARGS, (float *)nullptr, mf_pll_from);
                 }
 #undef PDT_MF_ARGS
                 done = true;
@@ -1328,6 +1359,12 @@ template <typename T> int run_capture(pdt_ctx *ctx, uint64_t n, int phase = RUN_
         if (!fused && (rc = ctx->agc_maps.ensure((size_t)(nb + 1) * (sizeof(AgcMap) + sizeof(double))))) return rc;
         AgcMap *d_maps = (AgcMap *)ctx->agc_maps.p;
         double *d_guess = (double *)(d_maps + (fused ? fused_tiles : nb) + 1);
+        // (a stream segment: the FIR kernel's maps are indexed from the window's first output, the AGC's blocks from the first
+        // NEW one -- a whole number of maps further on, seg_fast)
+        const long long map_len_fused = fuse_mix ? (long long)PDT_MF_RUN : 64ll * 26 * interp;
+        const long long map_first = fused ? first_out / map_len_fused : 0;
+        const AgcMap *d_maps_in = d_maps + map_first;
+        const long long n_maps_in = fused ? fused_tiles - map_first : nb;
         // warm-up length in gain time constants: the affine guess is off by the accumulated float rounding of
         // the true recurrence only, so a few time constants make the trajectories agree to the last bit
         double agc_K = (sizeof(T) == 4) ? 11.0 : 34.0;
@@ -1338,12 +1375,12 @@ template <typename T> int run_capture(pdt_ctx *ctx, uint64_t n, int phase = RUN_
         if (agc_maps_per_block == 0) agc_maps_per_block = agc_tiles_per_block;        // (the FIR kernel's maps: one per tile)
         if (fused && agc_maps_per_block > 1) {
             AgcMap *d_bmaps = (AgcMap *)(d_guess + nb + 1);
-            PDT_LAUNCH(256, k_agc_blockmaps, dim3((unsigned)((nb + 255) / 256)), dim3(256), 0, st, (const AgcMap *)d_maps, nb,
-                               (int)agc_maps_per_block, fused_tiles, d_bmaps);
+            PDT_LAUNCH(256, k_agc_blockmaps, dim3((unsigned)((nb + 255) / 256)), dim3(256), 0, st, d_maps_in, nb,
+                               (int)agc_maps_per_block, n_maps_in, d_bmaps);
             PDT_LAUNCH(1024, k_agc_guess<T>, dim3(1), dim3(1024), 0, st, (const AgcMap *)d_bmaps, nb, (const T *)d_norm, d_guess, 1, nb);
         } else
-        PDT_LAUNCH(1024, k_agc_guess<T>, dim3(1), dim3(1024), 0, st, (const AgcMap *)d_maps, nb, (const T *)d_norm, d_guess,
-                           fused ? (int)agc_maps_per_block : 1, fused ? fused_tiles : nb);
+        PDT_LAUNCH(1024, k_agc_guess<T>, dim3(1), dim3(1024), 0, st, d_maps_in, nb, (const T *)d_norm, d_guess,
+                           fused ? (int)agc_maps_per_block : 1, n_maps_in);
         // (Round 3: walkers that store only the gain in front of every 16-sample batch + a streaming kernel that applies them were
         // slower, 4.2 against 3.3 ms at an hour of 250 ksps: the walkers are not held up by their output stores.)
         // Round 4: the walkers move whole lines (k_agc_block_tr) wherever the FIR kernel delivered its tile maps -- float chain,
@@ -1351,7 +1388,7 @@ template <typename T> int run_capture(pdt_ctx *ctx, uint64_t n, int phase = RUN_
         bool agc_tr = false;
         float *agc_ckpt = nullptr;
         if constexpr (std::is_same<T, float>::value) {
-            agc_tr = fused && !ctx->tune.agc_lanes && !APs.squelch && !APs.raw_out && first_out == 0 && Ba % 32 == 0 &&
+            agc_tr = fused && !ctx->tune.agc_lanes && !APs.squelch && !APs.raw_out && first_out % 32 == 0 && Ba % 32 == 0 &&
                      agc_maps_per_block > 0 && Ba % agc_maps_per_block == 0;
             if (agc_tr) {
                 const long long tile_len = 64ll * 26 * interp;                         // a FIR tile (= 8 runs of k_mix_fir)
@@ -1367,8 +1404,8 @@ template <typename T> int run_capture(pdt_ctx *ctx, uint64_t n, int phase = RUN_
                     if ((rc = ctx->agc_ckpt.ensure(ck_bytes))) return rc;
                     agc_ckpt = (float *)ctx->agc_ckpt.p;
                     PDT_LAUNCH(64, (k_agc_block_tr<PDT_AGC_TR_R>), dim3((unsigned)grid), dim3(64), 0, st, (const float *)a_in, na, APs,
-                               (const float *)d_norm, Ba, Wa, (const double *)d_guess, (const AgcMap *)d_maps, (int)agc_maps_per_block,
-                               (int)(tile_len / map_len), fused_tiles, tile_len, (float *)a_out, (AgcSeam<float> *)ctx->seams_agc.p, agc_K, agc_ckpt);
+                               (const float *)d_norm, Ba, Wa, (const double *)d_guess, d_maps_in, (int)agc_maps_per_block,
+                               (int)(tile_len / map_len), n_maps_in, tile_len, (float *)a_out, (AgcSeam<float> *)ctx->seams_agc.p, agc_K, agc_ckpt);
                 }
             }
         }
@@ -1427,21 +1464,25 @@ template <typename T> int run_capture(pdt_ctx *ctx, uint64_t n, int phase = RUN_
                 // only and the few distinct exits of a row's first chunk are walked on through the others (k_gardner_span):
                 // scouts, candidate walks and chain hops per span chunks instead of per chunk.  A row's symbol count must fit
                 // the table cell.  Stream segments keep one chunk per row (they are short, and enter with a carried state).
-                int span = ctx->tune.gspan > 0 ? ctx->tune.gspan : ((!seg && n_chunks >= 4096) ? 16 : 1);
-                if (seg || 2 * n_q > 32 * PDT_GSPAN_BITMAP_WORDS || 8 * (long long)stepf + 256 >= PDT_GSUB_WIN) span = 1;
-                while (span > 1 && ((double)span * max_count >= (double)((1u << (32 - idx_bits)) - 2u) || (n_chunks - 1) / span < 4))
+                // (Round 5: a stream segment too, when its first new chunk is where a row begins -- the rows are counted from the
+                // window's chunk 0, the few in front of the first new chunk are history nobody asks for.)
+                int span = ctx->tune.gspan > 0 ? ctx->tune.gspan : ((n_chunks - seg_c_first >= 4096 && (!seg || seg_fast)) ? 16 : 1);
+                if (2 * n_q > 32 * PDT_GSPAN_BITMAP_WORDS || 8 * (long long)stepf + 256 >= PDT_GSUB_WIN) span = 1;
+                while (span > 1 && ((double)span * max_count >= (double)((1u << (32 - idx_bits)) - 2u) || (n_chunks - 1) / span - seg_c_first / span < 4))
                     span /= 2;
+                auto row_aligned = [&](int sp) { return !seg || seg_c_first % sp == 0; };
                 if (span >= 8 && !ctx->tune.gspan) {
                     // the group behind the last row is walked by one wavefront, chunk after chunk (0.8 ms for 16 chunks): take the span
                     // near the wanted one that leaves the fewest chunks there
                     int best = span;
-                    long long best_left = n_chunks - ((n_chunks - 1) / span) * span;
+                    long long best_left = row_aligned(span) ? n_chunks - ((n_chunks - 1) / span) * span : (1ll << 62);
                     for (int sp = span - span / 4; sp <= span + span / 4; sp++) {
                         const long long left = n_chunks - ((n_chunks - 1) / sp) * sp;
-                        if (left < best_left && (double)sp * max_count < (double)((1u << (32 - idx_bits)) - 2u)) { best = sp; best_left = left; }
+                        if (left < best_left && row_aligned(sp) && (double)sp * max_count < (double)((1u << (32 - idx_bits)) - 2u)) { best = sp; best_left = left; }
                     }
                     span = best;
                 }
+                if (!row_aligned(span)) span = 1;
                 GD.span = span;
             }
         }
@@ -1509,6 +1550,9 @@ template <typename T> int run_capture(pdt_ctx *ctx, uint64_t n, int phase = RUN_
             SamplerCarry<float> tab_carry;                   // where the chain starts: chunk, state, symbols already in the buffer
             tab_carry.a = (float)carry_in.a; tab_carry.b = (float)carry_in.b; tab_carry.c = (float)carry_in.c;
             tab_carry.c_first = carry_in.c_first; tab_carry.count0 = carry_in.count0;
+            SamplerCarry<float> chain_carry = tab_carry;     // the chain counts in table rows (groups of GD.span chunks)
+            chain_carry.c_first = tab_carry.c_first / GD.span;
+            const long long g_first = chain_carry.c_first;
             if ((rc = ctx->gtable.ensure((size_t)n_tab * (size_t)(2 * GD.n_q) * sizeof(unsigned)))) return rc;
             if ((rc = ctx->gentries.ensure((size_t)n_chunks * sizeof(GardnerEntry<float>)))) return rc;
             if ((rc = ctx->gbands.ensure((size_t)n_tab * sizeof(GardnerBand)))) return rc;
@@ -1591,7 +1635,7 @@ template <typename T> int run_capture(pdt_ctx *ctx, uint64_t n, int phase = RUN_
                                    (const float *)d_agc, GP, GD, n_groups,
                                    (const unsigned *)ctx->gtable.p, (const GardnerSegCell *)ctx->gsegmap.p, G,
                                    (GardnerSegStart *)ctx->gsegstart.p, (GardnerEntry<float> *)ctx->gentries.p, d_sc->gstats,
-                                   (const GardnerBand *)ctx->gbands.p, n_tab, tab_carry, (seg && seg->have_sampler) ? 1 : 0, c_hi,
+                                   (const GardnerBand *)ctx->gbands.p, n_tab, chain_carry, (seg && seg->have_sampler) ? 1 : 0, c_hi,
                                    (GardnerChainState *)ctx->gchain.p, r == 0 ? 1 : 0,
                                    (const unsigned *)(GD.span > 1 ? ctx->gspan_keys.p : nullptr), (const unsigned *)(GD.span > 1 ? ctx->gspan_tails.p : nullptr),
                                    (const GardnerSpanRow *)(GD.span > 1 ? ctx->gspan_rows.p : nullptr));
@@ -1612,13 +1656,13 @@ template <typename T> int run_capture(pdt_ctx *ctx, uint64_t n, int phase = RUN_
                     if ((rc = ctx->gcentries.ensure((size_t)n_chunks * sizeof(GardnerEntry<float>)))) return rc;
                     if ((rc = ctx->gflags.ensure((size_t)n_groups + 64))) return rc;
                     PL.memset_async(ctx->gflags.p, 1, (size_t)n_groups, PL.side_of(st_emit));
-                    PDT_LAUNCH(64, (k_gardner_emit_first<PDT_GEMIT_SUB_WIN>), dim3((unsigned)((n_tab + 3) / 4)), dim3(64), 0, st_emit, (const float *)d_agc, GP, GD,
+                    PDT_LAUNCH(64, (k_gardner_emit_first<PDT_GEMIT_SUB_WIN>), dim3((unsigned)((n_tab - g_first + 3) / 4)), dim3(64), 0, st_emit, (const float *)d_agc, GP, GD,
                                        n_tab, (const GardnerEntry<float> *)ctx->gentries.p, (const unsigned *)ctx->gspan_keys.p,
                                        (const GardnerSpanRow *)ctx->gspan_rows.p, (const GardnerSpanRec *)ctx->gspan_recs.p,
-                                       (GardnerEntry<float> *)ctx->gcentries.p, (unsigned char *)ctx->gflags.p, (float *)d_sym, d_symidx, sym_cap);
-                    PDT_LAUNCH(64, (k_gardner_emit_rest<PDT_GEMIT_SUB_WIN>), dim3((unsigned)((n_tab * (GD.span - 1) + 3) / 4)), dim3(64), 0, st_emit,
+                                       (GardnerEntry<float> *)ctx->gcentries.p, (unsigned char *)ctx->gflags.p, (float *)d_sym, d_symidx, sym_cap, g_first);
+                    PDT_LAUNCH(64, (k_gardner_emit_rest<PDT_GEMIT_SUB_WIN>), dim3((unsigned)(((n_tab - g_first) * (GD.span - 1) + 3) / 4)), dim3(64), 0, st_emit,
                                        (const float *)d_agc, GP, GD, n_tab, (const GardnerEntry<float> *)ctx->gcentries.p,
-                                       (const unsigned char *)ctx->gflags.p, (float *)d_sym, d_symidx, sym_cap);
+                                       (const unsigned char *)ctx->gflags.p, (float *)d_sym, d_symidx, sym_cap, g_first);
                     d_flags = (const unsigned char *)ctx->gflags.p;
                 }
                 if (c_hi > c_lo)
@@ -1786,6 +1830,33 @@ template <typename T> int run_capture(pdt_ctx *ctx, uint64_t n, int phase = RUN_
         return (double)ctx->axis_f.at((uint64_t)((c - 1) * chunk + j + 1));   // stale value of the previous chunk
     };
 
+    // ---- per-kernel timings (profile mode)
+    auto collect_timers = [&]() {
+    ctx->ktimes.clear();
+    for (auto &t : ctx->timers) {
+        float tms = 0;
+        (void)hipEventElapsedTime(&tms, t.a, t.b);
+        bool found = false;
+        for (auto &k : ctx->ktimes)
+            if (t.name == k.name) {
+                k.launches++;
+                k.total_ms += tms;
+                found = true;
+            }
+        if (!found) {
+            pdt_kernel_time k;
+            memset(&k, 0, sizeof k);
+            snprintf(k.name, sizeof k.name, "%s", t.name.c_str());
+            k.launches = 1;
+            k.total_ms = tms;
+            ctx->ktimes.push_back(k);
+        }
+        if (!t.shared_a) ctx->event_pool.push_back(t.a);
+        ctx->event_pool.push_back(t.b);
+    }
+    ctx->timers.clear();
+    };
+
     if (seg) {
         // ---- stream segment: hand the new frames to the stream code, carry every stage's state to the next segment
         SegTail<T> tail;
@@ -1892,12 +1963,7 @@ template <typename T> int run_capture(pdt_ctx *ctx, uint64_t n, int phase = RUN_
         ctx->stage_len[PDT_ST_AGC_RAW] = 0;
         ctx->stage_len[PDT_ST_SYM] = ctx->stage_len[PDT_ST_SYMIDX] = sc.nsym;
         ctx->stage_len[PDT_ST_BITS] = ctx->stage_len[PDT_ST_BITSYM] = sc.nbits;
-        // timers of the segment are dropped (profile mode describes whole captures)
-        for (auto &t : ctx->timers) {
-            if (!t.shared_a) ctx->event_pool.push_back(t.a);
-            ctx->event_pool.push_back(t.b);
-        }
-        ctx->timers.clear();
+        collect_timers();                     // (profile mode: the kernel groups of the LAST segment)
         return PDT_OK;
     }
 
@@ -1956,30 +2022,7 @@ template <typename T> int run_capture(pdt_ctx *ctx, uint64_t n, int phase = RUN_
         o.time = frame_time(r.time_src, N);
     }
 
-    // ---- per-kernel timings
-    ctx->ktimes.clear();
-    for (auto &t : ctx->timers) {
-        float tms = 0;
-        (void)hipEventElapsedTime(&tms, t.a, t.b);
-        bool found = false;
-        for (auto &k : ctx->ktimes)
-            if (t.name == k.name) {
-                k.launches++;
-                k.total_ms += tms;
-                found = true;
-            }
-        if (!found) {
-            pdt_kernel_time k;
-            memset(&k, 0, sizeof k);
-            snprintf(k.name, sizeof k.name, "%s", t.name.c_str());
-            k.launches = 1;
-            k.total_ms = tms;
-            ctx->ktimes.push_back(k);
-        }
-        if (!t.shared_a) ctx->event_pool.push_back(t.a);
-        ctx->event_pool.push_back(t.b);
-    }
-    ctx->timers.clear();
+    collect_timers();
     return PDT_OK;
 }
 
@@ -2158,6 +2201,18 @@ int pdt_abi_version(void) { return PDT_ABI_VERSION; }
 #define PDT_BUILD_TAG "untagged"
 #endif
 const char *pdt_build_tag(void) { return PDT_BUILD_TAG; }
+
+// test-only (include/pdt_dev.h): set (value != NULL), remove (value == NULL) or clear (name == NULL) developer switches
+int pdt_dev_set(const char *name, const char *value)
+{
+    try {
+        std::lock_guard<std::mutex> lock(g_dev_mu);
+        if (!name) g_dev.clear();
+        else if (!value) g_dev.erase(name);
+        else g_dev[name] = value;
+    } catch (const std::exception &) { return PDT_ERR_NOMEM; }
+    return PDT_OK;
+}
 
 const char *pdt_strerror(int code)
 {
@@ -2476,7 +2531,7 @@ int pdt_demod_pcm16(pdt_ctx *ctx, const int16_t *iq_host, uint64_t nframes)
     return demod_common(ctx, nframes);
 }
 
-static int demod_overlapped(pdt_ctx *ctx, const IngestSrc &src, uint64_t nframes, int fmt);
+static int demod_overlapped(pdt_ctx *ctx, const IngestSrc &src, uint64_t nframes, int fmt, int text_fd, uint64_t *text_bytes);
 // hour-long POES captures: the chain starts on the part of the capture that has arrived (demod_overlapped)
 static bool overlap_ingest(const pdt_ctx *ctx, uint64_t nframes, size_t fb)
 {
@@ -2500,7 +2555,7 @@ int pdt_demod_fd(pdt_ctx *ctx, int fd, uint64_t byte_offset, uint64_t nframes, i
     src.fd = fd;
     src.off = byte_offset;
     if (ctx->stream_open) return PDT_ERR_STATE;
-    if (overlap_ingest(ctx, nframes, fb)) return demod_overlapped(ctx, src, nframes, sample_format == PDT_FMT_F32 ? 1 : 0);
+    if (overlap_ingest(ctx, nframes, fb)) return demod_overlapped(ctx, src, nframes, sample_format == PDT_FMT_F32 ? 1 : 0, -1, nullptr);
     int rc = ctx->pcm.ensure((size_t)nframes * fb + 16);
     if (rc) return rc;
     if ((rc = ingest_capture(ctx, src, (size_t)nframes * fb, ctx->pcm.p))) return rc;
@@ -3274,7 +3329,9 @@ static uint64_t stream_align(const pdt_ctx *ctx)
 
 // Demodulate the samples [stream_done, upto) of the window (whole chunks, or everything at the end of the stream) from the
 // carried state, append the frames that became final to frames_host / stream_new, then let the window slide.
-static int stream_segment(pdt_ctx *ctx, uint64_t upto, bool final_seg)
+// segment_begin / segment_end bracket the run (demod_common in one piece, or its enqueue and finish phases with the wait for
+// the segment's last bytes in between: demod_overlapped).
+static void segment_begin(pdt_ctx *ctx, bool final_seg)
 {
     StreamCarry &C = ctx->sc;
     C.active = true;
@@ -3283,9 +3340,22 @@ static int stream_segment(pdt_ctx *ctx, uint64_t upto, bool final_seg)
     // (in place: the window is a view into the resident capture -- it "slides" by moving its base, not its samples)
     ctx->pcm_dev = (const unsigned char *)ctx->stream_in.p + (C.in_place ? (size_t)C.origin * (ctx->stream_fmt ? 8 : 4) : 0);
     ctx->pcm_fmt = ctx->stream_fmt;
+}
+
+static int segment_end(pdt_ctx *ctx, uint64_t upto, bool final_seg);
+
+static int stream_segment(pdt_ctx *ctx, uint64_t upto, bool final_seg)
+{
+    segment_begin(ctx, final_seg);
     const int rc = demod_common(ctx, upto);
-    C.active = false;
+    ctx->sc.active = false;
     if (rc) return rc;
+    return segment_end(ctx, upto, final_seg);
+}
+
+static int segment_end(pdt_ctx *ctx, uint64_t upto, bool final_seg)
+{
+    StreamCarry &C = ctx->sc;
     for (const pdt_frame &f : C.seg_frames) {
         ctx->frames_host.push_back(f);
         ctx->stream_new.push_back(f);
@@ -3312,6 +3382,9 @@ static int stream_segment(pdt_ctx *ctx, uint64_t upto, bool final_seg)
     // new sample; the input window and the tails later segments look back on move with it
     uint64_t align = stream_align(ctx);
     if (C.in_place && (align & 3)) align *= (align & 1) ? 4 : 2;     // the view's base stays 16-byte aligned
+    // (the overlapped ingest cuts its segments where the whole-capture kernels' units begin, and keeps the window's origin --
+    // and with it every segment's first new sample -- on the same grid: demod_overlapped, run_capture's seg_fast)
+    if (C.in_place && C.place_align) align = C.place_align;
     const uint64_t hist = stream_history(ctx);
     const uint64_t done_g = C.origin + ctx->stream_done;
     const uint64_t new_origin = done_g > hist ? (done_g - hist) / align * align : 0;
@@ -3358,11 +3431,58 @@ static int stream_segment(pdt_ctx *ctx, uint64_t upto, bool final_seg)
     return PDT_OK;
 }
 
-// A large capture from a file or from host memory: the spans arrive in the background (ingest_capture with a job) straight into
-// the stream window, which holds the whole capture and never slides; the chain runs over it in a few segments with carried
-// state (exactly the streaming path), each as soon as its samples are there.  What the call leaves behind is what
-// pdt_stream_end leaves: frames and statistics; the stage arrays are those of the last segment.
-static int demod_overlapped(pdt_ctx *ctx, const IngestSrc &src, uint64_t nframes, int fmt)
+// A large capture from a file: the spans arrive in the background (ingest_capture with a job) straight into the stream window,
+// which holds the whole capture (its origin moves, its samples never do); the chain runs over it in a few segments with carried
+// state -- the streaming path -- each as soon as its samples are there.  What the call leaves behind is what pdt_stream_end
+// leaves: frames and statistics; the stage arrays are those of the last segment.
+//
+// Round 5.  (i) The segments are cut on the grid where a segment may use the whole-capture kernels (run_capture's seg_fast:
+// k_mix_fir, k_agc_block_tr, table rows of several chunks): a multiple of the reference chunk, of the AGC maps' runs, of a
+// 128-byte line and of 16 x 13 chunks (so that the table rows of either span begin at the first new chunk); the window's origin
+// stays on that grid too.  (ii) They are UNEQUAL.  A segment of the fraction x of an hour at 250 ksps costs about 7 + 11.5 x ms
+// of GPU time (the 7: one PLL warm-up of ~100 000 steps and the other stages' latency floors, whatever the length), the
+// segments run one after the other, and the ingest takes ~67 ms: segment j + 1's samples must take at least as long to arrive
+// as segment j takes to run -- x_{j+1} >= 0.104 + 0.172 x_j -- and what is exposed behind the last byte is the last segment
+// alone.  Three segments of 64 / 22 / 14 % leave 8.6 ms there (two: 76 / 24 %, 9.7 ms; four equal ones, round 3: 12 ms of
+// floor each, 49 ms in all).  (iii) A segment's launch plan is recorded BEFORE the host waits for its last span, and the text
+// of a finished segment is formatted and written (text_fd) while the next one runs.
+struct TextSink {
+    int fd = -1;
+    uint64_t bytes = 0;
+    int rc = PDT_OK;
+    std::thread th;
+    std::vector<pdt_frame> batch;
+    void wait() { if (th.joinable()) th.join(); }
+    void push(const std::vector<pdt_frame> &frames)       // (the previous batch is on the file before the next one starts)
+    {
+        if (fd < 0 || frames.empty()) return;
+        wait();
+        if (rc) return;
+        try {
+            batch = frames;
+            th = std::thread([this] {
+                uint64_t w = 0;
+                const int r = pdt_write_records(batch.data(), batch.size(), fd, &w);
+                bytes += w;
+                if (r) rc = r;
+            });
+        } catch (const std::exception &) {
+            uint64_t w = 0;
+            const int r = pdt_write_records(frames.data(), frames.size(), fd, &w);
+            bytes += w;
+            if (r) rc = r;
+        }
+    }
+};
+
+static uint64_t lcm_u64(uint64_t a, uint64_t b)
+{
+    uint64_t x = a, y = b;
+    while (y) { const uint64_t t = x % y; x = y; y = t; }
+    return a / x * b;
+}
+
+static int demod_overlapped(pdt_ctx *ctx, const IngestSrc &src, uint64_t nframes, int fmt, int text_fd, uint64_t *text_bytes)
 {
     const size_t fb = fmt ? 8 : 4;
     int rc = pdt_stream_begin(ctx);
@@ -3373,38 +3493,101 @@ static int demod_overlapped(pdt_ctx *ctx, const IngestSrc &src, uint64_t nframes
     if ((rc = ingest_capture(ctx, src, (size_t)nframes * fb, ctx->stream_in.p, &job))) { (void)ingest_join(job); return rc; }
     ctx->sc.in_place = true;
     const uint64_t chunk = ctx->cfg.chunk;
-    // Four segments: every segment pays the latency floor of the block-parallel stages once more (a PLL warm-up is as long for a
-    // quarter of the capture as for all of it: ~7 ms at 250 ksps), so more of them cost more than they hide (3.6 GB: 108 ms
-    // without overlap, 102 / 132 / 144 ms with 4 / 6 / 8 segments).
-    const int K = ctx->tune.overlap_segments > 0 ? ctx->tune.overlap_segments : 4;
-    uint64_t done = 0;
-    for (int k = 1; k <= K && !rc; k++) {
-        const bool last = k == K;
-        const uint64_t upto = last ? nframes : (nframes / (uint64_t)K * (uint64_t)k) / chunk * chunk;
-        if (!last && (upto <= done || upto >= nframes)) continue;
+    // the grid of the segment boundaries and of the window's origin (see above)
+    const uint64_t grid = lcm_u64(lcm_u64(chunk * 208, 64 * 26 * (uint64_t)ctx->interp), 416);
+    std::vector<double> cut;                                  // cumulative fractions of the capture at the segments' ends
+    if (ctx->tune.overlap_segments > 0) {
+        for (int k = 1; k < ctx->tune.overlap_segments; k++) cut.push_back((double)k / ctx->tune.overlap_segments);
+    } else if (ctx->tune.overlap_split[0] > 0) {
+        double acc = 0;
+        for (int k = 0; k < 8 && ctx->tune.overlap_split[k] > 0; k++) { acc += ctx->tune.overlap_split[k]; if (acc < 1.0) cut.push_back(acc); }
+    } else {
+        cut = { 0.64, 0.86 };
+    }
+    std::vector<uint64_t> ends;
+    if (grid * 8 <= nframes) {
+        ctx->sc.place_align = grid;
+        for (double c : cut) {
+            const uint64_t e = (uint64_t)llround(c * (double)nframes / (double)grid) * grid;
+            if (e > (ends.empty() ? 0 : ends.back()) && e + grid <= nframes) ends.push_back(e);
+        }
+    } else {
+        // (an unusual chunk size: no such grid inside the capture -- the round-3 form: equal segments on chunk boundaries, the
+        // stream path's kernels)
+        for (double c : cut) {
+            const uint64_t e = (uint64_t)(c * (double)nframes) / chunk * chunk;
+            if (e > (ends.empty() ? 0 : ends.back()) && e < nframes) ends.push_back(e);
+        }
+    }
+    ends.push_back(nframes);
+    TextSink sink;
+    sink.fd = text_fd;
+    ctx->batch_hint = 1;
+    for (size_t k = 0; k < ends.size() && !rc; k++) {
+        const bool last = k + 1 == ends.size();
+        const uint64_t upto = ends[k];
         const auto t0 = std::chrono::steady_clock::now();
-        if ((rc = ingest_wait_prefix(ctx, job, (size_t)upto * fb, ctx->stream))) break;
-        const auto t1 = std::chrono::steady_clock::now();
         ctx->stream_have = upto - ctx->sc.origin;                   // (window-local, as the pushes keep it)
         ctx->stream_total = upto;
         const uint64_t win = upto - ctx->sc.origin;
-        rc = stream_segment(ctx, win, last);
-        if (ctx->tune.debug_overlap) {
-            const auto t2 = std::chrono::steady_clock::now();
-            fprintf(stderr, "segment %d: upto %llu window %llu: waited %.2f ms for the spans, segment %.2f ms (gpu %.2f)\n", k,
-                    (unsigned long long)upto, (unsigned long long)win, std::chrono::duration<double, std::milli>(t1 - t0).count(),
-                    std::chrono::duration<double, std::milli>(t2 - t1).count(), ctx->stats.gpu_ms);
+        segment_begin(ctx, last);
+        rc = demod_common(ctx, win, RUN_ENQUEUE);                   // the segment's launch plan (host only) ...
+        const auto t1 = std::chrono::steady_clock::now();
+        if (!rc) rc = ingest_wait_prefix(ctx, job, (size_t)upto * fb, ctx->stream);      // ... then its last bytes ...
+        const auto t2 = std::chrono::steady_clock::now();
+        if (!rc) {
+            pdt_ctx *self = ctx;
+            rc = execute_plans(&self, 1);                           // ... then the launches
         }
-        done = upto;
+        if (!rc) rc = demod_common(ctx, win, RUN_FINISH);
+        ctx->sc.active = false;
+        ctx->pending = false;
+        if (!rc) rc = segment_end(ctx, win, last);
+        if (!rc && !last) sink.push(ctx->sc.seg_frames);
+        if (ctx->tune.debug_overlap) {
+            const auto t3 = std::chrono::steady_clock::now();
+            auto ms = [](auto a, auto b) { return std::chrono::duration<double, std::milli>(b - a).count(); };
+            fprintf(stderr, "segment %zu: upto %llu window %llu: plan %.2f ms, waited %.2f ms for the spans, run %.2f ms (gpu %.2f)\n", k,
+                    (unsigned long long)upto, (unsigned long long)win, ms(t0, t1), ms(t1, t2), ms(t2, t3), ctx->stats.gpu_ms);
+        }
     }
     ctx->sc.in_place = false;
     const int rj = ingest_join(job);
+    sink.wait();
+    if (!rc && !rj && text_fd >= 0) {
+        if (sink.rc) rc = sink.rc;
+        else {
+            uint64_t w = 0;
+            rc = pdt_write_records(ctx->sc.seg_frames.data(), ctx->sc.seg_frames.size(), text_fd, &w);
+            sink.bytes += w;
+        }
+    }
+    if (text_bytes) *text_bytes = sink.bytes;
     // the stream machinery was borrowed: leave no stream behind (a later push starts a new one), keep frames and statistics
     ctx->sc = StreamCarry();
     ctx->stream_have = ctx->stream_done = ctx->stream_total = 0;
     ctx->stream_fmt = -1;
     ctx->stream_open = false;
     return rc ? rc : rj;
+}
+
+int pdt_demod_file(pdt_ctx *ctx, int fd, uint64_t byte_offset, uint64_t nframes, int sample_format, int text_fd, uint64_t *text_bytes)
+{
+    if (text_bytes) *text_bytes = 0;
+    if (!ctx || fd < 0 || text_fd < 0 || (sample_format != PDT_FMT_PCM16 && sample_format != PDT_FMT_F32)) return PDT_ERR_ARG;
+    if (sample_format == PDT_FMT_F32 && ctx->elem != 4) return PDT_ERR_FORMAT;
+    if (ctx->stream_open) return PDT_ERR_STATE;
+    HIP_TRY(hipSetDevice(ctx->cfg.device));
+    const size_t fb = sample_format == PDT_FMT_F32 ? 8 : 4;
+    if (overlap_ingest(ctx, nframes, fb)) {
+        IngestSrc src;
+        src.fd = fd;
+        src.off = byte_offset;
+        return demod_overlapped(ctx, src, nframes, sample_format == PDT_FMT_F32 ? 1 : 0, text_fd, text_bytes);
+    }
+    const int rc = pdt_demod_fd(ctx, fd, byte_offset, nframes, sample_format);
+    if (rc) return rc;
+    return pdt_write_frames(ctx, text_fd, text_bytes);
 }
 
 static int stream_push(pdt_ctx *ctx, const void *host, uint64_t nframes, int fmt, uint64_t *new_frames)
@@ -3657,16 +3840,30 @@ int pdt_write_records(const pdt_frame *frames, uint64_t nframes, int fd, uint64_
     if (bytes_written) *bytes_written = 0;
     if (fd < 0 || (!frames && nframes)) return PDT_ERR_ARG;
     if (!nframes) return PDT_OK;
-    const off_t at0 = lseek(fd, 0, SEEK_CUR);
+    off_t at0 = lseek(fd, 0, SEEK_CUR);
+    {
+        // pwrite on an O_APPEND descriptor ignores its offset and appends (Linux): the slices would land in completion order
+        const int fl = fcntl(fd, F_GETFL);
+        if (fl >= 0 && (fl & O_APPEND)) at0 = -1;            // ... so such a descriptor takes the text in order, like a pipe
+    }
     const int T = at0 < 0 ? 1 : (int)std::max<uint64_t>(1, std::min<uint64_t>(6, nframes / 2048));
-    std::vector<uint64_t> first((size_t)T + 1);
+    std::vector<uint64_t> first;
+    std::unique_ptr<std::atomic<long long>[]> size;
+    try {                                                     // (no exception crosses the C boundary, in this thread or a worker)
+        first.resize((size_t)T + 1);
+        size.reset(new std::atomic<long long>[(size_t)T]);
+    } catch (const std::bad_alloc &) { return PDT_ERR_NOMEM; }
     for (int t = 0; t <= T; t++) first[(size_t)t] = nframes * (uint64_t)t / (uint64_t)T;
-    std::unique_ptr<std::atomic<long long>[]> size(new std::atomic<long long>[(size_t)T]);
     for (int t = 0; t < T; t++) size[(size_t)t].store(-1);
-    std::atomic<int> bad{0};
+    std::atomic<int> bad{0};                                  // 1: write error, 2: out of memory
     auto work = [&](int t) {
         const uint64_t a = first[(size_t)t], b = first[(size_t)t + 1];
-        std::unique_ptr<char[]> buf(new char[(size_t)(b - a) * (PDT_TIME5_MAX + 4 + 3 * 104 + 2)]);     // (not touched beyond the text)
+        std::unique_ptr<char[]> buf(new (std::nothrow) char[(size_t)(b - a) * (PDT_TIME5_MAX + 4 + 3 * 104 + 2)]);     // (not touched beyond the text)
+        if (!buf) {
+            bad = 2;
+            size[(size_t)t].store(0, std::memory_order_release);         // (the slices behind this one must not wait for ever)
+            return;
+        }
         const uint64_t sz = pdt_format_records(frames + a, b - a, buf.get(), ~0ull);
         size[(size_t)t].store((long long)sz, std::memory_order_release);
         uint64_t off = 0;
@@ -3676,7 +3873,7 @@ int pdt_write_records(const pdt_frame *frames, uint64_t nframes, int fd, uint64_
             off += (uint64_t)v;
         }
         size_t done = 0;
-        while (done < sz) {
+        while (done < sz && !bad) {
             const ssize_t r = at0 >= 0 ? pwrite(fd, buf.get() + done, sz - done, at0 + (off_t)off + (off_t)done)
                                        : write(fd, buf.get() + done, sz - done);
             if (r < 0 && errno == EINTR) continue;
@@ -3685,9 +3882,15 @@ int pdt_write_records(const pdt_frame *frames, uint64_t nframes, int fd, uint64_
         }
     };
     std::vector<std::thread> pool;
-    for (int t = 1; t < T; t++) pool.emplace_back(work, t);
+    int started = 1;
+    try {
+        for (int t = 1; t < T; t++, started++) pool.emplace_back(work, t);
+    } catch (const std::exception &) {                        // std::system_error (no thread), std::bad_alloc
+    }
     work(0);
+    for (int t = started; t < T; t++) work(t);                // slices that got no thread: here, in order
     for (auto &th : pool) th.join();
+    if (bad == 2) return PDT_ERR_NOMEM;
     if (bad) return PDT_ERR_IO;
     uint64_t total = 0;
     for (int t = 0; t < T; t++) total += (uint64_t)size[(size_t)t].load();

@@ -63,6 +63,7 @@ struct pdt_gatherer {
     std::vector<unsigned char *> pin;                        // pinned staging per rank (records up)
     unsigned char *pin_root = nullptr;                       // ... and for the root's copy down
     size_t cap = 0, pin_root_cap = 0;                        // records the per-rank buffers hold
+    bool dead = false;                                       // a collective failed: the communicators may be unusable (aborted on close)
     std::mutex mu;
 };
 
@@ -122,7 +123,7 @@ extern "C" void pdt_gatherer_close(pdt_gatherer *g)
         if (g->d_cnt[(size_t)i]) (void)hipFree(g->d_cnt[(size_t)i]);
         if (g->d_all[(size_t)i]) (void)hipFree(g->d_all[(size_t)i]);
         if (g->st[(size_t)i]) (void)hipStreamDestroy(g->st[(size_t)i]);
-        if (g->comm[(size_t)i]) (void)ncclCommDestroy(g->comm[(size_t)i]);
+        if (g->comm[(size_t)i]) (void)(g->dead ? ncclCommAbort(g->comm[(size_t)i]) : ncclCommDestroy(g->comm[(size_t)i]));
     }
     delete g;
 }
@@ -133,8 +134,10 @@ extern "C" int pdt_gatherer_gather(pdt_gatherer *g, const pdt_frame *const *reco
 {
     if (!g || !records || !counts_in || !out || !counts || root < 0 || root >= g->n) return PDT_ERR_ARG;
     std::lock_guard<std::mutex> lock(g->mu);
+    if (g->dead) return PDT_ERR_STATE;                       // an earlier collective failed: open a new gatherer
     const int n = g->n;
     int rc = PDT_OK;
+    bool in_group = false;                                   // between ncclGroupStart and ncclGroupEnd
     std::vector<unsigned long long> all((size_t)n, 0);
     uint64_t nmax = 1;
     *out = nullptr;
@@ -146,8 +149,10 @@ extern "C" int pdt_gatherer_gather(pdt_gatherer *g, const pdt_frame *const *reco
         G_TRY(hipStreamSynchronize(g->st[(size_t)i]), PDT_ERR_NOGPU);            // (v leaves scope)
     }
     G_TRY(ncclGroupStart(), PDT_ERR_NOGPU);
+    in_group = true;
     for (int i = 0; i < n; i++)
         G_TRY(ncclAllGather(g->d_cnt[(size_t)i], g->d_all[(size_t)i], 1, ncclUint64, g->comm[(size_t)i], g->st[(size_t)i]), PDT_ERR_NOGPU);
+    in_group = false;
     G_TRY(ncclGroupEnd(), PDT_ERR_NOGPU);
     G_TRY(hipSetDevice(g->dev[(size_t)root]), PDT_ERR_NOGPU);
     G_TRY(hipMemcpyAsync(all.data(), g->d_all[(size_t)root], sizeof(unsigned long long) * (size_t)n, hipMemcpyDeviceToHost, g->st[(size_t)root]),
@@ -179,9 +184,11 @@ extern "C" int pdt_gatherer_gather(pdt_gatherer *g, const pdt_frame *const *reco
                              g->st[(size_t)i]), PDT_ERR_NOGPU);
     }
     G_TRY(ncclGroupStart(), PDT_ERR_NOGPU);
+    in_group = true;
     for (int i = 0; i < n; i++)
         G_TRY(ncclAllGather(g->d_rec[(size_t)i], g->d_gath[(size_t)i], (size_t)nmax * sizeof(pdt_frame), ncclUint8, g->comm[(size_t)i],
                             g->st[(size_t)i]), PDT_ERR_NOGPU);
+    in_group = false;
     G_TRY(ncclGroupEnd(), PDT_ERR_NOGPU);
     {
         uint64_t total = 0;
@@ -200,6 +207,10 @@ extern "C" int pdt_gatherer_gather(pdt_gatherer *g, const pdt_frame *const *reco
         *out = res;
     }
 done:
+    // a failure inside a group leaves it open, and a failed collective leaves the communicators in an unknown state: close the
+    // group, and never use this gatherer again (pdt_gather_frames evicts it from its cache; pdt_gatherer_close aborts it)
+    if (in_group) (void)ncclGroupEnd();
+    if (rc == PDT_ERR_NOGPU) g->dead = true;
     for (int i = 0; i < n; i++) {                            // (every rank's stream is idle when this returns)
         (void)hipSetDevice(g->dev[(size_t)i]);
         (void)hipStreamSynchronize(g->st[(size_t)i]);
@@ -246,5 +257,11 @@ extern "C" int pdt_gather_frames(pdt_ctx *const *ctxs, int n, int root, pdt_fram
         if (cnt[(size_t)i]) pdt_frames(ctxs[i], mine[(size_t)i].data(), cnt[(size_t)i]);
         ptr[(size_t)i] = mine[(size_t)i].data();
     }
-    return pdt_gatherer_gather(g, ptr.data(), cnt.data(), root, out, counts);
+    const int rc = pdt_gatherer_gather(g, ptr.data(), cnt.data(), root, out, counts);
+    if (g->dead) {                                           // the next call opens a fresh set of communicators
+        std::lock_guard<std::mutex> lock(g_cache_mu);
+        g_cache.erase(std::remove(g_cache.begin(), g_cache.end(), g), g_cache.end());
+        pdt_gatherer_close(g);
+    }
+    return rc;
 }

@@ -1603,15 +1603,19 @@ __device__ __forceinline__ void k_gardner_span_keys(GardnerDomain D, long long n
     }
     const unsigned total = s_scan[255];
     if (tid == 0) {
-        unsigned off = atomicAdd(&ctl->keys, total);
-        if ((unsigned long long)off + total > cap_keys) {
-            // (the reservation is given back, so that the cursor stays near cap_keys however many rows fail: left to grow, a
-            // very long noise-only capture could wrap it around 2^32 and a later row would pass this test with a wrapped `off`)
-            atomicSub(&ctl->keys, total);
-            off = ~0u;
-            atomicAdd(&ctl->overflow, 1u);
-        } else
-            s_item = atomicAdd(&ctl->items, (total + (unsigned)PDT_GSUB_KEYS - 1u) / (unsigned)PDT_GSUB_KEYS);
+        // Space in the shared key list is reserved with a compare-and-swap that only ever succeeds when the row fits: the cursor
+        // never passes cap_keys (no wrap around 2^32 however many rows fail) and a failed row leaves it untouched -- handing a
+        // failed fetch-and-add back with a subtraction could give two later rows the same range.
+        unsigned off = ~0u;
+        unsigned cur = __hip_atomic_load(&ctl->keys, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        for (;;) {
+            if ((unsigned long long)cur + total > cap_keys) break;
+            const unsigned seen = atomicCAS(&ctl->keys, cur, cur + total);
+            if (seen == cur) { off = cur; break; }
+            cur = seen;
+        }
+        if (off == ~0u) atomicAdd(&ctl->overflow, 1u);
+        else s_item = atomicAdd(&ctl->items, (total + (unsigned)PDT_GSUB_KEYS - 1u) / (unsigned)PDT_GSUB_KEYS);
         s_off = off;
     }
     __syncthreads();
@@ -1877,12 +1881,13 @@ __device__ __forceinline__ void k_gardner_emit_first(const float *__restrict__ i
                                                      const unsigned *__restrict__ keys, const GardnerSpanRow *__restrict__ rows,
                                                      const GardnerSpanRec *__restrict__ recs,
                                                      GardnerEntry<float> *__restrict__ centries, unsigned char *__restrict__ flags,
-                                                     float *__restrict__ sym, long long *__restrict__ symidx, long long sym_cap)
+                                                     float *__restrict__ sym, long long *__restrict__ symidx, long long sym_cap,
+                                                     long long g_first = 0 /* a stream segment: the rows in front are history (no entry states) */)
 {
     __shared__ __attribute__((aligned(16))) float win[4 * WIN];
     const int lane = threadIdx.x;
     const int mysub = lane >> 4;
-    const long long g0 = (long long)blockIdx.x * 4;
+    const long long g0 = g_first + (long long)blockIdx.x * 4;
     if (g0 >= n_rows) return;
     long long c_sub[4];
 #pragma unroll
@@ -1926,14 +1931,14 @@ template <int WIN>
 __device__ __forceinline__ void k_gardner_emit_rest(const float *__restrict__ in, GardnerParams<float> P, GardnerDomain D,
                                                     long long n_rows, const GardnerEntry<float> *__restrict__ centries,
                                                     const unsigned char *__restrict__ flags, float *__restrict__ sym,
-                                                    long long *__restrict__ symidx, long long sym_cap)
+                                                    long long *__restrict__ symidx, long long sym_cap, long long g_first = 0)
 {
     __shared__ __attribute__((aligned(16))) float win[4 * WIN];
     const int lane = threadIdx.x;
     const int mysub = lane >> 4;
     const long long per = D.span - 1;                       // chunks of a group that are not its first
     const long long total = n_rows * per;
-    const long long i0 = (long long)blockIdx.x * 4;
+    const long long i0 = g_first * per + (long long)blockIdx.x * 4;
     if (i0 >= total) return;
     // the chunk of every sub-group; one whose group is flagged (or past the end) shadows a chunk that is walked -- if there is none
     // in this wavefront, there is nothing to do

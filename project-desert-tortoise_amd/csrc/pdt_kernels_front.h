@@ -2166,7 +2166,9 @@ __device__ __forceinline__ void k_mix_fir(IqSrc pcm, const float *__restrict__ p
                                           const float *__restrict__ rot /* host-built rotated taps */, float *__restrict__ out,
                                           float *pll_out /* nullptr: the PLL output is not kept; the host passes the same buffer as
                                                             pll_pre (reads before the lock, writes behind it): no __restrict__ */,
-                                          AgcMap *__restrict__ run_maps, float agc_decay, float *__restrict__ term_out = nullptr)
+                                          AgcMap *__restrict__ run_maps, float agc_decay, float *__restrict__ term_out = nullptr,
+                                          long long pll_from = 0 /* pll_out is written from this sample on only (a stream segment
+                                                                    keeps just the tail the next segment's filter starts from) */)
 {
     static_assert(PDT_MF_RUN == 8 * K && PDT_MF_HALO >= K - 1 && PDT_MF_HALO % 4 == 0, "run = 8 ring revolutions, halo = whole phase vectors");
     static_assert(NWV == 4 || NWV == 8, "four or eight wavefronts per workgroup");
@@ -2260,7 +2262,10 @@ __device__ __forceinline__ void k_mix_fir(IqSrc pcm, const float *__restrict__ p
                 float tq = 0.0f;
                 const float x = mix(raw[it], *cell, tq);
                 *cell = x;
-                if (pll_out && col >= PDT_MF_HALO) pll_out[(blk0 + wave * RPW + rr) * B + p0 - PDT_MF_HALO + col] = x;
+                if (pll_out && col >= PDT_MF_HALO) {
+                    const long long io = (blk0 + wave * RPW + rr) * B + p0 - PDT_MF_HALO + col;
+                    if (io >= pll_from) pll_out[io] = x;
+                }
                 if (QT && col >= PDT_MF_HALO) term_out[(blk0 + wave * RPW + rr) * B + p0 - PDT_MF_HALO + col] = tq;
                 if ((it & 3) == 3) __builtin_amdgcn_sched_barrier(0);  // four evaluations interleaved, not fifty-nine (registers)
             }
@@ -2275,7 +2280,7 @@ __device__ __forceinline__ void k_mix_fir(IqSrc pcm, const float *__restrict__ p
                 if (i >= S && i < n) {
                     float tq = 0.0f;
                     x = mix(reinterpret_cast<const Raw *>(pcm.p)[i], *cell, tq);
-                    if (pll_out && col >= PDT_MF_HALO) pll_out[i] = x;
+                    if (pll_out && col >= PDT_MF_HALO && i >= pll_from) pll_out[i] = x;
                     if (QT && col >= PDT_MF_HALO) term_out[i] = tq;
                 } else if (i >= 0 && i < n)
                     x = pll_pre[i];                                    // up to the lock: the acquisition's output

@@ -398,8 +398,10 @@ int main(int argc, char **argv)
     if (rc == PDT_OK && outputRawFiles) {
         /* ARGOSdemod -r: every chunk's post-AGC, pre-Squelch doubles, appended to output.raw (main.c:171-180,273-274) */
         FILE *raw = fopen("output.raw", "wb");
+        /* (the sound-card twin, -l, is the float build: its DECIMAL_TYPE -- and this context's stage elements -- are floats) */
+        const size_t es = live ? sizeof(float) : sizeof(double);
         const uint64_t total = pdt_stage_len(ctx, PDT_ST_AGC_RAW), piece = 1u << 20;
-        double *tmp = (double *)malloc((size_t)piece * sizeof(double));
+        void *tmp = malloc((size_t)piece * sizeof(double));
         if (!raw || !tmp) {
             printf("Error opening output file\n");
             exit(1);
@@ -407,7 +409,7 @@ int main(int argc, char **argv)
         for (uint64_t at = 0; at < total; at += piece) {
             const int64_t got = pdt_read_stage(ctx, PDT_ST_AGC_RAW, at, piece, tmp);
             if (got <= 0) break;
-            fwrite(tmp, sizeof(double), (size_t)got, raw);
+            fwrite(tmp, es, (size_t)got, raw);
         }
         fclose(raw);
         free(tmp);

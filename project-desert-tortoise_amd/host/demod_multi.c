@@ -158,7 +158,7 @@ int main(int argc, char **argv)
     const double t_demod = now_s() - t_all;
 
     /* ---- gather: rank i = GPU i's records, its captures in the order it took them; one gatherer for the run */
-    int failed = 0, ranks = 0;
+    int failed = 0, ranks = 0, failed_alloc = 0;
     int *devs = (int *)calloc((size_t)ngpu, sizeof(int));
     pdt_frame **rec = (pdt_frame **)calloc((size_t)ngpu, sizeof(pdt_frame *));
     uint64_t *cnt = (uint64_t *)calloc((size_t)ngpu, sizeof(uint64_t)), *got = (uint64_t *)calloc((size_t)ngpu, sizeof(uint64_t));
@@ -177,11 +177,13 @@ int main(int argc, char **argv)
                     memcpy(rec[ranks] + at, g_cap[k].frames, (size_t)g_cap[k].nfr * sizeof(pdt_frame));
                     at += g_cap[k].nfr;
                 }
+        if (!rec[ranks]) failed_alloc = 1;
         ranks++;
     }
     pdt_frame *all = NULL;
-    int grc = PDT_OK;
-    if (ranks) {
+    int grc = failed_alloc ? PDT_ERR_NOMEM : PDT_OK;               /* no staging copy: no gather (every capture keeps its own frames) */
+    if (grc != PDT_OK) printf("gather skipped (%s): every capture's frames are taken from its own GPU's copy\n", pdt_strerror(grc));
+    if (ranks && grc == PDT_OK) {
         pdt_gatherer *g = NULL;
         grc = pdt_gatherer_open(devs, ranks, &g);
         if (grc == PDT_OK) grc = pdt_gatherer_gather(g, (const pdt_frame *const *)rec, cnt, 0, &all, got);   /* RCCL: counts, then padded records */

@@ -12,8 +12,8 @@ import pytest
 from conftest import GOLDEN, ROOT
 
 
-def header_functions():
-    src = open(os.path.join(ROOT, "include", "pdt.h")).read()
+def header_functions(name="pdt.h"):
+    src = open(os.path.join(ROOT, "include", name)).read()
     src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
     return sorted(set(re.findall(r"\b(pdt_[a-z0-9_]+)\s*\(", src)))
 
@@ -29,6 +29,20 @@ def test_exports_every_declared_symbol(pdt):
     for n in names:
         assert hasattr(L, n), f"{n} declared in include/pdt.h but not exported by libpdt.so"
     assert set(pdt.ABI_SYMBOLS) == set(names)
+    # the test-only entry (include/pdt_dev.h): the developer switches' registry
+    dev = header_functions("pdt_dev.h")
+    assert dev == sorted(pdt.DEV_SYMBOLS)
+    for n in dev:
+        assert hasattr(L, n)
+
+
+def test_the_product_never_reads_the_environment(pdt):
+    """Developer switches reach the library through pdt_dev_set only: no getenv in libpdt.so, the host
+    programs or the gather library."""
+    for rel in ("csrc/libpdt.so", "csrc/libpdtgather.so"):
+        path = os.path.join(os.path.dirname(os.path.dirname(pdt.LIBPDT_PATH)), rel)
+        out = subprocess.run(["nm", "-D", "--undefined-only", path], capture_output=True, text=True).stdout
+        assert "getenv" not in out, rel
 
 
 def test_library_contains_gfx950_code_object(pdt):
@@ -158,7 +172,7 @@ def test_write_records_equals_format_records(pdt, tmp_path):
     cannot seek (a pipe) takes the text in order.  Host only."""
     import numpy as np
     L = pdt.lib()
-    assert L.pdt_abi_version() == 2
+    assert L.pdt_abi_version() == 3
     rng = np.random.default_rng(11)
     for n in (0, 1, 7, 2048, 2049, 40000):
         fr = np.zeros(n, dtype=pdt.FRAME_DTYPE)

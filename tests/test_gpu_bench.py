@@ -30,7 +30,8 @@ def test_default_workload_shortened_one_gpu():
     for k in CONTRACT + ["cpu_baseline", "e2e", "parity"]:
         assert k in d, k
     assert d["n_gpus"] == 1 and d["steps"] == 2 and d["config"]["workload"].startswith("c3 = BASELINE configs[2]")
-    assert "resident in HBM" in d["metric"] and d["dtype"] == "f32" and d["scaling"] == "weak"
+    assert d["metric"] == json.load(open(os.path.join(ROOT, "BASELINE.json")))["metric"] and "RESIDENT IN HBM" in d["value_is"]
+    assert d["dtype"] == "f32" and d["scaling"] == "weak" and d["e2e"]["statistic"].startswith("median of 5") and d["value_e2e"] == d["e2e"]["value"]
     p = d["parity"]
     assert p["sample_text_equals_cpu_baseline"] is True and p["e2e_text_equals_resident_full_size"] is True
     assert p["cli_text_equals_resident_full_size"] is True and p["frames_equal_transmitted_full_size"] == [True]

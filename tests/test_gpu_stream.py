@@ -248,6 +248,74 @@ def test_file_ingest_overlapped_with_the_chain(pdt, orc, tmp_path):
     assert texts[""] == o.text() and texts["3"] == o.text() and texts["7"] == o.text()
 
 
+def _with_env(env, fn):
+    import os
+    os.environ.update(env)
+    try:
+        return fn()
+    finally:
+        for k in env:
+            os.environ.pop(k, None)
+
+
+@pytest.mark.parametrize("fs,block,extra", [(250000, 1040000, {"PDT_GSPAN": "13"}), (250000, 260000, {})])
+def test_aligned_segments_take_the_whole_capture_kernels(pdt, orc, fs, block, extra):
+    """Round 5: a segment whose first new sample lies on the grid of the whole-capture kernels' units (a multiple of the mix + FIR
+    kernel's 208-output runs and of a 128-byte line; the table rows' span dividing its first chunk) runs k_mix_fir /
+    k_agc_block_tr / rows of several chunks instead of the stream path's kernels.  Same frames as the oracle; PDT_SEG_PLAIN keeps
+    the stream path for the comparison, and the profile says which kernels ran."""
+    secs = 24.0
+    iq = pdt.synth_capture(0, fs, secs, seed=71)
+    o = orc.Oracle(orc.POES, fs, iq)
+
+    def run():
+        with pdt.Demodulator(pdt.MODE_POES, fs, profile=True) as d:
+            got, _, _ = stream_all(d, iq, block)
+            return got, d.text(), d.kernel_times()
+
+    got, text, kt = _with_env(extra, run)
+    assert text == o.text() and pdt.format_frames(got) == o.text() and len(got) >= int(secs * 10) - 12
+    assert "mix_fir" in kt, kt                              # (the last segment's groups: the fused kernel at INTERP 1)
+    got_p, text_p, kt_p = _with_env(dict(extra, PDT_SEG_PLAIN="1"), run)
+    assert text_p == o.text() and "mix_fir" not in kt_p
+
+
+@pytest.mark.parametrize("fs,secs", [(250000, 75.0), (50000, 1010.0)])
+def test_overlapped_file_in_unequal_segments(pdt, orc, tmp_path, fs, secs):
+    """pdt_demod_file on a large file (threshold brought down with PDT_OVERLAP_MIN_MB): three unequal segments cut on the
+    whole-capture kernels' grid (2 080 000 samples at chunk 10 000 and INTERP 1; 6 240 000 at INTERP 3, where the unit is a FIR
+    tile of 4 992 outputs), each segment's text written while the next one runs -- the file's bytes are the oracle's text,
+    whatever the split, and the same as the plain call's."""
+    import os
+    iq = pdt.synth_capture(0, fs, secs, seed=73)                          # 9 (8) grid units
+    o = orc.Oracle(orc.POES, fs, iq)
+    wav = str(tmp_path / "cap.wav")
+    pdt.write_wav(wav, fs, iq)
+    outs = {}
+    for name, env in (("plain", {"PDT_NO_OVERLAP": "1"}), ("default", {"PDT_OVERLAP_MIN_MB": "1", "PDT_GSPAN": "13"}),
+                      ("split", {"PDT_OVERLAP_MIN_MB": "1", "PDT_OVERLAP_SPLIT": "0.35,0.25,0.25,0.15", "PDT_GSPAN": "16"}),
+                      ("stream_kernels", {"PDT_OVERLAP_MIN_MB": "1", "PDT_SEG_PLAIN": "1"})):
+        def run():
+            with pdt.Demodulator(pdt.MODE_POES, fs, profile=True).keep_pll(False) as d:
+                fd = os.open(wav, os.O_RDONLY)
+                outp = str(tmp_path / f"{name}.txt")
+                fo = os.open(outp, os.O_RDWR | os.O_CREAT | os.O_TRUNC, 0o644)
+                try:
+                    nb = d.demod_file_text(fd, 44, len(iq), fo, 0)
+                finally:
+                    os.close(fd)
+                    os.close(fo)
+                data = open(outp, "rb").read()
+                assert nb == len(data) and data == d.text()
+                assert d.stats().samples == len(iq) and d.stats().frames == len(o.frames())
+                return data, d.kernel_times()
+        outs[name] = _with_env(env, run)
+    for name, (data, kt) in outs.items():
+        assert data == o.text(), name
+    if fs == 250000:
+        assert "mix_fir" in outs["default"][1] and "mix_fir" in outs["split"][1] and "mix_fir" not in outs["stream_kernels"][1]
+
+
 def test_stage_and_whole_capture_entries_are_refused_while_a_stream_is_open(pdt, clip):
     """The stage buffers hold the tails an open stream continues from: every pdt_stage_* / pdt_demod_* entry
     returns PDT_ERR_STATE between the first push and pdt_stream_end, and the stream is not disturbed by the attempt."""
