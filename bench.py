@@ -513,7 +513,7 @@ def run(args, pdt, torch, dist, rank, local, world, dev, cdev, cfg, kind, fs, se
         if legs:
             # ---- end to end, in process: what POESTIPdemod/main.c:284-512 does with the file
             e2e_ms, split = [], []
-            with pdt.Demodulator(mode, fs, device=local).keep_pll(False) as de:
+            with pdt.Demodulator(mode, fs, device=local, profile=bool(os.environ.get("PDT_DEBUG_OVERLAP"))).keep_pll(False) as de:
                 for rep in range(6):                                      # (rep 0 allocates the context's buffers: reported apart)
                     outp = os.path.join(tmp, f"e2e_out{rep}.txt")         # (a new file every time, as the host program's)
                     t1 = time.perf_counter()

@@ -158,6 +158,8 @@ typedef struct pdt_stats {
     uint32_t gardner_full_domain; /* chunks tabulated over the full boundary-state domain (scouts not locked)       */
     uint32_t sync_overflow;       /* 4096-bit tiles with more than 31 sync hits (generic path used)                */
     uint64_t gardner_candidates;  /* boundary states evaluated by the table kernel                                  */
+    double   ingest_ms;           /* (ABI 3) host wall time from the call's start until the capture's last byte had been queued
+                                     for the copy to HBM (pdt_demod_fd / _file / _pcm16 / _f32; 0: input was resident)     */
 } pdt_stats;
 
 typedef struct pdt_kernel_time {

@@ -93,6 +93,7 @@ class Stats(C.Structure):
         ("gardner_full_domain", C.c_uint32),
         ("sync_overflow", C.c_uint32),
         ("gardner_candidates", C.c_uint64),
+        ("ingest_ms", C.c_double),
     ]
 
 

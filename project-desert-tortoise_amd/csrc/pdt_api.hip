@@ -32,6 +32,9 @@
 using namespace pdt;
 
 static std::atomic<int> g_open_contexts{0};          // contexts alive in this process (pdt_open / pdt_close)
+// One ingest per GPU at a time.  Two contexts on one GPU (bin/demodMulti's two lanes) that read their captures at once would
+// share the PCIe link and both arrive late; taking turns, the second one's capture arrives while the first one's chain runs.
+static std::mutex g_link_mu[64];
 
 #define HIP_TRY(expr)                                                                                  \
     do {                                                                                               \
@@ -253,7 +256,7 @@ struct Tuning {
     double band_pad = 0.0, pll_warm_scale = 1.0, head_taus = 0.0, agc_k = 0.0, pll_warm_s = 0.0, agc_warm_s = 0.0;
     double overlap_split[8] = { 0, 0, 0, 0, 0, 0, 0, 0 };
     int scout_syms = 0, gspan = 0, gspan_cap = 0, mf_waves = 8, ingest_threads = 0, ingest_span_mb = 0, ingest_streams = 0, overlap_segments = 0, overlap_min_mb = 0, fir_wg_per_cu = 0, agc_tpb = 0, gseg = 0, acquire_mode = 0, pll_block = 0, fix_passes = 2;      // acquire_mode: 0 = two-wavefront pipeline, 1 = plain one-lane, 2 = one wavefront
-    bool fir_generic = false, mix_unfused = false, quality_inline = false, gemit_groups = false, agc_unfused = false, no_excl = false, gtab_nomerge = false, gardner_onebuf = false, gardner_noring = false, gardner_sequential = false, seg_sequential = false, agc_lanes = false, overlap = true, debug_overlap = false, chain_one_range = false, ema_noguess = false, debug_sync = false, pll_noshort = false, pll_nockpt = false, pll_noconsensus = false, seg_plain = false;
+    bool fir_generic = false, mix_unfused = false, quality_inline = false, gemit_groups = false, agc_unfused = false, no_excl = false, gtab_nomerge = false, gardner_onebuf = false, gardner_noring = false, gardner_sequential = false, seg_sequential = false, agc_lanes = false, overlap = true, debug_overlap = false, chain_one_range = false, ema_noguess = false, debug_sync = false, pll_noshort = false, pll_nockpt = false, pll_noconsensus = false, seg_plain = false, sync_block = false;
     void load()
     {
         std::lock_guard<std::mutex> lock(g_dev_mu);
@@ -310,7 +313,8 @@ struct Tuning {
         pll_noshort = get("PDT_PLL_NOSHORT") != nullptr;
         pll_nockpt = get("PDT_PLL_NOCKPT") != nullptr;
         pll_noconsensus = get("PDT_PLL_NOCONSENSUS") != nullptr;
-        seg_plain = get("PDT_SEG_PLAIN") != nullptr;        // stream segments on the stream path's kernels only (A/B)
+        seg_plain = get("PDT_SEG_PLAIN") != nullptr;
+        sync_block = get("PDT_SYNC_BLOCK") != nullptr;          // overlapped ingest: wait for a segment inside hipStreamSynchronize (A/B)        // stream segments on the stream path's kernels only (A/B)
     }
 };
 
@@ -1763,7 +1767,9 @@ template <typename T> int run_capture(pdt_ctx *ctx, uint64_t n, int phase = RUN_
     // ---- results back to the host
     // one synchronisation: the scalars, the lock record and (speculatively, into pinned memory) as many frame
     // records as the previous call of this context produced, plus a margin
-    const uint32_t spec_frames = std::min<uint32_t>(frame_cap, ctx->last_nframes + ctx->last_nframes / 8 + 64);
+    // (the overlapped ingest's segments differ in length: the whole capacity -- about twice what a segment yields, a few MB into
+    // pinned memory -- rather than a second, blocking copy between two segments)
+    const uint32_t spec_frames = (seg && seg->in_place) ? frame_cap : std::min<uint32_t>(frame_cap, ctx->last_nframes + ctx->last_nframes / 8 + 64);
     if ((size_t)spec_frames * sizeof(FrameRec) > ctx->pinned_cap) {
         if (ctx->pinned) (void)hipHostFree(ctx->pinned);
         ctx->pinned = nullptr;
@@ -1789,6 +1795,18 @@ template <typename T> int run_capture(pdt_ctx *ctx, uint64_t n, int phase = RUN_
     if (!ctx->pending || ctx->pend_n != n) return PDT_ERR_STATE;
     ctx->pending = false;
     pdt_ctx *lead = ctx->leader ? ctx->leader : ctx;
+    if (seg && seg->in_place && !ctx->tune.sync_block) {
+        // the overlapped ingest: wait for the segment WITHOUT sitting inside the runtime -- the ingest's submitter thread is
+        // queueing copies all the while (a blocking hipStreamSynchronize here held it up: the copies stopped for as long as a
+        // segment's kernels ran, tools/jobs/r5_e2e_ab.sh)
+        for (;;) {
+            const hipError_t e = hipEventQuery(lead->ev1);
+            if (e == hipSuccess) break;
+            if (e != hipErrorNotReady) { HIP_TRY(e); }
+            (void)hipGetLastError();
+            std::this_thread::sleep_for(std::chrono::microseconds(40));
+        }
+    }
     HIP_TRY(hipStreamSynchronize(lead->stream));
     const DevScalars &sc = *ctx->pend_sc;
     PllLockInfo<T> info;
@@ -2041,16 +2059,31 @@ struct IngestSrc {
 constexpr size_t PDT_INGEST_SPAN_DEFAULT = 2u << 20;
 constexpr int PDT_INGEST_SLOTS = 2;      // per thread
 
-// An ingest that goes on in the background: every span has an event of its own and a flag that says the event has been
-// recorded; the caller makes its stream wait for the spans of a prefix (ingest_wait_prefix) and starts work on it while the
-// rest still arrives, and joins the threads at the end (ingest_join).
+// An ingest that goes on in the background: every span has a flag that says its copy has been queued; the caller makes its
+// stream wait for the spans of a prefix (ingest_wait_mark) and starts work on it while the rest still arrives, and joins the
+// threads at the end (ingest_join).
 struct IngestJob {
     std::vector<std::thread> pool;
     std::unique_ptr<std::atomic<int>[]> submitted;
+    std::unique_ptr<std::atomic<int>[]> slot_state;                  // 0 free, 1 filled (to be copied), 2 copy in flight
     std::atomic<int> failed{0};
     size_t nspans = 0, span = 0, waited = 0;
+    hipStream_t cs[4] = { nullptr, nullptr, nullptr, nullptr };      // the copy streams the spans go round robin over
+    int ncs = 0;
+    // prefixes the caller will wait for (bytes, ascending; set before ingest_capture): when the last span of prefix m has been
+    // queued the submitter records one event per copy stream -- behind that prefix's copies and in front of everything later --
+    // and raises mark_ready[m]
+    std::vector<size_t> mark_bytes;
+    std::vector<size_t> mark_spans;
+    std::unique_ptr<std::atomic<int>[]> mark_ready;
 };
 
+// Round 5: ONE thread talks to the HIP runtime.  The readers only fill pinned slots (pread / memcpy) and raise a flag; the
+// submitter -- the calling thread, or one more background thread when the ingest runs beside the chain -- queues the copies, one
+// event per slot, and hands a slot back to its reader when its copy has completed (hipEventQuery on the oldest copy in flight
+// of each copy stream).  With eight readers calling hipMemcpyAsync / hipEventRecord / hipEventSynchronize themselves the
+// runtime's locks were contended: beside a chain that is launching kernels the ingest fell from 52 to ~41 GB/s, and a burst of
+// fifty launches took up to 7 ms instead of 0.2 (round 4: "the readers contend with the launches in the runtime").
 int ingest_capture(pdt_ctx *ctx, const IngestSrc &src, size_t bytes, void *dst, IngestJob *job = nullptr)
 {
     if (!bytes) return PDT_OK;
@@ -2063,15 +2096,15 @@ int ingest_capture(pdt_ctx *ctx, const IngestSrc &src, size_t bytes, void *dst, 
         return PDT_OK;
     }
     unsigned hw = std::thread::hardware_concurrency();
-    // (round 4, 3.6 GB from tmpfs: 4 / 6 / 8 / 12 / 16 threads -> 100 / 92 / 88 / 90 / 89 ms for the whole call; beside a chain that
-    // is launching kernels -- PDT_OVERLAP -- 8 / 16 / 24 / 32 -> 98 / 116 / 107 / 111: the readers contend with the launches)
-    // Several contexts of one process (bin/demodMulti: one per GPU) share the host's cores: half of them, divided by the open
+    // (round 4, 3.6 GB from tmpfs: 4 / 6 / 8 / 12 / 16 reader threads -> 100 / 92 / 88 / 90 / 89 ms for the whole call)
+    // Several contexts of one process (bin/demodMulti: two per GPU) share the host's cores: half of them, divided by the open
     // contexts, never fewer than two readers (8 GPUs on a 256-thread host: 8 each; on a 32-thread host: 2 each).
     const unsigned share = std::max(2u, (hw ? hw / 2u : 8u) / (unsigned)std::max(1, g_open_contexts.load()));
     const unsigned t_max = ctx->tune.ingest_threads > 0 ? (unsigned)ctx->tune.ingest_threads : std::min(8u, share);
     int T = (int)std::min<size_t>(std::min<unsigned>(hw ? hw / 2u + 1u : 4u, t_max), nspans);
     if (T < 1) T = 1;
-    const size_t need = (size_t)T * PDT_INGEST_SLOTS * PDT_INGEST_SPAN;
+    const int nslots = T * PDT_INGEST_SLOTS;
+    const size_t need = (size_t)nslots * PDT_INGEST_SPAN;
     if (need > ctx->ingest_pin_cap) {
         if (ctx->ingest_pin) (void)hipHostFree(ctx->ingest_pin);
         ctx->ingest_pin = nullptr;
@@ -2079,18 +2112,30 @@ int ingest_capture(pdt_ctx *ctx, const IngestSrc &src, size_t bytes, void *dst, 
         if (hipHostMalloc(&ctx->ingest_pin, need, hipHostMallocDefault) != hipSuccess) { (void)hipGetLastError(); return PDT_ERR_NOMEM; }
         ctx->ingest_pin_cap = need;
     }
-    if (!ctx->copy_stream) HIP_TRY(hipStreamCreateWithFlags(&ctx->copy_stream, hipStreamNonBlocking));
+    // The copy streams live at the LOWEST stream priority: streams of one priority share a few hardware queues, and a copy stream
+    // that lands on the queue of the demodulation stream waits behind that stream's kernels -- beside a running segment (a 5 ms PLL
+    // kernel) one of four copy streams stood still, and with it the ring of pinned slots: the overlapped ingest crawled at
+    // ~25 GB/s while kernels ran (round 5, tools/jobs/r5_e2e_ab.sh: four streams 95 ms, two -- no sharing -- 82 ms).  Another
+    // priority is another set of queues (the side stream uses the highest for the same reason).
+    auto make_copy_stream = [](hipStream_t *out) -> hipError_t {
+        int least = 0, greatest = 0;
+        (void)hipDeviceGetStreamPriorityRange(&least, &greatest);
+        if (least != greatest && hipStreamCreateWithPriority(out, hipStreamNonBlocking, least) == hipSuccess) return hipSuccess;
+        (void)hipGetLastError();
+        return hipStreamCreateWithFlags(out, hipStreamNonBlocking);
+    };
+    if (!ctx->copy_stream) HIP_TRY(make_copy_stream(&ctx->copy_stream));
     if (!ctx->ev_ingest) HIP_TRY(hipEventCreateWithFlags(&ctx->ev_ingest, hipEventDisableTiming));
     // copy streams in use: hour-long captures spread their span copies over four (3.6 GB: 123 -> 107 ms for the whole call,
     // ~51 GB/s from the page cache to HBM); ten-minute captures are no faster for it
     const int NS = std::min(4, std::max(1, ctx->tune.ingest_streams > 0 ? ctx->tune.ingest_streams : (bytes >= ((size_t)512 << 20) ? 4 : 1)));
     hipStream_t cs[4] = { ctx->copy_stream, nullptr, nullptr, nullptr };
     for (int q = 1; q < NS; q++) {
-        if (!ctx->copy_streams_more[q - 1]) HIP_TRY(hipStreamCreateWithFlags(&ctx->copy_streams_more[q - 1], hipStreamNonBlocking));
+        if (!ctx->copy_streams_more[q - 1]) HIP_TRY(make_copy_stream(&ctx->copy_streams_more[q - 1]));
         if (!ctx->ev_ingest_more[q - 1]) HIP_TRY(hipEventCreateWithFlags(&ctx->ev_ingest_more[q - 1], hipEventDisableTiming));
         cs[q] = ctx->copy_streams_more[q - 1];
     }
-    while (ctx->ingest_ev.size() < (size_t)T * PDT_INGEST_SLOTS) {
+    while (ctx->ingest_ev.size() < (size_t)nslots) {
         hipEvent_t e;
         HIP_TRY(hipEventCreateWithFlags(&e, hipEventDisableTiming));
         ctx->ingest_ev.push_back(e);
@@ -2098,32 +2143,45 @@ int ingest_capture(pdt_ctx *ctx, const IngestSrc &src, size_t bytes, void *dst, 
     // the destination may still be read by work queued earlier on the demodulation stream
     HIP_TRY(hipEventRecord(ctx->ev_ingest, ctx->stream));
     for (int q = 0; q < NS; q++) HIP_TRY(hipStreamWaitEvent(cs[q], ctx->ev_ingest, 0));
-    std::atomic<int> failed_here{0};
-    std::atomic<int> &failed = job ? job->failed : failed_here;
-    if (job) {
-        while (ctx->span_ev.size() < nspans) {
-            hipEvent_t e;
-            HIP_TRY(hipEventCreateWithFlags(&e, hipEventDisableTiming));
-            ctx->span_ev.push_back(e);
-        }
-        job->submitted.reset(new std::atomic<int>[nspans]);
-        for (size_t k = 0; k < nspans; k++) job->submitted[k].store(0);
-        job->nspans = nspans;
-        job->span = PDT_INGEST_SPAN;
-        job->waited = 0;
+    IngestJob local;
+    IngestJob *J = job ? job : &local;
+    for (int q = 0; q < NS; q++) J->cs[q] = cs[q];
+    J->ncs = NS;
+    J->submitted.reset(new std::atomic<int>[nspans]);
+    for (size_t k = 0; k < nspans; k++) J->submitted[k].store(0);
+    J->slot_state.reset(new std::atomic<int>[(size_t)nslots]);
+    for (int q = 0; q < nslots; q++) J->slot_state[(size_t)q].store(0);
+    J->nspans = nspans;
+    J->span = PDT_INGEST_SPAN;
+    J->waited = 0;
+    J->mark_spans.clear();
+    for (size_t b : J->mark_bytes) J->mark_spans.push_back(std::min(nspans, (b + PDT_INGEST_SPAN - 1) / PDT_INGEST_SPAN));
+    J->mark_ready.reset(new std::atomic<int>[J->mark_spans.size() + 1]);
+    for (size_t m = 0; m < J->mark_spans.size(); m++) J->mark_ready[m].store(0);
+    while (ctx->span_ev.size() < J->mark_spans.size() * (size_t)NS) {
+        hipEvent_t e;
+        HIP_TRY(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+        ctx->span_ev.push_back(e);
     }
-    // (the background form copies what the lambda needs: it outlives this call)
+    std::atomic<int> &failed = J->failed;
+    // span k is read by thread k % T into its slot (k / T) % SLOTS: slot index (k % T) * SLOTS + (k / T) % SLOTS
+    // (the background form copies what the lambdas need: they outlive this call)
     const IngestSrc src_c = src;
-    auto worker = [ctx, src_c, bytes, dst, nspans, T, NS, cs, PDT_INGEST_SPAN, job, &failed](int t) {
+    unsigned char *pin_base = (unsigned char *)ctx->ingest_pin;
+    auto reader = [J, src_c, bytes, nspans, T, PDT_INGEST_SPAN, pin_base](int t) {
+        std::atomic<int> &failed = J->failed;
         const IngestSrc &src = src_c;
-        if (hipSetDevice(ctx->cfg.device) != hipSuccess) { failed = 1; return; }
         int round = 0;
         for (size_t k = (size_t)t; k < nspans && !failed; k += (size_t)T, round++) {
             const int slot = t * PDT_INGEST_SLOTS + (round % PDT_INGEST_SLOTS);
-            unsigned char *pin = (unsigned char *)ctx->ingest_pin + (size_t)slot * PDT_INGEST_SPAN;
+            std::atomic<int> &st = J->slot_state[(size_t)slot];
+            while (st.load(std::memory_order_acquire) != 0) {          // its previous copy is still on its way
+                if (failed) return;
+                std::this_thread::sleep_for(std::chrono::microseconds(10));
+            }
+            unsigned char *pin = pin_base + (size_t)slot * PDT_INGEST_SPAN;
             const size_t at = k * PDT_INGEST_SPAN;
             const size_t len = std::min(PDT_INGEST_SPAN, bytes - at);
-            if (round >= PDT_INGEST_SLOTS && hipEventSynchronize(ctx->ingest_ev[(size_t)slot]) != hipSuccess) { failed = 1; return; }
             if (src.mem) {
                 memcpy(pin, src.mem + at, len);
             } else {
@@ -2135,26 +2193,77 @@ int ingest_capture(pdt_ctx *ctx, const IngestSrc &src, size_t bytes, void *dst, 
                     got += (size_t)r;
                 }
             }
-            hipStream_t mine = cs[t % NS];
-            if (hipMemcpyAsync((unsigned char *)dst + at, pin, len, hipMemcpyHostToDevice, mine) != hipSuccess ||
-                hipEventRecord(ctx->ingest_ev[(size_t)slot], mine) != hipSuccess) {
+            st.store(1, std::memory_order_release);
+        }
+    };
+    const bool background = job != nullptr;
+    auto submitter = [ctx, J, bytes, dst, nspans, T, NS, nslots, PDT_INGEST_SPAN, pin_base, background]() {
+        std::atomic<int> &failed = J->failed;
+        std::lock_guard<std::mutex> link(g_link_mu[(unsigned)ctx->cfg.device % 64u]);      // (the readers fill their first slots meanwhile)
+        if (hipSetDevice(ctx->cfg.device) != hipSuccess) { failed = 1; return; }
+        // spans are queued in order (readers are symmetric: span k + 1 is ready about when span k is), copy stream k % NS;
+        // per stream the slots in flight form a queue, oldest first
+        std::vector<int> inflight[4];
+        size_t head[4] = { 0, 0, 0, 0 };
+        size_t next = 0;
+        auto retire = [&](bool block) {
+            for (int q = 0; q < NS; q++)
+                while (head[q] < inflight[q].size()) {
+                    const int slot = inflight[q][head[q]];
+                    const hipError_t e = block ? hipEventSynchronize(ctx->ingest_ev[(size_t)slot]) : hipEventQuery(ctx->ingest_ev[(size_t)slot]);
+                    if (e == hipErrorNotReady) { (void)hipGetLastError(); break; }
+                    if (e != hipSuccess) { failed = 1; return; }
+                    J->slot_state[(size_t)slot].store(0, std::memory_order_release);
+                    head[q]++;
+                }
+        };
+        size_t mi = 0;
+        auto marks = [&]() {                                           // prefixes complete with the spans queued so far
+            while (mi < J->mark_spans.size() && J->mark_spans[mi] <= next) {
+                for (int q = 0; q < NS; q++)
+                    if (hipEventRecord(ctx->span_ev[mi * (size_t)NS + (size_t)q], J->cs[q]) != hipSuccess) { failed = 1; return; }
+                J->mark_ready[mi].store(1, std::memory_order_release);
+                mi++;
+            }
+        };
+        while (next < nspans && !failed) {
+            marks();
+            const int t = (int)(next % (size_t)T);
+            const int slot = t * PDT_INGEST_SLOTS + (int)((next / (size_t)T) % PDT_INGEST_SLOTS);
+            if (J->slot_state[(size_t)slot].load(std::memory_order_acquire) != 1) {
+                retire(false);
+                if (J->slot_state[(size_t)slot].load(std::memory_order_acquire) != 1) std::this_thread::sleep_for(std::chrono::microseconds(15));
+                continue;
+            }
+            const size_t at = next * PDT_INGEST_SPAN;
+            const size_t len = std::min(PDT_INGEST_SPAN, bytes - at);
+            const int q = (int)(next % (size_t)NS);
+            if (hipMemcpyAsync((unsigned char *)dst + at, pin_base + (size_t)slot * PDT_INGEST_SPAN, len, hipMemcpyHostToDevice, J->cs[q]) != hipSuccess ||
+                hipEventRecord(ctx->ingest_ev[(size_t)slot], J->cs[q]) != hipSuccess) {
                 failed = 1;
                 return;
             }
-            if (job) {
-                if (hipEventRecord(ctx->span_ev[k], mine) != hipSuccess) { failed = 1; return; }
-                job->submitted[k].store(1, std::memory_order_release);
-            }
+            J->slot_state[(size_t)slot].store(2, std::memory_order_release);
+            inflight[q].push_back(slot);
+            J->submitted[next].store(1, std::memory_order_release);
+            next++;
         }
+        marks();
+        (void)nslots;
+        // the background form leaves the pinned slots free; the foreground form returns with its last copies still on their way
+        // (the caller's stream waits for them, and the call does not return before that stream is idle)
+        if (background) retire(true);
     };
-    if (job) {
-        for (int t = 0; t < T; t++) job->pool.emplace_back(worker, t);
-        return PDT_OK;
+    try {
+        for (int t = 0; t < T; t++) J->pool.emplace_back(reader, t);
+        if (job) J->pool.emplace_back(submitter);
+    } catch (const std::exception &) {
+        failed = 1;
     }
-    std::vector<std::thread> pool;
-    for (int t = 1; t < T; t++) pool.emplace_back(worker, t);
-    worker(0);
-    for (auto &th : pool) th.join();
+    if (job) return failed ? PDT_ERR_NOMEM : PDT_OK;                   // (the caller joins: ingest_join)
+    if (!failed) submitter();
+    for (auto &th : J->pool) th.join();
+    J->pool.clear();
     if (failed == 2) return PDT_ERR_FORMAT;                // the file is shorter than announced
     if (failed == 3) return PDT_ERR_IO;
     if (failed) { (void)hipGetLastError(); return PDT_ERR_NOGPU; }
@@ -2167,17 +2276,19 @@ int ingest_capture(pdt_ctx *ctx, const IngestSrc &src, size_t bytes, void *dst, 
     return PDT_OK;
 }
 
-// make `stream` wait for every span that holds a byte below `upto_bytes`
-int ingest_wait_prefix(pdt_ctx *ctx, IngestJob &job, size_t upto_bytes, hipStream_t stream)
+// make `stream` wait for the copies of prefix `m` of the job (IngestJob::mark_bytes).  The host waits -- without touching the HIP
+// runtime: the submitter is in it all the time -- until the submitter has queued the prefix's last span and recorded one event
+// per copy stream behind it; the stream then waits for those events: for the prefix's copies and for nothing that was queued
+// later.  (Round 3 recorded an event per span and made the stream wait for each: ~300 calls, and the host's loop lagged 10 ms
+// behind the data.)
+int ingest_wait_mark(pdt_ctx *ctx, IngestJob &job, size_t m, hipStream_t stream)
 {
-    const size_t need = std::min(job.nspans, (upto_bytes + job.span - 1) / job.span);
-    for (; job.waited < need; job.waited++) {
-        while (!job.submitted[job.waited].load(std::memory_order_acquire)) {
-            if (job.failed) return job.failed == 2 ? PDT_ERR_FORMAT : job.failed == 3 ? PDT_ERR_IO : PDT_ERR_NOGPU;
-            std::this_thread::yield();
-        }
-        HIP_TRY(hipStreamWaitEvent(stream, ctx->span_ev[job.waited], 0));
+    if (m >= job.mark_spans.size()) return PDT_ERR_STATE;
+    while (!job.mark_ready[m].load(std::memory_order_acquire)) {
+        if (job.failed) return job.failed == 2 ? PDT_ERR_FORMAT : job.failed == 3 ? PDT_ERR_IO : PDT_ERR_NOGPU;
+        std::this_thread::sleep_for(std::chrono::microseconds(20));
     }
+    for (int q = 0; q < job.ncs; q++) HIP_TRY(hipStreamWaitEvent(stream, ctx->span_ev[m * (size_t)job.ncs + (size_t)q], 0));
     return PDT_OK;
 }
 
@@ -2525,10 +2636,14 @@ int pdt_demod_pcm16(pdt_ctx *ctx, const int16_t *iq_host, uint64_t nframes)
     if (rc) return rc;
     IngestSrc src;
     src.mem = (const unsigned char *)iq_host;
+    const auto t_in = std::chrono::steady_clock::now();
     if ((rc = ingest_capture(ctx, src, (size_t)nframes * 4, ctx->pcm.p))) return rc;
+    ctx->ingest_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_in).count();
     ctx->pcm_dev = ctx->pcm.p;
     ctx->pcm_fmt = 0;
-    return demod_common(ctx, nframes);
+    rc = demod_common(ctx, nframes);
+    ctx->stats.ingest_ms = ctx->ingest_ms;
+    return rc;
 }
 
 static int demod_overlapped(pdt_ctx *ctx, const IngestSrc &src, uint64_t nframes, int fmt, int text_fd, uint64_t *text_bytes);
@@ -2558,10 +2673,14 @@ int pdt_demod_fd(pdt_ctx *ctx, int fd, uint64_t byte_offset, uint64_t nframes, i
     if (overlap_ingest(ctx, nframes, fb)) return demod_overlapped(ctx, src, nframes, sample_format == PDT_FMT_F32 ? 1 : 0, -1, nullptr);
     int rc = ctx->pcm.ensure((size_t)nframes * fb + 16);
     if (rc) return rc;
+    const auto t_in = std::chrono::steady_clock::now();
     if ((rc = ingest_capture(ctx, src, (size_t)nframes * fb, ctx->pcm.p))) return rc;
+    ctx->ingest_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_in).count();
     ctx->pcm_dev = ctx->pcm.p;
     ctx->pcm_fmt = sample_format == PDT_FMT_F32 ? 1 : 0;
-    return demod_common(ctx, nframes);
+    rc = demod_common(ctx, nframes);
+    ctx->stats.ingest_ms = ctx->ingest_ms;
+    return rc;
 }
 
 int pdt_demod_device(pdt_ctx *ctx, const void *iq_device, uint64_t nframes)
@@ -2583,10 +2702,14 @@ int pdt_demod_f32(pdt_ctx *ctx, const float *iq_host, uint64_t nframes)
     if (rc) return rc;
     IngestSrc src;
     src.mem = (const unsigned char *)iq_host;
+    const auto t_in = std::chrono::steady_clock::now();
     if ((rc = ingest_capture(ctx, src, (size_t)nframes * 8, ctx->pcm.p))) return rc;
+    ctx->ingest_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_in).count();
     ctx->pcm_dev = ctx->pcm.p;
     ctx->pcm_fmt = 1;
-    return demod_common(ctx, nframes);
+    rc = demod_common(ctx, nframes);
+    ctx->stats.ingest_ms = ctx->ingest_ms;
+    return rc;
 }
 
 int pdt_demod_device_f32(pdt_ctx *ctx, const void *iq_device, uint64_t nframes)
@@ -3485,12 +3608,12 @@ static uint64_t lcm_u64(uint64_t a, uint64_t b)
 static int demod_overlapped(pdt_ctx *ctx, const IngestSrc &src, uint64_t nframes, int fmt, int text_fd, uint64_t *text_bytes)
 {
     const size_t fb = fmt ? 8 : 4;
+    const auto t_call = std::chrono::steady_clock::now();
     int rc = pdt_stream_begin(ctx);
     if (rc) return rc;
     ctx->stream_fmt = fmt;
     if ((rc = ctx->stream_in.ensure(((size_t)nframes + 64) * fb))) return rc;
     IngestJob job;
-    if ((rc = ingest_capture(ctx, src, (size_t)nframes * fb, ctx->stream_in.p, &job))) { (void)ingest_join(job); return rc; }
     ctx->sc.in_place = true;
     const uint64_t chunk = ctx->cfg.chunk;
     // the grid of the segment boundaries and of the window's origin (see above)
@@ -3502,7 +3625,7 @@ static int demod_overlapped(pdt_ctx *ctx, const IngestSrc &src, uint64_t nframes
         double acc = 0;
         for (int k = 0; k < 8 && ctx->tune.overlap_split[k] > 0; k++) { acc += ctx->tune.overlap_split[k]; if (acc < 1.0) cut.push_back(acc); }
     } else {
-        cut = { 0.64, 0.86 };
+        cut = { 0.48, 0.73, 0.88 };
     }
     std::vector<uint64_t> ends;
     if (grid * 8 <= nframes) {
@@ -3520,6 +3643,12 @@ static int demod_overlapped(pdt_ctx *ctx, const IngestSrc &src, uint64_t nframes
         }
     }
     ends.push_back(nframes);
+    for (uint64_t e : ends) job.mark_bytes.push_back((size_t)e * fb);
+    if ((rc = ingest_capture(ctx, src, (size_t)nframes * fb, ctx->stream_in.p, &job))) {
+        (void)ingest_join(job);
+        ctx->sc = StreamCarry();
+        return rc;
+    }
     TextSink sink;
     sink.fd = text_fd;
     ctx->batch_hint = 1;
@@ -3533,22 +3662,27 @@ static int demod_overlapped(pdt_ctx *ctx, const IngestSrc &src, uint64_t nframes
         segment_begin(ctx, last);
         rc = demod_common(ctx, win, RUN_ENQUEUE);                   // the segment's launch plan (host only) ...
         const auto t1 = std::chrono::steady_clock::now();
-        if (!rc) rc = ingest_wait_prefix(ctx, job, (size_t)upto * fb, ctx->stream);      // ... then its last bytes ...
+        if (!rc) rc = ingest_wait_mark(ctx, job, k, ctx->stream);      // ... then its last bytes ...
         const auto t2 = std::chrono::steady_clock::now();
+        if (last) ctx->ingest_ms = std::chrono::duration<double, std::milli>(t2 - t_call).count();
         if (!rc) {
             pdt_ctx *self = ctx;
             rc = execute_plans(&self, 1);                           // ... then the launches
         }
+        const auto t2a = std::chrono::steady_clock::now();
         if (!rc) rc = demod_common(ctx, win, RUN_FINISH);
+        const auto t2b = std::chrono::steady_clock::now();
         ctx->sc.active = false;
         ctx->pending = false;
         if (!rc) rc = segment_end(ctx, win, last);
+        const auto t2c = std::chrono::steady_clock::now();
         if (!rc && !last) sink.push(ctx->sc.seg_frames);
         if (ctx->tune.debug_overlap) {
             const auto t3 = std::chrono::steady_clock::now();
             auto ms = [](auto a, auto b) { return std::chrono::duration<double, std::milli>(b - a).count(); };
-            fprintf(stderr, "segment %zu: upto %llu window %llu: plan %.2f ms, waited %.2f ms for the spans, run %.2f ms (gpu %.2f)\n", k,
-                    (unsigned long long)upto, (unsigned long long)win, ms(t0, t1), ms(t1, t2), ms(t2, t3), ctx->stats.gpu_ms);
+            fprintf(stderr, "segment %zu: upto %llu window %llu: plan %.2f ms, waited %.2f ms for the spans, run %.2f ms = launch %.2f + finish %.2f + end %.2f + sink %.2f (gpu %.2f so far)\n", k,
+                    (unsigned long long)upto, (unsigned long long)win, ms(t0, t1), ms(t1, t2), ms(t2, t3), ms(t2, t2a), ms(t2a, t2b), ms(t2b, t2c), ms(t2c, t3), ctx->stats.gpu_ms);
+            for (const pdt_kernel_time &kt : ctx->ktimes) fprintf(stderr, "    %-16s %8.3f ms\n", kt.name, kt.total_ms);
         }
     }
     ctx->sc.in_place = false;
@@ -3563,6 +3697,7 @@ static int demod_overlapped(pdt_ctx *ctx, const IngestSrc &src, uint64_t nframes
         }
     }
     if (text_bytes) *text_bytes = sink.bytes;
+    ctx->stats.ingest_ms = ctx->ingest_ms;
     // the stream machinery was borrowed: leave no stream behind (a later push starts a new one), keep frames and statistics
     ctx->sc = StreamCarry();
     ctx->stream_have = ctx->stream_done = ctx->stream_total = 0;

@@ -2948,8 +2948,24 @@ __device__ __forceinline__ void agc_range_tr(const float *__restrict__ in, float
 #pragma unroll
                     for (int w = 0; w < 4; w++) y[4 * h + k].v[w] = agc_step(x[4 * h + k].v[w], g, P);
             }
-            if (STORE) gain = g;
-            else gain = (rel + 16 * h >= from) ? g : gain;
+            if (STORE && !PARTIAL) gain = g;
+            else if (STORE) {
+                // the wavefront that holds the stream's end: a lane's gain stops at its block's last sample inside the stream --
+                // the state a stream segment hands to the next one (round 5: the per-lane walkers always stopped there; this
+                // form walked every block to its nominal end, over whatever lies behind the stream, and nobody read that gain
+                // while only whole captures came this way)
+                const long long left = n - ((jb0 + t) * B + rel + 16 * h);       // samples of the stream from this half batch on
+                if (left >= 16) gain = g;
+                else if (left > 0) {
+                    float g2 = gain;
+#pragma unroll
+                    for (int k = 0; k < 4; k++)
+#pragma unroll
+                        for (int w = 0; w < 4; w++)
+                            if (4 * k + w < left) (void)agc_step(x[4 * h + k].v[w], g2, P);
+                    gain = g2;
+                }
+            } else gain = (rel + 16 * h >= from) ? g : gain;
         }
         if (STORE) {
 #pragma unroll

@@ -2,19 +2,23 @@
  * demod_multi.c -- demodMulti: several independent captures over the GPUs of one node, frames gathered on one GPU with RCCL.
  *
  * The reference demodulates one capture per process (POESTIPdemod/main.c:143-531).  This host program is the multi-GPU
- * front of the port: every GPU has one worker thread with one context (include/pdt.h; no collective on the data path) that
- * takes the NEXT capture from a shared queue whenever it has finished one -- a GPU is never idle while captures are waiting
- * (round 3 dealt the captures out in waves of one per GPU and joined every wave: a short capture's GPU waited for the longest
- * one of its wave).  When the queue is empty the decoded frame records of every GPU's captures are gathered on the first GPU
- * by libpdtgather (include/pdt_gather.h: ONE gatherer = one set of RCCL communicators for the whole run; all-gather of the
- * counts + padded all-gather of the records over xGMI), and this process writes one output file per capture -- the text
- * POESTIPdemod/ByteSync.c:62-69,96-101 / ARGOSdemod/ByteSync.c:62-70,99-103 print -- next to the input: <capture>.frames.txt.
+ * front of the port: every GPU has TWO worker threads ("lanes", -l) with a context each (include/pdt.h; no collective on the
+ * data path); a lane takes the NEXT capture from a shared queue whenever it has finished one -- a GPU is never idle while
+ * captures are waiting.  Why two: a capture is PCIe time first (3.6 GB: ~67 ms) and GPU time second (~18 ms, most of it
+ * behind the ingest since round 5, ~8 ms exposed); the library lets one ingest per GPU use the link at a time, so while one
+ * lane's capture is in its chain the other lane's is already arriving: a GPU's queue moves at one capture per ingest time
+ * (round 4, one context per GPU: ingest + chain, 67 + 18).  When the queue is empty the decoded frame records of every GPU's
+ * captures are gathered on the first GPU by libpdtgather (include/pdt_gather.h: ONE gatherer = one set of RCCL communicators
+ * for the whole run; all-gather of the counts + padded all-gather of the records over xGMI), and this process writes one
+ * output file per capture -- the text POESTIPdemod/ByteSync.c:62-69,96-101 / ARGOSdemod/ByteSync.c:62-70,99-103 print -- next
+ * to the input: <capture>.frames.txt.
  *
- * usage: demodMulti [-a] [-c chunk] [-g ngpus] capture1.wav capture2.wav ...      (-a: ARGOS chain; default POES)
+ * usage: demodMulti [-a] [-c chunk] [-g ngpus] [-l lanes] capture1.wav capture2.wav ...   (-a: ARGOS chain; default POES;
+ *        -l: contexts per GPU, 1 or 2, default 2)
  *
- * Host budget at N GPUs: N worker threads + per context up to min(8, cores / 2N) reader threads while a file
- * is being read (csrc/pdt_api.hip: ingest_capture) and 2 x 8 MiB of pinned staging per reader; frame records 136 B each
- * (4.9 MB per capture-hour) on the host until they are written.
+ * Host budget at N GPUs: 2 N worker threads + per ingesting context up to min(8, cores / 2 / contexts) reader
+ * threads (csrc/pdt_api.hip: ingest_capture) and 2 x 8 MiB of pinned staging per reader; frame records 136 B each (4.9 MB per
+ * capture-hour) on the host until they are written.
  */
 #include <pthread.h>
 #include <stdatomic.h>
@@ -44,13 +48,17 @@ typedef struct worker {
     pthread_t th;
     pdt_ctx *ctx;
     uint32_t ctx_rate;
-    int done;                       /* captures this GPU demodulated */
-    uint64_t nfr;                   /* frames of all of them */
 } worker;
+
+typedef struct gpu_tally {          /* what a GPU's lanes have done between them */
+    atomic_int done;                /* captures this GPU demodulated */
+    atomic_ullong nfr;              /* frames of all of them */
+} gpu_tally;
 
 static capture *g_cap;
 static int g_ncap;
 static atomic_int g_next;
+static gpu_tally *g_gpu;
 
 static double now_s(void)
 {
@@ -64,7 +72,7 @@ static void run_capture(worker *w, capture *c)
     const double t0 = now_s();
     c->rc = PDT_ERR_FORMAT;
     c->device = w->device;
-    c->order = w->done;
+    c->order = -1;
     const int fd = open(c->path, O_RDONLY);
     if (fd < 0) return;
     uint8_t hdr[44];
@@ -103,8 +111,8 @@ static void run_capture(worker *w, capture *c)
         pdt_get_stats(w->ctx, &c->st);
     }
     if (c->rc == PDT_OK) {
-        w->done++;
-        w->nfr += c->nfr;
+        c->order = atomic_fetch_add(&g_gpu[w->device].done, 1);      /* its place among its GPU's captures (both lanes count) */
+        atomic_fetch_add(&g_gpu[w->device].nfr, (unsigned long long)c->nfr);
     }
     c->seconds = now_s() - t0;
 }
@@ -122,39 +130,44 @@ static void *run_worker(void *arg)
 
 int main(int argc, char **argv)
 {
-    int mode = PDT_MODE_POES, c, ngpu = pdt_device_count();
+    int mode = PDT_MODE_POES, c, ngpu = pdt_device_count(), lanes = 2;
     unsigned long chunk = 0;
-    while ((c = getopt(argc, argv, "ac:g:")) != -1) {
+    while ((c = getopt(argc, argv, "ac:g:l:")) != -1) {
         if (c == 'a') mode = PDT_MODE_ARGOS;
         else if (c == 'c') chunk = strtoul(optarg, NULL, 10);
         else if (c == 'g') ngpu = atoi(optarg);
+        else if (c == 'l') lanes = atoi(optarg) >= 2 ? 2 : 1;
         else return 2;
     }
     const int n = argc - optind;
-    if (n <= 0) { fprintf(stderr, "usage: %s [-a] [-c chunk] [-g ngpus] capture.wav ...\n", argv[0]); return 2; }
+    if (n <= 0) { fprintf(stderr, "usage: %s [-a] [-c chunk] [-g ngpus] [-l lanes] capture.wav ...\n", argv[0]); return 2; }
     if (ngpu <= 0) { printf("GPU demodulator unavailable: %s\n", pdt_strerror(PDT_ERR_NOGPU)); return 1; }
     if (ngpu > pdt_device_count()) ngpu = pdt_device_count();
     if (ngpu > n) ngpu = n;
-    printf("Project Desert Tortoise: %d capture(s) on %d MI355X GPU(s), every GPU takes the next capture when it is free\n", n, ngpu);
+    if (lanes * ngpu > n) lanes = 1;                                 /* (fewer captures than lanes: one context per GPU will do) */
+    printf("Project Desert Tortoise: %d capture(s) on %d MI355X GPU(s), %d context(s) per GPU, every context takes the next capture when it is free\n",
+           n, ngpu, lanes);
     g_cap = (capture *)calloc((size_t)n, sizeof(capture));
     g_ncap = n;
     atomic_store(&g_next, 0);
-    worker *wk = (worker *)calloc((size_t)ngpu, sizeof(worker));
-    if (!g_cap || !wk) return 1;
+    const int nw = ngpu * lanes;
+    worker *wk = (worker *)calloc((size_t)nw, sizeof(worker));
+    g_gpu = (gpu_tally *)calloc((size_t)ngpu, sizeof(gpu_tally));
+    if (!g_cap || !wk || !g_gpu) return 1;
     for (int k = 0; k < n; k++) {
         g_cap[k].path = argv[optind + k];
         g_cap[k].rc = PDT_ERR_STATE;                                 /* (never taken: no worker could be started) */
         g_cap[k].device = -1;
     }
     const double t_all = now_s();
-    for (int d = 0; d < ngpu; d++) {
-        wk[d].device = d;
-        wk[d].mode = mode;
-        wk[d].chunk = chunk;
-        wk[d].started = pthread_create(&wk[d].th, NULL, run_worker, &wk[d]) == 0;
+    for (int i = 0; i < nw; i++) {                                   /* lane 0 of every GPU first: the first captures go one per GPU */
+        wk[i].device = i % ngpu;
+        wk[i].mode = mode;
+        wk[i].chunk = chunk;
+        wk[i].started = pthread_create(&wk[i].th, NULL, run_worker, &wk[i]) == 0;
     }
-    for (int d = 0; d < ngpu; d++)
-        if (wk[d].started) pthread_join(wk[d].th, NULL);
+    for (int i = 0; i < nw; i++)
+        if (wk[i].started) pthread_join(wk[i].th, NULL);
     const double t_demod = now_s() - t_all;
 
     /* ---- gather: rank i = GPU i's records, its captures in the order it took them; one gatherer for the run */
@@ -165,13 +178,15 @@ int main(int argc, char **argv)
     int *rank_of = (int *)calloc((size_t)ngpu, sizeof(int));
     for (int d = 0; d < ngpu; d++) {
         rank_of[d] = -1;
-        if (!wk[d].done) continue;                                   /* a GPU without a decoded capture takes no part */
+        const int d_done = atomic_load(&g_gpu[d].done);
+        const uint64_t d_nfr = (uint64_t)atomic_load(&g_gpu[d].nfr);
+        if (!d_done) continue;                                       /* a GPU without a decoded capture takes no part */
         rank_of[d] = ranks;
         devs[ranks] = d;
-        cnt[ranks] = wk[d].nfr;
-        rec[ranks] = (pdt_frame *)malloc((size_t)(wk[d].nfr ? wk[d].nfr : 1) * sizeof(pdt_frame));
+        cnt[ranks] = d_nfr;
+        rec[ranks] = (pdt_frame *)malloc((size_t)(d_nfr ? d_nfr : 1) * sizeof(pdt_frame));
         uint64_t at = 0;
-        for (int o = 0; o < wk[d].done && rec[ranks]; o++)          /* in the order the GPU took them */
+        for (int o = 0; o < d_done && rec[ranks]; o++)               /* in the order the GPU finished them */
             for (int k = 0; k < n; k++)
                 if (g_cap[k].rc == PDT_OK && g_cap[k].device == d && g_cap[k].order == o) {
                     memcpy(rec[ranks] + at, g_cap[k].frames, (size_t)g_cap[k].nfr * sizeof(pdt_frame));
@@ -197,9 +212,10 @@ int main(int argc, char **argv)
     uint64_t *rank_at = (uint64_t *)calloc((size_t)(ranks + 1), sizeof(uint64_t));
     for (int r = 0; r < ranks; r++) rank_at[r + 1] = rank_at[r] + cnt[r];
     uint64_t samples_all = 0;
+    double ingest_all = 0;
     for (int d = 0; d < ngpu; d++) {
         uint64_t at = rank_of[d] >= 0 ? rank_at[rank_of[d]] : 0;
-        for (int o = 0; o < wk[d].done; o++)
+        for (int o = 0; o < atomic_load(&g_gpu[d].done); o++)
             for (int k = 0; k < n; k++) {
                 capture *cp = &g_cap[k];
                 if (cp->rc != PDT_OK || cp->device != d || cp->order != o) continue;
@@ -216,10 +232,11 @@ int main(int argc, char **argv)
                     remove(name);                                    /* no frame, no file (main.c:508-512) */
                 }
                 if (!wrote) { printf("%s: could not be written\n", name); failed++; }
-                printf("GPU %d: %s: %0.3f Ks : %llu Sym : %llu Bits : %llu %s  (%.1f ms on the GPU, %.3f s with file read)\n", cp->device,
+                printf("GPU %d: %s: %0.3f Ks : %llu Sym : %llu Bits : %llu %s  (%.1f ms on the GPU, ingest %.1f ms, %.3f s in all)\n", cp->device,
                        cp->path, cp->st.samples / 1000.0, (unsigned long long)cp->st.symbols, (unsigned long long)cp->st.bits,
-                       (unsigned long long)cp->nfr, mode == PDT_MODE_ARGOS ? "Packets" : "Frames", cp->st.gpu_ms, cp->seconds);
+                       (unsigned long long)cp->nfr, mode == PDT_MODE_ARGOS ? "Packets" : "Frames", cp->st.gpu_ms, cp->st.ingest_ms, cp->seconds);
                 if (wrote) samples_all += cp->st.samples;
+                ingest_all += cp->st.ingest_ms;
             }
     }
     for (int k = 0; k < n; k++)
@@ -230,10 +247,12 @@ int main(int argc, char **argv)
     const double dt = now_s() - t_all;
     printf("%d capture(s), %.3f Msamples in %.3f s (%.3f s until the last GPU was done): %.1f Msamples/s\n", n - failed, samples_all / 1e6,
            dt, t_demod, samples_all / dt / 1e6);
-    for (int d = 0; d < ngpu; d++)
-        if (wk[d].ctx) pdt_close(wk[d].ctx);
+    /* (a GPU's link carries one ingest at a time: with two contexts per GPU the queue should move at about that pace) */
+    printf("queue: sum of the captures' ingest times %.1f ms on %d GPU(s), %.1f ms until the last GPU was done\n", ingest_all, ngpu, t_demod * 1e3);
+    for (int i = 0; i < nw; i++)
+        if (wk[i].ctx) pdt_close(wk[i].ctx);
     for (int r = 0; r < ranks; r++) free(rec[r]);
     for (int k = 0; k < n; k++) free(g_cap[k].frames);
-    free(all); free(rank_at); free(rank_of); free(got); free(cnt); free(rec); free(devs); free(wk); free(g_cap);
+    free(all); free(rank_at); free(rank_of); free(got); free(cnt); free(rec); free(devs); free(wk); free(g_gpu); free(g_cap);
     return failed ? 1 : 0;
 }

@@ -1,18 +1,20 @@
 /* tests/fake_pdt.c -- TEST INFRASTRUCTURE: stand-ins for the libpdt / libpdtgather entry points bin/demodMulti calls, so that its
  * scheduling (one worker per GPU, a shared queue of captures, one gather at the end) runs on a machine without a GPU
  * (tests/test_multi_queue.py links host/demod_multi.c against this file instead of the libraries).
- * A "capture" is a 44-byte PCM16 stereo WAV header followed by: u32 milliseconds the demodulation takes, u32 frames it yields,
- * then padding.  Frame k of a capture carries bytes derived from the file's size and k.  FAKE_DEVICES = number of GPUs. */
+ * A "capture" is a 44-byte PCM16 stereo WAV header followed by: u32 milliseconds its chain takes, u32 frames it yields, u32
+ * milliseconds its ingest takes (one ingest per GPU at a time, as in the library), then padding.  Frame k of a capture carries bytes derived from the file's size and k.  FAKE_DEVICES = number of GPUs. */
 #include <stdint.h>
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
 #include <unistd.h>
+#include <pthread.h>
 #include "pdt.h"
 #include "pdt_gather.h"
 
 struct pdt_ctx { pdt_config cfg; pdt_frame *fr; uint64_t nfr; pdt_stats st; };
 static int g_opens, g_closes, g_gather_opens;
+static pthread_mutex_t g_link[64] = { [0 ... 63] = PTHREAD_MUTEX_INITIALIZER };     /* one ingest per GPU at a time */
 
 const char *pdt_strerror(int c) { return c == PDT_OK ? "ok" : c == PDT_ERR_FORMAT ? "unsupported WAV format" : "error"; }
 int pdt_device_count(void) { const char *e = getenv("FAKE_DEVICES"); return e ? atoi(e) : 0; }
@@ -40,10 +42,13 @@ int pdt_wav_parse_header(const uint8_t h[44], uint32_t *rate, uint32_t *ch, uint
 }
 int pdt_demod_fd(pdt_ctx *c, int fd, uint64_t off, uint64_t nframes, int fmt)
 {
-    uint32_t w[2] = {0, 0};
+    uint32_t w[3] = {0, 0, 0};
     (void)fmt;
-    if (pread(fd, w, 8, (off_t)off) != 8) return PDT_ERR_FORMAT;
-    usleep(w[0] * 1000u);
+    if (pread(fd, w, 12, (off_t)off) != 12) return PDT_ERR_FORMAT;
+    pthread_mutex_lock(&g_link[c->cfg.device & 63]);
+    usleep(w[2] * 1000u);                                    /* the ingest: the link is this capture's */
+    pthread_mutex_unlock(&g_link[c->cfg.device & 63]);
+    usleep(w[0] * 1000u);                                    /* the chain */
     free(c->fr);
     c->nfr = w[1];
     c->fr = calloc(c->nfr ? c->nfr : 1, sizeof(pdt_frame));

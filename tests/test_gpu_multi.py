@@ -40,3 +40,43 @@ def test_demodmulti_argos(pdt, orc, tmp_path):
     r = subprocess.run([os.path.join(ROOT, "bin", "demodMulti"), "-a", str(path)], capture_output=True, text=True)
     assert r.returncode == 0, r.stdout + r.stderr
     assert open(str(path) + ".frames.txt", "rb").read() == orc.Oracle(orc.ARGOS, 32000, a).text()
+
+
+def test_two_contexts_per_gpu_move_the_queue_at_the_pace_of_the_ingest(pdt, tmp_path):
+    """Round 5: two lanes per GPU, one ingest per GPU at a time -- the chain of capture k runs while capture
+    k + 1 arrives.  c2-sized captures (30 M samples, 120 MB) through `demodMulti -g 1`: the EXTRA wall time of eight more
+    captures in the queue is at most 1.1 x the sum of their ingest times (one lane: ingest + chain each); every file's text is
+    the same whatever the number of lanes."""
+    import re
+    import shutil
+    shm = "/dev/shm" if os.path.isdir("/dev/shm") else str(tmp_path)
+    d = os.path.join(shm, f"pdt_lanes_{os.getpid()}")
+    os.makedirs(d, exist_ok=True)
+    try:
+        files = []
+        for k in range(12):
+            iq = pdt.synth_capture(0, 50000, 600.0, seed=500 + k)
+            p = os.path.join(d, f"q{k}.wav")
+            pdt.write_wav(p, 50000, iq)
+            files.append(p)
+
+        def run(lanes, fl):
+            r = subprocess.run([os.path.join(ROOT, "bin", "demodMulti"), "-g", "1", "-l", str(lanes)] + fl, capture_output=True, text=True)
+            assert r.returncode == 0, r.stdout + r.stderr
+            m = re.search(r"queue: sum of the captures' ingest times ([0-9.]+) ms on 1 GPU\(s\), ([0-9.]+) ms until", r.stdout)
+            texts = [open(f + ".frames.txt", "rb").read() for f in fl]
+            return float(m.group(1)), float(m.group(2)), texts
+
+        res = {}
+        for lanes in (1, 2):
+            i4, w4, _ = run(lanes, files[:4])
+            i12, w12, t12 = run(lanes, files)
+            res[lanes] = (i12 - i4, w12 - w4, t12)
+        (ing1, wall1, t1), (ing2, wall2, t2) = res[1], res[2]
+        print(f"eight more c2-sized captures in the queue: one context per GPU +{wall1:.1f} ms (their ingests {ing1:.1f} ms), "
+              f"two contexts +{wall2:.1f} ms (ingests {ing2:.1f} ms)")
+        assert t1 == t2 and all(len(t) > 1900000 for t in t1)           # ~6 000 frames of 324 characters each
+        assert wall2 <= 1.1 * ing2 + 2.0, (res[1][:2], res[2][:2])
+        assert wall2 < 0.85 * wall1, (res[1][:2], res[2][:2])
+    finally:
+        shutil.rmtree(d, ignore_errors=True)

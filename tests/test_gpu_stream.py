@@ -276,6 +276,24 @@ def test_aligned_segments_take_the_whole_capture_kernels(pdt, orc, fs, block, ex
     got, text, kt = _with_env(extra, run)
     assert text == o.text() and pdt.format_frames(got) == o.text() and len(got) >= int(secs * 10) - 12
     assert "mix_fir" in kt, kt                              # (the last segment's groups: the fused kernel at INTERP 1)
+
+    # stage by stage: after every push the window's newest FIR / AGC outputs are the oracle's, bit for bit (the window is
+    # local: its last element is the stream's newest)
+    def stages():
+        ofir, oagc = o.stage(orc.ST_FIR), o.stage(orc.ST_AGC)
+        with pdt.Demodulator(pdt.MODE_POES, fs) as d:
+            d.stream_begin()
+            for i in range(0, len(iq), block):
+                d.stream_push(iq[i:i + block])
+                done = min(i + block, len(iq)) // 10000 * 10000          # whole reference chunks so far
+                # (the window has already slid when the push returns: the tails the next segment looks back on were copied down over
+                # the window's older part, at least 700 000 elements from its end for these block sizes)
+                new = min(done - (i // 10000 * 10000), 700000)
+                for st, want in ((pdt.ST_FIR, ofir), (pdt.ST_AGC, oagc)):
+                    a = d.stage(st)
+                    assert len(a) >= new and a[len(a) - new:].tobytes() == want[done - new:done].tobytes(), (st, i)
+            d.stream_end()
+    _with_env(extra, stages)
     got_p, text_p, kt_p = _with_env(dict(extra, PDT_SEG_PLAIN="1"), run)
     assert text_p == o.text() and "mix_fir" not in kt_p
 

@@ -13,12 +13,12 @@ import pytest
 from conftest import ROOT
 
 
-def wav(path, ms, frames, rate=250000, pad=4000, channels=2):
+def wav(path, ms, frames, rate=250000, pad=4000, channels=2, ingest_ms=0):
     hdr = b"RIFF" + struct.pack("<I", 36 + pad) + b"WAVEfmt " + struct.pack("<IHHIIHH", 16, 1, channels, rate, rate * 4, 4, 16)
     hdr += b"data" + struct.pack("<I", pad)
     assert len(hdr) == 44
     with open(path, "wb") as f:
-        f.write(hdr + struct.pack("<II", ms, frames) + bytes(pad - 8))
+        f.write(hdr + struct.pack("<III", ms, frames, ingest_ms) + bytes(pad - 12))
 
 
 def expected_text(nsamples, frames):
@@ -37,7 +37,8 @@ def exe(tmp_path_factory):
     return out
 
 
-def run(exe, files, devices, extra=()):
+def run(exe, files, devices, extra=("-l", "1")):
+    # (-l 1: one context per GPU, the scheduling the round-4 tests below describe; the two-lane default has its own test)
     env = dict(os.environ, FAKE_DEVICES=str(devices))
     r = subprocess.run([exe, *extra, *files], capture_output=True, text=True, env=env, timeout=120)
     took = {}
@@ -102,3 +103,27 @@ def test_no_gpu(exe, tmp_path):
     wav(p, 1, 1)
     r, _ = run(exe, [p], 0)
     assert r.returncode == 1 and "GPU demodulator unavailable" in r.stdout
+
+
+def test_two_contexts_per_gpu_hide_the_chain_behind_the_next_ingest(exe, tmp_path):
+    """Round 5: two lanes per GPU.  A capture is link time first (its ingest: one per GPU at a time) and GPU time second; with
+    one context per GPU a queue of six captures costs 6 x (ingest + chain), with two the chain of capture k runs while capture
+    k + 1 arrives: 6 x ingest + one chain.  Same files, same text."""
+    import time
+    files = []
+    for k in range(6):
+        p = str(tmp_path / f"q{k}.wav")
+        wav(p, 80, 2 + k, pad=4000 + 40 * k, ingest_ms=100)
+        files.append(p)
+    walls = {}
+    for lanes in ("1", "2"):
+        t0 = time.perf_counter()
+        r, took = run(exe, files, 1, extra=("-l", lanes))
+        walls[lanes] = time.perf_counter() - t0
+        assert r.returncode == 0, r.stdout + r.stderr
+        assert set(took) == set(files) and set(took.values()) == {0}
+        assert f"{lanes} context(s) per GPU" in r.stdout
+        for k, p in enumerate(files):
+            assert open(p + ".frames.txt").read() == expected_text((os.path.getsize(p) - 44) // 4, 2 + k)
+        assert f"fake: {lanes} context(s) opened, {lanes} closed, 1 gatherer(s)" in r.stderr
+    assert walls["1"] > 6 * 0.18 and walls["2"] < 6 * 0.1 + 0.08 + 0.25, walls      # 1.08 s against 0.68 s (+ process start)
