@@ -561,12 +561,32 @@ def run(args, pdt, torch, dist, rank, local, world, dev, cdev, cfg, kind, fs, se
             if os.path.exists(exe):
                 cli_out = os.path.join(tmp, "cli_out.txt")
                 t1 = time.perf_counter()
-                r = subprocess.run([exe, "-d", str(local), "-o", cli_out, wav], capture_output=True, text=True)
+                r = subprocess.run([exe, "-T", "-d", str(local), "-o", cli_out, wav], capture_output=True, text=True)
                 cli_s = time.perf_counter() - t1
                 cli_text = open(cli_out, "rb").read() if os.path.exists(cli_out) else b""
+                split = None
+                for line in r.stderr.splitlines():
+                    if line.startswith('{"timing_ms"'):
+                        split = json.loads(line)["timing_ms"]
+                        split["process_start_and_loader"] = round(cli_s * 1e3 - split["total"], 2)
                 out["e2e_cli"] = {"seconds": round(cli_s, 3), "value": round(n / cli_s / 1e6, 3), "unit": "Msamples/s", "rc": r.returncode,
+                                  "split_ms": split,
                                   "includes": "process start, HIP initialisation, everything of `e2e`, the reference's per-chunk "
-                                              "progress / quality lines (averagePhase EMA)"}
+                                              "progress / quality lines (averagePhase EMA); split_ms from the program's own clock (-T): "
+                                              "`demod_call` contains `of_it_alloc` (device + pinned buffers of a first run) and "
+                                              "`of_it_ingest`"}
+                # ... and without the per-chunk reports (-P): the overlapped path of `e2e`, from process start
+                os.unlink(cli_out)
+                t1 = time.perf_counter()
+                r2 = subprocess.run([exe, "-T", "-P", "-d", str(local), "-o", cli_out, wav], capture_output=True, text=True)
+                cli2_s = time.perf_counter() - t1
+                split2 = None
+                for line in r2.stderr.splitlines():
+                    if line.startswith('{"timing_ms"'):
+                        split2 = json.loads(line)["timing_ms"]
+                        split2["process_start_and_loader"] = round(cli2_s * 1e3 - split2["total"], 2)
+                out["e2e_cli_noprogress"] = {"seconds": round(cli2_s, 3), "rc": r2.returncode, "split_ms": split2,
+                                             "text_equals_resident": bool(os.path.exists(cli_out) and open(cli_out, "rb").read() == gpu_text)}
                 parity["cli_text_equals_resident_full_size"] = bool(cli_text == gpu_text)
             os.unlink(wav)                                               # (3.6 GB of tmpfs back before the CPU legs)
             # ---- CPU baseline on a bounded sample: the first n_cpu samples of this capture, one thread ...

@@ -160,6 +160,8 @@ typedef struct pdt_stats {
     uint64_t gardner_candidates;  /* boundary states evaluated by the table kernel                                  */
     double   ingest_ms;           /* (ABI 3) host wall time from the call's start until the capture's last byte had been queued
                                      for the copy to HBM (pdt_demod_fd / _file / _pcm16 / _f32; 0: input was resident)     */
+    double   alloc_ms;            /* (ABI 3) host time this PROCESS has spent in device / pinned allocations so far (the cold
+                                     path's breakdown: a context's first capture of a size pays for its buffers)          */
 } pdt_stats;
 
 typedef struct pdt_kernel_time {

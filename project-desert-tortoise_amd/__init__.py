@@ -94,6 +94,7 @@ class Stats(C.Structure):
         ("sync_overflow", C.c_uint32),
         ("gardner_candidates", C.c_uint64),
         ("ingest_ms", C.c_double),
+        ("alloc_ms", C.c_double),
     ]
 
 

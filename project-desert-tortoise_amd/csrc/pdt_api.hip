@@ -48,12 +48,25 @@ static std::mutex g_link_mu[64];
 
 namespace {
 
+// host time this process has spent allocating device and pinned memory (pdt_stats.alloc_ms: the cold path's breakdown)
+static std::atomic<long long> g_alloc_ns{0};
+struct AllocTimer {
+    std::chrono::steady_clock::time_point t0 = std::chrono::steady_clock::now();
+    ~AllocTimer() { g_alloc_ns += std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now() - t0).count(); }
+};
+static hipError_t timed_host_malloc(void **p, size_t bytes)
+{
+    AllocTimer t;
+    return hipHostMalloc(p, bytes, hipHostMallocDefault);
+}
+
 struct DevBuf {
     void *p = nullptr;
     size_t cap = 0;
     int ensure(size_t bytes)
     {
         if (bytes <= cap) return PDT_OK;
+        AllocTimer t;
         if (p) (void)hipFree(p);
         p = nullptr;
         cap = 0;
@@ -69,6 +82,7 @@ struct DevBuf {
     int ensure_keep(size_t bytes, size_t keep)
     {
         if (bytes <= cap) return PDT_OK;
+        AllocTimer t;
         void *np = nullptr;
         const size_t want = bytes + bytes / 4 + 4096;
         if (hipMalloc(&np, want) != hipSuccess) {
@@ -545,7 +559,7 @@ int execute_plans(pdt_ctx *const *ctxs, int M)
         L0->packs_pin = nullptr;
         L0->packs_pin_cap = 0;
         const size_t want = 2 * total + 4096;
-        if (hipHostMalloc(&L0->packs_pin, want, hipHostMallocDefault) != hipSuccess) { (void)hipGetLastError(); return PDT_ERR_NOMEM; }
+        if (timed_host_malloc((void **)&L0->packs_pin, want) != hipSuccess) { (void)hipGetLastError(); return PDT_ERR_NOMEM; }
         L0->packs_pin_cap = want;
     }
     // pack of capture m for the launch at offset `off`: M * off + m * size
@@ -944,7 +958,7 @@ template <typename T> int run_capture(pdt_ctx *ctx, uint64_t n, int phase = RUN_
             if (ctx->qual_pin) (void)hipHostFree(ctx->qual_pin);
             ctx->qual_pin = nullptr;
             ctx->qual_pin_cap = 0;
-            if (hipHostMalloc(&ctx->qual_pin, want + want / 4, hipHostMallocDefault) != hipSuccess) {
+            if (timed_host_malloc((void **)&ctx->qual_pin, want + want / 4) != hipSuccess) {
                 (void)hipGetLastError();
                 return PDT_ERR_NOMEM;
             }
@@ -1775,7 +1789,7 @@ template <typename T> int run_capture(pdt_ctx *ctx, uint64_t n, int phase = RUN_
         ctx->pinned = nullptr;
         ctx->pinned_cap = 0;
         const size_t want = (size_t)spec_frames * sizeof(FrameRec) * 2 + 4096;
-        if (hipHostMalloc(&ctx->pinned, want, hipHostMallocDefault) == hipSuccess) ctx->pinned_cap = want;
+        if (timed_host_malloc((void **)&ctx->pinned, want) == hipSuccess) ctx->pinned_cap = want;
         else (void)hipGetLastError();
     }
     const uint32_t got_frames = (ctx->pinned_cap >= (size_t)spec_frames * sizeof(FrameRec)) ? spec_frames : 0u;
@@ -2066,6 +2080,7 @@ struct IngestJob {
     std::vector<std::thread> pool;
     std::unique_ptr<std::atomic<int>[]> submitted;
     std::unique_ptr<std::atomic<int>[]> slot_state;                  // 0 free, 1 filled (to be copied), 2 copy in flight
+    std::unique_ptr<size_t[]> slot_span;                             // the span a filled slot holds (written before state 1)
     std::atomic<int> failed{0};
     size_t nspans = 0, span = 0, waited = 0;
     hipStream_t cs[4] = { nullptr, nullptr, nullptr, nullptr };      // the copy streams the spans go round robin over
@@ -2109,7 +2124,7 @@ int ingest_capture(pdt_ctx *ctx, const IngestSrc &src, size_t bytes, void *dst, 
         if (ctx->ingest_pin) (void)hipHostFree(ctx->ingest_pin);
         ctx->ingest_pin = nullptr;
         ctx->ingest_pin_cap = 0;
-        if (hipHostMalloc(&ctx->ingest_pin, need, hipHostMallocDefault) != hipSuccess) { (void)hipGetLastError(); return PDT_ERR_NOMEM; }
+        if (timed_host_malloc((void **)&ctx->ingest_pin, need) != hipSuccess) { (void)hipGetLastError(); return PDT_ERR_NOMEM; }
         ctx->ingest_pin_cap = need;
     }
     // The copy streams live at the LOWEST stream priority: streams of one priority share a few hardware queues, and a copy stream
@@ -2151,6 +2166,7 @@ int ingest_capture(pdt_ctx *ctx, const IngestSrc &src, size_t bytes, void *dst, 
     for (size_t k = 0; k < nspans; k++) J->submitted[k].store(0);
     J->slot_state.reset(new std::atomic<int>[(size_t)nslots]);
     for (int q = 0; q < nslots; q++) J->slot_state[(size_t)q].store(0);
+    J->slot_span.reset(new size_t[(size_t)nslots]);
     J->nspans = nspans;
     J->span = PDT_INGEST_SPAN;
     J->waited = 0;
@@ -2193,19 +2209,22 @@ int ingest_capture(pdt_ctx *ctx, const IngestSrc &src, size_t bytes, void *dst, 
                     got += (size_t)r;
                 }
             }
+            J->slot_span[(size_t)slot] = k;
             st.store(1, std::memory_order_release);
         }
     };
     const bool background = job != nullptr;
-    auto submitter = [ctx, J, bytes, dst, nspans, T, NS, nslots, PDT_INGEST_SPAN, pin_base, background]() {
+    auto submitter = [ctx, J, bytes, dst, nspans, NS, nslots, PDT_INGEST_SPAN, pin_base, background]() {
         std::atomic<int> &failed = J->failed;
         std::lock_guard<std::mutex> link(g_link_mu[(unsigned)ctx->cfg.device % 64u]);      // (the readers fill their first slots meanwhile)
         if (hipSetDevice(ctx->cfg.device) != hipSuccess) { failed = 1; return; }
-        // spans are queued in order (readers are symmetric: span k + 1 is ready about when span k is), copy stream k % NS;
-        // per stream the slots in flight form a queue, oldest first
+        // Spans are queued as their slots fill, in whatever order that is: a reader that is late (descheduled: the hosts are
+        // shared) holds up its own two slots only, not the ring (queued strictly in span order, one late reader stopped all
+        // copies).  `upto` = every span below it has been queued: what the prefixes' boundary events go by.  Per copy stream the
+        // slots in flight form a queue, oldest first.
         std::vector<int> inflight[4];
         size_t head[4] = { 0, 0, 0, 0 };
-        size_t next = 0;
+        size_t upto = 0, queued = 0;
         auto retire = [&](bool block) {
             for (int q = 0; q < NS; q++)
                 while (head[q] < inflight[q].size()) {
@@ -2219,34 +2238,38 @@ int ingest_capture(pdt_ctx *ctx, const IngestSrc &src, size_t bytes, void *dst, 
         };
         size_t mi = 0;
         auto marks = [&]() {                                           // prefixes complete with the spans queued so far
-            while (mi < J->mark_spans.size() && J->mark_spans[mi] <= next) {
+            while (upto < nspans && J->submitted[upto].load(std::memory_order_relaxed)) upto++;
+            while (mi < J->mark_spans.size() && J->mark_spans[mi] <= upto) {
                 for (int q = 0; q < NS; q++)
                     if (hipEventRecord(ctx->span_ev[mi * (size_t)NS + (size_t)q], J->cs[q]) != hipSuccess) { failed = 1; return; }
                 J->mark_ready[mi].store(1, std::memory_order_release);
                 mi++;
             }
         };
-        while (next < nspans && !failed) {
-            marks();
-            const int t = (int)(next % (size_t)T);
-            const int slot = t * PDT_INGEST_SLOTS + (int)((next / (size_t)T) % PDT_INGEST_SLOTS);
-            if (J->slot_state[(size_t)slot].load(std::memory_order_acquire) != 1) {
-                retire(false);
-                if (J->slot_state[(size_t)slot].load(std::memory_order_acquire) != 1) std::this_thread::sleep_for(std::chrono::microseconds(15));
-                continue;
+        int rr = 0;                                                    // copy streams round robin
+        while (queued < nspans && !failed) {
+            bool any = false;
+            for (int slot = 0; slot < nslots && !failed; slot++) {
+                if (J->slot_state[(size_t)slot].load(std::memory_order_acquire) != 1) continue;
+                const size_t k = J->slot_span[(size_t)slot];
+                const size_t at = k * PDT_INGEST_SPAN;
+                const size_t len = std::min(PDT_INGEST_SPAN, bytes - at);
+                const int q = rr;
+                rr = (rr + 1 == NS) ? 0 : rr + 1;
+                if (hipMemcpyAsync((unsigned char *)dst + at, pin_base + (size_t)slot * PDT_INGEST_SPAN, len, hipMemcpyHostToDevice, J->cs[q]) != hipSuccess ||
+                    hipEventRecord(ctx->ingest_ev[(size_t)slot], J->cs[q]) != hipSuccess) {
+                    failed = 1;
+                    return;
+                }
+                J->slot_state[(size_t)slot].store(2, std::memory_order_release);
+                inflight[q].push_back(slot);
+                J->submitted[k].store(1, std::memory_order_release);
+                queued++;
+                any = true;
+                marks();
             }
-            const size_t at = next * PDT_INGEST_SPAN;
-            const size_t len = std::min(PDT_INGEST_SPAN, bytes - at);
-            const int q = (int)(next % (size_t)NS);
-            if (hipMemcpyAsync((unsigned char *)dst + at, pin_base + (size_t)slot * PDT_INGEST_SPAN, len, hipMemcpyHostToDevice, J->cs[q]) != hipSuccess ||
-                hipEventRecord(ctx->ingest_ev[(size_t)slot], J->cs[q]) != hipSuccess) {
-                failed = 1;
-                return;
-            }
-            J->slot_state[(size_t)slot].store(2, std::memory_order_release);
-            inflight[q].push_back(slot);
-            J->submitted[next].store(1, std::memory_order_release);
-            next++;
+            retire(false);
+            if (!any) std::this_thread::sleep_for(std::chrono::microseconds(15));
         }
         marks();
         (void)nslots;
@@ -2483,7 +2506,7 @@ int pdt_open(const pdt_config *cfg, pdt_ctx **out)
     ctx->own_stream = true;
     {
         void *small = nullptr;
-        if (hipHostMalloc(&small, sizeof(DevScalars) + 128 + 32768, hipHostMallocDefault) != hipSuccess) { pdt_close(ctx); return PDT_ERR_NOMEM; }
+        if (timed_host_malloc((void **)&small, sizeof(DevScalars) + 128 + 32768) != hipSuccess) { pdt_close(ctx); return PDT_ERR_NOMEM; }
         ctx->pend_sc = (DevScalars *)small;
         ctx->pend_info = (unsigned char *)small + ((sizeof(DevScalars) + 15) & ~(size_t)15);
         ctx->seg_pin = ctx->pend_info + 128;          // 4 KiB up (kept bits, history symbols, lock record, gain), the rest down (SegTail)
@@ -3625,7 +3648,7 @@ static int demod_overlapped(pdt_ctx *ctx, const IngestSrc &src, uint64_t nframes
         double acc = 0;
         for (int k = 0; k < 8 && ctx->tune.overlap_split[k] > 0; k++) { acc += ctx->tune.overlap_split[k]; if (acc < 1.0) cut.push_back(acc); }
     } else {
-        cut = { 0.48, 0.73, 0.88 };
+        cut = { 0.55, 0.83 };
     }
     std::vector<uint64_t> ends;
     if (grid * 8 <= nframes) {
@@ -3893,6 +3916,7 @@ int pdt_get_stats(const pdt_ctx *ctx, pdt_stats *out)
 {
     if (!ctx || !out) return PDT_ERR_ARG;
     *out = ctx->stats;
+    out->alloc_ms = (double)g_alloc_ns.load() * 1e-6;
     return PDT_OK;
 }
 

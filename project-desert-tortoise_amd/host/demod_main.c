@@ -43,14 +43,14 @@
 #ifdef PDT_ARGOS
 #define MODE PDT_MODE_ARGOS
 #define DEFAULT_CHUNKSIZE 2400
-#define OPTS "s:rn:c:o:d:mlP"      /* -l (round 4): the sound-card twin's chain, -s its rate in kHz when the samples come from a pipe */
+#define OPTS "s:rn:c:o:d:mlPT"      /* -l (round 4): the sound-card twin's chain, -s its rate in kHz when the samples come from a pipe */
 #define BANNER "Project Desert Tortoise: Wave file ARGOS Demodulator (MI355X build)\n"
 #define PREFIX "packets"
 #define UNIT "Packets"
 #else
 #define MODE PDT_MODE_POES
 #define DEFAULT_CHUNKSIZE 10000
-#define OPTS "s:rn:c:o:d:qmlP"
+#define OPTS "s:rn:c:o:d:qmlPT"
 #define BANNER "Project Desert Tortoise: Wave file NOAA TIP Demodulator (MI355X build)\n"
 #define PREFIX "minorFrames"
 #define UNIT "Frames"
@@ -207,8 +207,17 @@ static int live_loop(FILE *in, FILE *out, const char *outFileName, double sample
     return 0;
 }
 
+static double now_ms(void)
+{
+    struct timespec ts;
+    clock_gettime(CLOCK_MONOTONIC, &ts);
+    return 1e3 * (double)ts.tv_sec + 1e-6 * (double)ts.tv_nsec;
+}
+
 int main(int argc, char **argv)
 {
+    const double t_main = now_ms();                      /* -T: where the run's time goes, one JSON line on stderr at the end */
+    int timing = 0;
     unsigned long chunkSize = DEFAULT_CHUNKSIZE;
     double normFactor = 0, sampleRate = 0;
     int outputRawFiles = 0, device = 0, quality = 0, sampler = 0, live = 0, chunkGiven = 0, noProgress = 0, c;
@@ -243,6 +252,9 @@ int main(int argc, char **argv)
             break;
         case 'q':
             quality = 1;
+            break;
+        case 'T':
+            timing = 1;
             break;
         case 'P':                                       /* no progress lines (and no averagePhase pass on the GPU) */
             noProgress = 1;
@@ -374,7 +386,9 @@ int main(int argc, char **argv)
     cfg.sampler = sampler;
     cfg.chain = live ? PDT_CHAIN_LIVE : PDT_CHAIN_FILE;
     pdt_ctx *ctx = NULL;
+    const double t_open0 = now_ms();
     int rc = pdt_open(&cfg, &ctx);
+    const double t_open1 = now_ms();
     if (rc != PDT_OK) {
         printf("GPU demodulator unavailable: %s\n", pdt_strerror(rc));
         fclose(out);
@@ -386,7 +400,18 @@ int main(int argc, char **argv)
 #endif
     pdt_keep_pll(ctx, 0);                                            /* nothing here reads the PLL output stream */
     if (!noProgress) pdt_keep_quality(ctx, 1);                       /* the chunk loop's progress / quality line */
+    /* -P (no per-chunk reports): the one-call form -- a large file is demodulated in segments while it is still being read, and a
+     * finished segment's text goes to the file while the next one runs, as the reference's fprintf calls do (ByteSync.c:62-101) */
+    int text_written = 0;
+    fflush(out);
+#ifndef PDT_ARGOS
+    if (noProgress) {
+        rc = pdt_demod_file(ctx, fileno(in), (uint64_t)data_offset, nframes, is_raw ? PDT_FMT_F32 : PDT_FMT_PCM16, fileno(out), NULL);
+        text_written = 1;
+    } else
+#endif
     rc = pdt_demod_fd(ctx, fileno(in), (uint64_t)data_offset, nframes, is_raw ? PDT_FMT_F32 : PDT_FMT_PCM16);
+    const double t_demod1 = now_ms();
     fclose(in);
     if (rc != PDT_OK) {
         printf("Demodulation failed: %s\n", pdt_strerror(rc));
@@ -424,10 +449,12 @@ int main(int argc, char **argv)
 
     char *text = NULL;
     fflush(out);
-    if (pdt_write_frames(ctx, fileno(out), NULL) != PDT_OK) {        /* the minor frames / packets, all at once */
+    const double t_text0 = now_ms();
+    if (!text_written && pdt_write_frames(ctx, fileno(out), NULL) != PDT_OK) {        /* the minor frames / packets, all at once */
         printf("Error writing output file\n");
         exit(1);
     }
+    const double t_text1 = now_ms();
 #ifdef PDT_ARGOS
     {
         uint64_t need = pdt_format_frames(ctx, NULL, 0);
@@ -472,6 +499,14 @@ int main(int argc, char **argv)
         printf("\nAll done! Closing files and exiting.\nENJOY YOUR BITS AND HAVE A NICE DAY\n");
     }
     free(text);
+    const double t_close0 = now_ms();
+    pdt_get_stats(ctx, &st);
     pdt_close(ctx);
+    if (timing)          /* (process start -> main and the dynamic loader's share are the caller's wall time minus `total`) */
+        fprintf(stderr, "{\"timing_ms\": {\"main_to_open\": %.2f, \"open_hip_ready\": %.2f, \"demod_call\": %.2f, \"of_it_alloc\": %.2f, "
+                        "\"of_it_ingest\": %.2f, \"of_it_gpu_last_run\": %.2f, \"progress_and_stats\": %.2f, \"text_write\": %.2f, \"report_and_close_file\": %.2f, "
+                        "\"context_close\": %.2f, \"total\": %.2f}}\n",
+                t_open0 - t_main, t_open1 - t_open0, t_demod1 - t_open1, st.alloc_ms, st.ingest_ms, st.gpu_ms, t_text0 - t_demod1, t_text1 - t_text0,
+                t_close0 - t_text1, now_ms() - t_close0, now_ms() - t_main);
     return 0;
 }

@@ -17,10 +17,13 @@
  *   MMClockRecovery.h:3        MMClockRecovery
  *   ManchesterDecode.h:3       ManchesterDecode
  *   POESTIPdemod/ByteSync.h:4  ByteSyncOnSyncword        ARGOSdemod/ByteSync.h:3  FindSyncWords
+ *   wave.h:27-29               ReadWavHeader, GetComplexRawChunk, GetComplexWaveChunk (round 5; host only: file reads and the
+ *                              running-sum time axis, SURVEY Q1 -- a program linked against this library needs no object of
+ *                              the reference any more)
  * What the kernels do not carry -- the time arrays -- is index bookkeeping and is done here exactly as the reference does it
  * (LowPassFilter.c:67, GardenerClockRecovery.c:30,111, ManchesterDecode.c:86, ByteSync.c:96).  The constants a call passes
  * (loop bandwidths, baud rate, taps ...) must be the ones the mains pass: the kernels are built for those chains, anything else
- * ends the program with a message.  wave.c's readers are not part of this library.
+ * ends the program with a message.
  *
  * No CPU path: without a GPU the first call ends the program ("pdt_compat: ... no HIP device").
  */
@@ -371,3 +374,156 @@ int ByteSyncOnSyncword(unsigned char *bitStreamIn, DT *bitStreamInTime, unsigned
     return sync_common(bitStreamIn, bitStreamInTime, nSamples, syncWord, syncWordLength, minorFrameFile, "1110110111100010000", 19);
 }
 #endif
+
+
+/* ---- wave.h.  The capture readers: host-only, no GPU involved (they fill the caller's chunk buffers, which the stage functions
+ * above then take).  What they must reproduce besides the samples is the TIME AXIS: a running sum of Ts = 1 / sample_rate in
+ * DECIMAL_TYPE arithmetic, carried in function statics from chunk to chunk -- and from file to file --, one addition per sample
+ * (wave.c:91,96-97,167-168; SURVEY Q1: in float it runs fast or slow per binade and stalls at 2^24 Ts).
+ *
+ * HEADER is passed by value: its layout is part of the link contract (wave.h:8-24). */
+typedef struct HEADER {
+    unsigned char riff[4];
+    unsigned int overall_size;
+    unsigned char wave[4];
+    unsigned char fmt_chunk_marker[4];
+    unsigned int length_of_fmt;
+    unsigned int format_type;
+    unsigned int channels;
+    unsigned int sample_rate;
+    unsigned int byterate;
+    unsigned int block_align;
+    unsigned int bits_per_sample;
+    unsigned char data_chunk_header[4];
+    unsigned int data_size;
+    unsigned char type;
+} HEADER;
+
+static unsigned int le_field(const unsigned char *b, size_t got, size_t at, int nbytes)
+{
+    unsigned int v = 0;
+    for (int k = 0; k < nbytes; k++)
+        if (at + (size_t)k < got) v |= (unsigned int)b[at + (size_t)k] << (8 * k);
+    return v;
+}
+
+/* wave.c:303-378: the canonical 44-byte header, field by field, no validation (Q15: a `fmt ` chunk of 16 bytes followed at once
+ * by `data`); the file position ends behind it; what a short file does not hold stays zero */
+HEADER ReadWavHeader(FILE *waveFilePtr)
+{
+    HEADER h;
+    unsigned char b[44];
+    if (waveFilePtr == NULL) {
+        printf("Error opening file\n");
+        exit(1);
+    }
+    memset(&h, 0, sizeof h);
+    memset(b, 0, sizeof b);
+    const size_t got = fread(b, 1, sizeof b, waveFilePtr);
+    memcpy(h.riff, b, 4);
+    h.overall_size = le_field(b, got, 4, 4);
+    memcpy(h.wave, b + 8, 4);
+    memcpy(h.fmt_chunk_marker, b + 12, 4);
+    h.length_of_fmt = le_field(b, got, 16, 4);
+    h.format_type = le_field(b, got, 20, 2);
+    h.channels = le_field(b, got, 22, 2);
+    h.sample_rate = le_field(b, got, 24, 4);
+    h.byterate = le_field(b, got, 28, 4);
+    h.block_align = le_field(b, got, 32, 2);
+    h.bits_per_sample = le_field(b, got, 34, 2);
+    memcpy(h.data_chunk_header, b + 36, 4);
+    h.data_size = le_field(b, got, 40, 4);
+    return h;
+}
+
+static void reader_checks(FILE *f, const HEADER *h, const void *a, const void *b)
+{
+    if (f == NULL) {
+        printf("Error opening file\n");
+        exit(1);
+    }
+    if (a == NULL || b == NULL) {
+        printf("Dude, allocate your fracking memory already. UGH. \n");
+        exit(1);
+    }
+    if (h->channels != 2) {
+        printf("Complex read requires 2 channels (I and Q)\n");
+        exit(1);
+    }
+}
+
+/* wave.c:59-175.  PCM samples, I then Q, scaled by the full scale of the sample width; the value passes through an int16_t on
+ * the way (Q5: of a 32-bit sample only the low half survives, an 8-bit file yields its first byte for both channels), so only
+ * 16-bit files mean anything.  Returns the number of sample pairs the file still held. */
+unsigned long int GetComplexWaveChunk(FILE *waveFilePtr, HEADER header, DT complex *waveData, DT *waveDataTime, unsigned long int nSamples)
+{
+    static DT running_time = 0, Ts = -1;
+    reader_checks(waveFilePtr, &header, waveData, waveDataTime);
+    if (header.format_type != 1) {
+        printf("Only PCM is currently supported :(\n");
+        exit(1);
+    }
+    if (Ts < 0) Ts = 1.0 / (DT)header.sample_rate;
+    const long pair = (long)(header.channels * header.bits_per_sample) / 8;       /* bytes per I,Q pair */
+    const long per = pair / (long)header.channels;
+    if (per * (long)header.channels != pair) {
+        printf("Error: %ld x %ud <> %ld\n", per, header.channels, pair);
+        return nSamples;
+    }
+    const DT full = header.bits_per_sample == 8 ? (DT)128 : header.bits_per_sample == 16 ? (DT)32768
+                    : header.bits_per_sample == 32 ? (DT)2147483648LL : (DT)0;
+    unsigned char *raw = malloc((size_t)pair * (nSamples ? nSamples : 1));
+    if (!raw) die("malloc", PDT_ERR_NOMEM);
+    const unsigned long got = fread(raw, (size_t)pair, nSamples, waveFilePtr);
+    for (unsigned long i = 0; i < got; i++) {
+        const unsigned char *p = raw + (size_t)pair * i;
+        DT v[2] = { 0, 0 };
+        for (int ch = 0; ch < 2; ch++) {
+            int16_t word = 0;
+            if (per == 4) word = (int16_t)(p[4 * ch] | (p[4 * ch + 1] << 8) | (p[4 * ch + 2] << 16) | ((unsigned)p[4 * ch + 3] << 24));
+            else if (per == 2) word = (int16_t)(p[2 * ch] | (p[2 * ch + 1] << 8));
+            else if (per == 1) word = (int16_t)p[0];
+            v[ch] = word / full;
+        }
+        waveData[i] = v[0] + v[1] * I;
+        running_time += Ts;
+        waveDataTime[i] = running_time;
+    }
+    free(raw);
+    return got;
+}
+
+/* wave.c:413-540.  RAW captures: interleaved 32-bit IEEE floats as they are (no scaling); pair by pair, so a file that ends
+ * inside a chunk returns the pairs it held; statics of its own for the time axis */
+unsigned long int GetComplexRawChunk(FILE *rawFilePtr, HEADER header, DT complex *waveData, DT *waveDataTime, unsigned long int nSamples)
+{
+    static DT running_time = 0, Ts = 0;
+    if (header.channels != 2) {                                    /* (this reader tests the channel count first) */
+        printf("Complex read requires 2 channels (I and Q)\n");
+        exit(1);
+    }
+    reader_checks(rawFilePtr, &header, waveData, waveDataTime);
+    if (Ts == 0) Ts = 1.0 / (DT)header.sample_rate;
+    const long pair = (long)(header.channels * header.bits_per_sample) / 8;
+    const long per = pair / (long)header.channels;
+    if (per * (long)header.channels != pair) {
+        printf("Error: %ld x %ud <> %ld\n", per, header.channels, pair);
+        return nSamples;
+    }
+    unsigned char *p = malloc((size_t)(pair > 0 ? pair : 1));
+    if (!p) die("malloc", PDT_ERR_NOMEM);
+    for (unsigned long i = 0; i < nSamples; i++) {
+        if (fread(p, (size_t)pair, 1, rawFilePtr) != 1) {
+            free(p);
+            return i;
+        }
+        if (per != 4) exit(1);                                     /* anything but 32-bit floats ends the program there too */
+        float f[2];
+        memcpy(f, p, 8);
+        waveData[i] = (DT)f[0] + (DT)f[1] * I;
+        running_time += Ts;
+        waveDataTime[i] = running_time;
+    }
+    free(p);
+    return nSamples;
+}

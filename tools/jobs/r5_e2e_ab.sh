@@ -1,5 +1,5 @@
 #!/bin/bash
-# e2e A/B on ONE box: the capture ingested first (PDT_NO_OVERLAP) against the overlapped segments
+# e2e A/B on ONE box: the capture ingested first (PDT_NO_OVERLAP) against the overlapped segments, splits
 cd "$GRAFT_REPO_ROOT" 2>/dev/null || cd /root/repo
 mkdir -p gpurun_out/r5
 export TMPDIR=/tmp
@@ -13,13 +13,14 @@ print('$name', d['e2e']['ms'], d['e2e']['runs_ms'], d['parity'].get('e2e_text_eq
 PY
 }
 run plain PDT_NO_OVERLAP=1
-run overlap PDT_DEBUG_OVERLAP=1
-grep "^segment" gpurun_out/r5/ab_overlap.err | tail -3
-run overlap_2stream PDT_INGEST_STREAMS=2
-run overlap_3stream PDT_INGEST_STREAMS=3
-run overlap_t12 PDT_INGEST_THREADS=12
-run overlap_split PDT_OVERLAP_SPLIT=0.67,0.205,0.125
+run s4b PDT_DEBUG_OVERLAP=1 PDT_OVERLAP_SPLIT=0.42,0.27,0.18,0.13
+grep "^segment" gpurun_out/r5/ab_s4b.err | tail -4
+run s3b PDT_OVERLAP_SPLIT=0.55,0.28,0.17
+run s4 PDT_OVERLAP_SPLIT=0.48,0.25,0.15,0.12
+run s4c PDT_OVERLAP_SPLIT=0.38,0.27,0.20,0.15
+run s4b_t12 PDT_OVERLAP_SPLIT=0.42,0.27,0.18,0.13 PDT_INGEST_THREADS=12
+run s4b_t16 PDT_OVERLAP_SPLIT=0.42,0.27,0.18,0.13 PDT_INGEST_THREADS=16
+run plain_t12 PDT_NO_OVERLAP=1 PDT_INGEST_THREADS=12
 run plain2 PDT_NO_OVERLAP=1
-run overlap2 PDT_DEBUG_OVERLAP=1
-grep "^segment" gpurun_out/r5/ab_overlap2.err | tail -3
-timeout 300 python tools/probes/dma_ring_beside_kernels.py 2>&1 | grep -v amdgpu.ids | tee gpurun_out/r5/dma_ring_beside_kernels.txt
+run s4b_again PDT_DEBUG_OVERLAP=1 PDT_OVERLAP_SPLIT=0.42,0.27,0.18,0.13
+grep "^segment" gpurun_out/r5/ab_s4b_again.err | tail -4
