@@ -244,7 +244,7 @@ def pmc_traffic(cfg: str, kernel: str, build: str):
     """HBM bytes per launch of `kernel` from the committed rocprofv3 counter passes (FETCH_SIZE x2 + WRITE_SIZE, see
     tools/pmc_traffic.py and profiles/r3/README.md) -- only from a file measured with the library build that is running now
     (its `build` tag); otherwise None: a figure of another build says nothing about this one."""
-    for rnd in ("r4", "r3", "r2", "r1"):
+    for rnd in ("r5", "r4", "r3", "r2", "r1"):
         path = os.path.join(ROOT, "profiles", rnd, f"pmc_hbm_traffic_bench_{cfg}.json")
         try:
             doc = json.load(open(path))
@@ -267,13 +267,18 @@ def sq_valu_active(cfg: str, kernel: str, build: str):
     """Fraction of the kernel's wave cycles in which its wavefronts issue vector-ALU instructions, from the committed SQ counter
     pass of this build (profiles/r4/sq_counters_bench_<cfg>.json: SQ_ACTIVE_INST_VALU / SQ_WAVE_CYCLES), or None."""
     try:
-        doc = json.load(open(os.path.join(ROOT, "profiles", "r4", f"sq_counters_bench_{cfg}.json")))
-        if doc.get("build") != build:
-            return None
-        v = doc["kernels"][kernel]
-        return v["SQ_ACTIVE_INST_VALU"] / v["SQ_WAVE_CYCLES"]
+        for rnd in ("r5", "r4"):
+            path = os.path.join(ROOT, "profiles", rnd, f"sq_counters_bench_{cfg}.json")
+            if not os.path.exists(path):
+                continue
+            doc = json.load(open(path))
+            if doc.get("build") != build:
+                continue
+            v = doc["kernels"][kernel]
+            return v["SQ_ACTIVE_INST_VALU"] / v["SQ_WAVE_CYCLES"]
     except (OSError, ValueError, KeyError, ZeroDivisionError):
-        return None
+        pass
+    return None
 
 
 def roofline_bound(ms: float, traffic, alg_bytes: int, valu_active=None) -> str:

@@ -180,6 +180,32 @@ const char *pdt_strerror(int code);
 int  pdt_device_count(void);
 
 int  pdt_open(const pdt_config *cfg, pdt_ctx **out);
+
+/* The loop constants of the chain (ABI 3).  The reference's stage functions take them as arguments -- CarrierTrackPLL(...,
+ * Fs, freqRange, d_lock_threshold, lockSigAlpha, loopbw_acq, loopbw_track) (CarrierTrackPLL.h:11), NormalizingAGC(..., attack_rate,
+ * decay_rate) (AGC.h:7), GardenerClockRecovery(..., baud, stepRange, kp) (GardenerClockRecovery.h:3), ManchesterDecode(...,
+ * resyncThreshold) (ManchesterDecode.h:3) -- and its mains pass the values a context uses by default (POESTIPdemod/main.c:413,429,
+ * 438,445; ARGOSdemod/main.c:265,276-282).  A field left 0 keeps that default; the others replace it in every later
+ * pdt_demod_* / pdt_stream_* / pdt_stage_* call of the context, as the value of the context's DECIMAL_TYPE the reference's
+ * function would have received.  Nothing else changes: the block-parallel evaluation derives its warm-up lengths from the loop
+ * gains it is given and validates every seam bitwise, so the result is the sequential loop's for any constants (only the time
+ * moves: loops that contract slowly mean longer warm-ups and more repairs).  pdt_stage_agc's own rate arguments still win
+ * over agc_attack / agc_decay.  PDT_ERR_ARG: a negative or non-finite value, a baud rate that leaves fewer than two samples per
+ * symbol, a frequency range of half the sample rate or more, a step range above the mains' 0.1 (the samplers' windows and symbol
+ * capacities are sized for it).  PDT_ERR_STATE while a stream is open.                                                                          */
+typedef struct pdt_loop_params {
+    double pll_freq_range_hz;      /* frequency limit of the loop, Hz                                  4500 / 550        */
+    double pll_lock_threshold;     /* lock detector threshold                                         0.08 (twin 0.10) / 0.1 */
+    double pll_lock_alpha;         /* lockSigAlpha, per sample                                        0.3979 w / 3.1831 w, w = 2 pi / Fs */
+    double pll_loopbw_acq;         /* loop bandwidth before the lock, radians per sample              127.3240 w (twin 198.9437 w) / 16 w */
+    double pll_loopbw_track;       /* ... after it                                                    10.3451 w / 16 w  */
+    double agc_attack, agc_decay;  /* NormalizingAGC rates, per output sample                         79.5775 w', 159.1549 w', w' = 2 pi / (Fs interp) */
+    double gardner_baud;           /* symbols per second (Manchester half bits)                       16640.3 / 800     */
+    double gardner_step_range;     /* clip of the timing error, at most 0.1                           0.1               */
+    double gardner_kp;             /* timing loop gain                                                3.0               */
+    double manchester_threshold;   /* resyncThreshold                                                 1.0 (twin 0.75) / 0.5 */
+} pdt_loop_params;
+int  pdt_set_loop_params(pdt_ctx *ctx, const pdt_loop_params *params);
 int  pdt_get_device(const pdt_ctx *ctx);          /* the HIP device ordinal the context lives on */
 void pdt_close(pdt_ctx *ctx);
 

@@ -57,6 +57,11 @@ class Config(C.Structure):
     ]
 
 
+class LoopParams(C.Structure):
+    _fields_ = [(n, C.c_double) for n in ("pll_freq_range_hz", "pll_lock_threshold", "pll_lock_alpha", "pll_loopbw_acq", "pll_loopbw_track",
+                                          "agc_attack", "agc_decay", "gardner_baud", "gardner_step_range", "gardner_kp", "manchester_threshold")]
+
+
 class Frame(C.Structure):
     _fields_ = [
         ("time", C.c_double),
@@ -158,7 +163,7 @@ ABI_SYMBOLS = [
     "pdt_stream_begin", "pdt_stream_push_pcm16", "pdt_stream_push_f32", "pdt_stream_end", "pdt_stream_frames",
     "pdt_keep_quality", "pdt_chunk_reports", "pdt_stage_manchester", "pdt_stage_fir", "pdt_stage_agc", "pdt_stage_squelch", "pdt_stage_pll", "pdt_stage_gardner", "pdt_stage_static_gain", "pdt_stage_mm",
     "pdt_keep_presquelch", "pdt_keep_pll", "pdt_stage_bytesync_from", "pdt_demod_fd", "pdt_format_records", "pdt_stream_retained", "pdt_host_math", "pdt_get_device",
-    "pdt_write_frames", "pdt_write_records", "pdt_demod_file",
+    "pdt_write_frames", "pdt_write_records", "pdt_demod_file", "pdt_set_loop_params",
 ]
 DEV_SYMBOLS = ["pdt_dev_set"]        # include/pdt_dev.h (test-only)
 
@@ -274,6 +279,7 @@ def lib():
     L.pdt_write_frames.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.c_uint64)]
     L.pdt_write_records.argtypes = [C.c_void_p, C.c_uint64, C.c_int, C.POINTER(C.c_uint64)]
     L.pdt_dev_set.argtypes = [C.c_char_p, C.c_char_p]
+    L.pdt_set_loop_params.argtypes = [C.c_void_p, C.POINTER(LoopParams)]
     L.pdt_demod_file.argtypes = [C.c_void_p, C.c_int, C.c_uint64, C.c_uint64, C.c_int, C.c_int, C.POINTER(C.c_uint64)]
     if L.pdt_abi_version() != 3:
         raise PdtError("libpdt.so ABI version mismatch")
@@ -375,6 +381,12 @@ class Demodulator:
 
     def __exit__(self, *a):
         self.close()
+
+    def set_loop_params(self, **kw):
+        """``pdt_set_loop_params``: loop constants other than the mains' (fields of ``LoopParams``; 0 / absent = default)."""
+        lp = LoopParams(**kw)
+        _check(self._L.pdt_set_loop_params(self._h, C.byref(lp)), "pdt_set_loop_params")
+        return self
 
     def keep_presquelch(self, enable: bool = True):
         """Also keep the AGC output before Squelch (stage ST_AGC_RAW): what the reference's -r option dumps."""

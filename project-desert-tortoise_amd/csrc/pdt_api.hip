@@ -269,8 +269,8 @@ static std::map<std::string, std::string> g_dev;
 struct Tuning {
     double band_pad = 0.0, pll_warm_scale = 1.0, head_taus = 0.0, agc_k = 0.0, pll_warm_s = 0.0, agc_warm_s = 0.0;
     double overlap_split[8] = { 0, 0, 0, 0, 0, 0, 0, 0 };
-    int scout_syms = 0, gspan = 0, gspan_cap = 0, mf_waves = 8, ingest_threads = 0, ingest_span_mb = 0, ingest_streams = 0, overlap_segments = 0, overlap_min_mb = 0, fir_wg_per_cu = 0, agc_tpb = 0, gseg = 0, acquire_mode = 0, pll_block = 0, fix_passes = 2;      // acquire_mode: 0 = two-wavefront pipeline, 1 = plain one-lane, 2 = one wavefront
-    bool fir_generic = false, mix_unfused = false, quality_inline = false, gemit_groups = false, agc_unfused = false, no_excl = false, gtab_nomerge = false, gardner_onebuf = false, gardner_noring = false, gardner_sequential = false, seg_sequential = false, agc_lanes = false, overlap = true, debug_overlap = false, chain_one_range = false, ema_noguess = false, debug_sync = false, pll_noshort = false, pll_nockpt = false, pll_noconsensus = false, seg_plain = false, sync_block = false;
+    int scout_syms = 0, gspan = 0, gspan_cap = 0, ingest_threads = 0, ingest_span_mb = 0, ingest_streams = 0, overlap_segments = 0, overlap_min_mb = 0, fir_wg_per_cu = 0, agc_tpb = 0, gseg = 0, pll_block = 0, fix_passes = 2;
+    bool fir_generic = false, mix_unfused = false, quality_inline = false, gemit_groups = false, agc_unfused = false, no_excl = false, gardner_onebuf = false, gardner_noring = false, gardner_sequential = false, seg_sequential = false, agc_lanes = false, overlap = true, debug_overlap = false, chain_one_range = false, ema_noguess = false, debug_sync = false, pll_noshort = false, pll_nockpt = false, pll_noconsensus = false, seg_plain = false, sync_block = false;
     void load()
     {
         std::lock_guard<std::mutex> lock(g_dev_mu);
@@ -292,10 +292,7 @@ struct Tuning {
         if (const char *e = get("PDT_FIX_PASSES")) fix_passes = atoi(e);
         if (const char *e = get("PDT_GSEG")) gseg = std::min(64, std::max(2, atoi(e)));
         if (const char *e = get("PDT_GSPAN")) gspan = std::min(256, std::max(1, atoi(e)));
-        if (const char *e = get("PDT_MF_WAVES")) mf_waves = atoi(e) == 4 ? 4 : 8;
         if (const char *e = get("PDT_GSPAN_CAP")) gspan_cap = std::max(64, atoi(e));          // (tests: rows that do not fit the key list)
-        if (get("PDT_ACQUIRE_SIMPLE")) acquire_mode = 1;
-        else if (get("PDT_ACQUIRE_ONEWAVE")) acquire_mode = 2;
         fir_generic = get("PDT_FIR_GENERIC") != nullptr;
         mix_unfused = get("PDT_MIX_UNFUSED") != nullptr;
         quality_inline = get("PDT_QUALITY_INLINE") != nullptr;
@@ -303,7 +300,6 @@ struct Tuning {
         agc_unfused = get("PDT_AGC_UNFUSED") != nullptr;
         agc_lanes = get("PDT_AGC_LANES") != nullptr;           // the per-lane walkers of rounds 1 - 3 (k_agc_block)
         no_excl = get("PDT_NO_EXCL") != nullptr;
-        gtab_nomerge = get("PDT_GTAB_NOMERGE") != nullptr;
         gardner_onebuf = get("PDT_GARDNER_ONEBUF") != nullptr;
         gardner_noring = get("PDT_GARDNER_NORING") != nullptr;
         ema_noguess = get("PDT_EMA_NOGUESS") != nullptr;
@@ -328,7 +324,7 @@ struct Tuning {
         pll_nockpt = get("PDT_PLL_NOCKPT") != nullptr;
         pll_noconsensus = get("PDT_PLL_NOCONSENSUS") != nullptr;
         seg_plain = get("PDT_SEG_PLAIN") != nullptr;
-        sync_block = get("PDT_SYNC_BLOCK") != nullptr;          // overlapped ingest: wait for a segment inside hipStreamSynchronize (A/B)        // stream segments on the stream path's kernels only (A/B)
+        sync_block = get("PDT_SYNC_BLOCK") != nullptr;
     }
 };
 
@@ -372,6 +368,7 @@ struct StreamCarry {
 
 struct pdt_ctx {
     pdt_config cfg;
+    pdt_loop_params lp = {};     // pdt_set_loop_params: 0 = the mains' constant
     Tuning tune;
     StreamCarry sc;
     int elem;                 // sizeof(DT)
@@ -633,13 +630,14 @@ template <typename T> PllParams<T> make_pll_params(const pdt_ctx *ctx)
     const T Fs = (T)ctx->cfg.sample_rate;
     const bool argos = ctx->cfg.mode == PDT_MODE_ARGOS;
     const bool live = !argos && ctx->cfg.chain == PDT_CHAIN_LIVE;        // POESTIPdemodPortAudio/main.c:41-57
-    const T freqRange = argos ? (T)550.0 : (T)4500.0;
+    const pdt_loop_params &lp = ctx->lp;                                  // (what the caller's CarrierTrackPLL would have been handed)
+    const T freqRange = lp.pll_freq_range_hz != 0 ? (T)lp.pll_freq_range_hz : argos ? (T)550.0 : (T)4500.0;
     const double w = 2.0 * M_PI / (double)Fs;
-    const T bw_acq = (T)((argos ? 16.0 : live ? 198.9437 : 127.3240) * w);
-    const T bw_trk = (T)((argos ? 16.0 : 10.3451) * w);
+    const T bw_acq = lp.pll_loopbw_acq != 0 ? (T)lp.pll_loopbw_acq : (T)((argos ? 16.0 : live ? 198.9437 : 127.3240) * w);
+    const T bw_trk = lp.pll_loopbw_track != 0 ? (T)lp.pll_loopbw_track : (T)((argos ? 16.0 : 10.3451) * w);
     P.Fs = Fs;
-    P.lock_thr = argos ? (T)0.1 : live ? (T)0.10 : (T)0.08;
-    P.lock_alpha = (T)((argos ? 3.1831 : 0.3979) * w);
+    P.lock_thr = lp.pll_lock_threshold != 0 ? (T)lp.pll_lock_threshold : argos ? (T)0.1 : live ? (T)0.10 : (T)0.08;
+    P.lock_alpha = lp.pll_lock_alpha != 0 ? (T)lp.pll_lock_alpha : (T)((argos ? 3.1831 : 0.3979) * w);
     const T damp = (T)0.999;
     const T four = 4, one = 1, two = 2;
     P.alpha_acq = (four * damp * bw_acq) / (one + two * damp * bw_acq + bw_acq * bw_acq);     // :90-91, all DT
@@ -773,16 +771,16 @@ template <typename T> int run_capture(pdt_ctx *ctx, uint64_t n, int phase = RUN_
     }
     AgcParams<T> AP;
     const T fsi = Fs * (T)interp;                                              // POESTIPdemod/main.c:429
-    AP.attack = (T)(79.5775 * (2.0 * M_PI / (double)fsi));
-    AP.decay = (T)(159.1549 * (2.0 * M_PI / (double)fsi));
+    AP.attack = ctx->lp.agc_attack != 0 ? (T)ctx->lp.agc_attack : (T)(79.5775 * (2.0 * M_PI / (double)fsi));
+    AP.decay = ctx->lp.agc_decay != 0 ? (T)ctx->lp.agc_decay : (T)(159.1549 * (2.0 * M_PI / (double)fsi));
     AP.squelch = argos ? 1 : 0;
     AP.squelch_thr = (T)0.15;                                                  // ARGOSdemod/main.c:46,276
     AP.raw_out = nullptr;
     GardnerParams<T> GP;
-    const T baud = argos ? (T)(400 * 2.0) : (T)(8320 * 2 + 0.3);              // main.c:90 / ARGOS main.c:64
+    const T baud = ctx->lp.gardner_baud != 0 ? (T)ctx->lp.gardner_baud : argos ? (T)(400 * 2.0) : (T)(8320 * 2 + 0.3);   // main.c:90 / ARGOS main.c:64
     GP.step = (T)(int)fsi / baud;                                              // GardenerClockRecovery.c:19
-    GP.kp = (T)3.0;
-    GP.lim = (T)0.1;
+    GP.kp = ctx->lp.gardner_kp != 0 ? (T)ctx->lp.gardner_kp : (T)3.0;
+    GP.lim = ctx->lp.gardner_step_range != 0 ? (T)ctx->lp.gardner_step_range : (T)0.1;
     GP.n_total = n_out;
     GP.chunk_out = chunk_out;
     GP.argos_heap = 0;
@@ -797,7 +795,7 @@ template <typename T> int run_capture(pdt_ctx *ctx, uint64_t n, int phase = RUN_
         GP.argos_even = (int)((csz - 8 - req) / sizeof(T));
     }
     const bool argos_twin = argos && ctx->cfg.chain == PDT_CHAIN_LIVE;
-    const T manch_thr = argos ? (T)0.5 : live ? (T)0.75 : (T)1.0;              // main.c:445 / ARGOS main.c:282 / twin :65,393
+    const T manch_thr = ctx->lp.manchester_threshold != 0 ? (T)ctx->lp.manchester_threshold : argos ? (T)0.5 : live ? (T)0.75 : (T)1.0;              // main.c:445 / ARGOS main.c:282 / twin :65,393
     const SyncParams SP = make_sync_params(argos, argos_twin);
 
     // ---- block-parallel geometry (any values give the same output; they only move time around)
@@ -886,7 +884,7 @@ template <typename T> int run_capture(pdt_ctx *ctx, uint64_t n, int phase = RUN_
     // lag of the autocorrelation frequency guess: at least one Manchester symbol (so that the
     // modulation of the two samples is independent and the carrier term dominates the mean), while
     // pi/lag stays above the PLL's frequency limit
-    const double sym_rate = argos ? 800.0 : 16640.0, f_lim = argos ? 550.0 : 4500.0;
+    const double sym_rate = (double)baud, f_lim = (double)PP.max_freq * fs_d / (2.0 * M_PI);
     int lag = (int)ceil(fs_d / sym_rate);
     lag = std::max(1, std::min(lag, (int)(fs_d / (2.2 * f_lim))));
     lag = std::min(lag, 64);
@@ -1079,15 +1077,16 @@ template <typename T> int run_capture(pdt_ctx *ctx, uint64_t n, int phase = RUN_
         d_ckpt = (T *)ctx->pll_ckpt.p;
         PL.memset_async(d_ckpt, 0xff, ck_bytes);
     }
+    PllPhaseHint *d_hint = &d_sc->phase_hint;
     if (N > 0) {
         PL.simple(OP_FORK);
         L.begin("pll_phase", ctx->stream2);
         if (slow_wrap)
             PDT_LAUNCH(256, (k_pll_phase<T, true>), dim3((unsigned)phase_groups), dim3(256), 0, ctx->stream2, d_pcm, d_theta, N, PP, Bp,
-                               Wacq, Wp, lag, d_phi, (PllSeam<T> *)ctx->seams_pll.p, &d_sc->phase_hint, short_group, d_ckpt, pll_consensus);
+                               Wacq, Wp, lag, d_phi, (PllSeam<T> *)ctx->seams_pll.p, d_hint, short_group, d_ckpt, pll_consensus);
         else
             PDT_LAUNCH(256, (k_pll_phase<T, false>), dim3((unsigned)phase_groups), dim3(256), 0, ctx->stream2, d_pcm, d_theta, N, PP, Bp,
-                               Wacq, Wp, lag, d_phi, (PllSeam<T> *)ctx->seams_pll.p, &d_sc->phase_hint, short_group, d_ckpt, pll_consensus);
+                               Wacq, Wp, lag, d_phi, (PllSeam<T> *)ctx->seams_pll.p, d_hint, short_group, d_ckpt, pll_consensus);
         L.end();
         PL.simple(OP_JOIN_RECORD);
     }
@@ -1123,15 +1122,6 @@ template <typename T> int run_capture(pdt_ctx *ctx, uint64_t n, int phase = RUN_
         li.freq_at_lock = 0; li.avg_at_lock = (T)seg->avg_at_lock;
         memcpy(spin + 64, &li, sizeof li);
         PL.copy(OP_H2D, d_info, spin + 64, sizeof li);
-    } else if (ctx->tune.acquire_mode == 1 && !quality)        // plain one-lane form, kept for A/B checks
-        PDT_LAUNCH(64, k_pll_acquire<T>, dim3(1), dim3(64), 0, st, d_pcm, N, PP, d_pll, d_lock, d_info);
-    else if (ctx->tune.acquire_mode == 2 && !quality) {   // single-wavefront batched form, kept for A/B checks
-        if (slow_wrap)
-            PDT_LAUNCH(64, (k_pll_acquire_fast<T, true>), dim3(1), dim3(64), 0, st, d_pcm, N, PP, d_pll, d_lock,
-                               d_info);
-        else
-            PDT_LAUNCH(64, (k_pll_acquire_fast<T, false>), dim3(1), dim3(64), 0, st, d_pcm, N, PP, d_pll, d_lock,
-                               d_info);
     } else if (slow_wrap)
         PDT_LAUNCH(128, (k_pll_acquire_pipe<T, true>), dim3(1), dim3(128), 0, st, d_pcm, N, PP, d_pll, d_lock,
                            d_info, d_avgph);
@@ -1151,7 +1141,16 @@ template <typename T> int run_capture(pdt_ctx *ctx, uint64_t n, int phase = RUN_
         const double tau_trk = 2.0 / (double)PP.alpha_trk;
         double head_taus = (sizeof(T) == 4) ? 30.0 : 90.0;
         if (ctx->tune.head_taus > 0) head_taus = ctx->tune.head_taus;
-        const long long Hd = std::min<long long>(Wp, (long long)(head_taus * tau_trk));
+        long long Hd = std::min<long long>(Wp, (long long)(head_taus * tau_trk));
+        // A stream segment that continues a lock taken long ago starts from a state that remembers the acquisition no more than
+        // any other sample of the capture does: the head then only has to reach the next block boundary -- the warm-ups of the
+        // blocks behind it merge with the truth as anywhere else, and the seams are validated as ever (round 5: the mandatory
+        // 30 time constants kept a SIMD busy for 2.5 ms of every segment of the overlapped ingest).  What is left of the 30 since
+        // the lock stays.
+        if (seg && seg->locked && first > 0 && seg->in_place && !ctx->tune.head_taus) {
+            const long long since = (long long)seg->origin + first - 1 - (long long)seg->lock_sample;
+            Hd = std::max<long long>(0, std::min<long long>(Hd, Hd - since));
+        }
         // ... and further -- up to half as long again -- for as long as the block-parallel kernel beside it is still running: those
         // blocks cost nothing, and the first block behind a 30-tau head fails its seam now and then (an hour at 250 ksps: one
         // repair of two block walks, 1.6 ms; the head stopped 0.9 ms before the kernel beside it)
@@ -1177,15 +1176,15 @@ template <typename T> int run_capture(pdt_ctx *ctx, uint64_t n, int phase = RUN_
         L.begin("pll_head");
         if (slow_wrap)
             PDT_LAUNCH(64, (k_pll_head<T, true>), dim3(1), dim3(64), 0, st, d_theta, N, PP, d_info, Bp, Hd, d_hphi, d_hseams,
-                               d_hinfo, head_blocks, Hd_max, (const PllPhaseHint *)&d_sc->phase_hint, (unsigned)phase_groups,
+                               d_hinfo, head_blocks, Hd_max, (const PllPhaseHint *)d_hint, (unsigned)phase_groups,
                                ((Wacq / 4 + 3) & ~3ll) + Wacq + Wp + Bp);
         else if (serial_excl)
             PDT_LAUNCH(64, (k_pll_head<T, false, true>), dim3(1), dim3(64), 0, st, d_theta, N, PP, d_info, Bp, Hd, d_hphi, d_hseams,
-                               d_hinfo, head_blocks, Hd_max, (const PllPhaseHint *)&d_sc->phase_hint, (unsigned)phase_groups,
+                               d_hinfo, head_blocks, Hd_max, (const PllPhaseHint *)d_hint, (unsigned)phase_groups,
                                ((Wacq / 4 + 3) & ~3ll) + Wacq + Wp + Bp);
         else
             PDT_LAUNCH(64, (k_pll_head<T, false>), dim3(1), dim3(64), 0, st, d_theta, N, PP, d_info, Bp, Hd, d_hphi, d_hseams,
-                               d_hinfo, head_blocks, Hd_max, (const PllPhaseHint *)&d_sc->phase_hint, (unsigned)phase_groups,
+                               d_hinfo, head_blocks, Hd_max, (const PllPhaseHint *)d_hint, (unsigned)phase_groups,
                                ((Wacq / 4 + 3) & ~3ll) + Wacq + Wp + Bp);
         L.end();
         PL.simple(OP_JOIN_WAIT);                                           // join
@@ -1246,7 +1245,7 @@ template <typename T> int run_capture(pdt_ctx *ctx, uint64_t n, int phase = RUN_
             quality_side = !inject && !ctx->tune.quality_inline;
             // Round 4: where mix and filter are one kernel (k_mix_fir, eight wavefronts) that kernel writes the EMA's input term
             // on its way; the walkers below are then launched behind it (quality_walkers, further down)
-            quality_term_fused = quality_side && fuse_mix && ctx->tune.mf_waves != 4 && std::is_same<T, float>::value;
+            quality_term_fused = quality_side && fuse_mix && std::is_same<T, float>::value;
             }
         quality_walkers_late = [&](bool term_here) {
             hipStream_t sq = quality_side ? ctx->stream2 : st;
@@ -1315,16 +1314,13 @@ template <typename T> int run_capture(pdt_ctx *ctx, uint64_t n, int phase = RUN_
                     fused_tiles = runs_nat;
                     agc_maps_per_block = agc_tiles_per_block * (64 * 26 / PDT_MF_RUN);
                 }
-                // eight wavefronts per workgroup (two workgroups per CU = four wavefronts per SIMD); PDT_MF_WAVES=4: the first form
+                // eight wavefronts per workgroup (two workgroups per CU = four wavefronts per SIMD)
                 const unsigned mf_grid = (unsigned)(lt_tiles * (Bp / PDT_MF_RUN));
                 // (a stream segment keeps the PLL output's tail: the next segment's filter starts from its last 25 samples)
                 float *mf_pll = (ctx->keep_pll || seg) ? (float *)d_pll : (float *)nullptr;
                 const long long mf_pll_from = (seg && !ctx->keep_pll) ? std::max<long long>(0, N - 256) : 0ll;
 #define PDT_MF_ARGS d_pcm, (const float *)d_phi, (const float *)d_pll, N, Bp, (const PllLockInfo<float> *)d_info, (const float *)ctx->taps_rot.p, (float *)d_fir, mf_pll, run_maps, (float)AP.decay
-                if (ctx->tune.mf_waves == 4) {
-                    if (d_pcm.fmt == 0) PDT_LAUNCH(256, (k_mix_fir<26, 0, 4>), dim3(mf_grid), dim3(256), 0, st, PDT_MF_ARGS, (float *)nullptr, mf_pll_from);
-                    else PDT_LAUNCH(256, (k_mix_fir<26, 1, 4>), dim3(mf_grid), dim3(256), 0, st, PDT_MF_ARGS, (float *)nullptr, mf_pll_from);
-                } else if (quality_after_fir) {
+                if (quality_after_fir) {
                     float *d_tap = (float *)ctx->term_ap.p;
                     if (d_pcm.fmt == 0) PDT_LAUNCH(512, (k_mix_fir<26, 0, 8, true>), dim3(mf_grid), dim3(512), 0, st, PDT_MF_ARGS, d_tap, mf_pll_from);
                     else PDT_LAUNCH(512, (k_mix_fir<26, 1, 8, true>), dim3(mf_grid), dim3(512), 0, st, PDT_MF_ARGS, d_tap, mf_pll_from);
@@ -1585,13 +1581,7 @@ template <typename T> int run_capture(pdt_ctx *ctx, uint64_t n, int phase = RUN_
                                (GardnerBand *)ctx->gbands.p, (unsigned *)ctx->gclist.p, d_sc->gstats, scout_tail);
             {
                 // locked chunks carry 100-300 candidates that merge quickly: see k_gardner_table_merge
-                if (ctx->tune.gtab_nomerge) {
-                    constexpr int TT = PDT_GTAB_THREADS, TW = PDT_GTAB_WIN;
-                    const unsigned parts = (unsigned)((GD.n_cand + 2 * TT - 1) / (2 * TT));
-                    PDT_LAUNCH(PDT_GTAB_THREADS, (k_gardner_table<TT, TW>), dim3((unsigned)n_tab, parts), dim3(TT), 0, st, (const float *)d_agc, GP,
-                                       GD, n_tab, (const unsigned *)ctx->gcand.p, (const GardnerBand *)ctx->gbands.p,
-                                       (const unsigned *)ctx->gclist.p, (unsigned *)ctx->gtable.p, d_sc->gstats);
-                } else {
+                {
                     const unsigned parts = (unsigned)((GD.n_cand + PDT_GTM_SLOTS - 1) / PDT_GTM_SLOTS);
                     PDT_LAUNCH(PDT_GTM_THREADS, (k_gardner_table_merge<PDT_GTAB_WIN>), dim3((unsigned)n_tab, parts), dim3(PDT_GTM_THREADS), 0, st,
                                        (const float *)d_agc, GP, GD, n_tab, (const unsigned *)ctx->gcand.p,
@@ -2120,13 +2110,6 @@ int ingest_capture(pdt_ctx *ctx, const IngestSrc &src, size_t bytes, void *dst, 
     if (T < 1) T = 1;
     const int nslots = T * PDT_INGEST_SLOTS;
     const size_t need = (size_t)nslots * PDT_INGEST_SPAN;
-    if (need > ctx->ingest_pin_cap) {
-        if (ctx->ingest_pin) (void)hipHostFree(ctx->ingest_pin);
-        ctx->ingest_pin = nullptr;
-        ctx->ingest_pin_cap = 0;
-        if (timed_host_malloc((void **)&ctx->ingest_pin, need) != hipSuccess) { (void)hipGetLastError(); return PDT_ERR_NOMEM; }
-        ctx->ingest_pin_cap = need;
-    }
     // The copy streams live at the LOWEST stream priority: streams of one priority share a few hardware queues, and a copy stream
     // that lands on the queue of the demodulation stream waits behind that stream's kernels -- beside a running segment (a 5 ms PLL
     // kernel) one of four copy streams stood still, and with it the ring of pinned slots: the overlapped ingest crawled at
@@ -2139,17 +2122,29 @@ int ingest_capture(pdt_ctx *ctx, const IngestSrc &src, size_t bytes, void *dst, 
         (void)hipGetLastError();
         return hipStreamCreateWithFlags(out, hipStreamNonBlocking);
     };
-    if (!ctx->copy_stream) HIP_TRY(make_copy_stream(&ctx->copy_stream));
-    if (!ctx->ev_ingest) HIP_TRY(hipEventCreateWithFlags(&ctx->ev_ingest, hipEventDisableTiming));
+    const auto t_setup0 = std::chrono::steady_clock::now();
     // copy streams in use: hour-long captures spread their span copies over four (3.6 GB: 123 -> 107 ms for the whole call,
     // ~51 GB/s from the page cache to HBM); ten-minute captures are no faster for it
     const int NS = std::min(4, std::max(1, ctx->tune.ingest_streams > 0 ? ctx->tune.ingest_streams : (bytes >= ((size_t)512 << 20) ? 4 : 1)));
-    hipStream_t cs[4] = { ctx->copy_stream, nullptr, nullptr, nullptr };
+    // (A context's first ingest sets these up, and a one-shot process -- bin/demodPOES -- pays for it in full: a stream is ~10 ms
+    // to create, its first copy ~6 ms more (the runtime starts its DMA queue then), the pinned staging 25 - 30 ms:
+    // tools/probes/cold_path_probe.hip.  Setting them up side by side, a thread each, was measured and made it WORSE -- the pinned
+    // allocation alone then took 0.1 - 0.7 s: the runtime serialises them, badly.  One after the other.)
+    if (need > ctx->ingest_pin_cap) {
+        if (ctx->ingest_pin) (void)hipHostFree(ctx->ingest_pin);
+        ctx->ingest_pin = nullptr;
+        ctx->ingest_pin_cap = 0;
+        if (timed_host_malloc((void **)&ctx->ingest_pin, need) != hipSuccess) { (void)hipGetLastError(); return PDT_ERR_NOMEM; }
+        ctx->ingest_pin_cap = need;
+    }
+    if (!ctx->copy_stream) HIP_TRY(make_copy_stream(&ctx->copy_stream));
+    if (!ctx->ev_ingest) HIP_TRY(hipEventCreateWithFlags(&ctx->ev_ingest, hipEventDisableTiming));
     for (int q = 1; q < NS; q++) {
         if (!ctx->copy_streams_more[q - 1]) HIP_TRY(make_copy_stream(&ctx->copy_streams_more[q - 1]));
         if (!ctx->ev_ingest_more[q - 1]) HIP_TRY(hipEventCreateWithFlags(&ctx->ev_ingest_more[q - 1], hipEventDisableTiming));
-        cs[q] = ctx->copy_streams_more[q - 1];
     }
+    hipStream_t cs[4] = { ctx->copy_stream, nullptr, nullptr, nullptr };
+    for (int q = 1; q < NS; q++) cs[q] = ctx->copy_streams_more[q - 1];
     while (ctx->ingest_ev.size() < (size_t)nslots) {
         hipEvent_t e;
         HIP_TRY(hipEventCreateWithFlags(&e, hipEventDisableTiming));
@@ -2158,6 +2153,9 @@ int ingest_capture(pdt_ctx *ctx, const IngestSrc &src, size_t bytes, void *dst, 
     // the destination may still be read by work queued earlier on the demodulation stream
     HIP_TRY(hipEventRecord(ctx->ev_ingest, ctx->stream));
     for (int q = 0; q < NS; q++) HIP_TRY(hipStreamWaitEvent(cs[q], ctx->ev_ingest, 0));
+    if (ctx->tune.debug_overlap)
+        fprintf(stderr, "ingest_capture: streams / events / pinned staging ready after %.2f ms\n",
+                std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_setup0).count());
     IngestJob local;
     IngestJob *J = job ? job : &local;
     for (int q = 0; q < NS; q++) J->cs[q] = cs[q];
@@ -2502,11 +2500,27 @@ int pdt_open(const pdt_config *cfg, pdt_ctx **out)
             return PDT_ERR_NOGPU;
         }
     }
-    if (hipStreamCreate(&ctx->stream) != hipSuccess) { ctx->stream = nullptr; pdt_close(ctx); return PDT_ERR_NOGPU; }
+    // (the two streams side by side: ~10 ms each, 20 for a process's first -- tools/probes/cold_path_probe.hip)
+    std::thread side_stream_task;
+    auto make_side_stream = [ctx]() {
+        // the side stream at another priority than the main one: streams of one priority share a few hardware queues round
+        // robin, and two streams that land on the same queue run one after the other (seen in a batch trace: the block-parallel
+        // PLL kernel and the acquisition it should run beside, serialised); another priority is another set of queues
+        if (hipSetDevice(ctx->cfg.device) != hipSuccess) { (void)hipGetLastError(); return; }
+        int least = 0, greatest = 0;
+        (void)hipDeviceGetStreamPriorityRange(&least, &greatest);
+        if (hipStreamCreateWithPriority(&ctx->stream2, hipStreamNonBlocking, greatest) != hipSuccess) {
+            (void)hipGetLastError();
+            if (hipStreamCreateWithFlags(&ctx->stream2, hipStreamNonBlocking) != hipSuccess) { (void)hipGetLastError(); ctx->stream2 = nullptr; }
+        }
+    };
+    try { side_stream_task = std::thread(make_side_stream); } catch (const std::exception &) { make_side_stream(); }
+    auto join_side = [&]() { if (side_stream_task.joinable()) side_stream_task.join(); };     // (before the context goes away)
+    if (hipStreamCreate(&ctx->stream) != hipSuccess) { ctx->stream = nullptr; join_side(); pdt_close(ctx); return PDT_ERR_NOGPU; }
     ctx->own_stream = true;
     {
         void *small = nullptr;
-        if (timed_host_malloc((void **)&small, sizeof(DevScalars) + 128 + 32768) != hipSuccess) { pdt_close(ctx); return PDT_ERR_NOMEM; }
+        if (timed_host_malloc((void **)&small, sizeof(DevScalars) + 128 + 32768) != hipSuccess) { join_side(); pdt_close(ctx); return PDT_ERR_NOMEM; }
         ctx->pend_sc = (DevScalars *)small;
         ctx->pend_info = (unsigned char *)small + ((sizeof(DevScalars) + 15) & ~(size_t)15);
         ctx->seg_pin = ctx->pend_info + 128;          // 4 KiB up (kept bits, history symbols, lock record, gain), the rest down (SegTail)
@@ -2515,17 +2529,8 @@ int pdt_open(const pdt_config *cfg, pdt_ctx **out)
     (void)hipEventCreate(&ctx->ev1);
     (void)hipEventCreateWithFlags(&ctx->ev_fork, hipEventDisableTiming);
     (void)hipEventCreateWithFlags(&ctx->ev_join, hipEventDisableTiming);
-    {
-        // the side stream at another priority than the main one: streams of one priority share a few hardware queues round
-        // robin, and two streams that land on the same queue run one after the other (seen in a batch trace: the block-parallel
-        // PLL kernel and the acquisition it should run beside, serialised); another priority is another set of queues
-        int least = 0, greatest = 0;
-        (void)hipDeviceGetStreamPriorityRange(&least, &greatest);
-        if (hipStreamCreateWithPriority(&ctx->stream2, hipStreamNonBlocking, greatest) != hipSuccess) {
-            (void)hipGetLastError();
-            if (hipStreamCreateWithFlags(&ctx->stream2, hipStreamNonBlocking) != hipSuccess) { ctx->stream2 = nullptr; pdt_close(ctx); return PDT_ERR_NOGPU; }
-        }
-    }
+    join_side();
+    if (!ctx->stream2) { pdt_close(ctx); return PDT_ERR_NOGPU; }
     memset(&ctx->stats, 0, sizeof ctx->stats);
     memset(ctx->stage_len, 0, sizeof ctx->stage_len);
     ctx->axis_f.init((float)(1.0 / (double)(float)cfg->sample_rate));        // wave.c:96-97
@@ -2583,6 +2588,22 @@ int pdt_set_stream(pdt_ctx *ctx, void *hip_stream)
         if (hipStreamCreate(&ctx->stream) != hipSuccess) return PDT_ERR_NOGPU;
         ctx->own_stream = true;
     }
+    return PDT_OK;
+}
+
+int pdt_set_loop_params(pdt_ctx *ctx, const pdt_loop_params *p)
+{
+    if (!ctx || !p) return PDT_ERR_ARG;
+    if (ctx->stream_open) return PDT_ERR_STATE;
+    const double v[] = { p->pll_freq_range_hz, p->pll_lock_threshold, p->pll_lock_alpha, p->pll_loopbw_acq, p->pll_loopbw_track, p->agc_attack,
+                         p->agc_decay, p->gardner_baud, p->gardner_step_range, p->gardner_kp, p->manchester_threshold };
+    for (double x : v)
+        if (!(x >= 0.0) || !std::isfinite(x)) return PDT_ERR_ARG;
+    if (p->gardner_baud != 0 && (double)ctx->cfg.sample_rate * (double)ctx->interp / p->gardner_baud < 2.0) return PDT_ERR_ARG;
+    if (p->pll_freq_range_hz != 0 && p->pll_freq_range_hz >= 0.5 * (double)ctx->cfg.sample_rate) return PDT_ERR_ARG;
+    if ((float)p->gardner_step_range > 0.1f) return PDT_ERR_ARG;      // (the samplers' window margins and symbol capacities are sized for the mains' 0.1)
+    ctx->lp = *p;
+    ctx->gcand_key = -1;                    // (the sampler's candidate list depends on the step)
     return PDT_OK;
 }
 
@@ -3049,10 +3070,10 @@ template <typename T> static int stage_gardner(pdt_ctx *ctx, const void *in_host
     const T Fs = (T)ctx->cfg.sample_rate;
     const T fsi = Fs * (T)interp;
     GardnerParams<T> GP;
-    const T baud = argos ? (T)(400 * 2.0) : (T)(8320 * 2 + 0.3);              // main.c:90 / ARGOS main.c:64
+    const T baud = ctx->lp.gardner_baud != 0 ? (T)ctx->lp.gardner_baud : argos ? (T)(400 * 2.0) : (T)(8320 * 2 + 0.3);   // main.c:90 / ARGOS main.c:64
     GP.step = (T)(int)fsi / baud;                                              // GardenerClockRecovery.c:19
-    GP.kp = (T)3.0;
-    GP.lim = (T)0.1;
+    GP.kp = ctx->lp.gardner_kp != 0 ? (T)ctx->lp.gardner_kp : (T)3.0;
+    GP.lim = ctx->lp.gardner_step_range != 0 ? (T)ctx->lp.gardner_step_range : (T)0.1;
     GP.n_total = total;
     GP.chunk_out = C;
     GP.argos_heap = 0;
@@ -3155,7 +3176,7 @@ template <typename T> static int stage_mm(pdt_ctx *ctx, const void *in_host, uin
     const bool argos = ctx->cfg.mode == PDT_MODE_ARGOS;
     const T Fs = (T)ctx->cfg.sample_rate;
     const T fsi = Fs * (T)(int)ctx->interp;
-    const T baud = argos ? (T)(400 * 2.0) : (T)(8320 * 2 + 0.3);
+    const T baud = ctx->lp.gardner_baud != 0 ? (T)ctx->lp.gardner_baud : argos ? (T)(400 * 2.0) : (T)(8320 * 2 + 0.3);
     MmParams<T> MP;
     const T rangeT = (T)(ctx->cfg.mm_step_range != 0 ? ctx->cfg.mm_step_range : 3.0);     // ARGOSdemod/main.c:277
     MP.kp = (T)(ctx->cfg.mm_kp != 0 ? ctx->cfg.mm_kp : 0.15);
@@ -3216,8 +3237,8 @@ template <typename T> static int stage_agc(pdt_ctx *ctx, void *data_host, uint64
     const T Fs = (T)ctx->cfg.sample_rate;
     const T fsi = Fs * (T)interp;                                              // POESTIPdemod/main.c:429
     AgcParams<T> AP;
-    AP.attack = attack != 0 ? (T)attack : (T)(79.5775 * (2.0 * M_PI / (double)fsi));
-    AP.decay = decay != 0 ? (T)decay : (T)(159.1549 * (2.0 * M_PI / (double)fsi));
+    AP.attack = attack != 0 ? (T)attack : ctx->lp.agc_attack != 0 ? (T)ctx->lp.agc_attack : (T)(79.5775 * (2.0 * M_PI / (double)fsi));
+    AP.decay = decay != 0 ? (T)decay : ctx->lp.agc_decay != 0 ? (T)ctx->lp.agc_decay : (T)(159.1549 * (2.0 * M_PI / (double)fsi));
     AP.squelch = 0;
     AP.squelch_thr = 0;
     AP.raw_out = nullptr;

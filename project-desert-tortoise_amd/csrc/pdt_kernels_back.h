@@ -1112,161 +1112,8 @@ __device__ __forceinline__ void k_gardner_scout(const float *__restrict__ in, Ga
     if (lane == 0) bands[r] = bd;
 }
 
-// walk chunk c (a full one) with the NL trajectories every lane carries, window by window, up to the chunk's end (the roll-over
-// of the sampling instant is left to the caller).  The symbol counts go on from what they are.
-template <int THREADS, int WIN, int NL>
-__device__ __forceinline__ void gardner_lanes_chunk(float *win, const float *__restrict__ in, const GardnerParams<float> &P,
-                                                    long long c, GardnerLane (&L)[NL])
-{
-    const long long C = P.chunk_out;
-    const long long base = c * C;
-    const int n_cur = (int)C;
-    const float hs = (float)((double)P.step / 2.0);
-    const float kp = P.kp, lim = P.lim, step = P.step, nT = (float)n_cur;
-    const int margin = 2 * (int)step + 24;          // look-ahead the staged data must cover past a stop point
-    const int back = (int)step + 8;                 // a mid-point lies at most this far behind a stop point
-    int wbase = 0;
-    float enter_hi = step + 1.2f;                 // upper bound of ns when entering the window
-    bool all_started = true;
-    for (;;) {
-        // stage [wbase, wbase + WIN)
-        __syncthreads();
-        for (int t0 = 0; t0 < WIN; t0 += THREADS * 8) {
-            float r[8];
-#pragma unroll
-            for (int u = 0; u < 8; u++) {
-                const int t = t0 + u * THREADS + (int)threadIdx.x;
-                const int idx = wbase + t;
-                r[u] = (t < WIN && idx < n_cur) ? in[base + idx] : 0.0f;
-            }
-#pragma unroll
-            for (int u = 0; u < 8; u++) {
-                const int t = t0 + u * THREADS + (int)threadIdx.x;
-                const int idx = wbase + t;
-                if (t < WIN) {
-                    if (idx >= n_cur && idx < n_cur + margin)
-                        r[u] = gardner_beyond(in, (const float *)nullptr, P, c, (long long)n_cur, (long long)idx);
-                    win[t] = r[u];
-                }
-            }
-        }
-        __syncthreads();
-        const int wend = wbase + WIN;
-        const bool last_window = (wend - margin >= n_cur);
-        const float stop = last_window ? nT : (float)(wend - margin);    // lanes leave the window at rint(ns) >= stop
-        const float *wrel = win - wbase;          // indexed with chunk-relative indices
-        if (wbase == 0) {
-            // first symbol: the mid-point index is the stale one of the previous chunk (Q3)
-#pragma unroll
-            for (int l = 0; l < NL; l++) {
-                const float rn = __builtin_rintf(L[l].ns);
-                if (rn < nT) {
-                    const unsigned i_cur = (unsigned)rn;
-                    const unsigned i_half = (unsigned)__builtin_rintf(L[l].half);
-                    const float cur = win[i_cur];
-                    float mid;
-                    if (i_half < (unsigned)WIN) mid = win[i_half];
-                    else mid = (i_half < (unsigned)n_cur) ? in[base + i_half]
-                                                          : gardner_beyond(in, (const float *)nullptr, P, c, (long long)n_cur, (long long)i_half);
-                    const float err = __builtin_amdgcn_fmed3f(kp * (cur - L[l].prev) * mid, -lim, lim);
-                    L[l].ns = L[l].ns - err;
-                    L[l].q_last = L[l].ns;
-                    L[l].half = L[l].ns + hs;
-                    L[l].ns = L[l].ns + step;
-                    L[l].prev = cur;
-                    L[l].i_last = i_cur;
-                    L[l].count += 1;
-                } else
-                    all_started = false;
-            }
-        }
-        if (all_started) {
-            int k_min = (int)((stop - 4.0f - enter_hi) / (step + 0.101f)) - 1;
-            if (k_min < 0) k_min = 0;
-            for (int it = 0; it < k_min; it++) {
-#pragma unroll
-                for (int l = 0; l < NL; l++) gardner_lane_step(L[l], wrel, kp, lim, hs, step);
-            }
-#pragma unroll
-            for (int l = 0; l < NL; l++) {
-                L[l].count += (unsigned)k_min;
-                gardner_lane_tail(L[l], wrel, stop, kp, lim, hs, step);
-            }
-        }
-        if (last_window) break;
-        enter_hi = stop + step + 1.2f;
-        wbase = wend - margin - back;
-    }
-}
-
-// level 1: block (r, p) runs slice p (2 x THREADS candidates) of row r's candidate list through the row's first chunk, window by
-// window (WIN floats of LDS at a time).  A lane carries NL = 1 or 2 interleaved trajectories (one when
-// the slice holds no more candidates than threads: half the instructions).  All lanes are within a
-// symbol of each other, so they cross the window seams together; inside a window every trajectory
-// takes at least k_min steps before it can reach the stop point (a step advances by at most
-// step + 0.1), so the bulk of the walk is a counted, wave-uniform loop without any per-lane test.
-template <int THREADS, int WIN, int NL>
-__device__ __forceinline__ void gardner_table_block(float *win, const float *__restrict__ in, const GardnerParams<float> &P,
-                                                    const GardnerDomain &D, long long c, const unsigned *__restrict__ cand,
-                                                    int j0, int j_hi, unsigned *__restrict__ row, unsigned *__restrict__ stats)
-{
-    GardnerLane L[NL];
-#pragma unroll
-    for (int l = 0; l < NL; l++) {
-        L[l].ns = L[l].prev = L[l].half = L[l].q_last = 0;
-        L[l].i_last = L[l].count = 0;
-        L[l].k = 0;
-        L[l].active = (j0 + l * THREADS + (int)threadIdx.x) < j_hi;
-        if (L[l].active && c >= 1) {
-            L[l].k = (int)cand[j0 + l * THREADS + threadIdx.x];
-            gardner_entry_from_candidate(in, P, D, c, L[l].k, L[l].ns, L[l].prev, L[l].half);
-        }
-    }
-    // idle slots shadow an active one of the block (their results are discarded) so that every lane
-    // stays inside the staged windows
-    {
-        __shared__ float s_ref[3];
-        if (threadIdx.x == 0) { s_ref[0] = L[0].ns; s_ref[1] = L[0].prev; s_ref[2] = L[0].half; }
-        __syncthreads();
-#pragma unroll
-        for (int l = 0; l < NL; l++)
-            if (!L[l].active) { L[l].ns = s_ref[0]; L[l].prev = s_ref[1]; L[l].half = s_ref[2]; }
-    }
-    gardner_lanes_chunk<THREADS, WIN, NL>(win, in, P, c, L);
-#pragma unroll
-    for (int l = 0; l < NL; l++) {
-        if (L[l].active) {
-            const unsigned cell = gardner_encode_exit(D, L[l].q_last, L[l].i_last, L[l].count);
-            if (cell == PDT_GTAB_MISS) atomicAdd(&stats[0], 1u);  // exit outside the enumerated domain (never expected)
-            row[L[l].k] = cell;
-        }
-    }
-}
-
-template <int THREADS, int WIN>
-__device__ __forceinline__ void k_gardner_table(const float *__restrict__ in, GardnerParams<float> P,
-                                                            GardnerDomain D, long long n_tab_chunks,
-                                                            const unsigned *__restrict__ cand_k,
-                                                            const GardnerBand *__restrict__ bands,
-                                                            const unsigned *__restrict__ clist,
-                                                            unsigned *__restrict__ table,
-                                                            unsigned *__restrict__ stats /* [0] bad */)
-{
-    __shared__ float win[WIN];
-    const long long r = blockIdx.x;                 // table row
-    if (r >= n_tab_chunks) return;
-    const long long c = r * D.span;                 // its first chunk (always a full one)
-    const GardnerBand bd = bands[r];
-    const int j0 = bd.j_lo + (int)blockIdx.y * 2 * THREADS;
-    const int j_hi = bd.j_hi;
-    if (j0 >= j_hi) return;
-    const unsigned *cand = bd.listed ? (clist + (size_t)blockIdx.x * PDT_GTAB_LIST) : cand_k;
-    unsigned *row = table + (size_t)r * (size_t)(2 * D.n_q);
-    if (j_hi - j0 <= THREADS) gardner_table_block<THREADS, WIN, 1>(win, in, P, D, c, cand, j0, j_hi, row, stats);
-    else gardner_table_block<THREADS, WIN, 2>(win, in, P, D, c, cand, j0, j_hi, row, stats);
-}
-
-// level 1 with merging.  Candidate trajectories of one chunk collapse onto each other as they go
+// level 1: block (r, p) runs slice p of row r's candidate list through the row's first chunk, window by window, merging as it
+// goes.  Candidate trajectories of one chunk collapse onto each other as they go
 // (same picks -> same corrections -> identical state from then on): of ~150 entry states only a
 // handful of distinct trajectories are left after a few hundred symbols.  A workgroup of two
 // wavefronts therefore starts with up to 256 candidates (two per lane), and at every window seam,

@@ -135,58 +135,6 @@ template <typename T> __device__ __forceinline__ T pll_locksig(T a, T b, T t_rea
     return (T)((double)locksig * (1.0 - (double)lock_alpha) + (double)(lock_alpha * (re * t_real + im * t_imag)));
 }
 
-// Acquisition, plain form: the reference iteration sample by sample on one lane until the one-time lock
-// event (Q9).  Kept as the readable statement of the iteration and for A/B runs (PDT_ACQUIRE_SIMPLE); the
-// product path is k_pll_acquire_pipe below.
-template <typename T>
-__device__ __forceinline__ void k_pll_acquire(IqSrc pcm, long long n, PllParams<T> P,
-                                                     T *__restrict__ out, T *__restrict__ lock_out,
-                                                     PllLockInfo<T> *__restrict__ info)
-{
-    if (threadIdx.x != 0 || blockIdx.x != 0) return;
-    PllState<T> s;
-    s.phase = P.phase0;
-    s.freq = P.freq0;
-    s.avg_phase = P.avg0;
-    s.locksig = P.locksig0;
-    s.sweep = P.sweep0;
-    const T avg_alpha = (T)0.00005;
-    long long lock_at = -1;
-    T freq_at_lock = 0, avg_at_lock = P.avg0;
-    long long i = P.i0;
-    for (; i < n; i++) {
-        T a, b, o_re, o_im, t_real, t_imag;
-        IqSample<T>::get(pcm, i, a, b);
-        pll_core(a, b, s.phase, s.freq, P.alpha_acq, P.beta_acq, P.max_freq, P.min_freq, o_re, o_im, t_real, t_imag);
-        out[i] = o_im;
-        const T ph = arctan2_ref(o_im, o_re);                                              // :117
-        s.avg_phase = (T)((double)s.avg_phase * (1.0 - (double)avg_alpha) + (double)(avg_alpha * Real<T>::abs(ph)));
-        s.locksig = pll_locksig(a, b, t_real, t_imag, s.locksig, P.lock_alpha);
-        if (lock_out) lock_out[i] = s.locksig;
-        if ((double)Real<T>::abs((T)(PDT_PI / 2.0 - (double)s.avg_phase)) < 0.05) {        // :232-246
-            s.freq = s.freq + s.sweep;
-            if (s.freq >= P.max_freq)
-                s.sweep = -s.sweep;
-            else if (s.freq <= P.min_freq)
-                s.sweep = -s.sweep;
-            else if (s.freq >= 0)
-                s.sweep = Real<T>::abs(s.sweep);
-            else
-                s.sweep = -Real<T>::abs(s.sweep);
-        }
-        if (s.locksig > P.lock_thr) {                                                      // :266-274
-            lock_at = i;
-            freq_at_lock = s.freq;
-            avg_at_lock = s.avg_phase;
-            break;
-        }
-    }
-    info->lock_sample = lock_at;
-    info->st = s;
-    info->freq_at_lock = freq_at_lock;
-    info->avg_at_lock = avg_at_lock;
-}
-
 // ---- tracking phase, split in three so that only the true recurrence is serial -------------
 //   k_pll_theta : theta_i = arctan2(Im x_i, Re x_i)                (elementwise, state-free)
 //   k_pll_phase : (phase, freq) recurrence over theta, one lane per block, stores the phase
@@ -356,21 +304,6 @@ __device__ __forceinline__ void pll_phase_step(T th, T &phase, T &freq, T alpha,
     freq = PiAbs<T>::clamp(f1, minf, maxf);
 }
 
-// Acquisition, fast form.  One wavefront; the stream is taken in batches of 32 samples, sample k
-// of the batch living in lane k:
-//   pass 1 (serial, every lane computes the same values): the (phase, freq) loop filter over the
-//           precomputed theta, under the hypothesis that the sweep condition
-//           |pi/2 - averagePhase| < 0.05 keeps the value it had at the previous sample (it changes a
-//           handful of times per capture); lane k keeps the states around sample k;
-//   pass 2 (lane-parallel): everything that depends only on phase_k -- sincos, the mix, arctan2 of
-//           the output, the two EMA input terms;
-//   pass 3 (serial): the averagePhase and lock-detector EMAs (two interleaved f64 chains), the
-//           sweep condition and the lock test of every sample; the first sample whose sweep
-//           condition contradicts the hypothesis rolls the batch back to that sample.
-// The operations per sample and their order are those of the reference iteration
-// (CarrierTrackingPLL.c:102-275); only independent pieces of different samples are interleaved.
-// Lane <-> uniform traffic is v_readlane / v_cndmask only: no LDS, no barriers, and the only
-// memory operations are one coalesced load of theta and IQ per batch (issued one batch ahead).
 // theta of one sample, as k_pll_theta computes it (the acquisition reads a few thousand samples in natural order; the theta
 // stream itself is kept in the block-parallel kernel's LT layout)
 template <typename T> __device__ __forceinline__ T theta_of(IqSrc pcm, long long i)
@@ -408,167 +341,10 @@ template <typename T> __device__ __forceinline__ void pll_sweep_sel(T &fr, T &sw
     sw = on ? s2 : sw;
 }
 
-template <typename T, bool SLOW>
-__device__ __forceinline__ void k_pll_acquire_fast(IqSrc pcm, long long n, PllParams<T> P,
-                                                          T *__restrict__ out, T *__restrict__ lock_out,
-                                                          PllLockInfo<T> *__restrict__ info)
-{
-    const int lane = threadIdx.x;
-    const T avg_alpha = (T)0.00005;
-    const double k_avg = 1.0 - (double)avg_alpha, k_lock = 1.0 - (double)P.lock_alpha;
-    T phase = P.phase0, freq = P.freq0, avg = P.avg0, locksig = P.locksig0, sweep = P.sweep0;
-    bool hyp = avg >= P.cond_lo && avg <= P.cond_hi;   // sweep condition assumed for the next sample
-    long long lock_at = -1;
-    T freq_at_lock = 0, avg_at_lock = P.avg0;
-    long long i0 = P.i0;
-    // per-lane inputs of the current batch and of the one after it
-    T th_l = 0, a_l = 0, b_l = 0, th_n = 0, a_n = 0, b_n = 0;
-    long long i_next = -1;     // batch start th_n/a_n/b_n were loaded for
-    T p_o = 0, p_ls = 0;       // outputs of the previous batch, not yet stored
-    long long p_i0 = 0;
-    int p_done = 0;
-    if (lane < PDT_ACQ_NB && i0 + lane < n) {
-        IqSample<T>::get(pcm, i0 + lane, a_l, b_l);
-        th_l = arctan2_ref(b_l, a_l);
-    }
-#ifdef PDT_ACQ_PROF
-    long long pc[5] = {0, 0, 0, 0, 0}, pt = clock64(), nbatch = 0;
-#define PDT_ACQ_TICK(k) { const long long now_ = clock64(); pc[k] += now_ - pt; pt = now_; }
-#else
-#define PDT_ACQ_TICK(k)
-#endif
-    while (i0 < n && lock_at < 0) {
-        const int nb = (int)((n - i0 < PDT_ACQ_NB) ? (n - i0) : PDT_ACQ_NB);
-        i_next = i0 + PDT_ACQ_NB;
-        if (lane < PDT_ACQ_NB && i_next + lane < n) {
-            IqSample<T>::get(pcm, i_next + lane, a_n, b_n);
-            th_n = arctan2_ref(b_n, a_n);
-        }
-        if (lane < p_done) {
-            out[p_i0 + lane] = p_o;
-            if (lock_out) lock_out[p_i0 + lane] = p_ls;
-        }
-        p_done = 0;
-        PDT_ACQ_TICK(0)
-        // ---- pass 1: loop filter; lane k keeps phase before / after sample k, freq before the sweep
-        // step, and the sweep increment before it
-        T phi_l = 0, phn_l = 0, fpre_l = 0, swb_l = 0;
-        {
-            T ph = phase, fr = freq, sw = sweep;
-            for (int k = 0; k < nb; k++) {
-                const T th = lane_get(th_l, k);
-                const bool mine = lane == k;
-                phi_l = mine ? ph : phi_l;
-                pll_phase_step<T, SLOW>(th, ph, fr, P.alpha_acq, P.beta_acq, P.max_freq, P.min_freq);
-                phn_l = mine ? ph : phn_l;
-                fpre_l = mine ? fr : fpre_l;
-                swb_l = mine ? sw : swb_l;
-                pll_sweep_sel(fr, sw, P.max_freq, P.min_freq, hyp);
-            }
-        }
-        PDT_ACQ_TICK(1)
-        // ---- pass 2: per-sample work (lane k <-> sample k)
-        T t_l = 0, u_l = 0, o_l = 0;
-        {
-            T t_real, t_imag;
-            Real<T>::sincos(phi_l, t_imag, t_real);
-            const T c = t_real, d = -t_imag;
-            const T o_re = a_l * c - b_l * d;
-            const T o_im = a_l * d + b_l * c;
-            o_l = o_im;
-            const T ph = arctan2_ref(o_im, o_re);
-            t_l = avg_alpha * Real<T>::abs(ph);
-            const T mag2 = a_l * a_l + b_l * b_l;
-            const T inv = (T)q_rsqrt((float)mag2);
-            const T re = a_l * inv, im = b_l * inv;
-            u_l = P.lock_alpha * (re * t_real + im * t_imag);
-        }
-        PDT_ACQ_TICK(2)
-        // ---- pass 3: EMAs, sweep condition, lock test
-        int done = nb;            // samples of this batch that stand
-        bool flip = false;
-        T ls_l = 0;
-        {
-            // every sample of the batch is evaluated (no branch in the loop); the first sample whose sweep
-            // condition contradicts the hypothesis or whose lock detector crosses the threshold ends the
-            // batch, and the EMA values of that sample are picked up from the lane that kept them
-            T av = avg, ls = locksig, av_l = 0;
-            unsigned ev_flip = 0, ev_lock = 0;
-            for (int k = 0; k < nb; k++) {
-                av = (T)((double)av * k_avg + (double)lane_get(t_l, k));
-                ls = (T)((double)ls * k_lock + (double)lane_get(u_l, k));
-                const bool mine = lane == k;
-                ls_l = mine ? ls : ls_l;
-                av_l = mine ? av : av_l;
-                const bool cond = av >= P.cond_lo && av <= P.cond_hi;
-                ev_flip |= (cond != hyp) ? (1u << k) : 0u;
-                ev_lock |= (ls > P.lock_thr) ? (1u << k) : 0u;
-            }
-            ev_flip = (unsigned)__builtin_amdgcn_readfirstlane((int)ev_flip);
-            ev_lock = (unsigned)__builtin_amdgcn_readfirstlane((int)ev_lock);
-            const unsigned ev = ev_flip | ev_lock;
-            if (ev) {
-                // sample k ends the batch: its sweep step is taken with its own (true) condition
-                const int k = __builtin_ctz(ev);
-                flip = (ev_flip >> k) & 1u;
-                const bool cond = flip ? !hyp : hyp;
-                T fr = lane_get(fpre_l, k), sw = lane_get(swb_l, k);
-                if (cond) pll_sweep_step(fr, sw, P.max_freq, P.min_freq);
-                phase = lane_get(phn_l, k);
-                freq = fr;
-                sweep = sw;
-                hyp = cond;
-                done = k + 1;
-                avg = lane_get(av_l, k);
-                locksig = lane_get(ls_l, k);
-                if ((ev_lock >> k) & 1u) {
-                    lock_at = i0 + k;
-                    freq_at_lock = freq;
-                    avg_at_lock = avg;
-                }
-            } else {
-                // the whole batch stands: adopt the state after its last sample
-                avg = av;
-                locksig = ls;
-                const int kl = nb - 1;
-                T fr = lane_get(fpre_l, kl), sw = lane_get(swb_l, kl);
-                if (hyp) pll_sweep_step(fr, sw, P.max_freq, P.min_freq);
-                phase = lane_get(phn_l, kl);
-                freq = fr;
-                sweep = sw;
-            }
-        }
-        PDT_ACQ_TICK(3)
-        p_o = o_l; p_ls = ls_l; p_i0 = i0; p_done = done;
-        i0 += done;
-        if (i0 == i_next) {
-            th_l = th_n; a_l = a_n; b_l = b_n;
-        } else if (lane < PDT_ACQ_NB && i0 + lane < n) {
-            IqSample<T>::get(pcm, i0 + lane, a_l, b_l);
-            th_l = arctan2_ref(b_l, a_l);
-        }
-        PDT_ACQ_TICK(4)
-    }
-#ifdef PDT_ACQ_PROF
-    if (lane == 0)
-        printf("acquire: %lld samples; cycles top %lld pass1 %lld pass2 %lld pass3 %lld tail %lld\n", i0, pc[0], pc[1], pc[2], pc[3], pc[4]);
-#endif
-    if (lane < p_done) {
-        out[p_i0 + lane] = p_o;
-        if (lock_out) lock_out[p_i0 + lane] = p_ls;
-    }
-    if (lane == 0) {
-        PllState<T> st;
-        st.phase = phase; st.freq = freq; st.avg_phase = avg; st.locksig = locksig; st.sweep = sweep;
-        info->lock_sample = lock_at;
-        info->st = st;
-        info->freq_at_lock = freq_at_lock;
-        info->avg_at_lock = avg_at_lock;
-    }
-}
-
-// Acquisition, pipelined over two wavefronts.  The loop filter of a batch (pass 1 of
-// k_pll_acquire_fast) depends on the detector passes (2 and 3) only through the two rare events "sweep gate
+// Acquisition, pipelined over two wavefronts.  The stream is taken in batches, sample k of a batch in lane k.  The (phase, freq)
+// loop filter of a batch -- serial, run under the hypothesis that the sweep condition |pi/2 - averagePhase| < 0.05 keeps the value
+// it had (it changes a handful of times per capture) -- depends on the detector passes (lane-parallel sincos / mix / arctan2,
+// then the two serial EMAs with the sweep condition and the lock test of every sample) only through the two rare events "sweep gate
 // flipped" and "locked"; so wavefront 0 runs the loop filter of batch t while wavefront 1 evaluates
 // the detectors of batch t-1 from the per-sample states wavefront 0 left in LDS.  When wavefront 1
 // reports an event inside batch t-1, the speculative batch t is dropped and wavefront 0 resumes from

@@ -21,9 +21,11 @@
  *                              running-sum time axis, SURVEY Q1 -- a program linked against this library needs no object of
  *                              the reference any more)
  * What the kernels do not carry -- the time arrays -- is index bookkeeping and is done here exactly as the reference does it
- * (LowPassFilter.c:67, GardenerClockRecovery.c:30,111, ManchesterDecode.c:86, ByteSync.c:96).  The constants a call passes
- * (loop bandwidths, baud rate, taps ...) must be the ones the mains pass: the kernels are built for those chains, anything else
- * ends the program with a message.
+ * (LowPassFilter.c:67, GardenerClockRecovery.c:30,111, ManchesterDecode.c:86, ByteSync.c:96).  The loop constants a call passes
+ * (frequency range, lock threshold and rate, loop bandwidths; AGC rates; baud rate, timing gain and clip; resync threshold) are
+ * handed on to the context (pdt_set_loop_params, round 5): any values, call by call, as with the reference.  What must still be
+ * the mains': the filter (MakeLPFIR's design for the chain: the FIR kernels are built around its 26 taps per phase), a timing
+ * clip of at most 0.1, M&M's limits, the sync words -- anything else there ends the program with a message.
  *
  * No CPU path: without a GPU the first call ends the program ("pdt_compat: ... no HIP device").
  */
@@ -65,14 +67,19 @@ static pdt_ctx *ctx_for(uint32_t rate)
     memset(&cfg, 0, sizeof cfg);
     cfg.mode = COMPAT_MODE;
     cfg.sample_rate = rate ? rate : (COMPAT_MODE == PDT_MODE_ARGOS ? 32000u : 50000u);     /* (StaticGain does not depend on it) */
-    const char *tw = getenv("PDT_COMPAT_LIVE");                /* the sound-card twin's constants (POESTIPdemodPortAudio/main.c:41-65) */
-    if (tw && COMPAT_MODE == PDT_MODE_POES) cfg.chain = 1;
     g_rate = cfg.sample_rate;
     TRY(pdt_open(&cfg, &g_ctx));
     return g_ctx;
 }
 
-static int close_to(double a, double b) { return fabs(a - b) <= 1e-6 * fmax(fabs(a), fabs(b)) + 1e-300; }
+/* the loop constants the stage functions were last called with, as the context holds them (0 = the mains') */
+static pdt_loop_params g_lp;
+static void set_params(pdt_ctx *c, const pdt_loop_params *want)
+{
+    if (memcmp(&g_lp, want, sizeof g_lp) == 0) return;
+    TRY(pdt_set_loop_params(c, want));
+    g_lp = *want;
+}
 
 /* `DT complex` samples as something the stage entries take: float pairs as they are; doubles are the WAV's int16 / 32768
  * (wave.c:127-172), converted back exactly */
@@ -130,17 +137,15 @@ DT CarrierTrackPLL(DT complex *complexDataIn, DT *realDataOut, DT *lockSignalStr
 {
     pdt_ctx *c = ctx_for((uint32_t)Fs);
     g_used = 1;
-    /* the constants of POESTIPdemod/main.c:413 (twin: POESTIPdemodPortAudio/main.c:41-57) / ARGOSdemod/main.c:265 */
-    const double w = 2.0 * M_PI / (double)Fs;
-#ifdef PDT_COMPAT_ARGOS
-    const int ok = freqRange == (DT)550.0 && d_lock_threshold == (DT)0.1 && close_to(lockSigAlpha, 3.1831 * w) &&
-                   close_to(loopbw_acq, 16 * w) && close_to(loopbw_track, 16 * w);
-#else
-    const int twin = getenv("PDT_COMPAT_LIVE") != NULL;
-    const int ok = freqRange == (DT)4500.0 && d_lock_threshold == (DT)(twin ? 0.10 : 0.08) && close_to(lockSigAlpha, 0.3979 * w) &&
-                   close_to(loopbw_acq, (twin ? 198.9437 : 127.3240) * w) && close_to(loopbw_track, 10.3451 * w);
-#endif
-    if (!ok) die("CarrierTrackPLL constants", 0);
+    {   /* its constants, whatever they are (CarrierTrackPLL.h:11) */
+        pdt_loop_params lp = g_lp;
+        lp.pll_freq_range_hz = (double)freqRange;
+        lp.pll_lock_threshold = (double)d_lock_threshold;
+        lp.pll_lock_alpha = (double)lockSigAlpha;
+        lp.pll_loopbw_acq = (double)loopbw_acq;
+        lp.pll_loopbw_track = (double)loopbw_track;
+        set_params(c, &lp);
+    }
     int fmt;
     void *tmp;
     const void *iq = iq_arg(complexDataIn, nSamples, &fmt, &tmp);
@@ -208,8 +213,8 @@ static void check_sampler(int Fs, DT baud)
 {
     int interp = 1;
     TRY(pdt_make_lpf(COMPAT_MODE, g_rate, NULL, NULL, &interp));
-    if ((uint32_t)Fs != g_rate * (uint32_t)interp || baud != (DT)(COMPAT_MODE == PDT_MODE_ARGOS ? 400 * 2.0 : 8320 * 2 + 0.3))
-        die("sampler rate / baud", 0);
+    if ((uint32_t)Fs != g_rate * (uint32_t)interp) die("sampler rate other than the filter's output rate", 0);
+    (void)baud;
 }
 
 static pdt_gardner_state g_gardner;
@@ -219,7 +224,14 @@ unsigned long GardenerClockRecovery(DT *dataStreamIn, DT *dataStreamInTime, unsi
     pdt_ctx *c = ctx_for(0);
     g_used = 1;
     check_sampler(Fs, baud);
-    if (stepRange != (DT)0.1 || kp != (DT)3.0) die("GardenerClockRecovery limits", 0);       /* main.c:438, ARGOSdemod/main.c:278 */
+    {   /* baud, clip and gain of this call (GardenerClockRecovery.h:3; the mains: main.c:438, ARGOSdemod/main.c:278) */
+        pdt_loop_params lp = g_lp;
+        lp.gardner_baud = (double)baud;
+        lp.gardner_step_range = (double)stepRange;
+        lp.gardner_kp = (double)kp;
+        if (stepRange > (DT)0.1) die("GardenerClockRecovery stepRange above 0.1", 0);
+        set_params(c, &lp);
+    }
     /* The function reads a little past numSamples (the first symbol's stale mid-point index, Q3; the last symbol's look-ahead):
      * whatever lies behind the caller's samples, in its buffer or behind it (Q16).  So does this one: the kernel is handed the
      * caller's memory up to the furthest index the sampler can form. */
@@ -256,6 +268,11 @@ unsigned long MMClockRecovery(DT *dataStreamIn, DT *dataStreamInTime, unsigned l
     pdt_ctx *c = ctx_for(0);
     g_used = 1;
     check_sampler(Fs, baud);
+    {
+        pdt_loop_params lp = g_lp;
+        lp.gardner_baud = (double)baud;
+        set_params(c, &lp);
+    }
     if (stepRange != (DT)3.0 || kp != (DT)0.15) die("MMClockRecovery limits (the context's are 3 and 0.15, ARGOSdemod/main.c:277)", 0);
     const double step_min = (double)Fs / ((double)baud + (double)stepRange);
     const unsigned long cap_sym = (unsigned long)((double)numSamples / step_min) + 4;

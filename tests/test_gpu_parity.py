@@ -306,12 +306,11 @@ def test_ten_minute_capture_matches_oracle(pdt, orc):
         assert d.stats().frames == len(o.frames()) >= 5990
 
 
-@pytest.mark.parametrize("switch", ["PDT_ACQUIRE_SIMPLE", "PDT_ACQUIRE_ONEWAVE", "PDT_GTAB_NOMERGE", "PDT_FIR_GENERIC",
-                                    "PDT_AGC_UNFUSED", "PDT_GARDNER_ONEBUF", "PDT_GARDNER_NORING", "PDT_EMA_NOGUESS",
-                                    "PDT_GARDNER_SEQUENTIAL"])
+@pytest.mark.parametrize("switch", ["PDT_FIR_GENERIC", "PDT_AGC_UNFUSED", "PDT_GARDNER_ONEBUF", "PDT_GARDNER_NORING", "PDT_EMA_NOGUESS",
+                                    "PDT_GARDNER_SEQUENTIAL", "PDT_AGC_LANES"])
 def test_alternative_kernels_agree(pdt, orc, clip, switch):
-    """The older / generic kernel variants kept behind environment switches (tools/README.md) -- some of them are the
-    fallbacks other geometries take -- give the same bits as the default path."""
+    """The generic kernel variants behind developer switches (tools/README.md) -- the fallbacks other geometries take by
+    themselves -- give the same bits as the default path."""
     rate, iq = clip
     o = orc.Oracle(orc.POES, rate, iq)
     a = pdt.synth_capture(1, 32000, 8.0, f0_hz=150.0, seed=31)

@@ -2,4 +2,4 @@
 cd "$GRAFT_REPO_ROOT" 2>/dev/null || cd /root/repo
 mkdir -p gpurun_out/r5
 export TMPDIR=/tmp
-timeout 900 python tools/e2e_ab.py 10 plain=PDT_NO_OVERLAP:1 p_s2=PDT_NO_OVERLAP:1,PDT_INGEST_STREAMS:2 p_s2_t12=PDT_NO_OVERLAP:1,PDT_INGEST_STREAMS:2,PDT_INGEST_THREADS:12 p_s2_t16=PDT_NO_OVERLAP:1,PDT_INGEST_STREAMS:2,PDT_INGEST_THREADS:16 p_s3_t12=PDT_NO_OVERLAP:1,PDT_INGEST_STREAMS:3,PDT_INGEST_THREADS:12 p_s2_t12_4mb=PDT_NO_OVERLAP:1,PDT_INGEST_STREAMS:2,PDT_INGEST_THREADS:12,PDT_INGEST_SPAN_MB:4 p_s2_t12_16mb=PDT_NO_OVERLAP:1,PDT_INGEST_STREAMS:2,PDT_INGEST_THREADS:12,PDT_INGEST_SPAN_MB:16 2>&1 | grep -v amdgpu.ids | tee gpurun_out/r5/ab2_ingest.txt
+timeout 900 python tools/e2e_ab.py 24 plain=PDT_NO_OVERLAP:1 s3_noearly=PDT_NO_EARLY_PLL:1 s3_early=PDT_X:0 2>&1 | grep -v "amdgpu.ids" | tee gpurun_out/r5/ab_early.txt
