@@ -729,6 +729,282 @@ void launch_bytesync(pdt_ctx *ctx, Plan &PL, hipStream_t st, const SyncParams &S
                        &d_sc->nframes, frame_cap);
 }
 
+// What run_capture's recording phase hands to its finish phase (finish_capture): the capacities and flags the read-back needs.
+struct FinishArgs {
+    bool argos, need_lock, fuse_mix;
+    long long N, n_out, chunk, chunk_out, first, first_out, sym_cap;
+    int interp, ntaps;
+    uint32_t hit_cap, frame_cap;
+    SyncParams SP;
+};
+
+// The finish phase of a demodulation call (RUN_ALL / RUN_FINISH): wait for the launches, read the scalars, the lock record and
+// the frame records back, put the host-side time stamps on the frames, fill the statistics; for
+// a stream segment, carry every stage's state to the next one.  (Round 5: split off run_capture.)
+template <typename T> int finish_capture(pdt_ctx *ctx, uint64_t n, const FinishArgs &FA)
+{
+    const bool argos = FA.argos, need_lock = FA.need_lock, fuse_mix = FA.fuse_mix;
+    const long long N = FA.N, n_out = FA.n_out, chunk = FA.chunk, chunk_out = FA.chunk_out, first = FA.first, first_out = FA.first_out,
+                    sym_cap = FA.sym_cap;
+    const int interp = FA.interp, ntaps = FA.ntaps;
+    const uint32_t hit_cap = FA.hit_cap, frame_cap = FA.frame_cap;
+    const SyncParams &SP = FA.SP;
+    const T Fs = (T)ctx->cfg.sample_rate;
+    StreamCarry *seg = ctx->sc.active ? &ctx->sc : nullptr;
+    FrameRec *d_frames = (FrameRec *)ctx->frames.p;
+    (void)first_out;
+    if (!ctx->pending || ctx->pend_n != n) return PDT_ERR_STATE;
+    ctx->pending = false;
+    pdt_ctx *lead = ctx->leader ? ctx->leader : ctx;
+    if (seg && seg->in_place && !ctx->tune.sync_block) {
+        // the overlapped ingest: wait for the segment WITHOUT sitting inside the runtime -- the ingest's submitter thread is
+        // queueing copies all the while (a blocking hipStreamSynchronize here held it up: the copies stopped for as long as a
+        // segment's kernels ran, tools/jobs/r5_e2e_ab.sh)
+        for (;;) {
+            const hipError_t e = hipEventQuery(lead->ev1);
+            if (e == hipSuccess) break;
+            if (e != hipErrorNotReady) { HIP_TRY(e); }
+            (void)hipGetLastError();
+            std::this_thread::sleep_for(std::chrono::microseconds(40));
+        }
+    }
+    HIP_TRY(hipStreamSynchronize(lead->stream));
+    const DevScalars &sc = *ctx->pend_sc;
+    PllLockInfo<T> info;
+    memcpy(&info, ctx->pend_info, sizeof info);
+    const uint32_t got_frames = ctx->pend_got_frames;
+    if (sc.nframes > frame_cap || sc.nhits > hit_cap || (long long)sc.nsym > sym_cap) {
+        fprintf(stderr, "libpdt: internal capacity exceeded (frames %u/%u hits %u/%u symbols %llu/%lld)\n", sc.nframes,
+                frame_cap, sc.nhits, hit_cap, sc.nsym, sym_cap);
+        return PDT_ERR_STATE;
+    }
+    std::vector<FrameRec> recs(sc.nframes);
+    if (sc.nframes) {
+        const uint32_t have = std::min<uint32_t>(sc.nframes, got_frames);
+        if (have) memcpy(recs.data(), ctx->pinned, (size_t)have * sizeof(FrameRec));
+        if (sc.nframes > have)
+            HIP_TRY(hipMemcpy(recs.data() + have, d_frames + have, (size_t)(sc.nframes - have) * sizeof(FrameRec), hipMemcpyDeviceToHost));
+    }
+    ctx->last_nframes = sc.nframes;
+    ctx->chunk_host.clear();
+    if (ctx->pend_chunks && !seg) {
+        ctx->chunk_host.resize((size_t)ctx->pend_chunks);
+        memcpy(ctx->chunk_host.data(), ctx->qual_pin, (size_t)ctx->pend_chunks * sizeof(ChunkInfo));
+    }
+    ctx->pend_chunks = 0;
+
+    float ms = 0;
+    (void)hipEventElapsedTime(&ms, lead->ev0, lead->ev1);
+
+    // time stamp of the bit whose symbol was taken at global interpolated-sample index g, in a capture of n_all samples
+    // (SURVEY Appendix B Q1/Q2/Q4)
+    auto frame_time = [&](long long g, long long n_all) -> double {
+        if (argos && sizeof(T) == 4) return (double)ctx->axis_f.at((uint64_t)g + 1);     // the twin: float stamps (pdt_open)
+        if (argos) return ctx->axis_d.at((uint64_t)g + 1);                   // waveDataTime[i] = (i+1)-th partial sum
+        const long long c = g / chunk_out, rr = g % chunk_out;
+        const long long j = rr / interp + 1;                                  // Q2: time of the *next* input sample
+        const long long ns_c = std::min<long long>(chunk, n_all - c * chunk);
+        if (j < ns_c) return (double)ctx->axis_f.at((uint64_t)(c * chunk + j + 1));
+        if (ns_c == chunk || c == 0) return 0.0;                              // one past the array: never-written zero
+        return (double)ctx->axis_f.at((uint64_t)((c - 1) * chunk + j + 1));   // stale value of the previous chunk
+    };
+
+    // ---- per-kernel timings (profile mode)
+    auto collect_timers = [&]() {
+    ctx->ktimes.clear();
+    for (auto &t : ctx->timers) {
+        float tms = 0;
+        (void)hipEventElapsedTime(&tms, t.a, t.b);
+        bool found = false;
+        for (auto &k : ctx->ktimes)
+            if (t.name == k.name) {
+                k.launches++;
+                k.total_ms += tms;
+                found = true;
+            }
+        if (!found) {
+            pdt_kernel_time k;
+            memset(&k, 0, sizeof k);
+            snprintf(k.name, sizeof k.name, "%s", t.name.c_str());
+            k.launches = 1;
+            k.total_ms = tms;
+            ctx->ktimes.push_back(k);
+        }
+        if (!t.shared_a) ctx->event_pool.push_back(t.a);
+        ctx->event_pool.push_back(t.b);
+    }
+    ctx->timers.clear();
+    };
+
+    if (seg) {
+        // ---- stream segment: hand the new frames to the stream code, carry every stage's state to the next segment
+        SegTail<T> tail;
+        memcpy(&tail, ctx->seg_pin + 4096, sizeof tail);
+        const long long org_out = (long long)seg->origin * interp;
+        const long long n_all = (long long)seg->origin + N;                   // samples of the stream so far
+        const long long kept = (long long)seg->kept_bits.size();
+        const long long sym_pad = 2 + (long long)(seg->nsym_total & 1u);
+        const long long nbits_loc = (long long)sc.nbits;
+        if ((long long)sc.nsym < sym_pad || nbits_loc < kept) return PDT_ERR_STATE;
+        const uint64_t new_syms = sc.nsym - (uint64_t)sym_pad, new_bits = (uint64_t)(nbits_loc - kept);
+        // PLL
+        if (!seg->locked && info.lock_sample >= 0) {
+            seg->locked = true;
+            seg->lock_sample = info.lock_sample + (long long)seg->origin;
+            seg->lock_freq_hz = (double)(info.freq_at_lock * Fs) / (2.0 * M_PI);
+            seg->avg_at_lock = (double)info.avg_at_lock;
+        }
+        if (N > first || first == 0) {
+            if (seg->locked && N > 0) {
+                seg->phase = (double)tail.pll_phase;
+                seg->freq = (double)tail.pll_freq;
+                if (info.lock_sample == N - 1) {                              // locked on the very last sample: nothing walked after it
+                    seg->phase = (double)info.st.phase;
+                    seg->freq = (double)info.st.freq;
+                }
+                seg->locksig = need_lock ? (double)tail.locksig : (double)info.st.locksig;
+                seg->avg = (double)info.st.avg_phase;
+                seg->sweep = (double)info.st.sweep;
+            } else if (N > 0) {
+                seg->phase = (double)info.st.phase; seg->freq = (double)info.st.freq; seg->avg = (double)info.st.avg_phase;
+                seg->locksig = (double)info.st.locksig; seg->sweep = (double)info.st.sweep;
+            }
+        }
+        // StaticGain / AGC
+        if (!seg->have_norm && N > 0) {
+            T nv;
+            memcpy(&nv, &sc.norm, sizeof(T));
+            seg->norm_factor = (double)nv;
+            seg->gain = (double)nv;
+            seg->have_norm = true;
+        }
+        if (n_out - first_out > 0) seg->gain = (double)tail.agc_gain;
+        // sampler, Manchester
+        seg->sa = (double)tail.sampler.a; seg->sb = (double)tail.sampler.b; seg->sc = (double)tail.sampler.c;
+        seg->have_sampler = true;
+        if (sc.nsym >= 1) { seg->sym_m2 = (double)tail.sym_m2; seg->sym_m1 = (double)tail.sym_m1; }
+        seg->clockmod = tail.clock;
+        seg->nsym_total += new_syms;
+        seg->nbits_total += new_bits;
+        seg->seg_new_symbols = new_syms;
+        seg->seg_new_bits = new_bits;
+        // bits the device kept: local indices [b0, nbits_loc)
+        const long long b0 = nbits_loc - (long long)tail.nkeep;
+        auto src_of = [&](long long pos) -> long long {                      // global interpolated-sample index behind local bit pos
+            if (pos < kept) return seg->kept_src[(size_t)pos];
+            return tail.src[pos - b0] + org_out;
+        };
+        // frames
+        seg->seg_frames.clear();
+        long long open_pos = -1;
+        bool pend = false;
+        for (unsigned f = 0; f < sc.nframes; f++) {
+            const FrameRec &r = recs[f];
+            if (!r.complete && !seg->final_seg) { open_pos = r.bit_index; }
+            pdt_frame o;
+            memset(&o, 0, sizeof o);
+            o.bit_index = r.bit_index + (long long)seg->bit_base;
+            o.inverted = argos ? 0 : r.inverted;      // (the ARGOS twin re-inverts such a packet's bits but stamps it like any other)
+            o.nbytes = r.nbytes;
+            o.complete = r.complete;
+            memcpy(o.bytes, r.bytes, 104);
+            const long long g = (r.bit_index < kept) ? seg->kept_src[(size_t)r.bit_index] : r.time_src + org_out;
+            o.time_src = g;
+            o.time = frame_time(g, n_all);
+            if (!r.complete && !seg->final_seg) {
+                seg->pending = o;                                             // reported when it completes (or at the stream's end)
+                pend = true;
+                break;
+            }
+            seg->seg_frames.push_back(o);
+            seg->next_free = std::max<long long>(seg->next_free, o.bit_index + (long long)SP.span);
+        }
+        seg->have_pending = pend;
+        // what the next segment sees of these bits: from the sync word of the open frame, else the last len - 1
+        long long keep_from = std::max<long long>(0, nbits_loc - (long long)(SP.len - 1));
+        if (open_pos >= 0) keep_from = std::max<long long>(0, open_pos - (long long)(SP.len - 1));
+        if (keep_from < b0) return PDT_ERR_STATE;                             // (an open frame is shorter than the kept tail)
+        std::vector<unsigned char> nb((size_t)(nbits_loc - keep_from));
+        std::vector<long long> ns((size_t)(nbits_loc - keep_from));
+        for (long long q = keep_from; q < nbits_loc; q++) {
+            nb[(size_t)(q - keep_from)] = tail.bits[q - b0];
+            ns[(size_t)(q - keep_from)] = src_of(q);
+        }
+        seg->kept_bits.swap(nb);
+        seg->kept_src.swap(ns);
+        seg->bit_base += (uint64_t)keep_from;
+        ctx->stats.gpu_ms = ms;
+        // pdt_read_stage after a push: the segment's own arrays, window-local (PLL / FIR / AGC from the window's origin; symbols
+        // behind the two or three history symbols; bits behind the kept ones) -- a debugging aid, see tools/probes/stream_debug.py
+        ctx->stage_len[PDT_ST_PLL] = (uint64_t)N;
+        ctx->stage_len[PDT_ST_LOCK] = need_lock ? (uint64_t)N : 0;
+        ctx->stage_len[PDT_ST_FIR] = ctx->stage_len[PDT_ST_AGC] = (uint64_t)n_out;
+        ctx->stage_len[PDT_ST_AGC_RAW] = 0;
+        ctx->stage_len[PDT_ST_SYM] = ctx->stage_len[PDT_ST_SYMIDX] = sc.nsym;
+        ctx->stage_len[PDT_ST_BITS] = ctx->stage_len[PDT_ST_BITSYM] = sc.nbits;
+        collect_timers();                     // (profile mode: the kernel groups of the LAST segment)
+        return PDT_OK;
+    }
+
+    T norm_val;
+    memcpy(&norm_val, &sc.norm, sizeof(T));
+    pdt_stats &S = ctx->stats;
+    memset(&S, 0, sizeof S);
+    S.samples = n;
+    S.out_samples = (uint64_t)n_out;
+    S.symbols = sc.nsym;
+    S.bits = sc.nbits;
+    S.frames = sc.nframes;
+    S.lock_sample = info.lock_sample;
+    S.lock_freq_hz = (double)(info.freq_at_lock * Fs) / (2.0 * M_PI);         // CarrierTrackingPLL.c:269
+    S.avg_phase = (double)info.avg_at_lock;
+    S.norm_factor = (double)norm_val;
+    S.interp = (uint32_t)interp;
+    S.ntaps = (uint32_t)ntaps;
+    S.pll_blocks = sc.counters[0];
+    S.pll_seam_fixes = sc.counters[1];
+    S.agc_blocks = sc.counters[2];
+    S.agc_seam_fixes = sc.counters[3];
+    S.gpu_ms = ms;
+    S.gardner_parallel = (uint32_t)ctx->gardner_mode;
+    const bool tabled = ctx->gardner_mode != 0;
+    S.gardner_walked = tabled ? sc.gstats[2] : 0u;
+    S.gardner_full_domain = tabled ? sc.gstats[1] : 0u;
+    S.gardner_candidates = tabled ? sc.gstats[3] : 0u;
+    S.sync_overflow = sc.sync_overflow;
+
+    ctx->stage_len[PDT_ST_PLL] = (fuse_mix && !ctx->keep_pll) ? 0 : n;       // (k_mix_fir: the stream exists on request only)
+    ctx->stage_len[PDT_ST_LOCK] = need_lock ? n : 0;
+    ctx->stage_len[PDT_ST_FIR] = (uint64_t)n_out;
+    ctx->stage_len[PDT_ST_AGC] = (uint64_t)n_out;
+    ctx->stage_len[PDT_ST_AGC_RAW] = ctx->keep_agc_raw ? (uint64_t)n_out : 0;
+    ctx->stage_len[PDT_ST_SYM] = sc.nsym;
+    ctx->stage_len[PDT_ST_SYMIDX] = sc.nsym;
+    ctx->stage_len[PDT_ST_BITS] = sc.nbits;
+    ctx->stage_len[PDT_ST_BITSYM] = sc.nbits;
+
+    // ---- time stamps (host): SURVEY Appendix B Q1/Q2/Q4
+    ctx->frames_host.resize(sc.nframes);
+    ctx->frames_on_device = sc.nframes;
+    ctx->have_frames = true;
+    ctx->tip_host.clear();
+    for (unsigned f = 0; f < sc.nframes; f++) {
+        pdt_frame &o = ctx->frames_host[f];
+        const FrameRec &r = recs[f];
+        memset(&o, 0, sizeof o);
+        o.bit_index = r.bit_index;
+        o.time_src = r.time_src;
+        o.inverted = argos ? 0 : r.inverted;          // ARGOSdemodPortAudio/ByteSync.c:128: "%.5f " for the inverse word as well
+        o.nbytes = r.nbytes;
+        o.complete = r.complete;
+        memcpy(o.bytes, r.bytes, 104);
+        o.time = frame_time(r.time_src, N);
+    }
+
+    collect_timers();
+    return PDT_OK;
+}
+
 // phase: the whole call, or split for the batched entry point -- enqueue every kernel and the read-back copies of
 // one capture (no host synchronisation), later wait for them and build the host-side results
 enum { RUN_ALL = 0, RUN_ENQUEUE = 1, RUN_FINISH = 2 };
@@ -1796,256 +2072,11 @@ template <typename T> int run_capture(pdt_ctx *ctx, uint64_t n, int phase = RUN_
     }
     }   // phase != RUN_FINISH
     if (phase == RUN_ENQUEUE) return PDT_OK;
-    if (!ctx->pending || ctx->pend_n != n) return PDT_ERR_STATE;
-    ctx->pending = false;
-    pdt_ctx *lead = ctx->leader ? ctx->leader : ctx;
-    if (seg && seg->in_place && !ctx->tune.sync_block) {
-        // the overlapped ingest: wait for the segment WITHOUT sitting inside the runtime -- the ingest's submitter thread is
-        // queueing copies all the while (a blocking hipStreamSynchronize here held it up: the copies stopped for as long as a
-        // segment's kernels ran, tools/jobs/r5_e2e_ab.sh)
-        for (;;) {
-            const hipError_t e = hipEventQuery(lead->ev1);
-            if (e == hipSuccess) break;
-            if (e != hipErrorNotReady) { HIP_TRY(e); }
-            (void)hipGetLastError();
-            std::this_thread::sleep_for(std::chrono::microseconds(40));
-        }
-    }
-    HIP_TRY(hipStreamSynchronize(lead->stream));
-    const DevScalars &sc = *ctx->pend_sc;
-    PllLockInfo<T> info;
-    memcpy(&info, ctx->pend_info, sizeof info);
-    const uint32_t got_frames = ctx->pend_got_frames;
-    if (sc.nframes > frame_cap || sc.nhits > hit_cap || (long long)sc.nsym > sym_cap) {
-        fprintf(stderr, "libpdt: internal capacity exceeded (frames %u/%u hits %u/%u symbols %llu/%lld)\n", sc.nframes,
-                frame_cap, sc.nhits, hit_cap, sc.nsym, sym_cap);
-        return PDT_ERR_STATE;
-    }
-    std::vector<FrameRec> recs(sc.nframes);
-    if (sc.nframes) {
-        const uint32_t have = std::min<uint32_t>(sc.nframes, got_frames);
-        if (have) memcpy(recs.data(), ctx->pinned, (size_t)have * sizeof(FrameRec));
-        if (sc.nframes > have)
-            HIP_TRY(hipMemcpy(recs.data() + have, d_frames + have, (size_t)(sc.nframes - have) * sizeof(FrameRec), hipMemcpyDeviceToHost));
-    }
-    ctx->last_nframes = sc.nframes;
-    ctx->chunk_host.clear();
-    if (ctx->pend_chunks && !seg) {
-        ctx->chunk_host.resize((size_t)ctx->pend_chunks);
-        memcpy(ctx->chunk_host.data(), ctx->qual_pin, (size_t)ctx->pend_chunks * sizeof(ChunkInfo));
-    }
-    ctx->pend_chunks = 0;
-
-    float ms = 0;
-    (void)hipEventElapsedTime(&ms, lead->ev0, lead->ev1);
-
-    // time stamp of the bit whose symbol was taken at global interpolated-sample index g, in a capture of n_all samples
-    // (SURVEY Appendix B Q1/Q2/Q4)
-    auto frame_time = [&](long long g, long long n_all) -> double {
-        if (argos && sizeof(T) == 4) return (double)ctx->axis_f.at((uint64_t)g + 1);     // the twin: float stamps (pdt_open)
-        if (argos) return ctx->axis_d.at((uint64_t)g + 1);                   // waveDataTime[i] = (i+1)-th partial sum
-        const long long c = g / chunk_out, rr = g % chunk_out;
-        const long long j = rr / interp + 1;                                  // Q2: time of the *next* input sample
-        const long long ns_c = std::min<long long>(chunk, n_all - c * chunk);
-        if (j < ns_c) return (double)ctx->axis_f.at((uint64_t)(c * chunk + j + 1));
-        if (ns_c == chunk || c == 0) return 0.0;                              // one past the array: never-written zero
-        return (double)ctx->axis_f.at((uint64_t)((c - 1) * chunk + j + 1));   // stale value of the previous chunk
-    };
-
-    // ---- per-kernel timings (profile mode)
-    auto collect_timers = [&]() {
-    ctx->ktimes.clear();
-    for (auto &t : ctx->timers) {
-        float tms = 0;
-        (void)hipEventElapsedTime(&tms, t.a, t.b);
-        bool found = false;
-        for (auto &k : ctx->ktimes)
-            if (t.name == k.name) {
-                k.launches++;
-                k.total_ms += tms;
-                found = true;
-            }
-        if (!found) {
-            pdt_kernel_time k;
-            memset(&k, 0, sizeof k);
-            snprintf(k.name, sizeof k.name, "%s", t.name.c_str());
-            k.launches = 1;
-            k.total_ms = tms;
-            ctx->ktimes.push_back(k);
-        }
-        if (!t.shared_a) ctx->event_pool.push_back(t.a);
-        ctx->event_pool.push_back(t.b);
-    }
-    ctx->timers.clear();
-    };
-
-    if (seg) {
-        // ---- stream segment: hand the new frames to the stream code, carry every stage's state to the next segment
-        SegTail<T> tail;
-        memcpy(&tail, ctx->seg_pin + 4096, sizeof tail);
-        const long long org_out = (long long)seg->origin * interp;
-        const long long n_all = (long long)seg->origin + N;                   // samples of the stream so far
-        const long long kept = (long long)seg->kept_bits.size();
-        const long long sym_pad = 2 + (long long)(seg->nsym_total & 1u);
-        const long long nbits_loc = (long long)sc.nbits;
-        if ((long long)sc.nsym < sym_pad || nbits_loc < kept) return PDT_ERR_STATE;
-        const uint64_t new_syms = sc.nsym - (uint64_t)sym_pad, new_bits = (uint64_t)(nbits_loc - kept);
-        // PLL
-        if (!seg->locked && info.lock_sample >= 0) {
-            seg->locked = true;
-            seg->lock_sample = info.lock_sample + (long long)seg->origin;
-            seg->lock_freq_hz = (double)(info.freq_at_lock * Fs) / (2.0 * M_PI);
-            seg->avg_at_lock = (double)info.avg_at_lock;
-        }
-        if (N > first || first == 0) {
-            if (seg->locked && N > 0) {
-                seg->phase = (double)tail.pll_phase;
-                seg->freq = (double)tail.pll_freq;
-                if (info.lock_sample == N - 1) {                              // locked on the very last sample: nothing walked after it
-                    seg->phase = (double)info.st.phase;
-                    seg->freq = (double)info.st.freq;
-                }
-                seg->locksig = need_lock ? (double)tail.locksig : (double)info.st.locksig;
-                seg->avg = (double)info.st.avg_phase;
-                seg->sweep = (double)info.st.sweep;
-            } else if (N > 0) {
-                seg->phase = (double)info.st.phase; seg->freq = (double)info.st.freq; seg->avg = (double)info.st.avg_phase;
-                seg->locksig = (double)info.st.locksig; seg->sweep = (double)info.st.sweep;
-            }
-        }
-        // StaticGain / AGC
-        if (!seg->have_norm && N > 0) {
-            T nv;
-            memcpy(&nv, &sc.norm, sizeof(T));
-            seg->norm_factor = (double)nv;
-            seg->gain = (double)nv;
-            seg->have_norm = true;
-        }
-        if (n_out - first_out > 0) seg->gain = (double)tail.agc_gain;
-        // sampler, Manchester
-        seg->sa = (double)tail.sampler.a; seg->sb = (double)tail.sampler.b; seg->sc = (double)tail.sampler.c;
-        seg->have_sampler = true;
-        if (sc.nsym >= 1) { seg->sym_m2 = (double)tail.sym_m2; seg->sym_m1 = (double)tail.sym_m1; }
-        seg->clockmod = tail.clock;
-        seg->nsym_total += new_syms;
-        seg->nbits_total += new_bits;
-        seg->seg_new_symbols = new_syms;
-        seg->seg_new_bits = new_bits;
-        // bits the device kept: local indices [b0, nbits_loc)
-        const long long b0 = nbits_loc - (long long)tail.nkeep;
-        auto src_of = [&](long long pos) -> long long {                      // global interpolated-sample index behind local bit pos
-            if (pos < kept) return seg->kept_src[(size_t)pos];
-            return tail.src[pos - b0] + org_out;
-        };
-        // frames
-        seg->seg_frames.clear();
-        long long open_pos = -1;
-        bool pend = false;
-        for (unsigned f = 0; f < sc.nframes; f++) {
-            const FrameRec &r = recs[f];
-            if (!r.complete && !seg->final_seg) { open_pos = r.bit_index; }
-            pdt_frame o;
-            memset(&o, 0, sizeof o);
-            o.bit_index = r.bit_index + (long long)seg->bit_base;
-            o.inverted = argos ? 0 : r.inverted;      // (the ARGOS twin re-inverts such a packet's bits but stamps it like any other)
-            o.nbytes = r.nbytes;
-            o.complete = r.complete;
-            memcpy(o.bytes, r.bytes, 104);
-            const long long g = (r.bit_index < kept) ? seg->kept_src[(size_t)r.bit_index] : r.time_src + org_out;
-            o.time_src = g;
-            o.time = frame_time(g, n_all);
-            if (!r.complete && !seg->final_seg) {
-                seg->pending = o;                                             // reported when it completes (or at the stream's end)
-                pend = true;
-                break;
-            }
-            seg->seg_frames.push_back(o);
-            seg->next_free = std::max<long long>(seg->next_free, o.bit_index + (long long)SP.span);
-        }
-        seg->have_pending = pend;
-        // what the next segment sees of these bits: from the sync word of the open frame, else the last len - 1
-        long long keep_from = std::max<long long>(0, nbits_loc - (long long)(SP.len - 1));
-        if (open_pos >= 0) keep_from = std::max<long long>(0, open_pos - (long long)(SP.len - 1));
-        if (keep_from < b0) return PDT_ERR_STATE;                             // (an open frame is shorter than the kept tail)
-        std::vector<unsigned char> nb((size_t)(nbits_loc - keep_from));
-        std::vector<long long> ns((size_t)(nbits_loc - keep_from));
-        for (long long q = keep_from; q < nbits_loc; q++) {
-            nb[(size_t)(q - keep_from)] = tail.bits[q - b0];
-            ns[(size_t)(q - keep_from)] = src_of(q);
-        }
-        seg->kept_bits.swap(nb);
-        seg->kept_src.swap(ns);
-        seg->bit_base += (uint64_t)keep_from;
-        ctx->stats.gpu_ms = ms;
-        // pdt_read_stage after a push: the segment's own arrays, window-local (PLL / FIR / AGC from the window's origin; symbols
-        // behind the two or three history symbols; bits behind the kept ones) -- a debugging aid, see tools/probes/stream_debug.py
-        ctx->stage_len[PDT_ST_PLL] = (uint64_t)N;
-        ctx->stage_len[PDT_ST_LOCK] = need_lock ? (uint64_t)N : 0;
-        ctx->stage_len[PDT_ST_FIR] = ctx->stage_len[PDT_ST_AGC] = (uint64_t)n_out;
-        ctx->stage_len[PDT_ST_AGC_RAW] = 0;
-        ctx->stage_len[PDT_ST_SYM] = ctx->stage_len[PDT_ST_SYMIDX] = sc.nsym;
-        ctx->stage_len[PDT_ST_BITS] = ctx->stage_len[PDT_ST_BITSYM] = sc.nbits;
-        collect_timers();                     // (profile mode: the kernel groups of the LAST segment)
-        return PDT_OK;
-    }
-
-    T norm_val;
-    memcpy(&norm_val, &sc.norm, sizeof(T));
-    pdt_stats &S = ctx->stats;
-    memset(&S, 0, sizeof S);
-    S.samples = n;
-    S.out_samples = (uint64_t)n_out;
-    S.symbols = sc.nsym;
-    S.bits = sc.nbits;
-    S.frames = sc.nframes;
-    S.lock_sample = info.lock_sample;
-    S.lock_freq_hz = (double)(info.freq_at_lock * Fs) / (2.0 * M_PI);         // CarrierTrackingPLL.c:269
-    S.avg_phase = (double)info.avg_at_lock;
-    S.norm_factor = (double)norm_val;
-    S.interp = (uint32_t)interp;
-    S.ntaps = (uint32_t)ntaps;
-    S.pll_blocks = sc.counters[0];
-    S.pll_seam_fixes = sc.counters[1];
-    S.agc_blocks = sc.counters[2];
-    S.agc_seam_fixes = sc.counters[3];
-    S.gpu_ms = ms;
-    S.gardner_parallel = (uint32_t)ctx->gardner_mode;
-    const bool tabled = ctx->gardner_mode != 0;
-    S.gardner_walked = tabled ? sc.gstats[2] : 0u;
-    S.gardner_full_domain = tabled ? sc.gstats[1] : 0u;
-    S.gardner_candidates = tabled ? sc.gstats[3] : 0u;
-    S.sync_overflow = sc.sync_overflow;
-
-    ctx->stage_len[PDT_ST_PLL] = (fuse_mix && !ctx->keep_pll) ? 0 : n;       // (k_mix_fir: the stream exists on request only)
-    ctx->stage_len[PDT_ST_LOCK] = need_lock ? n : 0;
-    ctx->stage_len[PDT_ST_FIR] = (uint64_t)n_out;
-    ctx->stage_len[PDT_ST_AGC] = (uint64_t)n_out;
-    ctx->stage_len[PDT_ST_AGC_RAW] = ctx->keep_agc_raw ? (uint64_t)n_out : 0;
-    ctx->stage_len[PDT_ST_SYM] = sc.nsym;
-    ctx->stage_len[PDT_ST_SYMIDX] = sc.nsym;
-    ctx->stage_len[PDT_ST_BITS] = sc.nbits;
-    ctx->stage_len[PDT_ST_BITSYM] = sc.nbits;
-
-    // ---- time stamps (host): SURVEY Appendix B Q1/Q2/Q4
-    ctx->frames_host.resize(sc.nframes);
-    ctx->frames_on_device = sc.nframes;
-    ctx->have_frames = true;
-    ctx->tip_host.clear();
-    for (unsigned f = 0; f < sc.nframes; f++) {
-        pdt_frame &o = ctx->frames_host[f];
-        const FrameRec &r = recs[f];
-        memset(&o, 0, sizeof o);
-        o.bit_index = r.bit_index;
-        o.time_src = r.time_src;
-        o.inverted = argos ? 0 : r.inverted;          // ARGOSdemodPortAudio/ByteSync.c:128: "%.5f " for the inverse word as well
-        o.nbytes = r.nbytes;
-        o.complete = r.complete;
-        memcpy(o.bytes, r.bytes, 104);
-        o.time = frame_time(r.time_src, N);
-    }
-
-    collect_timers();
-    return PDT_OK;
+    FinishArgs FA;
+    FA.argos = argos; FA.need_lock = need_lock; FA.fuse_mix = fuse_mix;
+    FA.N = N; FA.n_out = n_out; FA.chunk = chunk; FA.chunk_out = chunk_out; FA.first = first; FA.first_out = first_out; FA.sym_cap = sym_cap;
+    FA.interp = interp; FA.ntaps = ntaps; FA.hit_cap = hit_cap; FA.frame_cap = frame_cap; FA.SP = SP;
+    return finish_capture<T>(ctx, n, FA);
 }
 
 
