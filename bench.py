@@ -565,6 +565,10 @@ def run(args, pdt, torch, dist, rank, local, world, dev, cdev, cfg, kind, fs, se
             exe = os.path.join(ROOT, "bin", "demodARGOS" if kind else "demodPOES")
             if os.path.exists(exe):
                 cli_out = os.path.join(tmp, "cli_out.txt")
+                # (this process has just closed a context with ~25 GB of buffers: the driver hands that memory back in the background,
+                # and a process that starts meanwhile waits for it in its runtime start-up and its first allocations -- up to 0.7 s)
+                torch.cuda.synchronize()
+                time.sleep(3.0)
                 t1 = time.perf_counter()
                 r = subprocess.run([exe, "-T", "-d", str(local), "-o", cli_out, wav], capture_output=True, text=True)
                 cli_s = time.perf_counter() - t1
@@ -582,6 +586,7 @@ def run(args, pdt, torch, dist, rank, local, world, dev, cdev, cfg, kind, fs, se
                                               "`of_it_ingest`"}
                 # ... and without the per-chunk reports (-P): the overlapped path of `e2e`, from process start
                 os.unlink(cli_out)
+                time.sleep(3.0)                                      # (the first program's buffers, likewise)
                 t1 = time.perf_counter()
                 r2 = subprocess.run([exe, "-T", "-P", "-d", str(local), "-o", cli_out, wav], capture_output=True, text=True)
                 cli2_s = time.perf_counter() - t1

@@ -2276,8 +2276,15 @@ int ingest_capture(pdt_ctx *ctx, const IngestSrc &src, size_t bytes, void *dst, 
             }
         };
         int rr = 0;                                                    // copy streams round robin
+        // (developer aid, PDT_DEBUG_OVERLAP: how long the submitter had nothing to queue, and how many copies were in flight on
+        // average while it waited -- near the ring's half: the copies are the pace (a reader refills a slot as soon as its copy has
+        // completed); near zero: the readers are)
+        double idle_ms = 0, flying_sum = 0, api_ms = 0;
+        long long idle_n = 0;
+        const auto t_sub0 = std::chrono::steady_clock::now();
         while (queued < nspans && !failed) {
             bool any = false;
+            const auto t_it0 = std::chrono::steady_clock::now();
             for (int slot = 0; slot < nslots && !failed; slot++) {
                 if (J->slot_state[(size_t)slot].load(std::memory_order_acquire) != 1) continue;
                 const size_t k = J->slot_span[(size_t)slot];
@@ -2298,9 +2305,22 @@ int ingest_capture(pdt_ctx *ctx, const IngestSrc &src, size_t bytes, void *dst, 
                 marks();
             }
             retire(false);
-            if (!any) std::this_thread::sleep_for(std::chrono::microseconds(15));
+            const auto t_it1 = std::chrono::steady_clock::now();
+            api_ms += std::chrono::duration<double, std::milli>(t_it1 - t_it0).count();
+            if (!any) {
+                int flying = 0;
+                for (int slot = 0; slot < nslots; slot++) flying += J->slot_state[(size_t)slot].load(std::memory_order_relaxed) == 2;
+                std::this_thread::sleep_for(std::chrono::microseconds(15));
+                idle_ms += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_it1).count();
+                flying_sum += flying;
+                idle_n++;
+            }
         }
         marks();
+        if (ctx->tune.debug_overlap)
+            fprintf(stderr, "ingest submitter: %.2f ms in all: %.2f in the runtime (queueing, polling), %.2f with nothing to queue (%.1f of %d slots in flight on average)\n",
+                    std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_sub0).count(), api_ms, idle_ms,
+                    idle_n ? flying_sum / (double)idle_n : 0.0, nslots);
         (void)nslots;
         // the background form leaves the pinned slots free; the foreground form returns with its last copies still on their way
         // (the caller's stream waits for them, and the call does not return before that stream is idle)

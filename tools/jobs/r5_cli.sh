@@ -15,6 +15,7 @@ bench.make_capture(pdt, bench.capture_params(pdt, "c3", 1234), n, 32, wav_path=w
 for args in ([], ["-P"]):
     for rep in range(3):
         out = os.path.join(tmp, "o.txt")
+        time.sleep(3.0)          # (the previous process's buffers go back to the driver in the background)
         t0 = time.perf_counter()
         r = subprocess.run(["bin/demodPOES", "-T"] + args + ["-o", out, wav], capture_output=True, text=True)
         dt = (time.perf_counter() - t0) * 1e3
