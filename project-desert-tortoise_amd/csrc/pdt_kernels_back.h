@@ -1405,7 +1405,7 @@ __device__ __forceinline__ void k_gardner_table_merge(const float *__restrict__ 
 struct GardnerSpanRow { unsigned off, n; };     // the row's keys: [off, off + n) of the key list; n = ~0u: not tabulated
 struct GardnerSpanItem { unsigned row, first, cnt; };
 struct GardnerSpanRec { float ns, prev, half; unsigned count; };   // sampler state in front of a chunk, symbols since the row's second chunk
-struct GardnerSpanCtl { unsigned keys, items, cursor, overflow; };
+struct GardnerSpanCtl { unsigned long long keys; unsigned items, cursor, overflow, pad_; };     // keys: a 64-bit cursor (never wraps)
 
 __device__ __forceinline__ void k_gardner_span_keys(GardnerDomain D, long long n_rows, const unsigned *__restrict__ cand_k,
                                                     GardnerBand *__restrict__ bands, const unsigned *__restrict__ clist,
@@ -1453,14 +1453,14 @@ __device__ __forceinline__ void k_gardner_span_keys(GardnerDomain D, long long n
         // Space in the shared key list is handed out by one fetch-and-add per row, and a reservation that does not fit is NOT
         // handed back: from the first overflow on the cursor stands behind cap_keys and every later row fails as well (its band
         // is emptied, the chain walks it) -- successful ranges can never overlap, which a give-back by subtraction allowed
-        // (ADVICE r4).  Rows that see the overflow flag no longer add, so the cursor cannot wrap around 2^32 either: behind
-        // the first overflow at most the rows resident at that moment (a few thousand, 2 n_q <= 262 144 keys each) still do.
-        // (A compare-and-swap loop that only reserves what fits was measured first: 5 625 rows arriving together retry each
-        // other quadratically -- 24 ms for this kernel at an hour of 250 ksps instead of 0.2.)
+        // (ADVICE r4).  The cursor is 64 bits wide: however many rows fail, it cannot wrap.  (Measured on the way: a
+        // compare-and-swap loop that only reserves what fits -- 5 625 rows arriving together retry each other quadratically, 24 ms
+        // for this kernel at an hour of 250 ksps; a look at the overflow flag in front of the add -- 0.20 -> 0.44 ms, the load
+        // queues behind the other rows' atomics on the same line.)
         unsigned off = ~0u;
-        if (__hip_atomic_load(&ctl->overflow, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0u) {
-            const unsigned got = atomicAdd(&ctl->keys, total);
-            if ((unsigned long long)got + total <= cap_keys) off = got;
+        {
+            const unsigned long long got = atomicAdd(&ctl->keys, (unsigned long long)total);
+            if (got + total <= (unsigned long long)cap_keys) off = (unsigned)got;
         }
         if (off == ~0u) atomicAdd(&ctl->overflow, 1u);
         else s_item = atomicAdd(&ctl->items, (total + (unsigned)PDT_GSUB_KEYS - 1u) / (unsigned)PDT_GSUB_KEYS);
