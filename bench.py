@@ -232,7 +232,7 @@ def group_kernel(group: str, dt: str, interp: int) -> str:
         "pll_head": f"k_pll_head<{dt}, false, true>", "pll_fix": f"k_pll_fix<{dt}, false>", "pll_theta": f"k_pll_theta<{dt}>",
         "pll_mix": f"k_pll_mix<{dt}, {'true' if dt == 'double' else 'false'}>", "lock_ema": f"k_lock_ema<{dt}>",
         "fir": f"k_fir_interp_rt<{dt}, {interp}, 26>" if dt == "float" else f"k_fir_plain<{dt}>",
-        "mix_fir": "k_mix_fir<26, 0, 8>",
+        "mix_fir": "k_mix_fir<26, 0, 8, false>",
         "agc_block": f"k_agc_block<{dt}>", "gardner_table": "k_gardner_table_merge<2048>",
         "gardner": "k_gardner<float, 2048, 256>" if dt == "float" else "k_gardner_ring<double, 2560, 6, 256>",
         "static_gain": f"k_static_gain<{dt}>", "manchester": f"k_manch_emit<{dt}>", "bytesync": "k_sync_frames_tiles",

@@ -91,16 +91,25 @@ int main(int argc, char **argv)
     const char *dump = NULL;
     int use_mm = 0;              /* -M: MMClockRecovery at the sampler's call site (ARGOSdemod/main.c:277, commented out there) */
     DT mmRange = 3, mmKp = 0.15;
+    double loopK[11] = {0};
+    int haveK = 0;
     int c;
     int live = 0;                /* -L: the sound-card twin's composition (POESTIPdemodPortAudio/main.c:324-393) over a
                                     float32 file: the twin's constants, lock stream kept, Squelch between PLL and FIR */
     int bits_only = 0;           /* -B: in.wav is a text file of '0'/'1'; run only the reference's byte synchroniser on it */
-    while ((c = getopt(argc, argv, "c:n:s:d:MR:K:BL")) != -1) {
+    while ((c = getopt(argc, argv, "c:n:s:d:MR:K:BLk:")) != -1) {
         if (c == 'L') { live = 1; continue; }
         if (c == 'M') { use_mm = 1; continue; }
         if (c == 'B') { bits_only = 1; continue; }
         if (c == 'R') { mmRange = atof(optarg); continue; }
         if (c == 'K') { mmKp = atof(optarg); continue; }
+        if (c == 'k') {        /* loop constants other than the mains' (POES, file chain): eleven numbers, hex floats welcome --
+                                  freqRange, lock threshold, lockSigAlpha, loopbw_acq, loopbw_track, AGC attack, decay, baud, stepRange, kp, resync threshold */
+            char *q = optarg;
+            for (int j = 0; j < 11; j++) { loopK[j] = strtod(q, &q); if (*q == ',') q++; }
+            haveK = 1;
+            continue;
+        }
         if (c == 'c') chunk = atoi(optarg);
         else if (c == 'n') normFactor = atof(optarg);
         else if (c == 's') sampleRate = atof(optarg);
@@ -267,24 +276,31 @@ int main(int argc, char **argv)
                             0.3979 * (2.0 * M_PI / Fs), 198.9437 * (2.0 * M_PI / Fs), 10.3451 * (2.0 * M_PI / Fs));
             dput(dlock, lockSignalStream, sizeof(DT), nSamples);
             Squelch(dataStreamReal, lockSignalStream, nSamples, (0.05));
-        } else
+        } else if (haveK)
+        averagePhase = CarrierTrackPLL(waveData, dataStreamReal, NULL, nSamples, Fs, loopK[0], loopK[1], loopK[2], loopK[3], loopK[4]);
+        else
         averagePhase = CarrierTrackPLL(waveData, dataStreamReal, NULL, nSamples, Fs, (4500.0), (0.08),
                         0.3979 * (2.0 * M_PI / Fs), 127.3240 * (2.0 * M_PI / Fs), 10.3451 * (2.0 * M_PI / Fs));
         dput(dpll, dataStreamReal, sizeof(DT), nSamples);
         LowPassFilterInterp(waveDataTime, dataStreamReal, dataStreamLPF, dataStreamLPFTime, nSamples, filterCoeffs, N, interp);
         dput(dfir, dataStreamLPF, sizeof(DT), nSamples * interp);
+        if (haveK) NormalizingAGC(dataStreamLPF, nSamples * interp, normFactor, loopK[5], loopK[6]);
+        else
         NormalizingAGC(dataStreamLPF, nSamples * interp, normFactor, (79.5775) * (2.0 * M_PI / (Fs * interp)),
                        (159.1549) * (2.0 * M_PI / (Fs * interp)));
         dput(dagc, dataStreamLPF, sizeof(DT), nSamples * interp);
         if (use_mm)
             nSymbols = MMClockRecovery(dataStreamLPF, dataStreamLPFTime, nSamples * interp, dataStreamSymbols,
                                        Fs * interp, (8320 * 2 + 0.3), mmRange, mmKp);
+        else if (haveK)
+            nSymbols = GardenerClockRecovery(dataStreamLPF, dataStreamLPFTime, nSamples * interp, dataStreamSymbols,
+                                             Fs * interp, loopK[7], loopK[8], loopK[9]);
         else
             nSymbols = GardenerClockRecovery(dataStreamLPF, dataStreamLPFTime, nSamples * interp, dataStreamSymbols,
                                              Fs * interp, (8320 * 2 + 0.3), (0.1), (3.0));
         dput(dsym, dataStreamSymbols, sizeof(DT), nSymbols);
         dput(dsymt, dataStreamLPFTime, sizeof(DT), nSymbols);
-        nBits = ManchesterDecode(dataStreamSymbols, dataStreamLPFTime, nSymbols, dataStreamBits, live ? (0.75) : 1.0);   /* twin: main.c:65,393 */
+        nBits = ManchesterDecode(dataStreamSymbols, dataStreamLPFTime, nSymbols, dataStreamBits, haveK ? loopK[10] : live ? (0.75) : 1.0);   /* twin: main.c:65,393 */
         dput(dbits, dataStreamBits, 1, nBits);
         dput(dbitt, dataStreamLPFTime, sizeof(DT), nBits);
         nFrames = ByteSyncOnSyncword(dataStreamBits, dataStreamLPFTime, nBits, "1110110111100010000", 19, out);

@@ -154,3 +154,45 @@ def test_stage_functions_take_any_loop_constants(pdt, tmp_path):
         for name, u, v in zip(names, a, b):
             assert u == v, f"chunk {c}: stage {name} differs from the reference's objects"
     assert sum(o[7] for o in want[2]) > 20000                          # (the constants still demodulate: bits come out)
+
+
+@pytest.mark.parametrize("fs,chunk", [(250000, 10000), (50000, 3333)])
+def test_other_loop_constants_three_ways(pdt, tmp_path, fs, chunk):
+    """The reference's chunk loop with loop constants that are not its mains' (oracle/ref_driver.c -k: the call sites take them
+    from the command line) over (1) the reference's own objects, (2) the link-compatible shim, and (3) ONE whole-capture call of a
+    context that was given the same constants with pdt_set_loop_params: the same minor-frame file, byte for byte -- time stamps,
+    chunk seams and all."""
+    w = 2.0 * np.pi / fs
+    interp = int(round(150000.0 / fs))
+    k = [3000.0, 0.12, 0.6 * w, 90.0 * w, 14.0 * w, 60.0 * 2.0 * np.pi / (fs * interp), 200.0 * 2.0 * np.pi / (fs * interp), 8320 * 2 + 0.3,
+         0.07, 2.2, 0.8]
+    kf = [float(np.float32(v)) for v in k]                     # what a DECIMAL_TYPE float parameter receives
+    iq = pdt.synth_capture(0, fs, 6.0 if fs == 250000 else 14.0, f0_hz=-1500.0, seed=91)
+    wav = str(tmp_path / "cap.wav")
+    pdt.write_wav(wav, fs, iq)
+    arg = ",".join(float(v).hex() for v in k)
+    outs = []
+    for exe in ("ref_demodPOES", "compat_demodPOES"):
+        out = str(tmp_path / (exe + ".txt"))
+        _run(_need(exe), ["-c", str(chunk), "-k", arg, wav], out)
+        outs.append(open(out, "rb").read())
+    with pdt.Demodulator(pdt.MODE_POES, fs, chunk=chunk) as d:
+        d.set_loop_params(pll_freq_range_hz=kf[0], pll_lock_threshold=kf[1], pll_lock_alpha=kf[2], pll_loopbw_acq=kf[3], pll_loopbw_track=kf[4],
+                          agc_attack=kf[5], agc_decay=kf[6], gardner_baud=kf[7], gardner_step_range=kf[8], gardner_kp=kf[9],
+                          manchester_threshold=kf[10])
+        d.demod(iq)
+        whole = d.text()
+        fd = os.open(wav, os.O_RDONLY)
+        try:
+            d.demod_file(fd, 44, len(iq), 0)                   # ... and through the file entry
+        finally:
+            os.close(fd)
+        assert d.text() == whole
+        with pytest.raises(pdt.PdtError):
+            d.set_loop_params(gardner_step_range=0.2)          # above the mains' 0.1: refused, the constants in force stay
+        d.demod(iq)
+        assert d.text() == whole
+    assert outs[0] == outs[1] == whole and whole.count(b"\n") > 40
+    with pdt.Demodulator(pdt.MODE_POES, fs, chunk=chunk) as d:
+        d.demod(iq)
+        assert d.text() != whole                               # (the constants do matter)
