@@ -230,8 +230,8 @@ int  pdt_keep_pll(pdt_ctx *ctx, int enable);
  * "\r" progress line shows.  Before the lock the acquisition kernel delivers averagePhase as it goes; after it, one more
  * block-parallel EMA over the whole capture (same scheme and the same bit-for-bit guarantee as the lock detector's stream).
  * Costs two stream-sized buffers and the EMA walkers' time (16 time constants of 20 000 samples per block: ~6 ms whatever the
- * capture's length); captures of 512 MiB and more are then ingested before the chain starts instead of segment by segment
- * while they arrive (pdt_demod_fd).  Off by default.                                                                     */
+ * capture's length).  The overlapped ingest of large captures (pdt_demod_fd / pdt_demod_file) keeps the reports too: its
+ * segments end on chunk boundaries, averagePhase and the counts are carried from one to the next.  Off by default.        */
 int  pdt_keep_quality(pdt_ctx *ctx, int enable);
 typedef struct pdt_chunk_report {
     uint64_t samples;     /* nSamples of the chunk (the last one may be short)                                          */
@@ -244,6 +244,16 @@ typedef struct pdt_chunk_report {
 /* Per-chunk reports of the last pdt_demod_* call, in chunk order; returns the number copied (out == NULL: the number
  * available; 0 unless pdt_keep_quality was on).                                                                          */
 uint64_t pdt_chunk_reports(const pdt_ctx *ctx, pdt_chunk_report *out, uint64_t max_chunks);
+/* The same reports WHILE a call runs -- the reference prints its progress line after every chunk (POESTIPdemod/main.c:457-481).
+ * With pdt_keep_quality on, `fn` is handed the reports of chunks [first_chunk, first_chunk + n) as soon as they are final:
+ * once per completed segment of an overlapped pdt_demod_fd / pdt_demod_file (from a thread of the library, in chunk order,
+ * never two calls at a time, the last one before the demod call returns), once at the end of any other whole-capture call
+ * (from the caller's thread).  `so_far`: pdt_get_stats as of the last of these chunks (norm_factor from the first chunk on,
+ * lock_sample / lock_freq_hz once the PLL has locked: what the reference prints between its progress lines, main.c:420,
+ * CarrierTrackingPLL.c:269).  Both pointers are only valid during the call; the callback must not call into the context.
+ * fn == NULL switches it off.                                                                                            */
+typedef void (*pdt_progress_fn)(void *user, uint64_t first_chunk, const pdt_chunk_report *reports, uint64_t n, const pdt_stats *so_far);
+int  pdt_set_progress(pdt_ctx *ctx, pdt_progress_fn fn, void *user);
 
 /* Demodulate one whole capture: nframes interleaved little-endian int16 I,Q pairs
  * in host memory (copied to the GPU) ...                                                        */
@@ -254,9 +264,9 @@ int  pdt_demod_pcm16(pdt_ctx *ctx, const int16_t *iq_host, uint64_t nframes);
  * threads into pinned memory and copies them to the GPU while the next spans are being read, so a capture is in HBM about
  * as soon as the page cache and the PCIe link allow.  PDT_ERR_FORMAT when the file ends early, PDT_ERR_IO on a read error
  * (EINTR is retried).
- * Large POES captures (512 MiB and more, Gardner sampler, no pdt_keep_quality): the chain starts before the last span has
- * arrived and runs in three unequal segments with carried state (the streaming path over the resident capture; 64 / 22 /
- * 14 % of the capture, cut where a segment can use the whole-capture kernels, so that only the last, small one is left to run
+ * Large POES captures (512 MiB and more, Gardner sampler): the chain starts before the last span has
+ * arrived and runs in three unequal segments with carried state (the streaming path over the resident capture; 55 / 28 /
+ * 17 % of the capture, cut where a segment can use the whole-capture kernels, so that only the last, small one is left to run
  * when the last byte has arrived).  Frames, text and pdt_get_stats' counts then describe the whole capture as ever; but
  * pdt_read_stage / pdt_stage_len describe the LAST SEGMENT only (window-local indices), the pll / agc seam counters and
  * gpu_ms are the last segment's, and no stream is left open behind the call.                                          */

@@ -109,6 +109,7 @@ class TipSummary(C.Structure):
                 ("time_frames", C.c_uint64)]
 
 
+PROGRESS_FN = C.CFUNCTYPE(None, C.c_void_p, C.c_uint64, C.c_void_p, C.c_uint64, C.c_void_p)     # == pdt_progress_fn
 # == pdt_chunk_report (48 bytes): what the reference's chunk loop knows after every chunk
 CHUNK_DTYPE = np.dtype([("samples", "<u8"), ("avg_phase", "<f8"), ("symbols", "<u8"), ("bits", "<u8"), ("frames", "<u8"),
                         ("time0", "<f8")])
@@ -163,7 +164,7 @@ ABI_SYMBOLS = [
     "pdt_stream_begin", "pdt_stream_push_pcm16", "pdt_stream_push_f32", "pdt_stream_end", "pdt_stream_frames",
     "pdt_keep_quality", "pdt_chunk_reports", "pdt_stage_manchester", "pdt_stage_fir", "pdt_stage_agc", "pdt_stage_squelch", "pdt_stage_pll", "pdt_stage_gardner", "pdt_stage_static_gain", "pdt_stage_mm",
     "pdt_keep_presquelch", "pdt_keep_pll", "pdt_stage_bytesync_from", "pdt_demod_fd", "pdt_format_records", "pdt_stream_retained", "pdt_host_math", "pdt_get_device",
-    "pdt_write_frames", "pdt_write_records", "pdt_demod_file", "pdt_set_loop_params",
+    "pdt_write_frames", "pdt_write_records", "pdt_demod_file", "pdt_set_loop_params", "pdt_set_progress",
 ]
 DEV_SYMBOLS = ["pdt_dev_set"]        # include/pdt_dev.h (test-only)
 
@@ -273,6 +274,7 @@ def lib():
     L.pdt_keep_pll.restype = C.c_int
     L.pdt_chunk_reports.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64]
     L.pdt_chunk_reports.restype = C.c_uint64
+    L.pdt_set_progress.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
     L.pdt_tip_check.argtypes = [C.c_void_p, C.POINTER(TipSummary)]
     L.pdt_tip_frames.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64]
     L.pdt_tip_frames.restype = C.c_uint64
@@ -402,6 +404,23 @@ class Demodulator:
         """Also keep the per-chunk reports (CarrierTrackPLL's return value = averagePhase, symbol / bit / frame counts):
         what the reference's progress line shows (POESTIPdemod/main.c:457-481)."""
         _check(self._L.pdt_keep_quality(self._h, int(enable)), "pdt_keep_quality")
+        return self
+
+    def set_progress(self, fn=None):
+        """``pdt_set_progress``: ``fn(first_chunk, reports, stats_so_far)`` is called with the reports (CHUNK_DTYPE array) of the
+        chunks that have become final -- once per completed segment of an overlapped ``demod_file`` / ``demod_file_text``
+        (from a thread of the library), once at the end of any other whole-capture call.  Needs ``keep_quality``."""
+        if fn is None:
+            self._progress_cb = None
+            _check(self._L.pdt_set_progress(self._h, None, None), "pdt_set_progress")
+            return self
+
+        def tramp(_user, first, reports, n, st):
+            arr = np.frombuffer(C.string_at(reports, int(n) * CHUNK_DTYPE.itemsize), dtype=CHUNK_DTYPE).copy()
+            fn(int(first), arr, Stats.from_buffer_copy(C.string_at(st, C.sizeof(Stats))))
+
+        self._progress_cb = PROGRESS_FN(tramp)                       # (kept alive as long as the context uses it)
+        _check(self._L.pdt_set_progress(self._h, C.cast(self._progress_cb, C.c_void_p), None), "pdt_set_progress")
         return self
 
     def chunk_reports(self) -> np.ndarray:

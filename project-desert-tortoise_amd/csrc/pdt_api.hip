@@ -336,6 +336,7 @@ struct StreamCarry {
     bool final_seg = false;       // the stream ends with this segment (short last chunk, partial frame reported)
     bool in_place = false;        // the whole capture has its place in the window (pdt_demod_fd of a large file): never slides
     uint64_t place_align = 0;     // in place: the grid the window's origin stays on (0 = stream_align)
+    bool quality = false;         // in place: the segments keep the per-chunk reports (pdt_keep_quality; chunk-aligned cuts)
     long long first = 0;          // local index of the first new input sample (a multiple of the chunk)
     uint64_t origin = 0;          // global sample index of local sample 0 (a multiple of lcm(chunk, FIR ring length))
     // StaticGain / AGC
@@ -394,7 +395,10 @@ struct pdt_ctx {
     void *qual_pin = nullptr;
     size_t qual_pin_cap = 0;
     uint64_t pend_chunks = 0;           // ChunkInfo records in flight (0 = none asked for)
-    std::vector<pdt::ChunkInfo> chunk_host;
+    std::vector<pdt::ChunkInfo> chunk_host;      // per chunk of the capture, counts cumulative from its first sample
+    uint64_t report_samples = 0;        // length of the capture the reports describe
+    pdt_progress_fn progress_fn = nullptr;
+    void *progress_user = nullptr;
     // (stream_in is declared with the streaming state below)
     long long gcand_key = -1;          // (chunk_out, step) the candidate list on the device was built for
     int gardner_mode = 0;              // 0 sequential, 1 state table (last run)
@@ -729,6 +733,45 @@ void launch_bytesync(pdt_ctx *ctx, Plan &PL, hipStream_t st, const SyncParams &S
                        &d_sc->nframes, frame_cap);
 }
 
+// reports of chunks [c0, c1) of the capture (c1 <= chunk_host.size()); `total`: the capture's length as far as it is known
+// `open_frame`: a frame whose sync word has been seen and whose last byte has not (a segment's end) -- counted where ByteSync
+// counts it, at the sync word
+static void chunk_reports_range(const pdt_ctx *ctx, uint64_t c0, uint64_t c1, uint64_t total, pdt_chunk_report *out, const pdt_frame *open_frame)
+{
+    const bool argos = ctx->cfg.mode == PDT_MODE_ARGOS;
+    const uint64_t chunk = ctx->cfg.chunk;
+    uint64_t sym_prev = c0 ? ctx->chunk_host[(size_t)c0 - 1].sym_upto : 0, bits_prev = c0 ? ctx->chunk_host[(size_t)c0 - 1].bits_upto : 0;
+    size_t f = 0;
+    if (c0) {                                            // first frame whose sync word was completed behind chunk c0 - 1
+        size_t lo = 0, hi = ctx->frames_host.size();
+        while (lo < hi) {
+            const size_t mid = (lo + hi) / 2;
+            if ((uint64_t)ctx->frames_host[mid].bit_index < bits_prev) lo = mid + 1; else hi = mid;
+        }
+        f = lo;
+    }
+    for (uint64_t c = c0; c < c1; c++) {
+        const pdt::ChunkInfo &ci = ctx->chunk_host[(size_t)c];
+        pdt_chunk_report &o = out[c - c0];
+        memset(&o, 0, sizeof o);
+        o.samples = std::min<uint64_t>(chunk, total - c * chunk);
+        o.avg_phase = ci.avg_phase;
+        o.symbols = ci.sym_upto - sym_prev;
+        o.bits = ci.bits_upto - bits_prev;
+        // ByteSyncOnSyncword / FindSyncWords count a frame at the bit that completes its sync word (ByteSync.c:105,139)
+        while (f < ctx->frames_host.size() && (uint64_t)ctx->frames_host[f].bit_index < ci.bits_upto) { o.frames++; f++; }
+        if (open_frame && (uint64_t)open_frame->bit_index >= bits_prev && (uint64_t)open_frame->bit_index < ci.bits_upto) o.frames++;
+        // waveDataTime[0] as the progress line prints it: POES keeps the input time axis apart (main.c:424,438,445), ARGOS
+        // compacts the symbol and bit times into it (ARGOSdemod/main.c:278,282)
+        o.time0 = (argos && ctx->elem == 8) ? const_cast<pdt_ctx *>(ctx)->axis_d.at((uint64_t)ci.t0_src + 1)
+                  : argos ? (double)const_cast<pdt_ctx *>(ctx)->axis_f.at((uint64_t)ci.t0_src + 1)
+                          : (double)const_cast<pdt_ctx *>(ctx)->axis_f.at(c * chunk + 1);
+        sym_prev = ci.sym_upto;
+        bits_prev = ci.bits_upto;
+    }
+}
+
+
 // What run_capture's recording phase hands to its finish phase (finish_capture): the capacities and flags the read-back needs.
 struct FinishArgs {
     bool argos, need_lock, fuse_mix;
@@ -786,10 +829,14 @@ template <typename T> int finish_capture(pdt_ctx *ctx, uint64_t n, const FinishA
             HIP_TRY(hipMemcpy(recs.data() + have, d_frames + have, (size_t)(sc.nframes - have) * sizeof(FrameRec), hipMemcpyDeviceToHost));
     }
     ctx->last_nframes = sc.nframes;
-    ctx->chunk_host.clear();
-    if (ctx->pend_chunks && !seg) {
-        ctx->chunk_host.resize((size_t)ctx->pend_chunks);
-        memcpy(ctx->chunk_host.data(), ctx->qual_pin, (size_t)ctx->pend_chunks * sizeof(ChunkInfo));
+    const uint64_t got_chunks = ctx->pend_chunks;     // (a segment: those of its new chunks, window-local counts -- see below)
+    if (!seg) {
+        ctx->chunk_host.clear();
+        ctx->report_samples = n;
+        if (got_chunks) {
+            ctx->chunk_host.resize((size_t)got_chunks);
+            memcpy(ctx->chunk_host.data(), ctx->qual_pin, (size_t)got_chunks * sizeof(ChunkInfo));
+        }
     }
     ctx->pend_chunks = 0;
 
@@ -884,6 +931,22 @@ template <typename T> int finish_capture(pdt_ctx *ctx, uint64_t n, const FinishA
         seg->have_sampler = true;
         if (sc.nsym >= 1) { seg->sym_m2 = (double)tail.sym_m2; seg->sym_m1 = (double)tail.sym_m1; }
         seg->clockmod = tail.clock;
+        if (got_chunks) {
+            // the reports of this segment's chunks: the window's counts include the history symbols and the kept bits (all in
+            // front of the first new chunk), the capture's counts those of the earlier segments
+            const ChunkInfo *ci = (const ChunkInfo *)ctx->qual_pin;
+            for (uint64_t c = 0; c < got_chunks; c++) {
+                ChunkInfo o = ci[c];
+                if ((long long)o.sym_upto < sym_pad || (long long)o.bits_upto < kept) return PDT_ERR_STATE;
+                o.sym_upto = o.sym_upto - (uint64_t)sym_pad + seg->nsym_total;
+                o.bits_upto = o.bits_upto - (uint64_t)kept + seg->nbits_total;
+                o.t0_src += org_out;
+                ctx->chunk_host.push_back(o);
+            }
+            // averagePhase goes on behind the lock (the lock record holds its value AT the lock): the next segment's walkers
+            // start from the value behind this segment's last sample = its last chunk's
+            if (seg->locked && N > first) seg->avg = ci[got_chunks - 1].avg_phase;
+        }
         seg->nsym_total += new_syms;
         seg->nbits_total += new_bits;
         seg->seg_new_symbols = new_syms;
@@ -1002,6 +1065,15 @@ template <typename T> int finish_capture(pdt_ctx *ctx, uint64_t n, const FinishA
     }
 
     collect_timers();
+    if (ctx->progress_fn && !ctx->chunk_host.empty()) {          // pdt_set_progress: a whole capture reports once, at its end
+        try {
+            std::vector<pdt_chunk_report> rep(ctx->chunk_host.size());
+            chunk_reports_range(ctx, 0, rep.size(), ctx->report_samples, rep.data(), nullptr);
+            ctx->progress_fn(ctx->progress_user, 0, rep.data(), rep.size(), &ctx->stats);
+        } catch (const std::bad_alloc &) {
+            return PDT_ERR_NOMEM;
+        }
+    }
     return PDT_OK;
 }
 
@@ -1210,7 +1282,8 @@ template <typename T> int run_capture(pdt_ctx *ctx, uint64_t n, int phase = RUN_
     if (ctx->keep_agc_raw) AP.raw_out = (T *)ctx->agc_raw.p;
     // quality figure (pdt_keep_quality; whole captures only): averagePhase is one more EMA of the lock detector's kind
     // (CarrierTrackingPLL.c:80,124,152), alpha 0.00005 -> blocks of one time constant, 16 of warm-up behind the affine guess
-    const bool quality = (ctx->keep_quality || inject) && !seg && N > 0;
+    // (in the segments of the overlapped ingest too: they begin and end on chunk boundaries, StreamCarry::quality)
+    const bool quality = (ctx->keep_quality || inject) && (!seg || (seg->quality && first % chunk == 0)) && N > 0;
     const T avg_alpha = (T)0.00005;
     // Blocks of one time constant for captures up to ~8 000 of them; longer captures get longer blocks (up to eight time
     // constants), the warm-up stays 16 time constants: with one-time-constant blocks an hour at 250 ksps re-read its input 17
@@ -1798,6 +1871,7 @@ template <typename T> int run_capture(pdt_ctx *ctx, uint64_t n, int phase = RUN_
         hist[sym_pad - 1] = (T)seg->sym_m1;
         memcpy(spin + 256, hist, sizeof hist);
         PL.copy(OP_H2D, d_sym, spin + 256, (size_t)sym_pad * sizeof(T));
+        if (quality) PL.memset_async(d_symidx, 0, (size_t)sym_pad * sizeof(long long));   // (k_chunk_info searches the picks' indices)
         clock0 = seg->clockmod;
         bit0 = seg->kept_bits.size();
         if (bit0) {
@@ -2030,7 +2104,7 @@ template <typename T> int run_capture(pdt_ctx *ctx, uint64_t n, int phase = RUN_
     if (inject) {
         // the stage call ends behind the PLL: drop what was recorded for the later stages (their counters stay zero)
         PL.ops.resize(ops_after_pll);
-    } else if (ctx->keep_quality && !seg && n_chunks > 0) {
+    } else if (quality && n_chunks > 0) {
         // (N > 0 here; a context without a PLL run -- never -- would leave avg_phase 0)
         if (quality_side) {                                  // the averagePhase stream is complete
             PL.simple(OP_JOIN_RECORD);
@@ -2039,8 +2113,10 @@ template <typename T> int run_capture(pdt_ctx *ctx, uint64_t n, int phase = RUN_
         PDT_LAUNCH(256, k_chunk_info<T>, dim3((unsigned)((n_chunks + 255) / 256)), dim3(256), 0, st, (const T *)d_avgph, N, chunk, n_chunks,
                            interp, (const long long *)d_symidx, (const unsigned long long *)&d_sc->nsym, (const unsigned *)d_bitsym,
                            (const unsigned long long *)&d_sc->nbits, (ChunkInfo *)ctx->chunkinfo.p);
-        PL.copy(OP_D2H, ctx->qual_pin, ctx->chunkinfo.p, (size_t)n_chunks * sizeof(ChunkInfo));
-        ctx->pend_chunks = (uint64_t)n_chunks;
+        // (a segment: the new chunks' records; those of the window's history were reported by the segments before)
+        const long long rep_first = seg ? first / chunk : 0;
+        PL.copy(OP_D2H, ctx->qual_pin, (const ChunkInfo *)ctx->chunkinfo.p + rep_first, (size_t)(n_chunks - rep_first) * sizeof(ChunkInfo));
+        ctx->pend_chunks = (uint64_t)(n_chunks - rep_first);
     }
     PL.simple(OP_EV1);
 
@@ -2672,29 +2748,16 @@ uint64_t pdt_chunk_reports(const pdt_ctx *ctx, pdt_chunk_report *out, uint64_t m
     const uint64_t nc = ctx->chunk_host.size();
     if (!out) return nc;
     const uint64_t m = std::min<uint64_t>(nc, max_chunks);
-    const bool argos = ctx->cfg.mode == PDT_MODE_ARGOS;
-    const uint64_t chunk = ctx->cfg.chunk;
-    uint64_t sym_prev = 0, bits_prev = 0;
-    size_t f = 0;
-    for (uint64_t c = 0; c < m; c++) {
-        const pdt::ChunkInfo &ci = ctx->chunk_host[(size_t)c];
-        pdt_chunk_report &o = out[c];
-        memset(&o, 0, sizeof o);
-        o.samples = std::min<uint64_t>(chunk, ctx->n_samples - c * chunk);
-        o.avg_phase = ci.avg_phase;
-        o.symbols = ci.sym_upto - sym_prev;
-        o.bits = ci.bits_upto - bits_prev;
-        // ByteSyncOnSyncword / FindSyncWords count a frame at the bit that completes its sync word (ByteSync.c:105,139)
-        while (f < ctx->frames_host.size() && (uint64_t)ctx->frames_host[f].bit_index < ci.bits_upto) { o.frames++; f++; }
-        // waveDataTime[0] as the progress line prints it: POES keeps the input time axis apart (main.c:424,438,445), ARGOS
-        // compacts the symbol and bit times into it (ARGOSdemod/main.c:278,282)
-        o.time0 = (argos && ctx->elem == 8) ? const_cast<pdt_ctx *>(ctx)->axis_d.at((uint64_t)ci.t0_src + 1)
-                  : argos ? (double)const_cast<pdt_ctx *>(ctx)->axis_f.at((uint64_t)ci.t0_src + 1)
-                          : (double)const_cast<pdt_ctx *>(ctx)->axis_f.at(c * chunk + 1);
-        sym_prev = ci.sym_upto;
-        bits_prev = ci.bits_upto;
-    }
+    chunk_reports_range(ctx, 0, m, ctx->report_samples, out, nullptr);
     return m;
+}
+
+int pdt_set_progress(pdt_ctx *ctx, pdt_progress_fn fn, void *user)
+{
+    if (!ctx) return PDT_ERR_ARG;
+    ctx->progress_fn = fn;
+    ctx->progress_user = user;
+    return PDT_OK;
 }
 
 int pdt_keep_pll(pdt_ctx *ctx, int enable)
@@ -2745,12 +2808,10 @@ static int demod_overlapped(pdt_ctx *ctx, const IngestSrc &src, uint64_t nframes
 // hour-long POES captures: the chain starts on the part of the capture that has arrived (demod_overlapped)
 static bool overlap_ingest(const pdt_ctx *ctx, uint64_t nframes, size_t fb)
 {
-    // (per-chunk reports come from whole-capture runs only: with pdt_keep_quality the capture is ingested first)
-    // Round 4: off unless PDT_OVERLAP is set.  Every segment pays the latency floor of the block-parallel stages again and runs
-    // the stream path's kernels (no fused mix + FIR, per-lane AGC walkers): with the whole-capture step at 19 ms the four
-    // segments cost 49 ms of GPU time and the ingest slows down beside them -- 3.6 GB file to frame file: 121 ms overlapped,
-    // 91 ms with the capture ingested first (profiles/r4).
-    return ctx->tune.overlap && !ctx->keep_quality && ctx->cfg.mode == PDT_MODE_POES && ctx->cfg.sampler != PDT_SAMPLER_MM && ctx->cfg.chain != PDT_CHAIN_LIVE &&
+    // Round 5: on by default (PDT_NO_OVERLAP switches it off) -- the segments are cut where they can take the whole-capture
+    // kernels and keep the per-chunk reports (demod_overlapped); 3.6 GB file to frame file 82-91 ms against 89-94 ms with the
+    // capture ingested first (profiles/r5).
+    return ctx->tune.overlap && ctx->cfg.mode == PDT_MODE_POES && ctx->cfg.sampler != PDT_SAMPLER_MM && ctx->cfg.chain != PDT_CHAIN_LIVE &&
            (size_t)nframes * fb >= ((size_t)(ctx->tune.overlap_min_mb > 0 ? ctx->tune.overlap_min_mb : 512) << 20) && ctx->cfg.chunk > 0 &&
            nframes / ctx->cfg.chunk >= 64;
 }
@@ -3516,6 +3577,8 @@ int pdt_stream_begin(pdt_ctx *ctx)
     ctx->stream_open = false;
     ctx->stream_new.clear();
     ctx->frames_host.clear();
+    ctx->chunk_host.clear();
+    ctx->report_samples = 0;
     ctx->tip_host.clear();
     ctx->frames_on_device = 0;
     memset(&ctx->stats, 0, sizeof ctx->stats);
@@ -3664,32 +3727,50 @@ static int segment_end(pdt_ctx *ctx, uint64_t upto, bool final_seg)
 // alone.  Three segments of 64 / 22 / 14 % leave 8.6 ms there (two: 76 / 24 %, 9.7 ms; four equal ones, round 3: 12 ms of
 // floor each, 49 ms in all).  (iii) A segment's launch plan is recorded BEFORE the host waits for its last span, and the text
 // of a finished segment is formatted and written (text_fd) while the next one runs.
+// ... and so are its per-chunk reports handed to the caller's progress function (pdt_set_progress)
 struct TextSink {
     int fd = -1;
     uint64_t bytes = 0;
     int rc = PDT_OK;
+    pdt_progress_fn fn = nullptr;
+    void *user = nullptr;
     std::thread th;
     std::vector<pdt_frame> batch;
+    std::vector<pdt_chunk_report> reports;
+    uint64_t rep_first = 0;
+    pdt_stats so_far;
     void wait() { if (th.joinable()) th.join(); }
-    void push(const std::vector<pdt_frame> &frames)       // (the previous batch is on the file before the next one starts)
+    void work()
     {
-        if (fd < 0 || frames.empty()) return;
-        wait();
-        if (rc) return;
-        try {
-            batch = frames;
-            th = std::thread([this] {
-                uint64_t w = 0;
-                const int r = pdt_write_records(batch.data(), batch.size(), fd, &w);
-                bytes += w;
-                if (r) rc = r;
-            });
-        } catch (const std::exception &) {
+        if (fd >= 0 && !batch.empty()) {
             uint64_t w = 0;
-            const int r = pdt_write_records(frames.data(), frames.size(), fd, &w);
+            const int r = pdt_write_records(batch.data(), batch.size(), fd, &w);
             bytes += w;
             if (r) rc = r;
         }
+        if (fn && !reports.empty()) fn(user, rep_first, reports.data(), reports.size(), &so_far);
+    }
+    // (the previous batch is on the file and reported before the next one starts)
+    void push(const std::vector<pdt_frame> &frames, std::vector<pdt_chunk_report> &&rep, uint64_t first_chunk, const pdt_stats &st, bool in_background)
+    {
+        if ((fd < 0 || frames.empty()) && (!fn || rep.empty())) return;
+        wait();
+        if (rc) return;
+        reports = std::move(rep);
+        rep_first = first_chunk;
+        so_far = st;
+        try {
+            if (fd >= 0) batch = frames; else batch.clear();
+            if (in_background) {
+                th = std::thread([this] { work(); });
+                return;
+            }
+        } catch (const std::bad_alloc &) {
+            rc = PDT_ERR_NOMEM;
+            return;
+        } catch (const std::exception &) {
+        }
+        work();
     }
 };
 
@@ -3710,6 +3791,8 @@ static int demod_overlapped(pdt_ctx *ctx, const IngestSrc &src, uint64_t nframes
     if ((rc = ctx->stream_in.ensure(((size_t)nframes + 64) * fb))) return rc;
     IngestJob job;
     ctx->sc.in_place = true;
+    ctx->sc.quality = ctx->keep_quality;          // (every cut below is a chunk boundary)
+    ctx->report_samples = nframes;
     const uint64_t chunk = ctx->cfg.chunk;
     // the grid of the segment boundaries and of the window's origin (see above)
     const uint64_t grid = lcm_u64(lcm_u64(chunk * 208, 64 * 26 * (uint64_t)ctx->interp), 416);
@@ -3746,6 +3829,18 @@ static int demod_overlapped(pdt_ctx *ctx, const IngestSrc &src, uint64_t nframes
     }
     TextSink sink;
     sink.fd = text_fd;
+    sink.fn = ctx->progress_fn;
+    sink.user = ctx->progress_user;
+    uint64_t reported = 0;                        // chunks whose reports have been handed on
+    auto segment_reports = [&]() {                // those of the segment that has just ended
+        std::vector<pdt_chunk_report> r;
+        const uint64_t have = ctx->chunk_host.size();
+        if (sink.fn && have > reported) {
+            r.resize((size_t)(have - reported));
+            chunk_reports_range(ctx, reported, have, nframes, r.data(), ctx->sc.have_pending ? &ctx->sc.pending : nullptr);
+        }
+        return r;
+    };
     ctx->batch_hint = 1;
     for (size_t k = 0; k < ends.size() && !rc; k++) {
         const bool last = k + 1 == ends.size();
@@ -3771,7 +3866,16 @@ static int demod_overlapped(pdt_ctx *ctx, const IngestSrc &src, uint64_t nframes
         ctx->pending = false;
         if (!rc) rc = segment_end(ctx, win, last);
         const auto t2c = std::chrono::steady_clock::now();
-        if (!rc && !last) sink.push(ctx->sc.seg_frames);
+        if (!rc && !last) {
+            try {
+                const uint64_t first_chunk = reported;
+                std::vector<pdt_chunk_report> r = segment_reports();
+                reported += r.size();
+                sink.push(ctx->sc.seg_frames, std::move(r), first_chunk, ctx->stats, true);
+            } catch (const std::bad_alloc &) {
+                rc = PDT_ERR_NOMEM;
+            }
+        }
         if (ctx->tune.debug_overlap) {
             const auto t3 = std::chrono::steady_clock::now();
             auto ms = [](auto a, auto b) { return std::chrono::duration<double, std::milli>(b - a).count(); };
@@ -3783,12 +3887,17 @@ static int demod_overlapped(pdt_ctx *ctx, const IngestSrc &src, uint64_t nframes
     ctx->sc.in_place = false;
     const int rj = ingest_join(job);
     sink.wait();
-    if (!rc && !rj && text_fd >= 0) {
+    if (!rc && !rj) {
         if (sink.rc) rc = sink.rc;
         else {
-            uint64_t w = 0;
-            rc = pdt_write_records(ctx->sc.seg_frames.data(), ctx->sc.seg_frames.size(), text_fd, &w);
-            sink.bytes += w;
+            try {
+                const uint64_t first_chunk = reported;
+                std::vector<pdt_chunk_report> r = segment_reports();
+                sink.push(ctx->sc.seg_frames, std::move(r), first_chunk, ctx->stats, false);
+                rc = sink.rc;
+            } catch (const std::bad_alloc &) {
+                rc = PDT_ERR_NOMEM;
+            }
         }
     }
     if (text_bytes) *text_bytes = sink.bytes;

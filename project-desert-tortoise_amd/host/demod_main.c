@@ -63,61 +63,85 @@
 #define ANSI_COLOR_GREEN "\x1b[32m"
 #define ANSI_COLOR_YELLOW "\x1b[33m"
 #define ANSI_COLOR_RESET "\x1b[0m"
-static void print_progress(pdt_ctx *ctx, long num_samples, unsigned long chunkSize)
+/* The lines are printed from the library's progress function (pdt_set_progress): a large capture is demodulated in segments
+ * while it is still being read, and every finished segment's chunks are reported while the next one runs.                      */
+typedef struct progress_state {
+    long num_samples;
+    unsigned long chunkSize;
+    uint64_t total_chunks;                 /* of the capture */
+    int extra;                             /* the zero-sample pass at the end of the file */
+    int norm_wanted, norm_printed, lock_printed, any;
+    unsigned long i, totalSymbols, totalBits, totalSamples;
+    int totalFrames;
+#ifdef PDT_ARGOS
+    double percentComplete;
+#else
+    float percentComplete;
+#endif
+} progress_state;
+
+static void print_norm_and_lock(progress_state *P, const pdt_stats *st)
 {
-    const uint64_t nc = pdt_chunk_reports(ctx, NULL, 0);
-    if (!nc) return;
-    pdt_chunk_report *r = (pdt_chunk_report *)malloc((size_t)nc * sizeof *r);
-    if (!r) return;
-    pdt_chunk_reports(ctx, r, nc);
-    unsigned long i = 0, totalSymbols = 0, totalBits = 0, totalSamples = 0;
-    int totalFrames = 0;
-#ifdef PDT_ARGOS
-    double percentComplete = 0;
-#else
-    float percentComplete = 0, averagePhase;
-    char qualityString[20];
-#endif
-    const int extra = r[nc - 1].samples == chunkSize;          /* the zero-sample pass at the end of the file */
-    for (uint64_t c = 0; c < nc + (uint64_t)extra; c++) {
-        const int last = c + 1 == nc + (uint64_t)extra;        /* feof(inFilePtr) */
-        const pdt_chunk_report *q = &r[c < nc ? c : nc - 1];
-        if (c < nc) {
-            i += q->samples;
-            totalBits += q->bits;
-            totalFrames += (int)q->frames;
-            totalSymbols += q->symbols;
-            totalSamples += q->samples;
-        }
-#ifdef PDT_ARGOS
-        if ((((double)(i) / num_samples) * 100.0 - percentComplete > 0.15) || last) {
-            percentComplete = ((double)(i) / num_samples) * 100.0;
-            printf("\r");
-            printf("%0.1f%% %0.3f Ks : %0.1f Sec: %ld Sym : %ld Bits : %d Packets", ((double)(i) / num_samples) * 100.0,
-                   (totalSamples) / 1000.0, q->time0, totalSymbols, totalBits, totalFrames);
-        }
-#else
-        if ((((float)(i) / num_samples) * 100.0 - percentComplete > 0.15) || last) {
-            percentComplete = ((float)(i) / num_samples) * 100.0;
-            averagePhase = (float)q->avg_phase;
-            printf("\r");
-            printf("%f\t", fabs(M_PI / 2.0 - averagePhase));
-            averagePhase = 10.0 * log10f(powf(fabs(M_PI / 2.0 - averagePhase), 2));
-            if (averagePhase > -4.3)
-                snprintf(qualityString, 20, "%s%02.1fQ%s", ANSI_COLOR_GREEN, averagePhase, ANSI_COLOR_RESET);
-            else if (averagePhase > -5)
-                snprintf(qualityString, 20, "%s%02.1fQ%s", ANSI_COLOR_YELLOW, averagePhase, ANSI_COLOR_RESET);
-            else if (averagePhase > -6)
-                snprintf(qualityString, 20, "%s%02.1fQ%s", ANSI_COLOR_YELLOW, averagePhase, ANSI_COLOR_RESET);
-            else
-                snprintf(qualityString, 20, "%s%02.1fQ%s", ANSI_COLOR_RED, averagePhase, ANSI_COLOR_RESET);
-            printf("%0.1f%% %0.3f Ks : %0.1f Sec: %ld Sym : %ld Bits : %d Frames : %s   ", ((float)(i) / num_samples) * 100.0,
-                   (totalSamples) / 1000.0, (float)q->time0, totalSymbols, totalBits, totalFrames, qualityString);
-        }
-#endif
+    if (P->norm_wanted && !P->norm_printed) {
+        printf("Normalization Factor: %f\n", st->norm_factor);                  /* main.c:420 */
+        P->norm_printed = 1;
     }
-    printf("\n");
-    free(r);
+    if (!P->lock_printed && st->lock_sample >= 0) {
+        printf(" : PLL locked at %0.2fHz\n", st->lock_freq_hz);                 /* CarrierTrackingPLL.c:269 */
+        P->lock_printed = 1;
+    }
+}
+
+static void progress_line(progress_state *P, const pdt_chunk_report *q, int last)
+{
+#ifdef PDT_ARGOS
+    if ((((double)(P->i) / P->num_samples) * 100.0 - P->percentComplete > 0.15) || last) {
+        P->percentComplete = ((double)(P->i) / P->num_samples) * 100.0;
+        printf("\r");
+        printf("%0.1f%% %0.3f Ks : %0.1f Sec: %ld Sym : %ld Bits : %d Packets", ((double)(P->i) / P->num_samples) * 100.0,
+               (P->totalSamples) / 1000.0, q->time0, P->totalSymbols, P->totalBits, P->totalFrames);
+    }
+#else
+    float averagePhase;
+    char qualityString[20];
+    if ((((float)(P->i) / P->num_samples) * 100.0 - P->percentComplete > 0.15) || last) {
+        P->percentComplete = ((float)(P->i) / P->num_samples) * 100.0;
+        averagePhase = (float)q->avg_phase;
+        printf("\r");
+        printf("%f\t", fabs(M_PI / 2.0 - averagePhase));
+        averagePhase = 10.0 * log10f(powf(fabs(M_PI / 2.0 - averagePhase), 2));
+        if (averagePhase > -4.3)
+            snprintf(qualityString, 20, "%s%02.1fQ%s", ANSI_COLOR_GREEN, averagePhase, ANSI_COLOR_RESET);
+        else if (averagePhase > -5)
+            snprintf(qualityString, 20, "%s%02.1fQ%s", ANSI_COLOR_YELLOW, averagePhase, ANSI_COLOR_RESET);
+        else if (averagePhase > -6)
+            snprintf(qualityString, 20, "%s%02.1fQ%s", ANSI_COLOR_YELLOW, averagePhase, ANSI_COLOR_RESET);
+        else
+            snprintf(qualityString, 20, "%s%02.1fQ%s", ANSI_COLOR_RED, averagePhase, ANSI_COLOR_RESET);
+        printf("%0.1f%% %0.3f Ks : %0.1f Sec: %ld Sym : %ld Bits : %d Frames : %s   ", ((float)(P->i) / P->num_samples) * 100.0,
+               (P->totalSamples) / 1000.0, (float)q->time0, P->totalSymbols, P->totalBits, P->totalFrames, qualityString);
+    }
+#endif
+}
+
+static void on_progress(void *user, uint64_t first_chunk, const pdt_chunk_report *r, uint64_t n, const pdt_stats *so_far)
+{
+    progress_state *P = (progress_state *)user;
+    print_norm_and_lock(P, so_far);
+    for (uint64_t k = 0; k < n; k++) {
+        const pdt_chunk_report *q = &r[k];
+        const int final_chunk = first_chunk + k + 1 == P->total_chunks;
+        P->i += q->samples;
+        P->totalBits += q->bits;
+        P->totalFrames += (int)q->frames;
+        P->totalSymbols += q->symbols;
+        P->totalSamples += q->samples;
+        progress_line(P, q, final_chunk && !P->extra);                 /* last: feof(inFilePtr) */
+        if (final_chunk && P->extra) progress_line(P, q, 1);
+        if (final_chunk) printf("\n");
+    }
+    P->any = 1;
+    fflush(stdout);
 }
 
 static const char *get_filename_ext(const char *filename)
@@ -399,18 +423,28 @@ int main(int argc, char **argv)
     if (outputRawFiles) pdt_keep_presquelch(ctx, 1);                 /* -r: the AGC output before Squelch, ARGOSdemod/main.c:273-274 */
 #endif
     pdt_keep_pll(ctx, 0);                                            /* nothing here reads the PLL output stream */
-    if (!noProgress) pdt_keep_quality(ctx, 1);                       /* the chunk loop's progress / quality line */
-    /* -P (no per-chunk reports): the one-call form -- a large file is demodulated in segments while it is still being read, and a
-     * finished segment's text goes to the file while the next one runs, as the reference's fprintf calls do (ByteSync.c:62-101) */
+    progress_state prog;
+    memset(&prog, 0, sizeof prog);
+    prog.num_samples = num_samples;
+    prog.chunkSize = (unsigned long)chunkSize;
+    prog.total_chunks = (nframes + (uint64_t)chunkSize - 1) / (uint64_t)chunkSize;
+    prog.extra = nframes % (uint64_t)chunkSize == 0;
+    prog.norm_wanted = normFactor == 0;
+    if (!noProgress && num_samples > 0) {                            /* the chunk loop's progress / quality line */
+        pdt_keep_quality(ctx, 1);
+        pdt_set_progress(ctx, on_progress, &prog);
+    }
+    /* POES: the one-call form -- a large file is demodulated in segments while it is still being read; a finished segment's
+     * text goes to the file (as the reference's fprintf calls do, ByteSync.c:62-101) and its progress lines to the console
+     * while the next one runs */
     int text_written = 0;
     fflush(out);
 #ifndef PDT_ARGOS
-    if (noProgress) {
-        rc = pdt_demod_file(ctx, fileno(in), (uint64_t)data_offset, nframes, is_raw ? PDT_FMT_F32 : PDT_FMT_PCM16, fileno(out), NULL);
-        text_written = 1;
-    } else
-#endif
+    rc = pdt_demod_file(ctx, fileno(in), (uint64_t)data_offset, nframes, is_raw ? PDT_FMT_F32 : PDT_FMT_PCM16, fileno(out), NULL);
+    text_written = 1;
+#else
     rc = pdt_demod_fd(ctx, fileno(in), (uint64_t)data_offset, nframes, is_raw ? PDT_FMT_F32 : PDT_FMT_PCM16);
+#endif
     const double t_demod1 = now_ms();
     fclose(in);
     if (rc != PDT_OK) {
@@ -442,10 +476,7 @@ int main(int argc, char **argv)
 #endif
     pdt_stats st;
     pdt_get_stats(ctx, &st);
-    if (normFactor == 0) printf("Normalization Factor: %f\n", st.norm_factor);
-    if (st.lock_sample >= 0) printf(" : PLL locked at %0.2fHz\n", st.lock_freq_hz);
-
-    if (!noProgress && num_samples > 0) print_progress(ctx, num_samples, (unsigned long)chunkSize);
+    print_norm_and_lock(&prog, &st);                                 /* (what the progress function has not printed) */
 
     char *text = NULL;
     fflush(out);

@@ -334,6 +334,58 @@ def test_overlapped_file_in_unequal_segments(pdt, orc, tmp_path, fs, secs):
         assert "mix_fir" in outs["default"][1] and "mix_fir" in outs["split"][1] and "mix_fir" not in outs["stream_kernels"][1]
 
 
+@pytest.mark.parametrize("lead_noise", [0, 7_000_000])
+def test_overlapped_segments_keep_the_chunk_reports(pdt, tmp_path, lead_noise):
+    """pdt_keep_quality with the overlapped ingest: the segments end on chunk boundaries, averagePhase (which goes on behind
+    the lock) and the symbol / bit counts are carried from one to the next -- the per-chunk reports are those of the plain
+    whole-capture call, bit for bit; pdt_set_progress hands them on segment by segment (in chunk order, each chunk once, the
+    frame whose sync word lies in one segment and whose last byte in the next counted where ByteSync counts it).  With seven
+    million samples of faint noise in front the PLL locks in the second of four equal segments: the first one reports the
+    acquisition's averagePhase."""
+    import os
+    fs = 250000
+    iq = pdt.synth_capture(0, fs, 75.0 - lead_noise / fs, seed=74)
+    if lead_noise:
+        # (a few LSB of noise rather than zeros: StaticGain normalises by the first chunk's mean magnitude)
+        iq = np.concatenate([np.random.default_rng(5).integers(-3, 4, size=(lead_noise, 2), dtype=np.int16), iq])
+    wav = str(tmp_path / "cap.wav")
+    pdt.write_wav(wav, fs, iq)
+    res = {}
+    for name, env in (("plain", {"PDT_NO_OVERLAP": "1"}), ("overlapped", {"PDT_OVERLAP_MIN_MB": "1"}),
+                      ("split", {"PDT_OVERLAP_MIN_MB": "1", "PDT_OVERLAP_SPLIT": "0.25,0.25,0.25,0.25"})):
+        def run():
+            calls = []
+            with pdt.Demodulator(pdt.MODE_POES, fs, profile=True).keep_pll(False) as d:
+                d.keep_quality().set_progress(lambda first, rep, st: calls.append((first, rep, st.lock_sample, st.norm_factor)))
+                fd = os.open(wav, os.O_RDONLY)
+                fo = os.open(str(tmp_path / f"{name}.txt"), os.O_RDWR | os.O_CREAT | os.O_TRUNC, 0o644)
+                try:
+                    d.demod_file_text(fd, 44, len(iq), fo, 0)
+                finally:
+                    os.close(fd)
+                    os.close(fo)
+                return d.chunk_reports(), calls, d.text(), d.stats(), d.kernel_times()
+        res[name] = _with_env(env, run)
+    rep0, calls0, text0, st0, _ = res["plain"]
+    assert len(rep0) == (len(iq) + 9999) // 10000 and len(calls0) == 1 and calls0[0][0] == 0
+    assert calls0[0][1].tobytes() == rep0.tobytes()
+    assert rep0["symbols"].sum() == st0.symbols and rep0["bits"].sum() == st0.bits and rep0["frames"].sum() == st0.frames
+    for name, ncalls in (("overlapped", 3), ("split", 4)):
+        rep, calls, text, st, kt = res[name]
+        assert text == text0 and "mix_fir" in kt and "quality" in kt
+        assert rep.tobytes() == rep0.tobytes(), name
+        assert len(calls) == ncalls
+        at = 0
+        for first, r, lock_sample, norm in calls:
+            assert first == at and len(r) > 0 and norm == st0.norm_factor
+            at += len(r)
+        assert at == len(rep0)
+        assert np.concatenate([c[1] for c in calls]).tobytes() == rep0.tobytes()
+        assert calls[-1][2] == st0.lock_sample
+        if lead_noise:                                 # nothing to lock on in the first quarter (the first 55 % hold the lock)
+            assert st0.lock_sample >= lead_noise and calls[0][2] == (-1 if name == "split" else st0.lock_sample)
+
+
 def test_stage_and_whole_capture_entries_are_refused_while_a_stream_is_open(pdt, clip):
     """The stage buffers hold the tails an open stream continues from: every pdt_stage_* / pdt_demod_* entry
     returns PDT_ERR_STATE between the first push and pdt_stream_end, and the stream is not disturbed by the attempt."""
