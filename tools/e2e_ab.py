@@ -1,7 +1,8 @@
 """End-to-end A/B on ONE box, interleaved: the c3 WAV on tmpfs -> minor-frame file through pdt_demod_file, one context per
 configuration (the developer switches are read when a context is opened), the configurations taken round robin for a number of
 rounds so that the neighbours' noise on a shared host hits all of them alike.  Prints median / min / all per configuration.
-Usage: python tools/e2e_ab.py [rounds] name=ENV1:VAL1,ENV2:VAL2 ...   (e.g. plain=PDT_NO_OVERLAP:1 s4=PDT_OVERLAP_SPLIT:0.42/0.27/0.18/0.13)"""
+Usage: python tools/e2e_ab.py [rounds] name=ENV1:VAL1,ENV2:VAL2 ...   (e.g. plain=PDT_NO_OVERLAP:1 s4=PDT_OVERLAP_SPLIT:0.42/0.27/0.18/0.13;
+AB_QUALITY:1 in a configuration = pdt_keep_quality on, the per-chunk reports the CLI programs ask for)"""
 import importlib, json, os, sys, tempfile, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
@@ -24,8 +25,11 @@ for spec in specs:
     for kv in filter(None, envs.split(",")):
         k, _, v = kv.partition(":")
         env[k] = v.replace("/", ",")
+    quality = env.pop("AB_QUALITY", None)                 # (not a switch of the library: pdt_keep_quality, what the CLI runs with)
     os.environ.update(env)
     ctxs[name] = pdt.Demodulator(0, fs, device=0).keep_pll(False)
+    if quality:
+        ctxs[name].keep_quality()
     for k in env:
         os.environ.pop(k)
 times = {k: [] for k in ctxs}
