@@ -1,7 +1,9 @@
 """Randomised check of the overlapped file path (pdt_demod_file on a file large enough to be demodulated in segments while it is
 read): random sample rates at INTERP 1 and above, chunk sizes, lengths, carrier offsets, noise, a noise-only lead (the lock then
 happens in a later segment), random splits into 2 - 6 segments, table rows of 1 / 13 / 16 / other chunks -- the output FILE's bytes
-must be the oracle's text, and every segment boundary lies on the grid where the segments take the whole-capture kernels
+must be the oracle's text, in half of the cases with the per-chunk reports on (pdt_keep_quality + pdt_set_progress: averagePhase
+and the symbol / bit counts of every chunk against the oracle's chunk loop, every chunk handed on once and in order) -- and every
+segment boundary lies on the grid where the segments take the whole-capture kernels
 (k_mix_fir, k_agc_block_tr, rows of several chunks).  Usage: python tests/tools/fuzz_segments.py [n_cases] [seed]"""
 import ctypes as C
 import importlib, os, sys, tempfile, time
@@ -47,6 +49,7 @@ for case in range(n_cases):
         env["PDT_GSPAN"] = str(span)
     if rng.random() < 0.15:
         env["PDT_SEG_PLAIN"] = "1"
+    quality = rng.random() < 0.5
     o = orc.Oracle(orc.POES, fs, iq, chunk=chunk)
     wav = os.path.join(tmp, "c.wav")
     outp = os.path.join(tmp, "o.txt")
@@ -54,6 +57,9 @@ for case in range(n_cases):
     os.environ.update(env)
     try:
         with pdt.Demodulator(pdt.MODE_POES, fs, chunk=chunk, profile=True).keep_pll(False) as d:
+            calls = []
+            if quality:
+                d.keep_quality().set_progress(lambda first, r, st: calls.append((first, r)))
             fd = os.open(wav, os.O_RDONLY)
             fo = os.open(outp, os.O_RDWR | os.O_CREAT | os.O_TRUNC, 0o644)
             nb = d.demod_file_text(fd, 44, n, fo, 0)
@@ -63,13 +69,26 @@ for case in range(n_cases):
             s = d.stats()
             kt = d.kernel_times()
             ok = data == o.text() and nb == len(data) and data == d.text() and s.samples == n
+            if quality:
+                rep = d.chunk_reports()
+                nc = (n + chunk - 1) // chunk
+                avg = o.stage(orc.ST_AVG)
+                cnt = o.stage(orc.ST_COUNTS).reshape(-1, 3)
+                okq = len(rep) == nc and rep["avg_phase"].astype(avg.dtype).tobytes() == avg[:nc].tobytes()
+                okq = okq and np.array_equal(rep["samples"], cnt[:nc, 0]) and np.array_equal(rep["symbols"], cnt[:nc, 1]) and \
+                    np.array_equal(rep["bits"], cnt[:nc, 2]) and rep["frames"].sum() == s.frames
+                okq = okq and len(calls) >= 2 and [c[0] for c in calls] == list(np.cumsum([0] + [len(c[1]) for c in calls[:-1]])) and \
+                    np.concatenate([c[1] for c in calls]).tobytes() == rep.tobytes()
+                if not okq:
+                    print("     reports differ")
+                ok = ok and okq
     finally:
         for key in env:
             os.environ.pop(key, None)
     bad += 0 if ok else 1
     print(f"{'ok  ' if ok else 'FAIL'} case {case}: fs {fs} chunk {chunk} n {n} ({n / grid:.2f} grid units) f0 {f0:.0f} noise x{p.noise_gain} lead {p.signal_start} "
           f"split {env['PDT_OVERLAP_SPLIT']} span {span} plain {'PDT_SEG_PLAIN' in env} frames {s.frames} lock {s.lock_sample} "
-          f"last segment: {'mix_fir' if 'mix_fir' in kt else 'fir'} par {s.gardner_parallel}", flush=True)
+          f"last segment: {'mix_fir' if 'mix_fir' in kt else 'fir'} par {s.gardner_parallel} reports {int(quality)}", flush=True)
 import shutil
 shutil.rmtree(tmp, ignore_errors=True)
 print(f"{n_cases - bad}/{n_cases} identical in {time.time() - t_start:.0f} s")
