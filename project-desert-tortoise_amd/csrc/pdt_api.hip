@@ -270,7 +270,7 @@ struct Tuning {
     double band_pad = 0.0, pll_warm_scale = 1.0, head_taus = 0.0, agc_k = 0.0, pll_warm_s = 0.0, agc_warm_s = 0.0;
     double overlap_split[8] = { 0, 0, 0, 0, 0, 0, 0, 0 };
     int scout_syms = 0, gspan = 0, gspan_cap = 0, ingest_threads = 0, ingest_span_mb = 0, ingest_streams = 0, overlap_segments = 0, overlap_min_mb = 0, fir_wg_per_cu = 0, agc_tpb = 0, gseg = 0, pll_block = 0, fix_passes = 2;
-    bool fir_generic = false, mix_unfused = false, quality_inline = false, gemit_groups = false, agc_unfused = false, no_excl = false, gardner_onebuf = false, gardner_noring = false, gardner_sequential = false, seg_sequential = false, agc_lanes = false, overlap = true, debug_overlap = false, chain_one_range = false, ema_noguess = false, debug_sync = false, pll_noshort = false, pll_nockpt = false, pll_noconsensus = false, seg_plain = false, sync_block = false;
+    bool fir_generic = false, mix_unfused = false, quality_inline = false, gemit_groups = false, agc_unfused = false, no_excl = false, gardner_onebuf = false, gardner_noring = false, gardner_sequential = false, seg_sequential = false, agc_lanes = false, overlap = true, debug_overlap = false, chain_one_range = false, ema_noguess = false, debug_sync = false, pll_noshort = false, pll_nockpt = false, pll_noconsensus = false, seg_plain = false, sync_block = false, gardner_nostride = false;
     void load()
     {
         std::lock_guard<std::mutex> lock(g_dev_mu);
@@ -296,6 +296,7 @@ struct Tuning {
         fir_generic = get("PDT_FIR_GENERIC") != nullptr;
         mix_unfused = get("PDT_MIX_UNFUSED") != nullptr;
         quality_inline = get("PDT_QUALITY_INLINE") != nullptr;
+        gardner_nostride = get("PDT_GARDNER_NOSTRIDE") != nullptr;
         gemit_groups = get("PDT_GEMIT_GROUPS") != nullptr;
         agc_unfused = get("PDT_AGC_UNFUSED") != nullptr;
         agc_lanes = get("PDT_AGC_LANES") != nullptr;           // the per-lane walkers of rounds 1 - 3 (k_agc_block)
@@ -2063,9 +2064,18 @@ template <typename T> int run_capture(pdt_ctx *ctx, uint64_t n, int phase = RUN_
             CalmEntry<T> *d_calm = (CalmEntry<T> *)((char *)ctx->gneed.p + need_bytes);
             PDT_LAUNCH(256, k_chunk_need<T>, dim3((unsigned)n_chunks), dim3(256), 0, st, (const T *)d_agc, n_out, chunk_out, n_chunks,
                                (unsigned char *)ctx->gneed.p);
+            // chunks without a walk in one stride: where sampling instants stay multiples of 2^(E - p) below 2^E (k_gardner_ring)
+            T gran_scale = 0;
+            if (!ctx->tune.gardner_nostride) {
+                const double top = (double)chunk_out + 2.0 * (double)GP.step + 2.0;
+                const int E = ilogb(top) + 1, p = sizeof(T) == 8 ? 53 : 24;
+                const T sc = (T)ldexp(1.0, p - E);
+                const T gstep = GP.step * sc;
+                if (E < p && gstep == (T)rint((double)gstep) && (double)gstep < ldexp(1.0, p - 1)) gran_scale = sc;
+            }
             PDT_LAUNCH(64 * (RING_NB + 1), (k_gardner_ring<T, RING_LEN, RING_NB, RING_OUT>), dim3(1), dim3(64 * (RING_NB + 1)), 0, st,
                                (const T *)d_agc, (const T *)d_lock, GP, (const unsigned char *)ctx->gneed.p, d_sym, d_symidx, &d_sc->nsym,
-                               sym_cap, d_calm);
+                               sym_cap, d_calm, gran_scale);
             PDT_LAUNCH(256, k_calm_emit<T>, dim3((unsigned)((n_chunks + 255) / 256)), dim3(256), 0, st, (const unsigned char *)ctx->gneed.p,
                                (const CalmEntry<T> *)d_calm, GP, d_sym, d_symidx, sym_cap);
         } else if (small_need <= SMALL_LEN && small_syms < SMALL_OUT && !ctx->tune.gardner_onebuf && !seg)

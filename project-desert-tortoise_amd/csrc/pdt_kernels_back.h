@@ -541,7 +541,7 @@ template <typename T, int LEN, int NB, int OUT>
 __device__ __forceinline__ void k_gardner_ring(const T *__restrict__ in, const T *__restrict__ lock, GardnerParams<T> P,
                                                const unsigned char *__restrict__ need, T *__restrict__ sym,
                                                long long *__restrict__ symidx, unsigned long long *__restrict__ nsym_out,
-                                               long long sym_cap, CalmEntry<T> *__restrict__ calm)
+                                               long long sym_cap, CalmEntry<T> *__restrict__ calm, T gran_scale)
 {
     __shared__ __align__(16) T win[NB][LEN];
     __shared__ T o_val[OUT];
@@ -625,6 +625,8 @@ __device__ __forceinline__ void k_gardner_ring(const T *__restrict__ in, const T
     const T kp = P.kp, lim = P.lim, step = P.step;
     const T adv = step + (T)0.101;
     T ns = 0, prev = 0, half = 0;
+    T memo_in = (T)-1e30, memo_nT = 0, memo_half = 0, memo_out = 0;   // the last chunk taken in one stride: entry -> picks, exit
+    int memo_K = 0;
     long long count = 0;
     int jn = 0;                                          // walked chunks so far
     for (long long c0 = 0; c0 < n_chunks; c0 += 64) {
@@ -645,6 +647,32 @@ __device__ __forceinline__ void k_gardner_ring(const T *__restrict__ in, const T
                     e.count = count;
                     calm[c] = e;
                 }
+                // Round 5: the chunk in one stride where every one of those additions is exact.  gran_scale = 2^(p - E), p the
+                // mantissa's length and 2^E above chunk + 2 steps (the host passes 0 unless the step is a multiple of 2^(E - p)):
+                // a sampling instant that is a multiple of 2^(E - p) itself -- as it is after every roll-over from the top binade
+                // -- stays one through every + step, all of them below 2^E: ns + k step is the k-th sum bit for bit, and the
+                // number of picks is the K with rint(ns + (K - 1) step) < n <= rint(ns + K step), found from a quotient and
+                // settled with the reference's own test (GardenerClockRecovery.c:25).  (60 dependent additions a chunk, 16 clocks
+                // each, were a fifth of the ARGOS sampler's time.)
+                // ... and not at all where the last such chunk started from the same instant (a pure function of it and of the
+                // chunk's length): step 40.0 and chunks of 2 400 samples bring the instant back to where it was, gap after gap
+                const T gs = ns * gran_scale;
+                if (uniform<int>((int)(ns == memo_in && nT == memo_nT))) {
+                    nout = memo_K;
+                    if (nout > 0) { half = memo_half; ns = memo_out; }
+                } else if (uniform<int>((int)(gran_scale != (T)0 && gs == Real<T>::rint(gs) && Real<T>::abs(gs) < (T)(sizeof(T) == 8 ? 4503599627370496.0 : 8388608.0)))) {
+                    const T ns_in = ns;
+                    const T q = (nT - (T)0.5 - ns) / step;
+                    int K = uniform<int>((q > (T)0) ? (int)q : 0);
+                    while (K > 0 && !uniform<int>((int)(Real<T>::rint(ns + (T)(K - 1) * step) < nT))) K--;
+                    while (uniform<int>((int)(Real<T>::rint(ns + (T)K * step) < nT))) K++;
+                    if (K > 0) {
+                        half = (ns + (T)(K - 1) * step) + hs;
+                        ns = ns + (T)K * step;
+                        nout = K;
+                    }
+                    memo_in = ns_in; memo_nT = nT; memo_K = K; memo_half = half; memo_out = ns;
+                } else
                 for (;;) {
                     const T rn = Real<T>::rint(ns);
                     const int in_chunk = uniform<int>((int)(rn < nT));

@@ -180,6 +180,30 @@ def test_argos_all_stages(pdt, orc, golden, seed, f0, secs, chunk):
             assert [bytes(f["bytes"][:7]) for f in fr] == sent          # round trip: all 9 bursts, payload exact
 
 
+@pytest.mark.parametrize("fs,chunk", [(32000, 2400), (32000, 2401), (32000, 1999), (44100, 2400), (32001, 2400), (48000, 777), (50000, 2500)])
+def test_argos_squelched_chunks_in_one_stride(pdt, orc, fs, chunk):
+    """Chunks whose samples are all +0.0 behind Squelch need no walk: the sampler only adds its step (k_chunk_need).  Round 5:
+    where the sampling instant and the step are multiples of 2^(E - 53) below 2^E -- step 40.0 at 32 ksps, 55.125 at 44.1 ksps,
+    62.5 at 50 ksps; after every roll-over of a chunk of 2 048 samples or more -- those additions are exact and the chunk is taken
+    in one stride (k_gardner_ring); 32 001 sps has a step that is no such multiple and keeps the additions one by one, a chunk of
+    1 999 or 777 samples rolls over below the top binade and strides only once the instant has been rounded there, an odd chunk
+    length has its last pick on a tie.  Same symbols, pick indices and packets as the oracle either way, and with the stride
+    switched off."""
+    import os
+    iq = pdt.synth_capture(1, fs, 24.0, f0_hz=130.0, seed=41)
+    o = orc.Oracle(orc.ARGOS, fs, iq, chunk=chunk, math_mode=orc.MATH_LIBM)
+    for env in ({}, {"PDT_GARDNER_NOSTRIDE": "1"}):
+        os.environ.update(env)
+        try:
+            with pdt.Demodulator(pdt.MODE_ARGOS, fs, chunk=chunk) as d:
+                d.demod(iq)
+                check_all_stages(pdt, orc, d, o)
+                assert d.stats().symbols > 0
+        finally:
+            for k in env:
+                os.environ.pop(k, None)
+
+
 def test_argos_block_geometry_and_short_inputs(pdt, orc):
     iq = pdt.synth_capture(1, 32000, 8.0, f0_hz=120.0, seed=5)
     o = orc.Oracle(orc.ARGOS, 32000, iq, math_mode=orc.MATH_LIBM)
