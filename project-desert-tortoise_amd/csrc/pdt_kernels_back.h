@@ -746,7 +746,10 @@ __device__ __forceinline__ void k_gardner_ring(const T *__restrict__ in, const T
                         // store offsets.  Tried and slower: both samples of step k + 1 fetched by the 64 lanes during step k and
                         // picked with v_readlane (readfirstlane / readlane and their wait states cost more than the LDS latency
                         // they replace: 102 vs 80 ns per symbol); the clip folded into the update as a select between
-                        // nextSample - e, nextSample - lim, nextSample + lim (two f64 compares: 96 ns).
+                        // nextSample - e, nextSample - lim, nextSample + lim (two f64 compares: 96 ns); round 5: the three
+                        // candidates of the next pick and of the next mid-point (the clipped error moves either by less than one
+                        // sample) read a step ahead and picked with two compares each -- the compiler issues the reads next to
+                        // their use, and even issued early the compare / select pairs cost what the LDS read did: 133 ns.
                         auto one = [&](int kk) {
                             const int ic = rint_index(ns), ih = rint_index(half);
                             const T c_k = w[ic], m_k = w[ih];
