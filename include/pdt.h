@@ -264,7 +264,7 @@ int  pdt_demod_pcm16(pdt_ctx *ctx, const int16_t *iq_host, uint64_t nframes);
  * threads into pinned memory and copies them to the GPU while the next spans are being read, so a capture is in HBM about
  * as soon as the page cache and the PCIe link allow.  PDT_ERR_FORMAT when the file ends early, PDT_ERR_IO on a read error
  * (EINTR is retried).
- * Large POES captures (512 MiB and more, Gardner sampler): the chain starts before the last span has
+ * Large POES captures (2.5 GiB and more -- below that the segments' latency floors cost more than the overlap hides --, Gardner sampler): the chain starts before the last span has
  * arrived and runs in three unequal segments with carried state (the streaming path over the resident capture; 55 / 28 /
  * 17 % of the capture, cut where a segment can use the whole-capture kernels, so that only the last, small one is left to run
  * when the last byte has arrived).  Frames, text and pdt_get_stats' counts then describe the whole capture as ever; but

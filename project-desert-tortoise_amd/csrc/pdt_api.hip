@@ -2820,9 +2820,11 @@ static bool overlap_ingest(const pdt_ctx *ctx, uint64_t nframes, size_t fb)
 {
     // Round 5: on by default (PDT_NO_OVERLAP switches it off) -- the segments are cut where they can take the whole-capture
     // kernels and keep the per-chunk reports (demod_overlapped); 3.6 GB file to frame file 82-91 ms against 89-94 ms with the
-    // capture ingested first (profiles/r5).
+    // capture ingested first (profiles/r5).  From 2.5 GiB on: every segment pays the block-parallel stages' latency floors again
+    // (~7 ms), hidden only while the next segment's samples take longer than that to arrive -- 0.6 GB: 30.8 ms overlapped
+    // against 21.3 ms, 1.2 GB: 40.7 / 37.3, 2.4 GB: 63.5 / 63.5, 3.0 GB: 75.2 / 76.5 (profiles/r5/e2e_ab_overlap_by_size.txt).
     return ctx->tune.overlap && ctx->cfg.mode == PDT_MODE_POES && ctx->cfg.sampler != PDT_SAMPLER_MM && ctx->cfg.chain != PDT_CHAIN_LIVE &&
-           (size_t)nframes * fb >= ((size_t)(ctx->tune.overlap_min_mb > 0 ? ctx->tune.overlap_min_mb : 512) << 20) && ctx->cfg.chunk > 0 &&
+           (size_t)nframes * fb >= ((size_t)(ctx->tune.overlap_min_mb > 0 ? ctx->tune.overlap_min_mb : 2560) << 20) && ctx->cfg.chunk > 0 &&
            nframes / ctx->cfg.chunk >= 64;
 }
 
