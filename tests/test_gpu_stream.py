@@ -386,6 +386,49 @@ def test_overlapped_segments_keep_the_chunk_reports(pdt, tmp_path, lead_noise):
             assert st0.lock_sample >= lead_noise and calls[0][2] == (-1 if name == "split" else st0.lock_sample)
 
 
+@pytest.mark.timeout(300)
+@pytest.mark.parametrize("mode", ["plain", "overlapped"])
+def test_file_entry_errors_leave_the_context_usable(pdt, tmp_path, mode):
+    """A capture file that ends before the claimed number of frames (PDT_ERR_FORMAT: the reader threads, the submitter, the
+    segments that have already run and the marks the later ones wait on all have to wind down), and a text descriptor that
+    cannot be written (PDT_ERR_IO) -- ingested first and in overlapped segments; the same context then demodulates the file
+    properly, with the same text as a fresh one."""
+    import os
+    fs = 250000
+    iq = pdt.synth_capture(0, fs, 75.0, seed=75)
+    wav = str(tmp_path / "cap.wav")
+    pdt.write_wav(wav, fs, iq)
+    with pdt.Demodulator(pdt.MODE_POES, fs) as ref:
+        ref.demod(iq)
+        want = ref.text()
+    assert len(want) > 1000
+
+    def run():
+        with pdt.Demodulator(pdt.MODE_POES, fs).keep_pll(False) as d:
+            fd = os.open(wav, os.O_RDONLY)
+            outp = str(tmp_path / f"{mode}.txt")
+            fo = os.open(outp, os.O_RDWR | os.O_CREAT | os.O_TRUNC, 0o644)
+            ro = os.open(outp, os.O_RDONLY)
+            try:
+                for claimed in (len(iq) + 5_000_000, len(iq) + 1, 4 * len(iq)):
+                    with pytest.raises(pdt.PdtError, match="WAV|format|ends"):
+                        d.demod_file_text(fd, 44, claimed, fo, 0)
+                with pytest.raises(pdt.PdtError):
+                    d.demod_file_text(fd, 44, len(iq), ro, 0)                   # text cannot be written
+                os.ftruncate(fo, 0)
+                os.lseek(fo, 0, os.SEEK_SET)
+                nb = d.demod_file_text(fd, 44, len(iq), fo, 0)
+                assert open(outp, "rb").read() == want and nb == len(want) and d.text() == want
+                d.demod(iq)                                                     # and the other entries work as ever
+                assert d.text() == want
+            finally:
+                os.close(fd)
+                os.close(fo)
+                os.close(ro)
+
+    _with_env({"PDT_OVERLAP_MIN_MB": "1"} if mode == "overlapped" else {"PDT_NO_OVERLAP": "1"}, run)
+
+
 def test_stage_and_whole_capture_entries_are_refused_while_a_stream_is_open(pdt, clip):
     """The stage buffers hold the tails an open stream continues from: every pdt_stage_* / pdt_demod_* entry
     returns PDT_ERR_STATE between the first push and pdt_stream_end, and the stream is not disturbed by the attempt."""
