@@ -40,3 +40,6 @@ def test_configs2_full_size_against_the_reference_objects():
     r = subprocess.run([sys.executable, os.path.join(HERE, "tools", "c3_check.py")], capture_output=True, text=True, env=env)
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
     assert "output identical: True" in r.stdout
+    # ... and the file entries on the same capture: ingested first and in three overlapped segments (the default at this size),
+    # same text, the per-chunk reports of the segments bit for bit those of the whole-capture run, handed on in order
+    assert "file entries: text identical: True; per-chunk reports identical: True (3 segment(s)" in r.stdout

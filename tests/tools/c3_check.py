@@ -28,6 +28,38 @@ with tempfile.TemporaryDirectory(dir=shm, prefix="pdt_c3_") as tmp:
     print(f"gpu: {s.frames} frames, gpu_ms {s.gpu_ms:.2f} ({n / s.gpu_ms / 1e3:.0f} Msamples/s), pll fixes {s.pll_seam_fixes}, "
           f"agc fixes {s.agc_seam_fixes}, walked {s.gardner_walked}, parallel {s.gardner_parallel}, cand {s.gardner_candidates}")
     print("  " + " ".join(f"{k} {v[1]:.2f}" for k, v in kt.items()), flush=True)
+    if wav:
+        # the FILE entries on the same capture at full size, while the CPU run goes on: ingested first, and the default -- three
+        # overlapped segments at the production geometry -- with the per-chunk reports handed on segment by segment
+        import numpy as np
+        res = {}
+        for name, env in (("plain", {"PDT_NO_OVERLAP": "1"}), ("default", {})):
+            os.environ.update(env)
+            try:
+                calls = []
+                with pdt.Demodulator(pdt.MODE_POES, rate).keep_pll(False) as f:
+                    f.keep_quality().set_progress(lambda first, rep, st: calls.append((first, rep)))
+                    fd = os.open(wav, os.O_RDONLY)
+                    fo = os.open(os.path.join(tmp, name + ".txt"), os.O_RDWR | os.O_CREAT | os.O_TRUNC, 0o644)
+                    t1 = time.time()
+                    f.demod_file_text(fd, 44, n, fo, 0)
+                    ms = (time.time() - t1) * 1e3
+                    os.close(fd); os.close(fo)
+                    res[name] = (open(os.path.join(tmp, name + ".txt"), "rb").read(), f.chunk_reports(), calls, ms)
+            finally:
+                for k in env:
+                    os.environ.pop(k, None)
+        t_plain, r_plain, c_plain, ms_plain = res["plain"]
+        t_def, r_def, c_def, ms_def = res["default"]
+        files_same = t_plain == d.text() and t_def == d.text()
+        big = n * 4 >= (2560 << 20)
+        reports_same = len(r_plain) == (n + 9999) // 10000 and r_def.tobytes() == r_plain.tobytes() and len(c_plain) == 1 and \
+            len(c_def) == (3 if big else 1) and np.concatenate([c[1] for c in c_def]).tobytes() == r_plain.tobytes() and \
+            [c[0] for c in c_def] == list(np.cumsum([0] + [len(c[1]) for c in c_def[:-1]]))
+        print(f"file entries: text identical: {files_same}; per-chunk reports identical: {reports_same} ({len(c_def)} segment(s); "
+              f"{ms_plain:.0f} ms ingested first, {ms_def:.0f} ms default, reports on)", flush=True)
+        if not (files_same and reports_same):
+            sys.exit(1)
     if cpu:
         cpu.communicate()
         dt = time.time() - t_cpu
