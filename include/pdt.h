@@ -60,14 +60,19 @@
 extern "C" {
 #endif
 
-/* 3 (round 5): + pdt_demod_file (capture file in, frame text out, in one call); pdt_demod_fd / pdt_demod_file demodulate a
+/* 4 (round 6): a capture that does not fit the device's free memory is demodulated through a bounded window (the streaming
+ * path, fed from the file or the caller's memory piece by piece) instead of failing with PDT_ERR_NOMEM -- the reference's chunk
+ * loop needs O(chunk) memory whatever the file's length (POESTIPdemod/main.c:373); pdt_stats.segments / .windowed say how a
+ * capture was taken; pdt_loop_params.zero_mask; a context whose caller asked for the PLL stream (pdt_keep_pll(ctx, 1)) is
+ * never demodulated in overlapped segments.
+ * 3 (round 5): + pdt_demod_file (capture file in, frame text out, in one call); pdt_demod_fd / pdt_demod_file demodulate a
  * large POES file in segments while it is still being read BY DEFAULT again (round 4: only on request), after which
  * pdt_read_stage / pdt_stage_len describe the last segment only.
  * 2 (round 4): + pdt_write_frames / pdt_write_records.  Behaviour a client of version 1 should know about, all of it
  * introduced under version 1 in round 3 without a bump: pdt_build_tag, pdt_keep_pll, pdt_stage_bytesync_from and the error
  * code PDT_ERR_IO exist; every pdt_demod_* and pdt_stage_* entry returns PDT_ERR_STATE while a stream is open, and the first
  * pdt_stream_push_* opens one by itself (resetting frames and statistics).                                              */
-#define PDT_ABI_VERSION 3
+#define PDT_ABI_VERSION 4
 
 enum { PDT_MODE_POES = 0, PDT_MODE_ARGOS = 1 };
 enum { PDT_SAMPLER_GARDNER = 0, PDT_SAMPLER_MM = 1 };
@@ -162,6 +167,11 @@ typedef struct pdt_stats {
                                      for the copy to HBM (pdt_demod_fd / _file / _pcm16 / _f32; 0: input was resident)     */
     double   alloc_ms;            /* (ABI 3) host time this PROCESS has spent in device / pinned allocations so far (the cold
                                      path's breakdown: a context's first capture of a size pays for its buffers)          */
+    uint32_t segments;            /* (ABI 4) pieces the last capture was demodulated in: 1 = one piece; more (the overlapped
+                                     ingest of a large file, the bounded window): pdt_read_stage / pdt_stage_len, the seam
+                                     counters and pdt_kernel_times describe the LAST piece only                            */
+    uint32_t windowed;            /* (ABI 4) 1 = the capture did not fit the device's free memory and went through the
+                                     bounded window (same frames, text, counts and per-chunk reports)                      */
 } pdt_stats;
 
 typedef struct pdt_kernel_time {
@@ -204,7 +214,12 @@ typedef struct pdt_loop_params {
     double gardner_step_range;     /* clip of the timing error, at most 0.1                           0.1               */
     double gardner_kp;             /* timing loop gain                                                3.0               */
     double manchester_threshold;   /* resyncThreshold                                                 1.0 (twin 0.75) / 0.5 */
+    uint32_t zero_mask;            /* (ABI 4) PDT_LP_ZERO_* bits: the field IS zero (not "keep the default") -- a lock threshold of 0
+                                      (lock on the first positive detector value), a timing gain or clip of 0 (open-loop
+                                      sampler), a resync threshold of 0.  The other constants must be positive to mean anything */
+    uint32_t reserved_;
 } pdt_loop_params;
+enum { PDT_LP_ZERO_LOCK_THRESHOLD = 1, PDT_LP_ZERO_GARDNER_KP = 2, PDT_LP_ZERO_GARDNER_STEP_RANGE = 4, PDT_LP_ZERO_MANCHESTER_THRESHOLD = 8 };
 int  pdt_set_loop_params(pdt_ctx *ctx, const pdt_loop_params *params);
 int  pdt_get_device(const pdt_ctx *ctx);          /* the HIP device ordinal the context lives on */
 void pdt_close(pdt_ctx *ctx);
@@ -269,7 +284,12 @@ int  pdt_demod_pcm16(pdt_ctx *ctx, const int16_t *iq_host, uint64_t nframes);
  * 17 % of the capture, cut where a segment can use the whole-capture kernels, so that only the last, small one is left to run
  * when the last byte has arrived).  Frames, text and pdt_get_stats' counts then describe the whole capture as ever; but
  * pdt_read_stage / pdt_stage_len describe the LAST SEGMENT only (window-local indices), the pll / agc seam counters and
- * gpu_ms are the last segment's, and no stream is left open behind the call.                                          */
+ * gpu_ms are the last segment's, and no stream is left open behind the call (pdt_stats.segments says so; a context
+ * whose caller switched the PLL stream on, pdt_keep_pll(ctx, 1), is demodulated in one piece).
+ * A capture that does not fit (ABI 4): when the buffers of a whole capture -- about 8 x the file for POES at 250 ksps --
+ * exceed the device's free memory, the capture goes through a bounded window instead (pieces of the file pushed through the
+ * streaming path with carried state: same frames, text, counts and reports; pdt_stats.windowed = 1).  The reference's loop
+ * takes a file of any length (POESTIPdemod/main.c:373, while(!feof)); so do pdt_demod_fd / _file / _pcm16 / _f32.            */
 int  pdt_demod_fd(pdt_ctx *ctx, int fd, uint64_t byte_offset, uint64_t nframes, int sample_format);
 /* The whole job of POESTIPdemod/main.c:373-492 / ARGOSdemod/main.c:250-306 in one call: capture file in (as pdt_demod_fd), the
  * minor-frame / packet text out to the descriptor text_fd, from its position on -- the reference's ByteSync.c:62-101 writes

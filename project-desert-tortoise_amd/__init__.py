@@ -59,7 +59,8 @@ class Config(C.Structure):
 
 class LoopParams(C.Structure):
     _fields_ = [(n, C.c_double) for n in ("pll_freq_range_hz", "pll_lock_threshold", "pll_lock_alpha", "pll_loopbw_acq", "pll_loopbw_track",
-                                          "agc_attack", "agc_decay", "gardner_baud", "gardner_step_range", "gardner_kp", "manchester_threshold")]
+                                          "agc_attack", "agc_decay", "gardner_baud", "gardner_step_range", "gardner_kp", "manchester_threshold")] \
+               + [("zero_mask", C.c_uint32), ("reserved_", C.c_uint32)]
 
 
 class Frame(C.Structure):
@@ -100,6 +101,8 @@ class Stats(C.Structure):
         ("gardner_candidates", C.c_uint64),
         ("ingest_ms", C.c_double),
         ("alloc_ms", C.c_double),
+        ("segments", C.c_uint32),
+        ("windowed", C.c_uint32),
     ]
 
 
@@ -283,7 +286,7 @@ def lib():
     L.pdt_dev_set.argtypes = [C.c_char_p, C.c_char_p]
     L.pdt_set_loop_params.argtypes = [C.c_void_p, C.POINTER(LoopParams)]
     L.pdt_demod_file.argtypes = [C.c_void_p, C.c_int, C.c_uint64, C.c_uint64, C.c_int, C.c_int, C.POINTER(C.c_uint64)]
-    if L.pdt_abi_version() != 3:
+    if L.pdt_abi_version() != 4:
         raise PdtError("libpdt.so ABI version mismatch")
     _lib = L
     return L
@@ -387,6 +390,10 @@ class Demodulator:
     def set_loop_params(self, **kw):
         """``pdt_set_loop_params``: loop constants other than the mains' (fields of ``LoopParams``; 0 / absent = default)."""
         lp = LoopParams(**kw)
+        # a constant given as 0 where 0 is a meaningful value (lock threshold, timing gain / clip, resync threshold) IS zero
+        zero_bits = {"pll_lock_threshold": 1, "gardner_kp": 2, "gardner_step_range": 4, "manchester_threshold": 8}
+        if "zero_mask" not in kw:
+            lp.zero_mask = sum(b for k, b in zero_bits.items() if k in kw and kw[k] == 0)
         _check(self._L.pdt_set_loop_params(self._h, C.byref(lp)), "pdt_set_loop_params")
         return self
 
@@ -589,6 +596,9 @@ class Demodulator:
         _check(self._L.pdt_write_frames(self._h, int(fd), C.byref(nb)), "pdt_write_frames")
         return int(nb.value)
 
+    def stage_len(self, st: int) -> int:
+        return int(self._L.pdt_stage_len(self._h, st))
+
     def stage(self, st: int, first: int = 0, count: int | None = None) -> np.ndarray:
         total = self._L.pdt_stage_len(self._h, st)
         if count is None:
@@ -697,7 +707,8 @@ class SynthParams(C.Structure):
     _fields_ = [
         ("kind", C.c_uint32), ("sample_rate", C.c_uint32), ("carrier_step", C.c_uint32), ("phase0", C.c_uint32),
         ("mod_index", C.c_uint32), ("amplitude", C.c_int32), ("noise_gain", C.c_int32), ("seed", C.c_uint64),
-        ("signal_start", C.c_uint64),
+        ("signal_start", C.c_uint64), ("signal_end", C.c_uint64), ("doppler_q32", C.c_int64), ("env_floor_q15", C.c_uint32),
+        ("pad_", C.c_uint32),
     ]
 
 
@@ -712,6 +723,8 @@ def synth_lib():
         S = C.CDLL(LIBSYNTH_PATH)
         S.pdt_synth_default_params.argtypes = [C.POINTER(SynthParams), C.c_int, C.c_uint32, C.c_double, C.c_uint64]
         S.pdt_synth_default_params.restype = None
+        S.pdt_synth_set_pass.argtypes = [C.POINTER(SynthParams), C.c_uint64, C.c_uint64, C.c_double, C.c_double, C.c_double]
+        S.pdt_synth_set_pass.restype = None
         S.pdt_synth_fill.argtypes = [C.POINTER(SynthParams), C.c_uint64, C.c_uint64, C.c_void_p]
         S.pdt_synth_fill.restype = None
         S.pdt_synth_poes_frame.argtypes = [C.POINTER(SynthParams), C.c_uint64, C.c_void_p]

@@ -269,6 +269,7 @@ static std::map<std::string, std::string> g_dev;
 struct Tuning {
     double band_pad = 0.0, pll_warm_scale = 1.0, head_taus = 0.0, agc_k = 0.0, pll_warm_s = 0.0, agc_warm_s = 0.0;
     double overlap_split[8] = { 0, 0, 0, 0, 0, 0, 0, 0 };
+    long long hbm_limit_mb = 0, window_piece = 0;
     int scout_syms = 0, gspan = 0, gspan_cap = 0, ingest_threads = 0, ingest_span_mb = 0, ingest_streams = 0, overlap_segments = 0, overlap_min_mb = 0, fir_wg_per_cu = 0, agc_tpb = 0, gseg = 0, pll_block = 0, fix_passes = 2;
     bool fir_generic = false, mix_unfused = false, quality_inline = false, gemit_groups = false, agc_unfused = false, no_excl = false, gardner_onebuf = false, gardner_noring = false, gardner_sequential = false, seg_sequential = false, agc_lanes = false, overlap = true, debug_overlap = false, chain_one_range = false, ema_noguess = false, debug_sync = false, pll_noshort = false, pll_nockpt = false, pll_noconsensus = false, seg_plain = false, sync_block = false, gardner_nostride = false;
     void load()
@@ -284,6 +285,8 @@ struct Tuning {
         if (const char *e = get("PDT_AGC_K")) agc_k = atof(e);
         if (const char *e = get("PDT_AGC_TPB")) agc_tpb = std::max(1, atoi(e));
         if (const char *e = get("PDT_PLL_BLOCK")) pll_block = atoi(e);
+        if (const char *e = get("PDT_HBM_LIMIT_MB")) hbm_limit_mb = std::max(1ll, atoll(e));        // (tests: pretend the device has this much free memory)
+        if (const char *e = get("PDT_WINDOW_PIECE")) window_piece = std::max(1ll, atoll(e));          // (tests: samples per piece of the bounded window)
         if (const char *e = get("PDT_SCOUT_SYMS")) scout_syms = std::max(16, atoi(e));
         if (const char *e = get("PDT_FIR_WG_PER_CU")) fir_wg_per_cu = std::min(4096, std::max(1, atoi(e)));
         if (const char *e = get("PDT_INGEST_THREADS")) ingest_threads = std::min(128, std::max(1, atoi(e)));
@@ -385,6 +388,7 @@ struct pdt_ctx {
     bool keep_agc_raw = false;   // pdt_keep_presquelch: also keep the AGC output before Squelch (stage PDT_ST_AGC_RAW)
     // pdt_keep_quality: the averagePhase stream (what CarrierTrackPLL returns, chunk by chunk) and the per-chunk counts
     bool keep_quality = false;
+    bool keep_pll_asked = false; // pdt_keep_pll(ctx, 1) was called: the caller reads the PLL stream -- one piece, no overlapped segments
     bool keep_pll = true;        // pdt_keep_pll: the PLL output stream (stage PDT_ST_PLL) is written out although only the filter reads it
     DevBuf avgph, term_ap, seams_q, chunkinfo;
     // pdt_stage_pll: the next run starts the PLL from this state, keeps the lock and averagePhase streams and stops after the PLL
@@ -641,7 +645,7 @@ template <typename T> PllParams<T> make_pll_params(const pdt_ctx *ctx)
     const T bw_acq = lp.pll_loopbw_acq != 0 ? (T)lp.pll_loopbw_acq : (T)((argos ? 16.0 : live ? 198.9437 : 127.3240) * w);
     const T bw_trk = lp.pll_loopbw_track != 0 ? (T)lp.pll_loopbw_track : (T)((argos ? 16.0 : 10.3451) * w);
     P.Fs = Fs;
-    P.lock_thr = lp.pll_lock_threshold != 0 ? (T)lp.pll_lock_threshold : argos ? (T)0.1 : live ? (T)0.10 : (T)0.08;
+    P.lock_thr = (lp.pll_lock_threshold != 0 || (lp.zero_mask & PDT_LP_ZERO_LOCK_THRESHOLD)) ? (T)lp.pll_lock_threshold : argos ? (T)0.1 : live ? (T)0.10 : (T)0.08;
     P.lock_alpha = lp.pll_lock_alpha != 0 ? (T)lp.pll_lock_alpha : (T)((argos ? 3.1831 : 0.3979) * w);
     const T damp = (T)0.999;
     const T four = 4, one = 1, two = 2;
@@ -1036,6 +1040,7 @@ template <typename T> int finish_capture(pdt_ctx *ctx, uint64_t n, const FinishA
     S.gardner_full_domain = tabled ? sc.gstats[1] : 0u;
     S.gardner_candidates = tabled ? sc.gstats[3] : 0u;
     S.sync_overflow = sc.sync_overflow;
+    S.segments = 1;
 
     ctx->stage_len[PDT_ST_PLL] = (fuse_mix && !ctx->keep_pll) ? 0 : n;       // (k_mix_fir: the stream exists on request only)
     ctx->stage_len[PDT_ST_LOCK] = need_lock ? n : 0;
@@ -1128,8 +1133,8 @@ template <typename T> int run_capture(pdt_ctx *ctx, uint64_t n, int phase = RUN_
     GardnerParams<T> GP;
     const T baud = ctx->lp.gardner_baud != 0 ? (T)ctx->lp.gardner_baud : argos ? (T)(400 * 2.0) : (T)(8320 * 2 + 0.3);   // main.c:90 / ARGOS main.c:64
     GP.step = (T)(int)fsi / baud;                                              // GardenerClockRecovery.c:19
-    GP.kp = ctx->lp.gardner_kp != 0 ? (T)ctx->lp.gardner_kp : (T)3.0;
-    GP.lim = ctx->lp.gardner_step_range != 0 ? (T)ctx->lp.gardner_step_range : (T)0.1;
+    GP.kp = (ctx->lp.gardner_kp != 0 || (ctx->lp.zero_mask & PDT_LP_ZERO_GARDNER_KP)) ? (T)ctx->lp.gardner_kp : (T)3.0;
+    GP.lim = (ctx->lp.gardner_step_range != 0 || (ctx->lp.zero_mask & PDT_LP_ZERO_GARDNER_STEP_RANGE)) ? (T)ctx->lp.gardner_step_range : (T)0.1;
     GP.n_total = n_out;
     GP.chunk_out = chunk_out;
     GP.argos_heap = 0;
@@ -1144,7 +1149,7 @@ template <typename T> int run_capture(pdt_ctx *ctx, uint64_t n, int phase = RUN_
         GP.argos_even = (int)((csz - 8 - req) / sizeof(T));
     }
     const bool argos_twin = argos && ctx->cfg.chain == PDT_CHAIN_LIVE;
-    const T manch_thr = ctx->lp.manchester_threshold != 0 ? (T)ctx->lp.manchester_threshold : argos ? (T)0.5 : live ? (T)0.75 : (T)1.0;              // main.c:445 / ARGOS main.c:282 / twin :65,393
+    const T manch_thr = (ctx->lp.manchester_threshold != 0 || (ctx->lp.zero_mask & PDT_LP_ZERO_MANCHESTER_THRESHOLD)) ? (T)ctx->lp.manchester_threshold : argos ? (T)0.5 : live ? (T)0.75 : (T)1.0;              // main.c:445 / ARGOS main.c:282 / twin :65,393
     const SyncParams SP = make_sync_params(argos, argos_twin);
 
     // ---- block-parallel geometry (any values give the same output; they only move time around)
@@ -1689,7 +1694,7 @@ template <typename T> int run_capture(pdt_ctx *ctx, uint64_t n, int phase = RUN_
         PDT_LAUNCH(PDT_FIR_THREADS, (k_fir_interp_rt<T, I, 26>), dim3(grid_rt), dim3(PDT_FIR_THREADS), sh_rt, st, d_pll, N, (const T *)ctx->taps_rot.p, d_fir, \
                            fir_tile_maps, AP.decay);                                                                                    \
         break;
-                    PDT_FIR_CASE(1) PDT_FIR_CASE(2) PDT_FIR_CASE(3) PDT_FIR_CASE(4) PDT_FIR_CASE(5) PDT_FIR_CASE(6)
+                    PDT_FIR_CASE(1) PDT_FIR_CASE(2) PDT_FIR_CASE(3) PDT_FIR_CASE(4) PDT_FIR_CASE(5) PDT_FIR_CASE(6) PDT_FIR_CASE(7) PDT_FIR_CASE(8)
 #undef PDT_FIR_CASE
                 default: done = false;
                 }
@@ -2412,13 +2417,17 @@ int ingest_capture(pdt_ctx *ctx, const IngestSrc &src, size_t bytes, void *dst, 
         // (the caller's stream waits for them, and the call does not return before that stream is idle)
         if (background) retire(true);
     };
+    bool spawn_failed = false;
     try {
         for (int t = 0; t < T; t++) J->pool.emplace_back(reader, t);
         if (job) J->pool.emplace_back(submitter);
     } catch (const std::exception &) {
         failed = 1;
+        spawn_failed = true;
     }
-    if (job) return failed ? PDT_ERR_NOMEM : PDT_OK;                   // (the caller joins: ingest_join)
+    // (background form: the readers are already running and may have set `failed` -- a short file, a read error: those codes
+    // come through ingest_wait_mark / ingest_join, always; only a thread that could not be started is reported here)
+    if (job) return spawn_failed ? PDT_ERR_NOMEM : PDT_OK;             // (the caller joins: ingest_join)
     if (!failed) submitter();
     for (auto &th : J->pool) th.join();
     J->pool.clear();
@@ -2739,6 +2748,11 @@ int pdt_set_loop_params(pdt_ctx *ctx, const pdt_loop_params *p)
     if (p->gardner_baud != 0 && (double)ctx->cfg.sample_rate * (double)ctx->interp / p->gardner_baud < 2.0) return PDT_ERR_ARG;
     if (p->pll_freq_range_hz != 0 && p->pll_freq_range_hz >= 0.5 * (double)ctx->cfg.sample_rate) return PDT_ERR_ARG;
     if ((float)p->gardner_step_range > 0.1f) return PDT_ERR_ARG;      // (the samplers' window margins and symbol capacities are sized for the mains' 0.1)
+    if (p->zero_mask & ~(uint32_t)(PDT_LP_ZERO_LOCK_THRESHOLD | PDT_LP_ZERO_GARDNER_KP | PDT_LP_ZERO_GARDNER_STEP_RANGE | PDT_LP_ZERO_MANCHESTER_THRESHOLD))
+        return PDT_ERR_ARG;
+    // a baud rate whose step would not fit the sequential samplers' LDS windows (a symbol and its mid-point must lie inside
+    // one; the casts of the step to integers further down stay in range with it): at most 4 096 samples per symbol
+    if (p->gardner_baud != 0 && !((double)ctx->cfg.sample_rate * (double)ctx->interp / p->gardner_baud <= 4096.0)) return PDT_ERR_ARG;
     ctx->lp = *p;
     ctx->gcand_key = -1;                    // (the sampler's candidate list depends on the step)
     return PDT_OK;
@@ -2774,6 +2788,7 @@ int pdt_keep_pll(pdt_ctx *ctx, int enable)
 {
     if (!ctx) return PDT_ERR_ARG;
     ctx->keep_pll = enable != 0;
+    ctx->keep_pll_asked = enable != 0;
     return PDT_OK;
 }
 
@@ -2795,15 +2810,53 @@ static int demod_common(pdt_ctx *ctx, uint64_t nframes, int phase = RUN_ALL)
     return run_capture<float>(ctx, nframes, phase);                 // POES, both twins
 }
 
+static int demod_overlapped(pdt_ctx *ctx, const IngestSrc &src, uint64_t nframes, int fmt, int text_fd, uint64_t *text_bytes);
+static int demod_windowed(pdt_ctx *ctx, const IngestSrc &src, uint64_t nframes, int fmt, int text_fd, uint64_t *text_bytes, uint64_t piece);
+static uint64_t stream_history(const pdt_ctx *ctx);
+
+// Does a capture of nframes fit the device in one piece?  The reference's chunk loop takes a file of any length in O(chunk)
+// memory (POESTIPdemod/main.c:373, while(!feof)); the one-piece path here keeps every stage's stream of the whole capture
+// resident -- about 8 x the file for POES at 250 ksps.  Returns 0 when that fits what the device has free (plus
+// what this context already holds), otherwise the number of samples per piece of the bounded window (demod_windowed), or a
+// negative error code when not even a window of a few chunks fits.
+static long long window_piece_for(pdt_ctx *ctx, uint64_t nframes, size_t fb)
+{
+    const bool need_lock = ctx->cfg.mode == PDT_MODE_ARGOS || ctx->cfg.chain == PDT_CHAIN_LIVE;
+    const double es = (double)ctx->elem, ip = (double)ctx->interp;
+    // bytes per input sample: input, PLL output, theta / phases (their own buffers when the capture is taken in segments), filter
+    // and AGC output, lock signal + its input term, the quality EMA's two streams, symbols / bits / tables (a few per cent)
+    const double per = (double)fb + es * (3.0 + 2.5 * ip) + 8.0 + (need_lock ? 2.0 * es : 0.0) + (ctx->keep_quality ? 2.0 * es : 0.0) +
+                       (ctx->keep_agc_raw ? es * ip : 0.0);
+    size_t free_b = 0, total_b = 0;
+    if (hipMemGetInfo(&free_b, &total_b) != hipSuccess) { (void)hipGetLastError(); return 0; }
+    // what the context already holds is its to re-use
+    const DevBuf *held[] = { &ctx->pcm, &ctx->pll, &ctx->lock, &ctx->fir, &ctx->agc, &ctx->term, &ctx->stream_in, &ctx->lt_theta, &ctx->lt_phi,
+                             &ctx->avgph, &ctx->term_ap, &ctx->agc_raw, &ctx->gtable, &ctx->sym, &ctx->symidx };
+    double avail = (double)free_b;
+    for (const DevBuf *b : held) avail += (double)b->cap;
+    if (ctx->tune.hbm_limit_mb > 0) avail = (double)ctx->tune.hbm_limit_mb * 1048576.0;
+    const double need = per * (double)nframes + 256.0 * 1048576.0;
+    if (need <= 0.92 * avail && !ctx->tune.window_piece) return 0;
+    // the window: its history (PLL warm-ups) + one piece, with the growth margins of the stream's buffers
+    const double per_win = 1.3 * per + 2.0 * es;
+    const uint64_t chunk = ctx->cfg.chunk, hist = stream_history(ctx) + 2 * chunk;
+    double piece = 0.5 * avail / per_win - (double)hist;
+    piece = std::min(piece, 64.0 * 1048576.0);                        // (a piece is a few ms of GPU time: no need for more)
+    if (ctx->tune.window_piece) piece = (double)ctx->tune.window_piece;
+    if (!(piece >= 16.0 * (double)chunk)) return PDT_ERR_NOMEM;
+    return (long long)((uint64_t)piece / chunk * chunk);
+}
+
 int pdt_demod_pcm16(pdt_ctx *ctx, const int16_t *iq_host, uint64_t nframes)
 {
     if (!ctx || (!iq_host && nframes)) return PDT_ERR_ARG;
     if (ctx->stream_open) return PDT_ERR_STATE;                      // pdt_stream_end / pdt_stream_begin first
     HIP_TRY(hipSetDevice(ctx->cfg.device));
-    int rc = ctx->pcm.ensure((size_t)nframes * 4 + 16);
-    if (rc) return rc;
     IngestSrc src;
     src.mem = (const unsigned char *)iq_host;
+    if (const long long piece = window_piece_for(ctx, nframes, 4)) return piece < 0 ? (int)piece : demod_windowed(ctx, src, nframes, 0, -1, nullptr, (uint64_t)piece);
+    int rc = ctx->pcm.ensure((size_t)nframes * 4 + 16);
+    if (rc) return rc;
     const auto t_in = std::chrono::steady_clock::now();
     if ((rc = ingest_capture(ctx, src, (size_t)nframes * 4, ctx->pcm.p))) return rc;
     ctx->ingest_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_in).count();
@@ -2814,7 +2867,6 @@ int pdt_demod_pcm16(pdt_ctx *ctx, const int16_t *iq_host, uint64_t nframes)
     return rc;
 }
 
-static int demod_overlapped(pdt_ctx *ctx, const IngestSrc &src, uint64_t nframes, int fmt, int text_fd, uint64_t *text_bytes);
 // hour-long POES captures: the chain starts on the part of the capture that has arrived (demod_overlapped)
 static bool overlap_ingest(const pdt_ctx *ctx, uint64_t nframes, size_t fb)
 {
@@ -2823,6 +2875,7 @@ static bool overlap_ingest(const pdt_ctx *ctx, uint64_t nframes, size_t fb)
     // capture ingested first (profiles/r5).  From 2.5 GiB on: every segment pays the block-parallel stages' latency floors again
     // (~7 ms), hidden only while the next segment's samples take longer than that to arrive -- 0.6 GB: 30.8 ms overlapped
     // against 21.3 ms, 1.2 GB: 40.7 / 37.3, 2.4 GB: 63.5 / 63.5, 3.0 GB: 75.2 / 76.5 (profiles/r5/e2e_ab_overlap_by_size.txt).
+    if (ctx->keep_pll_asked) return false;           // the caller asked for the stage arrays of the whole capture
     return ctx->tune.overlap && ctx->cfg.mode == PDT_MODE_POES && ctx->cfg.sampler != PDT_SAMPLER_MM && ctx->cfg.chain != PDT_CHAIN_LIVE &&
            (size_t)nframes * fb >= ((size_t)(ctx->tune.overlap_min_mb > 0 ? ctx->tune.overlap_min_mb : 2560) << 20) && ctx->cfg.chunk > 0 &&
            nframes / ctx->cfg.chunk >= 64;
@@ -2838,6 +2891,8 @@ int pdt_demod_fd(pdt_ctx *ctx, int fd, uint64_t byte_offset, uint64_t nframes, i
     src.fd = fd;
     src.off = byte_offset;
     if (ctx->stream_open) return PDT_ERR_STATE;
+    if (const long long piece = window_piece_for(ctx, nframes, fb))
+        return piece < 0 ? (int)piece : demod_windowed(ctx, src, nframes, sample_format == PDT_FMT_F32 ? 1 : 0, -1, nullptr, (uint64_t)piece);
     if (overlap_ingest(ctx, nframes, fb)) return demod_overlapped(ctx, src, nframes, sample_format == PDT_FMT_F32 ? 1 : 0, -1, nullptr);
     int rc = ctx->pcm.ensure((size_t)nframes * fb + 16);
     if (rc) return rc;
@@ -2866,10 +2921,11 @@ int pdt_demod_f32(pdt_ctx *ctx, const float *iq_host, uint64_t nframes)
     if (ctx->stream_open) return PDT_ERR_STATE;                      // pdt_stream_end / pdt_stream_begin first
     if (ctx->elem != 4) return PDT_ERR_FORMAT;       // ARGOSdemod/main.c:238-241: "RAW files not yet supported"
     HIP_TRY(hipSetDevice(ctx->cfg.device));
-    int rc = ctx->pcm.ensure((size_t)nframes * 8 + 16);
-    if (rc) return rc;
     IngestSrc src;
     src.mem = (const unsigned char *)iq_host;
+    if (const long long piece = window_piece_for(ctx, nframes, 8)) return piece < 0 ? (int)piece : demod_windowed(ctx, src, nframes, 1, -1, nullptr, (uint64_t)piece);
+    int rc = ctx->pcm.ensure((size_t)nframes * 8 + 16);
+    if (rc) return rc;
     const auto t_in = std::chrono::steady_clock::now();
     if ((rc = ingest_capture(ctx, src, (size_t)nframes * 8, ctx->pcm.p))) return rc;
     ctx->ingest_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_in).count();
@@ -3080,7 +3136,7 @@ template <typename T> static int stage_fir(pdt_ctx *ctx, const void *in_host, ui
         PDT_LAUNCH(PDT_FIR_THREADS, (k_fir_interp_rt<T, I, 26>), dim3(grid_rt), dim3(PDT_FIR_THREADS), sh_rt, st, (const T *)d_in, N, (const T *)ctx->taps_rot.p, d_out, \
                            (AgcMap *)nullptr, (T)0);                                                                          \
         break;
-                PDT_FIR_CASE(1) PDT_FIR_CASE(2) PDT_FIR_CASE(3) PDT_FIR_CASE(4) PDT_FIR_CASE(5) PDT_FIR_CASE(6)
+                PDT_FIR_CASE(1) PDT_FIR_CASE(2) PDT_FIR_CASE(3) PDT_FIR_CASE(4) PDT_FIR_CASE(5) PDT_FIR_CASE(6) PDT_FIR_CASE(7) PDT_FIR_CASE(8)
 #undef PDT_FIR_CASE
             default: done = false;
             }
@@ -3196,8 +3252,8 @@ template <typename T> static int stage_gardner(pdt_ctx *ctx, const void *in_host
     GardnerParams<T> GP;
     const T baud = ctx->lp.gardner_baud != 0 ? (T)ctx->lp.gardner_baud : argos ? (T)(400 * 2.0) : (T)(8320 * 2 + 0.3);   // main.c:90 / ARGOS main.c:64
     GP.step = (T)(int)fsi / baud;                                              // GardenerClockRecovery.c:19
-    GP.kp = ctx->lp.gardner_kp != 0 ? (T)ctx->lp.gardner_kp : (T)3.0;
-    GP.lim = ctx->lp.gardner_step_range != 0 ? (T)ctx->lp.gardner_step_range : (T)0.1;
+    GP.kp = (ctx->lp.gardner_kp != 0 || (ctx->lp.zero_mask & PDT_LP_ZERO_GARDNER_KP)) ? (T)ctx->lp.gardner_kp : (T)3.0;
+    GP.lim = (ctx->lp.gardner_step_range != 0 || (ctx->lp.zero_mask & PDT_LP_ZERO_GARDNER_STEP_RANGE)) ? (T)ctx->lp.gardner_step_range : (T)0.1;
     GP.n_total = total;
     GP.chunk_out = C;
     GP.argos_heap = 0;
@@ -3670,6 +3726,7 @@ static int segment_end(pdt_ctx *ctx, uint64_t upto, bool final_seg)
     S.ntaps = ctx->ntaps;
     ctx->stream_gpu_ms += S.gpu_ms;
     S.gpu_ms = ctx->stream_gpu_ms;
+    S.segments += 1;
     if (final_seg) return PDT_OK;
     // ---- slide the window: the new origin is the largest aligned position that leaves the history in front of the next
     // new sample; the input window and the tails later segments look back on move with it
@@ -3677,7 +3734,7 @@ static int segment_end(pdt_ctx *ctx, uint64_t upto, bool final_seg)
     if (C.in_place && (align & 3)) align *= (align & 1) ? 4 : 2;     // the view's base stays 16-byte aligned
     // (the overlapped ingest cuts its segments where the whole-capture kernels' units begin, and keeps the window's origin --
     // and with it every segment's first new sample -- on the same grid: demod_overlapped, run_capture's seg_fast)
-    if (C.in_place && C.place_align) align = C.place_align;
+    if (C.place_align) align = C.place_align;
     const uint64_t hist = stream_history(ctx);
     const uint64_t done_g = C.origin + ctx->stream_done;
     const uint64_t new_origin = done_g > hist ? (done_g - hist) / align * align : 0;
@@ -3922,6 +3979,82 @@ static int demod_overlapped(pdt_ctx *ctx, const IngestSrc &src, uint64_t nframes
     return rc ? rc : rj;
 }
 
+// A capture that does not fit the device in one piece (window_piece_for): the streaming path with a bounded window, fed from
+// the file (or the caller's memory) `piece` samples at a time -- what a caller of pdt_stream_push_* would do by hand, with the
+// threaded ingest in place of one pageable copy per push, the text of a finished piece written and its per-chunk reports
+// handed on while the next piece is read (as demod_overlapped does).  Every cut is a chunk boundary; the window's origin
+// stays on the grid where a segment may take the whole-capture kernels (run_capture: seg_fast) when the pieces are large
+// enough for that to matter.  The state it leaves is demod_overlapped's: frames, text, statistics and reports of the whole
+// capture, stage arrays of the last piece.
+static int demod_windowed(pdt_ctx *ctx, const IngestSrc &src, uint64_t nframes, int fmt, int text_fd, uint64_t *text_bytes, uint64_t piece)
+{
+    if (ctx->keep_agc_raw) return PDT_ERR_NOMEM;      // (the pre-Squelch stream of the WHOLE capture was asked for: that does not fit)
+    const size_t fb = fmt ? 8 : 4;
+    const auto t_call = std::chrono::steady_clock::now();
+    int rc = pdt_stream_begin(ctx);
+    if (rc) return rc;
+    ctx->stream_fmt = fmt;
+    ctx->sc.quality = ctx->keep_quality;              // (every cut below is a chunk boundary)
+    ctx->report_samples = nframes;
+    const uint64_t chunk = ctx->cfg.chunk;
+    const uint64_t grid = lcm_u64(lcm_u64(chunk * 208, 64 * 26 * (uint64_t)ctx->interp), 416);
+    if (piece >= 4 * grid) {
+        piece = piece / grid * grid;
+        ctx->sc.place_align = grid;
+    }
+    TextSink sink;
+    sink.fd = text_fd;
+    sink.fn = ctx->progress_fn;
+    sink.user = ctx->progress_user;
+    uint64_t reported = 0, pushed = 0;
+    double ingest_ms = 0;
+    auto segment_reports = [&]() {
+        std::vector<pdt_chunk_report> r;
+        const uint64_t have = ctx->chunk_host.size();
+        if (sink.fn && have > reported) {
+            r.resize((size_t)(have - reported));
+            chunk_reports_range(ctx, reported, have, nframes, r.data(), ctx->sc.have_pending ? &ctx->sc.pending : nullptr);
+        }
+        return r;
+    };
+    for (bool last = false; !last && !rc;) {
+        const uint64_t cnt = std::min<uint64_t>(piece, nframes - pushed);
+        last = pushed + cnt == nframes;
+        if ((rc = ctx->stream_in.ensure_keep(((size_t)(ctx->stream_have + cnt) + 64) * fb, (size_t)ctx->stream_have * fb))) break;
+        IngestSrc s = src;
+        if (s.mem) s.mem += (size_t)pushed * fb; else s.off += pushed * fb;
+        const auto t0 = std::chrono::steady_clock::now();
+        if ((rc = ingest_capture(ctx, s, (size_t)cnt * fb, (unsigned char *)ctx->stream_in.p + (size_t)ctx->stream_have * fb))) break;
+        ingest_ms += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+        ctx->stream_have += cnt;
+        ctx->stream_total += cnt;
+        pushed += cnt;
+        const uint64_t upto = last ? ctx->stream_have : (ctx->sc.origin + ctx->stream_have) / chunk * chunk - ctx->sc.origin;
+        if (upto <= ctx->stream_done && !last) continue;
+        if ((rc = stream_segment(ctx, upto, last))) break;
+        try {
+            const uint64_t first_chunk = reported;
+            std::vector<pdt_chunk_report> r = segment_reports();
+            reported += r.size();
+            sink.push(ctx->sc.seg_frames, std::move(r), first_chunk, ctx->stats, !last);
+        } catch (const std::bad_alloc &) {
+            rc = PDT_ERR_NOMEM;
+        }
+    }
+    sink.wait();
+    if (!rc && sink.rc) rc = sink.rc;
+    if (text_bytes) *text_bytes = sink.bytes;
+    (void)t_call;
+    ctx->ingest_ms = ingest_ms;
+    ctx->stats.ingest_ms = ingest_ms;
+    ctx->stats.windowed = 1;
+    ctx->sc = StreamCarry();
+    ctx->stream_have = ctx->stream_done = ctx->stream_total = 0;
+    ctx->stream_fmt = -1;
+    ctx->stream_open = false;
+    return rc;
+}
+
 int pdt_demod_file(pdt_ctx *ctx, int fd, uint64_t byte_offset, uint64_t nframes, int sample_format, int text_fd, uint64_t *text_bytes)
 {
     if (text_bytes) *text_bytes = 0;
@@ -3930,6 +4063,12 @@ int pdt_demod_file(pdt_ctx *ctx, int fd, uint64_t byte_offset, uint64_t nframes,
     if (ctx->stream_open) return PDT_ERR_STATE;
     HIP_TRY(hipSetDevice(ctx->cfg.device));
     const size_t fb = sample_format == PDT_FMT_F32 ? 8 : 4;
+    if (const long long piece = window_piece_for(ctx, nframes, fb)) {
+        IngestSrc src;
+        src.fd = fd;
+        src.off = byte_offset;
+        return piece < 0 ? (int)piece : demod_windowed(ctx, src, nframes, sample_format == PDT_FMT_F32 ? 1 : 0, text_fd, text_bytes, (uint64_t)piece);
+    }
     if (overlap_ingest(ctx, nframes, fb)) {
         IngestSrc src;
         src.fd = fd;

@@ -978,7 +978,7 @@ typedef const __attribute__((address_space(3))) float pdt_lds_cf;
 __device__ __forceinline__ float lds_rel_at(const float *wrel, float x)
 {
     const unsigned base = (unsigned)(size_t)wrel - (0x4B400000u << 2);
-    return *(pdt_lds_cf *)((__float_as_uint(x + 12582912.0f) << 2) + base);
+    return *(pdt_lds_cf *)(size_t)((__float_as_uint(x + 12582912.0f) << 2) + base);    // (an LDS address: 32 bits on the device)
 }
 
 __device__ __forceinline__ void gardner_lane_step(GardnerLane &L, const float *wrel, float kp, float lim, float hs, float step)

@@ -17,7 +17,9 @@
  *   output name minorFrames_YYYYMMDD_HHMMSS.txt / packets_YYYYMMDD_HHMMSS.txt   main.c:289 / ARGOS main.c:213
  *   "Normalization Factor: %f", " : PLL locked at %0.2fHz"                  main.c:388, CarrierTrackingPLL.c:269
  *   output removed when no frame was found             main.c:508-512
- * Additions: -o <file> chooses the output name (tests), -d <n> picks the GPU, -P drops the progress lines, -q (POES) prints the frame
+ * A capture of any length is taken (main.c:373 reads until end of file): one that does not fit the GPU's free memory goes through
+ * the library's bounded window (pdt.h, ABI 4).
+ * Additions: -o <file> chooses the output name (tests), -d <n> picks the GPU, -D NAME=VALUE sets a developer switch of the library, -P drops the progress lines, -q (POES) prints the frame
  * validation the reference keeps in MATLAB (checkParity.m:91-92, daytimeDecode.m:36,82-95) after decoding,
  * -m selects MMClockRecovery (the sampler the reference keeps commented out at ARGOSdemod/main.c:277),
  * -l (POES) runs the sound-card twin's chain (POESTIPdemodPortAudio/main.c:41-65,324-393: its PLL constants,
@@ -39,18 +41,19 @@
 #include <unistd.h>
 
 #include "pdt.h"
+#include "pdt_dev.h"                   /* -D NAME=VALUE: the library's developer switches (tests; the library never reads the environment) */
 
 #ifdef PDT_ARGOS
 #define MODE PDT_MODE_ARGOS
 #define DEFAULT_CHUNKSIZE 2400
-#define OPTS "s:rn:c:o:d:mlPT"      /* -l (round 4): the sound-card twin's chain, -s its rate in kHz when the samples come from a pipe */
+#define OPTS "s:rn:c:o:d:mlPTD:"      /* -l (round 4): the sound-card twin's chain, -s its rate in kHz when the samples come from a pipe */
 #define BANNER "Project Desert Tortoise: Wave file ARGOS Demodulator (MI355X build)\n"
 #define PREFIX "packets"
 #define UNIT "Packets"
 #else
 #define MODE PDT_MODE_POES
 #define DEFAULT_CHUNKSIZE 10000
-#define OPTS "s:rn:c:o:d:qmlPT"
+#define OPTS "s:rn:c:o:d:qmlPTD:"
 #define BANNER "Project Desert Tortoise: Wave file NOAA TIP Demodulator (MI355X build)\n"
 #define PREFIX "minorFrames"
 #define UNIT "Frames"
@@ -280,6 +283,16 @@ int main(int argc, char **argv)
         case 'T':
             timing = 1;
             break;
+        case 'D': {                                     /* developer switch, e.g. -D PDT_HBM_LIMIT_MB=2048 (before the context opens) */
+            char name[64];
+            const char *eq = strchr(optarg, '=');
+            const size_t len = eq ? (size_t)(eq - optarg) : strlen(optarg);
+            if (len == 0 || len >= sizeof name) return 1;
+            memcpy(name, optarg, len);
+            name[len] = 0;
+            pdt_dev_set(name, eq ? eq + 1 : "1");
+            break;
+        }
         case 'P':                                       /* no progress lines (and no averagePhase pass on the GPU) */
             noProgress = 1;
             break;

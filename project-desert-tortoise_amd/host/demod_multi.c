@@ -13,8 +13,11 @@
  * output file per capture -- the text POESTIPdemod/ByteSync.c:62-69,96-101 / ARGOSdemod/ByteSync.c:62-70,99-103 print -- next
  * to the input: <capture>.frames.txt.
  *
- * usage: demodMulti [-a] [-c chunk] [-g ngpus] [-l lanes] capture1.wav capture2.wav ...   (-a: ARGOS chain; default POES;
- *        -l: contexts per GPU, 1 or 2, default 2)
+ * usage: demodMulti [-a] [-c chunk] [-g ngpus] [-l lanes] [-R passes] [-J] capture1.wav capture2.wav ...   (-a: ARGOS chain; default
+ *        POES; -l: contexts per GPU, 1 or 2, default 2; -R: the whole queue this many times -- measurements: contexts, buffers and
+ *        communicators are warm from the second pass on --; -J: one machine-readable line with every pass's clock (first open ->
+ *        last output file closed, the gather inside) and every capture's ingest / GPU time: what bench.py --gpus N reports as the
+ *        end-to-end figure of BASELINE's metric)
  *
  * Host budget at N GPUs: 2 N worker threads + per ingesting context up to min(8, cores / 2 / contexts) reader
  * threads (csrc/pdt_api.hip: ingest_capture) and 2 x 8 MiB of pinned staging per reader; frame records 136 B each (4.9 MB per
@@ -128,44 +131,35 @@ static void *run_worker(void *arg)
     return NULL;
 }
 
-int main(int argc, char **argv)
+/* what one pass over the queue took (bench.py reads the -J line) */
+typedef struct rep_times {
+    double wall_s, demod_s, gather_ms, write_ms;
+    int failed;
+} rep_times;
+
+static worker *g_wk;
+static int g_nw, g_ngpu, g_mode;
+static pdt_gatherer *g_gatherer;             /* ONE set of RCCL communicators for the whole run, whatever the number of passes */
+static int g_gatherer_ranks;
+
+/* One pass: every capture through the queue, the records gathered on the first GPU, one output file per capture.  The clock runs
+ * from the moment the first worker may open its first capture until the last output file has been closed.                     */
+static void run_queue(int n, rep_times *T, int quiet)
 {
-    int mode = PDT_MODE_POES, c, ngpu = pdt_device_count(), lanes = 2;
-    unsigned long chunk = 0;
-    while ((c = getopt(argc, argv, "ac:g:l:")) != -1) {
-        if (c == 'a') mode = PDT_MODE_ARGOS;
-        else if (c == 'c') chunk = strtoul(optarg, NULL, 10);
-        else if (c == 'g') ngpu = atoi(optarg);
-        else if (c == 'l') lanes = atoi(optarg) >= 2 ? 2 : 1;
-        else return 2;
-    }
-    const int n = argc - optind;
-    if (n <= 0) { fprintf(stderr, "usage: %s [-a] [-c chunk] [-g ngpus] [-l lanes] capture.wav ...\n", argv[0]); return 2; }
-    if (ngpu <= 0) { printf("GPU demodulator unavailable: %s\n", pdt_strerror(PDT_ERR_NOGPU)); return 1; }
-    if (ngpu > pdt_device_count()) ngpu = pdt_device_count();
-    if (ngpu > n) ngpu = n;
-    if (lanes * ngpu > n) lanes = 1;                                 /* (fewer captures than lanes: one context per GPU will do) */
-    printf("Project Desert Tortoise: %d capture(s) on %d MI355X GPU(s), %d context(s) per GPU, every context takes the next capture when it is free\n",
-           n, ngpu, lanes);
-    g_cap = (capture *)calloc((size_t)n, sizeof(capture));
-    g_ncap = n;
-    atomic_store(&g_next, 0);
-    const int nw = ngpu * lanes;
-    worker *wk = (worker *)calloc((size_t)nw, sizeof(worker));
-    g_gpu = (gpu_tally *)calloc((size_t)ngpu, sizeof(gpu_tally));
-    if (!g_cap || !wk || !g_gpu) return 1;
+    const int ngpu = g_ngpu, nw = g_nw, mode = g_mode;
+    worker *wk = g_wk;
     for (int k = 0; k < n; k++) {
-        g_cap[k].path = argv[optind + k];
+        free(g_cap[k].frames);
+        g_cap[k].frames = NULL;
+        g_cap[k].nfr = 0;
         g_cap[k].rc = PDT_ERR_STATE;                                 /* (never taken: no worker could be started) */
         g_cap[k].device = -1;
     }
+    for (int d = 0; d < ngpu; d++) { atomic_store(&g_gpu[d].done, 0); atomic_store(&g_gpu[d].nfr, 0); }
+    atomic_store(&g_next, 0);
     const double t_all = now_s();
-    for (int i = 0; i < nw; i++) {                                   /* lane 0 of every GPU first: the first captures go one per GPU */
-        wk[i].device = i % ngpu;
-        wk[i].mode = mode;
-        wk[i].chunk = chunk;
+    for (int i = 0; i < nw; i++)                                     /* lane 0 of every GPU first: the first captures go one per GPU */
         wk[i].started = pthread_create(&wk[i].th, NULL, run_worker, &wk[i]) == 0;
-    }
     for (int i = 0; i < nw; i++)
         if (wk[i].started) pthread_join(wk[i].th, NULL);
     const double t_demod = now_s() - t_all;
@@ -196,18 +190,29 @@ int main(int argc, char **argv)
         ranks++;
     }
     pdt_frame *all = NULL;
+    const double t_g0 = now_s();
     int grc = failed_alloc ? PDT_ERR_NOMEM : PDT_OK;               /* no staging copy: no gather (every capture keeps its own frames) */
     if (grc != PDT_OK) printf("gather skipped (%s): every capture's frames are taken from its own GPU's copy\n", pdt_strerror(grc));
     if (ranks && grc == PDT_OK) {
-        pdt_gatherer *g = NULL;
-        grc = pdt_gatherer_open(devs, ranks, &g);
-        if (grc == PDT_OK) grc = pdt_gatherer_gather(g, (const pdt_frame *const *)rec, cnt, 0, &all, got);   /* RCCL: counts, then padded records */
+        if (g_gatherer && g_gatherer_ranks != ranks) {               /* (another set of GPUs did work this time) */
+            pdt_gatherer_close(g_gatherer);
+            g_gatherer = NULL;
+        }
+        if (!g_gatherer) {
+            grc = pdt_gatherer_open(devs, ranks, &g_gatherer);
+            g_gatherer_ranks = ranks;
+        }
+        if (grc == PDT_OK) grc = pdt_gatherer_gather(g_gatherer, (const pdt_frame *const *)rec, cnt, 0, &all, got);   /* RCCL: counts, then padded records */
         if (grc == PDT_OK)
             for (int r = 0; r < ranks; r++)
                 if (got[r] != cnt[r]) grc = PDT_ERR_STATE;
-        if (grc != PDT_OK) printf("gather failed (%s): every capture's frames are taken from its own GPU's copy\n", pdt_strerror(grc));
-        pdt_gatherer_close(g);
+        if (grc != PDT_OK) {
+            printf("gather failed (%s): every capture's frames are taken from its own GPU's copy\n", pdt_strerror(grc));
+            pdt_gatherer_close(g_gatherer);
+            g_gatherer = NULL;
+        }
     }
+    const double t_g1 = now_s();
     /* ---- one output file per capture, from the gathered array */
     uint64_t *rank_at = (uint64_t *)calloc((size_t)(ranks + 1), sizeof(uint64_t));
     for (int r = 0; r < ranks; r++) rank_at[r + 1] = rank_at[r] + cnt[r];
@@ -232,13 +237,15 @@ int main(int argc, char **argv)
                     remove(name);                                    /* no frame, no file (main.c:508-512) */
                 }
                 if (!wrote) { printf("%s: could not be written\n", name); failed++; }
-                printf("GPU %d: %s: %0.3f Ks : %llu Sym : %llu Bits : %llu %s  (%.1f ms on the GPU, ingest %.1f ms, %.3f s in all)\n", cp->device,
-                       cp->path, cp->st.samples / 1000.0, (unsigned long long)cp->st.symbols, (unsigned long long)cp->st.bits,
-                       (unsigned long long)cp->nfr, mode == PDT_MODE_ARGOS ? "Packets" : "Frames", cp->st.gpu_ms, cp->st.ingest_ms, cp->seconds);
+                if (!quiet)
+                    printf("GPU %d: %s: %0.3f Ks : %llu Sym : %llu Bits : %llu %s  (%.1f ms on the GPU, ingest %.1f ms, %.3f s in all)\n", cp->device,
+                           cp->path, cp->st.samples / 1000.0, (unsigned long long)cp->st.symbols, (unsigned long long)cp->st.bits,
+                           (unsigned long long)cp->nfr, mode == PDT_MODE_ARGOS ? "Packets" : "Frames", cp->st.gpu_ms, cp->st.ingest_ms, cp->seconds);
                 if (wrote) samples_all += cp->st.samples;
                 ingest_all += cp->st.ingest_ms;
             }
     }
+    const double t_w1 = now_s();
     for (int k = 0; k < n; k++)
         if (g_cap[k].rc != PDT_OK) {
             printf("%s: %s\n", g_cap[k].path, pdt_strerror(g_cap[k].rc));
@@ -249,10 +256,86 @@ int main(int argc, char **argv)
            dt, t_demod, samples_all / dt / 1e6);
     /* (a GPU's link carries one ingest at a time: with two contexts per GPU the queue should move at about that pace) */
     printf("queue: sum of the captures' ingest times %.1f ms on %d GPU(s), %.1f ms until the last GPU was done\n", ingest_all, ngpu, t_demod * 1e3);
+    T->wall_s = dt;
+    T->demod_s = t_demod;
+    T->gather_ms = (t_g1 - t_g0) * 1e3;
+    T->write_ms = (t_w1 - t_g1) * 1e3;
+    T->failed = failed;
+    for (int r = 0; r < ranks; r++) free(rec[r]);
+    free(all); free(rank_at); free(rank_of); free(got); free(cnt); free(rec); free(devs);
+}
+
+int main(int argc, char **argv)
+{
+    int mode = PDT_MODE_POES, c, ngpu = pdt_device_count(), lanes = 2, reps = 1, json = 0;
+    unsigned long chunk = 0;
+    const char *usage = "usage: %s [-a] [-c chunk] [-g ngpus] [-l 1|2] [-R passes] [-J] capture.wav ...\n";
+    while ((c = getopt(argc, argv, "ac:g:l:R:J")) != -1) {
+        if (c == 'a') mode = PDT_MODE_ARGOS;
+        else if (c == 'c') chunk = strtoul(optarg, NULL, 10);
+        else if (c == 'g') ngpu = atoi(optarg);
+        else if (c == 'l') {
+            lanes = atoi(optarg);
+            if (lanes != 1 && lanes != 2) { fprintf(stderr, "-l: contexts per GPU, 1 or 2\n"); fprintf(stderr, usage, argv[0]); return 2; }
+        }
+        else if (c == 'R') reps = atoi(optarg) > 0 ? atoi(optarg) : 1;   /* the whole queue this many times (measurements: contexts, buffers and communicators are warm from the second pass on) */
+        else if (c == 'J') json = 1;                                  /* one machine-readable line at the end (bench.py) */
+        else return 2;
+    }
+    const int n = argc - optind;
+    if (n <= 0) { fprintf(stderr, usage, argv[0]); return 2; }
+    if (ngpu <= 0) { printf("GPU demodulator unavailable: %s\n", pdt_strerror(PDT_ERR_NOGPU)); return 1; }
+    if (ngpu > pdt_device_count()) ngpu = pdt_device_count();
+    if (ngpu > n) ngpu = n;
+    if (lanes * ngpu > n && lanes > 1) {                             /* fewer captures than lanes: one context per GPU will do */
+        printf("%d capture(s) for %d GPU(s): one context per GPU\n", n, ngpu);
+        lanes = 1;
+    }
+    printf("Project Desert Tortoise: %d capture(s) on %d MI355X GPU(s), %d context(s) per GPU, every context takes the next capture when it is free\n",
+           n, ngpu, lanes);
+    g_cap = (capture *)calloc((size_t)n, sizeof(capture));
+    g_ncap = n;
+    const int nw = ngpu * lanes;
+    worker *wk = (worker *)calloc((size_t)nw, sizeof(worker));
+    g_gpu = (gpu_tally *)calloc((size_t)ngpu, sizeof(gpu_tally));
+    rep_times *RT = (rep_times *)calloc((size_t)reps, sizeof(rep_times));
+    if (!g_cap || !wk || !g_gpu || !RT) return 1;
+    for (int k = 0; k < n; k++) g_cap[k].path = argv[optind + k];
+    for (int i = 0; i < nw; i++) {
+        wk[i].device = i % ngpu;
+        wk[i].mode = mode;
+        wk[i].chunk = chunk;
+    }
+    g_wk = wk; g_nw = nw; g_ngpu = ngpu; g_mode = mode;
+    int failed = 0;
+    for (int r = 0; r < reps; r++) {
+        if (reps > 1) printf("pass %d of %d\n", r + 1, reps);
+        run_queue(n, &RT[r], 0);
+        failed = RT[r].failed;
+    }
+    if (json) {
+        /* one line: every pass's clock, and of the LAST pass every capture's account (bench.py: e2e at N GPUs) */
+        printf("{\"demodMulti\": {\"gpus\": %d, \"lanes\": %d, \"captures\": %d, \"passes\": [", ngpu, lanes, n);
+        for (int r = 0; r < reps; r++)
+            printf("%s{\"wall_s\": %.6f, \"until_last_gpu_s\": %.6f, \"gather_ms\": %.3f, \"write_ms\": %.3f, \"failed\": %d}", r ? ", " : "",
+                   RT[r].wall_s, RT[r].demod_s, RT[r].gather_ms, RT[r].write_ms, RT[r].failed);
+        printf("], \"last_pass\": [");
+        int first = 1;
+        for (int k = 0; k < n; k++) {
+            const capture *cp = &g_cap[k];
+            if (cp->rc != PDT_OK) continue;
+            printf("%s{\"capture\": %d, \"gpu\": %d, \"samples\": %llu, \"bytes\": %llu, \"frames\": %llu, \"ingest_ms\": %.3f, \"gpu_ms\": %.3f, "
+                   "\"seconds\": %.6f, \"segments\": %u, \"windowed\": %u}", first ? "" : ", ", k, cp->device, (unsigned long long)cp->st.samples,
+                   (unsigned long long)cp->st.samples * 4ull, (unsigned long long)cp->nfr, cp->st.ingest_ms, cp->st.gpu_ms, cp->seconds,
+                   cp->st.segments, cp->st.windowed);
+            first = 0;
+        }
+        printf("]}}\n");
+    }
+    if (g_gatherer) pdt_gatherer_close(g_gatherer);
     for (int i = 0; i < nw; i++)
         if (wk[i].ctx) pdt_close(wk[i].ctx);
-    for (int r = 0; r < ranks; r++) free(rec[r]);
     for (int k = 0; k < n; k++) free(g_cap[k].frames);
-    free(all); free(rank_at); free(rank_of); free(got); free(cnt); free(rec); free(devs); free(wk); free(g_gpu); free(g_cap);
+    free(RT); free(wk); free(g_gpu); free(g_cap);
     return failed ? 1 : 0;
 }

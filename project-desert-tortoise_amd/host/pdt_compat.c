@@ -121,6 +121,7 @@ static pdt_agc_state g_agc;
 void NormalizingAGC(DT *dataStreamIn, unsigned long nSamples, DT initial, DT attack_rate, DT decay_rate)
 {
     g_used = 1;
+    if (attack_rate == 0 || decay_rate == 0) die("NormalizingAGC rate of 0 (the stage entry reads 0 as \"the mains' constant\")", 0);
     TRY(pdt_stage_agc(ctx_for(0), dataStreamIn, nSamples, (double)initial, (double)attack_rate, (double)decay_rate, &g_agc));
 }
 
@@ -144,6 +145,10 @@ DT CarrierTrackPLL(DT complex *complexDataIn, DT *realDataOut, DT *lockSignalStr
         lp.pll_lock_alpha = (double)lockSigAlpha;
         lp.pll_loopbw_acq = (double)loopbw_acq;
         lp.pll_loopbw_track = (double)loopbw_track;
+        /* a field left 0 means "the mains' constant" to the context: a caller's own 0 must not turn into that.  A lock threshold
+         * of 0 is a value (zero_mask); a range, detector rate or bandwidth of 0 is no loop at all */
+        if (freqRange == 0 || lockSigAlpha == 0 || loopbw_acq == 0 || loopbw_track == 0) die("CarrierTrackPLL constant of 0", 0);
+        lp.zero_mask = (lp.zero_mask & ~(uint32_t)PDT_LP_ZERO_LOCK_THRESHOLD) | (d_lock_threshold == 0 ? PDT_LP_ZERO_LOCK_THRESHOLD : 0u);
         set_params(c, &lp);
     }
     int fmt;
@@ -230,6 +235,9 @@ unsigned long GardenerClockRecovery(DT *dataStreamIn, DT *dataStreamInTime, unsi
         lp.gardner_step_range = (double)stepRange;
         lp.gardner_kp = (double)kp;
         if (stepRange > (DT)0.1) die("GardenerClockRecovery stepRange above 0.1", 0);
+        lp.zero_mask &= ~(uint32_t)(PDT_LP_ZERO_GARDNER_KP | PDT_LP_ZERO_GARDNER_STEP_RANGE);       /* (an open-loop sampler: 0 is 0) */
+        if (kp == 0) lp.zero_mask |= PDT_LP_ZERO_GARDNER_KP;
+        if (stepRange == 0) lp.zero_mask |= PDT_LP_ZERO_GARDNER_STEP_RANGE;
         set_params(c, &lp);
     }
     /* The function reads a little past numSamples (the first symbol's stale mid-point index, Q3; the last symbol's look-ahead):

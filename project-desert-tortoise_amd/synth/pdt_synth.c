@@ -40,6 +40,22 @@ void pdt_synth_default_params(pdt_synth_params *p, int kind, uint32_t sample_rat
     p->seed = seed;
 }
 
+/* A pass: noise only outside [signal_start, signal_end), the carrier offset ramps linearly from f_start_hz to f_end_hz between the
+ * two (Doppler), the amplitude follows floor + (1 - floor) 4x(1 - x).  Everything is turned into integers here, once. */
+void pdt_synth_set_pass(pdt_synth_params *p, uint64_t signal_start, uint64_t signal_end, double f_start_hz, double f_end_hz,
+                        double env_floor)
+{
+    const double fs = (double)p->sample_rate;
+    p->signal_start = signal_start;
+    p->signal_end = signal_end;
+    p->carrier_step = (uint32_t)(int64_t)llrint(f_start_hz / fs * 4294967296.0);
+    p->doppler_q32 = 0;
+    if (signal_end > signal_start + 1 && f_end_hz != f_start_hz)
+        p->doppler_q32 = (int64_t)llrint((f_end_hz - f_start_hz) / fs * 4294967296.0 * 4294967296.0 / (double)(signal_end - signal_start));
+    p->env_floor_q15 = env_floor > 0 ? (uint32_t)llrint(env_floor * 32768.0) : 0u;
+    if (p->env_floor_q15 > 32768u) p->env_floor_q15 = 32768u;
+}
+
 void pdt_synth_fill(const pdt_synth_params *p, uint64_t start, uint64_t count, int16_t *out)
 {
     const int16_t *tab = pdt_synth_sine_table();
@@ -81,12 +97,14 @@ void pdt_synth_argos_payload(const pdt_synth_params *p, uint64_t burst, uint8_t 
 }
 
 #ifdef PDT_SYNTH_MAIN
-/* synth_wav poes|argos <sample_rate> <seconds> <f0_hz> <seed> out.wav */
+/* synth_wav poes|argos <sample_rate> <seconds> <f0_hz> <seed> out.wav [lead_s tail_s f_end_hz env_floor [noise_x]]
+ * with the optional arguments: a pass -- lead_s / tail_s seconds of noise only at the ends, the carrier ramping from f0_hz to
+ * f_end_hz in between, the amplitude envelope's floor (0 = flat), the noise amplitude multiplied by noise_x */
 #include <stdio.h>
 int main(int argc, char **argv)
 {
     if (argc < 7) {
-        fprintf(stderr, "usage: %s poes|argos sample_rate seconds f0_hz seed out.wav\n", argv[0]);
+        fprintf(stderr, "usage: %s poes|argos sample_rate seconds f0_hz seed out.wav [lead_s tail_s f_end_hz env_floor [noise_x]]\n", argv[0]);
         return 2;
     }
     int kind = strcmp(argv[1], "argos") == 0;
@@ -95,6 +113,11 @@ int main(int argc, char **argv)
     pdt_synth_params p;
     pdt_synth_default_params(&p, kind, fs, atof(argv[4]), strtoull(argv[5], NULL, 10));
     uint64_t n = (uint64_t)llrint(secs * fs);
+    if (argc >= 11) {
+        const uint64_t lead = (uint64_t)llrint(atof(argv[7]) * fs), tail = (uint64_t)llrint(atof(argv[8]) * fs);
+        pdt_synth_set_pass(&p, lead, n > tail ? n - tail : 0, atof(argv[4]), atof(argv[9]), atof(argv[10]));
+        if (argc >= 12) p.noise_gain = (int32_t)llrint(p.noise_gain * atof(argv[11]));
+    }
     FILE *f = fopen(argv[6], "wb");
     if (!f) { perror(argv[6]); return 1; }
     uint8_t hdr[44];

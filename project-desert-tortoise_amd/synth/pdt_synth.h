@@ -18,6 +18,13 @@
  *             15 x '1', 0001 0111, 1, 0000, 56 payload bits, 1010
  *             (sync "0001011110000": ARGOSdemod/main.c:284), noise 25 dB down.
  *
+ * A pass as a receiver sees it (round 6; every field 0 = off, the captures above unchanged): noise only before
+ * `signal_start` (the receiver is on before the satellite rises) and from `signal_end` on (it stays on after it has set);
+ * between the two a linear Doppler ramp -- the carrier's phase step grows by `doppler_q32` / 2^32 per sample, an integer
+ * phase accumulator in closed form, so that any sample is still a pure function of its index -- and an amplitude envelope
+ * `env_floor_q15` + (1 - floor) 4x(1 - x), x = the position inside the pass: strongest at culmination, `floor` of that at
+ * the horizon.
+ *
  * All arithmetic is uint32/uint64/int32; phases are 32-bit turns (2^32 = 2 pi).
  */
 #ifndef PDT_SYNTH_H
@@ -44,6 +51,12 @@ typedef struct pdt_synth_params {
     uint64_t seed;          /* payload + noise seed                                       */
     uint64_t signal_start;  /* samples before this index are noise only (carrier off): a  */
                             /* receiver switched on before the satellite rises; 0 = none  */
+    uint64_t signal_end;    /* samples from this index on are noise only; 0 = never       */
+    int64_t  doppler_q32;   /* carrier_step changes by doppler_q32 / 2^32 per sample      */
+                            /* behind signal_start (a linear Doppler ramp); 0 = none      */
+    uint32_t env_floor_q15; /* amplitude envelope over [signal_start, signal_end): this   */
+                            /* fraction (Q15) at both ends, 1 in the middle; 0 = flat     */
+    uint32_t pad_;
 } pdt_synth_params;
 
 PDT_SYNTH_FN uint64_t pdt_synth_mix(uint64_t z)
@@ -102,6 +115,21 @@ PDT_SYNTH_FN void pdt_synth_sample(const pdt_synth_params *p, const int16_t *sin
 {
     uint32_t theta = (uint32_t)(n * (uint64_t)p->carrier_step) + p->phase0;
     int32_t amp = n < p->signal_start ? 0 : p->amplitude;
+    if (p->signal_end && n >= p->signal_end) amp = 0;
+    if (amp && p->doppler_q32) {
+        /* sum over the m samples since signal_start of (k * doppler_q32) / 2^32 turns, k = 0 .. m - 1, floor taken of the sum:
+           bits 32..63 of the two's complement product doppler_q32 * m (m - 1) / 2 -- its low 64 bits are exact under wrap-around */
+        const uint64_t m = n - p->signal_start;
+        const uint64_t tri = (m & 1u) ? m * ((m - 1u) >> 1) : (m >> 1) * (m - 1u);
+        theta += (uint32_t)(((uint64_t)p->doppler_q32 * tri) >> 32);
+    }
+    if (amp && p->env_floor_q15 && p->signal_end > p->signal_start) {
+        const uint64_t m = n - p->signal_start, len = p->signal_end - p->signal_start;      /* (len < 2^40) */
+        const uint64_t x = (m << 16) / len;                                                 /* Q16 position, < 65536 */
+        const uint64_t par = 4u * x * (65536u - x);                                         /* Q32: 4x(1 - x) <= 2^32 */
+        const uint64_t e = p->env_floor_q15 + (((32768u - (uint64_t)p->env_floor_q15) * par) >> 32);   /* Q15 */
+        amp = (int32_t)(((uint64_t)amp * e + 16384u) >> 15);
+    }
     if (p->kind == 0) {
         uint64_t k = (n * 16640ull) / p->sample_rate;     /* Manchester symbol index */
         uint64_t bit = k >> 1;
@@ -145,6 +173,9 @@ extern "C" {
 /* host-side helpers (pdt_synth.c) */
 const int16_t *pdt_synth_sine_table(void);
 void pdt_synth_default_params(pdt_synth_params *p, int kind, uint32_t sample_rate, double f0_hz, uint64_t seed);
+/* a pass (round 6): noise only outside [signal_start, signal_end), linear Doppler ramp f_start_hz -> f_end_hz, amplitude envelope */
+void pdt_synth_set_pass(pdt_synth_params *p, uint64_t signal_start, uint64_t signal_end, double f_start_hz, double f_end_hz,
+                        double env_floor);
 /* fill out[2*count] with samples [start, start+count) */
 void pdt_synth_fill(const pdt_synth_params *p, uint64_t start, uint64_t count, int16_t *out);
 /* canonical 44-byte header (fmt=1, 2 ch, 16 bit) for `nframes` IQ samples */

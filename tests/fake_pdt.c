@@ -60,7 +60,7 @@ int pdt_demod_fd(pdt_ctx *c, int fd, uint64_t off, uint64_t nframes, int fmt)
         for (int b = 0; b < 104; b++) c->fr[k].bytes[b] = (uint8_t)(nframes * 7 + k * 13 + (uint64_t)b);
     }
     memset(&c->st, 0, sizeof c->st);
-    c->st.samples = nframes; c->st.frames = c->nfr; c->st.gpu_ms = w[0];
+    c->st.samples = nframes; c->st.frames = c->nfr; c->st.gpu_ms = w[0]; c->st.ingest_ms = w[2]; c->st.segments = 1;
     return PDT_OK;
 }
 uint64_t pdt_num_frames(const pdt_ctx *c) { return c->nfr; }

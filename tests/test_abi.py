@@ -172,7 +172,7 @@ def test_write_records_equals_format_records(pdt, tmp_path):
     cannot seek (a pipe) takes the text in order.  Host only."""
     import numpy as np
     L = pdt.lib()
-    assert L.pdt_abi_version() == 3
+    assert L.pdt_abi_version() == 4
     rng = np.random.default_rng(11)
     for n in (0, 1, 7, 2048, 2049, 40000):
         fr = np.zeros(n, dtype=pdt.FRAME_DTYPE)

@@ -43,3 +43,17 @@ def test_configs2_full_size_against_the_reference_objects():
     # ... and the file entries on the same capture: ingested first and in three overlapped segments (the default at this size),
     # same text, the per-chunk reports of the segments bit for bit those of the whole-capture run, handed on in order
     assert "file entries: text identical: True; per-chunk reports identical: True (3 segment(s)" in r.stdout
+
+
+def test_pass_shaped_capture_full_size_against_the_reference_objects():
+    """bench.py --config pass at full size (250 ksps x 15 min = 225 M samples): a minute of noise, the signal with a Doppler ramp
+    from +3 kHz to -3 kHz and an amplitude envelope of 0.25 .. 1, a minute of noise.  The sweep before the lock
+    (CarrierTrackingPLL.c:232-246), the one-time lock (:266-274) and the tracking loop on noise after the loss of signal at the
+    size a receiver records them: output file byte-identical to the reference's own objects."""
+    ref = os.path.join(ROOT, "oracle", "_ref", "ref_demodPOES")
+    if not os.path.exists(ref):
+        pytest.fail("oracle/_ref was not built (make -C oracle ref, where /root/reference exists; the binaries travel to the GPU box)")
+    env = dict(os.environ, PDT_SECS="900", PDT_RATE="250000", PDT_PASS="1")
+    r = subprocess.run([sys.executable, os.path.join(HERE, "tools", "c3_check.py")], capture_output=True, text=True, env=env)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
+    assert "output identical: True" in r.stdout and "file entries: text identical: True" in r.stdout

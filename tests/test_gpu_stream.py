@@ -386,6 +386,73 @@ def test_overlapped_segments_keep_the_chunk_reports(pdt, tmp_path, lead_noise):
             assert st0.lock_sample >= lead_noise and calls[0][2] == (-1 if name == "split" else st0.lock_sample)
 
 
+@pytest.mark.timeout(600)
+def test_capture_that_does_not_fit_goes_through_the_bounded_window(pdt, tmp_path):
+    """The reference's chunk loop takes a file of any length in O(chunk) memory (POESTIPdemod/main.c:373, while(!feof)).  The
+    one-piece path keeps every stage's stream of the capture resident; when that does not fit what the device has free, the
+    file entries feed the capture through the bounded window of the streaming path instead of failing.  BASELINE configs[1]
+    (50 ksps, 10 min) on a device that pretends to have 2 GB: same text, same per-chunk reports handed on piece by piece, the
+    window really bounded; the host-memory entry likewise; and the C host program (-D: its developer switch)."""
+    import os
+    import subprocess
+    fs = 50000
+    iq = pdt.synth_capture(0, fs, 600.0, seed=76)
+    wav = str(tmp_path / "c2.wav")
+    pdt.write_wav(wav, fs, iq)
+
+    def run(name, use_mem=False):
+        calls = []
+        with pdt.Demodulator(pdt.MODE_POES, fs).keep_pll(False) as d:
+            d.keep_quality().set_progress(lambda first, rep, st: calls.append((first, rep)))
+            if use_mem:
+                d.demod(iq)
+                text = d.text()
+            else:
+                fd = os.open(wav, os.O_RDONLY)
+                fo = os.open(str(tmp_path / f"{name}.txt"), os.O_RDWR | os.O_CREAT | os.O_TRUNC, 0o644)
+                try:
+                    d.demod_file_text(fd, 44, len(iq), fo, 0)
+                finally:
+                    os.close(fd)
+                    os.close(fo)
+                text = open(str(tmp_path / f"{name}.txt"), "rb").read()
+                assert text == d.text()
+            return text, d.chunk_reports(), calls, d.stats(), d.stage_len(pdt.ST_AGC)
+
+    text0, rep0, calls0, st0, agc0 = run("whole")
+    assert st0.segments == 1 and st0.windowed == 0 and agc0 == 3 * len(iq) and len(text0) > 1_000_000
+    for use_mem in (False, True):
+        text, rep, calls, st, agc = _with_env({"PDT_HBM_LIMIT_MB": "2048"}, lambda: run("windowed", use_mem))
+        assert st.windowed == 1 and st.segments >= 3, (st.windowed, st.segments)
+        assert text == text0
+        assert rep.tobytes() == rep0.tobytes()
+        assert len(calls) == st.segments and [c[0] for c in calls] == list(np.cumsum([0] + [len(c[1]) for c in calls[:-1]]))
+        assert np.concatenate([c[1] for c in calls]).tobytes() == rep0.tobytes()
+        assert agc < 3 * len(iq) // 2                                  # (the last piece's window, not the capture)
+        assert (st.samples, st.symbols, st.bits, st.frames, st.lock_sample) == (st0.samples, st0.symbols, st0.bits, st0.frames, st0.lock_sample)
+    # small pieces (a piece of 37 chunks: many slides of the window), ARGOS in double precision likewise
+    text, rep, calls, st, _ = _with_env({"PDT_WINDOW_PIECE": "370000"}, lambda: run("pieces"))
+    assert text == text0 and rep.tobytes() == rep0.tobytes() and st.segments == (len(iq) + 369999) // 370000
+    aq = pdt.synth_capture(1, 32000, 40.0, seed=77)
+    with pdt.Demodulator(pdt.MODE_ARGOS, 32000) as d:
+        d.demod(aq)
+        want = d.text()
+    def argos():
+        with pdt.Demodulator(pdt.MODE_ARGOS, 32000) as d:
+            d.demod(aq)
+            return d.text(), d.stats()
+    got, st = _with_env({"PDT_WINDOW_PIECE": "240000"}, argos)
+    assert got == want and len(want) > 100 and st.windowed == 1
+    # the host program: demodPOES -D PDT_HBM_LIMIT_MB=2048
+    exe = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "bin", "demodPOES")
+    outp = str(tmp_path / "cli.txt")
+    r = subprocess.run([exe, "-D", "PDT_HBM_LIMIT_MB=2048", "-o", outp, wav], capture_output=True, text=True)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    assert open(outp, "rb").read() == text0
+    r2 = subprocess.run([exe, "-D", "PDT_HBM_LIMIT_MB=64", "-o", outp, wav], capture_output=True, text=True)
+    assert r2.returncode != 0 and "Demodulation failed" in r2.stdout        # (not even a window of a few chunks fits 64 MB)
+
+
 @pytest.mark.timeout(300)
 @pytest.mark.parametrize("mode", ["plain", "overlapped"])
 def test_file_entry_errors_leave_the_context_usable(pdt, tmp_path, mode):

@@ -18,6 +18,11 @@ with tempfile.TemporaryDirectory(dir=shm, prefix="pdt_c3_") as tmp:
     out = os.path.join(tmp, "o.txt")
     t0 = time.time()
     par = pdt.synth_params(0, rate, 1000.0, 31)
+    if os.environ.get("PDT_PASS"):
+        # a pass as a receiver sees it (bench.py --config pass): noise, the signal rising out of it with its Doppler ramp and
+        # amplitude envelope, noise again -- the pre-lock sweep (CarrierTrackingPLL.c:232-246), the one-time lock and the loss of
+        # signal at full size
+        par = bench.capture_params(pdt, "pass", 31, secs)
     d_iq = bench.make_capture(pdt, par, n, min(32, os.cpu_count() or 8), device=torch.device("cuda", 0), wav_path=wav, fs=rate)
     print(f"synth {n} samples in {time.time() - t0:.1f} s", flush=True)
     cpu = subprocess.Popen([ref, wav, out], stdout=subprocess.PIPE, stderr=subprocess.PIPE) if have_ref else None
