@@ -18,9 +18,17 @@ LIBCOMPAT := $(CSRC)/libpdt_compat_poes.so $(CSRC)/libpdt_compat_argos.so
 
 all: $(LIBPDT) $(LIBSYNTH) $(LIBGATHER) $(LIBCOMPAT) bin/synth_wav bin/demodPOES bin/demodARGOS bin/demodMulti oracle
 
-LIBPDT_SRC := $(CSRC)/pdt_api.hip $(CSRC)/pdt_kernels_front.h $(CSRC)/pdt_kernels_back.h $(CSRC)/pdt_device_math.h $(CSRC)/pdt_sincostab.h $(CSRC)/pdt_timeaxis.h include/pdt.h
-$(LIBPDT): $(LIBPDT_SRC)
-	$(HIPCC) $(HIPFLAGS) -DPDT_BUILD_TAG="\"$$(cat $(LIBPDT_SRC) | sha1sum | cut -c1-12)\"" -shared -o $@ $(CSRC)/pdt_api.hip
+# libpdt.so = four translation units, compiled side by side (`make -j4`: two minutes; the device code of one unit is one single-threaded job
+# of the compiler: as ONE unit the library took six minutes): pdt_api (contexts, ingest, streaming, C ABI), the chain's launch
+# recording instantiated for float and for double with the kernels each launches, and the PLL kernels' slow-wrap variants
+LIBPDT_HDR := $(CSRC)/pdt_rt.h $(CSRC)/pdt_chain.inc $(CSRC)/pdt_kernels_front.h $(CSRC)/pdt_kernels_back.h $(CSRC)/pdt_device_math.h $(CSRC)/pdt_sincostab.h $(CSRC)/pdt_timeaxis.h include/pdt.h include/pdt_dev.h
+LIBPDT_UNITS := pdt_chain_f32 pdt_chain_f64 pdt_chain_wide_f32 pdt_chain_wide_f64 pdt_api
+LIBPDT_SRC := $(LIBPDT_UNITS:%=$(CSRC)/%.hip) $(LIBPDT_HDR)
+LIBPDT_OBJ := $(LIBPDT_UNITS:%=$(CSRC)/%.o)
+$(CSRC)/%.o: $(CSRC)/%.hip $(LIBPDT_HDR)
+	$(HIPCC) $(HIPFLAGS) -DPDT_BUILD_TAG="\"$$(cat $(LIBPDT_SRC) | sha1sum | cut -c1-12)\"" -c -o $@ $<
+$(LIBPDT): $(LIBPDT_OBJ)
+	$(HIPCC) --offload-arch=$(ARCH) -fPIC -shared -o $@ $(LIBPDT_OBJ)
 
 # RCCL gather of frame records (multi-GPU launcher): a library of its own, so that libpdt.so does not depend on RCCL
 $(LIBGATHER): $(CSRC)/pdt_gather.hip include/pdt_gather.h include/pdt.h $(LIBPDT)
@@ -56,7 +64,7 @@ oracle:
 	$(MAKE) -C oracle
 
 clean:
-	rm -f $(LIBPDT) $(LIBSYNTH) $(LIBGATHER) $(LIBCOMPAT) bin/*
+	rm -f $(LIBPDT) $(LIBPDT_OBJ) $(LIBSYNTH) $(LIBGATHER) $(LIBCOMPAT) bin/*
 	$(MAKE) -C oracle clean
 
 .PHONY: all oracle clean

@@ -1,551 +1,81 @@
 // pdt_api.hip -- libpdt.so: context management, kernel orchestration and the C ABI of
 // include/pdt.h.  Compiled for gfx950 only, with -ffp-contract=off (see pdt_device_math.h).
-#include <hip/hip_runtime.h>
-#include <math.h>
-#include <stdio.h>
-#include <stdlib.h>
-#include <string.h>
+#include "pdt_rt.h"
 
-#include <errno.h>
-#include <fcntl.h>
-#include <unistd.h>
-
-#include <algorithm>
-#include <functional>
-#include <map>
-#include <mutex>
-#include <atomic>
-#include <chrono>
-#include <memory>
-#include <new>
-#include <string>
-#include <thread>
-#include <type_traits>
-#include <vector>
-
-#include "../../include/pdt.h"
-#include "../../include/pdt_dev.h"
-#include "pdt_kernels_back.h"
-#include "pdt_kernels_front.h"
-#include "pdt_timeaxis.h"
-
-using namespace pdt;
+namespace pdtrt {
+PDT_CHAIN_INSTANCES(extern, float)
+PDT_CHAIN_INSTANCES(extern, double)
+std::atomic<long long> g_alloc_ns{0};
+}  // namespace pdtrt
 
 static std::atomic<int> g_open_contexts{0};          // contexts alive in this process (pdt_open / pdt_close)
 // One ingest per GPU at a time.  Two contexts on one GPU (bin/demodMulti's two lanes) that read their captures at once would
 // share the PCIe link and both arrive late; taking turns, the second one's capture arrives while the first one's chain runs.
 static std::mutex g_link_mu[64];
 
-#define HIP_TRY(expr)                                                                                  \
-    do {                                                                                               \
-        hipError_t e_ = (expr);                                                                        \
-        if (e_ != hipSuccess) {                                                                        \
-            fprintf(stderr, "libpdt: %s failed: %s (%s:%d)\n", #expr, hipGetErrorString(e_), __FILE__, \
-                    __LINE__);                                                                         \
-            return PDT_ERR_NOGPU;                                                                      \
-        }                                                                                              \
-    } while (0)
-
-namespace {
-
-// host time this process has spent allocating device and pinned memory (pdt_stats.alloc_ms: the cold path's breakdown)
-static std::atomic<long long> g_alloc_ns{0};
-struct AllocTimer {
-    std::chrono::steady_clock::time_point t0 = std::chrono::steady_clock::now();
-    ~AllocTimer() { g_alloc_ns += std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now() - t0).count(); }
-};
-static hipError_t timed_host_malloc(void **p, size_t bytes)
-{
-    AllocTimer t;
-    return hipHostMalloc(p, bytes, hipHostMallocDefault);
-}
-
-struct DevBuf {
-    void *p = nullptr;
-    size_t cap = 0;
-    int ensure(size_t bytes)
-    {
-        if (bytes <= cap) return PDT_OK;
-        AllocTimer t;
-        if (p) (void)hipFree(p);
-        p = nullptr;
-        cap = 0;
-        size_t want = bytes + bytes / 16 + 4096;
-        if (hipMalloc(&p, want) != hipSuccess) {
-            (void)hipGetLastError();
-            return PDT_ERR_NOMEM;
-        }
-        cap = want;
-        return PDT_OK;
-    }
-    // grow, keeping the first `keep` bytes (the windows of a stream hold history the next segment reads)
-    int ensure_keep(size_t bytes, size_t keep)
-    {
-        if (bytes <= cap) return PDT_OK;
-        AllocTimer t;
-        void *np = nullptr;
-        const size_t want = bytes + bytes / 4 + 4096;
-        if (hipMalloc(&np, want) != hipSuccess) {
-            (void)hipGetLastError();
-            return PDT_ERR_NOMEM;
-        }
-        if (p && keep) (void)hipMemcpy(np, p, std::min(keep, cap), hipMemcpyDeviceToDevice);
-        if (p) (void)hipFree(p);
-        p = np;
-        cap = want;
-        return PDT_OK;
-    }
-    void release()
-    {
-        if (p) (void)hipFree(p);
-        p = nullptr;
-        cap = 0;
-    }
-};
-
-struct KTimer {
-    std::string name;
-    hipEvent_t a, b;
-    bool shared_a = false;      // a is the previous group's b (returned to the pool once)
-};
-
-// device-side scalar block shared by all stages of one run
-struct DevScalars {
-    unsigned long long nsym;
-    unsigned long long nbits;
-    unsigned nhits;
-    unsigned nframes;
-    unsigned counters[4];   // pll blocks, pll fixes, agc blocks, agc fixes
-    unsigned sync_overflow; // a 4096-bit tile held more than 31 sync hits: generic path used
-    unsigned pad0_;
-    unsigned gstats[4];     // boundary-state tables: [0] exits outside the domain, [1] full-domain chunks,
-                            //                        [2] chunks the chain had to walk, [3] unused
-    double norm;            // storage for the normalisation factor (float or double)
-    long long agc_first_bad; // first AGC seam that does not close (k_agc_scan -> k_agc_fix)
-    PllPhaseHint phase_hint;     // k_pll_phase -> k_pll_head: workgroups finished, the clock at its start (walk on while it runs)
-};
-
-// ---------------------------------------------------------------- launch plans
-// Every kernel of pdt_kernels_*.h is a __device__ body; it is entered through k_run, which reads the body's
-// arguments from a device array of argument packs indexed by blockIdx.z = the capture.  A demodulation call first
-// records its launches, memsets, stream fork/joins and read-back copies as a PLAN (host only); the plan is then
-// executed -- alone (grid.z = 1) or zipped with the plans of other captures of the same shape (grid.z = M): ONE launch per
-// stage for the whole batch, so that the serial, few-wavefront kernels of all captures run side by side instead of queueing
-// behind each other on the hardware queues (batched many-capture mode).
-template <typename... A> struct Pack {};
-template <typename H, typename... R> struct Pack<H, R...> { H h; Pack<R...> r; };
-template <typename Sig> struct BodyTraits;
-template <typename... P> struct BodyTraits<void (*)(P...)> { using pack = Pack<P...>; };
-
-// Pointers that arrive through the pack are device-memory addresses; say so (address space 1), as the compiler does by itself
-// for pointer kernel arguments: otherwise every access through them is a flat access (no scalar loads of uniform data,
-// no global_load addressing modes) -- measured: FIR 0.26 -> 0.50 ms, PLL phase 0.97 -> 1.19 ms.
-template <typename H> __device__ __forceinline__ H as_global(H v)
-{
-    if constexpr (std::is_pointer<H>::value) {
-        using E = typename std::remove_pointer<H>::type;
-        __attribute__((address_space(1))) E *g = (__attribute__((address_space(1))) E *)v;
-        asm("" : "+s"(g));      // opaque (and still uniform): the optimizer would fold the cast pair away
-        return (H)g;
-    } else {
-        return v;
-    }
-}
-__device__ __forceinline__ IqSrc as_global(IqSrc v)
-{
-    v.p = as_global(v.p);
-    return v;
-}
-template <typename T> __device__ __forceinline__ AgcParams<T> as_global(AgcParams<T> v)
-{
-    v.raw_out = as_global(v.raw_out);
-    return v;
-}
-
-template <auto Body, typename... Done>
-__device__ __forceinline__ void call_body(const Pack<> &, Done... d) { Body(d...); }
-template <auto Body, typename H, typename... R, typename... Done>
-__device__ __forceinline__ void call_body(const Pack<H, R...> &p, Done... d) { call_body<Body>(p.r, d..., as_global(p.h)); }
-
-template <auto Body, int TB>
-__global__ void __launch_bounds__(TB) k_run(const typename BodyTraits<decltype(Body)>::pack *__restrict__ packs)
-{
-    call_body<Body>(packs[blockIdx.z]);
-}
-
-inline void pack_fill(Pack<> &) {}
-template <typename H, typename... R, typename A0, typename... AR> void pack_fill(Pack<H, R...> &p, A0 &&a0, AR &&...ar)
-{
-    p.h = (H)a0;
-    pack_fill(p.r, ar...);
-}
-
-typedef void (*GoFn)(dim3, dim3, size_t, hipStream_t, const void *);
-enum { OP_LAUNCH, OP_MEMSET, OP_FORK, OP_JOIN_RECORD, OP_JOIN_WAIT, OP_TBEGIN, OP_TEND, OP_TGAP, OP_D2H, OP_H2D, OP_EV0, OP_EV1 };
-struct PlanOp {
-    int op = OP_LAUNCH, side = 0;
-    GoFn go = nullptr;
-    dim3 grid, block;
-    size_t shmem = 0, pack_off = 0, pack_size = 0;
-    void *dst = nullptr;
-    const void *src = nullptr;
-    int value = 0;
-    size_t bytes = 0;
-    const char *name = nullptr;
-};
-struct Plan {
-    std::vector<PlanOp> ops;
-    std::vector<unsigned char> packs;
-    hipStream_t side_stream = nullptr;             // the context's second stream (launch sites name streams, the plan keeps sides)
-    void clear() { ops.clear(); packs.clear(); }
-    int side_of(hipStream_t s) const { return (side_stream && s == side_stream) ? 1 : 0; }
-    template <auto Body, int TB, typename... A> void launch(const char *kname, dim3 grid, dim3 block, size_t shmem, int side, A &&...args)
-    {
-        using PackT = typename BodyTraits<decltype(Body)>::pack;
-        static_assert(std::is_trivially_copyable<PackT>::value, "kernel arguments travel as plain bytes");
-        PackT pk;
-        memset((void *)&pk, 0, sizeof pk);
-        pack_fill(pk, args...);
-        PlanOp o;
-        o.op = OP_LAUNCH;
-        o.name = kname;
-        o.side = side;
-        o.grid = grid;
-        o.block = block;
-        o.shmem = shmem;
-        o.pack_off = (packs.size() + 15) & ~(size_t)15;
-        o.pack_size = sizeof(PackT);               // the stride k_run indexes the batch's packs with
-        static_assert(alignof(PackT) <= 16, "pack alignment");
-        packs.resize(o.pack_off + o.pack_size, 0);
-        memcpy(packs.data() + o.pack_off, &pk, sizeof pk);
-        o.go = [](dim3 g, dim3 b, size_t sh, hipStream_t st, const void *dp) {
-            hipLaunchKernelGGL((k_run<Body, TB>), g, b, sh, st, (const PackT *)dp);
-        };
-        ops.push_back(o);
-    }
-    void simple(int op, int side = 0, const char *name = nullptr)
-    {
-        PlanOp o;
-        o.op = op; o.side = side; o.name = name;
-        ops.push_back(o);
-    }
-    void memset_async(void *dst, int value, size_t bytes, int side = 0)
-    {
-        PlanOp o;
-        o.op = OP_MEMSET; o.side = side; o.dst = dst; o.value = value; o.bytes = bytes;
-        ops.push_back(o);
-    }
-    void copy(int op, void *dst, const void *src, size_t bytes)
-    {
-        PlanOp o;
-        o.op = op; o.dst = dst; o.src = src; o.bytes = bytes;
-        ops.push_back(o);
-    }
-    // two plans can share their launches when they are the same sequence of operations with the same kernels, block
-    // shapes and LDS sizes (grids may differ: the larger one is launched and every body checks its own bounds)
-    bool same_shape(const Plan &o) const
-    {
-        if (ops.size() != o.ops.size() || packs.size() != o.packs.size()) return false;
-        for (size_t i = 0; i < ops.size(); i++) {
-            const PlanOp &a = ops[i], &b = o.ops[i];
-            if (a.op != b.op || a.side != b.side || a.go != b.go || a.block.x != b.block.x || a.block.y != b.block.y ||
-                a.shmem != b.shmem || a.pack_off != b.pack_off || a.pack_size != b.pack_size)
-                return false;
-        }
-        return true;
-    }
-};
-#define PDT_LAUNCH(TB, KERNEL, grid, block, shmem, stream, ...) \
-    PL.launch<&KERNEL, TB>(#KERNEL, grid, block, shmem, PL.side_of(stream), __VA_ARGS__)
-
-}  // namespace
-
-// Developer switches (A/B runs of older kernel variants, tuning sweeps).  The library never reads the environment: the
-// switches come from a process-wide registry that only the TEST-ONLY entry pdt_dev_set fills (include/pdt_dev.h; the Python
-// binding used by tests/ and bench.py mirrors the PDT_* environment variables into it), and a context takes its copy ONCE,
-// when it is opened.
 static std::mutex g_dev_mu;
 static std::map<std::string, std::string> g_dev;
-struct Tuning {
-    double band_pad = 0.0, pll_warm_scale = 1.0, head_taus = 0.0, agc_k = 0.0, pll_warm_s = 0.0, agc_warm_s = 0.0;
-    double overlap_split[8] = { 0, 0, 0, 0, 0, 0, 0, 0 };
-    long long hbm_limit_mb = 0, window_piece = 0;
-    int scout_syms = 0, gspan = 0, gspan_cap = 0, ingest_threads = 0, ingest_span_mb = 0, ingest_streams = 0, overlap_segments = 0, overlap_min_mb = 0, fir_wg_per_cu = 0, agc_tpb = 0, gseg = 0, pll_block = 0, fix_passes = 2;
-    bool fir_generic = false, mix_unfused = false, quality_inline = false, gemit_groups = false, agc_unfused = false, no_excl = false, gardner_onebuf = false, gardner_noring = false, gardner_sequential = false, seg_sequential = false, agc_lanes = false, overlap = true, debug_overlap = false, chain_one_range = false, ema_noguess = false, debug_sync = false, pll_noshort = false, pll_nockpt = false, pll_noconsensus = false, seg_plain = false, sync_block = false, gardner_nostride = false;
-    void load()
-    {
-        std::lock_guard<std::mutex> lock(g_dev_mu);
-        if (g_dev.empty()) return;
-        auto get = [&](const char *n) -> const char * { auto it = g_dev.find(n); return it == g_dev.end() ? nullptr : it->second.c_str(); };
-        if (const char *e = get("PDT_PLL_WARM_SCALE")) pll_warm_scale = atof(e);
-        if (const char *e = get("PDT_HEAD_TAUS")) head_taus = atof(e);
-        if (const char *e = get("PDT_BAND_PAD")) band_pad = atof(e);
-        if (const char *e = get("PDT_PLL_WARM_S")) pll_warm_s = atof(e);
-        if (const char *e = get("PDT_AGC_WARM_S")) agc_warm_s = atof(e);
-        if (const char *e = get("PDT_AGC_K")) agc_k = atof(e);
-        if (const char *e = get("PDT_AGC_TPB")) agc_tpb = std::max(1, atoi(e));
-        if (const char *e = get("PDT_PLL_BLOCK")) pll_block = atoi(e);
-        if (const char *e = get("PDT_HBM_LIMIT_MB")) hbm_limit_mb = std::max(1ll, atoll(e));        // (tests: pretend the device has this much free memory)
-        if (const char *e = get("PDT_WINDOW_PIECE")) window_piece = std::max(1ll, atoll(e));          // (tests: samples per piece of the bounded window)
-        if (const char *e = get("PDT_SCOUT_SYMS")) scout_syms = std::max(16, atoi(e));
-        if (const char *e = get("PDT_FIR_WG_PER_CU")) fir_wg_per_cu = std::min(4096, std::max(1, atoi(e)));
-        if (const char *e = get("PDT_INGEST_THREADS")) ingest_threads = std::min(128, std::max(1, atoi(e)));
-        if (const char *e = get("PDT_INGEST_SPAN_MB")) ingest_span_mb = std::min(256, std::max(1, atoi(e)));
-        if (const char *e = get("PDT_INGEST_STREAMS")) ingest_streams = std::min(4, std::max(1, atoi(e)));
-        if (const char *e = get("PDT_FIX_PASSES")) fix_passes = atoi(e);
-        if (const char *e = get("PDT_GSEG")) gseg = std::min(64, std::max(2, atoi(e)));
-        if (const char *e = get("PDT_GSPAN")) gspan = std::min(256, std::max(1, atoi(e)));
-        if (const char *e = get("PDT_GSPAN_CAP")) gspan_cap = std::max(64, atoi(e));          // (tests: rows that do not fit the key list)
-        fir_generic = get("PDT_FIR_GENERIC") != nullptr;
-        mix_unfused = get("PDT_MIX_UNFUSED") != nullptr;
-        quality_inline = get("PDT_QUALITY_INLINE") != nullptr;
-        gardner_nostride = get("PDT_GARDNER_NOSTRIDE") != nullptr;
-        gemit_groups = get("PDT_GEMIT_GROUPS") != nullptr;
-        agc_unfused = get("PDT_AGC_UNFUSED") != nullptr;
-        agc_lanes = get("PDT_AGC_LANES") != nullptr;           // the per-lane walkers of rounds 1 - 3 (k_agc_block)
-        no_excl = get("PDT_NO_EXCL") != nullptr;
-        gardner_onebuf = get("PDT_GARDNER_ONEBUF") != nullptr;
-        gardner_noring = get("PDT_GARDNER_NORING") != nullptr;
-        ema_noguess = get("PDT_EMA_NOGUESS") != nullptr;
-        gardner_sequential = get("PDT_GARDNER_SEQUENTIAL") != nullptr;
-        seg_sequential = get("PDT_SEG_SEQUENTIAL") != nullptr;
-        overlap = get("PDT_NO_OVERLAP") == nullptr;            // (round 4: off unless PDT_OVERLAP; round 5: on)
-        if (const char *e = get("PDT_OVERLAP_SPLIT")) {          // "0.64,0.22,0.14": the segments' fractions of the capture
-            int k = 0;
-            for (const char *q = e; *q && k < 8; k++) {
-                char *end = nullptr;
-                overlap_split[k] = strtod(q, &end);
-                if (end == q) break;
-                q = (*end == ',') ? end + 1 : end;
-            }
-        }
-        chain_one_range = get("PDT_CHAIN_ONE_RANGE") != nullptr;
-        debug_overlap = get("PDT_DEBUG_OVERLAP") != nullptr;
-        if (const char *e = get("PDT_OVERLAP_SEGMENTS")) overlap_segments = std::min(64, std::max(1, atoi(e)));
-        if (const char *e = get("PDT_OVERLAP_MIN_MB")) overlap_min_mb = std::min(1 << 20, std::max(1, atoi(e)));
-        debug_sync = get("PDT_DEBUG_SYNC") != nullptr;
-        pll_noshort = get("PDT_PLL_NOSHORT") != nullptr;
-        pll_nockpt = get("PDT_PLL_NOCKPT") != nullptr;
-        pll_noconsensus = get("PDT_PLL_NOCONSENSUS") != nullptr;
-        seg_plain = get("PDT_SEG_PLAIN") != nullptr;
-        sync_block = get("PDT_SYNC_BLOCK") != nullptr;
-    }
-};
-
-// A stream is demodulated segment by segment (whole reference chunks).  Between segments every stage's exact state is
-// carried here -- T values as doubles (exact for float and double) -- and the device keeps a bounded window of the input
-// and of the few streams a later segment looks back on.
-struct StreamCarry {
-    bool active = false;          // run_capture works on a window of a stream
-    bool final_seg = false;       // the stream ends with this segment (short last chunk, partial frame reported)
-    bool in_place = false;        // the whole capture has its place in the window (pdt_demod_fd of a large file): never slides
-    uint64_t place_align = 0;     // in place: the grid the window's origin stays on (0 = stream_align)
-    bool quality = false;         // in place: the segments keep the per-chunk reports (pdt_keep_quality; chunk-aligned cuts)
-    long long first = 0;          // local index of the first new input sample (a multiple of the chunk)
-    uint64_t origin = 0;          // global sample index of local sample 0 (a multiple of lcm(chunk, FIR ring length))
-    // StaticGain / AGC
-    bool have_norm = false;
-    double norm_factor = 0, gain = 0;
-    // PLL
-    bool locked = false;
-    double phase = 0, freq = 0, avg = 0, locksig = 0, sweep = 0;
-    int64_t lock_sample = -1;     // global
-    double lock_freq_hz = 0, avg_at_lock = 0;
-    // symbol sampler (Gardner: nextSample, prev, halfSample; M&M: nextSample, stepSize, sampleLast)
-    bool have_sampler = false;
-    double sa = 0, sb = 0, sc = 0;
-    // Manchester
-    double sym_m2 = 0, sym_m1 = 0;
-    unsigned clockmod = 0;
-    uint64_t nsym_total = 0;
-    // byte sync: the last bits (from the sync word of a frame still open, else the last len-1), their time sources
-    std::vector<unsigned char> kept_bits;
-    std::vector<long long> kept_src;           // global interpolated-sample index per kept bit
-    uint64_t bit_base = 0;                     // global index of kept_bits[0]
-    uint64_t nbits_total = 0;
-    long long next_free = 0;                   // global bit index before which no new frame may open
-    bool have_pending = false;                 // an incomplete frame at the end of the last segment
-    pdt_frame pending;
-    // per segment, filled by run_capture for the stream code
-    std::vector<pdt_frame> seg_frames;
-    uint64_t seg_new_symbols = 0, seg_new_bits = 0;
-};
-
-struct pdt_ctx {
-    pdt_config cfg;
-    pdt_loop_params lp = {};     // pdt_set_loop_params: 0 = the mains' constant
-    Tuning tune;
-    StreamCarry sc;
-    int elem;                 // sizeof(DT)
-    uint32_t interp, ntaps;
-    hipStream_t stream = nullptr;
-    bool own_stream = false;
-    hipEvent_t ev0 = nullptr, ev1 = nullptr, ev_fork = nullptr, ev_join = nullptr;
-    hipStream_t stream2 = nullptr;     // side stream: block-parallel PLL phase runs beside the sequential acquisition
-
-    DevBuf pcm, pll, lock, fir, agc, sym, symidx, bits, bitsym, hits, frames, taps, mag, seams_pll, seams_agc, scal, lockinfo, term, seams_ema, gtable, gentries, gcand, gmfirst, stiles, gsegmap, gsegstart, gbands, gclist, gneed, gchain, gspan_keys, gspan_tails, gspan_rows, gspan_items, gspan_ctl, gspan_recs, gcentries, gflags, agc_maps, pll_head, taps_rot, pll_scratch, tip, sync_scr, agc_raw, agc_ckpt, pll_ckpt;
-    bool counted = false;        // this context is in g_open_contexts
-    bool keep_agc_raw = false;   // pdt_keep_presquelch: also keep the AGC output before Squelch (stage PDT_ST_AGC_RAW)
-    // pdt_keep_quality: the averagePhase stream (what CarrierTrackPLL returns, chunk by chunk) and the per-chunk counts
-    bool keep_quality = false;
-    bool keep_pll_asked = false; // pdt_keep_pll(ctx, 1) was called: the caller reads the PLL stream -- one piece, no overlapped segments
-    bool keep_pll = true;        // pdt_keep_pll: the PLL output stream (stage PDT_ST_PLL) is written out although only the filter reads it
-    DevBuf avgph, term_ap, seams_q, chunkinfo;
-    // pdt_stage_pll: the next run starts the PLL from this state, keeps the lock and averagePhase streams and stops after the PLL
-    struct PllInject {
-        bool active = false, started = false, locked = false;
-        double phase = 0, freq = 0, avg = 0, locksig = 0, sweep = 0;
-    } inj;
-    long long last_pll_block = 0;       // PLL block length of the last run (where the end state sits in seams_pll)
-    void *qual_pin = nullptr;
-    size_t qual_pin_cap = 0;
-    uint64_t pend_chunks = 0;           // ChunkInfo records in flight (0 = none asked for)
-    std::vector<pdt::ChunkInfo> chunk_host;      // per chunk of the capture, counts cumulative from its first sample
-    uint64_t report_samples = 0;        // length of the capture the reports describe
-    pdt_progress_fn progress_fn = nullptr;
-    void *progress_user = nullptr;
-    // (stream_in is declared with the streaming state below)
-    long long gcand_key = -1;          // (chunk_out, step) the candidate list on the device was built for
-    int gardner_mode = 0;              // 0 sequential, 1 state table (last run)
-    const void *pcm_dev = nullptr;     // input actually used (own copy or caller's buffer)
-    int pcm_fmt = 0;                   // 0 = int16 pairs, 1 = float32 pairs
-
-    std::vector<unsigned char> taps_host;
-    // results
-    uint64_t n_samples = 0, n_out = 0;
-    std::vector<pdt_frame> frames_host;
-    std::vector<pdt_tip_frame> tip_host;
-    uint32_t frames_on_device = 0;      // FrameRec records of the last demodulation still in ctx->frames
-    bool have_frames = false;           // a demodulation (or stage-level byte sync) has run
-    // streaming front end: everything received so far (device), what has been reported
-    Plan plan;                          // the operations of the demodulation call being issued
-    DevBuf packs_dev;                   // argument packs of the plan(s) being executed (this context leads the batch)
-    void *packs_pin = nullptr;          // pinned staging of the same
-    size_t packs_pin_cap = 0;
-    pdt_ctx *leader = nullptr;          // context whose streams / events carried the last execution
-    int batch_hint = 1;                 // captures demodulated together with this one (sizes the block-parallel geometry)
-    // host -> HBM ingest of a capture (file or memory): pinned slots filled by a few host threads, copies on a stream of their own
-    void *ingest_pin = nullptr;
-    size_t ingest_pin_cap = 0;
-    hipStream_t copy_stream = nullptr, copy_streams_more[3] = { nullptr, nullptr, nullptr };   // span copies go round robin over them
-    hipEvent_t ev_ingest = nullptr, ev_ingest_more[3] = { nullptr, nullptr, nullptr };
-    std::vector<hipEvent_t> ingest_ev, span_ev;      // per pinned slot; per span (overlapped ingest)
-    double stream_gpu_ms = 0;
-    double ingest_ms = 0;               // host wall time of the last ingest (issue of the last copy)
-    DevBuf stream_in, seg_dev, lt_theta, lt_phi;          // input window of the stream; small device block for the segment's carried-out state
-    uint64_t stream_have = 0, stream_done = 0;   // samples in the window / of them already demodulated (local indices)
-    uint64_t stream_total = 0;          // samples pushed since pdt_stream_begin
-    int stream_fmt = -1;                // -1 = no push yet, 0 = pcm16, 1 = float32
-    bool stream_open = false;           // between the first push and pdt_stream_end / _begin: the stage buffers hold the tails the next push continues from
-    std::vector<pdt_frame> stream_new;
-    unsigned char *seg_pin = nullptr;   // pinned staging for the small per-segment transfers (part of the pend_sc block)
-    pdt_stats stats;
-    std::vector<pdt_kernel_time> ktimes;
-    std::vector<KTimer> timers;
-    std::vector<hipEvent_t> event_pool;
-    void *pinned = nullptr;             // pinned staging buffer for the frame records
-    size_t pinned_cap = 0;
-    uint32_t last_nframes = 0;
-    // results in flight between the enqueue and the finish phase of a capture
-    DevScalars *pend_sc = nullptr;      // both in one small pinned block (pageable targets would make the
-    unsigned char *pend_info = nullptr; // "asynchronous" read-back copies wait for the stream)
-    uint32_t pend_got_frames = 0;
-    uint64_t pend_n = 0;
-    bool pending = false;
-    uint64_t stage_len[PDT_ST_COUNT];
-    TimeAxis<float> axis_f;
-    TimeAxis<double> axis_d;
-};
-
-namespace {
-
-// ---------------------------------------------------------------- FIR taps (LowPassFilter.c:127-175)
-// Evaluated on the host with the operations the reference performs (sinf / sin of the sinc argument, cos in the Blackman
-// window) -- through this library's own restatements of those C-library functions (pdt_device_math.h), so that the taps do
-// not depend on the libm of the machine the library runs on.
-template <typename T> void make_lpf(T *h, int N, T Fc, T Fs, int interp)
+void Tuning::load()
 {
-    const T Tt = (T)(1.0 / (double)Fs);
-    const T wc = (T)(2.0 * M_PI * (double)Fc * (double)Tt);
-    const T tou = (T)((N - 1.0) / 2.0);
-    for (int n = 0; n < N; n++) {
-        const T arg = wc * ((T)n - tou);
-        T sv;
-        if (sizeof(T) == 4) {
-            float sf, cf;
-            sincosf_glibc((float)arg, sf, cf);          // sinf: the sine half of glibc's shared sinf / sincosf evaluation
-            sv = (T)sf;
-        } else {
-            sv = (T)sin_glibc((double)arg);
+    std::lock_guard<std::mutex> lock(g_dev_mu);
+    if (g_dev.empty()) return;
+    auto get = [&](const char *n) -> const char * { auto it = g_dev.find(n); return it == g_dev.end() ? nullptr : it->second.c_str(); };
+    if (const char *e = get("PDT_PLL_WARM_SCALE")) pll_warm_scale = atof(e);
+    if (const char *e = get("PDT_HEAD_TAUS")) head_taus = atof(e);
+    if (const char *e = get("PDT_BAND_PAD")) band_pad = atof(e);
+    if (const char *e = get("PDT_PLL_WARM_S")) pll_warm_s = atof(e);
+    if (const char *e = get("PDT_AGC_WARM_S")) agc_warm_s = atof(e);
+    if (const char *e = get("PDT_AGC_K")) agc_k = atof(e);
+    if (const char *e = get("PDT_AGC_TPB")) agc_tpb = std::max(1, atoi(e));
+    if (const char *e = get("PDT_PLL_BLOCK")) pll_block = atoi(e);
+    if (const char *e = get("PDT_HBM_LIMIT_MB")) hbm_limit_mb = std::max(1ll, atoll(e));        // (tests: pretend the device has this much free memory)
+    if (const char *e = get("PDT_WINDOW_PIECE")) window_piece = std::max(1ll, atoll(e));          // (tests: samples per piece of the bounded window)
+    if (const char *e = get("PDT_SCOUT_SYMS")) scout_syms = std::max(16, atoi(e));
+    if (const char *e = get("PDT_FIR_WG_PER_CU")) fir_wg_per_cu = std::min(4096, std::max(1, atoi(e)));
+    if (const char *e = get("PDT_INGEST_THREADS")) ingest_threads = std::min(128, std::max(1, atoi(e)));
+    if (const char *e = get("PDT_INGEST_SPAN_MB")) ingest_span_mb = std::min(256, std::max(1, atoi(e)));
+    if (const char *e = get("PDT_INGEST_STREAMS")) ingest_streams = std::min(4, std::max(1, atoi(e)));
+    if (const char *e = get("PDT_FIX_PASSES")) fix_passes = atoi(e);
+    if (const char *e = get("PDT_GSEG")) gseg = std::min(64, std::max(2, atoi(e)));
+    if (const char *e = get("PDT_GSPAN")) gspan = std::min(256, std::max(1, atoi(e)));
+    if (const char *e = get("PDT_GSPAN_CAP")) gspan_cap = std::max(64, atoi(e));          // (tests: rows that do not fit the key list)
+    fir_generic = get("PDT_FIR_GENERIC") != nullptr;
+    mix_unfused = get("PDT_MIX_UNFUSED") != nullptr;
+    quality_inline = get("PDT_QUALITY_INLINE") != nullptr;
+    gardner_nostride = get("PDT_GARDNER_NOSTRIDE") != nullptr;
+    gemit_groups = get("PDT_GEMIT_GROUPS") != nullptr;
+    agc_unfused = get("PDT_AGC_UNFUSED") != nullptr;
+    agc_lanes = get("PDT_AGC_LANES") != nullptr;           // the per-lane walkers of rounds 1 - 3 (k_agc_block)
+    no_excl = get("PDT_NO_EXCL") != nullptr;
+    gardner_onebuf = get("PDT_GARDNER_ONEBUF") != nullptr;
+    gardner_noring = get("PDT_GARDNER_NORING") != nullptr;
+    ema_noguess = get("PDT_EMA_NOGUESS") != nullptr;
+    gardner_sequential = get("PDT_GARDNER_SEQUENTIAL") != nullptr;
+    seg_sequential = get("PDT_SEG_SEQUENTIAL") != nullptr;
+    overlap = get("PDT_NO_OVERLAP") == nullptr;            // (round 4: off unless PDT_OVERLAP; round 5: on)
+    if (const char *e = get("PDT_OVERLAP_SPLIT")) {          // "0.64,0.22,0.14": the segments' fractions of the capture
+        int k = 0;
+        for (const char *q = e; *q && k < 8; k++) {
+            char *end = nullptr;
+            overlap_split[k] = strtod(q, &end);
+            if (end == q) break;
+            q = (*end == ',') ? end + 1 : end;
         }
-        T hd = (T)((double)sv / (M_PI * (double)((T)n - tou)));
-        if (((T)n == tou) && ((N / 2) * 2 != N)) hd = (T)((double)wc / M_PI);
-        const T wn = (T)(0.42 - 0.5 * cos_glibc((2 * M_PI * n) / (N - 1)) + 0.08 * cos_glibc((4 * M_PI * n) / (N - 1)));
-        h[n] = hd * wn * (T)interp;
     }
+    chain_one_range = get("PDT_CHAIN_ONE_RANGE") != nullptr;
+    debug_overlap = get("PDT_DEBUG_OVERLAP") != nullptr;
+    if (const char *e = get("PDT_OVERLAP_SEGMENTS")) overlap_segments = std::min(64, std::max(1, atoi(e)));
+    if (const char *e = get("PDT_OVERLAP_MIN_MB")) overlap_min_mb = std::min(1 << 20, std::max(1, atoi(e)));
+    debug_sync = get("PDT_DEBUG_SYNC") != nullptr;
+    pll_noshort = get("PDT_PLL_NOSHORT") != nullptr;
+    pll_nockpt = get("PDT_PLL_NOCKPT") != nullptr;
+    pll_noconsensus = get("PDT_PLL_NOCONSENSUS") != nullptr;
+    pll_notail = get("PDT_PLL_NOTAIL") != nullptr;
+    seg_plain = get("PDT_SEG_PLAIN") != nullptr;
+    sync_block = get("PDT_SYNC_BLOCK") != nullptr;
 }
 
-int poes_interp(uint32_t rate) { return (int)rint(150000.0 / (double)(float)rate); }   // POESTIPdemod/main.c:347
-
-class Launcher {
-  public:
-    Launcher(pdt_ctx *c) : ctx(c) {}
-    // profile mode: one event per group boundary -- a group that starts right where the previous one ended on
-    // the same stream shares that event (every recorded event is a small gap in the stream)
-    void begin(const char *name, hipStream_t s = nullptr)
-    {
-        if (!ctx->cfg.profile) return;
-        KTimer t;
-        t.name = name;
-        cur = s ? s : ctx->stream;
-        if (have_last && last_stream == cur) {
-            t.a = last_b;
-            t.shared_a = true;
-        } else {
-            t.a = take();
-            t.shared_a = false;
-            (void)hipEventRecord(t.a, cur);
-        }
-        t.b = take();
-        ctx->timers.push_back(t);
-        open_idx = ctx->timers.size() - 1;
-        have_last = false;
-    }
-    void end()
-    {
-        if (!ctx->cfg.profile) return;
-        (void)hipEventRecord(ctx->timers[open_idx].b, cur);
-        last_b = ctx->timers[open_idx].b;
-        last_stream = cur;
-        have_last = true;
-    }
-    // work enqueued outside any group (copies, memsets, stream waits) breaks the sharing
-    void gap() { have_last = false; }
-
-  private:
-    hipEvent_t take()
-    {
-        hipEvent_t e;
-        if (!ctx->event_pool.empty()) { e = ctx->event_pool.back(); ctx->event_pool.pop_back(); }
-        else (void)hipEventCreate(&e);
-        return e;
-    }
-    pdt_ctx *ctx;
-    hipStream_t cur = nullptr, last_stream = nullptr;
-    hipEvent_t last_b = nullptr;
-    bool have_last = false;
-    size_t open_idx = 0;
-};
-
-// run_capture records its timer groups into the plan; the Launcher above turns them into events when the plan runs
-struct PlanGroups {
-    Plan &pl;
-    bool on;
-    void begin(const char *name, hipStream_t s = nullptr) { if (on) pl.simple(OP_TBEGIN, pl.side_of(s), name); }
-    void end() { if (on) pl.simple(OP_TEND); }
-    void gap() { if (on) pl.simple(OP_TGAP); }
-};
-
+namespace pdtrt {
 
 // Run the plans of M contexts (all of one shape, see Plan::same_shape) as one sequence of operations on the streams of
 // ctxs[0]: each launch covers the M captures through grid.z, memsets and copies are issued per capture.  No host wait.
@@ -632,90 +162,8 @@ int execute_plans(pdt_ctx *const *ctxs, int M)
     return PDT_OK;
 }
 
-template <typename T> PllParams<T> make_pll_params(const pdt_ctx *ctx)
-{
-    // call-site constants: POESTIPdemod/main.c:32-46,413 / ARGOSdemod/main.c:33-44,265
-    PllParams<T> P;
-    const T Fs = (T)ctx->cfg.sample_rate;
-    const bool argos = ctx->cfg.mode == PDT_MODE_ARGOS;
-    const bool live = !argos && ctx->cfg.chain == PDT_CHAIN_LIVE;        // POESTIPdemodPortAudio/main.c:41-57
-    const pdt_loop_params &lp = ctx->lp;                                  // (what the caller's CarrierTrackPLL would have been handed)
-    const T freqRange = lp.pll_freq_range_hz != 0 ? (T)lp.pll_freq_range_hz : argos ? (T)550.0 : (T)4500.0;
-    const double w = 2.0 * M_PI / (double)Fs;
-    const T bw_acq = lp.pll_loopbw_acq != 0 ? (T)lp.pll_loopbw_acq : (T)((argos ? 16.0 : live ? 198.9437 : 127.3240) * w);
-    const T bw_trk = lp.pll_loopbw_track != 0 ? (T)lp.pll_loopbw_track : (T)((argos ? 16.0 : 10.3451) * w);
-    P.Fs = Fs;
-    P.lock_thr = (lp.pll_lock_threshold != 0 || (lp.zero_mask & PDT_LP_ZERO_LOCK_THRESHOLD)) ? (T)lp.pll_lock_threshold : argos ? (T)0.1 : live ? (T)0.10 : (T)0.08;
-    P.lock_alpha = lp.pll_lock_alpha != 0 ? (T)lp.pll_lock_alpha : (T)((argos ? 3.1831 : 0.3979) * w);
-    const T damp = (T)0.999;
-    const T four = 4, one = 1, two = 2;
-    P.alpha_acq = (four * damp * bw_acq) / (one + two * damp * bw_acq + bw_acq * bw_acq);     // :90-91, all DT
-    P.beta_acq = (four * bw_acq * bw_acq) / (one + two * damp * bw_acq + bw_acq * bw_acq);
-    const double dd = (double)damp, db = (double)bw_trk;
-    P.alpha_trk = (T)((4.0 * dd * db) / (1.0 + 2.0 * dd * db + (double)(bw_trk * bw_trk)));   // :272-273, double
-    P.beta_trk = (T)((4.0 * db * db) / (1.0 + 2.0 * dd * db + (double)(bw_trk * bw_trk)));
-    {
-        const T bw_w = bw_acq * (T)8;
-        P.alpha_wide = (four * damp * bw_w) / (one + two * damp * bw_w + bw_w * bw_w);
-        P.beta_wide = (four * bw_w * bw_w) / (one + two * damp * bw_w + bw_w * bw_w);
-    }
-    P.max_freq = (T)(2.0 * M_PI * (double)freqRange / (double)Fs);
-    P.min_freq = (T)(-2.0 * M_PI * (double)freqRange / (double)Fs);
-    {
-        // sweep gate |pi/2 - averagePhase| < 0.05 (CarrierTrackingPLL.c:236, evaluated as there: the difference
-        // narrowed to DT, fabs, compared as double) is a monotone function of averagePhase on either side of
-        // pi/2: bisect the two edges over the ordered bit patterns so that the kernels need two compares only
-        auto gate = [](T av) { return (double)std::fabs((T)(M_PI / 2.0 - (double)av)) < 0.05; };
-        typedef typename std::conditional<sizeof(T) == 4, uint32_t, uint64_t>::type U;
-        auto bits = [](T v) { U u; memcpy(&u, &v, sizeof u); return u; };
-        auto val = [](U u) { T v; memcpy(&v, &u, sizeof v); return v; };
-        const T mid = (T)(M_PI / 2.0);
-        U in_lo = bits(mid), out_lo = bits((T)1.0);          // gate(mid) true, gate(1.0) false
-        while (in_lo - out_lo > 1) {
-            const U m = out_lo + (in_lo - out_lo) / 2;
-            if (gate(val(m))) in_lo = m; else out_lo = m;
-        }
-        U in_hi = bits(mid), out_hi = bits((T)2.5);
-        while (out_hi - in_hi > 1) {
-            const U m = in_hi + (out_hi - in_hi) / 2;
-            if (gate(val(m))) in_hi = m; else out_hi = m;
-        }
-        P.cond_lo = val(in_lo);
-        P.cond_hi = val(in_hi);
-    }
-    P.sweep0 = (T)(0.2 * (2.0 * M_PI / (double)Fs));
-    P.avg0 = (T)(M_PI / 2.0);
-    P.phase0 = (T)0.1;
-    P.freq0 = 0;
-    P.locksig0 = 0;
-    P.i0 = 0;
-    P.want_lock = (argos || live) ? 1 : 0;
-    return P;
-}
-
-uint32_t next_pow2(uint32_t v)
-{
-    uint32_t p = 1;
-    while (p < v) p <<= 1;
-    return p;
-}
-
-SyncParams make_sync_params(bool argos, bool argos_twin = false)
-{
-    SyncParams SP;
-    if (argos) {
-        SP.pattern = 0x02F0ull;   // "0001011110000"
-        SP.len = 13; SP.allow_inverse = 0; SP.span = 56; SP.first_bits = 8; SP.nbytes = 7; SP.prefix = 0;
-        if (argos_twin) SP.allow_inverse = 1;                 // ARGOSdemodPortAudio/ByteSync.c:112: the inverse word is looked for too
-    } else {
-        SP.pattern = 0x76F10ull;  // "1110110111100010000"
-        SP.len = 19; SP.allow_inverse = 1; SP.span = 813; SP.first_bits = 5; SP.nbytes = 102; SP.prefix = 2;
-    }
-    return SP;
-}
-
 void launch_bytesync(pdt_ctx *ctx, Plan &PL, hipStream_t st, const SyncParams &SP, DevScalars *d_sc, long long bit_cap, uint32_t hit_cap,
-                     uint32_t frame_cap, long long min_pos = 0)
+                     uint32_t frame_cap, long long min_pos)
 {
     unsigned char *d_bits = (unsigned char *)ctx->bits.p;
     unsigned *d_bitsym = (unsigned *)ctx->bitsym.p;
@@ -741,7 +189,7 @@ void launch_bytesync(pdt_ctx *ctx, Plan &PL, hipStream_t st, const SyncParams &S
 // reports of chunks [c0, c1) of the capture (c1 <= chunk_host.size()); `total`: the capture's length as far as it is known
 // `open_frame`: a frame whose sync word has been seen and whose last byte has not (a segment's end) -- counted where ByteSync
 // counts it, at the sync word
-static void chunk_reports_range(const pdt_ctx *ctx, uint64_t c0, uint64_t c1, uint64_t total, pdt_chunk_report *out, const pdt_frame *open_frame)
+void chunk_reports_range(const pdt_ctx *ctx, uint64_t c0, uint64_t c1, uint64_t total, pdt_chunk_report *out, const pdt_frame *open_frame)
 {
     const bool argos = ctx->cfg.mode == PDT_MODE_ARGOS;
     const uint64_t chunk = ctx->cfg.chunk;
@@ -777,1399 +225,9 @@ static void chunk_reports_range(const pdt_ctx *ctx, uint64_t c0, uint64_t c1, ui
 }
 
 
-// What run_capture's recording phase hands to its finish phase (finish_capture): the capacities and flags the read-back needs.
-struct FinishArgs {
-    bool argos, need_lock, fuse_mix;
-    long long N, n_out, chunk, chunk_out, first, first_out, sym_cap;
-    int interp, ntaps;
-    uint32_t hit_cap, frame_cap;
-    SyncParams SP;
-};
+}  // namespace pdtrt
 
-// The finish phase of a demodulation call (RUN_ALL / RUN_FINISH): wait for the launches, read the scalars, the lock record and
-// the frame records back, put the host-side time stamps on the frames, fill the statistics; for
-// a stream segment, carry every stage's state to the next one.  (Round 5: split off run_capture.)
-template <typename T> int finish_capture(pdt_ctx *ctx, uint64_t n, const FinishArgs &FA)
-{
-    const bool argos = FA.argos, need_lock = FA.need_lock, fuse_mix = FA.fuse_mix;
-    const long long N = FA.N, n_out = FA.n_out, chunk = FA.chunk, chunk_out = FA.chunk_out, first = FA.first, first_out = FA.first_out,
-                    sym_cap = FA.sym_cap;
-    const int interp = FA.interp, ntaps = FA.ntaps;
-    const uint32_t hit_cap = FA.hit_cap, frame_cap = FA.frame_cap;
-    const SyncParams &SP = FA.SP;
-    const T Fs = (T)ctx->cfg.sample_rate;
-    StreamCarry *seg = ctx->sc.active ? &ctx->sc : nullptr;
-    FrameRec *d_frames = (FrameRec *)ctx->frames.p;
-    (void)first_out;
-    if (!ctx->pending || ctx->pend_n != n) return PDT_ERR_STATE;
-    ctx->pending = false;
-    pdt_ctx *lead = ctx->leader ? ctx->leader : ctx;
-    if (seg && seg->in_place && !ctx->tune.sync_block) {
-        // the overlapped ingest: wait for the segment WITHOUT sitting inside the runtime -- the ingest's submitter thread is
-        // queueing copies all the while (a blocking hipStreamSynchronize here held it up: the copies stopped for as long as a
-        // segment's kernels ran, tools/jobs/r5_e2e_ab.sh)
-        for (;;) {
-            const hipError_t e = hipEventQuery(lead->ev1);
-            if (e == hipSuccess) break;
-            if (e != hipErrorNotReady) { HIP_TRY(e); }
-            (void)hipGetLastError();
-            std::this_thread::sleep_for(std::chrono::microseconds(40));
-        }
-    }
-    HIP_TRY(hipStreamSynchronize(lead->stream));
-    const DevScalars &sc = *ctx->pend_sc;
-    PllLockInfo<T> info;
-    memcpy(&info, ctx->pend_info, sizeof info);
-    const uint32_t got_frames = ctx->pend_got_frames;
-    if (sc.nframes > frame_cap || sc.nhits > hit_cap || (long long)sc.nsym > sym_cap) {
-        fprintf(stderr, "libpdt: internal capacity exceeded (frames %u/%u hits %u/%u symbols %llu/%lld)\n", sc.nframes,
-                frame_cap, sc.nhits, hit_cap, sc.nsym, sym_cap);
-        return PDT_ERR_STATE;
-    }
-    std::vector<FrameRec> recs(sc.nframes);
-    if (sc.nframes) {
-        const uint32_t have = std::min<uint32_t>(sc.nframes, got_frames);
-        if (have) memcpy(recs.data(), ctx->pinned, (size_t)have * sizeof(FrameRec));
-        if (sc.nframes > have)
-            HIP_TRY(hipMemcpy(recs.data() + have, d_frames + have, (size_t)(sc.nframes - have) * sizeof(FrameRec), hipMemcpyDeviceToHost));
-    }
-    ctx->last_nframes = sc.nframes;
-    const uint64_t got_chunks = ctx->pend_chunks;     // (a segment: those of its new chunks, window-local counts -- see below)
-    if (!seg) {
-        ctx->chunk_host.clear();
-        ctx->report_samples = n;
-        if (got_chunks) {
-            ctx->chunk_host.resize((size_t)got_chunks);
-            memcpy(ctx->chunk_host.data(), ctx->qual_pin, (size_t)got_chunks * sizeof(ChunkInfo));
-        }
-    }
-    ctx->pend_chunks = 0;
-
-    float ms = 0;
-    (void)hipEventElapsedTime(&ms, lead->ev0, lead->ev1);
-
-    // time stamp of the bit whose symbol was taken at global interpolated-sample index g, in a capture of n_all samples
-    // 
-    auto frame_time = [&](long long g, long long n_all) -> double {
-        if (argos && sizeof(T) == 4) return (double)ctx->axis_f.at((uint64_t)g + 1);     // the twin: float stamps (pdt_open)
-        if (argos) return ctx->axis_d.at((uint64_t)g + 1);                   // waveDataTime[i] = (i+1)-th partial sum
-        const long long c = g / chunk_out, rr = g % chunk_out;
-        const long long j = rr / interp + 1;                                  // Q2: time of the *next* input sample
-        const long long ns_c = std::min<long long>(chunk, n_all - c * chunk);
-        if (j < ns_c) return (double)ctx->axis_f.at((uint64_t)(c * chunk + j + 1));
-        if (ns_c == chunk || c == 0) return 0.0;                              // one past the array: never-written zero
-        return (double)ctx->axis_f.at((uint64_t)((c - 1) * chunk + j + 1));   // stale value of the previous chunk
-    };
-
-    // ---- per-kernel timings (profile mode)
-    auto collect_timers = [&]() {
-    ctx->ktimes.clear();
-    for (auto &t : ctx->timers) {
-        float tms = 0;
-        (void)hipEventElapsedTime(&tms, t.a, t.b);
-        bool found = false;
-        for (auto &k : ctx->ktimes)
-            if (t.name == k.name) {
-                k.launches++;
-                k.total_ms += tms;
-                found = true;
-            }
-        if (!found) {
-            pdt_kernel_time k;
-            memset(&k, 0, sizeof k);
-            snprintf(k.name, sizeof k.name, "%s", t.name.c_str());
-            k.launches = 1;
-            k.total_ms = tms;
-            ctx->ktimes.push_back(k);
-        }
-        if (!t.shared_a) ctx->event_pool.push_back(t.a);
-        ctx->event_pool.push_back(t.b);
-    }
-    ctx->timers.clear();
-    };
-
-    if (seg) {
-        // ---- stream segment: hand the new frames to the stream code, carry every stage's state to the next segment
-        SegTail<T> tail;
-        memcpy(&tail, ctx->seg_pin + 4096, sizeof tail);
-        const long long org_out = (long long)seg->origin * interp;
-        const long long n_all = (long long)seg->origin + N;                   // samples of the stream so far
-        const long long kept = (long long)seg->kept_bits.size();
-        const long long sym_pad = 2 + (long long)(seg->nsym_total & 1u);
-        const long long nbits_loc = (long long)sc.nbits;
-        if ((long long)sc.nsym < sym_pad || nbits_loc < kept) return PDT_ERR_STATE;
-        const uint64_t new_syms = sc.nsym - (uint64_t)sym_pad, new_bits = (uint64_t)(nbits_loc - kept);
-        // PLL
-        if (!seg->locked && info.lock_sample >= 0) {
-            seg->locked = true;
-            seg->lock_sample = info.lock_sample + (long long)seg->origin;
-            seg->lock_freq_hz = (double)(info.freq_at_lock * Fs) / (2.0 * M_PI);
-            seg->avg_at_lock = (double)info.avg_at_lock;
-        }
-        if (N > first || first == 0) {
-            if (seg->locked && N > 0) {
-                seg->phase = (double)tail.pll_phase;
-                seg->freq = (double)tail.pll_freq;
-                if (info.lock_sample == N - 1) {                              // locked on the very last sample: nothing walked after it
-                    seg->phase = (double)info.st.phase;
-                    seg->freq = (double)info.st.freq;
-                }
-                seg->locksig = need_lock ? (double)tail.locksig : (double)info.st.locksig;
-                seg->avg = (double)info.st.avg_phase;
-                seg->sweep = (double)info.st.sweep;
-            } else if (N > 0) {
-                seg->phase = (double)info.st.phase; seg->freq = (double)info.st.freq; seg->avg = (double)info.st.avg_phase;
-                seg->locksig = (double)info.st.locksig; seg->sweep = (double)info.st.sweep;
-            }
-        }
-        // StaticGain / AGC
-        if (!seg->have_norm && N > 0) {
-            T nv;
-            memcpy(&nv, &sc.norm, sizeof(T));
-            seg->norm_factor = (double)nv;
-            seg->gain = (double)nv;
-            seg->have_norm = true;
-        }
-        if (n_out - first_out > 0) seg->gain = (double)tail.agc_gain;
-        // sampler, Manchester
-        seg->sa = (double)tail.sampler.a; seg->sb = (double)tail.sampler.b; seg->sc = (double)tail.sampler.c;
-        seg->have_sampler = true;
-        if (sc.nsym >= 1) { seg->sym_m2 = (double)tail.sym_m2; seg->sym_m1 = (double)tail.sym_m1; }
-        seg->clockmod = tail.clock;
-        if (got_chunks) {
-            // the reports of this segment's chunks: the window's counts include the history symbols and the kept bits (all in
-            // front of the first new chunk), the capture's counts those of the earlier segments
-            const ChunkInfo *ci = (const ChunkInfo *)ctx->qual_pin;
-            for (uint64_t c = 0; c < got_chunks; c++) {
-                ChunkInfo o = ci[c];
-                if ((long long)o.sym_upto < sym_pad || (long long)o.bits_upto < kept) return PDT_ERR_STATE;
-                o.sym_upto = o.sym_upto - (uint64_t)sym_pad + seg->nsym_total;
-                o.bits_upto = o.bits_upto - (uint64_t)kept + seg->nbits_total;
-                o.t0_src += org_out;
-                ctx->chunk_host.push_back(o);
-            }
-            // averagePhase goes on behind the lock (the lock record holds its value AT the lock): the next segment's walkers
-            // start from the value behind this segment's last sample = its last chunk's
-            if (seg->locked && N > first) seg->avg = ci[got_chunks - 1].avg_phase;
-        }
-        seg->nsym_total += new_syms;
-        seg->nbits_total += new_bits;
-        seg->seg_new_symbols = new_syms;
-        seg->seg_new_bits = new_bits;
-        // bits the device kept: local indices [b0, nbits_loc)
-        const long long b0 = nbits_loc - (long long)tail.nkeep;
-        auto src_of = [&](long long pos) -> long long {                      // global interpolated-sample index behind local bit pos
-            if (pos < kept) return seg->kept_src[(size_t)pos];
-            return tail.src[pos - b0] + org_out;
-        };
-        // frames
-        seg->seg_frames.clear();
-        long long open_pos = -1;
-        bool pend = false;
-        for (unsigned f = 0; f < sc.nframes; f++) {
-            const FrameRec &r = recs[f];
-            if (!r.complete && !seg->final_seg) { open_pos = r.bit_index; }
-            pdt_frame o;
-            memset(&o, 0, sizeof o);
-            o.bit_index = r.bit_index + (long long)seg->bit_base;
-            o.inverted = argos ? 0 : r.inverted;      // (the ARGOS twin re-inverts such a packet's bits but stamps it like any other)
-            o.nbytes = r.nbytes;
-            o.complete = r.complete;
-            memcpy(o.bytes, r.bytes, 104);
-            const long long g = (r.bit_index < kept) ? seg->kept_src[(size_t)r.bit_index] : r.time_src + org_out;
-            o.time_src = g;
-            o.time = frame_time(g, n_all);
-            if (!r.complete && !seg->final_seg) {
-                seg->pending = o;                                             // reported when it completes (or at the stream's end)
-                pend = true;
-                break;
-            }
-            seg->seg_frames.push_back(o);
-            seg->next_free = std::max<long long>(seg->next_free, o.bit_index + (long long)SP.span);
-        }
-        seg->have_pending = pend;
-        // what the next segment sees of these bits: from the sync word of the open frame, else the last len - 1
-        long long keep_from = std::max<long long>(0, nbits_loc - (long long)(SP.len - 1));
-        if (open_pos >= 0) keep_from = std::max<long long>(0, open_pos - (long long)(SP.len - 1));
-        if (keep_from < b0) return PDT_ERR_STATE;                             // (an open frame is shorter than the kept tail)
-        std::vector<unsigned char> nb((size_t)(nbits_loc - keep_from));
-        std::vector<long long> ns((size_t)(nbits_loc - keep_from));
-        for (long long q = keep_from; q < nbits_loc; q++) {
-            nb[(size_t)(q - keep_from)] = tail.bits[q - b0];
-            ns[(size_t)(q - keep_from)] = src_of(q);
-        }
-        seg->kept_bits.swap(nb);
-        seg->kept_src.swap(ns);
-        seg->bit_base += (uint64_t)keep_from;
-        ctx->stats.gpu_ms = ms;
-        // pdt_read_stage after a push: the segment's own arrays, window-local (PLL / FIR / AGC from the window's origin; symbols
-        // behind the two or three history symbols; bits behind the kept ones) -- a debugging aid, see tools/probes/stream_debug.py
-        ctx->stage_len[PDT_ST_PLL] = (uint64_t)N;
-        ctx->stage_len[PDT_ST_LOCK] = need_lock ? (uint64_t)N : 0;
-        ctx->stage_len[PDT_ST_FIR] = ctx->stage_len[PDT_ST_AGC] = (uint64_t)n_out;
-        ctx->stage_len[PDT_ST_AGC_RAW] = 0;
-        ctx->stage_len[PDT_ST_SYM] = ctx->stage_len[PDT_ST_SYMIDX] = sc.nsym;
-        ctx->stage_len[PDT_ST_BITS] = ctx->stage_len[PDT_ST_BITSYM] = sc.nbits;
-        collect_timers();                     // (profile mode: the kernel groups of the LAST segment)
-        return PDT_OK;
-    }
-
-    T norm_val;
-    memcpy(&norm_val, &sc.norm, sizeof(T));
-    pdt_stats &S = ctx->stats;
-    memset(&S, 0, sizeof S);
-    S.samples = n;
-    S.out_samples = (uint64_t)n_out;
-    S.symbols = sc.nsym;
-    S.bits = sc.nbits;
-    S.frames = sc.nframes;
-    S.lock_sample = info.lock_sample;
-    S.lock_freq_hz = (double)(info.freq_at_lock * Fs) / (2.0 * M_PI);         // CarrierTrackingPLL.c:269
-    S.avg_phase = (double)info.avg_at_lock;
-    S.norm_factor = (double)norm_val;
-    S.interp = (uint32_t)interp;
-    S.ntaps = (uint32_t)ntaps;
-    S.pll_blocks = sc.counters[0];
-    S.pll_seam_fixes = sc.counters[1];
-    S.agc_blocks = sc.counters[2];
-    S.agc_seam_fixes = sc.counters[3];
-    S.gpu_ms = ms;
-    S.gardner_parallel = (uint32_t)ctx->gardner_mode;
-    const bool tabled = ctx->gardner_mode != 0;
-    S.gardner_walked = tabled ? sc.gstats[2] : 0u;
-    S.gardner_full_domain = tabled ? sc.gstats[1] : 0u;
-    S.gardner_candidates = tabled ? sc.gstats[3] : 0u;
-    S.sync_overflow = sc.sync_overflow;
-    S.segments = 1;
-
-    ctx->stage_len[PDT_ST_PLL] = (fuse_mix && !ctx->keep_pll) ? 0 : n;       // (k_mix_fir: the stream exists on request only)
-    ctx->stage_len[PDT_ST_LOCK] = need_lock ? n : 0;
-    ctx->stage_len[PDT_ST_FIR] = (uint64_t)n_out;
-    ctx->stage_len[PDT_ST_AGC] = (uint64_t)n_out;
-    ctx->stage_len[PDT_ST_AGC_RAW] = ctx->keep_agc_raw ? (uint64_t)n_out : 0;
-    ctx->stage_len[PDT_ST_SYM] = sc.nsym;
-    ctx->stage_len[PDT_ST_SYMIDX] = sc.nsym;
-    ctx->stage_len[PDT_ST_BITS] = sc.nbits;
-    ctx->stage_len[PDT_ST_BITSYM] = sc.nbits;
-
-    // ---- time stamps (host): SURVEY Appendix B Q1/Q2/Q4
-    ctx->frames_host.resize(sc.nframes);
-    ctx->frames_on_device = sc.nframes;
-    ctx->have_frames = true;
-    ctx->tip_host.clear();
-    for (unsigned f = 0; f < sc.nframes; f++) {
-        pdt_frame &o = ctx->frames_host[f];
-        const FrameRec &r = recs[f];
-        memset(&o, 0, sizeof o);
-        o.bit_index = r.bit_index;
-        o.time_src = r.time_src;
-        o.inverted = argos ? 0 : r.inverted;          // ARGOSdemodPortAudio/ByteSync.c:128: "%.5f " for the inverse word as well
-        o.nbytes = r.nbytes;
-        o.complete = r.complete;
-        memcpy(o.bytes, r.bytes, 104);
-        o.time = frame_time(r.time_src, N);
-    }
-
-    collect_timers();
-    if (ctx->progress_fn && !ctx->chunk_host.empty()) {          // pdt_set_progress: a whole capture reports once, at its end
-        try {
-            std::vector<pdt_chunk_report> rep(ctx->chunk_host.size());
-            chunk_reports_range(ctx, 0, rep.size(), ctx->report_samples, rep.data(), nullptr);
-            ctx->progress_fn(ctx->progress_user, 0, rep.data(), rep.size(), &ctx->stats);
-        } catch (const std::bad_alloc &) {
-            return PDT_ERR_NOMEM;
-        }
-    }
-    return PDT_OK;
-}
-
-// phase: the whole call, or split for the batched entry point -- enqueue every kernel and the read-back copies of
-// one capture (no host synchronisation), later wait for them and build the host-side results
-enum { RUN_ALL = 0, RUN_ENQUEUE = 1, RUN_FINISH = 2 };
-
-template <typename T> int run_capture(pdt_ctx *ctx, uint64_t n, int phase = RUN_ALL)
-{
-    const bool argos = ctx->cfg.mode == PDT_MODE_ARGOS;
-    // the sound-card twin's chain (POESTIPdemodPortAudio/main.c:324-393): the twin's constants, the lock signal kept and
-    // Squelch between PLL and FIR
-    const bool live = !argos && ctx->cfg.chain == PDT_CHAIN_LIVE;
-    const bool inject = ctx->inj.active && !ctx->sc.active;          // pdt_stage_pll
-    const bool need_lock = argos || live || inject;
-    const long long N = (long long)n;
-    const int interp = (int)ctx->interp;
-    const int ntaps = (int)ctx->ntaps;
-    const long long n_out = N * interp;
-    const long long chunk = (long long)ctx->cfg.chunk;
-    const long long chunk_out = chunk * interp;
-    hipStream_t st = ctx->stream;
-    Plan &PL = ctx->plan;
-    PlanGroups L{PL, ctx->cfg.profile != 0};
-    // stream segment: the window [0, n) holds history before `first`; every stage starts at `first` from the carried state
-    StreamCarry *seg = ctx->sc.active ? &ctx->sc : nullptr;
-    const long long first = seg ? seg->first : 0;
-    const long long first_out = first * interp;
-
-    // ---- parameters
-    const T Fs = (T)ctx->cfg.sample_rate;
-    PllParams<T> PP = make_pll_params<T>(ctx);
-    if (inject) {
-        PP.want_lock = 1;
-        if (ctx->inj.started && !ctx->inj.locked) {  // the acquisition goes on from the caller's state record
-            PP.phase0 = (T)ctx->inj.phase; PP.freq0 = (T)ctx->inj.freq; PP.avg0 = (T)ctx->inj.avg; PP.locksig0 = (T)ctx->inj.locksig;
-            PP.sweep0 = (T)ctx->inj.sweep; PP.i0 = 0;
-        }
-    }
-    if (seg && first > 0 && !seg->locked) {          // the acquisition goes on where the last segment left it
-        PP.phase0 = (T)seg->phase; PP.freq0 = (T)seg->freq; PP.avg0 = (T)seg->avg; PP.locksig0 = (T)seg->locksig;
-        PP.sweep0 = (T)seg->sweep; PP.i0 = first;
-    }
-    AgcParams<T> AP;
-    const T fsi = Fs * (T)interp;                                              // POESTIPdemod/main.c:429
-    AP.attack = ctx->lp.agc_attack != 0 ? (T)ctx->lp.agc_attack : (T)(79.5775 * (2.0 * M_PI / (double)fsi));
-    AP.decay = ctx->lp.agc_decay != 0 ? (T)ctx->lp.agc_decay : (T)(159.1549 * (2.0 * M_PI / (double)fsi));
-    AP.squelch = argos ? 1 : 0;
-    AP.squelch_thr = (T)0.15;                                                  // ARGOSdemod/main.c:46,276
-    AP.raw_out = nullptr;
-    GardnerParams<T> GP;
-    const T baud = ctx->lp.gardner_baud != 0 ? (T)ctx->lp.gardner_baud : argos ? (T)(400 * 2.0) : (T)(8320 * 2 + 0.3);   // main.c:90 / ARGOS main.c:64
-    GP.step = (T)(int)fsi / baud;                                              // GardenerClockRecovery.c:19
-    GP.kp = (ctx->lp.gardner_kp != 0 || (ctx->lp.zero_mask & PDT_LP_ZERO_GARDNER_KP)) ? (T)ctx->lp.gardner_kp : (T)3.0;
-    GP.lim = (ctx->lp.gardner_step_range != 0 || (ctx->lp.zero_mask & PDT_LP_ZERO_GARDNER_STEP_RANGE)) ? (T)ctx->lp.gardner_step_range : (T)0.1;
-    GP.n_total = n_out;
-    GP.chunk_out = chunk_out;
-    GP.argos_heap = 0;
-    GP.argos_field_bits = 0;
-    GP.argos_even = 0;
-    if (argos && (size_t)chunk * sizeof(T) < 128 * 1024) {                    // Q16, below M_MMAP_THRESHOLD
-        // (sizeof(T) = 4: the ARGOS sound-card twin, whose buffers are `chunk` floats, ARGOSdemodPortAudio/main.c:61-63)
-        const unsigned long long req = (unsigned long long)sizeof(T) * (unsigned long long)chunk;
-        const unsigned long long csz = (req + 8 + 15) & ~15ull;
-        GP.argos_heap = 1;
-        GP.argos_field_bits = csz | 1ull;
-        GP.argos_even = (int)((csz - 8 - req) / sizeof(T));
-    }
-    const bool argos_twin = argos && ctx->cfg.chain == PDT_CHAIN_LIVE;
-    const T manch_thr = (ctx->lp.manchester_threshold != 0 || (ctx->lp.zero_mask & PDT_LP_ZERO_MANCHESTER_THRESHOLD)) ? (T)ctx->lp.manchester_threshold : argos ? (T)0.5 : live ? (T)0.75 : (T)1.0;              // main.c:445 / ARGOS main.c:282 / twin :65,393
-    const SyncParams SP = make_sync_params(argos, argos_twin);
-
-    // ---- block-parallel geometry (any values give the same output; they only move time around)
-    const double fs_d = (double)ctx->cfg.sample_rate;
-    auto round4 = [](long long v) { return (v + 3) / 4 * 4; };
-    long long Bp = ctx->cfg.pll_block ? ctx->cfg.pll_block : (long long)((argos ? 0.5 : 0.05) * fs_d);
-    // (ARGOS: the loops only contract while a burst is on the air -- between bursts the detector sees noise and two close
-    // trajectories are kicked apart as fast as they are pulled together -- so a warm-up must contain one whole burst: 2 s cover
-    // a 1.5 s repetition period + one 0.36 s burst; measured on the 5-minute capture: 8 / 4 / 2 / 1 s -> 0 / 0 / 0 / 192 repaired
-    // seams.  Sparser transmissions fall back on the seam repairs, as ever.)
-    long long Wp = ctx->cfg.pll_warm ? ctx->cfg.pll_warm : (long long)((argos ? 2.0 : 0.3) * fs_d);
-    if (!ctx->cfg.pll_warm && !argos) {
-        // Measured (tools/pll_geom.py, 50 ksps): the probability that a block has not merged bit for bit after a
-        // warm-up of W samples falls like 200 exp(-W / 2.82 tau), tau = 2 / alpha_trk the tracking loop's time
-        // constant.  Aim at ~0.1 unhealthy seam per capture (a repair costs a sequential block walk, ~0.2 ms, against ~0.08 ms
-        // for the extra 1.6 tau of warm-up): short captures get away with less than 0.3 s, hour-long ones need a little more.
-        const double tau = 2.0 / (double)PP.alpha_trk;
-        const double nb = std::max(1.0, (double)N / (double)std::max<long long>(1, Bp));
-        // 200 nb exp(-w / 2.82 tau) = 0.1 expected unhealthy seams per capture.  (Round 3, an hour of 250 ksps, 61 000 blocks:
-        // warm-up x1 / 0.85 / 0.7 / 0.55 -> 1 / 1 / 52 / 837 repairs, phase kernel 7.6 / 6.7 / 6.0 / 5.2 ms, repairs 1.4 / 1.2 / 2.0 /
-        // 10.0 ms -- but the law with 50 in place of 2000 (x0.8) turned the same capture at six times the noise from 26 repairs in
-        // 3 ms into 315 in 202 ms: where the loop barely contracts every open seam starts a cascade.  The long warm-up stays.)
-        double w = 2.82 * tau * log(2000.0 * nb);
-        w *= ctx->tune.pll_warm_scale;
-        Wp = (long long)std::min(std::max(w, 0.15 * fs_d), 0.6 * fs_d);
-    }
-    long long Wacq = (long long)(0.02 * fs_d);             // acquisition-gain stage of the warm-up
-    long long Ba = ctx->cfg.agc_block ? ctx->cfg.agc_block : (long long)((argos ? 0.125 : 0.0625) * fs_d * interp);
-    // (the cap of a block's warm-up, which is 11 gain time constants = 11 gain / decay samples: weak input -- the noise in front
-    // of a pass -- means a high gain and a long memory; capped at one second, every seam of a minute of noise failed its check
-    // and was repaired in order, 219 ms; eight seconds cover gains up to ~700)
-    long long Wa = ctx->cfg.agc_warm ? ctx->cfg.agc_warm : (long long)((argos ? 2.0 : 8.0) * fs_d * interp);
-    if (!ctx->cfg.pll_block) {
-        // One walker wavefront saturates the vector ALU of its SIMD (a wave64 instruction occupies the 16 lanes for 4 clocks), so
-        // a second one on the same SIMD doubles the time of both: keep the walkers of everything that runs together -- this
-        // capture, or the whole batch -- under ~one per SIMD (240 groups of four; the rest is left to the serial kernels).
-        // (A capture on its own, round 3: 180 -- an hour at 250 ksps, where the warm-ups' re-reads press on HBM: blocks of 15 / 20 /
-        // 25 / 30 / 40 thousand samples -> phase kernel 7.6 / 6.9 / 6.8 / 7.7 / 8.3 ms.)
-        // (Round 4, with wavefront 0 out of the way -- it had been walking 7 B steps and favoured short blocks: the kernel sits under
-        // the issue roof, (W + B) steps, and the HBM roof of its re-reads, W / B + 2 passes over the capture, at once; blocks of
-        // 20 / 22.5 / 24 / 25 / 28 thousand samples -> 5.55 / 5.45 / 5.27 / 5.25 / 5.29 ms: 150 groups.)
-        const long long groups_max = ctx->batch_hint > 1 ? 240 : 150;
-        const long long share = std::max<long long>(1, groups_max / std::max(1, ctx->batch_hint));
-        const long long b_min = (N + share * 256 - 1) / (share * 256);
-        Bp = std::max(Bp, b_min);
-    }
-    Bp = std::min<long long>(Bp, std::max<long long>(N, 1));   // (one block at most: the LT layout keeps 64 blocks per tile)
-    Bp = std::max<long long>(64, (Bp + 63) / 64 * 64);         // whole transposition groups of the LT layout (pdt_kernels_front.h)
-    // mix and filter in one kernel (k_mix_fir: the PLL output never goes through HBM): the float chain at INTERP 1 with the
-    // register-tiled taps; its runs and ring phases need blocks of a multiple of lcm(64, 208) = 832 samples
-    // A stream segment may take the whole-capture kernels (k_mix_fir, the FIR kernel's AGC maps, k_agc_block_tr, table rows of
-    // several chunks) when its first new sample sits where those kernels' units begin: a multiple of the mix + FIR kernel's run
-    // (208 outputs: the AGC maps) and of a 128-byte line of the output streams (32 floats).  Round 5: the overlapped ingest of
-    // an hour-long file cuts its segments there (demod_overlapped); a pushed stream gets there when its pushes happen to.
-    const bool seg_fast = seg && first_out % PDT_MF_RUN == 0 && first_out % 32 == 0 && !ctx->tune.seg_plain;
-    bool fuse_mix = false;
-    if constexpr (std::is_same<T, float>::value) {
-        fuse_mix = !argos && !live && !inject && (!seg || seg_fast) && interp == 1 && ntaps == 26 && ctx->taps_rot.p && !ctx->tune.fir_generic &&
-                   !ctx->tune.mix_unfused && N >= 832;
-        if (fuse_mix && !ctx->cfg.pll_block) Bp = (Bp + 831) / 832 * 832;
-        if (fuse_mix && Bp % 832 != 0) fuse_mix = false;
-    }
-    Ba = std::max<long long>(64, round4(Ba));
-    // POES with the register-tiled FIR: AGC blocks made of whole FIR tiles (64 * 26 inputs), so that the FIR kernel can
-    // deliver the AGC's affine tile maps itself (0 = not fused: explicit block size, ARGOS, generic FIR)
-    long long agc_tiles_per_block = 0, fused_tiles = 0, agc_maps_per_block = 0;
-    if (!argos && !ctx->cfg.agc_block && ntaps == 26 * interp && ctx->taps_rot.p && !ctx->tune.fir_generic &&
-        !ctx->tune.agc_unfused && (!seg || (seg_fast && first_out % (64ll * 26 * interp) == 0) || (seg_fast && fuse_mix))) {
-        const long long tile_out = 64ll * 26 * interp;
-        agc_tiles_per_block = std::max<long long>(1, (Ba + tile_out / 2) / tile_out);
-        // a walker's look-ahead ring takes 64 KiB of LDS: two wavefronts per CU, 512 on the chip.  An hour at 250 ksps has more
-        // blocks than that (940 wavefronts = two rounds, the second one of a few stragglers): longer blocks, one round
-        // (4.2 -> 3.5 ms; tools/jobs/agc_tpb.sh).  (A batch shares the chip: no gain measured there.)
-        {
-            const long long tiles = (n_out - first_out + tile_out - 1) / tile_out;
-            const long long one_round = (tiles + 500ll * 64 - 1) / (500ll * 64);
-            if (ctx->batch_hint <= 1 && tiles / agc_tiles_per_block > 512ll * 64 && one_round <= 4 * agc_tiles_per_block)
-                agc_tiles_per_block = one_round;
-        }
-        if (ctx->tune.agc_tpb) agc_tiles_per_block = ctx->tune.agc_tpb;
-        Ba = agc_tiles_per_block * tile_out;
-    }
-    Wp = round4(Wp);
-    Wa = round4(Wa);
-    Wacq = round4(Wacq);
-    // lag of the autocorrelation frequency guess: at least one Manchester symbol (so that the
-    // modulation of the two samples is independent and the carrier term dominates the mean), while
-    // pi/lag stays above the PLL's frequency limit
-    const double sym_rate = (double)baud, f_lim = (double)PP.max_freq * fs_d / (2.0 * M_PI);
-    int lag = (int)ceil(fs_d / sym_rate);
-    lag = std::max(1, std::min(lag, (int)(fs_d / (2.2 * f_lim))));
-    lag = std::min(lag, 64);
-    const long long nb_pll = N / Bp + 2;
-    const long long nb_agc = (n_out - first_out + Ba - 1) / Ba + 1;
-
-    // ---- capacities
-    double min_step = (double)GP.step - 0.25;
-    if (ctx->cfg.sampler == PDT_SAMPLER_MM) {
-        const double rg = ctx->cfg.mm_step_range != 0 ? ctx->cfg.mm_step_range : 3.0;
-        if (!(rg >= 0) || rg >= (double)baud * 0.5) return PDT_ERR_ARG;        // stepMax must stay positive and finite
-        min_step = (double)(int)fsi / ((double)baud + rg) * 0.999;
-    }
-    const long long n_chunks = chunk_out > 0 ? (n_out + chunk_out - 1) / chunk_out : 0;
-    const long long sym_cap = (long long)((double)n_out / min_step) + n_chunks + 64 + (seg ? 2 * PDT_SEG_KEEP : 0);
-    const long long bit_cap = sym_cap;
-    // worst legal hit density: the ARGOS word overlaps itself by 3 bits (one hit per 10 bits), the POES word followed by
-    // its inverse by 3 (one per 16) -- e.g. a repeated sync-word test pattern; the reference decodes such streams
-    const uint32_t hit_cap = next_pow2((uint32_t)(bit_cap / 10 + 4096));
-    const uint32_t frame_cap = (uint32_t)(bit_cap / SP.span + 16);
-    const long long n_tiles = (sym_cap + PDT_TILE - 1) / PDT_TILE;
-    const long long n0 = std::min<long long>(chunk, N);
-
-    int rc;
-    if (seg) {
-        // the windows of a stream keep what earlier segments wrote (FIR history, stale reads of the sampler's chunk seams)
-        if ((rc = ctx->pll.ensure_keep((size_t)(N + 1) * sizeof(T), (size_t)first * sizeof(T)))) return rc;
-        if (need_lock && (rc = ctx->lock.ensure_keep((size_t)(N + 1) * sizeof(T), (size_t)first * sizeof(T)))) return rc;
-    }
-    if ((rc = ctx->pll.ensure((size_t)(N + 1) * sizeof(T)))) return rc;
-    if (need_lock && (rc = ctx->lock.ensure((size_t)(N + 1) * sizeof(T)))) return rc;
-    // theta and the phases live in the FIR / AGC buffers before those are written, in the lane-tiled layout: whole tiles of
-    // 64 blocks, plus the rows the walkers' look-ahead loads may touch past a tile
-    const long long lt_tiles = (N / Bp + 1 + 63) / 64;
-    const long long lt_elems = lt_tiles * 64 * Bp + 48 * 64 * (16 / (long long)sizeof(T)) + 64;
-    if (seg) {
-        // ... so theta and the phases get buffers of their own there (the AGC window must survive the PLL)
-        if ((rc = ctx->agc.ensure_keep((size_t)(n_out + 1) * sizeof(T), (size_t)first_out * sizeof(T)))) return rc;
-        if ((rc = ctx->lt_theta.ensure((size_t)(lt_elems + 1) * sizeof(T)))) return rc;
-        if ((rc = ctx->lt_phi.ensure((size_t)(lt_elems + 1) * sizeof(T)))) return rc;
-        if ((rc = ctx->seg_dev.ensure(sizeof(SegTail<T>) + 256))) return rc;
-    }
-    // (+ Ba + 1024: the full-line AGC walkers read whole super-batches of a last, partial block and a few beyond it)
-    if ((rc = ctx->fir.ensure((size_t)((seg ? n_out : std::max(n_out, lt_elems)) + 1 + Ba + 1024) * sizeof(T)))) return rc;
-    if ((rc = ctx->agc.ensure((size_t)((seg ? n_out : std::max(n_out, lt_elems)) + 1 + Ba + 1024) * sizeof(T)))) return rc;
-    if (ctx->keep_agc_raw && (rc = ctx->agc_raw.ensure((size_t)(n_out + 1) * sizeof(T)))) return rc;
-    if (ctx->keep_agc_raw) AP.raw_out = (T *)ctx->agc_raw.p;
-    // quality figure (pdt_keep_quality; whole captures only): averagePhase is one more EMA of the lock detector's kind
-    // (CarrierTrackingPLL.c:80,124,152), alpha 0.00005 -> blocks of one time constant, 16 of warm-up behind the affine guess
-    // (in the segments of the overlapped ingest too: they begin and end on chunk boundaries, StreamCarry::quality)
-    const bool quality = (ctx->keep_quality || inject) && (!seg || (seg->quality && first % chunk == 0)) && N > 0;
-    const T avg_alpha = (T)0.00005;
-    // Blocks of one time constant for captures up to ~8 000 of them; longer captures get longer blocks (up to eight time
-    // constants), the warm-up stays 16 time constants: with one-time-constant blocks an hour at 250 ksps re-read its input 17
-    // times (61 GB, 18.7 ms -- and 59 ms beside the chain's kernels on the side stream); 45 000 blocks -> 8 192: 14 GB.
-    const long long tau_q = std::max<long long>(64, round4((long long)(1.0 / (double)avg_alpha)));
-    const long long Bq = std::max(tau_q, std::min(8 * tau_q, round4(N / 8192)));
-    const long long Wq = 16 * tau_q;
-    const long long nb_q = N / Bq + 2;
-    double *d_q_zresp = nullptr, *d_q_guess = nullptr;
-    if (quality) {
-        if ((rc = ctx->avgph.ensure((size_t)(N + 1) * sizeof(T)))) return rc;
-        if ((rc = ctx->term_ap.ensure((size_t)(N + 1) * sizeof(T)))) return rc;
-        if ((rc = ctx->seams_q.ensure((size_t)nb_q * (sizeof(EmaSeam<T>) + 2 * sizeof(double))))) return rc;
-        if ((rc = ctx->chunkinfo.ensure((size_t)(n_chunks + 1) * sizeof(ChunkInfo)))) return rc;
-        d_q_zresp = (double *)((EmaSeam<T> *)ctx->seams_q.p + nb_q);
-        d_q_guess = d_q_zresp + nb_q;
-        const size_t want = (size_t)(n_chunks + 1) * sizeof(ChunkInfo);
-        if (want > ctx->qual_pin_cap) {
-            if (ctx->qual_pin) (void)hipHostFree(ctx->qual_pin);
-            ctx->qual_pin = nullptr;
-            ctx->qual_pin_cap = 0;
-            if (timed_host_malloc((void **)&ctx->qual_pin, want + want / 4) != hipSuccess) {
-                (void)hipGetLastError();
-                return PDT_ERR_NOMEM;
-            }
-            ctx->qual_pin_cap = want + want / 4;
-        }
-    }
-    T *d_avgph = quality ? (T *)ctx->avgph.p : nullptr;
-    if ((rc = ctx->sym.ensure((size_t)sym_cap * sizeof(T)))) return rc;
-    if ((rc = ctx->symidx.ensure((size_t)sym_cap * sizeof(long long)))) return rc;
-    if ((rc = ctx->bits.ensure((size_t)bit_cap))) return rc;
-    if ((rc = ctx->bitsym.ensure((size_t)bit_cap * sizeof(unsigned)))) return rc;
-    if ((rc = ctx->hits.ensure((size_t)hit_cap * sizeof(unsigned) + (size_t)n_tiles * sizeof(ManchTile)))) return rc;
-    if ((rc = ctx->sync_scr.ensure((2 * ((size_t)hit_cap + 1) + hit_cap / 32 + 2) * sizeof(unsigned)))) return rc;
-    if ((rc = ctx->frames.ensure((size_t)frame_cap * sizeof(FrameRec)))) return rc;
-    if ((rc = ctx->stiles.ensure((size_t)((bit_cap + 4095) / 4096 + 1) * sizeof(SyncTile)))) return rc;
-    if ((rc = ctx->mag.ensure((size_t)(n0 + 1) * sizeof(T)))) return rc;
-    if ((rc = ctx->seams_pll.ensure((size_t)nb_pll * sizeof(PllSeam<T>)))) return rc;
-    if ((rc = ctx->seams_agc.ensure((size_t)nb_agc * sizeof(AgcSeam<T>)))) return rc;
-    if (need_lock && (rc = ctx->term.ensure((size_t)(N + 1) * sizeof(T)))) return rc;
-    // lock-detector EMA (ARGOS): a pure contraction with factor 1 - lockSigAlpha per sample, so its own, much
-    // shorter geometry: 45 time constants of warm-up agree in 53 bits (20 in 24), blocks a quarter of that
-    // With the affine guess of the state at every block boundary (k_lock_ema_zero / _guess) 16 time constants do.
-    const bool ema_guess = !ctx->tune.ema_noguess;
-    long long We = round4((long long)((sizeof(T) == 8 ? 45.0 : 20.0) / (double)PP.lock_alpha) + 64);
-    long long Be = std::max<long long>(64, round4(We / 4));
-    if (ema_guess) {
-        Be = std::max<long long>(64, round4((long long)(1.0 / (double)PP.lock_alpha)));
-        We = 16 * Be;                  // a difference of D ulps survives n steps with probability ~ D (1 - alpha)^n; D is a few tens
-    }
-    const long long nb_ema = N / Be + 2;
-    if (need_lock && (rc = ctx->seams_ema.ensure((size_t)nb_ema * (sizeof(EmaSeam<T>) + 2 * sizeof(double))))) return rc;
-    double *d_ema_zresp = need_lock ? (double *)((EmaSeam<T> *)ctx->seams_ema.p + nb_ema) : nullptr;
-    double *d_ema_guess = need_lock ? d_ema_zresp + nb_ema : nullptr;
-    if ((rc = ctx->scal.ensure(sizeof(DevScalars)))) return rc;
-    if ((rc = ctx->lockinfo.ensure(sizeof(PllLockInfo<T>)))) return rc;
-
-    IqSrc d_pcm;
-    d_pcm.p = ctx->pcm_dev;
-    d_pcm.fmt = ctx->pcm_fmt;
-    T *d_pll = (T *)ctx->pll.p;
-    T *d_lock = need_lock ? (T *)ctx->lock.p : nullptr;
-    T *d_fir = (T *)ctx->fir.p;
-    T *d_agc = (T *)ctx->agc.p;
-    T *d_sym = (T *)ctx->sym.p;
-    long long *d_symidx = (long long *)ctx->symidx.p;
-    unsigned char *d_bits = (unsigned char *)ctx->bits.p;
-    unsigned *d_bitsym = (unsigned *)ctx->bitsym.p;
-    ManchTile *d_tiles = (ManchTile *)((unsigned char *)ctx->hits.p + (size_t)hit_cap * sizeof(unsigned));
-    FrameRec *d_frames = (FrameRec *)ctx->frames.p;
-    DevScalars *d_sc = (DevScalars *)ctx->scal.p;
-    PllLockInfo<T> *d_info = (PllLockInfo<T> *)ctx->lockinfo.p;
-    T *d_norm = (T *)&d_sc->norm;
-    T *d_taps = (T *)ctx->taps.p;
-
-    if (phase != RUN_FINISH) {
-    PL.clear();
-    PL.side_stream = ctx->stream2;
-    PL.simple(OP_EV0);
-    PL.memset_async(d_sc, 0, sizeof(DevScalars));
-    PL.memset_async(d_frames, 0, (size_t)frame_cap * sizeof(FrameRec));
-
-    // ---- StaticGain over the first chunk (main.c:384-389)
-    // per-segment staging in pinned memory (lives until the plan has run): [0] AGC gain, [64] lock record, [256] two
-    // history symbols, [512] kept bits
-    unsigned char *spin = ctx->seg_pin;
-    if (seg && seg->have_norm) {
-        const T g = (T)seg->gain;                    // the AGC goes on from its gain at the end of the last segment
-        memcpy(spin, &g, sizeof g);
-        PL.copy(OP_H2D, d_norm, spin, sizeof(T));
-    } else {
-        L.begin("static_gain");
-        PDT_LAUNCH(256, k_static_gain<T>, dim3(1), dim3(256), 0, st, d_pcm, n0, (T *)ctx->mag.p, (T)1.0,
-                           ctx->cfg.norm_override, d_norm);
-        L.end();
-    }
-
-    // ---- PLL: sequential acquisition, then theta / block-parallel phase recurrence / seam repair / mix.
-    // theta and phase live in the (not yet used) FIR and AGC buffers.
-    T *d_theta = seg ? (T *)ctx->lt_theta.p : d_fir;
-    T *d_phi = seg ? (T *)ctx->lt_phi.p : d_agc;
-    const long long lt_groups = lt_tiles * (Bp / (16 * (16 / (long long)sizeof(T))));      // workgroups of the transposing kernels
-    if (N > 0) {
-        L.begin("pll_theta");
-        PDT_LAUNCH(256, k_pll_theta<T>, dim3((unsigned)lt_groups), dim3(256), 0, st, d_pcm, N, Bp, d_theta);
-        L.end();
-    }
-    // fork: the block-parallel phase recurrence (side stream) runs beside the sequential acquisition
-    // workgroups of four wavefronts: the dispatcher spreads a workgroup's wavefronts over the four SIMDs of a CU, so the
-    // walkers are balanced over the SIMDs by construction (single-wavefront groups piled up on some SIMDs once there were
-    // more than ~1000 of them: 250 ksps hour-long captures, batches)
-    const long long grid_pll = (nb_pll + 255) / 256;
-    // one more workgroup for the walkers whose warm-up begins at sample 0 (k_pll_phase), when they fit into a wavefront
-    // ... and when it pays: in place, wavefront 0 runs every segment of the tracking stage for the longer of its two kinds of lane --
-    // the early walkers' first segment is B - (wide + acquisition stage), everybody else's W mod B (a wavefront with few lanes
-    // is not faster, rather the opposite: ARGOS, W = 4 B, +0.3 ms with the extra workgroup)
-    bool short_pays = false;
-    {
-        const long long w0 = ((Wacq / 4 + 3) & ~3ll) + Wacq;
-        const long long a = (Wp % Bp) ? Wp % Bp : Bp, s_first = Bp - w0 % Bp;
-        short_pays = (s_first - a) * 50 > w0 + Wp + Bp;
-    }
-    const int short_group = (short_pays && (((Wacq / 4 + 3) & ~3ll) + Wacq + Wp + Bp - 1) / Bp <= 64 && nb_pll > 64 && !ctx->tune.pll_noshort) ? (int)grid_pll : -1;
-    // outliers behind the wide-band stage take their wavefront's median frequency (k_pll_phase): POES only -- an ARGOS capture holds
-    // many transmitters, each at its own offset
-    const T pll_consensus = (!argos && !ctx->tune.pll_noconsensus) ? (T)(2.0 * M_PI * 800.0 / fs_d) : (T)0;
-    const long long phase_groups = grid_pll + (short_group >= 0 ? 1 : 0);
-    // a single +-2pi correction per step is exact as long as one step cannot move the phase by 2pi
-    const double worst = (double)PP.max_freq + M_PI * std::max({(double)PP.alpha_acq + (double)PP.beta_acq,
-                                                                (double)PP.alpha_trk + (double)PP.beta_trk,
-                                                                (double)PP.alpha_wide + (double)PP.beta_wide});
-    const bool slow_wrap = worst >= 2.0 * M_PI - 0.05;
-    // the walkers' frequency checkpoints (pll_phase_range): with them a seam repair stops where it has merged with the stored
-    // trajectory.  All ones = a NaN no loop state equals: a checkpoint nobody wrote never matches.
-    T *d_ckpt = nullptr;
-    if (N > 0 && !ctx->tune.pll_nockpt) {
-        const size_t ck_bytes = (size_t)((nb_pll + 63) / 64 + 1) * (size_t)pll_ckpt_count(Bp) * 64 * sizeof(T);
-        if ((rc = ctx->pll_ckpt.ensure(ck_bytes))) return rc;
-        d_ckpt = (T *)ctx->pll_ckpt.p;
-        PL.memset_async(d_ckpt, 0xff, ck_bytes);
-    }
-    PllPhaseHint *d_hint = &d_sc->phase_hint;
-    if (N > 0) {
-        PL.simple(OP_FORK);
-        L.begin("pll_phase", ctx->stream2);
-        if (slow_wrap)
-            PDT_LAUNCH(256, (k_pll_phase<T, true>), dim3((unsigned)phase_groups), dim3(256), 0, ctx->stream2, d_pcm, d_theta, N, PP, Bp,
-                               Wacq, Wp, lag, d_phi, (PllSeam<T> *)ctx->seams_pll.p, d_hint, short_group, d_ckpt, pll_consensus);
-        else
-            PDT_LAUNCH(256, (k_pll_phase<T, false>), dim3((unsigned)phase_groups), dim3(256), 0, ctx->stream2, d_pcm, d_theta, N, PP, Bp,
-                               Wacq, Wp, lag, d_phi, (PllSeam<T> *)ctx->seams_pll.p, d_hint, short_group, d_ckpt, pll_consensus);
-        L.end();
-        PL.simple(OP_JOIN_RECORD);
-    }
-    // the serial kernels (acquisition, head) ask for SIMDs of their own while the block-parallel kernel beside them
-    // leaves some free (1 024 SIMDs; it runs one wavefront per 64 blocks)
-    const bool serial_excl = 4 * grid_pll <= 960 && !ctx->tune.no_excl;
-    long long fix_regions = 1, fix_region_blocks = 0;
-    bool quality_side = false;            // the averagePhase EMA of pdt_keep_quality runs on the side stream
-    bool quality_term_fused = false, quality_after_fir = false;   // ... its input term written by k_mix_fir, its walkers launched behind that kernel
-    std::function<void(bool)> quality_walkers_late;   // (captures function-scope state only)
-    L.begin("pll_acquire");
-    if (inject && ctx->inj.locked) {
-        // pdt_stage_pll after the lock: sample 0 is a dummy the caller put in front, "locked at sample 0" with the state record
-        // = the state after it; the kernels that start behind the lock do the rest
-        PllLockInfo<T> li;
-        memset(&li, 0, sizeof li);
-        li.lock_sample = 0;
-        li.st.phase = (T)ctx->inj.phase; li.st.freq = (T)ctx->inj.freq; li.st.avg_phase = (T)ctx->inj.avg;
-        li.st.locksig = (T)ctx->inj.locksig; li.st.sweep = (T)ctx->inj.sweep;
-        memcpy(spin + 64, &li, sizeof li);
-        PL.copy(OP_H2D, d_info, spin + 64, sizeof li);
-        PL.memset_async(d_pll, 0, sizeof(T));
-        PL.memset_async(d_lock, 0, sizeof(T));
-        PL.memset_async(d_avgph, 0, sizeof(T));
-    } else if (seg && seg->locked) {
-        // the lock happened in an earlier segment: the kernels that start "after the lock" start at `first` with the carried
-        // true state (the head walks the first samples, the block-parallel results are validated against it as ever)
-        PllLockInfo<T> li;
-        memset(&li, 0, sizeof li);
-        li.lock_sample = first - 1;
-        li.st.phase = (T)seg->phase; li.st.freq = (T)seg->freq; li.st.avg_phase = (T)seg->avg;
-        li.st.locksig = (T)seg->locksig; li.st.sweep = (T)seg->sweep;
-        li.freq_at_lock = 0; li.avg_at_lock = (T)seg->avg_at_lock;
-        memcpy(spin + 64, &li, sizeof li);
-        PL.copy(OP_H2D, d_info, spin + 64, sizeof li);
-    } else if (slow_wrap)
-        PDT_LAUNCH(128, (k_pll_acquire_pipe<T, true>), dim3(1), dim3(128), 0, st, d_pcm, N, PP, d_pll, d_lock,
-                           d_info, d_avgph);
-    else if (serial_excl)
-        PDT_LAUNCH(128, (k_pll_acquire_pipe<T, false, true>), dim3(1), dim3(128), 0, st, d_pcm, N, PP, d_pll, d_lock,
-                           d_info, d_avgph);
-    else
-        PDT_LAUNCH(128, (k_pll_acquire_pipe<T, false>), dim3(1), dim3(128), 0, st, d_pcm, N, PP, d_pll, d_lock,
-                           d_info, d_avgph);
-    L.end();
-    if (N > 0) {
-        const long long grid = grid_pll;
-        // the sequential head (true state from the lock onwards, ~W samples) also runs beside k_pll_phase
-        // its length: until the true state has (nearly) forgotten the acquisition -- time constant of the critically
-        // damped tracking loop = 2 / alpha samples; 30 of them for 24 bits (measured: 28 suffice on every test
-        // capture, 40 never needed), 90 for 53 bits; a block that still disagrees afterwards is simply re-run
-        const double tau_trk = 2.0 / (double)PP.alpha_trk;
-        double head_taus = (sizeof(T) == 4) ? 30.0 : 90.0;
-        if (ctx->tune.head_taus > 0) head_taus = ctx->tune.head_taus;
-        long long Hd = std::min<long long>(Wp, (long long)(head_taus * tau_trk));
-        // A stream segment that continues a lock taken long ago starts from a state that remembers the acquisition no more than
-        // any other sample of the capture does: the head then only has to reach the next block boundary -- the warm-ups of the
-        // blocks behind it merge with the truth as anywhere else, and the seams are validated as ever (round 5: the mandatory
-        // 30 time constants kept a SIMD busy for 2.5 ms of every segment of the overlapped ingest).  What is left of the 30 since
-        // the lock stays.
-        if (seg && seg->locked && first > 0 && seg->in_place && !ctx->tune.head_taus) {
-            const long long since = (long long)seg->origin + first - 1 - (long long)seg->lock_sample;
-            Hd = std::max<long long>(0, std::min<long long>(Hd, Hd - since));
-        }
-        // ... and further -- up to half as long again -- for as long as the block-parallel kernel beside it is still running: those
-        // blocks cost nothing, and the first block behind a 30-tau head fails its seam now and then (an hour at 250 ksps: one
-        // repair of two block walks, 1.6 ms; the head stopped 0.9 ms before the kernel beside it)
-        // Only where the kernel beside it is bound by HBM (its warm-ups re-read more than ~12 GB: hour-long captures) -- there it
-        // runs ~25 % longer than acquisition + head; elsewhere the two finish together and an extra block is a block too many
-        // (10 min at 50 ksps: +0.1 ms; 10 min at 250 ksps: +0.45 ms).
-        const bool head_slack = (double)nb_pll * (double)(Wp + Bp) * sizeof(T) >= 12e9 && !ctx->tune.head_taus;
-        const long long Hd_max = head_slack ? std::min<long long>(Wp, Hd + Hd / 2) : Hd;
-        const long long head_blocks = Hd_max / Bp + 3;
-        if ((rc = ctx->pll_head.ensure((size_t)(head_blocks * Bp + 64) * sizeof(T) + (size_t)head_blocks * sizeof(PllSeam<T>) +
-                                       sizeof(PllHeadInfo<T>) + 64)))
-            return rc;
-        PllHeadInfo<T> *d_hinfo = (PllHeadInfo<T> *)ctx->pll_head.p;
-        PllSeam<T> *d_hseams = (PllSeam<T> *)((unsigned char *)ctx->pll_head.p + 64);
-        T *d_hphi = (T *)((unsigned char *)d_hseams + (((size_t)head_blocks * sizeof(PllSeam<T>) + 63) & ~(size_t)63));
-        // seam repairs: regions of the capture are validated and repaired side by side before the final in-order pass
-        // (k_pll_fix); every region workgroup has scratch for its 16 concurrent block re-runs
-        const long long nb_fix = (N + Bp - 1) / Bp;
-        fix_regions = (nb_fix >= 128) ? std::min<long long>(64, nb_fix / 16) : 1;
-        fix_region_blocks = (nb_fix + fix_regions - 1) / fix_regions;
-        if ((rc = ctx->pll_scratch.ensure((size_t)(fix_regions + 2) * (size_t)(PDT_FIX_THREADS / 64) *
-                                          (size_t)(((Bp + 63) & ~63ll) + ((pll_ckpt_count(Bp) + 63) & ~63ll) + 64) * sizeof(T)))) return rc;
-        L.begin("pll_head");
-        if (slow_wrap)
-            PDT_LAUNCH(64, (k_pll_head<T, true>), dim3(1), dim3(64), 0, st, d_theta, N, PP, d_info, Bp, Hd, d_hphi, d_hseams,
-                               d_hinfo, head_blocks, Hd_max, (const PllPhaseHint *)d_hint, (unsigned)phase_groups,
-                               ((Wacq / 4 + 3) & ~3ll) + Wacq + Wp + Bp);
-        else if (serial_excl)
-            PDT_LAUNCH(64, (k_pll_head<T, false, true>), dim3(1), dim3(64), 0, st, d_theta, N, PP, d_info, Bp, Hd, d_hphi, d_hseams,
-                               d_hinfo, head_blocks, Hd_max, (const PllPhaseHint *)d_hint, (unsigned)phase_groups,
-                               ((Wacq / 4 + 3) & ~3ll) + Wacq + Wp + Bp);
-        else
-            PDT_LAUNCH(64, (k_pll_head<T, false>), dim3(1), dim3(64), 0, st, d_theta, N, PP, d_info, Bp, Hd, d_hphi, d_hseams,
-                               d_hinfo, head_blocks, Hd_max, (const PllPhaseHint *)d_hint, (unsigned)phase_groups,
-                               ((Wacq / 4 + 3) & ~3ll) + Wacq + Wp + Bp);
-        L.end();
-        PL.simple(OP_JOIN_WAIT);                                           // join
-        L.gap();                                                           // (the wait is not part of pll_fix)
-        L.begin("pll_fix");
-        {
-            // graft the head, two optimistic region passes (region boundaries half a region apart), the final pass
-            auto fix = [&](int mode, unsigned grid, long long rb, long long ro) {
-                if (slow_wrap)
-                    PDT_LAUNCH(PDT_FIX_THREADS, (k_pll_fix<T, true>), dim3(grid), dim3(PDT_FIX_THREADS), 0, st, d_theta, N, PP, d_info, Bp, d_phi,
-                               (PllSeam<T> *)ctx->seams_pll.p, (const T *)d_hphi, (const PllSeam<T> *)d_hseams,
-                               (const PllHeadInfo<T> *)d_hinfo, (T *)ctx->pll_scratch.p, d_sc->counters, mode, rb, ro, d_ckpt);
-                else
-                    PDT_LAUNCH(PDT_FIX_THREADS, (k_pll_fix<T, false>), dim3(grid), dim3(PDT_FIX_THREADS), 0, st, d_theta, N, PP, d_info, Bp, d_phi,
-                               (PllSeam<T> *)ctx->seams_pll.p, (const T *)d_hphi, (const PllSeam<T> *)d_hseams,
-                               (const PllHeadInfo<T> *)d_hinfo, (T *)ctx->pll_scratch.p, d_sc->counters, mode, rb, ro, d_ckpt);
-            };
-            fix(0, 32, 0, 0);
-            if (fix_regions > 1) {
-                for (int pass = 0; pass < ctx->tune.fix_passes; pass++) {
-                    if (pass & 1) fix(1, (unsigned)fix_regions + 1, fix_region_blocks, fix_region_blocks / 2);
-                    else fix(1, (unsigned)fix_regions, fix_region_blocks, 0);
-                }
-            }
-            fix(2, 1, 0, 0);
-        }
-        L.end();
-        (void)grid;
-        if (!fuse_mix) {
-        L.begin("pll_mix");
-        if (need_lock)
-            PDT_LAUNCH(256, (k_pll_mix<T, true>), dim3((unsigned)lt_groups), dim3(256), 0, st, d_pcm, d_phi, N, Bp, PP,
-                               d_info, d_pll, (T *)ctx->term.p);
-        else
-            PDT_LAUNCH(256, (k_pll_mix<T, false>), dim3((unsigned)lt_groups), dim3(256), 0, st, d_pcm, d_phi, N, Bp, PP,
-                               d_info, d_pll, (T *)nullptr);
-        L.end();
-        }
-        if (need_lock) {
-            L.begin("lock_ema");
-            if (ema_guess) {
-                PDT_LAUNCH(64, k_lock_ema_zero<T>, dim3((unsigned)((nb_ema + 63) / 64)), dim3(64), 0, st, (const T *)ctx->term.p, N,
-                                   PP.lock_alpha, d_info, Be, d_ema_zresp);
-                PDT_LAUNCH(1024, k_lock_ema_guess<T>, dim3(1), dim3(1024), 0, st, (const double *)d_ema_zresp, N, PP.lock_alpha, d_info, Be,
-                                   pow(1.0 - (double)PP.lock_alpha, (double)Be), d_ema_guess);
-            }
-            PDT_LAUNCH(64, k_lock_ema<T>, dim3((unsigned)((nb_ema + 63) / 64)), dim3(64), 0, st, (const T *)ctx->term.p, N, PP.lock_alpha,
-                               d_info, Be, We, d_lock, (EmaSeam<T> *)ctx->seams_ema.p, (const double *)(ema_guess ? d_ema_guess : nullptr), 0ll);
-            PDT_LAUNCH(64, k_lock_ema_fix<T>, dim3(1), dim3(64), 0, st, (const T *)ctx->term.p, N, PP.lock_alpha, d_info,
-                               Be, d_lock, (EmaSeam<T> *)ctx->seams_ema.p, &d_sc->counters[1]);
-            L.end();
-        }
-        if (quality) {
-            // averagePhase after the lock: its input term from the phases (still in place), then the EMA like the lock detector's.
-            // Nothing later in the chain needs it (only k_chunk_info, at the very end): whole captures run it on the side stream,
-            // beside the filter, the AGC and the sampler; the chain only waits for the kernel that reads the phases (the AGC
-            // output will take their place).
-            quality_side = !inject && !ctx->tune.quality_inline;
-            // Round 4: where mix and filter are one kernel (k_mix_fir, eight wavefronts) that kernel writes the EMA's input term
-            // on its way; the walkers below are then launched behind it (quality_walkers, further down)
-            quality_term_fused = quality_side && fuse_mix && std::is_same<T, float>::value;
-            }
-        quality_walkers_late = [&](bool term_here) {
-            hipStream_t sq = quality_side ? ctx->stream2 : st;
-            if (quality_side) PL.simple(OP_FORK);
-            L.begin("quality", sq);
-            T *d_tap = (T *)ctx->term_ap.p;
-            if (term_here)
-            PDT_LAUNCH(256, (k_pll_mix<T, false, true>), dim3((unsigned)lt_groups), dim3(256), 0, sq, d_pcm, d_phi, N, Bp, PP,
-                               d_info, (T *)nullptr, d_tap);
-            if (quality_side && term_here) PL.simple(OP_JOIN_RECORD);
-            PDT_LAUNCH(64, k_lock_ema_zero_wave<T>, dim3((unsigned)nb_q), dim3(64), 0, sq, (const T *)d_tap, N,
-                               avg_alpha, d_info, Bq, d_q_zresp);
-            PDT_LAUNCH(1024, (k_lock_ema_guess<T, true>), dim3(1), dim3(1024), 0, sq, (const double *)d_q_zresp, N, avg_alpha, d_info, Bq,
-                               pow(1.0 - (double)avg_alpha, (double)Bq), d_q_guess);
-            PDT_LAUNCH(64, (k_lock_ema<T, true>), dim3((unsigned)((nb_q + 63) / 64)), dim3(64), 0, sq, (const T *)d_tap, N, avg_alpha,
-                               d_info, Bq, Wq, d_avgph, (EmaSeam<T> *)ctx->seams_q.p, (const double *)d_q_guess, (long long)chunk);
-            PDT_LAUNCH(64, k_lock_ema_fix<T>, dim3(1), dim3(64), 0, sq, (const T *)d_tap, N, avg_alpha, d_info,
-                               Bq, d_avgph, (EmaSeam<T> *)ctx->seams_q.p, &d_sc->pad0_);
-            L.end();
-        };
-        if (quality && !quality_term_fused) quality_walkers_late(true);
-        quality_after_fir = quality && quality_term_fused;
-        if (live) {                                            // twin main.c:370, DSP_SQLCH_THRESH 0.05 (:55)
-            L.begin("squelch");
-            PDT_LAUNCH(256, k_squelch<T>, dim3((unsigned)((N + 1023) / 1024)), dim3(256), 0, st, d_pll, (const T *)d_lock, N, (T)0.05);
-            L.end();
-        }
-    }
-
-    const size_t ops_after_pll = PL.ops.size();
-    ctx->last_pll_block = Bp;
-
-    // ---- FIR
-    if (n_out > 0) {
-        const int opt = 8;
-        const long long tile = (long long)PDT_FIR_THREADS * opt;
-        const long long grid = (n_out + tile - 1) / tile;
-        L.begin(fuse_mix ? "mix_fir" : "fir");
-        if (argos) {
-            const size_t sh = (size_t)(ntaps + tile + ntaps + 8) * sizeof(T);
-            PDT_LAUNCH(PDT_FIR_THREADS, k_fir_plain<T>, dim3((unsigned)grid), dim3(PDT_FIR_THREADS), sh, st, d_pll, N, ntaps, d_taps,
-                               d_fir, opt);
-        } else {
-            const int K = ntaps / interp;
-            const size_t sh_rt = (size_t)(65 * (K + 1) + 3 + 64 * K * interp) * sizeof(T);
-            const long long tiles_rt = (N + 64ll * K - 1) / (64ll * K);
-            // the AGC's affine tile maps are folded into this kernel when the AGC blocks are whole FIR tiles
-            AgcMap *fir_tile_maps = nullptr;
-            if (agc_tiles_per_block > 0) {
-                if ((rc = ctx->agc_maps.ensure((size_t)(tiles_rt + 1) * sizeof(AgcMap) + (size_t)(nb_agc + 2) * (sizeof(double) + sizeof(AgcMap))))) return rc;
-                fir_tile_maps = (AgcMap *)ctx->agc_maps.p;
-                fused_tiles = tiles_rt;
-            }
-            // workgroups take tiles round robin; 32 per CU measured best (c3: 3.9 / 3.7 / 3.2 / 3.1 / 3.1 ms at 4 / 8 / 16 / 32 / 64):
-            // the taps come by scalar loads per residue, nothing is kept across tiles, and a finer grain balances the tail
-            const long long fir_tpb = ctx->tune.fir_wg_per_cu > 0 ? ctx->tune.fir_wg_per_cu : 32;
-            const unsigned grid_rt = (unsigned)std::min<long long>(tiles_rt, 256ll * fir_tpb);
-            bool done = false;
-            if constexpr (std::is_same<T, float>::value) if (fuse_mix) {
-                // one map per run of 208 outputs instead of one per FIR tile of 1 664 (AGC blocks are whole tiles = 8 runs each)
-                const long long runs_nat = (N + PDT_MF_RUN - 1) / PDT_MF_RUN;
-                AgcMap *run_maps = nullptr;
-                if (agc_tiles_per_block > 0) {
-                    if ((rc = ctx->agc_maps.ensure((size_t)(runs_nat + 1) * sizeof(AgcMap) + (size_t)(nb_agc + 2) * (sizeof(double) + sizeof(AgcMap))))) return rc;
-                    run_maps = (AgcMap *)ctx->agc_maps.p;
-                    fused_tiles = runs_nat;
-                    agc_maps_per_block = agc_tiles_per_block * (64 * 26 / PDT_MF_RUN);
-                }
-                // eight wavefronts per workgroup (two workgroups per CU = four wavefronts per SIMD)
-                const unsigned mf_grid = (unsigned)(lt_tiles * (Bp / PDT_MF_RUN));
-                // (a stream segment keeps the PLL output's tail: the next segment's filter starts from its last 25 samples)
-                float *mf_pll = (ctx->keep_pll || seg) ? (float *)d_pll : (float *)nullptr;
-                const long long mf_pll_from = (seg && !ctx->keep_pll) ? std::max<long long>(0, N - 256) : 0ll;
-#define PDT_MF_ARGS d_pcm, (const float *)d_phi, (const float *)d_pll, N, Bp, (const PllLockInfo<float> *)d_info, (const float *)ctx->taps_rot.p, (float *)d_fir, mf_pll, run_maps, (float)AP.decay
-                if (quality_after_fir) {
-                    float *d_tap = (float *)ctx->term_ap.p;
-                    if (d_pcm.fmt == 0) PDT_LAUNCH(512, (k_mix_fir<26, 0, 8, true>), dim3(mf_grid), dim3(512), 0, st, PDT_MF_ARGS, d_tap, mf_pll_from);
-                    else PDT_LAUNCH(512, (k_mix_fir<26, 1, 8, true>), dim3(mf_grid), dim3(512), 0, st, PDT_MF_ARGS, d_tap, mf_pll_from);
-                } else {
-                    if (d_pcm.fmt == 0) PDT_LAUNCH(512, (k_mix_fir<26, 0, 8>), dim3(mf_grid), dim3(512), 0, st, PDT_MF_ARGS, (float *)nullptr, mf_pll_from);
-                    else PDT_LAUNCH(512, (k_mix_fir<26, 1, 8>), dim3(mf_grid), dim3(512), 0, st, PDT_MF_ARGS, (float *)nullptr, mf_pll_from);
-                }
-#undef PDT_MF_ARGS
-                done = true;
-            }
-            if (!done && K == 26 && sh_rt <= 64000 && ctx->taps_rot.p && !ctx->tune.fir_generic) {
-                done = true;
-                switch (interp) {
-#define PDT_FIR_CASE(I)                                                                                                       \
-    case I:                                                                                                                   \
-        PDT_LAUNCH(PDT_FIR_THREADS, (k_fir_interp_rt<T, I, 26>), dim3(grid_rt), dim3(PDT_FIR_THREADS), sh_rt, st, d_pll, N, (const T *)ctx->taps_rot.p, d_fir, \
-                           fir_tile_maps, AP.decay);                                                                                    \
-        break;
-                    PDT_FIR_CASE(1) PDT_FIR_CASE(2) PDT_FIR_CASE(3) PDT_FIR_CASE(4) PDT_FIR_CASE(5) PDT_FIR_CASE(6) PDT_FIR_CASE(7) PDT_FIR_CASE(8)
-#undef PDT_FIR_CASE
-                default: done = false;
-                }
-            }
-            if (!done) fused_tiles = 0;
-            if (!done) {                                       // any other interpolation factor: generic form
-                const size_t sh = (size_t)(ntaps + tile / interp + K + 8) * sizeof(T);
-                PDT_LAUNCH(PDT_FIR_THREADS, k_fir_interp<T>, dim3((unsigned)grid), dim3(PDT_FIR_THREADS), sh, st, d_pll, N, interp, K,
-                                   d_taps, d_fir, opt);
-            }
-        }
-        L.end();
-    }
-
-    // the averagePhase walkers, behind the kernel that wrote their input (side stream: nothing in the chain waits for them)
-    if (quality_after_fir) quality_walkers_late(false);
-
-    // ---- AGC (+Squelch); in a stream segment over the new outputs only, from the carried gain (*d_norm)
-    long long agc_last_block = -1;
-    if (n_out - first_out > 0) {
-        const long long na = n_out - first_out;
-        const T *a_in = d_fir + first_out;
-        T *a_out = d_agc + first_out;
-        const T *a_lock = d_lock ? d_lock + first_out : nullptr;       // (indexed like the outputs: interp is 1 where it is read)
-        AgcParams<T> APs = AP;
-        if (APs.raw_out) APs.raw_out += first_out;
-        const long long nb = (na + Ba - 1) / Ba;
-        agc_last_block = nb - 1;
-        const long long grid = (nb + 63) / 64;
-        const bool fused = fused_tiles > 0;                    // tile maps already written by the FIR kernel
-        if (!fused && (rc = ctx->agc_maps.ensure((size_t)(nb + 1) * (sizeof(AgcMap) + sizeof(double))))) return rc;
-        AgcMap *d_maps = (AgcMap *)ctx->agc_maps.p;
-        double *d_guess = (double *)(d_maps + (fused ? fused_tiles : nb) + 1);
-        // (a stream segment: the FIR kernel's maps are indexed from the window's first output, the AGC's blocks from the first
-        // NEW one -- a whole number of maps further on, seg_fast)
-        const long long map_len_fused = fuse_mix ? (long long)PDT_MF_RUN : 64ll * 26 * interp;
-        const long long map_first = fused ? first_out / map_len_fused : 0;
-        const AgcMap *d_maps_in = d_maps + map_first;
-        const long long n_maps_in = fused ? fused_tiles - map_first : nb;
-        // warm-up length in gain time constants: the affine guess is off by the accumulated float rounding of
-        // the true recurrence only, so a few time constants make the trajectories agree to the last bit
-        double agc_K = (sizeof(T) == 4) ? 11.0 : 34.0;
-        if (ctx->tune.agc_k > 0) agc_K = ctx->tune.agc_k;
-        if (quality_side && !quality_term_fused) PL.simple(OP_JOIN_WAIT);          // the phases (in the AGC output's buffer) have been read
-        L.begin("agc_block");
-        if (!fused) PDT_LAUNCH(256, k_agc_affine<T>, dim3((unsigned)nb), dim3(256), 0, st, a_in, na, APs.decay, Ba, d_maps);
-        if (agc_maps_per_block == 0) agc_maps_per_block = agc_tiles_per_block;        // (the FIR kernel's maps: one per tile)
-        if (fused && agc_maps_per_block > 1) {
-            AgcMap *d_bmaps = (AgcMap *)(d_guess + nb + 1);
-            PDT_LAUNCH(256, k_agc_blockmaps, dim3((unsigned)((nb + 255) / 256)), dim3(256), 0, st, d_maps_in, nb,
-                               (int)agc_maps_per_block, n_maps_in, d_bmaps);
-            PDT_LAUNCH(1024, k_agc_guess<T>, dim3(1), dim3(1024), 0, st, (const AgcMap *)d_bmaps, nb, (const T *)d_norm, d_guess, 1, nb);
-        } else
-        PDT_LAUNCH(1024, k_agc_guess<T>, dim3(1), dim3(1024), 0, st, d_maps_in, nb, (const T *)d_norm, d_guess,
-                           fused ? (int)agc_maps_per_block : 1, n_maps_in);
-        // (Round 3: walkers that store only the gain in front of every 16-sample batch + a streaming kernel that applies them were
-        // slower, 4.2 against 3.3 ms at an hour of 250 ksps: the walkers are not held up by their output stores.)
-        // Round 4: the walkers move whole lines (k_agc_block_tr) wherever the FIR kernel delivered its tile maps -- float chain,
-        // no Squelch, no raw copy; the double build, stream segments and explicit block sizes keep the per-lane form.
-        bool agc_tr = false;
-        float *agc_ckpt = nullptr;
-        if constexpr (std::is_same<T, float>::value) {
-            agc_tr = fused && !ctx->tune.agc_lanes && !APs.squelch && !APs.raw_out && first_out % 32 == 0 && Ba % 32 == 0 &&
-                     agc_maps_per_block > 0 && Ba % agc_maps_per_block == 0;
-            if (agc_tr) {
-                const long long tile_len = 64ll * 26 * interp;                         // a FIR tile (= 8 runs of k_mix_fir)
-                const long long map_len = Ba / agc_maps_per_block;                     // samples per map
-                agc_tr = tile_len % 32 == 0 && tile_len % map_len == 0 && Ba % tile_len == 0;
-                if (agc_tr) {
-                    // (no slack of a whole block behind the time constants any more.  An hour at 250 ksps: K = 10 / 11 / 12 / 13 / 14 / 16
-                    // -> 4 / 3 / 0 / 0 / 0 / 0 open seams, walkers 1.76 / 1.80 / 1.84 / 1.86 / 1.91 / 2.06 ms; a minute of noise in front:
-                    // 3 / 1 / 2 / 1 / 1 / 0 and 12.1 ... 19.1 ms.  A seam that stays open is cheap since the repairs stop at the first
-                    // checkpoint they reproduce.)
-                    if (ctx->tune.agc_k <= 0) agc_K = 12.0;
-                    const size_t ck_bytes = (size_t)(nb + 64) * (size_t)(Ba / PDT_AGC_CKPT + 1) * sizeof(float);
-                    if ((rc = ctx->agc_ckpt.ensure(ck_bytes))) return rc;
-                    agc_ckpt = (float *)ctx->agc_ckpt.p;
-                    PDT_LAUNCH(64, (k_agc_block_tr<PDT_AGC_TR_R>), dim3((unsigned)grid), dim3(64), 0, st, (const float *)a_in, na, APs,
-                               (const float *)d_norm, Ba, Wa, (const double *)d_guess, d_maps_in, (int)agc_maps_per_block,
-                               (int)(tile_len / map_len), n_maps_in, tile_len, (float *)a_out, (AgcSeam<float> *)ctx->seams_agc.p, agc_K, agc_ckpt);
-                }
-            }
-        }
-        T *agc_ckpt_any = (T *)agc_ckpt;
-        if (!agc_tr) {
-            // the per-lane walkers of the double-precision build leave checkpoints too (blocks of at least two of them)
-            if (sizeof(T) == 8 && Ba >= 2 * PDT_AGC_CKPT) {
-                if ((rc = ctx->agc_ckpt.ensure((size_t)(nb + 64) * (size_t)(Ba / PDT_AGC_CKPT) * sizeof(T)))) return rc;
-                agc_ckpt_any = (T *)ctx->agc_ckpt.p;
-            }
-            PDT_LAUNCH(64, k_agc_block<T>, dim3((unsigned)grid), dim3(64), 0, st, a_in, na, APs, d_norm, Ba, Wa,
-                               (const double *)d_guess, a_lock, a_out, (AgcSeam<T> *)ctx->seams_agc.p, agc_K, agc_ckpt_any);
-        }
-        L.end();
-        L.begin("agc_fix");
-        PDT_LAUNCH(1024, k_agc_scan<T>, dim3(1), dim3(1024), 0, st, na, Ba, (const AgcSeam<T> *)ctx->seams_agc.p, &d_sc->agc_first_bad);
-        PDT_LAUNCH(64, k_agc_fix<T>, dim3(1), dim3(64), 0, st, a_in, na, APs, Ba, a_lock, a_out,
-                           (AgcSeam<T> *)ctx->seams_agc.p, d_sc->counters, (const long long *)&d_sc->agc_first_bad, agc_ckpt_any);
-        L.end();
-    }
-
-    // ---- Gardner: exact parallel evaluation through boundary-state tables when the chunk geometry
-    // allows it (float build, chunk fits the LDS window, boundary states in one binade), otherwise the
-    // single-wavefront sequential chain.
-    const bool use_mm = ctx->cfg.sampler == PDT_SAMPLER_MM;
-    bool use_table = false;
-    GardnerDomain GD;
-    GD.q_min = 0; GD.u = 0; GD.n_q = 0; GD.n_cand = 0; GD.pad_q = 0; GD.idx_bits = 20; GD.span = 1;
-    if constexpr (std::is_same<T, float>::value) {
-        const int table_len = 1 << 22;     // the table kernel walks the chunk in LDS windows: no size limit of its own
-        const float nT = (float)chunk_out, stepf = (float)GP.step;
-        const long long seg_c_first = (seg && chunk > 0) ? first / chunk : 0;
-        if (!argos && !use_mm && !ctx->tune.gardner_sequential && n_chunks - seg_c_first >= 4 && chunk_out >= 256 &&
-            !(seg && ctx->tune.seg_sequential) &&
-            chunk_out + 2 * (long long)stepf + 24 <= table_len && 8 * (long long)stepf + 256 < PDT_GTAB_WIN && chunk_out < (1 << 22)) {
-            int e;
-            (void)frexpf(nT - stepf - 1.0f, &e);                              // value in [2^(e-1), 2^e)
-            const float u = ldexpf(1.0f, e - 24);
-            const float q_min = u * floorf((nT - stepf - 1.0f) / u);
-            const int n_q = (int)ceilf((stepf + 1.8f) / u);
-            const float q_max = q_min + (float)n_q * u;
-            const double max_count = (double)chunk_out / ((double)stepf - 0.11) + 2.0;
-            int idx_bits = 1;
-            while ((1ll << idx_bits) < 2 * (long long)n_q) idx_bits++;
-            if (q_min >= ldexpf(1.0f, e - 1) && q_max < ldexpf(1.0f, e) && idx_bits <= 20 &&
-                max_count < (double)((1u << (32 - idx_bits)) - 2u) && max_count < 65000.0) {
-                use_table = true;
-                GD.q_min = q_min;
-                GD.u = u;
-                GD.n_q = n_q;
-                GD.idx_bits = idx_bits;
-                const double pad = ctx->cfg.gardner_band_pad > 0 ? ctx->cfg.gardner_band_pad : (ctx->tune.band_pad > 0 ? ctx->tune.band_pad : 1.0 / 8.0);
-                GD.pad_q = std::max(2, (int)(pad / (double)u));
-                // Chunks per table row.  Many short chunks (an hour at 250 ksps: 90 000 of 666 symbols): the candidates of a chunk
-                // merge onto a handful of trajectories within it, so boundary states are tabulated in front of every span-th chunk
-                // only and the few distinct exits of a row's first chunk are walked on through the others (k_gardner_span):
-                // scouts, candidate walks and chain hops per span chunks instead of per chunk.  A row's symbol count must fit
-                // the table cell.  Stream segments keep one chunk per row (they are short, and enter with a carried state).
-                // (Round 5: a stream segment too, when its first new chunk is where a row begins -- the rows are counted from the
-                // window's chunk 0, the few in front of the first new chunk are history nobody asks for.)
-                int span = ctx->tune.gspan > 0 ? ctx->tune.gspan : ((n_chunks - seg_c_first >= 4096 && (!seg || seg_fast)) ? 16 : 1);
-                if (2 * n_q > 32 * PDT_GSPAN_BITMAP_WORDS || 8 * (long long)stepf + 256 >= PDT_GSUB_WIN) span = 1;
-                while (span > 1 && ((double)span * max_count >= (double)((1u << (32 - idx_bits)) - 2u) || (n_chunks - 1) / span - seg_c_first / span < 4))
-                    span /= 2;
-                auto row_aligned = [&](int sp) { return !seg || seg_c_first % sp == 0; };
-                if (span >= 8 && !ctx->tune.gspan) {
-                    // the group behind the last row is walked by one wavefront, chunk after chunk (0.8 ms for 16 chunks): take the span
-                    // near the wanted one that leaves the fewest chunks there
-                    int best = span;
-                    long long best_left = row_aligned(span) ? n_chunks - ((n_chunks - 1) / span) * span : (1ll << 62);
-                    for (int sp = span - span / 4; sp <= span + span / 4; sp++) {
-                        const long long left = n_chunks - ((n_chunks - 1) / sp) * sp;
-                        if (left < best_left && row_aligned(sp) && (double)sp * max_count < (double)((1u << (32 - idx_bits)) - 2u)) { best = sp; best_left = left; }
-                    }
-                    span = best;
-                }
-                if (!row_aligned(span)) span = 1;
-                GD.span = span;
-            }
-        }
-    }
-    ctx->gardner_mode = use_table ? 1 : 0;
-    // stream segment: the sequential samplers go on from the carried state at chunk first / chunk; the symbol buffer starts
-    // with the two symbols the Manchester stage looks back on, placed so that local and global symbol parities agree
-    SamplerCarry<T> carry_in;
-    carry_in.a = 0; carry_in.b = 0; carry_in.c = 0; carry_in.c_first = 0; carry_in.count0 = 0;
-    SegTail<T> *d_tail = seg ? (SegTail<T> *)ctx->seg_dev.p : nullptr;
-    SamplerCarry<T> *d_carry_out = seg ? &d_tail->sampler : nullptr;
-    long long sym_pad = 0;
-    unsigned clock0 = 0;
-    unsigned long long bit0 = 0;
-    long long sync_min_pos = 0;
-    if (seg) {
-        sym_pad = 2 + (long long)(seg->nsym_total & 1u);
-        carry_in.c_first = chunk > 0 ? first / chunk : 0;
-        carry_in.count0 = sym_pad;
-        if (seg->have_sampler) { carry_in.a = (T)seg->sa; carry_in.b = (T)seg->sb; carry_in.c = (T)seg->sc; }
-        T hist[4] = { 0, 0, 0, 0 };
-        hist[sym_pad - 2] = (T)seg->sym_m2;
-        hist[sym_pad - 1] = (T)seg->sym_m1;
-        memcpy(spin + 256, hist, sizeof hist);
-        PL.copy(OP_H2D, d_sym, spin + 256, (size_t)sym_pad * sizeof(T));
-        if (quality) PL.memset_async(d_symidx, 0, (size_t)sym_pad * sizeof(long long));   // (k_chunk_info searches the picks' indices)
-        clock0 = seg->clockmod;
-        bit0 = seg->kept_bits.size();
-        if (bit0) {
-            memcpy(spin + 512, seg->kept_bits.data(), (size_t)bit0);
-            PL.copy(OP_H2D, d_bits, spin + 512, (size_t)bit0);
-            PL.memset_async(d_bitsym, 0, (size_t)bit0 * sizeof(unsigned));
-        }
-        sync_min_pos = std::max<long long>(0, seg->next_free - (long long)seg->bit_base);
-        // The search treats the bits in front of local bit 0 as the zeros the reference's ring starts with -- true at the start
-        // of the stream only.  Later the kept bits are the last len - 1 (or more) of the previous segment: a sync word that ends
-        // inside them was looked at there with its real bits, and one that ends further on lies entirely inside this segment.
-        if (seg->bit_base > 0) sync_min_pos = std::max<long long>(sync_min_pos, (long long)SP.len - 1);
-    }
-    if (use_table) {
-        if constexpr (std::is_same<T, float>::value) {
-            // consistent (q, last pick) combinations: the last pick is rint(q + err), |err| <= 0.1
-            std::vector<unsigned> cand;
-            std::vector<int> mfirst((size_t)GD.n_q + 1);
-            cand.reserve((size_t)GD.n_q * 2);
-            for (int m = 0; m < GD.n_q; m++) {
-                mfirst[(size_t)m] = (int)cand.size();
-                const float q = GD.q_min + (float)m * GD.u;
-                const float fr = q - floorf(q);
-                if (fr <= 0.61f) cand.push_back((unsigned)(2 * m));
-                if (fr >= 0.39f) cand.push_back((unsigned)(2 * m + 1));
-            }
-            mfirst[(size_t)GD.n_q] = (int)cand.size();
-            GD.n_cand = (int)cand.size();
-            const long long key = chunk_out * 1000003ll + (long long)llround((double)GP.step * 4096.0);
-            if ((rc = ctx->gcand.ensure(cand.size() * sizeof(unsigned)))) return rc;
-            if ((rc = ctx->gmfirst.ensure(mfirst.size() * sizeof(int)))) return rc;
-            if (ctx->gcand_key != key) {
-                HIP_TRY(hipMemcpyAsync(ctx->gcand.p, cand.data(), cand.size() * sizeof(unsigned), hipMemcpyHostToDevice, st));
-                HIP_TRY(hipMemcpyAsync(ctx->gmfirst.p, mfirst.data(), mfirst.size() * sizeof(int), hipMemcpyHostToDevice, st));
-                HIP_TRY(hipStreamSynchronize(st));              // the host vectors die at the end of this scope
-                ctx->gcand_key = key;
-            }
-            const long long n_tab = (n_chunks - 1) / GD.span;        // table rows: groups of span full chunks that have a successor
-            const long long n_groups = n_tab + 1;                    // ... and the group behind the last row (<= span chunks, the last may be short)
-            SamplerCarry<float> tab_carry;                   // where the chain starts: chunk, state, symbols already in the buffer
-            tab_carry.a = (float)carry_in.a; tab_carry.b = (float)carry_in.b; tab_carry.c = (float)carry_in.c;
-            tab_carry.c_first = carry_in.c_first; tab_carry.count0 = carry_in.count0;
-            SamplerCarry<float> chain_carry = tab_carry;     // the chain counts in table rows (groups of GD.span chunks)
-            chain_carry.c_first = tab_carry.c_first / GD.span;
-            const long long g_first = chain_carry.c_first;
-            if ((rc = ctx->gtable.ensure((size_t)n_tab * (size_t)(2 * GD.n_q) * sizeof(unsigned)))) return rc;
-            if ((rc = ctx->gentries.ensure((size_t)n_chunks * sizeof(GardnerEntry<float>)))) return rc;
-            if ((rc = ctx->gbands.ensure((size_t)n_tab * sizeof(GardnerBand)))) return rc;
-            L.begin("gardner_table");
-            if ((rc = ctx->gclist.ensure((size_t)n_tab * PDT_GTAB_LIST * sizeof(unsigned)))) return rc;
-            // (the table is never initialised as a whole -- 12 GB for an hour at 250 ksps: every look-up checks the chunk's band)
-            // the scouts need symbols, not samples, to settle on the chunk's timing: the same number of them at every rate
-            const int scout_syms = ctx->tune.scout_syms > 0 ? ctx->tune.scout_syms : 455;
-            const int scout_tail = (int)std::min<long long>(PDT_GTAB_TAIL, std::max<long long>(256, (long long)((double)scout_syms * (double)GP.step) + 16));
-            PDT_LAUNCH(64, k_gardner_scout, dim3((unsigned)n_tab), dim3(64), 0, st, (const float *)d_agc, GP, GD, n_tab,
-                               (const int *)ctx->gmfirst.p, (const unsigned *)ctx->gcand.p, (unsigned *)ctx->gtable.p,
-                               (GardnerBand *)ctx->gbands.p, (unsigned *)ctx->gclist.p, d_sc->gstats, scout_tail);
-            {
-                // locked chunks carry 100-300 candidates that merge quickly: see k_gardner_table_merge
-                {
-                    const unsigned parts = (unsigned)((GD.n_cand + PDT_GTM_SLOTS - 1) / PDT_GTM_SLOTS);
-                    PDT_LAUNCH(PDT_GTM_THREADS, (k_gardner_table_merge<PDT_GTAB_WIN>), dim3((unsigned)n_tab, parts), dim3(PDT_GTM_THREADS), 0, st,
-                                       (const float *)d_agc, GP, GD, n_tab, (const unsigned *)ctx->gcand.p,
-                                       (const GardnerBand *)ctx->gbands.p, (const unsigned *)ctx->gclist.p,
-                                       (unsigned *)ctx->gtable.p, d_sc->gstats);
-                }
-                if (GD.span > 1) {
-                    // the distinct exits of every row's first chunk, walked on through the row's other chunks (see k_gardner_span_keys)
-                    const unsigned cap_keys = ctx->tune.gspan_cap ? (unsigned)ctx->tune.gspan_cap
-                                                                  : (unsigned)std::min<long long>(std::max<long long>(n_tab * 128, 1ll << 20), 1ll << 28);
-                    const size_t cap_items = (size_t)cap_keys / PDT_GSUB_KEYS + (size_t)n_tab + 1;
-                    if ((rc = ctx->gspan_keys.ensure((size_t)cap_keys * sizeof(unsigned)))) return rc;
-                    if ((rc = ctx->gspan_tails.ensure((size_t)cap_keys * sizeof(unsigned)))) return rc;
-                    if ((rc = ctx->gspan_recs.ensure((size_t)cap_keys * (size_t)(GD.span - 1) * sizeof(GardnerSpanRec)))) return rc;
-                    if ((rc = ctx->gspan_rows.ensure((size_t)n_tab * sizeof(GardnerSpanRow)))) return rc;
-                    if ((rc = ctx->gspan_items.ensure(cap_items * sizeof(GardnerSpanItem)))) return rc;
-                    if ((rc = ctx->gspan_ctl.ensure(sizeof(GardnerSpanCtl)))) return rc;
-                    PL.memset_async(ctx->gspan_ctl.p, 0, sizeof(GardnerSpanCtl));
-                    PDT_LAUNCH(256, k_gardner_span_keys, dim3((unsigned)n_tab), dim3(256), 0, st, GD, n_tab, (const unsigned *)ctx->gcand.p,
-                                       (GardnerBand *)ctx->gbands.p, (const unsigned *)ctx->gclist.p, (const unsigned *)ctx->gtable.p,
-                                       (unsigned *)ctx->gspan_keys.p, cap_keys, (GardnerSpanRow *)ctx->gspan_rows.p,
-                                       (GardnerSpanItem *)ctx->gspan_items.p, (GardnerSpanCtl *)ctx->gspan_ctl.p);
-                    const unsigned walkers = (unsigned)std::min<long long>(n_tab / PDT_GSUB + 64, 256ll * 16);     // persistent wavefronts (8 KiB of LDS each)
-                    PDT_LAUNCH(64, (k_gardner_span_walk<PDT_GSUB_WIN>), dim3(walkers), dim3(64), 0, st, (const float *)d_agc, GP, GD,
-                                       (const unsigned *)ctx->gspan_keys.p, (const GardnerSpanItem *)ctx->gspan_items.p,
-                                       (GardnerSpanCtl *)ctx->gspan_ctl.p, (unsigned *)ctx->gspan_tails.p, (GardnerSpanRec *)ctx->gspan_recs.p);
-                    PDT_LAUNCH(128, k_gardner_span_join, dim3((unsigned)n_tab), dim3(128), 0, st, GD, n_tab, (const unsigned *)ctx->gcand.p,
-                                       (const GardnerBand *)ctx->gbands.p, (const unsigned *)ctx->gclist.p, (unsigned *)ctx->gtable.p,
-                                       (const unsigned *)ctx->gspan_keys.p, (const unsigned *)ctx->gspan_tails.p,
-                                       (const GardnerSpanRow *)ctx->gspan_rows.p, d_sc->gstats);
-                }
-            }
-            L.end();
-            // chunks per chain segment: the chain hops one segment per ~1 us of dependent L2 look-ups, the composite maps and
-            // the re-trace of a segment take G such look-ups each but run in parallel over the segments
-            // (at most 64: k_gardner_segfill re-traces a segment with one lane per chunk)
-            int G = (n_groups < 8000) ? 32 : 64;
-            if (ctx->tune.gseg) G = ctx->tune.gseg;
-            const long long n_seg = (n_groups + G - 1) / G;
-            if ((rc = ctx->gsegmap.ensure((size_t)n_seg * (size_t)(2 * GD.n_q) * sizeof(GardnerSegCell)))) return rc;
-            if ((rc = ctx->gsegstart.ensure((size_t)n_seg * sizeof(GardnerSegStart)))) return rc;
-            L.begin("gardner_chain");
-            PL.memset_async(ctx->gsegstart.p, 0, (size_t)n_seg * sizeof(GardnerSegStart));
-            PDT_LAUNCH(1024, k_gardner_segmap, dim3((unsigned)n_seg), dim3(1024), 0, st, (const unsigned *)ctx->gtable.p, GD, n_groups,
-                               G, (GardnerSegCell *)ctx->gsegmap.p, (const GardnerBand *)ctx->gbands.p);
-            // Long captures: the chain runs range by range; as soon as a range is through, its entry states and symbols are produced
-            // on the side stream (segfill, emission -- chip-wide kernels) while the single workgroup of the chain hops on
-            // (an hour at 250 ksps: chain 1.6 ms + emission 1.8 ms one after the other -> the emission behind the chain).
-            const int n_ranges = (!seg && n_groups >= 8192 && GD.span == 1 && !ctx->tune.chain_one_range) ? 4 : 1;
-            if ((rc = ctx->gchain.ensure(sizeof(GardnerChainState)))) return rc;
-            const bool side = n_ranges > 1;
-            hipStream_t st_emit = side ? ctx->stream2 : st;
-            L.end();
-            long long c_lo = 0;
-            for (int r = 0; r < n_ranges; r++) {
-                const long long c_hi = (r == n_ranges - 1) ? n_groups : (n_groups * (r + 1) / n_ranges) / G * G;      // (groups)
-                L.begin("gardner_chain");
-                PDT_LAUNCH(256, k_gardner_chain, dim3(1), dim3(256), 0, st,      // 4 wavefronts: a walked chunk is staged 4x faster
-                                   (const float *)d_agc, GP, GD, n_groups,
-                                   (const unsigned *)ctx->gtable.p, (const GardnerSegCell *)ctx->gsegmap.p, G,
-                                   (GardnerSegStart *)ctx->gsegstart.p, (GardnerEntry<float> *)ctx->gentries.p, d_sc->gstats,
-                                   (const GardnerBand *)ctx->gbands.p, n_tab, chain_carry, (seg && seg->have_sampler) ? 1 : 0, c_hi,
-                                   (GardnerChainState *)ctx->gchain.p, r == 0 ? 1 : 0,
-                                   (const unsigned *)(GD.span > 1 ? ctx->gspan_keys.p : nullptr), (const unsigned *)(GD.span > 1 ? ctx->gspan_tails.p : nullptr),
-                                   (const GardnerSpanRow *)(GD.span > 1 ? ctx->gspan_rows.p : nullptr));
-                L.end();
-                if (side) PL.simple(OP_FORK);
-                const long long s_lo = c_lo / G, s_hi = (c_hi + G - 1) / G;
-                L.begin("gardner", st_emit);
-                if (s_hi > s_lo)
-                    PDT_LAUNCH(64, k_gardner_segfill, dim3((unsigned)(s_hi - s_lo)), dim3(64), 0, st_emit, (const float *)d_agc, GP, GD, n_groups,
-                                       (const unsigned *)ctx->gtable.p, G, (const GardnerSegStart *)ctx->gsegstart.p,
-                                       (GardnerEntry<float> *)ctx->gentries.p, s_lo);
-                // per-chunk emission: small LDS windows so that every chunk of a 10-minute capture is resident at once
-                const unsigned char *d_flags = nullptr;
-                if (GD.span > 1 && 8 * (long long)GP.step + 256 < PDT_GEMIT_SUB_WIN && !ctx->tune.gemit_groups &&
-                    (double)PDT_GEMIT_SUB_WIN / ((double)GP.step - 0.2) + 2.0 < (double)PDT_GSUB_OUT) {
-                    // rows of several chunks: four CHUNKS per wavefront (k_gardner_emit_first / _rest); the groups these cannot resolve,
-                    // and the one behind the last row, go through the wavefront-per-group kernel below
-                    if ((rc = ctx->gcentries.ensure((size_t)n_chunks * sizeof(GardnerEntry<float>)))) return rc;
-                    if ((rc = ctx->gflags.ensure((size_t)n_groups + 64))) return rc;
-                    PL.memset_async(ctx->gflags.p, 1, (size_t)n_groups, PL.side_of(st_emit));
-                    PDT_LAUNCH(64, (k_gardner_emit_first<PDT_GEMIT_SUB_WIN>), dim3((unsigned)((n_tab - g_first + 3) / 4)), dim3(64), 0, st_emit, (const float *)d_agc, GP, GD,
-                                       n_tab, (const GardnerEntry<float> *)ctx->gentries.p, (const unsigned *)ctx->gspan_keys.p,
-                                       (const GardnerSpanRow *)ctx->gspan_rows.p, (const GardnerSpanRec *)ctx->gspan_recs.p,
-                                       (GardnerEntry<float> *)ctx->gcentries.p, (unsigned char *)ctx->gflags.p, (float *)d_sym, d_symidx, sym_cap, g_first);
-                    PDT_LAUNCH(64, (k_gardner_emit_rest<PDT_GEMIT_SUB_WIN>), dim3((unsigned)(((n_tab - g_first) * (GD.span - 1) + 3) / 4)), dim3(64), 0, st_emit,
-                                       (const float *)d_agc, GP, GD, n_tab, (const GardnerEntry<float> *)ctx->gcentries.p,
-                                       (const unsigned char *)ctx->gflags.p, (float *)d_sym, d_symidx, sym_cap, g_first);
-                    d_flags = (const unsigned char *)ctx->gflags.p;
-                }
-                if (c_hi > c_lo)
-                    PDT_LAUNCH(256, (k_gardner<float, PDT_GEMIT_LEN, PDT_GEMIT_OUT>), dim3((unsigned)(c_hi - c_lo)), dim3(PDT_GARDNER_THREADS), 0, st_emit,
-                                       (const float *)d_agc, (const float *)d_lock, GP, (float *)d_sym, d_symidx, &d_sc->nsym, sym_cap,
-                                       (const GardnerEntry<float> *)ctx->gentries.p, tab_carry, (SamplerCarry<float> *)d_carry_out, c_lo, GD.span, d_flags);
-                L.end();
-                c_lo = c_hi;
-            }
-            if (side) {
-                PL.simple(OP_JOIN_RECORD);
-                PL.simple(OP_JOIN_WAIT);
-            }
-        }
-    } else if (use_mm) {
-        // MMClockRecovery at the sampler's call site: sequential, one wavefront
-        MmParams<T> MP;
-        const T rangeT = (T)(ctx->cfg.mm_step_range != 0 ? ctx->cfg.mm_step_range : 3.0);     // ARGOSdemod/main.c:277
-        MP.kp = (T)(ctx->cfg.mm_kp != 0 ? ctx->cfg.mm_kp : 0.15);
-        MP.step0 = (T)(int)fsi / baud;                                                        // MMClockRecovery.c:20
-        MP.step_max = (T)(int)fsi / (baud - rangeT);                                          // :9
-        MP.step_min = (T)(int)fsi / (baud + rangeT);                                          // :10
-        MP.n_total = n_out;
-        MP.chunk_out = chunk_out;
-        L.begin("gardner");
-        if (seg && !seg->have_sampler) carry_in.b = MP.step0;                 // (the M&M state starts at stepSize = Fs / baud, MMClockRecovery.c:20)
-        PDT_LAUNCH(PDT_GARDNER_THREADS, (k_mm<T, 8192, 1024>), dim3(1), dim3(PDT_GARDNER_THREADS), 0, st, (const T *)d_agc, MP, d_sym, d_symidx,
-                           &d_sc->nsym, sym_cap, carry_in, seg ? 1 : 0, d_carry_out);
-        L.end();
-    } else {
-        L.begin("gardner");
-        constexpr int SMALL_LEN = 32768 / (int)sizeof(T), SMALL_OUT = 1024;    // two 32 KiB windows
-        const long long small_need = chunk_out + 2 * (long long)GP.step + 24;
-        const double small_syms = (double)chunk_out / ((double)GP.step - 0.25) + 4.0;
-        constexpr int RING_LEN = 20480 / (int)sizeof(T), RING_NB = 6, RING_OUT = 256;   // six 20 KiB buffers
-        if (small_need <= RING_LEN && small_syms < RING_OUT && chunk_out >= 4 * (long long)GP.step + 8 && n_chunks >= 8 && !seg &&
-            !ctx->tune.gardner_onebuf && !ctx->tune.gardner_noring) {
-            const size_t need_bytes = ((size_t)n_chunks + 64 + 15) & ~(size_t)15;
-            if ((rc = ctx->gneed.ensure(need_bytes + (size_t)n_chunks * sizeof(CalmEntry<T>)))) return rc;
-            CalmEntry<T> *d_calm = (CalmEntry<T> *)((char *)ctx->gneed.p + need_bytes);
-            PDT_LAUNCH(256, k_chunk_need<T>, dim3((unsigned)n_chunks), dim3(256), 0, st, (const T *)d_agc, n_out, chunk_out, n_chunks,
-                               (unsigned char *)ctx->gneed.p);
-            // chunks without a walk in one stride: where sampling instants stay multiples of 2^(E - p) below 2^E (k_gardner_ring)
-            T gran_scale = 0;
-            if (!ctx->tune.gardner_nostride) {
-                const double top = (double)chunk_out + 2.0 * (double)GP.step + 2.0;
-                const int E = ilogb(top) + 1, p = sizeof(T) == 8 ? 53 : 24;
-                const T sc = (T)ldexp(1.0, p - E);
-                const T gstep = GP.step * sc;
-                if (E < p && gstep == (T)rint((double)gstep) && (double)gstep < ldexp(1.0, p - 1)) gran_scale = sc;
-            }
-            PDT_LAUNCH(64 * (RING_NB + 1), (k_gardner_ring<T, RING_LEN, RING_NB, RING_OUT>), dim3(1), dim3(64 * (RING_NB + 1)), 0, st,
-                               (const T *)d_agc, (const T *)d_lock, GP, (const unsigned char *)ctx->gneed.p, d_sym, d_symidx, &d_sc->nsym,
-                               sym_cap, d_calm, gran_scale);
-            PDT_LAUNCH(256, k_calm_emit<T>, dim3((unsigned)((n_chunks + 255) / 256)), dim3(256), 0, st, (const unsigned char *)ctx->gneed.p,
-                               (const CalmEntry<T> *)d_calm, GP, d_sym, d_symidx, sym_cap);
-        } else if (small_need <= SMALL_LEN && small_syms < SMALL_OUT && !ctx->tune.gardner_onebuf && !seg)
-            PDT_LAUNCH(256, (k_gardner_small<T, SMALL_LEN, SMALL_OUT>), dim3(1), dim3(256), 0, st, (const T *)d_agc, (const T *)d_lock, GP,
-                               d_sym, d_symidx, &d_sc->nsym, sym_cap);
-        else
-            PDT_LAUNCH(256, (k_gardner<T, GardnerLds<T>::LEN, GardnerLds<T>::OUT>), dim3(1), dim3(256), 0, st, d_agc, d_lock, GP, d_sym, d_symidx,
-                               &d_sc->nsym, sym_cap, (const GardnerEntry<T> *)nullptr, carry_in, d_carry_out, 0ll, 1, (const unsigned char *)nullptr);
-        L.end();
-    }
-
-    // ---- Manchester
-    L.begin("manchester");
-    PDT_LAUNCH(PDT_TILE_THREADS, k_manch_tile<T>, dim3((unsigned)n_tiles), dim3(PDT_TILE_THREADS), 0, st, d_sym, &d_sc->nsym, manch_thr,
-                       d_tiles, sym_pad);
-    PDT_LAUNCH(1024, k_manch_scan, dim3(1), dim3(1024), 0, st, d_tiles, &d_sc->nsym, &d_sc->nbits, sym_pad, clock0, bit0,
-                       seg ? &d_tail->clock : (unsigned *)nullptr);
-    PDT_LAUNCH(PDT_TILE_THREADS, k_manch_emit<T>, dim3((unsigned)n_tiles), dim3(PDT_TILE_THREADS), 0, st, d_sym, &d_sc->nsym, manch_thr,
-                       d_tiles, d_bits, d_bitsym, bit_cap, sym_pad);
-    L.end();
-
-    // ---- byte sync
-    L.begin("bytesync");
-    launch_bytesync(ctx, PL, st, SP, d_sc, bit_cap, hit_cap, frame_cap, sync_min_pos);
-    L.end();
-    if (seg) {
-        // everything the next segment starts from, in one record
-        const long long last_pll = (N > 0) ? (N - 1) / Bp : -1;
-        PDT_LAUNCH(256, (k_seg_tail<T, PllSeam<T>, AgcSeam<T>>), dim3(1), dim3(256), 0, st, (const PllSeam<T> *)ctx->seams_pll.p, last_pll,
-                   (const T *)d_lock, N, (const AgcSeam<T> *)ctx->seams_agc.p, agc_last_block, (const T *)d_sym, &d_sc->nsym,
-                   (const unsigned char *)d_bits, (const unsigned *)d_bitsym, (const long long *)d_symidx, &d_sc->nbits,
-                   (long long)bit0, d_tail);
-        PL.copy(OP_D2H, spin + 4096, d_tail, sizeof(SegTail<T>));
-    }
-    ctx->pend_chunks = 0;
-    if (inject) {
-        // the stage call ends behind the PLL: drop what was recorded for the later stages (their counters stay zero)
-        PL.ops.resize(ops_after_pll);
-    } else if (quality && n_chunks > 0) {
-        // (N > 0 here; a context without a PLL run -- never -- would leave avg_phase 0)
-        if (quality_side) {                                  // the averagePhase stream is complete
-            PL.simple(OP_JOIN_RECORD);
-            PL.simple(OP_JOIN_WAIT);
-        }
-        PDT_LAUNCH(256, k_chunk_info<T>, dim3((unsigned)((n_chunks + 255) / 256)), dim3(256), 0, st, (const T *)d_avgph, N, chunk, n_chunks,
-                           interp, (const long long *)d_symidx, (const unsigned long long *)&d_sc->nsym, (const unsigned *)d_bitsym,
-                           (const unsigned long long *)&d_sc->nbits, (ChunkInfo *)ctx->chunkinfo.p);
-        // (a segment: the new chunks' records; those of the window's history were reported by the segments before)
-        const long long rep_first = seg ? first / chunk : 0;
-        PL.copy(OP_D2H, ctx->qual_pin, (const ChunkInfo *)ctx->chunkinfo.p + rep_first, (size_t)(n_chunks - rep_first) * sizeof(ChunkInfo));
-        ctx->pend_chunks = (uint64_t)(n_chunks - rep_first);
-    }
-    PL.simple(OP_EV1);
-
-    // ---- results back to the host
-    // one synchronisation: the scalars, the lock record and (speculatively, into pinned memory) as many frame
-    // records as the previous call of this context produced, plus a margin
-    // (the overlapped ingest's segments differ in length: the whole capacity -- about twice what a segment yields, a few MB into
-    // pinned memory -- rather than a second, blocking copy between two segments)
-    const uint32_t spec_frames = (seg && seg->in_place) ? frame_cap : std::min<uint32_t>(frame_cap, ctx->last_nframes + ctx->last_nframes / 8 + 64);
-    if ((size_t)spec_frames * sizeof(FrameRec) > ctx->pinned_cap) {
-        if (ctx->pinned) (void)hipHostFree(ctx->pinned);
-        ctx->pinned = nullptr;
-        ctx->pinned_cap = 0;
-        const size_t want = (size_t)spec_frames * sizeof(FrameRec) * 2 + 4096;
-        if (timed_host_malloc((void **)&ctx->pinned, want) == hipSuccess) ctx->pinned_cap = want;
-        else (void)hipGetLastError();
-    }
-    const uint32_t got_frames = (ctx->pinned_cap >= (size_t)spec_frames * sizeof(FrameRec)) ? spec_frames : 0u;
-    static_assert(sizeof(PllLockInfo<T>) <= 96, "lock record staging");
-    PL.copy(OP_D2H, ctx->pend_sc, d_sc, sizeof(DevScalars));
-    PL.copy(OP_D2H, ctx->pend_info, d_info, sizeof(PllLockInfo<T>));
-    if (got_frames) PL.copy(OP_D2H, ctx->pinned, d_frames, (size_t)got_frames * sizeof(FrameRec));
-    ctx->pend_got_frames = got_frames;
-    ctx->pend_n = n;
-    ctx->pending = true;
-    if (phase == RUN_ALL) {
-        pdt_ctx *self = ctx;
-        if ((rc = execute_plans(&self, 1))) return rc;
-    }
-    }   // phase != RUN_FINISH
-    if (phase == RUN_ENQUEUE) return PDT_OK;
-    FinishArgs FA;
-    FA.argos = argos; FA.need_lock = need_lock; FA.fuse_mix = fuse_mix;
-    FA.N = N; FA.n_out = n_out; FA.chunk = chunk; FA.chunk_out = chunk_out; FA.first = first; FA.first_out = first_out; FA.sym_cap = sym_cap;
-    FA.interp = interp; FA.ntaps = ntaps; FA.hit_cap = hit_cap; FA.frame_cap = frame_cap; FA.SP = SP;
-    return finish_capture<T>(ctx, n, FA);
-}
-
+namespace {
 
 // ---------------------------------------------------------------- host -> HBM ingest
 // The capture (a file the caller opened, or host memory) is cut into 2 MiB spans.  A few host threads bring the spans into
@@ -3019,487 +1077,6 @@ int pdt_stage_bytesync_from(pdt_ctx *ctx, const uint8_t *bits_host, uint64_t nbi
     return PDT_OK;
 }
 
-// ---------------------------------------------------------------- stage-level entry points
-// One stage of the chain on caller data, the reference function's hidden statics as an explicit state record, so that the
-// per-chunk dumps of the reference (or of the oracle) can be replayed stage by stage through the kernels the whole-capture
-// path uses.
-extern "C++" {
-template <typename T> static int stage_manchester(pdt_ctx *ctx, const void *sym_host, uint64_t nsym, double thr_d,
-                                                  pdt_manchester_state *state, uint8_t *bits_out, uint32_t *bit_symbol_out,
-                                                  uint64_t *nbits_out)
-{
-    pdt_manchester_state fresh;
-    memset(&fresh, 0, sizeof fresh);
-    if (!state) state = &fresh;
-    // the two symbols the decisions look back on go in front, placed so that local and stream symbol parities agree
-    const long long pad = 2 + (long long)(state->even_odd & 1u);
-    const long long total = pad + (long long)nsym;
-    const long long sym_cap = total + 64, bit_cap = sym_cap;
-    const long long n_tiles = (sym_cap + PDT_TILE - 1) / PDT_TILE;
-    int rc;
-    if ((rc = ctx->sym.ensure((size_t)sym_cap * sizeof(T)))) return rc;
-    if ((rc = ctx->bits.ensure((size_t)bit_cap))) return rc;
-    if ((rc = ctx->bitsym.ensure((size_t)bit_cap * sizeof(unsigned)))) return rc;
-    if ((rc = ctx->hits.ensure((size_t)n_tiles * sizeof(ManchTile)))) return rc;
-    if ((rc = ctx->scal.ensure(sizeof(DevScalars)))) return rc;
-    hipStream_t st = ctx->stream;
-    T *d_sym = (T *)ctx->sym.p;
-    ManchTile *d_tiles = (ManchTile *)ctx->hits.p;
-    DevScalars *d_sc = (DevScalars *)ctx->scal.p;
-    DevScalars sc;
-    memset(&sc, 0, sizeof sc);
-    sc.nsym = (unsigned long long)total;
-    T hist[4] = { 0, 0, 0, 0 };
-    hist[pad - 2] = (T)state->previous;
-    hist[pad - 1] = (T)state->current;
-    const T thr = (T)thr_d;
-    Plan &PL = ctx->plan;
-    PL.clear();
-    PL.side_stream = ctx->stream2;
-    PL.copy(OP_H2D, d_sc, &sc, sizeof sc);
-    PL.copy(OP_H2D, d_sym, hist, (size_t)pad * sizeof(T));
-    if (nsym) PL.copy(OP_H2D, d_sym + pad, sym_host, (size_t)nsym * sizeof(T));
-    PDT_LAUNCH(PDT_TILE_THREADS, k_manch_tile<T>, dim3((unsigned)n_tiles), dim3(PDT_TILE_THREADS), 0, st, (const T *)d_sym,
-               (const unsigned long long *)&d_sc->nsym, thr, d_tiles, pad);
-    PDT_LAUNCH(1024, k_manch_scan, dim3(1), dim3(1024), 0, st, d_tiles, (const unsigned long long *)&d_sc->nsym, &d_sc->nbits, pad,
-               (unsigned)(state->clockmod & 1u), 0ull, &d_sc->pad0_);
-    PDT_LAUNCH(PDT_TILE_THREADS, k_manch_emit<T>, dim3((unsigned)n_tiles), dim3(PDT_TILE_THREADS), 0, st, (const T *)d_sym,
-               (const unsigned long long *)&d_sc->nsym, thr, d_tiles, (unsigned char *)ctx->bits.p, (unsigned *)ctx->bitsym.p, bit_cap, pad);
-    DevScalars *back = ctx->pend_sc;                                  // pinned
-    PL.copy(OP_D2H, back, d_sc, sizeof sc);
-    {
-        pdt_ctx *self = ctx;
-        if ((rc = execute_plans(&self, 1))) return rc;
-    }
-    HIP_TRY(hipStreamSynchronize(st));
-    sc = *back;
-    if ((long long)sc.nbits > bit_cap) return PDT_ERR_STATE;
-    if (sc.nbits && bits_out) HIP_TRY(hipMemcpy(bits_out, ctx->bits.p, (size_t)sc.nbits, hipMemcpyDeviceToHost));
-    if (sc.nbits && bit_symbol_out) {
-        HIP_TRY(hipMemcpy(bit_symbol_out, ctx->bitsym.p, (size_t)sc.nbits * sizeof(unsigned), hipMemcpyDeviceToHost));
-        for (uint64_t b = 0; b < sc.nbits; b++) bit_symbol_out[b] -= (uint32_t)pad;       // index into this call's symbols
-    }
-    if (nbits_out) *nbits_out = sc.nbits;
-    // ManchesterDecode.c:16-20: the statics after the call
-    const T *sy = (const T *)sym_host;
-    if (nsym >= 2) { state->previous = (double)sy[nsym - 2]; state->current = (double)sy[nsym - 1]; }
-    else if (nsym == 1) { state->previous = state->current; state->current = (double)sy[0]; }
-    state->clockmod = sc.pad0_;
-    state->even_odd = (uint32_t)((state->even_odd + nsym) & 0xffu);                       // unsigned char evenOddCounter
-    memset(ctx->stage_len, 0, sizeof ctx->stage_len);
-    return PDT_OK;
-}
-
-template <typename T> static int stage_fir(pdt_ctx *ctx, const void *in_host, uint64_t n, pdt_fir_state *state, void *out_host)
-{
-    pdt_fir_state fresh;
-    memset(&fresh, 0, sizeof fresh);
-    if (!state) state = &fresh;
-    const bool argos = ctx->cfg.mode == PDT_MODE_ARGOS;
-    const int interp = (int)ctx->interp, ntaps = (int)ctx->ntaps;
-    const int K = argos ? ntaps : ntaps / interp;                      // inputs an output looks back on
-    if (K < 1 || K > 64) return PDT_ERR_ARG;
-    // POES: the reference's ring keeps input m in slot m mod K and sums the slots in ascending order (LowPassFilter.c:43-70),
-    // so the local index of every input must equal its stream index modulo K: p zeros, the K last inputs, the new ones
-    const long long p = argos ? 0 : (long long)(state->count % (uint64_t)K);
-    const long long lead = p + K;
-    const long long N = lead + (long long)n, n_out = N * interp;
-    int rc;
-    if ((rc = ctx->pll.ensure((size_t)(N + 1) * sizeof(T)))) return rc;
-    if ((rc = ctx->fir.ensure((size_t)(n_out + 1) * sizeof(T)))) return rc;
-    hipStream_t st = ctx->stream;
-    T *d_in = (T *)ctx->pll.p, *d_out = (T *)ctx->fir.p, *d_taps = (T *)ctx->taps.p;
-    std::vector<T> head((size_t)lead, (T)0);
-    for (int i = 0; i < K; i++) head[(size_t)(p + i)] = (T)state->history[i];
-    Plan &PL = ctx->plan;
-    PL.clear();
-    PL.side_stream = ctx->stream2;
-    PL.copy(OP_H2D, d_in, head.data(), (size_t)lead * sizeof(T));
-    if (n) PL.copy(OP_H2D, d_in + lead, in_host, (size_t)n * sizeof(T));
-    const int opt = 8;
-    const long long tile = (long long)PDT_FIR_THREADS * opt;
-    const long long grid = (n_out + tile - 1) / tile;
-    if (argos) {
-        const size_t sh = (size_t)(ntaps + tile + ntaps + 8) * sizeof(T);
-        PDT_LAUNCH(PDT_FIR_THREADS, k_fir_plain<T>, dim3((unsigned)grid), dim3(PDT_FIR_THREADS), sh, st, (const T *)d_in, N, ntaps,
-                   (const T *)d_taps, d_out, opt);
-    } else {
-        const size_t sh_rt = (size_t)(65 * (K + 1) + 3 + 64 * K * interp) * sizeof(T);
-        const long long tiles_rt = (N + 64ll * K - 1) / (64ll * K);
-        const unsigned grid_rt = (unsigned)std::min<long long>(tiles_rt, 256ll * 32);
-        bool done = false;
-        if (K == 26 && sh_rt <= 64000 && ctx->taps_rot.p && !ctx->tune.fir_generic) {     // the kernel of the whole-capture path
-            done = true;
-            switch (interp) {
-#define PDT_FIR_CASE(I)                                                                                                       \
-    case I:                                                                                                                   \
-        PDT_LAUNCH(PDT_FIR_THREADS, (k_fir_interp_rt<T, I, 26>), dim3(grid_rt), dim3(PDT_FIR_THREADS), sh_rt, st, (const T *)d_in, N, (const T *)ctx->taps_rot.p, d_out, \
-                           (AgcMap *)nullptr, (T)0);                                                                          \
-        break;
-                PDT_FIR_CASE(1) PDT_FIR_CASE(2) PDT_FIR_CASE(3) PDT_FIR_CASE(4) PDT_FIR_CASE(5) PDT_FIR_CASE(6) PDT_FIR_CASE(7) PDT_FIR_CASE(8)
-#undef PDT_FIR_CASE
-            default: done = false;
-            }
-        }
-        if (!done) {
-            const size_t sh = (size_t)(ntaps + tile / interp + K + 8) * sizeof(T);
-            PDT_LAUNCH(PDT_FIR_THREADS, k_fir_interp<T>, dim3((unsigned)grid), dim3(PDT_FIR_THREADS), sh, st, (const T *)d_in, N, interp, K,
-                       (const T *)d_taps, d_out, opt);
-        }
-    }
-    {
-        pdt_ctx *self = ctx;
-        if ((rc = execute_plans(&self, 1))) return rc;
-    }
-    HIP_TRY(hipStreamSynchronize(st));
-    if (n && out_host)
-        HIP_TRY(hipMemcpy(out_host, d_out + lead * interp, (size_t)n * (size_t)interp * sizeof(T), hipMemcpyDeviceToHost));
-    // the ring after the call: the last K inputs, oldest first
-    const T *x = (const T *)in_host;
-    double nh[64];
-    for (int i = 0; i < K; i++) {
-        const long long src = (long long)n - K + i;                   // index into the new inputs, negative = older history
-        nh[i] = src >= 0 ? (double)x[src] : state->history[K + src];
-    }
-    memcpy(state->history, nh, sizeof(double) * (size_t)K);
-    state->count += n;
-    memset(ctx->stage_len, 0, sizeof ctx->stage_len);
-    return PDT_OK;
-}
-
-template <typename T> static int stage_pll(pdt_ctx *ctx, const void *iq_host, uint64_t n, int fmt, pdt_pll_state *state, void *out_host,
-                                           void *lock_out_host, double *avg_phase_ret)
-{
-    const size_t fb = fmt == PDT_FMT_F32 ? 8 : 4;                     // bytes per I,Q pair
-    pdt_pll_state fresh;
-    memset(&fresh, 0, sizeof fresh);
-    if (!state) state = &fresh;
-    if (n == 0) {                                                     // the loop body never runs; :277 returns the static
-        if (avg_phase_ret) *avg_phase_ret = state->started ? state->avg_phase : 0.0;
-        return PDT_OK;
-    }
-    const bool was_locked = state->started && state->locked;
-    const uint64_t lead = was_locked ? 1 : 0;                         // a dummy sample in front stands for "locked before sample 0"
-    const uint64_t N = n + lead;
-    int rc = ctx->pcm.ensure((size_t)N * fb + 16);
-    if (rc) return rc;
-    HIP_TRY(hipMemset(ctx->pcm.p, 0, 8));
-    HIP_TRY(hipMemcpy((char *)ctx->pcm.p + lead * fb, iq_host, (size_t)n * fb, hipMemcpyHostToDevice));
-    ctx->pcm_dev = ctx->pcm.p;
-    ctx->pcm_fmt = fmt == PDT_FMT_F32 ? 1 : 0;                        // float pairs = `float complex` as they are / int16 pairs, wave.c:127-172
-    ctx->inj.active = true;
-    ctx->inj.started = state->started != 0;
-    ctx->inj.locked = was_locked;
-    ctx->inj.phase = state->phase; ctx->inj.freq = state->freq; ctx->inj.avg = state->avg_phase;
-    ctx->inj.locksig = state->locksig; ctx->inj.sweep = state->sweep;
-    ctx->batch_hint = 1;
-    ctx->n_samples = N;
-    ctx->n_out = N * ctx->interp;
-    rc = run_capture<T>(ctx, N, RUN_ALL);
-    ctx->inj.active = false;
-    if (rc) return rc;
-    // outputs and the statics after the call, from the streams the run left on the device
-    if (out_host) HIP_TRY(hipMemcpy(out_host, (const T *)ctx->pll.p + lead, (size_t)n * sizeof(T), hipMemcpyDeviceToHost));
-    if (lock_out_host) HIP_TRY(hipMemcpy(lock_out_host, (const T *)ctx->lock.p + lead, (size_t)n * sizeof(T), hipMemcpyDeviceToHost));
-    T last_lock = 0, last_avg = 0;
-    HIP_TRY(hipMemcpy(&last_lock, (const T *)ctx->lock.p + (N - 1), sizeof(T), hipMemcpyDeviceToHost));
-    HIP_TRY(hipMemcpy(&last_avg, (const T *)ctx->avgph.p + (N - 1), sizeof(T), hipMemcpyDeviceToHost));
-    PllLockInfo<T> info;
-    HIP_TRY(hipMemcpy(&info, ctx->lockinfo.p, sizeof info, hipMemcpyDeviceToHost));
-    state->started = 1;
-    if (info.lock_sample < 0) {                                       // still searching: the acquisition's state after the last sample
-        state->phase = (double)info.st.phase; state->freq = (double)info.st.freq; state->sweep = (double)info.st.sweep;
-    } else {
-        if (!was_locked) {
-            state->locked = 1;
-            state->lock_index = info.lock_sample;
-            state->lock_freq_hz = (double)(info.freq_at_lock * (T)ctx->cfg.sample_rate) / (2.0 * M_PI);   // CarrierTrackingPLL.c:269
-        }
-        state->sweep = (double)info.st.sweep;
-        if (info.lock_sample == (long long)N - 1) {                   // locked on the very last sample: nothing walked behind it
-            state->phase = (double)info.st.phase; state->freq = (double)info.st.freq;
-        } else {
-            PllSeam<T> sm;
-            const long long Bp = ctx->last_pll_block > 0 ? ctx->last_pll_block : 1;
-            HIP_TRY(hipMemcpy(&sm, (const PllSeam<T> *)ctx->seams_pll.p + ((long long)N - 1) / Bp, sizeof sm, hipMemcpyDeviceToHost));
-            state->phase = (double)sm.phase1; state->freq = (double)sm.freq1;
-        }
-    }
-    state->locksig = (double)last_lock;
-    state->avg_phase = (double)last_avg;
-    if (avg_phase_ret) *avg_phase_ret = (double)last_avg;
-    memset(ctx->stage_len, 0, sizeof ctx->stage_len);
-    ctx->frames_host.clear();
-    return PDT_OK;
-}
-
-template <typename T> static int stage_gardner(pdt_ctx *ctx, const void *in_host, uint64_t n, uint64_t capacity,
-                                               const void *neighbour_host, pdt_gardner_state *state, void *out_host,
-                                               uint64_t *pick_out, uint64_t *nsym_out)
-{
-    pdt_gardner_state fresh;
-    memset(&fresh, 0, sizeof fresh);
-    if (!state) state = &fresh;
-    const bool argos = ctx->cfg.mode == PDT_MODE_ARGOS;
-    const int interp = (int)ctx->interp;
-    const long long C = (long long)capacity, na = (long long)n;
-    // The sampler's reads past the chunk (Q3: the mid-point index is not rolled over with nextSample) see what the caller's
-    // buffer still holds behind element n -- for the kernels that is "the previous chunk of the stream": a stream of two
-    // chunks of C, the buffer as it stands and then its first n elements, walked from chunk 1 on.
-    const long long total = C + na;
-    const T Fs = (T)ctx->cfg.sample_rate;
-    const T fsi = Fs * (T)interp;
-    GardnerParams<T> GP;
-    const T baud = ctx->lp.gardner_baud != 0 ? (T)ctx->lp.gardner_baud : argos ? (T)(400 * 2.0) : (T)(8320 * 2 + 0.3);   // main.c:90 / ARGOS main.c:64
-    GP.step = (T)(int)fsi / baud;                                              // GardenerClockRecovery.c:19
-    GP.kp = (ctx->lp.gardner_kp != 0 || (ctx->lp.zero_mask & PDT_LP_ZERO_GARDNER_KP)) ? (T)ctx->lp.gardner_kp : (T)3.0;
-    GP.lim = (ctx->lp.gardner_step_range != 0 || (ctx->lp.zero_mask & PDT_LP_ZERO_GARDNER_STEP_RANGE)) ? (T)ctx->lp.gardner_step_range : (T)0.1;
-    GP.n_total = total;
-    GP.chunk_out = C;
-    GP.argos_heap = 0;
-    GP.argos_field_bits = 0;
-    GP.argos_even = 0;
-    if (argos && neighbour_host && (size_t)C * 8 < 128 * 1024) {              // Q16: the array malloc'd behind this one
-        const unsigned long long req = 8ull * (unsigned long long)C;
-        GP.argos_heap = 1;
-        GP.argos_field_bits = ((req + 8 + 15) & ~15ull) | 1ull;
-        GP.argos_even = ((req + 8) % 16) != 0;
-    }
-    const long long sym_cap = (long long)((double)na / ((double)GP.step - 0.25)) + 64;
-    int rc;
-    if ((rc = ctx->agc.ensure((size_t)(total + 1) * sizeof(T)))) return rc;
-    if ((rc = ctx->lock.ensure((size_t)(total + 1) * sizeof(T)))) return rc;
-    if ((rc = ctx->sym.ensure((size_t)sym_cap * sizeof(T)))) return rc;
-    if ((rc = ctx->symidx.ensure((size_t)sym_cap * sizeof(long long)))) return rc;
-    if ((rc = ctx->scal.ensure(sizeof(DevScalars)))) return rc;
-    if ((rc = ctx->seg_dev.ensure(sizeof(SegTail<T>) + 256))) return rc;
-    hipStream_t st = ctx->stream;
-    T *d_in = (T *)ctx->agc.p, *d_nb = (T *)ctx->lock.p;
-    DevScalars *d_sc = (DevScalars *)ctx->scal.p;
-    SegTail<T> *d_tail = (SegTail<T> *)ctx->seg_dev.p;
-    SamplerCarry<T> carry_in;
-    carry_in.a = (T)state->next_sample; carry_in.b = (T)state->prev_bit; carry_in.c = (T)state->half_sample;
-    carry_in.c_first = 1; carry_in.count0 = 0;
-    Plan &PL = ctx->plan;
-    PL.clear();
-    PL.side_stream = ctx->stream2;
-    PL.memset_async(d_sc, 0, sizeof(DevScalars));
-    PL.copy(OP_H2D, d_in, in_host, (size_t)C * sizeof(T));
-    if (na) PL.copy(OP_H2D, d_in + C, in_host, (size_t)na * sizeof(T));
-    if (GP.argos_heap) {
-        PL.copy(OP_H2D, d_nb, neighbour_host, (size_t)C * sizeof(T));
-        if (na) PL.copy(OP_H2D, d_nb + C, neighbour_host, (size_t)na * sizeof(T));
-    }
-    PDT_LAUNCH(256, (k_gardner<T, GardnerLds<T>::LEN, GardnerLds<T>::OUT>), dim3(1), dim3(256), 0, st, (const T *)d_in,
-               (const T *)(GP.argos_heap ? d_nb : nullptr), GP, (T *)ctx->sym.p, (long long *)ctx->symidx.p, &d_sc->nsym, sym_cap,
-               (const GardnerEntry<T> *)nullptr, carry_in, &d_tail->sampler, 0ll, 1, (const unsigned char *)nullptr);
-    DevScalars *back = ctx->pend_sc;                                  // pinned
-    PL.copy(OP_D2H, back, d_sc, sizeof(DevScalars));
-    {
-        pdt_ctx *self = ctx;
-        if ((rc = execute_plans(&self, 1))) return rc;
-    }
-    HIP_TRY(hipStreamSynchronize(st));
-    const uint64_t nsym = back->nsym;
-    if ((long long)nsym > sym_cap) return PDT_ERR_STATE;
-    if (nsym && out_host) HIP_TRY(hipMemcpy(out_host, ctx->sym.p, (size_t)nsym * sizeof(T), hipMemcpyDeviceToHost));
-    if (nsym && pick_out) {
-        HIP_TRY(hipMemcpy(pick_out, ctx->symidx.p, (size_t)nsym * sizeof(long long), hipMemcpyDeviceToHost));
-        for (uint64_t k = 0; k < nsym; k++) pick_out[k] -= (uint64_t)C;                      // index into this call's samples
-    }
-    if (nsym_out) *nsym_out = nsym;
-    SamplerCarry<T> after;
-    HIP_TRY(hipMemcpy(&after, &d_tail->sampler, sizeof after, hipMemcpyDeviceToHost));
-    state->next_sample = (double)after.a; state->prev_bit = (double)after.b; state->half_sample = (double)after.c;
-    memset(ctx->stage_len, 0, sizeof ctx->stage_len);
-    return PDT_OK;
-}
-
-template <typename T> static int stage_static_gain(pdt_ctx *ctx, const void *iq_host, uint64_t n, int fmt, double level, double *gain_out)
-{
-    const size_t fb = fmt == PDT_FMT_F32 ? 8 : 4;
-    int rc;
-    if ((rc = ctx->pcm.ensure((size_t)n * fb + 16))) return rc;
-    if ((rc = ctx->mag.ensure((size_t)(n + 1) * sizeof(T)))) return rc;
-    if ((rc = ctx->scal.ensure(sizeof(DevScalars)))) return rc;
-    hipStream_t st = ctx->stream;
-    DevScalars *d_sc = (DevScalars *)ctx->scal.p;
-    IqSrc src;
-    src.p = ctx->pcm.p;
-    src.fmt = fmt == PDT_FMT_F32 ? 1 : 0;
-    Plan &PL = ctx->plan;
-    PL.clear();
-    PL.side_stream = ctx->stream2;
-    PL.memset_async(d_sc, 0, sizeof(DevScalars));
-    PL.copy(OP_H2D, ctx->pcm.p, iq_host, (size_t)n * fb);
-    PDT_LAUNCH(256, k_static_gain<T>, dim3(1), dim3(256), 0, st, src, (long long)n, (T *)ctx->mag.p, (T)level, 0.0, (T *)&d_sc->norm);
-    DevScalars *back = ctx->pend_sc;                                  // pinned
-    PL.copy(OP_D2H, back, d_sc, sizeof(DevScalars));
-    {
-        pdt_ctx *self = ctx;
-        if ((rc = execute_plans(&self, 1))) return rc;
-    }
-    HIP_TRY(hipStreamSynchronize(st));
-    T g;
-    memcpy(&g, &back->norm, sizeof(T));
-    if (gain_out) *gain_out = (double)g;
-    return PDT_OK;
-}
-
-template <typename T> static int stage_mm(pdt_ctx *ctx, const void *in_host, uint64_t n, pdt_mm_state *state, void *out_host,
-                                          uint64_t *pick_out, uint64_t *nsym_out)
-{
-    pdt_mm_state fresh;
-    memset(&fresh, 0, sizeof fresh);
-    if (!state) state = &fresh;
-    if (nsym_out) *nsym_out = 0;
-    const bool argos = ctx->cfg.mode == PDT_MODE_ARGOS;
-    const T Fs = (T)ctx->cfg.sample_rate;
-    const T fsi = Fs * (T)(int)ctx->interp;
-    const T baud = ctx->lp.gardner_baud != 0 ? (T)ctx->lp.gardner_baud : argos ? (T)(400 * 2.0) : (T)(8320 * 2 + 0.3);
-    MmParams<T> MP;
-    const T rangeT = (T)(ctx->cfg.mm_step_range != 0 ? ctx->cfg.mm_step_range : 3.0);     // ARGOSdemod/main.c:277
-    MP.kp = (T)(ctx->cfg.mm_kp != 0 ? ctx->cfg.mm_kp : 0.15);
-    MP.step0 = (T)(int)fsi / baud;                                                        // MMClockRecovery.c:20
-    MP.step_max = (T)(int)fsi / (baud - rangeT);                                          // :9
-    MP.step_min = (T)(int)fsi / (baud + rangeT);                                          // :10
-    MP.n_total = (long long)n;
-    MP.chunk_out = (long long)n;                                                          // one call = one chunk
-    if (!state->started) { state->started = 1; state->next_sample = 0; state->step_size = (double)MP.step0; state->sample_last = 0; }
-    if (n == 0) return PDT_OK;
-    const long long sym_cap = (long long)((double)n / ((double)MP.step_min * 0.999)) + 64;
-    int rc;
-    if ((rc = ctx->agc.ensure((size_t)(n + 1) * sizeof(T)))) return rc;
-    if ((rc = ctx->sym.ensure((size_t)sym_cap * sizeof(T)))) return rc;
-    if ((rc = ctx->symidx.ensure((size_t)sym_cap * sizeof(long long)))) return rc;
-    if ((rc = ctx->scal.ensure(sizeof(DevScalars)))) return rc;
-    if ((rc = ctx->seg_dev.ensure(sizeof(SegTail<T>) + 256))) return rc;
-    hipStream_t st = ctx->stream;
-    DevScalars *d_sc = (DevScalars *)ctx->scal.p;
-    SegTail<T> *d_tail = (SegTail<T> *)ctx->seg_dev.p;
-    SamplerCarry<T> carry_in;
-    carry_in.a = (T)state->next_sample; carry_in.b = (T)state->step_size; carry_in.c = (T)state->sample_last;
-    carry_in.c_first = 0; carry_in.count0 = 0;
-    Plan &PL = ctx->plan;
-    PL.clear();
-    PL.side_stream = ctx->stream2;
-    PL.memset_async(d_sc, 0, sizeof(DevScalars));
-    PL.copy(OP_H2D, ctx->agc.p, in_host, (size_t)n * sizeof(T));
-    PDT_LAUNCH(PDT_GARDNER_THREADS, (k_mm<T, 8192, 1024>), dim3(1), dim3(PDT_GARDNER_THREADS), 0, st, (const T *)ctx->agc.p, MP,
-               (T *)ctx->sym.p, (long long *)ctx->symidx.p, &d_sc->nsym, sym_cap, carry_in, 1, &d_tail->sampler);
-    DevScalars *back = ctx->pend_sc;                                  // pinned
-    PL.copy(OP_D2H, back, d_sc, sizeof(DevScalars));
-    {
-        pdt_ctx *self = ctx;
-        if ((rc = execute_plans(&self, 1))) return rc;
-    }
-    HIP_TRY(hipStreamSynchronize(st));
-    const uint64_t nsym = back->nsym;
-    if ((long long)nsym > sym_cap) return PDT_ERR_STATE;
-    if (nsym && out_host) HIP_TRY(hipMemcpy(out_host, ctx->sym.p, (size_t)nsym * sizeof(T), hipMemcpyDeviceToHost));
-    if (nsym && pick_out) HIP_TRY(hipMemcpy(pick_out, ctx->symidx.p, (size_t)nsym * sizeof(long long), hipMemcpyDeviceToHost));
-    if (nsym_out) *nsym_out = nsym;
-    SamplerCarry<T> after;
-    HIP_TRY(hipMemcpy(&after, &d_tail->sampler, sizeof after, hipMemcpyDeviceToHost));
-    state->next_sample = (double)after.a; state->step_size = (double)after.b; state->sample_last = (double)after.c;
-    memset(ctx->stage_len, 0, sizeof ctx->stage_len);
-    return PDT_OK;
-}
-
-template <typename T> static int stage_agc(pdt_ctx *ctx, void *data_host, uint64_t n, double initial, double attack, double decay,
-                                           pdt_agc_state *state)
-{
-    pdt_agc_state fresh;
-    memset(&fresh, 0, sizeof fresh);
-    if (!state) state = &fresh;
-    const bool argos = ctx->cfg.mode == PDT_MODE_ARGOS;
-    const int interp = (int)ctx->interp;
-    const T Fs = (T)ctx->cfg.sample_rate;
-    const T fsi = Fs * (T)interp;                                              // POESTIPdemod/main.c:429
-    AgcParams<T> AP;
-    AP.attack = attack != 0 ? (T)attack : ctx->lp.agc_attack != 0 ? (T)ctx->lp.agc_attack : (T)(79.5775 * (2.0 * M_PI / (double)fsi));
-    AP.decay = decay != 0 ? (T)decay : ctx->lp.agc_decay != 0 ? (T)ctx->lp.agc_decay : (T)(159.1549 * (2.0 * M_PI / (double)fsi));
-    AP.squelch = 0;
-    AP.squelch_thr = 0;
-    AP.raw_out = nullptr;
-    const T gain0 = state->started ? (T)state->gain : (T)initial;              // AGC.c:91-95: `initial` counts on the first call only
-    state->started = 1;
-    if (n == 0) { state->gain = (double)gain0; return PDT_OK; }
-    // the whole-capture path's block geometry (any values give the same output)
-    const double fs_d = (double)ctx->cfg.sample_rate;
-    auto round4 = [](long long v) { return (v + 3) / 4 * 4; };
-    long long Ba = ctx->cfg.agc_block ? ctx->cfg.agc_block : (long long)((argos ? 0.125 : 0.0625) * fs_d * interp);
-    long long Wa = ctx->cfg.agc_warm ? ctx->cfg.agc_warm : (long long)((argos ? 2.0 : 1.0) * fs_d * interp);
-    Ba = std::max<long long>(64, round4(Ba));
-    Wa = round4(Wa);
-    const long long na = (long long)n, nb = (na + Ba - 1) / Ba, grid = (nb + 63) / 64;
-    int rc;
-    if ((rc = ctx->fir.ensure((size_t)(na + 1) * sizeof(T)))) return rc;
-    if ((rc = ctx->agc.ensure((size_t)(na + 1) * sizeof(T)))) return rc;
-    if ((rc = ctx->seams_agc.ensure((size_t)(nb + 1) * sizeof(AgcSeam<T>)))) return rc;
-    if ((rc = ctx->agc_maps.ensure((size_t)(nb + 1) * (sizeof(AgcMap) + sizeof(double))))) return rc;
-    if ((rc = ctx->scal.ensure(sizeof(DevScalars)))) return rc;
-    hipStream_t st = ctx->stream;
-    const T *a_in = (const T *)ctx->fir.p;
-    T *a_out = (T *)ctx->agc.p;
-    DevScalars *d_sc = (DevScalars *)ctx->scal.p;
-    T *d_norm = (T *)&d_sc->norm;
-    AgcMap *d_maps = (AgcMap *)ctx->agc_maps.p;
-    double *d_guess = (double *)(d_maps + nb + 1);
-    DevScalars sc;
-    memset(&sc, 0, sizeof sc);
-    memcpy(&sc.norm, &gain0, sizeof(T));
-    double agc_K = (sizeof(T) == 4) ? 11.0 : 34.0;
-    if (ctx->tune.agc_k > 0) agc_K = ctx->tune.agc_k;
-    Plan &PL = ctx->plan;
-    PL.clear();
-    PL.side_stream = ctx->stream2;
-    PL.copy(OP_H2D, d_sc, &sc, sizeof sc);
-    PL.copy(OP_H2D, ctx->fir.p, data_host, (size_t)na * sizeof(T));
-    PDT_LAUNCH(256, k_agc_affine<T>, dim3((unsigned)nb), dim3(256), 0, st, a_in, na, AP.decay, Ba, d_maps);
-    PDT_LAUNCH(1024, k_agc_guess<T>, dim3(1), dim3(1024), 0, st, (const AgcMap *)d_maps, nb, (const T *)d_norm, d_guess, 1, nb);
-    PDT_LAUNCH(64, k_agc_block<T>, dim3((unsigned)grid), dim3(64), 0, st, a_in, na, AP, d_norm, Ba, Wa, (const double *)d_guess,
-               (const T *)nullptr, a_out, (AgcSeam<T> *)ctx->seams_agc.p, agc_K, (T *)nullptr);
-    PDT_LAUNCH(1024, k_agc_scan<T>, dim3(1), dim3(1024), 0, st, na, Ba, (const AgcSeam<T> *)ctx->seams_agc.p, &d_sc->agc_first_bad);
-    PDT_LAUNCH(64, k_agc_fix<T>, dim3(1), dim3(64), 0, st, a_in, na, AP, Ba, (const T *)nullptr, a_out, (AgcSeam<T> *)ctx->seams_agc.p,
-               d_sc->counters, (const long long *)&d_sc->agc_first_bad, (T *)nullptr);
-    {
-        pdt_ctx *self = ctx;
-        if ((rc = execute_plans(&self, 1))) return rc;
-    }
-    HIP_TRY(hipStreamSynchronize(st));
-    HIP_TRY(hipMemcpy(data_host, a_out, (size_t)na * sizeof(T), hipMemcpyDeviceToHost));      // in place, as the reference
-    AgcSeam<T> last;
-    HIP_TRY(hipMemcpy(&last, (const AgcSeam<T> *)ctx->seams_agc.p + (nb - 1), sizeof last, hipMemcpyDeviceToHost));
-    state->gain = (double)last.g1;
-    memset(ctx->stage_len, 0, sizeof ctx->stage_len);
-    return PDT_OK;
-}
-
-template <typename T> static int stage_squelch(pdt_ctx *ctx, void *data_host, const void *lock_host, uint64_t n, double thr)
-{
-    if (n == 0) return PDT_OK;
-    int rc;
-    if ((rc = ctx->agc.ensure((size_t)(n + 4) * sizeof(T)))) return rc;
-    if ((rc = ctx->lock.ensure((size_t)(n + 4) * sizeof(T)))) return rc;
-    hipStream_t st = ctx->stream;
-    Plan &PL = ctx->plan;
-    PL.clear();
-    PL.side_stream = ctx->stream2;
-    PL.copy(OP_H2D, ctx->agc.p, data_host, (size_t)n * sizeof(T));
-    PL.copy(OP_H2D, ctx->lock.p, lock_host, (size_t)n * sizeof(T));
-    PDT_LAUNCH(256, k_squelch<T>, dim3((unsigned)((n + 1023) / 1024)), dim3(256), 0, st, (T *)ctx->agc.p, (const T *)ctx->lock.p, (long long)n,
-               (T)thr);
-    {
-        pdt_ctx *self = ctx;
-        if ((rc = execute_plans(&self, 1))) return rc;
-    }
-    HIP_TRY(hipStreamSynchronize(st));
-    HIP_TRY(hipMemcpy(data_host, ctx->agc.p, (size_t)n * sizeof(T), hipMemcpyDeviceToHost));
-    memset(ctx->stage_len, 0, sizeof ctx->stage_len);
-    return PDT_OK;
-}
-}  // extern "C++"
 
 int pdt_stage_pll(pdt_ctx *ctx, const void *iq_host, uint64_t n, int sample_format, pdt_pll_state *state, void *out_host,
                   void *lock_out_host, double *avg_phase_ret)
@@ -4438,3 +2015,4 @@ int pdt_kernel_times(const pdt_ctx *ctx, pdt_kernel_time *out, int max_entries)
 }
 
 }  // extern "C"
+

@@ -69,6 +69,33 @@ template <typename T> struct IqSample {
     }
 };
 
+// The same in two halves, so that a load can be issued long before its conversion is wanted (the acquisition's pipeline): the raw
+// words of sample i, and their conversion -- exactly IqSample<T>::get's.
+__device__ __forceinline__ uint2 iq_raw(IqSrc s, long long i)
+{
+    uint2 r;
+    if (s.fmt == 0) {
+        r.x = (unsigned)reinterpret_cast<const int *>(s.p)[i];
+        r.y = 0u;
+    } else {
+        const float2 v = reinterpret_cast<const float2 *>(s.p)[i];
+        r.x = __float_as_uint(v.x);
+        r.y = __float_as_uint(v.y);
+    }
+    return r;
+}
+template <typename T> __device__ __forceinline__ void iq_conv(int fmt, uint2 r, T &a, T &b)
+{
+    if (fmt == 0) {
+        const int v = (int)r.x;
+        a = (T)(short)(v & 0xffff) / (T)32768;
+        b = (T)(short)(v >> 16) / (T)32768;
+    } else {
+        a = (T)__uint_as_float(r.x);
+        b = (T)__uint_as_float(r.y);
+    }
+}
+
 // NS consecutive IQ samples with 16-byte loads (4 PCM16 pairs / 2 float pairs per load; the address need only be
 // 4- resp. 8-byte aligned).  Same conversion as IqSample<T>::get.  A lane-per-block access touches one cache line per lane
 // whatever its width, so the wide form is a quarter (half) of the load instructions; the elementwise kernels use it to
@@ -341,6 +368,78 @@ template <typename T> __device__ __forceinline__ void pll_sweep_sel(T &fr, T &sw
     sw = on ? s2 : sw;
 }
 
+// Four samples of the acquisition's loop filter (float, plain wrap) as ONE block of machine code: pll_phase_step's 16 operations
+// (the block of pll_vec4_asm below, same order, same results) and, with the sweep gate open, pll_sweep_sel's step in four:
+//   f2 = fr + sw;  t = |sw| with the sign of f2 (v_bfi);  rail = |f2| >= max;  sw = rail ? -sw : t
+// -- the reference's four-way if (CarrierTrackingPLL.c:239-252) with min = -max (make_pll_params: the two limits are one product
+// and its negation) and f2 never -0 (a sum is -0 only if both terms are, and the sweep step is not zero).  Round 6: the loop is the
+// pace of everything in front of the lock -- a lone wavefront, every operation an issue slot of ~2.2 ns -- and took 25 slots a
+// sample: theta by v_readlane, the phase kept by compare + select, seven operations of sweep logic.  Here theta arrives four
+// samples at a time by one broadcast LDS read, the four phases leave by one LDS write, and the sweep is four operations:
+// 20.5 slots.  pb[k] = the phase sample k was mixed with (what the detectors need); phase / freq / sweep = the state after the
+// fourth sample.
+template <bool OPEN>
+__device__ __forceinline__ void acq_vec4_asm(const Vec16<float> &th, float &phase, float &freq, float &sweep, float (&pb)[4], float alpha,
+                                             float beta, float minf, float maxf_v)
+{
+    const float hi = 6.2831854820251465f, d = 1.7484555314695172e-07f;
+    float t1, t2, e, f1, p0, p1, p2, p3;
+    // (a vector compare's mask wants two other instructions before it is read: inside the block nobody inserts wait states, so
+    // the select that ends a sweep step stands behind the first operation of the next sample's step)
+#define PDT_ACQ_HEAD(TH, P) "v_sub_f32 %[e], " TH ", " P "\n\t"
+#define PDT_ACQ_REST(P, PN)                                             \
+    "v_cmp_ge_f32_e64 vcc, |%[e]|, %[pi]\n\t"                           \
+    "v_bfi_b32 %[t1], %[mask], 1.0, %[e]\n\t"                           \
+    "v_fma_f32 %[t2], %[t1], %[nhi], %[e]\n\t"                          \
+    "v_fma_f32 %[t2], %[t1], %[d], %[t2]\n\t"                           \
+    "v_cndmask_b32_e32 %[e], %[e], %[t2], vcc\n\t"                      \
+    "v_mul_f32 %[t1], %[beta], %[e]\n\t"                                \
+    "v_add_f32 %[f1], %[fr], %[t1]\n\t"                                 \
+    "v_add_f32 %[t2], " P ", %[f1]\n\t"                                  \
+    "v_mul_f32 %[t1], %[alpha], %[e]\n\t"                               \
+    "v_add_f32 %[t2], %[t2], %[t1]\n\t"                                 \
+    "v_mul_f32 %[t1], 0x3e22f983, %[t2]\n\t"                            \
+    "v_trunc_f32 %[t1], %[t1]\n\t"                                      \
+    "v_fma_f32 %[t2], %[t1], %[nhi], %[t2]\n\t"                         \
+    "v_fma_f32 " PN ", %[t1], %[d], %[t2]\n\t"                           \
+    "v_med3_f32 %[fr], %[f1], %[minf], %[maxf]\n\t"
+#define PDT_ACQ_SWEEP_A                                                 \
+    "v_add_f32 %[fr], %[fr], %[sw]\n\t"                                 \
+    "v_cmp_ge_f32_e64 vcc, |%[fr]|, %[maxf]\n\t"                        \
+    "v_bfi_b32 %[t1], %[mask], %[sw], %[fr]\n\t"
+#define PDT_ACQ_SWEEP_B "v_cndmask_b32_e64 %[sw], %[t1], -%[sw], vcc\n\t"
+    pb[0] = phase;
+    if constexpr (OPEN)
+        asm volatile(PDT_ACQ_HEAD("%[th0]", "%[ph]") PDT_ACQ_REST("%[ph]", "%[p0]") PDT_ACQ_SWEEP_A
+                     PDT_ACQ_HEAD("%[th1]", "%[p0]") PDT_ACQ_SWEEP_B PDT_ACQ_REST("%[p0]", "%[p1]") PDT_ACQ_SWEEP_A
+                     PDT_ACQ_HEAD("%[th2]", "%[p1]") PDT_ACQ_SWEEP_B PDT_ACQ_REST("%[p1]", "%[p2]") PDT_ACQ_SWEEP_A
+                     PDT_ACQ_HEAD("%[th3]", "%[p2]") PDT_ACQ_SWEEP_B PDT_ACQ_REST("%[p2]", "%[p3]") PDT_ACQ_SWEEP_A
+                     "s_nop 0\n\t" PDT_ACQ_SWEEP_B
+                     : [fr] "+v"(freq), [sw] "+v"(sweep), [p0] "=&v"(p0), [p1] "=&v"(p1), [p2] "=&v"(p2), [p3] "=&v"(p3), [t1] "=&v"(t1),
+                       [t2] "=&v"(t2), [e] "=&v"(e), [f1] "=&v"(f1)
+                     : [th0] "v"(th.v[0]), [th1] "v"(th.v[1]), [th2] "v"(th.v[2]), [th3] "v"(th.v[3]), [ph] "v"(phase),
+                       [pi] "s"(3.14159274101257324f), [mask] "s"(0x7fffffffu), [nhi] "s"(-hi), [d] "s"(d), [alpha] "s"(alpha), [beta] "s"(beta),
+                       [minf] "s"(minf), [maxf] "v"(maxf_v)
+                     : "vcc");
+    else
+        asm volatile(PDT_ACQ_HEAD("%[th0]", "%[ph]") PDT_ACQ_REST("%[ph]", "%[p0]")
+                     PDT_ACQ_HEAD("%[th1]", "%[p0]") PDT_ACQ_REST("%[p0]", "%[p1]")
+                     PDT_ACQ_HEAD("%[th2]", "%[p1]") PDT_ACQ_REST("%[p1]", "%[p2]")
+                     PDT_ACQ_HEAD("%[th3]", "%[p2]") PDT_ACQ_REST("%[p2]", "%[p3]")
+                     : [fr] "+v"(freq), [p0] "=&v"(p0), [p1] "=&v"(p1), [p2] "=&v"(p2), [p3] "=&v"(p3), [t1] "=&v"(t1),
+                       [t2] "=&v"(t2), [e] "=&v"(e), [f1] "=&v"(f1)
+                     : [th0] "v"(th.v[0]), [th1] "v"(th.v[1]), [th2] "v"(th.v[2]), [th3] "v"(th.v[3]), [ph] "v"(phase),
+                       [pi] "s"(3.14159274101257324f), [mask] "s"(0x7fffffffu), [nhi] "s"(-hi), [d] "s"(d), [alpha] "s"(alpha), [beta] "s"(beta),
+                       [minf] "s"(minf), [maxf] "v"(maxf_v)
+                     : "vcc");
+#undef PDT_ACQ_HEAD
+#undef PDT_ACQ_REST
+#undef PDT_ACQ_SWEEP_A
+#undef PDT_ACQ_SWEEP_B
+    pb[1] = p0; pb[2] = p1; pb[3] = p2;
+    phase = p3;
+}
+
 // Acquisition, pipelined over two wavefronts.  The stream is taken in batches, sample k of a batch in lane k.  The (phase, freq)
 // loop filter of a batch -- serial, run under the hypothesis that the sweep condition |pi/2 - averagePhase| < 0.05 keeps the value
 // it had (it changes a handful of times per capture) -- depends on the detector passes (lane-parallel sincos / mix / arctan2,
@@ -352,7 +451,7 @@ template <typename T> __device__ __forceinline__ void pll_sweep_sel(T &fr, T &sw
 #ifndef PDT_ACQP_NB
 #define PDT_ACQP_NB 64      // samples per batch of the two-wavefront pipeline (one per lane)
 #endif
-template <typename T> struct AcqSlot {
+template <typename T> struct alignas(16) AcqSlot {
     T phi[PDT_ACQP_NB];               // phase used for sample k (the value before its update)
     long long i0;
     int nb, valid, hyp;
@@ -372,6 +471,12 @@ __device__ __forceinline__ void k_pll_acquire_pipe(IqSrc pcm, long long n, PllPa
 {
     __shared__ AcqSlot<T> slot[2];
     __shared__ AcqVerdict<T> verdict;
+    // round 6, float with the plain wrap (POES): theta of the batch being filtered, read back four samples at a time (one broadcast
+    // LDS read in place of four v_readlane); the detectors' input terms as doubles and the two EMAs' values per sample likewise
+    constexpr bool FAST = std::is_same<T, float>::value && !SLOW && PDT_ACQP_NB == 64;
+    __shared__ __attribute__((aligned(16))) float s_theta[FAST ? PDT_ACQP_NB : 4];
+    __shared__ __attribute__((aligned(16))) double s_tu[FAST ? 2 * PDT_ACQP_NB : 2];
+    __shared__ __attribute__((aligned(16))) float s_ema[FAST ? 2 * PDT_ACQP_NB : 2];
     // EXCL: claim a whole SIMD's register file per wavefront (256 + 256 registers), so that the dispatcher can only put
     // these serial wavefronts on SIMDs that hold no wavefront of the concurrent block-parallel kernel -- sharing issue
     // slots with one costs them up to 15 %.  Only requested while that kernel leaves SIMDs free (the host decides).
@@ -412,6 +517,41 @@ __device__ __forceinline__ void k_pll_acquire_pipe(IqSrc pcm, long long n, PllPa
                 if (lane < PDT_ACQP_NB && i_pre + lane < n) th_pre = theta_of<T>(pcm, i_pre + lane);
                 T ph = phase, fr = freq, sw = sweep;
                 T phi_l = 0;
+                bool filtered = false;
+                if constexpr (FAST) {
+                    if (nb == PDT_ACQP_NB) {
+                        // the whole batch in sixteen blocks of four samples (acq_vec4_asm), no branch: theta of block g + 1 is
+                        // requested from LDS before block g runs (the LDS answers a wavefront's requests in order: the write
+                        // below is seen by the reads behind it)
+                        s_theta[lane] = th_l;
+                        float maxf_v = P.max_freq;
+                        asm volatile("" : "+v"(maxf_v));
+                        const Vec16<float> *tq = reinterpret_cast<const Vec16<float> *>(s_theta);
+                        Vec16<float> *pq = reinterpret_cast<Vec16<float> *>(mine.phi);
+                        Vec16<float> cur = tq[0];
+                        if (hyp) {
+#pragma unroll
+                            for (int g = 0; g < PDT_ACQP_NB / 4; g++) {
+                                const Vec16<float> nxt = tq[(g + 1) & (PDT_ACQP_NB / 4 - 1)];
+                                Vec16<float> pv;
+                                acq_vec4_asm<true>(cur, ph, fr, sw, pv.v, P.alpha_acq, P.beta_acq, P.min_freq, maxf_v);
+                                pq[g] = pv;
+                                cur = nxt;
+                            }
+                        } else {
+#pragma unroll
+                            for (int g = 0; g < PDT_ACQP_NB / 4; g++) {
+                                const Vec16<float> nxt = tq[(g + 1) & (PDT_ACQP_NB / 4 - 1)];
+                                Vec16<float> pv;
+                                acq_vec4_asm<false>(cur, ph, fr, sw, pv.v, P.alpha_acq, P.beta_acq, P.min_freq, maxf_v);
+                                pq[g] = pv;
+                                cur = nxt;
+                            }
+                        }
+                        filtered = true;
+                    }
+                }
+                if (!filtered) {
                 // (four samples per trip: a taken branch costs a lone wavefront as much as nine instructions.  This loop is the
                 // pace of the acquisition -- a lone wavefront, every operation an issue slot -- so it keeps only what the
                 // detectors need of every sample, the phase it was mixed with: the states around an event sample are replayed
@@ -437,6 +577,7 @@ __device__ __forceinline__ void k_pll_acquire_pipe(IqSrc pcm, long long n, PllPa
                     for (; k < nb; k++) filt_closed(k);
                 }
                 if (lane < nb) mine.phi[lane] = phi_l;
+                }   // !filtered
                 if (lane == 0) {
                     mine.i0 = i_prod; mine.nb = nb; mine.hyp = hyp ? 1 : 0; mine.valid = 1;
                     mine.ph_beg = phase; mine.fr_beg = freq; mine.sw_beg = sweep;
@@ -478,6 +619,35 @@ __device__ __forceinline__ void k_pll_acquire_pipe(IqSrc pcm, long long n, PllPa
                 // the serial part is the two EMAs only (a wavefront's pace is its instruction count); the sweep gate and
                 // the lock test of sample k are evaluated afterwards by lane k, which kept the EMA values of that sample
                 T av = avg, ls = locksig, av_l = 0, ls_l = 0;
+                bool ema_done = false;
+                if constexpr (FAST) {
+                    // the input terms of both EMAs as doubles side by side (one broadcast LDS read per sample in place of two
+                    // v_readlane and two conversions), the two values after every sample back through LDS (one write in place of
+                    // a compare and two selects): 14 issue slots a sample instead of 20 -- this wavefront must stay ahead of the
+                    // loop filter's, which round 6 made faster
+                    if (nb == PDT_ACQP_NB) {
+                        double2 tu;
+                        tu.x = (double)t_l;
+                        tu.y = (double)u_l;
+                        reinterpret_cast<double2 *>(s_tu)[lane] = tu;
+                        const double2 *tq = reinterpret_cast<const double2 *>(s_tu);
+                        float2 *eq = reinterpret_cast<float2 *>(s_ema);
+#pragma unroll 16
+                        for (int k = 0; k < PDT_ACQP_NB; k++) {
+                            const double2 in = tq[k];
+                            av = (T)((double)av * k_avg + in.x);
+                            ls = (T)((double)ls * k_lock + in.y);
+                            float2 o;
+                            o.x = (float)av;
+                            o.y = (float)ls;
+                            eq[k] = o;
+                        }
+                        const float2 mine_e = eq[lane];
+                        av_l = (T)mine_e.x;
+                        ls_l = (T)mine_e.y;
+                        ema_done = true;
+                    }
+                }
                 auto ema = [&](int k) {
                     av = (T)((double)av * k_avg + (double)lane_get(t_l, k));
                     ls = (T)((double)ls * k_lock + (double)lane_get(u_l, k));
@@ -486,8 +656,10 @@ __device__ __forceinline__ void k_pll_acquire_pipe(IqSrc pcm, long long n, PllPa
                     av_l = me ? av : av_l;
                 };
                 int k = 0;
-                for (; k + 4 <= nb; k += 4) { ema(k); ema(k + 1); ema(k + 2); ema(k + 3); }
-                for (; k < nb; k++) ema(k);
+                if (!ema_done) {
+                    for (; k + 4 <= nb; k += 4) { ema(k); ema(k + 1); ema(k + 2); ema(k + 3); }
+                    for (; k < nb; k++) ema(k);
+                }
                 const bool cond_l = av_l >= P.cond_lo && av_l <= P.cond_hi;
                 const unsigned long long ev_flip = __ballot(lane < nb && cond_l != h);
                 const unsigned long long ev_lock = __ballot(lane < nb && ls_l > P.lock_thr);
@@ -1335,6 +1507,63 @@ __device__ __forceinline__ void k_pll_fix(const T *__restrict__ theta, long long
         if (mode == 2) counters[0] = (unsigned)((S < n) ? nb_abs - j0 : 0);
         if (fixes) atomicAdd(&counters[1], fixes);
     }
+}
+
+// Tail pass (round 6): the end of a capture where the loop has nothing to track -- a receiver that stays on after the satellite
+// has set.  On noise the tracking loop does not contract: no warm-up merges with the truth there, every seam of the
+// stretch is open, and the true trajectory has to be WALKED through it, one lane, ~40 ns a sample -- a minute at 250 ksps is
+// 0.6 s.  Left to k_pll_fix that walk starts when the acquisition and the head are through; but it needs neither: the blocks in
+// front of the stretch merged with the truth as blocks do wherever there is a signal, so the end state of the last block of the
+// last run of `run` closed seams is -- almost certainly -- the true state there.  This kernel runs on the side stream right
+// behind k_pll_phase, BESIDE the acquisition (which spends its own second on the noise in front of the pass): it finds that
+// block and walks from its end state to the end of the capture -- in place, every block's seam record rewritten with the state
+// the walk really started from and ended in, as k_pll_fix's cascade does -- or until a seam it reaches is closed.  Nothing is
+// taken on trust: k_pll_fix validates every seam afterwards as ever, and a start state that a later repair changes fails its
+// seam check and is walked again.  (A capture that is noise throughout has no closed run: nothing happens.)
+template <typename T, bool SLOW>
+__device__ __forceinline__ void k_pll_tail(const T *__restrict__ theta, long long n, PllParams<T> P, long long B, T *__restrict__ phi,
+                                           PllSeam<T> *__restrict__ seams, unsigned *__restrict__ counters, T *ckpt, int run)
+{
+    __shared__ __attribute__((aligned(16))) unsigned char ring[PDT_PLL_RING_PF * PDT_RING_SLOT];
+    __shared__ unsigned long long s_last;                           // 1 + the last seam that ends a run of `run` closed ones
+    const long long nb = (n + B - 1) / B;
+    if (threadIdx.x == 0) s_last = 0;
+    __syncthreads();
+    auto closed = [&](long long r) {
+        const PllSeam<T> prev = seams[r - 1];
+        const PllSeam<T> cur = seams[r];
+        return bits_equal(prev.phase1, cur.phase0) && bits_equal(prev.freq1, cur.freq0);
+    };
+    unsigned long long best = 0;
+    for (long long r = run + (long long)threadIdx.x; r < nb; r += blockDim.x) {
+        bool all = true;
+        for (int q = 0; q < run && all; q++) all = closed(r - q);
+        if (all) best = (unsigned long long)r + 1;
+    }
+    if (best) atomicMax(&s_last, best);
+    __syncthreads();
+    if (threadIdx.x != 0 || s_last == 0) return;
+    const long long NC = pll_ckpt_count(B);
+    unsigned walked = 0;
+    for (long long r = (long long)s_last; r < nb; r++) {
+        const PllSeam<T> prev = seams[r - 1];
+        const PllSeam<T> cur = seams[r];
+        if (bits_equal(prev.phase1, cur.phase0) && bits_equal(prev.freq1, cur.freq0)) break;      // merged with the stored trajectory
+        T phase = prev.phase1, freq = prev.freq1;
+        const long long start = r * B;
+        const long long end = ((r + 1) * B < n) ? (r + 1) * B : n;
+        T *col = ckpt ? ckpt + ((r >> 6) * NC) * 64 + (r & 63) : (T *)nullptr;
+        pll_phase_range<T, true, SLOW, true, 32>(theta, phi, B, start, end, phase, freq, P.alpha_trk, P.beta_trk, P.max_freq, P.min_freq,
+                                                 nullptr, nullptr, ring, col);
+        PllSeam<T> upd;
+        upd.phase0 = prev.phase1;
+        upd.freq0 = prev.freq1;
+        upd.phase1 = phase;
+        upd.freq1 = freq;
+        seams[r] = upd;
+        walked++;
+    }
+    if (walked) atomicAdd(&counters[1], walked);
 }
 
 // elementwise mix for the samples after the lock (:106-113), and the lock-detector input

@@ -119,11 +119,27 @@ def test_hand_issued_lds_loads_are_the_only_users_of_m0(pdt, tmp_path):
     tools = [os.path.join(llvm, t) for t in ("llvm-objcopy", "clang-offload-bundler", "llvm-objdump")]
     if not all(os.path.exists(t) for t in tools):
         pytest.skip("ROCm LLVM tools not installed")
-    fat, co = str(tmp_path / "fat.bin"), str(tmp_path / "dev.co")
+    # the library is several translation units (round 6): its .hip_fatbin section holds one offload bundle per unit, back to
+    # back -- every unit's gfx950 code object is looked at
+    import struct
+    fat = str(tmp_path / "fat.bin")
     subprocess.run([tools[0], "--dump-section", f".hip_fatbin={fat}", pdt.LIBPDT_PATH], check=True)
-    subprocess.run([tools[1], "--type=o", "--unbundle", "--targets=hipv4-amdgcn-amd-amdhsa--gfx950", f"--input={fat}", f"--output={co}"],
-                   check=True, capture_output=True)
-    dis = subprocess.run([tools[2], "-d", co], check=True, capture_output=True, text=True).stdout
+    blob = open(fat, "rb").read()
+    magic, dis, units, at = b"__CLANG_OFFLOAD_BUNDLE__", "", 0, 0
+    while (at := blob.find(magic, at)) >= 0:
+        n = struct.unpack_from("<Q", blob, at + 24)[0]
+        off = at + 32
+        for _ in range(n):
+            o, size, tlen = struct.unpack_from("<QQQ", blob, off)
+            triple = blob[off + 24: off + 24 + tlen]
+            off += 24 + tlen
+            if b"gfx950" in triple and size:
+                co = str(tmp_path / f"dev{units}.co")
+                open(co, "wb").write(blob[at + o: at + o + size])
+                dis += subprocess.run([tools[2], "-d", co], check=True, capture_output=True, text=True).stdout
+                units += 1
+        at += len(magic)
+    assert units >= 4, f"{units} gfx950 code object(s) in libpdt.so: the chain's units are missing"
     kernel, per_kernel = None, {}
     for line in dis.splitlines():
         m = re.match(r"^[0-9a-f]+ <(\S+)>:", line)

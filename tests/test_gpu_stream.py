@@ -449,8 +449,11 @@ def test_capture_that_does_not_fit_goes_through_the_bounded_window(pdt, tmp_path
     r = subprocess.run([exe, "-D", "PDT_HBM_LIMIT_MB=2048", "-o", outp, wav], capture_output=True, text=True)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
     assert open(outp, "rb").read() == text0
-    r2 = subprocess.run([exe, "-D", "PDT_HBM_LIMIT_MB=64", "-o", outp, wav], capture_output=True, text=True)
-    assert r2.returncode != 0 and "Demodulation failed" in r2.stdout        # (not even a window of a few chunks fits 64 MB)
+    os.unlink(outp)
+    r2 = subprocess.run([exe, "-D", "PDT_HBM_LIMIT_MB=64", "-P", "-o", outp, wav], capture_output=True, text=True)   # (a window of 31 chunks)
+    assert r2.returncode == 0 and open(outp, "rb").read() == text0
+    r3 = subprocess.run([exe, "-D", "PDT_HBM_LIMIT_MB=8", "-o", outp, wav], capture_output=True, text=True)
+    assert r3.returncode != 0 and "Demodulation failed" in r3.stdout        # (not even a window of a few chunks fits 8 MB)
 
 
 @pytest.mark.timeout(300)

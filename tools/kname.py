@@ -1,5 +1,5 @@
 """Readable kernel names from rocprofv3 output.  Every kernel is entered through the k_run<&body, threads> wrapper
-(csrc/pdt_api.hip), whose mangled name the profiler cannot demangle; the body's name and template arguments are inside it:
+(csrc/pdt_rt.h), whose mangled name the profiler cannot demangle; the body's name and template arguments are inside it:
 ..._ZN3pdt11k_pll_phaseIfLb0EEEv...  ->  k_pll_phase<float, false>"""
 import re
 
