@@ -361,7 +361,8 @@ def e2e_multi(exe: str, wavs: list[str], ngpu: int, passes: int = 4, env=None, t
     samples = sum(c["samples"] for c in doc["last_pass"])
     per_gpu = {}
     for c in doc["last_pass"]:
-        g = per_gpu.setdefault(c["gpu"], {"captures": 0, "bytes": 0, "ingest_ms": 0.0, "gpu_ms": 0.0})
+        g = per_gpu.setdefault(c["gpu"], {"captures": 0, "bytes": 0, "ingest_ms": 0.0, "gpu_ms": 0.0, "direct": c.get("direct", 0),
+                                           "numa_node": c.get("numa_node", -1)})
         g["captures"] += 1
         g["bytes"] += c["bytes"]
         g["ingest_ms"] += c["ingest_ms"]

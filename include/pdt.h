@@ -172,6 +172,11 @@ typedef struct pdt_stats {
                                      counters and pdt_kernel_times describe the LAST piece only                            */
     uint32_t windowed;            /* (ABI 4) 1 = the capture did not fit the device's free memory and went through the
                                      bounded window (same frames, text, counts and per-chunk reports)                      */
+    uint32_t ingest_direct;       /* (ABI 4) 1 = the capture file was read with O_DIRECT straight into the pinned staging (its
+                                     pages were not in the page cache, the file system offers it): two passes over host memory
+                                     per byte instead of three                                                              */
+    int32_t  ingest_numa_node;    /* (ABI 4) NUMA node the reader threads and the staging memory were bound to (the GPU's, when
+                                     the file's cached pages lie there or it was read directly); -1 = not bound             */
 } pdt_stats;
 
 typedef struct pdt_kernel_time {

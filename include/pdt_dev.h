@@ -13,6 +13,11 @@ extern "C" {
 #endif
 /* value != NULL: set switch `name`; value == NULL: remove it; name == NULL: clear all.  Contexts opened afterwards see it. */
 int pdt_dev_set(const char *name, const char *value);
+/* (measurement aid, round 6) The boundary-state tables of the last demodulation when their rows span several chunks: the number
+ * of rows, and for the first `max` of them the number of DISTINCT exits of the row's first chunk (0xffffffff: a row that was
+ * left untabulated).  0 when the last run had no such rows.  What tools/span_hist.py turns into profiles/r6/gardner_row_exits_*.  */
+struct pdt_ctx;
+unsigned long long pdt_dev_span_rows(const struct pdt_ctx *ctx, unsigned *n_exits_out, unsigned long long max);
 #ifdef __cplusplus
 }
 #endif

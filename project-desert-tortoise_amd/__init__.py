@@ -103,6 +103,8 @@ class Stats(C.Structure):
         ("alloc_ms", C.c_double),
         ("segments", C.c_uint32),
         ("windowed", C.c_uint32),
+        ("ingest_direct", C.c_uint32),
+        ("ingest_numa_node", C.c_int32),
     ]
 
 
@@ -169,7 +171,7 @@ ABI_SYMBOLS = [
     "pdt_keep_presquelch", "pdt_keep_pll", "pdt_stage_bytesync_from", "pdt_demod_fd", "pdt_format_records", "pdt_stream_retained", "pdt_host_math", "pdt_get_device",
     "pdt_write_frames", "pdt_write_records", "pdt_demod_file", "pdt_set_loop_params", "pdt_set_progress",
 ]
-DEV_SYMBOLS = ["pdt_dev_set"]        # include/pdt_dev.h (test-only)
+DEV_SYMBOLS = ["pdt_dev_set", "pdt_dev_span_rows"]        # include/pdt_dev.h (test-only)
 
 _lib = None
 

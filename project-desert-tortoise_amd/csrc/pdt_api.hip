@@ -2,6 +2,12 @@
 // include/pdt.h.  Compiled for gfx950 only, with -ffp-contract=off (see pdt_device_math.h).
 #include "pdt_rt.h"
 
+#include <pthread.h>
+#include <sched.h>
+#include <sys/mman.h>
+#include <sys/stat.h>
+#include <sys/syscall.h>
+
 namespace pdtrt {
 PDT_CHAIN_INSTANCES(extern, float)
 PDT_CHAIN_INSTANCES(extern, double)
@@ -35,6 +41,8 @@ void Tuning::load()
     if (const char *e = get("PDT_INGEST_THREADS")) ingest_threads = std::min(128, std::max(1, atoi(e)));
     if (const char *e = get("PDT_INGEST_SPAN_MB")) ingest_span_mb = std::min(256, std::max(1, atoi(e)));
     if (const char *e = get("PDT_INGEST_STREAMS")) ingest_streams = std::min(4, std::max(1, atoi(e)));
+    if (const char *e = get("PDT_INGEST_DIRECT")) ingest_direct = atoi(e) ? 1 : 0;
+    if (const char *e = get("PDT_INGEST_NUMA")) ingest_numa = atoi(e) ? 1 : 0;
     if (const char *e = get("PDT_FIX_PASSES")) fix_passes = atoi(e);
     if (const char *e = get("PDT_GSEG")) gseg = std::min(64, std::max(2, atoi(e)));
     if (const char *e = get("PDT_GSPAN")) gspan = std::min(256, std::max(1, atoi(e)));
@@ -251,6 +259,9 @@ struct IngestJob {
     std::unique_ptr<std::atomic<int>[]> submitted;
     std::unique_ptr<std::atomic<int>[]> slot_state;                  // 0 free, 1 filled (to be copied), 2 copy in flight
     std::unique_ptr<size_t[]> slot_span;                             // the span a filled slot holds (written before state 1)
+    std::unique_ptr<size_t[]> slot_delta;                            // ... and where in the slot its first byte lies (O_DIRECT reads start on a 4 KiB boundary of the file)
+    int fd_direct = -1;                                              // the capture file once more, opened with O_DIRECT (or -1)
+    ~IngestJob() { if (fd_direct >= 0) close(fd_direct); }
     std::atomic<int> failed{0};
     size_t nspans = 0, span = 0, waited = 0;
     hipStream_t cs[4] = { nullptr, nullptr, nullptr, nullptr };      // the copy streams the spans go round robin over
@@ -262,6 +273,92 @@ struct IngestJob {
     std::vector<size_t> mark_spans;
     std::unique_ptr<std::atomic<int>[]> mark_ready;
 };
+
+// ---- where a capture file's bytes are, and where they should be read (round 6)
+// Every byte of a capture crosses host memory three times on its way -- out of the page cache, into a pinned slot, out again by
+// the DMA engine -- unless the file is read with O_DIRECT straight into the pinned slots: two.  At N = 8 GPUs the first is
+// ~1.3 TB/s of host traffic against the ~1.0 - 1.1 the two sockets deliver.  O_DIRECT is right for a file that is NOT
+// in the page cache (it then comes from the device either way; the copy through the cache is pure overhead) and wrong for one
+// that is (tmpfs does not offer it at all): a probe of the file's pages decides.  And a capture whose pages lie on the memory of
+// the GPU's own socket is read fastest by threads of that socket into staging memory of that socket -- while binding the readers
+// there when the pages lie on the OTHER socket was measured slower than not binding at all (round 4): the same probe says where
+// the pages are.
+struct FilePlacement {
+    double resident = 1.0;      // fraction of the sampled pages that are in the page cache (1 = nothing to gain from O_DIRECT)
+    int node = -1;              // the NUMA node that holds most of the resident ones (-1 = unknown / mixed)
+};
+static FilePlacement probe_file(int fd, uint64_t off, size_t bytes)
+{
+    FilePlacement fp;
+    const long page = sysconf(_SC_PAGESIZE);
+    if (page <= 0 || bytes < (size_t)(64 * page)) return fp;
+    const uint64_t a0 = off / (uint64_t)page * (uint64_t)page;
+    const size_t len = (size_t)(off + bytes - a0);
+    void *m = mmap(nullptr, len, PROT_READ, MAP_SHARED, fd, (off_t)a0);
+    if (m == MAP_FAILED) return fp;
+    constexpr int NS = 64;
+    const size_t npages = (len + (size_t)page - 1) / (size_t)page;
+    unsigned char vec = 0;
+    void *where[NS];
+    int got = 0, res = 0;
+    for (int k = 0; k < NS; k++) {
+        const size_t pg = (size_t)((double)k + 0.5) * npages / NS;
+        void *addr = (unsigned char *)m + pg * (size_t)page;
+        if (mincore(addr, (size_t)page, &vec) != 0) continue;
+        got++;
+        if (vec & 1) where[res++] = addr;
+    }
+    if (got) fp.resident = (double)res / (double)got;
+    if (res >= NS / 2) {
+        // the node of every resident sample page: touch it (maps the page-cache page into this process), then ask
+        int status[NS];
+        volatile unsigned char sink = 0;
+        for (int k = 0; k < res; k++) { sink = sink + *(volatile unsigned char *)where[k]; status[k] = -1; }
+        if (syscall(SYS_move_pages, 0, (unsigned long)res, where, nullptr, status, 0) == 0) {
+            int count[64] = {0}, best = -1;
+            for (int k = 0; k < res; k++)
+                if (status[k] >= 0 && status[k] < 64) count[status[k]]++;
+            for (int nd = 0; nd < 64; nd++)
+                if (count[nd] * 5 >= res * 4) best = nd;             // four pages in five on one node
+            fp.node = best;
+        }
+    }
+    munmap(m, len);
+    return fp;
+}
+// the NUMA node a GPU hangs on, and that node's CPUs
+static int gpu_numa_node(int device)
+{
+    char bus[64] = {0}, path[160];
+    if (hipDeviceGetPCIBusId(bus, (int)sizeof bus, device) != hipSuccess) { (void)hipGetLastError(); return -1; }
+    for (char *c = bus; *c; c++) *c = (char)tolower((unsigned char)*c);
+    snprintf(path, sizeof path, "/sys/bus/pci/devices/%s/numa_node", bus);
+    FILE *f = fopen(path, "r");
+    int node = -1;
+    if (f) { if (fscanf(f, "%d", &node) != 1) node = -1; fclose(f); }
+    return node;
+}
+static bool node_cpus(int node, cpu_set_t *set)
+{
+    char path[96];
+    snprintf(path, sizeof path, "/sys/devices/system/node/node%d/cpulist", node);
+    FILE *f = fopen(path, "r");
+    if (!f) return false;
+    CPU_ZERO(set);
+    int a, b, any = 0;
+    char sep;
+    while (fscanf(f, "%d", &a) == 1) {
+        b = a;
+        if (fscanf(f, "%c", &sep) == 1 && sep == '-') {
+            if (fscanf(f, "%d", &b) != 1) break;
+            if (fscanf(f, "%c", &sep) != 1) sep = 0;
+        }
+        for (int c = a; c <= b && c < CPU_SETSIZE; c++) { CPU_SET(c, set); any = 1; }
+        if (sep != ',') break;
+    }
+    fclose(f);
+    return any != 0;
+}
 
 // Round 5: ONE thread talks to the HIP runtime.  The readers only fill pinned slots (pread / memcpy) and raise a flag; the
 // submitter -- the calling thread, or one more background thread when the ingest runs beside the chain -- queues the copies, one
@@ -289,7 +386,30 @@ int ingest_capture(pdt_ctx *ctx, const IngestSrc &src, size_t bytes, void *dst, 
     int T = (int)std::min<size_t>(std::min<unsigned>(hw ? hw / 2u + 1u : 4u, t_max), nspans);
     if (T < 1) T = 1;
     const int nslots = T * PDT_INGEST_SLOTS;
-    const size_t need = (size_t)nslots * PDT_INGEST_SPAN;
+    // ---- how the file is read (see probe_file): O_DIRECT straight into the pinned slots when its pages are not cached; readers
+    // and staging on the GPU's NUMA node when -- and only when -- its cached pages lie there
+    struct FdGuard { int fd = -1; ~FdGuard() { if (fd >= 0) close(fd); } } direct_guard;
+    int fd_direct = -1, bind_node = -1;
+    constexpr size_t DIO = 4096;                                   // alignment of O_DIRECT reads (offset, length, address)
+    if (!src.mem && bytes >= ((size_t)64 << 20)) {
+        FilePlacement fp;
+        if (ctx->tune.ingest_direct < 0 || ctx->tune.ingest_numa < 0) fp = probe_file(src.fd, src.off, bytes);
+        const bool want_direct = ctx->tune.ingest_direct > 0 || (ctx->tune.ingest_direct < 0 && fp.resident < 0.1);
+        if (want_direct) {
+            char link[64];
+            snprintf(link, sizeof link, "/proc/self/fd/%d", src.fd);
+            fd_direct = open(link, O_RDONLY | O_DIRECT | O_CLOEXEC);        // (EINVAL where the file system has no direct I/O: tmpfs)
+            direct_guard.fd = fd_direct;
+        }
+        const int gnode = gpu_numa_node(ctx->cfg.device);
+        if (gnode >= 0 && (ctx->tune.ingest_numa > 0 || (ctx->tune.ingest_numa < 0 && (fd_direct >= 0 || fp.node == gnode)))) bind_node = gnode;
+    }
+    ctx->ingest_was_direct = fd_direct >= 0 ? 1 : 0;
+    ctx->ingest_numa_node = bind_node;
+    cpu_set_t node_set;
+    const bool have_cpus = bind_node >= 0 && node_cpus(bind_node, &node_set);
+    const size_t slot_stride = PDT_INGEST_SPAN + (fd_direct >= 0 ? 2 * DIO : 0);
+    const size_t need = (size_t)nslots * slot_stride;
     // The copy streams live at the LOWEST stream priority: streams of one priority share a few hardware queues, and a copy stream
     // that lands on the queue of the demodulation stream waits behind that stream's kernels -- beside a running segment (a 5 ms PLL
     // kernel) one of four copy streams stood still, and with it the ring of pinned slots: the overlapped ingest crawled at
@@ -314,7 +434,16 @@ int ingest_capture(pdt_ctx *ctx, const IngestSrc &src, size_t bytes, void *dst, 
         if (ctx->ingest_pin) (void)hipHostFree(ctx->ingest_pin);
         ctx->ingest_pin = nullptr;
         ctx->ingest_pin_cap = 0;
-        if (timed_host_malloc((void **)&ctx->ingest_pin, need) != hipSuccess) { (void)hipGetLastError(); return PDT_ERR_NOMEM; }
+        // (the staging memory on the node the readers run on: MPOL_PREFERRED = 1 for this thread while the runtime allocates and
+        // pins it, MPOL_DEFAULT = 0 again afterwards)
+        unsigned long mask[16] = {0};
+        if (bind_node >= 0 && bind_node < 1024) {
+            mask[bind_node / (8 * sizeof(long))] = 1ul << (bind_node % (8 * sizeof(long)));
+            (void)syscall(SYS_set_mempolicy, 1, mask, (unsigned long)(8 * sizeof mask));
+        }
+        const hipError_t he = timed_host_malloc((void **)&ctx->ingest_pin, need);
+        if (bind_node >= 0) (void)syscall(SYS_set_mempolicy, 0, nullptr, 0ul);
+        if (he != hipSuccess) { (void)hipGetLastError(); return PDT_ERR_NOMEM; }
         ctx->ingest_pin_cap = need;
     }
     if (!ctx->copy_stream) HIP_TRY(make_copy_stream(&ctx->copy_stream));
@@ -345,6 +474,11 @@ int ingest_capture(pdt_ctx *ctx, const IngestSrc &src, size_t bytes, void *dst, 
     J->slot_state.reset(new std::atomic<int>[(size_t)nslots]);
     for (int q = 0; q < nslots; q++) J->slot_state[(size_t)q].store(0);
     J->slot_span.reset(new size_t[(size_t)nslots]);
+    J->slot_delta.reset(new size_t[(size_t)nslots]);
+    for (int q = 0; q < nslots; q++) J->slot_delta[(size_t)q] = 0;
+    if (J->fd_direct >= 0) close(J->fd_direct);
+    J->fd_direct = direct_guard.fd;
+    direct_guard.fd = -1;
     J->nspans = nspans;
     J->span = PDT_INGEST_SPAN;
     J->waited = 0;
@@ -362,9 +496,11 @@ int ingest_capture(pdt_ctx *ctx, const IngestSrc &src, size_t bytes, void *dst, 
     // (the background form copies what the lambdas need: they outlive this call)
     const IngestSrc src_c = src;
     unsigned char *pin_base = (unsigned char *)ctx->ingest_pin;
-    auto reader = [J, src_c, bytes, nspans, T, PDT_INGEST_SPAN, pin_base](int t) {
+    auto reader = [J, src_c, bytes, nspans, T, PDT_INGEST_SPAN, pin_base, slot_stride, have_cpus, node_set](int t) {
         std::atomic<int> &failed = J->failed;
         const IngestSrc &src = src_c;
+        if (have_cpus) (void)pthread_setaffinity_np(pthread_self(), sizeof node_set, &node_set);      // the GPU's socket (see probe_file)
+        const int fd_direct = J->fd_direct;
         int round = 0;
         for (size_t k = (size_t)t; k < nspans && !failed; k += (size_t)T, round++) {
             const int slot = t * PDT_INGEST_SLOTS + (round % PDT_INGEST_SLOTS);
@@ -373,11 +509,25 @@ int ingest_capture(pdt_ctx *ctx, const IngestSrc &src, size_t bytes, void *dst, 
                 if (failed) return;
                 std::this_thread::sleep_for(std::chrono::microseconds(10));
             }
-            unsigned char *pin = pin_base + (size_t)slot * PDT_INGEST_SPAN;
+            unsigned char *pin = pin_base + (size_t)slot * slot_stride;
             const size_t at = k * PDT_INGEST_SPAN;
             const size_t len = std::min(PDT_INGEST_SPAN, bytes - at);
+            size_t delta = 0;
             if (src.mem) {
                 memcpy(pin, src.mem + at, len);
+            } else if (fd_direct >= 0) {
+                // from the device straight into the pinned slot: the read starts on the 4 KiB boundary below the span's first
+                // byte and ends on the one above its last (the slot has the room), the copy to the GPU starts `delta` bytes in
+                const uint64_t fo = src.off + at, a0 = fo & ~(uint64_t)4095;
+                delta = (size_t)(fo - a0);
+                const size_t want = (delta + len + 4095) & ~(size_t)4095;
+                size_t got = 0;
+                while (got < delta + len) {
+                    const ssize_t r = pread(fd_direct, pin + got, want - got, (off_t)(a0 + got));
+                    if (r < 0 && errno == EINTR) continue;
+                    if (r <= 0) { failed = r == 0 ? 2 : 3; return; }
+                    got += (size_t)r;
+                }
             } else {
                 size_t got = 0;
                 while (got < len) {
@@ -388,11 +538,12 @@ int ingest_capture(pdt_ctx *ctx, const IngestSrc &src, size_t bytes, void *dst, 
                 }
             }
             J->slot_span[(size_t)slot] = k;
+            J->slot_delta[(size_t)slot] = delta;
             st.store(1, std::memory_order_release);
         }
     };
     const bool background = job != nullptr;
-    auto submitter = [ctx, J, bytes, dst, nspans, NS, nslots, PDT_INGEST_SPAN, pin_base, background]() {
+    auto submitter = [ctx, J, bytes, dst, nspans, NS, nslots, PDT_INGEST_SPAN, pin_base, background, slot_stride]() {
         std::atomic<int> &failed = J->failed;
         std::lock_guard<std::mutex> link(g_link_mu[(unsigned)ctx->cfg.device % 64u]);      // (the readers fill their first slots meanwhile)
         if (hipSetDevice(ctx->cfg.device) != hipSuccess) { failed = 1; return; }
@@ -441,7 +592,7 @@ int ingest_capture(pdt_ctx *ctx, const IngestSrc &src, size_t bytes, void *dst, 
                 const size_t len = std::min(PDT_INGEST_SPAN, bytes - at);
                 const int q = rr;
                 rr = (rr + 1 == NS) ? 0 : rr + 1;
-                if (hipMemcpyAsync((unsigned char *)dst + at, pin_base + (size_t)slot * PDT_INGEST_SPAN, len, hipMemcpyHostToDevice, J->cs[q]) != hipSuccess ||
+                if (hipMemcpyAsync((unsigned char *)dst + at, pin_base + (size_t)slot * slot_stride + J->slot_delta[(size_t)slot], len, hipMemcpyHostToDevice, J->cs[q]) != hipSuccess ||
                     hipEventRecord(ctx->ingest_ev[(size_t)slot], J->cs[q]) != hipSuccess) {
                     failed = 1;
                     return;
@@ -548,6 +699,22 @@ int pdt_dev_set(const char *name, const char *value)
         else g_dev[name] = value;
     } catch (const std::exception &) { return PDT_ERR_NOMEM; }
     return PDT_OK;
+}
+
+unsigned long long pdt_dev_span_rows(const pdt_ctx *ctx, unsigned *n_exits_out, unsigned long long max)
+{
+    if (!ctx || ctx->gspan_nrows <= 0 || !ctx->gspan_rows.p) return 0;
+    const unsigned long long n = (unsigned long long)ctx->gspan_nrows, m = std::min(n, max);
+    if (n_exits_out && m) {
+        std::vector<GardnerSpanRow> rows((size_t)m);
+        if (hipSetDevice(ctx->cfg.device) != hipSuccess ||
+            hipMemcpy(rows.data(), ctx->gspan_rows.p, (size_t)m * sizeof(GardnerSpanRow), hipMemcpyDeviceToHost) != hipSuccess) {
+            (void)hipGetLastError();
+            return 0;
+        }
+        for (size_t k = 0; k < (size_t)m; k++) n_exits_out[k] = rows[k].n;
+    }
+    return n;
 }
 
 const char *pdt_strerror(int code)
@@ -922,6 +1089,8 @@ int pdt_demod_pcm16(pdt_ctx *ctx, const int16_t *iq_host, uint64_t nframes)
     ctx->pcm_fmt = 0;
     rc = demod_common(ctx, nframes);
     ctx->stats.ingest_ms = ctx->ingest_ms;
+    ctx->stats.ingest_direct = (uint32_t)ctx->ingest_was_direct;
+    ctx->stats.ingest_numa_node = ctx->ingest_numa_node;
     return rc;
 }
 
@@ -961,6 +1130,8 @@ int pdt_demod_fd(pdt_ctx *ctx, int fd, uint64_t byte_offset, uint64_t nframes, i
     ctx->pcm_fmt = sample_format == PDT_FMT_F32 ? 1 : 0;
     rc = demod_common(ctx, nframes);
     ctx->stats.ingest_ms = ctx->ingest_ms;
+    ctx->stats.ingest_direct = (uint32_t)ctx->ingest_was_direct;
+    ctx->stats.ingest_numa_node = ctx->ingest_numa_node;
     return rc;
 }
 
@@ -991,6 +1162,8 @@ int pdt_demod_f32(pdt_ctx *ctx, const float *iq_host, uint64_t nframes)
     ctx->pcm_fmt = 1;
     rc = demod_common(ctx, nframes);
     ctx->stats.ingest_ms = ctx->ingest_ms;
+    ctx->stats.ingest_direct = (uint32_t)ctx->ingest_was_direct;
+    ctx->stats.ingest_numa_node = ctx->ingest_numa_node;
     return rc;
 }
 
@@ -1548,6 +1721,8 @@ static int demod_overlapped(pdt_ctx *ctx, const IngestSrc &src, uint64_t nframes
     }
     if (text_bytes) *text_bytes = sink.bytes;
     ctx->stats.ingest_ms = ctx->ingest_ms;
+    ctx->stats.ingest_direct = (uint32_t)ctx->ingest_was_direct;
+    ctx->stats.ingest_numa_node = ctx->ingest_numa_node;
     // the stream machinery was borrowed: leave no stream behind (a later push starts a new one), keep frames and statistics
     ctx->sc = StreamCarry();
     ctx->stream_have = ctx->stream_done = ctx->stream_total = 0;
@@ -1624,6 +1799,8 @@ static int demod_windowed(pdt_ctx *ctx, const IngestSrc &src, uint64_t nframes, 
     (void)t_call;
     ctx->ingest_ms = ingest_ms;
     ctx->stats.ingest_ms = ingest_ms;
+    ctx->stats.ingest_direct = (uint32_t)ctx->ingest_was_direct;
+    ctx->stats.ingest_numa_node = ctx->ingest_numa_node;
     ctx->stats.windowed = 1;
     ctx->sc = StreamCarry();
     ctx->stream_have = ctx->stream_done = ctx->stream_total = 0;

@@ -2066,10 +2066,36 @@ __device__ __forceinline__ void k_fir_interp_rt(const T *__restrict__ in, long l
             for (int t = 0; t < K; t++)
 #pragma unroll
                 for (int r = 0; r < INTERP; r++) hv[t][r] = h[t * RS + r];
+            if constexpr (std::is_same<T, float>::value && INTERP >= 2) {
+                // Round 6: the INTERP outputs of an input position two at a time in packed arithmetic (v_pk_mul_f32 / v_pk_add_f32:
+                // per component exactly the reference's separate multiply and add, in its slot order, from +0 -- as k_mix_fir
+                // pairs a lane's two outputs at INTERP 1).  At INTERP 8 the kernel is bound by its vector instructions -- 52 per
+                // output, 540 M outputs for an hour at 18.75 ksps: 1.83 ms where the 36 B per input sample are 0.42 ms of HBM
+                // time (profiles/r6) -- and the taps of outputs r, r + 1 lie side by side in the table: one SGPR pair.
+                typedef float v2f __attribute__((ext_vector_type(2)));
+                v2f y2[INTERP / 2];
+#pragma unroll
+                for (int q = 0; q < INTERP / 2; q++) { y2[q].x = 0; y2[q].y = 0; }
+#pragma unroll
+                for (int t = 0; t < K; t++) {
+                    v2f xx;
+                    xx.x = x[t]; xx.y = x[t];
+#pragma unroll
+                    for (int q = 0; q < INTERP / 2; q++) {
+                        v2f hh;
+                        hh.x = hv[t][2 * q]; hh.y = hv[t][2 * q + 1];
+                        y2[q] = y2[q] + hh * xx;
+                    }
+                    if constexpr (INTERP & 1) y[INTERP - 1] = y[INTERP - 1] + hv[t][INTERP - 1] * x[t];
+                }
+#pragma unroll
+                for (int q = 0; q < INTERP / 2; q++) { y[2 * q] = y2[q].x; y[2 * q + 1] = y2[q].y; }
+            } else {
 #pragma unroll
             for (int t = 0; t < K; t++) {
 #pragma unroll
                 for (int r = 0; r < INTERP; r++) y[r] = y[r] + hv[t][r] * x[t];
+            }
             }
 #pragma unroll
             for (int r = 0; r < INTERP; r++) s_out[(c + K * j) * INTERP + r] = y[r];

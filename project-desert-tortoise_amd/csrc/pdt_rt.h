@@ -273,6 +273,7 @@ struct Tuning {
     double band_pad = 0.0, pll_warm_scale = 1.0, head_taus = 0.0, agc_k = 0.0, pll_warm_s = 0.0, agc_warm_s = 0.0;
     double overlap_split[8] = { 0, 0, 0, 0, 0, 0, 0, 0 };
     long long hbm_limit_mb = 0, window_piece = 0;
+    int ingest_direct = -1, ingest_numa = -1;        // -1 = decide by probing the file (ingest_capture), 0 = never, 1 = always try
     int scout_syms = 0, gspan = 0, gspan_cap = 0, ingest_threads = 0, ingest_span_mb = 0, ingest_streams = 0, overlap_segments = 0, overlap_min_mb = 0, fir_wg_per_cu = 0, agc_tpb = 0, gseg = 0, pll_block = 0, fix_passes = 2;
     bool fir_generic = false, mix_unfused = false, quality_inline = false, gemit_groups = false, agc_unfused = false, no_excl = false, gardner_onebuf = false, gardner_noring = false, gardner_sequential = false, seg_sequential = false, agc_lanes = false, overlap = true, debug_overlap = false, chain_one_range = false, ema_noguess = false, debug_sync = false, pll_noshort = false, pll_nockpt = false, pll_noconsensus = false, pll_notail = false, seg_plain = false, sync_block = false, gardner_nostride = false;
     void load();                 // (pdt_api.hip: from the registry pdt_dev_set fills)
@@ -353,6 +354,7 @@ struct pdt_ctx {
     // (stream_in is declared with the streaming state below)
     long long gcand_key = -1;          // (chunk_out, step) the candidate list on the device was built for
     int gardner_mode = 0;              // 0 sequential, 1 state table (last run)
+    long long gspan_nrows = 0;         // table rows of several chunks in the last run (0: none) -- pdt_dev_span_rows
     const void *pcm_dev = nullptr;     // input actually used (own copy or caller's buffer)
     int pcm_fmt = 0;                   // 0 = int16 pairs, 1 = float32 pairs
 
@@ -378,6 +380,7 @@ struct pdt_ctx {
     std::vector<hipEvent_t> ingest_ev, span_ev;      // per pinned slot; per span (overlapped ingest)
     double stream_gpu_ms = 0;
     double ingest_ms = 0;               // host wall time of the last ingest (issue of the last copy)
+    int ingest_was_direct = 0, ingest_numa_node = -1;   // how the last ingest read its file (pdt_stats)
     DevBuf stream_in, seg_dev, lt_theta, lt_phi;          // input window of the stream; small device block for the segment's carried-out state
     uint64_t stream_have = 0, stream_done = 0;   // samples in the window / of them already demodulated (local indices)
     uint64_t stream_total = 0;          // samples pushed since pdt_stream_begin

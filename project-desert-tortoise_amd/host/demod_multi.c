@@ -325,9 +325,9 @@ int main(int argc, char **argv)
             const capture *cp = &g_cap[k];
             if (cp->rc != PDT_OK) continue;
             printf("%s{\"capture\": %d, \"gpu\": %d, \"samples\": %llu, \"bytes\": %llu, \"frames\": %llu, \"ingest_ms\": %.3f, \"gpu_ms\": %.3f, "
-                   "\"seconds\": %.6f, \"segments\": %u, \"windowed\": %u}", first ? "" : ", ", k, cp->device, (unsigned long long)cp->st.samples,
-                   (unsigned long long)cp->st.samples * 4ull, (unsigned long long)cp->nfr, cp->st.ingest_ms, cp->st.gpu_ms, cp->seconds,
-                   cp->st.segments, cp->st.windowed);
+                   "\"seconds\": %.6f, \"segments\": %u, \"windowed\": %u, \"direct\": %u, \"numa_node\": %d}", first ? "" : ", ", k, cp->device,
+                   (unsigned long long)cp->st.samples, (unsigned long long)cp->st.samples * 4ull, (unsigned long long)cp->nfr, cp->st.ingest_ms,
+                   cp->st.gpu_ms, cp->seconds, cp->st.segments, cp->st.windowed, cp->st.ingest_direct, cp->st.ingest_numa_node);
             first = 0;
         }
         printf("]}}\n");

@@ -456,6 +456,47 @@ def test_capture_that_does_not_fit_goes_through_the_bounded_window(pdt, tmp_path
     assert r3.returncode != 0 and "Demodulation failed" in r3.stdout        # (not even a window of a few chunks fits 8 MB)
 
 
+def test_uncached_file_is_read_directly_into_the_pinned_staging(pdt, tmp_path):
+    """Round 6 (the host-memory budget at N = 8): a capture file whose pages are NOT in the page cache is read with
+    O_DIRECT straight into the pinned slots -- two passes over host memory per byte instead of three; one that is cached (or lives
+    on tmpfs, which has no direct I/O) keeps the buffered reads.  The 44-byte header makes every span start off a block boundary:
+    the reads start on the 4 KiB boundary below and the copy to the GPU starts inside the slot.  Same text either way."""
+    import os
+    fs = 250000
+    iq = pdt.synth_capture(0, fs, 80.0, seed=79)                     # 80 MB: above the size where the ingest probes at all
+    wav = str(tmp_path / "cold.wav")
+    pdt.write_wav(wav, fs, iq)
+    with pdt.Demodulator(pdt.MODE_POES, fs) as ref:
+        ref.demod(iq)
+        want = ref.text()
+
+    def run(evict):
+        fd = os.open(wav, os.O_RDONLY)
+        try:
+            if evict:
+                os.posix_fadvise(fd, 0, 0, os.POSIX_FADV_DONTNEED)
+            with pdt.Demodulator(pdt.MODE_POES, fs).keep_pll(False) as d:
+                d.demod_file(fd, 44, len(iq))
+                return d.text(), d.stats()
+        finally:
+            os.close(fd)
+
+    wfd = os.open(wav, os.O_RDWR)
+    os.fsync(wfd)                                                     # (clean pages can be dropped)
+    os.close(wfd)
+    text, st = _with_env({"PDT_INGEST_DIRECT": "1"}, lambda: run(False))          # forced: whatever the page cache holds
+    assert text == want
+    if not st.ingest_direct:
+        pytest.skip("no O_DIRECT on the file system under tmp_path")
+    text, st = run(True)                                              # evicted: the probe finds it cold
+    assert text == want and st.ingest_direct == 1
+    open(wav, "rb").read()                                            # cached again: buffered reads
+    text, st = run(False)
+    assert text == want and st.ingest_direct == 0
+    text, st = _with_env({"PDT_INGEST_NUMA": "1"}, lambda: run(False))            # readers + staging bound to the GPU's node
+    assert text == want
+
+
 @pytest.mark.timeout(300)
 @pytest.mark.parametrize("mode", ["plain", "overlapped"])
 def test_file_entry_errors_leave_the_context_usable(pdt, tmp_path, mode):
