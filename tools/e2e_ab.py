@@ -14,11 +14,16 @@ specs = [a for a in sys.argv[1:] if "=" in a] or ["plain=PDT_NO_OVERLAP:1", "def
 fs, n = 250000, 900_000_000
 secs = float(os.environ.get("AB_SECONDS", "3600"))
 n = int(secs * fs)
-tmp = tempfile.mkdtemp(dir="/dev/shm", prefix="pdt_ab_")
+tmp = tempfile.mkdtemp(dir=os.environ.get("AB_DIR", "/dev/shm"), prefix="pdt_ab_")      # (AB_DIR=/tmp: the capture on a disk file system)
 wav = os.path.join(tmp, "c3.wav")
 par = bench.capture_params(pdt, "c3", 1234)
 bench.make_capture(pdt, par, n, 32, wav_path=wav, fs=fs)
 ctxs = {}
+evict = set()
+if os.environ.get("AB_DIR"):
+    fdw = os.open(wav, os.O_RDWR)
+    os.fsync(fdw)
+    os.close(fdw)
 for spec in specs:
     name, _, envs = spec.partition("=")
     env = {}
@@ -26,6 +31,8 @@ for spec in specs:
         k, _, v = kv.partition(":")
         env[k] = v.replace("/", ",")
     quality = env.pop("AB_QUALITY", None)                 # (not a switch of the library: pdt_keep_quality, what the CLI runs with)
+    if env.pop("AB_EVICT", None):                         # (not a switch either: the file's pages dropped from the page cache before every run)
+        evict.add(name)
     os.environ.update(env)
     ctxs[name] = pdt.Demodulator(0, fs, device=0).keep_pll(False)
     if quality:
@@ -39,6 +46,9 @@ for r in range(rounds + 1):
         outp = os.path.join(tmp, f"o_{name}.txt")
         t0 = time.perf_counter()
         fd = os.open(wav, os.O_RDONLY)
+        if name in evict:
+            os.posix_fadvise(fd, 0, 0, os.POSIX_FADV_DONTNEED)
+            t0 = time.perf_counter()
         fo = os.open(outp, os.O_RDWR | os.O_CREAT | os.O_TRUNC, 0o644)
         d.demod_file_text(fd, 44, n, fo, 0)
         os.close(fd)
@@ -52,7 +62,8 @@ for r in range(rounds + 1):
 same = len(set(texts.values())) == 1
 for name, t in times.items():
     s = sorted(t)
-    print(f"{name:>14}: median {s[len(s) // 2]:7.2f}  min {s[0]:7.2f}  ingest {ctxs[name].stats().ingest_ms:6.1f}  all " + " ".join(f"{x:.1f}" for x in t))
+    st = ctxs[name].stats()
+    print(f"{name:>14}: median {s[len(s) // 2]:7.2f}  min {s[0]:7.2f}  ingest {st.ingest_ms:6.1f} (direct {st.ingest_direct}, node {st.ingest_numa_node})  all " + " ".join(f"{x:.1f}" for x in t))
 print("texts identical:", same)
 import shutil
 shutil.rmtree(tmp, ignore_errors=True)
