@@ -14,6 +14,10 @@ like-for-like weak-scaling figure:
   aos              (not in BASELINE) 250 ksps, 10 min, the first 60 s noise only: the receiver is switched
                    on before the satellite rises, the PLL sweeps for a minute before its one-time lock
   weak             (not in BASELINE) 250 ksps, 10 min at six times the noise amplitude (4.4 dB SNR in the sampled band)
+  pass             (not in BASELINE) 250 ksps, 15 min as a receiver records a pass: a minute of noise, the signal with a
+                   Doppler ramp from +3 kHz to -3 kHz and an amplitude envelope of 0.25 .. 1, a minute of noise
+  i8, c2h           the interpolating filter at scale: 18.75 ksps (interp 8) and 50 ksps (interp 3), 60 min each
+  --captures N     the batched many-capture mode (pdt_demod_batch_device), every slot its own capture, every slot's text checked
 One "step" = one pass of the whole hot path (StaticGain, PLL, FIR, AGC, Gardner, Manchester, ByteSync, frame records +
 time stamps) over one capture that is ALREADY RESIDENT IN HBM when the timed region starts: that is ``value``, and the
 ``metric`` string says so.  The figure from the WAV file to the closed output file is ``e2e`` (N = 1).  With N GPUs every
@@ -35,7 +39,8 @@ The JSON line carries, besides the contract keys:
                single thread on this host, on a bounded sample of the same capture: DSP-only rate (``value``, comparable
                with the resident GPU number) and end-to-end rate (``e2e_value``: file read and text output included)
   cpu_baseline_8proc  8 concurrent single-thread CPU processes, one capture each (BASELINE.md section 3, configs[4])
-  secondary    the c2 and argos workloads measured on the same GPU (resident step only), each a process of its own
+  secondary    the other workloads measured on the same GPU, each a process of its own: c2, argos (with their CPU legs), pass, i8 and
+               the batched ARGOS mode (64 captures per step)
 """
 from __future__ import annotations
 
@@ -811,17 +816,22 @@ def run(args, pdt, torch, dist, rank, local, world, dev, cdev, cfg, kind, fs, se
             del d_iq
             torch.cuda.empty_cache()
             out["secondary"] = {}
-            for c2 in ("c2", "argos", "aos"):
+            # the other workloads on the same GPU, each a process of its own: BASELINE configs[1] and [3] with their CPU legs; the pass-shaped
+            # capture, the interpolating filter at scale and the batched ARGOS mode resident only
+            for name, extra in (("c2", ["--config", "c2", "--steps", "10", "--warmup", "2"]),
+                                ("argos", ["--config", "argos", "--steps", "10", "--warmup", "2"]),
+                                ("pass", ["--config", "pass", "--steps", "2", "--warmup", "1", "--no-cpu"]),
+                                ("i8", ["--config", "i8", "--steps", "5", "--warmup", "2", "--no-cpu"]),
+                                ("argos_x64", ["--config", "argos", "--captures", "64", "--steps", "3", "--warmup", "1", "--no-cpu"])):
                 try:
-                    r = subprocess.run([sys.executable, os.path.abspath(__file__), "--config", c2, "--steps", "3" if c2 == "aos" else "10",
-                                        "--warmup", "1" if c2 == "aos" else "2", "--no-secondary"] + (["--no-cpu"] if c2 == "aos" else []),
-                                       capture_output=True, text=True, timeout=900)
+                    r = subprocess.run([sys.executable, os.path.abspath(__file__), "--no-secondary"] + extra, capture_output=True, text=True, timeout=900)
                     ref = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
-                    out["secondary"][c2] = {k: ref.get(k) for k in ("value", "unit", "ms_per_step", "dtype", "roofline", "fir_pll_stage",
-                                                                      "e2e", "e2e_cli", "cpu_baseline", "parity")}
-                    out["secondary"][c2]["workload"] = ref["config"]["workload"]
+                    out["secondary"][name] = {k: ref.get(k) for k in ("value", "unit", "ms_per_step", "dtype", "roofline", "fir_pll_stage",
+                                                                       "e2e", "e2e_cli", "value_e2e", "ms_e2e", "cpu_baseline", "parity")}
+                    out["secondary"][name]["workload"] = ref["config"]["workload"]
+                    out["secondary"][name]["stages_ms"] = {k: v["ms"] for k, v in ref.get("stages", {}).items()}
                 except Exception as e:                                     # (never fatal for the headline line)
-                    out["secondary"][c2] = {"error": (str(e) + " " + (r.stderr[-300:] if "r" in dir() else ""))[:500]}
+                    out["secondary"][name] = {"error": (str(e) + " " + (r.stderr[-300:] if "r" in dir() else ""))[:500]}
         bad = [k for k, v in parity.items() if v is False or (isinstance(v, list) and v and isinstance(v[0], bool) and not all(v))]
         if bad:
             sys.stderr.write("bench.py: parity failure -- no result line: " + json.dumps({k: parity[k] for k in bad}) + "\n")

@@ -279,10 +279,8 @@ struct IngestJob {
 // the DMA engine -- unless the file is read with O_DIRECT straight into the pinned slots: two.  At N = 8 GPUs the first is
 // ~1.3 TB/s of host traffic against the ~1.0 - 1.1 the two sockets deliver.  O_DIRECT is right for a file that is NOT
 // in the page cache (it then comes from the device either way; the copy through the cache is pure overhead) and wrong for one
-// that is (tmpfs does not offer it at all): a probe of the file's pages decides.  And a capture whose pages lie on the memory of
-// the GPU's own socket is read fastest by threads of that socket into staging memory of that socket -- while binding the readers
-// there when the pages lie on the OTHER socket was measured slower than not binding at all (round 4): the same probe says where
-// the pages are.
+// that is (tmpfs does not offer it at all): a probe of the file's pages decides.  The same probe says on which NUMA node the
+// cached pages lie (move_pages); what to do with that is ingest_capture's decision (measured: see there).
 struct FilePlacement {
     double resident = 1.0;      // fraction of the sampled pages that are in the page cache (1 = nothing to gain from O_DIRECT)
     int node = -1;              // the NUMA node that holds most of the resident ones (-1 = unknown / mixed)
@@ -402,7 +400,12 @@ int ingest_capture(pdt_ctx *ctx, const IngestSrc &src, size_t bytes, void *dst, 
             direct_guard.fd = fd_direct;
         }
         const int gnode = gpu_numa_node(ctx->cfg.device);
-        if (gnode >= 0 && (ctx->tune.ingest_numa > 0 || (ctx->tune.ingest_numa < 0 && (fd_direct >= 0 || fp.node == gnode)))) bind_node = gnode;
+        // (Measured, round 6, one box -- GPU and the capture's pages both on node 1: readers and staging bound there 100 - 106 ms for
+        // the 3.6 GB file -> frame file path, not bound 94.6, profiles/r6/e2e_ab_numa.txt: eight readers crowd one socket's cores
+        // beside the box's other tenants, as in round 4.  So buffered reads are bound on request only (PDT_INGEST_NUMA); direct
+        // reads -- the device writes the staging memory, the GPU's DMA engine reads it -- keep staging and readers on the GPU's node.)
+        if (gnode >= 0 && (ctx->tune.ingest_numa > 0 || (ctx->tune.ingest_numa < 0 && fd_direct >= 0))) bind_node = gnode;
+        (void)fp.node;
     }
     ctx->ingest_was_direct = fd_direct >= 0 ? 1 : 0;
     ctx->ingest_numa_node = bind_node;
