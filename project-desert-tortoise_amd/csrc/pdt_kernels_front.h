@@ -448,11 +448,11 @@ __device__ __forceinline__ void acq_vec4_asm(const Vec16<float> &th, float &phas
 // the detectors of batch t-1 from the per-sample states wavefront 0 left in LDS.  When wavefront 1
 // reports an event inside batch t-1, the speculative batch t is dropped and wavefront 0 resumes from
 // the corrected state after the event sample.  Same arithmetic per sample, half the time per batch.
-#ifndef PDT_ACQP_NB
-#define PDT_ACQP_NB 64      // samples per batch of the two-wavefront pipeline (one per lane)
-#endif
-template <typename T> struct alignas(16) AcqSlot {
-    T phi[PDT_ACQP_NB];               // phase used for sample k (the value before its update)
+// Round 6: the float build with the plain wrap (POES) takes batches of 128 samples, two per lane ("halves" h = 0, 1: sample
+// 64 h + lane): the per-batch costs -- two barriers, the hand-over through LDS, the prefetch of the next batch -- were a fifth
+// of the acquisition's time at 64.  The double build and the slow-wrap variants keep 64.
+template <typename T, int NB> struct alignas(16) AcqSlot {
+    T phi[NB];                        // phase used for sample k (the value before its update)
     long long i0;
     int nb, valid, hyp;
     T ph_beg, fr_beg, sw_beg;         // loop-filter state in front of the batch (an event replays the filter from here)
@@ -469,14 +469,15 @@ __device__ __forceinline__ void k_pll_acquire_pipe(IqSrc pcm, long long n, PllPa
                                                           T *__restrict__ out, T *__restrict__ lock_out,
                                                           PllLockInfo<T> *__restrict__ info, T *__restrict__ avg_out = nullptr)
 {
-    __shared__ AcqSlot<T> slot[2];
+    // FAST (float, plain wrap): theta of the batch being filtered read back four samples at a time (one broadcast LDS read in
+    // place of four v_readlane, acq_vec4_asm); the detectors' input terms as doubles and the two EMAs' values per sample likewise
+    constexpr bool FAST = std::is_same<T, float>::value && !SLOW;
+    constexpr int H = FAST ? 2 : 1, NB = 64 * H;
+    __shared__ AcqSlot<T, NB> slot[2];
     __shared__ AcqVerdict<T> verdict;
-    // round 6, float with the plain wrap (POES): theta of the batch being filtered, read back four samples at a time (one broadcast
-    // LDS read in place of four v_readlane); the detectors' input terms as doubles and the two EMAs' values per sample likewise
-    constexpr bool FAST = std::is_same<T, float>::value && !SLOW && PDT_ACQP_NB == 64;
-    __shared__ __attribute__((aligned(16))) float s_theta[FAST ? PDT_ACQP_NB : 4];
-    __shared__ __attribute__((aligned(16))) double s_tu[FAST ? 2 * PDT_ACQP_NB : 2];
-    __shared__ __attribute__((aligned(16))) float s_ema[FAST ? 2 * PDT_ACQP_NB : 2];
+    __shared__ __attribute__((aligned(16))) float s_theta[FAST ? NB : 4];
+    __shared__ __attribute__((aligned(16))) double s_tu[FAST ? 2 * NB : 2];
+    __shared__ __attribute__((aligned(16))) float s_ema[FAST ? 2 * NB : 2];
     // EXCL: claim a whole SIMD's register file per wavefront (256 + 256 registers), so that the dispatcher can only put
     // these serial wavefronts on SIMDs that hold no wavefront of the concurrent block-parallel kernel -- sharing issue
     // slots with one costs them up to 15 %.  Only requested while that kernel leaves SIMDs free (the host decides).
@@ -491,9 +492,11 @@ __device__ __forceinline__ void k_pll_acquire_pipe(IqSrc pcm, long long n, PllPa
     bool hyp = avg >= P.cond_lo && avg <= P.cond_hi;
     long long i_prod = P.i0;           // next sample the loop filter will take
     long long i_pre = -1;              // start of the batch th_pre was loaded for
-    T th_pre = 0;
+    T th_pre[H];
     long long iq_pre = -1;             // (wavefront 1) start of the batch a_pre / b_pre were loaded for
-    T a_pre = 0, b_pre = 0;
+    T a_pre[H], b_pre[H];
+#pragma unroll
+    for (int h = 0; h < H; h++) { th_pre[h] = 0; a_pre[h] = 0; b_pre[h] = 0; }
     long long lock_at = -1;
     T freq_at_lock = 0, avg_at_lock = P.avg0;
     T fin_phase = P.phase0, fin_freq = P.freq0, fin_sweep = P.sweep0;      // loop-filter state at the end (kept by wavefront 1)
@@ -501,29 +504,38 @@ __device__ __forceinline__ void k_pll_acquire_pipe(IqSrc pcm, long long n, PllPa
     if (threadIdx.x == 0) verdict.event = 0;
     __syncthreads();
     for (int t = 0;; t++) {
-        AcqSlot<T> &mine = slot[t & 1];
-        AcqSlot<T> &theirs = slot[(t & 1) ^ 1];
+        AcqSlot<T, NB> &mine = slot[t & 1];
+        AcqSlot<T, NB> &theirs = slot[(t & 1) ^ 1];
         const bool have_prev = theirs.valid != 0;
         const bool produce = i_prod < n;
         if (!have_prev && !produce) break;
         if (wave == 0) {
             // ---- loop filter of the batch starting at i_prod
             if (produce) {
-                const int nb = (int)((n - i_prod < PDT_ACQP_NB) ? (n - i_prod) : PDT_ACQP_NB);
+                const int nb = (int)((n - i_prod < NB) ? (n - i_prod) : NB);
                 // theta of this batch was requested one batch ago (unless an event moved the start)
-                T th_l = th_pre;
-                if (i_pre != i_prod) th_l = (lane < nb) ? theta_of<T>(pcm, i_prod + lane) : (T)0;
+                T th_l[H];
+#pragma unroll
+                for (int h = 0; h < H; h++) {
+                    th_l[h] = th_pre[h];
+                    if (i_pre != i_prod) th_l[h] = (64 * h + lane < nb) ? theta_of<T>(pcm, i_prod + 64 * h + lane) : (T)0;
+                }
                 i_pre = i_prod + nb;
-                if (lane < PDT_ACQP_NB && i_pre + lane < n) th_pre = theta_of<T>(pcm, i_pre + lane);
+#pragma unroll
+                for (int h = 0; h < H; h++)
+                    if (i_pre + 64 * h + lane < n) th_pre[h] = theta_of<T>(pcm, i_pre + 64 * h + lane);
                 T ph = phase, fr = freq, sw = sweep;
-                T phi_l = 0;
+                T phi_l[H];
+#pragma unroll
+                for (int h = 0; h < H; h++) phi_l[h] = 0;
                 bool filtered = false;
                 if constexpr (FAST) {
-                    if (nb == PDT_ACQP_NB) {
-                        // the whole batch in sixteen blocks of four samples (acq_vec4_asm), no branch: theta of block g + 1 is
-                        // requested from LDS before block g runs (the LDS answers a wavefront's requests in order: the write
-                        // below is seen by the reads behind it)
-                        s_theta[lane] = th_l;
+                    if (nb == NB) {
+                        // the whole batch in blocks of four samples (acq_vec4_asm), no branch: theta of block g + 1 is requested
+                        // from LDS before block g runs (the LDS answers a wavefront's requests in order: the writes below are
+                        // seen by the reads behind them)
+#pragma unroll
+                        for (int h = 0; h < H; h++) s_theta[64 * h + lane] = th_l[h];
                         float maxf_v = P.max_freq;
                         asm volatile("" : "+v"(maxf_v));
                         const Vec16<float> *tq = reinterpret_cast<const Vec16<float> *>(s_theta);
@@ -531,8 +543,8 @@ __device__ __forceinline__ void k_pll_acquire_pipe(IqSrc pcm, long long n, PllPa
                         Vec16<float> cur = tq[0];
                         if (hyp) {
 #pragma unroll
-                            for (int g = 0; g < PDT_ACQP_NB / 4; g++) {
-                                const Vec16<float> nxt = tq[(g + 1) & (PDT_ACQP_NB / 4 - 1)];
+                            for (int g = 0; g < NB / 4; g++) {
+                                const Vec16<float> nxt = tq[(g + 1) & (NB / 4 - 1)];
                                 Vec16<float> pv;
                                 acq_vec4_asm<true>(cur, ph, fr, sw, pv.v, P.alpha_acq, P.beta_acq, P.min_freq, maxf_v);
                                 pq[g] = pv;
@@ -540,8 +552,8 @@ __device__ __forceinline__ void k_pll_acquire_pipe(IqSrc pcm, long long n, PllPa
                             }
                         } else {
 #pragma unroll
-                            for (int g = 0; g < PDT_ACQP_NB / 4; g++) {
-                                const Vec16<float> nxt = tq[(g + 1) & (PDT_ACQP_NB / 4 - 1)];
+                            for (int g = 0; g < NB / 4; g++) {
+                                const Vec16<float> nxt = tq[(g + 1) & (NB / 4 - 1)];
                                 Vec16<float> pv;
                                 acq_vec4_asm<false>(cur, ph, fr, sw, pv.v, P.alpha_acq, P.beta_acq, P.min_freq, maxf_v);
                                 pq[g] = pv;
@@ -552,32 +564,40 @@ __device__ __forceinline__ void k_pll_acquire_pipe(IqSrc pcm, long long n, PllPa
                     }
                 }
                 if (!filtered) {
-                // (four samples per trip: a taken branch costs a lone wavefront as much as nine instructions.  This loop is the
-                // pace of the acquisition -- a lone wavefront, every operation an issue slot -- so it keeps only what the
-                // detectors need of every sample, the phase it was mixed with: the states around an event sample are replayed
-                // from the front of the batch by the wavefront that finds the event (a handful per capture), and the sweep
-                // step is compiled in or out with the gate's hypothesis instead of selected per sample.)
-                auto filt_open = [&](int k) {
-                    const T th = lane_get(th_l, k);
-                    phi_l = (lane == k) ? ph : phi_l;
-                    pll_phase_step<T, SLOW>(th, ph, fr, P.alpha_acq, P.beta_acq, P.max_freq, P.min_freq);
-                    pll_sweep_sel(fr, sw, P.max_freq, P.min_freq, true);       // (the select form: no branches in the chain)
-                };
-                auto filt_closed = [&](int k) {
-                    const T th = lane_get(th_l, k);
-                    phi_l = (lane == k) ? ph : phi_l;
-                    pll_phase_step<T, SLOW>(th, ph, fr, P.alpha_acq, P.beta_acq, P.max_freq, P.min_freq);
-                };
-                int k = 0;
-                if (hyp) {
-                    for (; k + 4 <= nb; k += 4) { filt_open(k); filt_open(k + 1); filt_open(k + 2); filt_open(k + 3); }
-                    for (; k < nb; k++) filt_open(k);
-                } else {
-                    for (; k + 4 <= nb; k += 4) { filt_closed(k); filt_closed(k + 1); filt_closed(k + 2); filt_closed(k + 3); }
-                    for (; k < nb; k++) filt_closed(k);
+                    // (four samples per trip: a taken branch costs a lone wavefront as much as nine instructions.  This loop keeps
+                    // only what the detectors need of every sample, the phase it was mixed with: the states around an event sample
+                    // are replayed from the front of the batch by the wavefront that finds the event (a handful per capture), and
+                    // the sweep step is compiled in or out with the gate's hypothesis instead of selected per sample.)
+#pragma unroll
+                    for (int h = 0; h < H; h++) {
+                        const int nh = (nb - 64 * h < 64) ? nb - 64 * h : 64;         // samples of this half (may be <= 0)
+                        const T thh = th_l[h];
+                        T phl = 0;
+                        auto filt_open = [&](int k) {
+                            const T th = lane_get(thh, k);
+                            phl = (lane == k) ? ph : phl;
+                            pll_phase_step<T, SLOW>(th, ph, fr, P.alpha_acq, P.beta_acq, P.max_freq, P.min_freq);
+                            pll_sweep_sel(fr, sw, P.max_freq, P.min_freq, true);       // (the select form: no branches in the chain)
+                        };
+                        auto filt_closed = [&](int k) {
+                            const T th = lane_get(thh, k);
+                            phl = (lane == k) ? ph : phl;
+                            pll_phase_step<T, SLOW>(th, ph, fr, P.alpha_acq, P.beta_acq, P.max_freq, P.min_freq);
+                        };
+                        int k = 0;
+                        if (hyp) {
+                            for (; k + 4 <= nh; k += 4) { filt_open(k); filt_open(k + 1); filt_open(k + 2); filt_open(k + 3); }
+                            for (; k < nh; k++) filt_open(k);
+                        } else {
+                            for (; k + 4 <= nh; k += 4) { filt_closed(k); filt_closed(k + 1); filt_closed(k + 2); filt_closed(k + 3); }
+                            for (; k < nh; k++) filt_closed(k);
+                        }
+                        phi_l[h] = phl;
+                    }
+#pragma unroll
+                    for (int h = 0; h < H; h++)
+                        if (64 * h + lane < nb) mine.phi[64 * h + lane] = phi_l[h];
                 }
-                if (lane < nb) mine.phi[lane] = phi_l;
-                }   // !filtered
                 if (lane == 0) {
                     mine.i0 = i_prod; mine.nb = nb; mine.hyp = hyp ? 1 : 0; mine.valid = 1;
                     mine.ph_beg = phase; mine.fr_beg = freq; mine.sw_beg = sweep;
@@ -591,49 +611,62 @@ __device__ __forceinline__ void k_pll_acquire_pipe(IqSrc pcm, long long n, PllPa
             if (have_prev) {
                 const long long i0 = theirs.i0;
                 const int nb = theirs.nb;
-                const bool h = theirs.hyp != 0;
-                T t_l = 0, u_l = 0, o_l = 0;
+                const bool h_open = theirs.hyp != 0;
+                T t_l[H], u_l[H], o_l[H], a_l[H], b_l[H];
                 // the IQ samples of this batch were requested one batch ago (unless an event moved the start); those of
                 // the batch wavefront 0 is filtering now are requested here
-                T a_l = a_pre, b_l = b_pre;
-                if (iq_pre != i0 && lane < nb) IqSample<T>::get(pcm, i0 + lane, a_l, b_l);
+#pragma unroll
+                for (int h = 0; h < H; h++) {
+                    t_l[h] = 0; u_l[h] = 0; o_l[h] = 0;
+                    a_l[h] = a_pre[h]; b_l[h] = b_pre[h];
+                    if (iq_pre != i0 && 64 * h + lane < nb) IqSample<T>::get(pcm, i0 + 64 * h + lane, a_l[h], b_l[h]);
+                }
                 iq_pre = -1;
                 if (produce) {
                     iq_pre = i_prod;
-                    if (lane < PDT_ACQP_NB && i_prod + lane < n) IqSample<T>::get(pcm, i_prod + lane, a_pre, b_pre);
+#pragma unroll
+                    for (int h = 0; h < H; h++)
+                        if (i_prod + 64 * h + lane < n) IqSample<T>::get(pcm, i_prod + 64 * h + lane, a_pre[h], b_pre[h]);
                 }
-                if (lane < nb) {
-                    T t_real, t_imag;
-                    Real<T>::sincos(theirs.phi[lane], t_imag, t_real);
-                    const T c = t_real, d = -t_imag;
-                    const T o_re = a_l * c - b_l * d;
-                    const T o_im = a_l * d + b_l * c;
-                    o_l = o_im;
-                    const T ph = arctan2_ref(o_im, o_re);
-                    t_l = avg_alpha * Real<T>::abs(ph);
-                    const T mag2 = a_l * a_l + b_l * b_l;
-                    const T inv = (T)q_rsqrt((float)mag2);
-                    const T re = a_l * inv, im = b_l * inv;
-                    u_l = P.lock_alpha * (re * t_real + im * t_imag);
-                }
+#pragma unroll
+                for (int h = 0; h < H; h++)
+                    if (64 * h + lane < nb) {
+                        T t_real, t_imag;
+                        Real<T>::sincos(theirs.phi[64 * h + lane], t_imag, t_real);
+                        const T c = t_real, d = -t_imag;
+                        const T o_re = a_l[h] * c - b_l[h] * d;
+                        const T o_im = a_l[h] * d + b_l[h] * c;
+                        o_l[h] = o_im;
+                        const T ph = arctan2_ref(o_im, o_re);
+                        t_l[h] = avg_alpha * Real<T>::abs(ph);
+                        const T mag2 = a_l[h] * a_l[h] + b_l[h] * b_l[h];
+                        const T inv = (T)q_rsqrt((float)mag2);
+                        const T re = a_l[h] * inv, im = b_l[h] * inv;
+                        u_l[h] = P.lock_alpha * (re * t_real + im * t_imag);
+                    }
                 // the serial part is the two EMAs only (a wavefront's pace is its instruction count); the sweep gate and
-                // the lock test of sample k are evaluated afterwards by lane k, which kept the EMA values of that sample
-                T av = avg, ls = locksig, av_l = 0, ls_l = 0;
+                // the lock test of sample k are evaluated afterwards by the lane that kept the EMA values of that sample
+                T av = avg, ls = locksig, av_l[H], ls_l[H];
+#pragma unroll
+                for (int h = 0; h < H; h++) { av_l[h] = 0; ls_l[h] = 0; }
                 bool ema_done = false;
                 if constexpr (FAST) {
                     // the input terms of both EMAs as doubles side by side (one broadcast LDS read per sample in place of two
                     // v_readlane and two conversions), the two values after every sample back through LDS (one write in place of
                     // a compare and two selects): 14 issue slots a sample instead of 20 -- this wavefront must stay ahead of the
-                    // loop filter's, which round 6 made faster
-                    if (nb == PDT_ACQP_NB) {
-                        double2 tu;
-                        tu.x = (double)t_l;
-                        tu.y = (double)u_l;
-                        reinterpret_cast<double2 *>(s_tu)[lane] = tu;
+                    // loop filter's
+                    if (nb == NB) {
+#pragma unroll
+                        for (int h = 0; h < H; h++) {
+                            double2 tu;
+                            tu.x = (double)t_l[h];
+                            tu.y = (double)u_l[h];
+                            reinterpret_cast<double2 *>(s_tu)[64 * h + lane] = tu;
+                        }
                         const double2 *tq = reinterpret_cast<const double2 *>(s_tu);
                         float2 *eq = reinterpret_cast<float2 *>(s_ema);
 #pragma unroll 16
-                        for (int k = 0; k < PDT_ACQP_NB; k++) {
+                        for (int k = 0; k < NB; k++) {
                             const double2 in = tq[k];
                             av = (T)((double)av * k_avg + in.x);
                             ls = (T)((double)ls * k_lock + in.y);
@@ -642,54 +675,84 @@ __device__ __forceinline__ void k_pll_acquire_pipe(IqSrc pcm, long long n, PllPa
                             o.y = (float)ls;
                             eq[k] = o;
                         }
-                        const float2 mine_e = eq[lane];
-                        av_l = (T)mine_e.x;
-                        ls_l = (T)mine_e.y;
+#pragma unroll
+                        for (int h = 0; h < H; h++) {
+                            const float2 mine_e = eq[64 * h + lane];
+                            av_l[h] = (T)mine_e.x;
+                            ls_l[h] = (T)mine_e.y;
+                        }
                         ema_done = true;
                     }
                 }
-                auto ema = [&](int k) {
-                    av = (T)((double)av * k_avg + (double)lane_get(t_l, k));
-                    ls = (T)((double)ls * k_lock + (double)lane_get(u_l, k));
-                    const bool me = lane == k;
-                    ls_l = me ? ls : ls_l;
-                    av_l = me ? av : av_l;
-                };
-                int k = 0;
                 if (!ema_done) {
-                    for (; k + 4 <= nb; k += 4) { ema(k); ema(k + 1); ema(k + 2); ema(k + 3); }
-                    for (; k < nb; k++) ema(k);
+#pragma unroll
+                    for (int h = 0; h < H; h++) {
+                        const int nh = (nb - 64 * h < 64) ? nb - 64 * h : 64;
+                        const T tl = t_l[h], ul = u_l[h];
+                        T avl = 0, lsl = 0;
+                        auto ema = [&](int k) {
+                            av = (T)((double)av * k_avg + (double)lane_get(tl, k));
+                            ls = (T)((double)ls * k_lock + (double)lane_get(ul, k));
+                            const bool me = lane == k;
+                            lsl = me ? ls : lsl;
+                            avl = me ? av : avl;
+                        };
+                        int k = 0;
+                        for (; k + 4 <= nh; k += 4) { ema(k); ema(k + 1); ema(k + 2); ema(k + 3); }
+                        for (; k < nh; k++) ema(k);
+                        av_l[h] = avl;
+                        ls_l[h] = lsl;
+                    }
                 }
-                const bool cond_l = av_l >= P.cond_lo && av_l <= P.cond_hi;
-                const unsigned long long ev_flip = __ballot(lane < nb && cond_l != h);
-                const unsigned long long ev_lock = __ballot(lane < nb && ls_l > P.lock_thr);
-                const unsigned long long ev = ev_flip | ev_lock;
+                // the first event of the batch: a flip of the sweep gate or the lock, whichever sample comes first
+                int ev_k = -1;
+                bool ev_is_flip = false, ev_is_lock = false;
+#pragma unroll
+                for (int h = 0; h < H; h++) {
+                    const bool in_batch = 64 * h + lane < nb;
+                    const bool cond_l = av_l[h] >= P.cond_lo && av_l[h] <= P.cond_hi;
+                    const unsigned long long ev_flip = __ballot(in_batch && cond_l != h_open);
+                    const unsigned long long ev_lock = __ballot(in_batch && ls_l[h] > P.lock_thr);
+                    const unsigned long long ev = ev_flip | ev_lock;
+                    if (ev_k < 0 && ev) {
+                        const int kk = __builtin_ctzll(ev);
+                        ev_k = 64 * h + kk;
+                        ev_is_flip = ((ev_flip >> kk) & 1ull) != 0;
+                        ev_is_lock = ((ev_lock >> kk) & 1ull) != 0;
+                    }
+                }
                 int done = nb;
-                if (ev) {
-                    const int k = __builtin_ctzll(ev);
-                    const bool cond = ((ev_flip >> k) & 1ull) ? !h : h;
+                if (ev_k >= 0) {
+                    const int k = ev_k;
+                    const bool cond = ev_is_flip ? !h_open : h_open;
                     // the loop filter again from the front of the batch up to the event sample: the gate kept its hypothesis
                     // for the samples before it, the event sample takes the true one
                     T rp = theirs.ph_beg, fr = theirs.fr_beg, sw = theirs.sw_beg;
-                    {
-                        const T thr_l = (lane < nb) ? arctan2_ref(b_l, a_l) : (T)0;        // theta_of of this lane's sample
-                        for (int q = 0; q <= k; q++) {
+#pragma unroll
+                    for (int h = 0; h < H; h++) {
+                        const T thr_l = (64 * h + lane < nb) ? arctan2_ref(b_l[h], a_l[h]) : (T)0;        // theta_of of this lane's sample
+                        const int q_hi = (k - 64 * h < 63) ? k - 64 * h : 63;                                 // last sample of this half to replay
+                        for (int q = 0; q <= q_hi; q++) {
                             pll_phase_step<T, SLOW>(lane_get(thr_l, q), rp, fr, P.alpha_acq, P.beta_acq, P.max_freq, P.min_freq);
-                            if (q < k && h) pll_sweep_step(fr, sw, P.max_freq, P.min_freq);
+                            if (64 * h + q < k && h_open) pll_sweep_step(fr, sw, P.max_freq, P.min_freq);
                         }
                     }
                     if (cond) pll_sweep_step(fr, sw, P.max_freq, P.min_freq);
                     done = k + 1;
-                    avg = lane_get(av_l, k);
-                    locksig = lane_get(ls_l, k);
+#pragma unroll
+                    for (int h = 0; h < H; h++)
+                        if ((k >> 6) == h) {
+                            avg = lane_get(av_l[h], k & 63);
+                            locksig = lane_get(ls_l[h], k & 63);
+                        }
                     fin_phase = rp; fin_freq = fr; fin_sweep = sw;
-                    if ((ev_lock >> k) & 1ull) {
+                    if (ev_is_lock) {
                         lock_at = i0 + k;
                         freq_at_lock = fr;
                         avg_at_lock = avg;
                     }
                     if (lane == 0) {
-                        verdict.event = 1; verdict.k = k; verdict.hyp = cond ? 1 : 0; verdict.locked = (int)((ev_lock >> k) & 1ull);
+                        verdict.event = 1; verdict.k = k; verdict.hyp = cond ? 1 : 0; verdict.locked = ev_is_lock ? 1 : 0;
                         verdict.phase = fin_phase; verdict.freq = fr; verdict.sweep = sw;
                     }
                 } else {
@@ -698,11 +761,13 @@ __device__ __forceinline__ void k_pll_acquire_pipe(IqSrc pcm, long long n, PllPa
                     fin_phase = theirs.ph_end; fin_freq = theirs.fr_end; fin_sweep = theirs.sw_end;
                     if (lane == 0) verdict.event = 0;
                 }
-                if (lane < done) {
-                    out[i0 + lane] = o_l;
-                    if (lock_out) lock_out[i0 + lane] = ls_l;
-                    if (avg_out) avg_out[i0 + lane] = av_l;            // averagePhase after this sample (:124,152; the value :277 returns)
-                }
+#pragma unroll
+                for (int h = 0; h < H; h++)
+                    if (64 * h + lane < done) {
+                        out[i0 + 64 * h + lane] = o_l[h];
+                        if (lock_out) lock_out[i0 + 64 * h + lane] = ls_l[h];
+                        if (avg_out) avg_out[i0 + 64 * h + lane] = av_l[h];    // averagePhase after this sample (:124,152; the value :277 returns)
+                    }
             } else if (lane == 0) {
                 verdict.event = 0;
             }
