@@ -270,7 +270,7 @@ def pmc_traffic(cfg: str, kernel: str, build: str):
     """HBM bytes per launch of `kernel` from the committed rocprofv3 counter passes (FETCH_SIZE x2 + WRITE_SIZE, see
     tools/pmc_traffic.py and profiles/r3/README.md) -- only from a file measured with the library build that is running now
     (its `build` tag); otherwise None: a figure of another build says nothing about this one."""
-    for rnd in ("r5", "r4", "r3", "r2", "r1"):
+    for rnd in ("r6", "r5", "r4", "r3", "r2", "r1"):
         path = os.path.join(ROOT, "profiles", rnd, f"pmc_hbm_traffic_bench_{cfg}.json")
         try:
             doc = json.load(open(path))
@@ -293,7 +293,7 @@ def sq_valu_active(cfg: str, kernel: str, build: str):
     """Fraction of the kernel's wave cycles in which its wavefronts issue vector-ALU instructions, from the committed SQ counter
     pass of this build (profiles/r4/sq_counters_bench_<cfg>.json: SQ_ACTIVE_INST_VALU / SQ_WAVE_CYCLES), or None."""
     try:
-        for rnd in ("r5", "r4"):
+        for rnd in ("r6", "r5", "r4"):
             path = os.path.join(ROOT, "profiles", rnd, f"sq_counters_bench_{cfg}.json")
             if not os.path.exists(path):
                 continue

@@ -131,6 +131,30 @@ static void *run_worker(void *arg)
     return NULL;
 }
 
+/* one capture's output file: <capture>.frames.txt from its records (no frame, no file: main.c:508-512) */
+typedef struct write_job { capture *cp; const pdt_frame *src; int wrote; } write_job;
+typedef struct write_queue { write_job *jobs; int n; atomic_int next; } write_queue;
+static void *run_writer(void *arg)
+{
+    write_queue *q = (write_queue *)arg;
+    for (;;) {
+        const int j = atomic_fetch_add(&q->next, 1);
+        if (j >= q->n) break;
+        write_job *w = &q->jobs[j];
+        char name[1200];
+        snprintf(name, sizeof name, "%s.frames.txt", w->cp->path);
+        w->wrote = 1;
+        if (w->cp->nfr) {
+            const int fd = open(name, O_RDWR | O_CREAT | O_TRUNC, 0644);
+            w->wrote = fd >= 0 && pdt_write_records(w->src, w->cp->nfr, fd, NULL) == PDT_OK;
+            if (fd >= 0 && close(fd) != 0) w->wrote = 0;
+        } else {
+            remove(name);
+        }
+    }
+    return NULL;
+}
+
 /* what one pass over the queue took (bench.py reads the -J line) */
 typedef struct rep_times {
     double wall_s, demod_s, gather_ms, write_ms;
@@ -213,38 +237,50 @@ static void run_queue(int n, rep_times *T, int quiet)
         }
     }
     const double t_g1 = now_s();
-    /* ---- one output file per capture, from the gathered array */
+    /* ---- one output file per capture, from the gathered array: the files are written side by side (eight hour-long captures:
+     * 8 x 5 ms one after the other would be a third of the pass behind the last GPU) */
     uint64_t *rank_at = (uint64_t *)calloc((size_t)(ranks + 1), sizeof(uint64_t));
     for (int r = 0; r < ranks; r++) rank_at[r + 1] = rank_at[r] + cnt[r];
     uint64_t samples_all = 0;
     double ingest_all = 0;
-    for (int d = 0; d < ngpu; d++) {
+    write_job *jobs = (write_job *)calloc((size_t)(n ? n : 1), sizeof(write_job));
+    int njobs = 0;
+    for (int d = 0; d < ngpu && jobs; d++) {
         uint64_t at = rank_of[d] >= 0 ? rank_at[rank_of[d]] : 0;
         for (int o = 0; o < atomic_load(&g_gpu[d].done); o++)
             for (int k = 0; k < n; k++) {
                 capture *cp = &g_cap[k];
                 if (cp->rc != PDT_OK || cp->device != d || cp->order != o) continue;
-                const pdt_frame *src = (grc == PDT_OK && all) ? all + at : cp->frames;
+                jobs[njobs].cp = cp;
+                jobs[njobs].src = (grc == PDT_OK && all) ? all + at : cp->frames;
+                jobs[njobs].wrote = 0;
+                njobs++;
                 at += cp->nfr;
-                char name[1200];
-                snprintf(name, sizeof name, "%s.frames.txt", cp->path);
-                int wrote = 1;
-                if (cp->nfr) {
-                    const int fd = open(name, O_RDWR | O_CREAT | O_TRUNC, 0644);
-                    wrote = fd >= 0 && pdt_write_records(src, cp->nfr, fd, NULL) == PDT_OK;
-                    if (fd >= 0 && close(fd) != 0) wrote = 0;
-                } else {
-                    remove(name);                                    /* no frame, no file (main.c:508-512) */
-                }
-                if (!wrote) { printf("%s: could not be written\n", name); failed++; }
-                if (!quiet)
-                    printf("GPU %d: %s: %0.3f Ks : %llu Sym : %llu Bits : %llu %s  (%.1f ms on the GPU, ingest %.1f ms, %.3f s in all)\n", cp->device,
-                           cp->path, cp->st.samples / 1000.0, (unsigned long long)cp->st.symbols, (unsigned long long)cp->st.bits,
-                           (unsigned long long)cp->nfr, mode == PDT_MODE_ARGOS ? "Packets" : "Frames", cp->st.gpu_ms, cp->st.ingest_ms, cp->seconds);
-                if (wrote) samples_all += cp->st.samples;
-                ingest_all += cp->st.ingest_ms;
             }
     }
+    {
+        write_queue q;
+        q.jobs = jobs;
+        q.n = njobs;
+        atomic_store(&q.next, 0);
+        pthread_t th[16];
+        int nth = njobs < 16 ? njobs : 16, started = 0;
+        for (int i = 1; i < nth; i++)                                   /* (this thread is the first writer) */
+            if (pthread_create(&th[started], NULL, run_writer, &q) == 0) started++;
+        run_writer(&q);
+        for (int i = 0; i < started; i++) pthread_join(th[i], NULL);
+    }
+    for (int j = 0; j < njobs; j++) {
+        capture *cp = jobs[j].cp;
+        if (!jobs[j].wrote) { printf("%s.frames.txt: could not be written\n", cp->path); failed++; }
+        if (!quiet)
+            printf("GPU %d: %s: %0.3f Ks : %llu Sym : %llu Bits : %llu %s  (%.1f ms on the GPU, ingest %.1f ms, %.3f s in all)\n", cp->device,
+                   cp->path, cp->st.samples / 1000.0, (unsigned long long)cp->st.symbols, (unsigned long long)cp->st.bits,
+                   (unsigned long long)cp->nfr, mode == PDT_MODE_ARGOS ? "Packets" : "Frames", cp->st.gpu_ms, cp->st.ingest_ms, cp->seconds);
+        if (jobs[j].wrote) samples_all += cp->st.samples;
+        ingest_all += cp->st.ingest_ms;
+    }
+    free(jobs);
     const double t_w1 = now_s();
     for (int k = 0; k < n; k++)
         if (g_cap[k].rc != PDT_OK) {

@@ -1,9 +1,9 @@
 #!/bin/bash
 # the C host program from process start, with its own timing (-T), default (per-chunk reports) and -P
 cd "$GRAFT_REPO_ROOT" 2>/dev/null || cd /root/repo
-mkdir -p gpurun_out/r5
+mkdir -p gpurun_out/cli
 export TMPDIR=/tmp
-python - <<'PY' 2>&1 | grep -v amdgpu.ids | tee gpurun_out/r5/cli_cold.txt
+python - <<'PY' 2>&1 | grep -v amdgpu.ids | tee gpurun_out/cli/cli_cold.txt
 import importlib, json, os, subprocess, sys, tempfile, time
 sys.path.insert(0, os.getcwd())
 import bench
