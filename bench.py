@@ -559,6 +559,13 @@ def run(args, pdt, torch, dist, rank, local, world, dev, cdev, cfg, kind, fs, se
                 multi = e2e_multi(exe_multi, wavs_m, world)
             except Exception as e:                                         # (never fatal for the resident figure)
                 multi = {"error": str(e)[:300]}
+            open(os.path.join(mdir, "launcher_done"), "w").close()
+        elif world > 1:
+            # (the other ranks wait on the HOST for the launcher: inside an RCCL barrier they would each keep a few CUs of their GPU
+            # spinning beside the launcher's kernels for as long as it runs)
+            t_wait = time.perf_counter()
+            while not os.path.exists(os.path.join(mdir, "launcher_done")) and time.perf_counter() - t_wait < 1900.0:
+                time.sleep(0.05)
         if world > 1:
             dist.barrier()
         out_m = my_wav + ".frames.txt"
