@@ -65,9 +65,9 @@ sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
 
-def _cfg(kind, fs, seconds, cpu_seconds, baseline, lead_s=0.0, tail_s=0.0, noise_x=1.0, f_end_hz=None, env_floor=0.0):
+def _cfg(kind, fs, seconds, cpu_seconds, baseline, lead_s=0.0, tail_s=0.0, noise_x=1.0, f_end_hz=None, env_floor=0.0, fade=None):
     return dict(kind=kind, fs=fs, seconds=seconds, cpu_seconds=cpu_seconds, baseline=baseline, lead_s=lead_s, tail_s=tail_s,
-                noise_x=noise_x, f_end_hz=f_end_hz, env_floor=env_floor)
+                noise_x=noise_x, f_end_hz=f_end_hz, env_floor=env_floor, fade=fade)
 
 
 CONFIGS = {
@@ -78,8 +78,9 @@ CONFIGS = {
     "weak":  _cfg(0, 250000, 600.0, 600.0, "none (noise amplitude x6)", noise_x=6.0),
     # a pass as a receiver sees it: a minute of noise, the signal rising out of it -- carrier offset ramping from
     # +3 kHz to -3 kHz (Doppler), amplitude from a quarter at the horizon to full at culmination and back --, a minute of noise
-    "pass":  _cfg(0, 250000, 900.0, 900.0, "none (15 min pass: 60 s noise, Doppler +3 -> -3 kHz, amplitude envelope 0.25 .. 1, 60 s noise)",
-                  lead_s=60.0, tail_s=60.0, f_end_hz=-3000.0, env_floor=0.25),
+    # ... and a fade of 20 s in the middle (the signal 30 dB down: the loop is on noise there too, and finds the signal again)
+    "pass":  _cfg(0, 250000, 900.0, 900.0, "none (15 min pass: 60 s noise, Doppler +3 -> -3 kHz, amplitude envelope 0.25 .. 1, a 20 s fade, 60 s noise)",
+                  lead_s=60.0, tail_s=60.0, f_end_hz=-3000.0, env_floor=0.25, fade=(0.5, 20.0, 0.03)),
     # the interpolating filter at scale (north star "FIR + 8x interpolator"): interp = rint(150000 / Fs)
     # (POESTIPdemod/main.c:347) is 8 at 18.75 ksps and 3 at 50 ksps
     "i8":    _cfg(0, 18750, 3600.0, 1200.0, "none (interp 8: 18.75 ksps x 60 min = 67.5 M samples, 540 M filter outputs)"),
@@ -116,6 +117,12 @@ def capture_params(pdt, cfg: str, seed: int, seconds: float | None = None):
         f_start = 3000.0 if c["f_end_hz"] is not None else 1000.0
         pdt.synth_lib().pdt_synth_set_pass(C.byref(p), lead, n - tail, f_start, c["f_end_hz"] if c["f_end_hz"] is not None else f_start,
                                            c["env_floor"])
+    if c["fade"]:
+        at, secs_f, level = c["fade"]                                   # (position as a fraction of the capture, seconds at full length, level)
+        scale = min(1.0, n / (c["seconds"] * fs))
+        p.fade_start = int(round(at * n))
+        p.fade_len = int(round(secs_f * fs * scale))
+        p.fade_q15 = int(round(level * 32768))
     p.noise_gain = int(round(p.noise_gain * c["noise_x"]))
     return p
 

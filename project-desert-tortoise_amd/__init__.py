@@ -710,7 +710,7 @@ class SynthParams(C.Structure):
         ("kind", C.c_uint32), ("sample_rate", C.c_uint32), ("carrier_step", C.c_uint32), ("phase0", C.c_uint32),
         ("mod_index", C.c_uint32), ("amplitude", C.c_int32), ("noise_gain", C.c_int32), ("seed", C.c_uint64),
         ("signal_start", C.c_uint64), ("signal_end", C.c_uint64), ("doppler_q32", C.c_int64), ("env_floor_q15", C.c_uint32),
-        ("pad_", C.c_uint32),
+        ("fade_q15", C.c_uint32), ("fade_start", C.c_uint64), ("fade_len", C.c_uint64),
     ]
 
 

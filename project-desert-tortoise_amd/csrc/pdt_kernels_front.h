@@ -1574,43 +1574,64 @@ __device__ __forceinline__ void k_pll_fix(const T *__restrict__ theta, long long
     }
 }
 
-// Tail pass (round 6): the end of a capture where the loop has nothing to track -- a receiver that stays on after the satellite
-// has set.  On noise the tracking loop does not contract: no warm-up merges with the truth there, every seam of the
-// stretch is open, and the true trajectory has to be WALKED through it, one lane, ~40 ns a sample -- a minute at 250 ksps is
-// 0.6 s.  Left to k_pll_fix that walk starts when the acquisition and the head are through; but it needs neither: the blocks in
-// front of the stretch merged with the truth as blocks do wherever there is a signal, so the end state of the last block of the
-// last run of `run` closed seams is -- almost certainly -- the true state there.  This kernel runs on the side stream right
-// behind k_pll_phase, BESIDE the acquisition (which spends its own second on the noise in front of the pass): it finds that
-// block and walks from its end state to the end of the capture -- in place, every block's seam record rewritten with the state
-// the walk really started from and ended in, as k_pll_fix's cascade does -- or until a seam it reaches is closed.  Nothing is
-// taken on trust: k_pll_fix validates every seam afterwards as ever, and a start state that a later repair changes fails its
-// seam check and is walked again.  (A capture that is noise throughout has no closed run: nothing happens.)
-template <typename T, bool SLOW>
-__device__ __forceinline__ void k_pll_tail(const T *__restrict__ theta, long long n, PllParams<T> P, long long B, T *__restrict__ phi,
-                                           PllSeam<T> *__restrict__ seams, unsigned *__restrict__ counters, T *ckpt, int run)
+// Tail pass (round 6): the stretches of a capture where the loop has nothing to track -- a receiver that stays on after the
+// satellite has set, a fade behind a building.  On noise the tracking loop does not contract: no warm-up merges with
+// the truth there, every seam of the stretch is open, and the true trajectory has to be WALKED through it, one lane, ~40 ns a
+// sample -- a minute at 250 ksps is 0.6 s.  Left to k_pll_fix that walk starts when the acquisition and the head are through; but
+// it needs neither: the blocks in front of a stretch merged with the truth as blocks do wherever there is a signal, so the end
+// state of the last block of a run of `run` closed seams is -- almost certainly -- the true state there.  This kernel runs on the
+// side stream right behind k_pll_phase, BESIDE the acquisition (which spends its own second on the noise in front of the pass):
+// every open seam that follows `run` closed ones starts a stretch; workgroup g takes the g-th stretch and walks it from the end
+// state of the block in front of it until it reaches a closed seam (the signal is back:
+// the stored trajectory is the walker's from there on) or the end of the capture -- in place, every block's seam record rewritten
+// with the state the walk really started from and ended in, as k_pll_fix's cascade does.  Walks never meet: a walk ends at the
+// first closed seam, a stretch begins behind `run` of them.  Nothing is taken on trust: k_pll_fix validates every seam afterwards
+// as ever, and a start state that a later repair changes fails its seam check and is walked again.  (The noise in FRONT of the
+// pass, and a capture that is noise throughout, have no closed run in front of them: nothing happens there.)
+// ... the stretches are listed first, by a launch of its own (one workgroup: k_pll_tail_scan), and walked by the next (a workgroup
+// per stretch): a walker rewrites seam records, and a search running beside it could take a half-written one for a closed seam.
+#define PDT_TAIL_MAX 64
+struct PllTailList {
+    unsigned n;                       // stretches found (more than PDT_TAIL_MAX: the rest is k_pll_fix's)
+    unsigned pad_;
+    long long start[PDT_TAIL_MAX];    // first block of each
+};
+template <typename T>
+__device__ __forceinline__ void k_pll_tail_scan(long long n, long long B, const PllSeam<T> *__restrict__ seams, PllTailList *__restrict__ list,
+                                                int run)
 {
-    __shared__ __attribute__((aligned(16))) unsigned char ring[PDT_PLL_RING_PF * PDT_RING_SLOT];
-    __shared__ unsigned long long s_last;                           // 1 + the last seam that ends a run of `run` closed ones
+    __shared__ unsigned s_n;
     const long long nb = (n + B - 1) / B;
-    if (threadIdx.x == 0) s_last = 0;
+    if (threadIdx.x == 0) s_n = 0;
     __syncthreads();
     auto closed = [&](long long r) {
         const PllSeam<T> prev = seams[r - 1];
         const PllSeam<T> cur = seams[r];
         return bits_equal(prev.phase1, cur.phase0) && bits_equal(prev.freq1, cur.freq0);
     };
-    unsigned long long best = 0;
-    for (long long r = run + (long long)threadIdx.x; r < nb; r += blockDim.x) {
+    for (long long r = run + 1 + (long long)threadIdx.x; r < nb; r += blockDim.x) {
+        if (closed(r)) continue;
         bool all = true;
-        for (int q = 0; q < run && all; q++) all = closed(r - q);
-        if (all) best = (unsigned long long)r + 1;
+        for (int q = 1; q <= run && all; q++) all = closed(r - q);
+        if (all) {
+            const unsigned slot = atomicAdd(&s_n, 1u);
+            if (slot < PDT_TAIL_MAX) list->start[slot] = r;
+        }
     }
-    if (best) atomicMax(&s_last, best);
     __syncthreads();
-    if (threadIdx.x != 0 || s_last == 0) return;
+    if (threadIdx.x == 0) list->n = s_n < (unsigned)PDT_TAIL_MAX ? s_n : (unsigned)PDT_TAIL_MAX;
+}
+template <typename T, bool SLOW>
+__device__ __forceinline__ void k_pll_tail(const T *__restrict__ theta, long long n, PllParams<T> P, long long B, T *__restrict__ phi,
+                                           PllSeam<T> *__restrict__ seams, unsigned *__restrict__ counters, T *ckpt,
+                                           const PllTailList *__restrict__ list)
+{
+    __shared__ __attribute__((aligned(16))) unsigned char ring[PDT_PLL_RING_PF * PDT_RING_SLOT];
+    if (threadIdx.x != 0 || blockIdx.x >= list->n) return;
+    const long long nb = (n + B - 1) / B;
     const long long NC = pll_ckpt_count(B);
     unsigned walked = 0;
-    for (long long r = (long long)s_last; r < nb; r++) {
+    for (long long r = list->start[blockIdx.x]; r < nb; r++) {
         const PllSeam<T> prev = seams[r - 1];
         const PllSeam<T> cur = seams[r];
         if (bits_equal(prev.phase1, cur.phase0) && bits_equal(prev.freq1, cur.freq0)) break;      // merged with the stored trajectory

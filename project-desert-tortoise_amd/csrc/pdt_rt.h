@@ -122,6 +122,7 @@ struct DevScalars {
     double norm;            // storage for the normalisation factor (float or double)
     long long agc_first_bad; // first AGC seam that does not close (k_agc_scan -> k_agc_fix)
     PllPhaseHint phase_hint;     // k_pll_phase -> k_pll_head: workgroups finished, the clock at its start (walk on while it runs)
+    PllTailList tail_list;       // k_pll_tail_scan -> k_pll_tail: the stretches of open seams behind closed runs
 };
 
 // ---------------------------------------------------------------- launch plans
@@ -634,6 +635,6 @@ template <typename T> int stage_squelch(pdt_ctx *ctx, void *data_host, const voi
     KW template void go_fn<&k_pll_acquire_pipe<T, true>, 128>(dim3, dim3, size_t, hipStream_t, const void *);      \
     KW template void go_fn<&k_pll_head<T, true>, 64>(dim3, dim3, size_t, hipStream_t, const void *);               \
     KW template void go_fn<&k_pll_fix<T, true>, PDT_FIX_THREADS>(dim3, dim3, size_t, hipStream_t, const void *);     \
-    KW template void go_fn<&k_pll_tail<T, true>, 256>(dim3, dim3, size_t, hipStream_t, const void *);
+    KW template void go_fn<&k_pll_tail<T, true>, 64>(dim3, dim3, size_t, hipStream_t, const void *);
 }  // namespace pdtrt
 #endif

@@ -23,7 +23,7 @@
  * between the two a linear Doppler ramp -- the carrier's phase step grows by `doppler_q32` / 2^32 per sample, an integer
  * phase accumulator in closed form, so that any sample is still a pure function of its index -- and an amplitude envelope
  * `env_floor_q15` + (1 - floor) 4x(1 - x), x = the position inside the pass: strongest at culmination, `floor` of that at
- * the horizon.
+ * the horizon; and a fade -- `fade_len` samples from `fade_start` at `fade_q15` of that amplitude (an antenna null, a building).
  *
  * All arithmetic is uint32/uint64/int32; phases are 32-bit turns (2^32 = 2 pi).
  */
@@ -56,7 +56,9 @@ typedef struct pdt_synth_params {
                             /* behind signal_start (a linear Doppler ramp); 0 = none      */
     uint32_t env_floor_q15; /* amplitude envelope over [signal_start, signal_end): this   */
                             /* fraction (Q15) at both ends, 1 in the middle; 0 = flat     */
-    uint32_t pad_;
+    uint32_t fade_q15;      /* a fade inside the pass: the amplitude times this fraction (Q15)  */
+    uint64_t fade_start;    /* ... over the samples [fade_start, fade_start + fade_len); len 0 = */
+    uint64_t fade_len;      /* none                                                               */
 } pdt_synth_params;
 
 PDT_SYNTH_FN uint64_t pdt_synth_mix(uint64_t z)
@@ -130,6 +132,8 @@ PDT_SYNTH_FN void pdt_synth_sample(const pdt_synth_params *p, const int16_t *sin
         const uint64_t e = p->env_floor_q15 + (((32768u - (uint64_t)p->env_floor_q15) * par) >> 32);   /* Q15 */
         amp = (int32_t)(((uint64_t)amp * e + 16384u) >> 15);
     }
+    if (amp && p->fade_len && n >= p->fade_start && n - p->fade_start < p->fade_len)
+        amp = (int32_t)(((uint64_t)amp * p->fade_q15 + 16384u) >> 15);
     if (p->kind == 0) {
         uint64_t k = (n * 16640ull) / p->sample_rate;     /* Manchester symbol index */
         uint64_t bit = k >> 1;
