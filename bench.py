@@ -15,7 +15,7 @@ like-for-like weak-scaling figure:
                    on before the satellite rises, the PLL sweeps for a minute before its one-time lock
   weak             (not in BASELINE) 250 ksps, 10 min at six times the noise amplitude (4.4 dB SNR in the sampled band)
   pass             (not in BASELINE) 250 ksps, 15 min as a receiver records a pass: a minute of noise, the signal with a
-                   Doppler ramp from +3 kHz to -3 kHz and an amplitude envelope of 0.25 .. 1, a minute of noise
+                   Doppler ramp from +3 kHz to -3 kHz, an amplitude envelope of 0.25 .. 1 and a 20 s fade, a minute of noise
   i8, c2h           the interpolating filter at scale: 18.75 ksps (interp 8) and 50 ksps (interp 3), 60 min each
   --captures N     the batched many-capture mode (pdt_demod_batch_device), every slot its own capture, every slot's text checked
 One "step" = one pass of the whole hot path (StaticGain, PLL, FIR, AGC, Gardner, Manchester, ByteSync, frame records +

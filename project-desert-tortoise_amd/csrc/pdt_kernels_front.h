@@ -1582,10 +1582,10 @@ __device__ __forceinline__ void k_pll_fix(const T *__restrict__ theta, long long
 // state of the last block of a run of `run` closed seams is -- almost certainly -- the true state there.  This kernel runs on the
 // side stream right behind k_pll_phase, BESIDE the acquisition (which spends its own second on the noise in front of the pass):
 // every open seam that follows `run` closed ones starts a stretch; workgroup g takes the g-th stretch and walks it from the end
-// state of the block in front of it until it reaches a closed seam (the signal is back:
+// state of the block in front of it until it has passed `run` closed seams in a row (the signal is back:
 // the stored trajectory is the walker's from there on) or the end of the capture -- in place, every block's seam record rewritten
-// with the state the walk really started from and ended in, as k_pll_fix's cascade does.  Walks never meet: a walk ends at the
-// first closed seam, a stretch begins behind `run` of them.  Nothing is taken on trust: k_pll_fix validates every seam afterwards
+// with the state the walk really started from and ended in, as k_pll_fix's cascade does; blocks whose seam is closed stand as
+// they are.  Walks never meet: a walk ends behind `run` closed seams, which is where the next stretch begins.  Nothing is taken on trust: k_pll_fix validates every seam afterwards
 // as ever, and a start state that a later repair changes fails its seam check and is walked again.  (The noise in FRONT of the
 // pass, and a capture that is noise throughout, have no closed run in front of them: nothing happens there.)
 // ... the stretches are listed first, by a launch of its own (one workgroup: k_pll_tail_scan), and walked by the next (a workgroup
@@ -1624,17 +1624,26 @@ __device__ __forceinline__ void k_pll_tail_scan(long long n, long long B, const 
 template <typename T, bool SLOW>
 __device__ __forceinline__ void k_pll_tail(const T *__restrict__ theta, long long n, PllParams<T> P, long long B, T *__restrict__ phi,
                                            PllSeam<T> *__restrict__ seams, unsigned *__restrict__ counters, T *ckpt,
-                                           const PllTailList *__restrict__ list)
+                                           const PllTailList *__restrict__ list, int run)
 {
     __shared__ __attribute__((aligned(16))) unsigned char ring[PDT_PLL_RING_PF * PDT_RING_SLOT];
     if (threadIdx.x != 0 || blockIdx.x >= list->n) return;
     const long long nb = (n + B - 1) / B;
     const long long NC = pll_ckpt_count(B);
     unsigned walked = 0;
+    int closed_run = 0;
     for (long long r = list->start[blockIdx.x]; r < nb; r++) {
         const PllSeam<T> prev = seams[r - 1];
         const PllSeam<T> cur = seams[r];
-        if (bits_equal(prev.phase1, cur.phase0) && bits_equal(prev.freq1, cur.freq0)) break;      // merged with the stored trajectory
+        if (bits_equal(prev.phase1, cur.phase0) && bits_equal(prev.freq1, cur.freq0)) {
+            // merged with the stored trajectory: this block stands as it is (the same start state gives the same samples).  A weak
+            // stretch -- a fade that leaves a little of the signal -- is patchy: a few blocks merge, the next seam is open again; the
+            // walker hops over the blocks that stand and goes on, and ends behind `run` closed seams in a row (where the search
+            // would begin the next stretch)
+            if (++closed_run >= run) break;
+            continue;
+        }
+        closed_run = 0;
         T phase = prev.phase1, freq = prev.freq1;
         const long long start = r * B;
         const long long end = ((r + 1) * B < n) ? (r + 1) * B : n;

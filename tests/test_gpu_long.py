@@ -47,7 +47,7 @@ def test_configs2_full_size_against_the_reference_objects():
 
 def test_pass_shaped_capture_full_size_against_the_reference_objects():
     """bench.py --config pass at full size (250 ksps x 15 min = 225 M samples): a minute of noise, the signal with a Doppler ramp
-    from +3 kHz to -3 kHz and an amplitude envelope of 0.25 .. 1, a minute of noise.  The sweep before the lock
+    from +3 kHz to -3 kHz, an amplitude envelope of 0.25 .. 1 and a 20 s fade in the middle, a minute of noise.  The sweep before the lock
     (CarrierTrackingPLL.c:232-246), the one-time lock (:266-274) and the tracking loop on noise after the loss of signal at the
     size a receiver records them: output file byte-identical to the reference's own objects."""
     ref = os.path.join(ROOT, "oracle", "_ref", "ref_demodPOES")
