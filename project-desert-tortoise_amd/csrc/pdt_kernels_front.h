@@ -1590,7 +1590,7 @@ __device__ __forceinline__ void k_pll_fix(const T *__restrict__ theta, long long
 // pass, and a capture that is noise throughout, have no closed run in front of them: nothing happens there.)
 // ... the stretches are listed first, by a launch of its own (one workgroup: k_pll_tail_scan), and walked by the next (a workgroup
 // per stretch): a walker rewrites seam records, and a search running beside it could take a half-written one for a closed seam.
-#define PDT_TAIL_MAX 64
+#define PDT_TAIL_MAX 1024   // (a weak stretch -- the first and last minute of a pass -- has isolated open seams by the hundred: each its own walker, side by side)
 struct PllTailList {
     unsigned n;                       // stretches found (more than PDT_TAIL_MAX: the rest is k_pll_fix's)
     unsigned pad_;
