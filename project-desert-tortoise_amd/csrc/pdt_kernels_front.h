@@ -1365,7 +1365,7 @@ template <> __device__ __forceinline__ bool bits_equal<double>(double x, double 
 template <typename T, bool SLOW, bool OUT_LT>
 __device__ __forceinline__ long long pll_rewalk(const T *__restrict__ theta, T *out, long long B, long long start, long long end, T &phase,
                                                 T &freq, const PllParams<T> &P, const T *phi_old /* LT */, T *ck_old /* column, stride 64, or null */,
-                                                T *ck_new, long long ck_new_stride, bool &merged)
+                                                T *ck_new, long long ck_new_stride, bool &merged, unsigned char *ring = nullptr)
 {
     const long long len = end - start;
     merged = false;
@@ -1379,7 +1379,10 @@ __device__ __forceinline__ long long pll_rewalk(const T *__restrict__ theta, T *
             ck_new[c * ck_new_stride] = freq;
         }
         const long long q = (p + PDT_PLL_CKPT < len) ? p + PDT_PLL_CKPT : len;
-        pll_phase_range<T, true, SLOW, OUT_LT, 32>(theta, out, B, start + p, start + q, phase, freq, P.alpha_trk, P.beta_trk, P.max_freq, P.min_freq);
+        // (`ring`: the hand-issued LDS look-ahead of the block walkers -- 36 - 39 ns a sample against 58 for the register ring the
+        // compiler schedules; the cascade of k_pll_fix, which walks whole runs of blocks, passes one)
+        pll_phase_range<T, true, SLOW, OUT_LT, 32>(theta, out, B, start + p, start + q, phase, freq, P.alpha_trk, P.beta_trk, P.max_freq, P.min_freq,
+                                                   nullptr, nullptr, ring);
         p = q;
     }
     return p;
@@ -1408,6 +1411,7 @@ __device__ __forceinline__ void k_pll_fix(const T *__restrict__ theta, long long
     __shared__ long long s_len[NW];                                 // samples a re-run walked before it merged (or the block's)
     __shared__ unsigned s_nbad;
     __shared__ long long s_min;
+    __shared__ __attribute__((aligned(16))) unsigned char cascade_ring[PDT_PLL_RING_PF * PDT_RING_SLOT];      // (thread 0's walks, below)
     const long long lock_at = info->lock_sample;
     if (lock_at < 0) {
         if (threadIdx.x == 0 && mode == 2) counters[0] = 0;
@@ -1548,7 +1552,7 @@ __device__ __forceinline__ void k_pll_fix(const T *__restrict__ theta, long long
                     const long long end = ((r + 1) * B < n) ? (r + 1) * B : n;
                     bool merged;
                     T *col = ck_col(r);
-                    (void)pll_rewalk<T, SLOW, true>(theta, phi, B, start, end, phase, freq, P, phi, col, col, 64, merged);
+                    (void)pll_rewalk<T, SLOW, true>(theta, phi, B, start, end, phase, freq, P, phi, col, col, 64, merged, cascade_ring);
                     PllSeam<T> upd;
                     upd.phase0 = prev.phase1;
                     upd.freq0 = prev.freq1;
