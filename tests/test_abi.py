@@ -153,7 +153,7 @@ def test_hand_issued_lds_loads_are_the_only_users_of_m0(pdt, tmp_path):
             per_kernel.setdefault(kernel, [0, 0])[1] += 1
     assert per_kernel, "no hand-issued LDS loads found: is the ring still there?"
     for k, (loads, movs) in per_kernel.items():
-        assert any(w in k for w in ("k_agc_", "k_pll_phase", "k_pll_head", "k_pll_tail", "k_lock_ema")), f"m0 / LDS-direct load in an unexpected kernel: {k}"
+        assert any(w in k for w in ("k_agc_", "k_pll_phase", "k_pll_head", "k_pll_tail", "k_pll_fix", "k_lock_ema")), f"m0 / LDS-direct load in an unexpected kernel: {k}"
         assert loads == movs and loads > 0, f"{k}: {loads} LDS-direct loads but {movs} writes of m0"
 
 
