@@ -733,7 +733,7 @@ def run(args, pdt, torch, dist, rank, local, world, dev, cdev, cfg, kind, fs, se
                           "runs_ms": [round(x, 3) for x in e2e_ms], "first_run_ms": round(first_ms, 3),
                           "gpu_ms_last_segment": round(e2e_gpu_ms, 3), "file_bytes": 44 + 4 * n, "split_ms": split[e2e_ms.index(med)],
                           "includes": "open WAV on tmpfs, header, output file created, pdt_demod_file (threaded pread into pinned memory + "
-                                      "copies to HBM; the chain in three unequal segments -- 64 / 22 / 14 % -- each as soon as its samples "
+                                      "copies to HBM; the chain in three unequal segments -- 55 / 28 / 17 % -- each as soon as its samples "
                                       "have arrived; frame records to the host, time stamps, each segment's text formatted and written "
                                       "while the next one runs), files closed; context already open (HIP initialised)"}
             # the figure BASELINE.json's metric names, beside `value` (which is the resident rate)
