@@ -622,3 +622,37 @@ def test_pass_shaped_snr_profile(pdt, orc):
         check_all_stages(pdt, orc, d, o)
         s = d.stats()
         assert s.pll_seam_fixes <= lone and s.frames >= 400
+
+
+def test_fades_and_a_noise_tail_all_stages(pdt, orc):
+    """Round 6, the tail pass (k_pll_tail_scan / k_pll_tail): stretches where the tracking loop has nothing to track -- two fades
+    inside the signal, one of them leaving a little of it (patchy: blocks that merge between open seams), and a noise tail behind
+    the loss of signal -- are walked from the last merged block in front of each, beside the acquisition.  Every stage equal to the
+    oracle, with the tail pass and without it (PDT_PLL_NOTAIL: k_pll_fix alone), small PLL blocks so that the stretches span
+    hundreds of seams; and the tail pass really took the repairs over."""
+    import ctypes as C
+    fs, seg_s = 50000, 3.0
+    n = int(fs * seg_s)
+    parts = []
+    for k, amp in enumerate([1.0, 1.0, 1.0, 0.0, 1.0, 1.0, 0.06, 0.06, 1.0, 1.0, 0.0, 0.0]):
+        p = pdt.synth_params(0, fs, -1500.0, 4712)
+        p.amplitude = int(round(p.amplitude * amp))
+        iq = np.zeros((n, 2), dtype="<i2")
+        pdt.synth_lib().pdt_synth_fill(C.byref(p), k * n, n, iq.ctypes.data)          # one continuous signal, amplitude per segment
+        parts.append(iq)
+    cap = np.concatenate(parts)
+    o = orc.Oracle(orc.POES, fs, cap)
+    fixes = {}
+    for name, env in (("tail", {}), ("notail", {"PDT_PLL_NOTAIL": "1"})):
+        os.environ.update(env)
+        try:
+            with pdt.Demodulator(pdt.MODE_POES, fs, pll_block=1024, profile=True) as d:
+                d.demod(cap)
+                check_all_stages(pdt, orc, d, o)
+                fixes[name] = d.stats().pll_seam_fixes
+                kt = d.kernel_times()
+                assert ("pll_tail" in kt) == (name == "tail")
+        finally:
+            for k in env:
+                os.environ.pop(k, None)
+    assert fixes["tail"] >= 100 and fixes["notail"] >= 100, fixes      # (both count the walked blocks: the stretches are ~9 s of 36)
