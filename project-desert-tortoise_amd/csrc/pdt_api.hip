@@ -61,7 +61,7 @@ void Tuning::load()
     gardner_sequential = get("PDT_GARDNER_SEQUENTIAL") != nullptr;
     seg_sequential = get("PDT_SEG_SEQUENTIAL") != nullptr;
     overlap = get("PDT_NO_OVERLAP") == nullptr;            // (round 4: off unless PDT_OVERLAP; round 5: on)
-    if (const char *e = get("PDT_OVERLAP_SPLIT")) {          // "0.64,0.22,0.14": the segments' fractions of the capture
+    if (const char *e = get("PDT_OVERLAP_SPLIT")) {          // "0.55,0.28,0.17": the segments' fractions of the capture
         int k = 0;
         for (const char *q = e; *q && k < 8; k++) {
             char *end = nullptr;
@@ -1546,8 +1546,9 @@ static int segment_end(pdt_ctx *ctx, uint64_t upto, bool final_seg)
 // of GPU time (the 7: one PLL warm-up of ~100 000 steps and the other stages' latency floors, whatever the length), the
 // segments run one after the other, and the ingest takes ~67 ms: segment j + 1's samples must take at least as long to arrive
 // as segment j takes to run -- x_{j+1} >= 0.104 + 0.172 x_j -- and what is exposed behind the last byte is the last segment
-// alone.  Three segments of 64 / 22 / 14 % leave 8.6 ms there (two: 76 / 24 %, 9.7 ms; four equal ones, round 3: 12 ms of
-// floor each, 49 ms in all).  (iii) A segment's launch plan is recorded BEFORE the host waits for its last span, and the text
+// alone.  By that model three segments of 64 / 22 / 14 % leave 8.6 ms there (two: 76 / 24 %, 9.7 ms; four equal ones, round 3:
+// 12 ms of floor each, 49 ms in all); measured round robin on one box, 55 / 28 / 17 % did best (beside the running ingest a
+// segment costs 5 + 25 x ms) and is the default below.  (iii) A segment's launch plan is recorded BEFORE the host waits for its last span, and the text
 // of a finished segment is formatted and written (text_fd) while the next one runs.
 // ... and so are its per-chunk reports handed to the caller's progress function (pdt_set_progress)
 struct TextSink {
