@@ -1595,6 +1595,7 @@ __device__ __forceinline__ void k_pll_fix(const T *__restrict__ theta, long long
 // ... the stretches are listed first, by a launch of its own (one workgroup: k_pll_tail_scan), and walked by the next (a workgroup
 // per stretch): a walker rewrites seam records, and a search running beside it could take a half-written one for a closed seam.
 #define PDT_TAIL_MAX 1024   // (a weak stretch -- the first and last minute of a pass -- has isolated open seams by the hundred: each its own walker, side by side)
+#define PDT_TAIL_LDS_CLAIM 147456   // of a CU's 163 840 bytes
 struct PllTailList {
     unsigned n;                       // stretches found (more than PDT_TAIL_MAX: the rest is k_pll_fix's)
     unsigned pad_;
@@ -1630,13 +1631,21 @@ __device__ __forceinline__ void k_pll_tail(const T *__restrict__ theta, long lon
                                            PllSeam<T> *__restrict__ seams, unsigned *__restrict__ counters, T *ckpt,
                                            const PllTailList *__restrict__ list, int run)
 {
-    __shared__ __attribute__((aligned(16))) unsigned char ring[PDT_PLL_RING_PF * PDT_RING_SLOT];
-    if (threadIdx.x != 0 || blockIdx.x >= list->n) return;
+    // A walker is one lone wavefront for half a second: it wants a SIMD's issue slots to itself.  (i) The ring is declared at
+    // PDT_TAIL_LDS_CLAIM bytes, more than half a CU's LDS, so that no two walkers are ever placed on one CU (the acquisition's two
+    // wavefronts claim their SIMDs' register files, EXCL).  (ii) In a batch (blockIdx.z = the capture) the g-th stretch of every
+    // capture would sit in the same workgroup index, which the dispatcher maps to ONE shader engine of ONE XCD (index mod 8, then
+    // (index / 8) mod 4): sixteen passes' noise tails on eight CUs, two to a SIMD or waiting for a CU (measured: 1.1 s instead of
+    // 0.5).  The index is rotated by 41 per capture -- the next XCD and the next shader engine.
+    __shared__ __attribute__((aligned(16))) unsigned char ring[PDT_TAIL_LDS_CLAIM];
+    static_assert(PDT_TAIL_LDS_CLAIM >= PDT_PLL_RING_PF * PDT_RING_SLOT, "the claim holds the ring");
+    const unsigned g = ((unsigned)blockIdx.x + 41u * (unsigned)blockIdx.z) % (unsigned)PDT_TAIL_MAX;
+    if (threadIdx.x != 0 || g >= list->n) return;
     const long long nb = (n + B - 1) / B;
     const long long NC = pll_ckpt_count(B);
     unsigned walked = 0;
     int closed_run = 0;
-    for (long long r = list->start[blockIdx.x]; r < nb; r++) {
+    for (long long r = list->start[g]; r < nb; r++) {
         const PllSeam<T> prev = seams[r - 1];
         const PllSeam<T> cur = seams[r];
         if (bits_equal(prev.phase1, cur.phase0) && bits_equal(prev.freq1, cur.freq0)) {

@@ -77,6 +77,41 @@ def test_batch_of_equal_captures_and_weak_signal(pdt, orc):
                 d.close()
 
 
+def test_batch_with_fades_and_noise_tails(pdt, orc):
+    """Round 6, last build: in a batch the tail pass (k_pll_tail) takes the g-th stretch of capture z in workgroup
+    (g - 41 z) mod 1024, so that the long walkers of a batch of passes do not meet on one shader engine.  Six slots, each with its own
+    fades and its own loss of signal (small PLL blocks: every stretch spans many seams), every stage of every slot equal to the
+    oracle on that slot's capture, and the tail pass ran."""
+    import ctypes as C
+    fs, seg_s = 50000, 1.5
+    n = int(fs * seg_s)
+    shapes = ([1, 1, 0, 1, 1, 0.06, 1, 0, 0], [1, 1, 1, 1, 0, 0, 0, 0, 0], [1, 0.06, 0.06, 1, 1, 1, 0, 1, 1],
+              [1, 1, 1, 1, 1, 1, 1, 1, 0], [1, 0, 1, 0, 1, 0, 1, 0, 1], [1, 1, 1, 0.06, 0, 0.06, 1, 1, 0])
+    caps = []
+    for z, amps in enumerate(shapes):
+        parts = []
+        for k, amp in enumerate(amps):
+            p = pdt.synth_params(0, fs, -1500.0 + 500.0 * z, 4800 + z)
+            p.amplitude = int(round(p.amplitude * amp))
+            iq = np.zeros((n, 2), dtype="<i2")
+            pdt.synth_lib().pdt_synth_fill(C.byref(p), k * n, n, iq.ctypes.data)
+            parts.append(iq)
+        caps.append(np.concatenate(parts))
+    oracles = [orc.Oracle(orc.POES, fs, iq) for iq in caps]
+    dev = [to_dev(iq) for iq in caps]
+    torch.cuda.synchronize()
+    ds = [pdt.Demodulator(pdt.MODE_POES, fs, pll_block=1024, profile=(z == 0)) for z in range(len(caps))]
+    try:
+        pdt.demod_batch(ds, [t.data_ptr() for t in dev], [len(iq) for iq in caps])
+        for d, o in zip(ds, oracles):
+            check_all_stages(pdt, orc, d, o)
+        assert "pll_tail" in ds[0].kernel_times()
+        assert all(d.stats().pll_seam_fixes >= 20 for d in ds), [d.stats().pll_seam_fixes for d in ds]
+    finally:
+        for d in ds:
+            d.close()
+
+
 def test_batch_mixed_modes(pdt, orc):
     p = pdt.synth_capture(0, 50000, 5.0, seed=11)
     a = pdt.synth_capture(1, 32000, 10.0, f0_hz=140.0, seed=12)

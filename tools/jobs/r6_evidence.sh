@@ -23,6 +23,7 @@ timeout 600 python bench.py --config c2 --steps 6 --warmup 2 --captures 8 --no-s
 for nc in 32 64; do
   timeout 900 python bench.py --config argos --captures $nc --steps 5 --warmup 2 --no-secondary > $OUT/bench_argos_batch${nc}_1gpu.json 2> $OUT/logs/bench_argos_batch$nc.err; echo "argos x$nc rc=$?"
 done
+timeout 900 python bench.py --config pass --captures 16 --steps 2 --warmup 1 --no-secondary > $OUT/bench_pass_batch16_1gpu.json 2> $OUT/logs/bench_pass_batch16.err; echo "pass x16 rc=$?"
 timeout 600 python tools/span_hist.py c3 2>&1 | grep -v amdgpu.ids > $OUT/gardner_row_exits_c3.txt
 timeout 600 python tools/span_hist.py c2h 2>&1 | grep -v amdgpu.ids > $OUT/gardner_row_exits_c2h.txt
 bash tools/jobs/cli_cold.sh > /dev/null 2>&1; cp gpurun_out/cli/cli_cold.txt $OUT/cli_cold.txt 2>/dev/null
@@ -56,7 +57,7 @@ try:
     json.dump({"build": importlib.import_module("project-desert-tortoise_amd").build_tag(), "kernels": out}, open("$OUT/sq_counters_bench_c3.json", "w"), indent=1)
 except Exception as e:
     print("sq pass failed", e)
-for f in ("bench_default_1gpu", "bench_c2_1gpu", "bench_argos_1gpu", "bench_aos_1gpu", "bench_weak_1gpu", "bench_pass_1gpu", "bench_i8_1gpu", "bench_c2h_1gpu", "bench_c2_batch8_1gpu", "bench_argos_batch32_1gpu", "bench_argos_batch64_1gpu"):
+for f in ("bench_default_1gpu", "bench_c2_1gpu", "bench_argos_1gpu", "bench_aos_1gpu", "bench_weak_1gpu", "bench_pass_1gpu", "bench_i8_1gpu", "bench_c2h_1gpu", "bench_c2_batch8_1gpu", "bench_argos_batch32_1gpu", "bench_argos_batch64_1gpu", "bench_pass_batch16_1gpu"):
     try:
         d = json.loads([l for l in open("$OUT/" + f + ".json") if l.startswith("{")][-1])
         par = d.get("parity", {})
